@@ -1,0 +1,45 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE ONLY.
+# Builds oracle/_ref/libgyref.so: the reference's OWN GY_HISTOGRAM / bucket-hash / jhash / IP_PORT code compiled from the
+# sources where they lie under /root/reference (SURVEY.md 8c recipe).  The reference's build system is not run (it needs
+# folly, liburcu, boost ... none of which exist here); only header-only code that is self-contained is used.
+#
+# Nothing from the reference is copied into the repo: the two headers that quote-include unavailable third-party headers
+# (gy_statistics.h -> folly TimeseriesSlabHistogram, gy_inet_inc.h -> liburcu) are copied into a throw-away mktemp dir next
+# to small stub headers so the stubs win the quote-include lookup; only the resulting .so lands in oracle/_ref/.
+set -euo pipefail
+REF=${GY_REFERENCE_DIR:-/root/reference}
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/_ref"
+if [ ! -d "$REF/common" ]; then
+	echo "build_ref.sh: $REF not present (GPU box?) - keeping prebuilt oracle/_ref if any" >&2
+	exit 0
+fi
+mkdir -p "$OUT"
+T="$(mktemp -d)"
+trap 'rm -rf "$T"' EXIT
+cp "$REF/common/gy_statistics.h" "$REF/common/gy_inet_inc.h" "$T/"
+# liburcu is absent: the only thing gy_inet_inc.h needs from gy_rcu_inc.h is this member-injection macro
+echo '#define RCU_HASH_CLASS_MEMBERS(...)' > "$T/gy_rcu_inc.h"
+: > "$T/TimeseriesSlabHistogram-defs.h"
+cat > "$T/gy_print_offload.h" <<'EOF'
+#pragma once
+#include "gy_common_inc.h"
+#define ERRORPRINTCOLOR_OFFLOAD(c,fmt,...) ERRORPRINTCOLOR(c,fmt,##__VA_ARGS__)
+EOF
+# folly is absent: TIME_HISTOGRAM can then be declared but not instantiated (windowed parity is unpinned)
+cat > "$T/TimeseriesSlabHistogram.h" <<'EOF'
+#pragma once
+#include <chrono>
+namespace folly {
+template <typename D = std::chrono::seconds> struct LegacyStatsClock { using duration = D; using time_point = std::chrono::time_point<LegacyStatsClock, D>; };
+template <typename T, typename CT = LegacyStatsClock<std::chrono::seconds>> class MultiLevelTimeSeries;
+template <typename T, typename H, typename CT = LegacyStatsClock<std::chrono::seconds>, typename C = MultiLevelTimeSeries<T, CT>> class TimeseriesSlabHistogram;
+}
+EOF
+# the forced includes paper over gcc-8 era transitive-include assumptions in gy_common_inc.h
+g++ -std=c++17 -O2 -D_GNU_SOURCE -DNDEBUG -pthread -fno-strict-aliasing -fPIC -shared -w \
+	-include string -include string_view -include optional -include vector -include algorithm -include functional \
+	-include chrono -include array -include tuple -include utility \
+	-I"$T" -I"$REF/common" "$HERE/ref_glue.cc" -o "$OUT/libgyref.so"
+echo "built $OUT/libgyref.so"

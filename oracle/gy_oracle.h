@@ -1,0 +1,179 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU oracle for the gyeeta_amd hot path.
+ *
+ * Plain-C restatement of the reference algorithms on the madhava/shyama aggregation path plus
+ * the frozen CPU definitions of the HLL / Count-Min / t-digest sketches the engine adds (the reference has none of its
+ * own; see DESIGN.md "oracle pinning").  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * this; the product library (gyeeta_amd/csrc) never links or calls it.
+ *
+ * Pinning status:
+ *   - jhash / key hashes / bucket hashes / GY_HISTOGRAM arithmetic: PINNED against test/test_histogram.cc:28-147 asserts,
+ *     the SURVEY 8c KATs and against oracle/_ref (the reference's own headers compiled here) in tests/test_oracle_vs_ref.py.
+ *   - LISTEN_SUMM_STATS / STATE_ONE sums: restated from server/gy_msocket.h:840-882, common/gy_comm_proto.h:3181-3210;
+ *     those headers are unbuildable here (folly/liburcu) -> structural restatement, parity unpinned beyond layout sizes.
+ *   - HLL / CMS / t-digest: builder-defined (no reference implementation exists) -> "parity unpinned" vs reference; the
+ *     acceptance test against reference behaviour is rank error vs exact sort + bucket agreement with GY_HISTOGRAM.
+ */
+#ifndef GY_ORACLE_H
+#define GY_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- hashing (common/jhash.h) */
+uint32_t gyo_jhash(const void *key, uint32_t length, uint32_t initval);
+uint32_t gyo_jhash2(const uint32_t *k, uint32_t length, uint32_t initval);
+uint32_t gyo_jhash_3words(uint32_t a, uint32_t b, uint32_t c, uint32_t initval);
+uint32_t gyo_jhash_2words(uint32_t a, uint32_t b, uint32_t initval);
+uint32_t gyo_jhash_1word(uint32_t a, uint32_t initval);
+uint32_t gyo_get_uint64_hash(uint64_t k);
+uint32_t gyo_get_uint32_hash(uint32_t k);
+
+/* key byte-packing + hash (ip: 4 bytes network order or 16 bytes in6_addr; port host order) */
+uint32_t gyo_ip_port_words(const uint8_t *ip, int is_v6, uint16_t port, int ignore_ip, uint32_t out[5]);
+uint32_t gyo_ip_port_hash(const uint8_t *ip, int is_v6, uint16_t port, int ignore_ip);
+uint32_t gyo_ns_ip_port_hash(const uint8_t *ip, int is_v6, uint16_t port, uint64_t inode, int ignore_ip);
+uint32_t gyo_pair_ip_port_words(const uint8_t *cip, int c6, uint16_t cport, const uint8_t *sip, int s6, uint16_t sport,
+				uint32_t out[10]);
+uint32_t gyo_pair_ip_port_hash(const uint8_t *cip, int c6, uint16_t cport, const uint8_t *sip, int s6, uint16_t sport);
+uint32_t gyo_machine_id_hash(uint64_t first, uint64_t second);
+
+/* 64-bit sketch hash: (jhash2(seed 0xceedfead) << 32) | jhash2(seed 0x9e3779b9)   */
+uint64_t gyo_hash64(const uint32_t *words, uint32_t nwords);
+
+/* ---------------------------------------------------------------- bucket hashes + GY_HISTOGRAM */
+enum {
+	GYO_RESP_TIME_HASH = 0,
+	GYO_SEMI_LOG_HASH = 1,
+	GYO_SEMI_LOG_HASH_LO = 2,
+	GYO_DURATION_HASH = 3,
+	GYO_HASH_10_5000 = 4,
+	GYO_HASH_5_250 = 5,
+	GYO_HASH_1_3000 = 6,
+	GYO_PERCENT_HASH = 7,      /* FIXED_DIFF_HASH<int64_t,0,100,10>, histogram T=int */
+	GYO_FIXED_9_26_5 = 8,      /* FIXED_DIFF_HASH<int8_t,9,26,5>,  T=int8_t (test_histogram.cc) */
+	GYO_FIXED_N15_N3_4 = 9,    /* FIXED_DIFF_HASH<int,-15,-3,4>,   T=int    (test_histogram.cc) */
+	GYO_NKINDS = 10
+};
+
+#define GYO_MAX_BUCKETS 16
+
+typedef struct {
+	uint64_t count;
+	int64_t sum;
+} gyo_hist_serial; /* == HIST_SERIAL, 16 bytes */
+
+typedef struct {
+	int kind;
+	int nbuckets;
+	gyo_hist_serial stats[GYO_MAX_BUCKETS];
+	uint64_t total_count;
+	int64_t max_val_seen;
+} gyo_hist;
+
+typedef struct {
+	int64_t data_value;
+	int64_t sum;
+	uint64_t count;
+	float percentile;
+} gyo_hist_data; /* == HIST_DATA */
+
+int gyo_hist_nbuckets(int kind);
+uint32_t gyo_bucket(int kind, int64_t data);
+void gyo_bucket_many(int kind, const int64_t *v, size_t n, uint32_t *out);
+int64_t gyo_bucket_max_threshold(int kind, size_t id);
+void gyo_hist_init(gyo_hist *h, int kind);
+uint32_t gyo_hist_add(gyo_hist *h, int64_t data);
+void gyo_hist_add_many(gyo_hist *h, const int64_t *v, size_t n);
+void gyo_hist_merge(gyo_hist *dst, const gyo_hist *src);
+void gyo_hist_percentiles(const gyo_hist *h, gyo_hist_data *pdata, size_t npct, uint64_t *total, int64_t *maxv, float *pavg);
+/* percentiles from raw serialized arrays (what the GPU exports) */
+void gyo_percentiles_raw(int kind, const gyo_hist_serial *stats, uint64_t total_count, gyo_hist_data *pdata, size_t npct, float *pavg);
+
+/* keyed bulk ingest: nkeys histograms of one kind; key index per value; the layout matches the GPU export:
+ * stats[key*16 + b], total[key], maxv[key] */
+void gyo_keyed_hist_ingest(int kind, const uint32_t *keyidx, const int32_t *vals, size_t n, gyo_hist_serial *stats /*[nkeys*16]*/,
+			   uint64_t *total, int64_t *maxv);
+
+/* CONN_BITMAP (common/gy_socket_stat.h:390-454): respmap[32] of 15-bit masks, slot = cli_port & 0x1F */
+void gyo_conn_bitmap_add(uint16_t respmap[32], uint16_t cli_port, uint8_t bucket);
+void gyo_conn_bitmap_breakup(const uint16_t respmap[32], uint8_t nconn_arr[15]);
+
+/* ---------------------------------------------------------------- HLL / CMS (builder-defined, frozen in DESIGN.md) */
+#define GYO_HLL_P 14
+#define GYO_HLL_M (1u << GYO_HLL_P)
+#define GYO_CMS_D 4
+#define GYO_CMS_W 65536u
+
+void gyo_hll_idx_rank(uint64_t h64, int p, uint32_t *idx, uint8_t *rank);
+void gyo_hll_add(uint8_t *regs, int p, uint64_t h64);
+void gyo_hll_add_words(uint8_t *regs, int p, const uint32_t *words, uint32_t nwords);
+void gyo_hll_merge(uint8_t *dst, const uint8_t *src, int p);
+double gyo_hll_estimate(const uint8_t *regs, int p);
+
+void gyo_cms_cols(const uint32_t *words, uint32_t nwords, uint32_t cols[GYO_CMS_D]);
+void gyo_cms_add(uint32_t *tbl /*[D*W]*/, const uint32_t *words, uint32_t nwords, uint32_t weight);
+uint32_t gyo_cms_query(const uint32_t *tbl, const uint32_t *words, uint32_t nwords);
+void gyo_cms64_add(uint64_t *tbl /*[D*W]*/, const uint32_t *words, uint32_t nwords, uint64_t weight);
+uint64_t gyo_cms64_query(const uint64_t *tbl, const uint32_t *words, uint32_t nwords);
+
+/* ---------------------------------------------------------------- t-digest (k-bucketed merging digest, exact integer) */
+#define GYO_TD_NB 100
+
+typedef struct {
+	int64_t sum[GYO_TD_NB];
+	uint32_t cnt[GYO_TD_NB];
+	int32_t vmin, vmax; /* valid when total > 0 */
+} gyo_tdigest;
+
+extern const uint64_t gyo_td_bnd[GYO_TD_NB + 1];
+
+void gyo_td_init(gyo_tdigest *d);
+uint64_t gyo_td_total(const gyo_tdigest *d);
+uint32_t gyo_td_cluster(uint64_t mid2, uint64_t twoN);
+/* merge m new values (any order; sorted internally) into d */
+void gyo_td_merge_values(gyo_tdigest *d, const int32_t *vals, size_t m);
+/* merge another digest's clusters into d (multi-GPU / window roll-up): other's clusters are treated as weighted points */
+void gyo_td_merge_digest(gyo_tdigest *d, const gyo_tdigest *o);
+double gyo_td_quantile(const gyo_tdigest *d, double q);
+
+/* ---------------------------------------------------------------- wire records + roll-ups */
+#define GYO_TCP_CONN_NOTIFY_SZ 280
+#define GYO_LISTENER_STATE_NOTIFY_SZ 88
+#define GYO_NSTATES 7 /* OBJ_STATE_E STATE_IDLE..STATE_DOWN (common/gy_common_inc.h) */
+
+typedef struct {
+	int32_t nstates[GYO_NSTATES];
+	int32_t tot_qps, tot_act_conn, tot_kb_inbound, tot_kb_outbound, tot_ser_errors, nlisteners, nactive;
+} gyo_listen_summ_stats; /* == LISTEN_SUMM_STATS<int> server/gy_msocket.h:840-851 */
+
+typedef struct {
+	uint32_t nhosts, ntasks_issue, ntaskissue_hosts, ntasks, nsvc_issue, nsvcissue_hosts, nsvc, total_qps, svc_net_mb,
+		ncpu_issue, nmem_issue;
+} gyo_cluster_state_one; /* == MS_CLUSTER_STATE::STATE_ONE common/gy_comm_proto.h:3183-3197 */
+
+/* walk a LISTENER_STATE_NOTIFY batch the way partha_listener_state does (gy_mconnhdlr.cc:11175) and fold every record
+ * whose curr_state_ <= STATE_DOWN into summ (gy_msocket.h:853-865).  Returns number of records walked; *nerrors counts
+ * records with an out of range state (gy_mconnhdlr.cc:11250-11256). */
+int gyo_listener_state_rollup(const uint8_t *batch, int nrec, const uint8_t *pend, gyo_listen_summ_stats *summ, int *nerrors);
+uint32_t gyo_listener_state_elem_size(const uint8_t *rec);
+uint32_t gyo_tcp_conn_elem_size(const uint8_t *rec);
+/* walk a TCP_CONN_NOTIFY batch (gy_mconnhdlr.cc:9130) producing for each record the PAIR_IP_PORT(nat_cli_, nat_ser_) key words
+ * (gy_mconnhdlr.cc:8707), ser_glob_id_, bytes_sent_, bytes_rcvd_; returns number of records walked */
+int gyo_tcp_conn_decode(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *keywords /*[nrec*10]*/, uint32_t *nwords,
+			uint64_t *ser_glob_id, uint64_t *bytes_sent, uint64_t *bytes_rcvd, uint8_t *flags);
+void gyo_cluster_state_update(gyo_cluster_state_one *c, uint32_t ntasks_issue, uint32_t ntasks, uint32_t nlisten_issue,
+			      uint32_t nlisten, uint32_t cpu_issue, uint32_t mem_issue, const gyo_listen_summ_stats *summ);
+void gyo_cluster_state_add(gyo_cluster_state_one *dst, const gyo_cluster_state_one *src);
+
+/* BOUNDED_PRIO_QUEUE<uint64_t, greater> (common/gy_statistics.h:356-383): returns retained values sorted descending */
+size_t gyo_topn_u64(const uint64_t *vals, size_t n, size_t maxn, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,251 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes bindings for oracle/liboracle.so (the plain-C restatement, gy_oracle.c) and, when
+built, oracle/_ref/libgyref.so (the reference's own headers compiled here by oracle/build_ref.sh).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+REF_PATH = os.path.join(HERE, "_ref", "libgyref.so")
+
+KINDS = {
+    "RESP_TIME_HASH": 0, "SEMI_LOG_HASH": 1, "SEMI_LOG_HASH_LO": 2, "DURATION_HASH": 3, "HASH_10_5000": 4,
+    "HASH_5_250": 5, "HASH_1_3000": 6, "PERCENT_HASH": 7, "FIXED_9_26_5": 8, "FIXED_N15_N3_4": 9,
+}
+MAX_BUCKETS = 16
+TD_NB = 100
+HLL_P = 14
+CMS_D = 4
+CMS_W = 65536
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+f32p = C.POINTER(C.c_float)
+
+
+def build_oracle(force=False):
+    src = os.path.join(HERE, "gy_oracle.c")
+    if (not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= os.path.getmtime(src)
+            and os.path.getmtime(LIB_PATH) >= os.path.getmtime(os.path.join(HERE, "gy_oracle.h"))):
+        return LIB_PATH
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-o", LIB_PATH, src, "-lm"])
+    return LIB_PATH
+
+
+class HistSerial(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("sum", C.c_int64)]
+
+
+class Hist(C.Structure):
+    _fields_ = [("kind", C.c_int), ("nbuckets", C.c_int), ("stats", HistSerial * MAX_BUCKETS),
+                ("total_count", C.c_uint64), ("max_val_seen", C.c_int64)]
+
+
+class HistData(C.Structure):
+    _fields_ = [("data_value", C.c_int64), ("sum", C.c_int64), ("count", C.c_uint64), ("percentile", C.c_float)]
+
+
+class TDigest(C.Structure):
+    _fields_ = [("sum", C.c_int64 * TD_NB), ("cnt", C.c_uint32 * TD_NB), ("vmin", C.c_int32), ("vmax", C.c_int32)]
+
+
+class ListenSummStats(C.Structure):
+    _fields_ = [("nstates", C.c_int32 * 6), ("tot_qps", C.c_int32), ("tot_act_conn", C.c_int32),
+                ("tot_kb_inbound", C.c_int32), ("tot_kb_outbound", C.c_int32), ("tot_ser_errors", C.c_int32),
+                ("nlisteners", C.c_int32), ("nactive", C.c_int32)]
+
+    def as_tuple(self):
+        return tuple(self.nstates) + (self.tot_qps, self.tot_act_conn, self.tot_kb_inbound, self.tot_kb_outbound,
+                                      self.tot_ser_errors, self.nlisteners, self.nactive)
+
+
+class ClusterStateOne(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("nhosts", "ntasks_issue", "ntaskissue_hosts", "ntasks", "nsvc_issue",
+                                          "nsvcissue_hosts", "nsvc", "total_qps", "svc_net_mb", "ncpu_issue", "nmem_issue")]
+
+    def as_tuple(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+def _sig(lib, name, restype, argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = argtypes
+    return f
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build_oracle()
+    L = C.CDLL(LIB_PATH)
+    _sig(L, "gyo_jhash", C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32])
+    _sig(L, "gyo_jhash2", C.c_uint32, [u32p, C.c_uint32, C.c_uint32])
+    _sig(L, "gyo_jhash_3words", C.c_uint32, [C.c_uint32] * 4)
+    _sig(L, "gyo_jhash_2words", C.c_uint32, [C.c_uint32] * 3)
+    _sig(L, "gyo_jhash_1word", C.c_uint32, [C.c_uint32] * 2)
+    _sig(L, "gyo_get_uint64_hash", C.c_uint32, [C.c_uint64])
+    _sig(L, "gyo_get_uint32_hash", C.c_uint32, [C.c_uint32])
+    _sig(L, "gyo_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, C.c_int])
+    _sig(L, "gyo_ns_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, C.c_uint64, C.c_int])
+    _sig(L, "gyo_pair_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, u8p, C.c_int, C.c_uint16])
+    _sig(L, "gyo_pair_ip_port_words", C.c_uint32, [u8p, C.c_int, C.c_uint16, u8p, C.c_int, C.c_uint16, u32p])
+    _sig(L, "gyo_machine_id_hash", C.c_uint32, [C.c_uint64, C.c_uint64])
+    _sig(L, "gyo_hash64", C.c_uint64, [u32p, C.c_uint32])
+    _sig(L, "gyo_hist_nbuckets", C.c_int, [C.c_int])
+    _sig(L, "gyo_bucket", C.c_uint32, [C.c_int, C.c_int64])
+    _sig(L, "gyo_bucket_many", None, [C.c_int, i64p, C.c_size_t, u32p])
+    _sig(L, "gyo_bucket_max_threshold", C.c_int64, [C.c_int, C.c_size_t])
+    _sig(L, "gyo_hist_init", None, [C.POINTER(Hist), C.c_int])
+    _sig(L, "gyo_hist_add", C.c_uint32, [C.POINTER(Hist), C.c_int64])
+    _sig(L, "gyo_hist_add_many", None, [C.POINTER(Hist), i64p, C.c_size_t])
+    _sig(L, "gyo_hist_merge", None, [C.POINTER(Hist), C.POINTER(Hist)])
+    _sig(L, "gyo_hist_percentiles", None, [C.POINTER(Hist), C.POINTER(HistData), C.c_size_t, u64p, i64p, f32p])
+    _sig(L, "gyo_percentiles_raw", None, [C.c_int, C.POINTER(HistSerial), C.c_uint64, C.POINTER(HistData), C.c_size_t, f32p])
+    _sig(L, "gyo_keyed_hist_ingest", None, [C.c_int, u32p, i32p, C.c_size_t, C.c_void_p, u64p, i64p])
+    _sig(L, "gyo_conn_bitmap_add", None, [u16p, C.c_uint16, C.c_uint8])
+    _sig(L, "gyo_conn_bitmap_breakup", None, [u16p, u8p])
+    _sig(L, "gyo_hll_idx_rank", None, [C.c_uint64, C.c_int, u32p, u8p])
+    _sig(L, "gyo_hll_add", None, [u8p, C.c_int, C.c_uint64])
+    _sig(L, "gyo_hll_add_words", None, [u8p, C.c_int, u32p, C.c_uint32])
+    _sig(L, "gyo_hll_merge", None, [u8p, u8p, C.c_int])
+    _sig(L, "gyo_hll_estimate", C.c_double, [u8p, C.c_int])
+    _sig(L, "gyo_cms_cols", None, [u32p, C.c_uint32, u32p])
+    _sig(L, "gyo_cms_add", None, [u32p, u32p, C.c_uint32, C.c_uint32])
+    _sig(L, "gyo_cms_query", C.c_uint32, [u32p, u32p, C.c_uint32])
+    _sig(L, "gyo_cms64_add", None, [u64p, u32p, C.c_uint32, C.c_uint64])
+    _sig(L, "gyo_cms64_query", C.c_uint64, [u64p, u32p, C.c_uint32])
+    _sig(L, "gyo_td_init", None, [C.POINTER(TDigest)])
+    _sig(L, "gyo_td_total", C.c_uint64, [C.POINTER(TDigest)])
+    _sig(L, "gyo_td_cluster", C.c_uint32, [C.c_uint64, C.c_uint64])
+    _sig(L, "gyo_td_merge_values", None, [C.POINTER(TDigest), i32p, C.c_size_t])
+    _sig(L, "gyo_td_merge_digest", None, [C.POINTER(TDigest), C.POINTER(TDigest)])
+    _sig(L, "gyo_td_quantile", C.c_double, [C.POINTER(TDigest), C.c_double])
+    _sig(L, "gyo_listener_state_rollup", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(ListenSummStats), C.POINTER(C.c_int)])
+    _sig(L, "gyo_listener_state_elem_size", C.c_uint32, [C.c_void_p])
+    _sig(L, "gyo_tcp_conn_elem_size", C.c_uint32, [C.c_void_p])
+    _sig(L, "gyo_tcp_conn_decode", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u32p, u32p, u64p, u64p, u64p, u8p])
+    _sig(L, "gyo_cluster_state_update", None, [C.POINTER(ClusterStateOne)] + [C.c_uint32] * 6 + [C.POINTER(ListenSummStats)])
+    _sig(L, "gyo_cluster_state_add", None, [C.POINTER(ClusterStateOne), C.POINTER(ClusterStateOne)])
+    _sig(L, "gyo_topn_u64", C.c_size_t, [u64p, C.c_size_t, C.c_size_t, u64p])
+    _lib = L
+    return L
+
+
+_ref = None
+
+
+def ref():
+    """The reference's own code (None when oracle/_ref has not been built, e.g. no /root/reference)."""
+    global _ref
+    if _ref is not None:
+        return _ref
+    if not os.path.exists(REF_PATH):
+        return None
+    R = C.CDLL(REF_PATH)
+    _sig(R, "ref_jhash", C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32])
+    _sig(R, "ref_jhash2", C.c_uint32, [u32p, C.c_uint32, C.c_uint32])
+    _sig(R, "ref_jhash_3words", C.c_uint32, [C.c_uint32] * 4)
+    _sig(R, "ref_jhash_2words", C.c_uint32, [C.c_uint32] * 3)
+    _sig(R, "ref_jhash_1word", C.c_uint32, [C.c_uint32] * 2)
+    _sig(R, "ref_get_uint64_hash", C.c_uint32, [C.c_uint64])
+    _sig(R, "ref_get_uint32_hash", C.c_uint32, [C.c_uint32])
+    _sig(R, "ref_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, C.c_int])
+    _sig(R, "ref_ns_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, C.c_uint64, C.c_int])
+    _sig(R, "ref_pair_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, u8p, C.c_int, C.c_uint16])
+    _sig(R, "ref_machine_id_hash", C.c_uint32, [C.c_uint64, C.c_uint64])
+    _sig(R, "ref_sizeof", C.c_size_t, [C.c_int])
+    _sig(R, "ref_ip_port_bytes", None, [u8p, C.c_int, C.c_uint16, u8p])
+    _sig(R, "ref_hist_new", C.c_void_p, [C.c_int])
+    _sig(R, "ref_hist_free", None, [C.c_void_p])
+    _sig(R, "ref_hist_nbuckets", C.c_size_t, [C.c_void_p])
+    _sig(R, "ref_hist_object_size", C.c_size_t, [C.c_void_p])
+    _sig(R, "ref_hist_add", C.c_size_t, [C.c_void_p, C.c_int64])
+    _sig(R, "ref_hist_add_many", None, [C.c_void_p, i64p, C.c_size_t])
+    _sig(R, "ref_hist_bucket_of", C.c_size_t, [C.c_void_p, C.c_int64])
+    _sig(R, "ref_hist_bucket_of_many", None, [C.c_void_p, i64p, C.c_size_t, u32p])
+    _sig(R, "ref_hist_bucket_max_threshold", C.c_int64, [C.c_void_p, C.c_size_t])
+    _sig(R, "ref_hist_percentiles", None, [C.c_void_p, f32p, C.c_size_t, i64p, i64p, u64p, u64p, i64p, f32p])
+    _sig(R, "ref_hist_serialized", None, [C.c_void_p, u64p, i64p, u64p, i64p])
+    _sig(R, "ref_hist_merge", None, [C.c_void_p, C.c_void_p])
+    _sig(R, "ref_hist_clear", None, [C.c_void_p])
+    _sig(R, "ref_topn_u64", C.c_size_t, [u64p, C.c_size_t, C.c_size_t, u64p])
+    _ref = R
+    return R
+
+
+# ------------------------------------------------------------------ numpy conveniences
+
+def ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def ip_bytes(ip):
+    """ip: int (ipv4, value whose little-endian bytes are the network-order address, i.e. ip32_be) or 16 raw bytes."""
+    if isinstance(ip, (bytes, bytearray)):
+        assert len(ip) == 16
+        return (C.c_uint8 * 16)(*ip), 1
+    return (C.c_uint8 * 4)(*int(ip).to_bytes(4, "little")), 0
+
+
+def hash64_words(words):
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    return lib().gyo_hash64(ptr(w, u32p), len(w))
+
+
+def glob_id_words(gid):
+    gid = int(gid)
+    return np.array([gid & 0xFFFFFFFF, gid >> 32], dtype=np.uint32)
+
+
+def hist_percentiles(kind, stats, total, pcts):
+    """stats: structured/2-col array [[count,sum]...] (>= nbuckets rows).  Returns (values, sums, counts, avg)."""
+    L = lib()
+    arr = (HistSerial * MAX_BUCKETS)()
+    for i in range(L.gyo_hist_nbuckets(kind)):
+        arr[i].count = int(stats[i][0])
+        arr[i].sum = int(stats[i][1])
+    pd = (HistData * len(pcts))()
+    for i, p in enumerate(pcts):
+        pd[i].percentile = p
+    avg = C.c_float(0)
+    L.gyo_percentiles_raw(kind, arr, int(total), pd, len(pcts), C.byref(avg))
+    return [d.data_value for d in pd], [d.sum for d in pd], [d.count for d in pd], avg.value
+
+
+def keyed_hist(kind, nkeys, keyidx, vals):
+    L = lib()
+    stats = np.zeros((nkeys, MAX_BUCKETS, 2), dtype=np.int64)  # [..,0]=count (as i64 bits) [..,1]=sum
+    total = np.zeros(nkeys, dtype=np.uint64)
+    maxv = np.full(nkeys, np.iinfo(np.int64).min if kind in (0,) else (np.iinfo(np.int32).min if kind not in (8,) else -128),
+                   dtype=np.int64)
+    k = np.ascontiguousarray(keyidx, dtype=np.uint32)
+    v = np.ascontiguousarray(vals, dtype=np.int32)
+    L.gyo_keyed_hist_ingest(kind, ptr(k, u32p), ptr(v, i32p), len(k), stats.ctypes.data, ptr(total, u64p), ptr(maxv, i64p))
+    return stats, total, maxv
+
+
+def td_from_arrays(sums, cnts, vmin, vmax):
+    d = TDigest()
+    for i in range(TD_NB):
+        d.sum[i] = int(sums[i])
+        d.cnt[i] = int(cnts[i])
+    d.vmin = int(vmin)
+    d.vmax = int(vmax)
+    return d
+
+
+def td_to_arrays(d):
+    return (np.array(list(d.sum), dtype=np.int64), np.array(list(d.cnt), dtype=np.uint32), d.vmin, d.vmax)

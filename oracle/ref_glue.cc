@@ -1,0 +1,229 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product library.
+//
+// Thin extern "C" wrapper around the REFERENCE's own headers, compiled where they lie under
+// /root/reference by oracle/build_ref.sh into oracle/_ref/libgyref.so.  Nothing from the reference
+// is copied into this file: it only #includes gy_common_inc.h / gy_statistics.h / gy_inet_inc.h /
+// jhash.h and forwards to the reference's classes so the plain-C restatement in oracle/gy_oracle.c
+// can be validated against the real thing (tests/test_oracle_vs_ref.py) and golden vectors can be
+// generated (tests/golden/make_golden.py).
+//
+// Reference entry points wrapped (file:line in /root/reference):
+//   common/jhash.h:43-140                jhash, jhash2, jhash_{1,2,3}words
+//   common/gy_common_inc.h:1110-1123     get_uint32_hash / get_uint64_hash
+//   common/gy_common_inc.h:11226-11244   IP_PORT::get_hash
+//   common/gy_inet_inc.h:136-160         NS_IP_PORT::get_hash
+//   common/gy_inet_inc.h:225-247         PAIR_IP_PORT::get_hash
+//   common/gy_sys_hardware.h:82-85       GY_MACHINE_ID::get_hash (== jhash2 over the 16 id bytes; that header is
+//                                        not buildable here (needs gy_netif.h -> libmnl), so the wrapper calls the
+//                                        reference jhash2 on the same 4 words)
+//   common/gy_statistics.h:455-894       HIST_SERIAL, GY_HISTOGRAM (add_data, add_histogram, get_percentiles ...)
+//   common/gy_statistics.h:1565-2063     bucket-hash classes
+//   common/gy_statistics.h:28-453        BOUNDED_PRIO_QUEUE
+#include "gy_common_inc.h"
+#include "gy_statistics.h"
+#include "gy_inet_inc.h"
+
+namespace gyeeta {
+// originals: common/gy_file_api.cc:60-63 (that TU needs the full build, so the three globals are defined here)
+bool guse_utc_time = false;
+int gdebugexecn = 0;
+thread_local GY_THR_LOCAL gthrdata_local_;
+}
+
+using namespace gyeeta;
+
+namespace {
+
+struct HistBase {
+	virtual ~HistBase() {}
+	virtual size_t nbuckets() const = 0;
+	virtual size_t add(int64_t v) = 0;
+	virtual size_t bucket_of(int64_t v) const = 0;
+	virtual int64_t bucket_max_threshold(size_t id) const = 0;
+	virtual void percentiles(const float *pcts, size_t n, int64_t *vals, int64_t *sums, uint64_t *counts,
+				 uint64_t *total, int64_t *maxv, float *avg) const = 0;
+	virtual void serialized(uint64_t *counts, int64_t *sums, uint64_t *total, int64_t *maxv) const = 0;
+	virtual void merge_from(const HistBase *other) = 0;
+	virtual void clear() = 0;
+	virtual size_t object_size() const = 0;
+};
+
+template <typename T, typename Hash>
+struct HistImpl final : HistBase {
+	using H = GY_HISTOGRAM<T, Hash>;
+	H h{1};
+
+	size_t nbuckets() const override { return H::maxbuckets_; }
+	size_t add(int64_t v) override { return h.add_data((T)v, 1); }
+	size_t bucket_of(int64_t v) const override { return Hash()((T)v); }
+	int64_t bucket_max_threshold(size_t id) const override { return (int64_t)(T)get_bucket_max_threshold<Hash, T>(id); }
+
+	void percentiles(const float *pcts, size_t n, int64_t *vals, int64_t *sums, uint64_t *counts, uint64_t *total,
+			 int64_t *maxv, float *avg) const override
+	{
+		std::vector<HIST_DATA> d(n);
+		for (size_t i = 0; i < n; ++i) d[i].percentile = pcts[i];
+		size_t tc = 0;
+		T mv = 0;
+		h.get_percentiles(d.data(), n, tc, mv, avg);
+		for (size_t i = 0; i < n; ++i) {
+			vals[i] = d[i].data_value;
+			sums[i] = d[i].sum;
+			counts[i] = d[i].count;
+		}
+		*total = tc;
+		*maxv = (int64_t)mv;
+	}
+
+	void serialized(uint64_t *counts, int64_t *sums, uint64_t *total, int64_t *maxv) const override
+	{
+		HIST_SERIAL arr[H::maxbuckets_];
+		size_t tc;
+		T mv;
+		uint64_t e, s;
+		h.get_serialized(arr, tc, mv, e, s);
+		for (size_t i = 0; i < H::maxbuckets_; ++i) {
+			counts[i] = arr[i].count;
+			sums[i] = arr[i].sum;
+		}
+		*total = tc;
+		*maxv = (int64_t)mv;
+	}
+
+	void merge_from(const HistBase *other) override { h.add_histogram(static_cast<const HistImpl *>(other)->h); }
+	void clear() override { h.clear(); }
+	size_t object_size() const override { return sizeof(H); }
+};
+
+HistBase *make_hist(int kind)
+{
+	switch (kind) {
+	case 0: return new HistImpl<int64_t, RESP_TIME_HASH>();
+	case 1: return new HistImpl<int, SEMI_LOG_HASH>();
+	case 2: return new HistImpl<int, SEMI_LOG_HASH_LO>();
+	case 3: return new HistImpl<int, DURATION_HASH>();
+	case 4: return new HistImpl<int, HASH_10_5000>();
+	case 5: return new HistImpl<int, HASH_5_250>();
+	case 6: return new HistImpl<int, HASH_1_3000>();
+	case 7: return new HistImpl<int, PERCENT_HASH>();                          // as used by test_histogram.cc CPUHistogram
+	case 8: return new HistImpl<int8_t, FIXED_DIFF_HASH<int8_t, 9, 26, 5>>();   // test_histogram.cc Hist_9_26
+	case 9: return new HistImpl<int, FIXED_DIFF_HASH<int, -15, -3, 4>>();       // test_histogram.cc Hist_n4
+	default: return nullptr;
+	}
+}
+
+GY_IP_ADDR mk_ip(const uint8_t *ip, int is_v6)
+{
+	if (is_v6) {
+		unsigned __int128 v;
+		std::memcpy(&v, ip, 16);
+		return GY_IP_ADDR(v);
+	}
+	uint32_t v4;
+	std::memcpy(&v4, ip, 4);
+	return GY_IP_ADDR(v4);
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t ref_jhash(const void *key, uint32_t len, uint32_t initval) { return jhash(key, len, initval); }
+uint32_t ref_jhash2(const uint32_t *k, uint32_t nwords, uint32_t initval) { return jhash2(k, nwords, initval); }
+uint32_t ref_jhash_3words(uint32_t a, uint32_t b, uint32_t c, uint32_t iv) { return jhash_3words(a, b, c, iv); }
+uint32_t ref_jhash_2words(uint32_t a, uint32_t b, uint32_t iv) { return jhash_2words(a, b, iv); }
+uint32_t ref_jhash_1word(uint32_t a, uint32_t iv) { return jhash_1word(a, iv); }
+uint32_t ref_get_uint64_hash(uint64_t k) { return get_uint64_hash(k); }
+uint32_t ref_get_uint32_hash(uint32_t k) { return get_uint32_hash(k); }
+
+// ip: 4 bytes (network order, as GY_IP_ADDR(uint32_t ip32_be)) or 16 bytes (in6_addr); port in host order
+uint32_t ref_ip_port_hash(const uint8_t *ip, int is_v6, uint16_t port, int ignore_ip)
+{
+	return IP_PORT(mk_ip(ip, is_v6), port).get_hash(!!ignore_ip);
+}
+
+uint32_t ref_ns_ip_port_hash(const uint8_t *ip, int is_v6, uint16_t port, uint64_t inode, int ignore_ip)
+{
+	return NS_IP_PORT(mk_ip(ip, is_v6), port, (ino_t)inode).get_hash(!!ignore_ip);
+}
+
+uint32_t ref_pair_ip_port_hash(const uint8_t *cip, int c6, uint16_t cport, const uint8_t *sip, int s6, uint16_t sport)
+{
+	return PAIR_IP_PORT(IP_PORT(mk_ip(cip, c6), cport), IP_PORT(mk_ip(sip, s6), sport)).get_hash();
+}
+
+uint32_t ref_machine_id_hash(uint64_t first, uint64_t second)
+{
+	std::pair<uint64_t, uint64_t> machid(first, second);
+	return jhash2((uint32_t *)(&machid), sizeof(machid) / sizeof(uint32_t), 0xceedfead);
+}
+
+size_t ref_sizeof(int what)
+{
+	switch (what) {
+	case 0: return sizeof(GY_IP_ADDR);
+	case 1: return sizeof(IP_PORT);
+	case 2: return sizeof(PAIR_IP_PORT);
+	case 3: return sizeof(NS_IP_PORT);
+	case 4: return sizeof(HIST_SERIAL);
+	case 5: return sizeof(GY_HISTOGRAM<int64_t, RESP_TIME_HASH>);
+	case 6: return sizeof(HIST_DATA);
+	default: return 0;
+	}
+}
+
+// Raw object bytes of an IP_PORT built the way the reference builds it (for layout checks of the wire restatement)
+void ref_ip_port_bytes(const uint8_t *ip, int is_v6, uint16_t port, uint8_t out[32])
+{
+	IP_PORT p(mk_ip(ip, is_v6), port);
+	std::memset(out, 0, 32);
+	std::memcpy(out, &p.ipaddr_, sizeof(GY_IP_ADDR));
+	std::memcpy(out + offsetof(IP_PORT, port_), &p.port_, 2);
+}
+
+void *ref_hist_new(int kind) { return make_hist(kind); }
+void ref_hist_free(void *h) { delete static_cast<HistBase *>(h); }
+size_t ref_hist_nbuckets(void *h) { return static_cast<HistBase *>(h)->nbuckets(); }
+size_t ref_hist_object_size(void *h) { return static_cast<HistBase *>(h)->object_size(); }
+size_t ref_hist_add(void *h, int64_t v) { return static_cast<HistBase *>(h)->add(v); }
+void ref_hist_add_many(void *h, const int64_t *v, size_t n)
+{
+	auto *p = static_cast<HistBase *>(h);
+	for (size_t i = 0; i < n; ++i) p->add(v[i]);
+}
+size_t ref_hist_bucket_of(void *h, int64_t v) { return static_cast<HistBase *>(h)->bucket_of(v); }
+void ref_hist_bucket_of_many(void *h, const int64_t *v, size_t n, uint32_t *out)
+{
+	auto *p = static_cast<HistBase *>(h);
+	for (size_t i = 0; i < n; ++i) out[i] = (uint32_t)p->bucket_of(v[i]);
+}
+int64_t ref_hist_bucket_max_threshold(void *h, size_t id) { return static_cast<HistBase *>(h)->bucket_max_threshold(id); }
+void ref_hist_percentiles(void *h, const float *pcts, size_t n, int64_t *vals, int64_t *sums, uint64_t *counts,
+			  uint64_t *total, int64_t *maxv, float *avg)
+{
+	static_cast<HistBase *>(h)->percentiles(pcts, n, vals, sums, counts, total, maxv, avg);
+}
+void ref_hist_serialized(void *h, uint64_t *counts, int64_t *sums, uint64_t *total, int64_t *maxv)
+{
+	static_cast<HistBase *>(h)->serialized(counts, sums, total, maxv);
+}
+void ref_hist_merge(void *dst, void *src) { static_cast<HistBase *>(dst)->merge_from(static_cast<HistBase *>(src)); }
+void ref_hist_clear(void *h) { static_cast<HistBase *>(h)->clear(); }
+
+// BOUNDED_PRIO_QUEUE<uint64_t, std::greater<>> top-N: feeds vals in order through push(); returns the retained values
+// sorted descending (the *multiset* of retained values is what is order independent; see DESIGN.md top-N note).
+size_t ref_topn_u64(const uint64_t *vals, size_t n, size_t maxn, uint64_t *out)
+{
+	struct GT { bool operator()(uint64_t a, uint64_t b) const noexcept { return a > b; } };
+	BOUNDED_PRIO_QUEUE<uint64_t, GT> q(maxn);
+	for (size_t i = 0; i < n; ++i) {
+		uint64_t v = vals[i];
+		q.push_locked(std::move(v));
+	}
+	std::vector<uint64_t> r(q.vecq_.begin(), q.vecq_.end());
+	std::sort(r.begin(), r.end(), std::greater<uint64_t>());
+	for (size_t i = 0; i < r.size(); ++i) out[i] = r[i];
+	return r.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+"""Randomised cross-check of the plain-C oracle against the reference's own compiled headers (oracle/_ref).  Skipped where
+oracle/_ref is absent (it is built only where /root/reference exists; the committed golden fixtures cover the rest)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("kind", range(10))
+def test_bucket_and_hist_random(oracle, reflib, kind):
+    L, R = oracle.lib(), reflib
+    rng = np.random.default_rng(100 + kind)
+    h = R.ref_hist_new(kind)
+    nb = R.ref_hist_nbuckets(h)
+    assert nb == L.gyo_hist_nbuckets(kind)
+    vals = np.concatenate([
+        rng.integers(-50, 200, 3000), rng.integers(-10, 6_000_000, 3000), (rng.lognormal(3, 2.5, 3000)).astype(np.int64),
+        np.array([2**31 - 1, 2**31, 2**31 + 5, -2**31, 2**40 + 17, -2**40, 2**62], dtype=np.int64)]).astype(np.int64)
+    if kind == 8:
+        vals = rng.integers(-128, 128, 3000).astype(np.int64)
+    bo = np.zeros(len(vals), dtype=np.uint32)
+    br = np.zeros(len(vals), dtype=np.uint32)
+    L.gyo_bucket_many(kind, oracle.ptr(vals, oracle.i64p), len(vals), oracle.ptr(bo, oracle.u32p))
+    R.ref_hist_bucket_of_many(h, oracle.ptr(vals, oracle.i64p), len(vals), oracle.ptr(br, oracle.u32p))
+    assert (bo == br).all()
+    for i in range(nb + 2):
+        assert L.gyo_bucket_max_threshold(kind, i) == R.ref_hist_bucket_max_threshold(h, i)
+
+    oh = oracle.Hist()
+    L.gyo_hist_init(C.byref(oh), kind)
+    h2 = R.ref_hist_new(kind)
+    oh2 = oracle.Hist()
+    L.gyo_hist_init(C.byref(oh2), kind)
+    half = len(vals) // 2
+    a, b = np.ascontiguousarray(vals[:half]), np.ascontiguousarray(vals[half:])
+    R.ref_hist_add_many(h, oracle.ptr(a, oracle.i64p), len(a))
+    R.ref_hist_add_many(h2, oracle.ptr(b, oracle.i64p), len(b))
+    L.gyo_hist_add_many(C.byref(oh), oracle.ptr(a, oracle.i64p), len(a))
+    L.gyo_hist_add_many(C.byref(oh2), oracle.ptr(b, oracle.i64p), len(b))
+    R.ref_hist_merge(h, h2)           # add_histogram
+    L.gyo_hist_merge(C.byref(oh), C.byref(oh2))
+
+    counts = np.zeros(nb, dtype=np.uint64)
+    sums = np.zeros(nb, dtype=np.int64)
+    total, maxv = C.c_uint64(), C.c_int64()
+    R.ref_hist_serialized(h, oracle.ptr(counts, oracle.u64p), oracle.ptr(sums, oracle.i64p), C.byref(total), C.byref(maxv))
+    assert [oh.stats[i].count for i in range(nb)] == counts.tolist()
+    assert [oh.stats[i].sum for i in range(nb)] == sums.tolist()
+    assert oh.total_count == total.value and oh.max_val_seen == maxv.value
+
+    pcts = np.array([0.001, 1, 10, 25, 50, 75, 90, 95, 99, 99.9, 99.999, 100], dtype=np.float32)
+    pv = np.zeros(len(pcts), dtype=np.int64)
+    ps = np.zeros(len(pcts), dtype=np.int64)
+    pc = np.zeros(len(pcts), dtype=np.uint64)
+    avg = C.c_float()
+    R.ref_hist_percentiles(h, oracle.ptr(pcts, oracle.f32p), len(pcts), oracle.ptr(pv, oracle.i64p), oracle.ptr(ps, oracle.i64p),
+                           oracle.ptr(pc, oracle.u64p), C.byref(total), C.byref(maxv), C.byref(avg))
+    pd = (oracle.HistData * len(pcts))()
+    for i, p in enumerate(pcts):
+        pd[i].percentile = float(p)
+    oavg = C.c_float()
+    L.gyo_hist_percentiles(C.byref(oh), pd, len(pcts), None, None, C.byref(oavg))
+    assert [d.data_value for d in pd] == pv.tolist()
+    assert [d.sum for d in pd] == ps.tolist()
+    assert [d.count for d in pd] == pc.tolist()
+    assert np.float32(oavg.value).tobytes() == np.float32(avg.value).tobytes()
+    R.ref_hist_free(h)
+    R.ref_hist_free(h2)
+
+
+def test_percentile_float_cutoff_large_counts(oracle, reflib):
+    """ncutoff = size_t * float: exercise counts above 2^24 where the float product rounds (gy_statistics.h:757-758)."""
+    L, R = oracle.lib(), reflib
+    h = R.ref_hist_new(0)
+    oh = oracle.Hist()
+    L.gyo_hist_init(C.byref(oh), 0)
+    rng = np.random.default_rng(7)
+    vals = rng.integers(0, 1200, 40_000_000 // 64).astype(np.int64)
+    for _ in range(64):  # 40M adds -> total_count > 2^25
+        R.ref_hist_add_many(h, oracle.ptr(vals, oracle.i64p), len(vals))
+        L.gyo_hist_add_many(C.byref(oh), oracle.ptr(vals, oracle.i64p), len(vals))
+    pcts = np.array([33.333, 50, 66.6667, 99.9999, 100], dtype=np.float32)
+    pv = np.zeros(len(pcts), dtype=np.int64)
+    ps = np.zeros(len(pcts), dtype=np.int64)
+    pc = np.zeros(len(pcts), dtype=np.uint64)
+    total, maxv, avg = C.c_uint64(), C.c_int64(), C.c_float()
+    R.ref_hist_percentiles(h, oracle.ptr(pcts, oracle.f32p), len(pcts), oracle.ptr(pv, oracle.i64p), oracle.ptr(ps, oracle.i64p),
+                           oracle.ptr(pc, oracle.u64p), C.byref(total), C.byref(maxv), C.byref(avg))
+    pd = (oracle.HistData * len(pcts))()
+    for i, p in enumerate(pcts):
+        pd[i].percentile = float(p)
+    oavg = C.c_float()
+    L.gyo_hist_percentiles(C.byref(oh), pd, len(pcts), None, None, C.byref(oavg))
+    assert [d.data_value for d in pd] == pv.tolist() and [d.count for d in pd] == pc.tolist()
+    assert np.float32(oavg.value).tobytes() == np.float32(avg.value).tobytes()
+    R.ref_hist_free(h)
+
+
+def test_hashes_random(oracle, reflib):
+    L, R = oracle.lib(), reflib
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        n = int(rng.integers(1, 13))
+        w = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        seed = int(rng.integers(0, 2**32))
+        assert L.gyo_jhash2(oracle.ptr(w, oracle.u32p), n, seed) == R.ref_jhash2(oracle.ptr(w, oracle.u32p), n, seed)
+        b = w.tobytes()[: int(rng.integers(0, 4 * n + 1))]
+        assert L.gyo_jhash(b, len(b), seed) == R.ref_jhash(b, len(b), seed)
+        k = int(rng.integers(0, 2**63))
+        assert L.gyo_get_uint64_hash(k) == R.ref_get_uint64_hash(k)
+        assert L.gyo_get_uint32_hash(k & 0xFFFFFFFF) == R.ref_get_uint32_hash(k & 0xFFFFFFFF)
+        a, c = int(rng.integers(0, 2**63)), int(rng.integers(0, 2**63))
+        assert L.gyo_machine_id_hash(a, c) == R.ref_machine_id_hash(a, c)
+        c6, s6 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        cip = bytes(rng.integers(0, 256, 16, dtype=np.uint8).tolist()) if c6 else int(rng.integers(0, 2**32))
+        sip = bytes(rng.integers(0, 256, 16, dtype=np.uint8).tolist()) if s6 else int(rng.integers(0, 2**32))
+        cb, cf = oracle.ip_bytes(cip)
+        sb, sf = oracle.ip_bytes(sip)
+        cp, sp = int(rng.integers(0, 65536)), int(rng.integers(0, 65536))
+        ino = int(rng.integers(0, 2**40))
+        for ign in (0, 1):
+            assert L.gyo_ip_port_hash(cb, cf, cp, ign) == R.ref_ip_port_hash(cb, cf, cp, ign)
+            assert L.gyo_ns_ip_port_hash(sb, sf, sp, ino, ign) == R.ref_ns_ip_port_hash(sb, sf, sp, ino, ign)
+        assert L.gyo_pair_ip_port_hash(cb, cf, cp, sb, sf, sp) == R.ref_pair_ip_port_hash(cb, cf, cp, sb, sf, sp)
+
+
+def test_topn_random(oracle, reflib):
+    L, R = oracle.lib(), reflib
+    rng = np.random.default_rng(11)
+    for n, m in [(10, 1000), (50, 3000), (10, 7), (1, 100)]:
+        v = rng.integers(0, 500, m, dtype=np.uint64)
+        o1 = np.zeros(n, dtype=np.uint64)
+        o2 = np.zeros(n, dtype=np.uint64)
+        k1 = L.gyo_topn_u64(oracle.ptr(v, oracle.u64p), m, n, oracle.ptr(o1, oracle.u64p))
+        k2 = R.ref_topn_u64(oracle.ptr(v, oracle.u64p), m, n, oracle.ptr(o2, oracle.u64p))
+        assert k1 == k2 and o1[:k1].tolist() == o2[:k2].tolist()
+
+
+def test_struct_sizes(reflib):
+    assert [reflib.ref_sizeof(i) for i in range(7)] == [24, 32, 64, 40, 16, 280, 32]
