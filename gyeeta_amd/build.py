@@ -1,0 +1,40 @@
+"""Build recipe for libgysketch.so (hipcc cross-compiles gfx950 without a GPU).  Used by __graft_entry__.build()."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libgysketch.so")
+SOURCES = ["gys_engine.hip"]
+DEPS = ["gys_engine.hip", "gys_kernels.hpp", "gys_device.hpp", "../../include/gysketch.h", "../../include/gys_tdigest_tbl.h"]
+
+
+def hipcc():
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if p and (os.path.isabs(p) and os.path.exists(p) or not os.path.isabs(p)):
+            return p
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-function", "-Wno-unused-value", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

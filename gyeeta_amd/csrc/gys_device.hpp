@@ -1,0 +1,278 @@
+// gys_device.hpp -- device-side primitives of libgysketch (gfx950 / CDNA4, wave64).
+//
+// Everything here is integer/byte work on the reference's own definitions; citations are file:line under the Gyeeta tree.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gysketch.h"
+#include "../../include/gys_tdigest_tbl.h"
+
+#define GYS_WAVE 64
+#define GYS_SEED 0xceedfeadu   // common/gy_common_inc.h:1112 (every reference key hash uses this initval)
+#define GYS_GOLDEN 0x9e3779b9u // common/jhash.h:37
+#define GYS_NOSLOT 0xFFFFFFFFu
+#define GYS_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+namespace gys {
+
+// ------------------------------------------------------------------------------------------------ jhash (common/jhash.h)
+__host__ __device__ __forceinline__ void jmix(uint32_t &a, uint32_t &b, uint32_t &c)
+{
+	// __jhash_mix common/jhash.h:23-34
+	a -= b; a -= c; a ^= (c >> 13);
+	b -= c; b -= a; b ^= (a << 8);
+	c -= a; c -= b; c ^= (b >> 13);
+	a -= b; a -= c; a ^= (c >> 12);
+	b -= c; b -= a; b ^= (a << 16);
+	c -= a; c -= b; c ^= (b >> 5);
+	a -= b; a -= c; a ^= (c >> 3);
+	b -= c; b -= a; b ^= (a << 10);
+	c -= a; c -= b; c ^= (b >> 15);
+}
+
+// jhash_3words / jhash_2words common/jhash.h:122-135
+__host__ __device__ __forceinline__ uint32_t jhash_3words(uint32_t a, uint32_t b, uint32_t c, uint32_t initval)
+{
+	a += GYS_GOLDEN;
+	b += GYS_GOLDEN;
+	c += initval;
+	jmix(a, b, c);
+	return c;
+}
+
+// get_uint64_hash common/gy_common_inc.h:1120-1123
+__host__ __device__ __forceinline__ uint32_t get_uint64_hash(uint64_t k)
+{
+	return jhash_3words((uint32_t)(k & 0xFFFFFFFFu), (uint32_t)(k >> 32), 0, GYS_SEED);
+}
+
+// jhash2 common/jhash.h:88-113 over a small register array; N is the compile-time capacity, n the live word count
+template <int N>
+__host__ __device__ __forceinline__ uint32_t jhash2(const uint32_t (&k)[N], uint32_t n, uint32_t initval)
+{
+	uint32_t a = GYS_GOLDEN, b = GYS_GOLDEN, c = initval;
+	uint32_t i = 0, len = n;
+#pragma unroll
+	for (int it = 0; it < N / 3; ++it) {
+		if (len >= 3) {
+			a += k[i];
+			b += k[i + 1];
+			c += k[i + 2];
+			jmix(a, b, c);
+			i += 3;
+			len -= 3;
+		}
+	}
+	c += n * 4;
+	if (len == 2) {
+		b += k[i + 1];
+		a += k[i];
+	} else if (len == 1) {
+		a += k[i];
+	}
+	jmix(a, b, c);
+	return c;
+}
+
+// two-word key (a 64-bit glob_id as lo,hi) through jhash2 with an arbitrary seed
+__host__ __device__ __forceinline__ uint32_t jhash2_u64(uint64_t key, uint32_t initval)
+{
+	uint32_t a = GYS_GOLDEN, b = GYS_GOLDEN, c = initval;
+	c += 8;
+	b += (uint32_t)(key >> 32);
+	a += (uint32_t)(key & 0xFFFFFFFFu);
+	jmix(a, b, c);
+	return c;
+}
+
+// ------------------------------------------------------------------------------------------------ bucket hashes
+struct HashDef {
+	int32_t nthr;
+	int32_t is_fixed_diff;
+	int32_t arg_bits, t_bits;
+	int64_t thr[14];
+	int64_t fd_min, fd_maxp1, fd_diff;
+};
+
+// common/gy_statistics.h:1674-2063 + FIXED_DIFF_HASH :1584 (PERCENT_HASH): one table, a __constant__ copy for kernels and a
+// host copy for the query path
+#define GYS_HASH_DEFS_INIT                                                                                                  \
+	{                                                                                                                   \
+		{13, 0, 64, 64, {1, 10, 30, 60, 100, 150, 200, 300, 450, 700, 1000, 3000, 15000}, 0, 0, 0},                      \
+		{12, 0, 32, 32, {1, 10, 100, 500, 1000, 5000, 25000, 50000, 100000, 300000, 1000000, 5000000}, 0, 0, 0},      \
+		{13, 0, 32, 32, {1, 10, 50, 200, 500, 1000, 3000, 6000, 10000, 15000, 25000, 60000, 150000}, 0, 0, 0},        \
+		{13, 0, 32, 32, {1, 10, 25, 50, 125, 400, 1000, 3000, 6000, 10000, 25000, 40000, 65000}, 0, 0, 0},            \
+		{12, 0, 32, 32, {10, 25, 50, 75, 100, 150, 300, 500, 800, 1000, 2000, 5000}, 0, 0, 0},                          \
+		{10, 0, 32, 32, {5, 10, 20, 40, 60, 80, 100, 140, 200, 250}, 0, 0, 0},                                          \
+		{12, 0, 32, 32, {1, 5, 10, 25, 50, 75, 100, 150, 300, 500, 1000, 3000}, 0, 0, 0},                               \
+		{11, 1, 64, 32, {9, 19, 29, 39, 49, 59, 69, 79, 89, 99, 100}, 0, 101, 10},                                      \
+	}
+
+__constant__ HashDef d_hash_defs[GYS_NUM_HASH_KINDS] = GYS_HASH_DEFS_INIT;
+static const HashDef h_hash_defs[GYS_NUM_HASH_KINDS] = GYS_HASH_DEFS_INIT;
+
+__host__ __device__ inline const HashDef &hash_def(int kind)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+	return d_hash_defs[kind];
+#else
+	return h_hash_defs[kind];
+#endif
+}
+
+// RESP_TIME_HASH::get_bucket_from_data common/gy_statistics.h:1698-1725, specialised: the mid-slot shortcut + linear walk
+// returns 1 + #{thresholds < data}; written as a branch-free compare sum (13 compares, no divergence inside a wave).
+__device__ __forceinline__ uint32_t resp_bucket(int64_t data)
+{
+	if (data < 0) return 0;
+	if (data >= 15001) return 14;
+	const int32_t d = (int32_t)data;
+	return 1u + (d > 1) + (d > 10) + (d > 30) + (d > 60) + (d > 100) + (d > 150) + (d > 200) + (d > 300) + (d > 450) + (d > 700) +
+	       (d > 1000) + (d > 3000) + (d > 15000);
+}
+
+// generic table walker for every other hash class (same algorithm, different table)
+__host__ __device__ inline uint32_t bucket_of(const HashDef &d, int64_t data)
+{
+	// GY_HISTOGRAM<T,..>::add_data(T data) narrows to T, then the hash's parameter type narrows again (int for most classes)
+	if (d.t_bits == 32) data = (int64_t)(int32_t)data;
+	if (d.arg_bits == 32) data = (int64_t)(int32_t)data;
+	const int nb = d.nthr + 2;
+	if (d.is_fixed_diff) {
+		if (data < d.fd_min) return 0;
+		if (data >= d.fd_maxp1) return (uint32_t)(nb - 1);
+		return (uint32_t)(1 + (data - d.fd_min) / d.fd_diff);
+	}
+	if (data < 0) return 0;
+	if (data >= d.thr[d.nthr - 1] + 1) return (uint32_t)(nb - 1);
+	uint32_t b = 1;
+	for (int i = 0; i < d.nthr; ++i) b += (data > d.thr[i]);
+	return b;
+}
+
+// get_bucket_max_threshold<HashClass,T> common/gy_statistics.h:500-515
+__host__ __device__ inline int64_t bucket_max_threshold(const HashDef &d, uint32_t id)
+{
+	const uint32_t nb = (uint32_t)d.nthr + 2;
+	const int64_t min_value = d.is_fixed_diff ? d.fd_min : 0;
+	const int64_t max_value = d.is_fixed_diff ? d.fd_maxp1 : d.thr[d.nthr - 1] + 1;
+	if (id == 0) return d.t_bits == 32 ? (int64_t)(int32_t)(min_value - 1) : min_value - 1;
+	if (id >= nb - 1) {
+		const int64_t maxt = d.t_bits == 64 ? INT64_MAX : INT32_MAX;
+		const int64_t lesst = max_value >= INT32_MAX ? INT64_MAX : (max_value > (INT16_MAX >> 1) ? INT32_MAX : INT16_MAX);
+		return lesst < maxt ? lesst : maxt;
+	}
+	return d.thr[id - 1];
+}
+
+// GY_HISTOGRAM::get_percentiles common/gy_statistics.h:753-790 for ONE percentile on a 256-byte record
+__host__ __device__ inline void hist_percentile(const HashDef &d, const gys_hist_rec &h, float pct, int64_t *data_value, int64_t *psum,
+						uint64_t *pcount)
+{
+	const int nb = d.nthr + 2;
+	const float multiplier = (float)((double)pct / 100.0); // float/double -> double, stored to a float (:757)
+	const float prod = (float)h.total_count * multiplier;  // size_t * float (:758); plain mul, nothing to contract
+	const uint64_t ncutoff = (uint64_t)prod;
+	uint64_t total = 0;
+	int64_t sum = 0;
+	int i;
+	for (i = 0; i < nb; ++i) {
+		total += h.stats[i].count;
+		sum += h.stats[i].sum;
+		if (total >= ncutoff) break;
+	}
+	*pcount = total;
+	*psum = sum;
+	if (i < nb)
+		*data_value = bucket_max_threshold(d, (uint32_t)i);
+	else
+		*data_value = bucket_max_threshold(d, h.total_count > 0 ? (uint32_t)nb : 0u); // :779-789
+}
+
+// ------------------------------------------------------------------------------------------------ open-addressing key table
+struct DevTable {
+	uint64_t *keys; // GYS_EMPTY_KEY = free
+	uint32_t *vals;
+	uint32_t mask;
+};
+
+// probe hash = the reference's own 64-bit-id hash (get_uint64_hash) so bucket choice mirrors listen_tbl_ lookups
+// (server/gy_mconnhdlr.cc:11180-11183)
+__device__ __forceinline__ uint32_t tbl_lookup(const DevTable &t, uint64_t key)
+{
+	uint32_t h = get_uint64_hash(key) & t.mask;
+	for (uint32_t probes = 0; probes <= t.mask; ++probes) {
+		const uint64_t k = t.keys[h];
+		if (k == key) return t.vals[h];
+		if (k == GYS_EMPTY_KEY) return GYS_NOSLOT;
+		h = (h + 1) & t.mask;
+	}
+	return GYS_NOSLOT;
+}
+
+// listener tuple key: (host_slot:16 | netns:32 | port:16).  The reference looks a response event's listener up per host by
+// NS_IP_PORT ignoring the IP (ANY_IP, common/gy_inet_inc.h:160-172 used at common/gy_socket_stat.cc:1671).
+__host__ __device__ __forceinline__ uint64_t listener_key(uint32_t host_slot, uint32_t netns, uint16_t port)
+{
+	return ((uint64_t)host_slot << 48) | ((uint64_t)netns << 16) | (uint64_t)port;
+}
+
+// ------------------------------------------------------------------------------------------------ sketches
+// 64-bit sketch hash = (jhash2(seed 0xceedfead) << 32) | jhash2(seed 0x9e3779b9)   
+template <int N>
+__host__ __device__ __forceinline__ uint64_t hash64(const uint32_t (&w)[N], uint32_t n)
+{
+	return ((uint64_t)jhash2<N>(w, n, GYS_SEED) << 32) | (uint64_t)jhash2<N>(w, n, GYS_GOLDEN);
+}
+
+__host__ __device__ __forceinline__ void hll_idx_rank(uint64_t h, int p, uint32_t *idx, uint32_t *rank)
+{
+	const uint64_t w = h << p;
+	*idx = (uint32_t)(h >> (64 - p));
+#ifdef __HIP_DEVICE_COMPILE__
+	*rank = w ? (uint32_t)__clzll((long long)w) + 1u : (uint32_t)(64 - p + 1);
+#else
+	*rank = w ? (uint32_t)__builtin_clzll(w) + 1u : (uint32_t)(64 - p + 1);
+#endif
+}
+
+// PAIR_IP_PORT::get_hash key bytes (common/gy_inet_inc.h:225-247) from two IPv4-or-IPv6 endpoints:
+// [cli inaddr][cli port LE, 00 00][ser inaddr][ser port LE, 00 00]; inaddr = 4 bytes if ip32_be != 0 else the 16 ip128 bytes
+// (GY_IP_ADDR::get_as_inaddr common/gy_common_inc.h:10950-10959).  Returns the word count (4, 7 or 10).
+__host__ __device__ __forceinline__ uint32_t pair_words(uint32_t cip32, const uint32_t cip128[4], uint16_t cport, uint32_t sip32,
+							const uint32_t sip128[4], uint16_t sport, uint32_t (&w)[10])
+{
+	uint32_t n = 0;
+	if (cip32) {
+		w[n++] = cip32;
+	} else {
+		w[n++] = cip128[0]; w[n++] = cip128[1]; w[n++] = cip128[2]; w[n++] = cip128[3];
+	}
+	w[n++] = (uint32_t)cport;
+	if (sip32) {
+		w[n++] = sip32;
+	} else {
+		w[n++] = sip128[0]; w[n++] = sip128[1]; w[n++] = sip128[2]; w[n++] = sip128[3];
+	}
+	w[n++] = (uint32_t)sport;
+	for (uint32_t i = n; i < 10; ++i) w[i] = 0;
+	return n;
+}
+
+// ------------------------------------------------------------------------------------------------ t-digest cluster thresholds
+__constant__ uint64_t c_td_bnd[GYS_TDIGEST_NB + 1] = GYS_TDIGEST_BND_INIT;
+static const uint64_t h_td_bnd[GYS_TDIGEST_NB + 1] = GYS_TDIGEST_BND_INIT;
+
+// cluster(mid2) = #{ j in 1..NB-1 : BND[j] * twoN <= mid2 * 2^32 } = #{ j : mid2 >= T_j },  T_j = ceil(BND[j] * twoN / 2^32)
+__device__ __forceinline__ uint64_t td_threshold(uint64_t bnd, uint64_t twoN)
+{
+	const uint64_t lo = bnd * twoN;
+	const uint64_t hi = __umul64hi(bnd, twoN);
+	uint64_t t = (hi << 32) | (lo >> 32);
+	if (lo & 0xFFFFFFFFull) t += 1;
+	return t;
+}
+
+} // namespace gys

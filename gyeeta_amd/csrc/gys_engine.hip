@@ -1,0 +1,1301 @@
+// gys_engine.hip -- host side of libgysketch.so: context, registries, the C ABI of include/gysketch.h.
+//
+// C++17 host code + hand-written HIP kernels (gys_kernels.hpp) for gfx950.  There is no CPU fallback anywhere in this library:
+// every ingest/query path runs on the GPU or fails with GYS_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "gys_kernels.hpp"
+
+using namespace gys;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+#define HIPCHK(expr)                                                                                       \
+	do {                                                                                               \
+		hipError_t e_ = (expr);                                                                    \
+		if (e_ != hipSuccess) {                                                                    \
+			set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return GYS_ERR_HIP;                                                                \
+		}                                                                                          \
+	} while (0)
+
+struct MachId {
+	uint64_t first, second;
+	bool operator==(const MachId &o) const { return first == o.first && second == o.second; }
+};
+struct MachIdHash {
+	// GY_MACHINE_ID::get_hash common/gy_sys_hardware.h:82-85
+	size_t operator()(const MachId &m) const
+	{
+		uint32_t w[4];
+		memcpy(w, &m.first, 8);
+		memcpy(w + 2, &m.second, 8);
+		uint32_t k[6] = {w[0], w[1], w[2], w[3], 0, 0};
+		return jhash2<6>(k, 4, GYS_SEED);
+	}
+};
+
+inline MachId to_machid(const uint8_t id[16])
+{
+	MachId m;
+	memcpy(&m.first, id, 8);
+	memcpy(&m.second, id + 8, 8);
+	return m;
+}
+
+struct ProfEntry {
+	double total_ms = 0;
+	uint64_t launches = 0;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+struct ArenaLayout {
+	uint64_t off_hll8, off_u32, n_u32, off_i64sum, n_i64sum, off_i64max, n_i64max, total;
+	uint64_t u32_cms, u32_cluster;        // element offsets inside the u32 section
+	uint64_t i64_cms, i64_ghist;          // element offsets inside the i64 SUM section
+};
+
+ArenaLayout arena_layout(uint32_t max_clusters)
+{
+	ArenaLayout a;
+	a.off_hll8 = 0;
+	a.off_u32 = align_up((uint64_t)1 << GYS_HLL_P, 256);
+	a.u32_cms = 0;
+	a.u32_cluster = (uint64_t)GYS_CMS_D * GYS_CMS_W;
+	a.n_u32 = a.u32_cluster + (uint64_t)max_clusters * 12;
+	a.off_i64sum = align_up(a.off_u32 + a.n_u32 * 4, 256);
+	a.i64_cms = 0;
+	a.i64_ghist = (uint64_t)GYS_CMS_D * GYS_CMS_W;
+	a.n_i64sum = a.i64_ghist + 32;
+	a.off_i64max = align_up(a.off_i64sum + a.n_i64sum * 8, 256);
+	a.n_i64max = 8;
+	a.total = align_up(a.off_i64max + a.n_i64max * 8, 256);
+	return a;
+}
+
+} // namespace
+
+struct gys_ctx {
+	gys_config cfg{};
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	int ncu = 256;
+
+	// registries (host)
+	std::unordered_map<MachId, uint32_t, MachIdHash> host_map;
+	std::vector<MachId> hosts;
+	std::vector<uint32_t> host_cluster_h;
+	std::unordered_map<std::string, uint32_t> cluster_map;
+	std::vector<std::string> cluster_names;
+	std::unordered_map<uint64_t, uint32_t> gid_map_h; // glob_id -> slot (host mirror for single-key queries)
+	uint32_t nsvc = 0;
+
+	// device state
+	DevTable lk_tbl{}, gid_tbl{};
+	uint64_t *svc_gid = nullptr;
+	gys_hist_rec *hist_win = nullptr, *hist_all = nullptr;
+	uint32_t *bitmap = nullptr;
+	int64_t *td_sum = nullptr;
+	uint32_t *td_cnt = nullptr;
+	int32_t *td_minmax = nullptr;
+	uint32_t *batch_cnt = nullptr, *batch_off = nullptr, *scan_block_sums = nullptr;
+	uint64_t *ev_kv = nullptr;
+	uint32_t *staged = nullptr;
+	uint32_t *huge_list = nullptr, *huge_count = nullptr, *huge_scratch = nullptr;
+	int huge_blocks = 0;
+	uint32_t *hll32 = nullptr;
+	unsigned long long *svc_ctr = nullptr;
+	uint8_t *svc_state = nullptr;
+	uint8_t *svc_hll = nullptr;
+	int32_t *host_summ_win = nullptr, *host_summ_last = nullptr;
+	gys_host_state *host_state = nullptr;
+	uint32_t *host_state_epoch = nullptr, *host_cluster = nullptr;
+	uint64_t *counters = nullptr;
+	uint32_t *misc = nullptr; // [0] table insert failures, [1] topn count
+	gys_resp_seg *segs_dev = nullptr;
+	uint32_t segs_cap = 0;
+
+	// reduce arena + last-window results
+	uint8_t *arena = nullptr;
+	bool own_arena = false;
+	ArenaLayout al{};
+	uint8_t *last = nullptr; // copy of the reduced arena of the last finished window (queries read this)
+	uint32_t epoch = 1;      // current window number (0 = never)
+	bool prepared = false;
+	bool have_last = false;
+
+	// staging for host-buffer ingest
+	uint8_t *dev_staging = nullptr;
+	uint64_t dev_staging_bytes = 0;
+	uint32_t *dev_offsets = nullptr;
+	uint32_t dev_offsets_cap = 0;
+	uint32_t *topn_slot = nullptr;
+	uint64_t *topn_metric = nullptr;
+	float *dev_pcts = nullptr;
+	float *zipf_cdf = nullptr;
+	uint32_t zipf_n = 0, zipf_milli = 0;
+
+	bool profile = false;
+	std::map<std::string, ProfEntry> prof;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ launch + profiling
+struct ProfScope {
+	gys_ctx *c;
+	ProfEntry *e = nullptr;
+	hipEvent_t a = nullptr, b = nullptr;
+	ProfScope(gys_ctx *ctx, const char *name) : c(ctx)
+	{
+		if (!c->profile) return;
+		e = &c->prof[name];
+		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+			e = nullptr;
+			return;
+		}
+		hipEventRecord(a, c->stream);
+	}
+	~ProfScope()
+	{
+		if (!e) return;
+		hipEventRecord(b, c->stream);
+		e->pending.emplace_back(a, b);
+		e->launches++;
+	}
+};
+
+void prof_resolve(gys_ctx *c)
+{
+	for (auto &kv : c->prof) {
+		for (auto &pr : kv.second.pending) {
+			float ms = 0;
+			hipEventSynchronize(pr.second);
+			if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.total_ms += ms;
+			hipEventDestroy(pr.first);
+			hipEventDestroy(pr.second);
+		}
+		kv.second.pending.clear();
+	}
+}
+
+inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap)
+{
+	uint64_t g = (n + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > cap) g = cap;
+	return (uint32_t)g;
+}
+
+template <typename T>
+int dev_alloc(T **p, uint64_t count, bool zero = true)
+{
+	if (count == 0) count = 1;
+	HIPCHK(hipMalloc((void **)p, count * sizeof(T)));
+	if (zero) HIPCHK(hipMemset(*p, 0, count * sizeof(T)));
+	return GYS_OK;
+}
+
+int ensure_staging(gys_ctx *c, uint64_t bytes, uint32_t nrec)
+{
+	if (bytes > c->dev_staging_bytes) {
+		if (c->dev_staging) {
+			HIPCHK(hipStreamSynchronize(c->stream));
+			HIPCHK(hipFree(c->dev_staging));
+		}
+		c->dev_staging_bytes = align_up(std::max<uint64_t>(bytes, 1u << 20), 4096);
+		HIPCHK(hipMalloc((void **)&c->dev_staging, c->dev_staging_bytes));
+	}
+	if (nrec > c->dev_offsets_cap) {
+		if (c->dev_offsets) {
+			HIPCHK(hipStreamSynchronize(c->stream));
+			HIPCHK(hipFree(c->dev_offsets));
+		}
+		c->dev_offsets_cap = std::max<uint32_t>(nrec, 4096);
+		HIPCHK(hipMalloc((void **)&c->dev_offsets, (uint64_t)c->dev_offsets_cap * 4));
+	}
+	return GYS_OK;
+}
+
+int lookup_host(gys_ctx *c, const uint8_t machine_id[16], uint32_t *slot)
+{
+	auto it = c->host_map.find(to_machid(machine_id));
+	if (it == c->host_map.end()) {
+		set_err("unknown machine id");
+		return GYS_ERR_NOTFOUND;
+	}
+	*slot = it->second;
+	return GYS_OK;
+}
+
+int check_owner(gys_ctx *c, const uint8_t machine_id[16])
+{
+	if (c->cfg.nranks > 1 && gys_shard_of(machine_id, c->cfg.nranks) != c->cfg.rank) {
+		set_err("host belongs to rank %u", gys_shard_of(machine_id, c->cfg.nranks));
+		return GYS_ERR_NOT_OWNER;
+	}
+	return GYS_OK;
+}
+
+uint32_t next_pow2(uint64_t v)
+{
+	uint64_t p = 1;
+	while (p < v) p <<= 1;
+	return (uint32_t)p;
+}
+
+// resp pipeline on a device-resident batch
+int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, const void *d_ev, uint64_t n)
+{
+	if (n == 0) return GYS_OK;
+	if (nsegs == 0 || !segs_host || segs_host[0].first_event != 0) {
+		set_err("resp batch needs >= 1 segment starting at event 0");
+		return GYS_ERR_INVAL;
+	}
+	const bool td = c->cfg.enable_tdigest != 0;
+	if (td && n > c->cfg.max_batch_events) {
+		set_err("batch of %llu events exceeds max_batch_events %llu", (unsigned long long)n, (unsigned long long)c->cfg.max_batch_events);
+		return GYS_ERR_NOMEM;
+	}
+	if (n >= (1ull << 32)) {
+		set_err("batch too large (u32 offsets)");
+		return GYS_ERR_INVAL;
+	}
+	for (uint32_t s = 0; s < nsegs; ++s) {
+		if (segs_host[s].host_slot >= c->hosts.size() || (s && segs_host[s].first_event < segs_host[s - 1].first_event)) {
+			set_err("bad resp segment %u", s);
+			return GYS_ERR_INVAL;
+		}
+	}
+	if (nsegs > c->segs_cap) {
+		if (c->segs_dev) {
+			HIPCHK(hipStreamSynchronize(c->stream));
+			HIPCHK(hipFree(c->segs_dev));
+		}
+		c->segs_cap = std::max<uint32_t>(nsegs, 1024);
+		HIPCHK(hipMalloc((void **)&c->segs_dev, (uint64_t)c->segs_cap * sizeof(gys_resp_seg)));
+	}
+	HIPCHK(hipMemcpyAsync(c->segs_dev, segs_host, (uint64_t)nsegs * sizeof(gys_resp_seg), hipMemcpyHostToDevice, c->stream));
+
+	int64_t *i64sum = (int64_t *)(c->arena + c->al.off_i64sum);
+	RespP1 p{};
+	p.ev = (const uint64_t *)d_ev;
+	p.n = n;
+	p.segs = c->segs_dev;
+	p.nsegs = nsegs;
+	p.lk = c->lk_tbl;
+	p.svc_gid = c->svc_gid;
+	p.hist_win = c->hist_win;
+	p.bitmap = c->bitmap;
+	p.hll32 = c->hll32;
+	p.cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
+	p.ghist = i64sum + c->al.i64_ghist;
+	p.gmax = (int64_t *)(c->arena + c->al.off_i64max);
+	p.batch_cnt = td ? c->batch_cnt : nullptr;
+	p.ev_kv = td ? c->ev_kv : nullptr;
+	p.counters = c->counters;
+	p.svc_hll = c->svc_hll;
+	p.svc_hll_p = c->cfg.svc_hll_p;
+	{
+		ProfScope ps(c, "resp_pass1");
+		hipLaunchKernelGGL(k_resp_pass1, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
+	}
+	HIPCHK(hipGetLastError());
+	if (!td) return GYS_OK;
+
+	const uint32_t nsvc = c->nsvc;
+	if (nsvc == 0) return GYS_OK;
+	const uint32_t nblk = (nsvc + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE;
+	{
+		ProfScope ps(c, "scan");
+		HIPCHK(hipMemsetAsync(c->huge_count, 0, 4, c->stream));
+		hipLaunchKernelGGL(k_scan_block_sums, dim3(nblk), dim3(256), 0, c->stream, c->batch_cnt, nsvc, c->scan_block_sums);
+		hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, c->stream, c->scan_block_sums, nblk);
+		hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, c->stream, c->batch_cnt, nsvc, c->scan_block_sums, c->batch_off, c->huge_list,
+				   c->huge_count);
+	}
+	{
+		ProfScope ps(c, "scatter");
+		hipLaunchKernelGGL(k_resp_scatter, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->ev_kv, n, c->batch_off, c->staged);
+	}
+	DigestP d{};
+	d.td_sum = c->td_sum;
+	d.td_cnt = c->td_cnt;
+	d.td_minmax = c->td_minmax;
+	d.batch_cnt = c->batch_cnt;
+	d.off_end = c->batch_off;
+	d.staged = c->staged;
+	d.nsvc = nsvc;
+	{
+		ProfScope ps(c, "digest_small");
+		hipLaunchKernelGGL(k_digest_small, dim3(std::min<uint32_t>(nsvc, (uint32_t)c->ncu * 16)), dim3(64), 0, c->stream, d);
+	}
+	{
+		ProfScope ps(c, "digest_huge");
+		HugeP h{};
+		h.d = d;
+		h.huge_list = c->huge_list;
+		h.huge_count = c->huge_count;
+		h.scratch = c->huge_scratch;
+		hipLaunchKernelGGL(k_digest_huge, dim3(c->huge_blocks), dim3(256), 0, c->stream, h);
+	}
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+// walk a variable-stride batch on the host (what COMM validate + the reference loops do) and produce record offsets
+template <typename SizeFn>
+int walk_batch(const uint8_t *batch, uint32_t n, const uint8_t *pend, uint32_t fixed, SizeFn elem_size, std::vector<uint32_t> &offs)
+{
+	const uint8_t *p = batch;
+	offs.clear();
+	offs.reserve(n);
+	for (uint32_t i = 0; i < n && p < pend; ++i) {
+		if ((size_t)(pend - p) < fixed) {
+			set_err("truncated record %u", i);
+			return GYS_ERR_INVAL;
+		}
+		const uint32_t sz = elem_size(p);
+		if ((sz & 7u) || p + sz > pend) {
+			set_err("record %u: bad element size %u", i, sz);
+			return GYS_ERR_INVAL;
+		}
+		offs.push_back((uint32_t)(p - batch));
+		p += sz;
+	}
+	return GYS_OK;
+}
+
+int run_conn(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, uint32_t n)
+{
+	if (!n) return GYS_OK;
+	ConnP p{};
+	p.batch = d_batch;
+	p.offsets = d_offsets;
+	p.n = n;
+	p.gid = c->gid_tbl;
+	p.hll32 = c->hll32;
+	p.cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
+	p.cms64 = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_cms;
+	p.svc_ctr = c->svc_ctr;
+	p.counters = c->counters;
+	ProfScope ps(c, "conn");
+	hipLaunchKernelGGL(k_conn_ingest, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+int run_lstate(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, const uint32_t *d_host_slot, uint32_t single_host, uint32_t n)
+{
+	if (!n) return GYS_OK;
+	LStateP p{};
+	p.batch = d_batch;
+	p.offsets = d_offsets;
+	p.host_slot = d_host_slot;
+	p.single_host = single_host;
+	p.n = n;
+	p.gid = c->gid_tbl;
+	p.svc_state = c->svc_state;
+	p.host_summ = c->host_summ_win;
+	p.epoch = c->epoch;
+	p.counters = c->counters;
+	ProfScope ps(c, "lstate");
+	hipLaunchKernelGGL(k_lstate_ingest, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+} // namespace
+
+// ==================================================================================================== C ABI
+extern "C" {
+
+uint32_t gys_abi_version(void) { return GYS_ABI_VERSION; }
+const char *gys_last_error(void) { return g_err; }
+
+uint32_t gys_machine_id_hash(const uint8_t machine_id[16]) { return (uint32_t)MachIdHash()(to_machid(machine_id)); }
+uint32_t gys_shard_of(const uint8_t machine_id[16], uint32_t nshards) { return nshards ? gys_machine_id_hash(machine_id) % nshards : 0; }
+
+uint64_t gys_reduce_arena_bytes(const gys_config *cfg) { return arena_layout(cfg ? cfg->max_clusters : 1).total; }
+
+int gys_create(const gys_config *cfg, gys_ctx **out)
+{
+	if (!cfg || !out || cfg->struct_size != sizeof(gys_config)) {
+		set_err("bad config (struct_size %u, expected %zu)", cfg ? cfg->struct_size : 0, sizeof(gys_config));
+		return GYS_ERR_INVAL;
+	}
+	if (!cfg->max_hosts || !cfg->max_services || cfg->max_hosts > 65534 || !cfg->max_clusters || cfg->nranks == 0 || cfg->rank >= cfg->nranks ||
+	    (cfg->svc_hll_p && (cfg->svc_hll_p < 4 || cfg->svc_hll_p > 10))) {
+		set_err("bad config values");
+		return GYS_ERR_INVAL;
+	}
+	int ndev = 0;
+	HIPCHK(hipGetDeviceCount(&ndev)); // fails loudly when there is no GPU: there is no CPU path
+	if (ndev <= 0) {
+		set_err("no HIP device");
+		return GYS_ERR_HIP;
+	}
+	gys_ctx *c = new gys_ctx();
+	c->cfg = *cfg;
+	if (cfg->device >= 0) {
+		c->device = cfg->device;
+		HIPCHK(hipSetDevice(c->device));
+	} else {
+		HIPCHK(hipGetDevice(&c->device));
+	}
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, c->device));
+	c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	if (cfg->stream) {
+		c->stream = (hipStream_t)cfg->stream;
+	} else {
+		HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		c->own_stream = true;
+	}
+	const uint64_t S = cfg->max_services, H = cfg->max_hosts;
+	const uint32_t cap = next_pow2(S * 2);
+	int rc;
+#define ALLOC(ptr, count)                        \
+	if ((rc = dev_alloc(&ptr, (count))) != GYS_OK) { \
+		gys_destroy(c);                          \
+		return rc;                               \
+	}
+	ALLOC(c->lk_tbl.keys, cap);
+	ALLOC(c->lk_tbl.vals, cap);
+	ALLOC(c->gid_tbl.keys, cap);
+	ALLOC(c->gid_tbl.vals, cap);
+	c->lk_tbl.mask = c->gid_tbl.mask = cap - 1;
+	HIPCHK(hipMemset(c->lk_tbl.keys, 0xFF, (uint64_t)cap * 8));
+	HIPCHK(hipMemset(c->gid_tbl.keys, 0xFF, (uint64_t)cap * 8));
+	ALLOC(c->svc_gid, S);
+	ALLOC(c->hist_win, S);
+	ALLOC(c->hist_all, S);
+	ALLOC(c->bitmap, S * 16);
+	ALLOC(c->svc_ctr, S * 4);
+	ALLOC(c->svc_state, S * 96);
+	ALLOC(c->hll32, (uint64_t)1 << GYS_HLL_P);
+	ALLOC(c->host_summ_win, H * 16);
+	ALLOC(c->host_summ_last, H * 16);
+	ALLOC(c->host_state, H);
+	ALLOC(c->host_state_epoch, H);
+	ALLOC(c->host_cluster, H);
+	ALLOC(c->counters, 16);
+	ALLOC(c->misc, 16);
+	ALLOC(c->topn_slot, S < 65536 ? S : 65536);
+	ALLOC(c->topn_metric, S < 65536 ? S : 65536);
+	ALLOC(c->dev_pcts, 64);
+	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
+	if (cfg->enable_tdigest) {
+		const uint64_t B = cfg->max_batch_events ? cfg->max_batch_events : 1;
+		ALLOC(c->td_sum, S * GYS_TD_NB);
+		ALLOC(c->td_cnt, S * GYS_TD_NB);
+		ALLOC(c->td_minmax, S * 2);
+		ALLOC(c->batch_cnt, align_up(S, 16));
+		ALLOC(c->batch_off, align_up(S, 16));
+		ALLOC(c->scan_block_sums, (S + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE + 1);
+		ALLOC(c->ev_kv, B);
+		ALLOC(c->staged, B);
+		ALLOC(c->huge_list, std::min<uint64_t>(S, B / GYS_SMALL_MAX + 1));
+		ALLOC(c->huge_count, 1);
+		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_SMALL_MAX + 1));
+		if (c->huge_blocks < 1) c->huge_blocks = 1;
+		ALLOC(c->huge_scratch, (uint64_t)c->huge_blocks * GYS_HUGE_BINS);
+		hipLaunchKernelGGL(k_minmax_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->td_minmax, S);
+	}
+#undef ALLOC
+	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_win, (uint64_t)0, S, (int64_t)INT64_MIN);
+	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_all, (uint64_t)0, S, (int64_t)INT64_MIN);
+	c->al = arena_layout(cfg->max_clusters);
+	if (cfg->reduce_arena) {
+		if (cfg->reduce_arena_bytes < c->al.total) {
+			set_err("reduce_arena too small: %llu < %llu", (unsigned long long)cfg->reduce_arena_bytes, (unsigned long long)c->al.total);
+			gys_destroy(c);
+			return GYS_ERR_INVAL;
+		}
+		c->arena = (uint8_t *)cfg->reduce_arena;
+	} else {
+		HIPCHK(hipMalloc((void **)&c->arena, c->al.total));
+		c->own_arena = true;
+	}
+	HIPCHK(hipMalloc((void **)&c->last, c->al.total));
+	HIPCHK(hipMemsetAsync(c->arena, 0, c->al.total, c->stream));
+	HIPCHK(hipMemsetAsync(c->last, 0, c->al.total, c->stream));
+	{
+		const int64_t mn = INT64_MIN;
+		HIPCHK(hipMemcpyAsync(c->arena + c->al.off_i64max, &mn, 8, hipMemcpyHostToDevice, c->stream));
+	}
+	HIPCHK(hipStreamSynchronize(c->stream));
+	*out = c;
+	return GYS_OK;
+}
+
+void gys_destroy(gys_ctx *c)
+{
+	if (!c) return;
+	if (c->stream) hipStreamSynchronize(c->stream);
+	prof_resolve(c);
+	void *ptrs[] = {c->lk_tbl.keys, c->lk_tbl.vals, c->gid_tbl.keys, c->gid_tbl.vals, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
+			c->td_cnt, c->td_minmax, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_list, c->huge_count,
+			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
+			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->segs_dev, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
+			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->own_arena ? c->arena : nullptr};
+	for (void *p : ptrs)
+		if (p) hipFree(p);
+	if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int gys_sync(gys_ctx *c)
+{
+	if (!c) return GYS_ERR_INVAL;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ registration
+int gys_register_cluster(gys_ctx *c, const char *cluster_name, uint32_t *cluster_idx)
+{
+	if (!c || !cluster_name) return GYS_ERR_INVAL;
+	auto it = c->cluster_map.find(cluster_name);
+	if (it == c->cluster_map.end()) {
+		if (c->cluster_names.size() >= c->cfg.max_clusters) {
+			set_err("max_clusters exhausted");
+			return GYS_ERR_NOMEM;
+		}
+		const uint32_t idx = (uint32_t)c->cluster_names.size();
+		c->cluster_names.emplace_back(cluster_name);
+		it = c->cluster_map.emplace(cluster_name, idx).first;
+	}
+	if (cluster_idx) *cluster_idx = it->second;
+	return GYS_OK;
+}
+
+int gys_register_host(gys_ctx *c, const uint8_t machine_id[16], const char *cluster_name, uint32_t *host_slot)
+{
+	if (!c || !machine_id) return GYS_ERR_INVAL;
+	int rc = check_owner(c, machine_id);
+	if (rc) return rc;
+	uint32_t cidx = 0;
+	rc = gys_register_cluster(c, cluster_name ? cluster_name : "", &cidx);
+	if (rc) return rc;
+	const MachId m = to_machid(machine_id);
+	auto it = c->host_map.find(m);
+	uint32_t slot;
+	if (it != c->host_map.end()) {
+		slot = it->second;
+	} else {
+		if (c->hosts.size() >= c->cfg.max_hosts) {
+			set_err("max_hosts exhausted");
+			return GYS_ERR_NOMEM;
+		}
+		slot = (uint32_t)c->hosts.size();
+		c->hosts.push_back(m);
+		c->host_cluster_h.push_back(cidx);
+		c->host_map.emplace(m, slot);
+	}
+	c->host_cluster_h[slot] = cidx;
+	HIPCHK(hipMemcpyAsync(c->host_cluster + slot, &cidx, 4, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (host_slot) *host_slot = slot;
+	return GYS_OK;
+}
+
+int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_listener_info *arr, uint32_t n, uint32_t *first_slot)
+{
+	if (!c || !machine_id || (!arr && n)) return GYS_ERR_INVAL;
+	uint32_t host;
+	int rc = lookup_host(c, machine_id, &host);
+	if (rc) return rc;
+	if ((uint64_t)c->nsvc + n > c->cfg.max_services) {
+		set_err("max_services exhausted");
+		return GYS_ERR_NOMEM;
+	}
+	if (first_slot) *first_slot = c->nsvc;
+	if (!n) return GYS_OK;
+	std::vector<uint64_t> keys(2 * (size_t)n);
+	for (uint32_t i = 0; i < n; ++i) {
+		if (arr[i].glob_id == GYS_EMPTY_KEY) {
+			set_err("glob_id ~0 is reserved");
+			return GYS_ERR_INVAL;
+		}
+		keys[i] = arr[i].glob_id;
+		keys[n + i] = listener_key(host, arr[i].netns, arr[i].port);
+	}
+	rc = ensure_staging(c, keys.size() * 8, 0);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(c->dev_staging, keys.data(), keys.size() * 8, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(c->svc_gid + c->nsvc, c->dev_staging, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(c->misc, 0, 4, c->stream));
+	hipLaunchKernelGGL(k_table_insert, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->gid_tbl, (const uint64_t *)c->dev_staging, c->nsvc, n, c->misc);
+	hipLaunchKernelGGL(k_table_insert, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->lk_tbl, (const uint64_t *)c->dev_staging + n, c->nsvc, n,
+			   c->misc);
+	uint32_t nfail = 0;
+	HIPCHK(hipMemcpyAsync(&nfail, c->misc, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (nfail) {
+		set_err("key table full (%u inserts failed)", nfail);
+		return GYS_ERR_NOMEM;
+	}
+	for (uint32_t i = 0; i < n; ++i) c->gid_map_h[arr[i].glob_id] = c->nsvc + i;
+	c->nsvc += n;
+	return GYS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ingest
+int gys_ingest_resp_events_dev(gys_ctx *c, const gys_resp_seg *segs, uint32_t nsegs, const void *d_ev24, uint64_t nevents)
+{
+	if (!c || (!d_ev24 && nevents)) return GYS_ERR_INVAL;
+	return run_resp_batch(c, segs, nsegs, d_ev24, nevents);
+}
+
+int gys_ingest_resp_events(gys_ctx *c, const uint8_t machine_id[16], const void *ev24, uint32_t nevents)
+{
+	if (!c || !machine_id || (!ev24 && nevents)) return GYS_ERR_INVAL;
+	uint32_t host;
+	int rc = lookup_host(c, machine_id, &host);
+	if (rc) return rc;
+	if (!nevents) return GYS_OK;
+	rc = ensure_staging(c, (uint64_t)nevents * 24, 0);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(c->dev_staging, ev24, (uint64_t)nevents * 24, hipMemcpyHostToDevice, c->stream));
+	gys_resp_seg seg{host, 0, 0};
+	return run_resp_batch(c, &seg, 1, c->dev_staging, nevents);
+}
+
+int gys_ingest_tcp_conn_dev(gys_ctx *c, const void *d_batch, const uint32_t *d_offsets, uint32_t nconns)
+{
+	if (!c || ((!d_batch || !d_offsets) && nconns)) return GYS_ERR_INVAL;
+	return run_conn(c, (const uint8_t *)d_batch, d_offsets, nconns);
+}
+
+int gys_ingest_tcp_conn(gys_ctx *c, const uint8_t machine_id[16], const void *batch, uint32_t nconns, const void *pend)
+{
+	if (!c || !machine_id || (!batch && nconns) || ((uintptr_t)batch & 7u)) return GYS_ERR_INVAL;
+	uint32_t host;
+	int rc = lookup_host(c, machine_id, &host);
+	if (rc) return rc;
+	if (!nconns) return GYS_OK;
+	std::vector<uint32_t> offs;
+	// TCP_CONN_NOTIFY::get_elem_size common/gy_comm_proto.h:1721-1724
+	rc = walk_batch((const uint8_t *)batch, nconns, (const uint8_t *)pend, 280, [](const uint8_t *p) {
+		uint16_t cl;
+		memcpy(&cl, p + 272, 2);
+		return (uint32_t)(280u + cl + p[279]);
+	}, offs);
+	if (rc) return rc;
+	if (offs.empty()) return GYS_OK;
+	const uint64_t bytes = (const uint8_t *)pend - (const uint8_t *)batch;
+	rc = ensure_staging(c, bytes, (uint32_t)offs.size());
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(c->dev_staging, batch, bytes, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(c->dev_offsets, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, c->stream));
+	rc = run_conn(c, c->dev_staging, c->dev_offsets, (uint32_t)offs.size());
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(c->stream)); // offs is a stack-owned pageable buffer
+	return GYS_OK;
+}
+
+int gys_ingest_listener_state_dev(gys_ctx *c, const void *d_batch, const uint32_t *d_offsets, const uint32_t *d_host_slot, uint32_t nrecs)
+{
+	if (!c || ((!d_batch || !d_offsets || !d_host_slot) && nrecs)) return GYS_ERR_INVAL;
+	return run_lstate(c, (const uint8_t *)d_batch, d_offsets, d_host_slot, 0, nrecs);
+}
+
+int gys_ingest_listener_state(gys_ctx *c, const uint8_t machine_id[16], const void *batch, uint32_t nrecs, const void *pend)
+{
+	if (!c || !machine_id || (!batch && nrecs) || ((uintptr_t)batch & 7u)) return GYS_ERR_INVAL;
+	uint32_t host;
+	int rc = lookup_host(c, machine_id, &host);
+	if (rc) return rc;
+	if (!nrecs) return GYS_OK;
+	std::vector<uint32_t> offs;
+	// LISTENER_STATE_NOTIFY::get_elem_size common/gy_comm_proto.h:2229-2232
+	rc = walk_batch((const uint8_t *)batch, nrecs, (const uint8_t *)pend, 88, [](const uint8_t *p) { return (uint32_t)(88u + p[85] + p[86]); }, offs);
+	if (rc) return rc;
+	if (offs.empty()) return GYS_OK;
+	const uint64_t bytes = (const uint8_t *)pend - (const uint8_t *)batch;
+	rc = ensure_staging(c, bytes, (uint32_t)offs.size());
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(c->dev_staging, batch, bytes, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(c->dev_offsets, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, c->stream));
+	rc = run_lstate(c, c->dev_staging, c->dev_offsets, nullptr, host, (uint32_t)offs.size());
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+int gys_ingest_host_state(gys_ctx *c, const uint8_t machine_id[16], const gys_host_state *st)
+{
+	if (!c || !machine_id || !st) return GYS_ERR_INVAL;
+	uint32_t host;
+	int rc = lookup_host(c, machine_id, &host);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(c->host_state + host, st, sizeof(*st), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(c->host_state_epoch + host, &c->epoch, 4, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ window boundary
+int gys_reduce_sections(gys_ctx *c, gys_reduce_section out[4], uint32_t *nsections)
+{
+	if (!c || !out || !nsections) return GYS_ERR_INVAL;
+	out[0] = {c->arena + c->al.off_hll8, (uint64_t)1 << GYS_HLL_P, 0, 0};
+	out[1] = {c->arena + c->al.off_u32, c->al.n_u32, 1, 1};
+	out[2] = {c->arena + c->al.off_i64sum, c->al.n_i64sum, 2, 1};
+	out[3] = {c->arena + c->al.off_i64max, c->al.n_i64max, 2, 0};
+	*nsections = 4;
+	return GYS_OK;
+}
+
+int gys_window_prepare(gys_ctx *c, uint64_t tusec)
+{
+	(void)tusec;
+	if (!c) return GYS_ERR_INVAL;
+	if (c->prepared) {
+		set_err("window already prepared");
+		return GYS_ERR_STATE;
+	}
+	PrepP p{};
+	p.host_summ = c->host_summ_win;
+	p.host_state = c->host_state;
+	p.host_state_epoch = c->host_state_epoch;
+	p.host_cluster = c->host_cluster;
+	p.nhosts = (uint32_t)c->hosts.size();
+	p.epoch = c->epoch;
+	p.cluster_state = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cluster;
+	p.hll32 = c->hll32;
+	p.hll8 = c->arena + c->al.off_hll8;
+	const uint32_t nthreads = std::max<uint32_t>(p.nhosts, (1u << GYS_HLL_P) / 4u);
+	{
+		ProfScope ps(c, "window_prepare");
+		hipLaunchKernelGGL(k_window_prepare, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, p);
+	}
+	HIPCHK(hipGetLastError());
+	c->prepared = true;
+	return GYS_OK;
+}
+
+int gys_window_finish(gys_ctx *c)
+{
+	if (!c) return GYS_ERR_INVAL;
+	if (!c->prepared) {
+		set_err("gys_window_finish without gys_window_prepare");
+		return GYS_ERR_STATE;
+	}
+	ProfScope ps(c, "window_finish");
+	// keep the (reduced) registers of this window for queries, start the next window from zero
+	HIPCHK(hipMemcpyAsync(c->last, c->arena, c->al.total, hipMemcpyDeviceToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(c->arena, 0, c->al.total, c->stream));
+	{
+		const int64_t mn = INT64_MIN;
+		HIPCHK(hipMemcpyAsync(c->arena + c->al.off_i64max, &mn, 8, hipMemcpyHostToDevice, c->stream));
+	}
+	HIPCHK(hipMemsetAsync(c->hll32, 0, (uint64_t)4 << GYS_HLL_P, c->stream));
+	if (c->nsvc) {
+		// all-time += window (GY_HISTOGRAM::add_histogram), window cleared; CONN_BITMAP cleared every window (secs_to_reset_ = 5)
+		hipLaunchKernelGGL(k_hist_fold, dim3((uint32_t)(((uint64_t)c->nsvc * 16 + 255) / 256)), dim3(256), 0, c->stream, c->hist_all, c->hist_win,
+				   (uint64_t)c->nsvc, 1);
+		HIPCHK(hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * 64, c->stream));
+		if (c->svc_hll) HIPCHK(hipMemsetAsync(c->svc_hll, 0, (uint64_t)c->nsvc << c->cfg.svc_hll_p, c->stream));
+	}
+	const uint64_t hb = (uint64_t)c->hosts.size() * 16 * 4;
+	if (hb) {
+		HIPCHK(hipMemcpyAsync(c->host_summ_last, c->host_summ_win, hb, hipMemcpyDeviceToDevice, c->stream));
+		HIPCHK(hipMemsetAsync(c->host_summ_win, 0, hb, c->stream));
+	}
+	HIPCHK(hipGetLastError());
+	c->epoch++;
+	c->prepared = false;
+	c->have_last = true;
+	return GYS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ queries
+int gys_query_svcsumm(gys_ctx *c, const uint8_t machine_id[16], gys_svcsumm *out)
+{
+	if (!c || !machine_id || !out) return GYS_ERR_INVAL;
+	uint32_t host;
+	int rc = lookup_host(c, machine_id, &host);
+	if (rc) return rc;
+	int32_t s[16];
+	HIPCHK(hipMemcpyAsync(s, c->host_summ_last + (size_t)host * 16, sizeof(s), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	for (int i = 0; i < GYS_NSTATES; ++i) out->nstates[i] = s[i];
+	out->tot_qps = s[6];
+	out->tot_act_conn = s[7];
+	out->tot_kb_inbound = s[8];
+	out->tot_kb_outbound = s[9];
+	out->tot_ser_errors = s[10];
+	out->nlisteners = s[11];
+	out->nactive = s[12];
+	return GYS_OK;
+}
+
+int gys_query_clusterstate(gys_ctx *c, const char *cluster_name, gys_cluster_state *out)
+{
+	if (!c || !cluster_name || !out) return GYS_ERR_INVAL;
+	auto it = c->cluster_map.find(cluster_name);
+	if (it == c->cluster_map.end()) {
+		set_err("unknown cluster");
+		return GYS_ERR_NOTFOUND;
+	}
+	uint32_t v[12];
+	const uint32_t *src = (const uint32_t *)(c->last + c->al.off_u32) + c->al.u32_cluster + (size_t)it->second * 12;
+	HIPCHK(hipMemcpyAsync(v, src, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	memcpy(out, v, sizeof(*out));
+	return GYS_OK;
+}
+
+int gys_lookup_service(gys_ctx *c, uint64_t glob_id, uint32_t *slot)
+{
+	if (!c || !slot) return GYS_ERR_INVAL;
+	auto it = c->gid_map_h.find(glob_id);
+	if (it == c->gid_map_h.end()) {
+		set_err("unknown glob_id %016llx", (unsigned long long)glob_id);
+		return GYS_ERR_NOTFOUND;
+	}
+	*slot = it->second;
+	return GYS_OK;
+}
+
+int gys_query_hist_percentiles(gys_ctx *c, uint64_t glob_id, int which, gys_hist_data *pdata, uint32_t npct, uint64_t *total_count, int64_t *max_val,
+			       float *pavg)
+{
+	if (!c || !pdata || which < 0 || which > 1) return GYS_ERR_INVAL;
+	uint32_t slot;
+	int rc = gys_lookup_service(c, glob_id, &slot);
+	if (rc) return rc;
+	gys_hist_rec h;
+	HIPCHK(hipMemcpyAsync(&h, (which ? c->hist_all : c->hist_win) + slot, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	const HashDef &d = hash_def(GYS_RESP_TIME_HASH);
+	if (total_count) *total_count = h.total_count;
+	if (max_val) *max_val = h.max_val_seen;
+	if (pavg) { // common/gy_statistics.h:734-750
+		int64_t total_sum = 0;
+		const int64_t cnt = h.total_count ? (int64_t)h.total_count : 1;
+		for (int i = 0; i < d.nthr + 2; ++i) total_sum += h.stats[i].sum;
+		*pavg = (total_sum * 1.0f) / cnt;
+	}
+	for (uint32_t i = 0; i < npct; ++i) hist_percentile(d, h, pdata[i].percentile, &pdata[i].data_value, &pdata[i].sum, &pdata[i].count);
+	return GYS_OK;
+}
+
+// quantile of an exact-integer digest: interpolation between cluster centres; only + - * / on doubles (matches oracle bit-for-bit)
+static double td_quantile_host(const int64_t *sum, const uint32_t *cnt, int32_t vmin, int32_t vmax, double q)
+{
+	uint64_t N = 0;
+	for (int k = 0; k < GYS_TD_NB; ++k) N += cnt[k];
+	if (!N) return 0.0;
+	if (q < 0.0) q = 0.0;
+	if (q > 1.0) q = 1.0;
+	const double t = q * (double)N;
+	double wbefore = 0.0, prev_c = 0.0, prev_mean = 0.0;
+	bool have_prev = false;
+	for (int k = 0; k < GYS_TD_NB; ++k) {
+		if (!cnt[k]) continue;
+		const double mean = (double)sum[k] / (double)cnt[k];
+		const double c = wbefore + (double)cnt[k] * 0.5;
+		if (t < c) {
+			if (!have_prev) {
+				const double lo = (double)vmin;
+				if (c <= 0.0) return mean;
+				return lo + (mean - lo) * (t / c);
+			}
+			return prev_mean + (mean - prev_mean) * ((t - prev_c) / (c - prev_c));
+		}
+		wbefore += (double)cnt[k];
+		prev_c = c;
+		prev_mean = mean;
+		have_prev = true;
+	}
+	const double hi = (double)vmax, span = (double)N - prev_c;
+	if (span <= 0.0) return hi;
+	return prev_mean + (hi - prev_mean) * ((t - prev_c) / span);
+}
+
+int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t nq, double *out)
+{
+	if (!c || !q || !out) return GYS_ERR_INVAL;
+	if (!c->cfg.enable_tdigest) {
+		set_err("t-digest disabled");
+		return GYS_ERR_STATE;
+	}
+	uint32_t slot;
+	int rc = gys_lookup_service(c, glob_id, &slot);
+	if (rc) return rc;
+	int64_t sum[GYS_TD_NB];
+	uint32_t cnt[GYS_TD_NB];
+	int32_t mm[2];
+	HIPCHK(hipMemcpyAsync(sum, c->td_sum + (size_t)slot * GYS_TD_NB, sizeof(sum), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(cnt, c->td_cnt + (size_t)slot * GYS_TD_NB, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(mm, c->td_minmax + (size_t)slot * 2, sizeof(mm), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	for (uint32_t i = 0; i < nq; ++i) out[i] = td_quantile_host(sum, cnt, mm[0], mm[1], q[i]);
+	return GYS_OK;
+}
+
+static double hll_estimate_host(const uint8_t *regs, int p)
+{
+	const uint32_t m = 1u << p;
+	double sum = 0.0;
+	uint32_t zeros = 0;
+	for (uint32_t i = 0; i < m; ++i) {
+		sum += 1.0 / (double)(1ull << regs[i]);
+		zeros += regs[i] == 0;
+	}
+	const double alpha = m == 16 ? 0.673 : (m == 32 ? 0.697 : (m == 64 ? 0.709 : 0.7213 / (1.0 + 1.079 / (double)m)));
+	double e = alpha * (double)m * (double)m / sum;
+	if (e <= 2.5 * (double)m && zeros) e = (double)m * std::log((double)m / (double)zeros);
+	return e;
+}
+
+int gys_query_distinct_flows(gys_ctx *c, double *out)
+{
+	if (!c || !out) return GYS_ERR_INVAL;
+	std::vector<uint8_t> regs((size_t)1 << GYS_HLL_P);
+	HIPCHK(hipMemcpyAsync(regs.data(), c->last + c->al.off_hll8, regs.size(), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	*out = hll_estimate_host(regs.data(), GYS_HLL_P);
+	return GYS_OK;
+}
+
+int gys_query_cms(gys_ctx *c, uint64_t glob_id, int which, uint64_t *out)
+{
+	if (!c || !out || which < 0 || which > 1) return GYS_ERR_INVAL;
+	uint64_t best = ~0ull;
+	for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
+		const uint32_t col = jhash2_u64(glob_id, GYS_SEED + r) & (GYS_CMS_W - 1);
+		uint64_t v = 0;
+		if (which == 0) {
+			uint32_t v32;
+			HIPCHK(hipMemcpyAsync(&v32, (const uint32_t *)(c->last + c->al.off_u32) + c->al.u32_cms + (size_t)r * GYS_CMS_W + col, 4,
+					      hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));
+			v = v32;
+		} else {
+			HIPCHK(hipMemcpyAsync(&v, (const uint64_t *)(c->last + c->al.off_i64sum) + c->al.i64_cms + (size_t)r * GYS_CMS_W + col, 8,
+					      hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));
+		}
+		best = std::min(best, v);
+	}
+	*out = best;
+	return GYS_OK;
+}
+
+int gys_query_topn(gys_ctx *c, const uint8_t machine_id[16], int kind, gys_topn_entry out[GYS_TOPN], uint32_t *nout)
+{
+	if (!c || !machine_id || !out || !nout || kind < 0 || kind > 3) return GYS_ERR_INVAL;
+	uint32_t host;
+	int rc = lookup_host(c, machine_id, &host);
+	if (rc) return rc;
+	*nout = 0;
+	if (!c->nsvc || c->epoch < 2) return GYS_OK;
+	const uint32_t cap = (uint32_t)std::min<uint64_t>(c->cfg.max_services, 65536);
+	HIPCHK(hipMemsetAsync(c->misc + 1, 0, 4, c->stream));
+	hipLaunchKernelGGL(k_topn_filter, dim3((c->nsvc + 255) / 256), dim3(256), 0, c->stream, c->svc_state, c->nsvc, host, c->epoch - 1, kind, c->topn_slot,
+			   c->topn_metric, c->misc + 1, cap);
+	uint32_t cnt = 0;
+	HIPCHK(hipMemcpyAsync(&cnt, c->misc + 1, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	cnt = std::min(cnt, cap);
+	if (!cnt) return GYS_OK;
+	std::vector<uint32_t> slots(cnt);
+	std::vector<uint64_t> metrics(cnt);
+	HIPCHK(hipMemcpy(slots.data(), c->topn_slot, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(metrics.data(), c->topn_metric, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+	std::vector<uint32_t> order(cnt);
+	for (uint32_t i = 0; i < cnt; ++i) order[i] = i;
+	// BOUNDED_PRIO_QUEUE keeps the N largest (common/gy_statistics.h:385-414); ties resolved by lowest service slot for determinism
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return metrics[a] != metrics[b] ? metrics[a] > metrics[b] : slots[a] < slots[b]; });
+	const uint32_t k = std::min<uint32_t>(cnt, GYS_TOPN);
+	for (uint32_t i = 0; i < k; ++i) {
+		const uint32_t s = slots[order[i]];
+		uint8_t rec[96];
+		HIPCHK(hipMemcpy(rec, c->svc_state + (size_t)s * 96, 96, hipMemcpyDeviceToHost));
+		memcpy(out[i].state, rec, 88);
+		memcpy(&out[i].glob_id, rec, 8);
+		out[i].host_slot = host;
+		out[i].metric = (uint32_t)metrics[order[i]];
+	}
+	*nout = k;
+	return GYS_OK;
+}
+
+int gys_scan_percentiles_dev(gys_ctx *c, int which, const float *pcts, uint32_t npct, int64_t *d_out)
+{
+	if (!c || !pcts || !d_out || !npct || npct > 64 || which < 0 || which > 1) return GYS_ERR_INVAL;
+	return gys_hist_percentiles_dev(c, GYS_RESP_TIME_HASH, which ? c->hist_all : c->hist_win, c->nsvc, pcts, npct, d_out);
+}
+
+// ------------------------------------------------------------------------------------------------ exports
+uint32_t gys_num_services(gys_ctx *c) { return c ? c->nsvc : 0; }
+uint32_t gys_num_hosts(gys_ctx *c) { return c ? (uint32_t)c->hosts.size() : 0; }
+
+#define RANGE_CHECK(first, n)                                       \
+	if (!c || !out || (uint64_t)(first) + (n) > c->nsvc) {      \
+		set_err("bad slot range");                          \
+		return GYS_ERR_INVAL;                               \
+	}
+
+int gys_export_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
+{
+	RANGE_CHECK(first_slot, nslots);
+	HIPCHK(hipMemcpyAsync(out, (which ? c->hist_all : c->hist_win) + first_slot, (size_t)nslots * sizeof(gys_hist_rec), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+int gys_export_conn_bitmap(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint16_t *out)
+{
+	RANGE_CHECK(first_slot, nslots);
+	HIPCHK(hipMemcpyAsync(out, c->bitmap + (size_t)first_slot * 16, (size_t)nslots * 64, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+int gys_export_hll(gys_ctx *c, uint8_t *out)
+{
+	if (!c || !out) return GYS_ERR_INVAL;
+	HIPCHK(hipMemcpyAsync(out, c->last + c->al.off_hll8, (size_t)1 << GYS_HLL_P, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+int gys_export_cms(gys_ctx *c, int which, void *out)
+{
+	if (!c || !out || which < 0 || which > 1) return GYS_ERR_INVAL;
+	const size_t n = (size_t)GYS_CMS_D * GYS_CMS_W;
+	if (which == 0)
+		HIPCHK(hipMemcpyAsync(out, (const uint32_t *)(c->last + c->al.off_u32) + c->al.u32_cms, n * 4, hipMemcpyDeviceToHost, c->stream));
+	else
+		HIPCHK(hipMemcpyAsync(out, (const int64_t *)(c->last + c->al.off_i64sum) + c->al.i64_cms, n * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+int gys_export_global_hist(gys_ctx *c, gys_hist_rec *out)
+{
+	if (!c || !out) return GYS_ERR_INVAL;
+	int64_t v[32];
+	int64_t mx;
+	HIPCHK(hipMemcpyAsync(v, (const int64_t *)(c->last + c->al.off_i64sum) + c->al.i64_ghist, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(&mx, c->last + c->al.off_i64max, 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	for (int i = 0; i < 15; ++i) {
+		out->stats[i].count = (uint64_t)v[2 * i];
+		out->stats[i].sum = v[2 * i + 1];
+	}
+	out->total_count = (uint64_t)v[30];
+	out->max_val_seen = mx;
+	return GYS_OK;
+}
+
+int gys_export_tdigest(gys_ctx *c, uint32_t first_slot, uint32_t nslots, int64_t *sums, uint32_t *cnts, int32_t *minmax)
+{
+	void *out = sums;
+	RANGE_CHECK(first_slot, nslots);
+	if (!c->cfg.enable_tdigest || !cnts || !minmax) return GYS_ERR_INVAL;
+	HIPCHK(hipMemcpyAsync(sums, c->td_sum + (size_t)first_slot * GYS_TD_NB, (size_t)nslots * GYS_TD_NB * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(cnts, c->td_cnt + (size_t)first_slot * GYS_TD_NB, (size_t)nslots * GYS_TD_NB * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(minmax, c->td_minmax + (size_t)first_slot * 2, (size_t)nslots * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+int gys_export_svc_counters(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint64_t *out)
+{
+	RANGE_CHECK(first_slot, nslots);
+	HIPCHK(hipMemcpyAsync(out, c->svc_ctr + (size_t)first_slot * 4, (size_t)nslots * 32, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+int gys_export_svc_hll(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint8_t *out)
+{
+	RANGE_CHECK(first_slot, nslots);
+	if (!c->svc_hll) return GYS_ERR_STATE;
+	HIPCHK(hipMemcpyAsync(out, c->svc_hll + ((size_t)first_slot << c->cfg.svc_hll_p), (size_t)nslots << c->cfg.svc_hll_p, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+int gys_get_counters(gys_ctx *c, gys_counters *out)
+{
+	if (!c || !out) return GYS_ERR_INVAL;
+	uint64_t v[16];
+	HIPCHK(hipMemcpyAsync(v, c->counters, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	out->resp_events = v[CTR_RESP_EVENTS];
+	out->resp_dropped_range = v[CTR_RESP_DROP_RANGE];
+	out->resp_dropped_nolistener = v[CTR_RESP_DROP_NOLISTENER];
+	out->conn_events = v[CTR_CONN_EVENTS];
+	out->conn_unknown_service = v[CTR_CONN_UNKNOWN];
+	out->lstate_records = v[CTR_LSTATE_RECORDS];
+	out->lstate_missed = v[CTR_LSTATE_MISSED];
+	out->lstate_errors = v[CTR_LSTATE_ERRORS];
+	out->lstate_deleted = v[CTR_LSTATE_DELETED];
+	return GYS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ standalone keyed histogram op
+int gys_hist_init_dev(gys_ctx *c, int kind, gys_hist_rec *d_hist, uint32_t nkeys)
+{
+	if (!c || !d_hist || kind < 0 || kind >= GYS_NUM_HASH_KINDS) return GYS_ERR_INVAL;
+	HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)nkeys * sizeof(gys_hist_rec), c->stream));
+	const int64_t mn = hash_def(kind).t_bits == 64 ? INT64_MIN : (int64_t)INT32_MIN; // std::numeric_limits<T>::min() (:563)
+	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(nkeys, 256, 2048)), dim3(256), 0, c->stream, d_hist, (uint64_t)0, (uint64_t)nkeys, mn);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+int gys_hist_add_dev(gys_ctx *c, int kind, gys_hist_rec *d_hist, uint32_t nkeys, const uint32_t *d_keyidx, const int32_t *d_vals, uint64_t n)
+{
+	if (!c || !d_hist || kind < 0 || kind >= GYS_NUM_HASH_KINDS || ((!d_keyidx || !d_vals) && n)) return GYS_ERR_INVAL;
+	if (!n) return GYS_OK;
+	ProfScope ps(c, "hist_add");
+	hipLaunchKernelGGL(k_hist_add, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, kind, d_hist, nkeys, d_keyidx, d_vals, n);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+int gys_hist_merge_dev(gys_ctx *c, gys_hist_rec *d_dst, const gys_hist_rec *d_src, uint32_t nkeys)
+{
+	if (!c || !d_dst || !d_src) return GYS_ERR_INVAL;
+	if (!nkeys) return GYS_OK;
+	ProfScope ps(c, "hist_merge");
+	hipLaunchKernelGGL(k_hist_fold, dim3((uint32_t)(((uint64_t)nkeys * 16 + 255) / 256)), dim3(256), 0, c->stream, d_dst, (gys_hist_rec *)d_src,
+			   (uint64_t)nkeys, 0);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+int gys_hist_percentiles_dev(gys_ctx *c, int kind, const gys_hist_rec *d_hist, uint32_t nkeys, const float *pcts, uint32_t npct, int64_t *d_out)
+{
+	if (!c || !d_hist || !pcts || !d_out || !npct || npct > 64 || kind < 0 || kind >= GYS_NUM_HASH_KINDS) return GYS_ERR_INVAL;
+	if (!nkeys) return GYS_OK;
+	HIPCHK(hipMemcpyAsync(c->dev_pcts, pcts, (size_t)npct * 4, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream)); // pcts may be a short-lived host buffer
+	ProfScope ps(c, "hist_percentiles");
+	const uint64_t t = (uint64_t)nkeys * npct;
+	hipLaunchKernelGGL(k_hist_percentiles, dim3((uint32_t)((t + 255) / 256)), dim3(256), 0, c->stream, kind, d_hist, nkeys, c->dev_pcts, npct, d_out);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+int gys_profile_enable(gys_ctx *c, int on)
+{
+	if (!c) return GYS_ERR_INVAL;
+	c->profile = on != 0;
+	return GYS_OK;
+}
+
+int gys_profile_reset(gys_ctx *c)
+{
+	if (!c) return GYS_ERR_INVAL;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	prof_resolve(c);
+	c->prof.clear();
+	return GYS_OK;
+}
+
+int gys_profile_get(gys_ctx *c, const char *kernel, double *total_ms, uint64_t *launches)
+{
+	if (!c || !kernel) return GYS_ERR_INVAL;
+	prof_resolve(c);
+	auto it = c->prof.find(kernel);
+	if (it == c->prof.end()) {
+		if (total_ms) *total_ms = 0;
+		if (launches) *launches = 0;
+		return GYS_ERR_NOTFOUND;
+	}
+	if (total_ms) *total_ms = it->second.total_ms;
+	if (launches) *launches = it->second.launches;
+	return GYS_OK;
+}
+
+int gys_profile_names(gys_ctx *c, char *buf, size_t buflen)
+{
+	if (!c || !buf || !buflen) return GYS_ERR_INVAL;
+	std::string s;
+	for (auto &kv : c->prof) {
+		if (!s.empty()) s += ",";
+		s += kv.first;
+	}
+	snprintf(buf, buflen, "%s", s.c_str());
+	return GYS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ synthetic generator
+int gys_gen_resp_events_dev(gys_ctx *c, void *d_ev24, uint64_t nevents, uint64_t seed, uint32_t first_host, uint32_t nhosts, uint32_t svcs_per_host,
+			    uint32_t zipf_milli, gys_resp_seg *segs_out)
+{
+	if (!c || !d_ev24 || !nhosts || !svcs_per_host || !segs_out) return GYS_ERR_INVAL;
+	if (zipf_milli && (c->zipf_n != svcs_per_host || c->zipf_milli != zipf_milli)) {
+		std::vector<float> cdf(svcs_per_host);
+		const double s = zipf_milli / 1000.0;
+		double tot = 0;
+		for (uint32_t k = 0; k < svcs_per_host; ++k) tot += 1.0 / std::pow((double)(k + 1), s);
+		double run = 0;
+		for (uint32_t k = 0; k < svcs_per_host; ++k) {
+			run += 1.0 / std::pow((double)(k + 1), s) / tot;
+			cdf[k] = (float)run;
+		}
+		cdf[svcs_per_host - 1] = 1.0f;
+		if (c->zipf_cdf) {
+			HIPCHK(hipStreamSynchronize(c->stream));
+			HIPCHK(hipFree(c->zipf_cdf));
+			c->zipf_cdf = nullptr;
+		}
+		HIPCHK(hipMalloc((void **)&c->zipf_cdf, (size_t)svcs_per_host * 4));
+		HIPCHK(hipMemcpy(c->zipf_cdf, cdf.data(), (size_t)svcs_per_host * 4, hipMemcpyHostToDevice));
+		c->zipf_n = svcs_per_host;
+		c->zipf_milli = zipf_milli;
+	}
+	GenP g{};
+	g.ev = (uint64_t *)d_ev24;
+	g.n = nevents;
+	g.seed = seed;
+	g.first_host = first_host;
+	g.nhosts = nhosts;
+	g.svcs_per_host = svcs_per_host;
+	g.zipf_cdf = zipf_milli ? c->zipf_cdf : nullptr;
+	g.per_host = std::max<uint64_t>(1, nevents / nhosts);
+	for (uint32_t h = 0; h < nhosts; ++h) {
+		segs_out[h].host_slot = first_host + h;
+		segs_out[h].reserved = 0;
+		segs_out[h].first_event = std::min<uint64_t>((uint64_t)h * g.per_host, nevents);
+	}
+	if (nevents) hipLaunchKernelGGL(k_gen_resp, dim3(grid_for(nevents, 256, 4096)), dim3(256), 0, c->stream, g);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,948 @@
+// gys_kernels.hpp -- the HIP kernels of libgysketch (gfx950, wave64).  Included once by gys_engine.hip.
+//
+// Hot path (per response event, replaces common/gy_socket_stat.cc:1517-1677 + common/gy_statistics.h:596-623):
+//   resp_pass1     24-B event -> listener slot (table probe) -> RESP_TIME_HASH bucket -> per-service exact histogram,
+//                  CONN_BITMAP, global histogram (LDS privatised), global HLL, Count-Min, per-key batch count, (slot,value) record
+//   scan_*         exclusive scan of the per-key batch counts (counting sort by key)
+//   resp_scatter   values scattered into per-key contiguous segments
+//   digest_small   one wave per key: LDS bitonic sort of the key's new values + exact-integer k-bucket t-digest merge
+//   digest_huge    keys with > GYS_SMALL_MAX new values: value-count array in HBM scratch + parallel rank-interval assignment
+// All of it is HBM-bound integer work: no MFMA.
+#pragma once
+
+#include "gys_device.hpp"
+
+namespace gys {
+
+#define GYS_SMALL_MAX 1024u        // largest per-key batch handled by digest_small (LDS bitonic sort by one wave)
+#define GYS_HUGE_VALUE_BITS 20     // resp values are <= 1,000,000 < 2^20 (drop filter common/gy_socket_stat.cc:1521-1524)
+#define GYS_HUGE_BINS (1u << GYS_HUGE_VALUE_BITS)
+
+enum { CTR_RESP_EVENTS = 0, CTR_RESP_DROP_RANGE, CTR_RESP_DROP_NOLISTENER, CTR_CONN_EVENTS, CTR_CONN_UNKNOWN, CTR_LSTATE_RECORDS,
+       CTR_LSTATE_MISSED, CTR_LSTATE_ERRORS, CTR_LSTATE_DELETED, CTR_NUM };
+
+// ---------------------------------------------------------------------------------------------------- table insert
+__global__ void k_table_insert(DevTable t, const uint64_t *keys, uint32_t first_val, uint32_t n, uint32_t *nfail)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t key = keys[i];
+	uint32_t h = get_uint64_hash(key) & t.mask;
+	for (uint32_t probes = 0; probes <= t.mask; ++probes) {
+		const unsigned long long prev = atomicCAS((unsigned long long *)&t.keys[h], (unsigned long long)GYS_EMPTY_KEY, (unsigned long long)key);
+		if (prev == GYS_EMPTY_KEY || prev == key) {
+			t.vals[h] = first_val + i; // re-registration of a key rebinds it to the newest slot
+			return;
+		}
+		h = (h + 1) & t.mask;
+	}
+	atomicAdd(nfail, 1u);
+}
+
+__global__ void k_fill_u64(uint64_t *p, uint64_t v, uint64_t n)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void k_hist_init(gys_hist_rec *h, uint64_t first, uint64_t n, int64_t minval)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) h[first + i].max_val_seen = minval;
+}
+
+__global__ void k_minmax_init(int32_t *mm, uint64_t n)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		mm[2 * i] = INT32_MAX;
+		mm[2 * i + 1] = INT32_MIN;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------- resp pass 1
+struct RespP1 {
+	const uint64_t *ev;       // 3 x u64 per event (tcp_ipv4_resp_event_t, common/gy_ebpf_kernel.h:106-111)
+	uint64_t n;
+	const gys_resp_seg *segs; // device copy
+	uint32_t nsegs;
+	DevTable lk;
+	const uint64_t *svc_gid;
+	gys_hist_rec *hist_win;
+	uint32_t *bitmap;         // [nsvc*16] u32 = 32 x u16 CONN_BITMAP rows
+	uint32_t *hll32;          // [1<<14]
+	uint32_t *cms32;          // arena [D*W]
+	int64_t *ghist;           // arena: 15 x {count,sum} + {total}
+	int64_t *gmax;            // arena (MAX section)
+	uint32_t *batch_cnt;      // nullptr when the t-digest is off
+	uint64_t *ev_kv;          // (slot << 32 | value) per event, ~0 = dropped
+	uint64_t *counters;
+	uint8_t *svc_hll;
+	uint32_t svc_hll_p;
+};
+
+__device__ __forceinline__ uint32_t find_seg(const gys_resp_seg *segs, uint32_t nsegs, uint64_t i)
+{
+	uint32_t lo = 0, hi = nsegs - 1; // largest s with segs[s].first_event <= i
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi + 1) >> 1;
+		if (segs[mid].first_event <= i) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+
+__device__ __forceinline__ uint16_t bswap16(uint16_t v) { return (uint16_t)((v >> 8) | (v << 8)); }
+
+__global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
+{
+	__shared__ unsigned long long s_gh[32]; // 15 x {count,sum} + total (global histogram privatised per block)
+	__shared__ long long s_gmax;
+	__shared__ unsigned int s_ctr[3];
+	if (threadIdx.x < 32) s_gh[threadIdx.x] = 0;
+	if (threadIdx.x == 0) s_gmax = INT64_MIN;
+	if (threadIdx.x < 3) s_ctr[threadIdx.x] = 0;
+	__syncthreads();
+
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
+		// struct ipv4_tuple_t {u32 saddr, daddr, netns; u16 sport, dport;} + u32 lsndtime, lrcvtime  (24 bytes)
+		const uint64_t w0 = p.ev[3 * i], w1 = p.ev[3 * i + 1], w2 = p.ev[3 * i + 2];
+		const uint32_t saddr = (uint32_t)w0, daddr = (uint32_t)(w0 >> 32);
+		const uint32_t netns = (uint32_t)w1;
+		const uint16_t sport = bswap16((uint16_t)(w1 >> 32)), dport = bswap16((uint16_t)(w1 >> 48)); // ntohs :1526-1527
+		const uint32_t lsnd = (uint32_t)w2, lrcv = (uint32_t)(w2 >> 32);
+		const uint32_t tresp = lsnd - lrcv; // int tresp_msec = lsndtime - lrcvtime (:1519)
+		uint64_t kv = ~0ull;
+
+		atomicAdd(&s_ctr[0], 1u);
+		if (tresp > 1000000u) { // "Ignore responses > 1000 sec or negative" (:1521-1524)
+			atomicAdd(&s_ctr[1], 1u);
+		} else {
+			const uint32_t host_slot = p.segs[find_seg(p.segs, p.nsegs, i)].host_slot;
+			const uint32_t slot = tbl_lookup(p.lk, listener_key(host_slot, netns, sport));
+			if (slot == GYS_NOSLOT) {
+				atomicAdd(&s_ctr[2], 1u); // no such listener: the reference ignores the event too (:1671-1676 miss path)
+			} else {
+				const uint32_t b = resp_bucket((int64_t)tresp);
+				// GY_HISTOGRAM::add_data / HIST_SERIAL::add (common/gy_statistics.h:463-467, :596-623)
+				gys_hist_rec *h = &p.hist_win[slot];
+				atomicAdd((unsigned long long *)&h->stats[b].count, 1ull);
+				atomicAdd((unsigned long long *)&h->stats[b].sum, (unsigned long long)tresp);
+				atomicAdd((unsigned long long *)&h->total_count, 1ull);
+				if (h->max_val_seen < (int64_t)tresp) atomicMax((long long *)&h->max_val_seen, (long long)tresp);
+				// CONN_BITMAP::add_response: respmap_[cli_port & 0x1F].set(bucket) (common/gy_socket_stat.h:403-410)
+				{
+					const uint32_t row = dport & 0x1Fu;
+					const uint32_t bit = (1u << b) << ((row & 1u) * 16u);
+					uint32_t *wp = &p.bitmap[(size_t)slot * 16u + (row >> 1)];
+					if ((*wp & bit) == 0) atomicOr(wp, bit);
+				}
+				// global histogram (block-private, flushed once per block)
+				atomicAdd(&s_gh[2 * b], 1ull);
+				atomicAdd(&s_gh[2 * b + 1], (unsigned long long)tresp);
+				atomicAdd(&s_gh[30], 1ull);
+				atomicMax(&s_gmax, (long long)tresp);
+				// distinct client flows: HLL over PAIR_IP_PORT(cli = daddr:dport, ser = saddr:sport) (common/gy_inet_inc.h:225-247)
+				{
+					uint32_t w[10];
+					const uint32_t z[4] = {0, 0, 0, 0};
+					const uint32_t nw = pair_words(daddr, z, dport, saddr, z, sport, w);
+					const uint64_t h64 = hash64<10>(w, nw);
+					uint32_t idx, rank;
+					hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
+					if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
+					if (p.svc_hll_p) {
+						// per-service distinct clients: key = client endpoint only (same hash, different split)
+						uint32_t sidx, srank;
+						hll_idx_rank(h64, (int)p.svc_hll_p, &sidx, &srank);
+						uint8_t *base = p.svc_hll + ((size_t)slot << p.svc_hll_p);
+						uint32_t *wp = (uint32_t *)(base + (sidx & ~3u));
+						const uint32_t sh = (sidx & 3u) * 8u;
+						uint32_t old = *wp;
+						while (((old >> sh) & 0xFFu) < srank) {
+							const uint32_t nv = (old & ~(0xFFu << sh)) | (srank << sh);
+							const uint32_t prev = atomicCAS(wp, old, nv);
+							if (prev == old) break;
+							old = prev;
+						}
+					}
+				}
+				// Count-Min: events per service key (glob_id), row hash jhash2(key, seed + r)
+				{
+					const uint64_t gid = p.svc_gid[slot];
+#pragma unroll
+					for (uint32_t r = 0; r < GYS_CMS_D; ++r)
+						atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(gid, GYS_SEED + r) & (GYS_CMS_W - 1))], 1u);
+				}
+				if (p.batch_cnt) {
+					atomicAdd(&p.batch_cnt[slot], 1u);
+					kv = ((uint64_t)slot << 32) | (uint64_t)tresp;
+				}
+			}
+		}
+		if (p.ev_kv) p.ev_kv[i] = kv;
+	}
+	__syncthreads();
+	if (threadIdx.x < 31 && s_gh[threadIdx.x]) atomicAdd((unsigned long long *)&p.ghist[threadIdx.x], s_gh[threadIdx.x]);
+	if (threadIdx.x == 31 && s_gmax != INT64_MIN) atomicMax((long long *)p.gmax, s_gmax);
+	if (threadIdx.x < 3 && s_ctr[threadIdx.x]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS + threadIdx.x], (unsigned long long)s_ctr[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------------- scan of batch counts
+#define GYS_SCAN_TILE 4096u // elements per 256-thread block (16 per thread)
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *s_wave, uint32_t *total)
+{
+	// inclusive wave scan by shuffles, then 4 wave totals through LDS
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t inc = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t t = __shfl_up(inc, d, 64);
+		if ((int)lane >= d) inc += t;
+	}
+	if (lane == 63) s_wave[wave] = inc;
+	__syncthreads();
+	uint32_t woff = 0, tot = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < 4; ++w) {
+		const uint32_t t = s_wave[w];
+		if (w < wave) woff += t;
+		tot += t;
+	}
+	__syncthreads();
+	*total = tot;
+	return woff + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_block_sums(const uint32_t *cnt, uint32_t n, uint32_t *block_sums)
+{
+	__shared__ uint32_t s_wave[4];
+	const uint32_t base = blockIdx.x * GYS_SCAN_TILE + threadIdx.x * 16u;
+	uint32_t s = 0;
+	if (base + 16u <= n) {
+		const uint4 *p4 = (const uint4 *)(cnt + base);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint4 v = p4[k];
+			s += v.x + v.y + v.z + v.w;
+		}
+	} else {
+		for (uint32_t k = 0; k < 16u; ++k)
+			if (base + k < n) s += cnt[base + k];
+	}
+	uint32_t total;
+	(void)block_exclusive_scan_256(s, s_wave, &total);
+	if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_scan_top(uint32_t *block_sums, uint32_t nblocks)
+{
+	__shared__ uint32_t s_wave[4];
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < nblocks; base += 256u) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < nblocks ? block_sums[i] : 0u;
+		uint32_t total;
+		const uint32_t ex = block_exclusive_scan_256(v, s_wave, &total);
+		if (i < nblocks) block_sums[i] = carry + ex;
+		carry += total;
+	}
+}
+
+// writes batch_off (exclusive prefix) and appends keys with > GYS_SMALL_MAX new values to the huge work list
+__global__ __launch_bounds__(256) void k_scan_final(const uint32_t *cnt, uint32_t n, const uint32_t *block_sums, uint32_t *off,
+						    uint32_t *huge_list, uint32_t *huge_count)
+{
+	__shared__ uint32_t s_wave[4];
+	const uint32_t base = blockIdx.x * GYS_SCAN_TILE + threadIdx.x * 16u;
+	uint32_t v[16];
+	uint32_t s = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < 16u; ++k) {
+		v[k] = (base + k < n) ? cnt[base + k] : 0u;
+		s += v[k];
+	}
+	uint32_t total;
+	uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan_256(s, s_wave, &total);
+#pragma unroll
+	for (uint32_t k = 0; k < 16u; ++k) {
+		if (base + k < n) {
+			off[base + k] = run;
+			if (v[k] > GYS_SMALL_MAX) huge_list[atomicAdd(huge_count, 1u)] = base + k;
+		}
+		run += v[k];
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------- scatter
+// after this kernel off[slot] = segment END (start = off - cnt)
+__global__ __launch_bounds__(256) void k_resp_scatter(const uint64_t *ev_kv, uint64_t n, uint32_t *off, uint32_t *staged)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const uint64_t kv = ev_kv[i];
+		if (kv == ~0ull) continue;
+		const uint32_t pos = atomicAdd(&off[(uint32_t)(kv >> 32)], 1u);
+		staged[pos] = (uint32_t)kv;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------- t-digest merge (small)
+struct DigestP {
+	int64_t *td_sum;    // [nsvc*100]
+	uint32_t *td_cnt;   // [nsvc*100]
+	int32_t *td_minmax; // [nsvc*2]
+	uint32_t *batch_cnt;
+	const uint32_t *off_end;
+	const uint32_t *staged;
+	uint32_t nsvc;
+};
+
+// lanes 0..63 each own entries (lane) and (lane + 64) of a <= 128 long array: exclusive prefix sum (u64) across the wave
+__device__ __forceinline__ void wave_excl_scan_2x(uint64_t a0, uint64_t a1, uint64_t *e0, uint64_t *e1, uint64_t *total)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	uint64_t i0 = a0, i1 = a1;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint64_t t0 = __shfl_up(i0, d, 64), t1 = __shfl_up(i1, d, 64);
+		if ((int)lane >= d) {
+			i0 += t0;
+			i1 += t1;
+		}
+	}
+	const uint64_t tot0 = __shfl(i0, 63, 64), tot1 = __shfl(i1, 63, 64);
+	*e0 = i0 - a0;
+	*e1 = tot0 + i1 - a1;
+	*total = tot0 + tot1;
+}
+
+// One 64-thread workgroup (= one wave) per key, grid-stride over keys.  Exact-integer k-bucket merge (DESIGN.md "t-digest"):
+//   merged order = by mean, old clusters before new values on ties; item with weighted mid-point mid2/2 of N goes to
+//   cluster #{j : mid2 >= T_j}, T_j = ceil(BND[j] * 2N / 2^32).
+__global__ __launch_bounds__(64) void k_digest_small(DigestP p)
+{
+	__shared__ int32_t s_val[GYS_SMALL_MAX];
+	__shared__ int64_t s_csum[GYS_TD_NB];  // compacted non-empty old clusters
+	__shared__ uint32_t s_ccnt[GYS_TD_NB];
+	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
+	__shared__ uint64_t s_T[GYS_TD_NB];    // s_T[j], j = 1..NB-1
+	__shared__ unsigned long long s_osum[GYS_TD_NB];
+	__shared__ uint32_t s_ocnt[GYS_TD_NB];
+	const uint32_t lane = threadIdx.x;
+
+	for (uint32_t slot = blockIdx.x; slot < p.nsvc; slot += gridDim.x) {
+		const uint32_t m = p.batch_cnt[slot];
+		if (m == 0 || m > GYS_SMALL_MAX) continue; // uniform per block
+		const uint32_t start = p.off_end[slot] - m;
+
+		// ---- old digest: entries lane, lane+64
+		const int64_t *gs = p.td_sum + (size_t)slot * GYS_TD_NB;
+		const uint32_t *gc = p.td_cnt + (size_t)slot * GYS_TD_NB;
+		const uint32_t j1 = lane + 64u;
+		const uint32_t c0 = gc[lane];
+		const uint32_t c1 = j1 < GYS_TD_NB ? gc[j1] : 0u;
+		const int64_t sm0 = gs[lane];
+		const int64_t sm1 = j1 < GYS_TD_NB ? gs[j1] : 0;
+		// compaction of non-empty clusters (order preserving)
+		const unsigned long long b0 = __ballot(c0 != 0), b1 = __ballot(c1 != 0);
+		const uint32_t n0 = (uint32_t)__popcll(b0), nc = n0 + (uint32_t)__popcll(b1);
+		const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+		uint64_t e0, e1, nold;
+		wave_excl_scan_2x((uint64_t)c0, (uint64_t)c1, &e0, &e1, &nold);
+		if (c0) {
+			const uint32_t pos = (uint32_t)__popcll(b0 & below);
+			s_csum[pos] = sm0;
+			s_ccnt[pos] = c0;
+			s_cpfx[pos] = e0;
+		}
+		if (c1) {
+			const uint32_t pos = n0 + (uint32_t)__popcll(b1 & below);
+			s_csum[pos] = sm1;
+			s_ccnt[pos] = c1;
+			s_cpfx[pos] = e1;
+		}
+		if (lane == 0) s_cpfx[nc] = nold;
+		// ---- new values -> LDS, padded to a power of two with +inf, bitonic sort by the wave
+		uint32_t P = 64;
+		while (P < m) P <<= 1;
+		for (uint32_t i = lane; i < P; i += 64u) s_val[i] = i < m ? (int32_t)p.staged[start + i] : INT32_MAX;
+		const uint64_t twoN = 2ull * (nold + (uint64_t)m);
+		if (lane >= 1 && lane < GYS_TD_NB) s_T[lane] = td_threshold(c_td_bnd[lane], twoN);
+		if (j1 < GYS_TD_NB) s_T[j1] = td_threshold(c_td_bnd[j1], twoN);
+		s_osum[lane] = 0;
+		s_ocnt[lane] = 0;
+		if (j1 < GYS_TD_NB) {
+			s_osum[j1] = 0;
+			s_ocnt[j1] = 0;
+		}
+		__syncthreads();
+		for (uint32_t k = 2; k <= P; k <<= 1) {
+			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+				for (uint32_t i = lane; i < P; i += 64u) {
+					const uint32_t ixj = i ^ j;
+					if (ixj > i) {
+						const int32_t a = s_val[i], b = s_val[ixj];
+						const bool up = (i & k) == 0;
+						if ((a > b) == up) {
+							s_val[i] = b;
+							s_val[ixj] = a;
+						}
+					}
+				}
+				__syncthreads();
+			}
+		}
+		// ---- old clusters: W = weight of old clusters before + #{new values strictly below the cluster mean}
+		for (uint32_t c = lane; c < nc; c += 64u) {
+			const int64_t cs = s_csum[c];
+			const uint32_t cc = s_ccnt[c];
+			uint32_t lo = 0, hi = m; // first index with v * cc >= cs
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if ((int64_t)s_val[mid] * (int64_t)cc < cs) lo = mid + 1; else hi = mid;
+			}
+			const uint64_t mid2 = 2ull * (s_cpfx[c] + (uint64_t)lo) + (uint64_t)cc;
+			uint32_t a = 0, bb = GYS_TD_NB - 1; // cluster = max j with (j == 0 or mid2 >= T_j)
+			while (a < bb) {
+				const uint32_t mid = (a + bb + 1) >> 1;
+				if (mid2 >= s_T[mid]) a = mid; else bb = mid - 1;
+			}
+			atomicAdd(&s_osum[a], (unsigned long long)cs);
+			atomicAdd(&s_ocnt[a], cc);
+		}
+		// ---- new values: W = rank among new values + weight of old clusters with mean <= v
+		for (uint32_t r = lane; r < m; r += 64u) {
+			const int64_t v = (int64_t)s_val[r];
+			uint32_t lo = 0, hi = nc; // first cluster with mean > v  (csum > v * ccnt)
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (s_csum[mid] <= v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
+			}
+			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[lo]) + 1ull;
+			uint32_t a = 0, bb = GYS_TD_NB - 1;
+			while (a < bb) {
+				const uint32_t mid = (a + bb + 1) >> 1;
+				if (mid2 >= s_T[mid]) a = mid; else bb = mid - 1;
+			}
+			atomicAdd(&s_osum[a], (unsigned long long)v);
+			atomicAdd(&s_ocnt[a], 1u);
+		}
+		__syncthreads();
+		// ---- write back
+		int64_t *ws = p.td_sum + (size_t)slot * GYS_TD_NB;
+		uint32_t *wc = p.td_cnt + (size_t)slot * GYS_TD_NB;
+		ws[lane] = (int64_t)s_osum[lane];
+		wc[lane] = s_ocnt[lane];
+		if (j1 < GYS_TD_NB) {
+			ws[j1] = (int64_t)s_osum[j1];
+			wc[j1] = s_ocnt[j1];
+		}
+		if (lane == 0) {
+			int32_t *mm = p.td_minmax + (size_t)slot * 2;
+			if (s_val[0] < mm[0]) mm[0] = s_val[0];
+			if (s_val[m - 1] > mm[1]) mm[1] = s_val[m - 1];
+			p.batch_cnt[slot] = 0;
+		}
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------- t-digest merge (huge)
+// One 256-thread workgroup per huge key (persistent over the work list).  Each workgroup owns a 2^20-bin u32 count array in HBM
+// scratch: values are histogrammed exactly, the bins are prefix-scanned, and every bin's rank interval is intersected with the
+// cluster rank intervals -- the same exact-integer assignment as digest_small without materialising a sort.
+struct HugeP {
+	DigestP d;
+	const uint32_t *huge_list;
+	const uint32_t *huge_count;
+	uint32_t *scratch; // [gridDim.x * GYS_HUGE_BINS]
+};
+
+__device__ __forceinline__ uint32_t td_cluster_of(const uint64_t *T, uint64_t mid2)
+{
+	uint32_t a = 0, bb = GYS_TD_NB - 1;
+	while (a < bb) {
+		const uint32_t mid = (a + bb + 1) >> 1;
+		if (mid2 >= T[mid]) a = mid; else bb = mid - 1;
+	}
+	return a;
+}
+
+__global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
+{
+	__shared__ int64_t s_csum[GYS_TD_NB];
+	__shared__ uint32_t s_ccnt[GYS_TD_NB];
+	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
+	__shared__ uint64_t s_T[GYS_TD_NB + 1];
+	__shared__ unsigned long long s_osum[GYS_TD_NB];
+	__shared__ unsigned long long s_ocnt[GYS_TD_NB];
+	__shared__ uint32_t s_part[256];
+	__shared__ uint32_t s_wave[4];
+	__shared__ uint32_t s_nc;
+	__shared__ int32_t s_min, s_max;
+	uint32_t *bins = p.scratch + (size_t)blockIdx.x * GYS_HUGE_BINS;
+	const uint32_t nh = *p.huge_count;
+	const uint32_t BPT = GYS_HUGE_BINS / 256u; // bins per thread (contiguous)
+
+	for (uint32_t w = blockIdx.x; w < nh; w += gridDim.x) {
+		const uint32_t slot = p.huge_list[w];
+		const uint32_t m = p.d.batch_cnt[slot];
+		const uint32_t start = p.d.off_end[slot] - m;
+		// zero the bins (16-byte stores)
+		for (uint32_t i = threadIdx.x; i < GYS_HUGE_BINS / 4u; i += 256u) ((uint4 *)bins)[i] = make_uint4(0, 0, 0, 0);
+		if (threadIdx.x < GYS_TD_NB) {
+			s_osum[threadIdx.x] = 0;
+			s_ocnt[threadIdx.x] = 0;
+		}
+		if (threadIdx.x == 0) {
+			// compact non-empty old clusters (serial: 100 entries, once per huge key)
+			const int64_t *gs = p.d.td_sum + (size_t)slot * GYS_TD_NB;
+			const uint32_t *gc = p.d.td_cnt + (size_t)slot * GYS_TD_NB;
+			uint32_t nc = 0;
+			uint64_t run = 0;
+			for (uint32_t j = 0; j < GYS_TD_NB; ++j) {
+				if (gc[j]) {
+					s_csum[nc] = gs[j];
+					s_ccnt[nc] = gc[j];
+					s_cpfx[nc] = run;
+					run += gc[j];
+					nc++;
+				}
+			}
+			s_cpfx[nc] = run;
+			s_nc = nc;
+			s_min = INT32_MAX;
+			s_max = INT32_MIN;
+		}
+		__syncthreads();
+		const uint32_t nc = s_nc;
+		const uint64_t nold = s_cpfx[nc];
+		const uint64_t twoN = 2ull * (nold + (uint64_t)m);
+		if (threadIdx.x >= 1 && threadIdx.x < GYS_TD_NB) s_T[threadIdx.x] = td_threshold(c_td_bnd[threadIdx.x], twoN);
+		if (threadIdx.x == 0) s_T[GYS_TD_NB] = ~0ull;
+		// exact value histogram
+		{
+			int32_t lmin = INT32_MAX, lmax = INT32_MIN;
+			for (uint32_t i = threadIdx.x; i < m; i += 256u) {
+				const uint32_t v = p.d.staged[start + i] & (GYS_HUGE_BINS - 1u);
+				atomicAdd(&bins[v], 1u);
+				lmin = min(lmin, (int32_t)v);
+				lmax = max(lmax, (int32_t)v);
+			}
+			atomicMin(&s_min, lmin);
+			atomicMax(&s_max, lmax);
+		}
+		__syncthreads();
+		// the atomics above were performed in L2; drop this CU's L1 copies of the bins before reading them with plain loads
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		// per-thread partial sums over its contiguous bins, block exclusive scan
+		uint32_t part = 0;
+		{
+			const uint4 *b4 = (const uint4 *)(bins + threadIdx.x * BPT);
+			for (uint32_t i = 0; i < BPT / 4u; ++i) {
+				const uint4 v = b4[i];
+				part += v.x + v.y + v.z + v.w;
+			}
+		}
+		uint32_t tot;
+		const uint32_t pfx = block_exclusive_scan_256(part, s_wave, &tot);
+		s_part[threadIdx.x] = pfx;
+		__syncthreads();
+		// ---- old clusters: lt = #{new v : v * cc < cs} = #{v <= (cs - 1) / cc}  (cs >= 1; none when cs <= 0)
+		if (threadIdx.x < nc) {
+			const int64_t cs = s_csum[threadIdx.x];
+			const uint32_t cc = s_ccnt[threadIdx.x];
+			uint64_t lt = 0;
+			if (cs > 0) {
+				int64_t vmax = (cs - 1) / (int64_t)cc;
+				if (vmax >= (int64_t)GYS_HUGE_BINS) vmax = GYS_HUGE_BINS - 1;
+				const uint32_t owner = (uint32_t)vmax / BPT;
+				lt = s_part[owner];
+				for (uint32_t b = owner * BPT; b <= (uint32_t)vmax; ++b) lt += bins[b];
+			}
+			const uint64_t mid2 = 2ull * (s_cpfx[threadIdx.x] + lt) + (uint64_t)cc;
+			const uint32_t cl = td_cluster_of(s_T, mid2);
+			atomicAdd(&s_osum[cl], (unsigned long long)cs);
+			atomicAdd(&s_ocnt[cl], (unsigned long long)cc);
+		}
+		// ---- new values bin by bin: ranks [r0, r0 + c) of value v, le = old weight with mean <= v
+		{
+			uint64_t r0 = pfx;
+			uint32_t ci = 0; // first compacted cluster with mean > v; monotone in v, so carried along the thread's bins
+			const uint32_t vbeg = threadIdx.x * BPT;
+			{
+				uint32_t lo = 0, hi = nc;
+				const int64_t v = (int64_t)vbeg;
+				while (lo < hi) {
+					const uint32_t mid = (lo + hi) >> 1;
+					if (s_csum[mid] <= v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
+				}
+				ci = lo;
+			}
+			for (uint32_t b = vbeg; b < vbeg + BPT; ++b) {
+				const uint32_t c = bins[b];
+				if (!c) continue;
+				const int64_t v = (int64_t)b;
+				while (ci < nc && s_csum[ci] <= v * (int64_t)s_ccnt[ci]) ci++;
+				const uint64_t le = s_cpfx[ci];
+				const uint64_t first = 2ull * (r0 + le) + 1ull, last = first + 2ull * (uint64_t)(c - 1u);
+				uint32_t cl = td_cluster_of(s_T, first);
+				const uint32_t cl_last = td_cluster_of(s_T, last);
+				uint64_t rbeg = r0;
+				for (; cl <= cl_last; ++cl) {
+					// ranks r with cluster == cl: mid2(r) < T[cl+1]  <=>  r < ceil((T - 1) / 2) - le   (T = T[cl+1] > 1 here)
+					uint64_t rend;
+					if (cl == cl_last) {
+						rend = r0 + c;
+					} else {
+						const uint64_t Tn = s_T[cl + 1];
+						rend = (Tn / 2ull) - le; // ceil((Tn-1)/2) == floor(Tn/2)
+						if (rend > r0 + c) rend = r0 + c;
+					}
+					if (rend > rbeg) {
+						const uint64_t k = rend - rbeg;
+						atomicAdd(&s_osum[cl], (unsigned long long)(k * (uint64_t)v));
+						atomicAdd(&s_ocnt[cl], (unsigned long long)k);
+						rbeg = rend;
+					}
+				}
+				r0 += c;
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x < GYS_TD_NB) {
+			p.d.td_sum[(size_t)slot * GYS_TD_NB + threadIdx.x] = (int64_t)s_osum[threadIdx.x];
+			p.d.td_cnt[(size_t)slot * GYS_TD_NB + threadIdx.x] = (uint32_t)s_ocnt[threadIdx.x];
+		}
+		if (threadIdx.x == 0) {
+			int32_t *mm = p.d.td_minmax + (size_t)slot * 2;
+			if (s_min < mm[0]) mm[0] = s_min;
+			if (s_max > mm[1]) mm[1] = s_max;
+			p.d.batch_cnt[slot] = 0;
+		}
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------- TCP_CONN_NOTIFY ingest
+// comm::TCP_CONN_NOTIFY (common/gy_comm_proto.h:1665-1742), 280 fixed bytes:
+//   IP_PORT cli_@0 ser_@32 nat_cli_@64 nat_ser_@96 (each: ip128 @0, ip32 @16, aftype @20, flags @22, port @24)
+//   tusec_start_@128 tusec_close_@136 ... ser_glob_id_@192 ... bytes_sent_@208 bytes_rcvd_@216 ... cli_cmdline_len_@272 flags@274.. padding_len_@279
+struct ConnP {
+	const uint8_t *batch;
+	const uint32_t *offsets;
+	uint32_t n;
+	DevTable gid;
+	uint32_t *hll32;
+	uint32_t *cms32;
+	unsigned long long *cms64;
+	unsigned long long *svc_ctr; // [nsvc*4] nconn, nclose, bytes_sent, bytes_rcvd
+	uint64_t *counters;
+};
+
+__global__ __launch_bounds__(256) void k_conn_ingest(ConnP p)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= p.n) return;
+	const uint8_t *rec = p.batch + p.offsets[i];
+	uint32_t c128[4], s128[4], c32, s32;
+	uint16_t cport, sport;
+	// flow key: PAIR_IP_PORT(nat_cli_, nat_ser_)  (server/gy_mconnhdlr.cc:8707)
+	{
+		// records start 8-byte aligned (COMM_HEADER::validate common/gy_comm_proto.cc:23-26) -> use 8-byte loads
+		const uint64_t *q = (const uint64_t *)(rec + 64);
+		const uint64_t a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+		c128[0] = (uint32_t)a0; c128[1] = (uint32_t)(a0 >> 32); c128[2] = (uint32_t)a1; c128[3] = (uint32_t)(a1 >> 32);
+		c32 = (uint32_t)a2;
+		cport = (uint16_t)a3;
+		const uint64_t *r = (const uint64_t *)(rec + 96);
+		const uint64_t b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3];
+		s128[0] = (uint32_t)b0; s128[1] = (uint32_t)(b0 >> 32); s128[2] = (uint32_t)b1; s128[3] = (uint32_t)(b1 >> 32);
+		s32 = (uint32_t)b2;
+		sport = (uint16_t)b3;
+	}
+	const uint64_t tusec_close = *(const uint64_t *)(rec + 136);
+	const uint64_t ser_glob_id = *(const uint64_t *)(rec + 192);
+	const uint64_t bytes_sent = *(const uint64_t *)(rec + 208), bytes_rcvd = *(const uint64_t *)(rec + 216);
+
+	uint32_t w[10];
+	const uint32_t nw = pair_words(c32, c128, cport, s32, s128, sport, w);
+	const uint64_t h64 = hash64<10>(w, nw);
+	uint32_t idx, rank;
+	hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
+	if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
+
+#pragma unroll
+	for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
+		const uint32_t col = jhash2_u64(ser_glob_id, GYS_SEED + r) & (GYS_CMS_W - 1);
+		atomicAdd(&p.cms32[r * GYS_CMS_W + col], 1u);
+		atomicAdd(&p.cms64[r * GYS_CMS_W + col], (unsigned long long)(bytes_sent + bytes_rcvd));
+	}
+	atomicAdd((unsigned long long *)&p.counters[CTR_CONN_EVENTS], 1ull);
+	const uint32_t slot = tbl_lookup(p.gid, ser_glob_id);
+	if (slot == GYS_NOSLOT) {
+		atomicAdd((unsigned long long *)&p.counters[CTR_CONN_UNKNOWN], 1ull);
+		return;
+	}
+	unsigned long long *c = p.svc_ctr + (size_t)slot * 4;
+	atomicAdd(&c[0], 1ull);
+	if (tusec_close) atomicAdd(&c[1], 1ull);
+	if (bytes_sent) atomicAdd(&c[2], (unsigned long long)bytes_sent);
+	if (bytes_rcvd) atomicAdd(&c[3], (unsigned long long)bytes_rcvd);
+}
+
+// ---------------------------------------------------------------------------------------------------- LISTENER_STATE_NOTIFY ingest
+// comm::LISTENER_STATE_NOTIFY (common/gy_comm_proto.h:2183-2254), 88 fixed bytes: glob_id_@0 nqrys_5s_@8 total_resp_5sec_@12 nconns_@16
+// nconns_active_@20 ntasks_@24 p95_5s@28 p95_5min@32 kb_in@36 kb_out@40 ser_errors_@44 cli_errors_@48 ... curr_state_@79 ...
+// query_flags_@84 issue_string_len_@85 padding_len_@86
+struct LStateP {
+	const uint8_t *batch;
+	const uint32_t *offsets;
+	const uint32_t *host_slot; // per record, or nullptr -> single_host
+	uint32_t single_host;
+	uint32_t n;
+	DevTable gid;
+	uint8_t *svc_state; // [nsvc*96]
+	int32_t *host_summ; // [nhosts*16] window accumulators (13 used)
+	uint32_t epoch;
+	uint64_t *counters;
+};
+
+__global__ __launch_bounds__(256) void k_lstate_ingest(LStateP p)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= p.n) return;
+	const uint8_t *rec = p.batch + p.offsets[i];
+	const uint64_t *q = (const uint64_t *)rec; // 8-byte aligned records
+	uint64_t w[11];
+#pragma unroll
+	for (int k = 0; k < 11; ++k) w[k] = q[k];
+	const uint64_t glob_id = w[0];
+	const uint32_t nqrys_5s = (uint32_t)w[1];
+	const uint32_t nconns_active = (uint32_t)(w[2] >> 32);
+	const uint32_t kb_in = (uint32_t)(w[4] >> 32), kb_out = (uint32_t)w[5], ser_errors = (uint32_t)(w[5] >> 32);
+	const uint32_t curr_state = (uint32_t)((w[9] >> 56) & 0xFF);  // byte 79
+	const uint32_t query_flags = (uint32_t)((w[10] >> 32) & 0xFF); // byte 84
+	atomicAdd((unsigned long long *)&p.counters[CTR_LSTATE_RECORDS], 1ull);
+
+	const uint32_t slot = tbl_lookup(p.gid, glob_id); // listen_tbl_.lookup_single_elem_locked(glob_id, get_uint64_hash(glob_id)) :11183
+	if (slot == GYS_NOSLOT) {
+		atomicAdd((unsigned long long *)&p.counters[CTR_LSTATE_MISSED], 1ull); // nmissed++ :11185-11188
+		return;
+	}
+	if (query_flags == 0xC0u) { // LISTEN_FLAG_DELETE :11194
+		atomicAdd((unsigned long long *)&p.counters[CTR_LSTATE_DELETED], 1ull);
+		*(uint32_t *)(p.svc_state + (size_t)slot * 96 + 88) = 0; // state no longer current
+		return;
+	}
+	if (curr_state > 5u) { // :11250-11256
+		atomicAdd((unsigned long long *)&p.counters[CTR_LSTATE_ERRORS], 1ull);
+		return;
+	}
+	const uint32_t host = p.host_slot ? p.host_slot[i] : p.single_host;
+	int32_t *s = p.host_summ + (size_t)host * 16;
+	// LISTEN_SUMM_STATS::update server/gy_msocket.h:853-865 (per-record integer quotient nqrys_5s_/5)
+	atomicAdd(&s[curr_state], 1);
+	if (nqrys_5s / 5u) atomicAdd(&s[6], (int32_t)(nqrys_5s / 5u));
+	if (nconns_active) atomicAdd(&s[7], (int32_t)nconns_active);
+	if (kb_in) atomicAdd(&s[8], (int32_t)kb_in);
+	if (kb_out) atomicAdd(&s[9], (int32_t)kb_out);
+	if (ser_errors) atomicAdd(&s[10], (int32_t)ser_errors);
+	atomicAdd(&s[11], 1);
+	if (nqrys_5s) atomicAdd(&s[12], 1);
+	// MTCP_LISTENER::set_state server/gy_msocket.h:1410-1437: keep the 88-byte record
+	uint64_t *d = (uint64_t *)(p.svc_state + (size_t)slot * 96);
+#pragma unroll
+	for (int k = 0; k < 11; ++k) d[k] = w[k];
+	d[11] = (uint64_t)p.epoch | ((uint64_t)host << 32);
+}
+
+// ---------------------------------------------------------------------------------------------------- window boundary
+struct PrepP {
+	const int32_t *host_summ;       // [nhosts*16]
+	const gys_host_state *host_state;
+	const uint32_t *host_state_epoch;
+	const uint32_t *host_cluster;
+	uint32_t nhosts;
+	uint32_t epoch;
+	uint32_t *cluster_state;        // arena [max_clusters*12]
+	const uint32_t *hll32;
+	uint8_t *hll8;                  // arena
+};
+
+// CLUSTER_STATE_ONE::update_from_state server/gy_mconnhdlr.cc:16032-16050 for every host whose host state is current
+// (send_cluster_state skips hosts without a recent state, :16068-16070)
+__global__ void k_window_prepare(PrepP p)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < (1u << GYS_HLL_P) / 4u) {
+		const uint4 v = ((const uint4 *)p.hll32)[i];
+		((uint32_t *)p.hll8)[i] = (v.x & 0xFF) | ((v.y & 0xFF) << 8) | ((v.z & 0xFF) << 16) | ((v.w & 0xFF) << 24);
+	}
+	if (i >= p.nhosts) return;
+	if (p.host_state_epoch[i] != p.epoch) return;
+	const gys_host_state st = p.host_state[i];
+	const int32_t *s = p.host_summ + (size_t)i * 16;
+	uint32_t *c = p.cluster_state + (size_t)p.host_cluster[i] * 12;
+	atomicAdd(&c[0], 1u);
+	if (st.ntasks_issue) { atomicAdd(&c[1], st.ntasks_issue); atomicAdd(&c[2], 1u); }
+	if (st.ntasks) atomicAdd(&c[3], st.ntasks);
+	if (st.nlisten_issue) { atomicAdd(&c[4], st.nlisten_issue); atomicAdd(&c[5], 1u); }
+	if (st.nlisten) atomicAdd(&c[6], st.nlisten);
+	atomicAdd(&c[7], (uint32_t)s[6]);
+	atomicAdd(&c[8], (uint32_t)((s[8] + s[9]) / 1024));
+	if (st.cpu_issue) atomicAdd(&c[9], 1u);
+	if (st.mem_issue) atomicAdd(&c[10], 1u);
+}
+
+// GY_HISTOGRAM::add_histogram (common/gy_statistics.h:625-660): all += win; win cleared (GY_HISTOGRAM::clear :630-636).
+// One thread per 16-byte {count,sum} pair (16 per record).
+__global__ __launch_bounds__(256) void k_hist_fold(gys_hist_rec *all, gys_hist_rec *win, uint64_t nrec, int clear_win)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nrec * 16ull) return;
+	const uint32_t k = (uint32_t)(t & 15u);
+	long long *a = (long long *)all + t * 2, *w = (long long *)win + t * 2;
+	const long long w0 = w[0], w1 = w[1];
+	if (k < 15u) {
+		if (w0 | w1) {
+			a[0] += w0;
+			a[1] += w1;
+		}
+		if (clear_win && (w0 | w1)) {
+			w[0] = 0;
+			w[1] = 0;
+		}
+	} else {
+		a[0] += w0;                 // total_count
+		if (a[1] < w1) a[1] = w1;   // max_val_seen
+		if (clear_win) {
+			w[0] = 0;
+			w[1] = INT64_MIN;
+		}
+	}
+}
+
+// standalone keyed histogram add for any hash kind (rows a1/a2)
+__global__ __launch_bounds__(256) void k_hist_add(int kind, gys_hist_rec *hist, uint32_t nkeys, const uint32_t *keyidx, const int32_t *vals, uint64_t n)
+{
+	const HashDef &d = hash_def(kind);
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const uint32_t k = keyidx[i];
+		if (k >= nkeys) continue;
+		const int64_t v = (int64_t)vals[i];
+		const uint32_t b = kind == GYS_RESP_TIME_HASH ? resp_bucket(v) : bucket_of(d, v);
+		gys_hist_rec *h = &hist[k];
+		atomicAdd((unsigned long long *)&h->stats[b].count, 1ull);
+		atomicAdd((unsigned long long *)&h->stats[b].sum, (unsigned long long)v);
+		atomicAdd((unsigned long long *)&h->total_count, 1ull);
+		if (h->max_val_seen < v) atomicMax((long long *)&h->max_val_seen, (long long)v);
+	}
+}
+
+// the per-key percentile scan (GY_HISTOGRAM::get_percentiles for every key, rows a3/a9)
+__global__ __launch_bounds__(256) void k_hist_percentiles(int kind, const gys_hist_rec *hist, uint32_t nkeys, const float *pcts, uint32_t npct, int64_t *out)
+{
+	const HashDef &d = hash_def(kind);
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= (uint64_t)nkeys * npct) return;
+	const uint32_t k = (uint32_t)(t / npct), pi = (uint32_t)(t % npct);
+	int64_t dv, sum;
+	uint64_t cnt;
+	hist_percentile(d, hist[k], pcts[pi], &dv, &sum, &cnt);
+	out[t] = dv;
+}
+
+// top-N candidate filter: services of one host whose state is from the last window, with the ranked metric per kind
+// (LISTEN_TOPN comparators + admission thresholds server/gy_msocket.h:740-790, server/gy_mconnhdlr.cc:11260-11304)
+__global__ __launch_bounds__(256) void k_topn_filter(const uint8_t *svc_state, uint32_t nsvc, uint32_t host, uint32_t epoch, int kind,
+						     uint32_t *out_slot, uint64_t *out_metric, uint32_t *out_count, uint32_t cap)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nsvc) return;
+	const uint64_t *q = (const uint64_t *)(svc_state + (size_t)s * 96);
+	const uint64_t tag = q[11];
+	if ((uint32_t)tag != epoch || (uint32_t)(tag >> 32) != host) return;
+	const uint32_t nqrys = (uint32_t)q[1], nactive = (uint32_t)(q[2] >> 32), kbin = (uint32_t)(q[4] >> 32), kbout = (uint32_t)q[5];
+	const uint32_t delay = (uint32_t)(q[6] >> 32); // tasks_delay_usec_ @52
+	const uint32_t state = (uint32_t)((q[9] >> 56) & 0xFF);
+	uint64_t metric;
+	bool ok;
+	switch (kind) {
+	case 0: ok = state > 2u; metric = ((uint64_t)state << 32) | delay; break;   // is_issue: curr_state_ > STATE_OK; (state, tasks_delay) order
+	case 1: ok = nqrys >= 5u; metric = nqrys; break;
+	case 2: ok = nactive >= 1u; metric = nactive; break;
+	default: ok = (kbin + kbout) > 0u; metric = (uint64_t)kbin + kbout; break;
+	}
+	if (!ok) return;
+	const uint32_t pos = atomicAdd(out_count, 1u);
+	if (pos < cap) {
+		out_slot[pos] = s;
+		out_metric[pos] = metric;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------- synthetic stream generator
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+	x += 0x9E3779B97F4A7C15ull;
+	x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+	x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+	return x ^ (x >> 31);
+}
+
+struct GenP {
+	uint64_t *ev;
+	uint64_t n;
+	uint64_t seed;
+	uint32_t first_host, nhosts, svcs_per_host;
+	const float *zipf_cdf; // [svcs_per_host] or nullptr (uniform)
+	uint64_t per_host;
+};
+
+// SURVEY 8d synthetic response events: host h serves svcs_per_host listeners (port 1024 + s % 60000, netns 0xF0000000 + 4h + s / 60000),
+// latency ms = floor(min(lognormal(mu_s, 1.5), 1e6)), mu_s ~ N(3,1) per service; clients uniform in 10/8, ports 16000..65535.
+__global__ __launch_bounds__(256) void k_gen_resp(GenP g)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
+		uint32_t hrel = (uint32_t)(i / g.per_host);
+		if (hrel >= g.nhosts) hrel = g.nhosts - 1;
+		const uint32_t h = g.first_host + hrel;
+		const uint64_t r0 = splitmix64(g.seed ^ (i * 0x9E3779B97F4A7C15ull));
+		const uint64_t r1 = splitmix64(r0), r2 = splitmix64(r1);
+		uint32_t s;
+		if (g.zipf_cdf) {
+			const float u = (float)(r0 >> 40) * (1.0f / 16777216.0f);
+			uint32_t lo = 0, hi = g.svcs_per_host - 1;
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (g.zipf_cdf[mid] < u) lo = mid + 1; else hi = mid;
+			}
+			s = lo;
+		} else {
+			s = (uint32_t)((r0 >> 32) % g.svcs_per_host);
+		}
+		// per-service mu ~ N(3,1) from a hash of (h,s); event latency lognormal(mu, 1.5) by Box-Muller
+		const uint64_t hs = splitmix64(((uint64_t)h << 20) + s + 0x1234567ull);
+		const float u1 = ((float)(hs >> 40) + 0.5f) * (1.0f / 16777216.0f), u2 = (float)((hs >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
+		const float mu = 3.0f + sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+		const float v1 = ((float)(r1 >> 40) + 0.5f) * (1.0f / 16777216.0f), v2 = (float)((r1 >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
+		const float z = sqrtf(-2.0f * __logf(v1)) * __cosf(6.2831853f * v2);
+		float lat = __expf(mu + 1.5f * z);
+		if (!(lat < 1.0e6f)) lat = 1.0e6f;
+		const uint32_t ms = (uint32_t)lat;
+		const uint32_t saddr = __builtin_bswap32(0x0A000000u | (h & 0xFFFFFFu)); // server 10.x.y.z, network order as ip32_be
+		const uint32_t daddr = __builtin_bswap32(0x0A000000u | (uint32_t)(r2 & 0xFFFFFFu));
+		const uint32_t netns = 0xF0000000u + 4u * h + s / 60000u;
+		const uint16_t sport = (uint16_t)(1024u + s % 60000u);
+		const uint16_t dport = (uint16_t)(16000u + (uint32_t)((r2 >> 24) % 49536u));
+		const uint32_t lrcv = (uint32_t)(r2 >> 40) * 7u;
+		const uint32_t lsnd = lrcv + ms;
+		g.ev[3 * i] = (uint64_t)saddr | ((uint64_t)daddr << 32);
+		g.ev[3 * i + 1] = (uint64_t)netns | ((uint64_t)bswap16(sport) << 32) | ((uint64_t)bswap16(dport) << 48);
+		g.ev[3 * i + 2] = (uint64_t)lsnd | ((uint64_t)lrcv << 32);
+	}
+}
+
+} // namespace gys

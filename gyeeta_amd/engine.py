@@ -1,0 +1,298 @@
+"""Host-side wrapper around the C ABI (plumbing for tests / bench).  It mirrors the reference's aggregation entry points
+(MCONN_HANDLER::partha_tcp_conn_info / partha_listener_state / send_cluster_state, server/gy_mconnhdlr.h:2091-2156) by name and
+argument meaning; the multi-GPU step (one exchange per window) is an all-reduce of the fixed-size sketch registers
+through torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests)."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+_TORCH_DTYPES = None
+
+
+def _torch_dtypes():
+    global _TORCH_DTYPES
+    if _TORCH_DTYPES is None:
+        import torch
+        _TORCH_DTYPES = {0: torch.uint8, 1: torch.int32, 2: torch.int64}  # u32 sums wrap identically as int32
+    return _TORCH_DTYPES
+
+
+def allreduce_sections(sections, group=None):
+    """sections: list of (tensor, op) with op 0 = MAX, 1 = SUM.  One collective per register family (HLL = max on u8,
+    CMS / histogram / cluster counters = sum); no-op when torch.distributed is not initialised or world_size == 1."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t, op in sections:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 0 else dist.ReduceOp.SUM, group=group)
+
+
+def mid_buf(machine_id):
+    assert len(machine_id) == 16
+    return (C.c_uint8 * 16)(*machine_id)
+
+
+class SketchEngine:
+    def __init__(self, max_hosts, max_services, max_clusters=16, enable_tdigest=True, svc_hll_p=0, max_batch_events=1 << 20,
+                 rank=0, nranks=1, device=None, torch_arena=True):
+        import torch
+        self.L = capi.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("SketchEngine needs a HIP device: the sketch engine has no CPU path")
+        self.torch = torch
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device)
+        cfg = capi.Config()
+        cfg.struct_size = C.sizeof(capi.Config)
+        cfg.device = int(device)
+        cfg.rank, cfg.nranks = rank, nranks
+        cfg.max_hosts, cfg.max_services, cfg.max_clusters = max_hosts, max_services, max_clusters
+        cfg.enable_tdigest = 1 if enable_tdigest else 0
+        cfg.svc_hll_p = svc_hll_p
+        cfg.max_batch_events = max_batch_events
+        with torch.cuda.device(self.device):
+            cfg.stream = torch.cuda.current_stream().cuda_stream
+            self.arena = None
+            if torch_arena:
+                nbytes = self.L.gys_reduce_arena_bytes(C.byref(cfg))
+                self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+                cfg.reduce_arena = self.arena.data_ptr()
+                cfg.reduce_arena_bytes = nbytes
+            h = C.c_void_p()
+            capi.check(self.L.gys_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.cfg = cfg
+        self.rank, self.nranks = rank, nranks
+        self._sections = None
+
+    def close(self):
+        if self.h:
+            self.L.gys_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- registration
+    def register_cluster(self, name):
+        idx = C.c_uint32()
+        capi.check(self.L.gys_register_cluster(self.h, name.encode(), C.byref(idx)))
+        return idx.value
+
+    def register_host(self, machine_id, cluster="cluster0"):
+        slot = C.c_uint32()
+        capi.check(self.L.gys_register_host(self.h, mid_buf(machine_id), cluster.encode(), C.byref(slot)))
+        return slot.value
+
+    def owns(self, machine_id):
+        return self.L.gys_shard_of(mid_buf(machine_id), self.nranks) == self.rank
+
+    def register_listeners(self, machine_id, glob_ids, netns, ports, comm=b"svc"):
+        n = len(glob_ids)
+        arr = (capi.ListenerInfo * n)()
+        for i in range(n):
+            arr[i].glob_id = int(glob_ids[i])
+            arr[i].netns = int(netns[i])
+            arr[i].port = int(ports[i])
+            arr[i].comm = comm
+        first = C.c_uint32()
+        capi.check(self.L.gys_register_listeners(self.h, mid_buf(machine_id), arr, n, C.byref(first)))
+        return first.value
+
+    def register_listeners_np(self, machine_id, glob_ids, netns, ports):
+        """bulk variant: fills the gys_listener_info array through numpy (no per-element python loop)"""
+        n = len(glob_ids)
+        dt = np.dtype([("glob_id", "<u8"), ("netns", "<u4"), ("port", "<u2"), ("reserved", "<u2"), ("comm", "S16")])
+        a = np.zeros(n, dtype=dt)
+        a["glob_id"], a["netns"], a["port"], a["comm"] = glob_ids, netns, ports, b"svc"
+        first = C.c_uint32()
+        capi.check(self.L.gys_register_listeners(self.h, mid_buf(machine_id), a.ctypes.data_as(C.POINTER(capi.ListenerInfo)), n, C.byref(first)))
+        return first.value
+
+    # ---------------------------------------------------------------- ingest (names follow the reference entry points)
+    def handle_resp_events(self, machine_id, events):
+        """TCP_SOCK_HANDLER::handle_ipv4_resp_event for a host batch (numpy RESP_EVENT array or bytes)"""
+        b = events.tobytes() if hasattr(events, "tobytes") else bytes(events)
+        capi.check(self.L.gys_ingest_resp_events(self.h, mid_buf(machine_id), b, len(b) // 24))
+
+    def handle_resp_events_dev(self, segs, d_ev, nevents):
+        capi.check(self.L.gys_ingest_resp_events_dev(self.h, segs, len(segs), C.c_void_p(d_ev), nevents))
+
+    def partha_tcp_conn_info(self, machine_id, batch_bytes, nconns):
+        """MCONN_HANDLER::partha_tcp_conn_info(partha, pone, nconns, pendptr)"""
+        buf = np.frombuffer(batch_bytes, dtype=np.uint8)
+        buf = np.require(buf, requirements=["A", "C"])
+        p = buf.ctypes.data
+        capi.check(self.L.gys_ingest_tcp_conn(self.h, mid_buf(machine_id), C.c_void_p(p), nconns, C.c_void_p(p + len(buf))))
+
+    def partha_listener_state(self, machine_id, batch_bytes, nrecs):
+        """MCONN_HANDLER::partha_listener_state(partha, pone, nconns, pendptr)"""
+        buf = np.frombuffer(batch_bytes, dtype=np.uint8)
+        buf = np.require(buf, requirements=["A", "C"])
+        p = buf.ctypes.data
+        capi.check(self.L.gys_ingest_listener_state(self.h, mid_buf(machine_id), C.c_void_p(p), nrecs, C.c_void_p(p + len(buf))))
+
+    def handle_host_state(self, machine_id, ntasks_issue=0, ntasks=0, nlisten_issue=0, nlisten=0, cpu_issue=0, mem_issue=0, curr_state=1):
+        st = capi.HostState(ntasks_issue, ntasks, nlisten_issue, nlisten, cpu_issue, mem_issue, curr_state, 0)
+        capi.check(self.L.gys_ingest_host_state(self.h, mid_buf(machine_id), C.byref(st)))
+
+    # ---------------------------------------------------------------- window boundary
+    def reduce_sections(self):
+        if self._sections is None:
+            secs = (capi.ReduceSection * 4)()
+            n = C.c_uint32()
+            capi.check(self.L.gys_reduce_sections(self.h, secs, C.byref(n)))
+            out = []
+            if self.arena is not None:
+                base = self.arena.data_ptr()
+                dts = _torch_dtypes()
+                for i in range(n.value):
+                    s = secs[i]
+                    esz = {0: 1, 1: 4, 2: 8}[s.dtype]
+                    off = s.dev_ptr - base
+                    out.append((self.arena[off:off + s.nelems * esz].view(dts[s.dtype]), s.op))
+            self._sections = out
+        return self._sections
+
+    def send_cluster_state(self, tusec=0, group=None):
+        """MCONN_HANDLER::send_cluster_state + SHCONN_HANDLER::aggregate_cluster_state: close the window on every rank."""
+        capi.check(self.L.gys_window_prepare(self.h, tusec))
+        if self.nranks > 1:
+            if self.arena is None:
+                raise RuntimeError("multi-rank reduce needs torch_arena=True")
+            allreduce_sections(self.reduce_sections(), group)
+        capi.check(self.L.gys_window_finish(self.h))
+
+    window_close = send_cluster_state
+
+    def sync(self):
+        capi.check(self.L.gys_sync(self.h))
+
+    # ---------------------------------------------------------------- queries / exports
+    def svcsumm(self, machine_id):
+        out = capi.SvcSumm()
+        capi.check(self.L.gys_query_svcsumm(self.h, mid_buf(machine_id), C.byref(out)))
+        return out
+
+    def clusterstate(self, name):
+        out = capi.ClusterState()
+        capi.check(self.L.gys_query_clusterstate(self.h, name.encode(), C.byref(out)))
+        return out
+
+    def hist_percentiles(self, glob_id, pcts, which=1):
+        pd = (capi.HistData * len(pcts))()
+        for i, p in enumerate(pcts):
+            pd[i].percentile = p
+        total, maxv, avg = C.c_uint64(), C.c_int64(), C.c_float()
+        capi.check(self.L.gys_query_hist_percentiles(self.h, int(glob_id), which, pd, len(pcts), C.byref(total), C.byref(maxv), C.byref(avg)))
+        return [d.data_value for d in pd], [d.sum for d in pd], [d.count for d in pd], total.value, maxv.value, avg.value
+
+    def quantiles(self, glob_id, qs):
+        q = (C.c_double * len(qs))(*qs)
+        out = (C.c_double * len(qs))()
+        capi.check(self.L.gys_query_quantiles(self.h, int(glob_id), q, len(qs), out))
+        return list(out)
+
+    def distinct_flows(self):
+        out = C.c_double()
+        capi.check(self.L.gys_query_distinct_flows(self.h, C.byref(out)))
+        return out.value
+
+    def cms(self, glob_id, which=0):
+        out = C.c_uint64()
+        capi.check(self.L.gys_query_cms(self.h, int(glob_id), which, C.byref(out)))
+        return out.value
+
+    def topn(self, machine_id, kind):
+        out = (capi.TopnEntry * capi.TOPN)()
+        n = C.c_uint32()
+        capi.check(self.L.gys_query_topn(self.h, mid_buf(machine_id), kind, out, C.byref(n)))
+        return [(out[i].glob_id, out[i].metric, bytes(out[i].state)) for i in range(n.value)]
+
+    def num_services(self):
+        return self.L.gys_num_services(self.h)
+
+    def lookup(self, glob_id):
+        s = C.c_uint32()
+        capi.check(self.L.gys_lookup_service(self.h, int(glob_id), C.byref(s)))
+        return s.value
+
+    def export_hist(self, which, first=0, n=None):
+        n = self.num_services() - first if n is None else n
+        out = np.zeros((n, 16, 2), dtype=np.int64)  # [slot][bucket]{count,sum}; [slot][15] = {total_count, max_val_seen}
+        capi.check(self.L.gys_export_hist(self.h, which, first, n, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def export_conn_bitmap(self, first=0, n=None):
+        n = self.num_services() - first if n is None else n
+        out = np.zeros((n, 32), dtype=np.uint16)
+        capi.check(self.L.gys_export_conn_bitmap(self.h, first, n, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def export_hll(self):
+        out = np.zeros(1 << capi.HLL_P, dtype=np.uint8)
+        capi.check(self.L.gys_export_hll(self.h, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def export_cms(self, which=0):
+        out = np.zeros((capi.CMS_D, capi.CMS_W), dtype=np.uint32 if which == 0 else np.int64)
+        capi.check(self.L.gys_export_cms(self.h, which, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def export_global_hist(self):
+        out = capi.HistRec()
+        capi.check(self.L.gys_export_global_hist(self.h, C.byref(out)))
+        return out
+
+    def export_tdigest(self, first=0, n=None):
+        n = self.num_services() - first if n is None else n
+        sums = np.zeros((n, capi.TD_NB), dtype=np.int64)
+        cnts = np.zeros((n, capi.TD_NB), dtype=np.uint32)
+        mm = np.zeros((n, 2), dtype=np.int32)
+        capi.check(self.L.gys_export_tdigest(self.h, first, n, C.c_void_p(sums.ctypes.data), C.c_void_p(cnts.ctypes.data), C.c_void_p(mm.ctypes.data)))
+        return sums, cnts, mm
+
+    def export_svc_counters(self, first=0, n=None):
+        n = self.num_services() - first if n is None else n
+        out = np.zeros((n, 4), dtype=np.uint64)
+        capi.check(self.L.gys_export_svc_counters(self.h, first, n, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def export_svc_hll(self, first=0, n=None):
+        n = self.num_services() - first if n is None else n
+        out = np.zeros((n, 1 << self.cfg.svc_hll_p), dtype=np.uint8)
+        capi.check(self.L.gys_export_svc_hll(self.h, first, n, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def counters(self):
+        out = capi.Counters()
+        capi.check(self.L.gys_get_counters(self.h, C.byref(out)))
+        return {n: getattr(out, n) for n, _ in out._fields_}
+
+    # ---------------------------------------------------------------- measurement helpers
+    def profile(self, on=True):
+        capi.check(self.L.gys_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        capi.check(self.L.gys_profile_reset(self.h))
+
+    def profile_get(self):
+        buf = C.create_string_buffer(1024)
+        capi.check(self.L.gys_profile_names(self.h, buf, 1024))
+        out = {}
+        for name in filter(None, buf.value.decode().split(",")):
+            ms, n = C.c_double(), C.c_uint64()
+            self.L.gys_profile_get(self.h, name.encode(), C.byref(ms), C.byref(n))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def gen_resp_events(self, d_ev, nevents, seed, first_host, nhosts, svcs_per_host, zipf_milli=0):
+        segs = (capi.RespSeg * nhosts)()
+        capi.check(self.L.gys_gen_resp_events_dev(self.h, C.c_void_p(d_ev), nevents, seed, first_host, nhosts, svcs_per_host, zipf_milli, segs))
+        return segs

@@ -1,0 +1,275 @@
+/*
+ * gysketch.h -- C ABI of libgysketch.so, the MI355X-native streaming-sketch aggregation engine that replaces the inside of
+ * Gyeeta's madhava/shyama roll-up path.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Each entry point names the reference interface it replaces (file:line under the Gyeeta source tree).  The reference has no
+ * FFI layer: its boundary is a set of C++ member functions called from the L2 dispatch switch
+ * (server/gy_mconnhdlr.cc:4700-4792); gyeeta_amd/csrc/gys_mconn_shim.hpp gives those same C++ signatures on top of this ABI
+ * and INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - All functions return 0 (GYS_OK) or a negative GYS_ERR_* code; nothing throws across the boundary
+ *     (reference: bool return + GY_CATCH_EXCEPTION, gy_mconnhdlr.cc:4771-4774).
+ *   - "batch"/"pend" pairs follow the reference iteration convention
+ *     for (i < n && (uint8_t*)p < pendptr; p += p->get_elem_size())   (gy_mconnhdlr.cc:9130, :11175).
+ *     Host buffers are only read during the call (the reference's DB_WRITE_ARR owns them, gy_mconnhdlr.h:350-442).
+ *   - *_dev variants take DEVICE pointers to batches already resident in HBM (the measured configuration).
+ *   - A context is bound to one GPU and one HIP stream; calls on one context must be serialised by the caller
+ *     (one context per L2 thread pool, or an external mutex; the reference serialises per host with connlistenmutex_).
+ */
+#ifndef GYSKETCH_H
+#define GYSKETCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GYS_ABI_VERSION 1
+
+enum {
+	GYS_OK = 0,
+	GYS_ERR_INVAL = -1,     /* bad argument / malformed batch */
+	GYS_ERR_NOMEM = -2,     /* capacity (hosts, services, batch staging) exhausted */
+	GYS_ERR_HIP = -3,       /* HIP runtime error (gys_last_error() has the text) */
+	GYS_ERR_NOTFOUND = -4,  /* unknown host / service */
+	GYS_ERR_NOT_OWNER = -5, /* host is sharded to another rank (jhash2(machine_id) % nranks != rank) */
+	GYS_ERR_STATE = -6      /* call sequence error (e.g. window_finish without window_prepare) */
+};
+
+/* bucket-hash kinds == the reference's hash classes, common/gy_statistics.h:1565-2063 */
+enum {
+	GYS_RESP_TIME_HASH = 0,   /* :1674 */
+	GYS_SEMI_LOG_HASH = 1,    /* :1729 */
+	GYS_SEMI_LOG_HASH_LO = 2, /* :1782 */
+	GYS_DURATION_HASH = 3,    /* :1835 */
+	GYS_HASH_10_5000 = 4,     /* :1908 */
+	GYS_HASH_5_250 = 5,       /* :1960 */
+	GYS_HASH_1_3000 = 6,      /* :2013 */
+	GYS_PERCENT_HASH = 7,     /* :1624 */
+	GYS_NUM_HASH_KINDS = 8
+};
+
+#define GYS_MAX_BUCKETS 16 /* all reference hash classes have <= 15 buckets; records are padded to 16 slots */
+#define GYS_TD_NB 100      /* t-digest clusters per key (delta = 100, common/gy_query_common.cc:1855) */
+#define GYS_HLL_P 14       /* global distinct-flow HLL precision: 16384 u8 registers */
+#define GYS_CMS_D 4
+#define GYS_CMS_W 65536
+#define GYS_NSTATES 6      /* OBJ_STATE_E STATE_IDLE..STATE_DOWN, common/gy_json_field_maps.h:242-250 */
+#define GYS_TOPN 10        /* per-host top-N, server/gy_mconnhdlr.h:961 */
+
+typedef struct gys_ctx gys_ctx;
+
+typedef struct {
+	uint32_t struct_size;      /* = sizeof(gys_config) */
+	int32_t device;            /* HIP device ordinal, -1 = current device */
+	uint32_t rank, nranks;     /* shard of the host-id space owned by this context; 0,1 for single GPU */
+	uint32_t max_hosts;        /* partha capacity (reference: MAX_PARTHA_PER_MADHAVA = 512 per madhava) */
+	uint32_t max_services;     /* listener capacity across all hosts */
+	uint32_t max_clusters;     /* cluster-name capacity (MS_CLUSTER_STATE::MAX_NUM_CLUSTERS = 512) */
+	uint32_t enable_tdigest;   /* per-service t-digest of response times */
+	uint32_t svc_hll_p;        /* per-service distinct-client HLL precision (0 = off, 4..10) */
+	uint32_t reserved0;
+	uint64_t max_batch_events; /* largest resp-event batch one ingest call may carry (t-digest staging capacity) */
+	void *stream;              /* hipStream_t to run on; NULL = the context creates its own */
+	void *reduce_arena;        /* optional caller-owned DEVICE buffer for the all-reducible registers (e.g. a torch tensor so */
+	uint64_t reduce_arena_bytes; /* that torch.distributed/RCCL can reduce it in place); NULL = the context allocates it  */
+} gys_config;
+
+/* -------------------------------------------------------------------------------------------------------------------
+ * lifecycle */
+uint32_t gys_abi_version(void);
+const char *gys_last_error(void);
+uint64_t gys_reduce_arena_bytes(const gys_config *cfg); /* size the caller must provide in cfg->reduce_arena */
+int gys_create(const gys_config *cfg, gys_ctx **out);
+void gys_destroy(gys_ctx *ctx);
+int gys_sync(gys_ctx *ctx); /* hipStreamSynchronize on the context stream */
+
+/* host-id shard function: GY_MACHINE_ID::get_hash() % nshards  (common/gy_sys_hardware.h:82-85) */
+uint32_t gys_machine_id_hash(const uint8_t machine_id[16]);
+uint32_t gys_shard_of(const uint8_t machine_id[16], uint32_t nshards);
+
+/* -------------------------------------------------------------------------------------------------------------------
+ * registration (control-plane facts the data path needs; the reference learns them from PM_CONNECT / NOTIFY_NEW_LISTENER,
+ * server/gy_mconnhdlr.cc partha registration + handle_add_listener -- out of scope beyond these two calls) */
+/* Cluster indices are assigned in first-seen order per context; in a multi-rank job call gys_register_cluster for every cluster
+ * name in the SAME order on every rank before registering hosts, so that the all-reduced cluster rows line up. */
+int gys_register_cluster(gys_ctx *ctx, const char *cluster_name, uint32_t *cluster_idx);
+int gys_register_host(gys_ctx *ctx, const uint8_t machine_id[16], const char *cluster_name, uint32_t *host_slot);
+
+typedef struct {
+	uint64_t glob_id;   /* TCP_LISTENER::glob_id_ (opaque 64-bit id on the wire) */
+	uint32_t netns;     /* network namespace inode as carried by the eBPF tuple (partha/gy_ebpf_kernel_struct.h:28-35) */
+	uint16_t port;      /* listener port, host order */
+	uint16_t reserved;
+	char comm[16];      /* TASK_COMM_LEN process name (LISTEN_TOPN::comm_) */
+} gys_listener_info;
+
+/* assigns consecutive service slots [*first_slot, *first_slot + n) */
+int gys_register_listeners(gys_ctx *ctx, const uint8_t machine_id[16], const gys_listener_info *arr, uint32_t n, uint32_t *first_slot);
+
+/* -------------------------------------------------------------------------------------------------------------------
+ * ingest */
+
+/* Raw response events in the eBPF layout tcp_ipv4_resp_event_t (common/gy_ebpf_kernel.h:106-111, 24 bytes: saddr,daddr,netns,
+ * sport,dport (network order), lsndtime, lrcvtime).  Replaces TCP_SOCK_HANDLER::handle_ipv4_resp_event + handle_tcp_resp_event
+ * (common/gy_socket_stat.cc:1517-1677): per event RESP_TIME_HASH bucket + histogram add + CONN_BITMAP + query count, plus the new
+ * t-digest / HLL / CMS sketches. */
+int gys_ingest_resp_events(gys_ctx *ctx, const uint8_t machine_id[16], const void *ev24, uint32_t nevents);
+
+typedef struct {
+	uint32_t host_slot;   /* from gys_register_host */
+	uint32_t reserved;
+	uint64_t first_event; /* index of this host's first event; segments sorted ascending, host's events contiguous */
+} gys_resp_seg;
+
+/* device-resident multi-host batch: d_ev24 is a DEVICE pointer to nevents 24-byte events; segs is a HOST array */
+int gys_ingest_resp_events_dev(gys_ctx *ctx, const gys_resp_seg *segs, uint32_t nsegs, const void *d_ev24, uint64_t nevents);
+
+/* Replaces MCONN_HANDLER::partha_tcp_conn_info(partha, TCP_CONN_NOTIFY *pone, int nconns, uint8_t *pendptr, ...)
+ * (server/gy_mconnhdlr.h:2091, .cc:9052-9444): flow key PAIR_IP_PORT(nat_cli_, nat_ser_) (.cc:8707) -> distinct-flow HLL;
+ * per-service connection / byte counters (connlistenmap_ roll-up .cc:9133-9319) -> exact per-service counters + CMS. */
+int gys_ingest_tcp_conn(gys_ctx *ctx, const uint8_t machine_id[16], const void *batch, uint32_t nconns, const void *pend);
+/* device-resident: d_offsets[i] = byte offset of record i inside d_batch (records are variable stride: get_elem_size()) */
+int gys_ingest_tcp_conn_dev(gys_ctx *ctx, const void *d_batch, const uint32_t *d_offsets, uint32_t nconns);
+
+/* Replaces MCONN_HANDLER::partha_listener_state(partha, const LISTENER_STATE_NOTIFY *pone, int nconns, uint8_t *pendptr, ...)
+ * (server/gy_mconnhdlr.h:2129, .cc:10993-11412): per record glob_id probe, LISTEN_SUMM_STATS::update, set_state, top-N. */
+int gys_ingest_listener_state(gys_ctx *ctx, const uint8_t machine_id[16], const void *batch, uint32_t nrecs, const void *pend);
+/* device-resident multi-host: d_host_slot[i] = host of record i */
+int gys_ingest_listener_state_dev(gys_ctx *ctx, const void *d_batch, const uint32_t *d_offsets, const uint32_t *d_host_slot,
+				  uint32_t nrecs);
+
+typedef struct {
+	uint32_t ntasks_issue, ntasks, nlisten_issue, nlisten; /* comm::HOST_STATE_NOTIFY fields used by update_from_state */
+	uint8_t cpu_issue, mem_issue, curr_state, reserved;
+} gys_host_state;
+/* Replaces the host_state_ store read by MCONN_HANDLER::send_cluster_state (server/gy_mconnhdlr.cc:16052-16075) */
+int gys_ingest_host_state(gys_ctx *ctx, const uint8_t machine_id[16], const gys_host_state *st);
+
+/* -------------------------------------------------------------------------------------------------------------------
+ * window boundary (the reference's 5 s cadence: send_cluster_state -> handle_cluster_state -> aggregate_cluster_state,
+ * server/gy_mconnhdlr.cc:16052, server/gy_shconnhdlr.cc:4554-4640)
+ *
+ *   gys_window_prepare : local roll-ups are written into the reduce arena (cluster STATE_ONE sums, global histogram, HLL, CMS)
+ *   <caller all-reduces every gys_reduce_section across ranks: RCCL over xGMI, or nothing for a single GPU>
+ *   gys_window_finish  : consumes the reduced arena (global answers), folds window histograms into the all-time ones,
+ *                        clears window state.
+ */
+typedef struct {
+	void *dev_ptr;
+	uint64_t nelems;
+	uint32_t dtype; /* 0 = u8, 1 = u32, 2 = i64 */
+	uint32_t op;    /* 0 = MAX, 1 = SUM */
+} gys_reduce_section;
+
+int gys_reduce_sections(gys_ctx *ctx, gys_reduce_section out[4], uint32_t *nsections);
+int gys_window_prepare(gys_ctx *ctx, uint64_t tusec);
+int gys_window_finish(gys_ctx *ctx);
+
+/* -------------------------------------------------------------------------------------------------------------------
+ * queries (result shapes: common/gy_json_field_maps.h svcsumm :1396-1416, clusterstate :2162-2180, svcstate :1102-1135) */
+
+typedef struct {
+	int32_t nstates[GYS_NSTATES];
+	int32_t tot_qps, tot_act_conn, tot_kb_inbound, tot_kb_outbound, tot_ser_errors, nlisteners, nactive;
+} gys_svcsumm; /* == LISTEN_SUMM_STATS<int>, server/gy_msocket.h:840-851 */
+
+typedef struct {
+	uint32_t nhosts, ntasks_issue, ntaskissue_hosts, ntasks, nsvc_issue, nsvcissue_hosts, nsvc, total_qps, svc_net_mb,
+		ncpu_issue, nmem_issue;
+} gys_cluster_state; /* == comm::MS_CLUSTER_STATE::STATE_ONE, common/gy_comm_proto.h:3183-3197 */
+
+typedef struct {
+	int64_t data_value; /* bucket ceiling, get_bucket_max_threshold (common/gy_statistics.h:500-515) */
+	int64_t sum;
+	uint64_t count;
+	float percentile;
+	uint32_t reserved;
+} gys_hist_data; /* == HIST_DATA, common/gy_statistics.h:473-484 */
+
+typedef struct {
+	uint64_t count;
+	int64_t sum;
+} gys_hist_serial; /* == HIST_SERIAL, common/gy_statistics.h:458-468 */
+
+typedef struct {
+	gys_hist_serial stats[GYS_MAX_BUCKETS - 1]; /* 15 buckets */
+	uint64_t total_count;
+	int64_t max_val_seen;
+} gys_hist_rec; /* 256 bytes: the arithmetic state of GY_HISTOGRAM<int64_t,RESP_TIME_HASH> (280 B incl. clocks) */
+
+int gys_query_svcsumm(gys_ctx *ctx, const uint8_t machine_id[16], gys_svcsumm *out);      /* web_curr_listener_summ, gy_mnodehandle.cc:1628 */
+int gys_query_clusterstate(gys_ctx *ctx, const char *cluster_name, gys_cluster_state *out); /* aggregate_cluster_state result */
+/* GY_HISTOGRAM::get_percentiles (common/gy_statistics.h:707-791) of one service; which: 0 = current window, 1 = all-time */
+int gys_query_hist_percentiles(gys_ctx *ctx, uint64_t glob_id, int which, gys_hist_data *pdata, uint32_t npct, uint64_t *total_count,
+			       int64_t *max_val, float *pavg);
+/* t-digest quantiles (q in [0,1]) of one service's response times */
+int gys_query_quantiles(gys_ctx *ctx, uint64_t glob_id, const double *q, uint32_t nq, double *out);
+/* distinct flows seen (global HLL over PAIR_IP_PORT keys; after gys_window_finish: the all-rank estimate) */
+int gys_query_distinct_flows(gys_ctx *ctx, double *out);
+/* Count-Min estimate for a service key: events (which = 0) or bytes (which = 1) in the last finished window */
+int gys_query_cms(gys_ctx *ctx, uint64_t glob_id, int which, uint64_t *out);
+
+typedef struct {
+	uint64_t glob_id;
+	uint32_t host_slot;
+	uint32_t metric; /* the ranked value */
+	uint8_t state[88]; /* the LISTENER_STATE_NOTIFY record (common/gy_comm_proto.h:2183-2254) as last ingested */
+} gys_topn_entry;
+/* per-host top-N of the last window by kind: 0 issue, 1 qps, 2 active conns, 3 net (LISTEN_TOPN comparators gy_msocket.h:720-796) */
+int gys_query_topn(gys_ctx *ctx, const uint8_t machine_id[16], int kind, gys_topn_entry out[GYS_TOPN], uint32_t *nout);
+
+/* The "per-key scan" (TCP_SOCK_HANDLER::listener_stats_update percentile part, common/gy_socket_stat.cc:4226-4230) over ALL services
+ * on the GPU: for service slot s and percentile i, d_out[s*npct + i] = bucket ceiling; which as above.  d_out is a DEVICE pointer. */
+int gys_scan_percentiles_dev(gys_ctx *ctx, int which, const float *pcts, uint32_t npct, int64_t *d_out);
+
+/* -------------------------------------------------------------------------------------------------------------------
+ * parity / checkpoint exports (host destination buffers) -- GY_HISTOGRAM::get_serialized analogue (gy_statistics.h:665-673) */
+uint32_t gys_num_services(gys_ctx *ctx);
+uint32_t gys_num_hosts(gys_ctx *ctx);
+int gys_lookup_service(gys_ctx *ctx, uint64_t glob_id, uint32_t *slot);
+int gys_export_hist(gys_ctx *ctx, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out);
+int gys_export_conn_bitmap(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint16_t *out /* [nslots*32] */);
+int gys_export_hll(gys_ctx *ctx, uint8_t *out /* [1 << GYS_HLL_P] */);
+int gys_export_cms(gys_ctx *ctx, int which, void *out /* which 0: u32[D*W]; which 1: i64[D*W] */);
+int gys_export_tdigest(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, int64_t *sums /* [nslots*100] */, uint32_t *cnts /* [nslots*100] */,
+		       int32_t *minmax /* [nslots*2] */);
+int gys_export_svc_counters(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint64_t *out /* [nslots*4]: nconn, nclose, bytes_sent, bytes_rcvd */);
+int gys_export_global_hist(gys_ctx *ctx, gys_hist_rec *out); /* all-service response histogram of the last finished window (all ranks) */
+int gys_export_svc_hll(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint8_t *out /* [nslots << svc_hll_p] */);
+
+typedef struct {
+	uint64_t resp_events, resp_dropped_range, resp_dropped_nolistener;
+	uint64_t conn_events, conn_unknown_service;
+	uint64_t lstate_records, lstate_missed, lstate_errors, lstate_deleted;
+} gys_counters;
+int gys_get_counters(gys_ctx *ctx, gys_counters *out);
+
+/* -------------------------------------------------------------------------------------------------------------------
+ * standalone keyed histogram op (rows a1/a2/a4 of SURVEY 8a for ANY hash kind): nkeys histograms of `kind`, caller-owned DEVICE
+ * memory hist[nkeys] (zero-initialised except max_val_seen = type min, see gys_hist_init_dev). */
+int gys_hist_init_dev(gys_ctx *ctx, int kind, gys_hist_rec *d_hist, uint32_t nkeys);
+int gys_hist_add_dev(gys_ctx *ctx, int kind, gys_hist_rec *d_hist, uint32_t nkeys, const uint32_t *d_keyidx, const int32_t *d_vals, uint64_t n);
+int gys_hist_merge_dev(gys_ctx *ctx, gys_hist_rec *d_dst, const gys_hist_rec *d_src, uint32_t nkeys); /* add_histogram :625 */
+int gys_hist_percentiles_dev(gys_ctx *ctx, int kind, const gys_hist_rec *d_hist, uint32_t nkeys, const float *pcts, uint32_t npct,
+			     int64_t *d_out);
+
+/* -------------------------------------------------------------------------------------------------------------------
+ * measurement helpers: per-kernel HIP-event timing on the context stream */
+int gys_profile_enable(gys_ctx *ctx, int on);
+int gys_profile_reset(gys_ctx *ctx);
+/* name: "resp_pass1", "scan", "scatter", "digest_small", "digest_huge", "conn", "lstate", ...; returns accumulated ms + launches */
+int gys_profile_get(gys_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
+int gys_profile_names(gys_ctx *ctx, char *buf, size_t buflen); /* comma separated */
+
+/* synthetic stream generators running ON the GPU (bench/test plumbing).  They write into caller DEVICE buffers. */
+int gys_gen_resp_events_dev(gys_ctx *ctx, void *d_ev24, uint64_t nevents, uint64_t seed, uint32_t first_host, uint32_t nhosts,
+			    uint32_t svcs_per_host, uint32_t zipf_milli /* 0 = uniform, else s*1000 */, gys_resp_seg *segs_out /* host, nhosts */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

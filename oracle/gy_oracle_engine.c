@@ -1,0 +1,231 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- sequential CPU restatement of the whole response-event hot path as ONE loop, the way the
+ * reference runs it on a host core (common/gy_socket_stat.cc:1517-1677: filter -> listener lookup -> RESP_TIME_HASH bucket ->
+ * histogram add -> CONN_BITMAP -> query count), extended with the builder-defined sketches (gy_oracle.c) so that every
+ * register the GPU produces has a CPU twin.  Used by the parity tests as the checker and by bench.py as the "port" cpu_baseline.
+ *
+ * The listener table is an open-addressing table probed with the reference's get_uint64_hash (stand-in for the liburcu
+ * RCU_HASH_TABLE, which is not installable here -- SURVEY 8c / A.5).
+ */
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gy_oracle.h"
+
+typedef struct gyo_engine {
+	uint32_t max_services, nsvc, mask;
+	int enable_td;
+	uint64_t *keys; /* listener keys, ~0 = empty */
+	uint32_t *vals;
+	uint64_t *svc_gid;
+	gyo_hist_serial *hist; /* [nsvc*16]; slot 15 = {total_count, (int64) max_val_seen} */
+	uint16_t *bitmap;      /* [nsvc*32] */
+	uint8_t hll[GYO_HLL_M];
+	uint32_t *cms;         /* [D*W] */
+	gyo_hist_serial ghist[16];
+	int64_t gmax;
+	gyo_tdigest *td;
+	/* per-batch staging for the digest: values bucketed by key (counting sort) */
+	uint32_t *bcnt, *boff;
+	uint64_t counters[4]; /* events, dropped_range, dropped_nolistener, accepted */
+} gyo_engine;
+
+static uint64_t lkey(uint32_t host, uint32_t netns, uint16_t port) { return ((uint64_t)host << 48) | ((uint64_t)netns << 16) | port; }
+
+gyo_engine *gyo_engine_new(uint32_t max_services, int enable_td)
+{
+	gyo_engine *e = (gyo_engine *)calloc(1, sizeof(*e));
+	uint32_t cap = 1;
+	while (cap < 2 * (uint64_t)max_services) cap <<= 1;
+	e->max_services = max_services;
+	e->mask = cap - 1;
+	e->enable_td = enable_td;
+	e->keys = (uint64_t *)malloc((size_t)cap * 8);
+	memset(e->keys, 0xFF, (size_t)cap * 8);
+	e->vals = (uint32_t *)calloc(cap, 4);
+	e->svc_gid = (uint64_t *)calloc(max_services, 8);
+	e->hist = (gyo_hist_serial *)calloc((size_t)max_services * 16, sizeof(gyo_hist_serial));
+	e->bitmap = (uint16_t *)calloc((size_t)max_services * 32, 2);
+	e->cms = (uint32_t *)calloc((size_t)GYO_CMS_D * GYO_CMS_W, 4);
+	e->gmax = LONG_MIN;
+	for (uint32_t s = 0; s < max_services; s++) e->hist[(size_t)s * 16 + 15].sum = LONG_MIN;
+	if (enable_td) {
+		e->td = (gyo_tdigest *)malloc((size_t)max_services * sizeof(gyo_tdigest));
+		for (uint32_t s = 0; s < max_services; s++) gyo_td_init(&e->td[s]);
+		e->bcnt = (uint32_t *)calloc(max_services, 4);
+		e->boff = (uint32_t *)calloc((size_t)max_services + 1, 4);
+	}
+	return e;
+}
+
+void gyo_engine_free(gyo_engine *e)
+{
+	if (!e) return;
+	free(e->keys); free(e->vals); free(e->svc_gid); free(e->hist); free(e->bitmap); free(e->cms); free(e->td); free(e->bcnt); free(e->boff);
+	free(e);
+}
+
+int gyo_engine_register(gyo_engine *e, uint32_t host_slot, uint64_t glob_id, uint32_t netns, uint16_t port)
+{
+	const uint64_t k = lkey(host_slot, netns, port);
+	uint32_t h = gyo_get_uint64_hash(k) & e->mask;
+	if (e->nsvc >= e->max_services) return -1;
+	while (e->keys[h] != ~0ull && e->keys[h] != k) h = (h + 1) & e->mask;
+	e->keys[h] = k;
+	e->vals[h] = e->nsvc;
+	e->svc_gid[e->nsvc] = glob_id;
+	return (int)e->nsvc++;
+}
+
+static uint32_t lookup(const gyo_engine *e, uint64_t k)
+{
+	uint32_t h = gyo_get_uint64_hash(k) & e->mask;
+	for (;;) {
+		if (e->keys[h] == k) return e->vals[h];
+		if (e->keys[h] == ~0ull) return 0xFFFFFFFFu;
+		h = (h + 1) & e->mask;
+	}
+}
+
+static uint16_t bswap16(uint16_t v) { return (uint16_t)((v >> 8) | (v << 8)); }
+
+/* One batch of 24-byte tcp_ipv4_resp_event_t (common/gy_ebpf_kernel.h:106-111); segment s covers events
+ * [seg_first[s], seg_first[s+1]) of host seg_host[s]. */
+void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs)
+{
+	uint32_t seg = 0;
+	uint32_t *slot_of = NULL;
+	int32_t *val_of = NULL;
+
+	if (e->enable_td) {
+		slot_of = (uint32_t *)malloc((size_t)(n ? n : 1) * 4);
+		val_of = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
+		memset(e->bcnt, 0, (size_t)e->nsvc * 4);
+	}
+	for (uint64_t i = 0; i < n; i++) {
+		const uint8_t *p = ev24 + i * 24;
+		uint32_t saddr, daddr, netns, lsnd, lrcv, tresp, slot, b;
+		uint16_t sport_be, dport_be, sport, dport;
+
+		memcpy(&saddr, p, 4); memcpy(&daddr, p + 4, 4); memcpy(&netns, p + 8, 4);
+		memcpy(&sport_be, p + 12, 2); memcpy(&dport_be, p + 14, 2);
+		memcpy(&lsnd, p + 16, 4); memcpy(&lrcv, p + 20, 4);
+		while (seg + 1 < nsegs && seg_first[seg + 1] <= i) seg++;
+		if (slot_of) slot_of[i] = 0xFFFFFFFFu;
+		e->counters[0]++;
+		tresp = lsnd - lrcv;                      /* gy_socket_stat.cc:1519 */
+		if (tresp > 1000000u) {                   /* :1521-1524 */
+			e->counters[1]++;
+			continue;
+		}
+		sport = bswap16(sport_be);                /* ntohs :1526-1527 */
+		dport = bswap16(dport_be);
+		slot = lookup(e, lkey(seg_host[seg], netns, sport)); /* listener_tbl_ lookup ignoring the IP :1671 */
+		if (slot == 0xFFFFFFFFu) {
+			e->counters[2]++;
+			continue;
+		}
+		e->counters[3]++;
+		b = gyo_bucket(GYO_RESP_TIME_HASH, (int64_t)tresp);
+		{
+			gyo_hist_serial *h = &e->hist[(size_t)slot * 16];
+			h[b].count++;                     /* HIST_SERIAL::add gy_statistics.h:463-467 */
+			h[b].sum += (int64_t)tresp;
+			h[15].count++;                    /* total_count_ */
+			if (h[15].sum < (int64_t)tresp) h[15].sum = (int64_t)tresp; /* max_val_seen_ */
+		}
+		gyo_conn_bitmap_add(&e->bitmap[(size_t)slot * 32], dport, (uint8_t)b); /* resp_bitmap_v4_.add_response */
+		e->ghist[b].count++;
+		e->ghist[b].sum += (int64_t)tresp;
+		e->ghist[15].count++;
+		if (e->gmax < (int64_t)tresp) e->gmax = (int64_t)tresp;
+		{
+			uint32_t w[10];
+			const uint32_t nw = gyo_pair_ip_port_words((const uint8_t *)&daddr, 0, dport, (const uint8_t *)&saddr, 0, sport, w);
+			gyo_hll_add_words(e->hll, GYO_HLL_P, w, nw);
+		}
+		{
+			uint32_t gw[2];
+			gw[0] = (uint32_t)(e->svc_gid[slot] & 0xFFFFFFFFu);
+			gw[1] = (uint32_t)(e->svc_gid[slot] >> 32);
+			gyo_cms_add(e->cms, gw, 2, 1);
+		}
+		if (slot_of) {
+			slot_of[i] = slot;
+			val_of[i] = (int32_t)tresp;
+			e->bcnt[slot]++;
+		}
+	}
+	if (e->enable_td) {
+		/* digest(key) <- merge(digest(key), multiset of this batch's values of the key) */
+		int32_t *staged = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
+		uint32_t run = 0;
+		for (uint32_t s = 0; s < e->nsvc; s++) {
+			e->boff[s] = run;
+			run += e->bcnt[s];
+		}
+		e->boff[e->nsvc] = run;
+		for (uint64_t i = 0; i < n; i++)
+			if (slot_of[i] != 0xFFFFFFFFu) staged[e->boff[slot_of[i]]++] = val_of[i];
+		run = 0;
+		for (uint32_t s = 0; s < e->nsvc; s++) {
+			if (e->bcnt[s]) gyo_td_merge_values(&e->td[s], staged + run, e->bcnt[s]);
+			run += e->bcnt[s];
+		}
+		free(staged);
+		free(slot_of);
+		free(val_of);
+	}
+}
+
+/* histogram-only variant == what the reference itself computes per event (no sketches): the "reference work" CPU baseline */
+void gyo_engine_resp_batch_histonly(gyo_engine *e, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs)
+{
+	uint32_t seg = 0;
+	for (uint64_t i = 0; i < n; i++) {
+		const uint8_t *p = ev24 + i * 24;
+		uint32_t netns, lsnd, lrcv, tresp, slot, b;
+		uint16_t sport_be, dport_be;
+
+		memcpy(&netns, p + 8, 4); memcpy(&sport_be, p + 12, 2); memcpy(&dport_be, p + 14, 2);
+		memcpy(&lsnd, p + 16, 4); memcpy(&lrcv, p + 20, 4);
+		while (seg + 1 < nsegs && seg_first[seg + 1] <= i) seg++;
+		tresp = lsnd - lrcv;
+		if (tresp > 1000000u) continue;
+		slot = lookup(e, lkey(seg_host[seg], netns, bswap16(sport_be)));
+		if (slot == 0xFFFFFFFFu) continue;
+		b = gyo_bucket(GYO_RESP_TIME_HASH, (int64_t)tresp);
+		{
+			gyo_hist_serial *h = &e->hist[(size_t)slot * 16];
+			h[b].count++;
+			h[b].sum += (int64_t)tresp;
+			h[15].count++;
+			if (h[15].sum < (int64_t)tresp) h[15].sum = (int64_t)tresp;
+		}
+		gyo_conn_bitmap_add(&e->bitmap[(size_t)slot * 32], bswap16(dport_be), (uint8_t)b);
+	}
+}
+
+uint32_t gyo_engine_nsvc(const gyo_engine *e) { return e->nsvc; }
+const gyo_hist_serial *gyo_engine_hist(const gyo_engine *e) { return e->hist; }
+const uint16_t *gyo_engine_bitmap(const gyo_engine *e) { return e->bitmap; }
+const uint8_t *gyo_engine_hll(const gyo_engine *e) { return e->hll; }
+const uint32_t *gyo_engine_cms(const gyo_engine *e) { return e->cms; }
+const gyo_hist_serial *gyo_engine_ghist(const gyo_engine *e) { return e->ghist; }
+int64_t gyo_engine_gmax(const gyo_engine *e) { return e->gmax; }
+const gyo_tdigest *gyo_engine_td(const gyo_engine *e, uint32_t slot) { return &e->td[slot]; }
+const uint64_t *gyo_engine_counters(const gyo_engine *e) { return e->counters; }
+/* window roll: clear the windowed sketches (CONN_BITMAP secs_to_reset_ = 5; HLL/CMS are per window) keeping histograms/digests */
+void gyo_engine_window_clear(gyo_engine *e, int clear_hist)
+{
+	memset(e->bitmap, 0, (size_t)e->max_services * 64);
+	memset(e->hll, 0, sizeof(e->hll));
+	memset(e->cms, 0, (size_t)GYO_CMS_D * GYO_CMS_W * 4);
+	memset(e->ghist, 0, sizeof(e->ghist));
+	e->gmax = LONG_MIN;
+	if (clear_hist) {
+		memset(e->hist, 0, (size_t)e->max_services * 16 * sizeof(gyo_hist_serial));
+		for (uint32_t s = 0; s < e->max_services; s++) e->hist[(size_t)s * 16 + 15].sum = LONG_MIN;
+	}
+}

@@ -31,12 +31,14 @@ i64p = C.POINTER(C.c_int64)
 f32p = C.POINTER(C.c_float)
 
 
+SOURCES = ["gy_oracle.c", "gy_oracle_engine.c"]
+
+
 def build_oracle(force=False):
-    src = os.path.join(HERE, "gy_oracle.c")
-    if (not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= os.path.getmtime(src)
-            and os.path.getmtime(LIB_PATH) >= os.path.getmtime(os.path.join(HERE, "gy_oracle.h"))):
+    deps = [os.path.join(HERE, f) for f in SOURCES + ["gy_oracle.h"]] + [os.path.join(HERE, "..", "include", "gys_tdigest_tbl.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-o", LIB_PATH, src, "-lm"])
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-o", LIB_PATH] + [os.path.join(HERE, f) for f in SOURCES] + ["-lm"])
     return LIB_PATH
 
 
@@ -140,6 +142,21 @@ def lib():
     _sig(L, "gyo_cluster_state_update", None, [C.POINTER(ClusterStateOne)] + [C.c_uint32] * 6 + [C.POINTER(ListenSummStats)])
     _sig(L, "gyo_cluster_state_add", None, [C.POINTER(ClusterStateOne), C.POINTER(ClusterStateOne)])
     _sig(L, "gyo_topn_u64", C.c_size_t, [u64p, C.c_size_t, C.c_size_t, u64p])
+    _sig(L, "gyo_engine_new", C.c_void_p, [C.c_uint32, C.c_int])
+    _sig(L, "gyo_engine_free", None, [C.c_void_p])
+    _sig(L, "gyo_engine_register", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint16])
+    _sig(L, "gyo_engine_resp_batch", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
+    _sig(L, "gyo_engine_resp_batch_histonly", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
+    _sig(L, "gyo_engine_nsvc", C.c_uint32, [C.c_void_p])
+    _sig(L, "gyo_engine_hist", C.c_void_p, [C.c_void_p])
+    _sig(L, "gyo_engine_bitmap", C.c_void_p, [C.c_void_p])
+    _sig(L, "gyo_engine_hll", C.c_void_p, [C.c_void_p])
+    _sig(L, "gyo_engine_cms", C.c_void_p, [C.c_void_p])
+    _sig(L, "gyo_engine_ghist", C.c_void_p, [C.c_void_p])
+    _sig(L, "gyo_engine_gmax", C.c_int64, [C.c_void_p])
+    _sig(L, "gyo_engine_td", C.POINTER(TDigest), [C.c_void_p, C.c_uint32])
+    _sig(L, "gyo_engine_counters", u64p, [C.c_void_p])
+    _sig(L, "gyo_engine_window_clear", None, [C.c_void_p, C.c_int])
     _lib = L
     return L
 
@@ -249,3 +266,75 @@ def td_from_arrays(sums, cnts, vmin, vmax):
 
 def td_to_arrays(d):
     return (np.array(list(d.sum), dtype=np.int64), np.array(list(d.cnt), dtype=np.uint32), d.vmin, d.vmax)
+
+
+class OracleEngine:
+    """python handle on the sequential CPU restatement of the response-event hot path (gy_oracle_engine.c)"""
+
+    def __init__(self, max_services, enable_td=True):
+        self.L = lib()
+        self.h = self.L.gyo_engine_new(max_services, 1 if enable_td else 0)
+        self.enable_td = enable_td
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.gyo_engine_free(self.h)
+            self.h = None
+
+    def register(self, host_slot, glob_id, netns, port):
+        s = self.L.gyo_engine_register(self.h, int(host_slot), int(glob_id), int(netns), int(port))
+        assert s >= 0
+        return s
+
+    def resp_batch(self, ev_bytes, seg_host, seg_first, histonly=False):
+        ev = np.frombuffer(ev_bytes, dtype=np.uint8)
+        sh = np.ascontiguousarray(seg_host, dtype=np.uint32)
+        sf = np.ascontiguousarray(seg_first, dtype=np.uint64)
+        fn = self.L.gyo_engine_resp_batch_histonly if histonly else self.L.gyo_engine_resp_batch
+        fn(self.h, ev.ctypes.data, len(ev) // 24, ptr(sh, u32p), ptr(sf, u64p), len(sh))
+
+    @property
+    def nsvc(self):
+        return self.L.gyo_engine_nsvc(self.h)
+
+    def _arr(self, p, dtype, shape):
+        n = int(np.prod(shape))
+        buf = (C.c_uint8 * (n * np.dtype(dtype).itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape).copy()
+
+    def hist(self):
+        return self._arr(self.L.gyo_engine_hist(self.h), np.int64, (self.nsvc, 16, 2))
+
+    def bitmap(self):
+        return self._arr(self.L.gyo_engine_bitmap(self.h), np.uint16, (self.nsvc, 32))
+
+    def hll(self):
+        return self._arr(self.L.gyo_engine_hll(self.h), np.uint8, (1 << HLL_P,))
+
+    def cms(self):
+        return self._arr(self.L.gyo_engine_cms(self.h), np.uint32, (CMS_D, CMS_W))
+
+    def ghist(self):
+        return self._arr(self.L.gyo_engine_ghist(self.h), np.int64, (16, 2)), self.L.gyo_engine_gmax(self.h)
+
+    def td(self, slot):
+        return self.L.gyo_engine_td(self.h, slot).contents
+
+    def td_arrays(self):
+        n = self.nsvc
+        sums = np.zeros((n, TD_NB), dtype=np.int64)
+        cnts = np.zeros((n, TD_NB), dtype=np.uint32)
+        mm = np.zeros((n, 2), dtype=np.int32)
+        for s in range(n):
+            d = self.td(s)
+            sums[s] = np.frombuffer(d.sum, dtype=np.int64)
+            cnts[s] = np.frombuffer(d.cnt, dtype=np.uint32)
+            mm[s] = (d.vmin, d.vmax)
+        return sums, cnts, mm
+
+    def counters(self):
+        c = self.L.gyo_engine_counters(self.h)
+        return {"events": c[0], "dropped_range": c[1], "dropped_nolistener": c[2], "accepted": c[3]}
+
+    def window_clear(self, clear_hist=False):
+        self.L.gyo_engine_window_clear(self.h, 1 if clear_hist else 0)

@@ -1,0 +1,186 @@
+"""GPU parity for the response-event hot path (SURVEY 8a rows a1,a2,a3,a4,a7,a8 + HLL/CMS/t-digest): every register the HIP
+kernels produce is compared bit-for-bit with the CPU oracle on the same events; t-digest quantiles are additionally checked
+against an exact sort (rank error <= 1 %) and against GY_HISTOGRAM bucket ceilings."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: -m gpu tests must run on the MI355X box")
+    return torch
+
+
+def _engine(**kw):
+    from gyeeta_amd.engine import SketchEngine
+    return SketchEngine(**kw)
+
+
+def _compare_all(eng, orc, oracle, check_td=True):
+    nsvc = orc.nsvc
+    helpers.assert_hist_equal(eng.export_hist(0, 0, nsvc), orc.hist(), nsvc)
+    assert (eng.export_conn_bitmap(0, nsvc) == orc.bitmap()).all()
+    if check_td:
+        gs, gc, gm = eng.export_tdigest(0, nsvc)
+        os_, oc, om = orc.td_arrays()
+        assert (gc == oc).all(), f"digest counts differ at {np.argwhere(gc != oc)[:4].tolist()}"
+        assert (gs == os_).all()
+        assert (gm == om).all()
+
+
+def _compare_window(eng, orc):
+    assert (eng.export_hll() == orc.hll()).all()
+    assert (eng.export_cms(0) == orc.cms()).all()
+    gh = eng.export_global_hist()
+    oh, omax = orc.ghist()
+    assert [gh.stats[i].count for i in range(15)] == oh[:15, 0].tolist()
+    assert [gh.stats[i].sum for i in range(15)] == oh[:15, 1].tolist()
+    assert gh.total_count == oh[15, 0] and gh.max_val_seen == omax
+
+
+def test_resp_small_hosts_edge_cases(torch_mod, oracle):
+    rng = np.random.default_rng(1)
+    nh, sp = 3, 7
+    eng = _engine(max_hosts=8, max_services=64, max_batch_events=1 << 16)
+    orc = oracle.OracleEngine(64)
+    info, gids = helpers.register_world(eng, orc, range(nh), sp)
+    total = 0
+    for rnd in range(4):
+        for h in range(nh):
+            n = int(rng.integers(1, 3000))
+            ev = helpers.make_resp_events(rng, h, n, sp)
+            eng.handle_resp_events(info[h][0], ev)
+            orc.resp_batch(ev.tobytes(), [info[h][1]], [0])
+            total += n
+    eng.handle_resp_events(info[0][0], np.zeros(0, dtype=helpers.wire.RESP_EVENT))  # empty batch is a no-op
+    eng.sync()
+    _compare_all(eng, orc, oracle)
+    c, oc = eng.counters(), orc.counters()
+    assert c["resp_events"] == total == oc["events"]
+    assert c["resp_dropped_range"] == oc["dropped_range"] and c["resp_dropped_nolistener"] == oc["dropped_nolistener"]
+    # percentiles / quantiles of every service vs the oracle (bit exact) and vs GY_HISTOGRAM semantics
+    hist = eng.export_hist(0, 0, orc.nsvc)
+    for h in range(nh):
+        for s in range(sp):
+            g = int(gids[h][s])
+            slot = eng.lookup(g)
+            vals, sums, counts, tot, mx, avg = eng.hist_percentiles(g, [25.0, 50.0, 95.0, 99.0, 99.99], which=0)
+            ov, os_, ocn, oavg = oracle.hist_percentiles(0, hist[slot][:15], hist[slot][15][0], [25.0, 50.0, 95.0, 99.0, 99.99])
+            assert vals == ov and sums == os_ and counts == ocn
+            assert np.float32(avg).tobytes() == np.float32(oavg).tobytes()
+            qs = [0.0, 0.01, 0.25, 0.5, 0.9, 0.99, 1.0]
+            gq = eng.quantiles(g, qs)
+            oq = [oracle.lib().gyo_td_quantile(C.byref(orc.td(slot)), q) for q in qs]
+            assert gq == oq
+    # window close: HLL / CMS / global histogram registers bit exact; histograms fold into the all-time set
+    eng.window_close()
+    _compare_window(eng, orc)
+    helpers.assert_hist_equal(eng.export_hist(1, 0, orc.nsvc), orc.hist(), orc.nsvc)
+    assert eng.export_hist(0, 0, orc.nsvc)[:, :15].sum() == 0  # window cleared
+    est = eng.distinct_flows()
+    assert est == pytest.approx(oracle.lib().gyo_hll_estimate(oracle.ptr(orc.hll(), oracle.u8p), 14), rel=1e-12)
+    for h in range(nh):
+        g = int(gids[h][0])
+        w = oracle.glob_id_words(g)
+        assert eng.cms(g, 0) == oracle.lib().gyo_cms_query(oracle.ptr(orc.cms(), oracle.u32p), oracle.ptr(w, oracle.u32p), 2)
+    eng.close()
+
+
+def test_resp_device_generated_stream(torch_mod, oracle):
+    """SURVEY 8d-style stream generated ON the GPU, replayed through the oracle on the host from the very same bytes"""
+    torch = torch_mod
+    nh, sp, n = 32, 50, 1 << 19
+    eng = _engine(max_hosts=nh, max_services=nh * sp, max_batch_events=n)
+    orc = oracle.OracleEngine(nh * sp)
+    helpers.register_world(eng, orc, range(nh), sp)
+    ev = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
+    exact = {}
+    for rnd in range(3):
+        segs = eng.gen_resp_events(ev.data_ptr(), n, 1234 + rnd, 0, nh, sp)
+        eng.handle_resp_events_dev(segs, ev.data_ptr(), n)
+        host = ev.cpu().numpy().tobytes()
+        orc.resp_batch(host, [s.host_slot for s in segs], [s.first_event for s in segs])
+        a = np.frombuffer(host, dtype=helpers.wire.RESP_EVENT)
+        exact[rnd] = a
+    eng.sync()
+    _compare_all(eng, orc, oracle)
+    assert eng.counters()["resp_dropped_nolistener"] == 0
+    # t-digest vs exact sort: rank error <= 1 % (north_star tolerance), and bucket agreement with GY_HISTOGRAM::get_percentile
+    allev = np.concatenate([exact[r] for r in range(3)])
+    lat = (allev["lsndtime"] - allev["lrcvtime"]).astype(np.int64)
+    hostidx = np.repeat(np.arange(nh), n // nh)
+    hostidx = np.concatenate([hostidx] * 3)
+    port = allev["sport_be"].astype(np.int64)
+    worst = 0.0
+    for h in (0, 7, 31):
+        for s in (0, 13, 49):
+            sel = (hostidx == h) & (port == 1024 + s)
+            x = np.sort(lat[sel])
+            g = int(helpers.wire.glob_id(h, s))
+            for q, gq in zip((0.5, 0.99), eng.quantiles(g, [0.5, 0.99])):
+                lo = np.searchsorted(x, gq, side="left") / len(x)
+                hi = np.searchsorted(x, gq, side="right") / len(x)
+                err = 0.0 if lo <= q <= hi else min(abs(lo - q), abs(hi - q))
+                worst = max(worst, err)
+    assert worst <= 0.01, f"t-digest rank error {worst:.4f} > 1%"
+    eng.window_close()
+    _compare_window(eng, orc)
+    eng.close()
+
+
+def test_resp_huge_key_batches(torch_mod, oracle):
+    """keys with more than 1024 new values in one batch take the value-count-array kernel; result must still equal the oracle,
+    including when a small batch, a huge batch and another small batch hit the same key"""
+    rng = np.random.default_rng(5)
+    eng = _engine(max_hosts=2, max_services=8, max_batch_events=1 << 18)
+    orc = oracle.OracleEngine(8)
+    info, gids = helpers.register_world(eng, orc, range(1), 3)
+    mid, slot = info[0]
+    for n, sp, mu in [(300, 3, 3.0), (150000, 1, 4.0), (900, 3, 2.0), (200000, 2, 6.5), (1, 1, 1.0), (1025, 1, 3.0), (1024, 1, 3.0)]:
+        ev = helpers.make_resp_events(rng, 0, n, sp, lat_mu=mu, bad_frac=0.01, unknown_frac=0.0)
+        eng.handle_resp_events(mid, ev)
+        orc.resp_batch(ev.tobytes(), [slot], [0])
+    eng.sync()
+    _compare_all(eng, orc, oracle)
+    for s in range(3):
+        g = int(gids[0][s])
+        qs = [0.001, 0.5, 0.999]
+        assert eng.quantiles(g, qs) == [oracle.lib().gyo_td_quantile(C.byref(orc.td(s)), q) for q in qs]
+    eng.close()
+
+
+def test_tdigest_disabled_and_identical_values(torch_mod, oracle):
+    rng = np.random.default_rng(9)
+    eng = _engine(max_hosts=1, max_services=4, enable_tdigest=False)
+    orc = oracle.OracleEngine(4, enable_td=False)
+    info, gids = helpers.register_world(eng, orc, range(1), 2)
+    ev = helpers.make_resp_events(rng, 0, 5000, 2)
+    eng.handle_resp_events(info[0][0], ev)
+    orc.resp_batch(ev.tobytes(), [0], [0])
+    eng.sync()
+    _compare_all(eng, orc, oracle, check_td=False)
+    from gyeeta_amd import capi
+    with pytest.raises(capi.GysError):
+        eng.quantiles(int(gids[0][0]), [0.5])
+    eng.close()
+    # all-identical values (every item ties with every other): exercises the tie rule old-before-new
+    eng = _engine(max_hosts=1, max_services=4, max_batch_events=1 << 16)
+    orc = oracle.OracleEngine(4)
+    info, gids = helpers.register_world(eng, orc, range(1), 1)
+    for n in (10, 2000, 700):
+        ev = helpers.make_resp_events(rng, 0, n, 1, bad_frac=0, unknown_frac=0, zero_ip_frac=0)
+        ev["lsndtime"] = ev["lrcvtime"] + np.uint32(42)
+        eng.handle_resp_events(info[0][0], ev)
+        orc.resp_batch(ev.tobytes(), [0], [0])
+    eng.sync()
+    _compare_all(eng, orc, oracle)
+    assert eng.quantiles(int(gids[0][0]), [0.1, 0.5, 0.9]) == [42.0, 42.0, 42.0]
+    eng.close()
