@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- events/sec ingested into merged HLL + Count-Min + t-digest (+ exact histogram) sketches on MI355X.
+
+Workload (BASELINE.json configs[2]/[3]): 10 000 hosts x 1 000 services = 10^7 service keys, raw 24-byte
+tcp_ipv4_resp_event_t response events uniform over the keys, per-service latency lognormal(mu_s, 1.5) with mu_s ~ N(3,1).
+Hosts are sharded over ranks by GY_MACHINE_ID::get_hash() % N; every rank ingests a fixed number of events per step
+drawn over ITS hosts (weak scaling in events) and one step = one 5-second window: ingest one device-resident batch, then the
+window close (RCCL all-reduce of the HLL / CMS / histogram / cluster registers over xGMI + local roll).
+
+One process per GPU (torchrun env RANK/LOCAL_RANK/WORLD_SIZE); rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+EVENT_BYTES = 24          # algorithmic bytes per event (raw tcp_ipv4_resp_event_t)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed):
+    """The oracle's sequential restatement of the same hot loop ("port"), timed on one host core on a bounded sample of the
+    same stream shape (same generator, same bytes).  Returns (full_ev_s, histonly_ev_s, sample description)."""
+    from gyeeta_amd import wire
+    from oracle import oracle as o
+    nsvc = total_hosts_sample * svcs
+    orc = o.OracleEngine(nsvc)
+    orc2 = o.OracleEngine(nsvc, enable_td=False)
+    for h in range(total_hosts_sample):
+        s = np.arange(svcs)
+        g = wire.glob_id(np.full(svcs, h), s)
+        ns = wire.listener_netns(h, s)
+        pt = wire.listener_port(s)
+        for i in range(svcs):
+            orc.register(h, int(g[i]), int(ns[i]), int(pt[i]))
+            orc2.register(h, int(g[i]), int(ns[i]), int(pt[i]))
+    ev = torch.empty(nevents * 24, dtype=torch.uint8, device="cuda")
+    segs = eng.gen_resp_events(ev.data_ptr(), nevents, seed, 0, total_hosts_sample, svcs)
+    eng.sync()
+    host = ev.cpu().numpy().tobytes()
+    del ev
+    sh = [s.host_slot for s in segs]
+    sf = [s.first_event for s in segs]
+    t0 = time.perf_counter()
+    orc.resp_batch(host, sh, sf)
+    t1 = time.perf_counter()
+    orc2.resp_batch(host, sh, sf, histonly=True)
+    t2 = time.perf_counter()
+    desc = (f"{nevents} events over {total_hosts_sample} hosts x {svcs} services ({nsvc} keys), one batch, single thread, "
+            f"gcc -O2; full = hist+bitmap+HLL+CMS+t-digest, histonly = the reference's own per-event work")
+    return nevents / (t1 - t0), nevents / (t2 - t1), desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--hosts", type=int, default=10000, help="total hosts across all ranks")
+    ap.add_argument("--svcs", type=int, default=1000, help="services per host")
+    ap.add_argument("--events", type=int, default=1 << 26, help="events per rank per step (one window)")
+    ap.add_argument("--zipf-milli", type=int, default=0, help="0 = uniform over services, else Zipf s*1000 (config 5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-events", type=int, default=1 << 23)
+    ap.add_argument("--cpu-hosts", type=int, default=1000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from gyeeta_amd import wire
+    from gyeeta_amd.engine import SketchEngine, mid_buf
+    from gyeeta_amd import capi
+    L = capi.load()
+
+    # shard the hosts by the reference's own machine-id hash
+    mids = [wire.machine_id(h) for h in range(args.hosts)]
+    mine = [h for h in range(args.hosts) if L.gys_shard_of(mid_buf(mids[h]), world) == rank]
+    nlocal = len(mine)
+    nsvc = nlocal * args.svcs
+    eng = SketchEngine(max_hosts=max(nlocal, 1), max_services=max(nsvc, 1), max_clusters=16, enable_tdigest=True,
+                       max_batch_events=args.events, rank=rank, nranks=world, device=local_rank)
+    for c in range(8):  # same cluster order on every rank (gysketch.h: gys_register_cluster)
+        eng.register_cluster("cluster%d" % c)
+    s = np.arange(args.svcs)
+    for j, h in enumerate(mine):
+        slot = eng.register_host(mids[h], "cluster%d" % (h % 8))
+        assert slot == j
+        eng.register_listeners_np(mids[h], wire.glob_id(np.full(args.svcs, h), s), wire.listener_netns(j, s), wire.listener_port(s))
+        if j % 64 == 0:
+            eng.handle_host_state(mids[h], ntasks=100, nlisten=args.svcs)
+
+    # two device-resident batches, generated on the GPU before the timed region
+    nbuf = 2
+    bufs, segs = [], []
+    for b in range(nbuf):
+        ev = torch.empty(args.events * EVENT_BYTES, dtype=torch.uint8, device="cuda")
+        segs.append(eng.gen_resp_events(ev.data_ptr(), args.events, 0x67796565746121 + 1000 * rank + b, 0, nlocal, args.svcs, args.zipf_milli))
+        bufs.append(ev)
+    eng.sync()
+
+    def step(i):
+        b = i % nbuf
+        eng.handle_resp_events_dev(segs[b], bufs[b].data_ptr(), args.events)
+        eng.window_close(tusec=5_000_000 * (i + 1))
+
+    for i in range(args.warmup):
+        step(i)
+    eng.profile(True)
+    eng.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = eng.profile_get()
+    eng.profile(False)
+
+    if rank == 0:
+        total_events = args.events * world * args.steps
+        value = total_events / dt
+        # dominant kernel = largest accumulated HIP-event time on the engine stream inside the timed region
+        dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 0))
+        dom_ms_avg = dom[1][0] / max(dom[1][1], 1)
+        alg_bytes = EVENT_BYTES * args.events  # per launch: every launch of the pipeline touches each of the batch's events once
+        achieved = alg_bytes / (dom_ms_avg * 1e-3) / 1e9 if dom_ms_avg > 0 else 0.0
+        out = {
+            "metric": "events/sec ingested into merged HLL+CMS+t-digest sketches",
+            "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": "C3/C4: %d hosts x %d services, raw 24-B tcp_ipv4_resp_event_t stream, %s over services, "
+                                   "1 window (ingest + window close) per step" % (args.hosts, args.svcs,
+                                                                                 "uniform" if not args.zipf_milli else "zipf %.2f" % (args.zipf_milli / 1000)),
+                       "events_per_rank_per_step": args.events, "service_keys_total": args.hosts * args.svcs,
+                       "service_keys_rank0": nsvc, "sketches": "exact RESP_TIME_HASH histogram + CONN_BITMAP + HLL p=14 + CMS 4x65536 + t-digest 100 clusters/key",
+                       "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_ms": dom_ms_avg, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernels_ms_avg": {k: v[0] / max(v[1], 1) for k, v in prof.items()}},
+        }
+        if not args.no_cpu_baseline:
+            full, honly, desc = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234)
+            out["cpu_baseline"] = {"value": full, "unit": "events/s", "cores": 1, "kind": "port", "sample": desc,
+                                   "histonly_value": honly}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
