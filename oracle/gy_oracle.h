@@ -144,7 +144,7 @@ double gyo_td_quantile(const gyo_tdigest *d, double q);
 /* ---------------------------------------------------------------- wire records + roll-ups */
 #define GYO_TCP_CONN_NOTIFY_SZ 280
 #define GYO_LISTENER_STATE_NOTIFY_SZ 88
-#define GYO_NSTATES 7 /* OBJ_STATE_E STATE_IDLE..STATE_DOWN (common/gy_common_inc.h) */
+#define GYO_NSTATES 6 /* OBJ_STATE_E STATE_IDLE..STATE_DOWN (common/gy_json_field_maps.h:242-250) */
 
 typedef struct {
 	int32_t nstates[GYO_NSTATES];

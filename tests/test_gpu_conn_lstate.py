@@ -1,0 +1,208 @@
+"""GPU parity for the madhava entry points: partha_tcp_conn_info (TCP_CONN_NOTIFY -> distinct-flow HLL, CMS, per-service
+counters), partha_listener_state (LISTENER_STATE_NOTIFY -> LISTEN_SUMM_STATS, top-N) and send_cluster_state (STATE_ONE sums)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gyeeta_amd import wire
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    return torch
+
+
+def _engine(**kw):
+    from gyeeta_amd.engine import SketchEngine
+    return SketchEngine(**kw)
+
+
+def _oracle_conn(oracle, batch, n, hll, cms32, cms64, known):
+    """oracle decode of a variable-stride TCP_CONN_NOTIFY batch + sketch updates; returns per-glob_id exact counters"""
+    L = oracle.lib()
+    buf = np.frombuffer(batch, dtype=np.uint8)
+    kw = np.zeros(n * 10, dtype=np.uint32)
+    nw = np.zeros(n, dtype=np.uint32)
+    gid = np.zeros(n, dtype=np.uint64)
+    bs = np.zeros(n, dtype=np.uint64)
+    br = np.zeros(n, dtype=np.uint64)
+    fl = np.zeros(n, dtype=np.uint8)
+    got = L.gyo_tcp_conn_decode(buf.ctypes.data, n, buf.ctypes.data + len(buf), oracle.ptr(kw, oracle.u32p), oracle.ptr(nw, oracle.u32p),
+                                oracle.ptr(gid, oracle.u64p), oracle.ptr(bs, oracle.u64p), oracle.ptr(br, oracle.u64p), oracle.ptr(fl, oracle.u8p))
+    assert got == n
+    ctr = {}
+    for i in range(n):
+        w = kw[i * 10:i * 10 + nw[i]]
+        L.gyo_hll_add_words(oracle.ptr(hll, oracle.u8p), 14, oracle.ptr(w, oracle.u32p), int(nw[i]))
+        gw = oracle.glob_id_words(int(gid[i]))
+        L.gyo_cms_add(oracle.ptr(cms32, oracle.u32p), oracle.ptr(gw, oracle.u32p), 2, 1)
+        L.gyo_cms64_add(oracle.ptr(cms64, oracle.u64p), oracle.ptr(gw, oracle.u32p), 2, int(bs[i]) + int(br[i]))
+        if int(gid[i]) in known:
+            c = ctr.setdefault(int(gid[i]), [0, 0, 0, 0])
+            c[0] += 1
+            c[2] += int(bs[i])
+            c[3] += int(br[i])
+    return ctr, gid
+
+
+def test_tcp_conn_info_v4_v6_variable_stride(torch_mod, oracle):
+    rng = np.random.default_rng(21)
+    nh, sp = 4, 9
+    eng = _engine(max_hosts=8, max_services=64, enable_tdigest=False)
+    info, gids = helpers.register_world(eng, None, range(nh), sp)
+    known = {int(g) for h in range(nh) for g in gids[h]}
+    hll = np.zeros(1 << 14, dtype=np.uint8)
+    cms32 = np.zeros(4 * 65536, dtype=np.uint32)
+    cms64 = np.zeros(4 * 65536, dtype=np.uint64)
+    exact = {}
+    nclose = {}
+    tuples = set()
+    for rnd in range(3):
+        for h in range(nh):
+            n = int(rng.integers(1, 2049))  # MAX_NUM_CONNS = 2048 per message
+            rec = wire.synth_tcp_conns(rng, n, list(range(nh)) + [77], sp, dup_frac=0.2, v6_frac=0.15)  # host 77: unregistered services
+            tails = [bytes(rng.integers(32, 127, int(k), dtype=np.uint8).tolist()) for k in rng.integers(0, 257, n) * (rng.random(n) < 0.3)]
+            batch = wire.pack_variable(rec, tails)
+            eng.partha_tcp_conn_info(info[h][0], batch, n)
+            ctr, gid = _oracle_conn(oracle, batch, n, hll, cms32, cms64, known)
+            for g, c in ctr.items():
+                e = exact.setdefault(g, [0, 0, 0, 0])
+                for k in range(4):
+                    e[k] += c[k]
+            for i in range(n):
+                if int(rec["ser_glob_id"][i]) in known and rec["tusec_close"][i]:
+                    nclose[int(rec["ser_glob_id"][i])] = nclose.get(int(rec["ser_glob_id"][i]), 0) + 1
+                tuples.add((rec["nat_cli"][i].tobytes(), rec["nat_ser"][i].tobytes()))
+    eng.window_close()
+    assert (eng.export_hll() == hll).all()
+    assert (eng.export_cms(0).ravel() == cms32).all()
+    assert (eng.export_cms(1).ravel().astype(np.uint64) == cms64).all()
+    ctrs = eng.export_svc_counters()
+    for g, e in exact.items():
+        s = eng.lookup(g)
+        assert ctrs[s].tolist() == [e[0], nclose.get(g, 0), e[2], e[3]]
+    c = eng.counters()
+    assert c["conn_unknown_service"] > 0 and c["conn_events"] == sum(v[0] for v in exact.values()) + c["conn_unknown_service"]
+    # HLL estimate vs the exact distinct flow count (ground truth = exact set over the key bytes): p=14 -> ~0.8 % std error
+    est = eng.distinct_flows()
+    assert abs(est - len(tuples)) / len(tuples) < 0.05
+    # malformed batch: truncated record is rejected, nothing ingested
+    from gyeeta_amd import capi
+    with pytest.raises(capi.GysError):
+        eng.partha_tcp_conn_info(info[0][0], batch[:-8], n)
+    eng.close()
+
+
+def test_listener_state_summ_topn_cluster(torch_mod, oracle):
+    rng = np.random.default_rng(33)
+    L = oracle.lib()
+    nh, sp = 6, 300
+    eng = _engine(max_hosts=8, max_services=nh * sp, enable_tdigest=False, max_clusters=4)
+    for c in ("cluster0", "cluster1", "cluster2"):
+        eng.register_cluster(c)
+    info, gids = helpers.register_world(eng, None, range(nh), sp)
+    summ = {}
+    recs = {}
+    hstate = {}
+    for h in range(nh):
+        st = dict(ntasks_issue=int(rng.integers(0, 3)), ntasks=int(rng.integers(10, 500)), nlisten_issue=int(rng.integers(0, 2)),
+                  nlisten=sp, cpu_issue=int(rng.integers(0, 2)), mem_issue=int(rng.integers(0, 2)))
+        hstate[h] = st
+        if h != 4:  # host 4 never reports a host state: send_cluster_state skips it (gy_mconnhdlr.cc:16068)
+            eng.handle_host_state(info[h][0], **st)
+        rec = wire.synth_listener_states(rng, h, np.arange(sp), delete_frac=0.01, bad_state_frac=0.01)
+        rec["glob_id"][5] = 0xDEADBEEF12345  # unknown listener -> nmissed
+        recs[h] = rec
+        s = oracle.ListenSummStats()
+        nerr = C.c_int(0)
+        # the host's states arrive split over several messages with issue strings (variable stride); the window accumulates them
+        for lo in range(0, sp, 128):
+            part = rec[lo:lo + 128]
+            tails = [b"issue!" * int(k) for k in rng.integers(0, 4, len(part))]
+            batch = wire.pack_variable(part, tails)
+            eng.partha_listener_state(info[h][0], batch, len(part))
+            known_part = part[part["glob_id"] != 0xDEADBEEF12345]
+            kb = wire.pack_variable(known_part, None)
+            kbuf = np.frombuffer(kb, dtype=np.uint8)
+            L.gyo_listener_state_rollup(kbuf.ctypes.data, len(known_part), kbuf.ctypes.data + len(kbuf), C.byref(s), C.byref(nerr))
+        summ[h] = s
+    eng.window_close()
+    for h in range(nh):
+        assert eng.svcsumm(info[h][0]).as_tuple() == summ[h].as_tuple()
+    c = eng.counters()
+    assert c["lstate_missed"] == nh and c["lstate_deleted"] > 0 and c["lstate_errors"] > 0
+    # cluster state: CLUSTER_STATE_ONE::update_from_state over the hosts of each cluster that reported a host state
+    for cl in range(3):
+        exp = oracle.ClusterStateOne()
+        for h in range(nh):
+            if h % 3 == cl and h != 4:
+                st = hstate[h]
+                L.gyo_cluster_state_update(C.byref(exp), st["ntasks_issue"], st["ntasks"], st["nlisten_issue"], st["nlisten"],
+                                           st["cpu_issue"], st["mem_issue"], C.byref(summ[h]))
+        assert eng.clusterstate("cluster%d" % cl).as_tuple() == exp.as_tuple()
+    # top-N per host: retained metric multiset == BOUNDED_PRIO_QUEUE result on the admitted records (gy_mconnhdlr.cc:11260-11304)
+    for h in (0, 3):
+        rec = recs[h]
+        ok = (rec["glob_id"] != 0xDEADBEEF12345) & (rec["query_flags"] != wire.LISTEN_FLAG_DELETE) & (rec["curr_state"] <= 5)
+        r = rec[ok]
+        for kind, vals in ((1, r["nqrys_5s"][r["nqrys_5s"] >= 5]), (2, r["nconns_active"][r["nconns_active"] >= 1]),
+                           (3, (r["curr_kbytes_inbound"].astype(np.int64) + r["curr_kbytes_outbound"])[(r["curr_kbytes_inbound"] + r["curr_kbytes_outbound"]) > 0])):
+            v = np.ascontiguousarray(vals, dtype=np.uint64)
+            out = np.zeros(10, dtype=np.uint64)
+            k = L.gyo_topn_u64(oracle.ptr(v, oracle.u64p), len(v), 10, oracle.ptr(out, oracle.u64p))
+            got = eng.topn(info[h][0], kind)
+            assert [m for _, m, _ in got] == out[:k].tolist()
+            for g, m, state in got:  # the entry carries the 88-byte record as ingested
+                srec = np.frombuffer(state, dtype=wire.LISTENER_STATE_NOTIFY)[0]
+                assert srec["glob_id"] == g
+        issue = r[r["curr_state"] > 2]
+        got = eng.topn(info[h][0], 0)
+        exp = sorted(zip(issue["curr_state"].tolist(), issue["tasks_delay_usec"].tolist()), reverse=True)[:10]
+        assert [(int(np.frombuffer(s, dtype=wire.LISTENER_STATE_NOTIFY)[0]["curr_state"]),
+                 int(np.frombuffer(s, dtype=wire.LISTENER_STATE_NOTIFY)[0]["tasks_delay_usec"])) for _, _, s in got] == exp
+    # a second window starts from zero
+    eng.window_close()
+    assert eng.svcsumm(info[0][0]).as_tuple() == (0,) * 13
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", range(8))
+def test_standalone_hist_all_kinds(torch_mod, oracle, kind):
+    """rows a1-a4 for every reference hash class: keyed add, merge (add_histogram) and the per-key percentile scan"""
+    torch = torch_mod
+    from gyeeta_amd import capi
+    rng = np.random.default_rng(40 + kind)
+    eng = _engine(max_hosts=1, max_services=1, enable_tdigest=False)
+    L = eng.L
+    nk, n = 257, 200_000
+    keys = rng.integers(0, nk, n).astype(np.uint32)
+    vals = np.concatenate([rng.integers(-20, 400, n // 2), (rng.lognormal(5, 3, n - n // 2)).clip(0, 2**31 - 1)]).astype(np.int32)
+    vals[:8] = [-1, 0, 1, 2**31 - 1, -2**31, 15000, 15001, 5000001]
+    dk, dv = torch.from_numpy(keys.view(np.int32)).cuda(), torch.from_numpy(vals).cuda()
+    h1 = torch.zeros(nk * 256, dtype=torch.uint8, device="cuda")
+    h2 = torch.zeros(nk * 256, dtype=torch.uint8, device="cuda")
+    half = n // 2
+    for hh, lo, hi in ((h1, 0, half), (h2, half, n)):
+        capi.check(L.gys_hist_init_dev(eng.h, kind, hh.data_ptr(), nk))
+        capi.check(L.gys_hist_add_dev(eng.h, kind, hh.data_ptr(), nk, dk[lo:hi].data_ptr(), dv[lo:hi].data_ptr(), hi - lo))
+    capi.check(L.gys_hist_merge_dev(eng.h, h1.data_ptr(), h2.data_ptr(), nk))
+    pcts = np.array([1, 25, 50, 75, 95, 99, 99.99, 100], dtype=np.float32)
+    out = torch.zeros(nk * len(pcts), dtype=torch.int64, device="cuda")
+    capi.check(L.gys_hist_percentiles_dev(eng.h, kind, h1.data_ptr(), nk, pcts.ctypes.data_as(capi.f32p), len(pcts), out.data_ptr()))
+    eng.sync()
+    got = h1.cpu().numpy().view(np.int64).reshape(nk, 16, 2)
+    stats, total, maxv = oracle.keyed_hist(kind, nk, keys, vals)
+    assert (got[:, :15, :] == stats[:, :15, :]).all()
+    assert (got[:, 15, 0] == total.astype(np.int64)).all() and (got[:, 15, 1] == maxv).all()
+    gp = out.cpu().numpy().reshape(nk, len(pcts))
+    for k in range(0, nk, 17):
+        ov, _, _, _ = oracle.hist_percentiles(kind, stats[k], total[k], [float(p) for p in pcts])
+        assert gp[k].tolist() == ov
+    eng.close()
