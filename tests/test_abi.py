@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: libgysketch.so loads without a GPU, exports every symbol include/gysketch.h declares,
+the ctypes table covers exactly that set, struct sizes agree, and compute entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "gysketch.h")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from gyeeta_amd import build, capi as c
+    if build.needs_build():
+        build.build()
+    c.load()
+    return c
+
+
+def declared_functions():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gys_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(capi):
+    names = declared_functions()
+    assert len(names) > 40
+    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
+    exported = set(re.findall(r"\bT (gys_[a-z0-9_]+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, f"declared in gysketch.h but not exported: {missing}"
+    assert sorted(capi.SIGNATURES) == names, (set(capi.SIGNATURES) ^ set(names))
+
+
+def test_struct_sizes_match_header(capi, tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "gysketch.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(gys_config),sizeof(gys_listener_info),sizeof(gys_resp_seg),sizeof(gys_host_state),sizeof(gys_reduce_section),"
+                   "sizeof(gys_svcsumm),sizeof(gys_cluster_state),sizeof(gys_hist_data),sizeof(gys_hist_rec),sizeof(gys_topn_entry),sizeof(gys_counters));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])  # header is plain C
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    exp = [C.sizeof(t) for t in (capi.Config, capi.ListenerInfo, capi.RespSeg, capi.HostState, capi.ReduceSection, capi.SvcSumm,
+                                 capi.ClusterState, capi.HistData, capi.HistRec, capi.TopnEntry, capi.Counters)]
+    assert got == exp
+    assert C.sizeof(capi.HistRec) == 256 and C.sizeof(capi.SvcSumm) == 52 and C.sizeof(capi.ClusterState) == 44
+
+
+def test_no_cpu_fallback(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = capi.load()
+    cfg = capi.Config()
+    cfg.struct_size = C.sizeof(capi.Config)
+    cfg.device, cfg.nranks, cfg.max_hosts, cfg.max_services, cfg.max_clusters = -1, 1, 4, 16, 2
+    h = C.c_void_p()
+    rc = L.gys_create(C.byref(cfg), C.byref(h))
+    assert rc == capi.ERR_HIP and b"hipGetDeviceCount" in L.gys_last_error()
+    from gyeeta_amd.engine import SketchEngine
+    with pytest.raises(RuntimeError):
+        SketchEngine(max_hosts=1, max_services=1)
+
+
+def test_bad_config_rejected(capi):
+    L = capi.load()
+    cfg = capi.Config()
+    h = C.c_void_p()
+    assert L.gys_create(C.byref(cfg), C.byref(h)) == capi.ERR_INVAL  # struct_size 0
+    assert L.gys_abi_version() == 1
+
+
+def test_shard_function_is_reference_machine_id_hash(capi, oracle):
+    from gyeeta_amd import wire
+    from gyeeta_amd.engine import mid_buf
+    L = capi.load()
+    for h in range(200):
+        mid = wire.machine_id(h)
+        first, second = int.from_bytes(mid[:8], "little"), int.from_bytes(mid[8:], "little")
+        ref = oracle.lib().gyo_machine_id_hash(first, second)  # GY_MACHINE_ID::get_hash (pinned against oracle/_ref)
+        assert L.gys_machine_id_hash(mid_buf(mid)) == ref
+        for n in (1, 2, 4, 8):
+            assert L.gys_shard_of(mid_buf(mid), n) == ref % n

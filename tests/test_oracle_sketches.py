@@ -1,0 +1,140 @@
+"""properties of the builder-defined sketches as frozen in the oracle (they are the bit-exact targets of the GPU registers):
+HLL accuracy vs exact distinct counts, CMS over-estimate bound, t-digest rank error vs exact sort (<= 1 %), order independence
+and digest-merge behaviour, bucket agreement with GY_HISTOGRAM (SURVEY 8c definition of quantile parity)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_hll_accuracy_and_merge(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(1)
+    for n in (100, 5000, 200_000):
+        regs = np.zeros(1 << 14, dtype=np.uint8)
+        a, b = np.zeros(1 << 14, dtype=np.uint8), np.zeros(1 << 14, dtype=np.uint8)
+        keys = rng.integers(0, 2**32, (n, 4), dtype=np.uint64).astype(np.uint32)
+        for i in range(n):
+            w = np.ascontiguousarray(keys[i])
+            L.gyo_hll_add_words(oracle.ptr(regs, oracle.u8p), 14, oracle.ptr(w, oracle.u32p), 4)
+            L.gyo_hll_add_words(oracle.ptr(a if i % 2 else b, oracle.u8p), 14, oracle.ptr(w, oracle.u32p), 4)
+            if i % 3 == 0:  # duplicates never change the registers
+                L.gyo_hll_add_words(oracle.ptr(regs, oracle.u8p), 14, oracle.ptr(w, oracle.u32p), 4)
+        est = L.gyo_hll_estimate(oracle.ptr(regs, oracle.u8p), 14)
+        assert abs(est - n) / n < 0.03
+        L.gyo_hll_merge(oracle.ptr(a, oracle.u8p), oracle.ptr(b, oracle.u8p), 14)  # register-wise max == sketch of the union
+        assert (a == regs).all()
+        assert regs.max() <= 51
+
+
+def test_cms_never_underestimates_and_bound(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(2)
+    tbl = np.zeros(4 * 65536, dtype=np.uint32)
+    nkeys, n = 20000, 300_000
+    zipf = np.minimum(rng.zipf(1.1, n), nkeys) - 1
+    exact = np.bincount(zipf, minlength=nkeys)
+    gids = rng.integers(1, 2**63, nkeys, dtype=np.uint64)
+    for k in np.nonzero(exact)[0]:
+        w = oracle.glob_id_words(int(gids[k]))
+        L.gyo_cms_add(oracle.ptr(tbl, oracle.u32p), oracle.ptr(w, oracle.u32p), 2, int(exact[k]))
+    eps_n = np.e / 65536 * n
+    over = 0
+    for k in range(0, nkeys, 7):
+        w = oracle.glob_id_words(int(gids[k]))
+        q = L.gyo_cms_query(oracle.ptr(tbl, oracle.u32p), oracle.ptr(w, oracle.u32p), 2)
+        assert q >= exact[k]
+        over += (q - exact[k]) > eps_n
+    assert over <= 0.02 * (nkeys / 7)
+    top_exact = set(np.argsort(-exact)[:50])  # heavy hitters: CMS ranking reproduces the exact top-50 (config 5 acceptance)
+    est = np.array([L.gyo_cms_query(oracle.ptr(tbl, oracle.u32p), oracle.ptr(oracle.glob_id_words(int(g)), oracle.u32p), 2) for g in gids])
+    assert set(np.argsort(-est.astype(np.int64), kind="stable")[:50]) == top_exact
+
+
+def _rank_err(x_sorted, v, q):
+    lo = np.searchsorted(x_sorted, v, side="left") / len(x_sorted)
+    hi = np.searchsorted(x_sorted, v, side="right") / len(x_sorted)
+    return 0.0 if lo <= q <= hi else min(abs(lo - q), abs(hi - q))
+
+
+@pytest.mark.parametrize("dist", ["lognormal", "uniform", "bimodal", "constant", "tiny"])
+def test_tdigest_rank_error_and_histogram_bucket_agreement(oracle, dist):
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    n = 200_000
+    if dist == "lognormal":
+        x = np.minimum(np.floor(rng.lognormal(3.0, 1.5, n)), 1e6)
+    elif dist == "uniform":
+        x = rng.integers(0, 20000, n)
+    elif dist == "bimodal":
+        x = np.where(rng.random(n) < 0.7, rng.normal(20, 3, n), rng.normal(900, 50, n)).clip(0)
+    elif dist == "constant":
+        x = np.full(n, 77)
+    else:
+        x, n = np.array([5, 1, 9]), 3
+    x = x.astype(np.int32)
+    d = oracle.TDigest()
+    L.gyo_td_init(C.byref(d))
+    for chunk in np.array_split(x, 37 if n > 100 else 1):  # many batch merges, like successive ingest calls
+        c = np.ascontiguousarray(chunk)
+        L.gyo_td_merge_values(C.byref(d), oracle.ptr(c, oracle.i32p), len(c))
+    assert L.gyo_td_total(C.byref(d)) == n
+    assert sum(d.sum) == int(x.astype(np.int64).sum())  # checksum: cluster sums add up exactly
+    xs = np.sort(x)
+    h = oracle.Hist()
+    L.gyo_hist_init(C.byref(h), 0)
+    x64 = x.astype(np.int64)
+    L.gyo_hist_add_many(C.byref(h), oracle.ptr(x64, oracle.i64p), n)
+    for q in (0.001, 0.01, 0.25, 0.5, 0.75, 0.95, 0.99, 0.999):
+        v = L.gyo_td_quantile(C.byref(d), q)
+        err = _rank_err(xs, v, q)
+        assert err <= max(0.01, 1.0 / n), (dist, q, v, err)  # rank granularity is 1/n for tiny inputs
+        # bucket ceiling of the digest quantile == GY_HISTOGRAM::get_percentile unless the exact quantile is within
+        # 1 % rank of a bucket edge
+        pd = (oracle.HistData * 1)()
+        pd[0].percentile = q * 100
+        L.gyo_hist_percentiles(C.byref(h), pd, 1, None, None, None)
+        ceil_td = L.gyo_bucket_max_threshold(0, L.gyo_bucket(0, int(round(v))))
+        if ceil_td != pd[0].data_value and n > 100:
+            lo_v, hi_v = xs[max(0, int((q - 0.01) * n))], xs[min(n - 1, int((q + 0.01) * n))]
+            assert L.gyo_bucket(0, int(lo_v)) != L.gyo_bucket(0, int(hi_v)), (dist, q, v, pd[0].data_value)
+    assert L.gyo_td_quantile(C.byref(d), 0.0) == float(xs[0]) and L.gyo_td_quantile(C.byref(d), 1.0) == float(xs[-1])
+
+
+def test_tdigest_batch_is_order_independent_and_digest_merge(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(4)
+    x = np.minimum(np.floor(rng.lognormal(3, 1.5, 5000)), 1e6).astype(np.int32)
+    base = np.minimum(np.floor(rng.lognormal(4, 1, 3000)), 1e6).astype(np.int32)
+    outs = []
+    for perm in (np.arange(5000), rng.permutation(5000), np.argsort(x)[::-1]):
+        d = oracle.TDigest()
+        L.gyo_td_init(C.byref(d))
+        L.gyo_td_merge_values(C.byref(d), oracle.ptr(base, oracle.i32p), len(base))
+        xp = np.ascontiguousarray(x[perm])
+        L.gyo_td_merge_values(C.byref(d), oracle.ptr(xp, oracle.i32p), len(xp))
+        outs.append((list(d.sum), list(d.cnt), d.vmin, d.vmax))
+    assert outs[0] == outs[1] == outs[2]
+    # merging two digests (the multi-GPU / roll-up operator) keeps totals and stays within the rank budget
+    a, b = oracle.TDigest(), oracle.TDigest()
+    L.gyo_td_init(C.byref(a))
+    L.gyo_td_init(C.byref(b))
+    L.gyo_td_merge_values(C.byref(a), oracle.ptr(x, oracle.i32p), len(x))
+    L.gyo_td_merge_values(C.byref(b), oracle.ptr(base, oracle.i32p), len(base))
+    L.gyo_td_merge_digest(C.byref(a), C.byref(b))
+    assert L.gyo_td_total(C.byref(a)) == 8000 and sum(a.sum) == int(x.astype(np.int64).sum() + base.astype(np.int64).sum())
+    xs = np.sort(np.concatenate([x, base]))
+    for q in (0.01, 0.5, 0.99):
+        assert _rank_err(xs, L.gyo_td_quantile(C.byref(a), q), q) <= 0.01
+    means = [s / c for s, c in zip(a.sum, a.cnt) if c]
+    assert all(means[i] <= means[i + 1] for i in range(len(means) - 1))  # cluster means stay sorted
+
+
+def test_conn_bitmap(oracle):
+    L = oracle.lib()
+    m = np.zeros(32, dtype=np.uint16)
+    for port, b in [(16000, 3), (16032, 3), (16001, 3), (16001, 7), (65535, 14)]:
+        L.gyo_conn_bitmap_add(oracle.ptr(m, oracle.u16p), port, b)
+    out = np.zeros(15, dtype=np.uint8)
+    L.gyo_conn_bitmap_breakup(oracle.ptr(m, oracle.u16p), oracle.ptr(out, oracle.u8p))
+    assert out[3] == 2 and out[7] == 1 and out[14] == 1 and out.sum() == 4  # ports 16000 and 16032 share slot 0
