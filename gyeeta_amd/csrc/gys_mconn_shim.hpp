@@ -1,0 +1,119 @@
+// gys_mconn_shim.hpp -- C++17 host-side mirror of the reference's aggregation entry points on top of the C ABI.
+//
+// The reference has no plugin layer: the path under replacement is a handful of MCONN_HANDLER / SHCONN_HANDLER member functions
+// invoked from the L2 dispatch switch (server/gy_mconnhdlr.cc:4756-4792).  This header gives a class with THOSE names, argument
+// order and error behaviour (bool return, never throws across the boundary) so that the bodies of the reference functions can be
+// replaced by one-line forwards (INTEGRATION.md shows the exact diff).  The reference types it cannot include here (comm::*,
+// PARTHA_INFO) appear as opaque byte pointers with the same memory layout contract:
+//
+//   reference signature (server/gy_mconnhdlr.h)                                              -> shim
+//   bool partha_tcp_conn_info(const std::shared_ptr<PARTHA_INFO>&, comm::TCP_CONN_NOTIFY*,      partha_tcp_conn_info(machine_id, pone, nconns, pendptr)
+//                             int nconns, uint8_t *pendptr, POOL_ALLOC_ARRAY*)            :2091
+//   bool partha_listener_state(const std::shared_ptr<PARTHA_INFO>&, const comm::LISTENER_STATE_NOTIFY*,  partha_listener_state(machine_id, pone, nconns, pendptr)
+//                             int nconns, uint8_t *pendptr, POOL_ALLOC_ARRAY*, PGConnPool&, bool) :2129
+//   void send_cluster_state() noexcept                                                    :2155  send_cluster_state(allreduce_cb)
+//   TCP_SOCK_HANDLER::handle_ipv4_resp_event(tcp_ipv4_resp_event_t*, bool) (gy_socket_stat.cc:1517)  handle_ipv4_resp_events(machine_id, pevents, n)
+//   web_curr_listener_summ (server/gy_mnodehandle.cc:1628)                                       get_listener_summ(machine_id, out)
+//
+// PARTHA_INFO is identified by its GY_MACHINE_ID (PARTHA_INFO::machine_id_, the key of partha_tbl_).
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/gysketch.h"
+
+namespace gyeeta_amd {
+
+class GYS_MCONN_HANDLER {
+public:
+	// cb: performs the cross-GPU reduce of every gys_reduce_section (RCCL ncclAllReduce with ncclMax / ncclSum on the section's
+	// dev_ptr); empty for a single GPU.  It is the analogue of NOTIFY_MS_CLUSTER_STATE -> SHCONN_HANDLER::aggregate_cluster_state.
+	using ReduceFn = std::function<bool(const gys_reduce_section *secs, uint32_t nsecs)>;
+
+	explicit GYS_MCONN_HANDLER(const gys_config &cfg)
+	{
+		if (gys_create(&cfg, &ctx_) != GYS_OK) throw std::runtime_error(std::string("gys_create: ") + gys_last_error());
+	}
+	~GYS_MCONN_HANDLER() { gys_destroy(ctx_); }
+	GYS_MCONN_HANDLER(const GYS_MCONN_HANDLER &) = delete;
+	GYS_MCONN_HANDLER &operator=(const GYS_MCONN_HANDLER &) = delete;
+
+	gys_ctx *ctx() noexcept { return ctx_; }
+
+	// partha registration (PM_CONNECT) and NOTIFY_NEW_LISTENER: the two control-plane facts the data path needs
+	bool partha_register(const uint8_t machine_id[16], const char *cluster_name) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		return gys_register_host(ctx_, machine_id, cluster_name, nullptr) == GYS_OK;
+	}
+	bool partha_new_listeners(const uint8_t machine_id[16], const gys_listener_info *arr, uint32_t n) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		return gys_register_listeners(ctx_, machine_id, arr, n, nullptr) == GYS_OK;
+	}
+
+	// MCONN_HANDLER::partha_tcp_conn_info: pone points into the L1 receive buffer, valid only during the call
+	bool partha_tcp_conn_info(const uint8_t machine_id[16], const void *pone, int nconns, const uint8_t *pendptr) noexcept
+	{
+		if (!pone || nconns < 0) return false;
+		std::lock_guard<std::mutex> g(mu_); // up to 16 L2 threads call concurrently (gy_mconnhdlr.h:60); one context == one stream
+		return gys_ingest_tcp_conn(ctx_, machine_id, pone, (uint32_t)nconns, pendptr) == GYS_OK;
+	}
+
+	// MCONN_HANDLER::partha_listener_state
+	bool partha_listener_state(const uint8_t machine_id[16], const void *pone, int nconns, const uint8_t *pendptr) noexcept
+	{
+		if (!pone || nconns < 0) return false;
+		std::lock_guard<std::mutex> g(mu_);
+		return gys_ingest_listener_state(ctx_, machine_id, pone, (uint32_t)nconns, pendptr) == GYS_OK;
+	}
+
+	// comm::HOST_STATE_NOTIFY store read by send_cluster_state (gy_mconnhdlr.cc:16052-16075)
+	bool partha_host_state(const uint8_t machine_id[16], const gys_host_state &st) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		return gys_ingest_host_state(ctx_, machine_id, &st) == GYS_OK;
+	}
+
+	// TCP_SOCK_HANDLER::handle_ipv4_resp_event for a batch of raw 24-byte events of one host
+	bool handle_ipv4_resp_events(const uint8_t machine_id[16], const void *pevents, uint32_t nevents) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		return gys_ingest_resp_events(ctx_, machine_id, pevents, nevents) == GYS_OK;
+	}
+
+	// MCONN_HANDLER::send_cluster_state (scheduled every 5000 ms, gy_mconnhdlr.cc:207-210) + the shyama-side aggregation
+	void send_cluster_state(uint64_t tusec, const ReduceFn &reduce = {}) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		if (gys_window_prepare(ctx_, tusec) != GYS_OK) return;
+		if (reduce) {
+			gys_reduce_section secs[4];
+			uint32_t n = 0;
+			if (gys_reduce_sections(ctx_, secs, &n) == GYS_OK) (void)reduce(secs, n);
+		}
+		(void)gys_window_finish(ctx_);
+	}
+
+	// web_curr_listener_summ: LISTEN_SUMM_STATS<int> of one partha (fields map 1:1 onto svcsumm JSON, gy_mfields.h:768-790)
+	bool get_listener_summ(const uint8_t machine_id[16], gys_svcsumm &out) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		return gys_query_svcsumm(ctx_, machine_id, &out) == GYS_OK;
+	}
+	bool get_cluster_state(const char *cluster, gys_cluster_state &out) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		return gys_query_clusterstate(ctx_, cluster, &out) == GYS_OK;
+	}
+
+private:
+	gys_ctx *ctx_ = nullptr;
+	std::mutex mu_;
+};
+
+} // namespace gyeeta_amd
