@@ -192,9 +192,14 @@ __host__ __device__ inline void hist_percentile(const HashDef &d, const gys_hist
 }
 
 // ------------------------------------------------------------------------------------------------ open-addressing key table
+struct TblEnt {
+	uint64_t key; // GYS_EMPTY_KEY = free
+	uint32_t val;
+	uint32_t pad;
+};
+
 struct DevTable {
-	uint64_t *keys; // GYS_EMPTY_KEY = free
-	uint32_t *vals;
+	TblEnt *ent; // 16-byte entries: one 16-B load per probe
 	uint32_t mask;
 };
 
@@ -204,8 +209,9 @@ __device__ __forceinline__ uint32_t tbl_lookup(const DevTable &t, uint64_t key)
 {
 	uint32_t h = get_uint64_hash(key) & t.mask;
 	for (uint32_t probes = 0; probes <= t.mask; ++probes) {
-		const uint64_t k = t.keys[h];
-		if (k == key) return t.vals[h];
+		const uint4 e = *(const uint4 *)&t.ent[h];
+		const uint64_t k = (uint64_t)e.x | ((uint64_t)e.y << 32);
+		if (k == key) return e.z;
 		if (k == GYS_EMPTY_KEY) return GYS_NOSLOT;
 		h = (h + 1) & t.mask;
 	}

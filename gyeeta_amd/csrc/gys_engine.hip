@@ -300,7 +300,6 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	}
 	HIPCHK(hipMemcpyAsync(c->segs_dev, segs_host, (uint64_t)nsegs * sizeof(gys_resp_seg), hipMemcpyHostToDevice, c->stream));
 
-	int64_t *i64sum = (int64_t *)(c->arena + c->al.off_i64sum);
 	RespP1 p{};
 	p.ev = (const uint64_t *)d_ev;
 	p.n = n;
@@ -312,8 +311,6 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	p.bitmap = c->bitmap;
 	p.hll32 = c->hll32;
 	p.cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
-	p.ghist = i64sum + c->al.i64_ghist;
-	p.gmax = (int64_t *)(c->arena + c->al.off_i64max);
 	p.batch_cnt = td ? c->batch_cnt : nullptr;
 	p.ev_kv = td ? c->ev_kv : nullptr;
 	p.counters = c->counters;
@@ -349,6 +346,13 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	d.off_end = c->batch_off;
 	d.staged = c->staged;
 	d.nsvc = nsvc;
+	d.hist_win = c->hist_win;
+	d.cms32 = p.cms32;
+	d.svc_gid = c->svc_gid;
+	{
+		ProfScope ps(c, "digest_wave");
+		hipLaunchKernelGGL(k_digest_wave, dim3(std::min<uint32_t>((nsvc + 3) / 4, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, d);
+	}
 	{
 		ProfScope ps(c, "digest_small");
 		hipLaunchKernelGGL(k_digest_small, dim3(std::min<uint32_t>(nsvc, (uint32_t)c->ncu * 16)), dim3(64), 0, c->stream, d);
@@ -483,13 +487,11 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		gys_destroy(c);                          \
 		return rc;                               \
 	}
-	ALLOC(c->lk_tbl.keys, cap);
-	ALLOC(c->lk_tbl.vals, cap);
-	ALLOC(c->gid_tbl.keys, cap);
-	ALLOC(c->gid_tbl.vals, cap);
+	ALLOC(c->lk_tbl.ent, cap);
+	ALLOC(c->gid_tbl.ent, cap);
 	c->lk_tbl.mask = c->gid_tbl.mask = cap - 1;
-	HIPCHK(hipMemset(c->lk_tbl.keys, 0xFF, (uint64_t)cap * 8));
-	HIPCHK(hipMemset(c->gid_tbl.keys, 0xFF, (uint64_t)cap * 8));
+	HIPCHK(hipMemset(c->lk_tbl.ent, 0xFF, (uint64_t)cap * sizeof(TblEnt)));
+	HIPCHK(hipMemset(c->gid_tbl.ent, 0xFF, (uint64_t)cap * sizeof(TblEnt)));
 	ALLOC(c->svc_gid, S);
 	ALLOC(c->hist_win, S);
 	ALLOC(c->hist_all, S);
@@ -557,7 +559,7 @@ void gys_destroy(gys_ctx *c)
 	if (!c) return;
 	if (c->stream) hipStreamSynchronize(c->stream);
 	prof_resolve(c);
-	void *ptrs[] = {c->lk_tbl.keys, c->lk_tbl.vals, c->gid_tbl.keys, c->gid_tbl.vals, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
+	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
 			c->td_cnt, c->td_minmax, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_list, c->huge_count,
 			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->segs_dev, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
@@ -793,6 +795,13 @@ int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 	{
 		ProfScope ps(c, "window_prepare");
 		hipLaunchKernelGGL(k_window_prepare, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, p);
+		if (c->nsvc) {
+			// all-time += window (GY_HISTOGRAM::add_histogram), window cleared, and the all-service histogram of the window reduced
+			// into the arena in the same pass over the records
+			long long *gh = (long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
+			hipLaunchKernelGGL(k_hist_fold, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->hist_all,
+					   c->hist_win, (uint64_t)c->nsvc, 1, gh, (long long *)(c->arena + c->al.off_i64max));
+		}
 	}
 	HIPCHK(hipGetLastError());
 	c->prepared = true;
@@ -816,9 +825,7 @@ int gys_window_finish(gys_ctx *c)
 	}
 	HIPCHK(hipMemsetAsync(c->hll32, 0, (uint64_t)4 << GYS_HLL_P, c->stream));
 	if (c->nsvc) {
-		// all-time += window (GY_HISTOGRAM::add_histogram), window cleared; CONN_BITMAP cleared every window (secs_to_reset_ = 5)
-		hipLaunchKernelGGL(k_hist_fold, dim3((uint32_t)(((uint64_t)c->nsvc * 16 + 255) / 256)), dim3(256), 0, c->stream, c->hist_all, c->hist_win,
-				   (uint64_t)c->nsvc, 1);
+		// CONN_BITMAP cleared every window (secs_to_reset_ = 5)
 		HIPCHK(hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * 64, c->stream));
 		if (c->svc_hll) HIPCHK(hipMemsetAsync(c->svc_hll, 0, (uint64_t)c->nsvc << c->cfg.svc_hll_p, c->stream));
 	}
@@ -1190,8 +1197,8 @@ int gys_hist_merge_dev(gys_ctx *c, gys_hist_rec *d_dst, const gys_hist_rec *d_sr
 	if (!c || !d_dst || !d_src) return GYS_ERR_INVAL;
 	if (!nkeys) return GYS_OK;
 	ProfScope ps(c, "hist_merge");
-	hipLaunchKernelGGL(k_hist_fold, dim3((uint32_t)(((uint64_t)nkeys * 16 + 255) / 256)), dim3(256), 0, c->stream, d_dst, (gys_hist_rec *)d_src,
-			   (uint64_t)nkeys, 0);
+	hipLaunchKernelGGL(k_hist_fold, dim3(grid_for((uint64_t)nkeys * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, d_dst,
+			   (gys_hist_rec *)d_src, (uint64_t)nkeys, 0, (long long *)nullptr, (long long *)nullptr);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
 }

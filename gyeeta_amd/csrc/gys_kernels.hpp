@@ -29,9 +29,9 @@ __global__ void k_table_insert(DevTable t, const uint64_t *keys, uint32_t first_
 	const uint64_t key = keys[i];
 	uint32_t h = get_uint64_hash(key) & t.mask;
 	for (uint32_t probes = 0; probes <= t.mask; ++probes) {
-		const unsigned long long prev = atomicCAS((unsigned long long *)&t.keys[h], (unsigned long long)GYS_EMPTY_KEY, (unsigned long long)key);
+		const unsigned long long prev = atomicCAS((unsigned long long *)&t.ent[h].key, (unsigned long long)GYS_EMPTY_KEY, (unsigned long long)key);
 		if (prev == GYS_EMPTY_KEY || prev == key) {
-			t.vals[h] = first_val + i; // re-registration of a key rebinds it to the newest slot
+			t.ent[h].val = first_val + i; // re-registration of a key rebinds it to the newest slot
 			return;
 		}
 		h = (h + 1) & t.mask;
@@ -69,8 +69,6 @@ struct RespP1 {
 	uint32_t *bitmap;         // [nsvc*16] u32 = 32 x u16 CONN_BITMAP rows
 	uint32_t *hll32;          // [1<<14]
 	uint32_t *cms32;          // arena [D*W]
-	int64_t *ghist;           // arena: 15 x {count,sum} + {total}
-	int64_t *gmax;            // arena (MAX section)
 	uint32_t *batch_cnt;      // nullptr when the t-digest is off
 	uint64_t *ev_kv;          // (slot << 32 | value) per event, ~0 = dropped
 	uint64_t *counters;
@@ -92,13 +90,10 @@ __device__ __forceinline__ uint16_t bswap16(uint16_t v) { return (uint16_t)((v >
 
 __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 {
-	__shared__ unsigned long long s_gh[32]; // 15 x {count,sum} + total (global histogram privatised per block)
-	__shared__ long long s_gmax;
 	__shared__ unsigned int s_ctr[3];
-	if (threadIdx.x < 32) s_gh[threadIdx.x] = 0;
-	if (threadIdx.x == 0) s_gmax = INT64_MIN;
 	if (threadIdx.x < 3) s_ctr[threadIdx.x] = 0;
 	__syncthreads();
+	const bool fused = p.batch_cnt != nullptr; // histogram + CMS are then produced per KEY by the digest kernels from the sorted runs
 
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
@@ -121,12 +116,19 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 				atomicAdd(&s_ctr[2], 1u); // no such listener: the reference ignores the event too (:1671-1676 miss path)
 			} else {
 				const uint32_t b = resp_bucket((int64_t)tresp);
-				// GY_HISTOGRAM::add_data / HIST_SERIAL::add (common/gy_statistics.h:463-467, :596-623)
-				gys_hist_rec *h = &p.hist_win[slot];
-				atomicAdd((unsigned long long *)&h->stats[b].count, 1ull);
-				atomicAdd((unsigned long long *)&h->stats[b].sum, (unsigned long long)tresp);
-				atomicAdd((unsigned long long *)&h->total_count, 1ull);
-				if (h->max_val_seen < (int64_t)tresp) atomicMax((long long *)&h->max_val_seen, (long long)tresp);
+				if (!fused) {
+					// GY_HISTOGRAM::add_data / HIST_SERIAL::add (common/gy_statistics.h:463-467, :596-623)
+					gys_hist_rec *h = &p.hist_win[slot];
+					atomicAdd((unsigned long long *)&h->stats[b].count, 1ull);
+					atomicAdd((unsigned long long *)&h->stats[b].sum, (unsigned long long)tresp);
+					atomicAdd((unsigned long long *)&h->total_count, 1ull);
+					if (h->max_val_seen < (int64_t)tresp) atomicMax((long long *)&h->max_val_seen, (long long)tresp);
+					// Count-Min: events per service key (glob_id), row hash jhash2(key, seed + r)
+					const uint64_t gid = p.svc_gid[slot];
+#pragma unroll
+					for (uint32_t r = 0; r < GYS_CMS_D; ++r)
+						atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(gid, GYS_SEED + r) & (GYS_CMS_W - 1))], 1u);
+				}
 				// CONN_BITMAP::add_response: respmap_[cli_port & 0x1F].set(bucket) (common/gy_socket_stat.h:403-410)
 				{
 					const uint32_t row = dport & 0x1Fu;
@@ -134,11 +136,6 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 					uint32_t *wp = &p.bitmap[(size_t)slot * 16u + (row >> 1)];
 					if ((*wp & bit) == 0) atomicOr(wp, bit);
 				}
-				// global histogram (block-private, flushed once per block)
-				atomicAdd(&s_gh[2 * b], 1ull);
-				atomicAdd(&s_gh[2 * b + 1], (unsigned long long)tresp);
-				atomicAdd(&s_gh[30], 1ull);
-				atomicMax(&s_gmax, (long long)tresp);
 				// distinct client flows: HLL over PAIR_IP_PORT(cli = daddr:dport, ser = saddr:sport) (common/gy_inet_inc.h:225-247)
 				{
 					uint32_t w[10];
@@ -149,7 +146,7 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 					hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
 					if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
 					if (p.svc_hll_p) {
-						// per-service distinct clients: key = client endpoint only (same hash, different split)
+						// per-service distinct clients: same hash, per-service register file (u8 packed, CAS on the word)
 						uint32_t sidx, srank;
 						hll_idx_rank(h64, (int)p.svc_hll_p, &sidx, &srank);
 						uint8_t *base = p.svc_hll + ((size_t)slot << p.svc_hll_p);
@@ -164,14 +161,7 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 						}
 					}
 				}
-				// Count-Min: events per service key (glob_id), row hash jhash2(key, seed + r)
-				{
-					const uint64_t gid = p.svc_gid[slot];
-#pragma unroll
-					for (uint32_t r = 0; r < GYS_CMS_D; ++r)
-						atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(gid, GYS_SEED + r) & (GYS_CMS_W - 1))], 1u);
-				}
-				if (p.batch_cnt) {
+				if (fused) {
 					atomicAdd(&p.batch_cnt[slot], 1u);
 					kv = ((uint64_t)slot << 32) | (uint64_t)tresp;
 				}
@@ -180,8 +170,6 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 		if (p.ev_kv) p.ev_kv[i] = kv;
 	}
 	__syncthreads();
-	if (threadIdx.x < 31 && s_gh[threadIdx.x]) atomicAdd((unsigned long long *)&p.ghist[threadIdx.x], s_gh[threadIdx.x]);
-	if (threadIdx.x == 31 && s_gmax != INT64_MIN) atomicMax((long long *)p.gmax, s_gmax);
 	if (threadIdx.x < 3 && s_ctr[threadIdx.x]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS + threadIdx.x], (unsigned long long)s_ctr[threadIdx.x]);
 }
 
@@ -294,7 +282,52 @@ struct DigestP {
 	const uint32_t *off_end;
 	const uint32_t *staged;
 	uint32_t nsvc;
+	// fused per-key outputs (the digest kernels see every key's values of the batch, so they also produce the exact histogram
+	// delta and the Count-Min increment of the key -- one coalesced record update instead of ~9 atomics per EVENT)
+	gys_hist_rec *hist_win;
+	uint32_t *cms32;
+	const uint64_t *svc_gid;
 };
+
+// applies a key's batch deltas: s_h[2b] = count, s_h[2b+1] = sum of bucket b (LDS), m values, vmax = largest value.
+// lanes 0..14: HIST_SERIAL buckets, lane 15: total_count_/max_val_seen_, lanes 16..19: the 4 Count-Min rows.
+__device__ __forceinline__ void key_epilogue(const DigestP &p, uint32_t slot, uint32_t m, int32_t vmax, const unsigned long long *s_h, uint32_t lane)
+{
+	gys_hist_rec *h = &p.hist_win[slot];
+	if (lane < 15u) {
+		const unsigned long long c = s_h[2 * lane];
+		if (c) {
+			h->stats[lane].count += c;
+			h->stats[lane].sum += (int64_t)s_h[2 * lane + 1];
+		}
+	} else if (lane == 15u) {
+		h->total_count += m;
+		if (h->max_val_seen < (int64_t)vmax) h->max_val_seen = (int64_t)vmax;
+	} else if (lane < 20u) {
+		const uint32_t r = lane - 16u;
+		atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(p.svc_gid[slot], GYS_SEED + r) & (GYS_CMS_W - 1))], m);
+	}
+}
+
+// wave-synchronous LDS hand-off: DS operations of one wave execute in order; this only stops the compiler from moving them
+#define GYS_WAVE_SYNC()                                              \
+	do {                                                         \
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+		__builtin_amdgcn_wave_barrier();                     \
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+	} while (0)
+
+#define GYS_WAVE_MAX 64u // keys with <= 64 new values: sorted in registers by k_digest_wave
+
+__device__ __forceinline__ uint32_t td_cluster_of(const uint64_t *T, uint64_t mid2)
+{
+	uint32_t a = 0, bb = GYS_TD_NB - 1;
+	while (a < bb) {
+		const uint32_t mid = (a + bb + 1) >> 1;
+		if (mid2 >= T[mid]) a = mid; else bb = mid - 1;
+	}
+	return a;
+}
 
 // lanes 0..63 each own entries (lane) and (lane + 64) of a <= 128 long array: exclusive prefix sum (u64) across the wave
 __device__ __forceinline__ void wave_excl_scan_2x(uint64_t a0, uint64_t a1, uint64_t *e0, uint64_t *e1, uint64_t *total)
@@ -315,6 +348,184 @@ __device__ __forceinline__ void wave_excl_scan_2x(uint64_t a0, uint64_t a1, uint
 	*total = tot0 + tot1;
 }
 
+// Keys with <= 64 new values (the common case at ~10..100 events per key per window): one WAVE per key, 4 independent waves per
+// workgroup, no workgroup barriers.  New values live one per lane and are sorted with a 21-step __shfl_xor bitonic network; old
+// clusters live two per lane; ranks are exchanged through a 65-entry LDS "weight at rank" array + a __shfl_up scan.
+// A wave walks a chunk of 64 consecutive keys: the chunk's counts/offsets come from ONE coalesced load (then v_readlane), and the
+// next key's digest / values / histogram record are prefetched into registers while the current key is merged, so the per-key
+// critical path holds no dependent HBM round trip.
+struct KeyRegs {
+	int32_t v;          // new value of this lane (INT32_MAX padding)
+	uint32_t c0, c1;    // old cluster counts (entries lane, lane + 64)
+	int64_t sm0, sm1;   // old cluster sums
+	uint64_t hc, hs;    // lanes 0..15: the 16-byte pair `lane` of the key's histogram record
+	uint64_t aux;       // lane 16..19: glob_id (Count-Min key); lane 20: packed {vmin, vmax}
+};
+
+__device__ __forceinline__ void key_prefetch(const DigestP &p, uint32_t slot, uint32_t m, uint32_t oend, uint32_t lane, KeyRegs &r)
+{
+	const uint32_t j1 = lane + 64u;
+	r.v = lane < m ? (int32_t)p.staged[oend - m + lane] : INT32_MAX;
+	const int64_t *gs = p.td_sum + (size_t)slot * GYS_TD_NB;
+	const uint32_t *gc = p.td_cnt + (size_t)slot * GYS_TD_NB;
+	r.c0 = gc[lane];
+	r.c1 = j1 < GYS_TD_NB ? gc[j1] : 0u;
+	r.sm0 = gs[lane];
+	r.sm1 = j1 < GYS_TD_NB ? gs[j1] : 0;
+	r.hc = 0;
+	r.hs = 0;
+	r.aux = 0;
+	if (lane < 16u) {
+		const uint64_t *h = (const uint64_t *)&p.hist_win[slot] + 2 * lane;
+		r.hc = h[0];
+		r.hs = h[1];
+	} else if (lane < 20u) {
+		r.aux = p.svc_gid[slot];
+	} else if (lane == 20u) {
+		r.aux = *(const uint64_t *)(p.td_minmax + (size_t)slot * 2);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
+{
+	__shared__ uint64_t s_T_[4][GYS_TD_NB];
+	__shared__ unsigned long long s_add_[4][GYS_WAVE_MAX + 2];
+	__shared__ unsigned long long s_osum_[4][GYS_TD_NB];
+	__shared__ uint32_t s_ocnt_[4][GYS_TD_NB];
+	__shared__ unsigned long long s_h_[4][32];
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	uint64_t *s_T = s_T_[wv];
+	unsigned long long *s_add = s_add_[wv], *s_osum = s_osum_[wv], *s_h = s_h_[wv];
+	uint32_t *s_ocnt = s_ocnt_[wv];
+	const uint32_t nwaves = gridDim.x * 4u;
+	const uint32_t j1 = lane + 64u;
+	const uint32_t nchunks = (p.nsvc + 63u) / 64u;
+
+	for (uint32_t chunk = blockIdx.x * 4u + wv; chunk < nchunks; chunk += nwaves) {
+		const uint32_t key = chunk * 64u + lane;
+		uint32_t mcnt = key < p.nsvc ? p.batch_cnt[key] : 0u;
+		const uint32_t oend = key < p.nsvc ? p.off_end[key] : 0u;
+		if (mcnt > GYS_WAVE_MAX) mcnt = 0; // larger keys belong to k_digest_small / k_digest_huge
+		unsigned long long todo = __ballot(mcnt != 0);
+		if (!todo) continue;
+		if (mcnt) p.batch_cnt[key] = 0; // consumed (coalesced reset for the whole chunk)
+		KeyRegs cur, nxt;
+		uint32_t i = (uint32_t)__ffsll((long long)todo) - 1u;
+		todo &= todo - 1;
+		key_prefetch(p, chunk * 64u + i, (uint32_t)__shfl((int)mcnt, (int)i, 64), (uint32_t)__shfl((int)oend, (int)i, 64), lane, cur);
+		for (;;) {
+			const uint32_t slot = chunk * 64u + i;
+			const uint32_t m = (uint32_t)__shfl((int)mcnt, (int)i, 64);
+			uint32_t inext = 64u;
+			if (todo) { // issue the next key's loads now; they are consumed one iteration later
+				inext = (uint32_t)__ffsll((long long)todo) - 1u;
+				todo &= todo - 1;
+				key_prefetch(p, chunk * 64u + inext, (uint32_t)__shfl((int)mcnt, (int)inext, 64), (uint32_t)__shfl((int)oend, (int)inext, 64), lane, nxt);
+			}
+			int32_t v = cur.v;
+			const uint32_t c0 = cur.c0, c1 = cur.c1;
+			const int64_t sm0 = cur.sm0, sm1 = cur.sm1;
+			// bitonic sort across the 64 lanes (ascending), padding = INT32_MAX
+#pragma unroll
+			for (uint32_t k = 2; k <= 64u; k <<= 1) {
+#pragma unroll
+				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+					const int32_t o = __shfl_xor(v, (int)j, 64);
+					const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+					v = (lower == up) ? min(v, o) : max(v, o);
+				}
+			}
+			uint64_t e0, e1, nold;
+			wave_excl_scan_2x((uint64_t)c0, (uint64_t)c1, &e0, &e1, &nold);
+			const uint64_t twoN = 2ull * (nold + (uint64_t)m);
+			if (lane >= 1) s_T[lane] = td_threshold(c_td_bnd[lane], twoN);
+			if (j1 < GYS_TD_NB) s_T[j1] = td_threshold(c_td_bnd[j1], twoN);
+			s_add[lane] = 0;
+			if (lane < 2u) s_add[64u + lane] = 0;
+			s_osum[lane] = 0;
+			s_ocnt[lane] = 0;
+			if (j1 < GYS_TD_NB) {
+				s_osum[j1] = 0;
+				s_ocnt[j1] = 0;
+			}
+			if (lane < 32u) s_h[lane] = 0;
+			GYS_WAVE_SYNC();
+			// ---- old clusters: lt = #{new values with v * cnt < sum} by broadcasting the (few) new values
+			uint32_t lt0 = 0, lt1 = 0;
+			for (uint32_t q = 0; q < m; ++q) {
+				const int64_t vi = (int64_t)__shfl(v, (int)q, 64);
+				lt0 += (vi * (int64_t)c0 < sm0) ? 1u : 0u;
+				lt1 += (vi * (int64_t)c1 < sm1) ? 1u : 0u;
+			}
+			if (c0) {
+				atomicAdd(&s_add[lt0], (unsigned long long)c0); // every new value of rank >= lt0 has this cluster at or before it
+				const uint32_t cl = td_cluster_of(s_T, 2ull * (e0 + lt0) + (uint64_t)c0);
+				atomicAdd(&s_osum[cl], (unsigned long long)sm0);
+				atomicAdd(&s_ocnt[cl], c0);
+			}
+			if (c1) {
+				atomicAdd(&s_add[lt1], (unsigned long long)c1);
+				const uint32_t cl = td_cluster_of(s_T, 2ull * (e1 + lt1) + (uint64_t)c1);
+				atomicAdd(&s_osum[cl], (unsigned long long)sm1);
+				atomicAdd(&s_ocnt[cl], c1);
+			}
+			GYS_WAVE_SYNC();
+			// ---- new values: le(rank r) = sum of s_add[0..r]
+			uint64_t le = s_add[lane];
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint64_t t = __shfl_up(le, d, 64);
+				if ((int)lane >= d) le += t;
+			}
+			if (lane < m) {
+				const uint32_t cl = td_cluster_of(s_T, 2ull * ((uint64_t)lane + le) + 1ull);
+				atomicAdd(&s_osum[cl], (unsigned long long)(int64_t)v);
+				atomicAdd(&s_ocnt[cl], 1u);
+				const uint32_t b = resp_bucket((int64_t)v);
+				atomicAdd(&s_h[2 * b], 1ull);
+				atomicAdd(&s_h[2 * b + 1], (unsigned long long)(int64_t)v);
+			}
+			GYS_WAVE_SYNC();
+			const int32_t vmin = __shfl(v, 0, 64), vmax = __shfl(v, (int)(m - 1), 64);
+			int64_t *ws = p.td_sum + (size_t)slot * GYS_TD_NB;
+			uint32_t *wc = p.td_cnt + (size_t)slot * GYS_TD_NB;
+			ws[lane] = (int64_t)s_osum[lane];
+			wc[lane] = s_ocnt[lane];
+			if (j1 < GYS_TD_NB) {
+				ws[j1] = (int64_t)s_osum[j1];
+				wc[j1] = s_ocnt[j1];
+			}
+			// ---- histogram record (prefetched pair + LDS delta), Count-Min, min/max
+			if (lane < 15u) {
+				const unsigned long long dc = s_h[2 * lane];
+				if (dc) {
+					uint64_t *h = (uint64_t *)&p.hist_win[slot] + 2 * lane;
+					h[0] = cur.hc + dc;
+					h[1] = (uint64_t)((int64_t)cur.hs + (int64_t)s_h[2 * lane + 1]);
+				}
+			} else if (lane == 15u) {
+				uint64_t *h = (uint64_t *)&p.hist_win[slot] + 30;
+				h[0] = cur.hc + m;
+				if ((int64_t)cur.hs < (int64_t)vmax) h[1] = (uint64_t)(int64_t)vmax;
+			} else if (lane < 20u) {
+				const uint32_t r = lane - 16u;
+				atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(cur.aux, GYS_SEED + r) & (GYS_CMS_W - 1))], m);
+			} else if (lane == 20u) {
+				int32_t mn = (int32_t)(uint32_t)cur.aux, mx = (int32_t)(uint32_t)(cur.aux >> 32);
+				if (vmin < mn || vmax > mx) {
+					mn = min(mn, vmin);
+					mx = max(mx, vmax);
+					*(uint64_t *)(p.td_minmax + (size_t)slot * 2) = (uint64_t)(uint32_t)mn | ((uint64_t)(uint32_t)mx << 32);
+				}
+			}
+			GYS_WAVE_SYNC();
+			if (inext >= 64u) break;
+			i = inext;
+			cur = nxt;
+		}
+	}
+}
+
 // One 64-thread workgroup (= one wave) per key, grid-stride over keys.  Exact-integer k-bucket merge (DESIGN.md "t-digest"):
 //   merged order = by mean, old clusters before new values on ties; item with weighted mid-point mid2/2 of N goes to
 //   cluster #{j : mid2 >= T_j}, T_j = ceil(BND[j] * 2N / 2^32).
@@ -327,11 +538,12 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 	__shared__ uint64_t s_T[GYS_TD_NB];    // s_T[j], j = 1..NB-1
 	__shared__ unsigned long long s_osum[GYS_TD_NB];
 	__shared__ uint32_t s_ocnt[GYS_TD_NB];
+	__shared__ unsigned long long s_h[32];
 	const uint32_t lane = threadIdx.x;
 
 	for (uint32_t slot = blockIdx.x; slot < p.nsvc; slot += gridDim.x) {
 		const uint32_t m = p.batch_cnt[slot];
-		if (m == 0 || m > GYS_SMALL_MAX) continue; // uniform per block
+		if (m <= GYS_WAVE_MAX || m > GYS_SMALL_MAX) continue; // uniform per block
 		const uint32_t start = p.off_end[slot] - m;
 
 		// ---- old digest: entries lane, lane+64
@@ -374,6 +586,7 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 			s_osum[j1] = 0;
 			s_ocnt[j1] = 0;
 		}
+		if (lane < 32u) s_h[lane] = 0;
 		__syncthreads();
 		for (uint32_t k = 2; k <= P; k <<= 1) {
 			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -425,8 +638,12 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 			}
 			atomicAdd(&s_osum[a], (unsigned long long)v);
 			atomicAdd(&s_ocnt[a], 1u);
+			const uint32_t b = resp_bucket(v);
+			atomicAdd(&s_h[2 * b], 1ull);
+			atomicAdd(&s_h[2 * b + 1], (unsigned long long)v);
 		}
 		__syncthreads();
+		key_epilogue(p, slot, m, s_val[m - 1], s_h, lane);
 		// ---- write back
 		int64_t *ws = p.td_sum + (size_t)slot * GYS_TD_NB;
 		uint32_t *wc = p.td_cnt + (size_t)slot * GYS_TD_NB;
@@ -457,16 +674,6 @@ struct HugeP {
 	uint32_t *scratch; // [gridDim.x * GYS_HUGE_BINS]
 };
 
-__device__ __forceinline__ uint32_t td_cluster_of(const uint64_t *T, uint64_t mid2)
-{
-	uint32_t a = 0, bb = GYS_TD_NB - 1;
-	while (a < bb) {
-		const uint32_t mid = (a + bb + 1) >> 1;
-		if (mid2 >= T[mid]) a = mid; else bb = mid - 1;
-	}
-	return a;
-}
-
 __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 {
 	__shared__ int64_t s_csum[GYS_TD_NB];
@@ -477,6 +684,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 	__shared__ unsigned long long s_ocnt[GYS_TD_NB];
 	__shared__ uint32_t s_part[256];
 	__shared__ uint32_t s_wave[4];
+	__shared__ unsigned long long s_h[32];
 	__shared__ uint32_t s_nc;
 	__shared__ int32_t s_min, s_max;
 	uint32_t *bins = p.scratch + (size_t)blockIdx.x * GYS_HUGE_BINS;
@@ -493,6 +701,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 			s_osum[threadIdx.x] = 0;
 			s_ocnt[threadIdx.x] = 0;
 		}
+		if (threadIdx.x >= 128u && threadIdx.x < 160u) s_h[threadIdx.x - 128u] = 0;
 		if (threadIdx.x == 0) {
 			// compact non-empty old clusters (serial: 100 entries, once per huge key)
 			const int64_t *gs = p.d.td_sum + (size_t)slot * GYS_TD_NB;
@@ -582,6 +791,11 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 				const uint32_t c = bins[b];
 				if (!c) continue;
 				const int64_t v = (int64_t)b;
+				{
+					const uint32_t hb = resp_bucket(v); // exact histogram delta of the key from the value counts
+					atomicAdd(&s_h[2 * hb], (unsigned long long)c);
+					atomicAdd(&s_h[2 * hb + 1], (unsigned long long)((uint64_t)c * (uint64_t)v));
+				}
 				while (ci < nc && s_csum[ci] <= v * (int64_t)s_ccnt[ci]) ci++;
 				const uint64_t le = s_cpfx[ci];
 				const uint64_t first = 2ull * (r0 + le) + 1ull, last = first + 2ull * (uint64_t)(c - 1u);
@@ -613,6 +827,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 			p.d.td_sum[(size_t)slot * GYS_TD_NB + threadIdx.x] = (int64_t)s_osum[threadIdx.x];
 			p.d.td_cnt[(size_t)slot * GYS_TD_NB + threadIdx.x] = (uint32_t)s_ocnt[threadIdx.x];
 		}
+		if (threadIdx.x >= 128u && threadIdx.x < 148u) key_epilogue(p.d, slot, m, s_max, s_h, threadIdx.x - 128u);
 		if (threadIdx.x == 0) {
 			int32_t *mm = p.d.td_minmax + (size_t)slot * 2;
 			if (s_min < mm[0]) mm[0] = s_min;
@@ -795,30 +1010,55 @@ __global__ void k_window_prepare(PrepP p)
 }
 
 // GY_HISTOGRAM::add_histogram (common/gy_statistics.h:625-660): all += win; win cleared (GY_HISTOGRAM::clear :630-636).
-// One thread per 16-byte {count,sum} pair (16 per record).
-__global__ __launch_bounds__(256) void k_hist_fold(gys_hist_rec *all, gys_hist_rec *win, uint64_t nrec, int clear_win)
+// One thread per 16-byte {count,sum} pair (16 per record), persistent grid.  When ghist != nullptr the kernel also reduces the
+// window records into the all-service histogram of the window (arena: 15 x {count,sum} + {total}; max in gmax): LDS accumulation,
+// one flush of 32 device atomics per workgroup.
+__global__ __launch_bounds__(256) void k_hist_fold(gys_hist_rec *all, gys_hist_rec *win, uint64_t nrec, int clear_win, long long *ghist, long long *gmax)
 {
-	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= nrec * 16ull) return;
-	const uint32_t k = (uint32_t)(t & 15u);
-	long long *a = (long long *)all + t * 2, *w = (long long *)win + t * 2;
-	const long long w0 = w[0], w1 = w[1];
-	if (k < 15u) {
-		if (w0 | w1) {
-			a[0] += w0;
-			a[1] += w1;
+	__shared__ unsigned long long s_g[32];
+	__shared__ long long s_gmax;
+	if (threadIdx.x < 32) s_g[threadIdx.x] = 0;
+	if (threadIdx.x == 0) s_gmax = INT64_MIN;
+	__syncthreads();
+	const uint64_t npairs = nrec * 16ull, stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += stride) {
+		const uint32_t k = (uint32_t)(t & 15u);
+		long long *a = (long long *)all + t * 2, *w = (long long *)win + t * 2;
+		const long long w0 = w[0], w1 = w[1];
+		if (k < 15u) {
+			if (w0 | w1) {
+				a[0] += w0;
+				a[1] += w1;
+				if (ghist) {
+					atomicAdd(&s_g[2 * k], (unsigned long long)w0);
+					atomicAdd(&s_g[2 * k + 1], (unsigned long long)w1);
+				}
+				if (clear_win) {
+					w[0] = 0;
+					w[1] = 0;
+				}
+			}
+		} else {
+			if (w0) {
+				a[0] += w0;               // total_count
+				if (a[1] < w1) a[1] = w1; // max_val_seen
+				if (ghist) {
+					atomicAdd(&s_g[30], (unsigned long long)w0);
+					atomicMax(&s_gmax, w1);
+				}
+			} else if (a[1] < w1) {
+				a[1] = w1;
+			}
+			if (clear_win && (w0 || w1 != INT64_MIN)) {
+				w[0] = 0;
+				w[1] = INT64_MIN;
+			}
 		}
-		if (clear_win && (w0 | w1)) {
-			w[0] = 0;
-			w[1] = 0;
-		}
-	} else {
-		a[0] += w0;                 // total_count
-		if (a[1] < w1) a[1] = w1;   // max_val_seen
-		if (clear_win) {
-			w[0] = 0;
-			w[1] = INT64_MIN;
-		}
+	}
+	__syncthreads();
+	if (ghist) {
+		if (threadIdx.x < 31 && s_g[threadIdx.x]) atomicAdd((unsigned long long *)&ghist[threadIdx.x], s_g[threadIdx.x]);
+		if (threadIdx.x == 31 && s_gmax != INT64_MIN) atomicMax(gmax, s_gmax);
 	}
 }
 
