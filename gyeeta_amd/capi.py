@@ -15,7 +15,7 @@ KINDS = {"RESP_TIME_HASH": 0, "SEMI_LOG_HASH": 1, "SEMI_LOG_HASH_LO": 2, "DURATI
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("rank", C.c_uint32), ("nranks", C.c_uint32),
                 ("max_hosts", C.c_uint32), ("max_services", C.c_uint32), ("max_clusters", C.c_uint32),
-                ("enable_tdigest", C.c_uint32), ("svc_hll_p", C.c_uint32), ("reserved0", C.c_uint32),
+                ("enable_tdigest", C.c_uint32), ("svc_hll_p", C.c_uint32), ("resp_path", C.c_uint32),
                 ("max_batch_events", C.c_uint64), ("stream", C.c_void_p), ("reduce_arena", C.c_void_p),
                 ("reduce_arena_bytes", C.c_uint64)]
 
@@ -72,7 +72,8 @@ class TopnEntry(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("resp_events", "resp_dropped_range", "resp_dropped_nolistener", "conn_events",
-                                          "conn_unknown_service", "lstate_records", "lstate_missed", "lstate_errors", "lstate_deleted")]
+                                          "conn_unknown_service", "lstate_records", "lstate_missed", "lstate_errors", "lstate_deleted",
+                                          "resp_batches_host_local", "resp_batches_general")]
 
 
 assert C.sizeof(HistRec) == 256 and C.sizeof(TopnEntry) == 104 and C.sizeof(RespSeg) == 16

@@ -71,6 +71,18 @@ struct ProfEntry {
 
 inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
+// host mirror of one host's listener sub-table (the device copy lives in the table / list pools, see k_resp_host)
+struct HostListeners {
+	std::vector<uint64_t> tbl;   // open addressing, entries (netns:32|port:16) << 16 | local index, ~0 = free
+	std::vector<uint32_t> slots; // local index -> service slot
+	std::vector<uint64_t> keys;  // local index -> (netns:32|port:16)
+	uint32_t tbl_off = 0, tbl_cap = 0, lst_off = 0;
+	bool on_device = false;
+	bool overflow = false;       // more listeners than the LDS path supports (or pools exhausted): general pipeline only
+};
+
+#define GYS_HOST_MAX_LOCAL 4096u // listeners per host the LDS sub-table path supports (16-bit local index, 64 KB LDS table + 16 KB counts)
+
 struct ArenaLayout {
 	uint64_t off_hll8, off_u32, n_u32, off_i64sum, n_i64sum, off_i64max, n_i64max, total;
 	uint64_t u32_cms, u32_cluster;        // element offsets inside the u32 section
@@ -112,6 +124,14 @@ struct gys_ctx {
 	std::vector<std::string> cluster_names;
 	std::unordered_map<uint64_t, uint32_t> gid_map_h; // glob_id -> slot (host mirror for single-key queries)
 	uint32_t nsvc = 0;
+	std::vector<HostListeners> host_lst;
+	std::vector<uint32_t> host_seen; // batch stamp per host (duplicate-host detection in a multi-segment batch)
+	uint32_t batch_stamp = 0;
+	uint64_t n_batches_host_local = 0, n_batches_general = 0;
+	uint64_t htbl_used = 0, htbl_cap = 0, hlst_used = 0, hlst_cap = 0;
+	uint64_t *htbl = nullptr; // pool of per-host sub-tables
+	uint32_t *hlst = nullptr; // pool of per-host local index -> slot lists
+	HostDesc *hdesc = nullptr;
 
 	// device state
 	DevTable lk_tbl{}, gid_tbl{};
@@ -267,6 +287,85 @@ uint32_t next_pow2(uint64_t v)
 	return (uint32_t)p;
 }
 
+// ---- per-host listener sub-tables (host mirror + device pools), used by k_resp_host
+inline uint64_t host_key48(uint32_t netns, uint16_t port) { return ((uint64_t)netns << 16) | (uint64_t)port; }
+
+int64_t host_tbl_find(const HostListeners &hl, uint64_t key48)
+{
+	if (hl.tbl.empty()) return -1;
+	const uint32_t mask = (uint32_t)hl.tbl.size() - 1;
+	uint32_t h = get_uint64_hash(key48) & mask;
+	for (uint32_t probes = 0; probes <= mask; ++probes) {
+		const uint64_t e = hl.tbl[h];
+		if (e == GYS_HOST_TBL_EMPTY) return -1;
+		if ((e >> 16) == key48) return (int64_t)h;
+		h = (h + 1) & mask;
+	}
+	return -1;
+}
+
+void host_tbl_put(HostListeners &hl, uint64_t key48, uint32_t local)
+{
+	const uint32_t mask = (uint32_t)hl.tbl.size() - 1;
+	uint32_t h = get_uint64_hash(key48) & mask;
+	while (hl.tbl[h] != GYS_HOST_TBL_EMPTY) h = (h + 1) & mask;
+	hl.tbl[h] = (key48 << 16) | (uint64_t)local;
+}
+
+// (re)uploads one host's sub-table, slot list and descriptor; regions only ever grow, an outgrown region is abandoned in the pool
+// (geometric growth: the abandoned total stays below the final size, which is what the pool capacity accounts for)
+int host_lst_upload(gys_ctx *c, uint32_t host)
+{
+	HostListeners &hl = c->host_lst[host];
+	if (hl.overflow) return GYS_OK;
+	if (!hl.on_device || hl.tbl.size() > hl.tbl_cap) {
+		if (c->htbl_used + hl.tbl.size() > c->htbl_cap || c->hlst_used + hl.tbl.size() / 2 > c->hlst_cap) {
+			hl.overflow = true; // pools exhausted: this host keeps working through the general pipeline
+			return GYS_OK;
+		}
+		hl.tbl_off = (uint32_t)c->htbl_used;
+		hl.tbl_cap = (uint32_t)hl.tbl.size();
+		c->htbl_used += hl.tbl.size();
+		hl.lst_off = (uint32_t)c->hlst_used;
+		c->hlst_used += hl.tbl.size() / 2;
+		hl.on_device = true;
+	}
+	HIPCHK(hipMemcpyAsync(c->htbl + hl.tbl_off, hl.tbl.data(), hl.tbl.size() * 8, hipMemcpyHostToDevice, c->stream));
+	if (!hl.slots.empty()) HIPCHK(hipMemcpyAsync(c->hlst + hl.lst_off, hl.slots.data(), hl.slots.size() * 4, hipMemcpyHostToDevice, c->stream));
+	const HostDesc hd{hl.tbl_off, (uint32_t)hl.tbl.size() - 1, (uint32_t)hl.slots.size(), hl.lst_off};
+	HIPCHK(hipMemcpyAsync(c->hdesc + host, &hd, sizeof(hd), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream)); // hd is a stack object
+	return GYS_OK;
+}
+
+int host_lst_add(gys_ctx *c, uint32_t host, const gys_listener_info *arr, uint32_t n, uint32_t first_slot)
+{
+	HostListeners &hl = c->host_lst[host];
+	if (hl.overflow) return GYS_OK;
+	for (uint32_t i = 0; i < n; ++i) {
+		const uint64_t key48 = host_key48(arr[i].netns, arr[i].port);
+		const int64_t pos = host_tbl_find(hl, key48);
+		if (pos >= 0) { // re-registration of a listener tuple rebinds it to the newest slot (same rule as the global table)
+			hl.slots[(uint32_t)(hl.tbl[(size_t)pos] & 0xFFFFu)] = first_slot + i;
+			continue;
+		}
+		if (hl.slots.size() >= GYS_HOST_MAX_LOCAL) {
+			hl.overflow = true; // too many listeners for the LDS sub-table: batches with this host take the general pipeline
+			return GYS_OK;
+		}
+		const uint32_t local = (uint32_t)hl.slots.size();
+		hl.slots.push_back(first_slot + i);
+		hl.keys.push_back(key48);
+		if (hl.slots.size() * 2 > hl.tbl.size()) {
+			hl.tbl.assign(next_pow2(std::max<uint64_t>(16, hl.slots.size() * 2)), GYS_HOST_TBL_EMPTY);
+			for (uint32_t l = 0; l < hl.keys.size(); ++l) host_tbl_put(hl, hl.keys[l], l);
+		} else {
+			host_tbl_put(hl, key48, local);
+		}
+	}
+	return host_lst_upload(c, host);
+}
+
 // resp pipeline on a device-resident batch
 int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, const void *d_ev, uint64_t n)
 {
@@ -300,44 +399,92 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	}
 	HIPCHK(hipMemcpyAsync(c->segs_dev, segs_host, (uint64_t)nsegs * sizeof(gys_resp_seg), hipMemcpyHostToDevice, c->stream));
 
-	RespP1 p{};
-	p.ev = (const uint64_t *)d_ev;
-	p.n = n;
-	p.segs = c->segs_dev;
-	p.nsegs = nsegs;
-	p.lk = c->lk_tbl;
-	p.svc_gid = c->svc_gid;
-	p.hist_win = c->hist_win;
-	p.bitmap = c->bitmap;
-	p.hll32 = c->hll32;
-	p.cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
-	p.batch_cnt = td ? c->batch_cnt : nullptr;
-	p.ev_kv = td ? c->ev_kv : nullptr;
-	p.counters = c->counters;
-	p.svc_hll = c->svc_hll;
-	p.svc_hll_p = c->cfg.svc_hll_p;
-	{
-		ProfScope ps(c, "resp_pass1");
-		hipLaunchKernelGGL(k_resp_pass1, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
+	// ---- pipeline choice: host-local (one workgroup per host segment, LDS sub-table + LDS counting sort) when every segment is a
+	// distinct host with an LDS-sized listener table and the segments are small enough to balance; otherwise the general pipeline
+	bool host_local = td && c->cfg.resp_path != 1 && c->nsvc != 0;
+	uint32_t max_tbl = 16, max_l = 1;
+	if (host_local) {
+		uint64_t max_len = 0;
+		c->batch_stamp++;
+		for (uint32_t s = 0; s < nsegs && host_local; ++s) {
+			const uint32_t host = segs_host[s].host_slot;
+			const HostListeners &hl = c->host_lst[host];
+			const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - segs_host[s].first_event;
+			if (c->host_seen[host] == c->batch_stamp || hl.overflow || !hl.on_device) host_local = false;
+			c->host_seen[host] = c->batch_stamp;
+			max_len = std::max(max_len, len);
+			max_tbl = std::max<uint32_t>(max_tbl, (uint32_t)hl.tbl.size());
+			max_l = std::max<uint32_t>(max_l, (uint32_t)hl.slots.size());
+		}
+		if (host_local && c->cfg.resp_path == 0) host_local = max_len <= (1u << 15) || (nsegs >= 128 && max_len <= (1u << 20));
+	}
+	const uint32_t nsvc = c->nsvc;
+	uint32_t *cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
+	if (host_local) {
+		c->n_batches_host_local++;
+		RespHostP hp{};
+		hp.ev = (const uint64_t *)d_ev;
+		hp.n = n;
+		hp.segs = c->segs_dev;
+		hp.nsegs = nsegs;
+		hp.hdesc = c->hdesc;
+		hp.htbl = c->htbl;
+		hp.hlst = c->hlst;
+		hp.hll32 = c->hll32;
+		hp.batch_cnt = c->batch_cnt;
+		hp.off_end = c->batch_off;
+		hp.ev_kv = c->ev_kv;
+		hp.staged = c->staged;
+		hp.huge_list = c->huge_list;
+		hp.huge_count = c->huge_count;
+		hp.counters = c->counters;
+		hp.svc_hll = c->svc_hll;
+		hp.svc_hll_p = c->cfg.svc_hll_p;
+		hp.lds_tbl_entries = max_tbl;
+		const size_t dyn = (size_t)max_tbl * 8 + align_up((uint64_t)max_l * 4, 8);
+		ProfScope ps(c, "resp_host");
+		HIPCHK(hipMemsetAsync(c->huge_count, 0, 4, c->stream));
+		hipLaunchKernelGGL(k_resp_host, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+	} else {
+		c->n_batches_general++;
+		RespP1 p{};
+		p.ev = (const uint64_t *)d_ev;
+		p.n = n;
+		p.segs = c->segs_dev;
+		p.nsegs = nsegs;
+		p.lk = c->lk_tbl;
+		p.svc_gid = c->svc_gid;
+		p.hist_win = c->hist_win;
+		p.bitmap = c->bitmap;
+		p.hll32 = c->hll32;
+		p.cms32 = cms32;
+		p.batch_cnt = td ? c->batch_cnt : nullptr;
+		p.ev_kv = td ? c->ev_kv : nullptr;
+		p.counters = c->counters;
+		p.svc_hll = c->svc_hll;
+		p.svc_hll_p = c->cfg.svc_hll_p;
+		{
+			ProfScope ps(c, "resp_pass1");
+			hipLaunchKernelGGL(k_resp_pass1, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
+		}
+		HIPCHK(hipGetLastError());
+		if (!td || nsvc == 0) return GYS_OK;
+		const uint32_t nblk = (nsvc + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE;
+		{
+			ProfScope ps(c, "scan");
+			HIPCHK(hipMemsetAsync(c->huge_count, 0, 4, c->stream));
+			hipLaunchKernelGGL(k_scan_block_sums, dim3(nblk), dim3(256), 0, c->stream, c->batch_cnt, nsvc, c->scan_block_sums);
+			hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, c->stream, c->scan_block_sums, nblk);
+			hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, c->stream, c->batch_cnt, nsvc, c->scan_block_sums, c->batch_off, c->huge_list,
+					   c->huge_count);
+		}
+		{
+			ProfScope ps(c, "scatter");
+			hipLaunchKernelGGL(k_resp_scatter, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->ev_kv, n, c->batch_off,
+					   c->staged);
+		}
 	}
 	HIPCHK(hipGetLastError());
-	if (!td) return GYS_OK;
-
-	const uint32_t nsvc = c->nsvc;
-	if (nsvc == 0) return GYS_OK;
-	const uint32_t nblk = (nsvc + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE;
-	{
-		ProfScope ps(c, "scan");
-		HIPCHK(hipMemsetAsync(c->huge_count, 0, 4, c->stream));
-		hipLaunchKernelGGL(k_scan_block_sums, dim3(nblk), dim3(256), 0, c->stream, c->batch_cnt, nsvc, c->scan_block_sums);
-		hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, c->stream, c->scan_block_sums, nblk);
-		hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, c->stream, c->batch_cnt, nsvc, c->scan_block_sums, c->batch_off, c->huge_list,
-				   c->huge_count);
-	}
-	{
-		ProfScope ps(c, "scatter");
-		hipLaunchKernelGGL(k_resp_scatter, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->ev_kv, n, c->batch_off, c->staged);
-	}
 	DigestP d{};
 	d.td_sum = c->td_sum;
 	d.td_cnt = c->td_cnt;
@@ -347,8 +494,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	d.staged = c->staged;
 	d.nsvc = nsvc;
 	d.hist_win = c->hist_win;
-	d.cms32 = p.cms32;
+	d.cms32 = cms32;
 	d.svc_gid = c->svc_gid;
+	d.bitmap = c->bitmap;
 	{
 		ProfScope ps(c, "digest_wave");
 		hipLaunchKernelGGL(k_digest_wave, dim3(std::min<uint32_t>((nsvc + 3) / 4, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, d);
@@ -509,6 +657,15 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	ALLOC(c->topn_slot, S < 65536 ? S : 65536);
 	ALLOC(c->topn_metric, S < 65536 ? S : 65536);
 	ALLOC(c->dev_pcts, 64);
+	c->htbl_cap = 8 * S + 32 * H; // every host's live sub-table (<= 4 L + 16 entries) plus its outgrown regions (< the live one)
+	c->hlst_cap = 4 * S + 16 * H;
+	ALLOC(c->htbl, c->htbl_cap);
+	ALLOC(c->hlst, c->hlst_cap);
+	ALLOC(c->hdesc, H);
+	c->host_lst.reserve(H);
+	// k_resp_host stages up to 8192 sub-table entries + 4096 counts in dynamic LDS (80 KiB of the CU's 160 KiB)
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_tdigest) {
 		const uint64_t B = cfg->max_batch_events ? cfg->max_batch_events : 1;
@@ -562,7 +719,7 @@ void gys_destroy(gys_ctx *c)
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
 			c->td_cnt, c->td_minmax, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_list, c->huge_count,
 			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
-			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->segs_dev, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
+			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->segs_dev, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -617,6 +774,11 @@ int gys_register_host(gys_ctx *c, const uint8_t machine_id[16], const char *clus
 		c->hosts.push_back(m);
 		c->host_cluster_h.push_back(cidx);
 		c->host_map.emplace(m, slot);
+		c->host_lst.emplace_back();
+		c->host_lst.back().tbl.assign(16, GYS_HOST_TBL_EMPTY);
+		c->host_seen.push_back(0);
+		rc = host_lst_upload(c, slot);
+		if (rc) return rc;
 	}
 	c->host_cluster_h[slot] = cidx;
 	HIPCHK(hipMemcpyAsync(c->host_cluster + slot, &cidx, 4, hipMemcpyHostToDevice, c->stream));
@@ -661,6 +823,8 @@ int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_l
 		set_err("key table full (%u inserts failed)", nfail);
 		return GYS_ERR_NOMEM;
 	}
+	rc = host_lst_add(c, host, arr, n, c->nsvc);
+	if (rc) return rc;
 	for (uint32_t i = 0; i < n; ++i) c->gid_map_h[arr[i].glob_id] = c->nsvc + i;
 	c->nsvc += n;
 	return GYS_OK;
@@ -1168,6 +1332,8 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 	out->lstate_missed = v[CTR_LSTATE_MISSED];
 	out->lstate_errors = v[CTR_LSTATE_ERRORS];
 	out->lstate_deleted = v[CTR_LSTATE_DELETED];
+	out->resp_batches_host_local = c->n_batches_host_local;
+	out->resp_batches_general = c->n_batches_general;
 	return GYS_OK;
 }
 

@@ -17,6 +17,10 @@ namespace gys {
 #define GYS_SMALL_MAX 1024u        // largest per-key batch handled by digest_small (LDS bitonic sort by one wave)
 #define GYS_HUGE_VALUE_BITS 20     // resp values are <= 1,000,000 < 2^20 (drop filter common/gy_socket_stat.cc:1521-1524)
 #define GYS_HUGE_BINS (1u << GYS_HUGE_VALUE_BITS)
+// staged word of one accepted event: (response ms << 5) | CONN_BITMAP row (cli_port & 0x1F, common/gy_socket_stat.h:403-410).
+// Sorting the words sorts by value; the digest kernels, which see all of a key's words, also produce the key's bitmap rows.
+#define GYS_ROW_BITS 5
+#define GYS_STAGED_WORD(tresp, cli_port) ((uint64_t)(((uint32_t)(tresp) << GYS_ROW_BITS) | ((uint32_t)(cli_port) & 0x1Fu)))
 
 enum { CTR_RESP_EVENTS = 0, CTR_RESP_DROP_RANGE, CTR_RESP_DROP_NOLISTENER, CTR_CONN_EVENTS, CTR_CONN_UNKNOWN, CTR_LSTATE_RECORDS,
        CTR_LSTATE_MISSED, CTR_LSTATE_ERRORS, CTR_LSTATE_DELETED, CTR_NUM };
@@ -58,6 +62,36 @@ __global__ void k_minmax_init(int32_t *mm, uint64_t n)
 }
 
 // ---------------------------------------------------------------------------------------------------- resp pass 1
+__device__ __forceinline__ uint16_t bswap16(uint16_t v) { return (uint16_t)((v >> 8) | (v << 8)); }
+
+__device__ __forceinline__ void hll_update_event(uint32_t *hll32, uint8_t *svc_hll, uint32_t svc_hll_p, uint32_t slot, uint32_t daddr, uint16_t dport,
+						 uint32_t saddr, uint16_t sport)
+{
+	// distinct client flows: HLL over PAIR_IP_PORT(cli = daddr:dport, ser = saddr:sport) (common/gy_inet_inc.h:225-247)
+	uint32_t w[10];
+	const uint32_t z[4] = {0, 0, 0, 0};
+	const uint32_t nw = pair_words(daddr, z, dport, saddr, z, sport, w);
+	const uint64_t h64 = hash64<10>(w, nw);
+	uint32_t idx, rank;
+	hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
+	if (hll32[idx] < rank) atomicMax(&hll32[idx], rank);
+	if (svc_hll_p) {
+		// per-service distinct clients: same hash, per-service register file (u8 packed, CAS on the word)
+		uint32_t sidx, srank;
+		hll_idx_rank(h64, (int)svc_hll_p, &sidx, &srank);
+		uint8_t *base = svc_hll + ((size_t)slot << svc_hll_p);
+		uint32_t *wp = (uint32_t *)(base + (sidx & ~3u));
+		const uint32_t sh = (sidx & 3u) * 8u;
+		uint32_t old = *wp;
+		while (((old >> sh) & 0xFFu) < srank) {
+			const uint32_t nv = (old & ~(0xFFu << sh)) | (srank << sh);
+			const uint32_t prev = atomicCAS(wp, old, nv);
+			if (prev == old) break;
+			old = prev;
+		}
+	}
+}
+
 struct RespP1 {
 	const uint64_t *ev;       // 3 x u64 per event (tcp_ipv4_resp_event_t, common/gy_ebpf_kernel.h:106-111)
 	uint64_t n;
@@ -85,8 +119,6 @@ __device__ __forceinline__ uint32_t find_seg(const gys_resp_seg *segs, uint32_t 
 	}
 	return lo;
 }
-
-__device__ __forceinline__ uint16_t bswap16(uint16_t v) { return (uint16_t)((v >> 8) | (v << 8)); }
 
 __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 {
@@ -130,40 +162,16 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 						atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(gid, GYS_SEED + r) & (GYS_CMS_W - 1))], 1u);
 				}
 				// CONN_BITMAP::add_response: respmap_[cli_port & 0x1F].set(bucket) (common/gy_socket_stat.h:403-410)
-				{
+				if (!fused) {
 					const uint32_t row = dport & 0x1Fu;
 					const uint32_t bit = (1u << b) << ((row & 1u) * 16u);
 					uint32_t *wp = &p.bitmap[(size_t)slot * 16u + (row >> 1)];
 					if ((*wp & bit) == 0) atomicOr(wp, bit);
 				}
-				// distinct client flows: HLL over PAIR_IP_PORT(cli = daddr:dport, ser = saddr:sport) (common/gy_inet_inc.h:225-247)
-				{
-					uint32_t w[10];
-					const uint32_t z[4] = {0, 0, 0, 0};
-					const uint32_t nw = pair_words(daddr, z, dport, saddr, z, sport, w);
-					const uint64_t h64 = hash64<10>(w, nw);
-					uint32_t idx, rank;
-					hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
-					if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
-					if (p.svc_hll_p) {
-						// per-service distinct clients: same hash, per-service register file (u8 packed, CAS on the word)
-						uint32_t sidx, srank;
-						hll_idx_rank(h64, (int)p.svc_hll_p, &sidx, &srank);
-						uint8_t *base = p.svc_hll + ((size_t)slot << p.svc_hll_p);
-						uint32_t *wp = (uint32_t *)(base + (sidx & ~3u));
-						const uint32_t sh = (sidx & 3u) * 8u;
-						uint32_t old = *wp;
-						while (((old >> sh) & 0xFFu) < srank) {
-							const uint32_t nv = (old & ~(0xFFu << sh)) | (srank << sh);
-							const uint32_t prev = atomicCAS(wp, old, nv);
-							if (prev == old) break;
-							old = prev;
-						}
-					}
-				}
+				hll_update_event(p.hll32, p.svc_hll, p.svc_hll_p, slot, daddr, dport, saddr, sport);
 				if (fused) {
 					atomicAdd(&p.batch_cnt[slot], 1u);
-					kv = ((uint64_t)slot << 32) | (uint64_t)tresp;
+					kv = ((uint64_t)slot << 32) | GYS_STAGED_WORD(tresp, dport);
 				}
 			}
 		}
@@ -273,6 +281,142 @@ __global__ __launch_bounds__(256) void k_resp_scatter(const uint64_t *ev_kv, uin
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------- host-local resp pass
+// One workgroup per host segment of the batch.  The reference resolves a response event's listener inside the HOST's own
+// listener table (TCP_SOCK_HANDLER is per host: common/gy_socket_stat.cc:1554-1677), so everything an event touches before the
+// per-key merge is host-local: the workgroup stages the host's (netns, port) -> local index sub-table in LDS, counts the segment's
+// events per listener in LDS, scans the counts in LDS and scatters the staged words with LDS atomics into the segment's own slice
+// of `staged` ([first_event, first_event + valid)).  No per-event device-scope atomic except the global HLL register max.
+struct HostDesc {
+	uint32_t tbl_off;  // first entry of the host's sub-table in the table pool
+	uint32_t mask;     // sub-table capacity - 1 (power of two)
+	uint32_t nlst;     // local listener indices in use
+	uint32_t lst_off;  // first entry of the host's local index -> service slot list in the list pool
+};
+
+#define GYS_HOST_TBL_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define GYS_HOST_THREADS 512
+
+struct RespHostP {
+	const uint64_t *ev;
+	uint64_t n;
+	const gys_resp_seg *segs;
+	uint32_t nsegs;
+	const HostDesc *hdesc;
+	const uint64_t *htbl;   // entries: (netns:32 | port:16) << 16 | local index:16
+	const uint32_t *hlst;
+	uint32_t *hll32;
+	uint32_t *batch_cnt, *off_end;
+	uint64_t *ev_kv;        // per event: local index << 32 | staged word, ~0 = dropped (written and re-read by the same thread)
+	uint32_t *staged;
+	uint32_t *huge_list, *huge_count;
+	uint64_t *counters;
+	uint8_t *svc_hll;
+	uint32_t svc_hll_p;
+	uint32_t lds_tbl_entries; // LDS table area of the launch (largest sub-table among the batch's hosts)
+};
+
+__global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
+{
+	extern __shared__ uint64_t s_dyn[];
+	__shared__ uint32_t s_wsum[GYS_HOST_THREADS / 64];
+	__shared__ uint32_t s_drop[2];
+	uint64_t *s_tbl = s_dyn;
+	uint32_t *s_cnt = (uint32_t *)(s_dyn + p.lds_tbl_entries);
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const gys_resp_seg seg = p.segs[blockIdx.x];
+	const uint64_t e0 = seg.first_event;
+	const uint64_t e1 = blockIdx.x + 1 < p.nsegs ? p.segs[blockIdx.x + 1].first_event : p.n;
+	if (e1 <= e0) return;
+	const HostDesc hd = p.hdesc[seg.host_slot];
+	const uint32_t mask = hd.mask, L = hd.nlst;
+	for (uint32_t i = tid; i <= mask; i += GYS_HOST_THREADS) s_tbl[i] = p.htbl[hd.tbl_off + i];
+	for (uint32_t i = tid; i < L; i += GYS_HOST_THREADS) s_cnt[i] = 0;
+	if (tid < 2) s_drop[tid] = 0;
+	__syncthreads();
+
+	// ---- pass A: resolve, filter, count
+	uint32_t ndrop_range = 0, ndrop_nol = 0;
+	for (uint64_t i = e0 + tid; i < e1; i += GYS_HOST_THREADS) {
+		const uint64_t w0 = p.ev[3 * i], w1 = p.ev[3 * i + 1], w2 = p.ev[3 * i + 2];
+		const uint32_t saddr = (uint32_t)w0, daddr = (uint32_t)(w0 >> 32);
+		const uint32_t netns = (uint32_t)w1;
+		const uint16_t sport = bswap16((uint16_t)(w1 >> 32)), dport = bswap16((uint16_t)(w1 >> 48)); // ntohs :1526-1527
+		const uint32_t tresp = (uint32_t)w2 - (uint32_t)(w2 >> 32); // lsndtime - lrcvtime (:1519)
+		uint64_t kv = ~0ull;
+		if (tresp > 1000000u) { // "Ignore responses > 1000 sec or negative" (:1521-1524)
+			ndrop_range++;
+		} else {
+			const uint64_t key48 = ((uint64_t)netns << 16) | (uint64_t)sport;
+			uint32_t h = get_uint64_hash(key48) & mask;
+			uint32_t local = GYS_NOSLOT;
+			for (uint32_t probes = 0; probes <= mask; ++probes) {
+				const uint64_t e = s_tbl[h];
+				if ((e >> 16) == key48) {
+					local = (uint32_t)(e & 0xFFFFu);
+					break;
+				}
+				if (e == GYS_HOST_TBL_EMPTY) break;
+				h = (h + 1) & mask;
+			}
+			if (local == GYS_NOSLOT) {
+				ndrop_nol++; // no such listener: the reference ignores the event too (:1671-1676 miss path)
+			} else {
+				hll_update_event(p.hll32, p.svc_hll, p.svc_hll_p, p.svc_hll_p ? p.hlst[hd.lst_off + local] : 0u, daddr, dport, saddr, sport);
+				atomicAdd(&s_cnt[local], 1u);
+				kv = ((uint64_t)local << 32) | GYS_STAGED_WORD(tresp, dport);
+			}
+		}
+		p.ev_kv[i] = kv;
+	}
+	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
+	if (ndrop_nol) atomicAdd(&s_drop[1], ndrop_nol);
+	__syncthreads();
+
+	// ---- counts -> per-key run starts (exclusive scan over the local indices), per-key batch_cnt / off_end for the digest kernels
+	{
+		const uint32_t K = (L + GYS_HOST_THREADS - 1) / GYS_HOST_THREADS;
+		const uint32_t lo = tid * K, hi = min(L, lo + K);
+		uint32_t sum = 0;
+		for (uint32_t k = lo; k < hi; ++k) sum += s_cnt[k];
+		uint32_t inc = sum;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(inc, d, 64);
+			if ((int)lane >= d) inc += t;
+		}
+		if (lane == 63) s_wsum[wave] = inc;
+		__syncthreads();
+		uint32_t run = inc - sum;
+		for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
+		for (uint32_t k = lo; k < hi; ++k) {
+			const uint32_t c = s_cnt[k];
+			s_cnt[k] = run;
+			if (c) {
+				const uint32_t slot = p.hlst[hd.lst_off + k];
+				p.batch_cnt[slot] = c;
+				p.off_end[slot] = (uint32_t)e0 + run + c;
+				if (c > GYS_SMALL_MAX) p.huge_list[atomicAdd(p.huge_count, 1u)] = slot;
+			}
+			run += c;
+		}
+	}
+	__syncthreads();
+
+	// ---- pass B: scatter the staged words into the key runs (positions from LDS atomics)
+	for (uint64_t i = e0 + tid; i < e1; i += GYS_HOST_THREADS) {
+		const uint64_t kv = p.ev_kv[i];
+		if (kv == ~0ull) continue;
+		const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)(kv >> 32)], 1u);
+		p.staged[e0 + pos] = (uint32_t)kv;
+	}
+	if (tid == 0) {
+		atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
+		if (s_drop[0]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_RANGE], (unsigned long long)s_drop[0]);
+		if (s_drop[1]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_NOLISTENER], (unsigned long long)s_drop[1]);
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------- t-digest merge (small)
 struct DigestP {
 	int64_t *td_sum;    // [nsvc*100]
@@ -287,12 +431,25 @@ struct DigestP {
 	gys_hist_rec *hist_win;
 	uint32_t *cms32;
 	const uint64_t *svc_gid;
+	uint32_t *bitmap; // [nsvc*16] u32 = 32 x u16 CONN_BITMAP rows (common/gy_socket_stat.h:390-454)
 };
 
-// applies a key's batch deltas: s_h[2b] = count, s_h[2b+1] = sum of bucket b (LDS), m values, vmax = largest value.
-// lanes 0..14: HIST_SERIAL buckets, lane 15: total_count_/max_val_seen_, lanes 16..19: the 4 Count-Min rows.
-__device__ __forceinline__ void key_epilogue(const DigestP &p, uint32_t slot, uint32_t m, int32_t vmax, const unsigned long long *s_h, uint32_t lane)
+// CONN_BITMAP::add_response for one staged word into a 16-word LDS row image: respmap_[row].set(bucket)
+__device__ __forceinline__ void bitmap_set_lds(uint32_t *s_bm, uint32_t word, uint32_t bucket)
 {
+	const uint32_t row = word & 0x1Fu;
+	atomicOr(&s_bm[row >> 1], (1u << bucket) << ((row & 1u) * 16u));
+}
+
+// applies a key's batch deltas: s_h[2b] = count, s_h[2b+1] = sum of bucket b (LDS), m values, vmax = largest value.
+// lanes 0..14: HIST_SERIAL buckets, lane 15: total_count_/max_val_seen_, lanes 16..19: the 4 Count-Min rows, lanes 20..35: CONN_BITMAP words.
+__device__ __forceinline__ void key_epilogue(const DigestP &p, uint32_t slot, uint32_t m, int32_t vmax, const unsigned long long *s_h, const uint32_t *s_bm,
+					     uint32_t lane)
+{
+	if (lane >= 20u && lane < 36u) { // the key is owned by this workgroup for the batch: plain read-modify-write
+		const uint32_t bits = s_bm[lane - 20u];
+		if (bits) p.bitmap[(size_t)slot * 16u + (lane - 20u)] |= bits;
+	}
 	gys_hist_rec *h = &p.hist_win[slot];
 	if (lane < 15u) {
 		const unsigned long long c = s_h[2 * lane];
@@ -359,7 +516,7 @@ struct KeyRegs {
 	uint32_t c0, c1;    // old cluster counts (entries lane, lane + 64)
 	int64_t sm0, sm1;   // old cluster sums
 	uint64_t hc, hs;    // lanes 0..15: the 16-byte pair `lane` of the key's histogram record
-	uint64_t aux;       // lane 16..19: glob_id (Count-Min key); lane 20: packed {vmin, vmax}
+	uint64_t aux;       // lane 16..19: glob_id (Count-Min key); lane 20: packed {vmin, vmax}; lanes 32..47: CONN_BITMAP word lane-32
 };
 
 __device__ __forceinline__ void key_prefetch(const DigestP &p, uint32_t slot, uint32_t m, uint32_t oend, uint32_t lane, KeyRegs &r)
@@ -383,6 +540,8 @@ __device__ __forceinline__ void key_prefetch(const DigestP &p, uint32_t slot, ui
 		r.aux = p.svc_gid[slot];
 	} else if (lane == 20u) {
 		r.aux = *(const uint64_t *)(p.td_minmax + (size_t)slot * 2);
+	} else if (lane >= 32u && lane < 48u) {
+		r.aux = (uint64_t)p.bitmap[(size_t)slot * 16u + (lane - 32u)];
 	}
 }
 
@@ -393,7 +552,9 @@ __global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
 	__shared__ unsigned long long s_osum_[4][GYS_TD_NB];
 	__shared__ uint32_t s_ocnt_[4][GYS_TD_NB];
 	__shared__ unsigned long long s_h_[4][32];
+	__shared__ uint32_t s_bm_[4][16];
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	uint32_t *s_bm = s_bm_[wv];
 	uint64_t *s_T = s_T_[wv];
 	unsigned long long *s_add = s_add_[wv], *s_osum = s_osum_[wv], *s_h = s_h_[wv];
 	uint32_t *s_ocnt = s_ocnt_[wv];
@@ -422,7 +583,7 @@ __global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
 				todo &= todo - 1;
 				key_prefetch(p, chunk * 64u + inext, (uint32_t)__shfl((int)mcnt, (int)inext, 64), (uint32_t)__shfl((int)oend, (int)inext, 64), lane, nxt);
 			}
-			int32_t v = cur.v;
+			int32_t w = cur.v; // staged word: value << 5 | CONN_BITMAP row
 			const uint32_t c0 = cur.c0, c1 = cur.c1;
 			const int64_t sm0 = cur.sm0, sm1 = cur.sm1;
 			// bitonic sort across the 64 lanes (ascending), padding = INT32_MAX
@@ -430,11 +591,12 @@ __global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
 			for (uint32_t k = 2; k <= 64u; k <<= 1) {
 #pragma unroll
 				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-					const int32_t o = __shfl_xor(v, (int)j, 64);
+					const int32_t o = __shfl_xor(w, (int)j, 64);
 					const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-					v = (lower == up) ? min(v, o) : max(v, o);
+					w = (lower == up) ? min(w, o) : max(w, o);
 				}
 			}
+			const int32_t v = w >> GYS_ROW_BITS;
 			uint64_t e0, e1, nold;
 			wave_excl_scan_2x((uint64_t)c0, (uint64_t)c1, &e0, &e1, &nold);
 			const uint64_t twoN = 2ull * (nold + (uint64_t)m);
@@ -449,6 +611,7 @@ __global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
 				s_ocnt[j1] = 0;
 			}
 			if (lane < 32u) s_h[lane] = 0;
+			if (lane < 16u) s_bm[lane] = 0;
 			GYS_WAVE_SYNC();
 			// ---- old clusters: lt = #{new values with v * cnt < sum} by broadcasting the (few) new values
 			uint32_t lt0 = 0, lt1 = 0;
@@ -484,6 +647,7 @@ __global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
 				const uint32_t b = resp_bucket((int64_t)v);
 				atomicAdd(&s_h[2 * b], 1ull);
 				atomicAdd(&s_h[2 * b + 1], (unsigned long long)(int64_t)v);
+				bitmap_set_lds(s_bm, (uint32_t)w, b);
 			}
 			GYS_WAVE_SYNC();
 			const int32_t vmin = __shfl(v, 0, 64), vmax = __shfl(v, (int)(m - 1), 64);
@@ -517,6 +681,9 @@ __global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
 					mx = max(mx, vmax);
 					*(uint64_t *)(p.td_minmax + (size_t)slot * 2) = (uint64_t)(uint32_t)mn | ((uint64_t)(uint32_t)mx << 32);
 				}
+			} else if (lane >= 32u && lane < 48u) {
+				const uint32_t bits = s_bm[lane - 32u];
+				if (bits & ~(uint32_t)cur.aux) p.bitmap[(size_t)slot * 16u + (lane - 32u)] = (uint32_t)cur.aux | bits;
 			}
 			GYS_WAVE_SYNC();
 			if (inext >= 64u) break;
@@ -539,6 +706,7 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 	__shared__ unsigned long long s_osum[GYS_TD_NB];
 	__shared__ uint32_t s_ocnt[GYS_TD_NB];
 	__shared__ unsigned long long s_h[32];
+	__shared__ uint32_t s_bm[16];
 	const uint32_t lane = threadIdx.x;
 
 	for (uint32_t slot = blockIdx.x; slot < p.nsvc; slot += gridDim.x) {
@@ -587,6 +755,7 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 			s_ocnt[j1] = 0;
 		}
 		if (lane < 32u) s_h[lane] = 0;
+		if (lane < 16u) s_bm[lane] = 0;
 		__syncthreads();
 		for (uint32_t k = 2; k <= P; k <<= 1) {
 			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -611,7 +780,7 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 			uint32_t lo = 0, hi = m; // first index with v * cc >= cs
 			while (lo < hi) {
 				const uint32_t mid = (lo + hi) >> 1;
-				if ((int64_t)s_val[mid] * (int64_t)cc < cs) lo = mid + 1; else hi = mid;
+				if ((int64_t)(s_val[mid] >> GYS_ROW_BITS) * (int64_t)cc < cs) lo = mid + 1; else hi = mid;
 			}
 			const uint64_t mid2 = 2ull * (s_cpfx[c] + (uint64_t)lo) + (uint64_t)cc;
 			uint32_t a = 0, bb = GYS_TD_NB - 1; // cluster = max j with (j == 0 or mid2 >= T_j)
@@ -624,7 +793,8 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 		}
 		// ---- new values: W = rank among new values + weight of old clusters with mean <= v
 		for (uint32_t r = lane; r < m; r += 64u) {
-			const int64_t v = (int64_t)s_val[r];
+			const int32_t w = s_val[r]; // sorted staged words: value << 5 | CONN_BITMAP row
+			const int64_t v = (int64_t)(w >> GYS_ROW_BITS);
 			uint32_t lo = 0, hi = nc; // first cluster with mean > v  (csum > v * ccnt)
 			while (lo < hi) {
 				const uint32_t mid = (lo + hi) >> 1;
@@ -641,9 +811,10 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 			const uint32_t b = resp_bucket(v);
 			atomicAdd(&s_h[2 * b], 1ull);
 			atomicAdd(&s_h[2 * b + 1], (unsigned long long)v);
+			bitmap_set_lds(s_bm, (uint32_t)w, b);
 		}
 		__syncthreads();
-		key_epilogue(p, slot, m, s_val[m - 1], s_h, lane);
+		key_epilogue(p, slot, m, s_val[m - 1] >> GYS_ROW_BITS, s_h, s_bm, lane);
 		// ---- write back
 		int64_t *ws = p.td_sum + (size_t)slot * GYS_TD_NB;
 		uint32_t *wc = p.td_cnt + (size_t)slot * GYS_TD_NB;
@@ -655,8 +826,9 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 		}
 		if (lane == 0) {
 			int32_t *mm = p.td_minmax + (size_t)slot * 2;
-			if (s_val[0] < mm[0]) mm[0] = s_val[0];
-			if (s_val[m - 1] > mm[1]) mm[1] = s_val[m - 1];
+			const int32_t vmin = s_val[0] >> GYS_ROW_BITS, vmax = s_val[m - 1] >> GYS_ROW_BITS;
+			if (vmin < mm[0]) mm[0] = vmin;
+			if (vmax > mm[1]) mm[1] = vmax;
 			p.batch_cnt[slot] = 0;
 		}
 		__syncthreads();
@@ -685,6 +857,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 	__shared__ uint32_t s_part[256];
 	__shared__ uint32_t s_wave[4];
 	__shared__ unsigned long long s_h[32];
+	__shared__ uint32_t s_bm[16];
 	__shared__ uint32_t s_nc;
 	__shared__ int32_t s_min, s_max;
 	uint32_t *bins = p.scratch + (size_t)blockIdx.x * GYS_HUGE_BINS;
@@ -702,6 +875,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 			s_ocnt[threadIdx.x] = 0;
 		}
 		if (threadIdx.x >= 128u && threadIdx.x < 160u) s_h[threadIdx.x - 128u] = 0;
+		if (threadIdx.x >= 160u && threadIdx.x < 176u) s_bm[threadIdx.x - 160u] = 0;
 		if (threadIdx.x == 0) {
 			// compact non-empty old clusters (serial: 100 entries, once per huge key)
 			const int64_t *gs = p.d.td_sum + (size_t)slot * GYS_TD_NB;
@@ -732,8 +906,14 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 		{
 			int32_t lmin = INT32_MAX, lmax = INT32_MIN;
 			for (uint32_t i = threadIdx.x; i < m; i += 256u) {
-				const uint32_t v = p.d.staged[start + i] & (GYS_HUGE_BINS - 1u);
+				const uint32_t w = p.d.staged[start + i];
+				const uint32_t v = (w >> GYS_ROW_BITS) & (GYS_HUGE_BINS - 1u);
 				atomicAdd(&bins[v], 1u);
+				{
+					const uint32_t row = w & 0x1Fu;
+					const uint32_t bit = (1u << resp_bucket((int64_t)v)) << ((row & 1u) * 16u);
+					if ((s_bm[row >> 1] & bit) == 0) atomicOr(&s_bm[row >> 1], bit);
+				}
 				lmin = min(lmin, (int32_t)v);
 				lmax = max(lmax, (int32_t)v);
 			}
@@ -827,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 			p.d.td_sum[(size_t)slot * GYS_TD_NB + threadIdx.x] = (int64_t)s_osum[threadIdx.x];
 			p.d.td_cnt[(size_t)slot * GYS_TD_NB + threadIdx.x] = (uint32_t)s_ocnt[threadIdx.x];
 		}
-		if (threadIdx.x >= 128u && threadIdx.x < 148u) key_epilogue(p.d, slot, m, s_max, s_h, threadIdx.x - 128u);
+		if (threadIdx.x >= 128u && threadIdx.x < 164u) key_epilogue(p.d, slot, m, s_max, s_h, s_bm, threadIdx.x - 128u);
 		if (threadIdx.x == 0) {
 			int32_t *mm = p.d.td_minmax + (size_t)slot * 2;
 			if (s_min < mm[0]) mm[0] = s_min;

@@ -36,7 +36,7 @@ def mid_buf(machine_id):
 
 class SketchEngine:
     def __init__(self, max_hosts, max_services, max_clusters=16, enable_tdigest=True, svc_hll_p=0, max_batch_events=1 << 20,
-                 rank=0, nranks=1, device=None, torch_arena=True):
+                 rank=0, nranks=1, device=None, torch_arena=True, resp_path=0):
         import torch
         self.L = capi.load()
         if not torch.cuda.is_available():
@@ -52,6 +52,7 @@ class SketchEngine:
         cfg.max_hosts, cfg.max_services, cfg.max_clusters = max_hosts, max_services, max_clusters
         cfg.enable_tdigest = 1 if enable_tdigest else 0
         cfg.svc_hll_p = svc_hll_p
+        cfg.resp_path = resp_path
         cfg.max_batch_events = max_batch_events
         with torch.cuda.device(self.device):
             cfg.stream = torch.cuda.current_stream().cuda_stream

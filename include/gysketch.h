@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GYS_ABI_VERSION 1
+#define GYS_ABI_VERSION 2
 
 enum {
 	GYS_OK = 0,
@@ -71,7 +71,8 @@ typedef struct {
 	uint32_t max_clusters;     /* cluster-name capacity (MS_CLUSTER_STATE::MAX_NUM_CLUSTERS = 512) */
 	uint32_t enable_tdigest;   /* per-service t-digest of response times */
 	uint32_t svc_hll_p;        /* per-service distinct-client HLL precision (0 = off, 4..10) */
-	uint32_t reserved0;
+	uint32_t resp_path;        /* 0 = choose per batch; 1 = always the general (global table + atomics) pipeline; 2 = prefer the
+	                              host-local pipeline (LDS sub-table per host segment) whenever the batch qualifies */
 	uint64_t max_batch_events; /* largest resp-event batch one ingest call may carry (t-digest staging capacity) */
 	void *stream;              /* hipStream_t to run on; NULL = the context creates its own */
 	void *reduce_arena;        /* optional caller-owned DEVICE buffer for the all-reducible registers (e.g. a torch tensor so */
@@ -245,6 +246,7 @@ typedef struct {
 	uint64_t resp_events, resp_dropped_range, resp_dropped_nolistener;
 	uint64_t conn_events, conn_unknown_service;
 	uint64_t lstate_records, lstate_missed, lstate_errors, lstate_deleted;
+	uint64_t resp_batches_host_local, resp_batches_general; /* which resp pipeline each ingest call took (gys_config.resp_path) */
 } gys_counters;
 int gys_get_counters(gys_ctx *ctx, gys_counters *out);
 

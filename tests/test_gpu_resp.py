@@ -46,10 +46,22 @@ def _compare_window(eng, orc):
     assert gh.total_count == oh[15, 0] and gh.max_val_seen == omax
 
 
-def test_resp_small_hosts_edge_cases(torch_mod, oracle):
+PATHS = pytest.mark.parametrize("resp_path", [1, 2], ids=["general", "hostlocal"])
+
+
+def _assert_path(eng, resp_path):
+    c = eng.counters()
+    if resp_path == 1:
+        assert c["resp_batches_host_local"] == 0 and c["resp_batches_general"] > 0
+    elif resp_path == 2:
+        assert c["resp_batches_general"] == 0 and c["resp_batches_host_local"] > 0
+
+
+@PATHS
+def test_resp_small_hosts_edge_cases(torch_mod, oracle, resp_path):
     rng = np.random.default_rng(1)
     nh, sp = 3, 7
-    eng = _engine(max_hosts=8, max_services=64, max_batch_events=1 << 16)
+    eng = _engine(max_hosts=8, max_services=64, max_batch_events=1 << 16, resp_path=resp_path)
     orc = oracle.OracleEngine(64)
     info, gids = helpers.register_world(eng, orc, range(nh), sp)
     total = 0
@@ -63,6 +75,7 @@ def test_resp_small_hosts_edge_cases(torch_mod, oracle):
     eng.handle_resp_events(info[0][0], np.zeros(0, dtype=helpers.wire.RESP_EVENT))  # empty batch is a no-op
     eng.sync()
     _compare_all(eng, orc, oracle)
+    _assert_path(eng, resp_path)
     c, oc = eng.counters(), orc.counters()
     assert c["resp_events"] == total == oc["events"]
     assert c["resp_dropped_range"] == oc["dropped_range"] and c["resp_dropped_nolistener"] == oc["dropped_nolistener"]
@@ -94,11 +107,12 @@ def test_resp_small_hosts_edge_cases(torch_mod, oracle):
     eng.close()
 
 
-def test_resp_device_generated_stream(torch_mod, oracle):
+@PATHS
+def test_resp_device_generated_stream(torch_mod, oracle, resp_path):
     """SURVEY 8d-style stream generated ON the GPU, replayed through the oracle on the host from the very same bytes"""
     torch = torch_mod
     nh, sp, n = 32, 50, 1 << 19
-    eng = _engine(max_hosts=nh, max_services=nh * sp, max_batch_events=n)
+    eng = _engine(max_hosts=nh, max_services=nh * sp, max_batch_events=n, resp_path=resp_path)
     orc = oracle.OracleEngine(nh * sp)
     helpers.register_world(eng, orc, range(nh), sp)
     ev = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
@@ -112,6 +126,7 @@ def test_resp_device_generated_stream(torch_mod, oracle):
         exact[rnd] = a
     eng.sync()
     _compare_all(eng, orc, oracle)
+    _assert_path(eng, resp_path)
     assert eng.counters()["resp_dropped_nolistener"] == 0
     # t-digest vs exact sort: rank error <= 1 % (north_star tolerance), and bucket agreement with GY_HISTOGRAM::get_percentile
     allev = np.concatenate([exact[r] for r in range(3)])
@@ -136,11 +151,12 @@ def test_resp_device_generated_stream(torch_mod, oracle):
     eng.close()
 
 
-def test_resp_huge_key_batches(torch_mod, oracle):
+@PATHS
+def test_resp_huge_key_batches(torch_mod, oracle, resp_path):
     """keys with more than 1024 new values in one batch take the value-count-array kernel; result must still equal the oracle,
     including when a small batch, a huge batch and another small batch hit the same key"""
     rng = np.random.default_rng(5)
-    eng = _engine(max_hosts=2, max_services=8, max_batch_events=1 << 18)
+    eng = _engine(max_hosts=2, max_services=8, max_batch_events=1 << 18, resp_path=resp_path)
     orc = oracle.OracleEngine(8)
     info, gids = helpers.register_world(eng, orc, range(1), 3)
     mid, slot = info[0]
@@ -150,6 +166,7 @@ def test_resp_huge_key_batches(torch_mod, oracle):
         orc.resp_batch(ev.tobytes(), [slot], [0])
     eng.sync()
     _compare_all(eng, orc, oracle)
+    _assert_path(eng, resp_path)
     for s in range(3):
         g = int(gids[0][s])
         qs = [0.001, 0.5, 0.999]
@@ -172,7 +189,7 @@ def test_tdigest_disabled_and_identical_values(torch_mod, oracle):
         eng.quantiles(int(gids[0][0]), [0.5])
     eng.close()
     # all-identical values (every item ties with every other): exercises the tie rule old-before-new
-    eng = _engine(max_hosts=1, max_services=4, max_batch_events=1 << 16)
+    eng = _engine(max_hosts=1, max_services=4, max_batch_events=1 << 16, resp_path=2)
     orc = oracle.OracleEngine(4)
     info, gids = helpers.register_world(eng, orc, range(1), 1)
     for n in (10, 2000, 700):
@@ -183,4 +200,63 @@ def test_tdigest_disabled_and_identical_values(torch_mod, oracle):
     eng.sync()
     _compare_all(eng, orc, oracle)
     assert eng.quantiles(int(gids[0][0]), [0.1, 0.5, 0.9]) == [42.0, 42.0, 42.0]
+    eng.close()
+
+
+def test_resp_hostlocal_incremental_registration_and_fallbacks(torch_mod, oracle):
+    """listeners registered in several interleaved calls (non-contiguous slots, growing sub-tables), a host with no listeners, and a
+    multi-segment batch that names one host twice (must take the general pipeline even when host-local is preferred)"""
+    torch = torch_mod
+    rng = np.random.default_rng(11)
+    nh, sp = 4, 40
+    eng = _engine(max_hosts=8, max_services=1024, max_batch_events=1 << 16, resp_path=2)
+    orc = oracle.OracleEngine(1024)
+    mids, slots = {}, {}
+    for h in range(nh + 1):  # host nh never gets a listener
+        mids[h] = helpers.wire.machine_id(h)
+        slots[h] = eng.register_host(mids[h], "c")
+    step = 5
+    for lo in range(0, sp, step):  # interleave hosts so that a host's slots are scattered
+        for h in range(nh):
+            s = np.arange(lo, min(sp, lo + step))
+            g = helpers.wire.glob_id(np.full(len(s), h), s)
+            ns, pt = helpers.wire.listener_netns(h, s), helpers.wire.listener_port(s)
+            eng.register_listeners_np(mids[h], g, ns, pt)
+            for i in range(len(s)):
+                orc.register(slots[h], int(g[i]), int(ns[i]), int(pt[i]))
+        # ingest between registration rounds: the sub-tables must be valid at every size
+        for h in range(nh):
+            ev = helpers.make_resp_events(rng, h, 700, min(sp, lo + step + 3))  # some events name listeners not registered yet
+            eng.handle_resp_events(mids[h], ev)
+            orc.resp_batch(ev.tobytes(), [slots[h]], [0])
+    ev = helpers.make_resp_events(rng, nh, 100, 3)
+    eng.handle_resp_events(mids[nh], ev)  # host without listeners: every in-range event is dropped "no listener"
+    orc.resp_batch(ev.tobytes(), [slots[nh]], [0])
+    eng.sync()
+    _compare_all(eng, orc, oracle)
+    c0 = eng.counters()
+    assert c0["resp_batches_general"] == 0 and c0["resp_dropped_nolistener"] == orc.counters()["dropped_nolistener"] > 0
+    # multi-segment device batch: distinct hosts -> host-local; a repeated host -> general
+    parts = [helpers.make_resp_events(rng, h, 500 + 37 * h, sp) for h in (0, 1, 2, 3)]
+    buf = np.concatenate(parts)
+    firsts = np.cumsum([0] + [len(x) for x in parts[:-1]])
+    from gyeeta_amd import capi
+    def run(hosts):
+        segs = (capi.RespSeg * len(hosts))()
+        for i, h in enumerate(hosts):
+            segs[i].host_slot, segs[i].first_event = slots[h], int(firsts[i])
+        d = torch.from_numpy(buf.view(np.uint8).copy()).cuda()
+        eng.handle_resp_events_dev(segs, d.data_ptr(), len(buf))
+        eng.sync()
+        orc.resp_batch(buf.tobytes(), [slots[h] for h in hosts], [int(f) for f in firsts])
+    run([0, 1, 2, 3])
+    c1 = eng.counters()
+    assert c1["resp_batches_host_local"] == c0["resp_batches_host_local"] + 1 and c1["resp_batches_general"] == 0
+    # same bytes, but segment 2 is attributed to host 0 again: events whose (netns, port) belong to host 2 miss in host 0's table
+    run([0, 1, 0, 3])
+    c2 = eng.counters()
+    assert c2["resp_batches_general"] == 1
+    _compare_all(eng, orc, oracle)
+    eng.window_close()
+    _compare_window(eng, orc)
     eng.close()
