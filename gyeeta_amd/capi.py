@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libgysketch.so")
 
 OK, ERR_INVAL, ERR_NOMEM, ERR_HIP, ERR_NOTFOUND, ERR_NOT_OWNER, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 MAX_BUCKETS, TD_NB, HLL_P, CMS_D, CMS_W, NSTATES, TOPN = 16, 100, 14, 4, 65536, 6, 10
+TD_PEND_CAP = 256
 KINDS = {"RESP_TIME_HASH": 0, "SEMI_LOG_HASH": 1, "SEMI_LOG_HASH_LO": 2, "DURATION_HASH": 3, "HASH_10_5000": 4, "HASH_5_250": 5,
          "HASH_1_3000": 6, "PERCENT_HASH": 7}
 
@@ -121,6 +122,7 @@ SIGNATURES = {
     "gys_export_hll": (C.c_int, [vp, vp]),
     "gys_export_cms": (C.c_int, [vp, C.c_int, vp]),
     "gys_export_tdigest": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp]),
+    "gys_export_tdigest_pending": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
     "gys_export_svc_counters": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
     "gys_export_global_hist": (C.c_int, [vp, C.POINTER(HistRec)]),
     "gys_export_svc_hll": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),

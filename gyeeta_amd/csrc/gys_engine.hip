@@ -140,7 +140,12 @@ struct gys_ctx {
 	uint32_t *bitmap = nullptr;
 	int64_t *td_sum = nullptr;
 	uint32_t *td_cnt = nullptr;
-	int32_t *td_minmax = nullptr;
+	TdMeta *td_meta = nullptr;
+	uint32_t *td_pend = nullptr;
+	MergeEnt *merge_list = nullptr;
+	uint32_t *merge_count = nullptr; // [0] merge list length of the batch, [1] = 1 (length of a query list)
+	int64_t *query_sum = nullptr;    // scratch of the non-destructive merge behind gys_query_quantiles
+	uint32_t *query_cnt = nullptr;
 	uint32_t *batch_cnt = nullptr, *batch_off = nullptr, *scan_block_sums = nullptr;
 	uint64_t *ev_kv = nullptr;
 	uint32_t *staged = nullptr;
@@ -488,7 +493,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	DigestP d{};
 	d.td_sum = c->td_sum;
 	d.td_cnt = c->td_cnt;
-	d.td_minmax = c->td_minmax;
+	d.td_meta = c->td_meta;
+	d.td_pend = c->td_pend;
+	d.merge_list = c->merge_list;
+	d.merge_count = c->merge_count;
 	d.batch_cnt = c->batch_cnt;
 	d.off_end = c->batch_off;
 	d.staged = c->staged;
@@ -498,12 +506,17 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	d.svc_gid = c->svc_gid;
 	d.bitmap = c->bitmap;
 	{
-		ProfScope ps(c, "digest_wave");
-		hipLaunchKernelGGL(k_digest_wave, dim3(std::min<uint32_t>((nsvc + 3) / 4, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, d);
+		ProfScope ps(c, "key_pass");
+		HIPCHK(hipMemsetAsync(c->merge_count, 0, 4, c->stream));
+		hipLaunchKernelGGL(k_key_pass, dim3(std::min<uint32_t>((nsvc + 255) / 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, d);
 	}
 	{
-		ProfScope ps(c, "digest_small");
-		hipLaunchKernelGGL(k_digest_small, dim3(std::min<uint32_t>(nsvc, (uint32_t)c->ncu * 16)), dim3(64), 0, c->stream, d);
+		ProfScope ps(c, "digest_merge");
+		MergeP mp{};
+		mp.d = d;
+		mp.list = c->merge_list;
+		mp.count = c->merge_count;
+		hipLaunchKernelGGL(k_digest_merge, dim3(std::min<uint64_t>(std::min<uint64_t>(nsvc, n), (uint64_t)c->ncu * 32)), dim3(64), 0, c->stream, mp);
 	}
 	{
 		ProfScope ps(c, "digest_huge");
@@ -671,7 +684,12 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		const uint64_t B = cfg->max_batch_events ? cfg->max_batch_events : 1;
 		ALLOC(c->td_sum, S * GYS_TD_NB);
 		ALLOC(c->td_cnt, S * GYS_TD_NB);
-		ALLOC(c->td_minmax, S * 2);
+		ALLOC(c->td_meta, S);
+		ALLOC(c->td_pend, S * GYS_TD_PEND_CAP);
+		ALLOC(c->merge_list, std::min<uint64_t>(S, B) + 1);
+		ALLOC(c->merge_count, 2);
+		ALLOC(c->query_sum, GYS_TD_NB);
+		ALLOC(c->query_cnt, GYS_TD_NB);
 		ALLOC(c->batch_cnt, align_up(S, 16));
 		ALLOC(c->batch_off, align_up(S, 16));
 		ALLOC(c->scan_block_sums, (S + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE + 1);
@@ -682,7 +700,11 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_SMALL_MAX + 1));
 		if (c->huge_blocks < 1) c->huge_blocks = 1;
 		ALLOC(c->huge_scratch, (uint64_t)c->huge_blocks * GYS_HUGE_BINS);
-		hipLaunchKernelGGL(k_minmax_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->td_minmax, S);
+		hipLaunchKernelGGL(k_tdmeta_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, (uint4 *)c->td_meta, S);
+		{
+			const uint32_t one = 1;
+			HIPCHK(hipMemcpyAsync(c->merge_count + 1, &one, 4, hipMemcpyHostToDevice, c->stream));
+		}
 	}
 #undef ALLOC
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_win, (uint64_t)0, S, (int64_t)INT64_MIN);
@@ -717,7 +739,7 @@ void gys_destroy(gys_ctx *c)
 	if (c->stream) hipStreamSynchronize(c->stream);
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
-			c->td_cnt, c->td_minmax, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_list, c->huge_count,
+			c->td_cnt, c->td_meta, c->td_pend, c->merge_list, c->merge_count, c->query_sum, c->query_cnt, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_list, c->huge_count,
 			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->segs_dev, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->own_arena ? c->arena : nullptr};
@@ -1078,7 +1100,7 @@ int gys_query_hist_percentiles(gys_ctx *c, uint64_t glob_id, int which, gys_hist
 }
 
 // quantile of an exact-integer digest: interpolation between cluster centres; only + - * / on doubles (matches oracle bit-for-bit)
-static double td_quantile_host(const int64_t *sum, const uint32_t *cnt, int32_t vmin, int32_t vmax, double q)
+static double td_quantile_interp(const int64_t *sum, const uint32_t *cnt, int32_t vmin, int32_t vmax, double q)
 {
 	uint64_t N = 0;
 	for (int k = 0; k < GYS_TD_NB; ++k) N += cnt[k];
@@ -1110,6 +1132,12 @@ static double td_quantile_host(const int64_t *sum, const uint32_t *cnt, int32_t 
 	return prev_mean + (hi - prev_mean) * ((t - prev_c) / span);
 }
 
+// integer-millisecond data: the interpolated value rounded half-up to the value domain (same definition as the oracle)
+static double td_quantile_host(const int64_t *sum, const uint32_t *cnt, int32_t vmin, int32_t vmax, double q)
+{
+	return std::floor(td_quantile_interp(sum, cnt, vmin, vmax, q) + 0.5);
+}
+
 int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t nq, double *out)
 {
 	if (!c || !q || !out) return GYS_ERR_INVAL;
@@ -1120,14 +1148,29 @@ int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t 
 	uint32_t slot;
 	int rc = gys_lookup_service(c, glob_id, &slot);
 	if (rc) return rc;
+	// merged view = clusters re-clustered with the key's buffered values (k_digest_merge in query mode: state is not modified)
 	int64_t sum[GYS_TD_NB];
 	uint32_t cnt[GYS_TD_NB];
-	int32_t mm[2];
-	HIPCHK(hipMemcpyAsync(sum, c->td_sum + (size_t)slot * GYS_TD_NB, sizeof(sum), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(cnt, c->td_cnt + (size_t)slot * GYS_TD_NB, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(mm, c->td_minmax + (size_t)slot * 2, sizeof(mm), hipMemcpyDeviceToHost, c->stream));
+	TdMeta mt;
+	const MergeEnt ent{slot, 0u, 0u, 0u};
+	HIPCHK(hipMemcpyAsync(c->merge_list, &ent, sizeof(ent), hipMemcpyHostToDevice, c->stream));
+	MergeP mp{};
+	mp.d.td_sum = c->td_sum;
+	mp.d.td_cnt = c->td_cnt;
+	mp.d.td_meta = c->td_meta;
+	mp.d.td_pend = c->td_pend;
+	mp.d.staged = c->staged;
+	mp.list = c->merge_list;
+	mp.count = c->merge_count + 1;
+	mp.out_sum = c->query_sum;
+	mp.out_cnt = c->query_cnt;
+	hipLaunchKernelGGL(k_digest_merge, dim3(1), dim3(64), 0, c->stream, mp);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(sum, c->query_sum, sizeof(sum), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(cnt, c->query_cnt, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(&mt, c->td_meta + slot, sizeof(mt), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
-	for (uint32_t i = 0; i < nq; ++i) out[i] = td_quantile_host(sum, cnt, mm[0], mm[1], q[i]);
+	for (uint32_t i = 0; i < nq; ++i) out[i] = td_quantile_host(sum, cnt, mt.vmin, mt.vmax, q[i]);
 	return GYS_OK;
 }
 
@@ -1295,8 +1338,26 @@ int gys_export_tdigest(gys_ctx *c, uint32_t first_slot, uint32_t nslots, int64_t
 	if (!c->cfg.enable_tdigest || !cnts || !minmax) return GYS_ERR_INVAL;
 	HIPCHK(hipMemcpyAsync(sums, c->td_sum + (size_t)first_slot * GYS_TD_NB, (size_t)nslots * GYS_TD_NB * 8, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(cnts, c->td_cnt + (size_t)first_slot * GYS_TD_NB, (size_t)nslots * GYS_TD_NB * 4, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(minmax, c->td_minmax + (size_t)first_slot * 2, (size_t)nslots * 8, hipMemcpyDeviceToHost, c->stream));
+	std::vector<TdMeta> meta(nslots);
+	HIPCHK(hipMemcpyAsync(meta.data(), c->td_meta + first_slot, (size_t)nslots * sizeof(TdMeta), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	for (uint32_t i = 0; i < nslots; ++i) {
+		minmax[2 * i] = meta[i].vmin;
+		minmax[2 * i + 1] = meta[i].vmax;
+	}
+	return GYS_OK;
+}
+
+int gys_export_tdigest_pending(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint32_t *npend, int32_t *pend)
+{
+	void *out = npend;
+	RANGE_CHECK(first_slot, nslots);
+	if (!c->cfg.enable_tdigest || !pend) return GYS_ERR_INVAL;
+	std::vector<TdMeta> meta(nslots);
+	HIPCHK(hipMemcpyAsync(meta.data(), c->td_meta + first_slot, (size_t)nslots * sizeof(TdMeta), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(pend, c->td_pend + (size_t)first_slot * GYS_TD_PEND_CAP, (size_t)nslots * GYS_TD_PEND_CAP * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	for (uint32_t i = 0; i < nslots; ++i) npend[i] = meta[i].npend;
 	return GYS_OK;
 }
 

@@ -5,7 +5,9 @@
 //                  CONN_BITMAP, global histogram (LDS privatised), global HLL, Count-Min, per-key batch count, (slot,value) record
 //   scan_*         exclusive scan of the per-key batch counts (counting sort by key)
 //   resp_scatter   values scattered into per-key contiguous segments
-//   digest_small   one wave per key: LDS bitonic sort of the key's new values + exact-integer k-bucket t-digest merge
+//   key_pass       one wave per key with new values: exact histogram record, CONN_BITMAP, Count-Min, min/max, append to the key's
+//                  t-digest buffer (or queue the key for a merge when the buffer would overflow)
+//   digest_merge   queued keys: LDS bitonic sort of (buffered + new) values + exact-integer k-bucket t-digest merge
 //   digest_huge    keys with > GYS_SMALL_MAX new values: value-count array in HBM scratch + parallel rank-interval assignment
 // All of it is HBM-bound integer work: no MFMA.
 #pragma once
@@ -14,7 +16,7 @@
 
 namespace gys {
 
-#define GYS_SMALL_MAX 1024u        // largest per-key batch handled by digest_small (LDS bitonic sort by one wave)
+#define GYS_SMALL_MAX 1024u        // largest per-key batch handled by k_key_pass / k_digest_merge; larger ones go to k_digest_huge
 #define GYS_HUGE_VALUE_BITS 20     // resp values are <= 1,000,000 < 2^20 (drop filter common/gy_socket_stat.cc:1521-1524)
 #define GYS_HUGE_BINS (1u << GYS_HUGE_VALUE_BITS)
 // staged word of one accepted event: (response ms << 5) | CONN_BITMAP row (cli_port & 0x1F, common/gy_socket_stat.h:403-410).
@@ -53,12 +55,11 @@ __global__ void k_hist_init(gys_hist_rec *h, uint64_t first, uint64_t n, int64_t
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) h[first + i].max_val_seen = minval;
 }
 
-__global__ void k_minmax_init(int32_t *mm, uint64_t n)
+__global__ void k_tdmeta_init(uint4 *meta, uint64_t n)
 {
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-		mm[2 * i] = INT32_MAX;
-		mm[2 * i + 1] = INT32_MIN;
-	}
+	// TdMeta {vmin = INT32_MAX, vmax = INT32_MIN, npend = 0, pad}
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+		meta[i] = make_uint4((uint32_t)INT32_MAX, (uint32_t)INT32_MIN, 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------- resp pass 1
@@ -417,21 +418,43 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	}
 }
 
-// ---------------------------------------------------------------------------------------------------- t-digest merge (small)
+// ---------------------------------------------------------------------------------------------------- per-key pass + t-digest merge
+// t-digest state of a key: 100 exact-integer clusters (td_sum / td_cnt) + a buffer of up to GYS_TD_PEND_CAP unmerged values
+// (the classic merging-digest buffer).  A batch's values are appended to the buffer; only when they no longer fit is the key
+// re-clustered with (buffered + new) values in ONE merge.  So the per-batch per-key work is light (k_key_pass: histogram record,
+// CONN_BITMAP, Count-Min, min/max, buffer append) and the expensive cluster merge (k_digest_merge) runs once per ~CAP values.
+static_assert(GYS_TD_PEND_CAP == GYS_TDIGEST_PEND_CAP, "gysketch.h and gys_tdigest_tbl.h disagree on the t-digest buffer size");
+
+struct TdMeta {
+	int32_t vmin, vmax; // over merged AND buffered values (INT32_MAX / INT32_MIN when empty)
+	uint32_t npend;     // buffered values in td_pend[slot * CAP ..]
+	uint32_t pad;
+};
+
+struct MergeEnt {
+	uint32_t slot;
+	uint32_t m;        // new values of the batch (staged[off_end - m .. off_end)), 0 for a query entry
+	uint32_t off_end;
+	uint32_t pad;
+};
+
 struct DigestP {
 	int64_t *td_sum;    // [nsvc*100]
 	uint32_t *td_cnt;   // [nsvc*100]
-	int32_t *td_minmax; // [nsvc*2]
+	TdMeta *td_meta;    // [nsvc]
+	uint32_t *td_pend;  // [nsvc*CAP]
 	uint32_t *batch_cnt;
 	const uint32_t *off_end;
 	const uint32_t *staged;
 	uint32_t nsvc;
-	// fused per-key outputs (the digest kernels see every key's values of the batch, so they also produce the exact histogram
-	// delta and the Count-Min increment of the key -- one coalesced record update instead of ~9 atomics per EVENT)
+	// per-key outputs of the batch (the per-key kernels see every value of the key: one coalesced record update per KEY instead of
+	// ~9 device atomics per EVENT)
 	gys_hist_rec *hist_win;
 	uint32_t *cms32;
 	const uint64_t *svc_gid;
 	uint32_t *bitmap; // [nsvc*16] u32 = 32 x u16 CONN_BITMAP rows (common/gy_socket_stat.h:390-454)
+	MergeEnt *merge_list;
+	uint32_t *merge_count;
 };
 
 // CONN_BITMAP::add_response for one staged word into a 16-word LDS row image: respmap_[row].set(bucket)
@@ -474,8 +497,6 @@ __device__ __forceinline__ void key_epilogue(const DigestP &p, uint32_t slot, ui
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
 	} while (0)
 
-#define GYS_WAVE_MAX 64u // keys with <= 64 new values: sorted in registers by k_digest_wave
-
 __device__ __forceinline__ uint32_t td_cluster_of(const uint64_t *T, uint64_t mid2)
 {
 	uint32_t a = 0, bb = GYS_TD_NB - 1;
@@ -505,33 +526,23 @@ __device__ __forceinline__ void wave_excl_scan_2x(uint64_t a0, uint64_t a1, uint
 	*total = tot0 + tot1;
 }
 
-// Keys with <= 64 new values (the common case at ~10..100 events per key per window): one WAVE per key, 4 independent waves per
-// workgroup, no workgroup barriers.  New values live one per lane and are sorted with a 21-step __shfl_xor bitonic network; old
-// clusters live two per lane; ranks are exchanged through a 65-entry LDS "weight at rank" array + a __shfl_up scan.
-// A wave walks a chunk of 64 consecutive keys: the chunk's counts/offsets come from ONE coalesced load (then v_readlane), and the
-// next key's digest / values / histogram record are prefetched into registers while the current key is merged, so the per-key
-// critical path holds no dependent HBM round trip.
+// ---- k_key_pass: every key with 1..GYS_SMALL_MAX new values.  One WAVE per key, 4 independent waves per workgroup, no workgroup
+// barriers.  A wave walks a chunk of 64 consecutive keys: the chunk's counts / offsets come from ONE coalesced load (then readlane),
+// and the next key's first 64 staged words, histogram record, glob_id, meta and bitmap words are prefetched into registers while
+// the current key is processed, so the per-key critical path holds no dependent HBM round trip.
 struct KeyRegs {
-	int32_t v;          // new value of this lane (INT32_MAX padding)
-	uint32_t c0, c1;    // old cluster counts (entries lane, lane + 64)
-	int64_t sm0, sm1;   // old cluster sums
-	uint64_t hc, hs;    // lanes 0..15: the 16-byte pair `lane` of the key's histogram record
-	uint64_t aux;       // lane 16..19: glob_id (Count-Min key); lane 20: packed {vmin, vmax}; lanes 32..47: CONN_BITMAP word lane-32
+	uint32_t w;        // staged word of this lane (first 64 values of the key)
+	uint64_t hc, hs;   // lanes 0..15: the 16-byte pair `lane` of the key's histogram record
+	uint64_t aux, aux2; // lanes 16..19: glob_id; lane 20: TdMeta {vmin,vmax | npend,pad}; lanes 32..47: CONN_BITMAP word lane-32
 };
 
 __device__ __forceinline__ void key_prefetch(const DigestP &p, uint32_t slot, uint32_t m, uint32_t oend, uint32_t lane, KeyRegs &r)
 {
-	const uint32_t j1 = lane + 64u;
-	r.v = lane < m ? (int32_t)p.staged[oend - m + lane] : INT32_MAX;
-	const int64_t *gs = p.td_sum + (size_t)slot * GYS_TD_NB;
-	const uint32_t *gc = p.td_cnt + (size_t)slot * GYS_TD_NB;
-	r.c0 = gc[lane];
-	r.c1 = j1 < GYS_TD_NB ? gc[j1] : 0u;
-	r.sm0 = gs[lane];
-	r.sm1 = j1 < GYS_TD_NB ? gs[j1] : 0;
+	r.w = lane < m ? p.staged[oend - m + lane] : 0u;
 	r.hc = 0;
 	r.hs = 0;
 	r.aux = 0;
+	r.aux2 = 0;
 	if (lane < 16u) {
 		const uint64_t *h = (const uint64_t *)&p.hist_win[slot] + 2 * lane;
 		r.hc = h[0];
@@ -539,34 +550,31 @@ __device__ __forceinline__ void key_prefetch(const DigestP &p, uint32_t slot, ui
 	} else if (lane < 20u) {
 		r.aux = p.svc_gid[slot];
 	} else if (lane == 20u) {
-		r.aux = *(const uint64_t *)(p.td_minmax + (size_t)slot * 2);
+		const uint64_t *mt = (const uint64_t *)&p.td_meta[slot];
+		r.aux = mt[0];
+		r.aux2 = mt[1];
 	} else if (lane >= 32u && lane < 48u) {
 		r.aux = (uint64_t)p.bitmap[(size_t)slot * 16u + (lane - 32u)];
 	}
 }
 
-__global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
+__global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 {
-	__shared__ uint64_t s_T_[4][GYS_TD_NB];
-	__shared__ unsigned long long s_add_[4][GYS_WAVE_MAX + 2];
-	__shared__ unsigned long long s_osum_[4][GYS_TD_NB];
-	__shared__ uint32_t s_ocnt_[4][GYS_TD_NB];
 	__shared__ unsigned long long s_h_[4][32];
 	__shared__ uint32_t s_bm_[4][16];
+	__shared__ int32_t s_mm_[4][2];
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	unsigned long long *s_h = s_h_[wv];
 	uint32_t *s_bm = s_bm_[wv];
-	uint64_t *s_T = s_T_[wv];
-	unsigned long long *s_add = s_add_[wv], *s_osum = s_osum_[wv], *s_h = s_h_[wv];
-	uint32_t *s_ocnt = s_ocnt_[wv];
+	int32_t *s_mm = s_mm_[wv];
 	const uint32_t nwaves = gridDim.x * 4u;
-	const uint32_t j1 = lane + 64u;
 	const uint32_t nchunks = (p.nsvc + 63u) / 64u;
 
 	for (uint32_t chunk = blockIdx.x * 4u + wv; chunk < nchunks; chunk += nwaves) {
 		const uint32_t key = chunk * 64u + lane;
 		uint32_t mcnt = key < p.nsvc ? p.batch_cnt[key] : 0u;
 		const uint32_t oend = key < p.nsvc ? p.off_end[key] : 0u;
-		if (mcnt > GYS_WAVE_MAX) mcnt = 0; // larger keys belong to k_digest_small / k_digest_huge
+		if (mcnt > GYS_SMALL_MAX) mcnt = 0; // larger keys belong to k_digest_huge (which also does their histogram / bitmap / CMS)
 		unsigned long long todo = __ballot(mcnt != 0);
 		if (!todo) continue;
 		if (mcnt) p.batch_cnt[key] = 0; // consumed (coalesced reset for the whole chunk)
@@ -577,89 +585,40 @@ __global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
 		for (;;) {
 			const uint32_t slot = chunk * 64u + i;
 			const uint32_t m = (uint32_t)__shfl((int)mcnt, (int)i, 64);
+			const uint32_t ke = (uint32_t)__shfl((int)oend, (int)i, 64);
 			uint32_t inext = 64u;
 			if (todo) { // issue the next key's loads now; they are consumed one iteration later
 				inext = (uint32_t)__ffsll((long long)todo) - 1u;
 				todo &= todo - 1;
 				key_prefetch(p, chunk * 64u + inext, (uint32_t)__shfl((int)mcnt, (int)inext, 64), (uint32_t)__shfl((int)oend, (int)inext, 64), lane, nxt);
 			}
-			int32_t w = cur.v; // staged word: value << 5 | CONN_BITMAP row
-			const uint32_t c0 = cur.c0, c1 = cur.c1;
-			const int64_t sm0 = cur.sm0, sm1 = cur.sm1;
-			// bitonic sort across the 64 lanes (ascending), padding = INT32_MAX
-#pragma unroll
-			for (uint32_t k = 2; k <= 64u; k <<= 1) {
-#pragma unroll
-				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-					const int32_t o = __shfl_xor(w, (int)j, 64);
-					const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-					w = (lower == up) ? min(w, o) : max(w, o);
-				}
-			}
-			const int32_t v = w >> GYS_ROW_BITS;
-			uint64_t e0, e1, nold;
-			wave_excl_scan_2x((uint64_t)c0, (uint64_t)c1, &e0, &e1, &nold);
-			const uint64_t twoN = 2ull * (nold + (uint64_t)m);
-			if (lane >= 1) s_T[lane] = td_threshold(c_td_bnd[lane], twoN);
-			if (j1 < GYS_TD_NB) s_T[j1] = td_threshold(c_td_bnd[j1], twoN);
-			s_add[lane] = 0;
-			if (lane < 2u) s_add[64u + lane] = 0;
-			s_osum[lane] = 0;
-			s_ocnt[lane] = 0;
-			if (j1 < GYS_TD_NB) {
-				s_osum[j1] = 0;
-				s_ocnt[j1] = 0;
-			}
+			const uint32_t npend = (uint32_t)__shfl((int)(uint32_t)cur.aux2, 20, 64);
+			const bool do_merge = npend + m > GYS_TD_PEND_CAP;
 			if (lane < 32u) s_h[lane] = 0;
 			if (lane < 16u) s_bm[lane] = 0;
-			GYS_WAVE_SYNC();
-			// ---- old clusters: lt = #{new values with v * cnt < sum} by broadcasting the (few) new values
-			uint32_t lt0 = 0, lt1 = 0;
-			for (uint32_t q = 0; q < m; ++q) {
-				const int64_t vi = (int64_t)__shfl(v, (int)q, 64);
-				lt0 += (vi * (int64_t)c0 < sm0) ? 1u : 0u;
-				lt1 += (vi * (int64_t)c1 < sm1) ? 1u : 0u;
-			}
-			if (c0) {
-				atomicAdd(&s_add[lt0], (unsigned long long)c0); // every new value of rank >= lt0 has this cluster at or before it
-				const uint32_t cl = td_cluster_of(s_T, 2ull * (e0 + lt0) + (uint64_t)c0);
-				atomicAdd(&s_osum[cl], (unsigned long long)sm0);
-				atomicAdd(&s_ocnt[cl], c0);
-			}
-			if (c1) {
-				atomicAdd(&s_add[lt1], (unsigned long long)c1);
-				const uint32_t cl = td_cluster_of(s_T, 2ull * (e1 + lt1) + (uint64_t)c1);
-				atomicAdd(&s_osum[cl], (unsigned long long)sm1);
-				atomicAdd(&s_ocnt[cl], c1);
+			if (lane == 0) {
+				s_mm[0] = INT32_MAX;
+				s_mm[1] = INT32_MIN;
 			}
 			GYS_WAVE_SYNC();
-			// ---- new values: le(rank r) = sum of s_add[0..r]
-			uint64_t le = s_add[lane];
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint64_t t = __shfl_up(le, d, 64);
-				if ((int)lane >= d) le += t;
-			}
-			if (lane < m) {
-				const uint32_t cl = td_cluster_of(s_T, 2ull * ((uint64_t)lane + le) + 1ull);
-				atomicAdd(&s_osum[cl], (unsigned long long)(int64_t)v);
-				atomicAdd(&s_ocnt[cl], 1u);
-				const uint32_t b = resp_bucket((int64_t)v);
-				atomicAdd(&s_h[2 * b], 1ull);
-				atomicAdd(&s_h[2 * b + 1], (unsigned long long)(int64_t)v);
-				bitmap_set_lds(s_bm, (uint32_t)w, b);
+			uint32_t *pend = p.td_pend + (size_t)slot * GYS_TD_PEND_CAP + npend;
+			for (uint32_t base = 0; base < m; base += 64u) {
+				const uint32_t idx = base + lane;
+				if (idx < m) {
+					const uint32_t w = base == 0 ? cur.w : p.staged[ke - m + idx]; // staged word: value << 5 | CONN_BITMAP row
+					const int32_t v = (int32_t)(w >> GYS_ROW_BITS);
+					const uint32_t b = resp_bucket((int64_t)v);
+					atomicAdd(&s_h[2 * b], 1ull);
+					atomicAdd(&s_h[2 * b + 1], (unsigned long long)(int64_t)v);
+					bitmap_set_lds(s_bm, w, b);
+					atomicMin(&s_mm[0], v);
+					atomicMax(&s_mm[1], v);
+					if (!do_merge) pend[idx] = (uint32_t)v;
+				}
 			}
 			GYS_WAVE_SYNC();
-			const int32_t vmin = __shfl(v, 0, 64), vmax = __shfl(v, (int)(m - 1), 64);
-			int64_t *ws = p.td_sum + (size_t)slot * GYS_TD_NB;
-			uint32_t *wc = p.td_cnt + (size_t)slot * GYS_TD_NB;
-			ws[lane] = (int64_t)s_osum[lane];
-			wc[lane] = s_ocnt[lane];
-			if (j1 < GYS_TD_NB) {
-				ws[j1] = (int64_t)s_osum[j1];
-				wc[j1] = s_ocnt[j1];
-			}
-			// ---- histogram record (prefetched pair + LDS delta), Count-Min, min/max
+			const int32_t vmin = s_mm[0], vmax = s_mm[1];
+			// ---- histogram record (prefetched pair + LDS delta), Count-Min, meta, bitmap
 			if (lane < 15u) {
 				const unsigned long long dc = s_h[2 * lane];
 				if (dc) {
@@ -676,10 +635,20 @@ __global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
 				atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(cur.aux, GYS_SEED + r) & (GYS_CMS_W - 1))], m);
 			} else if (lane == 20u) {
 				int32_t mn = (int32_t)(uint32_t)cur.aux, mx = (int32_t)(uint32_t)(cur.aux >> 32);
-				if (vmin < mn || vmax > mx) {
-					mn = min(mn, vmin);
-					mx = max(mx, vmax);
-					*(uint64_t *)(p.td_minmax + (size_t)slot * 2) = (uint64_t)(uint32_t)mn | ((uint64_t)(uint32_t)mx << 32);
+				mn = min(mn, vmin);
+				mx = max(mx, vmax);
+				uint64_t *mt = (uint64_t *)&p.td_meta[slot];
+				mt[0] = (uint64_t)(uint32_t)mn | ((uint64_t)(uint32_t)mx << 32);
+				if (!do_merge) mt[1] = (uint64_t)(npend + m);
+			} else if (lane == 21u) {
+				if (do_merge) { // the re-clustering of (buffered + new) values is done by k_digest_merge
+					const uint32_t at = atomicAdd(p.merge_count, 1u);
+					MergeEnt e;
+					e.slot = slot;
+					e.m = m;
+					e.off_end = ke;
+					e.pad = 0;
+					p.merge_list[at] = e;
 				}
 			} else if (lane >= 32u && lane < 48u) {
 				const uint32_t bits = s_bm[lane - 32u];
@@ -693,26 +662,40 @@ __global__ __launch_bounds__(256) void k_digest_wave(DigestP p)
 	}
 }
 
-// One 64-thread workgroup (= one wave) per key, grid-stride over keys.  Exact-integer k-bucket merge (DESIGN.md "t-digest"):
-//   merged order = by mean, old clusters before new values on ties; item with weighted mid-point mid2/2 of N goes to
-//   cluster #{j : mid2 >= T_j}, T_j = ceil(BND[j] * 2N / 2^32).
-__global__ __launch_bounds__(64) void k_digest_small(DigestP p)
+// ---- k_digest_merge: one 64-thread workgroup (= one wave) per merge-list entry.  Exact-integer k-bucket merge (DESIGN.md "t-digest"):
+//   values = the key's buffered values + the batch's new values; merged order = by mean, old clusters before values on ties; an item
+//   with weighted mid-point mid2/2 of N goes to cluster #{j : mid2 >= T_j}, T_j = ceil(BND[j] * 2N / 2^32).
+// query mode (out_sum != nullptr): entry w writes the merged view of its key to out_sum/out_cnt[w*100..] and leaves the state alone.
+#define GYS_MERGE_MAX (GYS_TD_PEND_CAP + GYS_SMALL_MAX)
+#define GYS_MERGE_LDS 2048u // power of two >= GYS_MERGE_MAX
+
+struct MergeP {
+	DigestP d;
+	const MergeEnt *list;
+	const uint32_t *count;
+	int64_t *out_sum;
+	uint32_t *out_cnt;
+};
+
+__global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 {
-	__shared__ int32_t s_val[GYS_SMALL_MAX];
+	const DigestP &p = q.d;
+	__shared__ int32_t s_val[GYS_MERGE_LDS];
 	__shared__ int64_t s_csum[GYS_TD_NB];  // compacted non-empty old clusters
 	__shared__ uint32_t s_ccnt[GYS_TD_NB];
 	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
 	__shared__ uint64_t s_T[GYS_TD_NB];    // s_T[j], j = 1..NB-1
 	__shared__ unsigned long long s_osum[GYS_TD_NB];
 	__shared__ uint32_t s_ocnt[GYS_TD_NB];
-	__shared__ unsigned long long s_h[32];
-	__shared__ uint32_t s_bm[16];
 	const uint32_t lane = threadIdx.x;
+	const uint32_t nent = *q.count;
 
-	for (uint32_t slot = blockIdx.x; slot < p.nsvc; slot += gridDim.x) {
-		const uint32_t m = p.batch_cnt[slot];
-		if (m <= GYS_WAVE_MAX || m > GYS_SMALL_MAX) continue; // uniform per block
-		const uint32_t start = p.off_end[slot] - m;
+	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
+		const MergeEnt ent = q.list[w];
+		const uint32_t slot = ent.slot;
+		const uint32_t npend = p.td_meta[slot].npend;
+		const uint32_t m = npend + ent.m;
+		const uint32_t start = ent.off_end - ent.m;
 
 		// ---- old digest: entries lane, lane+64
 		const int64_t *gs = p.td_sum + (size_t)slot * GYS_TD_NB;
@@ -741,10 +724,18 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 			s_cpfx[pos] = e1;
 		}
 		if (lane == 0) s_cpfx[nc] = nold;
-		// ---- new values -> LDS, padded to a power of two with +inf, bitonic sort by the wave
+		// ---- values (buffered, then new) -> LDS, padded to a power of two with +inf, bitonic sort by the wave
 		uint32_t P = 64;
 		while (P < m) P <<= 1;
-		for (uint32_t i = lane; i < P; i += 64u) s_val[i] = i < m ? (int32_t)p.staged[start + i] : INT32_MAX;
+		{
+			const uint32_t *pend = p.td_pend + (size_t)slot * GYS_TD_PEND_CAP;
+			for (uint32_t i = lane; i < P; i += 64u) {
+				int32_t v = INT32_MAX;
+				if (i < npend) v = (int32_t)pend[i];
+				else if (i < m) v = (int32_t)(p.staged[start + (i - npend)] >> GYS_ROW_BITS);
+				s_val[i] = v;
+			}
+		}
 		const uint64_t twoN = 2ull * (nold + (uint64_t)m);
 		if (lane >= 1 && lane < GYS_TD_NB) s_T[lane] = td_threshold(c_td_bnd[lane], twoN);
 		if (j1 < GYS_TD_NB) s_T[j1] = td_threshold(c_td_bnd[j1], twoN);
@@ -754,8 +745,6 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 			s_osum[j1] = 0;
 			s_ocnt[j1] = 0;
 		}
-		if (lane < 32u) s_h[lane] = 0;
-		if (lane < 16u) s_bm[lane] = 0;
 		__syncthreads();
 		for (uint32_t k = 2; k <= P; k <<= 1) {
 			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -773,64 +762,45 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 				__syncthreads();
 			}
 		}
-		// ---- old clusters: W = weight of old clusters before + #{new values strictly below the cluster mean}
+		// ---- old clusters: W = weight of old clusters before + #{values strictly below the cluster mean}
 		for (uint32_t c = lane; c < nc; c += 64u) {
 			const int64_t cs = s_csum[c];
 			const uint32_t cc = s_ccnt[c];
 			uint32_t lo = 0, hi = m; // first index with v * cc >= cs
 			while (lo < hi) {
 				const uint32_t mid = (lo + hi) >> 1;
-				if ((int64_t)(s_val[mid] >> GYS_ROW_BITS) * (int64_t)cc < cs) lo = mid + 1; else hi = mid;
+				if ((int64_t)s_val[mid] * (int64_t)cc < cs) lo = mid + 1; else hi = mid;
 			}
 			const uint64_t mid2 = 2ull * (s_cpfx[c] + (uint64_t)lo) + (uint64_t)cc;
-			uint32_t a = 0, bb = GYS_TD_NB - 1; // cluster = max j with (j == 0 or mid2 >= T_j)
-			while (a < bb) {
-				const uint32_t mid = (a + bb + 1) >> 1;
-				if (mid2 >= s_T[mid]) a = mid; else bb = mid - 1;
-			}
+			const uint32_t a = td_cluster_of(s_T, mid2);
 			atomicAdd(&s_osum[a], (unsigned long long)cs);
 			atomicAdd(&s_ocnt[a], cc);
 		}
-		// ---- new values: W = rank among new values + weight of old clusters with mean <= v
+		// ---- values: W = rank among the values + weight of old clusters with mean <= v
 		for (uint32_t r = lane; r < m; r += 64u) {
-			const int32_t w = s_val[r]; // sorted staged words: value << 5 | CONN_BITMAP row
-			const int64_t v = (int64_t)(w >> GYS_ROW_BITS);
+			const int64_t v = (int64_t)s_val[r];
 			uint32_t lo = 0, hi = nc; // first cluster with mean > v  (csum > v * ccnt)
 			while (lo < hi) {
 				const uint32_t mid = (lo + hi) >> 1;
 				if (s_csum[mid] <= v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
 			}
 			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[lo]) + 1ull;
-			uint32_t a = 0, bb = GYS_TD_NB - 1;
-			while (a < bb) {
-				const uint32_t mid = (a + bb + 1) >> 1;
-				if (mid2 >= s_T[mid]) a = mid; else bb = mid - 1;
-			}
+			const uint32_t a = td_cluster_of(s_T, mid2);
 			atomicAdd(&s_osum[a], (unsigned long long)v);
 			atomicAdd(&s_ocnt[a], 1u);
-			const uint32_t b = resp_bucket(v);
-			atomicAdd(&s_h[2 * b], 1ull);
-			atomicAdd(&s_h[2 * b + 1], (unsigned long long)v);
-			bitmap_set_lds(s_bm, (uint32_t)w, b);
 		}
 		__syncthreads();
-		key_epilogue(p, slot, m, s_val[m - 1] >> GYS_ROW_BITS, s_h, s_bm, lane);
 		// ---- write back
-		int64_t *ws = p.td_sum + (size_t)slot * GYS_TD_NB;
-		uint32_t *wc = p.td_cnt + (size_t)slot * GYS_TD_NB;
+		const bool query = q.out_sum != nullptr;
+		int64_t *ws = query ? q.out_sum + (size_t)w * GYS_TD_NB : p.td_sum + (size_t)slot * GYS_TD_NB;
+		uint32_t *wc = query ? q.out_cnt + (size_t)w * GYS_TD_NB : p.td_cnt + (size_t)slot * GYS_TD_NB;
 		ws[lane] = (int64_t)s_osum[lane];
 		wc[lane] = s_ocnt[lane];
 		if (j1 < GYS_TD_NB) {
 			ws[j1] = (int64_t)s_osum[j1];
 			wc[j1] = s_ocnt[j1];
 		}
-		if (lane == 0) {
-			int32_t *mm = p.td_minmax + (size_t)slot * 2;
-			const int32_t vmin = s_val[0] >> GYS_ROW_BITS, vmax = s_val[m - 1] >> GYS_ROW_BITS;
-			if (vmin < mm[0]) mm[0] = vmin;
-			if (vmax > mm[1]) mm[1] = vmax;
-			p.batch_cnt[slot] = 0;
-		}
+		if (lane == 0 && !query) p.td_meta[slot].npend = 0;
 		__syncthreads();
 	}
 }
@@ -838,7 +808,7 @@ __global__ __launch_bounds__(64) void k_digest_small(DigestP p)
 // ---------------------------------------------------------------------------------------------------- t-digest merge (huge)
 // One 256-thread workgroup per huge key (persistent over the work list).  Each workgroup owns a 2^20-bin u32 count array in HBM
 // scratch: values are histogrammed exactly, the bins are prefix-scanned, and every bin's rank interval is intersected with the
-// cluster rank intervals -- the same exact-integer assignment as digest_small without materialising a sort.
+// cluster rank intervals -- the same exact-integer assignment as k_digest_merge without materialising a sort.
 struct HugeP {
 	DigestP d;
 	const uint32_t *huge_list;
@@ -868,6 +838,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 		const uint32_t slot = p.huge_list[w];
 		const uint32_t m = p.d.batch_cnt[slot];
 		const uint32_t start = p.d.off_end[slot] - m;
+		const uint32_t npend = p.d.td_meta[slot].npend; // buffered values join the merge (npend + m > CAP always holds here)
 		// zero the bins (16-byte stores)
 		for (uint32_t i = threadIdx.x; i < GYS_HUGE_BINS / 4u; i += 256u) ((uint4 *)bins)[i] = make_uint4(0, 0, 0, 0);
 		if (threadIdx.x < GYS_TD_NB) {
@@ -899,7 +870,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 		__syncthreads();
 		const uint32_t nc = s_nc;
 		const uint64_t nold = s_cpfx[nc];
-		const uint64_t twoN = 2ull * (nold + (uint64_t)m);
+		const uint64_t twoN = 2ull * (nold + (uint64_t)m + (uint64_t)npend);
 		if (threadIdx.x >= 1 && threadIdx.x < GYS_TD_NB) s_T[threadIdx.x] = td_threshold(c_td_bnd[threadIdx.x], twoN);
 		if (threadIdx.x == 0) s_T[GYS_TD_NB] = ~0ull;
 		// exact value histogram
@@ -919,6 +890,8 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 			}
 			atomicMin(&s_min, lmin);
 			atomicMax(&s_max, lmax);
+			for (uint32_t i = threadIdx.x; i < npend; i += 256u)
+				atomicAdd(&bins[p.d.td_pend[(size_t)slot * GYS_TD_PEND_CAP + i] & (GYS_HUGE_BINS - 1u)], 1u);
 		}
 		__syncthreads();
 		// the atomics above were performed in L2; drop this CU's L1 copies of the bins before reading them with plain loads
@@ -1003,15 +976,24 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 			}
 		}
 		__syncthreads();
+		// the value counts included the buffered values: their histogram contribution was already applied when they were appended
+		for (uint32_t i = threadIdx.x; i < npend; i += 256u) {
+			const uint64_t pv = (uint64_t)(p.d.td_pend[(size_t)slot * GYS_TD_PEND_CAP + i] & (GYS_HUGE_BINS - 1u));
+			const uint32_t hb = resp_bucket((int64_t)pv);
+			atomicAdd(&s_h[2 * hb], ~0ull);          // -1
+			atomicAdd(&s_h[2 * hb + 1], 0ull - pv);  // -value
+		}
+		__syncthreads();
 		if (threadIdx.x < GYS_TD_NB) {
 			p.d.td_sum[(size_t)slot * GYS_TD_NB + threadIdx.x] = (int64_t)s_osum[threadIdx.x];
 			p.d.td_cnt[(size_t)slot * GYS_TD_NB + threadIdx.x] = (uint32_t)s_ocnt[threadIdx.x];
 		}
 		if (threadIdx.x >= 128u && threadIdx.x < 164u) key_epilogue(p.d, slot, m, s_max, s_h, s_bm, threadIdx.x - 128u);
 		if (threadIdx.x == 0) {
-			int32_t *mm = p.d.td_minmax + (size_t)slot * 2;
-			if (s_min < mm[0]) mm[0] = s_min;
-			if (s_max > mm[1]) mm[1] = s_max;
+			TdMeta *mt = &p.d.td_meta[slot];
+			if (s_min < mt->vmin) mt->vmin = s_min;
+			if (s_max > mt->vmax) mt->vmax = s_max;
+			mt->npend = 0;
 			p.d.batch_cnt[slot] = 0;
 		}
 		__syncthreads();

@@ -259,6 +259,17 @@ class SketchEngine:
         capi.check(self.L.gys_export_tdigest(self.h, first, n, C.c_void_p(sums.ctypes.data), C.c_void_p(cnts.ctypes.data), C.c_void_p(mm.ctypes.data)))
         return sums, cnts, mm
 
+    def export_tdigest_pending(self, first=0, n=None):
+        """(npend [n], pend [n][CAP]): each row's live prefix sorted ascending, the rest -1 (the buffer itself is unordered)"""
+        n = self.num_services() - first if n is None else n
+        npend = np.zeros(n, dtype=np.uint32)
+        pend = np.zeros((n, capi.TD_PEND_CAP), dtype=np.int32)
+        capi.check(self.L.gys_export_tdigest_pending(self.h, first, n, C.c_void_p(npend.ctypes.data), C.c_void_p(pend.ctypes.data)))
+        out = np.full_like(pend, -1)
+        for i in range(n):
+            out[i, :npend[i]] = np.sort(pend[i, :npend[i]])
+        return npend, out
+
     def export_svc_counters(self, first=0, n=None):
         n = self.num_services() - first if n is None else n
         out = np.zeros((n, 4), dtype=np.uint64)

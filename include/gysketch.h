@@ -54,6 +54,7 @@ enum {
 
 #define GYS_MAX_BUCKETS 16 /* all reference hash classes have <= 15 buckets; records are padded to 16 slots */
 #define GYS_TD_NB 100      /* t-digest clusters per key (delta = 100, common/gy_query_common.cc:1855) */
+#define GYS_TD_PEND_CAP 256 /* values a key's t-digest buffers before it is re-clustered (== GYS_TDIGEST_PEND_CAP) */
 #define GYS_HLL_P 14       /* global distinct-flow HLL precision: 16384 u8 registers */
 #define GYS_CMS_D 4
 #define GYS_CMS_W 65536
@@ -238,6 +239,9 @@ int gys_export_hll(gys_ctx *ctx, uint8_t *out /* [1 << GYS_HLL_P] */);
 int gys_export_cms(gys_ctx *ctx, int which, void *out /* which 0: u32[D*W]; which 1: i64[D*W] */);
 int gys_export_tdigest(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, int64_t *sums /* [nslots*100] */, uint32_t *cnts /* [nslots*100] */,
 		       int32_t *minmax /* [nslots*2] */);
+/* values a service's t-digest still buffers unmerged (unordered; only the first npend[i] entries of row i are meaningful) */
+int gys_export_tdigest_pending(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint32_t *npend /* [nslots] */,
+			       int32_t *pend /* [nslots*GYS_TD_PEND_CAP] */);
 int gys_export_svc_counters(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint64_t *out /* [nslots*4]: nconn, nclose, bytes_sent, bytes_rcvd */);
 int gys_export_global_hist(gys_ctx *ctx, gys_hist_rec *out); /* all-service response histogram of the last finished window (all ranks) */
 int gys_export_svc_hll(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint8_t *out /* [nslots << svc_hll_p] */);

@@ -6,6 +6,7 @@
 
 #include <limits.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 /* ================================================================ hashing */
@@ -667,7 +668,7 @@ void gyo_td_merge_digest(gyo_tdigest *d, const gyo_tdigest *o)
 
 /* Quantile by linear interpolation between cluster centres (centre of cluster k at cumulative weight W_{k-1} + cnt_k/2),
  * clamped to [vmin, vmax] at the ends.  Only + - * / on doubles (IEEE exact, no contraction) so CPU and GPU agree bit-for-bit. */
-double gyo_td_quantile(const gyo_tdigest *d, double q)
+static double td_quantile_interp(const gyo_tdigest *d, double q)
 {
 	const uint64_t N = gyo_td_total(d);
 	double t, wbefore = 0.0, prev_c = 0.0, prev_mean = 0.0;
@@ -702,6 +703,56 @@ double gyo_td_quantile(const gyo_tdigest *d, double q)
 		if (span <= 0.0) return hi;
 		return prev_mean + (hi - prev_mean) * ((t - prev_c) / span);
 	}
+}
+
+/* The values are integer milliseconds (tresp_msec, gy_socket_stat.cc:1519): the reported quantile is the interpolated value rounded
+ * half-up to the value domain, so that it can be ranked against the data without landing between two neighbouring integers. */
+double gyo_td_quantile(const gyo_tdigest *d, double q) { return floor(td_quantile_interp(d, q) + 0.5); }
+
+/* ---- buffered form (see gy_oracle.h) */
+#if GYO_TD_PEND_CAP != GYS_TDIGEST_PEND_CAP
+#error "GYO_TD_PEND_CAP must equal the shared constant GYS_TDIGEST_PEND_CAP"
+#endif
+
+void gyo_tdb_init(gyo_td_buffered *b)
+{
+	memset(b, 0, sizeof(*b));
+	gyo_td_init(&b->d);
+}
+
+uint64_t gyo_tdb_total(const gyo_td_buffered *b) { return gyo_td_total(&b->d) + b->npend; }
+
+void gyo_tdb_add_batch(gyo_td_buffered *b, const int32_t *vals, size_t m)
+{
+	if (!m) return;
+	if ((size_t)b->npend + m <= GYO_TD_PEND_CAP) {
+		for (size_t i = 0; i < m; i++) {
+			b->pend[b->npend + i] = vals[i];
+			if (vals[i] < b->d.vmin) b->d.vmin = vals[i];
+			if (vals[i] > b->d.vmax) b->d.vmax = vals[i];
+		}
+		b->npend += (uint32_t)m;
+	} else {
+		int32_t *all = (int32_t *)malloc(((size_t)b->npend + m) * sizeof(int32_t));
+		memcpy(all, b->pend, (size_t)b->npend * sizeof(int32_t));
+		memcpy(all + b->npend, vals, m * sizeof(int32_t));
+		gyo_td_merge_values(&b->d, all, (size_t)b->npend + m);
+		b->npend = 0;
+		free(all);
+	}
+}
+
+void gyo_tdb_merged_view(const gyo_td_buffered *b, gyo_tdigest *out)
+{
+	*out = b->d;
+	if (b->npend) gyo_td_merge_values(out, b->pend, b->npend);
+}
+
+double gyo_tdb_quantile(const gyo_td_buffered *b, double q)
+{
+	gyo_tdigest t;
+	gyo_tdb_merged_view(b, &t);
+	return gyo_td_quantile(&t, q);
 }
 
 /* ================================================================ wire records + roll-ups */

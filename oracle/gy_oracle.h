@@ -141,6 +141,22 @@ void gyo_td_merge_values(gyo_tdigest *d, const int32_t *vals, size_t m);
 void gyo_td_merge_digest(gyo_tdigest *d, const gyo_tdigest *o);
 double gyo_td_quantile(const gyo_tdigest *d, double q);
 
+/* Buffered form the engine keeps per service (the classic merging-digest buffer): up to GYO_TD_PEND_CAP values wait unmerged;
+ * a batch that would overflow the buffer re-clusters the digest with (buffered + new) values in ONE merge.  The result depends
+ * only on the sequence of batch multisets, not on the order of values inside a batch.  vmin / vmax always cover buffered values. */
+#define GYO_TD_PEND_CAP 256
+typedef struct {
+	gyo_tdigest d;
+	uint32_t npend;
+	int32_t pend[GYO_TD_PEND_CAP];
+} gyo_td_buffered;
+
+void gyo_tdb_init(gyo_td_buffered *b);
+uint64_t gyo_tdb_total(const gyo_td_buffered *b);       /* merged + buffered */
+void gyo_tdb_add_batch(gyo_td_buffered *b, const int32_t *vals, size_t m);
+void gyo_tdb_merged_view(const gyo_td_buffered *b, gyo_tdigest *out); /* digest with the buffer merged in; b is not modified */
+double gyo_tdb_quantile(const gyo_td_buffered *b, double q);         /* = gyo_td_quantile(merged view) */
+
 /* ---------------------------------------------------------------- wire records + roll-ups */
 #define GYO_TCP_CONN_NOTIFY_SZ 280
 #define GYO_LISTENER_STATE_NOTIFY_SZ 88

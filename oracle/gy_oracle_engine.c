@@ -25,7 +25,7 @@ typedef struct gyo_engine {
 	uint32_t *cms;         /* [D*W] */
 	gyo_hist_serial ghist[16];
 	int64_t gmax;
-	gyo_tdigest *td;
+	gyo_td_buffered *td;
 	/* per-batch staging for the digest: values bucketed by key (counting sort) */
 	uint32_t *bcnt, *boff;
 	uint64_t counters[4]; /* events, dropped_range, dropped_nolistener, accepted */
@@ -51,8 +51,8 @@ gyo_engine *gyo_engine_new(uint32_t max_services, int enable_td)
 	e->gmax = LONG_MIN;
 	for (uint32_t s = 0; s < max_services; s++) e->hist[(size_t)s * 16 + 15].sum = LONG_MIN;
 	if (enable_td) {
-		e->td = (gyo_tdigest *)malloc((size_t)max_services * sizeof(gyo_tdigest));
-		for (uint32_t s = 0; s < max_services; s++) gyo_td_init(&e->td[s]);
+		e->td = (gyo_td_buffered *)malloc((size_t)max_services * sizeof(gyo_td_buffered));
+		for (uint32_t s = 0; s < max_services; s++) gyo_tdb_init(&e->td[s]);
 		e->bcnt = (uint32_t *)calloc(max_services, 4);
 		e->boff = (uint32_t *)calloc((size_t)max_services + 1, 4);
 	}
@@ -158,7 +158,7 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 		}
 	}
 	if (e->enable_td) {
-		/* digest(key) <- merge(digest(key), multiset of this batch's values of the key) */
+		/* buffered digest(key) <- add_batch(multiset of this batch's values of the key): append, or one merge of buffer + batch */
 		int32_t *staged = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
 		uint32_t run = 0;
 		for (uint32_t s = 0; s < e->nsvc; s++) {
@@ -170,7 +170,7 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 			if (slot_of[i] != 0xFFFFFFFFu) staged[e->boff[slot_of[i]]++] = val_of[i];
 		run = 0;
 		for (uint32_t s = 0; s < e->nsvc; s++) {
-			if (e->bcnt[s]) gyo_td_merge_values(&e->td[s], staged + run, e->bcnt[s]);
+			if (e->bcnt[s]) gyo_tdb_add_batch(&e->td[s], staged + run, e->bcnt[s]);
 			run += e->bcnt[s];
 		}
 		free(staged);
@@ -214,7 +214,7 @@ const uint8_t *gyo_engine_hll(const gyo_engine *e) { return e->hll; }
 const uint32_t *gyo_engine_cms(const gyo_engine *e) { return e->cms; }
 const gyo_hist_serial *gyo_engine_ghist(const gyo_engine *e) { return e->ghist; }
 int64_t gyo_engine_gmax(const gyo_engine *e) { return e->gmax; }
-const gyo_tdigest *gyo_engine_td(const gyo_engine *e, uint32_t slot) { return &e->td[slot]; }
+const gyo_td_buffered *gyo_engine_td(const gyo_engine *e, uint32_t slot) { return &e->td[slot]; }
 const uint64_t *gyo_engine_counters(const gyo_engine *e) { return e->counters; }
 /* window roll: clear the windowed sketches (CONN_BITMAP secs_to_reset_ = 5; HLL/CMS are per window) keeping histograms/digests */
 void gyo_engine_window_clear(gyo_engine *e, int clear_hist)

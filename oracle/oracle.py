@@ -59,6 +59,13 @@ class TDigest(C.Structure):
     _fields_ = [("sum", C.c_int64 * TD_NB), ("cnt", C.c_uint32 * TD_NB), ("vmin", C.c_int32), ("vmax", C.c_int32)]
 
 
+TD_PEND_CAP = 256
+
+
+class TDBuffered(C.Structure):
+    _fields_ = [("d", TDigest), ("npend", C.c_uint32), ("pend", C.c_int32 * TD_PEND_CAP)]
+
+
 class ListenSummStats(C.Structure):
     _fields_ = [("nstates", C.c_int32 * 6), ("tot_qps", C.c_int32), ("tot_act_conn", C.c_int32),
                 ("tot_kb_inbound", C.c_int32), ("tot_kb_outbound", C.c_int32), ("tot_ser_errors", C.c_int32),
@@ -135,6 +142,11 @@ def lib():
     _sig(L, "gyo_td_merge_values", None, [C.POINTER(TDigest), i32p, C.c_size_t])
     _sig(L, "gyo_td_merge_digest", None, [C.POINTER(TDigest), C.POINTER(TDigest)])
     _sig(L, "gyo_td_quantile", C.c_double, [C.POINTER(TDigest), C.c_double])
+    _sig(L, "gyo_tdb_init", None, [C.POINTER(TDBuffered)])
+    _sig(L, "gyo_tdb_total", C.c_uint64, [C.POINTER(TDBuffered)])
+    _sig(L, "gyo_tdb_add_batch", None, [C.POINTER(TDBuffered), i32p, C.c_size_t])
+    _sig(L, "gyo_tdb_merged_view", None, [C.POINTER(TDBuffered), C.POINTER(TDigest)])
+    _sig(L, "gyo_tdb_quantile", C.c_double, [C.POINTER(TDBuffered), C.c_double])
     _sig(L, "gyo_listener_state_rollup", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(ListenSummStats), C.POINTER(C.c_int)])
     _sig(L, "gyo_listener_state_elem_size", C.c_uint32, [C.c_void_p])
     _sig(L, "gyo_tcp_conn_elem_size", C.c_uint32, [C.c_void_p])
@@ -154,7 +166,7 @@ def lib():
     _sig(L, "gyo_engine_cms", C.c_void_p, [C.c_void_p])
     _sig(L, "gyo_engine_ghist", C.c_void_p, [C.c_void_p])
     _sig(L, "gyo_engine_gmax", C.c_int64, [C.c_void_p])
-    _sig(L, "gyo_engine_td", C.POINTER(TDigest), [C.c_void_p, C.c_uint32])
+    _sig(L, "gyo_engine_td", C.POINTER(TDBuffered), [C.c_void_p, C.c_uint32])
     _sig(L, "gyo_engine_counters", u64p, [C.c_void_p])
     _sig(L, "gyo_engine_window_clear", None, [C.c_void_p, C.c_int])
     _lib = L
@@ -321,16 +333,28 @@ class OracleEngine:
         return self.L.gyo_engine_td(self.h, slot).contents
 
     def td_arrays(self):
+        """merged clusters + min/max of every service: (sums [n][100], cnts [n][100], minmax [n][2])"""
         n = self.nsvc
         sums = np.zeros((n, TD_NB), dtype=np.int64)
         cnts = np.zeros((n, TD_NB), dtype=np.uint32)
         mm = np.zeros((n, 2), dtype=np.int32)
         for s in range(n):
-            d = self.td(s)
+            d = self.td(s).d
             sums[s] = np.frombuffer(d.sum, dtype=np.int64)
             cnts[s] = np.frombuffer(d.cnt, dtype=np.uint32)
             mm[s] = (d.vmin, d.vmax)
         return sums, cnts, mm
+
+    def td_pending(self):
+        """buffered (unmerged) values of every service, each row sorted ascending and padded with -1: (npend [n], pend [n][CAP])"""
+        n = self.nsvc
+        npend = np.zeros(n, dtype=np.uint32)
+        pend = np.full((n, TD_PEND_CAP), -1, dtype=np.int32)
+        for s in range(n):
+            b = self.td(s)
+            npend[s] = b.npend
+            pend[s, :b.npend] = np.sort(np.frombuffer(b.pend, dtype=np.int32)[:b.npend])
+        return npend, pend
 
     def counters(self):
         c = self.L.gyo_engine_counters(self.h)

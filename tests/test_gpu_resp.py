@@ -34,6 +34,10 @@ def _compare_all(eng, orc, oracle, check_td=True):
         assert (gc == oc).all(), f"digest counts differ at {np.argwhere(gc != oc)[:4].tolist()}"
         assert (gs == os_).all()
         assert (gm == om).all()
+        gn, gp = eng.export_tdigest_pending(0, nsvc)  # buffered values (compared as sorted multisets)
+        on, op = orc.td_pending()
+        assert (gn == on).all(), f"buffer fill differs at {np.argwhere(gn != on)[:4].tolist()}"
+        assert (gp == op).all()
 
 
 def _compare_window(eng, orc):
@@ -91,7 +95,7 @@ def test_resp_small_hosts_edge_cases(torch_mod, oracle, resp_path):
             assert np.float32(avg).tobytes() == np.float32(oavg).tobytes()
             qs = [0.0, 0.01, 0.25, 0.5, 0.9, 0.99, 1.0]
             gq = eng.quantiles(g, qs)
-            oq = [oracle.lib().gyo_td_quantile(C.byref(orc.td(slot)), q) for q in qs]
+            oq = [oracle.lib().gyo_tdb_quantile(C.byref(orc.td(slot)), q) for q in qs]
             assert gq == oq
     # window close: HLL / CMS / global histogram registers bit exact; histograms fold into the all-time set
     eng.window_close()
@@ -170,7 +174,7 @@ def test_resp_huge_key_batches(torch_mod, oracle, resp_path):
     for s in range(3):
         g = int(gids[0][s])
         qs = [0.001, 0.5, 0.999]
-        assert eng.quantiles(g, qs) == [oracle.lib().gyo_td_quantile(C.byref(orc.td(s)), q) for q in qs]
+        assert eng.quantiles(g, qs) == [oracle.lib().gyo_tdb_quantile(C.byref(orc.td(s)), q) for q in qs]
     eng.close()
 
 
@@ -257,6 +261,38 @@ def test_resp_hostlocal_incremental_registration_and_fallbacks(torch_mod, oracle
     c2 = eng.counters()
     assert c2["resp_batches_general"] == 1
     _compare_all(eng, orc, oracle)
+    eng.window_close()
+    _compare_window(eng, orc)
+    eng.close()
+
+
+@PATHS
+def test_resp_buffer_fill_and_merge_cycles(torch_mod, oracle, resp_path):
+    """many small batches per key: the t-digest buffer fills (append), overflows (one merge of buffer + batch) and refills; batch
+    sizes straddle the buffer capacity, the 64-lane chunk size of the per-key pass and the merge kernel's sort sizes"""
+    rng = np.random.default_rng(21)
+    nh, sp = 2, 6
+    eng = _engine(max_hosts=2, max_services=16, max_batch_events=1 << 16, resp_path=resp_path)
+    orc = oracle.OracleEngine(16)
+    info, gids = helpers.register_world(eng, orc, range(nh), sp)
+    sizes = [5, 40, 64, 65, 130, 255, 256, 257, 1, 700, 1024 * sp, 300, 3, 511, 9, 9, 9, 2000, 77]
+    for rnd, n in enumerate(sizes):
+        for h in range(nh):
+            ev = helpers.make_resp_events(rng, h, n, sp if rnd % 3 else 1, lat_mu=2.0 + 0.2 * rnd, bad_frac=0.01, unknown_frac=0.01)
+            eng.handle_resp_events(info[h][0], ev)
+            orc.resp_batch(ev.tobytes(), [info[h][1]], [0])
+        if rnd % 5 == 4:
+            eng.sync()
+            _compare_all(eng, orc, oracle)
+            for h in range(nh):
+                g = int(gids[h][0])
+                qs = [0.0, 0.1, 0.5, 0.95, 1.0]
+                assert eng.quantiles(g, qs) == [oracle.lib().gyo_tdb_quantile(C.byref(orc.td(eng.lookup(g))), q) for q in qs]
+    eng.sync()
+    _compare_all(eng, orc, oracle)
+    _assert_path(eng, resp_path)
+    npend, _ = eng.export_tdigest_pending(0, orc.nsvc)
+    assert npend.max() <= 256
     eng.window_close()
     _compare_window(eng, orc)
     eng.close()

@@ -138,3 +138,43 @@ def test_conn_bitmap(oracle):
     out = np.zeros(15, dtype=np.uint8)
     L.gyo_conn_bitmap_breakup(oracle.ptr(m, oracle.u16p), oracle.ptr(out, oracle.u8p))
     assert out[3] == 2 and out[7] == 1 and out[14] == 1 and out.sum() == 4  # ports 16000 and 16032 share slot 0
+
+
+def test_tdigest_buffered_form(oracle):
+    """the per-service form: values wait in a 256-entry buffer and are merged in one step when a batch no longer fits;
+    quantiles come from the merged view (digest + buffer) and keep the 1 % rank bound for every batching of the same stream"""
+    L = oracle.lib()
+    rng = np.random.default_rng(77)
+    x = np.minimum(np.floor(rng.lognormal(3.0, 1.5, 30000)), 1e6).astype(np.int32)
+    xs = np.sort(x)
+    for batch in (1, 7, 27, 100, 256, 257, 5000):
+        b = oracle.TDBuffered()
+        L.gyo_tdb_init(C.byref(b))
+        fills = []
+        for i in range(0, len(x), batch):
+            c = np.ascontiguousarray(x[i:i + batch])
+            L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c, oracle.i32p), len(c))
+            fills.append(b.npend)
+        assert L.gyo_tdb_total(C.byref(b)) == len(x) and max(fills) <= oracle.TD_PEND_CAP
+        assert b.d.vmin == xs[0] and b.d.vmax == xs[-1]
+        view = oracle.TDigest()
+        L.gyo_tdb_merged_view(C.byref(b), C.byref(view))
+        assert L.gyo_td_total(C.byref(view)) == len(x) and sum(view.sum) == int(x.astype(np.int64).sum())
+        for q in (0.01, 0.25, 0.5, 0.9, 0.99, 0.999):
+            v = L.gyo_tdb_quantile(C.byref(b), q)
+            assert v == L.gyo_td_quantile(C.byref(view), q)
+            assert _rank_err(xs, v, q) <= 0.01, (batch, q)
+    # a batch that fits is only appended: the clusters do not change and the order inside the batch is irrelevant after sorting
+    b = oracle.TDBuffered()
+    L.gyo_tdb_init(C.byref(b))
+    c = np.ascontiguousarray(x[:200])
+    L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c, oracle.i32p), 200)
+    assert b.npend == 200 and L.gyo_td_total(C.byref(b.d)) == 0
+    c2 = np.ascontiguousarray(x[200:260])
+    L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c2, oracle.i32p), 60)  # 260 > 256: one merge of all 260 values
+    assert b.npend == 0 and L.gyo_td_total(C.byref(b.d)) == 260
+    d = oracle.TDigest()
+    L.gyo_td_init(C.byref(d))
+    allv = np.ascontiguousarray(x[:260][::-1])
+    L.gyo_td_merge_values(C.byref(d), oracle.ptr(allv, oracle.i32p), 260)
+    assert list(d.cnt) == list(b.d.cnt) and list(d.sum) == list(b.d.sum)
