@@ -526,47 +526,45 @@ __device__ __forceinline__ void wave_excl_scan_2x(uint64_t a0, uint64_t a1, uint
 	*total = tot0 + tot1;
 }
 
-// ---- k_key_pass: every key with 1..GYS_SMALL_MAX new values.  One WAVE per key, 4 independent waves per workgroup, no workgroup
-// barriers.  A wave walks a chunk of 64 consecutive keys: the chunk's counts / offsets come from ONE coalesced load (then readlane),
-// and the next key's first 64 staged words, histogram record, glob_id, meta and bitmap words are prefetched into registers while
-// the current key is processed, so the per-key critical path holds no dependent HBM round trip.
+// ---- k_key_pass: every key with 1..GYS_SMALL_MAX new values.  FOUR keys per wave: each 16-lane row owns one key -- lane g of the
+// row holds the key's histogram pair g (16 x {count,sum} = the 256-byte record, one coalesced 256-B access per row), its CONN_BITMAP
+// word g, and value g of every 16-value group.  A wave walks a chunk of 64 consecutive keys in 16 rounds of 4 keys: the chunk's
+// counts / offsets come from ONE coalesced load (then bpermute), and the next round's record / bitmap / meta / first 32 staged words
+// are prefetched into registers while the current round is processed, so the per-key critical path holds no dependent HBM round
+// trip.  No workgroup barriers (rows talk through per-row LDS accumulators).  Keys whose buffer would overflow are queued for
+// k_digest_merge with one aggregated atomic per chunk.
 struct KeyRegs {
-	uint32_t w;        // staged word of this lane (first 64 values of the key)
-	uint64_t hc, hs;   // lanes 0..15: the 16-byte pair `lane` of the key's histogram record
-	uint64_t aux, aux2; // lanes 16..19: glob_id; lane 20: TdMeta {vmin,vmax | npend,pad}; lanes 32..47: CONN_BITMAP word lane-32
+	uint32_t w0, w1;  // staged words g and 16 + g of the key
+	uint4 pair;       // histogram pair g: {count lo, count hi, sum lo, sum hi}
+	uint32_t bm;      // CONN_BITMAP word g
+	uint4 meta;       // TdMeta of the key (same for the 16 lanes of the row)
+	uint64_t gid;
 };
 
-__device__ __forceinline__ void key_prefetch(const DigestP &p, uint32_t slot, uint32_t m, uint32_t oend, uint32_t lane, KeyRegs &r)
+__device__ __forceinline__ void key_prefetch(const DigestP &p, uint32_t slot, uint32_t m, uint32_t oend, uint32_t g, KeyRegs &r)
 {
-	r.w = lane < m ? p.staged[oend - m + lane] : 0u;
-	r.hc = 0;
-	r.hs = 0;
-	r.aux = 0;
-	r.aux2 = 0;
-	if (lane < 16u) {
-		const uint64_t *h = (const uint64_t *)&p.hist_win[slot] + 2 * lane;
-		r.hc = h[0];
-		r.hs = h[1];
-	} else if (lane < 20u) {
-		r.aux = p.svc_gid[slot];
-	} else if (lane == 20u) {
-		const uint64_t *mt = (const uint64_t *)&p.td_meta[slot];
-		r.aux = mt[0];
-		r.aux2 = mt[1];
-	} else if (lane >= 32u && lane < 48u) {
-		r.aux = (uint64_t)p.bitmap[(size_t)slot * 16u + (lane - 32u)];
-	}
+	r.w0 = 0;
+	r.w1 = 0;
+	if (m == 0) return; // row idle this round
+	const uint32_t *sv = p.staged + (oend - m);
+	if (g < m) r.w0 = sv[g];
+	if (16u + g < m) r.w1 = sv[16u + g];
+	r.pair = ((const uint4 *)&p.hist_win[slot])[g];
+	r.bm = p.bitmap[(size_t)slot * 16u + g];
+	r.meta = *(const uint4 *)&p.td_meta[slot];
+	r.gid = p.svc_gid[slot];
 }
 
 __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 {
-	__shared__ unsigned long long s_h_[4][32];
-	__shared__ uint32_t s_bm_[4][16];
-	__shared__ int32_t s_mm_[4][2];
+	__shared__ unsigned long long s_h_[16][32];
+	__shared__ uint32_t s_bm_[16][16];
+	__shared__ int32_t s_mm_[16][2];
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-	unsigned long long *s_h = s_h_[wv];
-	uint32_t *s_bm = s_bm_[wv];
-	int32_t *s_mm = s_mm_[wv];
+	const uint32_t row = lane >> 4, g = lane & 15u;
+	unsigned long long *s_h = s_h_[wv * 4u + row];
+	uint32_t *s_bm = s_bm_[wv * 4u + row];
+	int32_t *s_mm = s_mm_[wv * 4u + row];
 	const uint32_t nwaves = gridDim.x * 4u;
 	const uint32_t nchunks = (p.nsvc + 63u) / 64u;
 
@@ -575,37 +573,47 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 		uint32_t mcnt = key < p.nsvc ? p.batch_cnt[key] : 0u;
 		const uint32_t oend = key < p.nsvc ? p.off_end[key] : 0u;
 		if (mcnt > GYS_SMALL_MAX) mcnt = 0; // larger keys belong to k_digest_huge (which also does their histogram / bitmap / CMS)
-		unsigned long long todo = __ballot(mcnt != 0);
+		const unsigned long long todo = __ballot(mcnt != 0);
 		if (!todo) continue;
 		if (mcnt) p.batch_cnt[key] = 0; // consumed (coalesced reset for the whole chunk)
+		uint32_t merge_rounds = 0;      // bit rd: the key this row handled in round rd must be merged
 		KeyRegs cur, nxt;
-		uint32_t i = (uint32_t)__ffsll((long long)todo) - 1u;
-		todo &= todo - 1;
-		key_prefetch(p, chunk * 64u + i, (uint32_t)__shfl((int)mcnt, (int)i, 64), (uint32_t)__shfl((int)oend, (int)i, 64), lane, cur);
+		uint32_t rd = (uint32_t)__ffsll((long long)todo) - 1u;
+		rd >>= 2; // first round with an active key
+		key_prefetch(p, chunk * 64u + rd * 4u + row, (uint32_t)__shfl((int)mcnt, (int)(rd * 4u + row), 64),
+			     (uint32_t)__shfl((int)oend, (int)(rd * 4u + row), 64), g, cur);
 		for (;;) {
-			const uint32_t slot = chunk * 64u + i;
-			const uint32_t m = (uint32_t)__shfl((int)mcnt, (int)i, 64);
-			const uint32_t ke = (uint32_t)__shfl((int)oend, (int)i, 64);
-			uint32_t inext = 64u;
-			if (todo) { // issue the next key's loads now; they are consumed one iteration later
-				inext = (uint32_t)__ffsll((long long)todo) - 1u;
-				todo &= todo - 1;
-				key_prefetch(p, chunk * 64u + inext, (uint32_t)__shfl((int)mcnt, (int)inext, 64), (uint32_t)__shfl((int)oend, (int)inext, 64), lane, nxt);
+			const uint32_t k = rd * 4u + row;
+			const uint32_t slot = chunk * 64u + k;
+			const uint32_t m = (uint32_t)__shfl((int)mcnt, (int)k, 64);
+			const uint32_t ke = (uint32_t)__shfl((int)oend, (int)k, 64);
+			uint32_t rnext = 16u;
+			{
+				const unsigned long long rest = rd < 15u ? (todo >> (4u * (rd + 1u))) : 0ull;
+				if (rest) { // issue the next round's loads now; they are consumed one iteration later
+					rnext = rd + 1u + (((uint32_t)__ffsll((long long)rest) - 1u) >> 2);
+					key_prefetch(p, chunk * 64u + rnext * 4u + row, (uint32_t)__shfl((int)mcnt, (int)(rnext * 4u + row), 64),
+						     (uint32_t)__shfl((int)oend, (int)(rnext * 4u + row), 64), g, nxt);
+				}
 			}
-			const uint32_t npend = (uint32_t)__shfl((int)(uint32_t)cur.aux2, 20, 64);
-			const bool do_merge = npend + m > GYS_TD_PEND_CAP;
-			if (lane < 32u) s_h[lane] = 0;
-			if (lane < 16u) s_bm[lane] = 0;
-			if (lane == 0) {
+			const uint32_t npend = cur.meta.z;
+			const bool do_merge = m != 0 && npend + m > GYS_TD_PEND_CAP;
+			s_h[g] = 0;
+			s_h[16u + g] = 0;
+			s_bm[g] = 0;
+			if (g == 0) {
 				s_mm[0] = INT32_MAX;
 				s_mm[1] = INT32_MIN;
 			}
 			GYS_WAVE_SYNC();
 			uint32_t *pend = p.td_pend + (size_t)slot * GYS_TD_PEND_CAP + npend;
-			for (uint32_t base = 0; base < m; base += 64u) {
-				const uint32_t idx = base + lane;
+			const uint32_t mmax = max(max((uint32_t)__shfl((int)m, 0, 64), (uint32_t)__shfl((int)m, 16, 64)),
+						  max((uint32_t)__shfl((int)m, 32, 64), (uint32_t)__shfl((int)m, 48, 64)));
+			for (uint32_t base = 0; base < mmax; base += 16u) {
+				const uint32_t idx = base + g;
 				if (idx < m) {
-					const uint32_t w = base == 0 ? cur.w : p.staged[ke - m + idx]; // staged word: value << 5 | CONN_BITMAP row
+					// staged word: value << 5 | CONN_BITMAP row
+					const uint32_t w = base == 0 ? cur.w0 : (base == 16u ? cur.w1 : p.staged[ke - m + idx]);
 					const int32_t v = (int32_t)(w >> GYS_ROW_BITS);
 					const uint32_t b = resp_bucket((int64_t)v);
 					atomicAdd(&s_h[2 * b], 1ull);
@@ -617,47 +625,60 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 				}
 			}
 			GYS_WAVE_SYNC();
-			const int32_t vmin = s_mm[0], vmax = s_mm[1];
-			// ---- histogram record (prefetched pair + LDS delta), Count-Min, meta, bitmap
-			if (lane < 15u) {
-				const unsigned long long dc = s_h[2 * lane];
-				if (dc) {
-					uint64_t *h = (uint64_t *)&p.hist_win[slot] + 2 * lane;
-					h[0] = cur.hc + dc;
-					h[1] = (uint64_t)((int64_t)cur.hs + (int64_t)s_h[2 * lane + 1]);
+			if (m) {
+				const int32_t vmin = s_mm[0], vmax = s_mm[1];
+				// ---- histogram record (prefetched pair + LDS delta), bitmap word, meta, Count-Min
+				uint4 *hp = (uint4 *)&p.hist_win[slot] + g;
+				if (g < 15u) {
+					const unsigned long long dc = s_h[2 * g];
+					if (dc) {
+						const uint64_t cnt = ((uint64_t)cur.pair.x | ((uint64_t)cur.pair.y << 32)) + dc;
+						const uint64_t sum = ((uint64_t)cur.pair.z | ((uint64_t)cur.pair.w << 32)) + s_h[2 * g + 1];
+						*hp = make_uint4((uint32_t)cnt, (uint32_t)(cnt >> 32), (uint32_t)sum, (uint32_t)(sum >> 32));
+					}
+				} else {
+					const uint64_t tot = ((uint64_t)cur.pair.x | ((uint64_t)cur.pair.y << 32)) + m; // total_count_
+					int64_t mx = (int64_t)((uint64_t)cur.pair.z | ((uint64_t)cur.pair.w << 32));  // max_val_seen_
+					if (mx < (int64_t)vmax) mx = (int64_t)vmax;
+					*hp = make_uint4((uint32_t)tot, (uint32_t)(tot >> 32), (uint32_t)(uint64_t)mx, (uint32_t)((uint64_t)mx >> 32));
 				}
-			} else if (lane == 15u) {
-				uint64_t *h = (uint64_t *)&p.hist_win[slot] + 30;
-				h[0] = cur.hc + m;
-				if ((int64_t)cur.hs < (int64_t)vmax) h[1] = (uint64_t)(int64_t)vmax;
-			} else if (lane < 20u) {
-				const uint32_t r = lane - 16u;
-				atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(cur.aux, GYS_SEED + r) & (GYS_CMS_W - 1))], m);
-			} else if (lane == 20u) {
-				int32_t mn = (int32_t)(uint32_t)cur.aux, mx = (int32_t)(uint32_t)(cur.aux >> 32);
-				mn = min(mn, vmin);
-				mx = max(mx, vmax);
-				uint64_t *mt = (uint64_t *)&p.td_meta[slot];
-				mt[0] = (uint64_t)(uint32_t)mn | ((uint64_t)(uint32_t)mx << 32);
-				if (!do_merge) mt[1] = (uint64_t)(npend + m);
-			} else if (lane == 21u) {
-				if (do_merge) { // the re-clustering of (buffered + new) values is done by k_digest_merge
-					const uint32_t at = atomicAdd(p.merge_count, 1u);
-					MergeEnt e;
-					e.slot = slot;
-					e.m = m;
-					e.off_end = ke;
-					e.pad = 0;
-					p.merge_list[at] = e;
+				{
+					const uint32_t bits = s_bm[g];
+					if (bits & ~cur.bm) p.bitmap[(size_t)slot * 16u + g] = cur.bm | bits;
 				}
-			} else if (lane >= 32u && lane < 48u) {
-				const uint32_t bits = s_bm[lane - 32u];
-				if (bits & ~(uint32_t)cur.aux) p.bitmap[(size_t)slot * 16u + (lane - 32u)] = (uint32_t)cur.aux | bits;
+				if (g == 0) {
+					const int32_t mn = min((int32_t)cur.meta.x, vmin), mx = max((int32_t)cur.meta.y, vmax);
+					*(uint4 *)&p.td_meta[slot] = make_uint4((uint32_t)mn, (uint32_t)mx, do_merge ? npend : npend + m, 0u);
+				} else if (g >= 4u && g < 8u) {
+					const uint32_t r = g - 4u;
+					atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(cur.gid, GYS_SEED + r) & (GYS_CMS_W - 1))], m);
+				}
+				if (do_merge) merge_rounds |= 1u << rd;
 			}
 			GYS_WAVE_SYNC();
-			if (inext >= 64u) break;
-			i = inext;
+			if (rnext >= 16u) break;
+			rd = rnext;
 			cur = nxt;
+		}
+		// ---- queue the keys whose buffer overflowed: lane = key of the chunk again (its count / offset are still in registers)
+		{
+			const uint32_t mr = (uint32_t)__shfl((int)merge_rounds, (int)((lane & 3u) * 16u), 64);
+			const bool need = (mr >> (lane >> 2)) & 1u;
+			const unsigned long long nb = __ballot(need);
+			if (nb) {
+				uint32_t at = 0;
+				if (lane == 0) at = atomicAdd(p.merge_count, (uint32_t)__popcll(nb));
+				at = (uint32_t)__shfl((int)at, 0, 64);
+				if (need) {
+					const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+					MergeEnt e;
+					e.slot = key;
+					e.m = mcnt;
+					e.off_end = oend;
+					e.pad = 0;
+					p.merge_list[at + (uint32_t)__popcll(nb & below)] = e;
+				}
+			}
 		}
 	}
 }
@@ -665,9 +686,13 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 // ---- k_digest_merge: one 64-thread workgroup (= one wave) per merge-list entry.  Exact-integer k-bucket merge (DESIGN.md "t-digest"):
 //   values = the key's buffered values + the batch's new values; merged order = by mean, old clusters before values on ties; an item
 //   with weighted mid-point mid2/2 of N goes to cluster #{j : mid2 >= T_j}, T_j = ceil(BND[j] * 2N / 2^32).
+// No sort: the (<= 100) old cluster means cut the value axis into intervals; interval(v) = #{clusters with mean <= v} comes from a
+// binary search, a counting sort by interval groups the values in LDS, and a value's rank is (values in lower intervals) + (its
+// rank inside its own interval, by direct comparison -- a digest's clusters track the distribution, so an interval holds a handful
+// of the batch's values).  Old cluster c is preceded by exactly the values of intervals 0..c.  Everything else is integer
+// arithmetic on ranks, so the result equals the sorted-merge definition bit for bit (ties among equal values are interchangeable).
 // query mode (out_sum != nullptr): entry w writes the merged view of its key to out_sum/out_cnt[w*100..] and leaves the state alone.
 #define GYS_MERGE_MAX (GYS_TD_PEND_CAP + GYS_SMALL_MAX)
-#define GYS_MERGE_LDS 2048u // power of two >= GYS_MERGE_MAX
 
 struct MergeP {
 	DigestP d;
@@ -680,13 +705,16 @@ struct MergeP {
 __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 {
 	const DigestP &p = q.d;
-	__shared__ int32_t s_val[GYS_MERGE_LDS];
-	__shared__ int64_t s_csum[GYS_TD_NB];  // compacted non-empty old clusters
+	__shared__ uint32_t s_x[GYS_MERGE_MAX];  // interval << 20 | value, in arrival order
+	__shared__ uint32_t s_g[GYS_MERGE_MAX];  // the same words grouped by interval
+	__shared__ int64_t s_csum[GYS_TD_NB];    // compacted non-empty old clusters
 	__shared__ uint32_t s_ccnt[GYS_TD_NB];
 	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
-	__shared__ uint64_t s_T[GYS_TD_NB];    // s_T[j], j = 1..NB-1
+	__shared__ uint64_t s_T[GYS_TD_NB];      // s_T[j], j = 1..NB-1
 	__shared__ unsigned long long s_osum[GYS_TD_NB];
 	__shared__ uint32_t s_ocnt[GYS_TD_NB];
+	__shared__ uint32_t s_icnt[GYS_TD_NB + 1]; // values per interval, then the running scatter cursor
+	__shared__ uint32_t s_ioff[GYS_TD_NB + 2]; // exclusive prefix of s_icnt (s_ioff[i + 1] = values in intervals 0..i)
 	const uint32_t lane = threadIdx.x;
 	const uint32_t nent = *q.count;
 
@@ -705,6 +733,17 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 		const uint32_t c1 = j1 < GYS_TD_NB ? gc[j1] : 0u;
 		const int64_t sm0 = gs[lane];
 		const int64_t sm1 = j1 < GYS_TD_NB ? gs[j1] : 0;
+		if (m == 0) { // nothing buffered (query of a freshly merged key): the merged view is the digest itself
+			if (q.out_sum) {
+				q.out_sum[(size_t)w * GYS_TD_NB + lane] = sm0;
+				q.out_cnt[(size_t)w * GYS_TD_NB + lane] = c0;
+				if (j1 < GYS_TD_NB) {
+					q.out_sum[(size_t)w * GYS_TD_NB + j1] = sm1;
+					q.out_cnt[(size_t)w * GYS_TD_NB + j1] = c1;
+				}
+			}
+			continue;
+		}
 		// compaction of non-empty clusters (order preserving)
 		const unsigned long long b0 = __ballot(c0 != 0), b1 = __ballot(c1 != 0);
 		const uint32_t n0 = (uint32_t)__popcll(b0), nc = n0 + (uint32_t)__popcll(b1);
@@ -724,69 +763,80 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			s_cpfx[pos] = e1;
 		}
 		if (lane == 0) s_cpfx[nc] = nold;
-		// ---- values (buffered, then new) -> LDS, padded to a power of two with +inf, bitonic sort by the wave
-		uint32_t P = 64;
-		while (P < m) P <<= 1;
-		{
-			const uint32_t *pend = p.td_pend + (size_t)slot * GYS_TD_PEND_CAP;
-			for (uint32_t i = lane; i < P; i += 64u) {
-				int32_t v = INT32_MAX;
-				if (i < npend) v = (int32_t)pend[i];
-				else if (i < m) v = (int32_t)(p.staged[start + (i - npend)] >> GYS_ROW_BITS);
-				s_val[i] = v;
-			}
-		}
 		const uint64_t twoN = 2ull * (nold + (uint64_t)m);
 		if (lane >= 1 && lane < GYS_TD_NB) s_T[lane] = td_threshold(c_td_bnd[lane], twoN);
 		if (j1 < GYS_TD_NB) s_T[j1] = td_threshold(c_td_bnd[j1], twoN);
 		s_osum[lane] = 0;
 		s_ocnt[lane] = 0;
+		s_icnt[lane] = 0;
 		if (j1 < GYS_TD_NB) {
 			s_osum[j1] = 0;
 			s_ocnt[j1] = 0;
 		}
+		if (j1 < GYS_TD_NB + 1) s_icnt[j1] = 0;
 		__syncthreads();
-		for (uint32_t k = 2; k <= P; k <<= 1) {
-			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-				for (uint32_t i = lane; i < P; i += 64u) {
-					const uint32_t ixj = i ^ j;
-					if (ixj > i) {
-						const int32_t a = s_val[i], b = s_val[ixj];
-						const bool up = (i & k) == 0;
-						if ((a > b) == up) {
-							s_val[i] = b;
-							s_val[ixj] = a;
-						}
-					}
+		// ---- values (buffered, then new): interval = first cluster with mean > v  (csum > v * ccnt), counted per interval
+		{
+			const uint32_t *pend = p.td_pend + (size_t)slot * GYS_TD_PEND_CAP;
+			for (uint32_t i = lane; i < m; i += 64u) {
+				const uint32_t uv = i < npend ? pend[i] : (p.staged[start + (i - npend)] >> GYS_ROW_BITS);
+				const int64_t v = (int64_t)uv;
+				uint32_t lo = 0, hi = nc;
+				while (lo < hi) {
+					const uint32_t mid = (lo + hi) >> 1;
+					if (s_csum[mid] <= v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
 				}
-				__syncthreads();
+				s_x[i] = (lo << 20) | uv;
+				atomicAdd(&s_icnt[lo], 1u);
 			}
 		}
-		// ---- old clusters: W = weight of old clusters before + #{values strictly below the cluster mean}
-		for (uint32_t c = lane; c < nc; c += 64u) {
-			const int64_t cs = s_csum[c];
-			const uint32_t cc = s_ccnt[c];
-			uint32_t lo = 0, hi = m; // first index with v * cc >= cs
-			while (lo < hi) {
-				const uint32_t mid = (lo + hi) >> 1;
-				if ((int64_t)s_val[mid] * (int64_t)cc < cs) lo = mid + 1; else hi = mid;
+		__syncthreads();
+		// ---- exclusive scan of the interval counts (<= 101 entries: lane, lane + 64)
+		{
+			const uint32_t a0 = lane <= nc ? s_icnt[lane] : 0u;
+			const uint32_t a1 = j1 <= nc ? s_icnt[j1] : 0u;
+			uint32_t i0 = a0, i1 = a1;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t t0 = __shfl_up(i0, d, 64), t1 = __shfl_up(i1, d, 64);
+				if ((int)lane >= d) {
+					i0 += t0;
+					i1 += t1;
+				}
 			}
-			const uint64_t mid2 = 2ull * (s_cpfx[c] + (uint64_t)lo) + (uint64_t)cc;
+			const uint32_t tot0 = __shfl(i0, 63, 64);
+			s_ioff[lane] = i0 - a0;
+			s_icnt[lane] = i0 - a0; // scatter cursor
+			if (j1 < GYS_TD_NB + 2) s_ioff[j1] = tot0 + i1 - a1;
+			if (j1 < GYS_TD_NB + 1) s_icnt[j1] = tot0 + i1 - a1;
+		}
+		__syncthreads();
+		for (uint32_t i = lane; i < m; i += 64u) {
+			const uint32_t x = s_x[i];
+			s_g[atomicAdd(&s_icnt[x >> 20], 1u)] = x;
+		}
+		__syncthreads();
+		// ---- old clusters: preceded by the old clusters before them and by the values of intervals 0..c (= values below the mean)
+		for (uint32_t c = lane; c < nc; c += 64u) {
+			const uint32_t cc = s_ccnt[c];
+			const uint64_t mid2 = 2ull * (s_cpfx[c] + (uint64_t)s_ioff[c + 1]) + (uint64_t)cc;
 			const uint32_t a = td_cluster_of(s_T, mid2);
-			atomicAdd(&s_osum[a], (unsigned long long)cs);
+			atomicAdd(&s_osum[a], (unsigned long long)s_csum[c]);
 			atomicAdd(&s_ocnt[a], cc);
 		}
-		// ---- values: W = rank among the values + weight of old clusters with mean <= v
-		for (uint32_t r = lane; r < m; r += 64u) {
-			const int64_t v = (int64_t)s_val[r];
-			uint32_t lo = 0, hi = nc; // first cluster with mean > v  (csum > v * ccnt)
-			while (lo < hi) {
-				const uint32_t mid = (lo + hi) >> 1;
-				if (s_csum[mid] <= v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
+		// ---- values: rank = values in lower intervals + rank inside the interval (ties by position); W adds the old weight <= v
+		for (uint32_t e = lane; e < m; e += 64u) {
+			const uint32_t x = s_g[e];
+			const uint32_t iv = x >> 20;
+			const uint32_t gb = s_ioff[iv], ge = s_ioff[iv + 1];
+			uint32_t r = gb;
+			for (uint32_t u = gb; u < ge; ++u) {
+				const uint32_t y = s_g[u];
+				r += (y < x || (y == x && u < e)) ? 1u : 0u;
 			}
-			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[lo]) + 1ull;
+			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[iv]) + 1ull;
 			const uint32_t a = td_cluster_of(s_T, mid2);
-			atomicAdd(&s_osum[a], (unsigned long long)v);
+			atomicAdd(&s_osum[a], (unsigned long long)(x & 0xFFFFFu));
 			atomicAdd(&s_ocnt[a], 1u);
 		}
 		__syncthreads();
