@@ -76,6 +76,17 @@ __host__ __device__ __forceinline__ uint32_t jhash2(const uint32_t (&k)[N], uint
 	return c;
 }
 
+// jhash2 over exactly four words (the PAIR_IP_PORT key of an IPv4 flow: cli ip, cli port, ser ip, ser port): one full round + tail
+__host__ __device__ __forceinline__ uint32_t jhash2_4w(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t initval)
+{
+	uint32_t a = GYS_GOLDEN + k0, b = GYS_GOLDEN + k1, c = initval + k2;
+	jmix(a, b, c);
+	c += 16u; // length in bytes (common/jhash.h:103)
+	a += k3;
+	jmix(a, b, c);
+	return c;
+}
+
 // two-word key (a 64-bit glob_id as lo,hi) through jhash2 with an arbitrary seed
 __host__ __device__ __forceinline__ uint32_t jhash2_u64(uint64_t key, uint32_t initval)
 {

@@ -516,7 +516,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		mp.d = d;
 		mp.list = c->merge_list;
 		mp.count = c->merge_count;
-		hipLaunchKernelGGL(k_digest_merge, dim3(std::min<uint64_t>(std::min<uint64_t>(nsvc, n), (uint64_t)c->ncu * 32)), dim3(64), 0, c->stream, mp);
+		const uint32_t mgrid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nsvc, n), (uint64_t)c->ncu * 32);
+		hipLaunchKernelGGL(k_digest_merge<128u>, dim3(mgrid), dim3(64), 0, c->stream, mp);
+		hipLaunchKernelGGL(k_digest_merge<GYS_SMALL_MAX>, dim3(std::min<uint32_t>(mgrid, (uint32_t)c->ncu * 8)), dim3(64), 0, c->stream, mp);
 	}
 	{
 		ProfScope ps(c, "digest_huge");
@@ -1164,7 +1166,7 @@ int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t 
 	mp.count = c->merge_count + 1;
 	mp.out_sum = c->query_sum;
 	mp.out_cnt = c->query_cnt;
-	hipLaunchKernelGGL(k_digest_merge, dim3(1), dim3(64), 0, c->stream, mp);
+	hipLaunchKernelGGL(k_digest_merge<128u>, dim3(1), dim3(64), 0, c->stream, mp);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(sum, c->query_sum, sizeof(sum), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(cnt, c->query_cnt, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));

@@ -65,32 +65,43 @@ __global__ void k_tdmeta_init(uint4 *meta, uint64_t n)
 // ---------------------------------------------------------------------------------------------------- resp pass 1
 __device__ __forceinline__ uint16_t bswap16(uint16_t v) { return (uint16_t)((v >> 8) | (v << 8)); }
 
-__device__ __forceinline__ void hll_update_event(uint32_t *hll32, uint8_t *svc_hll, uint32_t svc_hll_p, uint32_t slot, uint32_t daddr, uint16_t dport,
-						 uint32_t saddr, uint16_t sport)
+// 64-bit sketch hash of a response event's flow: PAIR_IP_PORT(cli = daddr:dport, ser = saddr:sport) (common/gy_inet_inc.h:225-247)
+__device__ __forceinline__ uint64_t flow_hash64(uint32_t daddr, uint16_t dport, uint32_t saddr, uint16_t sport)
 {
-	// distinct client flows: HLL over PAIR_IP_PORT(cli = daddr:dport, ser = saddr:sport) (common/gy_inet_inc.h:225-247)
+	if (daddr != 0 && saddr != 0) // both ends IPv4: the key is the 4 words [cli ip][cli port][ser ip][ser port]
+		return ((uint64_t)jhash2_4w(daddr, dport, saddr, sport, GYS_SEED) << 32) | (uint64_t)jhash2_4w(daddr, dport, saddr, sport, GYS_GOLDEN);
+	// 0.0.0.0 hashes as 16 zero bytes (GY_IP_ADDR::get_as_inaddr quirk): general word packing
 	uint32_t w[10];
 	const uint32_t z[4] = {0, 0, 0, 0};
 	const uint32_t nw = pair_words(daddr, z, dport, saddr, z, sport, w);
-	const uint64_t h64 = hash64<10>(w, nw);
+	return hash64<10>(w, nw);
+}
+
+// per-service distinct clients: same hash, per-service register file (u8 packed, CAS on the word)
+__device__ __forceinline__ void svc_hll_update(uint8_t *svc_hll, uint32_t svc_hll_p, uint32_t slot, uint64_t h64)
+{
+	uint32_t sidx, srank;
+	hll_idx_rank(h64, (int)svc_hll_p, &sidx, &srank);
+	uint8_t *base = svc_hll + ((size_t)slot << svc_hll_p);
+	uint32_t *wp = (uint32_t *)(base + (sidx & ~3u));
+	const uint32_t sh = (sidx & 3u) * 8u;
+	uint32_t old = *wp;
+	while (((old >> sh) & 0xFFu) < srank) {
+		const uint32_t nv = (old & ~(0xFFu << sh)) | (srank << sh);
+		const uint32_t prev = atomicCAS(wp, old, nv);
+		if (prev == old) break;
+		old = prev;
+	}
+}
+
+__device__ __forceinline__ void hll_update_event(uint32_t *hll32, uint8_t *svc_hll, uint32_t svc_hll_p, uint32_t slot, uint32_t daddr, uint16_t dport,
+						 uint32_t saddr, uint16_t sport)
+{
+	const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
 	uint32_t idx, rank;
 	hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
 	if (hll32[idx] < rank) atomicMax(&hll32[idx], rank);
-	if (svc_hll_p) {
-		// per-service distinct clients: same hash, per-service register file (u8 packed, CAS on the word)
-		uint32_t sidx, srank;
-		hll_idx_rank(h64, (int)svc_hll_p, &sidx, &srank);
-		uint8_t *base = svc_hll + ((size_t)slot << svc_hll_p);
-		uint32_t *wp = (uint32_t *)(base + (sidx & ~3u));
-		const uint32_t sh = (sidx & 3u) * 8u;
-		uint32_t old = *wp;
-		while (((old >> sh) & 0xFFu) < srank) {
-			const uint32_t nv = (old & ~(0xFFu << sh)) | (srank << sh);
-			const uint32_t prev = atomicCAS(wp, old, nv);
-			if (prev == old) break;
-			old = prev;
-		}
-	}
+	if (svc_hll_p) svc_hll_update(svc_hll, svc_hll_p, slot, h64);
 }
 
 struct RespP1 {
@@ -297,6 +308,7 @@ struct HostDesc {
 
 #define GYS_HOST_TBL_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define GYS_HOST_THREADS 512
+#define GYS_HOST_UNROLL 4
 
 struct RespHostP {
 	const uint64_t *ev;
@@ -336,18 +348,39 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	if (tid < 2) s_drop[tid] = 0;
 	__syncthreads();
 
-	// ---- pass A: resolve, filter, count
+	// ---- pass A: resolve, filter, count.  GYS_HOST_UNROLL events per thread and iteration, phase by phase (all event loads, then all
+	// the arithmetic, then all HLL register reads, then the updates) so that each wave keeps several HBM requests in flight.
 	uint32_t ndrop_range = 0, ndrop_nol = 0;
-	for (uint64_t i = e0 + tid; i < e1; i += GYS_HOST_THREADS) {
-		const uint64_t w0 = p.ev[3 * i], w1 = p.ev[3 * i + 1], w2 = p.ev[3 * i + 2];
-		const uint32_t saddr = (uint32_t)w0, daddr = (uint32_t)(w0 >> 32);
-		const uint32_t netns = (uint32_t)w1;
-		const uint16_t sport = bswap16((uint16_t)(w1 >> 32)), dport = bswap16((uint16_t)(w1 >> 48)); // ntohs :1526-1527
-		const uint32_t tresp = (uint32_t)w2 - (uint32_t)(w2 >> 32); // lsndtime - lrcvtime (:1519)
-		uint64_t kv = ~0ull;
-		if (tresp > 1000000u) { // "Ignore responses > 1000 sec or negative" (:1521-1524)
-			ndrop_range++;
-		} else {
+	for (uint64_t base = e0 + tid; base < e1; base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
+		uint64_t w0[GYS_HOST_UNROLL], w1[GYS_HOST_UNROLL], w2[GYS_HOST_UNROLL];
+#pragma unroll
+		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
+			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
+			w0[u] = 0; w1[u] = 0; w2[u] = 0;
+			if (i < e1) {
+				w0[u] = p.ev[3 * i];
+				w1[u] = p.ev[3 * i + 1];
+				w2[u] = p.ev[3 * i + 2];
+			}
+		}
+		uint64_t kv[GYS_HOST_UNROLL];
+		uint32_t hidx[GYS_HOST_UNROLL], hrank[GYS_HOST_UNROLL], hcur[GYS_HOST_UNROLL];
+#pragma unroll
+		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
+			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
+			// struct ipv4_tuple_t {u32 saddr, daddr, netns; u16 sport, dport;} + u32 lsndtime, lrcvtime  (24 bytes)
+			const uint32_t saddr = (uint32_t)w0[u], daddr = (uint32_t)(w0[u] >> 32);
+			const uint32_t netns = (uint32_t)w1[u];
+			const uint16_t sport = bswap16((uint16_t)(w1[u] >> 32)), dport = bswap16((uint16_t)(w1[u] >> 48)); // ntohs :1526-1527
+			const uint32_t tresp = (uint32_t)w2[u] - (uint32_t)(w2[u] >> 32); // lsndtime - lrcvtime (:1519)
+			kv[u] = ~0ull;
+			hrank[u] = 0;
+			hidx[u] = 0;
+			if (i >= e1) continue;
+			if (tresp > 1000000u) { // "Ignore responses > 1000 sec or negative" (:1521-1524)
+				ndrop_range++;
+				continue;
+			}
 			const uint64_t key48 = ((uint64_t)netns << 16) | (uint64_t)sport;
 			uint32_t h = get_uint64_hash(key48) & mask;
 			uint32_t local = GYS_NOSLOT;
@@ -362,13 +395,22 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 			}
 			if (local == GYS_NOSLOT) {
 				ndrop_nol++; // no such listener: the reference ignores the event too (:1671-1676 miss path)
-			} else {
-				hll_update_event(p.hll32, p.svc_hll, p.svc_hll_p, p.svc_hll_p ? p.hlst[hd.lst_off + local] : 0u, daddr, dport, saddr, sport);
-				atomicAdd(&s_cnt[local], 1u);
-				kv = ((uint64_t)local << 32) | GYS_STAGED_WORD(tresp, dport);
+				continue;
 			}
+			kv[u] = ((uint64_t)local << 32) | GYS_STAGED_WORD(tresp, dport);
+			const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
+			hll_idx_rank(h64, GYS_HLL_P, &hidx[u], &hrank[u]);
+			if (p.svc_hll_p) svc_hll_update(p.svc_hll, p.svc_hll_p, p.hlst[hd.lst_off + local], h64);
 		}
-		p.ev_kv[i] = kv;
+#pragma unroll
+		for (int u = 0; u < GYS_HOST_UNROLL; ++u) hcur[u] = hrank[u] ? p.hll32[hidx[u]] : 0xFFu; // read-first: most events do not raise the register
+#pragma unroll
+		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
+			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
+			if (hcur[u] < hrank[u]) atomicMax(&p.hll32[hidx[u]], hrank[u]);
+			if (kv[u] != ~0ull) atomicAdd(&s_cnt[(uint32_t)(kv[u] >> 32)], 1u);
+			if (i < e1) p.ev_kv[i] = kv[u];
+		}
 	}
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
 	if (ndrop_nol) atomicAdd(&s_drop[1], ndrop_nol);
@@ -405,11 +447,19 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	__syncthreads();
 
 	// ---- pass B: scatter the staged words into the key runs (positions from LDS atomics)
-	for (uint64_t i = e0 + tid; i < e1; i += GYS_HOST_THREADS) {
-		const uint64_t kv = p.ev_kv[i];
-		if (kv == ~0ull) continue;
-		const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)(kv >> 32)], 1u);
-		p.staged[e0 + pos] = (uint32_t)kv;
+	for (uint64_t base = e0 + tid; base < e1; base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
+		uint64_t kv[GYS_HOST_UNROLL];
+#pragma unroll
+		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
+			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
+			kv[u] = i < e1 ? p.ev_kv[i] : ~0ull;
+		}
+#pragma unroll
+		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
+			if (kv[u] == ~0ull) continue;
+			const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)(kv[u] >> 32)], 1u);
+			p.staged[e0 + pos] = (uint32_t)kv[u];
+		}
 	}
 	if (tid == 0) {
 		atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
@@ -504,6 +554,16 @@ __device__ __forceinline__ uint32_t td_cluster_of(const uint64_t *T, uint64_t mi
 		const uint32_t mid = (a + bb + 1) >> 1;
 		if (mid2 >= T[mid]) a = mid; else bb = mid - 1;
 	}
+	return a;
+}
+
+// same on a table padded to 128 entries with ~0: branch-free (7 dependent LDS reads, no divergent loop)
+__device__ __forceinline__ uint32_t td_cluster_of128(const uint64_t *T, uint64_t mid2)
+{
+	uint32_t a = 0; // #{j in 1..127 : mid2 >= T[j]}
+#pragma unroll
+	for (uint32_t step = 64u; step >= 1u; step >>= 1)
+		if (mid2 >= T[a + step]) a += step;
 	return a;
 }
 
@@ -702,15 +762,19 @@ struct MergeP {
 	uint32_t *out_cnt;
 };
 
+// Two instantiations share the list: NEWMAX = 128 (LDS for 384 values: the common case, ~2x the resident waves) takes the entries with
+// <= 128 new values, NEWMAX = GYS_SMALL_MAX the rest.
+template <uint32_t NEWMAX>
 __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 {
 	const DigestP &p = q.d;
-	__shared__ uint32_t s_x[GYS_MERGE_MAX];  // interval << 20 | value, in arrival order
-	__shared__ uint32_t s_g[GYS_MERGE_MAX];  // the same words grouped by interval
-	__shared__ int64_t s_csum[GYS_TD_NB];    // compacted non-empty old clusters
-	__shared__ uint32_t s_ccnt[GYS_TD_NB];
+	__shared__ uint32_t s_x[GYS_TD_PEND_CAP + NEWMAX];  // interval << 20 | value, in arrival order
+	__shared__ uint32_t s_g[GYS_TD_PEND_CAP + NEWMAX];  // the same words grouped by interval
+	__shared__ int64_t s_csum[128];          // compacted non-empty old clusters, padded with +inf means for the branch-free search
+	__shared__ uint32_t s_ccnt[128];
 	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
-	__shared__ uint64_t s_T[GYS_TD_NB];      // s_T[j], j = 1..NB-1
+	__shared__ uint64_t s_T[128];            // s_T[j], j = 1..NB-1; [NB..127] = ~0 (never reached)
+	__shared__ uint32_t s_imin[GYS_TD_NB + 1], s_imax[GYS_TD_NB + 1]; // smallest / largest value of each interval
 	__shared__ unsigned long long s_osum[GYS_TD_NB];
 	__shared__ uint32_t s_ocnt[GYS_TD_NB];
 	__shared__ uint32_t s_icnt[GYS_TD_NB + 1]; // values per interval, then the running scatter cursor
@@ -720,6 +784,7 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 
 	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
 		const MergeEnt ent = q.list[w];
+		if (NEWMAX == 128u ? ent.m > 128u : ent.m <= 128u) continue; // the other instantiation's entry
 		const uint32_t slot = ent.slot;
 		const uint32_t npend = p.td_meta[slot].npend;
 		const uint32_t m = npend + ent.m;
@@ -763,17 +828,31 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			s_cpfx[pos] = e1;
 		}
 		if (lane == 0) s_cpfx[nc] = nold;
+		if (lane >= nc) { // pad: mean = +inf
+			s_csum[lane] = INT64_MAX;
+			s_ccnt[lane] = 1;
+		}
+		if (j1 >= nc) {
+			s_csum[j1] = INT64_MAX;
+			s_ccnt[j1] = 1;
+		}
 		const uint64_t twoN = 2ull * (nold + (uint64_t)m);
-		if (lane >= 1 && lane < GYS_TD_NB) s_T[lane] = td_threshold(c_td_bnd[lane], twoN);
-		if (j1 < GYS_TD_NB) s_T[j1] = td_threshold(c_td_bnd[j1], twoN);
+		if (lane >= 1) s_T[lane] = td_threshold(c_td_bnd[lane], twoN);
+		s_T[j1] = j1 < GYS_TD_NB ? td_threshold(c_td_bnd[j1], twoN) : ~0ull;
 		s_osum[lane] = 0;
 		s_ocnt[lane] = 0;
 		s_icnt[lane] = 0;
+		s_imin[lane] = 0xFFFFFFFFu;
+		s_imax[lane] = 0;
 		if (j1 < GYS_TD_NB) {
 			s_osum[j1] = 0;
 			s_ocnt[j1] = 0;
 		}
-		if (j1 < GYS_TD_NB + 1) s_icnt[j1] = 0;
+		if (j1 < GYS_TD_NB + 1) {
+			s_icnt[j1] = 0;
+			s_imin[j1] = 0xFFFFFFFFu;
+			s_imax[j1] = 0;
+		}
 		__syncthreads();
 		// ---- values (buffered, then new): interval = first cluster with mean > v  (csum > v * ccnt), counted per interval
 		{
@@ -781,13 +860,16 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			for (uint32_t i = lane; i < m; i += 64u) {
 				const uint32_t uv = i < npend ? pend[i] : (p.staged[start + (i - npend)] >> GYS_ROW_BITS);
 				const int64_t v = (int64_t)uv;
-				uint32_t lo = 0, hi = nc;
-				while (lo < hi) {
-					const uint32_t mid = (lo + hi) >> 1;
-					if (s_csum[mid] <= v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
+				uint32_t lo = 0; // #{clusters with mean <= v}: branch-free lower bound over the padded 128-entry arrays
+#pragma unroll
+				for (uint32_t step = 64u; step >= 1u; step >>= 1) {
+					const uint32_t c = lo + step - 1u;
+					if (s_csum[c] <= v * (int64_t)s_ccnt[c]) lo += step;
 				}
 				s_x[i] = (lo << 20) | uv;
 				atomicAdd(&s_icnt[lo], 1u);
+				atomicMin(&s_imin[lo], uv);
+				atomicMax(&s_imax[lo], uv);
 			}
 		}
 		__syncthreads();
@@ -820,7 +902,7 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 		for (uint32_t c = lane; c < nc; c += 64u) {
 			const uint32_t cc = s_ccnt[c];
 			const uint64_t mid2 = 2ull * (s_cpfx[c] + (uint64_t)s_ioff[c + 1]) + (uint64_t)cc;
-			const uint32_t a = td_cluster_of(s_T, mid2);
+			const uint32_t a = td_cluster_of128(s_T, mid2);
 			atomicAdd(&s_osum[a], (unsigned long long)s_csum[c]);
 			atomicAdd(&s_ocnt[a], cc);
 		}
@@ -829,13 +911,16 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			const uint32_t x = s_g[e];
 			const uint32_t iv = x >> 20;
 			const uint32_t gb = s_ioff[iv], ge = s_ioff[iv + 1];
-			uint32_t r = gb;
-			for (uint32_t u = gb; u < ge; ++u) {
-				const uint32_t y = s_g[u];
-				r += (y < x || (y == x && u < e)) ? 1u : 0u;
+			uint32_t r = e; // an interval of equal values (the usual case for integer ms data): ties rank by position
+			if (s_imin[iv] != s_imax[iv]) {
+				r = gb;
+				for (uint32_t u = gb; u < ge; ++u) {
+					const uint32_t y = s_g[u];
+					r += (y < x || (y == x && u < e)) ? 1u : 0u;
+				}
 			}
 			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[iv]) + 1ull;
-			const uint32_t a = td_cluster_of(s_T, mid2);
+			const uint32_t a = td_cluster_of128(s_T, mid2);
 			atomicAdd(&s_osum[a], (unsigned long long)(x & 0xFFFFFu));
 			atomicAdd(&s_ocnt[a], 1u);
 		}
