@@ -497,6 +497,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	d.td_pend = c->td_pend;
 	d.merge_list = c->merge_list;
 	d.merge_count = c->merge_count;
+	d.hist_all = c->hist_all;
+	d.epoch = c->epoch;
+	d.ghist = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
+	d.gmax = (long long *)(c->arena + c->al.off_i64max);
 	d.batch_cnt = c->batch_cnt;
 	d.off_end = c->batch_off;
 	d.staged = c->staged;
@@ -983,9 +987,10 @@ int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 	{
 		ProfScope ps(c, "window_prepare");
 		hipLaunchKernelGGL(k_window_prepare, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, p);
-		if (c->nsvc) {
-			// all-time += window (GY_HISTOGRAM::add_histogram), window cleared, and the all-service histogram of the window reduced
-			// into the arena in the same pass over the records
+		if (c->nsvc && !c->cfg.enable_tdigest) {
+			// eager mode (no per-key pass): all-time += window (GY_HISTOGRAM::add_histogram), window cleared, and the all-service
+			// histogram of the window reduced into the arena in the same pass over the records.  With the t-digest on, keys roll
+			// lazily inside k_key_pass / k_digest_huge ("Lazy window roll" in gys_kernels.hpp) and there is nothing to sweep here.
 			long long *gh = (long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
 			hipLaunchKernelGGL(k_hist_fold, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->hist_all,
 					   c->hist_win, (uint64_t)c->nsvc, 1, gh, (long long *)(c->arena + c->al.off_i64max));
@@ -1013,8 +1018,8 @@ int gys_window_finish(gys_ctx *c)
 	}
 	HIPCHK(hipMemsetAsync(c->hll32, 0, (uint64_t)4 << GYS_HLL_P, c->stream));
 	if (c->nsvc) {
-		// CONN_BITMAP cleared every window (secs_to_reset_ = 5)
-		HIPCHK(hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * 64, c->stream));
+		// CONN_BITMAP cleared every window (secs_to_reset_ = 5); lazily (per key, on its next touch) when the per-key pass runs
+		if (!c->cfg.enable_tdigest) HIPCHK(hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * 64, c->stream));
 		if (c->svc_hll) HIPCHK(hipMemsetAsync(c->svc_hll, 0, (uint64_t)c->nsvc << c->cfg.svc_hll_p, c->stream));
 	}
 	const uint64_t hb = (uint64_t)c->hosts.size() * 16 * 4;
@@ -1086,8 +1091,8 @@ int gys_query_hist_percentiles(gys_ctx *c, uint64_t glob_id, int which, gys_hist
 	int rc = gys_lookup_service(c, glob_id, &slot);
 	if (rc) return rc;
 	gys_hist_rec h;
-	HIPCHK(hipMemcpyAsync(&h, (which ? c->hist_all : c->hist_win) + slot, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
+	rc = gys_export_hist(c, which, slot, 1, &h);
+	if (rc) return rc;
 	const HashDef &d = hash_def(GYS_RESP_TIME_HASH);
 	if (total_count) *total_count = h.total_count;
 	if (max_val) *max_val = h.max_val_seen;
@@ -1267,7 +1272,14 @@ int gys_query_topn(gys_ctx *c, const uint8_t machine_id[16], int kind, gys_topn_
 int gys_scan_percentiles_dev(gys_ctx *c, int which, const float *pcts, uint32_t npct, int64_t *d_out)
 {
 	if (!c || !pcts || !d_out || !npct || npct > 64 || which < 0 || which > 1) return GYS_ERR_INVAL;
-	return gys_hist_percentiles_dev(c, GYS_RESP_TIME_HASH, which ? c->hist_all : c->hist_win, c->nsvc, pcts, npct, d_out);
+	if (!c->nsvc) return GYS_OK;
+	HIPCHK(hipMemcpyAsync(c->dev_pcts, pcts, (size_t)npct * 4, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream)); // pcts may be a short-lived host buffer
+	ProfScope ps(c, "hist_percentiles");
+	hipLaunchKernelGGL(k_hist_percentiles_view, dim3((c->nsvc + 255) / 256), dim3(256), 0, c->stream, c->hist_win, c->hist_all,
+			   c->cfg.enable_tdigest ? c->td_meta : nullptr, c->epoch, which, c->nsvc, c->dev_pcts, npct, d_out);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ exports
@@ -1283,8 +1295,16 @@ uint32_t gys_num_hosts(gys_ctx *c) { return c ? (uint32_t)c->hosts.size() : 0; }
 int gys_export_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
 {
 	RANGE_CHECK(first_slot, nslots);
-	HIPCHK(hipMemcpyAsync(out, (which ? c->hist_all : c->hist_win) + first_slot, (size_t)nslots * sizeof(gys_hist_rec), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
+	if (which < 0 || which > 1) return GYS_ERR_INVAL;
+	if (!nslots) return GYS_OK;
+	gys_hist_rec *tmp = nullptr; // window / all-time VIEW of the records (lazy window roll: see gys_kernels.hpp)
+	HIPCHK(hipMalloc((void **)&tmp, (size_t)nslots * sizeof(gys_hist_rec)));
+	hipLaunchKernelGGL(k_hist_view, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, c->hist_win, c->hist_all,
+			   c->cfg.enable_tdigest ? c->td_meta : nullptr, c->epoch, which, first_slot, nslots, tmp);
+	hipError_t e = hipMemcpyAsync(out, tmp, (size_t)nslots * sizeof(gys_hist_rec), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	hipFree(tmp);
+	HIPCHK(e);
 	return GYS_OK;
 }
 
@@ -1292,7 +1312,14 @@ int gys_export_conn_bitmap(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uin
 {
 	RANGE_CHECK(first_slot, nslots);
 	HIPCHK(hipMemcpyAsync(out, c->bitmap + (size_t)first_slot * 16, (size_t)nslots * 64, hipMemcpyDeviceToHost, c->stream));
+	std::vector<TdMeta> meta;
+	if (c->cfg.enable_tdigest) { // rows of a key that has not been touched in the current window are logically cleared
+		meta.resize(nslots);
+		HIPCHK(hipMemcpyAsync(meta.data(), c->td_meta + first_slot, (size_t)nslots * sizeof(TdMeta), hipMemcpyDeviceToHost, c->stream));
+	}
 	HIPCHK(hipStreamSynchronize(c->stream));
+	for (size_t i = 0; i < meta.size(); ++i)
+		if (meta[i].win_epoch != c->epoch) memset(out + i * 32, 0, 64);
 	return GYS_OK;
 }
 

@@ -478,8 +478,15 @@ static_assert(GYS_TD_PEND_CAP == GYS_TDIGEST_PEND_CAP, "gysketch.h and gys_tdige
 struct TdMeta {
 	int32_t vmin, vmax; // over merged AND buffered values (INT32_MAX / INT32_MIN when empty)
 	uint32_t npend;     // buffered values in td_pend[slot * CAP ..]
-	uint32_t pad;
+	uint32_t win_epoch; // window number the key's hist_win record and CONN_BITMAP rows belong to (lazy window roll, see below)
 };
+
+// Lazy window roll.  The reference clears the per-listener 5-s state and folds it into the longer levels on a timer
+// (GY_HISTOGRAM::add_histogram / clear, common/gy_statistics.h:625-636).  Sweeping 10^7 records at every window boundary costs
+// ~1 KB of HBM traffic per key, so the engine tags each key with the window number its hist_win / bitmap contents belong to and
+// rolls a key the first time a later window touches it: all-time += old window record, window record := this batch.
+//   window view   = hist_win if win_epoch == current window, else empty
+//   all-time view = hist_all + hist_win (the window record is either the current window or a not-yet-folded older one)
 
 struct MergeEnt {
 	uint32_t slot;
@@ -505,6 +512,10 @@ struct DigestP {
 	uint32_t *bitmap; // [nsvc*16] u32 = 32 x u16 CONN_BITMAP rows (common/gy_socket_stat.h:390-454)
 	MergeEnt *merge_list;
 	uint32_t *merge_count;
+	gys_hist_rec *hist_all;
+	uint32_t epoch;              // current window number
+	unsigned long long *ghist;   // arena: all-service histogram of the window, 15 x {count,sum} + {total}
+	long long *gmax;             // arena: largest value of the window
 };
 
 // CONN_BITMAP::add_response for one staged word into a 16-word LDS row image: respmap_[row].set(bucket)
@@ -512,31 +523,6 @@ __device__ __forceinline__ void bitmap_set_lds(uint32_t *s_bm, uint32_t word, ui
 {
 	const uint32_t row = word & 0x1Fu;
 	atomicOr(&s_bm[row >> 1], (1u << bucket) << ((row & 1u) * 16u));
-}
-
-// applies a key's batch deltas: s_h[2b] = count, s_h[2b+1] = sum of bucket b (LDS), m values, vmax = largest value.
-// lanes 0..14: HIST_SERIAL buckets, lane 15: total_count_/max_val_seen_, lanes 16..19: the 4 Count-Min rows, lanes 20..35: CONN_BITMAP words.
-__device__ __forceinline__ void key_epilogue(const DigestP &p, uint32_t slot, uint32_t m, int32_t vmax, const unsigned long long *s_h, const uint32_t *s_bm,
-					     uint32_t lane)
-{
-	if (lane >= 20u && lane < 36u) { // the key is owned by this workgroup for the batch: plain read-modify-write
-		const uint32_t bits = s_bm[lane - 20u];
-		if (bits) p.bitmap[(size_t)slot * 16u + (lane - 20u)] |= bits;
-	}
-	gys_hist_rec *h = &p.hist_win[slot];
-	if (lane < 15u) {
-		const unsigned long long c = s_h[2 * lane];
-		if (c) {
-			h->stats[lane].count += c;
-			h->stats[lane].sum += (int64_t)s_h[2 * lane + 1];
-		}
-	} else if (lane == 15u) {
-		h->total_count += m;
-		if (h->max_val_seen < (int64_t)vmax) h->max_val_seen = (int64_t)vmax;
-	} else if (lane < 20u) {
-		const uint32_t r = lane - 16u;
-		atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(p.svc_gid[slot], GYS_SEED + r) & (GYS_CMS_W - 1))], m);
-	}
 }
 
 // wave-synchronous LDS hand-off: DS operations of one wave execute in order; this only stops the compiler from moving them
@@ -595,7 +581,8 @@ __device__ __forceinline__ void wave_excl_scan_2x(uint64_t a0, uint64_t a1, uint
 // k_digest_merge with one aggregated atomic per chunk.
 struct KeyRegs {
 	uint32_t w0, w1;  // staged words g and 16 + g of the key
-	uint4 pair;       // histogram pair g: {count lo, count hi, sum lo, sum hi}
+	uint4 pair;       // histogram pair g of the window record: {count lo, count hi, sum lo, sum hi}
+	uint4 apair;      // the same pair of the all-time record (needed when the key rolls to a new window)
 	uint32_t bm;      // CONN_BITMAP word g
 	uint4 meta;       // TdMeta of the key (same for the 16 lanes of the row)
 	uint64_t gid;
@@ -610,6 +597,7 @@ __device__ __forceinline__ void key_prefetch(const DigestP &p, uint32_t slot, ui
 	if (g < m) r.w0 = sv[g];
 	if (16u + g < m) r.w1 = sv[16u + g];
 	r.pair = ((const uint4 *)&p.hist_win[slot])[g];
+	r.apair = ((const uint4 *)&p.hist_all[slot])[g];
 	r.bm = p.bitmap[(size_t)slot * 16u + g];
 	r.meta = *(const uint4 *)&p.td_meta[slot];
 	r.gid = p.svc_gid[slot];
@@ -620,6 +608,11 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 	__shared__ unsigned long long s_h_[16][32];
 	__shared__ uint32_t s_bm_[16][16];
 	__shared__ int32_t s_mm_[16][2];
+	__shared__ unsigned long long s_gh[32]; // all-service histogram of this workgroup's keys (flushed once at the end)
+	__shared__ long long s_gmax;
+	if (threadIdx.x < 32u) s_gh[threadIdx.x] = 0;
+	if (threadIdx.x == 32u) s_gmax = INT64_MIN;
+	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	const uint32_t row = lane >> 4, g = lane & 15u;
 	unsigned long long *s_h = s_h_[wv * 4u + row];
@@ -687,28 +680,44 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 			GYS_WAVE_SYNC();
 			if (m) {
 				const int32_t vmin = s_mm[0], vmax = s_mm[1];
-				// ---- histogram record (prefetched pair + LDS delta), bitmap word, meta, Count-Min
+				const bool stale = cur.meta.w != p.epoch; // first touch of the key in this window: roll it (see "Lazy window roll")
+				// ---- histogram records (prefetched pairs + LDS delta), bitmap word, meta, Count-Min
 				uint4 *hp = (uint4 *)&p.hist_win[slot] + g;
+				const uint64_t w_lo = (uint64_t)cur.pair.x | ((uint64_t)cur.pair.y << 32), w_hi = (uint64_t)cur.pair.z | ((uint64_t)cur.pair.w << 32);
+				if (stale) { // all-time += old window record (GY_HISTOGRAM::add_histogram, common/gy_statistics.h:625-660)
+					const uint64_t a_lo = (uint64_t)cur.apair.x | ((uint64_t)cur.apair.y << 32), a_hi = (uint64_t)cur.apair.z | ((uint64_t)cur.apair.w << 32);
+					uint64_t n_lo = a_lo + w_lo, n_hi = a_hi + w_hi;
+					if (g == 15u) n_hi = (uint64_t)max((int64_t)a_hi, (int64_t)w_hi); // max_val_seen_
+					if (n_lo != a_lo || n_hi != a_hi)
+						((uint4 *)&p.hist_all[slot])[g] = make_uint4((uint32_t)n_lo, (uint32_t)(n_lo >> 32), (uint32_t)n_hi, (uint32_t)(n_hi >> 32));
+				}
 				if (g < 15u) {
-					const unsigned long long dc = s_h[2 * g];
+					const unsigned long long dc = s_h[2 * g], ds = s_h[2 * g + 1];
 					if (dc) {
-						const uint64_t cnt = ((uint64_t)cur.pair.x | ((uint64_t)cur.pair.y << 32)) + dc;
-						const uint64_t sum = ((uint64_t)cur.pair.z | ((uint64_t)cur.pair.w << 32)) + s_h[2 * g + 1];
+						atomicAdd(&s_gh[2 * g], dc);
+						atomicAdd(&s_gh[2 * g + 1], ds);
+					}
+					if (dc || (stale && (w_lo | w_hi))) {
+						const uint64_t cnt = (stale ? 0ull : w_lo) + dc;
+						const uint64_t sum = (stale ? 0ull : w_hi) + ds;
 						*hp = make_uint4((uint32_t)cnt, (uint32_t)(cnt >> 32), (uint32_t)sum, (uint32_t)(sum >> 32));
 					}
 				} else {
-					const uint64_t tot = ((uint64_t)cur.pair.x | ((uint64_t)cur.pair.y << 32)) + m; // total_count_
-					int64_t mx = (int64_t)((uint64_t)cur.pair.z | ((uint64_t)cur.pair.w << 32));  // max_val_seen_
+					const uint64_t tot = (stale ? 0ull : w_lo) + m; // total_count_
+					int64_t mx = stale ? INT64_MIN : (int64_t)w_hi;   // max_val_seen_
 					if (mx < (int64_t)vmax) mx = (int64_t)vmax;
 					*hp = make_uint4((uint32_t)tot, (uint32_t)(tot >> 32), (uint32_t)(uint64_t)mx, (uint32_t)((uint64_t)mx >> 32));
+					atomicAdd(&s_gh[30], (unsigned long long)m);
+					atomicMax(&s_gmax, (long long)vmax);
 				}
 				{
-					const uint32_t bits = s_bm[g];
-					if (bits & ~cur.bm) p.bitmap[(size_t)slot * 16u + g] = cur.bm | bits;
+					const uint32_t old = stale ? 0u : cur.bm;
+					const uint32_t bits = s_bm[g] | old;
+					if (bits != cur.bm) p.bitmap[(size_t)slot * 16u + g] = bits;
 				}
 				if (g == 0) {
 					const int32_t mn = min((int32_t)cur.meta.x, vmin), mx = max((int32_t)cur.meta.y, vmax);
-					*(uint4 *)&p.td_meta[slot] = make_uint4((uint32_t)mn, (uint32_t)mx, do_merge ? npend : npend + m, 0u);
+					*(uint4 *)&p.td_meta[slot] = make_uint4((uint32_t)mn, (uint32_t)mx, do_merge ? npend : npend + m, p.epoch);
 				} else if (g >= 4u && g < 8u) {
 					const uint32_t r = g - 4u;
 					atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(cur.gid, GYS_SEED + r) & (GYS_CMS_W - 1))], m);
@@ -741,6 +750,9 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 			}
 		}
 	}
+	__syncthreads();
+	if (threadIdx.x < 31u && s_gh[threadIdx.x]) atomicAdd(&p.ghist[threadIdx.x], s_gh[threadIdx.x]);
+	if (threadIdx.x == 31u && s_gmax != INT64_MIN) atomicMax(p.gmax, s_gmax);
 }
 
 // ---- k_digest_merge: one 64-thread workgroup (= one wave) per merge-list entry.  Exact-integer k-bucket merge (DESIGN.md "t-digest"):
@@ -1123,12 +1135,56 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 			p.d.td_sum[(size_t)slot * GYS_TD_NB + threadIdx.x] = (int64_t)s_osum[threadIdx.x];
 			p.d.td_cnt[(size_t)slot * GYS_TD_NB + threadIdx.x] = (uint32_t)s_ocnt[threadIdx.x];
 		}
-		if (threadIdx.x >= 128u && threadIdx.x < 164u) key_epilogue(p.d, slot, m, s_max, s_h, s_bm, threadIdx.x - 128u);
+		{
+			// the key's batch deltas: s_h[2b] = count, s_h[2b+1] = sum of bucket b, m new values, s_max = largest; the key is owned by this
+			// workgroup for the batch, so the records are updated with plain read-modify-writes (lazy window roll as in k_key_pass)
+			const bool stale = p.d.td_meta[slot].win_epoch != p.d.epoch;
+			const uint32_t t = threadIdx.x - 128u; // lanes 0..15: histogram pairs, 16..19: Count-Min rows, 20..35: CONN_BITMAP words
+			if (threadIdx.x >= 128u && t < 16u) {
+				gys_hist_serial *wp = (gys_hist_serial *)&p.d.hist_win[slot] + t, *ap = (gys_hist_serial *)&p.d.hist_all[slot] + t;
+				gys_hist_serial wv = *wp;
+				if (stale) { // all-time += old window record
+					gys_hist_serial av = *ap;
+					if (t < 15u) {
+						av.count += wv.count;
+						av.sum += wv.sum;
+					} else {
+						av.count += wv.count;
+						if (av.sum < wv.sum) av.sum = wv.sum;
+					}
+					*ap = av;
+					wv.count = 0;
+					wv.sum = t < 15u ? 0 : INT64_MIN;
+				}
+				if (t < 15u) {
+					wv.count += s_h[2 * t];
+					wv.sum += (int64_t)s_h[2 * t + 1];
+					if (s_h[2 * t]) {
+						atomicAdd(&p.d.ghist[2 * t], s_h[2 * t]);
+						atomicAdd(&p.d.ghist[2 * t + 1], s_h[2 * t + 1]);
+					}
+				} else {
+					wv.count += m; // total_count_
+					if (wv.sum < (int64_t)s_max) wv.sum = (int64_t)s_max; // max_val_seen_
+					atomicAdd(&p.d.ghist[30], (unsigned long long)m);
+					atomicMax(p.d.gmax, (long long)s_max);
+				}
+				*wp = wv;
+			} else if (threadIdx.x >= 128u && t < 20u) {
+				const uint32_t r = t - 16u;
+				atomicAdd(&p.d.cms32[r * GYS_CMS_W + (jhash2_u64(p.d.svc_gid[slot], GYS_SEED + r) & (GYS_CMS_W - 1))], m);
+			} else if (threadIdx.x >= 128u && t < 36u) {
+				uint32_t *bp = &p.d.bitmap[(size_t)slot * 16u + (t - 20u)];
+				*bp = (stale ? 0u : *bp) | s_bm[t - 20u];
+			}
+		}
+		__syncthreads(); // every reader of win_epoch is done before thread 0 rewrites the meta record
 		if (threadIdx.x == 0) {
 			TdMeta *mt = &p.d.td_meta[slot];
 			if (s_min < mt->vmin) mt->vmin = s_min;
 			if (s_max > mt->vmax) mt->vmax = s_max;
 			mt->npend = 0;
+			mt->win_epoch = p.d.epoch;
 			p.d.batch_cnt[slot] = 0;
 		}
 		__syncthreads();
@@ -1374,6 +1430,54 @@ __global__ __launch_bounds__(256) void k_hist_add(int kind, gys_hist_rec *hist, 
 		atomicAdd((unsigned long long *)&h->stats[b].sum, (unsigned long long)v);
 		atomicAdd((unsigned long long *)&h->total_count, 1ull);
 		if (h->max_val_seen < v) atomicMax((long long *)&h->max_val_seen, (long long)v);
+	}
+}
+
+// window / all-time view of the lazily rolled records (see "Lazy window roll"); meta == nullptr: the arrays are kept eagerly
+__device__ __forceinline__ gys_hist_rec hist_view(const gys_hist_rec *win, const gys_hist_rec *all, const TdMeta *meta, uint32_t epoch, int which, uint32_t slot)
+{
+	if (!meta) return which ? all[slot] : win[slot];
+	gys_hist_rec r;
+	if (which == 0) {
+		if (meta[slot].win_epoch == epoch) return win[slot];
+		for (int i = 0; i < 15; ++i) {
+			r.stats[i].count = 0;
+			r.stats[i].sum = 0;
+		}
+		r.total_count = 0;
+		r.max_val_seen = INT64_MIN;
+		return r;
+	}
+	r = all[slot];
+	const gys_hist_rec w = win[slot];
+	for (int i = 0; i < 15; ++i) {
+		r.stats[i].count += w.stats[i].count;
+		r.stats[i].sum += w.stats[i].sum;
+	}
+	r.total_count += w.total_count;
+	if (r.max_val_seen < w.max_val_seen) r.max_val_seen = w.max_val_seen;
+	return r;
+}
+
+__global__ __launch_bounds__(256) void k_hist_view(const gys_hist_rec *win, const gys_hist_rec *all, const TdMeta *meta, uint32_t epoch, int which,
+						   uint32_t first, uint32_t n, gys_hist_rec *out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = hist_view(win, all, meta, epoch, which, first + i);
+}
+
+__global__ __launch_bounds__(256) void k_hist_percentiles_view(const gys_hist_rec *win, const gys_hist_rec *all, const TdMeta *meta, uint32_t epoch, int which,
+								       uint32_t nkeys, const float *pcts, uint32_t npct, int64_t *out)
+{
+	const HashDef &d = hash_def(GYS_RESP_TIME_HASH);
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= nkeys) return;
+	const gys_hist_rec r = hist_view(win, all, meta, epoch, which, k);
+	for (uint32_t pi = 0; pi < npct; ++pi) {
+		int64_t dv, sum;
+		uint64_t cnt;
+		hist_percentile(d, r, pcts[pi], &dv, &sum, &cnt);
+		out[(size_t)k * npct + pi] = dv;
 	}
 }
 

@@ -296,3 +296,54 @@ def test_resp_buffer_fill_and_merge_cycles(torch_mod, oracle, resp_path):
     eng.window_close()
     _compare_window(eng, orc)
     eng.close()
+
+
+@PATHS
+def test_resp_windows_roll_lazily(torch_mod, oracle, resp_path):
+    """several 5-s windows in which some hosts / services stay silent: the window view, the all-time view, the CONN_BITMAP rows and
+    the per-window registers must equal an oracle that clears / folds eagerly at every boundary (the engine rolls a key only when a
+    later window touches it), including several batches per window and a window with no events at all"""
+    rng = np.random.default_rng(31)
+    nh, sp = 3, 9
+    eng = _engine(max_hosts=4, max_services=64, max_batch_events=1 << 16, resp_path=resp_path)
+    orc_all = oracle.OracleEngine(64)   # histograms never cleared  -> all-time view
+    orc_win = oracle.OracleEngine(64)   # histograms cleared at every boundary -> window view
+    info, gids = helpers.register_world(eng, orc_all, range(nh), sp)
+    helpers.register_world(None, orc_win, range(nh), sp)
+    pcts = np.array([50.0, 95.0, 99.0], dtype=np.float32)
+    plan = [  # per window: list of (host, events, services touched)
+        [(0, 900, sp), (1, 500, sp), (2, 40, 2)],
+        [(0, 300, 3)],                                  # hosts 1, 2 silent; host 0 touches 3 of 9 services
+        [],                                             # empty window
+        [(1, 700, sp), (1, 200, 4), (0, 50, 1)],        # two batches of host 1 in one window
+        [(2, 1200, sp), (0, 10, sp)],
+    ]
+    for wnd, batches in enumerate(plan):
+        for h, n, ns in batches:
+            ev = helpers.make_resp_events(rng, h, n, ns, lat_mu=2.5 + 0.3 * wnd)
+            eng.handle_resp_events(info[h][0], ev)
+            for o in (orc_all, orc_win):
+                o.resp_batch(ev.tobytes(), [info[h][1]], [0])
+        eng.sync()
+        nsvc = orc_all.nsvc
+        helpers.assert_hist_equal(eng.export_hist(0, 0, nsvc), orc_win.hist(), nsvc)   # window view
+        helpers.assert_hist_equal(eng.export_hist(1, 0, nsvc), orc_all.hist(), nsvc)   # all-time view (folded + unfolded)
+        assert (eng.export_conn_bitmap(0, nsvc) == orc_win.bitmap()).all()
+        # the device-side per-key percentile scan sees the same views
+        torch = torch_mod
+        for which, o in ((0, orc_win), (1, orc_all)):
+            d_out = torch.zeros(nsvc * len(pcts), dtype=torch.int64, device="cuda")
+            from gyeeta_amd import capi
+            capi.check(eng.L.gys_scan_percentiles_dev(eng.h, which, pcts.ctypes.data_as(capi.f32p), len(pcts), C.c_void_p(d_out.data_ptr())))
+            eng.sync()
+            got = d_out.cpu().numpy().reshape(nsvc, len(pcts))
+            oh = o.hist()
+            for s in range(nsvc):
+                ov, _, _, _ = oracle.hist_percentiles(0, oh[s][:15], oh[s][15][0], [float(x) for x in pcts])
+                assert got[s].tolist() == ov
+        eng.window_close()
+        _compare_window(eng, orc_win)
+        for o in (orc_all, orc_win):
+            o.window_clear(clear_hist=o is orc_win)
+    _assert_path(eng, resp_path)
+    eng.close()
