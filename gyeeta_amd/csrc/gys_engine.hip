@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -408,8 +409,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	// distinct host with an LDS-sized listener table and the segments are small enough to balance; otherwise the general pipeline
 	bool host_local = td && c->cfg.resp_path != 1 && c->nsvc != 0;
 	uint32_t max_tbl = 16, max_l = 1;
+	uint64_t max_len = 0;
 	if (host_local) {
-		uint64_t max_len = 0;
 		c->batch_stamp++;
 		for (uint32_t s = 0; s < nsegs && host_local; ++s) {
 			const uint32_t host = segs_host[s].host_slot;
@@ -446,7 +447,19 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hp.svc_hll = c->svc_hll;
 		hp.svc_hll_p = c->cfg.svc_hll_p;
 		hp.lds_tbl_entries = max_tbl;
-		const size_t dyn = (size_t)max_tbl * 8 + align_up((uint64_t)max_l * 4, 8);
+		hp.lds_cnt_entries = (uint32_t)align_up(max_l, 2);
+		{
+			// LDS budget of one workgroup: sub-table + counts + the scatter region; the region is used when the longest segment
+			// fits in what is left of ~150 KiB (one 1024-thread workgroup per CU then), otherwise segments scatter straight to HBM
+			const uint64_t fixed = (uint64_t)max_tbl * 8 + (uint64_t)hp.lds_cnt_entries * 4;
+			const uint64_t budget = 150u * 1024u;
+			hp.lds_region_entries = (fixed + max_len * 4 <= budget) ? (uint32_t)align_up(max_len, 2) : 0u;
+		}
+		{
+			static const char *dbg = getenv("GYS_DBG_SKIP"); // timing experiments only: results are wrong when set
+			hp.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
+		}
+		const size_t dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_cnt_entries * 4 + (size_t)hp.lds_region_entries * 4;
 		ProfScope ps(c, "resp_host");
 		HIPCHK(hipMemsetAsync(c->huge_count, 0, 4, c->stream));
 		hipLaunchKernelGGL(k_resp_host, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
@@ -682,8 +695,8 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	ALLOC(c->hlst, c->hlst_cap);
 	ALLOC(c->hdesc, H);
 	c->host_lst.reserve(H);
-	// k_resp_host stages up to 8192 sub-table entries + 4096 counts in dynamic LDS (80 KiB of the CU's 160 KiB)
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+	// k_resp_host: up to 8192 sub-table entries + 4096 counts (80 KiB) or, for the usual small tables, a scatter region (<= 150 KiB in all)
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
 	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_tdigest) {

@@ -307,7 +307,7 @@ struct HostDesc {
 };
 
 #define GYS_HOST_TBL_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define GYS_HOST_THREADS 512
+#define GYS_HOST_THREADS 1024
 #define GYS_HOST_UNROLL 4
 
 struct RespHostP {
@@ -327,6 +327,9 @@ struct RespHostP {
 	uint8_t *svc_hll;
 	uint32_t svc_hll_p;
 	uint32_t lds_tbl_entries; // LDS table area of the launch (largest sub-table among the batch's hosts)
+	uint32_t lds_cnt_entries; // LDS count area (largest listener count, even)
+	uint32_t lds_region_entries; // LDS scatter region of the launch (u32 entries, 0 = none): segments that fit are sorted there
+	uint32_t dbg; // timing experiments only (GYS_DBG_SKIP): 1 no HLL, 2 no staged store, 4 no pass B, 8 no ev_kv store
 };
 
 __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
@@ -334,8 +337,10 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	extern __shared__ uint64_t s_dyn[];
 	__shared__ uint32_t s_wsum[GYS_HOST_THREADS / 64];
 	__shared__ uint32_t s_drop[2];
+	__shared__ uint32_t s_floor;
 	uint64_t *s_tbl = s_dyn;
 	uint32_t *s_cnt = (uint32_t *)(s_dyn + p.lds_tbl_entries);
+	uint32_t *s_region = s_cnt + p.lds_cnt_entries; // the segment's slice of `staged`, built in LDS and flushed with full-line stores
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const gys_resp_seg seg = p.segs[blockIdx.x];
 	const uint64_t e0 = seg.first_event;
@@ -346,7 +351,26 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	for (uint32_t i = tid; i <= mask; i += GYS_HOST_THREADS) s_tbl[i] = p.htbl[hd.tbl_off + i];
 	for (uint32_t i = tid; i < L; i += GYS_HOST_THREADS) s_cnt[i] = 0;
 	if (tid < 2) s_drop[tid] = 0;
+	// HLL floor: a register can only grow, so min over the register file (read once per workgroup; stale L1 lines only lower it) is a
+	// lower bound for the rest of the window -- events whose rank does not exceed it skip the register read altogether.  Late in a
+	// window that is all but ~2^-floor of the events; without it every event pays a random 4-byte read.
+	if (tid == 0) s_floor = 0xFFFFFFFFu;
 	__syncthreads();
+	if (e1 - e0 >= 4096u && !(p.dbg & 16u)) {
+		uint32_t mn = 0xFFFFFFFFu;
+		const uint4 *h4 = (const uint4 *)p.hll32;
+		for (uint32_t i = tid; i < (1u << GYS_HLL_P) / 4u; i += GYS_HOST_THREADS) {
+			const uint4 v = h4[i];
+			mn = min(min(mn, min(v.x, v.y)), min(v.z, v.w));
+		}
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
+		if (lane == 0) atomicMin(&s_floor, mn);
+	} else if (tid == 0) {
+		s_floor = 0;
+	}
+	__syncthreads();
+	const uint32_t hll_floor = s_floor;
 
 	// ---- pass A: resolve, filter, count.  GYS_HOST_UNROLL events per thread and iteration, phase by phase (all event loads, then all
 	// the arithmetic, then all HLL register reads, then the updates) so that each wave keeps several HBM requests in flight.
@@ -400,16 +424,17 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 			kv[u] = ((uint64_t)local << 32) | GYS_STAGED_WORD(tresp, dport);
 			const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
 			hll_idx_rank(h64, GYS_HLL_P, &hidx[u], &hrank[u]);
+			if (hrank[u] <= hll_floor) hrank[u] = 0; // cannot raise any register
 			if (p.svc_hll_p) svc_hll_update(p.svc_hll, p.svc_hll_p, p.hlst[hd.lst_off + local], h64);
 		}
 #pragma unroll
-		for (int u = 0; u < GYS_HOST_UNROLL; ++u) hcur[u] = hrank[u] ? p.hll32[hidx[u]] : 0xFFu; // read-first: most events do not raise the register
+		for (int u = 0; u < GYS_HOST_UNROLL; ++u) hcur[u] = (hrank[u] && !(p.dbg & 1u)) ? p.hll32[hidx[u]] : 0xFFu; // read-first: most events do not raise the register
 #pragma unroll
 		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
 			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
 			if (hcur[u] < hrank[u]) atomicMax(&p.hll32[hidx[u]], hrank[u]);
 			if (kv[u] != ~0ull) atomicAdd(&s_cnt[(uint32_t)(kv[u] >> 32)], 1u);
-			if (i < e1) p.ev_kv[i] = kv[u];
+			if (i < e1 && !(p.dbg & 8u)) p.ev_kv[i] = kv[u];
 		}
 	}
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
@@ -446,8 +471,11 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	}
 	__syncthreads();
 
-	// ---- pass B: scatter the staged words into the key runs (positions from LDS atomics)
-	for (uint64_t base = e0 + tid; base < e1; base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
+	// ---- pass B: scatter the staged words into the key runs (positions from LDS atomics).  A scattered 4-byte store that leaves L2
+	// before its line is complete becomes a read-modify-write in HBM, so when the segment's slice fits the LDS region the runs are
+	// assembled there and written out with coalesced full-line stores.
+	const bool in_lds = (e1 - e0) <= (uint64_t)p.lds_region_entries;
+	for (uint64_t base = e0 + tid; base < e1 && !(p.dbg & 4u); base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
 		uint64_t kv[GYS_HOST_UNROLL];
 #pragma unroll
 		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
@@ -458,8 +486,14 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
 			if (kv[u] == ~0ull) continue;
 			const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)(kv[u] >> 32)], 1u);
-			p.staged[e0 + pos] = (uint32_t)kv[u];
+			if (in_lds) s_region[pos] = (uint32_t)kv[u];
+			else if (!(p.dbg & 2u)) p.staged[e0 + pos] = (uint32_t)kv[u];
 		}
+	}
+	if (in_lds) {
+		__syncthreads();
+		const uint32_t nvalid = (uint32_t)(e1 - e0) - s_drop[0] - s_drop[1];
+		for (uint32_t i = tid; i < nvalid; i += GYS_HOST_THREADS) p.staged[e0 + i] = s_region[i];
 	}
 	if (tid == 0) {
 		atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
