@@ -7,6 +7,12 @@ Hosts are sharded over ranks by GY_MACHINE_ID::get_hash() % N (SURVEY 8e); every
 drawn over ITS hosts (weak scaling in events) and one step = one 5-second window: ingest one device-resident batch, then the
 window close (RCCL all-reduce of the HLL / CMS / histogram / cluster registers over xGMI + local roll).
 
+Events per window: 2^28 per GPU by default = a 5-s window at 54 M events/s/GPU (the north-star rate of 1 G events/s on 8 GPUs
+would put 2^29.2 events into each GPU's window); 4 steps ingest the 2^30 events SURVEY 8d quotes per C3 run.  A key re-clusters
+its t-digest once per ~256 values (every ~9.5 windows at ~27 events per key and window); an untimed set-up pass spreads the keys'
+buffer fill levels evenly and then runs one full buffer cycle of ordinary windows, so that EVERY timed window, whatever
+--steps/--warmup, carries its long-run share of (steady-state, non-empty-digest) merges.
+
 One process per GPU (torchrun env RANK/LOCAL_RANK/WORLD_SIZE); rank 0 prints ONE JSON line.
 """
 import argparse
@@ -60,17 +66,36 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed):
     return nevents / (t1 - t0), nevents / (t2 - t1), desc
 
 
+def pmc_traffic(kernel, events, nsvc):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by
+    tools/pmc_collect.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950).  Only reported when the PMC run used this very workload; otherwise null."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return None
+    if t.get("events_per_launch") != events or t.get("service_keys") != nsvc:
+        return None
+    k = t.get("kernels", {}).get(kernel)
+    if not k:
+        return None
+    return {"bytes": k["fetch_bytes"] + k["write_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
+            "source": t.get("source", "profiles/pmc_traffic.json")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--hosts", type=int, default=10000, help="total hosts across all ranks")
     ap.add_argument("--svcs", type=int, default=1000, help="services per host")
-    ap.add_argument("--events", type=int, default=1 << 26, help="events per rank per step (one window)")
+    ap.add_argument("--events", type=int, default=1 << 28, help="events per rank per step (one window)")
     ap.add_argument("--zipf-milli", type=int, default=0, help="0 = uniform over services, else Zipf s*1000 (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-events", type=int, default=1 << 23)
+    ap.add_argument("--no-dephase", action="store_true", help="skip the untimed pass that spreads the keys' buffer fill levels")
+    ap.add_argument("--prime-windows", type=int, default=-1, help="untimed ordinary windows after the de-phase pass (-1: one buffer cycle)")
+    ap.add_argument("--cpu-events", type=int, default=1 << 26)
     ap.add_argument("--cpu-hosts", type=int, default=1000)
     args = ap.parse_args()
 
@@ -119,6 +144,30 @@ def main():
         bufs.append(ev)
     eng.sync()
 
+    # de-phase the per-key t-digest buffers (untimed set-up): with identical rates and an identical start every key would overflow
+    # its 256-value buffer in the same window (one window of 10^7 merges, then ~9 windows of none).  One pass of ~127 events per key
+    # on average, drawn with per-service weights spread over 0..255/256, leaves the fill levels evenly spread, so that from the first
+    # warm-up window on every window carries its long-run share of merges (events / ~270 per window).
+    if args.prime_windows < 0:  # one full buffer cycle: 256 values at events/keys values per window, plus one
+        args.prime_windows = min(40, int(256 * nsvc / max(args.events, 1)) + 2) if nsvc else 0
+    if not args.no_dephase and nsvc:
+        total = nsvc * 127
+        nb = max(1, -(-total // args.events))
+        per = min(args.events, total // nb)
+        for b in range(nb):
+            sg = eng.gen_resp_events(bufs[0].data_ptr(), per, 0xdef0 + 77 * b + rank, 0, nlocal, args.svcs, 0xFFFFFFFF)
+            eng.handle_resp_events_dev(sg, bufs[0].data_ptr(), per)
+        eng.window_close(tusec=0)
+        segs[0] = eng.gen_resp_events(bufs[0].data_ptr(), args.events, 0x67796565746121 + 1000 * rank, 0, nlocal, args.svcs, args.zipf_milli)
+        eng.sync()
+        # ... and one full buffer cycle of ordinary windows, so that every key has re-clustered at least once: a production engine's
+        # digests are never empty, and a key's very first merge (no clusters yet, all values in one interval) is its most expensive
+        for i in range(args.prime_windows):
+            b = i % nbuf
+            eng.handle_resp_events_dev(segs[b], bufs[b].data_ptr(), args.events)
+            eng.window_close(tusec=0)
+        eng.sync()
+
     def step(i):
         b = i % nbuf
         eng.handle_resp_events_dev(segs[b], bufs[b].data_ptr(), args.events)
@@ -151,6 +200,7 @@ def main():
         # dominant kernel = largest accumulated HIP-event time on the engine stream inside the timed region
         dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 0))
         dom_ms_avg = dom[1][0] / max(dom[1][1], 1)
+        traffic = pmc_traffic(dom[0], args.events, nsvc)
         alg_bytes = EVENT_BYTES * args.events  # per launch: every launch of the pipeline touches each of the batch's events once
         achieved = alg_bytes / (dom_ms_avg * 1e-3) / 1e9 if dom_ms_avg > 0 else 0.0
         out = {
@@ -165,7 +215,7 @@ def main():
                        "service_keys_rank0": nsvc, "sketches": "exact RESP_TIME_HASH histogram + CONN_BITMAP + HLL p=14 + CMS 4x65536 + t-digest 100 clusters/key",
                        "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_ms": dom_ms_avg, "algorithmic_bytes_per_launch": alg_bytes,
                          "kernels_ms_avg": {k: v[0] / max(v[1], 1) for k, v in prof.items()}},
         }

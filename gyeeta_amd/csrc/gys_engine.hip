@@ -1534,6 +1534,8 @@ int gys_gen_resp_events_dev(gys_ctx *c, void *d_ev24, uint64_t nevents, uint64_t
 			    uint32_t zipf_milli, gys_resp_seg *segs_out)
 {
 	if (!c || !d_ev24 || !nhosts || !svcs_per_host || !segs_out) return GYS_ERR_INVAL;
+	const bool spread = zipf_milli == GYS_GEN_SPREAD; // per-service weights 0..255/256 instead of a Zipf law
+	if (spread) zipf_milli = 0;
 	if (zipf_milli && (c->zipf_n != svcs_per_host || c->zipf_milli != zipf_milli)) {
 		std::vector<float> cdf(svcs_per_host);
 		const double s = zipf_milli / 1000.0;
@@ -1563,6 +1565,7 @@ int gys_gen_resp_events_dev(gys_ctx *c, void *d_ev24, uint64_t nevents, uint64_t
 	g.nhosts = nhosts;
 	g.svcs_per_host = svcs_per_host;
 	g.zipf_cdf = zipf_milli ? c->zipf_cdf : nullptr;
+	g.spread = spread ? 1u : 0u;
 	g.per_host = std::max<uint64_t>(1, nevents / nhosts);
 	for (uint32_t h = 0; h < nhosts; ++h) {
 		segs_out[h].host_slot = first_host + h;

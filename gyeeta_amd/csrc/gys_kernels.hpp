@@ -1572,6 +1572,7 @@ struct GenP {
 	uint64_t seed;
 	uint32_t first_host, nhosts, svcs_per_host;
 	const float *zipf_cdf; // [svcs_per_host] or nullptr (uniform)
+	uint32_t spread;       // 1: service s of host h is drawn with weight (hash(h,s) & 255) / 256 (rejection sampling)
 	uint64_t per_host;
 };
 
@@ -1597,6 +1598,15 @@ __global__ __launch_bounds__(256) void k_gen_resp(GenP g)
 			s = lo;
 		} else {
 			s = (uint32_t)((r0 >> 32) % g.svcs_per_host);
+			if (g.spread) { // per-service weights spread over 0..255/256: used once, before a benchmark, to de-phase the keys' buffers
+				uint64_t rr = r0;
+				for (int t = 0; t < 16; ++t) {
+					const uint32_t wgt = (uint32_t)(splitmix64(((uint64_t)h << 20) + s + 0x7654321ull) & 255u);
+					rr = splitmix64(rr + 0x51ull);
+					if ((uint32_t)(rr & 255u) < wgt) break;
+					s = (uint32_t)((rr >> 32) % g.svcs_per_host);
+				}
+			}
 		}
 		// per-service mu ~ N(3,1) from a hash of (h,s); event latency lognormal(mu, 1.5) by Box-Muller
 		const uint64_t hs = splitmix64(((uint64_t)h << 20) + s + 0x1234567ull);

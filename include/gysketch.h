@@ -272,6 +272,10 @@ int gys_profile_get(gys_ctx *ctx, const char *kernel, double *total_ms, uint64_t
 int gys_profile_names(gys_ctx *ctx, char *buf, size_t buflen); /* comma separated */
 
 /* synthetic stream generators running ON the GPU (bench/test plumbing).  They write into caller DEVICE buffers. */
+/* zipf_milli: 0 = services uniform; s*1000 = Zipf(s) over the services of a host; GYS_GEN_SPREAD = service weights spread evenly
+ * over 0..255/256 (bench.py uses one such pass before timing so that the keys' t-digest buffers start at evenly spread fill levels
+ * -- with identical rates and identical start all keys would otherwise overflow in the same window) */
+#define GYS_GEN_SPREAD 0xFFFFFFFFu
 int gys_gen_resp_events_dev(gys_ctx *ctx, void *d_ev24, uint64_t nevents, uint64_t seed, uint32_t first_host, uint32_t nhosts,
 			    uint32_t svcs_per_host, uint32_t zipf_milli /* 0 = uniform, else s*1000 */, gys_resp_seg *segs_out /* host, nhosts */);
 

@@ -6,8 +6,8 @@ O=$R/gpurun_out/$T
 mkdir -p $O
 cd $R
 (timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25) > $O/pytest.log
-timeout 300 python bench.py --no-cpu-baseline --events $((1<<26)) --steps 10 --warmup 3 "$@" > $O/bench_2p26.json 2> $O/bench.err
-timeout 300 python bench.py --no-cpu-baseline --events $((1<<28)) --steps 10 --warmup 12 "$@" > $O/bench_2p28.json 2>> $O/bench.err
+timeout 300 python bench.py --no-cpu-baseline --events $((1<<26)) --steps 10 --warmup 3 --prime-windows 12 "$@" > $O/bench_2p26.json 2> $O/bench.err
+timeout 300 python bench.py --no-cpu-baseline --events $((1<<28)) --steps 10 --warmup 3 "$@" > $O/bench_2p28.json 2>> $O/bench.err
 cat $O/pytest.log
 for f in $O/bench_2p26.json $O/bench_2p28.json; do python - $f <<'PY'
 import json, sys
