@@ -66,6 +66,53 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed):
     return nevents / (t1 - t0), nevents / (t2 - t1), desc
 
 
+def quantile_error(eng, torch, ingested, nlocal, svcs, host_ids, host_slots, wire):
+    """Second half of BASELINE.json's metric: p50 / p99 of the engine's t-digests against the EXACT quantiles of everything the run fed
+    them.  Untimed, after the run: every distinct batch is regenerated (the generator is deterministic), the segments of two hosts
+    (first and last slot: 2 x svcs service keys) are pulled to the CPU and each key's full value multiset is rebuilt with the number
+    of times its batch was ingested; rank error = distance of the engine's quantile from the [left, right] rank interval of that
+    value in the sorted data (the north-star tolerance is 0.01)."""
+    tmp = torch.empty(max(n for n, _, _, _ in ingested) * EVENT_BYTES, dtype=torch.uint8, device="cuda")
+    per_key = [[dict() for _ in range(svcs)] for _ in host_slots]
+    for n, seed, code, times in ingested:
+        if times == 0:
+            continue
+        sg = eng.gen_resp_events(tmp.data_ptr(), n, seed, 0, nlocal, svcs, code)
+        eng.sync()
+        for hi, slot in enumerate(host_slots):
+            lo = sg[slot].first_event
+            hi_e = sg[slot + 1].first_event if slot + 1 < nlocal else n
+            a = np.frombuffer(tmp[lo * EVENT_BYTES:hi_e * EVENT_BYTES].cpu().numpy().tobytes(), dtype=wire.RESP_EVENT)
+            lat = (a["lsndtime"] - a["lrcvtime"]).astype(np.int64)
+            svc = a["sport_be"].astype(np.int64) - 1024  # wire.listener_port(s) = 1024 + s for s < 60000 (network-order field name)
+            ok = (lat >= 0) & (lat <= 1000000) & (svc >= 0) & (svc < svcs)
+            lat, svc = lat[ok], svc[ok]
+            order = np.argsort(svc, kind="stable")
+            lat, svc = lat[order], svc[order]
+            cuts = np.searchsorted(svc, np.arange(svcs + 1))
+            for s_idx in range(svcs):
+                if cuts[s_idx + 1] > cuts[s_idx]:
+                    per_key[hi][s_idx][len(per_key[hi][s_idx])] = (lat[cuts[s_idx]:cuts[s_idx + 1]], times)
+    res = {"p50": [], "p99": []}
+    for hi, h in enumerate(host_ids):
+        gids = wire.glob_id(np.full(svcs, h), np.arange(svcs))
+        for s_idx in range(svcs):
+            parts = per_key[hi][s_idx]
+            if not parts:
+                continue
+            vals = np.concatenate([np.repeat(v, t) for v, t in parts.values()])
+            x = np.sort(vals)
+            got = eng.quantiles(int(gids[s_idx]), [0.5, 0.99])
+            for q, g, name in ((0.5, got[0], "p50"), (0.99, got[1], "p99")):
+                lo = np.searchsorted(x, g, side="left") / len(x)
+                hi_r = np.searchsorted(x, g, side="right") / len(x)
+                res[name].append(0.0 if lo <= q <= hi_r else min(abs(lo - q), abs(hi_r - q)))
+    return {"keys_checked": len(res["p50"]), "tolerance": 0.01,
+            "p50_rank_err_max": float(np.max(res["p50"])), "p50_rank_err_mean": float(np.mean(res["p50"])),
+            "p99_rank_err_max": float(np.max(res["p99"])), "p99_rank_err_mean": float(np.mean(res["p99"])),
+            "reference": "exact sort of every value the run ingested for the key (the reference's own answer is a RESP_TIME_HASH bucket ceiling)"}
+
+
 def pmc_traffic(kernel, events, nsvc):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by
     tools/pmc_collect.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
@@ -93,8 +140,10 @@ def main():
     ap.add_argument("--events", type=int, default=1 << 28, help="events per rank per step (one window)")
     ap.add_argument("--zipf-milli", type=int, default=0, help="0 = uniform over services, else Zipf s*1000 (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-quantile-check", action="store_true", help="skip the (untimed) t-digest rank-error check after the run")
     ap.add_argument("--no-dephase", action="store_true", help="skip the untimed pass that spreads the keys' buffer fill levels")
     ap.add_argument("--prime-windows", type=int, default=-1, help="untimed ordinary windows after the de-phase pass (-1: one buffer cycle)")
+    ap.add_argument("--nbuf", type=int, default=6, help="distinct device-resident event batches the windows cycle through")
     ap.add_argument("--cpu-events", type=int, default=1 << 26)
     ap.add_argument("--cpu-hosts", type=int, default=1000)
     args = ap.parse_args()
@@ -136,7 +185,8 @@ def main():
             eng.handle_host_state(mids[h], ntasks=100, nlisten=args.svcs)
 
     # two device-resident batches, generated on the GPU before the timed region
-    nbuf = 2
+    nbuf = max(2, args.nbuf)  # distinct resident batches the windows cycle through (6 x 6.4 GB by default; 288 GB of HBM)
+    buf_uses = [0] * nbuf
     bufs, segs = [], []
     for b in range(nbuf):
         ev = torch.empty(args.events * EVENT_BYTES, dtype=torch.uint8, device="cuda")
@@ -148,6 +198,7 @@ def main():
     # its 256-value buffer in the same window (one window of 10^7 merges, then ~9 windows of none).  One pass of ~127 events per key
     # on average, drawn with per-service weights spread over 0..255/256, leaves the fill levels evenly spread, so that from the first
     # warm-up window on every window carries its long-run share of merges (events / ~270 per window).
+    ingested = []  # (nevents, seed, zipf/spread code, times): everything the engine was fed, for the quantile-error check
     if args.prime_windows < 0:  # one full buffer cycle: 256 values at events/keys values per window, plus one
         args.prime_windows = min(40, int(256 * nsvc / max(args.events, 1)) + 2) if nsvc else 0
     if not args.no_dephase and nsvc:
@@ -157,6 +208,7 @@ def main():
         for b in range(nb):
             sg = eng.gen_resp_events(bufs[0].data_ptr(), per, 0xdef0 + 77 * b + rank, 0, nlocal, args.svcs, 0xFFFFFFFF)
             eng.handle_resp_events_dev(sg, bufs[0].data_ptr(), per)
+            ingested.append([per, 0xdef0 + 77 * b + rank, 0xFFFFFFFF, 1])
         eng.window_close(tusec=0)
         segs[0] = eng.gen_resp_events(bufs[0].data_ptr(), args.events, 0x67796565746121 + 1000 * rank, 0, nlocal, args.svcs, args.zipf_milli)
         eng.sync()
@@ -166,12 +218,14 @@ def main():
             b = i % nbuf
             eng.handle_resp_events_dev(segs[b], bufs[b].data_ptr(), args.events)
             eng.window_close(tusec=0)
+            buf_uses[b] += 1
         eng.sync()
 
     def step(i):
         b = i % nbuf
         eng.handle_resp_events_dev(segs[b], bufs[b].data_ptr(), args.events)
         eng.window_close(tusec=5_000_000 * (i + 1))
+        buf_uses[b] += 1
 
     for i in range(args.warmup):
         step(i)
@@ -194,6 +248,11 @@ def main():
     prof = eng.profile_get()
     eng.profile(False)
 
+    qerr = None
+    if rank == 0 and not args.no_quantile_check and nsvc:
+        for b in range(nbuf):
+            ingested.append([args.events, 0x67796565746121 + 1000 * rank + b, args.zipf_milli, buf_uses[b]])
+        qerr = quantile_error(eng, torch, ingested, nlocal, args.svcs, [mine[0], mine[-1]], [0, nlocal - 1], wire)
     if rank == 0:
         total_events = args.events * world * args.steps
         value = total_events / dt
@@ -219,6 +278,8 @@ def main():
                          "avg_ms": dom_ms_avg, "algorithmic_bytes_per_launch": alg_bytes,
                          "kernels_ms_avg": {k: v[0] / max(v[1], 1) for k, v in prof.items()}},
         }
+        if qerr is not None:
+            out["quantile_error"] = qerr
         if not args.no_cpu_baseline:
             full, honly, desc = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234)
             out["cpu_baseline"] = {"value": full, "unit": "events/s", "cores": 1, "kind": "port", "sample": desc,

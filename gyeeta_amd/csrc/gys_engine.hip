@@ -533,6 +533,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		mp.d = d;
 		mp.list = c->merge_list;
 		mp.count = c->merge_count;
+		{
+			static const char *dbg = getenv("GYS_DBG_SKIP");
+			mp.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
+		}
 		const uint32_t mgrid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nsvc, n), (uint64_t)c->ncu * 32);
 		hipLaunchKernelGGL(k_digest_merge<128u>, dim3(mgrid), dim3(64), 0, c->stream, mp);
 		hipLaunchKernelGGL(k_digest_merge<GYS_SMALL_MAX>, dim3(std::min<uint32_t>(mgrid, (uint32_t)c->ncu * 8)), dim3(64), 0, c->stream, mp);

@@ -789,13 +789,23 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 	if (threadIdx.x == 31u && s_gmax != INT64_MIN) atomicMax(p.gmax, s_gmax);
 }
 
+// quarter-octave grid cell of a value < 2^20: 0,1,2,3 for 0..3, then 4 cells per power of two (monotone; <= 75)
+__device__ __forceinline__ uint32_t value_grid(uint32_t v)
+{
+	if (v < 4u) return v;
+	const uint32_t msb = 31u - (uint32_t)__clz((int)v);
+	return 4u * (msb - 1u) + ((v >> (msb - 2u)) & 3u);
+}
+#define GYS_IVL 192u // refined intervals: gap index (<= 100) + grid cell (<= 75) < 192 = 3 per lane
+
 // ---- k_digest_merge: one 64-thread workgroup (= one wave) per merge-list entry.  Exact-integer k-bucket merge (DESIGN.md "t-digest"):
 //   values = the key's buffered values + the batch's new values; merged order = by mean, old clusters before values on ties; an item
 //   with weighted mid-point mid2/2 of N goes to cluster #{j : mid2 >= T_j}, T_j = ceil(BND[j] * 2N / 2^32).
-// No sort: the (<= 100) old cluster means cut the value axis into intervals; interval(v) = #{clusters with mean <= v} comes from a
-// binary search, a counting sort by interval groups the values in LDS, and a value's rank is (values in lower intervals) + (its
-// rank inside its own interval, by direct comparison -- a digest's clusters track the distribution, so an interval holds a handful
-// of the batch's values).  Old cluster c is preceded by exactly the values of intervals 0..c.  Everything else is integer
+// No sort: the (<= 100) old cluster means cut the value axis into gaps; gap(v) = #{clusters with mean <= v} comes from a branch-free
+// search; the gaps are refined by a fixed quarter-octave value grid (so a cell stays small even when the digest is empty or the
+// distribution has moved away from its clusters); a counting sort by refined interval groups the values in LDS, and a value's rank
+// is (values in lower intervals) + (its rank inside its own interval, by direct comparison -- an interval holds a handful of the
+// batch's values, all equal for typical integer-ms data).  Old cluster c is preceded by exactly the values of gaps 0..c.  Everything else is integer
 // arithmetic on ranks, so the result equals the sorted-merge definition bit for bit (ties among equal values are interchangeable).
 // query mode (out_sum != nullptr): entry w writes the merged view of its key to out_sum/out_cnt[w*100..] and leaves the state alone.
 #define GYS_MERGE_MAX (GYS_TD_PEND_CAP + GYS_SMALL_MAX)
@@ -806,6 +816,7 @@ struct MergeP {
 	const uint32_t *count;
 	int64_t *out_sum;
 	uint32_t *out_cnt;
+	uint32_t dbg; // timing experiments only (GYS_DBG_SKIP bit 32: no value grid)
 };
 
 // Two instantiations share the list: NEWMAX = 128 (LDS for 384 values: the common case, ~2x the resident waves) takes the entries with
@@ -820,11 +831,12 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 	__shared__ uint32_t s_ccnt[128];
 	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
 	__shared__ uint64_t s_T[128];            // s_T[j], j = 1..NB-1; [NB..127] = ~0 (never reached)
-	__shared__ uint32_t s_imin[GYS_TD_NB + 1], s_imax[GYS_TD_NB + 1]; // smallest / largest value of each interval
+	__shared__ uint32_t s_imin[GYS_IVL], s_imax[GYS_IVL]; // smallest / largest value of each interval
 	__shared__ unsigned long long s_osum[GYS_TD_NB];
 	__shared__ uint32_t s_ocnt[GYS_TD_NB];
-	__shared__ uint32_t s_icnt[GYS_TD_NB + 1]; // values per interval, then the running scatter cursor
-	__shared__ uint32_t s_ioff[GYS_TD_NB + 2]; // exclusive prefix of s_icnt (s_ioff[i + 1] = values in intervals 0..i)
+	__shared__ uint32_t s_icnt[GYS_IVL];     // values per (refined) interval, then the running scatter cursor
+	__shared__ uint32_t s_ioff[GYS_IVL + 1]; // exclusive prefix of s_icnt (s_ioff[i + 1] = values in intervals 0..i)
+	__shared__ uint32_t s_clt[GYS_TD_NB + 2]; // s_clt[c + 1] = values below the mean of compacted cluster c (prefix of the per-cluster-gap counts)
 	const uint32_t lane = threadIdx.x;
 	const uint32_t nent = *q.count;
 
@@ -887,17 +899,16 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 		s_T[j1] = j1 < GYS_TD_NB ? td_threshold(c_td_bnd[j1], twoN) : ~0ull;
 		s_osum[lane] = 0;
 		s_ocnt[lane] = 0;
-		s_icnt[lane] = 0;
-		s_imin[lane] = 0xFFFFFFFFu;
-		s_imax[lane] = 0;
+		for (uint32_t i = lane; i < GYS_IVL; i += 64u) {
+			s_icnt[i] = 0;
+			s_imin[i] = 0xFFFFFFFFu;
+			s_imax[i] = 0;
+		}
+		s_clt[lane] = 0;
+		if (j1 < GYS_TD_NB + 2) s_clt[j1] = 0;
 		if (j1 < GYS_TD_NB) {
 			s_osum[j1] = 0;
 			s_ocnt[j1] = 0;
-		}
-		if (j1 < GYS_TD_NB + 1) {
-			s_icnt[j1] = 0;
-			s_imin[j1] = 0xFFFFFFFFu;
-			s_imax[j1] = 0;
 		}
 		__syncthreads();
 		// ---- values (buffered, then new): interval = first cluster with mean > v  (csum > v * ccnt), counted per interval
@@ -912,31 +923,48 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 					const uint32_t c = lo + step - 1u;
 					if (s_csum[c] <= v * (int64_t)s_ccnt[c]) lo += step;
 				}
-				s_x[i] = (lo << 20) | uv;
-				atomicAdd(&s_icnt[lo], 1u);
-				atomicMin(&s_imin[lo], uv);
-				atomicMax(&s_imax[lo], uv);
+				// refined interval: the cluster means AND a fixed quarter-octave value grid cut the axis (both monotone in v, so their
+				// sum numbers the cells of the common refinement in value order); the grid bounds a cell's population when the digest
+				// is still empty or the distribution has moved away from its clusters
+				const uint32_t iv = lo + ((q.dbg & 32u) ? 0u : value_grid(uv));
+				s_x[i] = (iv << 20) | uv;
+				atomicAdd(&s_icnt[iv], 1u);
+				atomicMin(&s_imin[iv], uv);
+				atomicMax(&s_imax[iv], uv);
+				atomicAdd(&s_clt[lo + 1], 1u);
 			}
 		}
 		__syncthreads();
-		// ---- exclusive scan of the interval counts (<= 101 entries: lane, lane + 64)
+		// ---- exclusive scan of the refined-interval counts (GYS_IVL = 3 x 64 entries: 3 consecutive per lane) and inclusive scan of
+		// the per-cluster-gap counts (s_clt[c + 1] := values in cluster gaps 0..c = values below the mean of cluster c)
 		{
-			const uint32_t a0 = lane <= nc ? s_icnt[lane] : 0u;
-			const uint32_t a1 = j1 <= nc ? s_icnt[j1] : 0u;
-			uint32_t i0 = a0, i1 = a1;
+			const uint32_t t0 = s_icnt[3u * lane], t1 = s_icnt[3u * lane + 1u], t2 = s_icnt[3u * lane + 2u];
+			const uint32_t own = t0 + t1 + t2;
+			uint32_t inc = own;
+			uint32_t g0 = s_clt[lane], g1 = j1 < GYS_TD_NB + 2 ? s_clt[j1] : 0u;
+			const uint32_t h0 = g0, h1 = g1;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t t0 = __shfl_up(i0, d, 64), t1 = __shfl_up(i1, d, 64);
+				const uint32_t u = __shfl_up(inc, d, 64), u0 = __shfl_up(g0, d, 64), u1 = __shfl_up(g1, d, 64);
 				if ((int)lane >= d) {
-					i0 += t0;
-					i1 += t1;
+					inc += u;
+					g0 += u0;
+					g1 += u1;
 				}
 			}
-			const uint32_t tot0 = __shfl(i0, 63, 64);
-			s_ioff[lane] = i0 - a0;
-			s_icnt[lane] = i0 - a0; // scatter cursor
-			if (j1 < GYS_TD_NB + 2) s_ioff[j1] = tot0 + i1 - a1;
-			if (j1 < GYS_TD_NB + 1) s_icnt[j1] = tot0 + i1 - a1;
+			const uint32_t ex = inc - own;
+			s_ioff[3u * lane] = ex;
+			s_ioff[3u * lane + 1u] = ex + t0;
+			s_ioff[3u * lane + 2u] = ex + t0 + t1;
+			if (lane == 63u) s_ioff[GYS_IVL] = inc;
+			s_icnt[3u * lane] = ex; // scatter cursors
+			s_icnt[3u * lane + 1u] = ex + t0;
+			s_icnt[3u * lane + 2u] = ex + t0 + t1;
+			const uint32_t gt0 = __shfl(g0, 63, 64);
+			(void)h0;
+			(void)h1;
+			s_clt[lane] = g0;
+			if (j1 < GYS_TD_NB + 2) s_clt[j1] = gt0 + g1;
 		}
 		__syncthreads();
 		for (uint32_t i = lane; i < m; i += 64u) {
@@ -947,7 +975,7 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 		// ---- old clusters: preceded by the old clusters before them and by the values of intervals 0..c (= values below the mean)
 		for (uint32_t c = lane; c < nc; c += 64u) {
 			const uint32_t cc = s_ccnt[c];
-			const uint64_t mid2 = 2ull * (s_cpfx[c] + (uint64_t)s_ioff[c + 1]) + (uint64_t)cc;
+			const uint64_t mid2 = 2ull * (s_cpfx[c] + (uint64_t)s_clt[c + 1]) + (uint64_t)cc;
 			const uint32_t a = td_cluster_of128(s_T, mid2);
 			atomicAdd(&s_osum[a], (unsigned long long)s_csum[c]);
 			atomicAdd(&s_ocnt[a], cc);
@@ -965,7 +993,7 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 					r += (y < x || (y == x && u < e)) ? 1u : 0u;
 				}
 			}
-			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[iv]) + 1ull;
+			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[iv - ((q.dbg & 32u) ? 0u : value_grid(x & 0xFFFFFu))]) + 1ull; // old weight with mean <= v
 			const uint32_t a = td_cluster_of128(s_T, mid2);
 			atomicAdd(&s_osum[a], (unsigned long long)(x & 0xFFFFFu));
 			atomicAdd(&s_ocnt[a], 1u);
