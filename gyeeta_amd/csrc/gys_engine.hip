@@ -422,7 +422,13 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			max_tbl = std::max<uint32_t>(max_tbl, (uint32_t)hl.tbl.size());
 			max_l = std::max<uint32_t>(max_l, (uint32_t)hl.slots.size());
 		}
-		if (host_local && c->cfg.resp_path == 0) host_local = max_len <= (1u << 15) || (nsegs >= 128 && max_len <= (1u << 20));
+		if (host_local && c->cfg.resp_path == 0) {
+			// one workgroup walks a whole segment (~0.26 G events/s each, ncu of them at a time); the general pipeline spreads any
+			// batch over the whole chip at ~7 G events/s: take whichever model is faster, small batches always host-local
+			const double t_host = (double)((nsegs + c->ncu - 1) / c->ncu) * (double)max_len / 0.26e9;
+			const double t_general = (double)n / 7.0e9 + 20e-6;
+			host_local = max_len <= (1u << 15) || t_host <= t_general;
+		}
 	}
 	const uint32_t nsvc = c->nsvc;
 	uint32_t *cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;

@@ -832,6 +832,33 @@ int gyo_tcp_conn_decode(const uint8_t *batch, int nrec, const uint8_t *pend, uin
 	return i;
 }
 
+/* whole-batch form of the TCP_CONN_NOTIFY roll-up used by the engine: walk (:9130), flow key into the distinct-flow HLL, service key
+ * (ser_glob_id_) into the Count-Min rows (connection count and bytes_sent_ + bytes_rcvd_).  Returns the records walked. */
+int gyo_tcp_conn_sketch_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint8_t *hll, uint32_t *cms32, uint64_t *cms64)
+{
+	const uint8_t *p = batch;
+	int i;
+
+	for (i = 0; i < nrec && p < pend; ++i, p += gyo_tcp_conn_elem_size(p)) {
+		const uint8_t *cip, *sip;
+		int c6, s6;
+		uint16_t cport, sport;
+		uint32_t w[10], gw[2], nw;
+		uint64_t gid;
+
+		rd_ip_port(p + 64, &cip, &c6, &cport);
+		rd_ip_port(p + 96, &sip, &s6, &sport);
+		nw = gyo_pair_ip_port_words(cip, c6, cport, sip, s6, sport, w);
+		gyo_hll_add_words(hll, GYO_HLL_P, w, nw);
+		gid = rd_u64(p + 192);
+		gw[0] = (uint32_t)(gid & 0xFFFFFFFFu);
+		gw[1] = (uint32_t)(gid >> 32);
+		gyo_cms_add(cms32, gw, 2, 1);
+		gyo_cms64_add(cms64, gw, 2, rd_u64(p + 208) + rd_u64(p + 216));
+	}
+	return i;
+}
+
 /* CLUSTER_STATE_ONE::update_from_state server/gy_mconnhdlr.cc:16032-16050 */
 void gyo_cluster_state_update(gyo_cluster_state_one *c, uint32_t ntasks_issue, uint32_t ntasks, uint32_t nlisten_issue,
 			      uint32_t nlisten, uint32_t cpu_issue, uint32_t mem_issue, const gyo_listen_summ_stats *summ)

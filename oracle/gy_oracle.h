@@ -182,6 +182,7 @@ uint32_t gyo_tcp_conn_elem_size(const uint8_t *rec);
  * (gy_mconnhdlr.cc:8707), ser_glob_id_, bytes_sent_, bytes_rcvd_; returns number of records walked */
 int gyo_tcp_conn_decode(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *keywords /*[nrec*10]*/, uint32_t *nwords,
 			uint64_t *ser_glob_id, uint64_t *bytes_sent, uint64_t *bytes_rcvd, uint8_t *flags);
+int gyo_tcp_conn_sketch_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint8_t *hll, uint32_t *cms32, uint64_t *cms64);
 void gyo_cluster_state_update(gyo_cluster_state_one *c, uint32_t ntasks_issue, uint32_t ntasks, uint32_t nlisten_issue,
 			      uint32_t nlisten, uint32_t cpu_issue, uint32_t mem_issue, const gyo_listen_summ_stats *summ);
 void gyo_cluster_state_add(gyo_cluster_state_one *dst, const gyo_cluster_state_one *src);

@@ -151,6 +151,7 @@ def lib():
     _sig(L, "gyo_listener_state_elem_size", C.c_uint32, [C.c_void_p])
     _sig(L, "gyo_tcp_conn_elem_size", C.c_uint32, [C.c_void_p])
     _sig(L, "gyo_tcp_conn_decode", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u32p, u32p, u64p, u64p, u64p, u8p])
+    _sig(L, "gyo_tcp_conn_sketch_batch", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u8p, u32p, u64p])
     _sig(L, "gyo_cluster_state_update", None, [C.POINTER(ClusterStateOne)] + [C.c_uint32] * 6 + [C.POINTER(ListenSummStats)])
     _sig(L, "gyo_cluster_state_add", None, [C.POINTER(ClusterStateOne), C.POINTER(ClusterStateOne)])
     _sig(L, "gyo_topn_u64", C.c_size_t, [u64p, C.c_size_t, C.c_size_t, u64p])
