@@ -114,6 +114,10 @@ SIGNATURES = {
     "gys_query_cms": (C.c_int, [vp, C.c_uint64, C.c_int, u64p]),
     "gys_query_topn": (C.c_int, [vp, mid, C.c_int, C.POINTER(TopnEntry), u32p]),
     "gys_scan_percentiles_dev": (C.c_int, [vp, C.c_int, f32p, C.c_uint32, vp]),
+    "gys_set_host_name": (C.c_int, [vp, mid, C.c_char_p]),
+    "gys_json_svcsumm": (C.c_int, [vp, mid, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gys_json_svcstate": (C.c_int, [vp, mid, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gys_json_clusterstate": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_num_services": (C.c_uint32, [vp]),
     "gys_num_hosts": (C.c_uint32, [vp]),
     "gys_lookup_service": (C.c_int, [vp, C.c_uint64, u32p]),

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -76,6 +77,7 @@ inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 struct HostListeners {
 	std::vector<uint64_t> tbl;   // open addressing, entries (netns:32|port:16) << 16 | local index, ~0 = free
 	std::vector<uint32_t> slots; // local index -> service slot
+	std::vector<uint32_t> all_slots; // every service slot ever registered for the host (queries)
 	std::vector<uint64_t> keys;  // local index -> (netns:32|port:16)
 	uint32_t tbl_off = 0, tbl_cap = 0, lst_off = 0;
 	bool on_device = false;
@@ -120,6 +122,9 @@ struct gys_ctx {
 	// registries (host)
 	std::unordered_map<MachId, uint32_t, MachIdHash> host_map;
 	std::vector<MachId> hosts;
+	std::vector<std::string> host_names;
+	std::vector<std::array<char, 16>> svc_comm; // TASK_COMM_LEN process name per service slot (SvcStateFields "name")
+	std::vector<uint64_t> svc_gid_h;
 	std::vector<uint32_t> host_cluster_h;
 	std::unordered_map<std::string, uint32_t> cluster_map;
 	std::vector<std::string> cluster_names;
@@ -826,6 +831,7 @@ int gys_register_host(gys_ctx *c, const uint8_t machine_id[16], const char *clus
 		c->host_cluster_h.push_back(cidx);
 		c->host_map.emplace(m, slot);
 		c->host_lst.emplace_back();
+		c->host_names.emplace_back();
 		c->host_lst.back().tbl.assign(16, GYS_HOST_TBL_EMPTY);
 		c->host_seen.push_back(0);
 		rc = host_lst_upload(c, slot);
@@ -876,7 +882,14 @@ int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_l
 	}
 	rc = host_lst_add(c, host, arr, n, c->nsvc);
 	if (rc) return rc;
-	for (uint32_t i = 0; i < n; ++i) c->gid_map_h[arr[i].glob_id] = c->nsvc + i;
+	for (uint32_t i = 0; i < n; ++i) {
+		c->gid_map_h[arr[i].glob_id] = c->nsvc + i;
+		c->host_lst[host].all_slots.push_back(c->nsvc + i);
+		std::array<char, 16> cm{};
+		memcpy(cm.data(), arr[i].comm, 16);
+		c->svc_comm.push_back(cm);
+		c->svc_gid_h.push_back(arr[i].glob_id);
+	}
 	c->nsvc += n;
 	return GYS_OK;
 }
@@ -1588,3 +1601,5 @@ int gys_gen_resp_events_dev(gys_ctx *c, void *d_ev24, uint64_t nevents, uint64_t
 }
 
 } // extern "C"
+
+#include "gys_json.hpp"

@@ -216,6 +216,28 @@ class SketchEngine:
         capi.check(self.L.gys_query_topn(self.h, mid_buf(machine_id), kind, out, C.byref(n)))
         return [(out[i].glob_id, out[i].metric, bytes(out[i].state)) for i in range(n.value)]
 
+    def _json(self, fn, *args):
+        """two-call pattern: ask for the size, then fetch"""
+        need = C.c_size_t()
+        rc = fn(self.h, *args, None, 0, C.byref(need))
+        if rc not in (capi.OK, capi.ERR_NOMEM):
+            capi.check(rc)
+        buf = C.create_string_buffer(need.value + 1)
+        capi.check(fn(self.h, *args, buf, need.value + 1, C.byref(need)))
+        return buf.value.decode()
+
+    def set_host_name(self, machine_id, hostname):
+        capi.check(self.L.gys_set_host_name(self.h, mid_buf(machine_id), hostname.encode()))
+
+    def json_svcsumm(self, machine_id, madid="0" * 16, timestr=""):
+        return self._json(self.L.gys_json_svcsumm, mid_buf(machine_id), madid.encode(), timestr.encode())
+
+    def json_svcstate(self, machine_id, madid="0" * 16, timestr=""):
+        return self._json(self.L.gys_json_svcstate, mid_buf(machine_id), madid.encode(), timestr.encode())
+
+    def json_clusterstate(self, shyamaid="0" * 16, timestr=""):
+        return self._json(self.L.gys_json_clusterstate, shyamaid.encode(), timestr.encode())
+
     def num_services(self):
         return self.L.gys_num_services(self.h)
 

@@ -229,6 +229,21 @@ int gys_query_topn(gys_ctx *ctx, const uint8_t machine_id[16], int kind, gys_top
 int gys_scan_percentiles_dev(gys_ctx *ctx, int which, const float *pcts, uint32_t npct, int64_t *d_out);
 
 /* -------------------------------------------------------------------------------------------------------------------
+ * the same queries as JSON in the reference's web shapes (field names and order = common/gy_json_field_maps.h):
+ *   gys_json_svcsumm      {"madid":..,"summstats":[{time,nidle,ngood,nok,nbad,nsevere,ndown,totqps,totaconn,totkbin,totkbout,totsererr,
+ *                          nsvc,nactive}],"hostinfo":{parid,host,madid,cluster}}   MCONN_HANDLER::web_curr_listener_summ (gy_mnodehandle.cc:1628)
+ *   gys_json_svcstate     {"madid":..,"svcstate":[{time,svcid,name,qps5s,...,state,issue,ishttp,desc}],"hostinfo":{..}}
+ *                          MCONN_HANDLER::web_curr_listener_state (gy_mnodehandle.cc:4650), json_db_svcstate_arr (:1102-1135)
+ *   gys_json_clusterstate {"shyamaid":..,"clusterstate":[{time,cluster,nhosts,nprocissue,nprochosts,nproc,nlistissue,nlisthosts,nlisten,
+ *                          totqps,svcnetmb,ncpuissue,nmemissue}]}   SHCONN_HANDLER::web_curr_clusterstate (gy_shnodehandle.cc:508)
+ * buf receives a NUL-terminated string; *needed = strlen of the full result; GYS_ERR_NOMEM when buflen is too small.
+ * timestr: the "time" field as the caller wants it printed (the reference prints local ISO-8601); NULL = "". */
+int gys_set_host_name(gys_ctx *ctx, const uint8_t machine_id[16], const char *hostname); /* PARTHA_INFO::hostname_ for "host" */
+int gys_json_svcsumm(gys_ctx *ctx, const uint8_t machine_id[16], const char *madhava_id16, const char *timestr, char *buf, size_t buflen, size_t *needed);
+int gys_json_svcstate(gys_ctx *ctx, const uint8_t machine_id[16], const char *madhava_id16, const char *timestr, char *buf, size_t buflen, size_t *needed);
+int gys_json_clusterstate(gys_ctx *ctx, const char *shyama_id16, const char *timestr, char *buf, size_t buflen, size_t *needed);
+
+/* -------------------------------------------------------------------------------------------------------------------
  * parity / checkpoint exports (host destination buffers) -- GY_HISTOGRAM::get_serialized analogue (gy_statistics.h:665-673) */
 uint32_t gys_num_services(gys_ctx *ctx);
 uint32_t gys_num_hosts(gys_ctx *ctx);
