@@ -34,6 +34,11 @@ class HostState(C.Structure):
                 ("cpu_issue", C.c_uint8), ("mem_issue", C.c_uint8), ("curr_state", C.c_uint8), ("reserved", C.c_uint8)]
 
 
+class CommStats(C.Structure):
+    _fields_ = [("nmsgs", C.c_uint32), ("nmsgs_tcp_conn", C.c_uint32), ("nmsgs_listener_state", C.c_uint32), ("nmsgs_skipped", C.c_uint32),
+                ("nmsgs_invalid", C.c_uint32), ("reserved", C.c_uint32), ("nrecords", C.c_uint64), ("bytes_consumed", C.c_uint64)]
+
+
 class ReduceSection(C.Structure):
     _fields_ = [("dev_ptr", C.c_void_p), ("nelems", C.c_uint64), ("dtype", C.c_uint32), ("op", C.c_uint32)]
 
@@ -102,6 +107,7 @@ SIGNATURES = {
     "gys_ingest_tcp_conn_dev": (C.c_int, [vp, vp, vp, C.c_uint32]),
     "gys_ingest_listener_state": (C.c_int, [vp, mid, vp, C.c_uint32, vp]),
     "gys_ingest_listener_state_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint32]),
+    "gys_ingest_comm_stream": (C.c_int, [vp, mid, vp, C.c_uint64, C.POINTER(CommStats)]),
     "gys_ingest_host_state": (C.c_int, [vp, mid, C.POINTER(HostState)]),
     "gys_reduce_sections": (C.c_int, [vp, C.POINTER(ReduceSection), u32p]),
     "gys_window_prepare": (C.c_int, [vp, C.c_uint64]),

@@ -189,6 +189,13 @@ struct gys_ctx {
 	float *zipf_cdf = nullptr;
 	uint32_t zipf_n = 0, zipf_milli = 0;
 
+	// wire front-end scratch (grow-only)
+	uint64_t wire_slots_cap = 0;
+	uint32_t *wire_jump[2] = {nullptr, nullptr}, *wire_cnt = nullptr, *wire_rank = nullptr, *wire_bsums = nullptr, *wire_status = nullptr;
+	uint8_t *wire_mark = nullptr, *wire_flags = nullptr;
+	WireMsg *wire_msgs = nullptr;
+	uint32_t wire_msgs_cap = 0;
+
 	bool profile = false;
 	std::map<std::string, ProfEntry> prof;
 };
@@ -775,7 +782,8 @@ void gys_destroy(gys_ctx *c)
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
 			c->td_cnt, c->td_meta, c->td_pend, c->merge_list, c->merge_count, c->query_sum, c->query_cnt, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_list, c->huge_count,
 			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
-			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->segs_dev, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
+			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
+			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->segs_dev, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -974,6 +982,186 @@ int gys_ingest_listener_state(gys_ctx *c, const uint8_t machine_id[16], const vo
 	rc = run_lstate(c, c->dev_staging, c->dev_offsets, nullptr, host, (uint32_t)offs.size());
 	if (rc) return rc;
 	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ wire front-end
+// COMM_HEADER / EVENT_NOTIFY framing as an unmodified partha sends it to madhava (common/gy_comm_proto.h:336-420, :486-500).  The
+// 16-byte message headers are validated on the host exactly like COMM_HEADER::validate (common/gy_comm_proto.cc:10-57); the records
+// are walked, checked and indexed on the GPU (k_wire_*), then handed to the same ingest kernels as the batch entry points.
+namespace {
+constexpr uint32_t PM_HDR_MAGIC = 0x05666605u;      // COMM_HEADER::PM_HDR_MAGIC, partha to madhava
+constexpr uint32_t COMM_EVENT_NOTIFY_T = 14;        // COMM_TYPE_E::COMM_EVENT_NOTIFY
+constexpr uint32_t COMM_MIN_TYPE_T = 1, COMM_MAX_TYPE_T = 18;
+constexpr uint32_t MAX_COMM_DATA_SZ_T = 16u << 20;  // gy_comm_proto.h:31
+constexpr uint32_t NOTIFY_LISTENER_STATE_T = 0x309, NOTIFY_TCP_CONN_T = 0x30C; // NOTIFY_TYPE_E (0x301 + 8, + 11)
+constexpr uint32_t MAX_NUM_CONNS_T = 2048, MAX_NUM_LISTENERS_T = 512;          // gy_comm_proto.h:1711, :2222
+
+int wire_reserve(gys_ctx *c, uint64_t nslots, uint32_t nmsgs)
+{
+	if (nslots + 1 > c->wire_slots_cap) {
+		HIPCHK(hipStreamSynchronize(c->stream));
+		void *old[] = {c->wire_jump[0], c->wire_jump[1], c->wire_cnt, c->wire_rank, c->wire_bsums, c->wire_mark, c->wire_flags};
+		for (void *p : old)
+			if (p) hipFree(p);
+		c->wire_jump[0] = c->wire_jump[1] = c->wire_cnt = c->wire_rank = c->wire_bsums = nullptr;
+		c->wire_mark = c->wire_flags = nullptr;
+		const uint64_t cap = align_up(std::max<uint64_t>(nslots + 1, 1u << 16), 4096);
+		HIPCHK(hipMalloc((void **)&c->wire_jump[0], cap * 4));
+		HIPCHK(hipMalloc((void **)&c->wire_jump[1], cap * 4));
+		HIPCHK(hipMalloc((void **)&c->wire_cnt, cap * 4));
+		HIPCHK(hipMalloc((void **)&c->wire_rank, cap * 4));
+		HIPCHK(hipMalloc((void **)&c->wire_bsums, (cap / GYS_SCAN_TILE + 2) * 4));
+		HIPCHK(hipMalloc((void **)&c->wire_mark, cap));
+		HIPCHK(hipMalloc((void **)&c->wire_flags, cap));
+		c->wire_slots_cap = cap;
+	}
+	if (!c->wire_status) HIPCHK(hipMalloc((void **)&c->wire_status, 16));
+	if (nmsgs > c->wire_msgs_cap) {
+		if (c->wire_msgs) {
+			HIPCHK(hipStreamSynchronize(c->stream));
+			HIPCHK(hipFree(c->wire_msgs));
+		}
+		c->wire_msgs_cap = std::max<uint32_t>(nmsgs, 1024);
+		HIPCHK(hipMalloc((void **)&c->wire_msgs, (uint64_t)c->wire_msgs_cap * sizeof(WireMsg)));
+	}
+	return GYS_OK;
+}
+
+// d_buf: device copy of the stream (8-byte aligned); msgs: accepted messages of ONE record kind, sorted by position; fills
+// c->dev_offsets[0 .. total records) with the records' byte offsets inside d_buf
+int wire_decode(gys_ctx *c, const uint8_t *d_buf, uint64_t nbytes, std::vector<WireMsg> &msgs, uint32_t nrec_total)
+{
+	const uint32_t nslots = (uint32_t)(nbytes / 8) + 1; // + one terminal slot past the end
+	const uint32_t nmsgs = (uint32_t)msgs.size();
+	int rc = wire_reserve(c, nslots, nmsgs);
+	if (rc) return rc;
+	rc = ensure_staging(c, 0, nrec_total);
+	if (rc) return rc;
+	uint32_t maxev = 1;
+	for (const WireMsg &m : msgs) maxev = std::max(maxev, m.nevents);
+	HIPCHK(hipMemcpyAsync(c->wire_msgs, msgs.data(), (size_t)nmsgs * sizeof(WireMsg), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(c->wire_mark, 0, nslots, c->stream));
+	HIPCHK(hipMemsetAsync(c->wire_status, 0, 16, c->stream));
+	const dim3 gs((nslots + 255) / 256), gm((nmsgs + 255) / 256), b(256);
+	ProfScope ps(c, "wire_decode");
+	hipLaunchKernelGGL(k_wire_next, gs, b, 0, c->stream, (const uint64_t *)d_buf, c->wire_msgs, nmsgs, nslots, c->wire_jump[0], c->wire_flags);
+	hipLaunchKernelGGL(k_wire_seed, gm, b, 0, c->stream, c->wire_msgs, nmsgs, c->wire_mark);
+	int cur = 0;
+	for (uint32_t span = 1; span < maxev; span <<= 1) { // after the round for span, the first 2 * span records of every chain are marked
+		hipLaunchKernelGGL(k_wire_round, gs, b, 0, c->stream, nslots, c->wire_jump[cur], c->wire_jump[cur ^ 1], c->wire_mark);
+		cur ^= 1;
+	}
+	hipLaunchKernelGGL(k_wire_count, gs, b, 0, c->stream, nslots, c->wire_mark, c->wire_flags, c->wire_cnt);
+	const uint32_t nblk = (nslots + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE;
+	hipLaunchKernelGGL(k_scan_block_sums, dim3(nblk), b, 0, c->stream, c->wire_cnt, nslots, c->wire_bsums);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), b, 0, c->stream, c->wire_bsums, nblk);
+	hipLaunchKernelGGL(k_scan_final, dim3(nblk), b, 0, c->stream, c->wire_cnt, nslots, c->wire_bsums, c->wire_rank, c->wire_status + 2, c->wire_status + 1);
+	hipLaunchKernelGGL(k_wire_emit, gs, b, 0, c->stream, c->wire_msgs, nmsgs, nslots, c->wire_cnt, c->wire_rank, c->wire_flags, c->dev_offsets, c->wire_status);
+	hipLaunchKernelGGL(k_wire_check, gm, b, 0, c->stream, c->wire_msgs, nmsgs, nslots, c->wire_cnt, c->wire_rank, c->wire_status);
+	HIPCHK(hipGetLastError());
+	uint32_t status = 0;
+	HIPCHK(hipMemcpyAsync(&status, c->wire_status, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (status) {
+		set_err("malformed message: %s%s", (status & 1u) ? "record size / padding invalid or element overruns the message; " : "",
+			(status & 2u) ? "fewer records than nevents_" : "");
+		return GYS_ERR_INVAL;
+	}
+	return GYS_OK;
+}
+} // namespace
+
+int gys_ingest_comm_stream(gys_ctx *c, const uint8_t machine_id[16], const void *buf, uint64_t nbytes, gys_comm_stats *out)
+{
+	if (!c || !machine_id || (!buf && nbytes) || ((uintptr_t)buf & 7u)) return GYS_ERR_INVAL; // COMM_HEADER::validate: 8-byte aligned data
+	uint32_t host;
+	int rc = lookup_host(c, machine_id, &host);
+	if (rc) return rc;
+	gys_comm_stats st{};
+	if (nbytes >= (1ull << 32)) {
+		set_err("stream too large (u32 offsets)");
+		return GYS_ERR_INVAL;
+	}
+	std::vector<WireMsg> conn_msgs, lst_msgs;
+	uint32_t nconn = 0, nlst = 0;
+	const uint8_t *p = (const uint8_t *)buf, *pend = p + nbytes;
+	while ((size_t)(pend - p) >= 16) {
+		uint32_t magic, total_sz, data_type, padding_sz;
+		memcpy(&magic, p, 4);
+		memcpy(&total_sz, p + 4, 4);
+		memcpy(&data_type, p + 8, 4);
+		memcpy(&padding_sz, p + 12, 4);
+		// COMM_HEADER::validate common/gy_comm_proto.cc:12-22
+		if (!(magic == PM_HDR_MAGIC && total_sz < MAX_COMM_DATA_SZ_T && total_sz >= 16 && padding_sz < 8 && data_type > COMM_MIN_TYPE_T &&
+		      data_type < COMM_MAX_TYPE_T) || (total_sz & 7u) || total_sz > (uint64_t)(pend - p)) {
+			st.nmsgs_invalid++;
+			if (out) *out = st;
+			set_err("invalid COMM_HEADER at byte %zu", (size_t)(p - (const uint8_t *)buf));
+			return GYS_ERR_INVAL; // the reference terminates the connection
+		}
+		st.nmsgs++;
+		const uint32_t act = total_sz - padding_sz;
+		bool taken = false;
+		if (data_type == COMM_EVENT_NOTIFY_T) {
+			if (act < 16 + 8) {
+				st.nmsgs_invalid++;
+				if (out) *out = st;
+				set_err("EVENT_NOTIFY message shorter than its headers");
+				return GYS_ERR_INVAL;
+			}
+			uint32_t subtype, nevents;
+			memcpy(&subtype, p + 16, 4);
+			memcpy(&nevents, p + 20, 4);
+			if (subtype == NOTIFY_TCP_CONN_T || subtype == NOTIFY_LISTENER_STATE_T) {
+				const bool is_conn = subtype == NOTIFY_TCP_CONN_T;
+				if (nevents > (is_conn ? MAX_NUM_CONNS_T : MAX_NUM_LISTENERS_T)) { // :853, :968
+					st.nmsgs_invalid++;
+					if (out) *out = st;
+					set_err("nevents_ %u over the per-message limit", nevents);
+					return GYS_ERR_INVAL;
+				}
+				WireMsg m{};
+				m.pay_slot = (uint32_t)((p - (const uint8_t *)buf) + 24) / 8u;
+				m.end_slot = (uint32_t)((p - (const uint8_t *)buf) + act) / 8u; // act_len is a multiple of 8 for well-formed messages
+				m.nevents = nevents;
+				m.kind = is_conn ? 0u : 1u;
+				if (is_conn) {
+					m.out_base = nconn;
+					nconn += nevents;
+					conn_msgs.push_back(m);
+					st.nmsgs_tcp_conn++;
+				} else {
+					m.out_base = nlst;
+					nlst += nevents;
+					lst_msgs.push_back(m);
+					st.nmsgs_listener_state++;
+				}
+				taken = true;
+			}
+		}
+		if (!taken) st.nmsgs_skipped++; // registration, queries and the other notify subtypes belong to the control plane
+		p += total_sz;
+	}
+	st.bytes_consumed = (uint64_t)(p - (const uint8_t *)buf);
+	st.nrecords = (uint64_t)nconn + nlst;
+	if (nconn || nlst) {
+		rc = ensure_staging(c, nbytes + 8, 0);
+		if (rc) return rc;
+		HIPCHK(hipMemcpyAsync(c->dev_staging, buf, nbytes, hipMemcpyHostToDevice, c->stream));
+		if (nconn) {
+			rc = wire_decode(c, c->dev_staging, nbytes, conn_msgs, nconn);
+			if (!rc) rc = run_conn(c, c->dev_staging, c->dev_offsets, nconn);
+			if (rc) return rc;
+		}
+		if (nlst) {
+			rc = wire_decode(c, c->dev_staging, nbytes, lst_msgs, nlst);
+			if (!rc) rc = run_lstate(c, c->dev_staging, c->dev_offsets, nullptr, host, nlst);
+			if (rc) return rc;
+		}
+		HIPCHK(hipStreamSynchronize(c->stream)); // the caller's buffer is only valid during the call
+	}
+	if (out) *out = st;
 	return GYS_OK;
 }
 

@@ -1585,6 +1585,117 @@ __global__ __launch_bounds__(256) void k_topn_filter(const uint8_t *svc_state, u
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------- wire front-end
+// GPU-side decode of variable-stride record chains.  A partha message is [COMM_HEADER 16 B][EVENT_NOTIFY 8 B][records],
+// every record's size depends on its own length fields (TCP_CONN_NOTIFY::get_elem_size common/gy_comm_proto.h:1721-1724,
+// LISTENER_STATE_NOTIFY::get_elem_size :2229-2232), so the reference walks p += p->get_elem_size() serially
+// (server/gy_mconnhdlr.cc:9130, :11175).  Here every 8-byte slot of the buffer computes the record size it WOULD have if a record
+// started there (one 8-byte load holds both length fields), the true record starts are then found by pointer doubling from the
+// payload starts of all messages at once (log2(2048) rounds), a prefix sum ranks them, and the first nevents_ of each message
+// become the offset list the ingest kernels consume.  The per-record checks of TCP_CONN_NOTIFY::validate
+// (common/gy_comm_proto.cc:840-881) / LISTENER_STATE_NOTIFY::validate (:955-996) -- element fits, size multiple of 8, nevents_
+// records present -- are evaluated on the way.
+struct WireMsg {
+	uint32_t pay_slot;  // first payload slot (8-byte units from the start of the device buffer)
+	uint32_t end_slot;  // one past the last payload slot (COMM_HEADER::get_act_len)
+	uint32_t nevents;   // EVENT_NOTIFY::nevents_
+	uint32_t out_base;  // first entry of this message in the offset list
+	uint32_t kind;      // 0 = TCP_CONN_NOTIFY (280 B fixed), 1 = LISTENER_STATE_NOTIFY (88 B fixed)
+	uint32_t pad;
+};
+
+__device__ __forceinline__ int wire_find_msg(const WireMsg *msgs, uint32_t nmsgs, uint32_t slot)
+{
+	uint32_t lo = 0, hi = nmsgs; // last message with pay_slot <= slot
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (msgs[mid].pay_slot <= slot) lo = mid + 1; else hi = mid;
+	}
+	if (lo == 0) return -1;
+	return slot < msgs[lo - 1].end_slot ? (int)(lo - 1) : -1;
+}
+
+// next[i] = slot of the record after a record starting at slot i (== i for slots outside any payload and for malformed records);
+// rec[i] = 1 when slot i lies inside a payload (a candidate record start), bad[i] = 1 when a record starting there is malformed
+__global__ __launch_bounds__(256) void k_wire_next(const uint64_t *buf, const WireMsg *msgs, uint32_t nmsgs, uint32_t nslots, uint32_t *next, uint8_t *flags)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nslots) return;
+	const int m = wire_find_msg(msgs, nmsgs, i);
+	uint32_t nx = i;
+	uint8_t fl = 0;
+	if (m >= 0) {
+		const WireMsg mm = msgs[m];
+		const uint32_t fixed = mm.kind == 0 ? 280u / 8u : 88u / 8u;
+		fl = 1; // inside a payload
+		if (i + fixed > mm.end_slot) {
+			fl |= 2; // truncated fixed part
+		} else {
+			uint32_t size;
+			if (mm.kind == 0) {
+				const uint64_t w = buf[i + 272u / 8u]; // cli_cmdline_len_ @272 (u16) ... padding_len_ @279
+				size = 280u + (uint32_t)(w & 0xFFFFu) + (uint32_t)(w >> 56);
+			} else {
+				const uint64_t w = buf[i + 80u / 8u];  // issue_string_len_ @85, padding_len_ @86
+				size = 88u + (uint32_t)((w >> 40) & 0xFFu) + (uint32_t)((w >> 48) & 0xFFu);
+			}
+			if ((size & 7u) || i + size / 8u > mm.end_slot) fl |= 2; // "Padding issue" / element overruns the message
+			else nx = i + size / 8u;
+		}
+	}
+	next[i] = nx;
+	flags[i] = fl;
+}
+
+__global__ __launch_bounds__(256) void k_wire_seed(const WireMsg *msgs, uint32_t nmsgs, uint8_t *mark)
+{
+	const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m < nmsgs && msgs[m].nevents && msgs[m].pay_slot < msgs[m].end_slot) mark[msgs[m].pay_slot] = 1;
+}
+
+// one doubling round: everything marked marks its 2^k-th successor; jump_out = jump_in o jump_in
+__global__ __launch_bounds__(256) void k_wire_round(uint32_t nslots, const uint32_t *jump_in, uint32_t *jump_out, uint8_t *mark)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nslots) return;
+	const uint32_t j = jump_in[i];
+	if (mark[i] && j != i) mark[j] = 1;
+	jump_out[i] = jump_in[j];
+}
+
+// cnt[i] = 1 for true record starts (marked slots inside a payload), so that an exclusive scan ranks the records of the whole stream
+__global__ __launch_bounds__(256) void k_wire_count(uint32_t nslots, const uint8_t *mark, const uint8_t *flags, uint32_t *cnt)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nslots) cnt[i] = (mark[i] && (flags[i] & 1u)) ? 1u : 0u;
+}
+
+// the first nevents_ records of every message go to the offset list; status[0] |= 1 malformed record, 2 fewer records than nevents_
+__global__ __launch_bounds__(256) void k_wire_emit(const WireMsg *msgs, uint32_t nmsgs, uint32_t nslots, const uint32_t *cnt, const uint32_t *rank, const uint8_t *flags,
+						   uint32_t *offsets, uint32_t *status)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nslots || !cnt[i]) return;
+	const int m = wire_find_msg(msgs, nmsgs, i);
+	if (m < 0) return;
+	const WireMsg mm = msgs[m];
+	const uint32_t r = rank[i] - rank[mm.pay_slot];
+	if (r >= mm.nevents) return; // the reference stops after nevents_ records
+	if (flags[i] & 2u) atomicOr(status, 1u);
+	offsets[mm.out_base + r] = i * 8u;
+}
+
+__global__ __launch_bounds__(256) void k_wire_check(const WireMsg *msgs, uint32_t nmsgs, uint32_t nslots, const uint32_t *cnt, const uint32_t *rank, uint32_t *status)
+{
+	const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= nmsgs) return;
+	const WireMsg mm = msgs[m];
+	if (!mm.nevents) return;
+	const uint32_t last = mm.end_slot - 1u; // records found in [pay_slot, end_slot)
+	const uint32_t found = mm.end_slot > mm.pay_slot ? rank[last] + cnt[last] - rank[mm.pay_slot] : 0u;
+	if (found < mm.nevents) atomicOr(status, 2u);
+}
+
 // ---------------------------------------------------------------------------------------------------- synthetic stream generator
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {

@@ -72,6 +72,17 @@ public:
 		return gys_ingest_listener_state(ctx_, machine_id, pone, (uint32_t)nconns, pendptr) == GYS_OK;
 	}
 
+	// L1 + L2 in one step for a partha connection's receive buffer: COMM_HEADER-framed messages, records decoded on the GPU
+	// (MCONN_HANDLER::handle_l1 -> handle_l2_misc dispatch, gy_mconnhdlr.cc:4700-4792).  nconsumed: whole messages consumed.
+	bool handle_partha_stream(const uint8_t machine_id[16], const void *pbuf, uint64_t nbytes, uint64_t *nconsumed = nullptr) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		gys_comm_stats st{};
+		const bool ok = gys_ingest_comm_stream(ctx_, machine_id, pbuf, nbytes, &st) == GYS_OK;
+		if (nconsumed) *nconsumed = st.bytes_consumed;
+		return ok;
+	}
+
 	// comm::HOST_STATE_NOTIFY store read by send_cluster_state (gy_mconnhdlr.cc:16052-16075)
 	bool partha_host_state(const uint8_t machine_id[16], const gys_host_state &st) noexcept
 	{
@@ -111,7 +122,38 @@ public:
 		return gys_query_clusterstate(ctx_, cluster, &out) == GYS_OK;
 	}
 
+	// the same answers as the reference's web JSON (web_curr_listener_summ / web_curr_listener_state / web_curr_clusterstate)
+	bool web_curr_listener_summ(const uint8_t machine_id[16], const char *madid, const char *timestr, std::string &out) noexcept
+	{
+		return json_call(out, [&](char *b, size_t n, size_t *need) { return gys_json_svcsumm(ctx_, machine_id, madid, timestr, b, n, need); });
+	}
+	bool web_curr_listener_state(const uint8_t machine_id[16], const char *madid, const char *timestr, std::string &out) noexcept
+	{
+		return json_call(out, [&](char *b, size_t n, size_t *need) { return gys_json_svcstate(ctx_, machine_id, madid, timestr, b, n, need); });
+	}
+	bool web_curr_clusterstate(const char *shyamaid, const char *timestr, std::string &out) noexcept
+	{
+		return json_call(out, [&](char *b, size_t n, size_t *need) { return gys_json_clusterstate(ctx_, shyamaid, timestr, b, n, need); });
+	}
+
 private:
+	template <typename F>
+	bool json_call(std::string &out, F &&f) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		try {
+			size_t need = 0;
+			int rc = f(nullptr, 0, &need);
+			if (rc != GYS_OK && rc != GYS_ERR_NOMEM) return false;
+			out.resize(need + 1);
+			rc = f(out.data(), out.size(), &need);
+			out.resize(need);
+			return rc == GYS_OK;
+		} catch (...) {
+			return false;
+		}
+	}
+
 	gys_ctx *ctx_ = nullptr;
 	std::mutex mu_;
 };

@@ -139,6 +139,14 @@ class SketchEngine:
         p = buf.ctypes.data
         capi.check(self.L.gys_ingest_listener_state(self.h, mid_buf(machine_id), C.c_void_p(p), nrecs, C.c_void_p(p + len(buf))))
 
+    def handle_comm_stream(self, machine_id, stream_bytes):
+        """L1 + L2 of madhava for one partha connection: COMM_HEADER-framed messages -> partha_tcp_conn_info / partha_listener_state"""
+        buf = np.frombuffer(stream_bytes, dtype=np.uint8)
+        buf = np.require(buf, requirements=["A", "C"])
+        st = capi.CommStats()
+        capi.check(self.L.gys_ingest_comm_stream(self.h, mid_buf(machine_id), C.c_void_p(buf.ctypes.data), len(buf), C.byref(st)))
+        return st
+
     def handle_host_state(self, machine_id, ntasks_issue=0, ntasks=0, nlisten_issue=0, nlisten=0, cpu_issue=0, mem_issue=0, curr_state=1):
         st = capi.HostState(ntasks_issue, ntasks, nlisten_issue, nlisten, cpu_issue, mem_issue, curr_state, 0)
         capi.check(self.L.gys_ingest_host_state(self.h, mid_buf(machine_id), C.byref(st)))

@@ -172,3 +172,21 @@ def synth_listener_states(rng, host, svc_ids, delete_frac=0.0, bad_state_frac=0.
     if delete_frac:
         rec["query_flags"] = np.where(rng.random(n) < delete_frac, LISTEN_FLAG_DELETE, 0)
     return rec
+
+
+# ---- COMM_HEADER / EVENT_NOTIFY framing (common/gy_comm_proto.h:336-420, :486-500)
+PM_HDR_MAGIC = 0x05666605
+COMM_EVENT_NOTIFY = 14
+COMM_QUERY_CMD = 15
+NOTIFY_LISTENER_STATE = 0x309
+NOTIFY_TCP_CONN = 0x30C
+NOTIFY_CPU_MEM_STATE = 0x30F
+
+
+def frame_event_notify(subtype, nevents, payload, magic=PM_HDR_MAGIC, data_type=COMM_EVENT_NOTIFY):
+    """one message as COMM_HEADER::set_type_len builds it: total_sz_ rounded up to 8, padding_sz_ = the difference"""
+    act = 16 + 8 + len(payload)
+    total = (act + 7) & ~7
+    hdr = np.array([magic, total, data_type, total - act], dtype="<u4").tobytes()
+    ev = np.array([subtype, nevents], dtype="<u4").tobytes()
+    return hdr + ev + payload + b"\0" * (total - act)

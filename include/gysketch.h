@@ -140,6 +140,21 @@ int gys_ingest_tcp_conn_dev(gys_ctx *ctx, const void *d_batch, const uint32_t *d
 /* Replaces MCONN_HANDLER::partha_listener_state(partha, const LISTENER_STATE_NOTIFY *pone, int nconns, uint8_t *pendptr, ...)
  * (server/gy_mconnhdlr.h:2129, .cc:10993-11412): per record glob_id probe, LISTEN_SUMM_STATS::update, set_state, top-N. */
 int gys_ingest_listener_state(gys_ctx *ctx, const uint8_t machine_id[16], const void *batch, uint32_t nrecs, const void *pend);
+
+/* Wire front-end: a byte stream of COMM_HEADER-framed messages exactly as an unmodified partha sends them on its PM_HDR_MAGIC
+ * connection ([COMM_HEADER 16 B][EVENT_NOTIFY 8 B][nevents_ records][padding], common/gy_comm_proto.h:336-420, :486-500).
+ * Replaces the L1 validation + L2 dispatch in front of the two handlers above (COMM_HEADER::validate common/gy_comm_proto.cc:10-57,
+ * TCP_CONN_NOTIFY::validate :840-881, LISTENER_STATE_NOTIFY::validate :955-996, dispatch server/gy_mconnhdlr.cc:4756-4792): message
+ * headers are checked on the host, the variable-stride record chains are walked, checked and indexed ON THE GPU (pointer doubling +
+ * prefix sum, gys_kernels.hpp "wire front-end"), EVENT_NOTIFY subtypes NOTIFY_TCP_CONN / NOTIFY_LISTENER_STATE are ingested, every
+ * other message is skipped (control plane).  A malformed header or record rejects the call (the reference drops the connection);
+ * nothing of the rejected call is ingested for the kind that failed.  buf must be 8-byte aligned. */
+typedef struct {
+	uint32_t nmsgs, nmsgs_tcp_conn, nmsgs_listener_state, nmsgs_skipped, nmsgs_invalid, reserved;
+	uint64_t nrecords;       /* TCP_CONN_NOTIFY + LISTENER_STATE_NOTIFY records ingested */
+	uint64_t bytes_consumed; /* whole messages consumed; a trailing partial message is left to the caller */
+} gys_comm_stats;
+int gys_ingest_comm_stream(gys_ctx *ctx, const uint8_t machine_id[16], const void *buf, uint64_t nbytes, gys_comm_stats *out);
 /* device-resident multi-host: d_host_slot[i] = host of record i */
 int gys_ingest_listener_state_dev(gys_ctx *ctx, const void *d_batch, const uint32_t *d_offsets, const uint32_t *d_host_slot,
 				  uint32_t nrecs);

@@ -3,6 +3,7 @@
 // header + library link.
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../gyeeta_amd/csrc/gys_mconn_shim.hpp"
@@ -70,6 +71,28 @@ int main(int argc, char **argv)
 	if (s.tot_qps != exp_qps || s.nlisteners != 10 || s.nactive != exp_active || c.nhosts != 1 || c.total_qps != (uint32_t)exp_qps || c.nsvc != 10) return 8;
 	uint8_t other[16] = {9};
 	if (h.partha_listener_state(other, recs, 10, (const uint8_t *)(recs + 10))) return 9; // unknown partha -> false (reference: null partha_shr)
+	// the same window again through the wire front-end: one COMM_HEADER + EVENT_NOTIFY(NOTIFY_LISTENER_STATE) message, then the JSON query
+	{
+		alignas(8) uint8_t msg[16 + 8 + sizeof(recs)];
+		const uint32_t hdr[4] = {0x05666605u /* PM_HDR_MAGIC */, (uint32_t)sizeof(msg), 14u /* COMM_EVENT_NOTIFY */, 0u};
+		const uint32_t ev[2] = {0x309u /* NOTIFY_LISTENER_STATE */, 10u};
+		memcpy(msg, hdr, 16);
+		memcpy(msg + 16, ev, 8);
+		memcpy(msg + 24, recs, sizeof(recs));
+		uint64_t used = 0;
+		if (!h.handle_partha_stream(mid, msg, sizeof(msg), &used) || used != sizeof(msg)) return 10;
+		if (!h.partha_host_state(mid, st)) return 11;
+		h.send_cluster_state(10000000);
+		std::string js;
+		if (!h.web_curr_listener_summ(mid, "00112233aabbccdd", "2026-01-01T00:00:10+0000", js)) return 12;
+		char want[64];
+		snprintf(want, sizeof(want), "\"totqps\":%d,", exp_qps);
+		if (js.find(want) == std::string::npos || js.find("\"nsvc\":10,") == std::string::npos || js.find("\"cluster\":\"prod\"") == std::string::npos) {
+			fprintf(stderr, "unexpected json: %s\n", js.c_str());
+			return 13;
+		}
+		if (!h.web_curr_clusterstate("ffffffffffffffff", "", js) || js.find("\"nhosts\":1,") == std::string::npos) return 14;
+	}
 	printf("shim ok\n");
 	return 0;
 }
