@@ -112,11 +112,15 @@ ArenaLayout arena_layout(uint32_t max_clusters)
 
 } // namespace
 
+#define GYS_KEY_PIPE 8 // key ranges per batch: k_key_pass of range i+1 (HBM-bound) overlaps the merges of range i (issue-bound)
+
 struct gys_ctx {
 	gys_config cfg{};
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
+	hipStream_t aux_stream = nullptr;              // the t-digest merges of a batch run here, pipelined against k_key_pass
+	hipEvent_t ev_chunk[GYS_KEY_PIPE] = {}, ev_aux = nullptr;
 	int ncu = 256;
 
 	// registries (host)
@@ -207,7 +211,8 @@ struct ProfScope {
 	gys_ctx *c;
 	ProfEntry *e = nullptr;
 	hipEvent_t a = nullptr, b = nullptr;
-	ProfScope(gys_ctx *ctx, const char *name) : c(ctx)
+	hipStream_t st;
+	ProfScope(gys_ctx *ctx, const char *name, hipStream_t stream = nullptr) : c(ctx), st(stream ? stream : ctx->stream)
 	{
 		if (!c->profile) return;
 		e = &c->prof[name];
@@ -215,12 +220,12 @@ struct ProfScope {
 			e = nullptr;
 			return;
 		}
-		hipEventRecord(a, c->stream);
+		hipEventRecord(a, st);
 	}
 	~ProfScope()
 	{
 		if (!e) return;
-		hipEventRecord(b, c->stream);
+		hipEventRecord(b, st);
 		e->pending.emplace_back(a, b);
 		e->launches++;
 	}
@@ -530,6 +535,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	d.merge_count = c->merge_count;
 	d.hist_all = c->hist_all;
 	d.epoch = c->epoch;
+	d.chunk_lo = 0;
+	d.chunk_hi = (c->nsvc + 63u) / 64u;
 	d.ghist = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
 	d.gmax = (long long *)(c->arena + c->al.off_i64max);
 	d.batch_cnt = c->batch_cnt;
@@ -541,23 +548,48 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	d.svc_gid = c->svc_gid;
 	d.bitmap = c->bitmap;
 	{
-		ProfScope ps(c, "key_pass");
-		HIPCHK(hipMemsetAsync(c->merge_count, 0, 4, c->stream));
-		hipLaunchKernelGGL(k_key_pass, dim3(std::min<uint32_t>((nsvc + 255) / 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, d);
-	}
-	{
-		ProfScope ps(c, "digest_merge");
-		MergeP mp{};
-		mp.d = d;
-		mp.list = c->merge_list;
-		mp.count = c->merge_count;
-		{
-			static const char *dbg = getenv("GYS_DBG_SKIP");
-			mp.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
+		// The per-key pass is HBM-bound, the merges it queues are instruction-issue bound: the keys are cut into GYS_KEY_PIPE ranges,
+		// k_key_pass walks them on the main stream and each range's merges start on the auxiliary stream as soon as its list is
+		// complete, so the two kinds of work share the chip.  (Merge lists are per range: at most one entry per key.)
+		const uint32_t nchunks = (nsvc + 63u) / 64u;
+		const uint32_t npipe = nchunks >= 4096u ? GYS_KEY_PIPE : 1u;
+		const uint32_t per = (nchunks + npipe - 1) / npipe;
+		static const char *dbg = getenv("GYS_DBG_SKIP");
+		const uint32_t dbgv = dbg ? (uint32_t)atoi(dbg) : 0u;
+		const bool overlap = !(dbgv & 64u);
+		HIPCHK(hipMemsetAsync(c->merge_count, 0, 4 * GYS_KEY_PIPE, c->stream));
+		for (uint32_t r = 0; r < npipe; ++r) {
+			const uint32_t lo = r * per, hi = std::min(nchunks, lo + per);
+			if (lo >= hi) break;
+			DigestP dr = d;
+			dr.chunk_lo = lo;
+			dr.chunk_hi = hi;
+			dr.merge_list = c->merge_list + (size_t)lo * 64u;
+			dr.merge_count = c->merge_count + r;
+			{
+				ProfScope ps(c, "key_pass");
+				hipLaunchKernelGGL(k_key_pass, dim3(std::min<uint32_t>((hi - lo + 3) / 4, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, dr);
+			}
+			hipStream_t ms = c->stream;
+			if (overlap && npipe > 1) {
+				HIPCHK(hipEventRecord(c->ev_chunk[r], c->stream));
+				HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_chunk[r], 0));
+				ms = c->aux_stream;
+			}
+			ProfScope ps(c, "digest_merge", ms);
+			MergeP mp{};
+			mp.d = dr;
+			mp.list = dr.merge_list;
+			mp.count = dr.merge_count;
+			mp.dbg = dbgv;
+			const uint32_t mgrid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>((uint64_t)(hi - lo) * 64u, n), (uint64_t)c->ncu * 32);
+			hipLaunchKernelGGL(k_digest_merge<128u>, dim3(mgrid), dim3(64), 0, ms, mp);
+			hipLaunchKernelGGL(k_digest_merge<GYS_SMALL_MAX>, dim3(std::min<uint32_t>(mgrid, (uint32_t)c->ncu * 8)), dim3(64), 0, ms, mp);
 		}
-		const uint32_t mgrid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nsvc, n), (uint64_t)c->ncu * 32);
-		hipLaunchKernelGGL(k_digest_merge<128u>, dim3(mgrid), dim3(64), 0, c->stream, mp);
-		hipLaunchKernelGGL(k_digest_merge<GYS_SMALL_MAX>, dim3(std::min<uint32_t>(mgrid, (uint32_t)c->ncu * 8)), dim3(64), 0, c->stream, mp);
+		if (overlap && npipe > 1) { // the batch is complete (for the next call and for queries on the main stream) when the merges are
+			HIPCHK(hipEventRecord(c->ev_aux, c->aux_stream));
+			HIPCHK(hipStreamWaitEvent(c->stream, c->ev_aux, 0));
+		}
 	}
 	{
 		ProfScope ps(c, "digest_huge");
@@ -681,6 +713,9 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		c->own_stream = true;
 	}
+	HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+	for (int i = 0; i < GYS_KEY_PIPE; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
 	const uint64_t S = cfg->max_services, H = cfg->max_hosts;
 	const uint32_t cap = next_pow2(S * 2);
 	int rc;
@@ -728,7 +763,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		ALLOC(c->td_meta, S);
 		ALLOC(c->td_pend, S * GYS_TD_PEND_CAP);
 		ALLOC(c->merge_list, std::min<uint64_t>(S, B) + 1);
-		ALLOC(c->merge_count, 2);
+		ALLOC(c->merge_count, GYS_KEY_PIPE + 2);
 		ALLOC(c->query_sum, GYS_TD_NB);
 		ALLOC(c->query_cnt, GYS_TD_NB);
 		ALLOC(c->batch_cnt, align_up(S, 16));
@@ -744,7 +779,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		hipLaunchKernelGGL(k_tdmeta_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, (uint4 *)c->td_meta, S);
 		{
 			const uint32_t one = 1;
-			HIPCHK(hipMemcpyAsync(c->merge_count + 1, &one, 4, hipMemcpyHostToDevice, c->stream));
+			HIPCHK(hipMemcpyAsync(c->merge_count + GYS_KEY_PIPE, &one, 4, hipMemcpyHostToDevice, c->stream));
 		}
 	}
 #undef ALLOC
@@ -787,6 +822,13 @@ void gys_destroy(gys_ctx *c)
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
+	if (c->aux_stream) {
+		hipStreamSynchronize(c->aux_stream);
+		hipStreamDestroy(c->aux_stream);
+	}
+	for (int i = 0; i < GYS_KEY_PIPE; ++i)
+		if (c->ev_chunk[i]) hipEventDestroy(c->ev_chunk[i]);
+	if (c->ev_aux) hipEventDestroy(c->ev_aux);
 	if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -1392,7 +1434,7 @@ int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t 
 	mp.d.td_pend = c->td_pend;
 	mp.d.staged = c->staged;
 	mp.list = c->merge_list;
-	mp.count = c->merge_count + 1;
+	mp.count = c->merge_count + GYS_KEY_PIPE;
 	mp.out_sum = c->query_sum;
 	mp.out_cnt = c->query_cnt;
 	hipLaunchKernelGGL(k_digest_merge<128u>, dim3(1), dim3(64), 0, c->stream, mp);

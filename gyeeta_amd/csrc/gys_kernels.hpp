@@ -549,6 +549,7 @@ struct DigestP {
 	gys_hist_rec *hist_all;
 	uint32_t epoch;              // current window number
 	unsigned long long *ghist;   // arena: all-service histogram of the window, 15 x {count,sum} + {total}
+	uint32_t chunk_lo, chunk_hi; // k_key_pass: 64-key chunks [chunk_lo, chunk_hi) of this launch (key ranges pipeline against the merges)
 	long long *gmax;             // arena: largest value of the window
 };
 
@@ -653,9 +654,8 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 	uint32_t *s_bm = s_bm_[wv * 4u + row];
 	int32_t *s_mm = s_mm_[wv * 4u + row];
 	const uint32_t nwaves = gridDim.x * 4u;
-	const uint32_t nchunks = (p.nsvc + 63u) / 64u;
 
-	for (uint32_t chunk = blockIdx.x * 4u + wv; chunk < nchunks; chunk += nwaves) {
+	for (uint32_t chunk = p.chunk_lo + blockIdx.x * 4u + wv; chunk < p.chunk_hi; chunk += nwaves) {
 		const uint32_t key = chunk * 64u + lane;
 		uint32_t mcnt = key < p.nsvc ? p.batch_cnt[key] : 0u;
 		const uint32_t oend = key < p.nsvc ? p.off_end[key] : 0u;
