@@ -158,7 +158,9 @@ struct gys_ctx {
 	uint32_t *query_cnt = nullptr;
 	uint32_t *batch_cnt = nullptr, *batch_off = nullptr, *scan_block_sums = nullptr;
 	uint64_t *ev_kv = nullptr;
-	uint32_t *staged = nullptr;
+	uint32_t *staged = nullptr, *staged2 = nullptr; // double-buffered: the merges of batch b read theirs while batch b+1 is staged
+	int staged_sel = 0;
+	bool aux_pending = false; // merges still running on aux_stream (joined before the next per-key pass and before digest reads)
 	uint32_t *huge_list = nullptr, *huge_count = nullptr, *huge_scratch = nullptr;
 	int huge_blocks = 0;
 	uint32_t *hll32 = nullptr;
@@ -230,6 +232,15 @@ struct ProfScope {
 		e->launches++;
 	}
 };
+
+// main stream waits for the merges of the last batch (no-op when none are outstanding)
+inline void join_aux(gys_ctx *c)
+{
+	if (c->aux_pending) {
+		hipStreamWaitEvent(c->stream, c->ev_aux, 0);
+		c->aux_pending = false;
+	}
+}
 
 void prof_resolve(gys_ctx *c)
 {
@@ -449,6 +460,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	}
 	const uint32_t nsvc = c->nsvc;
 	uint32_t *cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
+	uint32_t *staged_cur = c->staged_sel ? c->staged2 : c->staged;
 	if (host_local) {
 		c->n_batches_host_local++;
 		RespHostP hp{};
@@ -463,7 +475,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hp.batch_cnt = c->batch_cnt;
 		hp.off_end = c->batch_off;
 		hp.ev_kv = c->ev_kv;
-		hp.staged = c->staged;
+		hp.staged = staged_cur;
 		hp.huge_list = c->huge_list;
 		hp.huge_count = c->huge_count;
 		hp.counters = c->counters;
@@ -522,7 +534,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		{
 			ProfScope ps(c, "scatter");
 			hipLaunchKernelGGL(k_resp_scatter, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->ev_kv, n, c->batch_off,
-					   c->staged);
+					   staged_cur);
 		}
 	}
 	HIPCHK(hipGetLastError());
@@ -541,7 +553,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	d.gmax = (long long *)(c->arena + c->al.off_i64max);
 	d.batch_cnt = c->batch_cnt;
 	d.off_end = c->batch_off;
-	d.staged = c->staged;
+	d.staged = staged_cur;
 	d.nsvc = nsvc;
 	d.hist_win = c->hist_win;
 	d.cms32 = cms32;
@@ -557,6 +569,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		static const char *dbg = getenv("GYS_DBG_SKIP");
 		const uint32_t dbgv = dbg ? (uint32_t)atoi(dbg) : 0u;
 		const bool overlap = !(dbgv & 64u);
+		// the previous batch's merges may still be running (they overlapped this batch's resp pass, which only touches its own staging
+		// buffer): the per-key pass appends to the digest buffers and must see them finished
+		join_aux(c);
 		HIPCHK(hipMemsetAsync(c->merge_count, 0, 4 * GYS_KEY_PIPE, c->stream));
 		for (uint32_t r = 0; r < npipe; ++r) {
 			const uint32_t lo = r * per, hi = std::min(nchunks, lo + per);
@@ -586,10 +601,12 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			hipLaunchKernelGGL(k_digest_merge<128u>, dim3(mgrid), dim3(64), 0, ms, mp);
 			hipLaunchKernelGGL(k_digest_merge<GYS_SMALL_MAX>, dim3(std::min<uint32_t>(mgrid, (uint32_t)c->ncu * 8)), dim3(64), 0, ms, mp);
 		}
-		if (overlap && npipe > 1) { // the batch is complete (for the next call and for queries on the main stream) when the merges are
+		if (overlap && npipe > 1) { // not joined here: the next batch's resp pass may start while the last merges finish (join_aux)
 			HIPCHK(hipEventRecord(c->ev_aux, c->aux_stream));
-			HIPCHK(hipStreamWaitEvent(c->stream, c->ev_aux, 0));
+			c->aux_pending = true;
+			if (dbgv & 128u) join_aux(c);
 		}
+		c->staged_sel ^= 1;
 	}
 	{
 		ProfScope ps(c, "digest_huge");
@@ -771,6 +788,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		ALLOC(c->scan_block_sums, (S + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE + 1);
 		ALLOC(c->ev_kv, B);
 		ALLOC(c->staged, B);
+		ALLOC(c->staged2, B);
 		ALLOC(c->huge_list, std::min<uint64_t>(S, B / GYS_SMALL_MAX + 1));
 		ALLOC(c->huge_count, 1);
 		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_SMALL_MAX + 1));
@@ -812,10 +830,11 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 void gys_destroy(gys_ctx *c)
 {
 	if (!c) return;
+	if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
-			c->td_cnt, c->td_meta, c->td_pend, c->merge_list, c->merge_count, c->query_sum, c->query_cnt, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_list, c->huge_count,
+			c->td_cnt, c->td_meta, c->td_pend, c->merge_list, c->merge_count, c->query_sum, c->query_cnt, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->staged2, c->huge_list, c->huge_count,
 			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->segs_dev, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
@@ -836,6 +855,7 @@ void gys_destroy(gys_ctx *c)
 int gys_sync(gys_ctx *c)
 {
 	if (!c) return GYS_ERR_INVAL;
+	join_aux(c);
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
 }
@@ -1422,6 +1442,7 @@ int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t 
 	int rc = gys_lookup_service(c, glob_id, &slot);
 	if (rc) return rc;
 	// merged view = clusters re-clustered with the key's buffered values (k_digest_merge in query mode: state is not modified)
+	join_aux(c); // the last batch's merges may still be running (and still reading merge_list)
 	int64_t sum[GYS_TD_NB];
 	uint32_t cnt[GYS_TD_NB];
 	TdMeta mt;
@@ -1631,6 +1652,7 @@ int gys_export_tdigest(gys_ctx *c, uint32_t first_slot, uint32_t nslots, int64_t
 	void *out = sums;
 	RANGE_CHECK(first_slot, nslots);
 	if (!c->cfg.enable_tdigest || !cnts || !minmax) return GYS_ERR_INVAL;
+	join_aux(c);
 	HIPCHK(hipMemcpyAsync(sums, c->td_sum + (size_t)first_slot * GYS_TD_NB, (size_t)nslots * GYS_TD_NB * 8, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(cnts, c->td_cnt + (size_t)first_slot * GYS_TD_NB, (size_t)nslots * GYS_TD_NB * 4, hipMemcpyDeviceToHost, c->stream));
 	std::vector<TdMeta> meta(nslots);
@@ -1648,6 +1670,7 @@ int gys_export_tdigest_pending(gys_ctx *c, uint32_t first_slot, uint32_t nslots,
 	void *out = npend;
 	RANGE_CHECK(first_slot, nslots);
 	if (!c->cfg.enable_tdigest || !pend) return GYS_ERR_INVAL;
+	join_aux(c);
 	std::vector<TdMeta> meta(nslots);
 	HIPCHK(hipMemcpyAsync(meta.data(), c->td_meta + first_slot, (size_t)nslots * sizeof(TdMeta), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(pend, c->td_pend + (size_t)first_slot * GYS_TD_PEND_CAP, (size_t)nslots * GYS_TD_PEND_CAP * 4, hipMemcpyDeviceToHost, c->stream));
