@@ -63,7 +63,28 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed):
     t2 = time.perf_counter()
     desc = (f"{nevents} events over {total_hosts_sample} hosts x {svcs} services ({nsvc} keys), one batch, single thread, "
             f"gcc -O2; full = hist+bitmap+HLL+CMS+t-digest, histonly = the reference's own per-event work")
-    return nevents / (t1 - t0), nevents / (t2 - t1), desc
+    # the reference's OWN classes on the same bytes (oracle/_ref: GY_HISTOGRAM<int64_t, RESP_TIME_HASH>::add_data behind an
+    # unordered_map with GY_JHASHER standing in for the RCU listener table): kind "reference"
+    ref_rate = None
+    R = o.ref()
+    if R is not None and hasattr(R, "ref_keyed_new"):
+        k = R.ref_keyed_new()
+        for h in range(total_hosts_sample):
+            s = np.arange(svcs)
+            ns = wire.listener_netns(h, s)
+            pt = wire.listener_port(s)
+            for i in range(svcs):
+                R.ref_keyed_register(k, h, int(ns[i]), int(pt[i]))
+        buf = np.frombuffer(host, dtype=np.uint8)
+        sh_a = np.ascontiguousarray(sh, dtype=np.uint32)
+        sf_a = np.ascontiguousarray(sf, dtype=np.uint64)
+        t3 = time.perf_counter()
+        added = R.ref_keyed_resp_batch(k, buf.ctypes.data, nevents, o.ptr(sh_a, o.u32p), o.ptr(sf_a, o.u64p), len(sh_a))
+        t4 = time.perf_counter()
+        R.ref_keyed_free(k)
+        if added:
+            ref_rate = nevents / (t4 - t3)
+    return nevents / (t1 - t0), nevents / (t2 - t1), desc, ref_rate
 
 
 def quantile_error(eng, torch, ingested, nlocal, svcs, host_ids, host_slots, wire):
@@ -282,9 +303,12 @@ def main():
         if qerr is not None:
             out["quantile_error"] = qerr
         if not args.no_cpu_baseline:
-            full, honly, desc = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234)
+            full, honly, desc, ref_rate = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234)
             out["cpu_baseline"] = {"value": full, "unit": "events/s", "cores": 1, "kind": "port", "sample": desc,
                                    "histonly_value": honly}
+            if ref_rate is not None:  # the reference's own GY_HISTOGRAM + GY_JHASHER compiled from /root/reference (oracle/_ref)
+                out["cpu_baseline"]["reference_hist_value"] = ref_rate
+                out["cpu_baseline"]["reference_hist_kind"] = "reference"
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -160,6 +160,13 @@ struct gys_ctx {
 	uint64_t *ev_kv = nullptr;
 	uint32_t *staged = nullptr, *staged2 = nullptr; // double-buffered: the merges of batch b read theirs while batch b+1 is staged
 	int staged_sel = 0;
+	// the window boundary's fixed sequence of copies / clears, captured once per registry shape as a hipGraph and replayed
+	hipGraph_t win_graph = nullptr;
+	hipGraphExec_t win_graph_exec = nullptr;
+	uint64_t win_graph_shape = 0; // (hosts, services) the graph was captured for
+	int win_graph_state = 0;      // 0 not tried, 1 usable, -1 capture unavailable: plain launches
+	uint64_t win_graph_launches = 0;
+	int64_t i64min = INT64_MIN;   // stable host source of the graph's 8-byte copy
 	bool aux_pending = false; // merges still running on aux_stream (joined before the next per-key pass and before digest reads)
 	uint32_t *huge_list = nullptr, *huge_count = nullptr, *huge_scratch = nullptr;
 	int huge_blocks = 0;
@@ -832,6 +839,8 @@ void gys_destroy(gys_ctx *c)
 	if (!c) return;
 	if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
 	if (c->stream) hipStreamSynchronize(c->stream);
+	if (c->win_graph_exec) hipGraphExecDestroy(c->win_graph_exec);
+	if (c->win_graph) hipGraphDestroy(c->win_graph);
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
 			c->td_cnt, c->td_meta, c->td_pend, c->merge_list, c->merge_count, c->query_sum, c->query_cnt, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->staged2, c->huge_list, c->huge_count,
@@ -1295,23 +1304,50 @@ int gys_window_finish(gys_ctx *c)
 		return GYS_ERR_STATE;
 	}
 	ProfScope ps(c, "window_finish");
-	// keep the (reduced) registers of this window for queries, start the next window from zero
-	HIPCHK(hipMemcpyAsync(c->last, c->arena, c->al.total, hipMemcpyDeviceToDevice, c->stream));
-	HIPCHK(hipMemsetAsync(c->arena, 0, c->al.total, c->stream));
-	{
-		const int64_t mn = INT64_MIN;
-		HIPCHK(hipMemcpyAsync(c->arena + c->al.off_i64max, &mn, 8, hipMemcpyHostToDevice, c->stream));
+	// keep the (reduced) registers of this window for queries, start the next window from zero.  The sequence is the same every
+	// window for a given registry shape: it is captured into a hipGraph the first time and replayed afterwards (one launch instead
+	// of seven); any capture problem falls back to plain stream operations.
+	const uint64_t shape = ((uint64_t)c->hosts.size() << 32) | (uint64_t)c->nsvc;
+	auto enqueue = [&](hipStream_t st) -> hipError_t {
+		hipError_t e;
+		if ((e = hipMemcpyAsync(c->last, c->arena, c->al.total, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+		if ((e = hipMemsetAsync(c->arena, 0, c->al.total, st)) != hipSuccess) return e;
+		if ((e = hipMemcpyAsync(c->arena + c->al.off_i64max, &c->i64min, 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+		if ((e = hipMemsetAsync(c->hll32, 0, (uint64_t)4 << GYS_HLL_P, st)) != hipSuccess) return e;
+		if (c->nsvc) {
+			// CONN_BITMAP cleared every window (secs_to_reset_ = 5); lazily (per key, on its next touch) when the per-key pass runs
+			if (!c->cfg.enable_tdigest && (e = hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * 64, st)) != hipSuccess) return e;
+			if (c->svc_hll && (e = hipMemsetAsync(c->svc_hll, 0, (uint64_t)c->nsvc << c->cfg.svc_hll_p, st)) != hipSuccess) return e;
+		}
+		const uint64_t hb = (uint64_t)c->hosts.size() * 16 * 4;
+		if (hb) {
+			if ((e = hipMemcpyAsync(c->host_summ_last, c->host_summ_win, hb, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+			if ((e = hipMemsetAsync(c->host_summ_win, 0, hb, st)) != hipSuccess) return e;
+		}
+		return hipSuccess;
+	};
+	if (c->win_graph_state >= 0 && (c->win_graph_state == 0 || c->win_graph_shape != shape)) {
+		if (c->win_graph_exec) hipGraphExecDestroy(c->win_graph_exec);
+		if (c->win_graph) hipGraphDestroy(c->win_graph);
+		c->win_graph_exec = nullptr;
+		c->win_graph = nullptr;
+		c->win_graph_state = -1;
+		if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+			const hipError_t e1 = enqueue(c->stream);
+			const hipError_t e2 = hipStreamEndCapture(c->stream, &c->win_graph);
+			if (e1 == hipSuccess && e2 == hipSuccess && c->win_graph &&
+			    hipGraphInstantiate(&c->win_graph_exec, c->win_graph, nullptr, nullptr, 0) == hipSuccess) {
+				c->win_graph_state = 1;
+				c->win_graph_shape = shape;
+			}
+		}
+		(void)hipGetLastError();
 	}
-	HIPCHK(hipMemsetAsync(c->hll32, 0, (uint64_t)4 << GYS_HLL_P, c->stream));
-	if (c->nsvc) {
-		// CONN_BITMAP cleared every window (secs_to_reset_ = 5); lazily (per key, on its next touch) when the per-key pass runs
-		if (!c->cfg.enable_tdigest) HIPCHK(hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * 64, c->stream));
-		if (c->svc_hll) HIPCHK(hipMemsetAsync(c->svc_hll, 0, (uint64_t)c->nsvc << c->cfg.svc_hll_p, c->stream));
-	}
-	const uint64_t hb = (uint64_t)c->hosts.size() * 16 * 4;
-	if (hb) {
-		HIPCHK(hipMemcpyAsync(c->host_summ_last, c->host_summ_win, hb, hipMemcpyDeviceToDevice, c->stream));
-		HIPCHK(hipMemsetAsync(c->host_summ_win, 0, hb, c->stream));
+	if (c->win_graph_state == 1) {
+		HIPCHK(hipGraphLaunch(c->win_graph_exec, c->stream));
+		c->win_graph_launches++;
+	} else {
+		HIPCHK(enqueue(c->stream));
 	}
 	HIPCHK(hipGetLastError());
 	c->epoch++;
@@ -1713,6 +1749,7 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 	out->lstate_deleted = v[CTR_LSTATE_DELETED];
 	out->resp_batches_host_local = c->n_batches_host_local;
 	out->resp_batches_general = c->n_batches_general;
+	out->window_graph_launches = c->win_graph_launches;
 	return GYS_OK;
 }
 

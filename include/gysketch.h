@@ -281,6 +281,7 @@ typedef struct {
 	uint64_t conn_events, conn_unknown_service;
 	uint64_t lstate_records, lstate_missed, lstate_errors, lstate_deleted;
 	uint64_t resp_batches_host_local, resp_batches_general; /* which resp pipeline each ingest call took (gys_config.resp_path) */
+	uint64_t window_graph_launches; /* window boundaries replayed from the captured hipGraph (0: plain stream operations were used) */
 } gys_counters;
 int gys_get_counters(gys_ctx *ctx, gys_counters *out);
 

@@ -212,6 +212,12 @@ def ref():
     _sig(R, "ref_hist_merge", None, [C.c_void_p, C.c_void_p])
     _sig(R, "ref_hist_clear", None, [C.c_void_p])
     _sig(R, "ref_topn_u64", C.c_size_t, [u64p, C.c_size_t, C.c_size_t, u64p])
+    if hasattr(R, "ref_keyed_new"):  # present in builds of oracle/ref_glue.cc that carry the keyed CPU-baseline loop
+        _sig(R, "ref_keyed_new", C.c_void_p, [])
+        _sig(R, "ref_keyed_free", None, [C.c_void_p])
+        _sig(R, "ref_keyed_register", C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint16])
+        _sig(R, "ref_keyed_resp_batch", C.c_uint64, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
+        _sig(R, "ref_keyed_total", C.c_uint64, [C.c_void_p, C.c_uint32])
     _ref = R
     return R
 

@@ -19,6 +19,7 @@
 //   common/gy_statistics.h:455-894       HIST_SERIAL, GY_HISTOGRAM (add_data, add_histogram, get_percentiles ...)
 //   common/gy_statistics.h:1565-2063     bucket-hash classes
 //   common/gy_statistics.h:28-453        BOUNDED_PRIO_QUEUE
+#include <unordered_map>
 #include "gy_common_inc.h"
 #include "gy_statistics.h"
 #include "gy_inet_inc.h"
@@ -226,4 +227,53 @@ size_t ref_topn_u64(const uint64_t *vals, size_t n, size_t maxn, uint64_t *out)
 	return r.size();
 }
 
+
+// ---- the reference's own per-event work on the response path, keyed, for the CPU baseline of bench.py (kind "reference"):
+// listener lookup by (host, netns, port) in an unordered_map hashed with the reference's GY_JHASHER (stand-in for the liburcu RCU
+// table listener_tbl_, which is not buildable here), then GY_HISTOGRAM<int64_t, RESP_TIME_HASH>::add_data -- the reference class
+// itself, common/gy_statistics.h:596-623 -- per event; the tresp filter as common/gy_socket_stat.cc:1519-1524.
+struct RefKeyed {
+	std::unordered_map<uint64_t, uint32_t, GY_JHASHER<uint64_t>> tbl;
+	std::vector<GY_HISTOGRAM<int64_t, RESP_TIME_HASH>> hist;
+};
+
+void *ref_keyed_new(void) { return new RefKeyed(); }
+void ref_keyed_free(void *p) { delete static_cast<RefKeyed *>(p); }
+uint32_t ref_keyed_register(void *p, uint32_t host, uint32_t netns, uint16_t port)
+{
+	RefKeyed *k = static_cast<RefKeyed *>(p);
+	const uint64_t key = ((uint64_t)host << 48) | ((uint64_t)netns << 16) | port;
+	auto it = k->tbl.find(key);
+	if (it != k->tbl.end()) return it->second;
+	const uint32_t idx = (uint32_t)k->hist.size();
+	k->hist.emplace_back(1);
+	k->tbl.emplace(key, idx);
+	return idx;
+}
+// returns the number of events added to a histogram
+uint64_t ref_keyed_resp_batch(void *p, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs)
+{
+	RefKeyed *k = static_cast<RefKeyed *>(p);
+	uint64_t added = 0;
+	uint32_t seg = 0;
+	for (uint64_t i = 0; i < n; ++i) {
+		const uint8_t *e = ev24 + i * 24;
+		uint32_t netns, lsnd, lrcv;
+		uint16_t sport_be;
+		std::memcpy(&netns, e + 8, 4);
+		std::memcpy(&sport_be, e + 12, 2);
+		std::memcpy(&lsnd, e + 16, 4);
+		std::memcpy(&lrcv, e + 20, 4);
+		while (seg + 1 < nsegs && seg_first[seg + 1] <= i) seg++;
+		const uint32_t tresp = lsnd - lrcv;
+		if (tresp > 1000000u) continue;
+		const uint16_t sport = (uint16_t)((sport_be >> 8) | (sport_be << 8));
+		auto it = k->tbl.find(((uint64_t)seg_host[seg] << 48) | ((uint64_t)netns << 16) | sport);
+		if (it == k->tbl.end()) continue;
+		k->hist[it->second].add_data((int64_t)tresp, 1);
+		added++;
+	}
+	return added;
+}
+uint64_t ref_keyed_total(void *p, uint32_t idx) { return static_cast<RefKeyed *>(p)->hist[idx].get_total_count(); }
 }  // extern "C"

@@ -346,4 +346,5 @@ def test_resp_windows_roll_lazily(torch_mod, oracle, resp_path):
         for o in (orc_all, orc_win):
             o.window_clear(clear_hist=o is orc_win)
     _assert_path(eng, resp_path)
+    assert eng.counters()["window_graph_launches"] == len(plan)  # every boundary replayed the captured hipGraph
     eng.close()

@@ -138,3 +138,33 @@ def test_topn_random(oracle, reflib):
 
 def test_struct_sizes(reflib):
     assert [reflib.ref_sizeof(i) for i in range(7)] == [24, 32, 64, 40, 16, 280, 32]
+
+
+def test_keyed_resp_loop_of_the_reference_classes_matches_the_port(oracle):
+    """bench.py's cpu_baseline kind "reference": the reference's own GY_HISTOGRAM<int64_t, RESP_TIME_HASH> behind an unordered_map with
+    GY_JHASHER (oracle/ref_glue.cc) must count exactly what the plain-C port counts on the same event bytes"""
+    R = oracle.ref()
+    if R is None or not hasattr(R, "ref_keyed_new"):
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    from gyeeta_amd import wire
+    from tests import helpers
+    rng = np.random.default_rng(1)
+    k = R.ref_keyed_new()
+    orc = oracle.OracleEngine(64, enable_td=False)
+    for h in range(3):
+        s = np.arange(6)
+        ns, pt, g = wire.listener_netns(h, s), wire.listener_port(s), wire.glob_id(np.full(6, h), s)
+        for i in range(6):
+            assert R.ref_keyed_register(k, h, int(ns[i]), int(pt[i])) == h * 6 + i
+            orc.register(h, int(g[i]), int(ns[i]), int(pt[i]))
+    added = 0
+    for h in range(3):
+        ev = helpers.make_resp_events(rng, h, 4000, 6)
+        b = ev.tobytes()
+        buf = np.frombuffer(b, dtype=np.uint8)
+        sh, sf = np.array([h], dtype=np.uint32), np.array([0], dtype=np.uint64)
+        added += R.ref_keyed_resp_batch(k, buf.ctypes.data, 4000, oracle.ptr(sh, oracle.u32p), oracle.ptr(sf, oracle.u64p), 1)
+        orc.resp_batch(b, [h], [0])
+    assert added == orc.counters()["accepted"]
+    assert [R.ref_keyed_total(k, i) for i in range(18)] == orc.hist()[:18, 15, 0].tolist()
+    R.ref_keyed_free(k)
