@@ -297,7 +297,11 @@ def main():
                        "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_ms": dom_ms_avg, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_ms": dom_ms_avg, "launches_per_step": dom[1][1] / max(args.steps, 1),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "pipeline": {"achieved": alg_bytes / (dt / args.steps) / 1e9, "frac": alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "24 B x events / whole step; stage times below overlap (key ranges of the per-key pass "
+                                              "run against the merges on a second stream), so they add up to more than a step"},
                          "kernels_ms_avg": {k: v[0] / max(args.steps, 1) for k, v in prof.items()}},
         }
         if qerr is not None:

@@ -497,10 +497,6 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			const uint64_t budget = 150u * 1024u;
 			hp.lds_region_entries = (fixed + max_len * 4 <= budget) ? (uint32_t)align_up(max_len, 2) : 0u;
 		}
-		{
-			static const char *dbg = getenv("GYS_DBG_SKIP"); // timing experiments only: results are wrong when set
-			hp.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
-		}
 		const size_t dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_cnt_entries * 4 + (size_t)hp.lds_region_entries * 4;
 		ProfScope ps(c, "resp_host");
 		HIPCHK(hipMemsetAsync(c->huge_count, 0, 4, c->stream));
@@ -573,9 +569,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		const uint32_t nchunks = (nsvc + 63u) / 64u;
 		const uint32_t npipe = nchunks >= 4096u ? GYS_KEY_PIPE : 1u;
 		const uint32_t per = (nchunks + npipe - 1) / npipe;
-		static const char *dbg = getenv("GYS_DBG_SKIP");
-		const uint32_t dbgv = dbg ? (uint32_t)atoi(dbg) : 0u;
-		const bool overlap = !(dbgv & 64u);
+		// GYS_NO_OVERLAP=1 serialises the two streams (A/B timing; results are identical either way)
+		static const char *no_ov = getenv("GYS_NO_OVERLAP");
+		const bool overlap = !(no_ov && no_ov[0] == '1');
 		// the previous batch's merges may still be running (they overlapped this batch's resp pass, which only touches its own staging
 		// buffer): the per-key pass appends to the digest buffers and must see them finished
 		join_aux(c);
@@ -603,7 +599,6 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			mp.d = dr;
 			mp.list = dr.merge_list;
 			mp.count = dr.merge_count;
-			mp.dbg = dbgv;
 			const uint32_t mgrid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>((uint64_t)(hi - lo) * 64u, n), (uint64_t)c->ncu * 32);
 			hipLaunchKernelGGL(k_digest_merge<128u>, dim3(mgrid), dim3(64), 0, ms, mp);
 			hipLaunchKernelGGL(k_digest_merge<GYS_SMALL_MAX>, dim3(std::min<uint32_t>(mgrid, (uint32_t)c->ncu * 8)), dim3(64), 0, ms, mp);
@@ -611,7 +606,6 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		if (overlap && npipe > 1) { // not joined here: the next batch's resp pass may start while the last merges finish (join_aux)
 			HIPCHK(hipEventRecord(c->ev_aux, c->aux_stream));
 			c->aux_pending = true;
-			if (dbgv & 128u) join_aux(c);
 		}
 		c->staged_sel ^= 1;
 	}

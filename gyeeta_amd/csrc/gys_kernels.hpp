@@ -329,7 +329,6 @@ struct RespHostP {
 	uint32_t lds_tbl_entries; // LDS table area of the launch (largest sub-table among the batch's hosts)
 	uint32_t lds_cnt_entries; // LDS count area (largest listener count, even)
 	uint32_t lds_region_entries; // LDS scatter region of the launch (u32 entries, 0 = none): segments that fit are sorted there
-	uint32_t dbg; // timing experiments only (GYS_DBG_SKIP): 1 no HLL, 2 no staged store, 4 no pass B, 8 no ev_kv store
 };
 
 __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	// window that is all but ~2^-floor of the events; without it every event pays a random 4-byte read.
 	if (tid == 0) s_floor = 0xFFFFFFFFu;
 	__syncthreads();
-	if (e1 - e0 >= 4096u && !(p.dbg & 16u)) {
+	if (e1 - e0 >= 4096u) {
 		uint32_t mn = 0xFFFFFFFFu;
 		const uint4 *h4 = (const uint4 *)p.hll32;
 		for (uint32_t i = tid; i < (1u << GYS_HLL_P) / 4u; i += GYS_HOST_THREADS) {
@@ -428,13 +427,13 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 			if (p.svc_hll_p) svc_hll_update(p.svc_hll, p.svc_hll_p, p.hlst[hd.lst_off + local], h64);
 		}
 #pragma unroll
-		for (int u = 0; u < GYS_HOST_UNROLL; ++u) hcur[u] = (hrank[u] && !(p.dbg & 1u)) ? p.hll32[hidx[u]] : 0xFFu; // read-first: most events do not raise the register
+		for (int u = 0; u < GYS_HOST_UNROLL; ++u) hcur[u] = hrank[u] ? p.hll32[hidx[u]] : 0xFFu; // read-first: most events do not raise the register
 #pragma unroll
 		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
 			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
 			if (hcur[u] < hrank[u]) atomicMax(&p.hll32[hidx[u]], hrank[u]);
 			if (kv[u] != ~0ull) atomicAdd(&s_cnt[(uint32_t)(kv[u] >> 32)], 1u);
-			if (i < e1 && !(p.dbg & 8u)) p.ev_kv[i] = kv[u];
+			if (i < e1) p.ev_kv[i] = kv[u];
 		}
 	}
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
@@ -475,7 +474,7 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	// before its line is complete becomes a read-modify-write in HBM, so when the segment's slice fits the LDS region the runs are
 	// assembled there and written out with coalesced full-line stores.
 	const bool in_lds = (e1 - e0) <= (uint64_t)p.lds_region_entries;
-	for (uint64_t base = e0 + tid; base < e1 && !(p.dbg & 4u); base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
+	for (uint64_t base = e0 + tid; base < e1; base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
 		uint64_t kv[GYS_HOST_UNROLL];
 #pragma unroll
 		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
@@ -487,7 +486,7 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 			if (kv[u] == ~0ull) continue;
 			const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)(kv[u] >> 32)], 1u);
 			if (in_lds) s_region[pos] = (uint32_t)kv[u];
-			else if (!(p.dbg & 2u)) p.staged[e0 + pos] = (uint32_t)kv[u];
+			else p.staged[e0 + pos] = (uint32_t)kv[u];
 		}
 	}
 	if (in_lds) {
@@ -816,7 +815,6 @@ struct MergeP {
 	const uint32_t *count;
 	int64_t *out_sum;
 	uint32_t *out_cnt;
-	uint32_t dbg; // timing experiments only (GYS_DBG_SKIP bit 32: no value grid)
 };
 
 // Two instantiations share the list: NEWMAX = 128 (LDS for 384 values: the common case, ~2x the resident waves) takes the entries with
@@ -926,7 +924,7 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 				// refined interval: the cluster means AND a fixed quarter-octave value grid cut the axis (both monotone in v, so their
 				// sum numbers the cells of the common refinement in value order); the grid bounds a cell's population when the digest
 				// is still empty or the distribution has moved away from its clusters
-				const uint32_t iv = lo + ((q.dbg & 32u) ? 0u : value_grid(uv));
+				const uint32_t iv = lo + value_grid(uv);
 				s_x[i] = (iv << 20) | uv;
 				atomicAdd(&s_icnt[iv], 1u);
 				atomicMin(&s_imin[iv], uv);
@@ -993,7 +991,7 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 					r += (y < x || (y == x && u < e)) ? 1u : 0u;
 				}
 			}
-			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[iv - ((q.dbg & 32u) ? 0u : value_grid(x & 0xFFFFFu))]) + 1ull; // old weight with mean <= v
+			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[iv - value_grid(x & 0xFFFFFu)]) + 1ull; // old weight with mean <= v
 			const uint32_t a = td_cluster_of128(s_T, mid2);
 			atomicAdd(&s_osum[a], (unsigned long long)(x & 0xFFFFFu));
 			atomicAdd(&s_ocnt[a], 1u);

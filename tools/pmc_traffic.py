@@ -14,7 +14,9 @@ NAMES = {"k_resp_host": "resp_host", "k_key_pass": "key_pass", "k_digest_merge":
 
 
 def per_kernel(root, counter, skip):
-    vals = collections.defaultdict(lambda: collections.defaultdict(float))
+    """bytes-counter per kernel and STEP: a bench step starts at a k_resp_host dispatch; every dispatch of the other pipeline kernels
+    up to the next k_resp_host belongs to it (key ranges and merge size classes are several launches per step)"""
+    rows = []
     for d, _, fs in os.walk(root):
         for f in fs:
             if f.endswith("counter_collection.csv"):
@@ -23,19 +25,21 @@ def per_kernel(root, counter, skip):
                         continue
                     for k, short in NAMES.items():
                         if k in r["Kernel_Name"]:
-                            vals[short][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+                            rows.append((int(r["Dispatch_Id"]), short, float(r["Counter_Value"])))
+    rows.sort()
+    starts = sorted({d for d, short, _ in rows if short == "resp_host"})
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    import bisect
+    for d, short, v in rows:
+        step = bisect.bisect_right(starts, d) - 1
+        if step >= 0:
+            per[short][step] += v
     out = {}
-    for short, disp in vals.items():
-        ids = sorted(disp)
-        # several instantiations of one kernel share a profile name: group consecutive dispatches per bench step
-        per_step = collections.defaultdict(float)
-        order = {d: i for i, d in enumerate(ids)}
-        n_per_step = 2 if short == "digest_merge" else 1
-        for d in ids:
-            per_step[order[d] // n_per_step] += disp[d]
-        steps = sorted(per_step)[skip:]
-        if steps:
-            out[short] = sum(per_step[s] for s in steps) / len(steps)
+    for short, steps in per.items():
+        # only full-size steps: the set-up passes before the first timed window use other batch sizes; keep the LAST (nsteps - skip)
+        ids = sorted(steps)[skip:]
+        if ids:
+            out[short] = sum(steps[i] for i in ids) / len(ids)
     return out
 
 
