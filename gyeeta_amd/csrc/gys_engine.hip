@@ -112,6 +112,7 @@ ArenaLayout arena_layout(uint32_t max_clusters)
 
 } // namespace
 
+#define GYS_SEG_RING 4
 #define GYS_KEY_PIPE 8 // key ranges per batch: k_key_pass of range i+1 (HBM-bound) overlaps the merges of range i (issue-bound)
 
 struct gys_ctx {
@@ -179,8 +180,15 @@ struct gys_ctx {
 	uint32_t *host_state_epoch = nullptr, *host_cluster = nullptr;
 	uint64_t *counters = nullptr;
 	uint32_t *misc = nullptr; // [0] table insert failures, [1] topn count
-	gys_resp_seg *segs_dev = nullptr;
-	uint32_t segs_cap = 0;
+	// segment descriptors of the batches in flight: a caller's segs array is only valid during the call and several batches may be
+	// queued on the stream, so each call copies it into one of GYS_SEG_RING pinned host buffers (+ its own device buffer); a slot is
+	// reused only after the kernels that read it have finished (event)
+	struct SegSlot {
+		gys_resp_seg *host = nullptr, *dev = nullptr;
+		uint32_t cap = 0;
+		hipEvent_t done = nullptr;
+	} seg_ring[GYS_SEG_RING];
+	uint32_t seg_next = 0;
 
 	// reduce arena + last-window results
 	uint8_t *arena = nullptr;
@@ -430,15 +438,21 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			return GYS_ERR_INVAL;
 		}
 	}
-	if (nsegs > c->segs_cap) {
-		if (c->segs_dev) {
-			HIPCHK(hipStreamSynchronize(c->stream));
-			HIPCHK(hipFree(c->segs_dev));
-		}
-		c->segs_cap = std::max<uint32_t>(nsegs, 1024);
-		HIPCHK(hipMalloc((void **)&c->segs_dev, (uint64_t)c->segs_cap * sizeof(gys_resp_seg)));
+	gys_ctx::SegSlot &slot = c->seg_ring[c->seg_next];
+	c->seg_next = (c->seg_next + 1) % GYS_SEG_RING;
+	if (!slot.done) HIPCHK(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+	HIPCHK(hipEventSynchronize(slot.done)); // the batch that used this slot GYS_SEG_RING calls ago has consumed it
+	if (nsegs > slot.cap) {
+		if (slot.host) HIPCHK(hipHostFree(slot.host));
+		if (slot.dev) HIPCHK(hipFree(slot.dev));
+		slot.host = slot.dev = nullptr;
+		slot.cap = std::max<uint32_t>(nsegs, 1024);
+		HIPCHK(hipHostMalloc((void **)&slot.host, (uint64_t)slot.cap * sizeof(gys_resp_seg), hipHostMallocDefault));
+		HIPCHK(hipMalloc((void **)&slot.dev, (uint64_t)slot.cap * sizeof(gys_resp_seg)));
 	}
-	HIPCHK(hipMemcpyAsync(c->segs_dev, segs_host, (uint64_t)nsegs * sizeof(gys_resp_seg), hipMemcpyHostToDevice, c->stream));
+	memcpy(slot.host, segs_host, (uint64_t)nsegs * sizeof(gys_resp_seg));
+	HIPCHK(hipMemcpyAsync(slot.dev, slot.host, (uint64_t)nsegs * sizeof(gys_resp_seg), hipMemcpyHostToDevice, c->stream));
+	gys_resp_seg *segs_dev = slot.dev;
 
 	// ---- pipeline choice: host-local (one workgroup per host segment, LDS sub-table + LDS counting sort) when every segment is a
 	// distinct host with an LDS-sized listener table and the segments are small enough to balance; otherwise the general pipeline
@@ -473,7 +487,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		RespHostP hp{};
 		hp.ev = (const uint64_t *)d_ev;
 		hp.n = n;
-		hp.segs = c->segs_dev;
+		hp.segs = segs_dev;
 		hp.nsegs = nsegs;
 		hp.hdesc = c->hdesc;
 		hp.htbl = c->htbl;
@@ -506,7 +520,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		RespP1 p{};
 		p.ev = (const uint64_t *)d_ev;
 		p.n = n;
-		p.segs = c->segs_dev;
+		p.segs = segs_dev;
 		p.nsegs = nsegs;
 		p.lk = c->lk_tbl;
 		p.svc_gid = c->svc_gid;
@@ -524,7 +538,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			hipLaunchKernelGGL(k_resp_pass1, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
 		}
 		HIPCHK(hipGetLastError());
-		if (!td || nsvc == 0) return GYS_OK;
+		if (!td || nsvc == 0) {
+			HIPCHK(hipEventRecord(slot.done, c->stream));
+			return GYS_OK;
+		}
 		const uint32_t nblk = (nsvc + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE;
 		{
 			ProfScope ps(c, "scan");
@@ -541,6 +558,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		}
 	}
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(slot.done, c->stream)); // the segment descriptors have been consumed once the stream gets here
 	DigestP d{};
 	d.td_sum = c->td_sum;
 	d.td_cnt = c->td_cnt;
@@ -795,13 +813,16 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_SMALL_MAX + 1));
 		if (c->huge_blocks < 1) c->huge_blocks = 1;
 		ALLOC(c->huge_scratch, (uint64_t)c->huge_blocks * GYS_HUGE_BINS);
-		hipLaunchKernelGGL(k_tdmeta_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, (uint4 *)c->td_meta, S);
-		{
-			const uint32_t one = 1;
-			HIPCHK(hipMemcpyAsync(c->merge_count + GYS_KEY_PIPE, &one, 4, hipMemcpyHostToDevice, c->stream));
-		}
 	}
 #undef ALLOC
+	// dev_alloc zeroes with hipMemset on the NULL stream, which may still be in flight; the context stream is non-blocking, so the
+	// initialisation kernels / copies below must not start before every one of those clears has landed
+	HIPCHK(hipDeviceSynchronize());
+	if (cfg->enable_tdigest) {
+		hipLaunchKernelGGL(k_tdmeta_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, (uint4 *)c->td_meta, S);
+		static const uint32_t one = 1; // static: the source of an async copy must outlive the call
+		HIPCHK(hipMemcpyAsync(c->merge_count + GYS_KEY_PIPE, &one, 4, hipMemcpyHostToDevice, c->stream));
+	}
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_win, (uint64_t)0, S, (int64_t)INT64_MIN);
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_all, (uint64_t)0, S, (int64_t)INT64_MIN);
 	c->al = arena_layout(cfg->max_clusters);
@@ -820,8 +841,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	HIPCHK(hipMemsetAsync(c->arena, 0, c->al.total, c->stream));
 	HIPCHK(hipMemsetAsync(c->last, 0, c->al.total, c->stream));
 	{
-		const int64_t mn = INT64_MIN;
-		HIPCHK(hipMemcpyAsync(c->arena + c->al.off_i64max, &mn, 8, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(c->arena + c->al.off_i64max, &c->i64min, 8, hipMemcpyHostToDevice, c->stream));
 	}
 	HIPCHK(hipStreamSynchronize(c->stream));
 	*out = c;
@@ -835,12 +855,17 @@ void gys_destroy(gys_ctx *c)
 	if (c->stream) hipStreamSynchronize(c->stream);
 	if (c->win_graph_exec) hipGraphExecDestroy(c->win_graph_exec);
 	if (c->win_graph) hipGraphDestroy(c->win_graph);
+	for (auto &sl : c->seg_ring) {
+		if (sl.host) hipHostFree(sl.host);
+		if (sl.dev) hipFree(sl.dev);
+		if (sl.done) hipEventDestroy(sl.done);
+	}
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
 			c->td_cnt, c->td_meta, c->td_pend, c->merge_list, c->merge_count, c->query_sum, c->query_cnt, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->staged2, c->huge_list, c->huge_count,
 			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
-			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->segs_dev, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
+			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -985,7 +1010,10 @@ int gys_ingest_resp_events(gys_ctx *c, const uint8_t machine_id[16], const void 
 	if (rc) return rc;
 	HIPCHK(hipMemcpyAsync(c->dev_staging, ev24, (uint64_t)nevents * 24, hipMemcpyHostToDevice, c->stream));
 	gys_resp_seg seg{host, 0, 0};
-	return run_resp_batch(c, &seg, 1, c->dev_staging, nevents);
+	rc = run_resp_batch(c, &seg, 1, c->dev_staging, nevents);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(c->stream)); // ev24 is only valid during the call and dev_staging is reused by the next one
+	return GYS_OK;
 }
 
 int gys_ingest_tcp_conn_dev(gys_ctx *c, const void *d_batch, const uint32_t *d_offsets, uint32_t nconns)
