@@ -819,14 +819,28 @@ struct MergeP {
 
 // Two instantiations share the list: NEWMAX = 128 (LDS for 384 values: the common case, ~2x the resident waves) takes the entries with
 // <= 128 new values, NEWMAX = GYS_SMALL_MAX the rest.
+// ceil(cs / cc) for 0 <= cs < 2^52, cc >= 1 (a cluster's integer "mean threshold": mean <= v  <=>  ceil(cs/cc) <= v for integer v)
+__device__ __forceinline__ uint32_t ceil_div_sum_cnt(int64_t cs, uint32_t cc)
+{
+	uint64_t f = (uint64_t)((double)cs / (double)cc); // cs is exact in a double; the quotient may be off by one after rounding
+	int64_t r = cs - (int64_t)(f * (uint64_t)cc);
+	if (r < 0) {
+		f--;
+		r += cc;
+	} else if (r >= (int64_t)cc) {
+		f++;
+		r -= cc;
+	}
+	return (uint32_t)(f + (r != 0));
+}
+
 template <uint32_t NEWMAX>
 __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 {
 	const DigestP &p = q.d;
 	__shared__ uint32_t s_x[GYS_TD_PEND_CAP + NEWMAX];  // interval << 20 | value, in arrival order
 	__shared__ uint32_t s_g[GYS_TD_PEND_CAP + NEWMAX];  // the same words grouped by interval
-	__shared__ int64_t s_csum[128];          // compacted non-empty old clusters, padded with +inf means for the branch-free search
-	__shared__ uint32_t s_ccnt[128];
+	__shared__ uint32_t s_thr[128];          // compacted non-empty old clusters: ceil(sum / count), padded with ~0 for the branch-free search
 	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
 	__shared__ uint64_t s_T[128];            // s_T[j], j = 1..NB-1; [NB..127] = ~0 (never reached)
 	__shared__ uint32_t s_imin[GYS_IVL], s_imax[GYS_IVL]; // smallest / largest value of each interval
@@ -865,33 +879,25 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			}
 			continue;
 		}
-		// compaction of non-empty clusters (order preserving)
+		// compaction of non-empty clusters (order preserving): compacted index pos0 / pos1 of this lane's two entries
 		const unsigned long long b0 = __ballot(c0 != 0), b1 = __ballot(c1 != 0);
 		const uint32_t n0 = (uint32_t)__popcll(b0), nc = n0 + (uint32_t)__popcll(b1);
 		const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+		const uint32_t pos0 = (uint32_t)__popcll(b0 & below), pos1 = n0 + (uint32_t)__popcll(b1 & below);
 		uint64_t e0, e1, nold;
 		wave_excl_scan_2x((uint64_t)c0, (uint64_t)c1, &e0, &e1, &nold);
+		s_thr[lane] = 0xFFFFFFFFu; // pad: mean = +inf
+		s_thr[j1] = 0xFFFFFFFFu;
+		GYS_WAVE_SYNC();
 		if (c0) {
-			const uint32_t pos = (uint32_t)__popcll(b0 & below);
-			s_csum[pos] = sm0;
-			s_ccnt[pos] = c0;
-			s_cpfx[pos] = e0;
+			s_thr[pos0] = ceil_div_sum_cnt(sm0, c0);
+			s_cpfx[pos0] = e0;
 		}
 		if (c1) {
-			const uint32_t pos = n0 + (uint32_t)__popcll(b1 & below);
-			s_csum[pos] = sm1;
-			s_ccnt[pos] = c1;
-			s_cpfx[pos] = e1;
+			s_thr[pos1] = ceil_div_sum_cnt(sm1, c1);
+			s_cpfx[pos1] = e1;
 		}
 		if (lane == 0) s_cpfx[nc] = nold;
-		if (lane >= nc) { // pad: mean = +inf
-			s_csum[lane] = INT64_MAX;
-			s_ccnt[lane] = 1;
-		}
-		if (j1 >= nc) {
-			s_csum[j1] = INT64_MAX;
-			s_ccnt[j1] = 1;
-		}
 		const uint64_t twoN = 2ull * (nold + (uint64_t)m);
 		if (lane >= 1) s_T[lane] = td_threshold(c_td_bnd[lane], twoN);
 		s_T[j1] = j1 < GYS_TD_NB ? td_threshold(c_td_bnd[j1], twoN) : ~0ull;
@@ -909,27 +915,39 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			s_ocnt[j1] = 0;
 		}
 		__syncthreads();
-		// ---- values (buffered, then new): interval = first cluster with mean > v  (csum > v * ccnt), counted per interval
+		// ---- values (buffered, then new): gap = #{clusters with mean <= v} = #{thresholds <= v}, two values per lane and iteration so that
+		// the two 7-step dependent LDS searches overlap
 		{
 			const uint32_t *pend = p.td_pend + (size_t)slot * GYS_TD_PEND_CAP;
-			for (uint32_t i = lane; i < m; i += 64u) {
-				const uint32_t uv = i < npend ? pend[i] : (p.staged[start + (i - npend)] >> GYS_ROW_BITS);
-				const int64_t v = (int64_t)uv;
-				uint32_t lo = 0; // #{clusters with mean <= v}: branch-free lower bound over the padded 128-entry arrays
+			for (uint32_t base = 0; base < m; base += 128u) {
+				uint32_t uv[2], lo[2];
+#pragma unroll
+				for (int u = 0; u < 2; ++u) {
+					const uint32_t i = base + lane + 64u * u;
+					uv[u] = 0;
+					if (i < m) uv[u] = i < npend ? pend[i] : (p.staged[start + (i - npend)] >> GYS_ROW_BITS);
+					lo[u] = 0;
+				}
 #pragma unroll
 				for (uint32_t step = 64u; step >= 1u; step >>= 1) {
-					const uint32_t c = lo + step - 1u;
-					if (s_csum[c] <= v * (int64_t)s_ccnt[c]) lo += step;
+#pragma unroll
+					for (int u = 0; u < 2; ++u)
+						if (s_thr[lo[u] + step - 1u] <= uv[u]) lo[u] += step;
 				}
-				// refined interval: the cluster means AND a fixed quarter-octave value grid cut the axis (both monotone in v, so their
-				// sum numbers the cells of the common refinement in value order); the grid bounds a cell's population when the digest
-				// is still empty or the distribution has moved away from its clusters
-				const uint32_t iv = lo + value_grid(uv);
-				s_x[i] = (iv << 20) | uv;
-				atomicAdd(&s_icnt[iv], 1u);
-				atomicMin(&s_imin[iv], uv);
-				atomicMax(&s_imax[iv], uv);
-				atomicAdd(&s_clt[lo + 1], 1u);
+#pragma unroll
+				for (int u = 0; u < 2; ++u) {
+					const uint32_t i = base + lane + 64u * u;
+					if (i >= m) continue;
+					// refined interval: the cluster means AND a fixed quarter-octave value grid cut the axis (both monotone in v, so
+					// their sum numbers the cells of the common refinement in value order); the grid bounds a cell's population
+					// when the digest is still empty or the distribution has moved away from its clusters
+					const uint32_t iv = lo[u] + value_grid(uv[u]);
+					s_x[i] = (iv << 20) | uv[u];
+					atomicAdd(&s_icnt[iv], 1u);
+					atomicMin(&s_imin[iv], uv[u]);
+					atomicMax(&s_imax[iv], uv[u]);
+					atomicAdd(&s_clt[lo[u] + 1], 1u);
+				}
 			}
 		}
 		__syncthreads();
@@ -940,7 +958,6 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			const uint32_t own = t0 + t1 + t2;
 			uint32_t inc = own;
 			uint32_t g0 = s_clt[lane], g1 = j1 < GYS_TD_NB + 2 ? s_clt[j1] : 0u;
-			const uint32_t h0 = g0, h1 = g1;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
 				const uint32_t u = __shfl_up(inc, d, 64), u0 = __shfl_up(g0, d, 64), u1 = __shfl_up(g1, d, 64);
@@ -959,8 +976,6 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			s_icnt[3u * lane + 1u] = ex + t0;
 			s_icnt[3u * lane + 2u] = ex + t0 + t1;
 			const uint32_t gt0 = __shfl(g0, 63, 64);
-			(void)h0;
-			(void)h1;
 			s_clt[lane] = g0;
 			if (j1 < GYS_TD_NB + 2) s_clt[j1] = gt0 + g1;
 		}
@@ -970,31 +985,63 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			s_g[atomicAdd(&s_icnt[x >> 20], 1u)] = x;
 		}
 		__syncthreads();
-		// ---- old clusters: preceded by the old clusters before them and by the values of intervals 0..c (= values below the mean)
-		for (uint32_t c = lane; c < nc; c += 64u) {
-			const uint32_t cc = s_ccnt[c];
-			const uint64_t mid2 = 2ull * (s_cpfx[c] + (uint64_t)s_clt[c + 1]) + (uint64_t)cc;
-			const uint32_t a = td_cluster_of128(s_T, mid2);
-			atomicAdd(&s_osum[a], (unsigned long long)s_csum[c]);
-			atomicAdd(&s_ocnt[a], cc);
+		// ---- old clusters (this lane's two entries, from registers): preceded by the old weight before them and by the values of
+		// gaps 0..c (= values below the mean)
+		{
+			uint64_t mid2[2] = {0, 0};
+			if (c0) mid2[0] = 2ull * (e0 + (uint64_t)s_clt[pos0 + 1]) + (uint64_t)c0;
+			if (c1) mid2[1] = 2ull * (e1 + (uint64_t)s_clt[pos1 + 1]) + (uint64_t)c1;
+			uint32_t a[2] = {0, 0};
+#pragma unroll
+			for (uint32_t step = 64u; step >= 1u; step >>= 1) {
+#pragma unroll
+				for (int u = 0; u < 2; ++u)
+					if (mid2[u] >= s_T[a[u] + step]) a[u] += step;
+			}
+			if (c0) {
+				atomicAdd(&s_osum[a[0]], (unsigned long long)sm0);
+				atomicAdd(&s_ocnt[a[0]], c0);
+			}
+			if (c1) {
+				atomicAdd(&s_osum[a[1]], (unsigned long long)sm1);
+				atomicAdd(&s_ocnt[a[1]], c1);
+			}
 		}
 		// ---- values: rank = values in lower intervals + rank inside the interval (ties by position); W adds the old weight <= v
-		for (uint32_t e = lane; e < m; e += 64u) {
-			const uint32_t x = s_g[e];
-			const uint32_t iv = x >> 20;
-			const uint32_t gb = s_ioff[iv], ge = s_ioff[iv + 1];
-			uint32_t r = e; // an interval of equal values (the usual case for integer ms data): ties rank by position
-			if (s_imin[iv] != s_imax[iv]) {
-				r = gb;
-				for (uint32_t u = gb; u < ge; ++u) {
-					const uint32_t y = s_g[u];
-					r += (y < x || (y == x && u < e)) ? 1u : 0u;
+		for (uint32_t base = 0; base < m; base += 128u) {
+			uint32_t x[2];
+			uint64_t mid2[2];
+			bool live[2];
+#pragma unroll
+			for (int u = 0; u < 2; ++u) {
+				const uint32_t e = base + lane + 64u * u;
+				live[u] = e < m;
+				x[u] = live[u] ? s_g[e] : 0u;
+				const uint32_t iv = x[u] >> 20;
+				uint32_t r = e; // an interval of equal values (the usual case for integer ms data): ties rank by position
+				if (live[u] && s_imin[iv] != s_imax[iv]) {
+					const uint32_t gb = s_ioff[iv], ge = s_ioff[iv + 1];
+					r = gb;
+					for (uint32_t t = gb; t < ge; ++t) {
+						const uint32_t y = s_g[t];
+						r += (y < x[u] || (y == x[u] && t < e)) ? 1u : 0u;
+					}
 				}
+				mid2[u] = 2ull * ((uint64_t)r + s_cpfx[iv - value_grid(x[u] & 0xFFFFFu)]) + 1ull; // old weight with mean <= v
 			}
-			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[iv - value_grid(x & 0xFFFFFu)]) + 1ull; // old weight with mean <= v
-			const uint32_t a = td_cluster_of128(s_T, mid2);
-			atomicAdd(&s_osum[a], (unsigned long long)(x & 0xFFFFFu));
-			atomicAdd(&s_ocnt[a], 1u);
+			uint32_t a[2] = {0, 0};
+#pragma unroll
+			for (uint32_t step = 64u; step >= 1u; step >>= 1) {
+#pragma unroll
+				for (int u = 0; u < 2; ++u)
+					if (mid2[u] >= s_T[a[u] + step]) a[u] += step;
+			}
+#pragma unroll
+			for (int u = 0; u < 2; ++u) {
+				if (!live[u]) continue;
+				atomicAdd(&s_osum[a[u]], (unsigned long long)(x[u] & 0xFFFFFu));
+				atomicAdd(&s_ocnt[a[u]], 1u);
+			}
 		}
 		__syncthreads();
 		// ---- write back
