@@ -510,11 +510,18 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			const uint64_t fixed = (uint64_t)max_tbl * 8 + (uint64_t)hp.lds_cnt_entries * 4;
 			const uint64_t budget = 150u * 1024u;
 			hp.lds_region_entries = (fixed + max_len * 4 <= budget) ? (uint32_t)align_up(max_len, 2) : 0u;
+			// longer segments: tile by tile through an image of GYS_HOST_TILE words + their destinations (+ two count arrays)
+			const uint64_t tile_entries = 2ull * hp.lds_cnt_entries + 2ull * GYS_HOST_TILE;
+			if (!hp.lds_region_entries && fixed + tile_entries * 4 <= budget) {
+				hp.lds_region_entries = (uint32_t)tile_entries;
+				hp.lds_tile_events = GYS_HOST_TILE;
+			}
 		}
 		const size_t dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_cnt_entries * 4 + (size_t)hp.lds_region_entries * 4;
 		ProfScope ps(c, "resp_host");
 		HIPCHK(hipMemsetAsync(c->huge_count, 0, 4, c->stream));
-		hipLaunchKernelGGL(k_resp_host, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+		if (hp.lds_tile_events) hipLaunchKernelGGL(k_resp_host<true>, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+		else hipLaunchKernelGGL(k_resp_host<false>, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
 	} else {
 		c->n_batches_general++;
 		RespP1 p{};
@@ -789,7 +796,8 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	ALLOC(c->hdesc, H);
 	c->host_lst.reserve(H);
 	// k_resp_host: up to 8192 sub-table entries + 4096 counts (80 KiB) or, for the usual small tables, a scatter region (<= 150 KiB in all)
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
 	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_tdigest) {

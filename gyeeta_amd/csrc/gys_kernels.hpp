@@ -309,6 +309,8 @@ struct HostDesc {
 #define GYS_HOST_TBL_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define GYS_HOST_THREADS 1024
 #define GYS_HOST_UNROLL 4
+#define GYS_HOST_TILE 8192u                                  // events per LDS scatter tile of a long segment
+#define GYS_HOST_TILE_PER_THREAD (GYS_HOST_TILE / GYS_HOST_THREADS)
 
 struct RespHostP {
 	const uint64_t *ev;
@@ -329,8 +331,11 @@ struct RespHostP {
 	uint32_t lds_tbl_entries; // LDS table area of the launch (largest sub-table among the batch's hosts)
 	uint32_t lds_cnt_entries; // LDS count area (largest listener count, even)
 	uint32_t lds_region_entries; // LDS scatter region of the launch (u32 entries, 0 = none): segments that fit are sorted there
+	uint32_t lds_tile_events;    // > 0: longer segments are scattered tile by tile through the region (2 x cnt + 2 x tile entries)
 };
 
+// TILED = true: the instantiation for launches with long segments (keeps a tile's records in registers: more VGPRs, one workgroup per CU)
+template <bool TILED>
 __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 {
 	extern __shared__ uint64_t s_dyn[];
@@ -473,26 +478,90 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	// ---- pass B: scatter the staged words into the key runs (positions from LDS atomics).  A scattered 4-byte store that leaves L2
 	// before its line is complete becomes a read-modify-write in HBM, so when the segment's slice fits the LDS region the runs are
 	// assembled there and written out with coalesced full-line stores.
-	const bool in_lds = (e1 - e0) <= (uint64_t)p.lds_region_entries;
-	for (uint64_t base = e0 + tid; base < e1; base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
-		uint64_t kv[GYS_HOST_UNROLL];
+	const bool tiled = TILED && p.lds_tile_events != 0 && (e1 - e0) > (uint64_t)p.lds_tile_events;
+	const bool in_lds = !tiled && (e1 - e0) <= (uint64_t)p.lds_region_entries;
+	if (tiled) {
+		// Long segment: the key runs are assembled tile by tile.  Per tile of GYS_HOST_TILE events: per-key counts of the tile (LDS), scan,
+		// scatter of the tile's words into an LDS image grouped by key together with their final positions (the key's global cursor +
+		// rank inside the tile's run), flush -- consecutive image entries of a key go to consecutive addresses, so the stores leave as
+		// full sectors -- and the cursors advance by the tile's counts.  s_cnt holds the cursors (run starts after the scan above).
+		const uint32_t Lc = p.lds_cnt_entries;
+		uint32_t *s_tstart = s_region;                 // [Lc] start of the key's run inside the tile image
+		uint32_t *s_tcur = s_region + Lc;              // [Lc] counts, then running cursor inside the tile image
+		uint32_t *s_val = s_region + 2u * Lc;          // [tile] words
+		uint32_t *s_dest = s_val + GYS_HOST_TILE;      // [tile] final position (relative to e0)
+		const uint32_t K = (L + GYS_HOST_THREADS - 1) / GYS_HOST_THREADS;
+		const uint32_t klo = tid * K, khi = min(L, klo + K);
+		for (uint64_t t0 = e0; t0 < e1; t0 += GYS_HOST_TILE) {
+			for (uint32_t k = tid; k < L; k += GYS_HOST_THREADS) s_tcur[k] = 0;
+			__syncthreads();
+			uint64_t kvr[GYS_HOST_TILE_PER_THREAD];
 #pragma unroll
-		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
-			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
-			kv[u] = i < e1 ? p.ev_kv[i] : ~0ull;
-		}
+			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u) {
+				const uint64_t i = t0 + tid + (uint64_t)u * GYS_HOST_THREADS;
+				kvr[u] = i < e1 ? p.ev_kv[i] : ~0ull;
+			}
 #pragma unroll
-		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
-			if (kv[u] == ~0ull) continue;
-			const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)(kv[u] >> 32)], 1u);
-			if (in_lds) s_region[pos] = (uint32_t)kv[u];
-			else p.staged[e0 + pos] = (uint32_t)kv[u];
+			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u)
+				if (kvr[u] != ~0ull) atomicAdd(&s_tcur[(uint32_t)(kvr[u] >> 32)], 1u);
+			__syncthreads();
+			{ // exclusive scan of the tile counts -> run starts inside the image (s_tstart) and scatter cursors (s_tcur)
+				uint32_t sum = 0;
+				for (uint32_t k = klo; k < khi; ++k) sum += s_tcur[k];
+				uint32_t inc = sum;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) {
+					const uint32_t t = __shfl_up(inc, d, 64);
+					if ((int)lane >= d) inc += t;
+				}
+				if (lane == 63) s_wsum[wave] = inc;
+				__syncthreads();
+				uint32_t run = inc - sum;
+				for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
+				for (uint32_t k = klo; k < khi; ++k) {
+					const uint32_t c = s_tcur[k];
+					s_tstart[k] = run;
+					s_tcur[k] = run;
+					run += c;
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u) {
+				if (kvr[u] == ~0ull) continue;
+				const uint32_t local = (uint32_t)(kvr[u] >> 32);
+				const uint32_t idx = atomicAdd(&s_tcur[local], 1u);
+				s_val[idx] = (uint32_t)kvr[u];
+				s_dest[idx] = s_cnt[local] + (idx - s_tstart[local]);
+			}
+			__syncthreads();
+			uint32_t ntile = 0; // valid words of the tile = end cursor of the last key = total (every thread computes it from the wave sums)
+			for (uint32_t w = 0; w < GYS_HOST_THREADS / 64; ++w) ntile += s_wsum[w];
+			for (uint32_t e = tid; e < ntile; e += GYS_HOST_THREADS) p.staged[e0 + s_dest[e]] = s_val[e];
+			for (uint32_t k = tid; k < L; k += GYS_HOST_THREADS) s_cnt[k] += s_tcur[k] - s_tstart[k];
+			__syncthreads();
 		}
-	}
-	if (in_lds) {
-		__syncthreads();
-		const uint32_t nvalid = (uint32_t)(e1 - e0) - s_drop[0] - s_drop[1];
-		for (uint32_t i = tid; i < nvalid; i += GYS_HOST_THREADS) p.staged[e0 + i] = s_region[i];
+	} else {
+		for (uint64_t base = e0 + tid; base < e1; base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
+			uint64_t kv[GYS_HOST_UNROLL];
+#pragma unroll
+			for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
+				const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
+				kv[u] = i < e1 ? p.ev_kv[i] : ~0ull;
+			}
+#pragma unroll
+			for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
+				if (kv[u] == ~0ull) continue;
+				const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)(kv[u] >> 32)], 1u);
+				if (in_lds) s_region[pos] = (uint32_t)kv[u];
+				else p.staged[e0 + pos] = (uint32_t)kv[u];
+			}
+		}
+		if (in_lds) {
+			__syncthreads();
+			const uint32_t nvalid = (uint32_t)(e1 - e0) - s_drop[0] - s_drop[1];
+			for (uint32_t i = tid; i < nvalid; i += GYS_HOST_THREADS) p.staged[e0 + i] = s_region[i];
+		}
 	}
 	if (tid == 0) {
 		atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
