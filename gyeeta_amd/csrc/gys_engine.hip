@@ -626,6 +626,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			mp.count = dr.merge_count;
 			const uint32_t mgrid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>((uint64_t)(hi - lo) * 64u, n), (uint64_t)c->ncu * 32);
 			hipLaunchKernelGGL(k_digest_merge<128u>, dim3(mgrid), dim3(64), 0, ms, mp);
+			hipLaunchKernelGGL(k_digest_merge<384u>, dim3(std::min<uint32_t>(mgrid, (uint32_t)c->ncu * 16)), dim3(64), 0, ms, mp);
 			hipLaunchKernelGGL(k_digest_merge<GYS_SMALL_MAX>, dim3(std::min<uint32_t>(mgrid, (uint32_t)c->ncu * 8)), dim3(64), 0, ms, mp);
 		}
 		if (overlap && npipe > 1) { // not joined here: the next batch's resp pass may start while the last merges finish (join_aux)

@@ -886,8 +886,8 @@ struct MergeP {
 	uint32_t *out_cnt;
 };
 
-// Two instantiations share the list: NEWMAX = 128 (LDS for 384 values: the common case, ~2x the resident waves) takes the entries with
-// <= 128 new values, NEWMAX = GYS_SMALL_MAX the rest.
+// Three instantiations share the list, split by the number of new values (LDS for CAP + NEWMAX values: the smaller the class, the more
+// waves are resident): NEWMAX = 128 takes the entries with <= 128 new values, 384 those with 129..384, GYS_SMALL_MAX the rest.
 // ceil(cs / cc) for 0 <= cs < 2^52, cc >= 1 (a cluster's integer "mean threshold": mean <= v  <=>  ceil(cs/cc) <= v for integer v)
 __device__ __forceinline__ uint32_t ceil_div_sum_cnt(int64_t cs, uint32_t cc)
 {
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 
 	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
 		const MergeEnt ent = q.list[w];
-		if (NEWMAX == 128u ? ent.m > 128u : ent.m <= 128u) continue; // the other instantiation's entry
+		if (NEWMAX == 128u ? ent.m > 128u : (NEWMAX == 384u ? (ent.m <= 128u || ent.m > 384u) : ent.m <= 384u)) continue; // another class's entry
 		const uint32_t slot = ent.slot;
 		const uint32_t npend = p.td_meta[slot].npend;
 		const uint32_t m = npend + ent.m;
