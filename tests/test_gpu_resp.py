@@ -348,3 +348,61 @@ def test_resp_windows_roll_lazily(torch_mod, oracle, resp_path):
     _assert_path(eng, resp_path)
     assert eng.counters()["window_graph_launches"] == len(plan)  # every boundary replayed the captured hipGraph
     eng.close()
+
+
+@PATHS
+def test_resp_ragged_segments_and_bad_arguments(torch_mod, oracle, resp_path):
+    """multi-host device batches with empty segments (first, middle, last), a host without events, a batch of zero events, and the
+    argument errors: first segment not at event 0, descending offsets, unknown host slot, batch above max_batch_events"""
+    torch = torch_mod
+    from gyeeta_amd import capi
+    rng = np.random.default_rng(41)
+    nh, sp = 5, 6
+    eng = _engine(max_hosts=8, max_services=64, max_batch_events=1 << 14, resp_path=resp_path)
+    orc = oracle.OracleEngine(64)
+    info, gids = helpers.register_world(eng, orc, range(nh), sp)
+    slot = {h: info[h][1] for h in range(nh)}
+
+    def run(lengths):  # lengths per host 0..nh-1 (0 = empty segment)
+        parts = [helpers.make_resp_events(rng, h, n, sp) for h, n in enumerate(lengths)]
+        buf = np.concatenate(parts) if sum(lengths) else np.zeros(0, dtype=helpers.wire.RESP_EVENT)
+        firsts = np.cumsum([0] + list(lengths[:-1]))
+        segs = (capi.RespSeg * nh)()
+        for h in range(nh):
+            segs[h].host_slot, segs[h].first_event = slot[h], int(firsts[h])
+        d = torch.from_numpy(np.frombuffer(buf.tobytes() + b"\0" * 24, dtype=np.uint8).copy()).cuda()
+        eng.handle_resp_events_dev(segs, d.data_ptr(), len(buf))
+        eng.sync()
+        orc.resp_batch(buf.tobytes(), [slot[h] for h in range(nh)], [int(f) for f in firsts])
+
+    run([0, 700, 0, 0, 300])      # empty first / middle segments
+    run([50, 0, 9, 1, 0])         # empty last segment, tiny segments
+    run([0, 0, 0, 0, 0])          # no events at all
+    run([3000, 1, 2000, 0, 64])
+    _compare_all(eng, orc, oracle)
+    c, oc = eng.counters(), orc.counters()
+    assert c["resp_events"] == oc["events"] and c["resp_dropped_nolistener"] == oc["dropped_nolistener"]
+    # argument errors leave the state untouched
+    d = torch.zeros(24 * 16, dtype=torch.uint8, device="cuda")
+    segs = (capi.RespSeg * 2)()
+    for bad in ([(slot[0], 1), (slot[1], 8)],          # first segment does not start at event 0
+                [(slot[0], 0), (77, 8)]):              # unknown host slot
+        for i, (hs, fe) in enumerate(bad):
+            segs[i].host_slot, segs[i].first_event = hs, fe
+        with pytest.raises(capi.GysError) as ei:
+            eng.handle_resp_events_dev(segs, d.data_ptr(), 16)
+        assert ei.value.code == capi.ERR_INVAL
+    segs2 = (capi.RespSeg * 3)()
+    for i, (hs, fe) in enumerate([(slot[0], 0), (slot[1], 9), (slot[2], 4)]):  # descending offsets
+        segs2[i].host_slot, segs2[i].first_event = hs, fe
+    with pytest.raises(capi.GysError):
+        eng.handle_resp_events_dev(segs2, d.data_ptr(), 16)
+    big = torch.zeros(24 * ((1 << 14) + 1), dtype=torch.uint8, device="cuda")
+    one = (capi.RespSeg * 1)()
+    one[0].host_slot = slot[0]
+    with pytest.raises(capi.GysError) as ei:
+        eng.handle_resp_events_dev(one, big.data_ptr(), (1 << 14) + 1)
+    assert ei.value.code == capi.ERR_NOMEM
+    eng.sync()
+    _compare_all(eng, orc, oracle)
+    eng.close()
