@@ -134,6 +134,31 @@ def quantile_error(eng, torch, ingested, nlocal, svcs, host_ids, host_slots, wir
             "reference": "exact sort of every value the run ingested for the key (the reference's own answer is a RESP_TIME_HASH bucket ceiling)"}
 
 
+def host_fed_rate(eng, torch, nev, nlocal, svcs):
+    """When the boundary hands over HOST buffers the events cross PCIe first.  Measured after the run (never part of `value`): a batch
+    of nev events in pinned host memory, 3 x (asynchronous H2D copy on the engine's stream + ingest + window close), wall clock."""
+    dev = torch.empty(nev * EVENT_BYTES, dtype=torch.uint8, device="cuda")
+    sg = eng.gen_resp_events(dev.data_ptr(), nev, 0xF00D, 0, nlocal, svcs)
+    eng.sync()
+    pinned = torch.empty(nev * EVENT_BYTES, dtype=torch.uint8, pin_memory=True)
+    pinned.copy_(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev.copy_(pinned, non_blocking=True)
+    torch.cuda.synchronize()
+    t_copy = time.perf_counter() - t0
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dev.copy_(pinned, non_blocking=True)
+        eng.handle_resp_events_dev(sg, dev.data_ptr(), nev)
+        eng.window_close(tusec=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": reps * nev / dt, "unit": "events/s", "events_per_batch": nev, "h2d_GBps": nev * EVENT_BYTES / t_copy / 1e9,
+            "note": "pinned host buffer -> HBM copy on the engine stream, then ingest + window close, serial; PCIe Gen5 x16 bound"}
+
+
 def pmc_traffic(kernel, events, nsvc):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by
     tools/pmc_collect.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
@@ -162,6 +187,7 @@ def main():
     ap.add_argument("--zipf-milli", type=int, default=0, help="0 = uniform over services, else Zipf s*1000 (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quantile-check", action="store_true", help="skip the (untimed) t-digest rank-error check after the run")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the (untimed) host-fed measurement: pinned H2D copy + ingest")
     ap.add_argument("--no-dephase", action="store_true", help="skip the untimed pass that spreads the keys' buffer fill levels")
     ap.add_argument("--prime-windows", type=int, default=-1, help="untimed ordinary windows after the de-phase pass (-1: one buffer cycle)")
     ap.add_argument("--nbuf", type=int, default=6, help="distinct device-resident event batches the windows cycle through")
@@ -274,6 +300,9 @@ def main():
         for b in range(nbuf):
             ingested.append([args.events, 0x67796565746121 + 1000 * rank + b, args.zipf_milli, buf_uses[b]])
         qerr = quantile_error(eng, torch, ingested, nlocal, args.svcs, [mine[0], mine[-1]], [0, nlocal - 1], wire)
+    host_fed = None
+    if rank == 0 and not args.no_host_fed and nsvc:
+        host_fed = host_fed_rate(eng, torch, min(args.events, 1 << 26), nlocal, args.svcs)
     if rank == 0:
         total_events = args.events * world * args.steps
         value = total_events / dt
@@ -306,6 +335,8 @@ def main():
         }
         if qerr is not None:
             out["quantile_error"] = qerr
+        if host_fed is not None:
+            out["host_fed"] = host_fed
         if not args.no_cpu_baseline:
             full, honly, desc, ref_rate = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234)
             out["cpu_baseline"] = {"value": full, "unit": "events/s", "cores": 1, "kind": "port", "sample": desc,
