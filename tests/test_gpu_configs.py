@@ -1,5 +1,6 @@
 """BASELINE.json's configurations as GPU parity cases at their FULL sizes.
 
+configs[0] (C1): 1 host x 100 services, long replay (the reference's own CPU-runnable case, here GPU vs the C oracle)
 configs[1] (C2): 1 000 hosts x 100 services, TCP_CONN_NOTIFY flow stream + LISTENER_STATE_NOTIFY roll-up
 configs[2] (C3): 10 000 hosts x 1 000 services = 10^7 service keys, response-event stream
 configs[4] (C5): 10^5 services, Zipf(1.1) -- heavy hitters
@@ -130,6 +131,42 @@ def test_c3_full_size_properties(torch_mod):
     assert q1[0] <= q1[1] <= q1[2]
     # window view after the last close is empty for every key; all-time view is unchanged by the close
     assert eng.export_hist(0, 5_000_000, 1000)[:, :15].sum() == 0
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- C1
+@pytest.mark.parametrize("resp_path", [0, 2], ids=["auto-general", "hostlocal-tiled"])
+def test_c1_single_host_replay_bit_exact(torch_mod, oracle, resp_path):
+    """ONE host, 100 services, a long replay (2^24 response events in one call, then 2^22 more): every key gets
+    ~10^5 values per call (k_digest_huge with buffered values joining the merge), the single segment is far longer than any LDS image
+    (general pipeline by the time model / tiled host-local pipeline when forced).  Everything bit-exact vs the C oracle."""
+    torch = torch_mod
+    sp = 100
+    eng = _engine(max_hosts=1, max_services=sp, max_batch_events=1 << 24, resp_path=resp_path)
+    orc = oracle.OracleEngine(sp)
+    helpers.register_world(eng, orc, range(1), sp)
+    for n, seed in ((1 << 24, 0xC1), (1 << 22, 0xC2), (5000, 0xC3)):
+        ev = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
+        segs = eng.gen_resp_events(ev.data_ptr(), n, seed, 0, 1, sp)
+        eng.handle_resp_events_dev(segs, ev.data_ptr(), n)
+        orc.resp_batch(ev.cpu().numpy().tobytes(), [0], [0])
+    eng.sync()
+    c = eng.counters()
+    assert (c["resp_batches_general"] > 0) == (resp_path == 0) and (c["resp_batches_host_local"] > 0)  # the 5000-event call is always host-local
+    helpers.assert_hist_equal(eng.export_hist(0, 0, sp), orc.hist(), sp)
+    assert (eng.export_conn_bitmap(0, sp) == orc.bitmap()).all()
+    gs, gc, gm = eng.export_tdigest(0, sp)
+    os_, oc, om = orc.td_arrays()
+    assert (gc == oc).all() and (gs == os_).all() and (gm == om).all()
+    gn, gp = eng.export_tdigest_pending(0, sp)
+    on, op = orc.td_pending()
+    assert (gn == on).all() and (gp == op).all()
+    for s_idx in (0, 57, 99):
+        g = int(wire.glob_id(0, s_idx))
+        qs = [0.001, 0.5, 0.95, 0.999]
+        assert eng.quantiles(g, qs) == [oracle.lib().gyo_tdb_quantile(C.byref(orc.td(s_idx)), q) for q in qs]
+    eng.window_close()
+    assert (eng.export_hll() == orc.hll()).all() and (eng.export_cms(0) == orc.cms()).all()
     eng.close()
 
 
