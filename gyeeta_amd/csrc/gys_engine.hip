@@ -173,6 +173,8 @@ struct gys_ctx {
 	int huge_blocks = 0;
 	uint32_t *hll32 = nullptr;
 	unsigned long long *svc_ctr = nullptr;
+	unsigned long long *svc_win = nullptr; // per-service window accumulators of the connection path (k_conn_ingest / k_conn_fold)
+	bool conn_dirty = false;
 	uint8_t *svc_state = nullptr;
 	uint8_t *svc_hll = nullptr;
 	int32_t *host_summ_win = nullptr, *host_summ_last = nullptr;
@@ -682,11 +684,23 @@ int run_conn(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, uint
 	p.hll32 = c->hll32;
 	p.cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
 	p.cms64 = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_cms;
-	p.svc_ctr = c->svc_ctr;
+	p.svc_win = c->svc_win;
+	c->conn_dirty = true;
 	p.counters = c->counters;
 	ProfScope ps(c, "conn");
 	hipLaunchKernelGGL(k_conn_ingest, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+// folds the connection path's per-service window accumulators (cumulative counters, Count-Min rows)
+int conn_fold(gys_ctx *c)
+{
+	if (!c->conn_dirty || !c->nsvc) return GYS_OK;
+	hipLaunchKernelGGL(k_conn_fold, dim3((c->nsvc + 255) / 256), dim3(256), 0, c->stream, c->svc_win, c->svc_ctr, c->svc_gid, c->nsvc,
+			   (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms, (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_cms);
+	HIPCHK(hipGetLastError());
+	c->conn_dirty = false;
 	return GYS_OK;
 }
 
@@ -778,6 +792,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	ALLOC(c->hist_all, S);
 	ALLOC(c->bitmap, S * 16);
 	ALLOC(c->svc_ctr, S * 4);
+	ALLOC(c->svc_win, S * 3);
 	ALLOC(c->svc_state, S * 96);
 	ALLOC(c->hll32, (uint64_t)1 << GYS_HLL_P);
 	ALLOC(c->host_summ_win, H * 16);
@@ -872,7 +887,7 @@ void gys_destroy(gys_ctx *c)
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
 			c->td_cnt, c->td_meta, c->td_pend, c->merge_list, c->merge_count, c->query_sum, c->query_cnt, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->staged2, c->huge_list, c->huge_count,
-			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
+			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->own_arena ? c->arena : nullptr};
@@ -1312,6 +1327,10 @@ int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 	const uint32_t nthreads = std::max<uint32_t>(p.nhosts, (1u << GYS_HLL_P) / 4u);
 	{
 		ProfScope ps(c, "window_prepare");
+		{
+			const int rcf = conn_fold(c);
+			if (rcf) return rcf;
+		}
 		hipLaunchKernelGGL(k_window_prepare, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, p);
 		if (c->nsvc && !c->cfg.enable_tdigest) {
 			// eager mode (no per-key pass): all-time += window (GY_HISTOGRAM::add_histogram), window cleared, and the all-service
@@ -1749,6 +1768,12 @@ int gys_export_tdigest_pending(gys_ctx *c, uint32_t first_slot, uint32_t nslots,
 int gys_export_svc_counters(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint64_t *out)
 {
 	RANGE_CHECK(first_slot, nslots);
+	{
+		// mid-window: the cumulative counters must include the window so far (its Count-Min share moves into the arena a little early,
+		// which nothing can observe before the window closes)
+		const int rcf = conn_fold(c);
+		if (rcf) return rcf;
+	}
 	HIPCHK(hipMemcpyAsync(out, c->svc_ctr + (size_t)first_slot * 4, (size_t)nslots * 32, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;

@@ -1367,7 +1367,19 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 	}
 }
 
+// one device atomic per WAVE instead of one per record on the shared statistics counters (a single hot address serialises in L2)
+__device__ __forceinline__ void wave_count(uint64_t *ctr, bool pred)
+{
+	const unsigned long long b = __ballot(pred);
+	if (b && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)b) - 1)) atomicAdd((unsigned long long *)ctr, (unsigned long long)__popcll(b));
+}
+
 // ---------------------------------------------------------------------------------------------------- TCP_CONN_NOTIFY ingest
+// The kernel is bound by the chip's device-atomic rate (~30 G/s), so a record of a KNOWN service costs three atomics only: the
+// service's window accumulators {connections | closed << 32, bytes sent, bytes received}.  Both Count-Min tables are linear in the
+// per-service sums, so their 8 updates per record are replaced by 8 per ACTIVE SERVICE at the window boundary (k_conn_fold), where
+// the accumulators also fold into the cumulative per-service counters.  Records of services the engine was never told about (rare)
+// still update the Count-Min tables directly.
 // comm::TCP_CONN_NOTIFY (common/gy_comm_proto.h:1665-1742), 280 fixed bytes:
 //   IP_PORT cli_@0 ser_@32 nat_cli_@64 nat_ser_@96 (each: ip128 @0, ip32 @16, aftype @20, flags @22, port @24)
 //   tusec_start_@128 tusec_close_@136 ... ser_glob_id_@192 ... bytes_sent_@208 bytes_rcvd_@216 ... cli_cmdline_len_@272 flags@274.. padding_len_@279
@@ -1379,13 +1391,14 @@ struct ConnP {
 	uint32_t *hll32;
 	uint32_t *cms32;
 	unsigned long long *cms64;
-	unsigned long long *svc_ctr; // [nsvc*4] nconn, nclose, bytes_sent, bytes_rcvd
+	unsigned long long *svc_win; // [nsvc*3] window accumulators: nconn | nclose << 32, bytes_sent, bytes_rcvd
 	uint64_t *counters;
 };
 
 __global__ __launch_bounds__(256) void k_conn_ingest(ConnP p)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	wave_count(&p.counters[CTR_CONN_EVENTS], i < p.n);
 	if (i >= p.n) return;
 	const uint8_t *rec = p.batch + p.offsets[i];
 	uint32_t c128[4], s128[4], c32, s32;
@@ -1415,23 +1428,49 @@ __global__ __launch_bounds__(256) void k_conn_ingest(ConnP p)
 	hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
 	if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
 
-#pragma unroll
-	for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
-		const uint32_t col = jhash2_u64(ser_glob_id, GYS_SEED + r) & (GYS_CMS_W - 1);
-		atomicAdd(&p.cms32[r * GYS_CMS_W + col], 1u);
-		atomicAdd(&p.cms64[r * GYS_CMS_W + col], (unsigned long long)(bytes_sent + bytes_rcvd));
-	}
-	atomicAdd((unsigned long long *)&p.counters[CTR_CONN_EVENTS], 1ull);
 	const uint32_t slot = tbl_lookup(p.gid, ser_glob_id);
 	if (slot == GYS_NOSLOT) {
 		atomicAdd((unsigned long long *)&p.counters[CTR_CONN_UNKNOWN], 1ull);
+#pragma unroll
+		for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
+			const uint32_t col = jhash2_u64(ser_glob_id, GYS_SEED + r) & (GYS_CMS_W - 1);
+			atomicAdd(&p.cms32[r * GYS_CMS_W + col], 1u);
+			atomicAdd(&p.cms64[r * GYS_CMS_W + col], (unsigned long long)(bytes_sent + bytes_rcvd));
+		}
 		return;
 	}
-	unsigned long long *c = p.svc_ctr + (size_t)slot * 4;
-	atomicAdd(&c[0], 1ull);
-	if (tusec_close) atomicAdd(&c[1], 1ull);
-	if (bytes_sent) atomicAdd(&c[2], (unsigned long long)bytes_sent);
-	if (bytes_rcvd) atomicAdd(&c[3], (unsigned long long)bytes_rcvd);
+	unsigned long long *c = p.svc_win + (size_t)slot * 3;
+	atomicAdd(&c[0], 1ull + (tusec_close ? (1ull << 32) : 0ull)); // a window's connection count of one service stays far below 2^32
+	if (bytes_sent) atomicAdd(&c[1], (unsigned long long)bytes_sent);
+	if (bytes_rcvd) atomicAdd(&c[2], (unsigned long long)bytes_rcvd);
+}
+
+// window boundary (and counter exports): cumulative per-service counters += window accumulators; Count-Min rows of the service +=
+// (connections, bytes) of the window; accumulators cleared
+__global__ __launch_bounds__(256) void k_conn_fold(unsigned long long *svc_win, unsigned long long *svc_ctr, const uint64_t *svc_gid, uint32_t nsvc, uint32_t *cms32,
+						   unsigned long long *cms64)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nsvc) return;
+	unsigned long long *w = svc_win + (size_t)s * 3;
+	const unsigned long long cnt = w[0], sent = w[1], rcvd = w[2];
+	if (!(cnt | sent | rcvd)) return;
+	const unsigned long long nconn = cnt & 0xFFFFFFFFull, nclose = cnt >> 32;
+	unsigned long long *c = svc_ctr + (size_t)s * 4;
+	c[0] += nconn;
+	c[1] += nclose;
+	c[2] += sent;
+	c[3] += rcvd;
+	const uint64_t gid = svc_gid[s];
+#pragma unroll
+	for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
+		const uint32_t col = jhash2_u64(gid, GYS_SEED + r) & (GYS_CMS_W - 1);
+		atomicAdd(&cms32[r * GYS_CMS_W + col], (uint32_t)nconn);
+		if (sent + rcvd) atomicAdd(&cms64[r * GYS_CMS_W + col], sent + rcvd);
+	}
+	w[0] = 0;
+	w[1] = 0;
+	w[2] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------- LISTENER_STATE_NOTIFY ingest
