@@ -223,7 +223,8 @@ int gys_query_clusterstate(gys_ctx *ctx, const char *cluster_name, gys_cluster_s
 /* GY_HISTOGRAM::get_percentiles (common/gy_statistics.h:707-791) of one service; which: 0 = current window, 1 = all-time */
 int gys_query_hist_percentiles(gys_ctx *ctx, uint64_t glob_id, int which, gys_hist_data *pdata, uint32_t npct, uint64_t *total_count,
 			       int64_t *max_val, float *pavg);
-/* t-digest quantiles (q in [0,1]) of one service's response times */
+/* t-digest quantiles (q in [0,1]) of one service's response times: computed from the merged view (clusters re-clustered with the
+ * values the key still buffers; the stored state is not modified), rounded half-up to whole milliseconds */
 int gys_query_quantiles(gys_ctx *ctx, uint64_t glob_id, const double *q, uint32_t nq, double *out);
 /* distinct flows seen (global HLL over PAIR_IP_PORT keys; after gys_window_finish: the all-rank estimate) */
 int gys_query_distinct_flows(gys_ctx *ctx, double *out);
@@ -298,7 +299,7 @@ int gys_hist_percentiles_dev(gys_ctx *ctx, int kind, const gys_hist_rec *d_hist,
  * measurement helpers: per-kernel HIP-event timing on the context stream */
 int gys_profile_enable(gys_ctx *ctx, int on);
 int gys_profile_reset(gys_ctx *ctx);
-/* name: "resp_pass1", "scan", "scatter", "digest_small", "digest_huge", "conn", "lstate", ...; returns accumulated ms + launches */
+/* name: "resp_host", "key_pass", "digest_merge", "digest_huge" (general pipeline: "resp_pass1", "scan", "scatter"), "conn", "lstate", "wire_decode", ...; returns accumulated ms + launches */
 int gys_profile_get(gys_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 int gys_profile_names(gys_ctx *ctx, char *buf, size_t buflen); /* comma separated */
 
