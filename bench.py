@@ -7,8 +7,8 @@ Hosts are sharded over ranks by GY_MACHINE_ID::get_hash() % N (SURVEY 8e); every
 drawn over ITS hosts (weak scaling in events) and one step = one 5-second window: ingest one device-resident batch, then the
 window close (RCCL all-reduce of the HLL / CMS / histogram / cluster registers over xGMI + local roll).
 
-Events per window: 2^28 per GPU by default = a 5-s window at 54 M events/s/GPU (the north-star rate of 1 G events/s on 8 GPUs
-would put 2^29.2 events into each GPU's window); 4 steps ingest the 2^30 events SURVEY 8d quotes per C3 run.  A key re-clusters
+Events per window: 2^29 per GPU by default: the north-star rate of 1 G events/s on 8 GPUs is 125 M events/s/GPU, i.e. 2^29.2 events
+in each GPU's 5-s window; 2 steps ingest the 2^30 events SURVEY 8d quotes per C3 run (`--events 268435456` = a window at 54 M/s/GPU).  A key re-clusters
 its t-digest once per ~256 values (every ~9.5 windows at ~27 events per key and window); an untimed set-up pass spreads the keys'
 buffer fill levels evenly and then runs one full buffer cycle of ordinary windows, so that EVERY timed window, whatever
 --steps/--warmup, carries its long-run share of (steady-state, non-empty-digest) merges.
@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--hosts", type=int, default=10000, help="total hosts across all ranks")
     ap.add_argument("--svcs", type=int, default=1000, help="services per host")
-    ap.add_argument("--events", type=int, default=1 << 28, help="events per rank per step (one window)")
+    ap.add_argument("--events", type=int, default=1 << 29, help="events per rank per step (one window)")
     ap.add_argument("--zipf-milli", type=int, default=0, help="0 = uniform over services, else Zipf s*1000 (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quantile-check", action="store_true", help="skip the (untimed) t-digest rank-error check after the run")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-rank load of the N-GPU runs emulated on one GPU: hosts/N hosts, 2^28 events per window
+# per-rank load of the N-GPU runs emulated on one GPU: hosts/N hosts, the default 2^29 events per window
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for h in "$@"; do
   timeout 250 python bench.py --no-cpu-baseline --no-quantile-check --hosts $h --steps 6 --warmup 2 2>/dev/null | python -c "
