@@ -984,8 +984,16 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			s_ocnt[j1] = 0;
 		}
 		__syncthreads();
+		// the first three levels of both 7-level searches are decided against pivots held in registers (every 16th entry: 8 independent
+		// compares instead of 3 dependent LDS round trips); the last four levels walk the 16-entry block in LDS
+		uint32_t pthr[8];
+		uint64_t pT[7];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) pthr[k] = s_thr[16 * k + 15];
+#pragma unroll
+		for (int k = 0; k < 7; ++k) pT[k] = s_T[16 * (k + 1)];
 		// ---- values (buffered, then new): gap = #{clusters with mean <= v} = #{thresholds <= v}, two values per lane and iteration so that
-		// the two 7-step dependent LDS searches overlap
+		// the two dependent LDS searches overlap
 		{
 			const uint32_t *pend = p.td_pend + (size_t)slot * GYS_TD_PEND_CAP;
 			for (uint32_t base = 0; base < m; base += 128u) {
@@ -995,13 +1003,16 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 					const uint32_t i = base + lane + 64u * u;
 					uv[u] = 0;
 					if (i < m) uv[u] = i < npend ? pend[i] : (p.staged[start + (i - npend)] >> GYS_ROW_BITS);
-					lo[u] = 0;
+					uint32_t blocks = 0; // 16-entry blocks that lie entirely at or below the value (the thresholds ascend)
+#pragma unroll
+					for (int k = 0; k < 8; ++k) blocks += pthr[k] <= uv[u] ? 1u : 0u;
+					lo[u] = 16u * blocks;
 				}
 #pragma unroll
-				for (uint32_t step = 64u; step >= 1u; step >>= 1) {
+				for (uint32_t step = 8u; step >= 1u; step >>= 1) {
 #pragma unroll
 					for (int u = 0; u < 2; ++u)
-						if (s_thr[lo[u] + step - 1u] <= uv[u]) lo[u] += step;
+						if (lo[u] < 128u && s_thr[lo[u] + step - 1u] <= uv[u]) lo[u] += step;
 				}
 #pragma unroll
 				for (int u = 0; u < 2; ++u) {
@@ -1060,9 +1071,16 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 			uint64_t mid2[2] = {0, 0};
 			if (c0) mid2[0] = 2ull * (e0 + (uint64_t)s_clt[pos0 + 1]) + (uint64_t)c0;
 			if (c1) mid2[1] = 2ull * (e1 + (uint64_t)s_clt[pos1 + 1]) + (uint64_t)c1;
-			uint32_t a[2] = {0, 0};
+			uint32_t a[2];
 #pragma unroll
-			for (uint32_t step = 64u; step >= 1u; step >>= 1) {
+			for (int u = 0; u < 2; ++u) {
+				uint32_t blocks = 0;
+#pragma unroll
+				for (int k = 0; k < 7; ++k) blocks += mid2[u] >= pT[k] ? 1u : 0u;
+				a[u] = 16u * blocks;
+			}
+#pragma unroll
+			for (uint32_t step = 8u; step >= 1u; step >>= 1) {
 #pragma unroll
 				for (int u = 0; u < 2; ++u)
 					if (mid2[u] >= s_T[a[u] + step]) a[u] += step;
@@ -1098,9 +1116,16 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 				}
 				mid2[u] = 2ull * ((uint64_t)r + s_cpfx[iv - value_grid(x[u] & 0xFFFFFu)]) + 1ull; // old weight with mean <= v
 			}
-			uint32_t a[2] = {0, 0};
+			uint32_t a[2];
 #pragma unroll
-			for (uint32_t step = 64u; step >= 1u; step >>= 1) {
+			for (int u = 0; u < 2; ++u) {
+				uint32_t blocks = 0;
+#pragma unroll
+				for (int k = 0; k < 7; ++k) blocks += mid2[u] >= pT[k] ? 1u : 0u;
+				a[u] = 16u * blocks;
+			}
+#pragma unroll
+			for (uint32_t step = 8u; step >= 1u; step >>= 1) {
 #pragma unroll
 				for (int u = 0; u < 2; ++u)
 					if (mid2[u] >= s_T[a[u] + step]) a[u] += step;
