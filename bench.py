@@ -144,13 +144,15 @@ def host_fed_rate(eng, torch, nev, nlocal, svcs):
     pinned.copy_(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    dev.copy_(pinned, non_blocking=True)
+    with torch.cuda.stream(eng.stream):
+        dev.copy_(pinned, non_blocking=True)
     torch.cuda.synchronize()
     t_copy = time.perf_counter() - t0
     reps = 3
     t0 = time.perf_counter()
     for _ in range(reps):
-        dev.copy_(pinned, non_blocking=True)
+        with torch.cuda.stream(eng.stream):  # copy and ingest in one stream's order
+            dev.copy_(pinned, non_blocking=True)
         eng.handle_resp_events_dev(sg, dev.data_ptr(), nev)
         eng.window_close(tusec=0)
     torch.cuda.synchronize()

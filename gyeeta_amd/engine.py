@@ -55,7 +55,10 @@ class SketchEngine:
         cfg.resp_path = resp_path
         cfg.max_batch_events = max_batch_events
         with torch.cuda.device(self.device):
-            cfg.stream = torch.cuda.current_stream().cuda_stream
+            # the engine gets its own torch stream: torch work (tensor fills / copies on the current stream, collectives) and engine work are
+            # ordered explicitly -- order() before handing device buffers to the engine, sync() (or stream.synchronize) before reading results
+            self.stream = torch.cuda.Stream(device=self.device)
+            cfg.stream = self.stream.cuda_stream
             self.arena = None
             if torch_arena:
                 nbytes = self.L.gys_reduce_arena_bytes(C.byref(cfg))
@@ -68,6 +71,11 @@ class SketchEngine:
         self.cfg = cfg
         self.rank, self.nranks = rank, nranks
         self._sections = None
+
+    def order(self):
+        """engine work submitted after this call starts after everything queued so far on torch's current stream (e.g. the fill / copy
+        that produced a device buffer about to be handed to the engine)"""
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
 
     def close(self):
         if self.h:
@@ -123,6 +131,7 @@ class SketchEngine:
         capi.check(self.L.gys_ingest_resp_events(self.h, mid_buf(machine_id), b, len(b) // 24))
 
     def handle_resp_events_dev(self, segs, d_ev, nevents):
+        self.order()
         capi.check(self.L.gys_ingest_resp_events_dev(self.h, segs, len(segs), C.c_void_p(d_ev), nevents))
 
     def partha_tcp_conn_info(self, machine_id, batch_bytes, nconns):
@@ -175,7 +184,8 @@ class SketchEngine:
         if self.nranks > 1:
             if self.arena is None:
                 raise RuntimeError("multi-rank reduce needs torch_arena=True")
-            allreduce_sections(self.reduce_sections(), group)
+            with self.torch.cuda.stream(self.stream):  # the collectives read / write the arena in the engine stream's order
+                allreduce_sections(self.reduce_sections(), group)
         capi.check(self.L.gys_window_finish(self.h))
 
     window_close = send_cluster_state
@@ -336,5 +346,6 @@ class SketchEngine:
 
     def gen_resp_events(self, d_ev, nevents, seed, first_host, nhosts, svcs_per_host, zipf_milli=0):
         segs = (capi.RespSeg * nhosts)()
+        self.order()
         capi.check(self.L.gys_gen_resp_events_dev(self.h, C.c_void_p(d_ev), nevents, seed, first_host, nhosts, svcs_per_host, zipf_milli, segs))
         return segs

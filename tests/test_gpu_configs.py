@@ -149,6 +149,7 @@ def test_c1_single_host_replay_bit_exact(torch_mod, oracle, resp_path):
         ev = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
         segs = eng.gen_resp_events(ev.data_ptr(), n, seed, 0, 1, sp)
         eng.handle_resp_events_dev(segs, ev.data_ptr(), n)
+        eng.sync()
         orc.resp_batch(ev.cpu().numpy().tobytes(), [0], [0])
     eng.sync()
     c = eng.counters()
@@ -184,6 +185,7 @@ def test_c5_zipf_heavy_hitters_bit_exact(torch_mod, oracle):
     for rnd in range(3):
         segs = eng.gen_resp_events(ev.data_ptr(), n, 0xC5 + rnd, 0, nh, sp, 1100)
         eng.handle_resp_events_dev(segs, ev.data_ptr(), n)
+        eng.sync()
         orc.resp_batch(ev.cpu().numpy().tobytes(), [s.host_slot for s in segs], [s.first_event for s in segs])
     eng.sync()
     c = eng.counters()
@@ -233,6 +235,7 @@ def test_c2_conn_and_listener_state_full_size(torch_mod, oracle):
     d_batch = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda()
     d_off = torch.arange(0, n * 280, 280, dtype=torch.int32, device="cuda")
     from gyeeta_amd import capi
+    eng.order()
     capi.check(eng.L.gys_ingest_tcp_conn_dev(eng.h, C.c_void_p(d_batch.data_ptr()), C.c_void_p(d_off.data_ptr()), n))
     hll = np.zeros(1 << 14, dtype=np.uint8)
     cms32 = np.zeros(4 * 65536, dtype=np.uint32)

@@ -189,6 +189,7 @@ def test_standalone_hist_all_kinds(torch_mod, oracle, kind):
     h1 = torch.zeros(nk * 256, dtype=torch.uint8, device="cuda")
     h2 = torch.zeros(nk * 256, dtype=torch.uint8, device="cuda")
     half = n // 2
+    eng.order()  # the torch fills / copies above precede the engine's kernels
     for hh, lo, hi in ((h1, 0, half), (h2, half, n)):
         capi.check(L.gys_hist_init_dev(eng.h, kind, hh.data_ptr(), nk))
         capi.check(L.gys_hist_add_dev(eng.h, kind, hh.data_ptr(), nk, dk[lo:hi].data_ptr(), dv[lo:hi].data_ptr(), hi - lo))

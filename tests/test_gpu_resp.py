@@ -124,6 +124,7 @@ def test_resp_device_generated_stream(torch_mod, oracle, resp_path):
     for rnd in range(3):
         segs = eng.gen_resp_events(ev.data_ptr(), n, 1234 + rnd, 0, nh, sp)
         eng.handle_resp_events_dev(segs, ev.data_ptr(), n)
+        eng.sync()
         host = ev.cpu().numpy().tobytes()
         orc.resp_batch(host, [s.host_slot for s in segs], [s.first_event for s in segs])
         a = np.frombuffer(host, dtype=helpers.wire.RESP_EVENT)
@@ -334,6 +335,7 @@ def test_resp_windows_roll_lazily(torch_mod, oracle, resp_path):
         for which, o in ((0, orc_win), (1, orc_all)):
             d_out = torch.zeros(nsvc * len(pcts), dtype=torch.int64, device="cuda")
             from gyeeta_amd import capi
+            eng.order()
             capi.check(eng.L.gys_scan_percentiles_dev(eng.h, which, pcts.ctypes.data_as(capi.f32p), len(pcts), C.c_void_p(d_out.data_ptr())))
             eng.sync()
             got = d_out.cpu().numpy().reshape(nsvc, len(pcts))
