@@ -710,7 +710,6 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 {
 	__shared__ unsigned long long s_h_[16][32];
 	__shared__ uint32_t s_bm_[16][16];
-	__shared__ int32_t s_mm_[16][2];
 	__shared__ unsigned long long s_gh[32]; // all-service histogram of this workgroup's keys (flushed once at the end)
 	__shared__ long long s_gmax;
 	if (threadIdx.x < 32u) s_gh[threadIdx.x] = 0;
@@ -720,7 +719,6 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 	const uint32_t row = lane >> 4, g = lane & 15u;
 	unsigned long long *s_h = s_h_[wv * 4u + row];
 	uint32_t *s_bm = s_bm_[wv * 4u + row];
-	int32_t *s_mm = s_mm_[wv * 4u + row];
 	const uint32_t nwaves = gridDim.x * 4u;
 
 	for (uint32_t chunk = p.chunk_lo + blockIdx.x * 4u + wv; chunk < p.chunk_hi; chunk += nwaves) {
@@ -756,14 +754,11 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 			s_h[g] = 0;
 			s_h[16u + g] = 0;
 			s_bm[g] = 0;
-			if (g == 0) {
-				s_mm[0] = INT32_MAX;
-				s_mm[1] = INT32_MIN;
-			}
 			GYS_WAVE_SYNC();
 			uint32_t *pend = p.td_pend + (size_t)slot * GYS_TD_PEND_CAP + npend;
 			const uint32_t mmax = max(max((uint32_t)__shfl((int)m, 0, 64), (uint32_t)__shfl((int)m, 16, 64)),
 						  max((uint32_t)__shfl((int)m, 32, 64), (uint32_t)__shfl((int)m, 48, 64)));
+			int32_t lmin = INT32_MAX, lmax = INT32_MIN;
 			for (uint32_t base = 0; base < mmax; base += 16u) {
 				const uint32_t idx = base + g;
 				if (idx < m) {
@@ -774,14 +769,21 @@ __global__ __launch_bounds__(256) void k_key_pass(DigestP p)
 					atomicAdd(&s_h[2 * b], 1ull);
 					atomicAdd(&s_h[2 * b + 1], (unsigned long long)(int64_t)v);
 					bitmap_set_lds(s_bm, w, b);
-					atomicMin(&s_mm[0], v);
-					atomicMax(&s_mm[1], v);
+					lmin = min(lmin, v);
+					lmax = max(lmax, v);
 					if (!do_merge) pend[idx] = (uint32_t)v;
 				}
 			}
+			// smallest / largest value of the key: per-lane running values, then an xor butterfly inside the 16-lane row (16 lanes hammering
+			// one LDS word with atomicMin / atomicMax serialise; the LDS pipe of this kernel was ~70 % conflict cycles)
+#pragma unroll
+			for (int d = 8; d >= 1; d >>= 1) {
+				lmin = min(lmin, __shfl_xor(lmin, d, 64));
+				lmax = max(lmax, __shfl_xor(lmax, d, 64));
+			}
 			GYS_WAVE_SYNC();
 			if (m) {
-				const int32_t vmin = s_mm[0], vmax = s_mm[1];
+				const int32_t vmin = lmin, vmax = lmax;
 				const bool stale = cur.meta.w != p.epoch; // first touch of the key in this window: roll it (see "Lazy window roll")
 				// ---- histogram records (prefetched pairs + LDS delta), bitmap word, meta, Count-Min
 				uint4 *hp = (uint4 *)&p.hist_win[slot] + g;
