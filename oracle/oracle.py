@@ -218,6 +218,8 @@ def ref():
         _sig(R, "ref_keyed_register", C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint16])
         _sig(R, "ref_keyed_resp_batch", C.c_uint64, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
         _sig(R, "ref_keyed_total", C.c_uint64, [C.c_void_p, C.c_uint32])
+        if hasattr(R, "ref_keyed_resp_batch_mt"):
+            _sig(R, "ref_keyed_resp_batch_mt", C.c_uint64, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32, C.c_uint32])
     _ref = R
     return R
 

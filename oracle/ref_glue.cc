@@ -19,6 +19,7 @@
 //   common/gy_statistics.h:455-894       HIST_SERIAL, GY_HISTOGRAM (add_data, add_histogram, get_percentiles ...)
 //   common/gy_statistics.h:1565-2063     bucket-hash classes
 //   common/gy_statistics.h:28-453        BOUNDED_PRIO_QUEUE
+#include <thread>
 #include <unordered_map>
 #include "gy_common_inc.h"
 #include "gy_statistics.h"
@@ -274,6 +275,30 @@ uint64_t ref_keyed_resp_batch(void *p, const uint8_t *ev24, uint64_t n, const ui
 		added++;
 	}
 	return added;
+}
+// the same loop on nthreads host threads: the segments (hosts) are cut into contiguous ranges, one per thread -- a host's listeners are
+// only ever touched by the thread that owns the host (the reference pins a connection's batches to one L2 queue the same way,
+// server/gy_mconnhdlr.cc:16252); the listener map is read-only here
+uint64_t ref_keyed_resp_batch_mt(void *p, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs, uint32_t nthreads)
+{
+	if (nthreads <= 1 || nsegs <= 1) return ref_keyed_resp_batch(p, ev24, n, seg_host, seg_first, nsegs);
+	if (nthreads > nsegs) nthreads = nsegs;
+	std::vector<uint64_t> added(nthreads, 0);
+	std::vector<std::thread> th;
+	for (uint32_t t = 0; t < nthreads; ++t) {
+		th.emplace_back([&, t]() {
+			const uint32_t s0 = (uint32_t)((uint64_t)nsegs * t / nthreads), s1 = (uint32_t)((uint64_t)nsegs * (t + 1) / nthreads);
+			if (s0 >= s1) return;
+			const uint64_t e0 = seg_first[s0], e1 = s1 < nsegs ? seg_first[s1] : n;
+			std::vector<uint64_t> first(seg_first + s0, seg_first + s1);
+			for (auto &f : first) f -= e0;
+			added[t] = ref_keyed_resp_batch(p, ev24 + e0 * 24, e1 - e0, seg_host + s0, first.data(), s1 - s0);
+		});
+	}
+	for (auto &x : th) x.join();
+	uint64_t tot = 0;
+	for (uint64_t a : added) tot += a;
+	return tot;
 }
 uint64_t ref_keyed_total(void *p, uint32_t idx) { return static_cast<RefKeyed *>(p)->hist[idx].get_total_count(); }
 }  // extern "C"

@@ -56,3 +56,10 @@ def assert_hist_equal(gpu_hist, orc_hist, nsvc):
     o = np.asarray(orc_hist)[:nsvc]
     bad = np.argwhere(g != o)
     assert bad.size == 0, f"histogram mismatch at {bad[:5].tolist()}: gpu {g[tuple(bad[0])]} oracle {o[tuple(bad[0])]}"
+
+
+def concat_events(parts):
+    """byte-level concatenation of RESP_EVENT arrays.  (np.concatenate would normalise the big-endian port fields to native byte
+    order, i.e. silently rewrite the wire bytes.)"""
+    raw = b"".join(p.tobytes() for p in parts)
+    return np.frombuffer(raw, dtype=wire.RESP_EVENT)

@@ -243,7 +243,7 @@ def test_resp_hostlocal_incremental_registration_and_fallbacks(torch_mod, oracle
     assert c0["resp_batches_general"] == 0 and c0["resp_dropped_nolistener"] == orc.counters()["dropped_nolistener"] > 0
     # multi-segment device batch: distinct hosts -> host-local; a repeated host -> general
     parts = [helpers.make_resp_events(rng, h, 500 + 37 * h, sp) for h in (0, 1, 2, 3)]
-    buf = np.concatenate(parts)
+    buf = helpers.concat_events(parts)
     firsts = np.cumsum([0] + [len(x) for x in parts[:-1]])
     from gyeeta_amd import capi
     def run(hosts):
@@ -367,7 +367,7 @@ def test_resp_ragged_segments_and_bad_arguments(torch_mod, oracle, resp_path):
 
     def run(lengths):  # lengths per host 0..nh-1 (0 = empty segment)
         parts = [helpers.make_resp_events(rng, h, n, sp) for h, n in enumerate(lengths)]
-        buf = np.concatenate(parts) if sum(lengths) else np.zeros(0, dtype=helpers.wire.RESP_EVENT)
+        buf = helpers.concat_events(parts)
         firsts = np.cumsum([0] + list(lengths[:-1]))
         segs = (capi.RespSeg * nh)()
         for h in range(nh):

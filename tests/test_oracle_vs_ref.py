@@ -167,4 +167,17 @@ def test_keyed_resp_loop_of_the_reference_classes_matches_the_port(oracle):
         orc.resp_batch(b, [h], [0])
     assert added == orc.counters()["accepted"]
     assert [R.ref_keyed_total(k, i) for i in range(18)] == orc.hist()[:18, 15, 0].tolist()
+    # the multi-host batch form, single- and multi-threaded (hosts cut into ranges), must count the same again
+    parts = [helpers.make_resp_events(rng, h, 2500, 6) for h in range(3)]
+    raw = b"".join(p.tobytes() for p in parts)
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    sh, sf = np.arange(3, dtype=np.uint32), (np.arange(3) * 2500).astype(np.uint64)
+    a1 = R.ref_keyed_resp_batch(k, buf.ctypes.data, 7500, oracle.ptr(sh, oracle.u32p), oracle.ptr(sf, oracle.u64p), 3)
+    orc.resp_batch(raw, [0, 1, 2], [0, 2500, 5000])
+    assert added + a1 == orc.counters()["accepted"] and a1 > 7000
+    if hasattr(R, "ref_keyed_resp_batch_mt"):
+        a2 = R.ref_keyed_resp_batch_mt(k, buf.ctypes.data, 7500, oracle.ptr(sh, oracle.u32p), oracle.ptr(sf, oracle.u64p), 3, 3)
+        orc.resp_batch(raw, [0, 1, 2], [0, 2500, 5000])
+        assert a2 == a1
+        assert [R.ref_keyed_total(k, i) for i in range(18)] == orc.hist()[:18, 15, 0].tolist()
     R.ref_keyed_free(k)
