@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libgysketch.so")
 
 OK, ERR_INVAL, ERR_NOMEM, ERR_HIP, ERR_NOTFOUND, ERR_NOT_OWNER, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 MAX_BUCKETS, TD_NB, HLL_P, CMS_D, CMS_W, NSTATES, TOPN = 16, 100, 14, 4, 65536, 6, 10
+NLEVELS, LEVEL_RING = 4, 10
 TD_PEND_CAP = 256
 KINDS = {"RESP_TIME_HASH": 0, "SEMI_LOG_HASH": 1, "SEMI_LOG_HASH_LO": 2, "DURATION_HASH": 3, "HASH_10_5000": 4, "HASH_5_250": 5,
          "HASH_1_3000": 6, "PERCENT_HASH": 7}
@@ -18,7 +19,7 @@ class Config(C.Structure):
                 ("max_hosts", C.c_uint32), ("max_services", C.c_uint32), ("max_clusters", C.c_uint32),
                 ("enable_tdigest", C.c_uint32), ("svc_hll_p", C.c_uint32), ("resp_path", C.c_uint32),
                 ("max_batch_events", C.c_uint64), ("stream", C.c_void_p), ("reduce_arena", C.c_void_p),
-                ("reduce_arena_bytes", C.c_uint64)]
+                ("reduce_arena_bytes", C.c_uint64), ("enable_levels", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class ListenerInfo(C.Structure):
@@ -72,6 +73,16 @@ class HistRec(C.Structure):
     _fields_ = [("stats", HistSerial * 15), ("total_count", C.c_uint64), ("max_val_seen", C.c_int64)]
 
 
+class TimeHistVal(C.Structure):
+    _fields_ = [("data_value", C.c_int64), ("percentile", C.c_float), ("pad", C.c_uint32)]
+
+
+class ListenerDayStats(C.Structure):
+    _fields_ = [("glob_id", C.c_uint64), ("tcount_5d", C.c_int64), ("tsum_5d", C.c_int64), ("p95_5d_respms", C.c_uint32),
+                ("p25_5d_respms", C.c_uint32), ("p95_qps", C.c_uint32), ("p25_qps", C.c_uint32), ("p95_nactive", C.c_uint32),
+                ("p25_nactive", C.c_uint32)]
+
+
 class TopnEntry(C.Structure):
     _fields_ = [("glob_id", C.c_uint64), ("host_slot", C.c_uint32), ("metric", C.c_uint32), ("state", C.c_uint8 * 88)]
 
@@ -82,7 +93,7 @@ class Counters(C.Structure):
                                           "resp_batches_host_local", "resp_batches_general", "window_graph_launches")]
 
 
-assert C.sizeof(HistRec) == 256 and C.sizeof(TopnEntry) == 104 and C.sizeof(RespSeg) == 16
+assert C.sizeof(HistRec) == 256 and C.sizeof(TopnEntry) == 104 and C.sizeof(RespSeg) == 16 and C.sizeof(ListenerDayStats) == 48
 
 vp, u8p, u32p, u64p, i64p, i32p, f32p, f64p = (C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                                C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double))
@@ -120,6 +131,10 @@ SIGNATURES = {
     "gys_query_cms": (C.c_int, [vp, C.c_uint64, C.c_int, u64p]),
     "gys_query_topn": (C.c_int, [vp, mid, C.c_int, C.POINTER(TopnEntry), u32p]),
     "gys_scan_percentiles_dev": (C.c_int, [vp, C.c_int, f32p, C.c_uint32, vp]),
+    "gys_query_hist_level_stats": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(TimeHistVal), C.c_uint32, i64p, i64p, f64p]),
+    "gys_export_hist_level": (C.c_int, [vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
+    "gys_export_day_stats": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
+    "gys_export_svc_hist": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_uint32, vp]),
     "gys_set_host_name": (C.c_int, [vp, mid, C.c_char_p]),
     "gys_json_svcsumm": (C.c_int, [vp, mid, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_json_svcstate": (C.c_int, [vp, mid, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -202,6 +202,29 @@ __host__ __device__ inline void hist_percentile(const HashDef &d, const gys_hist
 		*data_value = bucket_max_threshold(d, h.total_count > 0 ? (uint32_t)nb : 0u); // :779-789
 }
 
+// SlabHistogramBuckets::getPercentileBucketIdx (thirdparty/SlabHistogramBucket.h:165-240), the rule TIME_HISTOGRAM::get_stats uses
+// on a time level (common/gy_statistics.h:1352): first non-empty bucket whose cumulative fraction reaches pct01; empty -> bucket 1.
+__host__ __device__ inline uint32_t slab_percentile_idx(const gys_hist_rec &h, int nb, double pct01)
+{
+	uint64_t total = 0, cur = 0;
+	for (int i = 0; i < nb; ++i) total += h.stats[i].count;
+	if (total == 0) return 1u;
+	int idx;
+	for (idx = 0; idx < nb; ++idx) {
+		if (h.stats[idx].count == 0) continue;
+		cur += h.stats[idx].count;
+		if (pct01 <= (double)cur / (double)total) break;
+	}
+	return (uint32_t)idx;
+}
+
+// one TIME_HIST_VAL of TIME_HISTOGRAM::get_stats: ceiling of that bucket, negatives clamped to 0 (:1352-1354)
+__host__ __device__ inline int64_t level_percentile(const HashDef &d, const gys_hist_rec &h, float pct)
+{
+	const int64_t v = bucket_max_threshold(d, slab_percentile_idx(h, d.nthr + 2, (double)pct / 100.0));
+	return v < 0 ? 0 : v;
+}
+
 // ------------------------------------------------------------------------------------------------ open-addressing key table
 struct TblEnt {
 	uint64_t key; // GYS_EMPTY_KEY = free

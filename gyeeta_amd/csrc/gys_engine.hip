@@ -219,6 +219,12 @@ struct gys_ctx {
 	WireMsg *wire_msgs = nullptr;
 	uint32_t wire_msgs_cap = 0;
 
+	// multi-level windows (cfg.enable_levels; kernels: "multi-level windows" in gys_kernels.hpp)
+	gys_hist_rec *lvl_snap = nullptr; // [2][GYS_LEVEL_RING][max_services] cumulative records at the last start of every ring bucket
+	gys_hist_rec *lvl_last = nullptr; // [max_services] the window closed last (level 0)
+	gys_hist_rec *qps_hist = nullptr, *act_hist = nullptr; // per-service QPS_HISTOGRAM / ACTIVE_CONN_HISTOGRAM
+	int64_t lvl_t_last = -1;          // close time (s) of the last window, -1: none yet
+
 	bool profile = false;
 	std::map<std::string, ProfEntry> prof;
 };
@@ -650,6 +656,84 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	return GYS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ multi-level windows
+constexpr int64_t LEVEL_SECS[GYS_NLEVELS] = {5, 300, 5 * 24 * 3600, 0}; // Level_5s_5min_5days_all common/gy_statistics.h:1545-1551
+
+// most recent start (<= t) of ring bucket j of a level of `dur` seconds (folly BucketedTimeSeries::getBucketInfo; dur % ring == 0)
+inline int64_t level_bucket_start(int64_t t, int64_t dur, uint32_t j)
+{
+	const int64_t s = (t / dur) * dur + (int64_t)j * (dur / GYS_LEVEL_RING);
+	return s <= t ? s : s - dur;
+}
+
+inline uint32_t level_bucket_idx(int64_t t, int64_t dur) { return (uint32_t)((t % dur) * GYS_LEVEL_RING / dur); }
+
+// window close at tusec: remember the closing window as level 0 and snapshot the cumulative records into every ring bucket whose
+// start was crossed since the previous close
+int level_roll(gys_ctx *c, uint64_t tusec)
+{
+	int64_t tnow = (int64_t)(tusec / 1000000ull);
+	if (tnow < c->lvl_t_last) tnow = c->lvl_t_last; // time does not go backwards (BucketedTimeSeries::update)
+	LevelRollP p{};
+	p.win = c->hist_win;
+	p.all = c->hist_all;
+	p.meta = c->cfg.enable_tdigest ? c->td_meta : nullptr;
+	p.epoch = c->epoch;
+	p.nsvc = c->nsvc;
+	p.snap = c->lvl_snap;
+	p.last = c->lvl_last;
+	p.stride = c->cfg.max_services;
+	for (int li = 0; li < 2; ++li) {
+		const int64_t dur = LEVEL_SECS[li + 1];
+		for (uint32_t j = 0; j < GYS_LEVEL_RING; ++j)
+			if (c->lvl_t_last >= 0 && level_bucket_start(tnow, dur, j) > c->lvl_t_last) p.mask[li] |= 1u << j;
+	}
+	c->lvl_t_last = tnow;
+	if (!c->nsvc) return GYS_OK;
+	ProfScope ps(c, "level_roll");
+	hipLaunchKernelGGL(k_level_roll, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+// device records of one level at time tusec for slots [first, first + n) into d_out
+int level_view(gys_ctx *c, int level, uint64_t tusec, uint32_t first, uint32_t n, gys_hist_rec *d_out)
+{
+	int64_t tq = (int64_t)(tusec / 1000000ull);
+	if (tq < c->lvl_t_last) tq = c->lvl_t_last;
+	LevelViewP p{};
+	p.win = c->hist_win;
+	p.all = c->hist_all;
+	p.meta = c->cfg.enable_tdigest ? c->td_meta : nullptr;
+	p.epoch_open = c->epoch + (c->prepared ? 1u : 0u);
+	p.first = first;
+	p.n = n;
+	p.out = d_out;
+	if (level == 3) {
+		p.mode = 0;
+	} else if (level == 0) {
+		// a 5-s ring keeps an add for 5 s: the window closed last, until a window's length has passed without another close
+		if (c->lvl_t_last >= 0 && tq - c->lvl_t_last < LEVEL_SECS[0]) {
+			p.mode = 2;
+			p.sub = c->lvl_last;
+		} else {
+			p.mode = 1;
+		}
+	} else {
+		const int64_t dur = LEVEL_SECS[level];
+		const uint32_t oldest = (level_bucket_idx(tq, dur) + 1u) % GYS_LEVEL_RING;
+		if (c->lvl_t_last < 0 || level_bucket_start(tq, dur, oldest) > c->lvl_t_last) {
+			p.mode = 1; // every add is older than the ring's oldest live bucket
+		} else {
+			p.mode = 0;
+			p.sub = c->lvl_snap + ((uint64_t)(level - 1) * GYS_LEVEL_RING + oldest) * c->cfg.max_services;
+		}
+	}
+	hipLaunchKernelGGL(k_level_view, dim3((uint32_t)(((uint64_t)n * 16 + 255) / 256)), dim3(256), 0, c->stream, p);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
 // walk a variable-stride batch on the host (what COMM validate + the reference loops do) and produce record offsets
 template <typename SizeFn>
 int walk_batch(const uint8_t *batch, uint32_t n, const uint8_t *pend, uint32_t fixed, SizeFn elem_size, std::vector<uint32_t> &offs)
@@ -718,6 +802,8 @@ int run_lstate(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, co
 	p.host_summ = c->host_summ_win;
 	p.epoch = c->epoch;
 	p.counters = c->counters;
+	p.qps_hist = c->qps_hist;
+	p.act_hist = c->act_hist;
 	ProfScope ps(c, "lstate");
 	hipLaunchKernelGGL(k_lstate_ingest, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
@@ -816,6 +902,12 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
 	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
+	if (cfg->enable_levels) {
+		ALLOC(c->lvl_snap, 2 * GYS_LEVEL_RING * S);
+		ALLOC(c->lvl_last, S);
+		ALLOC(c->qps_hist, S);
+		ALLOC(c->act_hist, S);
+	}
 	if (cfg->enable_tdigest) {
 		const uint64_t B = cfg->max_batch_events ? cfg->max_batch_events : 1;
 		ALLOC(c->td_sum, S * GYS_TD_NB);
@@ -849,6 +941,12 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	}
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_win, (uint64_t)0, S, (int64_t)INT64_MIN);
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_all, (uint64_t)0, S, (int64_t)INT64_MIN);
+	if (cfg->enable_levels) {
+		hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->lvl_last, (uint64_t)0, S, (int64_t)INT64_MIN);
+		// GY_HISTOGRAM<int, ...>: max_val_seen_ starts at std::numeric_limits<int>::min()
+		hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->qps_hist, (uint64_t)0, S, (int64_t)INT32_MIN);
+		hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->act_hist, (uint64_t)0, S, (int64_t)INT32_MIN);
+	}
 	c->al = arena_layout(cfg->max_clusters);
 	if (cfg->reduce_arena) {
 		if (cfg->reduce_arena_bytes < c->al.total) {
@@ -890,7 +988,7 @@ void gys_destroy(gys_ctx *c)
 			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
-			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->own_arena ? c->arena : nullptr};
+			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	if (c->aux_stream) {
@@ -1308,11 +1406,14 @@ int gys_reduce_sections(gys_ctx *c, gys_reduce_section out[4], uint32_t *nsectio
 
 int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 {
-	(void)tusec;
 	if (!c) return GYS_ERR_INVAL;
 	if (c->prepared) {
 		set_err("window already prepared");
 		return GYS_ERR_STATE;
+	}
+	if (c->cfg.enable_levels) {
+		const int rcl = level_roll(c, tusec); // before the eager fold below: it needs the cumulative records WITHOUT the closing window
+		if (rcl) return rcl;
 	}
 	PrepP p{};
 	p.host_summ = c->host_summ_win;
@@ -1806,6 +1907,100 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 	out->resp_batches_host_local = c->n_batches_host_local;
 	out->resp_batches_general = c->n_batches_general;
 	out->window_graph_launches = c->win_graph_launches;
+	return GYS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ multi-level windows
+#define LEVELS_CHECK()                                                        \
+	if (!c->cfg.enable_levels) {                                          \
+		set_err("gys_config.enable_levels was not set");              \
+		return GYS_ERR_STATE;                                         \
+	}
+
+int gys_export_hist_level(gys_ctx *c, int level, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
+{
+	RANGE_CHECK(first_slot, nslots);
+	LEVELS_CHECK();
+	if (level < 0 || level >= GYS_NLEVELS) return GYS_ERR_INVAL;
+	if (!nslots) return GYS_OK;
+	gys_hist_rec *tmp = nullptr;
+	HIPCHK(hipMalloc((void **)&tmp, (size_t)nslots * sizeof(gys_hist_rec)));
+	int rc = level_view(c, level, tusec, first_slot, nslots, tmp);
+	if (rc == GYS_OK) {
+		hipError_t e = hipMemcpyAsync(out, tmp, (size_t)nslots * sizeof(gys_hist_rec), hipMemcpyDeviceToHost, c->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+		if (e != hipSuccess) {
+			set_err("level export copy: %s", hipGetErrorString(e));
+			rc = GYS_ERR_HIP;
+		}
+	}
+	hipFree(tmp);
+	return rc;
+}
+
+int gys_query_hist_level_stats(gys_ctx *c, uint64_t glob_id, int level, uint64_t tusec, gys_time_hist_val *pstats, uint32_t nstats, int64_t *tcount,
+			       int64_t *tsum, double *mean_val)
+{
+	if (!c || (!pstats && nstats)) return GYS_ERR_INVAL;
+	uint32_t slot;
+	int rc = gys_lookup_service(c, glob_id, &slot);
+	if (rc) return rc;
+	gys_hist_rec h;
+	rc = gys_export_hist_level(c, level, tusec, slot, 1, &h);
+	if (rc) return rc;
+	const HashDef &d = hash_def(GYS_RESP_TIME_HASH);
+	int64_t tc = 0, ts = 0;
+	for (int b = 0; b < d.nthr + 2; ++b) { // slabhist.count(level) / sum(level), common/gy_statistics.h:1358-1359
+		tc += (int64_t)h.stats[b].count;
+		ts += h.stats[b].sum;
+	}
+	for (uint32_t i = 0; i < nstats; ++i) pstats[i].data_value = level_percentile(d, h, pstats[i].percentile);
+	if (tcount) *tcount = tc;
+	if (tsum) *tsum = ts;
+	if (mean_val) *mean_val = (double)ts / (double)(tc != 0 ? tc : 1); // :1361
+	return GYS_OK;
+}
+
+int gys_export_day_stats(gys_ctx *c, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_listener_day_stats *out)
+{
+	RANGE_CHECK(first_slot, nslots);
+	LEVELS_CHECK();
+	if (!nslots) return GYS_OK;
+	gys_hist_rec *lv = nullptr;
+	gys_listener_day_stats *d_out = nullptr;
+	HIPCHK(hipMalloc((void **)&lv, (size_t)nslots * sizeof(gys_hist_rec)));
+	hipError_t e = hipMalloc((void **)&d_out, (size_t)nslots * sizeof(gys_listener_day_stats));
+	if (e != hipSuccess) {
+		hipFree(lv);
+		HIPCHK(e);
+	}
+	int rc = level_view(c, 2, tusec, first_slot, nslots, lv);
+	if (rc == GYS_OK) {
+		ProfScope ps(c, "day_stats");
+		hipLaunchKernelGGL(k_day_stats, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, lv, c->qps_hist, c->act_hist, c->svc_gid, first_slot, nslots,
+				   d_out);
+		e = hipGetLastError();
+		if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)nslots * sizeof(gys_listener_day_stats), hipMemcpyDeviceToHost, c->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+		if (e != hipSuccess) {
+			set_err("day stats: %s", hipGetErrorString(e));
+			rc = GYS_ERR_HIP;
+		}
+	}
+	hipFree(lv);
+	hipFree(d_out);
+	return rc;
+}
+
+int gys_export_svc_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
+{
+	RANGE_CHECK(first_slot, nslots);
+	LEVELS_CHECK();
+	if (which < 0 || which > 1) return GYS_ERR_INVAL;
+	if (!nslots) return GYS_OK;
+	const gys_hist_rec *src = (which ? c->act_hist : c->qps_hist) + first_slot;
+	HIPCHK(hipMemcpyAsync(out, src, (size_t)nslots * sizeof(gys_hist_rec), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
 }
 

@@ -1500,6 +1500,16 @@ __global__ __launch_bounds__(256) void k_conn_fold(unsigned long long *svc_win, 
 	w[2] = 0;
 }
 
+// GY_HISTOGRAM::add_data (common/gy_statistics.h:596-623) on a record other threads may be adding to
+__device__ __forceinline__ void hist_add_atomic(const HashDef &d, int kind, gys_hist_rec *h, int64_t v)
+{
+	const uint32_t b = kind == GYS_RESP_TIME_HASH ? resp_bucket(v) : bucket_of(d, v);
+	atomicAdd((unsigned long long *)&h->stats[b].count, 1ull);
+	atomicAdd((unsigned long long *)&h->stats[b].sum, (unsigned long long)v);
+	atomicAdd((unsigned long long *)&h->total_count, 1ull);
+	if (h->max_val_seen < v) atomicMax((long long *)&h->max_val_seen, (long long)v);
+}
+
 // ---------------------------------------------------------------------------------------------------- LISTENER_STATE_NOTIFY ingest
 // comm::LISTENER_STATE_NOTIFY (common/gy_comm_proto.h:2183-2254), 88 fixed bytes: glob_id_@0 nqrys_5s_@8 total_resp_5sec_@12 nconns_@16
 // nconns_active_@20 ntasks_@24 p95_5s@28 p95_5min@32 kb_in@36 kb_out@40 ser_errors_@44 cli_errors_@48 ... curr_state_@79 ...
@@ -1515,6 +1525,7 @@ struct LStateP {
 	int32_t *host_summ; // [nhosts*16] window accumulators (13 used)
 	uint32_t epoch;
 	uint64_t *counters;
+	gys_hist_rec *qps_hist, *act_hist; // per service (levels enabled) or nullptr
 };
 
 __global__ __launch_bounds__(256) void k_lstate_ingest(LStateP p)
@@ -1564,6 +1575,12 @@ __global__ __launch_bounds__(256) void k_lstate_ingest(LStateP p)
 #pragma unroll
 	for (int k = 0; k < 11; ++k) d[k] = w[k];
 	d[11] = (uint64_t)p.epoch | ((uint64_t)host << 32);
+	if (p.qps_hist) {
+		// the per-listener QPS_HISTOGRAM / ACTIVE_CONN_HISTOGRAM behind LISTENER_DAY_STATS (common/gy_socket_stat.h:548-549, :633-635;
+		// one sample per 5-s state record: gy_socket_stat.cc:4109-4127), fed from the record's own nqrys_5s_/5 and nconns_active_
+		hist_add_atomic(hash_def(GYS_SEMI_LOG_HASH_LO), GYS_SEMI_LOG_HASH_LO, &p.qps_hist[slot], (int64_t)(int32_t)(nqrys_5s / 5u));
+		hist_add_atomic(hash_def(GYS_HASH_1_3000), GYS_HASH_1_3000, &p.act_hist[slot], (int64_t)(int32_t)nconns_active);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------- window boundary
@@ -1665,13 +1682,7 @@ __global__ __launch_bounds__(256) void k_hist_add(int kind, gys_hist_rec *hist, 
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
 		const uint32_t k = keyidx[i];
 		if (k >= nkeys) continue;
-		const int64_t v = (int64_t)vals[i];
-		const uint32_t b = kind == GYS_RESP_TIME_HASH ? resp_bucket(v) : bucket_of(d, v);
-		gys_hist_rec *h = &hist[k];
-		atomicAdd((unsigned long long *)&h->stats[b].count, 1ull);
-		atomicAdd((unsigned long long *)&h->stats[b].sum, (unsigned long long)v);
-		atomicAdd((unsigned long long *)&h->total_count, 1ull);
-		if (h->max_val_seen < v) atomicMax((long long *)&h->max_val_seen, (long long)v);
+		hist_add_atomic(d, kind, &hist[k], (int64_t)vals[i]);
 	}
 }
 
@@ -1734,6 +1745,147 @@ __global__ __launch_bounds__(256) void k_hist_percentiles(int kind, const gys_hi
 	uint64_t cnt;
 	hist_percentile(d, hist[k], pcts[pi], &dv, &sum, &cnt);
 	out[t] = dv;
+}
+
+// ---------------------------------------------------------------------------------------------------- multi-level windows
+// The reference keeps, per listener, a TIME_HISTOGRAM<RESP_TIME_HASH, Level_5s_5min_5days_all> (common/gy_statistics.h:1082-1551,
+// :2067): per histogram bucket a folly MultiLevelTimeSeries whose 300-s and 5-day levels are rings of 10 {sum,count} buckets that
+// are cleared as time advances.  Held that way 10^7 services would cost 2 levels x 10 ring buckets x 256 B of read-modify-write
+// traffic per key per window.  A ring level is however just "everything added since the start of its oldest live bucket", and the
+// engine already has the cumulative (all-time) record of every key, so it keeps SNAPSHOTS instead: snap[level][j][key] = the
+// cumulative record at the most recent start of ring bucket j.  A level at time t is then
+//       cumulative(t) - snap[level][(bucket(t) + 1) % 10]
+// Snapshots are written only when a bucket boundary is crossed (every 30 s for the 300-s level, every 12 h for the 5-day level),
+// as one streaming 16-B-per-lane copy over the records (k_level_roll); nothing is touched per event or per key-window.  Never
+// written snapshots are zero == the cumulative record before any data, which is exactly what a young series needs.  Level 0
+// ("last 5 seconds") is the engine's tumbling window itself: the record of the window closed last (last[]), kept by the same pass.
+// oracle: oracle/gy_oracle_levels.c keeps the rings the way folly does; tests/test_gpu_levels.py compares the two.
+struct LevelRollP {
+	const gys_hist_rec *win, *all;
+	const TdMeta *meta; // nullptr: eagerly kept arrays (win is the closing window of every key, all does not hold it yet)
+	uint32_t epoch;     // the window being closed
+	uint32_t nsvc;
+	gys_hist_rec *snap; // [2][GYS_LEVEL_RING][stride]
+	gys_hist_rec *last; // [stride]
+	uint64_t stride;
+	uint32_t mask[2];   // ring buckets of the 300-s / 5-day level whose start lies in (previous close, this close]
+};
+
+// records as 16 x {u64, i64}: lanes 0..14 {count, sum}, lane 15 {total_count, max_val_seen}
+__device__ __forceinline__ ulonglong2 pair_add(ulonglong2 a, ulonglong2 b, uint32_t k)
+{
+	ulonglong2 r;
+	r.x = a.x + b.x;
+	if (k < 15u)
+		r.y = a.y + b.y;
+	else
+		r.y = (unsigned long long)((long long)a.y < (long long)b.y ? (long long)b.y : (long long)a.y);
+	return r;
+}
+
+__global__ __launch_bounds__(256) void k_level_roll(LevelRollP p)
+{
+	const uint64_t npairs = (uint64_t)p.nsvc * 16ull, gstride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += gstride) {
+		const uint32_t slot = (uint32_t)(t >> 4), k = (uint32_t)(t & 15u);
+		const ulonglong2 w = ((const ulonglong2 *)p.win)[t];
+		const bool cur = !p.meta || p.meta[slot].win_epoch == p.epoch;
+		ulonglong2 closing;
+		if (cur) {
+			closing = w;
+		} else { // the key was not touched in the closing window: win still holds an older, not yet folded window
+			closing.x = 0;
+			closing.y = k < 15u ? 0ull : (unsigned long long)INT64_MIN;
+		}
+		((ulonglong2 *)p.last)[t] = closing;
+		if (p.mask[0] | p.mask[1]) {
+			// cumulative record BEFORE the closing window: its add happens at the close time, i.e. at or after the boundary
+			ulonglong2 before = ((const ulonglong2 *)p.all)[t];
+			if (!cur) before = pair_add(before, w, k);
+			for (int li = 0; li < 2; ++li)
+				for (uint32_t m = p.mask[li]; m; m &= m - 1) {
+					const uint32_t j = (uint32_t)__builtin_ctz(m);
+					((ulonglong2 *)(p.snap + ((uint64_t)li * GYS_LEVEL_RING + j) * p.stride))[t] = before;
+				}
+		}
+	}
+}
+
+struct LevelViewP {
+	const gys_hist_rec *win, *all;
+	const TdMeta *meta;
+	uint32_t epoch_open;     // windows before this one have been added (closed)
+	uint32_t first, n;
+	const gys_hist_rec *sub; // mode 0: snapshot to subtract (nullptr: nothing); mode 2: the last-window records
+	int mode;                // 0 cumulative - sub, 1 empty, 2 copy of sub
+	gys_hist_rec *out;       // [n]; max_val_seen is the all-time maximum for every level (the reference keeps no per-level maximum)
+};
+
+__global__ __launch_bounds__(256) void k_level_view(LevelViewP p)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= (uint64_t)p.n * 16ull) return;
+	const uint32_t slot = p.first + (uint32_t)(t >> 4), k = (uint32_t)(t & 15u);
+	const uint64_t g = (uint64_t)slot * 16ull + k;
+	ulonglong2 cum = ((const ulonglong2 *)p.all)[g];
+	const ulonglong2 w = ((const ulonglong2 *)p.win)[g];
+	if (p.meta) {
+		if (p.meta[slot].win_epoch != p.epoch_open)
+			cum = pair_add(cum, w, k); // a closed window that has not been folded yet
+		else if (k == 15u && (long long)cum.y < (long long)w.y)
+			cum.y = w.y;               // the maximum is reported over everything seen
+	} else if (k == 15u && (long long)cum.y < (long long)w.y) {
+		cum.y = w.y;
+	}
+	ulonglong2 r;
+	if (p.mode == 0) {
+		r = cum;
+		if (p.sub) {
+			const ulonglong2 s = ((const ulonglong2 *)p.sub)[g];
+			r.x -= s.x;
+			if (k < 15u) r.y -= s.y;
+		}
+	} else if (p.mode == 2) {
+		r = ((const ulonglong2 *)p.sub)[g];
+		if (k == 15u) r.y = cum.y;
+	} else {
+		r.x = 0;
+		r.y = k < 15u ? 0ull : cum.y;
+	}
+	((ulonglong2 *)p.out)[t] = r;
+}
+
+// comm::LISTENER_DAY_STATS (common/gy_comm_proto.h:1620-1632) the way TCP_LISTENER::get_curr_state fills it
+// (common/gy_socket_stat.cc:2053-2112): 5-day level count / sum / p95 / p25 of the response histogram (TIME_HISTOGRAM::get_stats),
+// p95 / p25 of the QPS and active-connection histograms (GY_HISTOGRAM::get_percentiles, HIST_DATA {95, 25}).
+__global__ __launch_bounds__(256) void k_day_stats(const gys_hist_rec *lvl5d, const gys_hist_rec *qps, const gys_hist_rec *act, const uint64_t *svc_gid,
+						   uint32_t first, uint32_t n, gys_listener_day_stats *out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const gys_hist_rec r = lvl5d[i];
+	gys_listener_day_stats o;
+	o.glob_id = svc_gid[first + i];
+	int64_t ts = 0;
+	for (int b = 0; b < 15; ++b) ts += r.stats[b].sum;
+	o.tcount_5d = (int64_t)r.total_count;
+	o.tsum_5d = ts;
+	const HashDef &dr = hash_def(GYS_RESP_TIME_HASH);
+	o.p95_5d_respms = (uint32_t)level_percentile(dr, r, 95.0f);
+	o.p25_5d_respms = (uint32_t)level_percentile(dr, r, 25.0f);
+	int64_t dv, sum;
+	uint64_t cnt;
+	const gys_hist_rec q = qps[first + i];
+	hist_percentile(hash_def(GYS_SEMI_LOG_HASH_LO), q, 95.0f, &dv, &sum, &cnt);
+	o.p95_qps = (uint32_t)dv;
+	hist_percentile(hash_def(GYS_SEMI_LOG_HASH_LO), q, 25.0f, &dv, &sum, &cnt);
+	o.p25_qps = (uint32_t)dv;
+	const gys_hist_rec a = act[first + i];
+	hist_percentile(hash_def(GYS_HASH_1_3000), a, 95.0f, &dv, &sum, &cnt);
+	o.p95_nactive = (uint32_t)dv;
+	hist_percentile(hash_def(GYS_HASH_1_3000), a, 25.0f, &dv, &sum, &cnt);
+	o.p25_nactive = (uint32_t)dv;
+	out[i] = o;
 }
 
 // top-N candidate filter: services of one host whose state is from the last window, with the ranked metric per kind

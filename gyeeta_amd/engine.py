@@ -36,7 +36,7 @@ def mid_buf(machine_id):
 
 class SketchEngine:
     def __init__(self, max_hosts, max_services, max_clusters=16, enable_tdigest=True, svc_hll_p=0, max_batch_events=1 << 20,
-                 rank=0, nranks=1, device=None, torch_arena=True, resp_path=0):
+                 rank=0, nranks=1, device=None, torch_arena=True, resp_path=0, enable_levels=False):
         import torch
         self.L = capi.load()
         if not torch.cuda.is_available():
@@ -53,6 +53,7 @@ class SketchEngine:
         cfg.enable_tdigest = 1 if enable_tdigest else 0
         cfg.svc_hll_p = svc_hll_p
         cfg.resp_path = resp_path
+        cfg.enable_levels = 1 if enable_levels else 0
         cfg.max_batch_events = max_batch_events
         with torch.cuda.device(self.device):
             # the engine gets its own torch stream: torch work (tensor fills / copies on the current stream, collectives) and engine work are
@@ -268,6 +269,33 @@ class SketchEngine:
         n = self.num_services() - first if n is None else n
         out = np.zeros((n, 16, 2), dtype=np.int64)  # [slot][bucket]{count,sum}; [slot][15] = {total_count, max_val_seen}
         capi.check(self.L.gys_export_hist(self.h, which, first, n, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def export_hist_level(self, level, tusec, first=0, n=None):
+        """records of one time level (0: last window, 1: 300 s, 2: 5 days, 3: all) as of tusec; same layout as export_hist"""
+        n = self.num_services() - first if n is None else n
+        out = np.zeros((n, 16, 2), dtype=np.int64)
+        capi.check(self.L.gys_export_hist_level(self.h, level, int(tusec), first, n, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def query_hist_level_stats(self, glob_id, level, tusec, pcts):
+        st = (capi.TimeHistVal * len(pcts))()
+        for i, p in enumerate(pcts):
+            st[i].percentile = p
+        tc, ts, mean = C.c_int64(), C.c_int64(), C.c_double()
+        capi.check(self.L.gys_query_hist_level_stats(self.h, int(glob_id), level, int(tusec), st, len(pcts), C.byref(tc), C.byref(ts), C.byref(mean)))
+        return [s.data_value for s in st], tc.value, ts.value, mean.value
+
+    def export_day_stats(self, tusec, first=0, n=None):
+        n = self.num_services() - first if n is None else n
+        out = (capi.ListenerDayStats * n)()
+        capi.check(self.L.gys_export_day_stats(self.h, int(tusec), first, n, C.cast(out, C.c_void_p)))
+        return out
+
+    def export_svc_hist(self, which, first=0, n=None):
+        n = self.num_services() - first if n is None else n
+        out = np.zeros((n, 16, 2), dtype=np.int64)
+        capi.check(self.L.gys_export_svc_hist(self.h, which, first, n, C.c_void_p(out.ctypes.data)))
         return out
 
     def export_conn_bitmap(self, first=0, n=None):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GYS_ABI_VERSION 2
+#define GYS_ABI_VERSION 3
 
 enum {
 	GYS_OK = 0,
@@ -78,6 +78,8 @@ typedef struct {
 	void *stream;              /* hipStream_t to run on; NULL = the context creates its own */
 	void *reduce_arena;        /* optional caller-owned DEVICE buffer for the all-reducible registers (e.g. a torch tensor so */
 	uint64_t reduce_arena_bytes; /* that torch.distributed/RCCL can reduce it in place); NULL = the context allocates it  */
+	uint32_t enable_levels;    /* multi-level windows (5 s / 300 s / 5 days / all) + per-service QPS / active-connection histograms */
+	uint32_t reserved0;        /* (costs 21 hist records = 5.4 KB of HBM per service; see "multi-level windows" below) */
 } gys_config;
 
 /* -------------------------------------------------------------------------------------------------------------------
@@ -243,6 +245,41 @@ int gys_query_topn(gys_ctx *ctx, const uint8_t machine_id[16], int kind, gys_top
 /* The "per-key scan" (TCP_SOCK_HANDLER::listener_stats_update percentile part, common/gy_socket_stat.cc:4226-4230) over ALL services
  * on the GPU: for service slot s and percentile i, d_out[s*npct + i] = bucket ceiling; which as above.  d_out is a DEVICE pointer. */
 int gys_scan_percentiles_dev(gys_ctx *ctx, int which, const float *pcts, uint32_t npct, int64_t *d_out);
+
+/* -------------------------------------------------------------------------------------------------------------------
+ * multi-level windows (gys_config.enable_levels).  Replaces the per-listener RESP_TIME_HISTOGRAM =
+ * TIME_HISTOGRAM<RESP_TIME_HASH, Level_5s_5min_5days_all> (common/gy_statistics.h:1082-1551, :2067), i.e. folly::MultiLevelTimeSeries
+ * per histogram bucket with 10 ring buckets per level, and the QPS_HISTOGRAM / ACTIVE_CONN_HISTOGRAM behind LISTENER_DAY_STATS
+ * (common/gy_socket_stat.h:548-549).  Every gys_window_prepare(tusec) is one add_histogram_data(tnow = tusec / 10^6, window
+ * histogram, flush) of every service (gy_statistics.h:1213-1247); a query at tusec first advances the series to that time
+ * (get_stats_with_flush :1369).  Times are whole seconds and must not go backwards (folly clamps, so does the engine).
+ * level: 0 = the window closed last ("last 5 seconds": the engine's tumbling window itself; empty once 5 s have passed since its
+ * close), 1 = last 300 s, 2 = last 5 days (rings of GYS_LEVEL_RING buckets, so between 9/10 and 10/10 of the nominal span, exactly
+ * as folly's rings), 3 = since start.  Only windows closed by gys_window_prepare are in a level, never the open one. */
+#define GYS_NLEVELS 4
+#define GYS_LEVEL_RING 10 /* ntimeseries_buckets, common/gy_statistics.h:1104 */
+typedef struct {
+	int64_t data_value;
+	float percentile; /* 0..100 */
+	uint32_t pad;
+} gys_time_hist_val; /* == TIME_HIST_VAL, common/gy_statistics.h:489-498 */
+/* TIME_HISTOGRAM::get_stats_with_flush(level, pstats, nstats, tcount, tsum, mean_val, tnow) :1333-1374 */
+int gys_query_hist_level_stats(gys_ctx *ctx, uint64_t glob_id, int level, uint64_t tusec, gys_time_hist_val *pstats, uint32_t nstats,
+			       int64_t *tcount, int64_t *tsum, double *mean_val);
+/* TIME_HISTOGRAM::get_level_data :1166-1200 for a range of services; out[i].max_val_seen = the all-time maximum for every level */
+int gys_export_hist_level(gys_ctx *ctx, int level, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out);
+
+typedef struct {
+	uint64_t glob_id;
+	int64_t tcount_5d, tsum_5d;
+	uint32_t p95_5d_respms, p25_5d_respms, p95_qps, p25_qps, p95_nactive, p25_nactive;
+} gys_listener_day_stats; /* == comm::LISTENER_DAY_STATS, 48 bytes, common/gy_comm_proto.h:1620-1632 */
+/* What TCP_LISTENER::get_curr_state puts into LISTENER_DAY_STATS (common/gy_socket_stat.cc:2053-2112) for a range of services, as the
+ * NOTIFY_LISTENER_DAY_STATS payload madhava consumes (handle_listener_day_stats server/gy_mconnhdlr.cc:12805).  The reference sends
+ * zeros for a listener younger than 15 minutes; listener start times are control-plane state, that rule is left to the caller. */
+int gys_export_day_stats(gys_ctx *ctx, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_listener_day_stats *out);
+/* the per-service QPS (which = 0, SEMI_LOG_HASH_LO) / active-connection (which = 1, HASH_1_3000) histograms fed by listener state */
+int gys_export_svc_hist(gys_ctx *ctx, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out);
 
 /* -------------------------------------------------------------------------------------------------------------------
  * the same queries as JSON in the reference's web shapes (field names and order = common/gy_json_field_maps.h):

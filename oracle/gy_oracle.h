@@ -187,6 +187,42 @@ void gyo_cluster_state_update(gyo_cluster_state_one *c, uint32_t ntasks_issue, u
 			      uint32_t nlisten, uint32_t cpu_issue, uint32_t mem_issue, const gyo_listen_summ_stats *summ);
 void gyo_cluster_state_add(gyo_cluster_state_one *dst, const gyo_cluster_state_one *src);
 
+/* ---------------------------------------------------------------- multi-level time-series histogram (gy_oracle_levels.c; PARITY UNPINNED)
+ * folly::BucketedTimeSeries / MultiLevelTimeSeries as TIME_HISTOGRAM<RESP_TIME_HASH, Level_5s_5min_5days_all> drives them
+ * (common/gy_statistics.h:1082-1551); times are whole seconds (folly::LegacyStatsClock<std::chrono::seconds>). */
+#define GYO_BTS_MAXB 16
+#define GYO_MLH_LEVELS 4 /* 5 s, 300 s, 5 days, all-time */
+
+typedef struct {
+	int64_t duration; /* seconds; 0 = all-time */
+	uint32_t nbuckets;
+	int64_t first_time, latest_time;
+	int64_t tot_sum;
+	uint64_t tot_cnt;
+	int64_t bsum[GYO_BTS_MAXB];
+	uint64_t bcnt[GYO_BTS_MAXB];
+} gyo_bts;
+
+void gyo_bts_init(gyo_bts *s, uint32_t nbuckets, int64_t duration);
+int gyo_bts_add(gyo_bts *s, int64_t now, int64_t sum, uint64_t nsamples); /* addValueAggregated */
+void gyo_bts_update(gyo_bts *s, int64_t now);
+
+typedef struct {
+	int kind, nb;
+	gyo_bts s[GYO_MAX_BUCKETS][GYO_MLH_LEVELS];
+	int64_t cached_time[GYO_MAX_BUCKETS];
+	gyo_hist_serial cached[GYO_MAX_BUCKETS];
+} gyo_mlhist;
+
+int64_t gyo_mlh_level_seconds(int level);
+void gyo_mlh_init(gyo_mlhist *h, int kind, uint32_t ntimeseries_buckets /* reference default 10 */);
+void gyo_mlh_add_hist(gyo_mlhist *h, int64_t tnow, const gyo_hist_serial *stats /*[nb]*/, int flush);
+void gyo_mlh_flush(gyo_mlhist *h, int64_t tnow);
+void gyo_mlh_level(const gyo_mlhist *h, int level, gyo_hist_serial *out /*[16]*/);
+size_t gyo_slab_percentile_idx(const uint64_t *counts, size_t nb, double pct);
+void gyo_mlh_get_stats(const gyo_mlhist *h, int level, const float *pcts, size_t npct, int64_t *values, int64_t *tcount, int64_t *tsum,
+		       double *mean);
+
 /* BOUNDED_PRIO_QUEUE<uint64_t, greater> (common/gy_statistics.h:356-383): returns retained values sorted descending */
 size_t gyo_topn_u64(const uint64_t *vals, size_t n, size_t maxn, uint64_t *out);
 

@@ -16,6 +16,7 @@ KINDS = {
     "RESP_TIME_HASH": 0, "SEMI_LOG_HASH": 1, "SEMI_LOG_HASH_LO": 2, "DURATION_HASH": 3, "HASH_10_5000": 4,
     "HASH_5_250": 5, "HASH_1_3000": 6, "PERCENT_HASH": 7, "FIXED_9_26_5": 8, "FIXED_N15_N3_4": 9,
 }
+RESP_TIME_HASH = KINDS["RESP_TIME_HASH"]
 MAX_BUCKETS = 16
 TD_NB = 100
 HLL_P = 14
@@ -29,9 +30,10 @@ i32p = C.POINTER(C.c_int32)
 u64p = C.POINTER(C.c_uint64)
 i64p = C.POINTER(C.c_int64)
 f32p = C.POINTER(C.c_float)
+HIST_SERIAL_DT = np.dtype([("count", "<u8"), ("sum", "<i8")])  # HIST_SERIAL as a numpy record
 
 
-SOURCES = ["gy_oracle.c", "gy_oracle_engine.c"]
+SOURCES = ["gy_oracle.c", "gy_oracle_engine.c", "gy_oracle_levels.c"]
 
 
 def build_oracle(force=False):
@@ -64,6 +66,20 @@ TD_PEND_CAP = 256
 
 class TDBuffered(C.Structure):
     _fields_ = [("d", TDigest), ("npend", C.c_uint32), ("pend", C.c_int32 * TD_PEND_CAP)]
+
+
+BTS_MAXB = 16
+MLH_LEVELS = 4
+
+
+class BTS(C.Structure):
+    _fields_ = [("duration", C.c_int64), ("nbuckets", C.c_uint32), ("first_time", C.c_int64), ("latest_time", C.c_int64),
+                ("tot_sum", C.c_int64), ("tot_cnt", C.c_uint64), ("bsum", C.c_int64 * BTS_MAXB), ("bcnt", C.c_uint64 * BTS_MAXB)]
+
+
+class MLHist(C.Structure):
+    _fields_ = [("kind", C.c_int), ("nb", C.c_int), ("s", (BTS * MLH_LEVELS) * MAX_BUCKETS),
+                ("cached_time", C.c_int64 * MAX_BUCKETS), ("cached", HistSerial * MAX_BUCKETS)]
 
 
 class ListenSummStats(C.Structure):
@@ -155,6 +171,16 @@ def lib():
     _sig(L, "gyo_cluster_state_update", None, [C.POINTER(ClusterStateOne)] + [C.c_uint32] * 6 + [C.POINTER(ListenSummStats)])
     _sig(L, "gyo_cluster_state_add", None, [C.POINTER(ClusterStateOne), C.POINTER(ClusterStateOne)])
     _sig(L, "gyo_topn_u64", C.c_size_t, [u64p, C.c_size_t, C.c_size_t, u64p])
+    _sig(L, "gyo_bts_init", None, [C.POINTER(BTS), C.c_uint32, C.c_int64])
+    _sig(L, "gyo_bts_add", C.c_int, [C.POINTER(BTS), C.c_int64, C.c_int64, C.c_uint64])
+    _sig(L, "gyo_bts_update", None, [C.POINTER(BTS), C.c_int64])
+    _sig(L, "gyo_mlh_level_seconds", C.c_int64, [C.c_int])
+    _sig(L, "gyo_mlh_init", None, [C.POINTER(MLHist), C.c_int, C.c_uint32])
+    _sig(L, "gyo_mlh_add_hist", None, [C.POINTER(MLHist), C.c_int64, C.c_void_p, C.c_int])
+    _sig(L, "gyo_mlh_flush", None, [C.POINTER(MLHist), C.c_int64])
+    _sig(L, "gyo_mlh_level", None, [C.POINTER(MLHist), C.c_int, C.c_void_p])
+    _sig(L, "gyo_slab_percentile_idx", C.c_size_t, [u64p, C.c_size_t, C.c_double])
+    _sig(L, "gyo_mlh_get_stats", None, [C.POINTER(MLHist), C.c_int, f32p, C.c_size_t, i64p, i64p, i64p, C.POINTER(C.c_double)])
     _sig(L, "gyo_engine_new", C.c_void_p, [C.c_uint32, C.c_int])
     _sig(L, "gyo_engine_free", None, [C.c_void_p])
     _sig(L, "gyo_engine_register", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint16])

@@ -38,16 +38,18 @@ def test_header_symbols_exported(capi):
 
 def test_struct_sizes_match_header(capi, tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "gysketch.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "gysketch.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(gys_config),sizeof(gys_listener_info),sizeof(gys_resp_seg),sizeof(gys_host_state),sizeof(gys_reduce_section),"
-                   "sizeof(gys_svcsumm),sizeof(gys_cluster_state),sizeof(gys_hist_data),sizeof(gys_hist_rec),sizeof(gys_topn_entry),sizeof(gys_counters));return 0;}\n")
+                   "sizeof(gys_svcsumm),sizeof(gys_cluster_state),sizeof(gys_hist_data),sizeof(gys_hist_rec),sizeof(gys_topn_entry),sizeof(gys_counters),sizeof(gys_time_hist_val),sizeof(gys_listener_day_stats));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])  # header is plain C
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     exp = [C.sizeof(t) for t in (capi.Config, capi.ListenerInfo, capi.RespSeg, capi.HostState, capi.ReduceSection, capi.SvcSumm,
-                                 capi.ClusterState, capi.HistData, capi.HistRec, capi.TopnEntry, capi.Counters)]
+                                 capi.ClusterState, capi.HistData, capi.HistRec, capi.TopnEntry, capi.Counters, capi.TimeHistVal,
+                                 capi.ListenerDayStats)]
     assert got == exp
     assert C.sizeof(capi.HistRec) == 256 and C.sizeof(capi.SvcSumm) == 52 and C.sizeof(capi.ClusterState) == 44
+    assert C.sizeof(capi.ListenerDayStats) == 48  # comm::LISTENER_DAY_STATS
 
 
 def test_no_cpu_fallback(capi):
@@ -71,7 +73,7 @@ def test_bad_config_rejected(capi):
     cfg = capi.Config()
     h = C.c_void_p()
     assert L.gys_create(C.byref(cfg), C.byref(h)) == capi.ERR_INVAL  # struct_size 0
-    assert L.gys_abi_version() == 2
+    assert L.gys_abi_version() == 3
 
 
 def test_shard_function_is_reference_machine_id_hash(capi, oracle):
