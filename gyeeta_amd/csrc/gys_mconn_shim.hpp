@@ -19,6 +19,7 @@
 #pragma once
 
 #include <cstdint>
+#include <ctime>
 #include <functional>
 #include <mutex>
 #include <stdexcept>
@@ -120,6 +121,25 @@ public:
 	{
 		std::lock_guard<std::mutex> g(mu_);
 		return gys_query_clusterstate(ctx_, cluster, &out) == GYS_OK;
+	}
+
+	// RESP_TIME_HISTOGRAM::get_stats_with_flush of one listener on one time level (Level_5s_5min_5days_all index 0..3;
+	// common/gy_statistics.h:1333-1374); needs gys_config.enable_levels
+	int get_resp_level_stats(uint64_t glob_id, int level, time_t tnow, gys_time_hist_val *pstats, size_t nstats, int64_t &tcount, int64_t &tsum,
+				 double &mean_val) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		return gys_query_hist_level_stats(ctx_, glob_id, level, (uint64_t)tnow * 1000000ull, pstats, (uint32_t)nstats, &tcount, &tsum, &mean_val) == GYS_OK
+			       ? 0
+			       : -1;
+	}
+
+	// the NOTIFY_LISTENER_DAY_STATS payload (comm::LISTENER_DAY_STATS[], MAX_NUM_LISTENERS = 2048 per message) for service slots
+	// [first_slot, first_slot + nslots), as TCP_LISTENER::get_curr_state fills it (common/gy_socket_stat.cc:2098-2112)
+	bool listener_day_stats(time_t tnow, uint32_t first_slot, uint32_t nslots, gys_listener_day_stats *pout) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		return gys_export_day_stats(ctx_, (uint64_t)tnow * 1000000ull, first_slot, nslots, pout) == GYS_OK;
 	}
 
 	// the same answers as the reference's web JSON (web_curr_listener_summ / web_curr_listener_state / web_curr_clusterstate)

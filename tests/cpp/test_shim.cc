@@ -32,6 +32,7 @@ int main(int argc, char **argv)
 	cfg.max_hosts = 4;
 	cfg.max_services = 64;
 	cfg.max_clusters = 2;
+	cfg.enable_levels = 1;
 	gyeeta_amd::GYS_MCONN_HANDLER h(cfg);
 	uint8_t mid[16];
 	for (int i = 0; i < 16; ++i) mid[i] = (uint8_t)(i * 7 + 1);
@@ -92,6 +93,21 @@ int main(int argc, char **argv)
 			return 13;
 		}
 		if (!h.web_curr_clusterstate("ffffffffffffffff", "", js) || js.find("\"nhosts\":1,") == std::string::npos) return 14;
+	}
+	// multi-level windows: the two windows closed above (at 5 s and 10 s) carried no response events -> empty levels, ceiling of
+	// bucket 1; the listener-state records fed the QPS / active-connection histograms twice
+	{
+		gys_time_hist_val tv[2] = {{0, 95.0f, 0}, {0, 25.0f, 0}};
+		int64_t tcount = -1, tsum = -1;
+		double mean = -1;
+		if (h.get_resp_level_stats(0x1003, 2, 10, tv, 2, tcount, tsum, mean) != 0 || tcount != 0 || tsum != 0 || tv[0].data_value != 1) return 15;
+		gys_listener_day_stats ds[10];
+		if (!h.listener_day_stats(10, 0, 10, ds)) return 16;
+		// service 9: nqrys_5s = 63 -> two QPS samples of 12 (SEMI_LOG_HASH_LO bucket ceiling 50); no active connections -> ceiling 1
+		if (ds[9].glob_id != 0x1009 || ds[9].tcount_5d != 0 || ds[9].p95_qps != 50 || ds[9].p95_nactive != 1) {
+			fprintf(stderr, "day stats: gid %llx p95_qps %u p95_nactive %u\n", (unsigned long long)ds[9].glob_id, ds[9].p95_qps, ds[9].p95_nactive);
+			return 17;
+		}
 	}
 	printf("shim ok\n");
 	return 0;
