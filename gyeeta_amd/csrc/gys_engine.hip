@@ -1618,21 +1618,11 @@ static double td_quantile_host(const int64_t *sum, const uint32_t *cnt, int32_t 
 	return std::floor(td_quantile_interp(sum, cnt, vmin, vmax, q) + 0.5);
 }
 
-int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t nq, double *out)
+// merged view of one service's digest = its clusters re-clustered with its buffered values (k_digest_merge in query mode: the state
+// is not modified)
+static int td_merged_view(gys_ctx *c, uint32_t slot, int64_t *sum, uint32_t *cnt, TdMeta *mt)
 {
-	if (!c || !q || !out) return GYS_ERR_INVAL;
-	if (!c->cfg.enable_tdigest) {
-		set_err("t-digest disabled");
-		return GYS_ERR_STATE;
-	}
-	uint32_t slot;
-	int rc = gys_lookup_service(c, glob_id, &slot);
-	if (rc) return rc;
-	// merged view = clusters re-clustered with the key's buffered values (k_digest_merge in query mode: state is not modified)
 	join_aux(c); // the last batch's merges may still be running (and still reading merge_list)
-	int64_t sum[GYS_TD_NB];
-	uint32_t cnt[GYS_TD_NB];
-	TdMeta mt;
 	const MergeEnt ent{slot, 0u, 0u, 0u};
 	HIPCHK(hipMemcpyAsync(c->merge_list, &ent, sizeof(ent), hipMemcpyHostToDevice, c->stream));
 	MergeP mp{};
@@ -1647,11 +1637,119 @@ int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t 
 	mp.out_cnt = c->query_cnt;
 	hipLaunchKernelGGL(k_digest_merge<128u>, dim3(1), dim3(64), 0, c->stream, mp);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpyAsync(sum, c->query_sum, sizeof(sum), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(cnt, c->query_cnt, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(&mt, c->td_meta + slot, sizeof(mt), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(sum, c->query_sum, sizeof(int64_t) * GYS_TD_NB, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(cnt, c->query_cnt, sizeof(uint32_t) * GYS_TD_NB, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(mt, c->td_meta + slot, sizeof(*mt), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+#define TDIGEST_CHECK()                         \
+	if (!c->cfg.enable_tdigest) {           \
+		set_err("t-digest disabled");   \
+		return GYS_ERR_STATE;           \
+	}
+
+int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t nq, double *out)
+{
+	if (!c || !q || !out) return GYS_ERR_INVAL;
+	TDIGEST_CHECK();
+	uint32_t slot;
+	int rc = gys_lookup_service(c, glob_id, &slot);
+	if (rc) return rc;
+	int64_t sum[GYS_TD_NB];
+	uint32_t cnt[GYS_TD_NB];
+	TdMeta mt;
+	rc = td_merged_view(c, slot, sum, cnt, &mt);
+	if (rc) return rc;
 	for (uint32_t i = 0; i < nq; ++i) out[i] = td_quantile_host(sum, cnt, mt.vmin, mt.vmax, q[i]);
+	return GYS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Postgres tdigest forms
+// The reference aggregates percentiles in SQL with the tdigest extension (tvondra/tdigest, not in /root/reference and unpinned:
+// "create extension if not exists tdigest" common/gy_query_common.cc:3387; public.tdigest(col, 100) / public.tdigest_percentile
+// :1818-1855, common/gy_json_field_maps.h:2641).  These two calls hand a service's digest over in that type's own external forms so
+// that '<text>'::public.tdigest (or the binary COPY / libpq form) can be fed to public.tdigest_percentile and unioned with row
+// digests.  Restated from the extension's published I/O functions (tdigest_out / tdigest_send, format with the TDIGEST_STORES_MEAN
+// flag, 1.2.0 and later); the extension is absent here => PARITY UNPINNED.
+//   text:   flags 1 count <N> compression 100 centroids <K> (<mean %lf>, <count>) ...      (means ascending)
+//   binary: int32 flags | int64 count | int32 compression | int32 ncentroids | K x { float8 mean, int64 count }, network byte order
+static int td_sql_centroids(gys_ctx *c, uint64_t glob_id, double *mean, int64_t *count, int *k, int64_t *total)
+{
+	uint32_t slot;
+	int rc = gys_lookup_service(c, glob_id, &slot);
+	if (rc) return rc;
+	int64_t sum[GYS_TD_NB];
+	uint32_t cnt[GYS_TD_NB];
+	TdMeta mt;
+	rc = td_merged_view(c, slot, sum, cnt, &mt);
+	if (rc) return rc;
+	*k = 0;
+	*total = 0;
+	for (int i = 0; i < GYS_TD_NB; ++i)
+		if (cnt[i]) {
+			mean[*k] = (double)sum[i] / (double)cnt[i];
+			count[*k] = (int64_t)cnt[i];
+			*total += (int64_t)cnt[i];
+			++*k;
+		}
+	if (*k == 0) { // tdigest_in rejects count <= 0: an empty digest has no literal (SQL NULL is the empty aggregate)
+		set_err("service %016llx has no response values yet", (unsigned long long)glob_id);
+		return GYS_ERR_NOTFOUND;
+	}
+	return GYS_OK;
+}
+
+int gys_tdigest_sql_text(gys_ctx *c, uint64_t glob_id, char *buf, size_t buflen, size_t *needed)
+{
+	if (!c || (!buf && buflen)) return GYS_ERR_INVAL;
+	TDIGEST_CHECK();
+	double mean[GYS_TD_NB];
+	int64_t count[GYS_TD_NB], total;
+	int k;
+	const int rc = td_sql_centroids(c, glob_id, mean, count, &k, &total);
+	if (rc) return rc;
+	std::string out;
+	char tmp[96];
+	snprintf(tmp, sizeof(tmp), "flags 1 count %lld compression %d centroids %d", (long long)total, GYS_TD_NB, k);
+	out = tmp;
+	for (int i = 0; i < k; ++i) {
+		snprintf(tmp, sizeof(tmp), " (%lf, %lld)", mean[i], (long long)count[i]);
+		out += tmp;
+	}
+	if (needed) *needed = out.size();
+	if (out.size() + 1 > buflen) return GYS_ERR_NOMEM;
+	memcpy(buf, out.c_str(), out.size() + 1);
+	return GYS_OK;
+}
+
+int gys_tdigest_sql_binary(gys_ctx *c, uint64_t glob_id, void *buf, size_t buflen, size_t *needed)
+{
+	if (!c || (!buf && buflen)) return GYS_ERR_INVAL;
+	TDIGEST_CHECK();
+	double mean[GYS_TD_NB];
+	int64_t count[GYS_TD_NB], total;
+	int k;
+	const int rc = td_sql_centroids(c, glob_id, mean, count, &k, &total);
+	if (rc) return rc;
+	const size_t len = 4 + 8 + 4 + 4 + (size_t)k * 16;
+	if (needed) *needed = len;
+	if (len > buflen) return GYS_ERR_NOMEM;
+	uint8_t *p = (uint8_t *)buf;
+	auto be = [&p](uint64_t v, int nbytes) { // pq_sendint32 / pq_sendint64 / pq_sendfloat8: big endian
+		for (int i = nbytes - 1; i >= 0; --i) *p++ = (uint8_t)(v >> (8 * i));
+	};
+	be(1u, 4);
+	be((uint64_t)total, 8);
+	be((uint64_t)GYS_TD_NB, 4);
+	be((uint64_t)k, 4);
+	for (int i = 0; i < k; ++i) {
+		uint64_t bits;
+		memcpy(&bits, &mean[i], 8);
+		be(bits, 8);
+		be((uint64_t)count[i], 8);
+	}
 	return GYS_OK;
 }
 

@@ -271,6 +271,25 @@ class SketchEngine:
         capi.check(self.L.gys_export_hist(self.h, which, first, n, C.c_void_p(out.ctypes.data)))
         return out
 
+    def tdigest_sql_text(self, glob_id):
+        """the service's digest as a literal of the Postgres tdigest type ('...'::public.tdigest)"""
+        need = C.c_size_t()
+        rc = self.L.gys_tdigest_sql_text(self.h, int(glob_id), None, 0, C.byref(need))
+        if rc != capi.ERR_NOMEM:
+            capi.check(rc)
+        buf = C.create_string_buffer(need.value + 1)
+        capi.check(self.L.gys_tdigest_sql_text(self.h, int(glob_id), buf, len(buf), C.byref(need)))
+        return buf.value.decode()
+
+    def tdigest_sql_binary(self, glob_id):
+        need = C.c_size_t()
+        rc = self.L.gys_tdigest_sql_binary(self.h, int(glob_id), None, 0, C.byref(need))
+        if rc != capi.ERR_NOMEM:
+            capi.check(rc)
+        buf = C.create_string_buffer(need.value)
+        capi.check(self.L.gys_tdigest_sql_binary(self.h, int(glob_id), buf, len(buf), C.byref(need)))
+        return buf.raw
+
     def export_hist_level(self, level, tusec, first=0, n=None):
         """records of one time level (0: last window, 1: 300 s, 2: 5 days, 3: all) as of tusec; same layout as export_hist"""
         n = self.num_services() - first if n is None else n

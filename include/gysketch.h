@@ -247,6 +247,17 @@ int gys_query_topn(gys_ctx *ctx, const uint8_t machine_id[16], int kind, gys_top
 int gys_scan_percentiles_dev(gys_ctx *ctx, int which, const float *pcts, uint32_t npct, int64_t *d_out);
 
 /* -------------------------------------------------------------------------------------------------------------------
+ * a service's response-time t-digest in the external forms of the Postgres tdigest type, so that the reference's SQL
+ * percentile aggregation -- public.tdigest(col, 100) / public.tdigest_percentile(digest, p), common/gy_query_common.cc:1818-1855,
+ * extension loaded at :3387 -- can consume engine digests ('<text>'::public.tdigest, or the binary send/recv form).
+ *   text:   "flags 1 count N compression 100 centroids K (mean, count) ..."     NUL terminated; *needed = strlen
+ *   binary: int32 flags, int64 count, int32 compression, int32 ncentroids, K x {float8 mean, int64 count}, network byte order
+ * The digest handed over is the merged view (clusters + still buffered values).  GYS_ERR_NOMEM when buflen is too small (*needed
+ * is set), GYS_ERR_NOTFOUND for a service without values (the type has no empty literal). */
+int gys_tdigest_sql_text(gys_ctx *ctx, uint64_t glob_id, char *buf, size_t buflen, size_t *needed);
+int gys_tdigest_sql_binary(gys_ctx *ctx, uint64_t glob_id, void *buf, size_t buflen, size_t *needed);
+
+/* -------------------------------------------------------------------------------------------------------------------
  * multi-level windows (gys_config.enable_levels).  Replaces the per-listener RESP_TIME_HISTOGRAM =
  * TIME_HISTOGRAM<RESP_TIME_HASH, Level_5s_5min_5days_all> (common/gy_statistics.h:1082-1551, :2067), i.e. folly::MultiLevelTimeSeries
  * per histogram bucket with 10 ring buckets per level, and the QPS_HISTOGRAM / ACTIVE_CONN_HISTOGRAM behind LISTENER_DAY_STATS
