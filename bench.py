@@ -310,7 +310,7 @@ def main():
             ingested.append([args.events, 0x67796565746121 + 1000 * rank + b, args.zipf_milli, buf_uses[b]])
         qerr = quantile_error(eng, torch, ingested, nlocal, args.svcs, [mine[0], mine[-1]], [0, nlocal - 1], wire)
     host_fed = None
-    if rank == 0 and not args.no_host_fed and nsvc:
+    if rank == 0 and world == 1 and not args.no_host_fed and nsvc:
         host_fed = host_fed_rate(eng, torch, min(args.events, 1 << 26), nlocal, args.svcs)
     if rank == 0:
         total_events = args.events * world * args.steps
@@ -346,7 +346,7 @@ def main():
             out["quantile_error"] = qerr
         if host_fed is not None:
             out["host_fed"] = host_fed
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N = 1 only
             full, honly, desc, ref_rate = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234)
             out["cpu_baseline"] = {"value": full, "unit": "events/s", "cores": 1, "kind": "port", "sample": desc,
                                    "histonly_value": honly}
@@ -359,6 +359,7 @@ def main():
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
+        dist.barrier()  # rank 0's untimed checks take longer than the other ranks' exit path: leave together
         dist.destroy_process_group()
 
 
