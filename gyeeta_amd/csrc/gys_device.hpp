@@ -98,6 +98,10 @@ __host__ __device__ __forceinline__ uint32_t jhash2_u64(uint64_t key, uint32_t i
 	return c;
 }
 
+// slot hash of the per-host listener sub-tables (an engine-internal structure: k_resp_host probes it once per event, so it is a
+// multiplicative hash -- one 64-bit multiply -- instead of the 36-instruction jhash mix; keys are (netns << 16 | port))
+__host__ __device__ __forceinline__ uint32_t host_tbl_hash(uint64_t key48) { return (uint32_t)((key48 * 0x9E3779B97F4A7C15ull) >> 32); }
+
 // ------------------------------------------------------------------------------------------------ bucket hashes
 struct HashDef {
 	int32_t nthr;

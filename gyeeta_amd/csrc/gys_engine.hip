@@ -351,7 +351,7 @@ int64_t host_tbl_find(const HostListeners &hl, uint64_t key48)
 {
 	if (hl.tbl.empty()) return -1;
 	const uint32_t mask = (uint32_t)hl.tbl.size() - 1;
-	uint32_t h = get_uint64_hash(key48) & mask;
+	uint32_t h = host_tbl_hash(key48) & mask;
 	for (uint32_t probes = 0; probes <= mask; ++probes) {
 		const uint64_t e = hl.tbl[h];
 		if (e == GYS_HOST_TBL_EMPTY) return -1;
@@ -364,7 +364,7 @@ int64_t host_tbl_find(const HostListeners &hl, uint64_t key48)
 void host_tbl_put(HostListeners &hl, uint64_t key48, uint32_t local)
 {
 	const uint32_t mask = (uint32_t)hl.tbl.size() - 1;
-	uint32_t h = get_uint64_hash(key48) & mask;
+	uint32_t h = host_tbl_hash(key48) & mask;
 	while (hl.tbl[h] != GYS_HOST_TBL_EMPTY) h = (h + 1) & mask;
 	hl.tbl[h] = (key48 << 16) | (uint64_t)local;
 }

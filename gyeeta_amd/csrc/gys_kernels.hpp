@@ -77,6 +77,26 @@ __device__ __forceinline__ uint64_t flow_hash64(uint32_t daddr, uint16_t dport, 
 	return hash64<10>(w, nw);
 }
 
+// Register index and rank of a response event's flow in the global HLL (== hll_idx_rank(flow_hash64(...), GYS_HLL_P)).  The index
+// and the first 18 rank bits come from the HIGH hash half alone; the low half (a second jhash2, ~75 instructions) can only matter
+// when those 18 bits are all zero, i.e. for one event in 2^18, so it is computed on that branch only.
+__device__ __forceinline__ void flow_hll_idx_rank(uint32_t daddr, uint16_t dport, uint32_t saddr, uint16_t sport, uint32_t *idx, uint32_t *rank)
+{
+	if (daddr != 0 && saddr != 0) {
+		const uint32_t hi = jhash2_4w(daddr, dport, saddr, sport, GYS_SEED);
+		const uint32_t rest = hi << GYS_HLL_P;
+		*idx = hi >> (32 - GYS_HLL_P);
+		if (rest) {
+			*rank = (uint32_t)__clz((int)rest) + 1u;
+			return;
+		}
+		const uint32_t lo = jhash2_4w(daddr, dport, saddr, sport, GYS_GOLDEN);
+		*rank = (32u - GYS_HLL_P) + (lo ? (uint32_t)__clz((int)lo) : 32u) + 1u;
+		return;
+	}
+	hll_idx_rank(flow_hash64(daddr, dport, saddr, sport), GYS_HLL_P, idx, rank);
+}
+
 // per-service distinct clients: same hash, per-service register file (u8 packed, CAS on the word)
 __device__ __forceinline__ void svc_hll_update(uint8_t *svc_hll, uint32_t svc_hll_p, uint32_t slot, uint64_t h64)
 {
@@ -97,11 +117,15 @@ __device__ __forceinline__ void svc_hll_update(uint8_t *svc_hll, uint32_t svc_hl
 __device__ __forceinline__ void hll_update_event(uint32_t *hll32, uint8_t *svc_hll, uint32_t svc_hll_p, uint32_t slot, uint32_t daddr, uint16_t dport,
 						 uint32_t saddr, uint16_t sport)
 {
-	const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
 	uint32_t idx, rank;
-	hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
+	if (svc_hll_p) { // the per-service registers need the whole 64-bit hash
+		const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
+		hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
+		svc_hll_update(svc_hll, svc_hll_p, slot, h64);
+	} else {
+		flow_hll_idx_rank(daddr, dport, saddr, sport, &idx, &rank);
+	}
 	if (hll32[idx] < rank) atomicMax(&hll32[idx], rank);
-	if (svc_hll_p) svc_hll_update(svc_hll, svc_hll_p, slot, h64);
 }
 
 struct RespP1 {
@@ -410,7 +434,7 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 				continue;
 			}
 			const uint64_t key48 = ((uint64_t)netns << 16) | (uint64_t)sport;
-			uint32_t h = get_uint64_hash(key48) & mask;
+			uint32_t h = host_tbl_hash(key48) & mask;
 			uint32_t local = GYS_NOSLOT;
 			for (uint32_t probes = 0; probes <= mask; ++probes) {
 				const uint64_t e = s_tbl[h];
@@ -426,10 +450,14 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 				continue;
 			}
 			kv[u] = ((uint64_t)local << 32) | GYS_STAGED_WORD(tresp, dport);
-			const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
-			hll_idx_rank(h64, GYS_HLL_P, &hidx[u], &hrank[u]);
+			if (p.svc_hll_p) { // the per-service registers need the whole 64-bit hash
+				const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
+				hll_idx_rank(h64, GYS_HLL_P, &hidx[u], &hrank[u]);
+				svc_hll_update(p.svc_hll, p.svc_hll_p, p.hlst[hd.lst_off + local], h64);
+			} else {
+				flow_hll_idx_rank(daddr, dport, saddr, sport, &hidx[u], &hrank[u]);
+			}
 			if (hrank[u] <= hll_floor) hrank[u] = 0; // cannot raise any register
-			if (p.svc_hll_p) svc_hll_update(p.svc_hll, p.svc_hll_p, p.hlst[hd.lst_off + local], h64);
 		}
 #pragma unroll
 		for (int u = 0; u < GYS_HOST_UNROLL; ++u) hcur[u] = hrank[u] ? p.hll32[hidx[u]] : 0xFFu; // read-first: most events do not raise the register
