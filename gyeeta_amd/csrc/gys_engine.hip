@@ -159,6 +159,7 @@ struct gys_ctx {
 	uint32_t *query_cnt = nullptr;
 	uint32_t *batch_cnt = nullptr, *batch_off = nullptr, *scan_block_sums = nullptr;
 	uint64_t *ev_kv = nullptr;
+	uint64_t ev_kv_cap = 0; // events
 	uint32_t *staged = nullptr, *staged2 = nullptr; // double-buffered: the merges of batch b read theirs while batch b+1 is staged
 	int staged_sel = 0;
 	// the window boundary's fixed sequence of copies / clears, captured once per registry shape as a hipGraph and replayed
@@ -503,7 +504,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hp.hll32 = c->hll32;
 		hp.batch_cnt = c->batch_cnt;
 		hp.off_end = c->batch_off;
-		hp.ev_kv = c->ev_kv;
+		hp.ev_w = (uint32_t *)c->ev_kv;                              // the 8-B-per-event scratch of the general pipeline holds the host-local
+		hp.ev_row = (uint8_t *)c->ev_kv + (size_t)c->ev_kv_cap * 4; // pipeline's 4-B words followed by its 1-B rows
 		hp.staged = staged_cur;
 		hp.huge_list = c->huge_list;
 		hp.huge_count = c->huge_count;
@@ -922,6 +924,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		ALLOC(c->batch_off, align_up(S, 16));
 		ALLOC(c->scan_block_sums, (S + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE + 1);
 		ALLOC(c->ev_kv, B);
+		c->ev_kv_cap = B;
 		ALLOC(c->staged, B);
 		ALLOC(c->staged2, B);
 		ALLOC(c->huge_list, std::min<uint64_t>(S, B / GYS_SMALL_MAX + 1));

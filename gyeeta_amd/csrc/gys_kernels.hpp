@@ -331,6 +331,9 @@ struct HostDesc {
 };
 
 #define GYS_HOST_TBL_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define GYS_EV_DROPPED 0xFFFFFFFFu                          // response ms field 0xFFFFF > 10^6: never a kept event
+#define GYS_EV_LOCAL(w) ((w) >> 20)
+#define GYS_EV_STAGED(w, row) ((((w) & 0xFFFFFu) << GYS_ROW_BITS) | (uint32_t)(row))
 #define GYS_HOST_THREADS 1024
 #define GYS_HOST_UNROLL 4
 #define GYS_HOST_TILE 8192u                                  // events per LDS scatter tile of a long segment
@@ -346,7 +349,9 @@ struct RespHostP {
 	const uint32_t *hlst;
 	uint32_t *hll32;
 	uint32_t *batch_cnt, *off_end;
-	uint64_t *ev_kv;        // per event: local index << 32 | staged word, ~0 = dropped (written and re-read by the same thread)
+	// per event, written in pass A and re-read in pass B by the same thread: 5 bytes instead of the event's 24 --
+	uint32_t *ev_w;         // local index << 20 | response ms (<= 10^6 < 2^20), GYS_EV_DROPPED = dropped
+	uint8_t *ev_row;        // CONN_BITMAP row (client port & 0x1F); only written for kept events
 	uint32_t *staged;
 	uint32_t *huge_list, *huge_count;
 	uint64_t *counters;
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 				w2[u] = p.ev[3 * i + 2];
 			}
 		}
-		uint64_t kv[GYS_HOST_UNROLL];
+		uint32_t kw[GYS_HOST_UNROLL], krow[GYS_HOST_UNROLL];
 		uint32_t hidx[GYS_HOST_UNROLL], hrank[GYS_HOST_UNROLL], hcur[GYS_HOST_UNROLL];
 #pragma unroll
 		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
@@ -425,7 +430,8 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 			const uint32_t netns = (uint32_t)w1[u];
 			const uint16_t sport = bswap16((uint16_t)(w1[u] >> 32)), dport = bswap16((uint16_t)(w1[u] >> 48)); // ntohs :1526-1527
 			const uint32_t tresp = (uint32_t)w2[u] - (uint32_t)(w2[u] >> 32); // lsndtime - lrcvtime (:1519)
-			kv[u] = ~0ull;
+			kw[u] = GYS_EV_DROPPED;
+			krow[u] = 0;
 			hrank[u] = 0;
 			hidx[u] = 0;
 			if (i >= e1) continue;
@@ -449,7 +455,8 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 				ndrop_nol++; // no such listener: the reference ignores the event too (:1671-1676 miss path)
 				continue;
 			}
-			kv[u] = ((uint64_t)local << 32) | GYS_STAGED_WORD(tresp, dport);
+			kw[u] = (local << 20) | tresp;
+			krow[u] = (uint32_t)dport & 0x1Fu;
 			if (p.svc_hll_p) { // the per-service registers need the whole 64-bit hash
 				const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
 				hll_idx_rank(h64, GYS_HLL_P, &hidx[u], &hrank[u]);
@@ -465,8 +472,11 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
 			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
 			if (hcur[u] < hrank[u]) atomicMax(&p.hll32[hidx[u]], hrank[u]);
-			if (kv[u] != ~0ull) atomicAdd(&s_cnt[(uint32_t)(kv[u] >> 32)], 1u);
-			if (i < e1) p.ev_kv[i] = kv[u];
+			if (kw[u] != GYS_EV_DROPPED) {
+				atomicAdd(&s_cnt[GYS_EV_LOCAL(kw[u])], 1u);
+				p.ev_row[i] = (uint8_t)krow[u];
+			}
+			if (i < e1) p.ev_w[i] = kw[u];
 		}
 	}
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
@@ -523,15 +533,20 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 		for (uint64_t t0 = e0; t0 < e1; t0 += GYS_HOST_TILE) {
 			for (uint32_t k = tid; k < L; k += GYS_HOST_THREADS) s_tcur[k] = 0;
 			__syncthreads();
-			uint64_t kvr[GYS_HOST_TILE_PER_THREAD];
+			uint32_t kwr[GYS_HOST_TILE_PER_THREAD], rowr[GYS_HOST_TILE_PER_THREAD];
 #pragma unroll
 			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u) {
 				const uint64_t i = t0 + tid + (uint64_t)u * GYS_HOST_THREADS;
-				kvr[u] = i < e1 ? p.ev_kv[i] : ~0ull;
+				kwr[u] = i < e1 ? p.ev_w[i] : GYS_EV_DROPPED;
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u) {
+				const uint64_t i = t0 + tid + (uint64_t)u * GYS_HOST_THREADS;
+				rowr[u] = kwr[u] != GYS_EV_DROPPED ? (uint32_t)p.ev_row[i] : 0u;
 			}
 #pragma unroll
 			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u)
-				if (kvr[u] != ~0ull) atomicAdd(&s_tcur[(uint32_t)(kvr[u] >> 32)], 1u);
+				if (kwr[u] != GYS_EV_DROPPED) atomicAdd(&s_tcur[GYS_EV_LOCAL(kwr[u])], 1u);
 			__syncthreads();
 			{ // exclusive scan of the tile counts -> run starts inside the image (s_tstart) and scatter cursors (s_tcur)
 				uint32_t sum = 0;
@@ -556,10 +571,10 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 			__syncthreads();
 #pragma unroll
 			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u) {
-				if (kvr[u] == ~0ull) continue;
-				const uint32_t local = (uint32_t)(kvr[u] >> 32);
+				if (kwr[u] == GYS_EV_DROPPED) continue;
+				const uint32_t local = GYS_EV_LOCAL(kwr[u]);
 				const uint32_t idx = atomicAdd(&s_tcur[local], 1u);
-				s_val[idx] = (uint32_t)kvr[u];
+				s_val[idx] = GYS_EV_STAGED(kwr[u], rowr[u]);
 				s_dest[idx] = s_cnt[local] + (idx - s_tstart[local]);
 			}
 			__syncthreads();
@@ -571,18 +586,24 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 		}
 	} else {
 		for (uint64_t base = e0 + tid; base < e1; base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
-			uint64_t kv[GYS_HOST_UNROLL];
+			uint32_t kw[GYS_HOST_UNROLL], krow[GYS_HOST_UNROLL];
 #pragma unroll
 			for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
 				const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
-				kv[u] = i < e1 ? p.ev_kv[i] : ~0ull;
+				kw[u] = i < e1 ? p.ev_w[i] : GYS_EV_DROPPED;
 			}
 #pragma unroll
 			for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
-				if (kv[u] == ~0ull) continue;
-				const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)(kv[u] >> 32)], 1u);
-				if (in_lds) s_region[pos] = (uint32_t)kv[u];
-				else p.staged[e0 + pos] = (uint32_t)kv[u];
+				const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
+				krow[u] = kw[u] != GYS_EV_DROPPED ? (uint32_t)p.ev_row[i] : 0u;
+			}
+#pragma unroll
+			for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
+				if (kw[u] == GYS_EV_DROPPED) continue;
+				const uint32_t pos = atomicAdd(&s_cnt[GYS_EV_LOCAL(kw[u])], 1u);
+				const uint32_t word = GYS_EV_STAGED(kw[u], krow[u]);
+				if (in_lds) s_region[pos] = word;
+				else p.staged[e0 + pos] = word;
 			}
 		}
 		if (in_lds) {
