@@ -138,7 +138,7 @@ struct gys_ctx {
 	std::vector<HostListeners> host_lst;
 	std::vector<uint32_t> host_seen; // batch stamp per host (duplicate-host detection in a multi-segment batch)
 	uint32_t batch_stamp = 0;
-	uint64_t n_batches_host_local = 0, n_batches_general = 0;
+	uint64_t n_batches_host_local = 0, n_batches_general = 0, n_batches_host_split = 0;
 	uint64_t htbl_used = 0, htbl_cap = 0, hlst_used = 0, hlst_cap = 0;
 	uint64_t *htbl = nullptr; // pool of per-host sub-tables
 	uint32_t *hlst = nullptr; // pool of per-host local index -> slot lists
@@ -190,7 +190,12 @@ struct gys_ctx {
 		gys_resp_seg *host = nullptr, *dev = nullptr;
 		uint32_t cap = 0;
 		hipEvent_t done = nullptr;
+		// split form of the host-local pipeline: [part descriptors as gys_resp_seg][SplitPart per part][SplitSeg per host segment]
+		uint8_t *xhost = nullptr, *xdev = nullptr;
+		uint64_t xcap = 0;
 	} seg_ring[GYS_SEG_RING];
+	uint32_t *split_cnt = nullptr; // count / cursor matrix of the split form (grow-only)
+	uint64_t split_cnt_cap = 0;
 	uint32_t seg_next = 0;
 
 	// reduce arena + last-window results
@@ -424,6 +429,83 @@ int host_lst_add(gys_ctx *c, uint32_t host, const gys_listener_info *arr, uint32
 	return host_lst_upload(c, host);
 }
 
+// split form of the host-local pipeline ("few hosts, long segments" in gys_kernels.hpp): part descriptors, count matrix, three launches
+int run_resp_split(gys_ctx *c, gys_ctx::SegSlot &slot, const gys_resp_seg *segs_host, uint32_t nsegs, uint64_t n, RespHostP hp, size_t dyn)
+{
+	uint64_t nparts = 0, ncnt = 0;
+	for (uint32_t s = 0; s < nsegs; ++s) {
+		const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - segs_host[s].first_event;
+		const uint64_t np = (len + GYS_SPLIT_PART - 1) / GYS_SPLIT_PART;
+		nparts += np;
+		ncnt += np * c->host_lst[segs_host[s].host_slot].slots.size();
+	}
+	const uint64_t off_parts = align_up(nparts * sizeof(gys_resp_seg), 16), off_segs = align_up(off_parts + nparts * sizeof(SplitPart), 16);
+	const uint64_t xbytes = off_segs + (uint64_t)nsegs * sizeof(SplitSeg);
+	if (xbytes > slot.xcap) {
+		if (slot.xhost) HIPCHK(hipHostFree(slot.xhost));
+		if (slot.xdev) HIPCHK(hipFree(slot.xdev));
+		slot.xhost = slot.xdev = nullptr;
+		slot.xcap = std::max<uint64_t>(xbytes, 1u << 16);
+		HIPCHK(hipHostMalloc((void **)&slot.xhost, slot.xcap, hipHostMallocDefault));
+		HIPCHK(hipMalloc((void **)&slot.xdev, slot.xcap));
+	}
+	if (ncnt + 1 > c->split_cnt_cap) {
+		HIPCHK(hipStreamSynchronize(c->stream)); // an earlier batch may still be using the old matrix
+		if (c->split_cnt) HIPCHK(hipFree(c->split_cnt));
+		c->split_cnt = nullptr;
+		c->split_cnt_cap = align_up(ncnt + 1, 1u << 16);
+		HIPCHK(hipMalloc((void **)&c->split_cnt, c->split_cnt_cap * 4));
+	}
+	gys_resp_seg *vseg = (gys_resp_seg *)slot.xhost;
+	SplitPart *parts = (SplitPart *)(slot.xhost + off_parts);
+	SplitSeg *rsegs = (SplitSeg *)(slot.xhost + off_segs);
+	uint64_t v = 0, cnt_off = 0;
+	for (uint32_t s = 0; s < nsegs; ++s) {
+		const uint64_t first = segs_host[s].first_event;
+		const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - first;
+		const uint32_t L = (uint32_t)c->host_lst[segs_host[s].host_slot].slots.size();
+		const uint64_t np = (len + GYS_SPLIT_PART - 1) / GYS_SPLIT_PART;
+		rsegs[s] = SplitSeg{first, segs_host[s].host_slot, (uint32_t)np, (uint32_t)cnt_off, 0u};
+		for (uint64_t q = 0; q < np; ++q, ++v) {
+			vseg[v] = gys_resp_seg{segs_host[s].host_slot, 0u, first + q * GYS_SPLIT_PART};
+			parts[v] = SplitPart{first, (uint32_t)cnt_off, 0u};
+			cnt_off += L;
+		}
+	}
+	if (cnt_off >= (1ull << 32)) {
+		set_err("split count matrix too large");
+		return GYS_ERR_INVAL;
+	}
+	HIPCHK(hipMemcpyAsync(slot.xdev, slot.xhost, xbytes, hipMemcpyHostToDevice, c->stream));
+	hp.segs = (const gys_resp_seg *)slot.xdev;
+	hp.nsegs = (uint32_t)nparts;
+	hp.parts = (const SplitPart *)(slot.xdev + off_parts);
+	hp.split_cnt = c->split_cnt;
+	{
+		ProfScope ps(c, "resp_host");
+		hipLaunchKernelGGL((k_resp_host<true, 1>), dim3((uint32_t)nparts), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+	}
+	{
+		ProfScope ps(c, "resp_split_scan");
+		SplitScanP sp{};
+		sp.segs = (const SplitSeg *)(slot.xdev + off_segs);
+		sp.hdesc = c->hdesc;
+		sp.hlst = c->hlst;
+		sp.split_cnt = c->split_cnt;
+		sp.batch_cnt = hp.batch_cnt;
+		sp.off_end = hp.off_end;
+		sp.huge_list = hp.huge_list;
+		sp.huge_count = hp.huge_count;
+		hipLaunchKernelGGL(k_split_scan, dim3(nsegs), dim3(GYS_HOST_THREADS), 0, c->stream, sp);
+	}
+	{
+		ProfScope ps(c, "resp_host_scatter");
+		hipLaunchKernelGGL((k_resp_host<true, 2>), dim3((uint32_t)nparts), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+	}
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
 // resp pipeline on a device-resident batch
 int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, const void *d_ev, uint64_t n)
 {
@@ -465,7 +547,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 
 	// ---- pipeline choice: host-local (one workgroup per host segment, LDS sub-table + LDS counting sort) when every segment is a
 	// distinct host with an LDS-sized listener table and the segments are small enough to balance; otherwise the general pipeline
-	bool host_local = td && c->cfg.resp_path != 1 && c->nsvc != 0;
+	bool host_local = td && c->cfg.resp_path != 1 && c->nsvc != 0, host_split = false;
 	uint32_t max_tbl = 16, max_l = 1;
 	uint64_t max_len = 0;
 	if (host_local) {
@@ -480,10 +562,14 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			max_tbl = std::max<uint32_t>(max_tbl, (uint32_t)hl.tbl.size());
 			max_l = std::max<uint32_t>(max_l, (uint32_t)hl.slots.size());
 		}
-		if (host_local && c->cfg.resp_path == 0) {
+		// split form (segments cut into parts of GYS_SPLIT_PART events, three launches): whole chip at ~30 G events/s whatever the
+		// number of hosts, but two passes more over the per-event records than the fused form
+		const double t_host = (double)((nsegs + c->ncu - 1) / c->ncu) * (double)max_len / 0.26e9;
+		const double t_split = (double)n / 30.0e9 + 40e-6;
+		if (host_local && max_len > GYS_SPLIT_PART && (c->cfg.resp_path == 3 || (c->cfg.resp_path == 0 && t_split < t_host))) host_split = true;
+		if (host_local && !host_split && c->cfg.resp_path == 0) {
 			// one workgroup walks a whole segment (~0.26 G events/s each, ncu of them at a time); the general pipeline spreads any
 			// batch over the whole chip at ~7 G events/s: take whichever model is faster, small batches always host-local
-			const double t_host = (double)((nsegs + c->ncu - 1) / c->ncu) * (double)max_len / 0.26e9;
 			const double t_general = (double)n / 7.0e9 + 20e-6;
 			host_local = max_len <= (1u << 15) || t_host <= t_general;
 		}
@@ -528,10 +614,17 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			}
 		}
 		const size_t dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_cnt_entries * 4 + (size_t)hp.lds_region_entries * 4;
-		ProfScope ps(c, "resp_host");
 		HIPCHK(hipMemsetAsync(c->huge_count, 0, 4, c->stream));
-		if (hp.lds_tile_events) hipLaunchKernelGGL(k_resp_host<true>, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
-		else hipLaunchKernelGGL(k_resp_host<false>, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+		if (host_split && hp.lds_tile_events) {
+			const int rcs = run_resp_split(c, slot, segs_host, nsegs, n, hp, dyn);
+			if (rcs) return rcs;
+			c->n_batches_host_local--;
+			c->n_batches_host_split++;
+		} else {
+			ProfScope ps(c, "resp_host");
+			if (hp.lds_tile_events) hipLaunchKernelGGL(k_resp_host<true>, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+			else hipLaunchKernelGGL(k_resp_host<false>, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+		}
 	} else {
 		c->n_batches_general++;
 		RespP1 p{};
@@ -902,6 +995,8 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	// k_resp_host: up to 8192 sub-table entries + 4096 counts (80 KiB) or, for the usual small tables, a scatter region (<= 150 KiB in all)
 	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
 	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
 	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_levels) {
@@ -983,6 +1078,8 @@ void gys_destroy(gys_ctx *c)
 	for (auto &sl : c->seg_ring) {
 		if (sl.host) hipHostFree(sl.host);
 		if (sl.dev) hipFree(sl.dev);
+		if (sl.xhost) hipHostFree(sl.xhost);
+		if (sl.xdev) hipFree(sl.xdev);
 		if (sl.done) hipEventDestroy(sl.done);
 	}
 	prof_resolve(c);
@@ -991,7 +1088,7 @@ void gys_destroy(gys_ctx *c)
 			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
-			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
+			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->split_cnt, c->lvl_snap, c->lvl_last, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	if (c->aux_stream) {
@@ -2008,6 +2105,7 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 	out->resp_batches_host_local = c->n_batches_host_local;
 	out->resp_batches_general = c->n_batches_general;
 	out->window_graph_launches = c->win_graph_launches;
+	out->resp_batches_host_split = c->n_batches_host_split;
 	return GYS_OK;
 }
 

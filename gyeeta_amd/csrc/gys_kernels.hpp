@@ -339,6 +339,26 @@ struct HostDesc {
 #define GYS_HOST_TILE 8192u                                  // events per LDS scatter tile of a long segment
 #define GYS_HOST_TILE_PER_THREAD (GYS_HOST_TILE / GYS_HOST_THREADS)
 
+// Few hosts, long segments (a small installation, or C1's single host): one workgroup per host segment would leave most of the chip
+// idle, so the segments are cut into PARTS of GYS_SPLIT_PART events and the pass runs in three launches instead of one:
+//   k_resp_host<.., 1>  one workgroup per part: resolve / filter / HLL / per-event records as usual, per-listener counts of the part
+//                       into its row of split_cnt
+//   k_split_scan        one workgroup per host: key run starts from the column sums, every part's row becomes its run cursors
+//   k_resp_host<.., 2>  one workgroup per part: scatter of the part's records through the LDS tile image, positions from its row
+// The result (staged runs per key, batch_cnt / off_end) is exactly what the fused form writes.
+#define GYS_SPLIT_PART 65536u
+struct SplitPart {
+	uint64_t real_first; // first event of the host's whole segment: staged positions are relative to it
+	uint32_t cnt_off;    // first entry of the part's row in split_cnt
+	uint32_t pad;
+};
+struct SplitSeg {
+	uint64_t first_event; // of the host's whole segment
+	uint32_t host_slot, nparts;
+	uint32_t cnt_off;     // row of part 0; the parts' rows follow each other, L entries each
+	uint32_t pad;
+};
+
 struct RespHostP {
 	const uint64_t *ev;
 	uint64_t n;
@@ -361,10 +381,14 @@ struct RespHostP {
 	uint32_t lds_cnt_entries; // LDS count area (largest listener count, even)
 	uint32_t lds_region_entries; // LDS scatter region of the launch (u32 entries, 0 = none): segments that fit are sorted there
 	uint32_t lds_tile_events;    // > 0: longer segments are scattered tile by tile through the region (2 x cnt + 2 x tile entries)
+	// split form (MODE 1 / 2): `segs` are PARTS of host segments, see "few hosts, long segments" below
+	const SplitPart *parts;
+	uint32_t *split_cnt;         // per part a row of the host's L counters: counts (MODE 1), then run cursors (k_split_scan), read by MODE 2
 };
 
 // TILED = true: the instantiation for launches with long segments (keeps a tile's records in registers: more VGPRs, one workgroup per CU)
-template <bool TILED>
+// MODE 0: the whole pass in one launch; 1 / 2: the two halves of the split form
+template <bool TILED, int MODE = 0>
 __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 {
 	extern __shared__ uint64_t s_dyn[];
@@ -381,6 +405,9 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	if (e1 <= e0) return;
 	const HostDesc hd = p.hdesc[seg.host_slot];
 	const uint32_t mask = hd.mask, L = hd.nlst;
+	// staged positions count from the first event of the HOST's segment (split form: the part's row holds cursors relative to it)
+	const uint64_t sbase = MODE == 0 ? e0 : p.parts[blockIdx.x].real_first;
+	if (MODE != 2) {
 	for (uint32_t i = tid; i <= mask; i += GYS_HOST_THREADS) s_tbl[i] = p.htbl[hd.tbl_off + i];
 	for (uint32_t i = tid; i < L; i += GYS_HOST_THREADS) s_cnt[i] = 0;
 	if (tid < 2) s_drop[tid] = 0;
@@ -482,9 +509,24 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
 	if (ndrop_nol) atomicAdd(&s_drop[1], ndrop_nol);
 	__syncthreads();
+	} // MODE != 2
+	if (MODE == 1) { // split form, first half: the part's per-listener counts go to its row; k_split_scan turns the rows into cursors
+		uint32_t *rowp = p.split_cnt + p.parts[blockIdx.x].cnt_off;
+		for (uint32_t k = tid; k < L; k += GYS_HOST_THREADS) rowp[k] = s_cnt[k];
+		if (tid == 0) {
+			atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
+			if (s_drop[0]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_RANGE], (unsigned long long)s_drop[0]);
+			if (s_drop[1]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_NOLISTENER], (unsigned long long)s_drop[1]);
+		}
+		return;
+	}
+	if (MODE == 2) { // split form, second half: run cursors of this part (relative to the host segment's start)
+		const uint32_t *rowp = p.split_cnt + p.parts[blockIdx.x].cnt_off;
+		for (uint32_t k = tid; k < L; k += GYS_HOST_THREADS) s_cnt[k] = rowp[k];
+	}
 
 	// ---- counts -> per-key run starts (exclusive scan over the local indices), per-key batch_cnt / off_end for the digest kernels
-	{
+	if (MODE == 0) {
 		const uint32_t K = (L + GYS_HOST_THREADS - 1) / GYS_HOST_THREADS;
 		const uint32_t lo = tid * K, hi = min(L, lo + K);
 		uint32_t sum = 0;
@@ -516,7 +558,8 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	// ---- pass B: scatter the staged words into the key runs (positions from LDS atomics).  A scattered 4-byte store that leaves L2
 	// before its line is complete becomes a read-modify-write in HBM, so when the segment's slice fits the LDS region the runs are
 	// assembled there and written out with coalesced full-line stores.
-	const bool tiled = TILED && p.lds_tile_events != 0 && (e1 - e0) > (uint64_t)p.lds_tile_events;
+	// (a part's key runs are not contiguous in `staged`: the split form always goes through the tile image)
+	const bool tiled = TILED && p.lds_tile_events != 0 && (MODE == 2 || (e1 - e0) > (uint64_t)p.lds_tile_events);
 	const bool in_lds = !tiled && (e1 - e0) <= (uint64_t)p.lds_region_entries;
 	if (tiled) {
 		// Long segment: the key runs are assembled tile by tile.  Per tile of GYS_HOST_TILE events: per-key counts of the tile (LDS), scan,
@@ -580,7 +623,7 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 			__syncthreads();
 			uint32_t ntile = 0; // valid words of the tile = end cursor of the last key = total (every thread computes it from the wave sums)
 			for (uint32_t w = 0; w < GYS_HOST_THREADS / 64; ++w) ntile += s_wsum[w];
-			for (uint32_t e = tid; e < ntile; e += GYS_HOST_THREADS) p.staged[e0 + s_dest[e]] = s_val[e];
+			for (uint32_t e = tid; e < ntile; e += GYS_HOST_THREADS) p.staged[sbase + s_dest[e]] = s_val[e];
 			for (uint32_t k = tid; k < L; k += GYS_HOST_THREADS) s_cnt[k] += s_tcur[k] - s_tstart[k];
 			__syncthreads();
 		}
@@ -612,10 +655,63 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 			for (uint32_t i = tid; i < nvalid; i += GYS_HOST_THREADS) p.staged[e0 + i] = s_region[i];
 		}
 	}
-	if (tid == 0) {
+	if (MODE == 0 && tid == 0) {
 		atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
 		if (s_drop[0]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_RANGE], (unsigned long long)s_drop[0]);
 		if (s_drop[1]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_NOLISTENER], (unsigned long long)s_drop[1]);
+	}
+}
+
+// split form, middle launch: one workgroup per host.  Column k of the host's count matrix (one row per part) sums to the key's run
+// length; an exclusive scan over the keys gives the run starts; every row entry becomes the position (relative to the host segment's
+// start) where that part's first value of the key goes.  Also the per-key batch_cnt / off_end / huge list, as the fused form writes them.
+struct SplitScanP {
+	const SplitSeg *segs;
+	const HostDesc *hdesc;
+	const uint32_t *hlst;
+	uint32_t *split_cnt;
+	uint32_t *batch_cnt, *off_end;
+	uint32_t *huge_list, *huge_count;
+};
+
+__global__ __launch_bounds__(GYS_HOST_THREADS) void k_split_scan(SplitScanP p)
+{
+	__shared__ uint32_t s_wsum[GYS_HOST_THREADS / 64];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const SplitSeg sg = p.segs[blockIdx.x];
+	const HostDesc hd = p.hdesc[sg.host_slot];
+	const uint32_t L = hd.nlst;
+	uint32_t *mat = p.split_cnt + sg.cnt_off;
+	const uint32_t K = (L + GYS_HOST_THREADS - 1) / GYS_HOST_THREADS;
+	const uint32_t lo = min(L, tid * K), hi = min(L, lo + K);
+	uint32_t sum = 0;
+	for (uint32_t k = lo; k < hi; ++k)
+		for (uint32_t q = 0; q < sg.nparts; ++q) sum += mat[(size_t)q * L + k];
+	uint32_t inc = sum;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t t = __shfl_up(inc, d, 64);
+		if ((int)lane >= d) inc += t;
+	}
+	if (lane == 63) s_wsum[wave] = inc;
+	__syncthreads();
+	uint32_t run = inc - sum;
+	for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
+	for (uint32_t k = lo; k < hi; ++k) {
+		uint32_t cur = run;
+		for (uint32_t q = 0; q < sg.nparts; ++q) {
+			const uint32_t c = mat[(size_t)q * L + k];
+			mat[(size_t)q * L + k] = cur;
+			cur += c;
+		}
+		const uint32_t c = cur - run;
+		if (c) {
+			const uint32_t slot = p.hlst[hd.lst_off + k];
+			p.batch_cnt[slot] = c;
+			p.off_end[slot] = (uint32_t)sg.first_event + cur;
+			if (c > GYS_SMALL_MAX) p.huge_list[atomicAdd(p.huge_count, 1u)] = slot;
+		}
+		run = cur;
 	}
 }
 

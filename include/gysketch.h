@@ -73,7 +73,8 @@ typedef struct {
 	uint32_t enable_tdigest;   /* per-service t-digest of response times */
 	uint32_t svc_hll_p;        /* per-service distinct-client HLL precision (0 = off, 4..10) */
 	uint32_t resp_path;        /* 0 = choose per batch; 1 = always the general (global table + atomics) pipeline; 2 = prefer the
-	                              host-local pipeline (LDS sub-table per host segment) whenever the batch qualifies */
+	                              host-local pipeline (LDS sub-table per host segment) whenever the batch qualifies; 3 = as 2, and
+	                              segments longer than 65536 events are cut into parts (split form: few hosts, long segments) */
 	uint64_t max_batch_events; /* largest resp-event batch one ingest call may carry (t-digest staging capacity) */
 	void *stream;              /* hipStream_t to run on; NULL = the context creates its own */
 	void *reduce_arena;        /* optional caller-owned DEVICE buffer for the all-reducible registers (e.g. a torch tensor so */
@@ -331,6 +332,7 @@ typedef struct {
 	uint64_t lstate_records, lstate_missed, lstate_errors, lstate_deleted;
 	uint64_t resp_batches_host_local, resp_batches_general; /* which resp pipeline each ingest call took (gys_config.resp_path) */
 	uint64_t window_graph_launches; /* window boundaries replayed from the captured hipGraph (0: plain stream operations were used) */
+	uint64_t resp_batches_host_split; /* host-local pipeline in its split form (few hosts, long segments: parts of 65536 events) */
 } gys_counters;
 int gys_get_counters(gys_ctx *ctx, gys_counters *out);
 

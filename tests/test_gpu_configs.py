@@ -135,11 +135,12 @@ def test_c3_full_size_properties(torch_mod):
 
 
 # ---------------------------------------------------------------------------------------------------------------- C1
-@pytest.mark.parametrize("resp_path", [0, 2], ids=["auto-general", "hostlocal-tiled"])
+@pytest.mark.parametrize("resp_path", [0, 1, 2, 3], ids=["auto-split", "general", "hostlocal-tiled", "hostlocal-split"])
 def test_c1_single_host_replay_bit_exact(torch_mod, oracle, resp_path):
     """ONE host, 100 services, a long replay (2^24 response events in one call, then 2^22 more): every key gets
-    ~10^5 values per call (k_digest_huge with buffered values joining the merge), the single segment is far longer than any LDS image
-    (general pipeline by the time model / tiled host-local pipeline when forced).  Everything bit-exact vs the C oracle."""
+    ~10^5 values per call (k_digest_huge with buffered values joining the merge), the single segment is far longer than any LDS image:
+    the split form of the host-local pipeline (256 / 64 parts of 65536 events; what the time model picks), the general pipeline and the
+    fused host-local pipeline with its tiled LDS image when forced.  Everything bit-exact vs the C oracle."""
     torch = torch_mod
     sp = 100
     eng = _engine(max_hosts=1, max_services=sp, max_batch_events=1 << 24, resp_path=resp_path)
@@ -153,7 +154,8 @@ def test_c1_single_host_replay_bit_exact(torch_mod, oracle, resp_path):
         orc.resp_batch(ev.cpu().numpy().tobytes(), [0], [0])
     eng.sync()
     c = eng.counters()
-    assert (c["resp_batches_general"] > 0) == (resp_path == 0) and (c["resp_batches_host_local"] > 0)  # the 5000-event call is always host-local
+    want = {0: (0, 1, 2), 1: (3, 0, 0), 2: (0, 3, 0), 3: (0, 1, 2)}[resp_path]  # (general, fused host-local, split); the 5000-event call is never split
+    assert (c["resp_batches_general"], c["resp_batches_host_local"], c["resp_batches_host_split"]) == want
     helpers.assert_hist_equal(eng.export_hist(0, 0, sp), orc.hist(), sp)
     assert (eng.export_conn_bitmap(0, sp) == orc.bitmap()).all()
     gs, gc, gm = eng.export_tdigest(0, sp)

@@ -352,6 +352,53 @@ def test_resp_windows_roll_lazily(torch_mod, oracle, resp_path):
     eng.close()
 
 
+def test_resp_split_form_few_hosts_long_segments(torch_mod, oracle):
+    """few hosts with long segments: the host-local pipeline in its split form (parts of 65536 events: per-part counts, per-host scan,
+    per-part scatter) must leave exactly what the fused form leaves -- every register vs the oracle over several batches and a window
+    roll; segment lengths straddle the part size (one part, just over one part, several parts with a short tail), one host has a
+    single listener, one batch is short enough to stay fused"""
+    rng = np.random.default_rng(91)
+    svc = {0: 37, 1: 1, 2: 200, 3: 64}
+    eng = _engine(max_hosts=4, max_services=512, max_batch_events=1 << 20, resp_path=3)
+    orc = oracle.OracleEngine(512)
+    info = {}
+    for h, sp in svc.items():
+        i, _ = helpers.register_world(eng, orc, [h], sp)
+        info.update(i)
+    plans = [
+        [(0, 200_000), (1, 65_537), (2, 30_000), (3, 65_536)],
+        [(2, 400_001), (0, 70_000)],
+        [(3, 10_000), (1, 20_000)],           # no segment longer than a part: fused form
+        [(1, 131_072), (3, 300_000), (0, 1)],
+    ]
+    for b, plan in enumerate(plans):
+        parts, seg_host, seg_first, pos = [], [], [], 0
+        for h, n in plan:
+            parts.append(helpers.make_resp_events(rng, h, n, svc[h], lat_mu=2.5 + 0.4 * b))
+            seg_host.append(info[h][1])
+            seg_first.append(pos)
+            pos += n
+        buf = helpers.concat_events(parts)
+        d = torch_mod.from_numpy(buf.view(np.uint8).copy()).cuda()
+        eng.order()
+        from gyeeta_amd import capi
+        segs = (capi.RespSeg * len(plan))()
+        for i in range(len(plan)):
+            segs[i].host_slot, segs[i].first_event = seg_host[i], seg_first[i]
+        eng.handle_resp_events_dev(segs, d.data_ptr(), pos)
+        eng.sync()
+        orc.resp_batch(buf.tobytes(), seg_host, seg_first)
+        _compare_all(eng, orc, oracle)
+        if b == 1:
+            eng.window_close()
+            _compare_window(eng, orc)
+            orc.window_clear(clear_hist=True)  # _compare_all looks at the window view
+    c = eng.counters()
+    assert (c["resp_batches_host_split"], c["resp_batches_host_local"], c["resp_batches_general"]) == (3, 1, 0)
+    assert c["resp_events"] == orc.counters()["events"] and c["resp_dropped_nolistener"] == orc.counters()["dropped_nolistener"]
+    eng.close()
+
+
 @PATHS
 def test_resp_ragged_segments_and_bad_arguments(torch_mod, oracle, resp_path):
     """multi-host device batches with empty segments (first, middle, last), a host without events, a batch of zero events, and the
