@@ -37,9 +37,28 @@ template <typename T, typename CT = LegacyStatsClock<std::chrono::seconds>> clas
 template <typename T, typename H, typename CT = LegacyStatsClock<std::chrono::seconds>, typename C = MultiLevelTimeSeries<T, CT>> class TimeseriesSlabHistogram;
 }
 EOF
+# thirdparty/SlabHistogramBucket.h (the in-tree, modified folly histogram-bucket container whose getPercentileBucketIdx is the
+# percentile rule of TIME_HISTOGRAM::get_stats) is compiled where it lies; it only wants two folly headers for SCOPE_EXIT and
+# glog's CHECK macros, stubbed here
+mkdir -p "$T/folly"
+: > "$T/folly/Conv.h"
+cat > "$T/folly/ScopeGuard.h" <<'EOF'
+#pragma once
+#include <utility>
+namespace gy_stub {
+template <class F> struct ScopeExit { F f; ~ScopeExit() { f(); } };
+struct ScopeExitTag {};
+template <class F> ScopeExit<F> operator+(ScopeExitTag, F &&f) { return ScopeExit<F>{std::forward<F>(f)}; }
+}
+#define GY_STUB_CAT2(a, b) a##b
+#define GY_STUB_CAT(a, b) GY_STUB_CAT2(a, b)
+#define SCOPE_EXIT auto GY_STUB_CAT(gy_stub_scope_exit_, __LINE__) = gy_stub::ScopeExitTag{} + [&]()
+#define CHECK_GE(a, b) ((void)0)
+#define CHECK_LE(a, b) ((void)0)
+EOF
 # the forced includes paper over gcc-8 era transitive-include assumptions in gy_common_inc.h
 g++ -std=c++17 -O2 -D_GNU_SOURCE -DNDEBUG -pthread -fno-strict-aliasing -fPIC -shared -w \
 	-include string -include string_view -include optional -include vector -include algorithm -include functional \
 	-include chrono -include array -include tuple -include utility \
-	-I"$T" -I"$REF/common" "$HERE/ref_glue.cc" -o "$OUT/libgyref.so"
+	-I"$T" -I"$REF/common" -I"$REF/thirdparty" "$HERE/ref_glue.cc" -o "$OUT/libgyref.so"
 echo "built $OUT/libgyref.so"

@@ -2,7 +2,8 @@
  * TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's multi-level ("Last 5 seconds / 5 minutes / 5 days / since
  * start") response histogram: TIME_HISTOGRAM<RESP_TIME_HASH, Level_5s_5min_5days_all> (common/gy_statistics.h:1082-1551, :2067).
  *
- * PARITY UNPINNED.  The arithmetic of that class lives in a third-party dependency that is absent from /root/reference:
+ * PARITY UNPINNED for the ring arithmetic; the percentile rule IS pinned (see the end of this comment).  The arithmetic of that class
+ * lives in a third-party dependency that is absent from /root/reference:
  * facebook/folly (version unpinned -- Makefile.common:61 only names an install directory), folly/stats/BucketedTimeSeries{.h,-inl.h}
  * and folly/stats/MultiLevelTimeSeries{.h,-inl.h}; the reference's only test at this boundary (test/test_timeseries_hist.cc)
  * prints and asserts nothing.  What follows restates folly's published algorithm directly (a ring of per-bucket {sum, count}
@@ -13,6 +14,9 @@
  *   read         gy_statistics.h:1166-1200  get_level_data(): levelobj.sum() / levelobj.count()
  *                gy_statistics.h:1333-1367  get_stats(): get_bucket_max_threshold(slabhist.getPercentileBucketIdx(pct, level))
  *   percentile   thirdparty/SlabHistogramBucket.h:165-240 (in tree) getPercentileBucketIdx
+ * Pinned part: gyo_slab_percentile_idx and the bucket numbering are checked against the reference's OWN in-tree container
+ * (thirdparty/SlabHistogramBucket.h compiled into oracle/_ref: tests/test_oracle_vs_ref.py::test_slab_percentile_rule_vs_reference_container,
+ * golden vectors "slab" in tests/golden/ref_vectors.json).
  * The engine does NOT keep such rings (it keeps cumulative snapshots at bucket boundaries and answers a level as a difference,
  * DESIGN.md "multi-level windows"), so agreement between the two is a real check of both.
  */

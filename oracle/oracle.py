@@ -222,6 +222,10 @@ def ref():
     _sig(R, "ref_ns_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, C.c_uint64, C.c_int])
     _sig(R, "ref_pair_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, u8p, C.c_int, C.c_uint16])
     _sig(R, "ref_machine_id_hash", C.c_uint32, [C.c_uint64, C.c_uint64])
+    if hasattr(R, "ref_slab_percentile_idx"):
+        _sig(R, "ref_slab_num_buckets", C.c_size_t, [])
+        _sig(R, "ref_slab_bucket_idx", C.c_size_t, [C.c_int64])
+        _sig(R, "ref_slab_percentile_idx", C.c_size_t, [u64p, C.c_size_t, C.c_double])
     _sig(R, "ref_sizeof", C.c_size_t, [C.c_int])
     _sig(R, "ref_ip_port_bytes", None, [u8p, C.c_int, C.c_uint16, u8p])
     _sig(R, "ref_hist_new", C.c_void_p, [C.c_int])

@@ -19,11 +19,14 @@
 //   common/gy_statistics.h:455-894       HIST_SERIAL, GY_HISTOGRAM (add_data, add_histogram, get_percentiles ...)
 //   common/gy_statistics.h:1565-2063     bucket-hash classes
 //   common/gy_statistics.h:28-453        BOUNDED_PRIO_QUEUE
+//   thirdparty/SlabHistogramBucket.h:70-78, :165-240   SlabHistogramBuckets::getBucketIdx / getPercentileBucketIdx, constructed the
+//                                        way TIME_HISTOGRAM constructs its slab histogram (common/gy_statistics.h:1106-1108)
 #include <thread>
 #include <unordered_map>
 #include "gy_common_inc.h"
 #include "gy_statistics.h"
 #include "gy_inet_inc.h"
+#include "SlabHistogramBucket.h" // thirdparty/ (in tree): folly::detail::SlabHistogramBuckets, the container behind TimeseriesSlabHistogram
 
 namespace gyeeta {
 // originals: common/gy_file_api.cc:60-63 (that TU needs the full build, so the three globals are defined here)
@@ -301,4 +304,23 @@ uint64_t ref_keyed_resp_batch_mt(void *p, const uint8_t *ev24, uint64_t n, const
 	return tot;
 }
 uint64_t ref_keyed_total(void *p, uint32_t idx) { return static_cast<RefKeyed *>(p)->hist[idx].get_total_count(); }
+
+// the slab-histogram bucket container of TIME_HISTOGRAM<RESP_TIME_HASH, ...>, with a bare counter as the bucket type
+struct SlabCount {
+	uint64_t count = 0;
+};
+using RespSlab = folly::detail::SlabHistogramBuckets<int64_t, SlabCount, RESP_TIME_HASH>;
+static RespSlab make_resp_slab()
+{
+	return RespSlab(RESP_TIME_HASH::max_buckets - 2, RESP_TIME_HASH::get_threshold_array(), RESP_TIME_HASH::min_value, RESP_TIME_HASH::max_value, SlabCount());
+}
+size_t ref_slab_num_buckets(void) { return make_resp_slab().getNumBuckets(); }
+size_t ref_slab_bucket_idx(int64_t value) { return make_resp_slab().getBucketIdx(value); }
+// counts[nb] with nb == ref_slab_num_buckets(); pct in [0, 1] (TimeseriesSlabHistogram::getPercentileBucketIdx passes pct / 100.0)
+size_t ref_slab_percentile_idx(const uint64_t *counts, size_t nb, double pct)
+{
+	RespSlab b = make_resp_slab();
+	for (size_t i = 0; i < nb && i < b.getNumBuckets(); ++i) b.getByIndex(i).count = counts[i];
+	return b.getPercentileBucketIdx(pct, [](const SlabCount &x) { return x.count; });
+}
 }  // extern "C"

@@ -124,6 +124,30 @@ ipb6, _ = o.ip_bytes(ip6)
 R.ref_ip_port_bytes(ipb6, 1, 443, buf)
 g["ip_port_layout_v6"] = bytes(buf).hex()
 
+# thirdparty/SlabHistogramBucket.h (in tree): bucket numbering + percentile rule of the time levels (TIME_HISTOGRAM::get_stats).
+# Drawn last so that the vectors above keep their values.
+g["slab"] = {"nbuckets": R.ref_slab_num_buckets(), "bucket_idx": [], "percentile_idx": []}
+for v in [-3, -1, 0, 1, 2, 10, 11, 30, 31, 59, 60, 61, 700, 701, 1000, 1001, 3000, 3001, 14999, 15000, 15001, 10**6, 2**40, -2**40] + \
+        rng.integers(-10, 20000, 40).tolist():
+    g["slab"]["bucket_idx"].append({"value": int(v), "idx": R.ref_slab_bucket_idx(int(v))})
+for trial in range(60):
+    kind = trial % 4
+    if kind == 0:
+        counts = rng.integers(0, 1000, 15)
+    elif kind == 1:
+        counts = rng.integers(0, 3, 15) * rng.integers(0, 10**6, 15)
+    elif kind == 2:
+        counts = np.zeros(15, dtype=np.int64)
+        counts[rng.integers(0, 15)] = rng.integers(1, 10**9)
+    else:
+        counts = rng.integers(0, 2**40, 15)
+    if trial == 59:
+        counts = np.zeros(15, dtype=np.int64)  # empty histogram -> bucket 1
+    counts = counts.astype(np.uint64)
+    for pct in [0.0, 0.25, 0.5, 0.95, 0.99, 0.9999, 1.0] + rng.random(3).tolist():
+        g["slab"]["percentile_idx"].append({"counts": counts.tolist(), "pct": float(pct),
+                                            "idx": R.ref_slab_percentile_idx(o.ptr(counts, o.u64p), 15, float(pct))})
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_vectors.json")
 json.dump(g, open(out, "w"))
 print("wrote", out, os.path.getsize(out), "bytes")

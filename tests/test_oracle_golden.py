@@ -124,3 +124,10 @@ def test_golden_fixture(oracle):
         out = np.zeros(rec["n"], dtype=np.uint64)
         k = L.gyo_topn_u64(oracle.ptr(v, oracle.u64p), len(v), rec["n"], oracle.ptr(out, oracle.u64p))
         assert out[:k].tolist() == rec["top"]
+    # time levels: bucket numbering and percentile rule of the reference's in-tree slab-histogram container
+    assert g["slab"]["nbuckets"] == L.gyo_hist_nbuckets(oracle.RESP_TIME_HASH)
+    for rec in g["slab"]["bucket_idx"]:
+        assert L.gyo_bucket(oracle.RESP_TIME_HASH, rec["value"]) == rec["idx"]
+    for rec in g["slab"]["percentile_idx"]:
+        c = np.array(rec["counts"], dtype=np.uint64)
+        assert L.gyo_slab_percentile_idx(oracle.ptr(c, oracle.u64p), len(c), rec["pct"]) == rec["idx"]

@@ -181,3 +181,37 @@ def test_keyed_resp_loop_of_the_reference_classes_matches_the_port(oracle):
         assert a2 == a1
         assert [R.ref_keyed_total(k, i) for i in range(18)] == orc.hist()[:18, 15, 0].tolist()
     R.ref_keyed_free(k)
+
+
+def test_slab_percentile_rule_vs_reference_container(reflib, oracle):
+    """TIME_HISTOGRAM::get_stats ranks with folly::detail::SlabHistogramBuckets::getPercentileBucketIdx -- the reference's OWN in-tree
+    copy (thirdparty/SlabHistogramBucket.h:165-240), compiled here and constructed as TIME_HISTOGRAM constructs it
+    (common/gy_statistics.h:1106-1108).  The oracle's (and the engine's) percentile rule and bucket numbering for the time levels are
+    pinned against it; what stays unpinned of the multi-level windows is folly's ring arithmetic alone."""
+    R, L = reflib, oracle.lib()
+    if not hasattr(R, "ref_slab_percentile_idx"):
+        pytest.skip("oracle/_ref built without the slab container")
+    assert R.ref_slab_num_buckets() == 15 == L.gyo_hist_nbuckets(oracle.RESP_TIME_HASH)
+    rng = np.random.default_rng(2024)
+    vals = np.concatenate([np.arange(-3, 40), [59, 60, 61, 999, 1000, 1001, 14999, 15000, 15001, 10**6, 2**40, -2**40],
+                           rng.integers(-10, 20000, 2000)])
+    for v in vals:
+        assert R.ref_slab_bucket_idx(int(v)) == L.gyo_bucket(oracle.RESP_TIME_HASH, int(v)), v
+    pcts = [0.0, 1e-9, 0.001, 0.25, 0.5, 0.75, 0.95, 0.99, 0.999, 0.9999, 1.0]
+    for trial in range(400):
+        kind = trial % 4
+        if kind == 0:
+            counts = rng.integers(0, 1000, 15)
+        elif kind == 1:
+            counts = rng.integers(0, 3, 15) * rng.integers(0, 10**6, 15)      # many empty buckets
+        elif kind == 2:
+            counts = np.zeros(15, dtype=np.int64)
+            counts[rng.integers(0, 15)] = rng.integers(1, 10**9)              # a single bucket
+        else:
+            counts = rng.integers(0, 2**40, 15)                               # counts beyond 2^32: double rounding of the fractions
+        counts = counts.astype(np.uint64)
+        for pct in pcts + rng.random(5).tolist():
+            want = R.ref_slab_percentile_idx(oracle.ptr(counts, oracle.u64p), 15, float(pct))
+            assert L.gyo_slab_percentile_idx(oracle.ptr(counts, oracle.u64p), 15, float(pct)) == want, (counts.tolist(), pct)
+    empty = np.zeros(15, dtype=np.uint64)
+    assert R.ref_slab_percentile_idx(oracle.ptr(empty, oracle.u64p), 15, 0.95) == 1 == L.gyo_slab_percentile_idx(oracle.ptr(empty, oracle.u64p), 15, 0.95)
