@@ -1,6 +1,6 @@
 #!/bin/bash
 # TEST INFRASTRUCTURE ONLY.
-# Builds oracle/_ref/libgyref.so: the reference's OWN GY_HISTOGRAM / bucket-hash / jhash / IP_PORT code compiled from the
+# Builds oracle/_ref/libgyref.so: the reference's OWN GY_HISTOGRAM / bucket-hash / jhash / IP_PORT / wire-struct code compiled from the
 # sources where they lie under /root/reference (SURVEY.md 8c recipe).  The reference's build system is not run (it needs
 # folly, liburcu, boost ... none of which exist here); only header-only code that is self-contained is used.
 #
@@ -56,9 +56,30 @@ template <class F> ScopeExit<F> operator+(ScopeExitTag, F &&f) { return ScopeExi
 #define CHECK_GE(a, b) ((void)0)
 #define CHECK_LE(a, b) ((void)0)
 EOF
+# the wire structs and their validators (common/gy_comm_proto.h / .cc) compile once gy_sys_hardware.h -- which drags in libmnl,
+# folly and boost for things the wire structs do not use -- is replaced by a stand-in that only declares the 16-byte GY_MACHINE_ID
+# (layout of common/gy_sys_hardware.h:20-24: one std::pair<uint64_t, uint64_t>)
+cp "$REF/common/gy_comm_proto.h" "$REF/common/gy_comm_proto.cc" "$T/"
+cat > "$T/gy_sys_hardware.h" <<'EOF'
+#pragma once
+#include "gy_common_inc.h"
+#include "jhash.h"
+namespace gyeeta {
+class GY_MACHINE_ID {
+public:
+	std::pair<uint64_t, uint64_t> machid_ {};
+	GY_MACHINE_ID() noexcept = default;
+	GY_MACHINE_ID(uint64_t hi, uint64_t lo) noexcept : machid_(hi, lo) {}
+	uint64_t get_first() const noexcept { return machid_.first; }
+	uint64_t get_second() const noexcept { return machid_.second; }
+	uint32_t get_hash() const noexcept { return jhash2((uint32_t *)&machid_, sizeof(machid_) / sizeof(uint32_t), 0xceedfead); }
+	bool operator==(const GY_MACHINE_ID &o) const noexcept { return machid_ == o.machid_; }
+};
+}
+EOF
 # the forced includes paper over gcc-8 era transitive-include assumptions in gy_common_inc.h
-g++ -std=c++17 -O2 -D_GNU_SOURCE -DNDEBUG -pthread -fno-strict-aliasing -fPIC -shared -w \
+g++ -std=c++17 -O2 -D_GNU_SOURCE -DNDEBUG -DTASK_COMM_LEN=16 -pthread -fno-strict-aliasing -fPIC -shared -w \
 	-include string -include string_view -include optional -include vector -include algorithm -include functional \
 	-include chrono -include array -include tuple -include utility \
-	-I"$T" -I"$REF/common" -I"$REF/thirdparty" "$HERE/ref_glue.cc" -o "$OUT/libgyref.so"
+	-I"$T" -I"$REF/common" -I"$REF/thirdparty" "$HERE/ref_glue.cc" "$T/gy_comm_proto.cc" -o "$OUT/libgyref.so"
 echo "built $OUT/libgyref.so"

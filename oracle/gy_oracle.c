@@ -767,6 +767,54 @@ uint32_t gyo_listener_state_elem_size(const uint8_t *rec) { return GYO_LISTENER_
 /* TCP_CONN_NOTIFY::get_elem_size common/gy_comm_proto.h:1721-1724: 280 + cli_cmdline_len_ + padding_len_ */
 uint32_t gyo_tcp_conn_elem_size(const uint8_t *rec) { return GYO_TCP_CONN_NOTIFY_SZ + rd_u16(rec + 272) + rec[279]; }
 
+/* ---------------------------------------------------------------- wire framing: L1 validation of a partha -> madhava message
+ * COMM_HEADER (16 B: magic_, total_sz_, data_type_, padding_sz_) + EVENT_NOTIFY (8 B: subtype_, nevents_) + records
+ * (common/gy_comm_proto.h:336-420, :486-500).  PINNED: tests/test_wire.py runs these against the reference's own validators
+ * (common/gy_comm_proto.cc compiled into oracle/_ref). */
+#define GYO_PM_HDR_MAGIC 0x05666605u
+#define GYO_COMM_EVENT_NOTIFY 14u
+#define GYO_COMM_MIN_TYPE 1u
+#define GYO_COMM_MAX_TYPE 18u
+#define GYO_MAX_COMM_DATA_SZ (16u << 20)
+
+/* COMM_HEADER::validate (common/gy_comm_proto.cc:10-57) for the message types the engine looks into (EVENT_NOTIFY); any other
+ * in-range data_type_ is only checked for the generic header rules (the engine skips those messages) */
+int gyo_comm_header_validate(const uint8_t *msg, uint32_t req_magic)
+{
+	const uint32_t magic = rd_u32(msg), total_sz = rd_u32(msg + 4), data_type = rd_u32(msg + 8), padding_sz = rd_u32(msg + 12);
+	if (!(magic == req_magic && total_sz < GYO_MAX_COMM_DATA_SZ && total_sz >= 16 && padding_sz < 8 && data_type > GYO_COMM_MIN_TYPE &&
+	      data_type < GYO_COMM_MAX_TYPE))
+		return 0;
+	if (total_sz & 7u) return 0;
+	if (((uintptr_t)msg) & 7u) return 0; /* "We will terminate connections resulting in unaligned accesses" */
+	if (data_type == GYO_COMM_EVENT_NOTIFY) return (total_sz - padding_sz) >= 16 + 8;
+	return 1;
+}
+
+/* TCP_CONN_NOTIFY::validate (:840-881) / LISTENER_STATE_NOTIFY::validate (:955-996): nevents_ records of get_elem_size() bytes,
+ * each a multiple of 8, inside the message's actual length */
+static int chain_validate(const uint8_t *msg, uint32_t fixed, uint32_t max_elems, uint32_t (*elem_size)(const uint8_t *))
+{
+	const int64_t act = (int64_t)rd_u32(msg + 4) - (int64_t)rd_u32(msg + 12);
+	if (act < 16 + 8) return 0;
+	const uint32_t nelems = rd_u32(msg + 20);
+	if (nelems > max_elems) return 0;
+	int64_t totallen = act - (16 + 8);
+	const uint8_t *p = msg + 24;
+	uint32_t i;
+	for (i = 0; i < nelems && totallen >= (int64_t)fixed; ++i) {
+		const int64_t sz = (int64_t)elem_size(p);
+		if (totallen < sz) return 0;
+		if (sz & 7) return 0; /* "Padding issue" */
+		totallen -= sz;
+		p += sz;
+	}
+	return i == nelems;
+}
+
+int gyo_tcp_conn_validate(const uint8_t *msg) { return chain_validate(msg, GYO_TCP_CONN_NOTIFY_SZ, 2048u, gyo_tcp_conn_elem_size); }
+int gyo_listener_state_validate(const uint8_t *msg) { return chain_validate(msg, GYO_LISTENER_STATE_NOTIFY_SZ, 512u, gyo_listener_state_elem_size); }
+
 /* partha_listener_state loop server/gy_mconnhdlr.cc:11175-11256 + LISTEN_SUMM_STATS::update server/gy_msocket.h:853-865.
  * Records flagged LISTEN_FLAG_DELETE (0xC0, gy_comm_proto.h:2180) are skipped before the update (:11194-11248). */
 int gyo_listener_state_rollup(const uint8_t *batch, int nrec, const uint8_t *pend, gyo_listen_summ_stats *summ, int *nerrors)

@@ -9,8 +9,12 @@
  * Pinning status:
  *   - jhash / key hashes / bucket hashes / GY_HISTOGRAM arithmetic: PINNED against test/test_histogram.cc:28-147 asserts,
  *     the SURVEY 8c KATs and against oracle/_ref (the reference's own headers compiled here) in tests/test_oracle_vs_ref.py.
- *   - LISTEN_SUMM_STATS / STATE_ONE sums: restated from server/gy_msocket.h:840-882, common/gy_comm_proto.h:3181-3210;
- *     those headers are unbuildable here (folly/liburcu) -> structural restatement, parity unpinned beyond layout sizes.
+ *   - wire structs + L1 validators (COMM_HEADER, EVENT_NOTIFY, TCP_CONN_NOTIFY, LISTENER_STATE_NOTIFY, LISTENER_DAY_STATS member
+ *     offsets, get_elem_size, COMM_HEADER / TCP_CONN_NOTIFY / LISTENER_STATE_NOTIFY::validate) and MS_CLUSTER_STATE::STATE_ONE::add_stats:
+ *     PINNED against common/gy_comm_proto.h / .cc compiled into oracle/_ref (gy_sys_hardware.h replaced by a 16-byte GY_MACHINE_ID
+ *     stand-in, oracle/build_ref.sh): tests/test_wire.py, tests/test_oracle_vs_ref.py.
+ *   - LISTEN_SUMM_STATS<int>::update (server/gy_msocket.h:840-882) and CLUSTER_STATE_ONE::update_from_state
+ *     (server/gy_mconnhdlr.cc:16032-16050) live in server/ headers that need folly/liburcu/boost -> structural restatement, unpinned.
  *   - HLL / CMS / t-digest: builder-defined (no reference implementation exists) -> "parity unpinned" vs reference; the
  *     acceptance test against reference behaviour is rank error vs exact sort + bucket agreement with GY_HISTOGRAM.
  */
@@ -178,6 +182,11 @@ typedef struct {
 int gyo_listener_state_rollup(const uint8_t *batch, int nrec, const uint8_t *pend, gyo_listen_summ_stats *summ, int *nerrors);
 uint32_t gyo_listener_state_elem_size(const uint8_t *rec);
 uint32_t gyo_tcp_conn_elem_size(const uint8_t *rec);
+/* L1 validation of one partha -> madhava message (msg = COMM_HEADER, 8-byte aligned): COMM_HEADER::validate, TCP_CONN_NOTIFY::validate,
+ * LISTENER_STATE_NOTIFY::validate (common/gy_comm_proto.cc:10-57, :840-881, :955-996).  1 = valid */
+int gyo_comm_header_validate(const uint8_t *msg, uint32_t req_magic);
+int gyo_tcp_conn_validate(const uint8_t *msg);
+int gyo_listener_state_validate(const uint8_t *msg);
 /* walk a TCP_CONN_NOTIFY batch (gy_mconnhdlr.cc:9130) producing for each record the PAIR_IP_PORT(nat_cli_, nat_ser_) key words
  * (gy_mconnhdlr.cc:8707), ser_glob_id_, bytes_sent_, bytes_rcvd_; returns number of records walked */
 int gyo_tcp_conn_decode(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *keywords /*[nrec*10]*/, uint32_t *nwords,

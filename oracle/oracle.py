@@ -166,6 +166,9 @@ def lib():
     _sig(L, "gyo_listener_state_rollup", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(ListenSummStats), C.POINTER(C.c_int)])
     _sig(L, "gyo_listener_state_elem_size", C.c_uint32, [C.c_void_p])
     _sig(L, "gyo_tcp_conn_elem_size", C.c_uint32, [C.c_void_p])
+    _sig(L, "gyo_comm_header_validate", C.c_int, [C.c_void_p, C.c_uint32])
+    _sig(L, "gyo_tcp_conn_validate", C.c_int, [C.c_void_p])
+    _sig(L, "gyo_listener_state_validate", C.c_int, [C.c_void_p])
     _sig(L, "gyo_tcp_conn_decode", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u32p, u32p, u64p, u64p, u64p, u8p])
     _sig(L, "gyo_tcp_conn_sketch_batch", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u8p, u32p, u64p])
     _sig(L, "gyo_cluster_state_update", None, [C.POINTER(ClusterStateOne)] + [C.c_uint32] * 6 + [C.POINTER(ListenSummStats)])
@@ -222,6 +225,20 @@ def ref():
     _sig(R, "ref_ns_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, C.c_uint64, C.c_int])
     _sig(R, "ref_pair_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, u8p, C.c_int, C.c_uint16])
     _sig(R, "ref_machine_id_hash", C.c_uint32, [C.c_uint64, C.c_uint64])
+    if hasattr(R, "ref_comm_sizeof"):
+        _sig(R, "ref_comm_nfields", C.c_int, [])
+        _sig(R, "ref_comm_field_name", C.c_char_p, [C.c_int])
+        _sig(R, "ref_comm_field_offset", C.c_size_t, [C.c_int])
+        _sig(R, "ref_comm_sizeof", C.c_size_t, [C.c_int])
+        _sig(R, "ref_comm_const", C.c_uint64, [C.c_int])
+        _sig(R, "ref_comm_hdr_validate", C.c_int, [C.c_void_p, C.c_uint32])
+        _sig(R, "ref_tcp_conn_validate", C.c_int, [C.c_void_p])
+        _sig(R, "ref_listener_state_validate", C.c_int, [C.c_void_p])
+        _sig(R, "ref_tcp_conn_elem_size", C.c_uint32, [C.c_void_p])
+        _sig(R, "ref_state_one_sizeof", C.c_size_t, [])
+        _sig(R, "ref_state_one_add", None, [u32p, u32p])
+        _sig(R, "ref_state_one_fields", None, [u32p, u32p])
+        _sig(R, "ref_listener_state_elem_size", C.c_uint32, [C.c_void_p])
     if hasattr(R, "ref_slab_percentile_idx"):
         _sig(R, "ref_slab_num_buckets", C.c_size_t, [])
         _sig(R, "ref_slab_bucket_idx", C.c_size_t, [C.c_int64])

@@ -19,6 +19,9 @@
 //   common/gy_statistics.h:455-894       HIST_SERIAL, GY_HISTOGRAM (add_data, add_histogram, get_percentiles ...)
 //   common/gy_statistics.h:1565-2063     bucket-hash classes
 //   common/gy_statistics.h:28-453        BOUNDED_PRIO_QUEUE
+//   common/gy_comm_proto.h:336-420, :486-500, :1620-1653, :1665-1760, :2183-2254   COMM_HEADER, EVENT_NOTIFY, LISTENER_DAY_STATS,
+//                                        TCP_CONN_NOTIFY, LISTENER_STATE_NOTIFY: sizes, member offsets, get_elem_size
+//   common/gy_comm_proto.cc:10-57, :840-881, :955-996   COMM_HEADER::validate, TCP_CONN_NOTIFY::validate, LISTENER_STATE_NOTIFY::validate
 //   thirdparty/SlabHistogramBucket.h:70-78, :165-240   SlabHistogramBuckets::getBucketIdx / getPercentileBucketIdx, constructed the
 //                                        way TIME_HISTOGRAM constructs its slab histogram (common/gy_statistics.h:1106-1108)
 #include <thread>
@@ -26,6 +29,7 @@
 #include "gy_common_inc.h"
 #include "gy_statistics.h"
 #include "gy_inet_inc.h"
+#include "gy_comm_proto.h"       // wire structs + validators (gy_comm_proto.cc is compiled next to this file, see build_ref.sh)
 #include "SlabHistogramBucket.h" // thirdparty/ (in tree): folly::detail::SlabHistogramBuckets, the container behind TimeseriesSlabHistogram
 
 namespace gyeeta {
@@ -323,4 +327,107 @@ size_t ref_slab_percentile_idx(const uint64_t *counts, size_t nb, double pct)
 	for (size_t i = 0; i < nb && i < b.getNumBuckets(); ++i) b.getByIndex(i).count = counts[i];
 	return b.getPercentileBucketIdx(pct, [](const SlabCount &x) { return x.count; });
 }
+
+// ---- wire structs: layout facts as the compiler sees them + the reference's validators
+#define GY_REF_OFF(S, f) {#S "." #f, offsetof(comm::S, f##_)}
+static const struct {
+	const char *name;
+	size_t off;
+} g_comm_offs[] = {
+	GY_REF_OFF(COMM_HEADER, magic), GY_REF_OFF(COMM_HEADER, total_sz), GY_REF_OFF(COMM_HEADER, data_type), GY_REF_OFF(COMM_HEADER, padding_sz),
+	GY_REF_OFF(EVENT_NOTIFY, subtype), GY_REF_OFF(EVENT_NOTIFY, nevents),
+	GY_REF_OFF(TCP_CONN_NOTIFY, cli), GY_REF_OFF(TCP_CONN_NOTIFY, ser), GY_REF_OFF(TCP_CONN_NOTIFY, nat_cli), GY_REF_OFF(TCP_CONN_NOTIFY, nat_ser),
+	GY_REF_OFF(TCP_CONN_NOTIFY, tusec_start), GY_REF_OFF(TCP_CONN_NOTIFY, tusec_close), GY_REF_OFF(TCP_CONN_NOTIFY, cli_task_aggr_id),
+	GY_REF_OFF(TCP_CONN_NOTIFY, cli_related_listen_id), GY_REF_OFF(TCP_CONN_NOTIFY, cli_madhava_id), GY_REF_OFF(TCP_CONN_NOTIFY, cli_ser_machine_id),
+	GY_REF_OFF(TCP_CONN_NOTIFY, ser_related_listen_id), GY_REF_OFF(TCP_CONN_NOTIFY, ser_glob_id), GY_REF_OFF(TCP_CONN_NOTIFY, ser_madhava_id),
+	GY_REF_OFF(TCP_CONN_NOTIFY, bytes_sent), GY_REF_OFF(TCP_CONN_NOTIFY, bytes_rcvd), GY_REF_OFF(TCP_CONN_NOTIFY, cli_pid), GY_REF_OFF(TCP_CONN_NOTIFY, ser_pid),
+	GY_REF_OFF(TCP_CONN_NOTIFY, ser_conn_hash), GY_REF_OFF(TCP_CONN_NOTIFY, ser_sock_inode), GY_REF_OFF(TCP_CONN_NOTIFY, cli_comm),
+	GY_REF_OFF(TCP_CONN_NOTIFY, ser_comm), GY_REF_OFF(TCP_CONN_NOTIFY, cli_cmdline_len), GY_REF_OFF(TCP_CONN_NOTIFY, is_tcp_connect_event),
+	GY_REF_OFF(TCP_CONN_NOTIFY, is_tcp_accept_event), GY_REF_OFF(TCP_CONN_NOTIFY, is_loopback_conn), GY_REF_OFF(TCP_CONN_NOTIFY, is_pre_existing),
+	GY_REF_OFF(TCP_CONN_NOTIFY, notified_before), GY_REF_OFF(TCP_CONN_NOTIFY, padding_len),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, glob_id), GY_REF_OFF(LISTENER_STATE_NOTIFY, nqrys_5s), GY_REF_OFF(LISTENER_STATE_NOTIFY, total_resp_5sec),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, nconns), GY_REF_OFF(LISTENER_STATE_NOTIFY, nconns_active), GY_REF_OFF(LISTENER_STATE_NOTIFY, ntasks),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, p95_5s_resp_ms), GY_REF_OFF(LISTENER_STATE_NOTIFY, p95_5min_resp_ms),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, curr_kbytes_inbound), GY_REF_OFF(LISTENER_STATE_NOTIFY, curr_kbytes_outbound),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, ser_errors), GY_REF_OFF(LISTENER_STATE_NOTIFY, cli_errors), GY_REF_OFF(LISTENER_STATE_NOTIFY, tasks_delay_usec),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, tasks_cpudelay_usec), GY_REF_OFF(LISTENER_STATE_NOTIFY, tasks_blkiodelay_usec),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, tasks_user_cpu), GY_REF_OFF(LISTENER_STATE_NOTIFY, tasks_sys_cpu), GY_REF_OFF(LISTENER_STATE_NOTIFY, tasks_rss_mb),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, ntasks_issue), GY_REF_OFF(LISTENER_STATE_NOTIFY, is_http_svc), GY_REF_OFF(LISTENER_STATE_NOTIFY, curr_state),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, curr_issue), GY_REF_OFF(LISTENER_STATE_NOTIFY, issue_bit_hist), GY_REF_OFF(LISTENER_STATE_NOTIFY, high_resp_bit_hist),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, last_issue_subsrc), GY_REF_OFF(LISTENER_STATE_NOTIFY, query_flags), GY_REF_OFF(LISTENER_STATE_NOTIFY, issue_string_len),
+	GY_REF_OFF(LISTENER_STATE_NOTIFY, padding_len),
+	GY_REF_OFF(LISTENER_DAY_STATS, glob_id), GY_REF_OFF(LISTENER_DAY_STATS, tcount_5d), GY_REF_OFF(LISTENER_DAY_STATS, tsum_5d),
+	GY_REF_OFF(LISTENER_DAY_STATS, p95_5d_respms), GY_REF_OFF(LISTENER_DAY_STATS, p25_5d_respms), GY_REF_OFF(LISTENER_DAY_STATS, p95_qps),
+	GY_REF_OFF(LISTENER_DAY_STATS, p25_qps), GY_REF_OFF(LISTENER_DAY_STATS, p95_nactive), GY_REF_OFF(LISTENER_DAY_STATS, p25_nactive),
+};
+int ref_comm_nfields(void) { return (int)(sizeof(g_comm_offs) / sizeof(g_comm_offs[0])); }
+const char *ref_comm_field_name(int i) { return g_comm_offs[i].name; }
+size_t ref_comm_field_offset(int i) { return g_comm_offs[i].off; }
+size_t ref_comm_sizeof(int which)
+{
+	switch (which) {
+	case 0: return sizeof(comm::COMM_HEADER);
+	case 1: return sizeof(comm::EVENT_NOTIFY);
+	case 2: return sizeof(comm::TCP_CONN_NOTIFY);
+	case 3: return sizeof(comm::LISTENER_STATE_NOTIFY);
+	case 4: return sizeof(comm::LISTENER_DAY_STATS);
+	case 5: return sizeof(GY_MACHINE_ID);
+	default: return 0;
+	}
+}
+// 0 PM_HDR_MAGIC, 1 COMM_EVENT_NOTIFY, 2 COMM_MIN_TYPE, 3 COMM_MAX_TYPE, 4 MAX_COMM_DATA_SZ, 5 NOTIFY_TCP_CONN, 6 NOTIFY_LISTENER_STATE,
+// 7 TCP_CONN_NOTIFY::MAX_NUM_CONNS, 8 LISTENER_STATE_NOTIFY::MAX_NUM_LISTENERS, 9 LISTENER_DAY_STATS::MAX_NUM_LISTENERS, 10 LISTEN_FLAG_DELETE
+uint64_t ref_comm_const(int which)
+{
+	switch (which) {
+	case 0: return (uint64_t)comm::COMM_HEADER::PM_HDR_MAGIC;
+	case 1: return (uint64_t)comm::COMM_EVENT_NOTIFY;
+	case 2: return (uint64_t)comm::COMM_MIN_TYPE;
+	case 3: return (uint64_t)comm::COMM_MAX_TYPE;
+	case 4: return (uint64_t)comm::MAX_COMM_DATA_SZ;
+	case 5: return (uint64_t)comm::NOTIFY_TCP_CONN;
+	case 6: return (uint64_t)comm::NOTIFY_LISTENER_STATE;
+	case 7: return (uint64_t)comm::TCP_CONN_NOTIFY::MAX_NUM_CONNS;
+	case 8: return (uint64_t)comm::LISTENER_STATE_NOTIFY::MAX_NUM_LISTENERS;
+	case 9: return (uint64_t)comm::LISTENER_DAY_STATS::MAX_NUM_LISTENERS;
+	case 10: return (uint64_t)comm::LISTEN_FLAG_DELETE;
+	default: return ~0ull;
+	}
+}
+// msg points at a COMM_HEADER (8-byte aligned, writable: the record validators NUL-terminate the strings in place)
+int ref_comm_hdr_validate(const uint8_t *msg, uint32_t req_magic)
+{
+	return ((const comm::COMM_HEADER *)msg)->validate(msg, (comm::COMM_HEADER::HDR_MAGIC_E)req_magic) ? 1 : 0;
+}
+int ref_tcp_conn_validate(uint8_t *msg)
+{
+	return comm::TCP_CONN_NOTIFY::validate((const comm::COMM_HEADER *)msg, (const comm::EVENT_NOTIFY *)(msg + sizeof(comm::COMM_HEADER))) ? 1 : 0;
+}
+int ref_listener_state_validate(uint8_t *msg)
+{
+	return comm::LISTENER_STATE_NOTIFY::validate((const comm::COMM_HEADER *)msg, (const comm::EVENT_NOTIFY *)(msg + sizeof(comm::COMM_HEADER))) ? 1 : 0;
+}
+// comm::MS_CLUSTER_STATE::STATE_ONE (common/gy_comm_proto.h:3183-3213): member order as 11 consecutive uint32_t + add_stats (the shyama-side
+// fan-in of the per-madhava cluster states)
+size_t ref_state_one_sizeof(void) { return sizeof(comm::MS_CLUSTER_STATE::STATE_ONE); }
+void ref_state_one_add(uint32_t dst[11], const uint32_t src[11])
+{
+	comm::MS_CLUSTER_STATE::STATE_ONE a, b;
+	static_assert(offsetof(comm::MS_CLUSTER_STATE::STATE_ONE, nmem_issue_) == 40, "11 consecutive uint32_t");
+	memcpy(&a, dst, 44);
+	memcpy(&b, src, 44);
+	a.add_stats(b);
+	memcpy(dst, &a, 44);
+}
+// member-wise view, to pin the ORDER of the 11 counters
+void ref_state_one_fields(const uint32_t in[11], uint32_t out[11])
+{
+	comm::MS_CLUSTER_STATE::STATE_ONE a;
+	memcpy(&a, in, 44);
+	const uint32_t v[11] = {a.nhosts_, a.ntasks_issue_, a.ntaskissue_hosts_, a.ntasks_, a.nsvc_issue_, a.nsvcissue_hosts_, a.nsvc_, a.total_qps_,
+				a.svc_net_mb_, a.ncpu_issue_, a.nmem_issue_};
+	memcpy(out, v, 44);
+}
+uint32_t ref_tcp_conn_elem_size(const uint8_t *rec) { return (uint32_t)((const comm::TCP_CONN_NOTIFY *)rec)->get_elem_size(); }
+uint32_t ref_listener_state_elem_size(const uint8_t *rec) { return (uint32_t)((const comm::LISTENER_STATE_NOTIFY *)rec)->get_elem_size(); }
 }  // extern "C"

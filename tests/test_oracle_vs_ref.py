@@ -215,3 +215,28 @@ def test_slab_percentile_rule_vs_reference_container(reflib, oracle):
             assert L.gyo_slab_percentile_idx(oracle.ptr(counts, oracle.u64p), 15, float(pct)) == want, (counts.tolist(), pct)
     empty = np.zeros(15, dtype=np.uint64)
     assert R.ref_slab_percentile_idx(oracle.ptr(empty, oracle.u64p), 15, 0.95) == 1 == L.gyo_slab_percentile_idx(oracle.ptr(empty, oracle.u64p), 15, 0.95)
+
+
+def test_cluster_state_one_vs_reference(reflib, oracle):
+    """comm::MS_CLUSTER_STATE::STATE_ONE (common/gy_comm_proto.h:3183-3213): counter order and add_stats == gyo_cluster_state_one /
+    gyo_cluster_state_add (what the engine's all-reduce of the cluster rows computes)"""
+    R, L = reflib, oracle.lib()
+    if not hasattr(R, "ref_state_one_add"):
+        pytest.skip("oracle/_ref built without gy_comm_proto")
+    assert R.ref_state_one_sizeof() == 48  # 11 x u32, alignas(8)
+    names = [n for n, _ in oracle.ClusterStateOne._fields_]
+    assert names == ["nhosts", "ntasks_issue", "ntaskissue_hosts", "ntasks", "nsvc_issue", "nsvcissue_hosts", "nsvc", "total_qps", "svc_net_mb",
+                     "ncpu_issue", "nmem_issue"]
+    probe = np.arange(100, 111, dtype=np.uint32)
+    out = np.zeros(11, dtype=np.uint32)
+    R.ref_state_one_fields(oracle.ptr(probe, oracle.u32p), oracle.ptr(out, oracle.u32p))
+    assert out.tolist() == probe.tolist()  # members in declaration order, no holes
+    rng = np.random.default_rng(8)
+    for _ in range(50):
+        a = rng.integers(0, 2**32, 11, dtype=np.uint64).astype(np.uint32)
+        b = rng.integers(0, 2**32, 11, dtype=np.uint64).astype(np.uint32)
+        ra = a.copy()
+        R.ref_state_one_add(oracle.ptr(ra, oracle.u32p), oracle.ptr(b, oracle.u32p))
+        oa, ob = oracle.ClusterStateOne(*a.tolist()), oracle.ClusterStateOne(*b.tolist())
+        L.gyo_cluster_state_add(C.byref(oa), C.byref(ob))
+        assert list(oa.as_tuple()) == ra.tolist()  # wraps modulo 2^32 like the reference's uint32_t sums
