@@ -61,6 +61,25 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed):
     t1 = time.perf_counter()
     orc2.resp_batch(host, sh, sf, histonly=True)
     t2 = time.perf_counter()
+    port_mt = None
+    try:  # the full port again on every host core (hosts cut into per-thread ranges; identical resulting state, tests/test_oracle_sketches.py)
+        ncores = os.cpu_count() or 1
+        if ncores > 1:
+            orc3 = o.OracleEngine(nsvc)
+            for h in range(total_hosts_sample):
+                s = np.arange(svcs)
+                g = wire.glob_id(np.full(svcs, h), s)
+                ns = wire.listener_netns(h, s)
+                pt = wire.listener_port(s)
+                for i in range(svcs):
+                    orc3.register(h, int(g[i]), int(ns[i]), int(pt[i]))
+            t7 = time.perf_counter()
+            orc3.resp_batch(host, sh, sf, nthreads=ncores)
+            t8 = time.perf_counter()
+            port_mt = {"value": nevents / (t8 - t7), "cores": ncores}
+            del orc3
+    except Exception as ex:  # never let the optional leg take the JSON line down
+        print(f"bench.py: all-cores port baseline skipped: {ex}", file=sys.stderr)
     desc = (f"{nevents} events over {total_hosts_sample} hosts x {svcs} services ({nsvc} keys), one batch, single thread, "
             f"gcc -O2; full = hist+bitmap+HLL+CMS+t-digest, histonly = the reference's own per-event work")
     # the reference's OWN classes on the same bytes (oracle/_ref: GY_HISTOGRAM<int64_t, RESP_TIME_HASH>::add_data behind an
@@ -91,7 +110,7 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed):
             ref_rate["mt_value"] = nevents / (t6 - t5)
             ref_rate["mt_cores"] = ncores
         R.ref_keyed_free(k)
-    return nevents / (t1 - t0), nevents / (t2 - t1), desc, ref_rate
+    return nevents / (t1 - t0), nevents / (t2 - t1), desc, ref_rate, port_mt
 
 
 def quantile_error(eng, torch, ingested, nlocal, svcs, host_ids, host_slots, wire):
@@ -351,9 +370,12 @@ def main():
         if host_fed is not None:
             out["host_fed"] = host_fed
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N = 1 only
-            full, honly, desc, ref_rate = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234)
+            full, honly, desc, ref_rate, port_mt = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234)
             out["cpu_baseline"] = {"value": full, "unit": "events/s", "cores": 1, "kind": "port", "sample": desc,
                                    "histonly_value": honly}
+            if port_mt is not None:  # the same full port (histogram + bitmap + HLL + CMS + t-digest) on all host threads
+                out["cpu_baseline"]["allcores_value"] = port_mt["value"]
+                out["cpu_baseline"]["allcores"] = port_mt["cores"]
             if ref_rate is not None:  # the reference's own GY_HISTOGRAM + GY_JHASHER compiled from /root/reference (oracle/_ref)
                 out["cpu_baseline"]["reference_hist_value"] = ref_rate["value"]
                 out["cpu_baseline"]["reference_hist_kind"] = "reference"

@@ -90,20 +90,22 @@ static uint32_t lookup(const gyo_engine *e, uint64_t k)
 
 static uint16_t bswap16(uint16_t v) { return (uint16_t)((v >> 8) | (v << 8)); }
 
-/* One batch of 24-byte tcp_ipv4_resp_event_t (common/gy_ebpf_kernel.h:106-111); segment s covers events
- * [seg_first[s], seg_first[s+1]) of host seg_host[s]. */
-void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs)
-{
-	uint32_t seg = 0;
-	uint32_t *slot_of = NULL;
-	int32_t *val_of = NULL;
+/* where one pass over a range of events accumulates the registers that are shared between services (the per-service records are
+ * addressed by slot and a service belongs to one host, so ranges made of whole hosts never touch the same record) */
+typedef struct {
+	uint8_t *hll;
+	uint32_t *cms;
+	gyo_hist_serial *ghist; /* [16] */
+	int64_t *gmax;
+	uint64_t *counters;     /* [4] */
+} resp_sinks;
 
-	if (e->enable_td) {
-		slot_of = (uint32_t *)malloc((size_t)(n ? n : 1) * 4);
-		val_of = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
-		memset(e->bcnt, 0, (size_t)e->nsvc * 4);
-	}
-	for (uint64_t i = 0; i < n; i++) {
+/* events [i0, i1) of a batch; seg = index of the segment containing i0.  slot_of / val_of (NULL without t-digests) get one entry
+ * per event; bcnt[slot] counts the kept events of each service. */
+static void resp_range(gyo_engine *e, const uint8_t *ev24, uint64_t i0, uint64_t i1, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs,
+		       uint32_t seg, uint32_t *slot_of, int32_t *val_of, resp_sinks k)
+{
+	for (uint64_t i = i0; i < i1; i++) {
 		const uint8_t *p = ev24 + i * 24;
 		uint32_t saddr, daddr, netns, lsnd, lrcv, tresp, slot, b;
 		uint16_t sport_be, dport_be, sport, dport;
@@ -113,20 +115,20 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 		memcpy(&lsnd, p + 16, 4); memcpy(&lrcv, p + 20, 4);
 		while (seg + 1 < nsegs && seg_first[seg + 1] <= i) seg++;
 		if (slot_of) slot_of[i] = 0xFFFFFFFFu;
-		e->counters[0]++;
+		k.counters[0]++;
 		tresp = lsnd - lrcv;                      /* gy_socket_stat.cc:1519 */
 		if (tresp > 1000000u) {                   /* :1521-1524 */
-			e->counters[1]++;
+			k.counters[1]++;
 			continue;
 		}
 		sport = bswap16(sport_be);                /* ntohs :1526-1527 */
 		dport = bswap16(dport_be);
 		slot = lookup(e, lkey(seg_host[seg], netns, sport)); /* listener_tbl_ lookup ignoring the IP :1671 */
 		if (slot == 0xFFFFFFFFu) {
-			e->counters[2]++;
+			k.counters[2]++;
 			continue;
 		}
-		e->counters[3]++;
+		k.counters[3]++;
 		b = gyo_bucket(GYO_RESP_TIME_HASH, (int64_t)tresp);
 		{
 			gyo_hist_serial *h = &e->hist[(size_t)slot * 16];
@@ -136,20 +138,20 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 			if (h[15].sum < (int64_t)tresp) h[15].sum = (int64_t)tresp; /* max_val_seen_ */
 		}
 		gyo_conn_bitmap_add(&e->bitmap[(size_t)slot * 32], dport, (uint8_t)b); /* resp_bitmap_v4_.add_response */
-		e->ghist[b].count++;
-		e->ghist[b].sum += (int64_t)tresp;
-		e->ghist[15].count++;
-		if (e->gmax < (int64_t)tresp) e->gmax = (int64_t)tresp;
+		k.ghist[b].count++;
+		k.ghist[b].sum += (int64_t)tresp;
+		k.ghist[15].count++;
+		if (*k.gmax < (int64_t)tresp) *k.gmax = (int64_t)tresp;
 		{
 			uint32_t w[10];
 			const uint32_t nw = gyo_pair_ip_port_words((const uint8_t *)&daddr, 0, dport, (const uint8_t *)&saddr, 0, sport, w);
-			gyo_hll_add_words(e->hll, GYO_HLL_P, w, nw);
+			gyo_hll_add_words(k.hll, GYO_HLL_P, w, nw);
 		}
 		{
 			uint32_t gw[2];
 			gw[0] = (uint32_t)(e->svc_gid[slot] & 0xFFFFFFFFu);
 			gw[1] = (uint32_t)(e->svc_gid[slot] >> 32);
-			gyo_cms_add(e->cms, gw, 2, 1);
+			gyo_cms_add(k.cms, gw, 2, 1);
 		}
 		if (slot_of) {
 			slot_of[i] = slot;
@@ -157,6 +159,27 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 			e->bcnt[slot]++;
 		}
 	}
+}
+
+static resp_sinks own_sinks(gyo_engine *e)
+{
+	resp_sinks k = {e->hll, e->cms, e->ghist, &e->gmax, e->counters};
+	return k;
+}
+
+/* One batch of 24-byte tcp_ipv4_resp_event_t (common/gy_ebpf_kernel.h:106-111); segment s covers events
+ * [seg_first[s], seg_first[s+1]) of host seg_host[s]. */
+void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs)
+{
+	uint32_t *slot_of = NULL;
+	int32_t *val_of = NULL;
+
+	if (e->enable_td) {
+		slot_of = (uint32_t *)malloc((size_t)(n ? n : 1) * 4);
+		val_of = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
+		memset(e->bcnt, 0, (size_t)e->nsvc * 4);
+	}
+	resp_range(e, ev24, 0, n, seg_host, seg_first, nsegs, 0, slot_of, val_of, own_sinks(e));
 	if (e->enable_td) {
 		/* buffered digest(key) <- add_batch(multiset of this batch's values of the key): append, or one merge of buffer + batch */
 		int32_t *staged = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
@@ -177,6 +200,133 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 		free(slot_of);
 		free(val_of);
 	}
+}
+
+/* The same batch on nthreads host threads ("all cores" CPU baseline): the segments (hosts) are cut into contiguous ranges, one per
+ * thread -- the reference pins a partha's batches to one L2 thread the same way (server/gy_mconnhdlr.cc:16252).  Every segment must
+ * be a different host (a service's records are then owned by one thread); the registers shared between services (HLL, Count-Min,
+ * all-service histogram, counters) are kept per thread and merged at the end (max / sum: order free), the per-service digests are
+ * re-clustered in parallel over service ranges.  The resulting state is identical to gyo_engine_resp_batch's. */
+typedef struct {
+	gyo_engine *e;
+	const uint8_t *ev24;
+	uint64_t n;
+	const uint32_t *seg_host;
+	const uint64_t *seg_first;
+	uint32_t nsegs, s0, s1;
+	uint32_t *slot_of;
+	int32_t *val_of, *staged;
+	uint8_t hll[GYO_HLL_M];
+	uint32_t *cms;
+	gyo_hist_serial ghist[16];
+	int64_t gmax;
+	uint64_t counters[4];
+	uint32_t k0, k1; /* service range of the digest phase */
+	const uint32_t *kstart;
+} mt_worker;
+
+static void *mt_pass1(void *arg)
+{
+	mt_worker *w = (mt_worker *)arg;
+	if (w->s0 >= w->s1) return NULL;
+	const uint64_t i0 = w->seg_first[w->s0], i1 = w->s1 < w->nsegs ? w->seg_first[w->s1] : w->n;
+	resp_sinks k = {w->hll, w->cms, w->ghist, &w->gmax, w->counters};
+	resp_range(w->e, w->ev24, i0, i1, w->seg_host, w->seg_first, w->nsegs, w->s0, w->slot_of, w->val_of, k);
+	return NULL;
+}
+
+static void *mt_scatter(void *arg) /* a thread's events only name its own hosts' services: the cursors it moves are its own */
+{
+	mt_worker *w = (mt_worker *)arg;
+	if (w->s0 >= w->s1) return NULL;
+	const uint64_t i0 = w->seg_first[w->s0], i1 = w->s1 < w->nsegs ? w->seg_first[w->s1] : w->n;
+	for (uint64_t i = i0; i < i1; i++)
+		if (w->slot_of[i] != 0xFFFFFFFFu) w->staged[w->e->boff[w->slot_of[i]]++] = w->val_of[i];
+	return NULL;
+}
+
+static void *mt_digest(void *arg)
+{
+	mt_worker *w = (mt_worker *)arg;
+	for (uint32_t s = w->k0; s < w->k1; s++)
+		if (w->e->bcnt[s]) gyo_tdb_add_batch(&w->e->td[s], w->staged + w->kstart[s], w->e->bcnt[s]);
+	return NULL;
+}
+
+#include <pthread.h>
+
+static void run_all(mt_worker *w, uint32_t nt, void *(*fn)(void *))
+{
+	pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nt);
+	for (uint32_t t = 0; t < nt; t++) pthread_create(&th[t], NULL, fn, &w[t]);
+	for (uint32_t t = 0; t < nt; t++) pthread_join(th[t], NULL);
+	free(th);
+}
+
+void gyo_engine_resp_batch_mt(gyo_engine *e, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs,
+			      uint32_t nthreads)
+{
+	if (nthreads <= 1 || nsegs <= 1) {
+		gyo_engine_resp_batch(e, ev24, n, seg_host, seg_first, nsegs);
+		return;
+	}
+	if (nthreads > nsegs) nthreads = nsegs;
+	uint32_t *slot_of = NULL, *kstart = NULL;
+	int32_t *val_of = NULL, *staged = NULL;
+	if (e->enable_td) {
+		slot_of = (uint32_t *)malloc((size_t)(n ? n : 1) * 4);
+		val_of = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
+		staged = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
+		kstart = (uint32_t *)malloc(((size_t)e->nsvc + 1) * 4);
+		memset(e->bcnt, 0, (size_t)e->nsvc * 4);
+	}
+	mt_worker *w = (mt_worker *)calloc(nthreads, sizeof(mt_worker));
+	for (uint32_t t = 0; t < nthreads; t++) {
+		w[t].e = e;
+		w[t].ev24 = ev24;
+		w[t].n = n;
+		w[t].seg_host = seg_host;
+		w[t].seg_first = seg_first;
+		w[t].nsegs = nsegs;
+		w[t].s0 = (uint32_t)((uint64_t)nsegs * t / nthreads);
+		w[t].s1 = (uint32_t)((uint64_t)nsegs * (t + 1) / nthreads);
+		w[t].slot_of = slot_of;
+		w[t].val_of = val_of;
+		w[t].staged = staged;
+		w[t].cms = (uint32_t *)calloc((size_t)GYO_CMS_D * GYO_CMS_W, 4);
+		w[t].gmax = LONG_MIN;
+		w[t].k0 = (uint32_t)((uint64_t)e->nsvc * t / nthreads);
+		w[t].k1 = (uint32_t)((uint64_t)e->nsvc * (t + 1) / nthreads);
+		w[t].kstart = kstart;
+	}
+	run_all(w, nthreads, mt_pass1);
+	for (uint32_t t = 0; t < nthreads; t++) { /* the shared registers: max / sums, independent of the order */
+		gyo_hll_merge(e->hll, w[t].hll, GYO_HLL_P);
+		for (size_t i = 0; i < (size_t)GYO_CMS_D * GYO_CMS_W; i++) e->cms[i] += w[t].cms[i];
+		for (int b = 0; b < 16; b++) {
+			e->ghist[b].count += w[t].ghist[b].count;
+			e->ghist[b].sum += w[t].ghist[b].sum;
+		}
+		if (e->gmax < w[t].gmax) e->gmax = w[t].gmax;
+		for (int c = 0; c < 4; c++) e->counters[c] += w[t].counters[c];
+		free(w[t].cms);
+	}
+	if (e->enable_td) {
+		uint32_t run = 0;
+		for (uint32_t s = 0; s < e->nsvc; s++) {
+			e->boff[s] = run;
+			kstart[s] = run;
+			run += e->bcnt[s];
+		}
+		e->boff[e->nsvc] = run;
+		run_all(w, nthreads, mt_scatter);
+		run_all(w, nthreads, mt_digest);
+		free(staged);
+		free(slot_of);
+		free(val_of);
+		free(kstart);
+	}
+	free(w);
 }
 
 /* histogram-only variant == what the reference itself computes per event (no sketches): the "reference work" CPU baseline */

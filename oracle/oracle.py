@@ -40,7 +40,7 @@ def build_oracle(force=False):
     deps = [os.path.join(HERE, f) for f in SOURCES + ["gy_oracle.h"]] + [os.path.join(HERE, "..", "include", "gys_tdigest_tbl.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-o", LIB_PATH] + [os.path.join(HERE, f) for f in SOURCES] + ["-lm"])
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-pthread", "-o", LIB_PATH] + [os.path.join(HERE, f) for f in SOURCES] + ["-lm"])
     return LIB_PATH
 
 
@@ -189,6 +189,7 @@ def lib():
     _sig(L, "gyo_engine_register", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint16])
     _sig(L, "gyo_engine_resp_batch", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
     _sig(L, "gyo_engine_resp_batch_histonly", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
+    _sig(L, "gyo_engine_resp_batch_mt", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32, C.c_uint32])
     _sig(L, "gyo_engine_nsvc", C.c_uint32, [C.c_void_p])
     _sig(L, "gyo_engine_hist", C.c_void_p, [C.c_void_p])
     _sig(L, "gyo_engine_bitmap", C.c_void_p, [C.c_void_p])
@@ -354,10 +355,14 @@ class OracleEngine:
         assert s >= 0
         return s
 
-    def resp_batch(self, ev_bytes, seg_host, seg_first, histonly=False):
+    def resp_batch(self, ev_bytes, seg_host, seg_first, histonly=False, nthreads=1):
+        """nthreads > 1: the same batch with the segments (distinct hosts) cut into per-thread ranges; identical resulting state"""
         ev = np.frombuffer(ev_bytes, dtype=np.uint8)
         sh = np.ascontiguousarray(seg_host, dtype=np.uint32)
         sf = np.ascontiguousarray(seg_first, dtype=np.uint64)
+        if nthreads > 1 and not histonly:
+            self.L.gyo_engine_resp_batch_mt(self.h, ev.ctypes.data, len(ev) // 24, ptr(sh, u32p), ptr(sf, u64p), len(sh), nthreads)
+            return
         fn = self.L.gyo_engine_resp_batch_histonly if histonly else self.L.gyo_engine_resp_batch
         fn(self.h, ev.ctypes.data, len(ev) // 24, ptr(sh, u32p), ptr(sf, u64p), len(sh))
 

@@ -178,3 +178,36 @@ def test_tdigest_buffered_form(oracle):
     allv = np.ascontiguousarray(x[:260][::-1])
     L.gyo_td_merge_values(C.byref(d), oracle.ptr(allv, oracle.i32p), 260)
     assert list(d.cnt) == list(b.d.cnt) and list(d.sum) == list(b.d.sum)
+
+
+def test_oracle_engine_multithreaded_batch_is_identical(oracle):
+    """the all-cores form of the oracle's hot loop (bench.py cpu_baseline, "port"): hosts cut into per-thread ranges, shared registers
+    kept per thread and merged -- every register, digest, buffer and counter equals the sequential loop's, over several batches"""
+    from gyeeta_amd import wire
+    from tests import helpers
+    rng = np.random.default_rng(17)
+    nh, sp = 13, 9
+    a, b = oracle.OracleEngine(256), oracle.OracleEngine(256)
+    helpers.register_world(None, a, range(nh), sp)
+    helpers.register_world(None, b, range(nh), sp)
+    for batch in range(4):
+        hosts = rng.permutation(nh)[:int(rng.integers(2, nh + 1))]
+        parts = [helpers.make_resp_events(rng, int(h), int(rng.integers(1, 3000)), sp, lat_mu=2.0 + 0.5 * batch) for h in hosts]
+        raw = helpers.concat_events(parts).tobytes()
+        firsts = np.cumsum([0] + [len(p) for p in parts[:-1]]).tolist()
+        slots = [int(h) for h in hosts]  # register_world(None, ...) numbers the hosts 0..nh-1 in order
+        a.resp_batch(raw, slots, firsts)
+        b.resp_batch(raw, slots, firsts, nthreads=int(rng.integers(2, 9)))
+        assert (np.array(a.hist()) == np.array(b.hist())).all() and (a.bitmap() == b.bitmap()).all()
+        assert (a.hll() == b.hll()).all() and (a.cms() == b.cms()).all()
+        (ga, ma), (gb, mb) = a.ghist(), b.ghist()
+        assert (ga == gb).all() and ma == mb
+        for x, y in zip(a.td_arrays(), b.td_arrays()):
+            assert (x == y).all()
+        for x, y in zip(a.td_pending(), b.td_pending()):
+            assert (x == y).all()
+        assert a.counters() == b.counters()
+        if batch == 1:
+            a.window_clear()
+            b.window_clear()
+    assert a.counters()["accepted"] > 1000
