@@ -98,7 +98,26 @@ typedef struct {
 	gyo_hist_serial *ghist; /* [16] */
 	int64_t *gmax;
 	uint64_t *counters;     /* [4] */
+	int shared;             /* hll / cms are written by several threads at once: register max by CAS, counter add atomically
+	                           (max and + commute, so the registers end up exactly as in the sequential loop) */
 } resp_sinks;
+
+static void hll_add_shared(uint8_t *regs, const uint32_t *words, uint32_t nwords)
+{
+	uint32_t idx;
+	uint8_t rank;
+	gyo_hll_idx_rank(gyo_hash64(words, nwords), GYO_HLL_P, &idx, &rank);
+	uint8_t cur = __atomic_load_n(&regs[idx], __ATOMIC_RELAXED);
+	while (cur < rank && !__atomic_compare_exchange_n(&regs[idx], &cur, rank, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+	}
+}
+
+static void cms_add_shared(uint32_t *tbl, const uint32_t *words, uint32_t nwords, uint32_t weight)
+{
+	uint32_t cols[GYO_CMS_D];
+	gyo_cms_cols(words, nwords, cols);
+	for (uint32_t r = 0; r < GYO_CMS_D; r++) __atomic_fetch_add(&tbl[(size_t)r * GYO_CMS_W + cols[r]], weight, __ATOMIC_RELAXED);
+}
 
 /* events [i0, i1) of a batch; seg = index of the segment containing i0.  slot_of / val_of (NULL without t-digests) get one entry
  * per event; bcnt[slot] counts the kept events of each service. */
@@ -145,13 +164,15 @@ static void resp_range(gyo_engine *e, const uint8_t *ev24, uint64_t i0, uint64_t
 		{
 			uint32_t w[10];
 			const uint32_t nw = gyo_pair_ip_port_words((const uint8_t *)&daddr, 0, dport, (const uint8_t *)&saddr, 0, sport, w);
-			gyo_hll_add_words(k.hll, GYO_HLL_P, w, nw);
+			if (k.shared) hll_add_shared(k.hll, w, nw);
+			else gyo_hll_add_words(k.hll, GYO_HLL_P, w, nw);
 		}
 		{
 			uint32_t gw[2];
 			gw[0] = (uint32_t)(e->svc_gid[slot] & 0xFFFFFFFFu);
 			gw[1] = (uint32_t)(e->svc_gid[slot] >> 32);
-			gyo_cms_add(k.cms, gw, 2, 1);
+			if (k.shared) cms_add_shared(k.cms, gw, 2, 1);
+			else gyo_cms_add(k.cms, gw, 2, 1);
 		}
 		if (slot_of) {
 			slot_of[i] = slot;
@@ -163,7 +184,7 @@ static void resp_range(gyo_engine *e, const uint8_t *ev24, uint64_t i0, uint64_t
 
 static resp_sinks own_sinks(gyo_engine *e)
 {
-	resp_sinks k = {e->hll, e->cms, e->ghist, &e->gmax, e->counters};
+	resp_sinks k = {e->hll, e->cms, e->ghist, &e->gmax, e->counters, 0};
 	return k;
 }
 
@@ -204,9 +225,10 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 
 /* The same batch on nthreads host threads ("all cores" CPU baseline): the segments (hosts) are cut into contiguous ranges, one per
  * thread -- the reference pins a partha's batches to one L2 thread the same way (server/gy_mconnhdlr.cc:16252).  Every segment must
- * be a different host (a service's records are then owned by one thread); the registers shared between services (HLL, Count-Min,
- * all-service histogram, counters) are kept per thread and merged at the end (max / sum: order free), the per-service digests are
- * re-clustered in parallel over service ranges.  The resulting state is identical to gyo_engine_resp_batch's. */
+ * be a different host (a service's records are then owned by one thread); the HLL registers and Count-Min counters shared between
+ * services are updated atomically (CAS max / fetch-add: order free), the all-service histogram and the counters are kept per thread
+ * and summed at the end, the per-service digests are re-clustered in parallel over service ranges.  The resulting state is identical
+ * to gyo_engine_resp_batch's. */
 typedef struct {
 	gyo_engine *e;
 	const uint8_t *ev24;
@@ -216,8 +238,6 @@ typedef struct {
 	uint32_t nsegs, s0, s1;
 	uint32_t *slot_of;
 	int32_t *val_of, *staged;
-	uint8_t hll[GYO_HLL_M];
-	uint32_t *cms;
 	gyo_hist_serial ghist[16];
 	int64_t gmax;
 	uint64_t counters[4];
@@ -230,7 +250,7 @@ static void *mt_pass1(void *arg)
 	mt_worker *w = (mt_worker *)arg;
 	if (w->s0 >= w->s1) return NULL;
 	const uint64_t i0 = w->seg_first[w->s0], i1 = w->s1 < w->nsegs ? w->seg_first[w->s1] : w->n;
-	resp_sinks k = {w->hll, w->cms, w->ghist, &w->gmax, w->counters};
+	resp_sinks k = {w->e->hll, w->e->cms, w->ghist, &w->gmax, w->counters, 1};
 	resp_range(w->e, w->ev24, i0, i1, w->seg_host, w->seg_first, w->nsegs, w->s0, w->slot_of, w->val_of, k);
 	return NULL;
 }
@@ -293,23 +313,19 @@ void gyo_engine_resp_batch_mt(gyo_engine *e, const uint8_t *ev24, uint64_t n, co
 		w[t].slot_of = slot_of;
 		w[t].val_of = val_of;
 		w[t].staged = staged;
-		w[t].cms = (uint32_t *)calloc((size_t)GYO_CMS_D * GYO_CMS_W, 4);
 		w[t].gmax = LONG_MIN;
 		w[t].k0 = (uint32_t)((uint64_t)e->nsvc * t / nthreads);
 		w[t].k1 = (uint32_t)((uint64_t)e->nsvc * (t + 1) / nthreads);
 		w[t].kstart = kstart;
 	}
 	run_all(w, nthreads, mt_pass1);
-	for (uint32_t t = 0; t < nthreads; t++) { /* the shared registers: max / sums, independent of the order */
-		gyo_hll_merge(e->hll, w[t].hll, GYO_HLL_P);
-		for (size_t i = 0; i < (size_t)GYO_CMS_D * GYO_CMS_W; i++) e->cms[i] += w[t].cms[i];
+	for (uint32_t t = 0; t < nthreads; t++) { /* the small per-thread registers: sums / max, independent of the order */
 		for (int b = 0; b < 16; b++) {
 			e->ghist[b].count += w[t].ghist[b].count;
 			e->ghist[b].sum += w[t].ghist[b].sum;
 		}
 		if (e->gmax < w[t].gmax) e->gmax = w[t].gmax;
 		for (int c = 0; c < 4; c++) e->counters[c] += w[t].counters[c];
-		free(w[t].cms);
 	}
 	if (e->enable_td) {
 		uint32_t run = 0;
