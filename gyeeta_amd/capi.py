@@ -7,9 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgysketch.so")
 
 OK, ERR_INVAL, ERR_NOMEM, ERR_HIP, ERR_NOTFOUND, ERR_NOT_OWNER, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
-MAX_BUCKETS, TD_NB, HLL_P, CMS_D, CMS_W, NSTATES, TOPN = 16, 100, 14, 4, 65536, 6, 10
+MAX_BUCKETS, TD_NB, HLL_P, CMS_D, CMS_W, NSTATES, TOPN = 16, 200, 14, 4, 65536, 6, 10
 NLEVELS, LEVEL_RING = 4, 10
-TD_PEND_CAP = 256
+TD_PEND_CAP = 768
 KINDS = {"RESP_TIME_HASH": 0, "SEMI_LOG_HASH": 1, "SEMI_LOG_HASH_LO": 2, "DURATION_HASH": 3, "HASH_10_5000": 4, "HASH_5_250": 5,
          "HASH_1_3000": 6, "PERCENT_HASH": 7}
 
@@ -19,7 +19,7 @@ class Config(C.Structure):
                 ("max_hosts", C.c_uint32), ("max_services", C.c_uint32), ("max_clusters", C.c_uint32),
                 ("enable_tdigest", C.c_uint32), ("svc_hll_p", C.c_uint32), ("resp_path", C.c_uint32),
                 ("max_batch_events", C.c_uint64), ("stream", C.c_void_p), ("reduce_arena", C.c_void_p),
-                ("reduce_arena_bytes", C.c_uint64), ("enable_levels", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("reduce_arena_bytes", C.c_uint64), ("enable_levels", C.c_uint32), ("td_buf_values", C.c_uint32)]
 
 
 class ListenerInfo(C.Structure):

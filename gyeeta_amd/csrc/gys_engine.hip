@@ -84,7 +84,7 @@ struct HostListeners {
 	bool overflow = false;       // more listeners than the LDS path supports (or pools exhausted): general pipeline only
 };
 
-#define GYS_HOST_MAX_LOCAL 4096u // listeners per host the LDS sub-table path supports (16-bit local index, 64 KB LDS table + 16 KB counts)
+#define GYS_HOST_MAX_LOCAL 2048u // listeners per host the LDS sub-table path supports (32 KB LDS table + 48 KB per-key areas + the tile image)
 
 struct ArenaLayout {
 	uint64_t off_hll8, off_u32, n_u32, off_i64sum, n_i64sum, off_i64max, n_i64max, total;
@@ -113,15 +113,12 @@ ArenaLayout arena_layout(uint32_t max_clusters)
 } // namespace
 
 #define GYS_SEG_RING 4
-#define GYS_KEY_PIPE 8 // key ranges per batch: k_key_pass of range i+1 (HBM-bound) overlaps the merges of range i (issue-bound)
 
 struct gys_ctx {
 	gys_config cfg{};
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
-	hipStream_t aux_stream = nullptr;              // the t-digest merges of a batch run here, pipelined against k_key_pass
-	hipEvent_t ev_chunk[GYS_KEY_PIPE] = {}, ev_aux = nullptr;
 	int ncu = 256;
 
 	// registries (host)
@@ -152,16 +149,22 @@ struct gys_ctx {
 	int64_t *td_sum = nullptr;
 	uint32_t *td_cnt = nullptr;
 	TdMeta *td_meta = nullptr;
-	uint32_t *td_pend = nullptr;
-	MergeEnt *merge_list = nullptr;
-	uint32_t *merge_count = nullptr; // [0] merge list length of the batch, [1] = 1 (length of a query list)
+	int2 *td_minmax = nullptr;
+	uint32_t *td_pend = nullptr;     // per service a buffer of pcap staged words ("per-key value buffers" in gys_kernels.hpp)
+	uint32_t *td_cur = nullptr;      // words in each buffer (== td_meta.npend between batches)
+	uint32_t *td_run = nullptr;      // spilled services: fill cursor of the run in `staged`
+	uint32_t *svc_host = nullptr;    // host slot of each service
+	uint32_t *host_spill = nullptr;  // per host: batch stamp of the last batch in which one of its services spilled
+	uint32_t spill_stamp = 0;
+	uint32_t pcap = 0;
+	MergeEnt *merge_list = nullptr, *huge_list = nullptr, *query_list = nullptr;
+	uint32_t *merge_count = nullptr; // [0] merge list length of the batch, [1] huge list length, [2] run allocation cursor, [4] = 1 (query list)
 	int64_t *query_sum = nullptr;    // scratch of the non-destructive merge behind gys_query_quantiles
 	uint32_t *query_cnt = nullptr;
 	uint32_t *batch_cnt = nullptr, *batch_off = nullptr, *scan_block_sums = nullptr;
-	uint64_t *ev_kv = nullptr;
+	uint64_t *ev_kv = nullptr;       // general front end: (slot, staged word) per event
 	uint64_t ev_kv_cap = 0; // events
-	uint32_t *staged = nullptr, *staged2 = nullptr; // double-buffered: the merges of batch b read theirs while batch b+1 is staged
-	int staged_sel = 0;
+	uint32_t *staged = nullptr;      // runs of the general front end / of spilled services
 	// the window boundary's fixed sequence of copies / clears, captured once per registry shape as a hipGraph and replayed
 	hipGraph_t win_graph = nullptr;
 	hipGraphExec_t win_graph_exec = nullptr;
@@ -169,8 +172,7 @@ struct gys_ctx {
 	int win_graph_state = 0;      // 0 not tried, 1 usable, -1 capture unavailable: plain launches
 	uint64_t win_graph_launches = 0;
 	int64_t i64min = INT64_MIN;   // stable host source of the graph's 8-byte copy
-	bool aux_pending = false; // merges still running on aux_stream (joined before the next per-key pass and before digest reads)
-	uint32_t *huge_list = nullptr, *huge_count = nullptr, *huge_scratch = nullptr;
+	uint32_t *huge_scratch = nullptr;
 	int huge_blocks = 0;
 	uint32_t *hll32 = nullptr;
 	unsigned long long *svc_ctr = nullptr;
@@ -190,12 +192,10 @@ struct gys_ctx {
 		gys_resp_seg *host = nullptr, *dev = nullptr;
 		uint32_t cap = 0;
 		hipEvent_t done = nullptr;
-		// split form of the host-local pipeline: [part descriptors as gys_resp_seg][SplitPart per part][SplitSeg per host segment]
+		// long segments cut into parts: the part descriptors (gys_resp_seg each)
 		uint8_t *xhost = nullptr, *xdev = nullptr;
 		uint64_t xcap = 0;
 	} seg_ring[GYS_SEG_RING];
-	uint32_t *split_cnt = nullptr; // count / cursor matrix of the split form (grow-only)
-	uint64_t split_cnt_cap = 0;
 	uint32_t seg_next = 0;
 
 	// reduce arena + last-window results
@@ -261,15 +261,6 @@ struct ProfScope {
 		e->launches++;
 	}
 };
-
-// main stream waits for the merges of the last batch (no-op when none are outstanding)
-inline void join_aux(gys_ctx *c)
-{
-	if (c->aux_pending) {
-		hipStreamWaitEvent(c->stream, c->ev_aux, 0);
-		c->aux_pending = false;
-	}
-}
 
 void prof_resolve(gys_ctx *c)
 {
@@ -429,81 +420,44 @@ int host_lst_add(gys_ctx *c, uint32_t host, const gys_listener_info *arr, uint32
 	return host_lst_upload(c, host);
 }
 
-// split form of the host-local pipeline ("few hosts, long segments" in gys_kernels.hpp): part descriptors, count matrix, three launches
-int run_resp_split(gys_ctx *c, gys_ctx::SegSlot &slot, const gys_resp_seg *segs_host, uint32_t nsegs, uint64_t n, RespHostP hp, size_t dyn)
+inline DigestP digest_params(gys_ctx *c)
 {
-	uint64_t nparts = 0, ncnt = 0;
-	for (uint32_t s = 0; s < nsegs; ++s) {
-		const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - segs_host[s].first_event;
-		const uint64_t np = (len + GYS_SPLIT_PART - 1) / GYS_SPLIT_PART;
-		nparts += np;
-		ncnt += np * c->host_lst[segs_host[s].host_slot].slots.size();
-	}
-	const uint64_t off_parts = align_up(nparts * sizeof(gys_resp_seg), 16), off_segs = align_up(off_parts + nparts * sizeof(SplitPart), 16);
-	const uint64_t xbytes = off_segs + (uint64_t)nsegs * sizeof(SplitSeg);
-	if (xbytes > slot.xcap) {
-		if (slot.xhost) HIPCHK(hipHostFree(slot.xhost));
-		if (slot.xdev) HIPCHK(hipFree(slot.xdev));
-		slot.xhost = slot.xdev = nullptr;
-		slot.xcap = std::max<uint64_t>(xbytes, 1u << 16);
-		HIPCHK(hipHostMalloc((void **)&slot.xhost, slot.xcap, hipHostMallocDefault));
-		HIPCHK(hipMalloc((void **)&slot.xdev, slot.xcap));
-	}
-	if (ncnt + 1 > c->split_cnt_cap) {
-		HIPCHK(hipStreamSynchronize(c->stream)); // an earlier batch may still be using the old matrix
-		if (c->split_cnt) HIPCHK(hipFree(c->split_cnt));
-		c->split_cnt = nullptr;
-		c->split_cnt_cap = align_up(ncnt + 1, 1u << 16);
-		HIPCHK(hipMalloc((void **)&c->split_cnt, c->split_cnt_cap * 4));
-	}
-	gys_resp_seg *vseg = (gys_resp_seg *)slot.xhost;
-	SplitPart *parts = (SplitPart *)(slot.xhost + off_parts);
-	SplitSeg *rsegs = (SplitSeg *)(slot.xhost + off_segs);
-	uint64_t v = 0, cnt_off = 0;
-	for (uint32_t s = 0; s < nsegs; ++s) {
-		const uint64_t first = segs_host[s].first_event;
-		const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - first;
-		const uint32_t L = (uint32_t)c->host_lst[segs_host[s].host_slot].slots.size();
-		const uint64_t np = (len + GYS_SPLIT_PART - 1) / GYS_SPLIT_PART;
-		rsegs[s] = SplitSeg{first, segs_host[s].host_slot, (uint32_t)np, (uint32_t)cnt_off, 0u};
-		for (uint64_t q = 0; q < np; ++q, ++v) {
-			vseg[v] = gys_resp_seg{segs_host[s].host_slot, 0u, first + q * GYS_SPLIT_PART};
-			parts[v] = SplitPart{first, (uint32_t)cnt_off, 0u};
-			cnt_off += L;
-		}
-	}
-	if (cnt_off >= (1ull << 32)) {
-		set_err("split count matrix too large");
-		return GYS_ERR_INVAL;
-	}
-	HIPCHK(hipMemcpyAsync(slot.xdev, slot.xhost, xbytes, hipMemcpyHostToDevice, c->stream));
-	hp.segs = (const gys_resp_seg *)slot.xdev;
-	hp.nsegs = (uint32_t)nparts;
-	hp.parts = (const SplitPart *)(slot.xdev + off_parts);
-	hp.split_cnt = c->split_cnt;
-	{
-		ProfScope ps(c, "resp_host");
-		hipLaunchKernelGGL((k_resp_host<true, 1>), dim3((uint32_t)nparts), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
-	}
-	{
-		ProfScope ps(c, "resp_split_scan");
-		SplitScanP sp{};
-		sp.segs = (const SplitSeg *)(slot.xdev + off_segs);
-		sp.hdesc = c->hdesc;
-		sp.hlst = c->hlst;
-		sp.split_cnt = c->split_cnt;
-		sp.batch_cnt = hp.batch_cnt;
-		sp.off_end = hp.off_end;
-		sp.huge_list = hp.huge_list;
-		sp.huge_count = hp.huge_count;
-		hipLaunchKernelGGL(k_split_scan, dim3(nsegs), dim3(GYS_HOST_THREADS), 0, c->stream, sp);
-	}
-	{
-		ProfScope ps(c, "resp_host_scatter");
-		hipLaunchKernelGGL((k_resp_host<true, 2>), dim3((uint32_t)nparts), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
-	}
+	DigestP d{};
+	d.td_sum = c->td_sum;
+	d.td_cnt = c->td_cnt;
+	d.td_meta = c->td_meta;
+	d.td_minmax = c->td_minmax;
+	d.td_pend = c->td_pend;
+	d.td_cur = c->td_cur;
+	d.pcap = c->pcap;
+	d.nsvc = c->nsvc;
+	d.staged = c->staged;
+	d.hist_win = c->hist_win;
+	d.hist_all = c->hist_all;
+	d.bitmap = c->bitmap;
+	return d;
+}
+
+// lazy fold (t-digest on): the records of services [first, first + n) are brought up to date with their buffered values before
+// anything reads them ("per-key value buffers" in gys_kernels.hpp)
+int fold_range(gys_ctx *c, uint32_t first, uint32_t n)
+{
+	if (!c->cfg.enable_tdigest || !n) return GYS_OK;
+	FoldP f{};
+	f.d = digest_params(c);
+	f.first = first;
+	f.n = n;
+	ProfScope ps(c, "fold");
+	const uint32_t nchunks = (n + 63u) / 64u;
+	hipLaunchKernelGGL(k_fold, dim3(std::min<uint32_t>((nchunks + 3u) / 4u, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, f);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
+}
+
+template <int TPT, bool SHARED, bool SPILL>
+void launch_resp_host(gys_ctx *c, uint32_t grid, size_t dyn, const RespHostP &hp)
+{
+	hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL>), dim3(grid), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
 }
 
 // resp pipeline on a device-resident batch
@@ -519,12 +473,12 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		set_err("batch of %llu events exceeds max_batch_events %llu", (unsigned long long)n, (unsigned long long)c->cfg.max_batch_events);
 		return GYS_ERR_NOMEM;
 	}
-	if (n >= (1ull << 32)) {
+	if (n >= (1ull << 31)) {
 		set_err("batch too large (u32 offsets)");
 		return GYS_ERR_INVAL;
 	}
 	for (uint32_t s = 0; s < nsegs; ++s) {
-		if (segs_host[s].host_slot >= c->hosts.size() || (s && segs_host[s].first_event < segs_host[s - 1].first_event)) {
+		if (segs_host[s].host_slot >= c->hosts.size() || segs_host[s].first_event > n || (s && segs_host[s].first_event < segs_host[s - 1].first_event)) {
 			set_err("bad resp segment %u", s);
 			return GYS_ERR_INVAL;
 		}
@@ -543,10 +497,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	}
 	memcpy(slot.host, segs_host, (uint64_t)nsegs * sizeof(gys_resp_seg));
 	HIPCHK(hipMemcpyAsync(slot.dev, slot.host, (uint64_t)nsegs * sizeof(gys_resp_seg), hipMemcpyHostToDevice, c->stream));
-	gys_resp_seg *segs_dev = slot.dev;
+	const gys_resp_seg *segs_dev = slot.dev;
 
-	// ---- pipeline choice: host-local (one workgroup per host segment, LDS sub-table + LDS counting sort) when every segment is a
-	// distinct host with an LDS-sized listener table and the segments are small enough to balance; otherwise the general pipeline
+	// ---- front end choice: host-local (one workgroup per host segment, LDS sub-table + tile-wise LDS counting sort straight into the
+	// services' value buffers) when every segment is a distinct host with an LDS-sized listener table; otherwise the general front end
 	bool host_local = td && c->cfg.resp_path != 1 && c->nsvc != 0, host_split = false;
 	uint32_t max_tbl = 16, max_l = 1;
 	uint64_t max_len = 0;
@@ -562,24 +516,23 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			max_tbl = std::max<uint32_t>(max_tbl, (uint32_t)hl.tbl.size());
 			max_l = std::max<uint32_t>(max_l, (uint32_t)hl.slots.size());
 		}
-		// split form (segments cut into parts of GYS_SPLIT_PART events, three launches): whole chip at ~30 G events/s whatever the
-		// number of hosts, but two passes more over the per-event records than the fused form
-		const double t_host = (double)((nsegs + c->ncu - 1) / c->ncu) * (double)max_len / 0.26e9;
-		const double t_split = (double)n / 30.0e9 + 40e-6;
+		// few hosts with long segments: one workgroup per segment would leave most of the chip idle, so the segments are cut into parts
+		// of GYS_SPLIT_PART events (SHARED form: buffer space reserved with device atomics).  A workgroup walks ~0.35 G events/s.
+		const double t_host = (double)((nsegs + c->ncu - 1) / c->ncu) * (double)max_len / 0.35e9;
+		const double t_split = (double)n / 40.0e9 + 20e-6;
 		if (host_local && max_len > GYS_SPLIT_PART && (c->cfg.resp_path == 3 || (c->cfg.resp_path == 0 && t_split < t_host))) host_split = true;
-		if (host_local && !host_split && c->cfg.resp_path == 0) {
-			// one workgroup walks a whole segment (~0.26 G events/s each, ncu of them at a time); the general pipeline spreads any
-			// batch over the whole chip at ~7 G events/s: take whichever model is faster, small batches always host-local
-			const double t_general = (double)n / 7.0e9 + 20e-6;
-			host_local = max_len <= (1u << 15) || t_host <= t_general;
-		}
 	}
 	const uint32_t nsvc = c->nsvc;
 	uint32_t *cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
-	uint32_t *staged_cur = c->staged_sel ? c->staged2 : c->staged;
+	unsigned long long *ghist = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
+	long long *gmax = (long long *)(c->arena + c->al.off_i64max);
+	if (td) HIPCHK(hipMemsetAsync(c->merge_count, 0, 16, c->stream)); // merge / huge list lengths, run allocation cursor
+	RespHostP hp{};
+	uint32_t hgrid = 0;
+	size_t dyn = 0;
+	static const int tpt = [] { const char *e = getenv("GYS_TPT"); return (e && atoi(e) == 16) ? 16 : 8; }();
+	bool tpt16 = false;
 	if (host_local) {
-		c->n_batches_host_local++;
-		RespHostP hp{};
 		hp.ev = (const uint64_t *)d_ev;
 		hp.n = n;
 		hp.segs = segs_dev;
@@ -588,42 +541,62 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hp.htbl = c->htbl;
 		hp.hlst = c->hlst;
 		hp.hll32 = c->hll32;
-		hp.batch_cnt = c->batch_cnt;
-		hp.off_end = c->batch_off;
-		hp.ev_w = (uint32_t *)c->ev_kv;                              // the 8-B-per-event scratch of the general pipeline holds the host-local
-		hp.ev_row = (uint8_t *)c->ev_kv + (size_t)c->ev_kv_cap * 4; // pipeline's 4-B words followed by its 1-B rows
-		hp.staged = staged_cur;
-		hp.huge_list = c->huge_list;
-		hp.huge_count = c->huge_count;
+		hp.td_cur = c->td_cur;
+		hp.td_pend = c->td_pend;
+		hp.pcap = c->pcap;
+		hp.td_run = c->td_run;
+		hp.staged = c->staged;
+		hp.host_spill = c->host_spill;
+		hp.spill_stamp = ++c->spill_stamp;
 		hp.counters = c->counters;
 		hp.svc_hll = c->svc_hll;
 		hp.svc_hll_p = c->cfg.svc_hll_p;
+		hp.ghist = ghist;
+		hp.gmax = gmax;
 		hp.lds_tbl_entries = max_tbl;
-		hp.lds_cnt_entries = (uint32_t)align_up(max_l, 2);
-		{
-			// LDS budget of one workgroup: sub-table + counts + the scatter region; the region is used when the longest segment
-			// fits in what is left of ~150 KiB (one 1024-thread workgroup per CU then), otherwise segments scatter straight to HBM
-			const uint64_t fixed = (uint64_t)max_tbl * 8 + (uint64_t)hp.lds_cnt_entries * 4;
-			const uint64_t budget = 150u * 1024u;
-			hp.lds_region_entries = (fixed + max_len * 4 <= budget) ? (uint32_t)align_up(max_len, 2) : 0u;
-			// longer segments: tile by tile through an image of GYS_HOST_TILE words + their destinations (+ two count arrays)
-			const uint64_t tile_entries = 2ull * hp.lds_cnt_entries + 2ull * GYS_HOST_TILE;
-			if (!hp.lds_region_entries && fixed + tile_entries * 4 <= budget) {
-				hp.lds_region_entries = (uint32_t)tile_entries;
-				hp.lds_tile_events = GYS_HOST_TILE;
+		hp.lds_key_entries = (uint32_t)align_up(max_l, 2);
+		hgrid = nsegs;
+		if (host_split) {
+			uint64_t nparts = 0;
+			for (uint32_t s = 0; s < nsegs; ++s) {
+				const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - segs_host[s].first_event;
+				nparts += (len + GYS_SPLIT_PART - 1) / GYS_SPLIT_PART;
 			}
-		}
-		const size_t dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_cnt_entries * 4 + (size_t)hp.lds_region_entries * 4;
-		HIPCHK(hipMemsetAsync(c->huge_count, 0, 4, c->stream));
-		if (host_split && hp.lds_tile_events) {
-			const int rcs = run_resp_split(c, slot, segs_host, nsegs, n, hp, dyn);
-			if (rcs) return rcs;
-			c->n_batches_host_local--;
+			const uint64_t xbytes = nparts * sizeof(gys_resp_seg);
+			if (xbytes > slot.xcap) {
+				if (slot.xhost) HIPCHK(hipHostFree(slot.xhost));
+				if (slot.xdev) HIPCHK(hipFree(slot.xdev));
+				slot.xhost = slot.xdev = nullptr;
+				slot.xcap = std::max<uint64_t>(xbytes, 1u << 16);
+				HIPCHK(hipHostMalloc((void **)&slot.xhost, slot.xcap, hipHostMallocDefault));
+				HIPCHK(hipMalloc((void **)&slot.xdev, slot.xcap));
+			}
+			gys_resp_seg *vseg = (gys_resp_seg *)slot.xhost;
+			uint64_t v = 0;
+			for (uint32_t s = 0; s < nsegs; ++s) {
+				const uint64_t first = segs_host[s].first_event;
+				const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - first;
+				for (uint64_t q = 0; q * GYS_SPLIT_PART < len; ++q) vseg[v++] = gys_resp_seg{segs_host[s].host_slot, 0u, first + q * GYS_SPLIT_PART};
+			}
+			HIPCHK(hipMemcpyAsync(slot.xdev, slot.xhost, xbytes, hipMemcpyHostToDevice, c->stream));
+			hp.segs = (const gys_resp_seg *)slot.xdev;
+			hp.nsegs = (uint32_t)nparts;
+			hgrid = (uint32_t)nparts;
 			c->n_batches_host_split++;
 		} else {
+			c->n_batches_host_local++;
+		}
+		tpt16 = tpt == 16 && (uint64_t)max_tbl * 8 + (uint64_t)hp.lds_key_entries * 24 + 16384u * 6u <= 150u * 1024u;
+		dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_key_entries * 24 + (size_t)(tpt16 ? 16384u : 8192u) * 6u;
+		{
 			ProfScope ps(c, "resp_host");
-			if (hp.lds_tile_events) hipLaunchKernelGGL(k_resp_host<true>, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
-			else hipLaunchKernelGGL(k_resp_host<false>, dim3(nsegs), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+			if (host_split) {
+				if (tpt16) launch_resp_host<16, true, false>(c, hgrid, dyn, hp);
+				else launch_resp_host<8, true, false>(c, hgrid, dyn, hp);
+			} else {
+				if (tpt16) launch_resp_host<16, false, false>(c, hgrid, dyn, hp);
+				else launch_resp_host<8, false, false>(c, hgrid, dyn, hp);
+			}
 		}
 	} else {
 		c->n_batches_general++;
@@ -643,6 +616,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		p.counters = c->counters;
 		p.svc_hll = c->svc_hll;
 		p.svc_hll_p = c->cfg.svc_hll_p;
+		p.ghist = ghist;
+		p.gmax = gmax;
 		{
 			ProfScope ps(c, "resp_pass1");
 			hipLaunchKernelGGL(k_resp_pass1, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
@@ -655,95 +630,82 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		const uint32_t nblk = (nsvc + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE;
 		{
 			ProfScope ps(c, "scan");
-			HIPCHK(hipMemsetAsync(c->huge_count, 0, 4, c->stream));
 			hipLaunchKernelGGL(k_scan_block_sums, dim3(nblk), dim3(256), 0, c->stream, c->batch_cnt, nsvc, c->scan_block_sums);
 			hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, c->stream, c->scan_block_sums, nblk);
-			hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, c->stream, c->batch_cnt, nsvc, c->scan_block_sums, c->batch_off, c->huge_list,
-					   c->huge_count);
+			hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, c->stream, c->batch_cnt, nsvc, c->scan_block_sums, c->batch_off);
 		}
 		{
 			ProfScope ps(c, "scatter");
-			hipLaunchKernelGGL(k_resp_scatter, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->ev_kv, n, c->batch_off,
-					   staged_cur);
+			hipLaunchKernelGGL(k_resp_scatter, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->ev_kv, n, c->batch_off, c->staged);
+		}
+		{
+			ProfScope ps(c, "key_append");
+			AppendP ap{};
+			ap.batch_cnt = c->batch_cnt;
+			ap.off_end = c->batch_off;
+			ap.staged = c->staged;
+			ap.td_cur = c->td_cur;
+			ap.td_pend = c->td_pend;
+			ap.pcap = c->pcap;
+			ap.nsvc = nsvc;
+			const uint32_t nchunks = (nsvc + 63u) / 64u;
+			hipLaunchKernelGGL(k_key_append, dim3(std::min<uint32_t>((nchunks + 3u) / 4u, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, ap);
 		}
 	}
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(slot.done, c->stream)); // the segment descriptors have been consumed once the stream gets here
-	DigestP d{};
-	d.td_sum = c->td_sum;
-	d.td_cnt = c->td_cnt;
-	d.td_meta = c->td_meta;
-	d.td_pend = c->td_pend;
-	d.merge_list = c->merge_list;
-	d.merge_count = c->merge_count;
-	d.hist_all = c->hist_all;
-	d.epoch = c->epoch;
-	d.chunk_lo = 0;
-	d.chunk_hi = (c->nsvc + 63u) / 64u;
-	d.ghist = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
-	d.gmax = (long long *)(c->arena + c->al.off_i64max);
-	d.batch_cnt = c->batch_cnt;
-	d.off_end = c->batch_off;
-	d.staged = staged_cur;
-	d.nsvc = nsvc;
-	d.hist_win = c->hist_win;
-	d.cms32 = cms32;
-	d.svc_gid = c->svc_gid;
-	d.bitmap = c->bitmap;
 	{
-		// The per-key pass is HBM-bound, the merges it queues are instruction-issue bound: the keys are cut into GYS_KEY_PIPE ranges,
-		// k_key_pass walks them on the main stream and each range's merges start on the auxiliary stream as soon as its list is
-		// complete, so the two kinds of work share the chip.  (Merge lists are per range: at most one entry per key.)
-		const uint32_t nchunks = (nsvc + 63u) / 64u;
-		const uint32_t npipe = nchunks >= 4096u ? GYS_KEY_PIPE : 1u;
-		const uint32_t per = (nchunks + npipe - 1) / npipe;
-		// GYS_NO_OVERLAP=1 serialises the two streams (A/B timing; results are identical either way)
-		static const char *no_ov = getenv("GYS_NO_OVERLAP");
-		const bool overlap = !(no_ov && no_ov[0] == '1');
-		// the previous batch's merges may still be running (they overlapped this batch's resp pass, which only touches its own staging
-		// buffer): the per-key pass appends to the digest buffers and must see them finished
-		join_aux(c);
-		HIPCHK(hipMemsetAsync(c->merge_count, 0, 4 * GYS_KEY_PIPE, c->stream));
-		for (uint32_t r = 0; r < npipe; ++r) {
-			const uint32_t lo = r * per, hi = std::min(nchunks, lo + per);
-			if (lo >= hi) break;
-			DigestP dr = d;
-			dr.chunk_lo = lo;
-			dr.chunk_hi = hi;
-			dr.merge_list = c->merge_list + (size_t)lo * 64u;
-			dr.merge_count = c->merge_count + r;
-			{
-				ProfScope ps(c, "key_pass");
-				hipLaunchKernelGGL(k_key_pass, dim3(std::min<uint32_t>((hi - lo + 3) / 4, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, dr);
-			}
-			hipStream_t ms = c->stream;
-			if (overlap && npipe > 1) {
-				HIPCHK(hipEventRecord(c->ev_chunk[r], c->stream));
-				HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_chunk[r], 0));
-				ms = c->aux_stream;
-			}
-			ProfScope ps(c, "digest_merge", ms);
-			MergeP mp{};
-			mp.d = dr;
-			mp.list = dr.merge_list;
-			mp.count = dr.merge_count;
-			const uint32_t mgrid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>((uint64_t)(hi - lo) * 64u, n), (uint64_t)c->ncu * 32);
-			hipLaunchKernelGGL(k_digest_merge<128u>, dim3(mgrid), dim3(64), 0, ms, mp);
-			hipLaunchKernelGGL(k_digest_merge<384u>, dim3(std::min<uint32_t>(mgrid, (uint32_t)c->ncu * 16)), dim3(64), 0, ms, mp);
-			hipLaunchKernelGGL(k_digest_merge<GYS_SMALL_MAX>, dim3(std::min<uint32_t>(mgrid, (uint32_t)c->ncu * 8)), dim3(64), 0, ms, mp);
+		ProfScope ps(c, "key_finalize");
+		FinP f{};
+		f.td_cur = c->td_cur;
+		f.td_meta = c->td_meta;
+		f.nsvc = nsvc;
+		f.pcap = c->pcap;
+		f.epoch = c->epoch;
+		f.cms32 = cms32;
+		f.svc_gid = c->svc_gid;
+		f.merge_list = c->merge_list;
+		f.huge_list = c->huge_list;
+		f.merge_count = c->merge_count;
+		f.huge_count = c->merge_count + 1;
+		f.run_alloc = c->merge_count + 2;
+		f.td_run = c->td_run;
+		f.batch_off = host_local ? nullptr : c->batch_off;
+		f.svc_host = c->svc_host;
+		f.host_spill = c->host_spill;
+		f.spill_stamp = hp.spill_stamp;
+		hipLaunchKernelGGL(k_key_finalize, dim3((nsvc + 255) / 256), dim3(256), 0, c->stream, f);
+	}
+	if (host_local) {
+		// second pass over the hosts that have spilled services (a workgroup of any other host returns at once): their events again,
+		// only the spilled services' values, into the runs k_key_finalize allocated in `staged`
+		ProfScope ps(c, "resp_spill");
+		if (tpt16) launch_resp_host<16, true, true>(c, hgrid, dyn, hp);
+		else launch_resp_host<8, true, true>(c, hgrid, dyn, hp);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(slot.done, c->stream)); // the segment descriptors have been consumed once the stream gets here
+	{
+		MergeP mp{};
+		mp.d = digest_params(c);
+		mp.list = c->merge_list;
+		mp.count = c->merge_count;
+		const uint32_t cap = (uint32_t)std::min<uint64_t>(nsvc, n);
+		{
+			ProfScope ps(c, "digest_merge");
+			hipLaunchKernelGGL((k_digest_merge<1024u, 0u, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 7))), dim3(256), 0, c->stream, mp);
 		}
-		if (overlap && npipe > 1) { // not joined here: the next batch's resp pass may start while the last merges finish (join_aux)
-			HIPCHK(hipEventRecord(c->ev_aux, c->aux_stream));
-			c->aux_pending = true;
+		{
+			ProfScope ps(c, "digest_merge_big");
+			hipLaunchKernelGGL((k_digest_merge<4096u, 1024u, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 3))), dim3(256), 0, c->stream, mp);
+			hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_LDS_MAX, 4096u, 1024u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(1024), 0, c->stream, mp);
 		}
-		c->staged_sel ^= 1;
 	}
 	{
 		ProfScope ps(c, "digest_huge");
 		HugeP h{};
-		h.d = d;
+		h.d = digest_params(c);
 		h.huge_list = c->huge_list;
-		h.huge_count = c->huge_count;
+		h.huge_count = c->merge_count + 1;
 		h.scratch = c->huge_scratch;
 		hipLaunchKernelGGL(k_digest_huge, dim3(c->huge_blocks), dim3(256), 0, c->stream, h);
 	}
@@ -769,6 +731,10 @@ int level_roll(gys_ctx *c, uint64_t tusec)
 {
 	int64_t tnow = (int64_t)(tusec / 1000000ull);
 	if (tnow < c->lvl_t_last) tnow = c->lvl_t_last; // time does not go backwards (BucketedTimeSeries::update)
+	{
+		const int rcf = fold_range(c, 0, c->nsvc); // every service's closing-window record must be complete
+		if (rcf) return rcf;
+	}
 	LevelRollP p{};
 	p.win = c->hist_win;
 	p.all = c->hist_all;
@@ -925,7 +891,8 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		return GYS_ERR_INVAL;
 	}
 	if (!cfg->max_hosts || !cfg->max_services || cfg->max_hosts > 65534 || !cfg->max_clusters || cfg->nranks == 0 || cfg->rank >= cfg->nranks ||
-	    (cfg->svc_hll_p && (cfg->svc_hll_p < 4 || cfg->svc_hll_p > 10))) {
+	    (cfg->svc_hll_p && (cfg->svc_hll_p < 4 || cfg->svc_hll_p > 10)) ||
+	    (cfg->td_buf_values && (cfg->td_buf_values < GYS_TD_PEND_CAP + 64u || cfg->td_buf_values > GYS_PCAP_MAX))) {
 		set_err("bad config values");
 		return GYS_ERR_INVAL;
 	}
@@ -952,9 +919,6 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		c->own_stream = true;
 	}
-	HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-	for (int i = 0; i < GYS_KEY_PIPE; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
-	HIPCHK(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
 	const uint64_t S = cfg->max_services, H = cfg->max_hosts;
 	const uint32_t cap = next_pow2(S * 2);
 	int rc;
@@ -991,12 +955,16 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	ALLOC(c->htbl, c->htbl_cap);
 	ALLOC(c->hlst, c->hlst_cap);
 	ALLOC(c->hdesc, H);
+	ALLOC(c->svc_host, S);
+	ALLOC(c->host_spill, H);
 	c->host_lst.reserve(H);
-	// k_resp_host: up to 8192 sub-table entries + 4096 counts (80 KiB) or, for the usual small tables, a scatter region (<= 150 KiB in all)
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+	// k_resp_host: up to 4096 sub-table entries (32 KiB) + 2048 x 24 B of per-key areas (48 KiB) + the tile image (48 or 96 KiB)
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<16, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<16, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
 	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_levels) {
@@ -1007,12 +975,28 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	}
 	if (cfg->enable_tdigest) {
 		const uint64_t B = cfg->max_batch_events ? cfg->max_batch_events : 1;
+		// value buffer of a service: GYS_TD_PEND_CAP values wait for a merge, the rest is room for one batch's values of the service
+		// (a batch that does not fit takes the slower spill path); sized to the services, within ~40 GiB unless the caller says otherwise
+		if (cfg->td_buf_values) {
+			c->pcap = cfg->td_buf_values;
+		} else {
+			const uint64_t fit = ((40ull << 30) / (4 * S)) / 256 * 256;
+			c->pcap = (uint32_t)std::min<uint64_t>(GYS_PCAP_MAX, std::max<uint64_t>(1024, fit));
+		}
 		ALLOC(c->td_sum, S * GYS_TD_NB);
 		ALLOC(c->td_cnt, S * GYS_TD_NB);
 		ALLOC(c->td_meta, S);
-		ALLOC(c->td_pend, S * GYS_TD_PEND_CAP);
+		ALLOC(c->td_minmax, S);
+		ALLOC(c->td_cur, align_up(S, 64));
+		ALLOC(c->td_run, S);
+		if ((rc = dev_alloc(&c->td_pend, S * c->pcap, false)) != GYS_OK) { // never read before written: no clear of (up to) tens of GB
+			gys_destroy(c);
+			return rc;
+		}
 		ALLOC(c->merge_list, std::min<uint64_t>(S, B) + 1);
-		ALLOC(c->merge_count, GYS_KEY_PIPE + 2);
+		ALLOC(c->huge_list, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1) + 1);
+		ALLOC(c->query_list, 4);
+		ALLOC(c->merge_count, 8);
 		ALLOC(c->query_sum, GYS_TD_NB);
 		ALLOC(c->query_cnt, GYS_TD_NB);
 		ALLOC(c->batch_cnt, align_up(S, 16));
@@ -1021,10 +1005,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		ALLOC(c->ev_kv, B);
 		c->ev_kv_cap = B;
 		ALLOC(c->staged, B);
-		ALLOC(c->staged2, B);
-		ALLOC(c->huge_list, std::min<uint64_t>(S, B / GYS_SMALL_MAX + 1));
-		ALLOC(c->huge_count, 1);
-		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_SMALL_MAX + 1));
+		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1));
 		if (c->huge_blocks < 1) c->huge_blocks = 1;
 		ALLOC(c->huge_scratch, (uint64_t)c->huge_blocks * GYS_HUGE_BINS);
 	}
@@ -1033,9 +1014,9 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	// initialisation kernels / copies below must not start before every one of those clears has landed
 	HIPCHK(hipDeviceSynchronize());
 	if (cfg->enable_tdigest) {
-		hipLaunchKernelGGL(k_tdmeta_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, (uint4 *)c->td_meta, S);
+		hipLaunchKernelGGL(k_minmax_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->td_minmax, S);
 		static const uint32_t one = 1; // static: the source of an async copy must outlive the call
-		HIPCHK(hipMemcpyAsync(c->merge_count + GYS_KEY_PIPE, &one, 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(c->merge_count + 4, &one, 4, hipMemcpyHostToDevice, c->stream));
 	}
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_win, (uint64_t)0, S, (int64_t)INT64_MIN);
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_all, (uint64_t)0, S, (int64_t)INT64_MIN);
@@ -1071,7 +1052,6 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 void gys_destroy(gys_ctx *c)
 {
 	if (!c) return;
-	if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	if (c->win_graph_exec) hipGraphExecDestroy(c->win_graph_exec);
 	if (c->win_graph) hipGraphDestroy(c->win_graph);
@@ -1084,20 +1064,13 @@ void gys_destroy(gys_ctx *c)
 	}
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
-			c->td_cnt, c->td_meta, c->td_pend, c->merge_list, c->merge_count, c->query_sum, c->query_cnt, c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->staged2, c->huge_list, c->huge_count,
-			c->huge_scratch, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
+			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
+			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
-			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->split_cnt, c->lvl_snap, c->lvl_last, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
+			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
-	if (c->aux_stream) {
-		hipStreamSynchronize(c->aux_stream);
-		hipStreamDestroy(c->aux_stream);
-	}
-	for (int i = 0; i < GYS_KEY_PIPE; ++i)
-		if (c->ev_chunk[i]) hipEventDestroy(c->ev_chunk[i]);
-	if (c->ev_aux) hipEventDestroy(c->ev_aux);
 	if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -1105,7 +1078,6 @@ void gys_destroy(gys_ctx *c)
 int gys_sync(gys_ctx *c)
 {
 	if (!c) return GYS_ERR_INVAL;
-	join_aux(c);
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
 }
@@ -1199,6 +1171,11 @@ int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_l
 	if (nfail) {
 		set_err("key table full (%u inserts failed)", nfail);
 		return GYS_ERR_NOMEM;
+	}
+	{
+		std::vector<uint32_t> hs(n, host);
+		HIPCHK(hipMemcpyAsync(c->svc_host + c->nsvc, hs.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
 	}
 	rc = host_lst_add(c, host, arr, n, c->nsvc);
 	if (rc) return rc;
@@ -1371,7 +1348,7 @@ int wire_decode(gys_ctx *c, const uint8_t *d_buf, uint64_t nbytes, std::vector<W
 	const uint32_t nblk = (nslots + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE;
 	hipLaunchKernelGGL(k_scan_block_sums, dim3(nblk), b, 0, c->stream, c->wire_cnt, nslots, c->wire_bsums);
 	hipLaunchKernelGGL(k_scan_top, dim3(1), b, 0, c->stream, c->wire_bsums, nblk);
-	hipLaunchKernelGGL(k_scan_final, dim3(nblk), b, 0, c->stream, c->wire_cnt, nslots, c->wire_bsums, c->wire_rank, c->wire_status + 2, c->wire_status + 1);
+	hipLaunchKernelGGL(k_scan_final, dim3(nblk), b, 0, c->stream, c->wire_cnt, nslots, c->wire_bsums, c->wire_rank);
 	hipLaunchKernelGGL(k_wire_emit, gs, b, 0, c->stream, c->wire_msgs, nmsgs, nslots, c->wire_cnt, c->wire_rank, c->wire_flags, c->dev_offsets, c->wire_status);
 	hipLaunchKernelGGL(k_wire_check, gm, b, 0, c->stream, c->wire_msgs, nmsgs, nslots, c->wire_cnt, c->wire_rank, c->wire_status);
 	HIPCHK(hipGetLastError());
@@ -1534,9 +1511,9 @@ int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 		}
 		hipLaunchKernelGGL(k_window_prepare, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, p);
 		if (c->nsvc && !c->cfg.enable_tdigest) {
-			// eager mode (no per-key pass): all-time += window (GY_HISTOGRAM::add_histogram), window cleared, and the all-service
-			// histogram of the window reduced into the arena in the same pass over the records.  With the t-digest on, keys roll
-			// lazily inside k_key_pass / k_digest_huge ("Lazy window roll" in gys_kernels.hpp) and there is nothing to sweep here.
+			// eager mode (records updated per event): all-time += window (GY_HISTOGRAM::add_histogram), window cleared, and the all-service
+			// histogram of the window reduced into the arena in the same pass over the records.  With the t-digest on, the records are
+			// folded lazily from the value buffers ("per-key value buffers" in gys_kernels.hpp) and there is nothing to sweep here.
 			long long *gh = (long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
 			hipLaunchKernelGGL(k_hist_fold, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->hist_all,
 					   c->hist_win, (uint64_t)c->nsvc, 1, gh, (long long *)(c->arena + c->al.off_i64max));
@@ -1720,27 +1697,32 @@ static double td_quantile_host(const int64_t *sum, const uint32_t *cnt, int32_t 
 
 // merged view of one service's digest = its clusters re-clustered with its buffered values (k_digest_merge in query mode: the state
 // is not modified)
-static int td_merged_view(gys_ctx *c, uint32_t slot, int64_t *sum, uint32_t *cnt, TdMeta *mt)
+static int td_merged_view(gys_ctx *c, uint32_t slot, int64_t *sum, uint32_t *cnt, int32_t *vmin, int32_t *vmax)
 {
-	join_aux(c); // the last batch's merges may still be running (and still reading merge_list)
-	const MergeEnt ent{slot, 0u, 0u, 0u};
-	HIPCHK(hipMemcpyAsync(c->merge_list, &ent, sizeof(ent), hipMemcpyHostToDevice, c->stream));
+	int rc = fold_range(c, slot, 1); // min / max must cover the buffered values
+	if (rc) return rc;
+	TdMeta mt;
+	HIPCHK(hipMemcpyAsync(&mt, c->td_meta + slot, sizeof(mt), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	const MergeEnt ent{slot, mt.npend, 0u, 0u};
+	HIPCHK(hipMemcpyAsync(c->query_list, &ent, sizeof(ent), hipMemcpyHostToDevice, c->stream));
 	MergeP mp{};
-	mp.d.td_sum = c->td_sum;
-	mp.d.td_cnt = c->td_cnt;
-	mp.d.td_meta = c->td_meta;
-	mp.d.td_pend = c->td_pend;
-	mp.d.staged = c->staged;
-	mp.list = c->merge_list;
-	mp.count = c->merge_count + GYS_KEY_PIPE;
+	mp.d = digest_params(c);
+	mp.list = c->query_list;
+	mp.count = c->merge_count + 4;
 	mp.out_sum = c->query_sum;
 	mp.out_cnt = c->query_cnt;
-	hipLaunchKernelGGL(k_digest_merge<128u>, dim3(1), dim3(64), 0, c->stream, mp);
+	if (mt.npend <= 1024u) hipLaunchKernelGGL((k_digest_merge<1024u, 0u, 256u>), dim3(1), dim3(256), 0, c->stream, mp);
+	else if (mt.npend <= 4096u) hipLaunchKernelGGL((k_digest_merge<4096u, 1024u, 256u>), dim3(1), dim3(256), 0, c->stream, mp);
+	else hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_LDS_MAX, 4096u, 1024u>), dim3(1), dim3(1024), 0, c->stream, mp);
 	HIPCHK(hipGetLastError());
+	int2 mm;
 	HIPCHK(hipMemcpyAsync(sum, c->query_sum, sizeof(int64_t) * GYS_TD_NB, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(cnt, c->query_cnt, sizeof(uint32_t) * GYS_TD_NB, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(mt, c->td_meta + slot, sizeof(*mt), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(&mm, c->td_minmax + slot, sizeof(mm), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	*vmin = mm.x;
+	*vmax = mm.y;
 	return GYS_OK;
 }
 
@@ -1759,10 +1741,10 @@ int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t 
 	if (rc) return rc;
 	int64_t sum[GYS_TD_NB];
 	uint32_t cnt[GYS_TD_NB];
-	TdMeta mt;
-	rc = td_merged_view(c, slot, sum, cnt, &mt);
+	int32_t vmin, vmax;
+	rc = td_merged_view(c, slot, sum, cnt, &vmin, &vmax);
 	if (rc) return rc;
-	for (uint32_t i = 0; i < nq; ++i) out[i] = td_quantile_host(sum, cnt, mt.vmin, mt.vmax, q[i]);
+	for (uint32_t i = 0; i < nq; ++i) out[i] = td_quantile_host(sum, cnt, vmin, vmax, q[i]);
 	return GYS_OK;
 }
 
@@ -1782,8 +1764,8 @@ static int td_sql_centroids(gys_ctx *c, uint64_t glob_id, double *mean, int64_t 
 	if (rc) return rc;
 	int64_t sum[GYS_TD_NB];
 	uint32_t cnt[GYS_TD_NB];
-	TdMeta mt;
-	rc = td_merged_view(c, slot, sum, cnt, &mt);
+	int32_t vmin, vmax;
+	rc = td_merged_view(c, slot, sum, cnt, &vmin, &vmax);
 	if (rc) return rc;
 	*k = 0;
 	*total = 0;
@@ -1947,6 +1929,10 @@ int gys_scan_percentiles_dev(gys_ctx *c, int which, const float *pcts, uint32_t 
 	if (!c->nsvc) return GYS_OK;
 	HIPCHK(hipMemcpyAsync(c->dev_pcts, pcts, (size_t)npct * 4, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream)); // pcts may be a short-lived host buffer
+	{
+		const int rcf = fold_range(c, 0, c->nsvc);
+		if (rcf) return rcf;
+	}
 	ProfScope ps(c, "hist_percentiles");
 	hipLaunchKernelGGL(k_hist_percentiles_view, dim3((c->nsvc + 255) / 256), dim3(256), 0, c->stream, c->hist_win, c->hist_all,
 			   c->cfg.enable_tdigest ? c->td_meta : nullptr, c->epoch, which, c->nsvc, c->dev_pcts, npct, d_out);
@@ -1969,7 +1955,11 @@ int gys_export_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots,
 	RANGE_CHECK(first_slot, nslots);
 	if (which < 0 || which > 1) return GYS_ERR_INVAL;
 	if (!nslots) return GYS_OK;
-	gys_hist_rec *tmp = nullptr; // window / all-time VIEW of the records (lazy window roll: see gys_kernels.hpp)
+	{
+		const int rcf = fold_range(c, first_slot, nslots);
+		if (rcf) return rcf;
+	}
+	gys_hist_rec *tmp = nullptr; // window / all-time VIEW of the records (hist_view in gys_kernels.hpp)
 	HIPCHK(hipMalloc((void **)&tmp, (size_t)nslots * sizeof(gys_hist_rec)));
 	hipLaunchKernelGGL(k_hist_view, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, c->hist_win, c->hist_all,
 			   c->cfg.enable_tdigest ? c->td_meta : nullptr, c->epoch, which, first_slot, nslots, tmp);
@@ -1983,6 +1973,10 @@ int gys_export_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots,
 int gys_export_conn_bitmap(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint16_t *out)
 {
 	RANGE_CHECK(first_slot, nslots);
+	{
+		const int rcf = fold_range(c, first_slot, nslots);
+		if (rcf) return rcf;
+	}
 	HIPCHK(hipMemcpyAsync(out, c->bitmap + (size_t)first_slot * 16, (size_t)nslots * 64, hipMemcpyDeviceToHost, c->stream));
 	std::vector<TdMeta> meta;
 	if (c->cfg.enable_tdigest) { // rows of a key that has not been touched in the current window are logically cleared
@@ -1991,7 +1985,7 @@ int gys_export_conn_bitmap(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uin
 	}
 	HIPCHK(hipStreamSynchronize(c->stream));
 	for (size_t i = 0; i < meta.size(); ++i)
-		if (meta[i].win_epoch != c->epoch) memset(out + i * 32, 0, 64);
+		if (meta[i].hw_epoch != c->epoch) memset(out + i * 32, 0, 64);
 	return GYS_OK;
 }
 
@@ -2037,16 +2031,14 @@ int gys_export_tdigest(gys_ctx *c, uint32_t first_slot, uint32_t nslots, int64_t
 	void *out = sums;
 	RANGE_CHECK(first_slot, nslots);
 	if (!c->cfg.enable_tdigest || !cnts || !minmax) return GYS_ERR_INVAL;
-	join_aux(c);
+	{
+		const int rcf = fold_range(c, first_slot, nslots); // min / max cover the buffered values
+		if (rcf) return rcf;
+	}
 	HIPCHK(hipMemcpyAsync(sums, c->td_sum + (size_t)first_slot * GYS_TD_NB, (size_t)nslots * GYS_TD_NB * 8, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(cnts, c->td_cnt + (size_t)first_slot * GYS_TD_NB, (size_t)nslots * GYS_TD_NB * 4, hipMemcpyDeviceToHost, c->stream));
-	std::vector<TdMeta> meta(nslots);
-	HIPCHK(hipMemcpyAsync(meta.data(), c->td_meta + first_slot, (size_t)nslots * sizeof(TdMeta), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(minmax, c->td_minmax + first_slot, (size_t)nslots * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
-	for (uint32_t i = 0; i < nslots; ++i) {
-		minmax[2 * i] = meta[i].vmin;
-		minmax[2 * i + 1] = meta[i].vmax;
-	}
 	return GYS_OK;
 }
 
@@ -2055,12 +2047,17 @@ int gys_export_tdigest_pending(gys_ctx *c, uint32_t first_slot, uint32_t nslots,
 	void *out = npend;
 	RANGE_CHECK(first_slot, nslots);
 	if (!c->cfg.enable_tdigest || !pend) return GYS_ERR_INVAL;
-	join_aux(c);
 	std::vector<TdMeta> meta(nslots);
 	HIPCHK(hipMemcpyAsync(meta.data(), c->td_meta + first_slot, (size_t)nslots * sizeof(TdMeta), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(pend, c->td_pend + (size_t)first_slot * GYS_TD_PEND_CAP, (size_t)nslots * GYS_TD_PEND_CAP * 4, hipMemcpyDeviceToHost, c->stream));
+	// a service buffers at most GYS_TD_PEND_CAP values between batches (the rest of its pcap-entry buffer is room for a batch)
+	HIPCHK(hipMemcpy2DAsync(pend, (size_t)GYS_TD_PEND_CAP * 4, c->td_pend + (size_t)first_slot * c->pcap, (size_t)c->pcap * 4, (size_t)GYS_TD_PEND_CAP * 4, nslots,
+				hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
-	for (uint32_t i = 0; i < nslots; ++i) npend[i] = meta[i].npend;
+	for (uint32_t i = 0; i < nslots; ++i) {
+		npend[i] = meta[i].npend;
+		for (uint32_t k = 0; k < GYS_TD_PEND_CAP; ++k) // staged words: value << 5 | CONN_BITMAP row
+			pend[(size_t)i * GYS_TD_PEND_CAP + k] = k < meta[i].npend ? (int32_t)((uint32_t)pend[(size_t)i * GYS_TD_PEND_CAP + k] >> GYS_ROW_BITS) : 0;
+	}
 	return GYS_OK;
 }
 

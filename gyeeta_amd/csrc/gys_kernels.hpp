@@ -1,14 +1,15 @@
 // gys_kernels.hpp -- the HIP kernels of libgysketch (gfx950, wave64).  Included once by gys_engine.hip.
 //
 // Hot path (per response event, replaces common/gy_socket_stat.cc:1517-1677 + common/gy_statistics.h:596-623):
-//   resp_pass1     24-B event -> listener slot (table probe) -> RESP_TIME_HASH bucket -> per-service exact histogram,
-//                  CONN_BITMAP, global histogram (LDS privatised), global HLL, Count-Min, per-key batch count, (slot,value) record
-//   scan_*         exclusive scan of the per-key batch counts (counting sort by key)
-//   resp_scatter   values scattered into per-key contiguous segments
-//   key_pass       one wave per key with new values: exact histogram record, CONN_BITMAP, Count-Min, min/max, append to the key's
-//                  t-digest buffer (or queue the key for a merge when the buffer would overflow)
-//   digest_merge   queued keys: LDS bitonic sort of (buffered + new) values + exact-integer k-bucket t-digest merge
-//   digest_huge    keys with > GYS_SMALL_MAX new values: value-count array in HBM scratch + parallel rank-interval assignment
+//   resp_host      one workgroup per host segment: 24-B event -> listener (LDS sub-table of the host) -> global HLL, all-service
+//                  histogram -> staged word appended to the service's value buffer (tile-wise LDS counting sort by key); one pass
+//   key_finalize   per service with new values: meta record, Count-Min, merge queue (buffer above GYS_TD_PEND_CAP) / spill
+//   digest_merge   queued keys: exact-integer k-bucket t-digest merge of the buffered values (sort-free, LDS), which also folds the
+//                  values into the service's exact histogram record / CONN_BITMAP rows / min-max (lazy fold, see "per-key value buffers")
+//   digest_huge    keys with more values than the LDS merge takes: value-count array in HBM scratch + parallel rank-interval assignment
+//   fold           brings the records of a slot range up to date before a query / export / level roll reads them
+//   resp_pass1 / scan_* / resp_scatter / key_append   general front end (global listener table + device atomics + counting sort by key
+//                  through HBM): hosts with more listeners than the LDS path takes, forced by gys_config.resp_path = 1, t-digest off
 // All of it is HBM-bound integer work: no MFMA.
 #pragma once
 
@@ -16,7 +17,6 @@
 
 namespace gys {
 
-#define GYS_SMALL_MAX 1024u        // largest per-key batch handled by k_key_pass / k_digest_merge; larger ones go to k_digest_huge
 #define GYS_HUGE_VALUE_BITS 20     // resp values are <= 1,000,000 < 2^20 (drop filter common/gy_socket_stat.cc:1521-1524)
 #define GYS_HUGE_BINS (1u << GYS_HUGE_VALUE_BITS)
 // staged word of one accepted event: (response ms << 5) | CONN_BITMAP row (cli_port & 0x1F, common/gy_socket_stat.h:403-410).
@@ -53,13 +53,6 @@ __global__ void k_fill_u64(uint64_t *p, uint64_t v, uint64_t n)
 __global__ void k_hist_init(gys_hist_rec *h, uint64_t first, uint64_t n, int64_t minval)
 {
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) h[first + i].max_val_seen = minval;
-}
-
-__global__ void k_tdmeta_init(uint4 *meta, uint64_t n)
-{
-	// TdMeta {vmin = INT32_MAX, vmax = INT32_MIN, npend = 0, pad}
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		meta[i] = make_uint4((uint32_t)INT32_MAX, (uint32_t)INT32_MIN, 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------- resp pass 1
@@ -144,6 +137,8 @@ struct RespP1 {
 	uint64_t *counters;
 	uint8_t *svc_hll;
 	uint32_t svc_hll_p;
+	unsigned long long *ghist; // arena: all-service histogram of the window (t-digest on: accumulated here per event)
+	long long *gmax;
 };
 
 __device__ __forceinline__ uint32_t find_seg(const gys_resp_seg *segs, uint32_t nsegs, uint64_t i)
@@ -159,9 +154,14 @@ __device__ __forceinline__ uint32_t find_seg(const gys_resp_seg *segs, uint32_t 
 __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 {
 	__shared__ unsigned int s_ctr[3];
+	__shared__ unsigned long long s_gh[4][16]; // per wave and bucket: count << 40 | sum (a thread sees at most a few thousand events)
+	__shared__ int s_gmax;
 	if (threadIdx.x < 3) s_ctr[threadIdx.x] = 0;
+	if (threadIdx.x < 64) ((unsigned long long *)s_gh)[threadIdx.x] = 0;
+	if (threadIdx.x == 0) s_gmax = INT32_MIN;
 	__syncthreads();
-	const bool fused = p.batch_cnt != nullptr; // histogram + CMS are then produced per KEY by the digest kernels from the sorted runs
+	const bool fused = p.batch_cnt != nullptr; // the records are then produced per KEY from the buffered values (lazy fold)
+	int tmax = INT32_MIN;
 
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
@@ -208,13 +208,29 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 				if (fused) {
 					atomicAdd(&p.batch_cnt[slot], 1u);
 					kv = ((uint64_t)slot << 32) | GYS_STAGED_WORD(tresp, dport);
+					atomicAdd(&s_gh[threadIdx.x >> 6][b], (1ull << 40) | (unsigned long long)tresp);
+					tmax = max(tmax, (int)tresp);
 				}
 			}
 		}
 		if (p.ev_kv) p.ev_kv[i] = kv;
 	}
+	if (fused && tmax != INT32_MIN) atomicMax(&s_gmax, tmax);
 	__syncthreads();
 	if (threadIdx.x < 3 && s_ctr[threadIdx.x]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS + threadIdx.x], (unsigned long long)s_ctr[threadIdx.x]);
+	if (fused && threadIdx.x < 15) {
+		unsigned long long cnt = 0, sum = 0;
+		for (int w = 0; w < 4; ++w) {
+			cnt += s_gh[w][threadIdx.x] >> 40;
+			sum += s_gh[w][threadIdx.x] & ((1ull << 40) - 1);
+		}
+		if (cnt) {
+			atomicAdd(&p.ghist[2 * threadIdx.x], cnt);
+			atomicAdd(&p.ghist[2 * threadIdx.x + 1], sum);
+			atomicAdd(&p.ghist[30], cnt);
+		}
+	}
+	if (fused && threadIdx.x == 15 && s_gmax != INT32_MIN) atomicMax(p.gmax, (long long)s_gmax);
 }
 
 // ---------------------------------------------------------------------------------------------------- scan of batch counts
@@ -279,9 +295,8 @@ __global__ __launch_bounds__(256) void k_scan_top(uint32_t *block_sums, uint32_t
 	}
 }
 
-// writes batch_off (exclusive prefix) and appends keys with > GYS_SMALL_MAX new values to the huge work list
-__global__ __launch_bounds__(256) void k_scan_final(const uint32_t *cnt, uint32_t n, const uint32_t *block_sums, uint32_t *off,
-						    uint32_t *huge_list, uint32_t *huge_count)
+// writes the exclusive prefix
+__global__ __launch_bounds__(256) void k_scan_final(const uint32_t *cnt, uint32_t n, const uint32_t *block_sums, uint32_t *off)
 {
 	__shared__ uint32_t s_wave[4];
 	const uint32_t base = blockIdx.x * GYS_SCAN_TILE + threadIdx.x * 16u;
@@ -296,10 +311,7 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t *cnt, uint32_
 	uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan_256(s, s_wave, &total);
 #pragma unroll
 	for (uint32_t k = 0; k < 16u; ++k) {
-		if (base + k < n) {
-			off[base + k] = run;
-			if (v[k] > GYS_SMALL_MAX) huge_list[atomicAdd(huge_count, 1u)] = base + k;
-		}
+		if (base + k < n) off[base + k] = run;
 		run += v[k];
 	}
 }
@@ -317,12 +329,56 @@ __global__ __launch_bounds__(256) void k_resp_scatter(const uint64_t *ev_kv, uin
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------- per-key value buffers
+// Every service owns a buffer of `pcap` staged words (td_pend[slot * pcap ..], word = response ms << 5 | CONN_BITMAP row).  A batch's
+// accepted events are APPENDED to their key's buffer and nothing else of the key is touched per event: the key's exact histogram
+// record, its CONN_BITMAP rows and its min / max are pure functions of the appended values, so they are brought up to date lazily
+// ("fold") -- when the buffer is drained by a t-digest merge, before a query / export reads them, or at a window close when the
+// multi-level windows need every window's record.  The per-batch cost of a key is then 4 bytes per value plus one 16-byte meta
+// record, instead of ~1 KB of record traffic per key and batch.
+//   t-digest rule (oracle: gyo_tdb_add_batch): a batch's values of a key are appended when buffered + new <= GYS_TD_PEND_CAP, otherwise
+//   ONE merge re-clusters the digest with (buffered + new) values.  Physically the new values are always appended first (the buffer has
+//   pcap > GYS_TD_PEND_CAP entries); a key whose buffer then holds more than GYS_TD_PEND_CAP values is queued for k_digest_merge.  A key
+//   whose batch does not fit the buffer at all ("spilled") gets its batch values as a run in `staged` instead (second pass of
+//   k_resp_host over the hosts that have such keys) and is merged from buffer + run.
+struct TdMeta {
+	uint32_t npend;     // staged words in the key's buffer
+	uint16_t nh;        // words [0, nh) are already folded into the histogram records / CONN_BITMAP rows / min-max
+	uint16_t nw;        // words [nw, npend) arrived in window win_epoch, words [0, nw) in earlier windows
+	uint32_t win_epoch; // window number of the key's latest values (0 = never touched)
+	uint32_t hw_epoch;  // window number the hist_win record and the CONN_BITMAP rows belong to
+};
+static_assert(sizeof(TdMeta) == 16, "TdMeta is read and written as one 16-byte word");
+static_assert(GYS_TD_PEND_CAP == GYS_TDIGEST_PEND_CAP, "gysketch.h and gys_tdigest_tbl.h disagree on the t-digest buffer size");
+static_assert(GYS_TD_NB == GYS_TDIGEST_NB && GYS_TD_NB <= 256, "the merge kernels hold one cluster per thread of a 256-thread group");
+
+#define GYS_SPILL_BIT 0x80000000u // td_cur[slot]: the key's values of the running batch go to a run in `staged`, not to its buffer
+#define GYS_MERGE_LDS_MAX 16384u  // largest (buffered + run) value count k_digest_merge handles; larger keys go to k_digest_huge
+#define GYS_PCAP_MAX 16384u
+
+struct MergeEnt {
+	uint32_t slot;
+	uint32_t nbuf;     // values taken from the key's buffer
+	uint32_t mrun;     // values taken from the key's run staged[off_end - mrun .. off_end) (spilled keys), else 0
+	uint32_t off_end;
+};
+
+__global__ void k_minmax_init(int2 *mm, uint64_t n)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mm[i] = make_int2(INT32_MAX, INT32_MIN);
+}
+
 // ---------------------------------------------------------------------------------------------------- host-local resp pass
-// One workgroup per host segment of the batch.  The reference resolves a response event's listener inside the HOST's own
-// listener table (TCP_SOCK_HANDLER is per host: common/gy_socket_stat.cc:1554-1677), so everything an event touches before the
-// per-key merge is host-local: the workgroup stages the host's (netns, port) -> local index sub-table in LDS, counts the segment's
-// events per listener in LDS, scans the counts in LDS and scatters the staged words with LDS atomics into the segment's own slice
-// of `staged` ([first_event, first_event + valid)).  No per-event device-scope atomic except the global HLL register max.
+// One workgroup per host segment of the batch (or per PART of a segment, SHARED).  The reference resolves a response event's listener
+// inside the HOST's own listener table (TCP_SOCK_HANDLER is per host: common/gy_socket_stat.cc:1554-1677), so everything an event
+// touches is host-local: the workgroup stages the host's (netns, port) -> local index sub-table in LDS and walks its events ONCE, tile
+// by tile: per tile the events are resolved and filtered (registers), ranked inside their key with one LDS atomic each, the tile's
+// per-key counts are scanned, the staged words are grouped by key in an LDS image, and every key's piece of the tile is appended to
+// the key's value buffer with consecutive image entries going to consecutive addresses.  No per-event device-scope atomic except the
+// global HLL register max; no intermediate per-event array in HBM.
+//   SHARED: several workgroups may hold events of the same host (long segments cut into parts, a host named by two segments): buffer
+//           space is reserved with one device atomic per (tile, key) instead of an LDS cursor.
+//   SPILL:  second pass over the hosts that have spilled keys: only those keys' events, into their runs in `staged`.
 struct HostDesc {
 	uint32_t tbl_off;  // first entry of the host's sub-table in the table pool
 	uint32_t mask;     // sub-table capacity - 1 (power of two)
@@ -331,33 +387,9 @@ struct HostDesc {
 };
 
 #define GYS_HOST_TBL_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define GYS_EV_DROPPED 0xFFFFFFFFu                          // response ms field 0xFFFFF > 10^6: never a kept event
-#define GYS_EV_LOCAL(w) ((w) >> 20)
-#define GYS_EV_STAGED(w, row) ((((w) & 0xFFFFFu) << GYS_ROW_BITS) | (uint32_t)(row))
+#define GYS_EV_DROPPED 0xFFFFFFFFu
 #define GYS_HOST_THREADS 1024
-#define GYS_HOST_UNROLL 4
-#define GYS_HOST_TILE 8192u                                  // events per LDS scatter tile of a long segment
-#define GYS_HOST_TILE_PER_THREAD (GYS_HOST_TILE / GYS_HOST_THREADS)
-
-// Few hosts, long segments (a small installation, or C1's single host): one workgroup per host segment would leave most of the chip
-// idle, so the segments are cut into PARTS of GYS_SPLIT_PART events and the pass runs in three launches instead of one:
-//   k_resp_host<.., 1>  one workgroup per part: resolve / filter / HLL / per-event records as usual, per-listener counts of the part
-//                       into its row of split_cnt
-//   k_split_scan        one workgroup per host: key run starts from the column sums, every part's row becomes its run cursors
-//   k_resp_host<.., 2>  one workgroup per part: scatter of the part's records through the LDS tile image, positions from its row
-// The result (staged runs per key, batch_cnt / off_end) is exactly what the fused form writes.
-#define GYS_SPLIT_PART 65536u
-struct SplitPart {
-	uint64_t real_first; // first event of the host's whole segment: staged positions are relative to it
-	uint32_t cnt_off;    // first entry of the part's row in split_cnt
-	uint32_t pad;
-};
-struct SplitSeg {
-	uint64_t first_event; // of the host's whole segment
-	uint32_t host_slot, nparts;
-	uint32_t cnt_off;     // row of part 0; the parts' rows follow each other, L entries each
-	uint32_t pad;
-};
+#define GYS_SPLIT_PART 65536u // events per part when long segments are cut (SHARED)
 
 struct RespHostP {
 	const uint64_t *ev;
@@ -368,410 +400,418 @@ struct RespHostP {
 	const uint64_t *htbl;   // entries: (netns:32 | port:16) << 16 | local index:16
 	const uint32_t *hlst;
 	uint32_t *hll32;
-	uint32_t *batch_cnt, *off_end;
-	// per event, written in pass A and re-read in pass B by the same thread: 5 bytes instead of the event's 24 --
-	uint32_t *ev_w;         // local index << 20 | response ms (<= 10^6 < 2^20), GYS_EV_DROPPED = dropped
-	uint8_t *ev_row;        // CONN_BITMAP row (client port & 0x1F); only written for kept events
+	uint32_t *td_cur;       // per service: words in its buffer including this batch's (SHARED: reserved with device atomics)
+	uint32_t *td_pend;
+	uint32_t pcap;
+	uint32_t *td_run;       // SPILL: per spilled service the fill cursor of its run in `staged`
 	uint32_t *staged;
-	uint32_t *huge_list, *huge_count;
+	const uint32_t *host_spill; // SPILL: hosts with spilled keys carry spill_stamp
+	uint32_t spill_stamp;
 	uint64_t *counters;
 	uint8_t *svc_hll;
 	uint32_t svc_hll_p;
-	uint32_t lds_tbl_entries; // LDS table area of the launch (largest sub-table among the batch's hosts)
-	uint32_t lds_cnt_entries; // LDS count area (largest listener count, even)
-	uint32_t lds_region_entries; // LDS scatter region of the launch (u32 entries, 0 = none): segments that fit are sorted there
-	uint32_t lds_tile_events;    // > 0: longer segments are scattered tile by tile through the region (2 x cnt + 2 x tile entries)
-	// split form (MODE 1 / 2): `segs` are PARTS of host segments, see "few hosts, long segments" below
-	const SplitPart *parts;
-	uint32_t *split_cnt;         // per part a row of the host's L counters: counts (MODE 1), then run cursors (k_split_scan), read by MODE 2
+	unsigned long long *ghist; // arena: all-service histogram of the window, 15 x {count,sum} + {total}
+	long long *gmax;           // arena: largest value of the window
+	uint32_t lds_tbl_entries;  // LDS table area of the launch (largest sub-table among the batch's hosts)
+	uint32_t lds_key_entries;  // LDS per-key areas (largest listener count, even)
 };
 
-// TILED = true: the instantiation for launches with long segments (keeps a tile's records in registers: more VGPRs, one workgroup per CU)
-// MODE 0: the whole pass in one launch; 1 / 2: the two halves of the split form
-template <bool TILED, int MODE = 0>
+template <int TPT, bool SHARED, bool SPILL>
 __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 {
+	constexpr uint32_t T = GYS_HOST_THREADS;
+	constexpr uint32_t TILE = (uint32_t)TPT * T;
 	extern __shared__ uint64_t s_dyn[];
-	__shared__ uint32_t s_wsum[GYS_HOST_THREADS / 64];
+	__shared__ uint32_t s_wsum[T / 64];
 	__shared__ uint32_t s_drop[2];
 	__shared__ uint32_t s_floor;
+	__shared__ unsigned long long s_gh[T / 64][16]; // per wave and bucket: count << 40 | sum of the wave's events since the last flush
+	__shared__ int32_t s_gmax;
+	const uint32_t Lc = p.lds_key_entries;
 	uint64_t *s_tbl = s_dyn;
-	uint32_t *s_cnt = (uint32_t *)(s_dyn + p.lds_tbl_entries);
-	uint32_t *s_region = s_cnt + p.lds_cnt_entries; // the segment's slice of `staged`, built in LDS and flushed with full-line stores
+	uint64_t *s_base = s_dyn + p.lds_tbl_entries;  // [Lc] destination index of the key's piece of the tile (~0: dropped)
+	uint32_t *s_cur = (uint32_t *)(s_base + Lc);   // [Lc] words in the key's buffer (SPILL: non-zero = spilled key)
+	uint32_t *s_slot = s_cur + Lc;                 // [Lc] service slot of the local index
+	uint32_t *s_tcnt = s_slot + Lc;                // [Lc] the tile's values of the key
+	uint32_t *s_tstart = s_tcnt + Lc;              // [Lc] start of the key's run inside the tile image
+	uint32_t *s_val = s_tstart + Lc;               // [TILE] staged words grouped by key
+	uint16_t *s_key = (uint16_t *)(s_val + TILE);  // [TILE] local index of each image entry
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const gys_resp_seg seg = p.segs[blockIdx.x];
 	const uint64_t e0 = seg.first_event;
-	const uint64_t e1 = blockIdx.x + 1 < p.nsegs ? p.segs[blockIdx.x + 1].first_event : p.n;
+	uint64_t e1 = blockIdx.x + 1 < p.nsegs ? p.segs[blockIdx.x + 1].first_event : p.n;
+	if (e1 > p.n) e1 = p.n;
 	if (e1 <= e0) return;
+	if (SPILL && p.host_spill[seg.host_slot] != p.spill_stamp) return;
 	const HostDesc hd = p.hdesc[seg.host_slot];
 	const uint32_t mask = hd.mask, L = hd.nlst;
-	// staged positions count from the first event of the HOST's segment (split form: the part's row holds cursors relative to it)
-	const uint64_t sbase = MODE == 0 ? e0 : p.parts[blockIdx.x].real_first;
-	if (MODE != 2) {
-	for (uint32_t i = tid; i <= mask; i += GYS_HOST_THREADS) s_tbl[i] = p.htbl[hd.tbl_off + i];
-	for (uint32_t i = tid; i < L; i += GYS_HOST_THREADS) s_cnt[i] = 0;
+	for (uint32_t i = tid; i <= mask; i += T) s_tbl[i] = p.htbl[hd.tbl_off + i];
+	for (uint32_t k = tid; k < L; k += T) {
+		const uint32_t slot = p.hlst[hd.lst_off + k];
+		const uint32_t c = p.td_cur[slot];
+		s_slot[k] = slot;
+		s_cur[k] = SPILL ? (c & GYS_SPILL_BIT) : c;
+	}
 	if (tid < 2) s_drop[tid] = 0;
+	if (tid < (T / 64) * 16) ((unsigned long long *)s_gh)[tid] = 0;
+	if (tid == 0) {
+		s_floor = SPILL ? 0u : 0xFFFFFFFFu;
+		s_gmax = INT32_MIN;
+	}
+	__syncthreads();
 	// HLL floor: a register can only grow, so min over the register file (read once per workgroup; stale L1 lines only lower it) is a
 	// lower bound for the rest of the window -- events whose rank does not exceed it skip the register read altogether.  Late in a
 	// window that is all but ~2^-floor of the events; without it every event pays a random 4-byte read.
-	if (tid == 0) s_floor = 0xFFFFFFFFu;
-	__syncthreads();
-	if (e1 - e0 >= 4096u) {
-		uint32_t mn = 0xFFFFFFFFu;
-		const uint4 *h4 = (const uint4 *)p.hll32;
-		for (uint32_t i = tid; i < (1u << GYS_HLL_P) / 4u; i += GYS_HOST_THREADS) {
-			const uint4 v = h4[i];
-			mn = min(min(mn, min(v.x, v.y)), min(v.z, v.w));
-		}
+	if (!SPILL) {
+		if (e1 - e0 >= 4096u) {
+			uint32_t mn = 0xFFFFFFFFu;
+			const uint4 *h4 = (const uint4 *)p.hll32;
+			for (uint32_t i = tid; i < (1u << GYS_HLL_P) / 4u; i += T) {
+				const uint4 v = h4[i];
+				mn = min(min(mn, min(v.x, v.y)), min(v.z, v.w));
+			}
 #pragma unroll
-		for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
-		if (lane == 0) atomicMin(&s_floor, mn);
-	} else if (tid == 0) {
-		s_floor = 0;
+			for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
+			if (lane == 0) atomicMin(&s_floor, mn);
+		} else if (tid == 0) {
+			s_floor = 0;
+		}
+		__syncthreads();
 	}
-	__syncthreads();
 	const uint32_t hll_floor = s_floor;
+	const uint32_t K = (L + T - 1) / T;
+	const uint32_t klo = min(L, tid * K), khi = min(L, klo + K);
+	uint32_t *const dst = SPILL ? p.staged : p.td_pend;
 
-	// ---- pass A: resolve, filter, count.  GYS_HOST_UNROLL events per thread and iteration, phase by phase (all event loads, then all
-	// the arithmetic, then all HLL register reads, then the updates) so that each wave keeps several HBM requests in flight.
-	uint32_t ndrop_range = 0, ndrop_nol = 0;
-	for (uint64_t base = e0 + tid; base < e1; base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
-		uint64_t w0[GYS_HOST_UNROLL], w1[GYS_HOST_UNROLL], w2[GYS_HOST_UNROLL];
+	uint32_t ndrop_range = 0, ndrop_nol = 0, tile_no = 0;
+	int32_t tmax = INT32_MIN;
+	for (uint64_t t0 = e0; t0 < e1; t0 += TILE, ++tile_no) {
+		for (uint32_t k = tid; k < L; k += T) s_tcnt[k] = 0;
+		__syncthreads();
+		// ---- resolve, filter, rank: 4 events per thread at a time, phase by phase (all event loads, then the arithmetic, then the HLL
+		// register reads, then the updates) so that each wave keeps several HBM requests in flight
+		uint32_t wd[TPT], lr[TPT]; // staged word (GYS_EV_DROPPED: not kept) / local index | rank inside the key's tile run << 12
 #pragma unroll
-		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
-			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
-			w0[u] = 0; w1[u] = 0; w2[u] = 0;
-			if (i < e1) {
-				w0[u] = p.ev[3 * i];
-				w1[u] = p.ev[3 * i + 1];
-				w2[u] = p.ev[3 * i + 2];
-			}
-		}
-		uint32_t kw[GYS_HOST_UNROLL], krow[GYS_HOST_UNROLL];
-		uint32_t hidx[GYS_HOST_UNROLL], hrank[GYS_HOST_UNROLL], hcur[GYS_HOST_UNROLL];
+		for (int g = 0; g < TPT; g += 4) {
+			uint64_t w0[4], w1[4], w2[4];
 #pragma unroll
-		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
-			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
-			// struct ipv4_tuple_t {u32 saddr, daddr, netns; u16 sport, dport;} + u32 lsndtime, lrcvtime  (24 bytes)
-			const uint32_t saddr = (uint32_t)w0[u], daddr = (uint32_t)(w0[u] >> 32);
-			const uint32_t netns = (uint32_t)w1[u];
-			const uint16_t sport = bswap16((uint16_t)(w1[u] >> 32)), dport = bswap16((uint16_t)(w1[u] >> 48)); // ntohs :1526-1527
-			const uint32_t tresp = (uint32_t)w2[u] - (uint32_t)(w2[u] >> 32); // lsndtime - lrcvtime (:1519)
-			kw[u] = GYS_EV_DROPPED;
-			krow[u] = 0;
-			hrank[u] = 0;
-			hidx[u] = 0;
-			if (i >= e1) continue;
-			if (tresp > 1000000u) { // "Ignore responses > 1000 sec or negative" (:1521-1524)
-				ndrop_range++;
-				continue;
-			}
-			const uint64_t key48 = ((uint64_t)netns << 16) | (uint64_t)sport;
-			uint32_t h = host_tbl_hash(key48) & mask;
-			uint32_t local = GYS_NOSLOT;
-			for (uint32_t probes = 0; probes <= mask; ++probes) {
-				const uint64_t e = s_tbl[h];
-				if ((e >> 16) == key48) {
-					local = (uint32_t)(e & 0xFFFFu);
-					break;
+			for (int u = 0; u < 4; ++u) {
+				const uint64_t i = t0 + tid + (uint64_t)(g + u) * T;
+				w0[u] = 0; w1[u] = 0; w2[u] = 0;
+				if (i < e1) {
+					w0[u] = p.ev[3 * i];
+					w1[u] = p.ev[3 * i + 1];
+					w2[u] = p.ev[3 * i + 2];
 				}
-				if (e == GYS_HOST_TBL_EMPTY) break;
-				h = (h + 1) & mask;
 			}
-			if (local == GYS_NOSLOT) {
-				ndrop_nol++; // no such listener: the reference ignores the event too (:1671-1676 miss path)
-				continue;
-			}
-			kw[u] = (local << 20) | tresp;
-			krow[u] = (uint32_t)dport & 0x1Fu;
-			if (p.svc_hll_p) { // the per-service registers need the whole 64-bit hash
-				const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
-				hll_idx_rank(h64, GYS_HLL_P, &hidx[u], &hrank[u]);
-				svc_hll_update(p.svc_hll, p.svc_hll_p, p.hlst[hd.lst_off + local], h64);
-			} else {
-				flow_hll_idx_rank(daddr, dport, saddr, sport, &hidx[u], &hrank[u]);
-			}
-			if (hrank[u] <= hll_floor) hrank[u] = 0; // cannot raise any register
-		}
+			uint32_t hidx[4], hrank[4], hcur[4];
 #pragma unroll
-		for (int u = 0; u < GYS_HOST_UNROLL; ++u) hcur[u] = hrank[u] ? p.hll32[hidx[u]] : 0xFFu; // read-first: most events do not raise the register
-#pragma unroll
-		for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
-			const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
-			if (hcur[u] < hrank[u]) atomicMax(&p.hll32[hidx[u]], hrank[u]);
-			if (kw[u] != GYS_EV_DROPPED) {
-				atomicAdd(&s_cnt[GYS_EV_LOCAL(kw[u])], 1u);
-				p.ev_row[i] = (uint8_t)krow[u];
+			for (int u = 0; u < 4; ++u) {
+				const uint64_t i = t0 + tid + (uint64_t)(g + u) * T;
+				// struct ipv4_tuple_t {u32 saddr, daddr, netns; u16 sport, dport;} + u32 lsndtime, lrcvtime  (24 bytes)
+				const uint32_t saddr = (uint32_t)w0[u], daddr = (uint32_t)(w0[u] >> 32);
+				const uint32_t netns = (uint32_t)w1[u];
+				const uint16_t sport = bswap16((uint16_t)(w1[u] >> 32)), dport = bswap16((uint16_t)(w1[u] >> 48)); // ntohs :1526-1527
+				const uint32_t tresp = (uint32_t)w2[u] - (uint32_t)(w2[u] >> 32); // lsndtime - lrcvtime (:1519)
+				wd[g + u] = GYS_EV_DROPPED;
+				lr[g + u] = 0;
+				hrank[u] = 0;
+				hidx[u] = 0;
+				if (i >= e1) continue;
+				if (tresp > 1000000u) { // "Ignore responses > 1000 sec or negative" (:1521-1524)
+					ndrop_range++;
+					continue;
+				}
+				const uint64_t key48 = ((uint64_t)netns << 16) | (uint64_t)sport;
+				uint32_t h = host_tbl_hash(key48) & mask;
+				uint32_t local = GYS_NOSLOT;
+				for (uint32_t probes = 0; probes <= mask; ++probes) {
+					const uint64_t e = s_tbl[h];
+					if ((e >> 16) == key48) {
+						local = (uint32_t)(e & 0xFFFFu);
+						break;
+					}
+					if (e == GYS_HOST_TBL_EMPTY) break;
+					h = (h + 1) & mask;
+				}
+				if (local == GYS_NOSLOT) {
+					ndrop_nol++; // no such listener: the reference ignores the event too (:1671-1676 miss path)
+					continue;
+				}
+				if (SPILL && !s_cur[local]) continue; // the key's values already sit in its buffer
+				wd[g + u] = (tresp << GYS_ROW_BITS) | ((uint32_t)dport & 0x1Fu);
+				lr[g + u] = local;
+				if (!SPILL) {
+					if (p.svc_hll_p) { // the per-service registers need the whole 64-bit hash
+						const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
+						hll_idx_rank(h64, GYS_HLL_P, &hidx[u], &hrank[u]);
+						svc_hll_update(p.svc_hll, p.svc_hll_p, s_slot[local], h64);
+					} else {
+						flow_hll_idx_rank(daddr, dport, saddr, sport, &hidx[u], &hrank[u]);
+					}
+					if (hrank[u] <= hll_floor) hrank[u] = 0; // cannot raise any register
+					// all-service histogram of the window (GY_HISTOGRAM::add_data on the aggregate): one packed LDS add per event
+					atomicAdd(&s_gh[wave][resp_bucket((int64_t)tresp)], (1ull << 40) | (unsigned long long)tresp);
+					tmax = max(tmax, (int32_t)tresp);
+				}
 			}
-			if (i < e1) p.ev_w[i] = kw[u];
+			if (!SPILL) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) hcur[u] = hrank[u] ? p.hll32[hidx[u]] : 0xFFu; // read-first: most events do not raise the register
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+					if (hcur[u] < hrank[u]) atomicMax(&p.hll32[hidx[u]], hrank[u]);
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+				if (wd[g + u] != GYS_EV_DROPPED) lr[g + u] |= atomicAdd(&s_tcnt[lr[g + u]], 1u) << 12;
 		}
+		__syncthreads();
+		// ---- exclusive scan of the tile's per-key counts -> run starts inside the image; every key's piece gets its destination
+		{
+			uint32_t sum = 0;
+			for (uint32_t k = klo; k < khi; ++k) sum += s_tcnt[k];
+			uint32_t inc = sum;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t t = __shfl_up(inc, d, 64);
+				if ((int)lane >= d) inc += t;
+			}
+			if (lane == 63) s_wsum[wave] = inc;
+			__syncthreads();
+			uint32_t run = inc - sum;
+			for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
+			for (uint32_t k = klo; k < khi; ++k) {
+				const uint32_t c = s_tcnt[k];
+				s_tstart[k] = run;
+				if (c) {
+					uint64_t base = ~0ull;
+					if (SPILL) {
+						base = (uint64_t)atomicAdd(&p.td_run[s_slot[k]], c);
+					} else {
+						uint32_t b;
+						if (SHARED) {
+							b = atomicAdd(&p.td_cur[s_slot[k]], c);
+						} else {
+							b = s_cur[k];
+							s_cur[k] = b + c;
+						}
+						// a piece that does not fit is dropped: the key's count ends above pcap, k_key_finalize then spills the key
+						if ((uint64_t)b + c <= (uint64_t)p.pcap) base = (uint64_t)s_slot[k] * p.pcap + b;
+					}
+					s_base[k] = base;
+				}
+				run += c;
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int u = 0; u < TPT; ++u) {
+			if (wd[u] == GYS_EV_DROPPED) continue;
+			const uint32_t local = lr[u] & 0xFFFu;
+			const uint32_t pos = s_tstart[local] + (lr[u] >> 12);
+			s_val[pos] = wd[u];
+			s_key[pos] = (uint16_t)local;
+		}
+		__syncthreads();
+		{
+			uint32_t ntile = 0; // kept events of the tile (every thread computes it from the wave sums)
+#pragma unroll
+			for (uint32_t w = 0; w < T / 64; ++w) ntile += s_wsum[w];
+			for (uint32_t e = tid; e < ntile; e += T) {
+				const uint32_t k = s_key[e];
+				const uint64_t base = s_base[k];
+				if (base != ~0ull) dst[base + (e - s_tstart[k])] = s_val[e];
+			}
+		}
+		if (!SPILL && (tile_no & 63u) == 63u) { // keep the packed per-wave sums far from their 40-bit field
+			__syncthreads();
+			if (tid < 15u) {
+				unsigned long long cnt = 0, sum = 0;
+				for (uint32_t w = 0; w < T / 64; ++w) {
+					const unsigned long long v = s_gh[w][tid];
+					cnt += v >> 40;
+					sum += v & ((1ull << 40) - 1);
+					s_gh[w][tid] = 0;
+				}
+				if (cnt) {
+					atomicAdd(&p.ghist[2 * tid], cnt);
+					atomicAdd(&p.ghist[2 * tid + 1], sum);
+					atomicAdd(&p.ghist[30], cnt);
+				}
+			}
+		}
+		// (the next tile's first barrier orders this tile's flush before the image is rewritten)
 	}
+	if (SPILL) return;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) tmax = max(tmax, __shfl_xor(tmax, d, 64));
+	if (lane == 0 && tmax != INT32_MIN) atomicMax(&s_gmax, tmax);
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
 	if (ndrop_nol) atomicAdd(&s_drop[1], ndrop_nol);
 	__syncthreads();
-	} // MODE != 2
-	if (MODE == 1) { // split form, first half: the part's per-listener counts go to its row; k_split_scan turns the rows into cursors
-		uint32_t *rowp = p.split_cnt + p.parts[blockIdx.x].cnt_off;
-		for (uint32_t k = tid; k < L; k += GYS_HOST_THREADS) rowp[k] = s_cnt[k];
-		if (tid == 0) {
-			atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
-			if (s_drop[0]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_RANGE], (unsigned long long)s_drop[0]);
-			if (s_drop[1]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_NOLISTENER], (unsigned long long)s_drop[1]);
+	if (!SHARED)
+		for (uint32_t k = tid; k < L; k += T) p.td_cur[s_slot[k]] = s_cur[k];
+	if (tid < 15u) {
+		unsigned long long cnt = 0, sum = 0;
+		for (uint32_t w = 0; w < T / 64; ++w) {
+			const unsigned long long v = s_gh[w][tid];
+			cnt += v >> 40;
+			sum += v & ((1ull << 40) - 1);
 		}
-		return;
-	}
-	if (MODE == 2) { // split form, second half: run cursors of this part (relative to the host segment's start)
-		const uint32_t *rowp = p.split_cnt + p.parts[blockIdx.x].cnt_off;
-		for (uint32_t k = tid; k < L; k += GYS_HOST_THREADS) s_cnt[k] = rowp[k];
-	}
-
-	// ---- counts -> per-key run starts (exclusive scan over the local indices), per-key batch_cnt / off_end for the digest kernels
-	if (MODE == 0) {
-		const uint32_t K = (L + GYS_HOST_THREADS - 1) / GYS_HOST_THREADS;
-		const uint32_t lo = tid * K, hi = min(L, lo + K);
-		uint32_t sum = 0;
-		for (uint32_t k = lo; k < hi; ++k) sum += s_cnt[k];
-		uint32_t inc = sum;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t t = __shfl_up(inc, d, 64);
-			if ((int)lane >= d) inc += t;
-		}
-		if (lane == 63) s_wsum[wave] = inc;
-		__syncthreads();
-		uint32_t run = inc - sum;
-		for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
-		for (uint32_t k = lo; k < hi; ++k) {
-			const uint32_t c = s_cnt[k];
-			s_cnt[k] = run;
-			if (c) {
-				const uint32_t slot = p.hlst[hd.lst_off + k];
-				p.batch_cnt[slot] = c;
-				p.off_end[slot] = (uint32_t)e0 + run + c;
-				if (c > GYS_SMALL_MAX) p.huge_list[atomicAdd(p.huge_count, 1u)] = slot;
-			}
-			run += c;
+		if (cnt) {
+			atomicAdd(&p.ghist[2 * tid], cnt);
+			atomicAdd(&p.ghist[2 * tid + 1], sum);
+			atomicAdd(&p.ghist[30], cnt);
 		}
 	}
-	__syncthreads();
-
-	// ---- pass B: scatter the staged words into the key runs (positions from LDS atomics).  A scattered 4-byte store that leaves L2
-	// before its line is complete becomes a read-modify-write in HBM, so when the segment's slice fits the LDS region the runs are
-	// assembled there and written out with coalesced full-line stores.
-	// (a part's key runs are not contiguous in `staged`: the split form always goes through the tile image)
-	const bool tiled = TILED && p.lds_tile_events != 0 && (MODE == 2 || (e1 - e0) > (uint64_t)p.lds_tile_events);
-	const bool in_lds = !tiled && (e1 - e0) <= (uint64_t)p.lds_region_entries;
-	if (tiled) {
-		// Long segment: the key runs are assembled tile by tile.  Per tile of GYS_HOST_TILE events: per-key counts of the tile (LDS), scan,
-		// scatter of the tile's words into an LDS image grouped by key together with their final positions (the key's global cursor +
-		// rank inside the tile's run), flush -- consecutive image entries of a key go to consecutive addresses, so the stores leave as
-		// full sectors -- and the cursors advance by the tile's counts.  s_cnt holds the cursors (run starts after the scan above).
-		const uint32_t Lc = p.lds_cnt_entries;
-		uint32_t *s_tstart = s_region;                 // [Lc] start of the key's run inside the tile image
-		uint32_t *s_tcur = s_region + Lc;              // [Lc] counts, then running cursor inside the tile image
-		uint32_t *s_val = s_region + 2u * Lc;          // [tile] words
-		uint32_t *s_dest = s_val + GYS_HOST_TILE;      // [tile] final position (relative to e0)
-		const uint32_t K = (L + GYS_HOST_THREADS - 1) / GYS_HOST_THREADS;
-		const uint32_t klo = tid * K, khi = min(L, klo + K);
-		for (uint64_t t0 = e0; t0 < e1; t0 += GYS_HOST_TILE) {
-			for (uint32_t k = tid; k < L; k += GYS_HOST_THREADS) s_tcur[k] = 0;
-			__syncthreads();
-			uint32_t kwr[GYS_HOST_TILE_PER_THREAD], rowr[GYS_HOST_TILE_PER_THREAD];
-#pragma unroll
-			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u) {
-				const uint64_t i = t0 + tid + (uint64_t)u * GYS_HOST_THREADS;
-				kwr[u] = i < e1 ? p.ev_w[i] : GYS_EV_DROPPED;
-			}
-#pragma unroll
-			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u) {
-				const uint64_t i = t0 + tid + (uint64_t)u * GYS_HOST_THREADS;
-				rowr[u] = kwr[u] != GYS_EV_DROPPED ? (uint32_t)p.ev_row[i] : 0u;
-			}
-#pragma unroll
-			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u)
-				if (kwr[u] != GYS_EV_DROPPED) atomicAdd(&s_tcur[GYS_EV_LOCAL(kwr[u])], 1u);
-			__syncthreads();
-			{ // exclusive scan of the tile counts -> run starts inside the image (s_tstart) and scatter cursors (s_tcur)
-				uint32_t sum = 0;
-				for (uint32_t k = klo; k < khi; ++k) sum += s_tcur[k];
-				uint32_t inc = sum;
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) {
-					const uint32_t t = __shfl_up(inc, d, 64);
-					if ((int)lane >= d) inc += t;
-				}
-				if (lane == 63) s_wsum[wave] = inc;
-				__syncthreads();
-				uint32_t run = inc - sum;
-				for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
-				for (uint32_t k = klo; k < khi; ++k) {
-					const uint32_t c = s_tcur[k];
-					s_tstart[k] = run;
-					s_tcur[k] = run;
-					run += c;
-				}
-			}
-			__syncthreads();
-#pragma unroll
-			for (uint32_t u = 0; u < GYS_HOST_TILE_PER_THREAD; ++u) {
-				if (kwr[u] == GYS_EV_DROPPED) continue;
-				const uint32_t local = GYS_EV_LOCAL(kwr[u]);
-				const uint32_t idx = atomicAdd(&s_tcur[local], 1u);
-				s_val[idx] = GYS_EV_STAGED(kwr[u], rowr[u]);
-				s_dest[idx] = s_cnt[local] + (idx - s_tstart[local]);
-			}
-			__syncthreads();
-			uint32_t ntile = 0; // valid words of the tile = end cursor of the last key = total (every thread computes it from the wave sums)
-			for (uint32_t w = 0; w < GYS_HOST_THREADS / 64; ++w) ntile += s_wsum[w];
-			for (uint32_t e = tid; e < ntile; e += GYS_HOST_THREADS) p.staged[sbase + s_dest[e]] = s_val[e];
-			for (uint32_t k = tid; k < L; k += GYS_HOST_THREADS) s_cnt[k] += s_tcur[k] - s_tstart[k];
-			__syncthreads();
-		}
-	} else {
-		for (uint64_t base = e0 + tid; base < e1; base += (uint64_t)GYS_HOST_UNROLL * GYS_HOST_THREADS) {
-			uint32_t kw[GYS_HOST_UNROLL], krow[GYS_HOST_UNROLL];
-#pragma unroll
-			for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
-				const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
-				kw[u] = i < e1 ? p.ev_w[i] : GYS_EV_DROPPED;
-			}
-#pragma unroll
-			for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
-				const uint64_t i = base + (uint64_t)u * GYS_HOST_THREADS;
-				krow[u] = kw[u] != GYS_EV_DROPPED ? (uint32_t)p.ev_row[i] : 0u;
-			}
-#pragma unroll
-			for (int u = 0; u < GYS_HOST_UNROLL; ++u) {
-				if (kw[u] == GYS_EV_DROPPED) continue;
-				const uint32_t pos = atomicAdd(&s_cnt[GYS_EV_LOCAL(kw[u])], 1u);
-				const uint32_t word = GYS_EV_STAGED(kw[u], krow[u]);
-				if (in_lds) s_region[pos] = word;
-				else p.staged[e0 + pos] = word;
-			}
-		}
-		if (in_lds) {
-			__syncthreads();
-			const uint32_t nvalid = (uint32_t)(e1 - e0) - s_drop[0] - s_drop[1];
-			for (uint32_t i = tid; i < nvalid; i += GYS_HOST_THREADS) p.staged[e0 + i] = s_region[i];
-		}
-	}
-	if (MODE == 0 && tid == 0) {
+	if (tid == 0) {
+		if (s_gmax != INT32_MIN) atomicMax(p.gmax, (long long)s_gmax);
 		atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
 		if (s_drop[0]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_RANGE], (unsigned long long)s_drop[0]);
 		if (s_drop[1]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_NOLISTENER], (unsigned long long)s_drop[1]);
 	}
 }
 
-// split form, middle launch: one workgroup per host.  Column k of the host's count matrix (one row per part) sums to the key's run
-// length; an exclusive scan over the keys gives the run starts; every row entry becomes the position (relative to the host segment's
-// start) where that part's first value of the key goes.  Also the per-key batch_cnt / off_end / huge list, as the fused form writes them.
-struct SplitScanP {
-	const SplitSeg *segs;
-	const HostDesc *hdesc;
-	const uint32_t *hlst;
-	uint32_t *split_cnt;
-	uint32_t *batch_cnt, *off_end;
-	uint32_t *huge_list, *huge_count;
-};
-
-__global__ __launch_bounds__(GYS_HOST_THREADS) void k_split_scan(SplitScanP p)
-{
-	__shared__ uint32_t s_wsum[GYS_HOST_THREADS / 64];
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const SplitSeg sg = p.segs[blockIdx.x];
-	const HostDesc hd = p.hdesc[sg.host_slot];
-	const uint32_t L = hd.nlst;
-	uint32_t *mat = p.split_cnt + sg.cnt_off;
-	const uint32_t K = (L + GYS_HOST_THREADS - 1) / GYS_HOST_THREADS;
-	const uint32_t lo = min(L, tid * K), hi = min(L, lo + K);
-	uint32_t sum = 0;
-	for (uint32_t k = lo; k < hi; ++k)
-		for (uint32_t q = 0; q < sg.nparts; ++q) sum += mat[(size_t)q * L + k];
-	uint32_t inc = sum;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t t = __shfl_up(inc, d, 64);
-		if ((int)lane >= d) inc += t;
-	}
-	if (lane == 63) s_wsum[wave] = inc;
-	__syncthreads();
-	uint32_t run = inc - sum;
-	for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
-	for (uint32_t k = lo; k < hi; ++k) {
-		uint32_t cur = run;
-		for (uint32_t q = 0; q < sg.nparts; ++q) {
-			const uint32_t c = mat[(size_t)q * L + k];
-			mat[(size_t)q * L + k] = cur;
-			cur += c;
-		}
-		const uint32_t c = cur - run;
-		if (c) {
-			const uint32_t slot = p.hlst[hd.lst_off + k];
-			p.batch_cnt[slot] = c;
-			p.off_end[slot] = (uint32_t)sg.first_event + cur;
-			if (c > GYS_SMALL_MAX) p.huge_list[atomicAdd(p.huge_count, 1u)] = slot;
-		}
-		run = cur;
-	}
-}
-
-// ---------------------------------------------------------------------------------------------------- per-key pass + t-digest merge
-// t-digest state of a key: 100 exact-integer clusters (td_sum / td_cnt) + a buffer of up to GYS_TD_PEND_CAP unmerged values
-// (the classic merging-digest buffer).  A batch's values are appended to the buffer; only when they no longer fit is the key
-// re-clustered with (buffered + new) values in ONE merge.  So the per-batch per-key work is light (k_key_pass: histogram record,
-// CONN_BITMAP, Count-Min, min/max, buffer append) and the expensive cluster merge (k_digest_merge) runs once per ~CAP values.
-static_assert(GYS_TD_PEND_CAP == GYS_TDIGEST_PEND_CAP, "gysketch.h and gys_tdigest_tbl.h disagree on the t-digest buffer size");
-
-struct TdMeta {
-	int32_t vmin, vmax; // over merged AND buffered values (INT32_MAX / INT32_MIN when empty)
-	uint32_t npend;     // buffered values in td_pend[slot * CAP ..]
-	uint32_t win_epoch; // window number the key's hist_win record and CONN_BITMAP rows belong to (lazy window roll, see below)
-};
-
-// Lazy window roll.  The reference clears the per-listener 5-s state and folds it into the longer levels on a timer
-// (GY_HISTOGRAM::add_histogram / clear, common/gy_statistics.h:625-636).  Sweeping 10^7 records at every window boundary costs
-// ~1 KB of HBM traffic per key, so the engine tags each key with the window number its hist_win / bitmap contents belong to and
-// rolls a key the first time a later window touches it: all-time += old window record, window record := this batch.
-//   window view   = hist_win if win_epoch == current window, else empty
-//   all-time view = hist_all + hist_win (the window record is either the current window or a not-yet-folded older one)
-
-struct MergeEnt {
-	uint32_t slot;
-	uint32_t m;        // new values of the batch (staged[off_end - m .. off_end)), 0 for a query entry
-	uint32_t off_end;
-	uint32_t pad;
-};
-
-struct DigestP {
-	int64_t *td_sum;    // [nsvc*100]
-	uint32_t *td_cnt;   // [nsvc*100]
-	TdMeta *td_meta;    // [nsvc]
-	uint32_t *td_pend;  // [nsvc*CAP]
+// ---------------------------------------------------------------------------------------------------- general front end -> buffers
+// The general pipeline (k_resp_pass1 / scan / k_resp_scatter) leaves every key's batch values as a run staged[off_end - m .. off_end).
+// Runs that fit are copied behind the key's buffered values; for the others only the count moves (k_key_finalize then spills the key
+// and the merge reads the run where it lies).  One wave per chunk of 64 keys, the wave copies one key's run at a time.
+struct AppendP {
 	uint32_t *batch_cnt;
 	const uint32_t *off_end;
 	const uint32_t *staged;
-	uint32_t nsvc;
-	// per-key outputs of the batch (the per-key kernels see every value of the key: one coalesced record update per KEY instead of
-	// ~9 device atomics per EVENT)
-	gys_hist_rec *hist_win;
-	uint32_t *cms32;
-	const uint64_t *svc_gid;
-	uint32_t *bitmap; // [nsvc*16] u32 = 32 x u16 CONN_BITMAP rows (common/gy_socket_stat.h:390-454)
-	MergeEnt *merge_list;
-	uint32_t *merge_count;
-	gys_hist_rec *hist_all;
-	uint32_t epoch;              // current window number
-	unsigned long long *ghist;   // arena: all-service histogram of the window, 15 x {count,sum} + {total}
-	uint32_t chunk_lo, chunk_hi; // k_key_pass: 64-key chunks [chunk_lo, chunk_hi) of this launch (key ranges pipeline against the merges)
-	long long *gmax;             // arena: largest value of the window
+	uint32_t *td_cur;
+	uint32_t *td_pend;
+	uint32_t pcap, nsvc;
 };
 
-// CONN_BITMAP::add_response for one staged word into a 16-word LDS row image: respmap_[row].set(bucket)
-__device__ __forceinline__ void bitmap_set_lds(uint32_t *s_bm, uint32_t word, uint32_t bucket)
+__global__ __launch_bounds__(256) void k_key_append(AppendP p)
 {
-	const uint32_t row = word & 0x1Fu;
-	atomicOr(&s_bm[row >> 1], (1u << bucket) << ((row & 1u) * 16u));
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t nchunks = (p.nsvc + 63u) / 64u, nwaves = gridDim.x * 4u;
+	for (uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6); chunk < nchunks; chunk += nwaves) {
+		const uint32_t key = chunk * 64u + lane;
+		const uint32_t m = key < p.nsvc ? p.batch_cnt[key] : 0u;
+		unsigned long long todo = __ballot(m != 0);
+		if (!todo) continue;
+		const uint32_t oend = m ? p.off_end[key] : 0u;
+		const uint32_t cur = m ? p.td_cur[key] : 0u;
+		if (m) {
+			p.batch_cnt[key] = 0;
+			p.td_cur[key] = cur + m;
+		}
+		while (todo) {
+			const int k = __ffsll((long long)todo) - 1;
+			todo &= todo - 1;
+			const uint32_t km = (uint32_t)__shfl((int)m, k, 64), ke = (uint32_t)__shfl((int)oend, k, 64), kc = (uint32_t)__shfl((int)cur, k, 64);
+			if ((uint64_t)kc + km > (uint64_t)p.pcap) continue; // spilled: the run stays in `staged`
+			const uint32_t *src = p.staged + (ke - km);
+			uint32_t *dst = p.td_pend + (size_t)(chunk * 64u + (uint32_t)k) * p.pcap + kc;
+			for (uint32_t i = lane; i < km; i += 64u) dst[i] = src[i];
+		}
+	}
 }
+
+// ---------------------------------------------------------------------------------------------------- per-key end of batch
+// One thread per service: keys whose value count moved in this batch get their meta record updated (window bookkeeping of the lazy
+// fold), their Count-Min rows (events per service key), and are queued for a merge when the buffer holds more than GYS_TD_PEND_CAP
+// values; keys whose batch did not fit the buffer are spilled (run allocated in `staged`, host flagged for the second resp pass).
+struct FinP {
+	uint32_t *td_cur;
+	TdMeta *td_meta;
+	uint32_t nsvc, pcap, epoch;
+	uint32_t *cms32;
+	const uint64_t *svc_gid;
+	MergeEnt *merge_list, *huge_list;
+	uint32_t *merge_count, *huge_count;
+	uint32_t *run_alloc;       // bump cursor into `staged` (host-local front end)
+	uint32_t *td_run;
+	const uint32_t *batch_off; // general front end: end of the key's run in `staged` (nullptr: host-local front end)
+	const uint32_t *svc_host;
+	uint32_t *host_spill;
+	uint32_t spill_stamp;
+};
+
+__global__ __launch_bounds__(256) void k_key_finalize(FinP p)
+{
+	const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u;
+	bool to_merge = false, to_huge = false;
+	MergeEnt ent{};
+	if (key < p.nsvc) {
+		const uint32_t cur = p.td_cur[key];
+		const uint4 mraw = *(const uint4 *)&p.td_meta[key];
+		const uint32_t npend0 = mraw.x;
+		if (cur != npend0) {
+			const uint32_t m = cur - npend0;
+			uint32_t nh = mraw.y & 0xFFFFu, nw = mraw.y >> 16, win_epoch = mraw.z;
+			if (win_epoch != p.epoch) { // first values of the key in this window: everything buffered so far belongs to earlier windows
+				nw = npend0;
+				win_epoch = p.epoch;
+			}
+			const uint64_t gid = p.svc_gid[key];
+#pragma unroll
+			for (uint32_t r = 0; r < GYS_CMS_D; ++r) atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(gid, GYS_SEED + r) & (GYS_CMS_W - 1))], m);
+			ent.slot = key;
+			if (cur <= p.pcap) {
+				*(uint4 *)&p.td_meta[key] = make_uint4(cur, nh | (nw << 16), win_epoch, mraw.w);
+				if (cur > GYS_TD_PEND_CAP) {
+					ent.nbuf = cur;
+					to_merge = true;
+				}
+			} else { // spilled
+				*(uint4 *)&p.td_meta[key] = make_uint4(npend0, nh | (nw << 16), win_epoch, mraw.w);
+				p.td_cur[key] = npend0 | GYS_SPILL_BIT;
+				ent.nbuf = npend0;
+				ent.mrun = m;
+				if (p.batch_off) {
+					ent.off_end = p.batch_off[key];
+				} else {
+					const uint32_t start = atomicAdd(p.run_alloc, m);
+					p.td_run[key] = start;
+					ent.off_end = start + m;
+					p.host_spill[p.svc_host[key]] = p.spill_stamp;
+				}
+				if ((uint64_t)npend0 + m > GYS_MERGE_LDS_MAX) to_huge = true;
+				else to_merge = true;
+			}
+		}
+	}
+	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+	{
+		const unsigned long long nb = __ballot(to_merge);
+		if (nb) {
+			uint32_t at = 0;
+			if (lane == 0) at = atomicAdd(p.merge_count, (uint32_t)__popcll(nb));
+			at = (uint32_t)__shfl((int)at, 0, 64);
+			if (to_merge) p.merge_list[at + (uint32_t)__popcll(nb & below)] = ent;
+		}
+	}
+	{
+		const unsigned long long nb = __ballot(to_huge);
+		if (nb) {
+			uint32_t at = 0;
+			if (lane == 0) at = atomicAdd(p.huge_count, (uint32_t)__popcll(nb));
+			at = (uint32_t)__shfl((int)at, 0, 64);
+			if (to_huge) p.huge_list[at + (uint32_t)__popcll(nb & below)] = ent;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------- fold + t-digest merge
+struct DigestP {
+	int64_t *td_sum;    // [nsvc*NB]
+	uint32_t *td_cnt;   // [nsvc*NB]
+	TdMeta *td_meta;    // [nsvc]
+	int2 *td_minmax;    // [nsvc] smallest / largest value over merged AND folded values
+	uint32_t *td_pend;  // [nsvc*pcap] staged words
+	uint32_t *td_cur;
+	uint32_t pcap, nsvc;
+	const uint32_t *staged;
+	gys_hist_rec *hist_win, *hist_all;
+	uint32_t *bitmap;   // [nsvc*16] u32 = 32 x u16 CONN_BITMAP rows (common/gy_socket_stat.h:390-454)
+};
 
 // wave-synchronous LDS hand-off: DS operations of one wave execute in order; this only stops the compiler from moving them
 #define GYS_WAVE_SYNC()                                              \
@@ -780,6 +820,136 @@ __device__ __forceinline__ void bitmap_set_lds(uint32_t *s_bm, uint32_t word, ui
 		__builtin_amdgcn_wave_barrier();                     \
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
 	} while (0)
+
+#define GYS_PACK_ONE (1ull << 40)              // packed {count:24 | sum:40} accumulators: one LDS atomic per value
+#define GYS_PACK_SUM(v) ((v) & (GYS_PACK_ONE - 1))
+
+// Brings the records of a key up to date with the not yet folded words of its buffer (and, inside a merge, of its run).  `da` / `dw`
+// are the packed bucket deltas of ALL not yet folded values / of those that belong to window mt.win_epoch; lane g (0..15) of the
+// calling group owns histogram pair g and bitmap word g:
+//   all-time record += da (GY_HISTOGRAM::add_data for every value, common/gy_statistics.h:596-623);
+//   window record: a record of an older window is dropped first (the reference clears the 5-s state on its timer,
+//   GY_HISTOGRAM::clear :630-636; here a key rolls when the first values of a later window are folded), then += dw; same for the rows.
+__device__ __forceinline__ void fold_records(const DigestP &p, uint32_t slot, uint32_t g, bool roll, unsigned long long da, unsigned long long dw,
+					     uint32_t n_all, uint32_t n_win, int32_t max_all, int32_t max_win, uint32_t bm)
+{
+	uint4 *ap = (uint4 *)&p.hist_all[slot] + g, *wp = (uint4 *)&p.hist_win[slot] + g;
+	if (n_all) {
+		const uint4 a = *ap;
+		uint64_t lo = (uint64_t)a.x | ((uint64_t)a.y << 32), hi = (uint64_t)a.z | ((uint64_t)a.w << 32);
+		if (g < 15u) {
+			lo += da >> 40;
+			hi += GYS_PACK_SUM(da);
+		} else {
+			lo += n_all;                                                    // total_count_
+			if ((int64_t)hi < (int64_t)max_all) hi = (uint64_t)(int64_t)max_all; // max_val_seen_
+		}
+		if (g == 15u || da) *ap = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+	}
+	if (n_win) {
+		uint64_t lo = 0, hi = g < 15u ? 0ull : (uint64_t)INT64_MIN;
+		if (!roll) {
+			const uint4 w = *wp;
+			lo = (uint64_t)w.x | ((uint64_t)w.y << 32);
+			hi = (uint64_t)w.z | ((uint64_t)w.w << 32);
+		}
+		if (g < 15u) {
+			lo += dw >> 40;
+			hi += GYS_PACK_SUM(dw);
+		} else {
+			lo += n_win;
+			if ((int64_t)hi < (int64_t)max_win) hi = (uint64_t)(int64_t)max_win;
+		}
+		if (roll || g == 15u || dw) *wp = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+		uint32_t *bp = &p.bitmap[(size_t)slot * 16u + g];
+		const uint32_t old = roll ? 0u : *bp;
+		if (roll || (old | bm) != old) *bp = old | bm;
+	}
+}
+
+// ---- k_fold: services [first, first + n): every key with not yet folded words gets its records brought up to date.  FOUR keys per
+// wave: each 16-lane row owns one key -- lane g of the row holds the key's histogram pair g (16 x {count,sum} = the 256-byte record,
+// one coalesced 256-B access per row), its CONN_BITMAP word g, and word g of every 16-word group of the buffer.
+struct FoldP {
+	DigestP d;
+	uint32_t first, n;
+};
+
+__global__ __launch_bounds__(256) void k_fold(FoldP q)
+{
+	const DigestP &p = q.d;
+	__shared__ unsigned long long s_a_[16][16], s_w_[16][16];
+	__shared__ uint32_t s_bm_[16][16];
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	const uint32_t row = lane >> 4, g = lane & 15u;
+	unsigned long long *s_a = s_a_[wv * 4u + row], *s_w = s_w_[wv * 4u + row];
+	uint32_t *s_bm = s_bm_[wv * 4u + row];
+	const uint32_t nchunks = (q.n + 63u) / 64u, nwaves = gridDim.x * 4u;
+	for (uint32_t chunk = blockIdx.x * 4u + wv; chunk < nchunks; chunk += nwaves) {
+		const uint32_t rel = chunk * 64u + lane;
+		uint4 mraw = make_uint4(0, 0, 0, 0);
+		if (rel < q.n) mraw = *(const uint4 *)&p.td_meta[q.first + rel];
+		const unsigned long long todo = __ballot(mraw.x > (mraw.y & 0xFFFFu));
+		if (!todo) continue;
+		for (uint32_t rd = 0; rd < 16u; ++rd) {
+			if (!((todo >> (4u * rd)) & 0xFull)) continue;
+			const uint32_t k = rd * 4u + row;
+			const uint32_t slot = q.first + chunk * 64u + k;
+			uint4 mt;
+			mt.x = (uint32_t)__shfl((int)mraw.x, (int)k, 64);
+			mt.y = (uint32_t)__shfl((int)mraw.y, (int)k, 64);
+			mt.z = (uint32_t)__shfl((int)mraw.z, (int)k, 64);
+			mt.w = (uint32_t)__shfl((int)mraw.w, (int)k, 64);
+			const uint32_t npend = mt.x, nh = mt.y & 0xFFFFu, nw = mt.y >> 16;
+			const uint32_t nwin0 = max(nh, nw); // first word of the not yet folded part that belongs to window win_epoch
+			const uint32_t m = npend > nh ? npend - nh : 0u;
+			s_a[g] = 0;
+			s_w[g] = 0;
+			s_bm[g] = 0;
+			GYS_WAVE_SYNC();
+			const uint32_t *pend = p.td_pend + (size_t)slot * p.pcap;
+			const uint32_t mmax = max(max((uint32_t)__shfl((int)m, 0, 64), (uint32_t)__shfl((int)m, 16, 64)),
+						  max((uint32_t)__shfl((int)m, 32, 64), (uint32_t)__shfl((int)m, 48, 64)));
+			int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmax = INT32_MIN;
+			for (uint32_t base = 0; base < mmax; base += 16u) {
+				const uint32_t i = nh + base + g;
+				if (base + g < m) {
+					const uint32_t w = pend[i];
+					const int32_t v = (int32_t)(w >> GYS_ROW_BITS);
+					const uint32_t b = resp_bucket((int64_t)v);
+					const unsigned long long one = GYS_PACK_ONE | (unsigned long long)(uint32_t)v;
+					atomicAdd(&s_a[b], one);
+					lmin = min(lmin, v);
+					lmax = max(lmax, v);
+					if (i >= nwin0) {
+						atomicAdd(&s_w[b], one);
+						const uint32_t r = w & 0x1Fu; // CONN_BITMAP::add_response: respmap_[row].set(bucket) (common/gy_socket_stat.h:403-410)
+						atomicOr(&s_bm[r >> 1], (1u << b) << ((r & 1u) * 16u));
+						wmax = max(wmax, v);
+					}
+				}
+			}
+#pragma unroll
+			for (int d = 8; d >= 1; d >>= 1) {
+				lmin = min(lmin, __shfl_xor(lmin, d, 64));
+				lmax = max(lmax, __shfl_xor(lmax, d, 64));
+				wmax = max(wmax, __shfl_xor(wmax, d, 64));
+			}
+			GYS_WAVE_SYNC();
+			if (m) {
+				const uint32_t n_win = npend > nwin0 ? npend - nwin0 : 0u;
+				const bool roll = mt.w != mt.z;
+				fold_records(p, slot, g, roll, s_a[g], s_w[g], m, n_win, lmax, wmax, s_bm[g]);
+				if (g == 0) {
+					*(uint4 *)&p.td_meta[slot] = make_uint4(npend, npend | (nw << 16), mt.z, n_win ? mt.z : mt.w);
+					const int2 mm = p.td_minmax[slot];
+					if (lmin < mm.x || lmax > mm.y) p.td_minmax[slot] = make_int2(min(mm.x, lmin), max(mm.y, lmax));
+				}
+			}
+			GYS_WAVE_SYNC();
+		}
+	}
+}
 
 __device__ __forceinline__ uint32_t td_cluster_of(const uint64_t *T, uint64_t mid2)
 {
@@ -791,219 +961,6 @@ __device__ __forceinline__ uint32_t td_cluster_of(const uint64_t *T, uint64_t mi
 	return a;
 }
 
-// same on a table padded to 128 entries with ~0: branch-free (7 dependent LDS reads, no divergent loop)
-__device__ __forceinline__ uint32_t td_cluster_of128(const uint64_t *T, uint64_t mid2)
-{
-	uint32_t a = 0; // #{j in 1..127 : mid2 >= T[j]}
-#pragma unroll
-	for (uint32_t step = 64u; step >= 1u; step >>= 1)
-		if (mid2 >= T[a + step]) a += step;
-	return a;
-}
-
-// lanes 0..63 each own entries (lane) and (lane + 64) of a <= 128 long array: exclusive prefix sum (u64) across the wave
-__device__ __forceinline__ void wave_excl_scan_2x(uint64_t a0, uint64_t a1, uint64_t *e0, uint64_t *e1, uint64_t *total)
-{
-	const uint32_t lane = threadIdx.x & 63u;
-	uint64_t i0 = a0, i1 = a1;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint64_t t0 = __shfl_up(i0, d, 64), t1 = __shfl_up(i1, d, 64);
-		if ((int)lane >= d) {
-			i0 += t0;
-			i1 += t1;
-		}
-	}
-	const uint64_t tot0 = __shfl(i0, 63, 64), tot1 = __shfl(i1, 63, 64);
-	*e0 = i0 - a0;
-	*e1 = tot0 + i1 - a1;
-	*total = tot0 + tot1;
-}
-
-// ---- k_key_pass: every key with 1..GYS_SMALL_MAX new values.  FOUR keys per wave: each 16-lane row owns one key -- lane g of the
-// row holds the key's histogram pair g (16 x {count,sum} = the 256-byte record, one coalesced 256-B access per row), its CONN_BITMAP
-// word g, and value g of every 16-value group.  A wave walks a chunk of 64 consecutive keys in 16 rounds of 4 keys: the chunk's
-// counts / offsets come from ONE coalesced load (then bpermute), and the next round's record / bitmap / meta / first 32 staged words
-// are prefetched into registers while the current round is processed, so the per-key critical path holds no dependent HBM round
-// trip.  No workgroup barriers (rows talk through per-row LDS accumulators).  Keys whose buffer would overflow are queued for
-// k_digest_merge with one aggregated atomic per chunk.
-struct KeyRegs {
-	uint32_t w0, w1;  // staged words g and 16 + g of the key
-	uint4 pair;       // histogram pair g of the window record: {count lo, count hi, sum lo, sum hi}
-	uint4 apair;      // the same pair of the all-time record (needed when the key rolls to a new window)
-	uint32_t bm;      // CONN_BITMAP word g
-	uint4 meta;       // TdMeta of the key (same for the 16 lanes of the row)
-	uint64_t gid;
-};
-
-__device__ __forceinline__ void key_prefetch(const DigestP &p, uint32_t slot, uint32_t m, uint32_t oend, uint32_t g, KeyRegs &r)
-{
-	r.w0 = 0;
-	r.w1 = 0;
-	if (m == 0) return; // row idle this round
-	const uint32_t *sv = p.staged + (oend - m);
-	if (g < m) r.w0 = sv[g];
-	if (16u + g < m) r.w1 = sv[16u + g];
-	r.pair = ((const uint4 *)&p.hist_win[slot])[g];
-	r.apair = ((const uint4 *)&p.hist_all[slot])[g];
-	r.bm = p.bitmap[(size_t)slot * 16u + g];
-	r.meta = *(const uint4 *)&p.td_meta[slot];
-	r.gid = p.svc_gid[slot];
-}
-
-__global__ __launch_bounds__(256) void k_key_pass(DigestP p)
-{
-	__shared__ unsigned long long s_h_[16][32];
-	__shared__ uint32_t s_bm_[16][16];
-	__shared__ unsigned long long s_gh[32]; // all-service histogram of this workgroup's keys (flushed once at the end)
-	__shared__ long long s_gmax;
-	if (threadIdx.x < 32u) s_gh[threadIdx.x] = 0;
-	if (threadIdx.x == 32u) s_gmax = INT64_MIN;
-	__syncthreads();
-	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-	const uint32_t row = lane >> 4, g = lane & 15u;
-	unsigned long long *s_h = s_h_[wv * 4u + row];
-	uint32_t *s_bm = s_bm_[wv * 4u + row];
-	const uint32_t nwaves = gridDim.x * 4u;
-
-	for (uint32_t chunk = p.chunk_lo + blockIdx.x * 4u + wv; chunk < p.chunk_hi; chunk += nwaves) {
-		const uint32_t key = chunk * 64u + lane;
-		uint32_t mcnt = key < p.nsvc ? p.batch_cnt[key] : 0u;
-		const uint32_t oend = key < p.nsvc ? p.off_end[key] : 0u;
-		if (mcnt > GYS_SMALL_MAX) mcnt = 0; // larger keys belong to k_digest_huge (which also does their histogram / bitmap / CMS)
-		const unsigned long long todo = __ballot(mcnt != 0);
-		if (!todo) continue;
-		if (mcnt) p.batch_cnt[key] = 0; // consumed (coalesced reset for the whole chunk)
-		uint32_t merge_rounds = 0;      // bit rd: the key this row handled in round rd must be merged
-		KeyRegs cur, nxt;
-		uint32_t rd = (uint32_t)__ffsll((long long)todo) - 1u;
-		rd >>= 2; // first round with an active key
-		key_prefetch(p, chunk * 64u + rd * 4u + row, (uint32_t)__shfl((int)mcnt, (int)(rd * 4u + row), 64),
-			     (uint32_t)__shfl((int)oend, (int)(rd * 4u + row), 64), g, cur);
-		for (;;) {
-			const uint32_t k = rd * 4u + row;
-			const uint32_t slot = chunk * 64u + k;
-			const uint32_t m = (uint32_t)__shfl((int)mcnt, (int)k, 64);
-			const uint32_t ke = (uint32_t)__shfl((int)oend, (int)k, 64);
-			uint32_t rnext = 16u;
-			{
-				const unsigned long long rest = rd < 15u ? (todo >> (4u * (rd + 1u))) : 0ull;
-				if (rest) { // issue the next round's loads now; they are consumed one iteration later
-					rnext = rd + 1u + (((uint32_t)__ffsll((long long)rest) - 1u) >> 2);
-					key_prefetch(p, chunk * 64u + rnext * 4u + row, (uint32_t)__shfl((int)mcnt, (int)(rnext * 4u + row), 64),
-						     (uint32_t)__shfl((int)oend, (int)(rnext * 4u + row), 64), g, nxt);
-				}
-			}
-			const uint32_t npend = cur.meta.z;
-			const bool do_merge = m != 0 && npend + m > GYS_TD_PEND_CAP;
-			s_h[g] = 0;
-			s_h[16u + g] = 0;
-			s_bm[g] = 0;
-			GYS_WAVE_SYNC();
-			uint32_t *pend = p.td_pend + (size_t)slot * GYS_TD_PEND_CAP + npend;
-			const uint32_t mmax = max(max((uint32_t)__shfl((int)m, 0, 64), (uint32_t)__shfl((int)m, 16, 64)),
-						  max((uint32_t)__shfl((int)m, 32, 64), (uint32_t)__shfl((int)m, 48, 64)));
-			int32_t lmin = INT32_MAX, lmax = INT32_MIN;
-			for (uint32_t base = 0; base < mmax; base += 16u) {
-				const uint32_t idx = base + g;
-				if (idx < m) {
-					// staged word: value << 5 | CONN_BITMAP row
-					const uint32_t w = base == 0 ? cur.w0 : (base == 16u ? cur.w1 : p.staged[ke - m + idx]);
-					const int32_t v = (int32_t)(w >> GYS_ROW_BITS);
-					const uint32_t b = resp_bucket((int64_t)v);
-					atomicAdd(&s_h[2 * b], 1ull);
-					atomicAdd(&s_h[2 * b + 1], (unsigned long long)(int64_t)v);
-					bitmap_set_lds(s_bm, w, b);
-					lmin = min(lmin, v);
-					lmax = max(lmax, v);
-					if (!do_merge) pend[idx] = (uint32_t)v;
-				}
-			}
-			// smallest / largest value of the key: per-lane running values, then an xor butterfly inside the 16-lane row (16 lanes hammering
-			// one LDS word with atomicMin / atomicMax serialise; the LDS pipe of this kernel was ~70 % conflict cycles)
-#pragma unroll
-			for (int d = 8; d >= 1; d >>= 1) {
-				lmin = min(lmin, __shfl_xor(lmin, d, 64));
-				lmax = max(lmax, __shfl_xor(lmax, d, 64));
-			}
-			GYS_WAVE_SYNC();
-			if (m) {
-				const int32_t vmin = lmin, vmax = lmax;
-				const bool stale = cur.meta.w != p.epoch; // first touch of the key in this window: roll it (see "Lazy window roll")
-				// ---- histogram records (prefetched pairs + LDS delta), bitmap word, meta, Count-Min
-				uint4 *hp = (uint4 *)&p.hist_win[slot] + g;
-				const uint64_t w_lo = (uint64_t)cur.pair.x | ((uint64_t)cur.pair.y << 32), w_hi = (uint64_t)cur.pair.z | ((uint64_t)cur.pair.w << 32);
-				if (stale) { // all-time += old window record (GY_HISTOGRAM::add_histogram, common/gy_statistics.h:625-660)
-					const uint64_t a_lo = (uint64_t)cur.apair.x | ((uint64_t)cur.apair.y << 32), a_hi = (uint64_t)cur.apair.z | ((uint64_t)cur.apair.w << 32);
-					uint64_t n_lo = a_lo + w_lo, n_hi = a_hi + w_hi;
-					if (g == 15u) n_hi = (uint64_t)max((int64_t)a_hi, (int64_t)w_hi); // max_val_seen_
-					if (n_lo != a_lo || n_hi != a_hi)
-						((uint4 *)&p.hist_all[slot])[g] = make_uint4((uint32_t)n_lo, (uint32_t)(n_lo >> 32), (uint32_t)n_hi, (uint32_t)(n_hi >> 32));
-				}
-				if (g < 15u) {
-					const unsigned long long dc = s_h[2 * g], ds = s_h[2 * g + 1];
-					if (dc) {
-						atomicAdd(&s_gh[2 * g], dc);
-						atomicAdd(&s_gh[2 * g + 1], ds);
-					}
-					if (dc || (stale && (w_lo | w_hi))) {
-						const uint64_t cnt = (stale ? 0ull : w_lo) + dc;
-						const uint64_t sum = (stale ? 0ull : w_hi) + ds;
-						*hp = make_uint4((uint32_t)cnt, (uint32_t)(cnt >> 32), (uint32_t)sum, (uint32_t)(sum >> 32));
-					}
-				} else {
-					const uint64_t tot = (stale ? 0ull : w_lo) + m; // total_count_
-					int64_t mx = stale ? INT64_MIN : (int64_t)w_hi;   // max_val_seen_
-					if (mx < (int64_t)vmax) mx = (int64_t)vmax;
-					*hp = make_uint4((uint32_t)tot, (uint32_t)(tot >> 32), (uint32_t)(uint64_t)mx, (uint32_t)((uint64_t)mx >> 32));
-					atomicAdd(&s_gh[30], (unsigned long long)m);
-					atomicMax(&s_gmax, (long long)vmax);
-				}
-				{
-					const uint32_t old = stale ? 0u : cur.bm;
-					const uint32_t bits = s_bm[g] | old;
-					if (bits != cur.bm) p.bitmap[(size_t)slot * 16u + g] = bits;
-				}
-				if (g == 0) {
-					const int32_t mn = min((int32_t)cur.meta.x, vmin), mx = max((int32_t)cur.meta.y, vmax);
-					*(uint4 *)&p.td_meta[slot] = make_uint4((uint32_t)mn, (uint32_t)mx, do_merge ? npend : npend + m, p.epoch);
-				} else if (g >= 4u && g < 8u) {
-					const uint32_t r = g - 4u;
-					atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(cur.gid, GYS_SEED + r) & (GYS_CMS_W - 1))], m);
-				}
-				if (do_merge) merge_rounds |= 1u << rd;
-			}
-			GYS_WAVE_SYNC();
-			if (rnext >= 16u) break;
-			rd = rnext;
-			cur = nxt;
-		}
-		// ---- queue the keys whose buffer overflowed: lane = key of the chunk again (its count / offset are still in registers)
-		{
-			const uint32_t mr = (uint32_t)__shfl((int)merge_rounds, (int)((lane & 3u) * 16u), 64);
-			const bool need = (mr >> (lane >> 2)) & 1u;
-			const unsigned long long nb = __ballot(need);
-			if (nb) {
-				uint32_t at = 0;
-				if (lane == 0) at = atomicAdd(p.merge_count, (uint32_t)__popcll(nb));
-				at = (uint32_t)__shfl((int)at, 0, 64);
-				if (need) {
-					const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-					MergeEnt e;
-					e.slot = key;
-					e.m = mcnt;
-					e.off_end = oend;
-					e.pad = 0;
-					p.merge_list[at + (uint32_t)__popcll(nb & below)] = e;
-				}
-			}
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x < 31u && s_gh[threadIdx.x]) atomicAdd(&p.ghist[threadIdx.x], s_gh[threadIdx.x]);
-	if (threadIdx.x == 31u && s_gmax != INT64_MIN) atomicMax(p.gmax, s_gmax);
-}
-
 // quarter-octave grid cell of a value < 2^20: 0,1,2,3 for 0..3, then 4 cells per power of two (monotone; <= 75)
 __device__ __forceinline__ uint32_t value_grid(uint32_t v)
 {
@@ -1011,30 +968,9 @@ __device__ __forceinline__ uint32_t value_grid(uint32_t v)
 	const uint32_t msb = 31u - (uint32_t)__clz((int)v);
 	return 4u * (msb - 1u) + ((v >> (msb - 2u)) & 3u);
 }
-#define GYS_IVL 192u // refined intervals: gap index (<= 100) + grid cell (<= 75) < 192 = 3 per lane
+#define GYS_IVL 320u // refined intervals: gap index (<= 200) + grid cell (<= 75) < 320 = 5 per lane of one wave
+#define GYS_NBP 256u // cluster arrays padded to a power of two for the branch-free searches
 
-// ---- k_digest_merge: one 64-thread workgroup (= one wave) per merge-list entry.  Exact-integer k-bucket merge (DESIGN.md "t-digest"):
-//   values = the key's buffered values + the batch's new values; merged order = by mean, old clusters before values on ties; an item
-//   with weighted mid-point mid2/2 of N goes to cluster #{j : mid2 >= T_j}, T_j = ceil(BND[j] * 2N / 2^32).
-// No sort: the (<= 100) old cluster means cut the value axis into gaps; gap(v) = #{clusters with mean <= v} comes from a branch-free
-// search; the gaps are refined by a fixed quarter-octave value grid (so a cell stays small even when the digest is empty or the
-// distribution has moved away from its clusters); a counting sort by refined interval groups the values in LDS, and a value's rank
-// is (values in lower intervals) + (its rank inside its own interval, by direct comparison -- an interval holds a handful of the
-// batch's values, all equal for typical integer-ms data).  Old cluster c is preceded by exactly the values of gaps 0..c.  Everything else is integer
-// arithmetic on ranks, so the result equals the sorted-merge definition bit for bit (ties among equal values are interchangeable).
-// query mode (out_sum != nullptr): entry w writes the merged view of its key to out_sum/out_cnt[w*100..] and leaves the state alone.
-#define GYS_MERGE_MAX (GYS_TD_PEND_CAP + GYS_SMALL_MAX)
-
-struct MergeP {
-	DigestP d;
-	const MergeEnt *list;
-	const uint32_t *count;
-	int64_t *out_sum;
-	uint32_t *out_cnt;
-};
-
-// Three instantiations share the list, split by the number of new values (LDS for CAP + NEWMAX values: the smaller the class, the more
-// waves are resident): NEWMAX = 128 takes the entries with <= 128 new values, 384 those with 129..384, GYS_SMALL_MAX the rest.
 // ceil(cs / cc) for 0 <= cs < 2^52, cc >= 1 (a cluster's integer "mean threshold": mean <= v  <=>  ceil(cs/cc) <= v for integer v)
 __device__ __forceinline__ uint32_t ceil_div_sum_cnt(int64_t cs, uint32_t cc)
 {
@@ -1050,252 +986,272 @@ __device__ __forceinline__ uint32_t ceil_div_sum_cnt(int64_t cs, uint32_t cc)
 	return (uint32_t)(f + (r != 0));
 }
 
-template <uint32_t NEWMAX>
-__global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
+// ---- k_digest_merge: one workgroup of NT threads per merge-list entry.  Exact-integer k-bucket merge (DESIGN.md "t-digest"):
+//   values = the key's buffered words (+ its run when the key spilled); merged order = by mean, old clusters before values on ties; an
+//   item with weighted mid-point mid2/2 of N goes to cluster #{j : mid2 >= T_j}, T_j = ceil(BND[j] * 2N / 2^32).
+// No sort: the (<= 200) old cluster means cut the value axis into gaps; gap(v) = #{clusters with mean <= v} comes from a branch-free
+// search; the gaps are refined by a fixed quarter-octave value grid (so a cell stays small even when the digest is empty or the
+// distribution has moved away from its clusters); a counting sort by refined interval groups the values in LDS, and a value's rank
+// is (values in lower intervals) + (its rank inside its own interval, by direct comparison -- an interval holds a handful of the
+// values, all equal for typical integer-ms data).  Old cluster c is preceded by exactly the values of gaps 0..c.  Everything else is
+// integer arithmetic on ranks, so the result equals the sorted-merge definition bit for bit (ties among equal values are interchangeable).
+// The not yet folded values of the key are folded into its records on the way (they leave the buffer here).
+// query mode (out_sum != nullptr): entry w writes the merged view of its key to out_sum/out_cnt[w*NB..] and leaves the state alone.
+struct MergeP {
+	DigestP d;
+	const MergeEnt *list;
+	const uint32_t *count;
+	int64_t *out_sum;
+	uint32_t *out_cnt;
+};
+
+template <uint32_t MAXV, uint32_t MINV, uint32_t NT>
+__global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 {
 	const DigestP &p = q.d;
-	__shared__ uint32_t s_x[GYS_TD_PEND_CAP + NEWMAX];  // interval << 20 | value, in arrival order
-	__shared__ uint32_t s_g[GYS_TD_PEND_CAP + NEWMAX];  // the same words grouped by interval
-	__shared__ uint32_t s_thr[128];          // compacted non-empty old clusters: ceil(sum / count), padded with ~0 for the branch-free search
-	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
-	__shared__ uint64_t s_T[128];            // s_T[j], j = 1..NB-1; [NB..127] = ~0 (never reached)
+	__shared__ uint32_t s_x[MAXV];            // interval << 20 | value, in arrival order
+	__shared__ uint32_t s_g[MAXV];            // the same words grouped by interval
+	__shared__ uint32_t s_thr[GYS_NBP];       // compacted non-empty old clusters: ceil(sum / count), padded with ~0 for the branch-free search
+	__shared__ uint64_t s_cpfx[GYS_NBP + 1];  // old weight before compacted cluster c
+	__shared__ uint64_t s_T[GYS_NBP];         // s_T[j], j = 1..NB-1; [0] = 0, [NB..] = ~0 (never reached)
 	__shared__ uint32_t s_imin[GYS_IVL], s_imax[GYS_IVL]; // smallest / largest value of each interval
-	__shared__ unsigned long long s_osum[GYS_TD_NB];
-	__shared__ uint32_t s_ocnt[GYS_TD_NB];
-	__shared__ uint32_t s_icnt[GYS_IVL];     // values per (refined) interval, then the running scatter cursor
-	__shared__ uint32_t s_ioff[GYS_IVL + 1]; // exclusive prefix of s_icnt (s_ioff[i + 1] = values in intervals 0..i)
-	__shared__ uint32_t s_clt[GYS_TD_NB + 2]; // s_clt[c + 1] = values below the mean of compacted cluster c (prefix of the per-cluster-gap counts)
-	const uint32_t lane = threadIdx.x;
+	__shared__ unsigned long long s_osum[GYS_NBP];
+	__shared__ uint32_t s_ocnt[GYS_NBP];
+	__shared__ uint32_t s_icnt[GYS_IVL];      // values per (refined) interval, then the running scatter cursor
+	__shared__ uint32_t s_ioff[GYS_IVL + 1];  // exclusive prefix of s_icnt (s_ioff[i + 1] = values in intervals 0..i)
+	__shared__ uint32_t s_clt[GYS_IVL];       // s_clt[c + 1] = values below the mean of compacted cluster c (prefix of the per-cluster-gap counts)
+	__shared__ unsigned long long s_fa[16], s_fw[16]; // fold: packed bucket deltas of the not yet folded values (all / window part)
+	__shared__ uint32_t s_fbm[16];
+	__shared__ int32_t s_fmm[3];              // fold: min, max (all), max (window part)
+	__shared__ uint32_t s_wv[2 * (NT / 64) + 2];
+	__shared__ uint64_t s_ww[NT / 64];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t nent = *q.count;
+	const bool query = q.out_sum != nullptr;
 
 	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
 		const MergeEnt ent = q.list[w];
-		if (NEWMAX == 128u ? ent.m > 128u : (NEWMAX == 384u ? (ent.m <= 128u || ent.m > 384u) : ent.m <= 384u)) continue; // another class's entry
+		const uint32_t m = ent.nbuf + ent.mrun;
+		if (m > MAXV || m <= MINV) continue; // another size class's entry
 		const uint32_t slot = ent.slot;
-		const uint32_t npend = p.td_meta[slot].npend;
-		const uint32_t m = npend + ent.m;
-		const uint32_t start = ent.off_end - ent.m;
+		const uint4 mt = *(const uint4 *)&p.td_meta[slot];
+		const uint32_t nh = query ? ent.nbuf : (mt.y & 0xFFFFu), nw = mt.y >> 16;
+		const uint32_t nwin0 = max(nh, nw);
+		const uint32_t run0 = ent.off_end - ent.mrun;
 
-		// ---- old digest: entries lane, lane+64
+		// ---- old digest: thread t < 256 holds cluster t
 		const int64_t *gs = p.td_sum + (size_t)slot * GYS_TD_NB;
 		const uint32_t *gc = p.td_cnt + (size_t)slot * GYS_TD_NB;
-		const uint32_t j1 = lane + 64u;
-		const uint32_t c0 = gc[lane];
-		const uint32_t c1 = j1 < GYS_TD_NB ? gc[j1] : 0u;
-		const int64_t sm0 = gs[lane];
-		const int64_t sm1 = j1 < GYS_TD_NB ? gs[j1] : 0;
+		uint32_t c0 = 0;
+		int64_t sm0 = 0;
+		if (tid < GYS_TD_NB) {
+			c0 = gc[tid];
+			sm0 = gs[tid];
+		}
 		if (m == 0) { // nothing buffered (query of a freshly merged key): the merged view is the digest itself
-			if (q.out_sum) {
-				q.out_sum[(size_t)w * GYS_TD_NB + lane] = sm0;
-				q.out_cnt[(size_t)w * GYS_TD_NB + lane] = c0;
-				if (j1 < GYS_TD_NB) {
-					q.out_sum[(size_t)w * GYS_TD_NB + j1] = sm1;
-					q.out_cnt[(size_t)w * GYS_TD_NB + j1] = c1;
-				}
+			if (query && tid < GYS_TD_NB) {
+				q.out_sum[(size_t)w * GYS_TD_NB + tid] = sm0;
+				q.out_cnt[(size_t)w * GYS_TD_NB + tid] = c0;
 			}
 			continue;
 		}
-		// compaction of non-empty clusters (order preserving): compacted index pos0 / pos1 of this lane's two entries
-		const unsigned long long b0 = __ballot(c0 != 0), b1 = __ballot(c1 != 0);
-		const uint32_t n0 = (uint32_t)__popcll(b0), nc = n0 + (uint32_t)__popcll(b1);
-		const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-		const uint32_t pos0 = (uint32_t)__popcll(b0 & below), pos1 = n0 + (uint32_t)__popcll(b1 & below);
-		uint64_t e0, e1, nold;
-		wave_excl_scan_2x((uint64_t)c0, (uint64_t)c1, &e0, &e1, &nold);
-		s_thr[lane] = 0xFFFFFFFFu; // pad: mean = +inf
-		s_thr[j1] = 0xFFFFFFFFu;
-		GYS_WAVE_SYNC();
+		// compaction of the non-empty clusters (order preserving) + exclusive prefix of their weights, over the first four waves
+		uint32_t pos0 = 0, nc = 0;
+		uint64_t e0 = 0, nold = 0;
+		{
+			const unsigned long long b0 = __ballot(c0 != 0);
+			const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+			uint64_t inc = c0;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint64_t t = __shfl_up(inc, d, 64);
+				if ((int)lane >= d) inc += t;
+			}
+			if (lane == 63u) s_ww[wave] = inc;
+			if (lane == 0u) s_wv[wave] = (uint32_t)__popcll(b0);
+			__syncthreads();
+			uint32_t pbase = 0;
+			uint64_t wbase = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; ++k) {
+				if (k < wave) {
+					pbase += s_wv[k];
+					wbase += s_ww[k];
+				}
+				nc += s_wv[k];
+				nold += s_ww[k];
+			}
+			pos0 = pbase + (uint32_t)__popcll(b0 & below);
+			e0 = wbase + inc - c0;
+		}
+		const uint64_t twoN = 2ull * (nold + (uint64_t)m);
+		if (tid < GYS_NBP) {
+			s_thr[tid] = 0xFFFFFFFFu; // pad: mean = +inf
+			s_T[tid] = (tid >= 1u && tid < GYS_TD_NB) ? td_threshold(c_td_bnd[tid], twoN) : (tid ? ~0ull : 0ull);
+			s_osum[tid] = 0;
+			s_ocnt[tid] = 0;
+		}
+		for (uint32_t i = tid; i < GYS_IVL; i += NT) {
+			s_icnt[i] = 0;
+			s_imin[i] = 0xFFFFFFFFu;
+			s_imax[i] = 0;
+			s_clt[i] = 0;
+		}
+		if (tid < 16u) {
+			s_fa[tid] = 0;
+			s_fw[tid] = 0;
+			s_fbm[tid] = 0;
+		}
+		if (tid == 0) {
+			s_fmm[0] = INT32_MAX;
+			s_fmm[1] = INT32_MIN;
+			s_fmm[2] = INT32_MIN;
+		}
+		__syncthreads();
 		if (c0) {
 			s_thr[pos0] = ceil_div_sum_cnt(sm0, c0);
 			s_cpfx[pos0] = e0;
 		}
-		if (c1) {
-			s_thr[pos1] = ceil_div_sum_cnt(sm1, c1);
-			s_cpfx[pos1] = e1;
-		}
-		if (lane == 0) s_cpfx[nc] = nold;
-		const uint64_t twoN = 2ull * (nold + (uint64_t)m);
-		if (lane >= 1) s_T[lane] = td_threshold(c_td_bnd[lane], twoN);
-		s_T[j1] = j1 < GYS_TD_NB ? td_threshold(c_td_bnd[j1], twoN) : ~0ull;
-		s_osum[lane] = 0;
-		s_ocnt[lane] = 0;
-		for (uint32_t i = lane; i < GYS_IVL; i += 64u) {
-			s_icnt[i] = 0;
-			s_imin[i] = 0xFFFFFFFFu;
-			s_imax[i] = 0;
-		}
-		s_clt[lane] = 0;
-		if (j1 < GYS_TD_NB + 2) s_clt[j1] = 0;
-		if (j1 < GYS_TD_NB) {
-			s_osum[j1] = 0;
-			s_ocnt[j1] = 0;
-		}
+		if (tid == 0) s_cpfx[nc] = nold;
 		__syncthreads();
-		// the first three levels of both 7-level searches are decided against pivots held in registers (every 16th entry: 8 independent
-		// compares instead of 3 dependent LDS round trips); the last four levels walk the 16-entry block in LDS
-		uint32_t pthr[8];
-		uint64_t pT[7];
-#pragma unroll
-		for (int k = 0; k < 8; ++k) pthr[k] = s_thr[16 * k + 15];
-#pragma unroll
-		for (int k = 0; k < 7; ++k) pT[k] = s_T[16 * (k + 1)];
-		// ---- values (buffered, then new): gap = #{clusters with mean <= v} = #{thresholds <= v}, two values per lane and iteration so that
-		// the two dependent LDS searches overlap
+		// ---- values (buffered, then the run): gap = #{clusters with mean <= v} = #{thresholds <= v}
 		{
-			const uint32_t *pend = p.td_pend + (size_t)slot * GYS_TD_PEND_CAP;
-			for (uint32_t base = 0; base < m; base += 128u) {
-				uint32_t uv[2], lo[2];
+			const uint32_t *pend = p.td_pend + (size_t)slot * p.pcap;
+			int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmax = INT32_MIN;
+			for (uint32_t i = tid; i < m; i += NT) {
+				const uint32_t word = i < ent.nbuf ? pend[i] : p.staged[run0 + (i - ent.nbuf)];
+				const uint32_t uv = word >> GYS_ROW_BITS;
+				uint32_t lo = 0;
 #pragma unroll
-				for (int u = 0; u < 2; ++u) {
-					const uint32_t i = base + lane + 64u * u;
-					uv[u] = 0;
-					if (i < m) uv[u] = i < npend ? pend[i] : (p.staged[start + (i - npend)] >> GYS_ROW_BITS);
-					uint32_t blocks = 0; // 16-entry blocks that lie entirely at or below the value (the thresholds ascend)
-#pragma unroll
-					for (int k = 0; k < 8; ++k) blocks += pthr[k] <= uv[u] ? 1u : 0u;
-					lo[u] = 16u * blocks;
+				for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
+					if (s_thr[lo + step - 1u] <= uv) lo += step;
+				// refined interval: the cluster means AND a fixed quarter-octave value grid cut the axis (both monotone in v, so
+				// their sum numbers the cells of the common refinement in value order)
+				const uint32_t iv = lo + value_grid(uv);
+				s_x[i] = (iv << 20) | uv;
+				atomicAdd(&s_icnt[iv], 1u);
+				atomicMin(&s_imin[iv], uv);
+				atomicMax(&s_imax[iv], uv);
+				atomicAdd(&s_clt[lo + 1], 1u);
+				if (i >= nh) { // not yet folded: histogram bucket of the key's records, CONN_BITMAP row, min / max
+					const uint32_t b = resp_bucket((int64_t)uv);
+					const unsigned long long one = GYS_PACK_ONE | (unsigned long long)uv;
+					atomicAdd(&s_fa[b], one);
+					lmin = min(lmin, (int32_t)uv);
+					lmax = max(lmax, (int32_t)uv);
+					if (i >= nwin0) {
+						atomicAdd(&s_fw[b], one);
+						const uint32_t r = word & 0x1Fu;
+						atomicOr(&s_fbm[r >> 1], (1u << b) << ((r & 1u) * 16u));
+						wmax = max(wmax, (int32_t)uv);
+					}
 				}
+			}
+			if (!query && m > nh) {
 #pragma unroll
-				for (uint32_t step = 8u; step >= 1u; step >>= 1) {
-#pragma unroll
-					for (int u = 0; u < 2; ++u)
-						if (lo[u] < 128u && s_thr[lo[u] + step - 1u] <= uv[u]) lo[u] += step;
+				for (int d = 32; d >= 1; d >>= 1) {
+					lmin = min(lmin, __shfl_xor(lmin, d, 64));
+					lmax = max(lmax, __shfl_xor(lmax, d, 64));
+					wmax = max(wmax, __shfl_xor(wmax, d, 64));
 				}
-#pragma unroll
-				for (int u = 0; u < 2; ++u) {
-					const uint32_t i = base + lane + 64u * u;
-					if (i >= m) continue;
-					// refined interval: the cluster means AND a fixed quarter-octave value grid cut the axis (both monotone in v, so
-					// their sum numbers the cells of the common refinement in value order); the grid bounds a cell's population
-					// when the digest is still empty or the distribution has moved away from its clusters
-					const uint32_t iv = lo[u] + value_grid(uv[u]);
-					s_x[i] = (iv << 20) | uv[u];
-					atomicAdd(&s_icnt[iv], 1u);
-					atomicMin(&s_imin[iv], uv[u]);
-					atomicMax(&s_imax[iv], uv[u]);
-					atomicAdd(&s_clt[lo[u] + 1], 1u);
+				if (lane == 0) {
+					if (lmin != INT32_MAX) atomicMin(&s_fmm[0], lmin);
+					if (lmax != INT32_MIN) atomicMax(&s_fmm[1], lmax);
+					if (wmax != INT32_MIN) atomicMax(&s_fmm[2], wmax);
 				}
 			}
 		}
 		__syncthreads();
-		// ---- exclusive scan of the refined-interval counts (GYS_IVL = 3 x 64 entries: 3 consecutive per lane) and inclusive scan of
-		// the per-cluster-gap counts (s_clt[c + 1] := values in cluster gaps 0..c = values below the mean of cluster c)
-		{
-			const uint32_t t0 = s_icnt[3u * lane], t1 = s_icnt[3u * lane + 1u], t2 = s_icnt[3u * lane + 2u];
-			const uint32_t own = t0 + t1 + t2;
-			uint32_t inc = own;
-			uint32_t g0 = s_clt[lane], g1 = j1 < GYS_TD_NB + 2 ? s_clt[j1] : 0u;
+		// ---- exclusive scan of the refined-interval counts and inclusive scan of the per-cluster-gap counts (GYS_IVL = 5 x 64
+		// entries each: wave 0 takes 5 consecutive entries per lane of both arrays)
+		if (wave == 0) {
+			uint32_t t[5], gcl[5];
+			uint32_t own = 0, gown = 0;
+#pragma unroll
+			for (int k = 0; k < 5; ++k) {
+				t[k] = s_icnt[5u * lane + k];
+				gcl[k] = s_clt[5u * lane + k];
+				own += t[k];
+				gown += gcl[k];
+			}
+			uint32_t inc = own, ginc = gown;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t u = __shfl_up(inc, d, 64), u0 = __shfl_up(g0, d, 64), u1 = __shfl_up(g1, d, 64);
+				const uint32_t u = __shfl_up(inc, d, 64), gu = __shfl_up(ginc, d, 64);
 				if ((int)lane >= d) {
 					inc += u;
-					g0 += u0;
-					g1 += u1;
+					ginc += gu;
 				}
 			}
-			const uint32_t ex = inc - own;
-			s_ioff[3u * lane] = ex;
-			s_ioff[3u * lane + 1u] = ex + t0;
-			s_ioff[3u * lane + 2u] = ex + t0 + t1;
+			uint32_t ex = inc - own, gex = ginc - gown;
+#pragma unroll
+			for (int k = 0; k < 5; ++k) {
+				s_ioff[5u * lane + k] = ex;
+				s_icnt[5u * lane + k] = ex; // scatter cursors
+				ex += t[k];
+				gex += gcl[k];
+				s_clt[5u * lane + k] = gex;
+			}
 			if (lane == 63u) s_ioff[GYS_IVL] = inc;
-			s_icnt[3u * lane] = ex; // scatter cursors
-			s_icnt[3u * lane + 1u] = ex + t0;
-			s_icnt[3u * lane + 2u] = ex + t0 + t1;
-			const uint32_t gt0 = __shfl(g0, 63, 64);
-			s_clt[lane] = g0;
-			if (j1 < GYS_TD_NB + 2) s_clt[j1] = gt0 + g1;
 		}
 		__syncthreads();
-		for (uint32_t i = lane; i < m; i += 64u) {
+		for (uint32_t i = tid; i < m; i += NT) {
 			const uint32_t x = s_x[i];
 			s_g[atomicAdd(&s_icnt[x >> 20], 1u)] = x;
 		}
 		__syncthreads();
-		// ---- old clusters (this lane's two entries, from registers): preceded by the old weight before them and by the values of
-		// gaps 0..c (= values below the mean)
-		{
-			uint64_t mid2[2] = {0, 0};
-			if (c0) mid2[0] = 2ull * (e0 + (uint64_t)s_clt[pos0 + 1]) + (uint64_t)c0;
-			if (c1) mid2[1] = 2ull * (e1 + (uint64_t)s_clt[pos1 + 1]) + (uint64_t)c1;
-			uint32_t a[2];
+		// ---- old clusters (one per thread, from registers): preceded by the old weight before them and by the values of gaps 0..c
+		// (= values below the mean)
+		if (c0) {
+			const uint64_t mid2 = 2ull * (e0 + (uint64_t)s_clt[pos0 + 1]) + (uint64_t)c0;
+			uint32_t a = 0;
 #pragma unroll
-			for (int u = 0; u < 2; ++u) {
-				uint32_t blocks = 0;
-#pragma unroll
-				for (int k = 0; k < 7; ++k) blocks += mid2[u] >= pT[k] ? 1u : 0u;
-				a[u] = 16u * blocks;
-			}
-#pragma unroll
-			for (uint32_t step = 8u; step >= 1u; step >>= 1) {
-#pragma unroll
-				for (int u = 0; u < 2; ++u)
-					if (mid2[u] >= s_T[a[u] + step]) a[u] += step;
-			}
-			if (c0) {
-				atomicAdd(&s_osum[a[0]], (unsigned long long)sm0);
-				atomicAdd(&s_ocnt[a[0]], c0);
-			}
-			if (c1) {
-				atomicAdd(&s_osum[a[1]], (unsigned long long)sm1);
-				atomicAdd(&s_ocnt[a[1]], c1);
-			}
+			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
+				if (mid2 >= s_T[a + step]) a += step;
+			atomicAdd(&s_osum[a], (unsigned long long)sm0);
+			atomicAdd(&s_ocnt[a], c0);
 		}
 		// ---- values: rank = values in lower intervals + rank inside the interval (ties by position); W adds the old weight <= v
-		for (uint32_t base = 0; base < m; base += 128u) {
-			uint32_t x[2];
-			uint64_t mid2[2];
-			bool live[2];
-#pragma unroll
-			for (int u = 0; u < 2; ++u) {
-				const uint32_t e = base + lane + 64u * u;
-				live[u] = e < m;
-				x[u] = live[u] ? s_g[e] : 0u;
-				const uint32_t iv = x[u] >> 20;
-				uint32_t r = e; // an interval of equal values (the usual case for integer ms data): ties rank by position
-				if (live[u] && s_imin[iv] != s_imax[iv]) {
-					const uint32_t gb = s_ioff[iv], ge = s_ioff[iv + 1];
-					r = gb;
-					for (uint32_t t = gb; t < ge; ++t) {
-						const uint32_t y = s_g[t];
-						r += (y < x[u] || (y == x[u] && t < e)) ? 1u : 0u;
-					}
+		for (uint32_t e = tid; e < m; e += NT) {
+			const uint32_t x = s_g[e];
+			const uint32_t iv = x >> 20;
+			uint32_t r = e; // an interval of equal values (the usual case for integer ms data): ties rank by position
+			if (s_imin[iv] != s_imax[iv]) {
+				const uint32_t gb = s_ioff[iv], ge = s_ioff[iv + 1];
+				r = gb;
+				for (uint32_t t = gb; t < ge; ++t) {
+					const uint32_t y = s_g[t];
+					r += (y < x || (y == x && t < e)) ? 1u : 0u;
 				}
-				mid2[u] = 2ull * ((uint64_t)r + s_cpfx[iv - value_grid(x[u] & 0xFFFFFu)]) + 1ull; // old weight with mean <= v
 			}
-			uint32_t a[2];
+			const uint64_t mid2 = 2ull * ((uint64_t)r + s_cpfx[iv - value_grid(x & 0xFFFFFu)]) + 1ull; // old weight with mean <= v
+			uint32_t a = 0;
 #pragma unroll
-			for (int u = 0; u < 2; ++u) {
-				uint32_t blocks = 0;
-#pragma unroll
-				for (int k = 0; k < 7; ++k) blocks += mid2[u] >= pT[k] ? 1u : 0u;
-				a[u] = 16u * blocks;
-			}
-#pragma unroll
-			for (uint32_t step = 8u; step >= 1u; step >>= 1) {
-#pragma unroll
-				for (int u = 0; u < 2; ++u)
-					if (mid2[u] >= s_T[a[u] + step]) a[u] += step;
-			}
-#pragma unroll
-			for (int u = 0; u < 2; ++u) {
-				if (!live[u]) continue;
-				atomicAdd(&s_osum[a[u]], (unsigned long long)(x[u] & 0xFFFFFu));
-				atomicAdd(&s_ocnt[a[u]], 1u);
-			}
+			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
+				if (mid2 >= s_T[a + step]) a += step;
+			atomicAdd(&s_osum[a], (unsigned long long)(x & 0xFFFFFu));
+			atomicAdd(&s_ocnt[a], 1u);
 		}
 		__syncthreads();
 		// ---- write back
-		const bool query = q.out_sum != nullptr;
-		int64_t *ws = query ? q.out_sum + (size_t)w * GYS_TD_NB : p.td_sum + (size_t)slot * GYS_TD_NB;
-		uint32_t *wc = query ? q.out_cnt + (size_t)w * GYS_TD_NB : p.td_cnt + (size_t)slot * GYS_TD_NB;
-		ws[lane] = (int64_t)s_osum[lane];
-		wc[lane] = s_ocnt[lane];
-		if (j1 < GYS_TD_NB) {
-			ws[j1] = (int64_t)s_osum[j1];
-			wc[j1] = s_ocnt[j1];
+		if (tid < GYS_TD_NB) {
+			int64_t *ws = query ? q.out_sum + (size_t)w * GYS_TD_NB : p.td_sum + (size_t)slot * GYS_TD_NB;
+			uint32_t *wc = query ? q.out_cnt + (size_t)w * GYS_TD_NB : p.td_cnt + (size_t)slot * GYS_TD_NB;
+			ws[tid] = (int64_t)s_osum[tid];
+			wc[tid] = s_ocnt[tid];
 		}
-		if (lane == 0 && !query) p.td_meta[slot].npend = 0;
+		if (!query) {
+			const uint32_t n_all = m - nh, n_win = m > nwin0 ? m - nwin0 : 0u;
+			if (tid < 16u && n_all) fold_records(p, slot, tid, mt.w != mt.z, s_fa[tid], s_fw[tid], n_all, n_win, s_fmm[1], s_fmm[2], s_fbm[tid]);
+			if (tid == 16u) {
+				*(uint4 *)&p.td_meta[slot] = make_uint4(0u, 0u, mt.z, n_win ? mt.z : mt.w); // buffer drained
+				p.td_cur[slot] = 0;
+				if (n_all) {
+					const int2 mm = p.td_minmax[slot];
+					if (s_fmm[0] < mm.x || s_fmm[1] > mm.y) p.td_minmax[slot] = make_int2(min(mm.x, s_fmm[0]), max(mm.y, s_fmm[1]));
+				}
+			}
+		}
 		__syncthreads();
 	}
 }
@@ -1306,7 +1262,7 @@ __global__ __launch_bounds__(64) void k_digest_merge(MergeP q)
 // cluster rank intervals -- the same exact-integer assignment as k_digest_merge without materialising a sort.
 struct HugeP {
 	DigestP d;
-	const uint32_t *huge_list;
+	const MergeEnt *huge_list;
 	const uint32_t *huge_count;
 	uint32_t *scratch; // [gridDim.x * GYS_HUGE_BINS]
 };
@@ -1321,29 +1277,36 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 	__shared__ unsigned long long s_ocnt[GYS_TD_NB];
 	__shared__ uint32_t s_part[256];
 	__shared__ uint32_t s_wave[4];
-	__shared__ unsigned long long s_h[32];
+	__shared__ unsigned long long s_ha[32], s_hw[32]; // exact {count, sum} per bucket of all values / of the window part
 	__shared__ uint32_t s_bm[16];
 	__shared__ uint32_t s_nc;
-	__shared__ int32_t s_min, s_max;
+	__shared__ int32_t s_min, s_max, s_wmax;
 	uint32_t *bins = p.scratch + (size_t)blockIdx.x * GYS_HUGE_BINS;
-	const uint32_t nh = *p.huge_count;
+	const uint32_t nh_list = *p.huge_count;
 	const uint32_t BPT = GYS_HUGE_BINS / 256u; // bins per thread (contiguous)
 
-	for (uint32_t w = blockIdx.x; w < nh; w += gridDim.x) {
-		const uint32_t slot = p.huge_list[w];
-		const uint32_t m = p.d.batch_cnt[slot];
-		const uint32_t start = p.d.off_end[slot] - m;
-		const uint32_t npend = p.d.td_meta[slot].npend; // buffered values join the merge (npend + m > CAP always holds here)
+	for (uint32_t w = blockIdx.x; w < nh_list; w += gridDim.x) {
+		const MergeEnt ent = p.huge_list[w];
+		const uint32_t slot = ent.slot;
+		const uint32_t m = ent.mrun, npend = ent.nbuf;
+		const uint32_t start = ent.off_end - m;
+		const uint4 mt = *(const uint4 *)&p.d.td_meta[slot];
+		const uint32_t nh = mt.y & 0xFFFFu, nw = mt.y >> 16;
+		const uint32_t nwin0 = max(nh, nw);
+		const uint32_t *pend = p.d.td_pend + (size_t)slot * p.d.pcap;
 		// zero the bins (16-byte stores)
 		for (uint32_t i = threadIdx.x; i < GYS_HUGE_BINS / 4u; i += 256u) ((uint4 *)bins)[i] = make_uint4(0, 0, 0, 0);
 		if (threadIdx.x < GYS_TD_NB) {
 			s_osum[threadIdx.x] = 0;
 			s_ocnt[threadIdx.x] = 0;
 		}
-		if (threadIdx.x >= 128u && threadIdx.x < 160u) s_h[threadIdx.x - 128u] = 0;
+		if (threadIdx.x < 32u) {
+			s_ha[threadIdx.x] = 0;
+			s_hw[threadIdx.x] = 0;
+		}
 		if (threadIdx.x >= 160u && threadIdx.x < 176u) s_bm[threadIdx.x - 160u] = 0;
 		if (threadIdx.x == 0) {
-			// compact non-empty old clusters (serial: 100 entries, once per huge key)
+			// compact non-empty old clusters (serial: <= 200 entries, once per huge key)
 			const int64_t *gs = p.d.td_sum + (size_t)slot * GYS_TD_NB;
 			const uint32_t *gc = p.d.td_cnt + (size_t)slot * GYS_TD_NB;
 			uint32_t nc = 0;
@@ -1361,6 +1324,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 			s_nc = nc;
 			s_min = INT32_MAX;
 			s_max = INT32_MIN;
+			s_wmax = INT32_MIN;
 		}
 		__syncthreads();
 		const uint32_t nc = s_nc;
@@ -1368,25 +1332,32 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 		const uint64_t twoN = 2ull * (nold + (uint64_t)m + (uint64_t)npend);
 		if (threadIdx.x >= 1 && threadIdx.x < GYS_TD_NB) s_T[threadIdx.x] = td_threshold(c_td_bnd[threadIdx.x], twoN);
 		if (threadIdx.x == 0) s_T[GYS_TD_NB] = ~0ull;
-		// exact value histogram
+		// exact value histogram of (buffered + run) values; the records' deltas come from the not yet folded ones
 		{
-			int32_t lmin = INT32_MAX, lmax = INT32_MIN;
-			for (uint32_t i = threadIdx.x; i < m; i += 256u) {
-				const uint32_t w = p.d.staged[start + i];
-				const uint32_t v = (w >> GYS_ROW_BITS) & (GYS_HUGE_BINS - 1u);
+			int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmax = INT32_MIN;
+			for (uint32_t i = threadIdx.x; i < npend + m; i += 256u) {
+				const uint32_t word = i < npend ? pend[i] : p.d.staged[start + (i - npend)];
+				const uint32_t v = (word >> GYS_ROW_BITS) & (GYS_HUGE_BINS - 1u);
 				atomicAdd(&bins[v], 1u);
-				{
-					const uint32_t row = w & 0x1Fu;
-					const uint32_t bit = (1u << resp_bucket((int64_t)v)) << ((row & 1u) * 16u);
-					if ((s_bm[row >> 1] & bit) == 0) atomicOr(&s_bm[row >> 1], bit);
+				if (i >= nh) {
+					const uint32_t hb = resp_bucket((int64_t)v);
+					atomicAdd(&s_ha[2 * hb], 1ull);
+					atomicAdd(&s_ha[2 * hb + 1], (unsigned long long)v);
+					lmin = min(lmin, (int32_t)v);
+					lmax = max(lmax, (int32_t)v);
+					if (i >= nwin0) {
+						atomicAdd(&s_hw[2 * hb], 1ull);
+						atomicAdd(&s_hw[2 * hb + 1], (unsigned long long)v);
+						const uint32_t row = word & 0x1Fu;
+						const uint32_t bit = (1u << hb) << ((row & 1u) * 16u);
+						if ((s_bm[row >> 1] & bit) == 0) atomicOr(&s_bm[row >> 1], bit);
+						wmax = max(wmax, (int32_t)v);
+					}
 				}
-				lmin = min(lmin, (int32_t)v);
-				lmax = max(lmax, (int32_t)v);
 			}
 			atomicMin(&s_min, lmin);
 			atomicMax(&s_max, lmax);
-			for (uint32_t i = threadIdx.x; i < npend; i += 256u)
-				atomicAdd(&bins[p.d.td_pend[(size_t)slot * GYS_TD_PEND_CAP + i] & (GYS_HUGE_BINS - 1u)], 1u);
+			atomicMax(&s_wmax, wmax);
 		}
 		__syncthreads();
 		// the atomics above were performed in L2; drop this CU's L1 copies of the bins before reading them with plain loads
@@ -1439,11 +1410,6 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 				const uint32_t c = bins[b];
 				if (!c) continue;
 				const int64_t v = (int64_t)b;
-				{
-					const uint32_t hb = resp_bucket(v); // exact histogram delta of the key from the value counts
-					atomicAdd(&s_h[2 * hb], (unsigned long long)c);
-					atomicAdd(&s_h[2 * hb + 1], (unsigned long long)((uint64_t)c * (uint64_t)v));
-				}
 				while (ci < nc && s_csum[ci] <= v * (int64_t)s_ccnt[ci]) ci++;
 				const uint64_t le = s_cpfx[ci];
 				const uint64_t first = 2ull * (r0 + le) + 1ull, last = first + 2ull * (uint64_t)(c - 1u);
@@ -1471,69 +1437,54 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 			}
 		}
 		__syncthreads();
-		// the value counts included the buffered values: their histogram contribution was already applied when they were appended
-		for (uint32_t i = threadIdx.x; i < npend; i += 256u) {
-			const uint64_t pv = (uint64_t)(p.d.td_pend[(size_t)slot * GYS_TD_PEND_CAP + i] & (GYS_HUGE_BINS - 1u));
-			const uint32_t hb = resp_bucket((int64_t)pv);
-			atomicAdd(&s_h[2 * hb], ~0ull);          // -1
-			atomicAdd(&s_h[2 * hb + 1], 0ull - pv);  // -value
-		}
-		__syncthreads();
 		if (threadIdx.x < GYS_TD_NB) {
 			p.d.td_sum[(size_t)slot * GYS_TD_NB + threadIdx.x] = (int64_t)s_osum[threadIdx.x];
 			p.d.td_cnt[(size_t)slot * GYS_TD_NB + threadIdx.x] = (uint32_t)s_ocnt[threadIdx.x];
 		}
 		{
-			// the key's batch deltas: s_h[2b] = count, s_h[2b+1] = sum of bucket b, m new values, s_max = largest; the key is owned by this
-			// workgroup for the batch, so the records are updated with plain read-modify-writes (lazy window roll as in k_key_pass)
-			const bool stale = p.d.td_meta[slot].win_epoch != p.d.epoch;
-			const uint32_t t = threadIdx.x - 128u; // lanes 0..15: histogram pairs, 16..19: Count-Min rows, 20..35: CONN_BITMAP words
+			// the key's record deltas (the key is owned by this workgroup for the batch: plain read-modify-writes, see fold_records)
+			const uint32_t n_all = npend + m - nh, n_win = npend + m - nwin0;
+			const uint32_t t = threadIdx.x - 128u;
 			if (threadIdx.x >= 128u && t < 16u) {
-				gys_hist_serial *wp = (gys_hist_serial *)&p.d.hist_win[slot] + t, *ap = (gys_hist_serial *)&p.d.hist_all[slot] + t;
-				gys_hist_serial wv = *wp;
-				if (stale) { // all-time += old window record
-					gys_hist_serial av = *ap;
-					if (t < 15u) {
-						av.count += wv.count;
-						av.sum += wv.sum;
-					} else {
-						av.count += wv.count;
-						if (av.sum < wv.sum) av.sum = wv.sum;
-					}
-					*ap = av;
-					wv.count = 0;
-					wv.sum = t < 15u ? 0 : INT64_MIN;
-				}
+				// huge keys can exceed the packed accumulators' ranges: exact 64-bit pairs, same rules as fold_records
+				gys_hist_serial *ap = (gys_hist_serial *)&p.d.hist_all[slot] + t, *wp = (gys_hist_serial *)&p.d.hist_win[slot] + t;
+				const bool roll = mt.w != mt.z;
+				gys_hist_serial av = *ap;
 				if (t < 15u) {
-					wv.count += s_h[2 * t];
-					wv.sum += (int64_t)s_h[2 * t + 1];
-					if (s_h[2 * t]) {
-						atomicAdd(&p.d.ghist[2 * t], s_h[2 * t]);
-						atomicAdd(&p.d.ghist[2 * t + 1], s_h[2 * t + 1]);
-					}
+					av.count += s_ha[2 * t];
+					av.sum += (int64_t)s_ha[2 * t + 1];
 				} else {
-					wv.count += m; // total_count_
-					if (wv.sum < (int64_t)s_max) wv.sum = (int64_t)s_max; // max_val_seen_
-					atomicAdd(&p.d.ghist[30], (unsigned long long)m);
-					atomicMax(p.d.gmax, (long long)s_max);
+					av.count += n_all;
+					if (av.sum < (int64_t)s_max) av.sum = (int64_t)s_max;
 				}
-				*wp = wv;
-			} else if (threadIdx.x >= 128u && t < 20u) {
-				const uint32_t r = t - 16u;
-				atomicAdd(&p.d.cms32[r * GYS_CMS_W + (jhash2_u64(p.d.svc_gid[slot], GYS_SEED + r) & (GYS_CMS_W - 1))], m);
-			} else if (threadIdx.x >= 128u && t < 36u) {
-				uint32_t *bp = &p.d.bitmap[(size_t)slot * 16u + (t - 20u)];
-				*bp = (stale ? 0u : *bp) | s_bm[t - 20u];
+				*ap = av;
+				if (n_win) {
+					gys_hist_serial wv;
+					if (roll) {
+						wv.count = 0;
+						wv.sum = t < 15u ? 0 : INT64_MIN;
+					} else {
+						wv = *wp;
+					}
+					if (t < 15u) {
+						wv.count += s_hw[2 * t];
+						wv.sum += (int64_t)s_hw[2 * t + 1];
+					} else {
+						wv.count += n_win;
+						if (wv.sum < (int64_t)s_wmax) wv.sum = (int64_t)s_wmax;
+					}
+					*wp = wv;
+					uint32_t *bp = &p.d.bitmap[(size_t)slot * 16u + t];
+					*bp = (roll ? 0u : *bp) | s_bm[t];
+				}
 			}
-		}
-		__syncthreads(); // every reader of win_epoch is done before thread 0 rewrites the meta record
-		if (threadIdx.x == 0) {
-			TdMeta *mt = &p.d.td_meta[slot];
-			if (s_min < mt->vmin) mt->vmin = s_min;
-			if (s_max > mt->vmax) mt->vmax = s_max;
-			mt->npend = 0;
-			mt->win_epoch = p.d.epoch;
-			p.d.batch_cnt[slot] = 0;
+			__syncthreads(); // every reader of the meta record is done before thread 0 rewrites it
+			if (threadIdx.x == 0) {
+				*(uint4 *)&p.d.td_meta[slot] = make_uint4(0u, 0u, mt.z, n_win ? mt.z : mt.w);
+				p.d.td_cur[slot] = 0;
+				const int2 mm = p.d.td_minmax[slot];
+				p.d.td_minmax[slot] = make_int2(min(mm.x, s_min), max(mm.y, s_max));
+			}
 		}
 		__syncthreads();
 	}
@@ -1831,13 +1782,15 @@ __global__ __launch_bounds__(256) void k_hist_add(int kind, gys_hist_rec *hist, 
 	}
 }
 
-// window / all-time view of the lazily rolled records (see "Lazy window roll"); meta == nullptr: the arrays are kept eagerly
+// window / all-time view of a service's records.  meta != nullptr (t-digest on, lazy fold; the caller has folded the range): the
+// all-time record holds every folded value, the window record is valid when it belongs to the open window.  meta == nullptr (eager
+// records, updated per event): the all-time record gets the window added at the boundary (k_hist_fold), so the view adds the open
+// window itself -- both modes answer "everything ingested so far".
 __device__ __forceinline__ gys_hist_rec hist_view(const gys_hist_rec *win, const gys_hist_rec *all, const TdMeta *meta, uint32_t epoch, int which, uint32_t slot)
 {
-	if (!meta) return which ? all[slot] : win[slot];
 	gys_hist_rec r;
 	if (which == 0) {
-		if (meta[slot].win_epoch == epoch) return win[slot];
+		if (!meta || meta[slot].hw_epoch == epoch) return win[slot];
 		for (int i = 0; i < 15; ++i) {
 			r.stats[i].count = 0;
 			r.stats[i].sum = 0;
@@ -1847,6 +1800,7 @@ __device__ __forceinline__ gys_hist_rec hist_view(const gys_hist_rec *win, const
 		return r;
 	}
 	r = all[slot];
+	if (meta) return r;
 	const gys_hist_rec w = win[slot];
 	for (int i = 0; i < 15; ++i) {
 		r.stats[i].count += w.stats[i].count;
@@ -1934,19 +1888,23 @@ __global__ __launch_bounds__(256) void k_level_roll(LevelRollP p)
 	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += gstride) {
 		const uint32_t slot = (uint32_t)(t >> 4), k = (uint32_t)(t & 15u);
 		const ulonglong2 w = ((const ulonglong2 *)p.win)[t];
-		const bool cur = !p.meta || p.meta[slot].win_epoch == p.epoch;
+		const bool cur = !p.meta || p.meta[slot].hw_epoch == p.epoch;
 		ulonglong2 closing;
 		if (cur) {
 			closing = w;
-		} else { // the key was not touched in the closing window: win still holds an older, not yet folded window
+		} else { // the key was not touched in the closing window: win still holds an older window
 			closing.x = 0;
 			closing.y = k < 15u ? 0ull : (unsigned long long)INT64_MIN;
 		}
 		((ulonglong2 *)p.last)[t] = closing;
 		if (p.mask[0] | p.mask[1]) {
-			// cumulative record BEFORE the closing window: its add happens at the close time, i.e. at or after the boundary
+			// cumulative record BEFORE the closing window: its add happens at the close time, i.e. at or after the boundary.  Lazily
+			// folded records (meta) already hold the closing window (the caller folded every service first): take it out again.
 			ulonglong2 before = ((const ulonglong2 *)p.all)[t];
-			if (!cur) before = pair_add(before, w, k);
+			if (p.meta && cur) {
+				before.x -= w.x;
+				if (k < 15u) before.y -= w.y;
+			}
 			for (int li = 0; li < 2; ++li)
 				for (uint32_t m = p.mask[li]; m; m &= m - 1) {
 					const uint32_t j = (uint32_t)__builtin_ctz(m);
@@ -1975,12 +1933,12 @@ __global__ __launch_bounds__(256) void k_level_view(LevelViewP p)
 	ulonglong2 cum = ((const ulonglong2 *)p.all)[g];
 	const ulonglong2 w = ((const ulonglong2 *)p.win)[g];
 	if (p.meta) {
-		if (p.meta[slot].win_epoch != p.epoch_open)
-			cum = pair_add(cum, w, k); // a closed window that has not been folded yet
-		else if (k == 15u && (long long)cum.y < (long long)w.y)
-			cum.y = w.y;               // the maximum is reported over everything seen
+		if (p.meta[slot].hw_epoch == p.epoch_open) { // the folded part of the OPEN window is not in any level yet
+			cum.x -= w.x;
+			if (k < 15u) cum.y -= w.y;
+		}
 	} else if (k == 15u && (long long)cum.y < (long long)w.y) {
-		cum.y = w.y;
+		cum.y = w.y; // the maximum is reported over everything seen
 	}
 	ulonglong2 r;
 	if (p.mode == 0) {

@@ -36,7 +36,7 @@ def mid_buf(machine_id):
 
 class SketchEngine:
     def __init__(self, max_hosts, max_services, max_clusters=16, enable_tdigest=True, svc_hll_p=0, max_batch_events=1 << 20,
-                 rank=0, nranks=1, device=None, torch_arena=True, resp_path=0, enable_levels=False):
+                 rank=0, nranks=1, device=None, torch_arena=True, resp_path=0, enable_levels=False, td_buf_values=0):
         import torch
         self.L = capi.load()
         if not torch.cuda.is_available():
@@ -54,6 +54,7 @@ class SketchEngine:
         cfg.svc_hll_p = svc_hll_p
         cfg.resp_path = resp_path
         cfg.enable_levels = 1 if enable_levels else 0
+        cfg.td_buf_values = td_buf_values
         cfg.max_batch_events = max_batch_events
         with torch.cuda.device(self.device):
             # the engine gets its own torch stream: torch work (tensor fills / copies on the current stream, collectives) and engine work are

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GYS_ABI_VERSION 3
+#define GYS_ABI_VERSION 4
 
 enum {
 	GYS_OK = 0,
@@ -53,8 +53,8 @@ enum {
 };
 
 #define GYS_MAX_BUCKETS 16 /* all reference hash classes have <= 15 buckets; records are padded to 16 slots */
-#define GYS_TD_NB 100      /* t-digest clusters per key (delta = 100, common/gy_query_common.cc:1855) */
-#define GYS_TD_PEND_CAP 256 /* values a key's t-digest buffers before it is re-clustered (== GYS_TDIGEST_PEND_CAP) */
+#define GYS_TD_NB 200      /* t-digest clusters per key (2 x the delta = 100 the reference hands to Postgres tdigest, common/gy_query_common.cc:1855) */
+#define GYS_TD_PEND_CAP 768 /* values a key's t-digest buffers before it is re-clustered (== GYS_TDIGEST_PEND_CAP) */
 #define GYS_HLL_P 14       /* global distinct-flow HLL precision: 16384 u8 registers */
 #define GYS_CMS_D 4
 #define GYS_CMS_W 65536
@@ -80,7 +80,9 @@ typedef struct {
 	void *reduce_arena;        /* optional caller-owned DEVICE buffer for the all-reducible registers (e.g. a torch tensor so */
 	uint64_t reduce_arena_bytes; /* that torch.distributed/RCCL can reduce it in place); NULL = the context allocates it  */
 	uint32_t enable_levels;    /* multi-level windows (5 s / 300 s / 5 days / all) + per-service QPS / active-connection histograms */
-	uint32_t reserved0;        /* (costs 21 hist records = 5.4 KB of HBM per service; see "multi-level windows" below) */
+	                           /* (costs 21 hist records = 5.4 KB of HBM per service; see "multi-level windows" below) */
+	uint32_t td_buf_values;    /* entries of a service's value buffer (GYS_TD_PEND_CAP + 64 .. 16384; 0 = sized to max_services): the values
+	                              waiting for the next t-digest merge plus room for one batch's values of the service */
 } gys_config;
 
 /* -------------------------------------------------------------------------------------------------------------------

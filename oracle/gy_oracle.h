@@ -126,7 +126,7 @@ void gyo_cms64_add(uint64_t *tbl /*[D*W]*/, const uint32_t *words, uint32_t nwor
 uint64_t gyo_cms64_query(const uint64_t *tbl, const uint32_t *words, uint32_t nwords);
 
 /* ---------------------------------------------------------------- t-digest (k-bucketed merging digest, exact integer) */
-#define GYO_TD_NB 100
+#define GYO_TD_NB 200
 
 typedef struct {
 	int64_t sum[GYO_TD_NB];
@@ -148,7 +148,7 @@ double gyo_td_quantile(const gyo_tdigest *d, double q);
 /* Buffered form the engine keeps per service (the classic merging-digest buffer): up to GYO_TD_PEND_CAP values wait unmerged;
  * a batch that would overflow the buffer re-clusters the digest with (buffered + new) values in ONE merge.  The result depends
  * only on the sequence of batch multisets, not on the order of values inside a batch.  vmin / vmax always cover buffered values. */
-#define GYO_TD_PEND_CAP 256
+#define GYO_TD_PEND_CAP 768
 typedef struct {
 	gyo_tdigest d;
 	uint32_t npend;

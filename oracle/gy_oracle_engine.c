@@ -395,3 +395,96 @@ void gyo_engine_window_clear(gyo_engine *e, int clear_hist)
 		for (uint32_t s = 0; s < e->max_services; s++) e->hist[(size_t)s * 16 + 15].sum = LONG_MIN;
 	}
 }
+
+/* ---------------------------------------------------------------- t-digest accuracy stress (test support)
+ * nkeys independent keys, each streaming nvals values through the buffered digest in random batches of 1..2*bmean values (so a key
+ * re-clusters about nvals / GYO_TD_PEND_CAP times); afterwards the digest's quantiles are ranked against the exact sort of the
+ * key's stream.  dist: 0 lognormal(mu_key ~ N(3,1), 1.5) floored to integer ms (the SURVEY 8d latency law), 1 narrow uniform,
+ * 2 the same lognormal with a drifting scale (x1 -> x4 over the stream), 3 lognormal drawn once (330 values) and cycled.
+ * out[3*i + {0,1,2}] = max rank error over the keys of quantile qs[i]; keys are cut over nthreads threads. */
+#include <math.h>
+typedef struct {
+	uint32_t k0, k1, nvals, bmean;
+	int dist;
+	uint64_t seed;
+	const double *qs;
+	uint32_t nq;
+	double *worst; /* [nq] */
+} td_stress_job;
+
+static uint64_t sm64(uint64_t *s)
+{
+	uint64_t x = (*s += 0x9E3779B97F4A7C15ull);
+	x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+	x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+	return x ^ (x >> 31);
+}
+static double sm_unif(uint64_t *s) { return ((double)(sm64(s) >> 11) + 0.5) / 9007199254740992.0; }
+static double sm_gauss(uint64_t *s) { return sqrt(-2.0 * log(sm_unif(s))) * cos(6.283185307179586 * sm_unif(s)); }
+static int cmp_int(const void *a, const void *b) { const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b; return (x > y) - (x < y); }
+
+static void *td_stress_run(void *arg)
+{
+	td_stress_job *j = (td_stress_job *)arg;
+	int32_t *x = (int32_t *)malloc((size_t)j->nvals * 4), *srt = (int32_t *)malloc((size_t)j->nvals * 4);
+	for (uint32_t q = 0; q < j->nq; q++) j->worst[q] = 0.0;
+	for (uint32_t k = j->k0; k < j->k1; k++) {
+		uint64_t s = j->seed + (uint64_t)k * 0x632BE59BD9B4E019ull;
+		gyo_td_buffered b;
+		const double mu = 3.0 + sm_gauss(&s);
+		gyo_tdb_init(&b);
+		for (uint32_t i = 0; i < j->nvals; i++) {
+			double v;
+			if (j->dist == 1) v = 1000.0 + sm_unif(&s) * 100.0;
+			else if (j->dist == 2) v = exp(mu + 1.5 * sm_gauss(&s)) * (1.0 + 3.0 * (double)i / (double)j->nvals);
+			else if (j->dist == 3 && i >= 330) { x[i] = x[i - 330]; continue; }
+			else v = exp(mu + 1.5 * sm_gauss(&s));
+			if (v > 1e6) v = 1e6;
+			x[i] = (int32_t)v;
+		}
+		for (uint32_t pos = 0; pos < j->nvals;) {
+			uint32_t m = 1u + (uint32_t)(sm64(&s) % (2u * j->bmean));
+			if (m > j->nvals - pos) m = j->nvals - pos;
+			gyo_tdb_add_batch(&b, x + pos, m);
+			pos += m;
+		}
+		memcpy(srt, x, (size_t)j->nvals * 4);
+		qsort(srt, j->nvals, 4, cmp_int);
+		for (uint32_t qi = 0; qi < j->nq; qi++) {
+			const double g = gyo_tdb_quantile(&b, j->qs[qi]), q = j->qs[qi];
+			uint32_t a = 0, c = j->nvals, lo, hi;
+			while (a < c) { const uint32_t m = (a + c) / 2; if ((double)srt[m] < g) a = m + 1; else c = m; }
+			lo = a; a = 0; c = j->nvals;
+			while (a < c) { const uint32_t m = (a + c) / 2; if ((double)srt[m] <= g) a = m + 1; else c = m; }
+			hi = a;
+			{
+				const double l = (double)lo / j->nvals, h = (double)hi / j->nvals;
+				const double err = (l <= q && q <= h) ? 0.0 : (fabs(l - q) < fabs(h - q) ? fabs(l - q) : fabs(h - q));
+				if (err > j->worst[qi]) j->worst[qi] = err;
+			}
+		}
+	}
+	free(x);
+	free(srt);
+	return NULL;
+}
+
+void gyo_td_stress(uint32_t nkeys, uint32_t nvals, uint32_t bmean, int dist, uint64_t seed, const double *qs, uint32_t nq, uint32_t nthreads, double *out)
+{
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > 64) nthreads = 64;
+	td_stress_job jobs[64];
+	double worst[64][8];
+	pthread_t th[64];
+	if (nq > 8) nq = 8;
+	for (uint32_t t = 0; t < nthreads; t++) {
+		jobs[t] = (td_stress_job){(uint32_t)((uint64_t)nkeys * t / nthreads), (uint32_t)((uint64_t)nkeys * (t + 1) / nthreads), nvals, bmean, dist, seed, qs, nq, worst[t]};
+		pthread_create(&th[t], NULL, td_stress_run, &jobs[t]);
+	}
+	for (uint32_t q = 0; q < nq; q++) out[q] = 0.0;
+	for (uint32_t t = 0; t < nthreads; t++) {
+		pthread_join(th[t], NULL);
+		for (uint32_t q = 0; q < nq; q++)
+			if (worst[t][q] > out[q]) out[q] = worst[t][q];
+	}
+}

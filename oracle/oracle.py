@@ -18,7 +18,7 @@ KINDS = {
 }
 RESP_TIME_HASH = KINDS["RESP_TIME_HASH"]
 MAX_BUCKETS = 16
-TD_NB = 100
+TD_NB = 200
 HLL_P = 14
 CMS_D = 4
 CMS_W = 65536
@@ -61,7 +61,7 @@ class TDigest(C.Structure):
     _fields_ = [("sum", C.c_int64 * TD_NB), ("cnt", C.c_uint32 * TD_NB), ("vmin", C.c_int32), ("vmax", C.c_int32)]
 
 
-TD_PEND_CAP = 256
+TD_PEND_CAP = 768
 
 
 class TDBuffered(C.Structure):
@@ -190,6 +190,7 @@ def lib():
     _sig(L, "gyo_engine_resp_batch", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
     _sig(L, "gyo_engine_resp_batch_histonly", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
     _sig(L, "gyo_engine_resp_batch_mt", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32, C.c_uint32])
+    _sig(L, "gyo_td_stress", None, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.POINTER(C.c_double)])
     _sig(L, "gyo_engine_nsvc", C.c_uint32, [C.c_void_p])
     _sig(L, "gyo_engine_hist", C.c_void_p, [C.c_void_p])
     _sig(L, "gyo_engine_bitmap", C.c_void_p, [C.c_void_p])

@@ -157,11 +157,13 @@ def test_resp_device_generated_stream(torch_mod, oracle, resp_path):
 
 
 @PATHS
-def test_resp_huge_key_batches(torch_mod, oracle, resp_path):
-    """keys with more than 1024 new values in one batch take the value-count-array kernel; result must still equal the oracle,
-    including when a small batch, a huge batch and another small batch hit the same key"""
+@pytest.mark.parametrize("td_buf", [0, 1024], ids=["bufauto", "buf1024"])
+def test_resp_huge_key_batches(torch_mod, oracle, resp_path, td_buf):
+    """keys whose batch does not fit their value buffer are spilled (second resp pass / run in the staging area) and, above 16384
+    values, take the value-count-array kernel; the result must still equal the oracle, including when a small batch, a huge batch and
+    another small batch hit the same key"""
     rng = np.random.default_rng(5)
-    eng = _engine(max_hosts=2, max_services=8, max_batch_events=1 << 18, resp_path=resp_path)
+    eng = _engine(max_hosts=2, max_services=8, max_batch_events=1 << 18, resp_path=resp_path, td_buf_values=td_buf)
     orc = oracle.OracleEngine(8)
     info, gids = helpers.register_world(eng, orc, range(1), 3)
     mid, slot = info[0]
@@ -268,15 +270,17 @@ def test_resp_hostlocal_incremental_registration_and_fallbacks(torch_mod, oracle
 
 
 @PATHS
-def test_resp_buffer_fill_and_merge_cycles(torch_mod, oracle, resp_path):
+@pytest.mark.parametrize("td_buf", [0, 1024], ids=["bufauto", "buf1024"])
+def test_resp_buffer_fill_and_merge_cycles(torch_mod, oracle, resp_path, td_buf):
     """many small batches per key: the t-digest buffer fills (append), overflows (one merge of buffer + batch) and refills; batch
     sizes straddle the buffer capacity, the 64-lane chunk size of the per-key pass and the merge kernel's sort sizes"""
     rng = np.random.default_rng(21)
     nh, sp = 2, 6
-    eng = _engine(max_hosts=2, max_services=16, max_batch_events=1 << 16, resp_path=resp_path)
+    eng = _engine(max_hosts=2, max_services=16, max_batch_events=1 << 16, resp_path=resp_path, td_buf_values=td_buf)
     orc = oracle.OracleEngine(16)
     info, gids = helpers.register_world(eng, orc, range(nh), sp)
-    sizes = [5, 40, 64, 65, 130, 255, 256, 257, 1, 700, 1024 * sp, 300, 3, 511, 9, 9, 9, 2000, 77]
+    # (with a 1024-entry buffer the larger batches do not fit behind the buffered values: spilled keys, merged from buffer + run)
+    sizes = [5, 40, 64, 65, 130, 255, 256, 257, 1, 700, 1024 * sp, 300, 3, 511, 9, 9, 9, 2000, 77, 767, 1, 768 * sp, 2, 4500 * sp, 20000 * sp, 30]
     for rnd, n in enumerate(sizes):
         for h in range(nh):
             ev = helpers.make_resp_events(rng, h, n, sp if rnd % 3 else 1, lat_mu=2.0 + 0.2 * rnd, bad_frac=0.01, unknown_frac=0.01)
@@ -293,20 +297,22 @@ def test_resp_buffer_fill_and_merge_cycles(torch_mod, oracle, resp_path):
     _compare_all(eng, orc, oracle)
     _assert_path(eng, resp_path)
     npend, _ = eng.export_tdigest_pending(0, orc.nsvc)
-    assert npend.max() <= 256
+    from gyeeta_amd import capi
+    assert npend.max() <= capi.TD_PEND_CAP
     eng.window_close()
     _compare_window(eng, orc)
     eng.close()
 
 
 @PATHS
-def test_resp_windows_roll_lazily(torch_mod, oracle, resp_path):
+@pytest.mark.parametrize("td_buf", [0, 1024], ids=["bufauto", "buf1024"])
+def test_resp_windows_roll_lazily(torch_mod, oracle, resp_path, td_buf):
     """several 5-s windows in which some hosts / services stay silent: the window view, the all-time view, the CONN_BITMAP rows and
     the per-window registers must equal an oracle that clears / folds eagerly at every boundary (the engine rolls a key only when a
     later window touches it), including several batches per window and a window with no events at all"""
     rng = np.random.default_rng(31)
     nh, sp = 3, 9
-    eng = _engine(max_hosts=4, max_services=64, max_batch_events=1 << 16, resp_path=resp_path)
+    eng = _engine(max_hosts=4, max_services=64, max_batch_events=1 << 16, resp_path=resp_path, td_buf_values=td_buf)
     orc_all = oracle.OracleEngine(64)   # histograms never cleared  -> all-time view
     orc_win = oracle.OracleEngine(64)   # histograms cleared at every boundary -> window view
     info, gids = helpers.register_world(eng, orc_all, range(nh), sp)
@@ -318,6 +324,8 @@ def test_resp_windows_roll_lazily(torch_mod, oracle, resp_path):
         [],                                             # empty window
         [(1, 700, sp), (1, 200, 4), (0, 50, 1)],        # two batches of host 1 in one window
         [(2, 1200, sp), (0, 10, sp)],
+        [(0, 9000, sp), (2, 3000, 2), (0, 2500, 1)],    # buffers overflow mid-window: merges fold the window's values, later batches add to it
+        [(2, 2, 2)],
     ]
     for wnd, batches in enumerate(plan):
         for h, n, ns in batches:
@@ -352,14 +360,15 @@ def test_resp_windows_roll_lazily(torch_mod, oracle, resp_path):
     eng.close()
 
 
-def test_resp_split_form_few_hosts_long_segments(torch_mod, oracle):
+@pytest.mark.parametrize("td_buf", [0, 2048], ids=["bufauto", "buf2048"])
+def test_resp_split_form_few_hosts_long_segments(torch_mod, oracle, td_buf):
     """few hosts with long segments: the host-local pipeline in its split form (parts of 65536 events: per-part counts, per-host scan,
     per-part scatter) must leave exactly what the fused form leaves -- every register vs the oracle over several batches and a window
     roll; segment lengths straddle the part size (one part, just over one part, several parts with a short tail), one host has a
     single listener, one batch is short enough to stay fused"""
     rng = np.random.default_rng(91)
     svc = {0: 37, 1: 1, 2: 200, 3: 64}
-    eng = _engine(max_hosts=4, max_services=512, max_batch_events=1 << 20, resp_path=3)
+    eng = _engine(max_hosts=4, max_services=512, max_batch_events=1 << 20, resp_path=3, td_buf_values=td_buf)
     orc = oracle.OracleEngine(512)
     info = {}
     for h, sp in svc.items():

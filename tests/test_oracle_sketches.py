@@ -141,13 +141,13 @@ def test_conn_bitmap(oracle):
 
 
 def test_tdigest_buffered_form(oracle):
-    """the per-service form: values wait in a 256-entry buffer and are merged in one step when a batch no longer fits;
+    """the per-service form: values wait in a GYO_TD_PEND_CAP-entry buffer and are merged in one step when a batch no longer fits;
     quantiles come from the merged view (digest + buffer) and keep the 1 % rank bound for every batching of the same stream"""
     L = oracle.lib()
     rng = np.random.default_rng(77)
     x = np.minimum(np.floor(rng.lognormal(3.0, 1.5, 30000)), 1e6).astype(np.int32)
     xs = np.sort(x)
-    for batch in (1, 7, 27, 100, 256, 257, 5000):
+    for batch in (1, 7, 27, 100, 256, 257, 768, 769, 5000):
         b = oracle.TDBuffered()
         L.gyo_tdb_init(C.byref(b))
         fills = []
@@ -167,17 +167,33 @@ def test_tdigest_buffered_form(oracle):
     # a batch that fits is only appended: the clusters do not change and the order inside the batch is irrelevant after sorting
     b = oracle.TDBuffered()
     L.gyo_tdb_init(C.byref(b))
-    c = np.ascontiguousarray(x[:200])
-    L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c, oracle.i32p), 200)
-    assert b.npend == 200 and L.gyo_td_total(C.byref(b.d)) == 0
-    c2 = np.ascontiguousarray(x[200:260])
-    L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c2, oracle.i32p), 60)  # 260 > 256: one merge of all 260 values
-    assert b.npend == 0 and L.gyo_td_total(C.byref(b.d)) == 260
+    cap = oracle.TD_PEND_CAP
+    c = np.ascontiguousarray(x[:cap - 56])
+    L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c, oracle.i32p), cap - 56)
+    assert b.npend == cap - 56 and L.gyo_td_total(C.byref(b.d)) == 0
+    c2 = np.ascontiguousarray(x[cap - 56:cap + 4])
+    L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c2, oracle.i32p), 60)  # cap + 4 > cap: one merge of all cap + 4 values
+    assert b.npend == 0 and L.gyo_td_total(C.byref(b.d)) == cap + 4
     d = oracle.TDigest()
     L.gyo_td_init(C.byref(d))
-    allv = np.ascontiguousarray(x[:260][::-1])
-    L.gyo_td_merge_values(C.byref(d), oracle.ptr(allv, oracle.i32p), 260)
+    allv = np.ascontiguousarray(x[:cap + 4][::-1])
+    L.gyo_td_merge_values(C.byref(d), oracle.ptr(allv, oracle.i32p), cap + 4)
     assert list(d.cnt) == list(b.d.cnt) and list(d.sum) == list(b.d.sum)
+
+
+@pytest.mark.parametrize("nkeys,nvals,dist", [(10000, 12000, 0), (1500, 120000, 0), (4000, 12000, 1), (4000, 20000, 2), (10000, 3000, 3)],
+                         ids=["lognormal-10k-keys", "lognormal-150-remerges", "narrow-uniform", "drifting", "cycled-330-values"])
+def test_tdigest_rank_error_margin_many_keys_many_remerges(oracle, nkeys, nvals, dist):
+    """north_star tolerance (+-1 % rank error) with margin: every key streams its values through the buffered digest in random batches
+    of 1..108 values (the C3 bench's per-key batch is ~54), i.e. up to ~150 re-clusterings of old clusters + buffer per key, over
+    thousands of keys / seeds; the worst p25 / p50 / p99 rank error over ALL keys must stay <= 0.8 %.  (With 100 clusters the worst key
+    sat at 1.0-1.2 %; gys_tdigest_tbl.h now has 200.)  The cycled case repeats 330 distinct values, like a bench that replays batches."""
+    import os
+    L = oracle.lib()
+    qs = (C.c_double * 3)(0.25, 0.5, 0.99)
+    out = (C.c_double * 3)()
+    L.gyo_td_stress(nkeys, nvals, 54, dist, 20260923, qs, 3, min(8, os.cpu_count() or 1), out)
+    assert max(out) <= 0.008, list(out)
 
 
 def test_oracle_engine_multithreaded_batch_is_identical(oracle):
