@@ -762,6 +762,10 @@ int level_view(gys_ctx *c, int level, uint64_t tusec, uint32_t first, uint32_t n
 {
 	int64_t tq = (int64_t)(tusec / 1000000ull);
 	if (tq < c->lvl_t_last) tq = c->lvl_t_last;
+	{
+		const int rcf = fold_range(c, first, n); // max_val_seen is reported over everything ingested, the open window included
+		if (rcf) return rcf;
+	}
 	LevelViewP p{};
 	p.win = c->hist_win;
 	p.all = c->hist_all;

@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
 		const MergeEnt ent = q.list[w];
 		const uint32_t m = ent.nbuf + ent.mrun;
-		if (m > MAXV || m <= MINV) continue; // another size class's entry
+		if (m > MAXV || (MINV != 0u && m <= MINV)) continue; // another size class's entry
 		const uint32_t slot = ent.slot;
 		const uint4 mt = *(const uint4 *)&p.td_meta[slot];
 		const uint32_t nh = query ? ent.nbuf : (mt.y & 0xFFFFu), nw = mt.y >> 16;

@@ -175,12 +175,12 @@ def test_c1_single_host_replay_bit_exact(torch_mod, oracle, resp_path):
 
 # ---------------------------------------------------------------------------------------------------------------- C5
 def test_c5_zipf_heavy_hitters_bit_exact(torch_mod, oracle):
-    """10^5 services (25 hosts x 4000 listeners: the largest LDS sub-tables), Zipf(1.1) over a host's services: the head keys get
+    """10^5 services (50 hosts x 2000 listeners: close to the largest LDS sub-tables), Zipf(1.1) over a host's services: the head keys get
     10^5+ values per batch (k_digest_huge), the tail a handful (buffer appends).  Bit-exact vs the C oracle; CMS top-50 == exact top-50."""
     torch = torch_mod
-    nh, sp, n = 25, 4000, 1 << 22
+    nh, sp, n = 50, 2000, 1 << 22
     nsvc = nh * sp
-    eng = _engine(max_hosts=nh, max_services=nsvc, max_batch_events=n, resp_path=2)  # 25 long segments: prefer host-local explicitly
+    eng = _engine(max_hosts=nh, max_services=nsvc, max_batch_events=n, resp_path=2)  # 50 long segments: prefer host-local explicitly
     orc = oracle.OracleEngine(nsvc)
     helpers.register_world(eng, orc, range(nh), sp)
     ev = torch.empty(n * 24, dtype=torch.uint8, device="cuda")

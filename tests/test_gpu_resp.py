@@ -276,7 +276,7 @@ def test_resp_buffer_fill_and_merge_cycles(torch_mod, oracle, resp_path, td_buf)
     sizes straddle the buffer capacity, the 64-lane chunk size of the per-key pass and the merge kernel's sort sizes"""
     rng = np.random.default_rng(21)
     nh, sp = 2, 6
-    eng = _engine(max_hosts=2, max_services=16, max_batch_events=1 << 16, resp_path=resp_path, td_buf_values=td_buf)
+    eng = _engine(max_hosts=2, max_services=16, max_batch_events=1 << 17, resp_path=resp_path, td_buf_values=td_buf)
     orc = oracle.OracleEngine(16)
     info, gids = helpers.register_world(eng, orc, range(nh), sp)
     # (with a 1024-entry buffer the larger batches do not fit behind the buffered values: spilled keys, merged from buffer + run)

@@ -44,17 +44,17 @@ def test_tdigest_sql_text_and_binary(oracle):
                 gid, slot = int(gids[h][s]), h * sp + s
                 cents = _oracle_centroids(oracle, orc, slot)
                 total = sum(c for _, c in cents)
-                want = "flags 1 count %d compression 100 centroids %d" % (total, len(cents)) + "".join(" (%f, %d)" % mc for mc in cents)
+                want = "flags 1 count %d compression %d centroids %d" % (total, oracle.TD_NB, len(cents)) + "".join(" (%f, %d)" % mc for mc in cents)
                 got = eng.tdigest_sql_text(gid)
                 assert got == want, (rnd, h, s)
                 # what tdigest_in checks
                 m = re.fullmatch(r"flags (\d+) count (\d+) compression (\d+) centroids (\d+)((?: \([-0-9.]+, \d+\))+)", got)
-                assert m and int(m.group(1)) == 1 and int(m.group(3)) == 100 and 0 < int(m.group(4)) <= 10 * 100
+                assert m and int(m.group(1)) == 1 and int(m.group(3)) == oracle.TD_NB and 0 < int(m.group(4)) <= 10 * oracle.TD_NB
                 pairs = [(float(a), int(b)) for a, b in re.findall(r"\(([-0-9.]+), (\d+)\)", m.group(5))]
                 assert len(pairs) == int(m.group(4)) and sum(b for _, b in pairs) == int(m.group(2)) > 0
                 assert all(pairs[i][0] <= pairs[i + 1][0] for i in range(len(pairs) - 1))
                 raw = eng.tdigest_sql_binary(gid)
-                assert raw == struct.pack(">iqii", 1, total, 100, len(cents)) + b"".join(struct.pack(">dq", mean, c) for mean, c in cents)
+                assert raw == struct.pack(">iqii", 1, total, oracle.TD_NB, len(cents)) + b"".join(struct.pack(">dq", mean, c) for mean, c in cents)
     with pytest.raises(capi.GysError) as ei:   # no values yet: the type has no empty literal
         eng.tdigest_sql_text(int(gids[1][sp - 1]))
     assert ei.value.code == capi.ERR_NOTFOUND
