@@ -673,6 +673,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		f.svc_host = c->svc_host;
 		f.host_spill = c->host_spill;
 		f.spill_stamp = hp.spill_stamp;
+		f.counters = c->counters;
 		hipLaunchKernelGGL(k_key_finalize, dim3((nsvc + 255) / 256), dim3(256), 0, c->stream, f);
 	}
 	if (host_local) {
@@ -2107,6 +2108,8 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 	out->resp_batches_general = c->n_batches_general;
 	out->window_graph_launches = c->win_graph_launches;
 	out->resp_batches_host_split = c->n_batches_host_split;
+	out->td_merges = v[CTR_TD_MERGES];
+	out->td_merge_values = v[CTR_TD_MERGE_VALUES];
 	return GYS_OK;
 }
 

@@ -25,7 +25,7 @@ namespace gys {
 #define GYS_STAGED_WORD(tresp, cli_port) ((uint64_t)(((uint32_t)(tresp) << GYS_ROW_BITS) | ((uint32_t)(cli_port) & 0x1Fu)))
 
 enum { CTR_RESP_EVENTS = 0, CTR_RESP_DROP_RANGE, CTR_RESP_DROP_NOLISTENER, CTR_CONN_EVENTS, CTR_CONN_UNKNOWN, CTR_LSTATE_RECORDS,
-       CTR_LSTATE_MISSED, CTR_LSTATE_ERRORS, CTR_LSTATE_DELETED, CTR_NUM };
+       CTR_LSTATE_MISSED, CTR_LSTATE_ERRORS, CTR_LSTATE_DELETED, CTR_TD_MERGES, CTR_TD_MERGE_VALUES, CTR_NUM };
 
 // ---------------------------------------------------------------------------------------------------- table insert
 __global__ void k_table_insert(DevTable t, const uint64_t *keys, uint32_t first_val, uint32_t n, uint32_t *nfail)
@@ -731,6 +731,7 @@ struct FinP {
 	const uint32_t *svc_host;
 	uint32_t *host_spill;
 	uint32_t spill_stamp;
+	uint64_t *counters;
 };
 
 __global__ __launch_bounds__(256) void k_key_finalize(FinP p)
@@ -786,6 +787,18 @@ __global__ __launch_bounds__(256) void k_key_finalize(FinP p)
 			if (lane == 0) at = atomicAdd(p.merge_count, (uint32_t)__popcll(nb));
 			at = (uint32_t)__shfl((int)at, 0, 64);
 			if (to_merge) p.merge_list[at + (uint32_t)__popcll(nb & below)] = ent;
+		}
+	}
+	{
+		const unsigned long long nb = __ballot(to_merge || to_huge);
+		if (nb) { // statistics: re-clusterings queued and the values they carry (one pair of atomics per wave)
+			uint32_t nv = (to_merge || to_huge) ? ent.nbuf + ent.mrun : 0u;
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1) nv += (uint32_t)__shfl_xor((int)nv, d, 64);
+			if (lane == 0) {
+				atomicAdd((unsigned long long *)&p.counters[CTR_TD_MERGES], (unsigned long long)__popcll(nb));
+				atomicAdd((unsigned long long *)&p.counters[CTR_TD_MERGE_VALUES], (unsigned long long)nv);
+			}
 		}
 	}
 	{

@@ -335,6 +335,7 @@ typedef struct {
 	uint64_t resp_batches_host_local, resp_batches_general; /* which resp pipeline each ingest call took (gys_config.resp_path) */
 	uint64_t window_graph_launches; /* window boundaries replayed from the captured hipGraph (0: plain stream operations were used) */
 	uint64_t resp_batches_host_split; /* host-local pipeline in its split form (few hosts, long segments: parts of 65536 events) */
+	uint64_t td_merges, td_merge_values; /* t-digest re-clusterings queued so far and the buffered values they merged */
 } gys_counters;
 int gys_get_counters(gys_ctx *ctx, gys_counters *out);
 
