@@ -157,8 +157,12 @@ struct gys_ctx {
 	uint32_t *host_spill = nullptr;  // per host: batch stamp of the last batch in which one of its services spilled
 	uint32_t spill_stamp = 0;
 	uint32_t pcap = 0;
-	MergeEnt *merge_list = nullptr, *huge_list = nullptr, *query_list = nullptr;
-	uint32_t *merge_count = nullptr; // [0] merge list length of the batch, [1] huge list length, [2] run allocation cursor, [4] = 1 (query list)
+	MergeEnt *merge_list = nullptr, *merge_list1 = nullptr, *merge_list2 = nullptr, *huge_list = nullptr, *query_list = nullptr;
+	uint32_t *merge_count = nullptr; // [FIN_*]: merge list lengths by size class, huge list length, run allocation cursor; [8] = 1 (query list)
+	uint32_t *resp_win = nullptr;    // per service: response events of the open window (-> Count-Min rows at the window boundary)
+	uint32_t *cms_partial = nullptr; // [cms_nch][GYS_CMS_D][GYS_CMS_W] partial rows of k_cms_partial
+	uint32_t cms_nch = 0;
+	bool resp_dirty = false;
 	int64_t *query_sum = nullptr;    // scratch of the non-destructive merge behind gys_query_quantiles
 	uint32_t *query_cnt = nullptr;
 	uint32_t *batch_cnt = nullptr, *batch_off = nullptr, *scan_block_sums = nullptr;
@@ -526,7 +530,28 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	uint32_t *cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
 	unsigned long long *ghist = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
 	long long *gmax = (long long *)(c->arena + c->al.off_i64max);
-	if (td) HIPCHK(hipMemsetAsync(c->merge_count, 0, 16, c->stream)); // merge / huge list lengths, run allocation cursor
+	if (td) {
+		HIPCHK(hipMemsetAsync(c->merge_count, 0, FIN_NCOUNTS * 4, c->stream)); // merge / huge list lengths, run allocation cursor
+		c->resp_dirty = true;
+	}
+	FinP fin{};
+	if (td) {
+		fin.td_cur = c->td_cur;
+		fin.td_meta = c->td_meta;
+		fin.nsvc = c->nsvc;
+		fin.pcap = c->pcap;
+		fin.epoch = c->epoch;
+		fin.resp_win = c->resp_win;
+		fin.list[FIN_CLASS0] = c->merge_list;
+		fin.list[FIN_CLASS1] = c->merge_list1;
+		fin.list[FIN_CLASS2] = c->merge_list2;
+		fin.list[FIN_HUGE] = c->huge_list;
+		fin.counts = c->merge_count;
+		fin.td_run = c->td_run;
+		fin.svc_host = c->svc_host;
+		fin.host_spill = c->host_spill;
+		fin.counters = c->counters;
+	}
 	RespHostP hp{};
 	uint32_t hgrid = 0;
 	size_t dyn = 0;
@@ -548,6 +573,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hp.staged = c->staged;
 		hp.host_spill = c->host_spill;
 		hp.spill_stamp = ++c->spill_stamp;
+		fin.spill_stamp = hp.spill_stamp;
+		hp.fin = fin;
 		hp.counters = c->counters;
 		hp.svc_hll = c->svc_hll;
 		hp.svc_hll_p = c->cfg.svc_hll_p;
@@ -653,28 +680,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		}
 	}
 	HIPCHK(hipGetLastError());
-	{
+	if (!host_local || host_split) { // (the fused host-local form finalizes its keys in the tail of k_resp_host)
 		ProfScope ps(c, "key_finalize");
-		FinP f{};
-		f.td_cur = c->td_cur;
-		f.td_meta = c->td_meta;
-		f.nsvc = nsvc;
-		f.pcap = c->pcap;
-		f.epoch = c->epoch;
-		f.cms32 = cms32;
-		f.svc_gid = c->svc_gid;
-		f.merge_list = c->merge_list;
-		f.huge_list = c->huge_list;
-		f.merge_count = c->merge_count;
-		f.huge_count = c->merge_count + 1;
-		f.run_alloc = c->merge_count + 2;
-		f.td_run = c->td_run;
-		f.batch_off = host_local ? nullptr : c->batch_off;
-		f.svc_host = c->svc_host;
-		f.host_spill = c->host_spill;
-		f.spill_stamp = hp.spill_stamp;
-		f.counters = c->counters;
-		hipLaunchKernelGGL(k_key_finalize, dim3((nsvc + 255) / 256), dim3(256), 0, c->stream, f);
+		fin.batch_off = host_local ? nullptr : c->batch_off;
+		hipLaunchKernelGGL(k_key_finalize, dim3((nsvc + 255) / 256), dim3(256), 0, c->stream, fin);
 	}
 	if (host_local) {
 		// second pass over the hosts that have spilled services (a workgroup of any other host returns at once): their events again,
@@ -688,17 +697,21 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	{
 		MergeP mp{};
 		mp.d = digest_params(c);
-		mp.list = c->merge_list;
-		mp.count = c->merge_count;
 		const uint32_t cap = (uint32_t)std::min<uint64_t>(nsvc, n);
 		{
 			ProfScope ps(c, "digest_merge");
-			hipLaunchKernelGGL((k_digest_merge<1024u, 0u, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 7))), dim3(256), 0, c->stream, mp);
+			mp.list = c->merge_list;
+			mp.count = c->merge_count + FIN_CLASS0;
+			hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 7))), dim3(256), 0, c->stream, mp);
 		}
 		{
 			ProfScope ps(c, "digest_merge_big");
-			hipLaunchKernelGGL((k_digest_merge<4096u, 1024u, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 3))), dim3(256), 0, c->stream, mp);
-			hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_LDS_MAX, 4096u, 1024u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(1024), 0, c->stream, mp);
+			mp.list = c->merge_list1;
+			mp.count = c->merge_count + FIN_CLASS1;
+			hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS1, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 3))), dim3(256), 0, c->stream, mp);
+			mp.list = c->merge_list2;
+			mp.count = c->merge_count + FIN_CLASS2;
+			hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_LDS_MAX, 1024u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(1024), 0, c->stream, mp);
 		}
 	}
 	{
@@ -706,7 +719,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		HugeP h{};
 		h.d = digest_params(c);
 		h.huge_list = c->huge_list;
-		h.huge_count = c->merge_count + 1;
+		h.huge_count = c->merge_count + FIN_HUGE;
 		h.scratch = c->huge_scratch;
 		hipLaunchKernelGGL(k_digest_huge, dim3(c->huge_blocks), dim3(256), 0, c->stream, h);
 	}
@@ -851,6 +864,21 @@ int conn_fold(gys_ctx *c)
 			   (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms, (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_cms);
 	HIPCHK(hipGetLastError());
 	c->conn_dirty = false;
+	return GYS_OK;
+}
+
+// builds the window's Count-Min rows of the response path from the per-service event counts ("Count-Min rows of the window" in
+// gys_kernels.hpp); the counts start the next window from zero
+int resp_cms_fold(gys_ctx *c)
+{
+	if (!c->resp_dirty || !c->nsvc || !c->resp_win) return GYS_OK;
+	const uint32_t nch = std::max(1u, std::min<uint32_t>(c->cms_nch, (c->nsvc + 65535u) / 65536u));
+	uint32_t *cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
+	hipLaunchKernelGGL(k_cms_partial, dim3(nch, GYS_CMS_D * 2), dim3(1024), GYS_CMSF_CELLS * 4, c->stream, c->resp_win, c->svc_gid, c->nsvc, nch, c->cms_partial);
+	hipLaunchKernelGGL(k_cms_reduce, dim3((GYS_CMS_D * GYS_CMS_W + 255) / 256), dim3(256), 0, c->stream, c->cms_partial, nch, cms32);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemsetAsync(c->resp_win, 0, (uint64_t)c->nsvc * 4, c->stream));
+	c->resp_dirty = false;
 	return GYS_OK;
 }
 
@@ -999,9 +1027,16 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 			return rc;
 		}
 		ALLOC(c->merge_list, std::min<uint64_t>(S, B) + 1);
+		// a key lands in a larger merge size class only when the batch itself brought it more than CLASS0 - PEND_CAP values
+		ALLOC(c->merge_list1, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS0 - GYS_TD_PEND_CAP) + 1) + 1);
+		ALLOC(c->merge_list2, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1) + 1);
+		ALLOC(c->resp_win, S);
+		c->cms_nch = (uint32_t)std::min<uint64_t>(32, (S + 65535) / 65536);
+		ALLOC(c->cms_partial, (uint64_t)c->cms_nch * GYS_CMS_D * GYS_CMS_W);
+		HIPCHK(hipFuncSetAttribute((const void *)k_cms_partial, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_CMSF_CELLS * 4));
 		ALLOC(c->huge_list, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1) + 1);
 		ALLOC(c->query_list, 4);
-		ALLOC(c->merge_count, 8);
+		ALLOC(c->merge_count, 16);
 		ALLOC(c->query_sum, GYS_TD_NB);
 		ALLOC(c->query_cnt, GYS_TD_NB);
 		ALLOC(c->batch_cnt, align_up(S, 16));
@@ -1021,7 +1056,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	if (cfg->enable_tdigest) {
 		hipLaunchKernelGGL(k_minmax_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->td_minmax, S);
 		static const uint32_t one = 1; // static: the source of an async copy must outlive the call
-		HIPCHK(hipMemcpyAsync(c->merge_count + 4, &one, 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(c->merge_count + 8, &one, 4, hipMemcpyHostToDevice, c->stream));
 	}
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_win, (uint64_t)0, S, (int64_t)INT64_MIN);
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_all, (uint64_t)0, S, (int64_t)INT64_MIN);
@@ -1069,7 +1104,7 @@ void gys_destroy(gys_ctx *c)
 	}
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
-			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
+			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
@@ -1511,7 +1546,8 @@ int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 	{
 		ProfScope ps(c, "window_prepare");
 		{
-			const int rcf = conn_fold(c);
+			int rcf = conn_fold(c);
+			if (!rcf) rcf = resp_cms_fold(c);
 			if (rcf) return rcf;
 		}
 		hipLaunchKernelGGL(k_window_prepare, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, p);
@@ -1714,12 +1750,12 @@ static int td_merged_view(gys_ctx *c, uint32_t slot, int64_t *sum, uint32_t *cnt
 	MergeP mp{};
 	mp.d = digest_params(c);
 	mp.list = c->query_list;
-	mp.count = c->merge_count + 4;
+	mp.count = c->merge_count + 8;
 	mp.out_sum = c->query_sum;
 	mp.out_cnt = c->query_cnt;
-	if (mt.npend <= 1024u) hipLaunchKernelGGL((k_digest_merge<1024u, 0u, 256u>), dim3(1), dim3(256), 0, c->stream, mp);
-	else if (mt.npend <= 4096u) hipLaunchKernelGGL((k_digest_merge<4096u, 1024u, 256u>), dim3(1), dim3(256), 0, c->stream, mp);
-	else hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_LDS_MAX, 4096u, 1024u>), dim3(1), dim3(1024), 0, c->stream, mp);
+	if (mt.npend <= GYS_MERGE_CLASS0) hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(1), dim3(256), 0, c->stream, mp);
+	else if (mt.npend <= GYS_MERGE_CLASS1) hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS1, 256u>), dim3(1), dim3(256), 0, c->stream, mp);
+	else hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_LDS_MAX, 1024u>), dim3(1), dim3(1024), 0, c->stream, mp);
 	HIPCHK(hipGetLastError());
 	int2 mm;
 	HIPCHK(hipMemcpyAsync(sum, c->query_sum, sizeof(int64_t) * GYS_TD_NB, hipMemcpyDeviceToHost, c->stream));

@@ -368,6 +368,139 @@ __global__ void k_minmax_init(int2 *mm, uint64_t n)
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mm[i] = make_int2(INT32_MAX, INT32_MIN);
 }
 
+// ---------------------------------------------------------------------------------------------------- per-key end of batch
+// Keys whose value count moved in this batch get their meta record updated (window bookkeeping of the lazy fold), their events added
+// to the window's per-service event count (the Count-Min rows are built from those counts once per window, k_cms_partial), and are
+// queued for a merge when the buffer holds more than GYS_TD_PEND_CAP values -- one list per merge size class; keys whose batch did
+// not fit the buffer are spilled (run allocated in `staged`, host flagged for the second resp pass).  finalize_key is wave-collective:
+// the host-local front end calls it from the tail of k_resp_host (the workgroup owns the host's keys), the other front ends through
+// k_key_finalize (one thread per service).
+#define GYS_MERGE_CLASS0 1024u // largest (buffered + run) value count of merge size class 0 / 1 (class 2: up to GYS_MERGE_LDS_MAX)
+#define GYS_MERGE_CLASS1 4096u
+enum { FIN_CLASS0 = 0, FIN_CLASS1, FIN_CLASS2, FIN_HUGE, FIN_RUN_ALLOC, FIN_NCOUNTS };
+
+struct FinP {
+	uint32_t *td_cur;
+	TdMeta *td_meta;
+	uint32_t nsvc, pcap, epoch;
+	uint32_t *resp_win;        // per service: response events of the open window
+	MergeEnt *list[4];         // merge lists by size class, [FIN_HUGE] = the huge list
+	uint32_t *counts;          // [FIN_NCOUNTS]: list lengths, bump cursor into `staged`
+	uint32_t *td_run;
+	const uint32_t *batch_off; // general front end: end of the key's run in `staged` (nullptr: host-local front end)
+	const uint32_t *svc_host;
+	uint32_t *host_spill;
+	uint32_t spill_stamp;
+	uint64_t *counters;
+};
+
+template <bool WRITE_CUR>
+__device__ __forceinline__ void finalize_key(const FinP &p, bool valid, uint32_t key, uint32_t cur, uint32_t lane)
+{
+	int cls = -1;
+	MergeEnt ent{};
+	if (valid) {
+		const uint4 mraw = *(const uint4 *)&p.td_meta[key];
+		const uint32_t npend0 = mraw.x;
+		if (cur != npend0) {
+			const uint32_t m = cur - npend0;
+			uint32_t nh = mraw.y & 0xFFFFu, nw = mraw.y >> 16, win_epoch = mraw.z;
+			if (win_epoch != p.epoch) { // first values of the key in this window: everything buffered so far belongs to earlier windows
+				nw = npend0;
+				win_epoch = p.epoch;
+			}
+			p.resp_win[key] += m; // the key is owned by this thread for the batch
+			ent.slot = key;
+			if (cur <= p.pcap) {
+				*(uint4 *)&p.td_meta[key] = make_uint4(cur, nh | (nw << 16), win_epoch, mraw.w);
+				if (WRITE_CUR) p.td_cur[key] = cur;
+				if (cur > GYS_TD_PEND_CAP) {
+					ent.nbuf = cur;
+					cls = cur <= GYS_MERGE_CLASS0 ? FIN_CLASS0 : cur <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_CLASS2;
+				}
+			} else { // spilled
+				*(uint4 *)&p.td_meta[key] = make_uint4(npend0, nh | (nw << 16), win_epoch, mraw.w);
+				p.td_cur[key] = npend0 | GYS_SPILL_BIT;
+				ent.nbuf = npend0;
+				ent.mrun = m;
+				if (p.batch_off) {
+					ent.off_end = p.batch_off[key];
+				} else {
+					const uint32_t start = atomicAdd(&p.counts[FIN_RUN_ALLOC], m);
+					p.td_run[key] = start;
+					ent.off_end = start + m;
+					p.host_spill[p.svc_host[key]] = p.spill_stamp;
+				}
+				const uint64_t tot = (uint64_t)npend0 + m;
+				cls = tot <= GYS_MERGE_CLASS0 ? FIN_CLASS0 : tot <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : tot <= GYS_MERGE_LDS_MAX ? FIN_CLASS2 : FIN_HUGE;
+			}
+		}
+	}
+	const unsigned long long any = __ballot(cls >= 0);
+	if (!any) return;
+	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const unsigned long long nb = __ballot(cls == c);
+		if (nb) {
+			uint32_t at = 0;
+			if (lane == 0) at = atomicAdd(&p.counts[c], (uint32_t)__popcll(nb));
+			at = (uint32_t)__shfl((int)at, 0, 64);
+			if (cls == c) p.list[c][at + (uint32_t)__popcll(nb & below)] = ent;
+		}
+	}
+	// statistics: re-clusterings queued and the values they carry (one pair of atomics per wave)
+	uint32_t nv = cls >= 0 ? ent.nbuf + ent.mrun : 0u;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) nv += (uint32_t)__shfl_xor((int)nv, d, 64);
+	if (lane == 0) {
+		atomicAdd((unsigned long long *)&p.counters[CTR_TD_MERGES], (unsigned long long)__popcll(any));
+		atomicAdd((unsigned long long *)&p.counters[CTR_TD_MERGE_VALUES], (unsigned long long)nv);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_key_finalize(FinP p)
+{
+	const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool valid = key < p.nsvc;
+	finalize_key<false>(p, valid, key, valid ? p.td_cur[key] : 0u, threadIdx.x & 63u);
+}
+
+// ---------------------------------------------------------------------------------------------------- Count-Min rows of the window
+// Count-Min is linear in the per-service event counts, so the response path only keeps one counter per service and window (resp_win)
+// and the rows are built ONCE per window: 4 x 10^7 device-scope atomics per batch (3.5 ms at 10^7 services: they execute memory-side
+// on a multi-XCD part) become LDS atomics.  Workgroup (chunk, row r, half h) walks its chunk of the services and adds the counts whose
+// column hash_r(glob_id) falls into half h of the row into a 128-KiB LDS image, then stores the image as a partial row; k_cms_reduce
+// sums the partials into the arena.  Row hash = jhash2(key, seed + r) as in the per-event form (DESIGN.md "Count-Min").
+#define GYS_CMSF_CELLS (GYS_CMS_W / 2u)
+__global__ __launch_bounds__(1024) void k_cms_partial(const uint32_t *resp_win, const uint64_t *svc_gid, uint32_t nsvc, uint32_t nch, uint32_t *partial)
+{
+	extern __shared__ uint32_t s_cells[]; // [GYS_CMSF_CELLS]
+	const uint32_t r = blockIdx.y >> 1, half = blockIdx.y & 1u;
+	for (uint32_t i = threadIdx.x; i < GYS_CMSF_CELLS; i += 1024u) s_cells[i] = 0;
+	__syncthreads();
+	const uint32_t per = (nsvc + nch - 1u) / nch;
+	const uint32_t first = blockIdx.x * per, last = min(nsvc, first + per);
+	for (uint32_t s = first + threadIdx.x; s < last; s += 1024u) {
+		const uint32_t m = resp_win[s];
+		if (!m) continue;
+		const uint32_t col = jhash2_u64(svc_gid[s], GYS_SEED + r) & (GYS_CMS_W - 1);
+		if ((col / GYS_CMSF_CELLS) == half) atomicAdd(&s_cells[col % GYS_CMSF_CELLS], m);
+	}
+	__syncthreads();
+	uint32_t *out = partial + ((size_t)blockIdx.x * GYS_CMS_D + r) * GYS_CMS_W + half * GYS_CMSF_CELLS;
+	for (uint32_t i = threadIdx.x; i < GYS_CMSF_CELLS; i += 1024u) out[i] = s_cells[i];
+}
+
+__global__ __launch_bounds__(256) void k_cms_reduce(const uint32_t *partial, uint32_t nch, uint32_t *cms32)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= GYS_CMS_D * GYS_CMS_W) return;
+	uint32_t sum = 0;
+	for (uint32_t c = 0; c < nch; ++c) sum += partial[(size_t)c * GYS_CMS_D * GYS_CMS_W + i];
+	if (sum) cms32[i] += sum;
+}
+
 // ---------------------------------------------------------------------------------------------------- host-local resp pass
 // One workgroup per host segment of the batch (or per PART of a segment, SHARED).  The reference resolves a response event's listener
 // inside the HOST's own listener table (TCP_SOCK_HANDLER is per host: common/gy_socket_stat.cc:1554-1677), so everything an event
@@ -414,6 +547,7 @@ struct RespHostP {
 	long long *gmax;           // arena: largest value of the window
 	uint32_t lds_tbl_entries;  // LDS table area of the launch (largest sub-table among the batch's hosts)
 	uint32_t lds_key_entries;  // LDS per-key areas (largest listener count, even)
+	FinP fin;                  // !SHARED && !SPILL: the workgroup finalizes its host's keys itself (finalize_key)
 };
 
 template <int TPT, bool SHARED, bool SPILL>
@@ -650,8 +784,12 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
 	if (ndrop_nol) atomicAdd(&s_drop[1], ndrop_nol);
 	__syncthreads();
-	if (!SHARED)
-		for (uint32_t k = tid; k < L; k += T) p.td_cur[s_slot[k]] = s_cur[k];
+	if (!SHARED) // the host's keys are this workgroup's alone: their end-of-batch bookkeeping happens here (no pass over all services)
+		for (uint32_t kb = 0; kb < L; kb += T) {
+			const uint32_t k = kb + tid;
+			const bool valid = k < L;
+			finalize_key<true>(p.fin, valid, valid ? s_slot[k] : 0u, valid ? s_cur[k] : 0u, lane);
+		}
 	if (tid < 15u) {
 		unsigned long long cnt = 0, sum = 0;
 		for (uint32_t w = 0; w < T / 64; ++w) {
@@ -709,105 +847,6 @@ __global__ __launch_bounds__(256) void k_key_append(AppendP p)
 			const uint32_t *src = p.staged + (ke - km);
 			uint32_t *dst = p.td_pend + (size_t)(chunk * 64u + (uint32_t)k) * p.pcap + kc;
 			for (uint32_t i = lane; i < km; i += 64u) dst[i] = src[i];
-		}
-	}
-}
-
-// ---------------------------------------------------------------------------------------------------- per-key end of batch
-// One thread per service: keys whose value count moved in this batch get their meta record updated (window bookkeeping of the lazy
-// fold), their Count-Min rows (events per service key), and are queued for a merge when the buffer holds more than GYS_TD_PEND_CAP
-// values; keys whose batch did not fit the buffer are spilled (run allocated in `staged`, host flagged for the second resp pass).
-struct FinP {
-	uint32_t *td_cur;
-	TdMeta *td_meta;
-	uint32_t nsvc, pcap, epoch;
-	uint32_t *cms32;
-	const uint64_t *svc_gid;
-	MergeEnt *merge_list, *huge_list;
-	uint32_t *merge_count, *huge_count;
-	uint32_t *run_alloc;       // bump cursor into `staged` (host-local front end)
-	uint32_t *td_run;
-	const uint32_t *batch_off; // general front end: end of the key's run in `staged` (nullptr: host-local front end)
-	const uint32_t *svc_host;
-	uint32_t *host_spill;
-	uint32_t spill_stamp;
-	uint64_t *counters;
-};
-
-__global__ __launch_bounds__(256) void k_key_finalize(FinP p)
-{
-	const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t lane = threadIdx.x & 63u;
-	bool to_merge = false, to_huge = false;
-	MergeEnt ent{};
-	if (key < p.nsvc) {
-		const uint32_t cur = p.td_cur[key];
-		const uint4 mraw = *(const uint4 *)&p.td_meta[key];
-		const uint32_t npend0 = mraw.x;
-		if (cur != npend0) {
-			const uint32_t m = cur - npend0;
-			uint32_t nh = mraw.y & 0xFFFFu, nw = mraw.y >> 16, win_epoch = mraw.z;
-			if (win_epoch != p.epoch) { // first values of the key in this window: everything buffered so far belongs to earlier windows
-				nw = npend0;
-				win_epoch = p.epoch;
-			}
-			const uint64_t gid = p.svc_gid[key];
-#pragma unroll
-			for (uint32_t r = 0; r < GYS_CMS_D; ++r) atomicAdd(&p.cms32[r * GYS_CMS_W + (jhash2_u64(gid, GYS_SEED + r) & (GYS_CMS_W - 1))], m);
-			ent.slot = key;
-			if (cur <= p.pcap) {
-				*(uint4 *)&p.td_meta[key] = make_uint4(cur, nh | (nw << 16), win_epoch, mraw.w);
-				if (cur > GYS_TD_PEND_CAP) {
-					ent.nbuf = cur;
-					to_merge = true;
-				}
-			} else { // spilled
-				*(uint4 *)&p.td_meta[key] = make_uint4(npend0, nh | (nw << 16), win_epoch, mraw.w);
-				p.td_cur[key] = npend0 | GYS_SPILL_BIT;
-				ent.nbuf = npend0;
-				ent.mrun = m;
-				if (p.batch_off) {
-					ent.off_end = p.batch_off[key];
-				} else {
-					const uint32_t start = atomicAdd(p.run_alloc, m);
-					p.td_run[key] = start;
-					ent.off_end = start + m;
-					p.host_spill[p.svc_host[key]] = p.spill_stamp;
-				}
-				if ((uint64_t)npend0 + m > GYS_MERGE_LDS_MAX) to_huge = true;
-				else to_merge = true;
-			}
-		}
-	}
-	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-	{
-		const unsigned long long nb = __ballot(to_merge);
-		if (nb) {
-			uint32_t at = 0;
-			if (lane == 0) at = atomicAdd(p.merge_count, (uint32_t)__popcll(nb));
-			at = (uint32_t)__shfl((int)at, 0, 64);
-			if (to_merge) p.merge_list[at + (uint32_t)__popcll(nb & below)] = ent;
-		}
-	}
-	{
-		const unsigned long long nb = __ballot(to_merge || to_huge);
-		if (nb) { // statistics: re-clusterings queued and the values they carry (one pair of atomics per wave)
-			uint32_t nv = (to_merge || to_huge) ? ent.nbuf + ent.mrun : 0u;
-#pragma unroll
-			for (int d = 32; d >= 1; d >>= 1) nv += (uint32_t)__shfl_xor((int)nv, d, 64);
-			if (lane == 0) {
-				atomicAdd((unsigned long long *)&p.counters[CTR_TD_MERGES], (unsigned long long)__popcll(nb));
-				atomicAdd((unsigned long long *)&p.counters[CTR_TD_MERGE_VALUES], (unsigned long long)nv);
-			}
-		}
-	}
-	{
-		const unsigned long long nb = __ballot(to_huge);
-		if (nb) {
-			uint32_t at = 0;
-			if (lane == 0) at = atomicAdd(p.huge_count, (uint32_t)__popcll(nb));
-			at = (uint32_t)__shfl((int)at, 0, 64);
-			if (to_huge) p.huge_list[at + (uint32_t)__popcll(nb & below)] = ent;
 		}
 	}
 }
@@ -1018,7 +1057,7 @@ struct MergeP {
 	uint32_t *out_cnt;
 };
 
-template <uint32_t MAXV, uint32_t MINV, uint32_t NT>
+template <uint32_t MAXV, uint32_t NT>
 __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 {
 	const DigestP &p = q.d;
@@ -1045,7 +1084,7 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
 		const MergeEnt ent = q.list[w];
 		const uint32_t m = ent.nbuf + ent.mrun;
-		if (m > MAXV || (MINV != 0u && m <= MINV)) continue; // another size class's entry
+		if (m > MAXV) continue; // never queued on this class's list (finalize_key)
 		const uint32_t slot = ent.slot;
 		const uint4 mt = *(const uint4 *)&p.td_meta[slot];
 		const uint32_t nh = query ? ent.nbuf : (mt.y & 0xFFFFu), nw = mt.y >> 16;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Builds profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md
-prescribes).  usage: pmc_traffic.py <fetch_dir> <write_dir> <events_per_launch> <service_keys> <skip_first_launches> <out.json>
+prescribes).  usage: pmc_traffic.py <fetch_dir> <write_dir> <events_per_launch> <service_keys> <keep_last_steps> <out.json>
 Units: rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE counts a 128-B request as 64 B, so it is doubled
 (calibration in this repo: k_gen_resp writes exactly 24 B x events and WRITE_SIZE reports exactly that number of KiB)."""
 import collections
@@ -9,8 +9,19 @@ import json
 import os
 import sys
 
-NAMES = {"k_resp_host": "resp_host", "k_key_pass": "key_pass", "k_digest_merge": "digest_merge", "k_digest_huge": "digest_huge",
-         "k_resp_pass1": "resp_pass1", "k_resp_scatter": "scatter"}
+NAMES = {"k_resp_host": "resp_host", "k_key_finalize": "key_finalize", "k_fold": "fold", "k_digest_merge": "digest_merge",
+         "k_digest_huge": "digest_huge", "k_resp_pass1": "resp_pass1", "k_resp_scatter": "scatter", "k_window_prepare": "window_prepare"}
+
+
+def short_name(kernel, k, short):
+    """the second (SPILL) pass of k_resp_host is its own stage: template arguments <TPT, SHARED, SPILL> end in `true>` / `1>`"""
+    if k == "k_resp_host":
+        i = kernel.find("k_resp_host<")
+        if i >= 0:
+            args = kernel[i:kernel.find(">", i)]
+            if args.rstrip().endswith(("true", " 1")):
+                return "resp_spill"
+    return short
 
 
 def per_kernel(root, counter, skip):
@@ -25,7 +36,7 @@ def per_kernel(root, counter, skip):
                         continue
                     for k, short in NAMES.items():
                         if k in r["Kernel_Name"]:
-                            rows.append((int(r["Dispatch_Id"]), short, float(r["Counter_Value"])))
+                            rows.append((int(r["Dispatch_Id"]), short_name(r["Kernel_Name"], k, short), float(r["Counter_Value"])))
     rows.sort()
     starts = sorted({d for d, short, _ in rows if short == "resp_host"})
     per = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -37,7 +48,7 @@ def per_kernel(root, counter, skip):
     out = {}
     for short, steps in per.items():
         # only full-size steps: the set-up passes before the first timed window use other batch sizes; keep the LAST (nsteps - skip)
-        ids = sorted(steps)[skip:]
+        ids = sorted(steps)[-skip:]  # the timed windows are the last ones of the run
         if ids:
             out[short] = sum(steps[i] for i in ids) / len(ids)
     return out

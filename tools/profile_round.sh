@@ -8,6 +8,6 @@ for f in $(find /tmp/kt -name "*.db"); do python $R/tools/rocprof_summary.py $f 
 rm -rf /tmp/pf /tmp/pw
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf -o p --output-format csv -- python $R/bench.py --no-cpu-baseline --no-quantile-check --no-host-fed --steps 3 > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw -o p --output-format csv -- python $R/bench.py --no-cpu-baseline --no-quantile-check --no-host-fed --steps 3 > $O/pmc_write.log 2>&1
-python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw $((1<<29)) 10000000 12 $O/pmc_traffic.json
+python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw $((1<<29)) 10000000 3 $O/pmc_traffic.json
 (echo "## FETCH_SIZE pass"; python $R/tools/pmc_kernels.py /tmp/pf gys::; echo "## WRITE_SIZE pass"; python $R/tools/pmc_kernels.py /tmp/pw gys::) > $O/pmc_summary.txt
 head -c 1500 $O/bench_line.json; echo; head -12 $O/kernel_stats.txt | cut -c1-170
