@@ -157,7 +157,7 @@ struct gys_ctx {
 	uint32_t *host_spill = nullptr;  // per host: batch stamp of the last batch in which one of its services spilled
 	uint32_t spill_stamp = 0;
 	uint32_t pcap = 0;
-	MergeEnt *merge_list = nullptr, *merge_list1 = nullptr, *merge_list2 = nullptr, *huge_list = nullptr, *query_list = nullptr;
+	MergeEnt *merge_list = nullptr, *merge_list_slow = nullptr, *merge_list1 = nullptr, *merge_list2 = nullptr, *huge_list = nullptr, *query_list = nullptr;
 	uint32_t *merge_count = nullptr; // [FIN_*]: merge list lengths by size class, huge list length, run allocation cursor; [8] = 1 (query list)
 	uint32_t *resp_win = nullptr;    // per service: response events of the open window (-> Count-Min rows at the window boundary)
 	uint32_t *cms_partial = nullptr; // [cms_nch][GYS_CMS_D][GYS_CMS_W] partial rows of k_cms_partial
@@ -700,9 +700,23 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		const uint32_t cap = (uint32_t)std::min<uint64_t>(nsvc, n);
 		{
 			ProfScope ps(c, "digest_merge");
+			static const bool old_merge = getenv("GYS_OLD_MERGE") != nullptr; // A/B: the general kernel for class 0 as well
 			mp.list = c->merge_list;
 			mp.count = c->merge_count + FIN_CLASS0;
-			hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 7))), dim3(256), 0, c->stream, mp);
+			if (old_merge) {
+				hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 7))), dim3(256), 0, c->stream, mp);
+			} else {
+				MergeBP bp{};
+				bp.d = mp.d;
+				bp.list = c->merge_list;
+				bp.count = c->merge_count + FIN_CLASS0;
+				bp.slow_list = c->merge_list_slow;
+				bp.slow_count = c->merge_count + FIN_SLOW;
+				hipLaunchKernelGGL(k_digest_bins, dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 8))), dim3(256), 0, c->stream, bp);
+				mp.list = c->merge_list_slow; // entries whose total weight needs 64-bit arithmetic (normally none)
+				mp.count = c->merge_count + FIN_SLOW;
+				hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
+			}
 		}
 		{
 			ProfScope ps(c, "digest_merge_big");
@@ -1027,6 +1041,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 			return rc;
 		}
 		ALLOC(c->merge_list, std::min<uint64_t>(S, B) + 1);
+		ALLOC(c->merge_list_slow, std::min<uint64_t>(S, B) + 1);
 		// a key lands in a larger merge size class only when the batch itself brought it more than CLASS0 - PEND_CAP values
 		ALLOC(c->merge_list1, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS0 - GYS_TD_PEND_CAP) + 1) + 1);
 		ALLOC(c->merge_list2, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1) + 1);
@@ -1104,7 +1119,7 @@ void gys_destroy(gys_ctx *c)
 	}
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
-			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
+			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,

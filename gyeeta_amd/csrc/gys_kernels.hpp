@@ -377,7 +377,7 @@ __global__ void k_minmax_init(int2 *mm, uint64_t n)
 // k_key_finalize (one thread per service).
 #define GYS_MERGE_CLASS0 1024u // largest (buffered + run) value count of merge size class 0 / 1 (class 2: up to GYS_MERGE_LDS_MAX)
 #define GYS_MERGE_CLASS1 4096u
-enum { FIN_CLASS0 = 0, FIN_CLASS1, FIN_CLASS2, FIN_HUGE, FIN_RUN_ALLOC, FIN_NCOUNTS };
+enum { FIN_CLASS0 = 0, FIN_CLASS1, FIN_CLASS2, FIN_HUGE, FIN_RUN_ALLOC, FIN_SLOW, FIN_NCOUNTS }; // FIN_SLOW: k_digest_bins' hand-over list
 
 struct FinP {
 	uint32_t *td_cur;
@@ -1296,6 +1296,313 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 			const uint32_t n_all = m - nh, n_win = m > nwin0 ? m - nwin0 : 0u;
 			if (tid < 16u && n_all) fold_records(p, slot, tid, mt.w != mt.z, s_fa[tid], s_fw[tid], n_all, n_win, s_fmm[1], s_fmm[2], s_fbm[tid]);
 			if (tid == 16u) {
+				*(uint4 *)&p.td_meta[slot] = make_uint4(0u, 0u, mt.z, n_win ? mt.z : mt.w); // buffer drained
+				p.td_cur[slot] = 0;
+				if (n_all) {
+					const int2 mm = p.td_minmax[slot];
+					if (s_fmm[0] < mm.x || s_fmm[1] > mm.y) p.td_minmax[slot] = make_int2(min(mm.x, s_fmm[0]), max(mm.y, s_fmm[1]));
+				}
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------- t-digest merge (value bins)
+// The hot merge: entries of size class 0 (m <= 1024 values), one 256-thread workgroup per entry, every thread keeps its (up to) four
+// values in registers.  Same exact-integer definition as k_digest_merge (bit-identical result), computed by counting over the VALUE
+// DOMAIN instead of over cluster gaps: integer-millisecond response times are small, so values below 1024 get one LDS bin each
+// (rank = values in lower bins + arrival order inside the bin: equal values are interchangeable) and larger values fall into
+// 64-cells-per-octave bins and rank inside their cell by direct comparison against the (short) list of large values.  A bin word is
+// {values : 16 | clusters whose integer mean threshold lies in the bin : 16}; ONE prefix scan of the bins therefore yields, per bin,
+// the values below it (-> a value's rank, a cluster's count of smaller values) and the clusters at or below it (-> a value's gap,
+// i.e. the old weight that precedes it).  Per value: one LDS atomic, one LDS read, one threshold search; no sort, no per-interval
+// comparison loops, no staging of the values in LDS.  The all-time record's bucket deltas come from the scanned bins (a thread's 7
+// consecutive bins touch at most two RESP_TIME_HASH buckets) instead of one contended LDS atomic per value.
+//   Weights are 32-bit here (total weight < 2^31: thresholds and mid-points fit a u32); an entry beyond that is handed to the
+//   general kernel through slow_list.
+#define GYS_MB_EXACT 1024u
+#define GYS_MB_BINS 1792u // 1024 one-value bins + 10 octaves x 64 cells (values < 2^20), padded to 7 bins per thread
+#define GYS_MB_BPT 7u
+
+__device__ __forceinline__ uint32_t mb_bin(uint32_t v)
+{
+	if (v < GYS_MB_EXACT) return v;
+	const uint32_t msb = 31u - (uint32_t)__clz((int)v);
+	return GYS_MB_EXACT + (msb - 10u) * 64u + ((v >> (msb - 6u)) & 63u);
+}
+
+struct MergeBP {
+	DigestP d;
+	const MergeEnt *list;
+	const uint32_t *count;
+	int64_t *out_sum; // query mode (see k_digest_merge)
+	uint32_t *out_cnt;
+	MergeEnt *slow_list;
+	uint32_t *slow_count;
+};
+
+__global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
+{
+	const DigestP &p = q.d;
+	__shared__ uint32_t s_bin[GYS_MB_BINS];
+	__shared__ uint32_t s_big[GYS_MERGE_CLASS0]; // values >= GYS_MB_EXACT: index << 20 | value
+	__shared__ uint32_t s_thr[GYS_NBP];          // compacted non-empty old clusters: ceil(sum / count), padded with ~0
+	__shared__ uint32_t s_cpfx[GYS_NBP + 1];     // old weight before compacted cluster c
+	__shared__ uint32_t s_T[GYS_NBP];            // T_j, j = 1..NB-1; [0] = 0, [NB..] = ~0
+	__shared__ unsigned long long s_osum[GYS_TD_NB];
+	__shared__ uint32_t s_ocnt[GYS_TD_NB];
+	__shared__ unsigned long long s_fa[16], s_fw[16];
+	__shared__ uint32_t s_fbm[16];
+	__shared__ int32_t s_fmm[3];
+	__shared__ uint32_t s_wv[4], s_ws[4], s_nbig;
+	__shared__ uint64_t s_ww[4];
+	const uint32_t nent = *q.count;
+	const bool query = q.out_sum != nullptr;
+
+	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
+		// the thread index is re-derived per entry behind an opaque move: otherwise every LDS address, lane mask and per-bin
+		// bucket the thread uses is hoisted out of this loop and held in registers across it (> 96 VGPRs instead of < 64)
+		uint32_t tid = threadIdx.x;
+		asm volatile("" : "+v"(tid));
+		const uint32_t lane = tid & 63u, wave = tid >> 6;
+		const MergeEnt ent = q.list[w];
+		const uint32_t m = ent.nbuf + ent.mrun;
+		if (m > GYS_MERGE_CLASS0) continue; // never queued on this list (finalize_key)
+		const uint32_t slot = ent.slot;
+		const uint4 mt = *(const uint4 *)&p.td_meta[slot];
+		const uint32_t nh = query ? m : (mt.y & 0xFFFFu), nw = mt.y >> 16;
+		const uint32_t nwin0 = max(nh, nw);
+		const uint32_t run0 = ent.off_end - ent.mrun;
+		// ---- loads: cluster tid, values tid + 256 k
+		uint32_t c0 = 0;
+		int64_t sm0 = 0;
+		if (tid < GYS_TD_NB) {
+			c0 = p.td_cnt[(size_t)slot * GYS_TD_NB + tid];
+			sm0 = p.td_sum[(size_t)slot * GYS_TD_NB + tid];
+		}
+		uint32_t wd[4];
+		{
+			const uint32_t *pend = p.td_pend + (size_t)slot * p.pcap;
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; ++k) {
+				const uint32_t i = tid + 256u * k;
+				wd[k] = 0;
+				if (i < m) wd[k] = i < ent.nbuf ? pend[i] : p.staged[run0 + (i - ent.nbuf)];
+			}
+		}
+		if (m == 0) { // nothing buffered (query of a freshly merged key): the merged view is the digest itself
+			if (query && tid < GYS_TD_NB) {
+				q.out_sum[(size_t)w * GYS_TD_NB + tid] = sm0;
+				q.out_cnt[(size_t)w * GYS_TD_NB + tid] = c0;
+			}
+			continue;
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < GYS_MB_BPT; ++k) s_bin[tid + 256u * k] = 0;
+		s_thr[tid] = 0xFFFFFFFFu;
+		if (tid < GYS_TD_NB) {
+			s_osum[tid] = 0;
+			s_ocnt[tid] = 0;
+		}
+		if (tid < 16u) {
+			s_fa[tid] = 0;
+			s_fw[tid] = 0;
+			s_fbm[tid] = 0;
+		}
+		if (tid == 0) {
+			s_fmm[0] = INT32_MAX;
+			s_fmm[1] = INT32_MIN;
+			s_fmm[2] = INT32_MIN;
+			s_nbig = 0;
+		}
+		// compaction of the non-empty clusters (order preserving) + exclusive prefix of their weights
+		const unsigned long long b0 = __ballot(c0 != 0);
+		uint64_t inc = c0;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint64_t t = __shfl_up(inc, d, 64);
+			if ((int)lane >= d) inc += t;
+		}
+		if (lane == 63u) s_ww[wave] = inc;
+		if (lane == 0u) s_wv[wave] = (uint32_t)__popcll(b0);
+		__syncthreads();
+		uint32_t pbase = 0, nc = 0;
+		uint64_t wbase = 0, nold64 = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < 4u; ++k) {
+			if (k < wave) {
+				pbase += s_wv[k];
+				wbase += s_ww[k];
+			}
+			nc += s_wv[k];
+			nold64 += s_ww[k];
+		}
+		if (nold64 + (uint64_t)m >= (1ull << 31)) { // 64-bit weights: the general kernel's job
+			if (tid == 0) q.slow_list[atomicAdd(q.slow_count, 1u)] = ent;
+			__syncthreads();
+			continue;
+		}
+		const uint32_t pos0 = pbase + (uint32_t)__popcll(b0 & (lane ? (~0ull >> (64 - lane)) : 0ull));
+		const uint32_t e0 = (uint32_t)(wbase + inc - c0), nold = (uint32_t)nold64;
+		const uint32_t twoN = 2u * (nold + m);
+		uint32_t thr = 0;
+		if (c0) {
+			thr = ceil_div_sum_cnt(sm0, c0);
+			s_thr[pos0] = thr;
+			s_cpfx[pos0] = e0;
+			atomicAdd(&s_bin[mb_bin(thr)], 1u << 16);
+		}
+		if (tid == 0) s_cpfx[nc] = nold;
+		s_T[tid] = (tid >= 1u && tid < GYS_TD_NB) ? (uint32_t)td_threshold(c_td_bnd[tid], (uint64_t)twoN) : (tid ? 0xFFFFFFFFu : 0u);
+		// ---- values, pass 1: bin count (-> arrival order inside the bin), list of large values, window part of the fold
+		const bool fold_scan = !query && nh == 0u; // the all-time deltas of the one-value bins come from the scan
+		uint32_t pos[4];
+		int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmax = INT32_MIN;
+#pragma unroll
+		for (uint32_t k = 0; k < 4u; ++k) {
+			const uint32_t i = tid + 256u * k;
+			pos[k] = 0;
+			if (i >= m) continue;
+			const uint32_t uv = wd[k] >> GYS_ROW_BITS;
+			pos[k] = atomicAdd(&s_bin[mb_bin(uv)], 1u) & 0xFFFFu;
+			const bool big = uv >= GYS_MB_EXACT;
+			if (big) s_big[atomicAdd(&s_nbig, 1u)] = (i << 20) | uv;
+			if (i >= nh) { // not yet folded: histogram bucket of the key's records, CONN_BITMAP row, min / max
+				lmin = min(lmin, (int32_t)uv);
+				lmax = max(lmax, (int32_t)uv);
+				const bool win = i >= nwin0;
+				if (big || !fold_scan || win) {
+					const uint32_t b = resp_bucket((int64_t)uv);
+					const unsigned long long one = GYS_PACK_ONE | (unsigned long long)uv;
+					if (big || !fold_scan) atomicAdd(&s_fa[b], one);
+					if (win) {
+						atomicAdd(&s_fw[b], one);
+						const uint32_t r = wd[k] & 0x1Fu;
+						atomicOr(&s_fbm[r >> 1], (1u << b) << ((r & 1u) * 16u));
+						wmax = max(wmax, (int32_t)uv);
+					}
+				}
+			}
+		}
+		if (!query && m > nh) {
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1) {
+				lmin = min(lmin, __shfl_xor(lmin, d, 64));
+				lmax = max(lmax, __shfl_xor(lmax, d, 64));
+				wmax = max(wmax, __shfl_xor(wmax, d, 64));
+			}
+			if (lane == 0) {
+				if (lmin != INT32_MAX) atomicMin(&s_fmm[0], lmin);
+				if (lmax != INT32_MIN) atomicMax(&s_fmm[1], lmax);
+				if (wmax != INT32_MIN) atomicMax(&s_fmm[2], wmax);
+			}
+		}
+		__syncthreads();
+		// ---- one scan over the bins: thread t owns bins [7t, 7t + 7)
+		{
+			uint32_t bv[GYS_MB_BPT], own = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < GYS_MB_BPT; ++k) {
+				bv[k] = s_bin[GYS_MB_BPT * tid + k];
+				own += bv[k];
+			}
+			uint32_t sc = own;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t t = __shfl_up(sc, d, 64);
+				if ((int)lane >= d) sc += t;
+			}
+			if (lane == 63u) s_ws[wave] = sc;
+			__syncthreads();
+			uint32_t run = sc - own;
+#pragma unroll
+			for (uint32_t k = 0; k < 3u; ++k)
+				if (k < wave) run += s_ws[k];
+			uint32_t curb = 0xFFu;
+			unsigned long long acc = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < GYS_MB_BPT; ++k) {
+				const uint32_t bin = GYS_MB_BPT * tid + k;
+				// {values in lower bins : 16 | clusters with threshold in this or a lower bin : 16}
+				s_bin[bin] = (run & 0xFFFFu) | (((run >> 16) + (bv[k] >> 16)) << 16);
+				run += bv[k];
+				const uint32_t cnt = bv[k] & 0xFFFFu;
+				if (fold_scan && cnt && bin < GYS_MB_EXACT) { // GY_HISTOGRAM::add_data for cnt values equal to `bin`
+					const uint32_t b = resp_bucket((int64_t)bin);
+					if (b != curb) {
+						if (acc) atomicAdd(&s_fa[curb], acc);
+						curb = b;
+						acc = 0;
+					}
+					acc += (unsigned long long)cnt * (GYS_PACK_ONE | (unsigned long long)bin);
+				}
+			}
+			if (acc) atomicAdd(&s_fa[curb], acc);
+		}
+		__syncthreads();
+		const uint32_t nbig = s_nbig;
+		// ---- old clusters: preceded by the old weight before them and by the values below their mean
+		if (c0) {
+			uint32_t nb = s_bin[mb_bin(thr)] & 0xFFFFu;
+			if (thr >= GYS_MB_EXACT) {
+				const uint32_t sh = (31u - (uint32_t)__clz((int)thr)) - 6u;
+				for (uint32_t j = 0; j < nbig; ++j) {
+					const uint32_t u = s_big[j] & 0xFFFFFu;
+					nb += ((u >> sh) == (thr >> sh) && u < thr) ? 1u : 0u;
+				}
+			}
+			const uint32_t mid2 = 2u * (e0 + nb) + c0;
+			uint32_t a = 0;
+#pragma unroll
+			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
+				if (mid2 >= s_T[a + step]) a += step;
+			atomicAdd(&s_osum[a], (unsigned long long)sm0);
+			atomicAdd(&s_ocnt[a], c0);
+		}
+		// ---- values, pass 2: rank and gap from the scanned bin
+#pragma unroll
+		for (uint32_t k = 0; k < 4u; ++k) {
+			const uint32_t i = tid + 256u * k;
+			if (i >= m) continue;
+			const uint32_t uv = wd[k] >> GYS_ROW_BITS;
+			const uint32_t bw = s_bin[mb_bin(uv)];
+			uint32_t r = bw & 0xFFFFu, gap;
+			if (uv < GYS_MB_EXACT) {
+				r += pos[k];
+				gap = bw >> 16;
+			} else {
+				const uint32_t sh = (31u - (uint32_t)__clz((int)uv)) - 6u;
+				for (uint32_t j = 0; j < nbig; ++j) {
+					const uint32_t e = s_big[j], u = e & 0xFFFFFu;
+					r += ((u >> sh) == (uv >> sh) && (u < uv || (u == uv && (e >> 20) < i))) ? 1u : 0u;
+				}
+				gap = 0;
+#pragma unroll
+				for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
+					if (s_thr[gap + step - 1u] <= uv) gap += step;
+			}
+			const uint32_t mid2 = 2u * (r + s_cpfx[gap]) + 1u;
+			uint32_t a = 0;
+#pragma unroll
+			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
+				if (mid2 >= s_T[a + step]) a += step;
+			atomicAdd(&s_osum[a], (unsigned long long)uv);
+			atomicAdd(&s_ocnt[a], 1u);
+		}
+		__syncthreads();
+		// ---- write back
+		if (tid < GYS_TD_NB) {
+			int64_t *ws = query ? q.out_sum + (size_t)w * GYS_TD_NB : p.td_sum + (size_t)slot * GYS_TD_NB;
+			uint32_t *wc = query ? q.out_cnt + (size_t)w * GYS_TD_NB : p.td_cnt + (size_t)slot * GYS_TD_NB;
+			ws[tid] = (int64_t)s_osum[tid];
+			wc[tid] = s_ocnt[tid];
+		}
+		if (!query) {
+			const uint32_t n_all = m - nh, n_win = m > nwin0 ? m - nwin0 : 0u;
+			if (tid >= 192u && tid < 208u && n_all)
+				fold_records(p, slot, tid - 192u, mt.w != mt.z, s_fa[tid - 192u], s_fw[tid - 192u], n_all, n_win, s_fmm[1], s_fmm[2], s_fbm[tid - 192u]);
+			if (tid == 208u) {
 				*(uint4 *)&p.td_meta[slot] = make_uint4(0u, 0u, mt.z, n_win ? mt.z : mt.w); // buffer drained
 				p.td_cur[slot] = 0;
 				if (n_all) {
