@@ -555,7 +555,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	RespHostP hp{};
 	uint32_t hgrid = 0;
 	size_t dyn = 0;
-	static const int tpt = [] { const char *e = getenv("GYS_TPT"); return (e && atoi(e) == 16) ? 16 : 8; }();
+	// 16 events per thread and tile (16384-event tiles: longer per-key runs in the flush) when the LDS budget allows; GYS_TPT=8 for A/B
+	static const int tpt = [] { const char *e = getenv("GYS_TPT"); return (e && atoi(e) == 8) ? 8 : 16; }();
 	bool tpt16 = false;
 	if (host_local) {
 		hp.ev = (const uint64_t *)d_ev;

@@ -1317,13 +1317,13 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 // {values : 16 | clusters whose integer mean threshold lies in the bin : 16}; ONE prefix scan of the bins therefore yields, per bin,
 // the values below it (-> a value's rank, a cluster's count of smaller values) and the clusters at or below it (-> a value's gap,
 // i.e. the old weight that precedes it).  Per value: one LDS atomic, one LDS read, one threshold search; no sort, no per-interval
-// comparison loops, no staging of the values in LDS.  The all-time record's bucket deltas come from the scanned bins (a thread's 7
+// comparison loops, no staging of the values in LDS.  The all-time record's bucket deltas come from the scanned bins (a thread's 8
 // consecutive bins touch at most two RESP_TIME_HASH buckets) instead of one contended LDS atomic per value.
 //   Weights are 32-bit here (total weight < 2^31: thresholds and mid-points fit a u32); an entry beyond that is handed to the
 //   general kernel through slow_list.
 #define GYS_MB_EXACT 1024u
-#define GYS_MB_BINS 1792u // 1024 one-value bins + 10 octaves x 64 cells (values < 2^20), padded to 7 bins per thread
-#define GYS_MB_BPT 7u
+#define GYS_MB_BINS 2048u // 1024 one-value bins + 10 octaves x 64 cells (values < 2^20), padded to 8 bins per thread
+#define GYS_MB_BPT 8u
 
 __device__ __forceinline__ uint32_t mb_bin(uint32_t v)
 {
@@ -1345,7 +1345,7 @@ struct MergeBP {
 __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 {
 	const DigestP &p = q.d;
-	__shared__ uint32_t s_bin[GYS_MB_BINS];
+	__shared__ __align__(16) uint32_t s_bin[GYS_MB_BINS];
 	__shared__ uint32_t s_big[GYS_MERGE_CLASS0]; // values >= GYS_MB_EXACT: index << 20 | value
 	__shared__ uint32_t s_thr[GYS_NBP];          // compacted non-empty old clusters: ceil(sum / count), padded with ~0
 	__shared__ uint32_t s_cpfx[GYS_NBP + 1];     // old weight before compacted cluster c
@@ -1359,6 +1359,14 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 	__shared__ uint64_t s_ww[4];
 	const uint32_t nent = *q.count;
 	const bool query = q.out_sum != nullptr;
+	// RESP_TIME_HASH bucket of the thread's first bin and the first of its 8 bins that lies in the next bucket (8 = none): the
+	// thresholds are at least 9 apart, so 8 consecutive values touch at most two buckets
+	uint32_t bk_first = 0, bk_chg = GYS_MB_BPT;
+	if (GYS_MB_BPT * threadIdx.x < GYS_MB_EXACT) {
+		bk_first = resp_bucket((int64_t)(GYS_MB_BPT * threadIdx.x));
+		for (uint32_t k = GYS_MB_BPT - 1u; k >= 1u; --k)
+			if (resp_bucket((int64_t)(GYS_MB_BPT * threadIdx.x + k)) != bk_first) bk_chg = k;
+	}
 
 	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
 		// the thread index is re-derived per entry behind an opaque move: otherwise every LDS address, lane mask and per-bin
@@ -1499,14 +1507,16 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			}
 		}
 		__syncthreads();
-		// ---- one scan over the bins: thread t owns bins [7t, 7t + 7)
+		// ---- one scan over the bins: thread t owns bins [8t, 8t + 8)
 		{
 			uint32_t bv[GYS_MB_BPT], own = 0;
-#pragma unroll
-			for (uint32_t k = 0; k < GYS_MB_BPT; ++k) {
-				bv[k] = s_bin[GYS_MB_BPT * tid + k];
-				own += bv[k];
+			{
+				const uint4 lo4 = ((const uint4 *)s_bin)[2u * tid], hi4 = ((const uint4 *)s_bin)[2u * tid + 1u]; // two 16-byte reads per lane
+				bv[0] = lo4.x; bv[1] = lo4.y; bv[2] = lo4.z; bv[3] = lo4.w;
+				bv[4] = hi4.x; bv[5] = hi4.y; bv[6] = hi4.z; bv[7] = hi4.w;
 			}
+#pragma unroll
+			for (uint32_t k = 0; k < GYS_MB_BPT; ++k) own += bv[k];
 			uint32_t sc = own;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
@@ -1519,26 +1529,24 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 #pragma unroll
 			for (uint32_t k = 0; k < 3u; ++k)
 				if (k < wave) run += s_ws[k];
-			uint32_t curb = 0xFFu;
-			unsigned long long acc = 0;
+			unsigned long long acc0 = 0, acc1 = 0; // GY_HISTOGRAM::add_data for cnt values equal to `bin`, per bucket of the thread's bins
 #pragma unroll
 			for (uint32_t k = 0; k < GYS_MB_BPT; ++k) {
 				const uint32_t bin = GYS_MB_BPT * tid + k;
 				// {values in lower bins : 16 | clusters with threshold in this or a lower bin : 16}
-				s_bin[bin] = (run & 0xFFFFu) | (((run >> 16) + (bv[k] >> 16)) << 16);
-				run += bv[k];
-				const uint32_t cnt = bv[k] & 0xFFFFu;
-				if (fold_scan && cnt && bin < GYS_MB_EXACT) { // GY_HISTOGRAM::add_data for cnt values equal to `bin`
-					const uint32_t b = resp_bucket((int64_t)bin);
-					if (b != curb) {
-						if (acc) atomicAdd(&s_fa[curb], acc);
-						curb = b;
-						acc = 0;
-					}
-					acc += (unsigned long long)cnt * (GYS_PACK_ONE | (unsigned long long)bin);
-				}
+				const uint32_t raw = bv[k];
+				bv[k] = (run & 0xFFFFu) | (((run >> 16) + (raw >> 16)) << 16);
+				run += raw;
+				const uint32_t cnt = raw & 0xFFFFu; // cnt x {1 : 24 | bin : 40}: cnt <= 1024 and bin < 1024, the halves cannot meet
+				const unsigned long long d = ((unsigned long long)(cnt << 8) << 32) | (unsigned long long)(cnt * bin);
+				if (k < bk_chg) acc0 += d; else acc1 += d;
 			}
-			if (acc) atomicAdd(&s_fa[curb], acc);
+			((uint4 *)s_bin)[2u * tid] = make_uint4(bv[0], bv[1], bv[2], bv[3]);
+			((uint4 *)s_bin)[2u * tid + 1u] = make_uint4(bv[4], bv[5], bv[6], bv[7]);
+			if (fold_scan && GYS_MB_BPT * tid < GYS_MB_EXACT) { // (a thread's 8 bins are all one-value bins or all cells: 1024 = 8 x 128)
+				if (acc0) atomicAdd(&s_fa[bk_first], acc0);
+				if (acc1) atomicAdd(&s_fa[bk_first + 1u], acc1);
+			}
 		}
 		__syncthreads();
 		const uint32_t nbig = s_nbig;
@@ -1564,24 +1572,31 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 #pragma unroll
 		for (uint32_t k = 0; k < 4u; ++k) {
 			const uint32_t i = tid + 256u * k;
-			if (i >= m) continue;
 			const uint32_t uv = wd[k] >> GYS_ROW_BITS;
-			const uint32_t bw = s_bin[mb_bin(uv)];
-			uint32_t r = bw & 0xFFFFu, gap;
-			if (uv < GYS_MB_EXACT) {
-				r += pos[k];
-				gap = bw >> 16;
-			} else {
-				const uint32_t sh = (31u - (uint32_t)__clz((int)uv)) - 6u;
-				for (uint32_t j = 0; j < nbig; ++j) {
-					const uint32_t e = s_big[j], u = e & 0xFFFFFu;
-					r += ((u >> sh) == (uv >> sh) && (u < uv || (u == uv && (e >> 20) < i))) ? 1u : 0u;
-				}
-				gap = 0;
+			if (i >= m || uv >= GYS_MB_EXACT) continue;
+			const uint32_t bw = s_bin[uv];
+			const uint32_t mid2 = 2u * ((bw & 0xFFFFu) + pos[k] + s_cpfx[bw >> 16]) + 1u;
+			uint32_t a = 0;
 #pragma unroll
-				for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
-					if (s_thr[gap + step - 1u] <= uv) gap += step;
+			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
+				if (mid2 >= s_T[a + step]) a += step;
+			atomicAdd(&s_osum[a], (unsigned long long)uv);
+			atomicAdd(&s_ocnt[a], 1u);
+		}
+		// the (few) large values, one per thread from the list: rank inside the cell by comparison with the other large values, gap by
+		// search over the cluster thresholds
+		for (uint32_t j = tid; j < nbig; j += 256u) {
+			const uint32_t me = s_big[j], uv = me & 0xFFFFFu, i = me >> 20;
+			const uint32_t sh = (31u - (uint32_t)__clz((int)uv)) - 6u;
+			uint32_t r = s_bin[mb_bin(uv)] & 0xFFFFu;
+			for (uint32_t jj = 0; jj < nbig; ++jj) {
+				const uint32_t e = s_big[jj], u = e & 0xFFFFFu;
+				r += ((u >> sh) == (uv >> sh) && (u < uv || (u == uv && (e >> 20) < i))) ? 1u : 0u;
 			}
+			uint32_t gap = 0;
+#pragma unroll
+			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
+				if (s_thr[gap + step - 1u] <= uv) gap += step;
 			const uint32_t mid2 = 2u * (r + s_cpfx[gap]) + 1u;
 			uint32_t a = 0;
 #pragma unroll
