@@ -461,7 +461,17 @@ int fold_range(gys_ctx *c, uint32_t first, uint32_t n)
 template <int TPT, bool SHARED, bool SPILL>
 void launch_resp_host(gys_ctx *c, uint32_t grid, size_t dyn, const RespHostP &hp)
 {
-	hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL>), dim3(grid), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+	if (!SPILL && hp.svc_hll_p) hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, !SPILL>), dim3(grid), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+	else hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, false>), dim3(grid), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+}
+
+template <int TPT, bool SHARED, bool SPILL>
+hipError_t resp_host_lds_attr()
+{
+	hipError_t e = hipFuncSetAttribute((const void *)k_resp_host<TPT, SHARED, SPILL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+	if (e == hipSuccess && !SPILL)
+		e = hipFuncSetAttribute((const void *)k_resp_host<TPT, SHARED, SPILL, !SPILL>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+	return e;
 }
 
 // resp pipeline on a device-resident batch
@@ -576,6 +586,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hp.spill_stamp = ++c->spill_stamp;
 		fin.spill_stamp = hp.spill_stamp;
 		hp.fin = fin;
+		{
+			static const uint32_t dbg = [] { const char *e = getenv("GYS_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
+			hp.dbg = dbg;
+		}
 		hp.counters = c->counters;
 		hp.svc_hll = c->svc_hll;
 		hp.svc_hll_p = c->cfg.svc_hll_p;
@@ -1007,12 +1021,12 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	ALLOC(c->host_spill, H);
 	c->host_lst.reserve(H);
 	// k_resp_host: up to 4096 sub-table entries (32 KiB) + 2048 x 24 B of per-key areas (48 KiB) + the tile image (48 or 96 KiB)
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<16, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<16, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-	HIPCHK(hipFuncSetAttribute((const void *)k_resp_host<16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+	HIPCHK((resp_host_lds_attr<8, false, false>()));
+	HIPCHK((resp_host_lds_attr<8, true, false>()));
+	HIPCHK((resp_host_lds_attr<8, true, true>()));
+	HIPCHK((resp_host_lds_attr<16, false, false>()));
+	HIPCHK((resp_host_lds_attr<16, true, false>()));
+	HIPCHK((resp_host_lds_attr<16, true, true>()));
 	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_levels) {

@@ -548,9 +548,10 @@ struct RespHostP {
 	uint32_t lds_tbl_entries;  // LDS table area of the launch (largest sub-table among the batch's hosts)
 	uint32_t lds_key_entries;  // LDS per-key areas (largest listener count, even)
 	FinP fin;                  // !SHARED && !SPILL: the workgroup finalizes its host's keys itself (finalize_key)
+	uint32_t dbg;              // timing experiments only (GYS_DBG): 1 no flush, 2 no image, 4 no HLL, 8 no all-service histogram, 16 no key counts
 };
 
-template <int TPT, bool SHARED, bool SPILL>
+template <int TPT, bool SHARED, bool SPILL, bool SVCHLL>
 __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 {
 	constexpr uint32_t T = GYS_HOST_THREADS;
@@ -623,9 +624,12 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 		for (uint32_t k = tid; k < L; k += T) s_tcnt[k] = 0;
 		__syncthreads();
 		// ---- resolve, filter, rank: 4 events per thread at a time, phase by phase (all event loads, then the arithmetic, then the HLL
-		// register reads, then the updates) so that each wave keeps several HBM requests in flight
+		// register reads, then the updates) so that each wave keeps several HBM requests in flight.  The loop over the groups of 4 is
+		// NOT unrolled (one copy of the event code instead of TPT / 4: the unrolled form was > 100 KB of instructions, twice the
+		// instruction cache two CUs share); the per-event results live in registers all the same: wd / lr are shifted down by 4 per
+		// group, so that every index stays a compile-time constant and after TPT / 4 groups event g sits at wd[g].
 		uint32_t wd[TPT], lr[TPT]; // staged word (GYS_EV_DROPPED: not kept) / local index | rank inside the key's tile run << 12
-#pragma unroll
+#pragma unroll 1
 		for (int g = 0; g < TPT; g += 4) {
 			uint64_t w0[4], w1[4], w2[4];
 #pragma unroll
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 					w2[u] = p.ev[3 * i + 2];
 				}
 			}
-			uint32_t hidx[4], hrank[4], hcur[4];
+			uint32_t hidx[4], hrank[4], hcur[4], nwd[4], nlr[4], rare = 0;
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				const uint64_t i = t0 + tid + (uint64_t)(g + u) * T;
@@ -647,8 +651,8 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 				const uint32_t netns = (uint32_t)w1[u];
 				const uint16_t sport = bswap16((uint16_t)(w1[u] >> 32)), dport = bswap16((uint16_t)(w1[u] >> 48)); // ntohs :1526-1527
 				const uint32_t tresp = (uint32_t)w2[u] - (uint32_t)(w2[u] >> 32); // lsndtime - lrcvtime (:1519)
-				wd[g + u] = GYS_EV_DROPPED;
-				lr[g + u] = 0;
+				nwd[u] = GYS_EV_DROPPED;
+				nlr[u] = 0;
 				hrank[u] = 0;
 				hidx[u] = 0;
 				if (i >= e1) continue;
@@ -673,20 +677,40 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 					continue;
 				}
 				if (SPILL && !s_cur[local]) continue; // the key's values already sit in its buffer
-				wd[g + u] = (tresp << GYS_ROW_BITS) | ((uint32_t)dport & 0x1Fu);
-				lr[g + u] = local;
+				nwd[u] = (tresp << GYS_ROW_BITS) | ((uint32_t)dport & 0x1Fu);
+				nlr[u] = local;
 				if (!SPILL) {
-					if (p.svc_hll_p) { // the per-service registers need the whole 64-bit hash
-						const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
-						hll_idx_rank(h64, GYS_HLL_P, &hidx[u], &hrank[u]);
-						svc_hll_update(p.svc_hll, p.svc_hll_p, s_slot[local], h64);
-					} else {
+					// both ends IPv4 and no per-service registers: index and rank from the first hash half (flow_hll_idx_rank).  Everything
+					// else (0.0.0.0 / IPv6-mapped ends hash as 7 / 10 words; the per-service registers need all 64 bits) is rare or a
+					// non-default configuration and goes through ONE rolled copy of the general code below
+					if (p.dbg & 4u) {
+					} else if (!SVCHLL && daddr != 0 && saddr != 0) {
 						flow_hll_idx_rank(daddr, dport, saddr, sport, &hidx[u], &hrank[u]);
+						if (hrank[u] <= hll_floor) hrank[u] = 0; // cannot raise any register
+					} else {
+						rare |= 1u << u;
 					}
-					if (hrank[u] <= hll_floor) hrank[u] = 0; // cannot raise any register
 					// all-service histogram of the window (GY_HISTOGRAM::add_data on the aggregate): one packed LDS add per event
-					atomicAdd(&s_gh[wave][resp_bucket((int64_t)tresp)], (1ull << 40) | (unsigned long long)tresp);
+					if (!(p.dbg & 8u)) atomicAdd(&s_gh[wave][resp_bucket((int64_t)tresp)], (1ull << 40) | (unsigned long long)tresp);
 					tmax = max(tmax, (int32_t)tresp);
+				}
+			}
+			if (!SPILL && rare) {
+#pragma unroll 1
+				for (uint32_t u = 0; u < 4u; ++u) {
+					if (!((rare >> u) & 1u)) continue;
+					const uint64_t i = t0 + tid + (uint64_t)((uint32_t)g + u) * T;
+					const uint64_t x0 = p.ev[3 * i], x1 = p.ev[3 * i + 1]; // (re-read: keeps the four events' words out of this loop's registers)
+					const uint32_t saddr = (uint32_t)x0, daddr = (uint32_t)(x0 >> 32);
+					const uint16_t sport = bswap16((uint16_t)(x1 >> 32)), dport = bswap16((uint16_t)(x1 >> 48));
+					const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
+					uint32_t idx, rank;
+					hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
+					if (SVCHLL) {
+						const uint32_t l = u == 0u ? nlr[0] : u == 1u ? nlr[1] : u == 2u ? nlr[2] : nlr[3];
+						svc_hll_update(p.svc_hll, p.svc_hll_p, s_slot[l], h64);
+					}
+					if (rank > hll_floor && p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
 				}
 			}
 			if (!SPILL) {
@@ -698,7 +722,17 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 			}
 #pragma unroll
 			for (int u = 0; u < 4; ++u)
-				if (wd[g + u] != GYS_EV_DROPPED) lr[g + u] |= atomicAdd(&s_tcnt[lr[g + u]], 1u) << 12;
+				if (nwd[u] != GYS_EV_DROPPED && !(p.dbg & 16u)) nlr[u] |= atomicAdd(&s_tcnt[nlr[u]], 1u) << 12;
+#pragma unroll
+			for (int j = 0; j + 4 < TPT; ++j) {
+				wd[j] = wd[j + 4];
+				lr[j] = lr[j + 4];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				wd[TPT - 4 + u] = nwd[u];
+				lr[TPT - 4 + u] = nlr[u];
+			}
 		}
 		__syncthreads();
 		// ---- exclusive scan of the tile's per-key counts -> run starts inside the image; every key's piece gets its destination
@@ -741,7 +775,7 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 		__syncthreads();
 #pragma unroll
 		for (int u = 0; u < TPT; ++u) {
-			if (wd[u] == GYS_EV_DROPPED) continue;
+			if (wd[u] == GYS_EV_DROPPED || (p.dbg & 2u)) continue;
 			const uint32_t local = lr[u] & 0xFFFu;
 			const uint32_t pos = s_tstart[local] + (lr[u] >> 12);
 			s_val[pos] = wd[u];
@@ -752,6 +786,7 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 			uint32_t ntile = 0; // kept events of the tile (every thread computes it from the wave sums)
 #pragma unroll
 			for (uint32_t w = 0; w < T / 64; ++w) ntile += s_wsum[w];
+			if (p.dbg & 3u) ntile = 0;
 			for (uint32_t e = tid; e < ntile; e += T) {
 				const uint32_t k = s_key[e];
 				const uint64_t base = s_base[k];
