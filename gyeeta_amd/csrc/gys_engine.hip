@@ -14,6 +14,7 @@
 #include <map>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "gys_kernels.hpp"
@@ -849,7 +850,7 @@ int walk_batch(const uint8_t *batch, uint32_t n, const uint8_t *pend, uint32_t f
 	const uint8_t *p = batch;
 	offs.clear();
 	offs.reserve(n);
-	for (uint32_t i = 0; i < n && p < pend; ++i) {
+	for (uint32_t i = 0; i < n && p < pend; ++i) { // the reference's loop shape (gy_mconnhdlr.cc:9130, :11175)
 		if ((size_t)(pend - p) < fixed) {
 			set_err("truncated record %u", i);
 			return GYS_ERR_INVAL;
@@ -1206,12 +1207,29 @@ int gys_register_host(gys_ctx *c, const uint8_t machine_id[16], const char *clus
 	return GYS_OK;
 }
 
-int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_listener_info *arr, uint32_t n, uint32_t *first_slot)
+int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_listener_info *arr_in, uint32_t n_in, uint32_t *first_slot)
 {
-	if (!c || !machine_id || (!arr && n)) return GYS_ERR_INVAL;
+	if (!c || !machine_id || (!arr_in && n_in)) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
 	if (rc) return rc;
+	// a partha resends NEW_LISTENER after a reconnect: a glob_id the engine already knows keeps its slot (and its histograms, digest,
+	// counters); repeats inside one call are dropped as well, so that the device tables never see the same key twice
+	std::vector<gys_listener_info> fresh;
+	const gys_listener_info *arr = arr_in;
+	uint32_t n = n_in;
+	{
+		std::unordered_set<uint64_t> seen;
+		bool dup = false;
+		for (uint32_t i = 0; i < n_in && !dup; ++i) dup = c->gid_map_h.count(arr_in[i].glob_id) != 0 || !seen.insert(arr_in[i].glob_id).second;
+		if (dup) {
+			seen.clear();
+			for (uint32_t i = 0; i < n_in; ++i)
+				if (!c->gid_map_h.count(arr_in[i].glob_id) && seen.insert(arr_in[i].glob_id).second) fresh.push_back(arr_in[i]);
+			arr = fresh.data();
+			n = (uint32_t)fresh.size();
+		}
+	}
 	if ((uint64_t)c->nsvc + n > c->cfg.max_services) {
 		set_err("max_services exhausted");
 		return GYS_ERR_NOMEM;
@@ -1456,12 +1474,15 @@ int gys_ingest_comm_stream(gys_ctx *c, const uint8_t machine_id[16], const void 
 		memcpy(&padding_sz, p + 12, 4);
 		// COMM_HEADER::validate common/gy_comm_proto.cc:12-22
 		if (!(magic == PM_HDR_MAGIC && total_sz < MAX_COMM_DATA_SZ_T && total_sz >= 16 && padding_sz < 8 && data_type > COMM_MIN_TYPE_T &&
-		      data_type < COMM_MAX_TYPE_T) || (total_sz & 7u) || total_sz > (uint64_t)(pend - p)) {
+		      data_type < COMM_MAX_TYPE_T) || (total_sz & 7u)) {
 			st.nmsgs_invalid++;
 			if (out) *out = st;
 			set_err("invalid COMM_HEADER at byte %zu", (size_t)(p - (const uint8_t *)buf));
 			return GYS_ERR_INVAL; // the reference terminates the connection
 		}
+		// a well-formed header whose body has not arrived yet (a recv() chunk ends inside the message): end of input, the whole
+		// messages before it are ingested and bytes_consumed tells the caller where to resume (gysketch.h)
+		if (total_sz > (uint64_t)(pend - p)) break;
 		st.nmsgs++;
 		const uint32_t act = total_sz - padding_sz;
 		bool taken = false;

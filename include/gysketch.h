@@ -114,7 +114,9 @@ typedef struct {
 	char comm[16];      /* TASK_COMM_LEN process name (LISTEN_TOPN::comm_) */
 } gys_listener_info;
 
-/* assigns consecutive service slots [*first_slot, *first_slot + n) */
+/* assigns consecutive service slots [*first_slot, *first_slot + n) to the listeners the engine does not know yet.  A glob_id that is
+ * already registered (a partha resends its listeners after a reconnect) keeps its slot and all of its state, and repeats inside one call
+ * are dropped: with such entries fewer than n slots are assigned (gys_lookup_service gives any listener's slot). */
 int gys_register_listeners(gys_ctx *ctx, const uint8_t machine_id[16], const gys_listener_info *arr, uint32_t n, uint32_t *first_slot);
 
 /* -------------------------------------------------------------------------------------------------------------------
@@ -137,7 +139,10 @@ int gys_ingest_resp_events_dev(gys_ctx *ctx, const gys_resp_seg *segs, uint32_t 
 
 /* Replaces MCONN_HANDLER::partha_tcp_conn_info(partha, TCP_CONN_NOTIFY *pone, int nconns, uint8_t *pendptr, ...)
  * (server/gy_mconnhdlr.h:2091, .cc:9052-9444): flow key PAIR_IP_PORT(nat_cli_, nat_ser_) (.cc:8707) -> distinct-flow HLL;
- * per-service connection / byte counters (connlistenmap_ roll-up .cc:9133-9319) -> exact per-service counters + CMS. */
+ * per-service connection / byte counters (connlistenmap_ roll-up .cc:9133-9319) -> exact per-service counters + CMS.
+ * nconns is an UPPER BOUND, exactly as in the reference's L2 loop `for (i < nconns && p < pendptr)` (.cc:9130, :11175): records that
+ * do not fit before `pend` are not an error here (L1 already validated the message); the wire front end gys_ingest_comm_stream
+ * applies the L1 validators' own rule (every announced record must be present, common/gy_comm_proto.cc:880, :995). */
 int gys_ingest_tcp_conn(gys_ctx *ctx, const uint8_t machine_id[16], const void *batch, uint32_t nconns, const void *pend);
 /* device-resident: d_offsets[i] = byte offset of record i inside d_batch (records are variable stride: get_elem_size()) */
 int gys_ingest_tcp_conn_dev(gys_ctx *ctx, const void *d_batch, const uint32_t *d_offsets, uint32_t nconns);
@@ -225,7 +230,10 @@ typedef struct {
 
 int gys_query_svcsumm(gys_ctx *ctx, const uint8_t machine_id[16], gys_svcsumm *out);      /* web_curr_listener_summ, gy_mnodehandle.cc:1628 */
 int gys_query_clusterstate(gys_ctx *ctx, const char *cluster_name, gys_cluster_state *out); /* aggregate_cluster_state result */
-/* GY_HISTOGRAM::get_percentiles (common/gy_statistics.h:707-791) of one service; which: 0 = current window, 1 = all-time */
+/* GY_HISTOGRAM::get_percentiles (common/gy_statistics.h:707-791) of one service; which: 0 = current (open) window, 1 = all-time.
+ * "All-time" is every response ingested so far INCLUDING the open window, in both record modes (t-digest on: lazily folded records;
+ * off: per-event records, window added at the boundary) -- the same answer mid-window whichever mode runs (tests/test_gpu_resp.py).
+ * The same `which` applies to gys_scan_percentiles_dev and gys_export_hist. */
 int gys_query_hist_percentiles(gys_ctx *ctx, uint64_t glob_id, int which, gys_hist_data *pdata, uint32_t npct, uint64_t *total_count,
 			       int64_t *max_val, float *pavg);
 /* t-digest quantiles (q in [0,1]) of one service's response times: computed from the merged view (clusters re-clustered with the

@@ -45,12 +45,43 @@ def _register_bulk(eng, nhosts, svcs):
 
 
 # ---------------------------------------------------------------------------------------------------------------- C3
-def test_c3_full_size_properties(torch_mod):
+def test_c3_full_size_properties(torch_mod, oracle):
     torch = torch_mod
     nh, sp, n = 10_000, 1_000, 1 << 26
     nsvc = nh * sp
     eng = _engine(max_hosts=nh, max_services=nsvc, max_batch_events=n)
     _register_bulk(eng, nh, sp)
+    # bit-exact slice inside the full-size engine: the oracle is fed the whole segments of 50 hosts (the first and the last 25 host
+    # slots = 50 000 of the 10^7 keys) of every batch the engine ingests, cut out of the very same bytes
+    SLICE = list(range(25)) + list(range(nh - 25, nh))
+    orc = oracle.OracleEngine(len(SLICE) * sp)
+    for j, h in enumerate(SLICE):
+        s = np.arange(sp)
+        g, ns, pt = wire.glob_id(np.full(sp, h), s), wire.listener_netns(h, s), wire.listener_port(s)
+        for i in range(sp):
+            orc.register(j, int(g[i]), int(ns[i]), int(pt[i]))
+
+    def oracle_feed(ev_dev, sg, nev):
+        for j, h in enumerate(SLICE):
+            idx = next((k for k, x in enumerate(sg) if x.host_slot == h), None)
+            if idx is None:
+                continue
+            lo = sg[idx].first_event
+            hi = sg[idx + 1].first_event if idx + 1 < len(sg) else nev
+            orc.resp_batch(ev_dev[lo * 24:hi * 24].cpu().numpy().tobytes(), [j], [0])
+
+    def slice_compare(window_open):
+        for part, first in ((0, 0), (1, nsvc - 25 * sp)):
+            k0, k1 = part * 25 * sp, (part + 1) * 25 * sp
+            helpers.assert_hist_equal(eng.export_hist(1, first, 25 * sp), orc.hist()[k0:k1], 25 * sp)
+            if window_open:
+                assert (eng.export_conn_bitmap(first, 25 * sp) == orc.bitmap()[k0:k1]).all()
+            gs, gc, gm = eng.export_tdigest(first, 25 * sp)
+            os_, oc, om = orc.td_arrays()
+            assert (gc == oc[k0:k1]).all() and (gs == os_[k0:k1]).all() and (gm == om[k0:k1]).all()
+            gn, gp = eng.export_tdigest_pending(first, 25 * sp)
+            on, op = orc.td_pending()
+            assert (gn == on[k0:k1]).all() and (gp == op[k0:k1]).all()
     bufs, segs = [], []
     for b in range(2):
         ev = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
@@ -61,7 +92,10 @@ def test_c3_full_size_properties(torch_mod):
     def window(batches):
         for b in batches:
             eng.handle_resp_events_dev(segs[b], bufs[b].data_ptr(), n)
+            oracle_feed(bufs[b], segs[b], n)
+        slice_compare(True)
         eng.window_close()
+        orc.window_clear(clear_hist=False)  # the oracle's record is the cumulative one: compared with the engine's all-time view
         gh = eng.export_global_hist()
         return (eng.export_hll().copy(), eng.export_cms(0).copy(), np.array([[gh.stats[i].count, gh.stats[i].sum] for i in range(15)], dtype=np.int64),
                 gh.total_count, gh.max_val_seen)
@@ -131,6 +165,22 @@ def test_c3_full_size_properties(torch_mod):
     assert q1[0] <= q1[1] <= q1[2]
     # window view after the last close is empty for every key; all-time view is unchanged by the close
     assert eng.export_hist(0, 5_000_000, 1000)[:, :15].sum() == 0
+    slice_compare(False)
+    # ---- the slice again after its keys have re-clustered inside the 10^7-key engine: 24 batches aimed at the first 25 hosts
+    # (~42 values per key and batch: every key crosses the 768-value buffer once, i.e. 25 000 merges of steady-state size), two windows
+    nb = 1 << 20
+    for r in range(24):
+        sg = eng.gen_resp_events(bufs[0].data_ptr(), nb, 0xC300 + r, 0, 25, sp)
+        eng.handle_resp_events_dev(sg, bufs[0].data_ptr(), nb)
+        eng.sync()
+        oracle_feed(bufs[0], sg, nb)
+        if r == 11:
+            eng.window_close()
+            orc.window_clear(clear_hist=False)
+    assert eng.counters()["td_merges"] >= 25 * sp
+    slice_compare(True)
+    g = int(wire.glob_id(3, 77))
+    assert eng.quantiles(g, [0.25, 0.5, 0.99]) == [oracle.lib().gyo_tdb_quantile(C.byref(orc.td(3 * sp + 77)), q) for q in (0.25, 0.5, 0.99)]
     eng.close()
 
 

@@ -1,0 +1,221 @@
+"""Round-2 parity additions (VERDICT r1 "what's weak" 2-4):
+  * per-service distinct-client HLL (svc_hll_p) against an oracle built from the reference's own flow-key bytes;
+  * the all-time view mid-window in both record modes (lazily folded records / per-event records);
+  * re-registration of a known glob_id keeps the slot and its state;
+  * the window exchange driven through the ENGINE with nranks = 2 (two processes on one GPU, gloo all-reduce of the four register
+    sections): reduced registers, Count-Min, all-service histogram and gys_query_clusterstate equal the single-rank run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from gyeeta_amd import wire
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: -m gpu tests must run on the MI355X box")
+    return torch
+
+
+def _engine(**kw):
+    from gyeeta_amd.engine import SketchEngine
+    return SketchEngine(**kw)
+
+
+def _flow_words(ev):
+    """the bytes PAIR_IP_PORT(cli = daddr:dport, ser = saddr:sport).get_hash() hashes (common/gy_inet_inc.h:225-247) as u32 words:
+    an IPv4 address is 1 word when ip32_be != 0, else the 16 zero bytes of ip128_be (GY_IP_ADDR::get_as_inaddr)"""
+    out = []
+    for daddr, dport, saddr, sport in zip(ev["daddr"].tolist(), ev["dport_be"].tolist(), ev["saddr"].tolist(), ev["sport_be"].tolist()):
+        w = ([daddr] if daddr else [0, 0, 0, 0]) + [dport] + ([saddr] if saddr else [0, 0, 0, 0]) + [sport]
+        out.append(np.array(w, dtype=np.uint32))
+    return out
+
+
+@pytest.mark.parametrize("resp_path", [1, 2], ids=["general", "hostlocal"])
+def test_svc_hll_registers_bit_exact(torch_mod, oracle, resp_path):
+    rng = np.random.default_rng(21)
+    nh, sp, P = 2, 5, 8
+    eng = _engine(max_hosts=4, max_services=32, max_batch_events=1 << 16, svc_hll_p=P, resp_path=resp_path)
+    orc = oracle.OracleEngine(32)
+    info, gids = helpers.register_world(eng, orc, range(nh), sp)
+    regs = np.zeros((nh * sp, 1 << P), dtype=np.uint8)
+    L = oracle.lib()
+    for rnd in range(3):
+        for h in range(nh):
+            ev = helpers.make_resp_events(rng, h, 2500, sp, zero_ip_frac=0.05)
+            eng.handle_resp_events(info[h][0], ev)
+            orc.resp_batch(ev.tobytes(), [info[h][1]], [0])
+            lat = (ev["lsndtime"] - ev["lrcvtime"]).astype(np.uint32)
+            svc = ev["sport_be"].astype(np.int64) - 1024
+            keep = (lat <= 1000000) & (svc >= 0) & (svc < sp)
+            for w, s, k in zip(_flow_words(ev), svc.tolist(), keep.tolist()):
+                if k:
+                    slot = eng.lookup(int(gids[h][s]))
+                    L.gyo_hll_add_words(oracle.ptr(regs[slot], oracle.u8p), P, oracle.ptr(w, oracle.u32p), len(w))
+    eng.sync()
+    got = eng.export_svc_hll(0, nh * sp)
+    assert (got == regs).all(), f"per-service HLL registers differ at {np.argwhere(got != regs)[:4].tolist()}"
+    assert (eng.export_hll() == orc.hll()).all()  # the global registers come out of the same hash
+    eng.window_close()
+    assert eng.export_svc_hll(0, nh * sp).sum() == 0  # per-window registers
+    eng.close()
+
+
+@pytest.mark.parametrize("td", [True, False], ids=["lazy_records", "per_event_records"])
+def test_alltime_view_includes_open_window_in_both_modes(torch_mod, oracle, td):
+    """which = 1 answers "everything ingested so far" mid-window whichever record mode runs (gysketch.h)"""
+    rng = np.random.default_rng(23)
+    eng = _engine(max_hosts=2, max_services=8, max_batch_events=1 << 14, enable_tdigest=td)
+    cum = oracle.OracleEngine(8, enable_td=False)   # never cleared: the all-time truth
+    win = oracle.OracleEngine(8, enable_td=False)   # cleared at every boundary: the open window
+    info, gids = helpers.register_world(eng, cum, range(1), 3)
+    helpers.register_world(None, win, range(1), 3)
+    for w in range(3):
+        for b in range(2):
+            ev = helpers.make_resp_events(rng, 0, 1500 + 400 * b, 3)
+            eng.handle_resp_events(info[0][0], ev)
+            cum.resp_batch(ev.tobytes(), [0], [0])
+            win.resp_batch(ev.tobytes(), [0], [0])
+            # mid-window: window view = this window's events, all-time view = every event so far
+            helpers.assert_hist_equal(eng.export_hist(0, 0, 3), win.hist(), 3)
+            helpers.assert_hist_equal(eng.export_hist(1, 0, 3), cum.hist(), 3)
+            g = int(gids[0][1])
+            vals, sums, counts, tot, mx, avg = eng.hist_percentiles(g, [50.0, 99.0], which=1)
+            h = cum.hist()[1]
+            ov, os_, ocn, oavg = oracle.hist_percentiles(0, h[:15], h[15][0], [50.0, 99.0])
+            assert vals == ov and counts == ocn and tot == h[15][0]
+        eng.window_close()
+        win.window_clear(clear_hist=True)
+        helpers.assert_hist_equal(eng.export_hist(1, 0, 3), cum.hist(), 3)
+    eng.close()
+
+
+def test_reregistration_keeps_slot_and_state(torch_mod, oracle):
+    rng = np.random.default_rng(24)
+    eng = _engine(max_hosts=2, max_services=16, max_batch_events=1 << 14)
+    orc = oracle.OracleEngine(16)
+    info, gids = helpers.register_world(eng, orc, range(1), 4)
+    mid = info[0][0]
+    ev = helpers.make_resp_events(rng, 0, 3000, 4)
+    eng.handle_resp_events(mid, ev)
+    orc.resp_batch(ev.tobytes(), [0], [0])
+    before = eng.num_services()
+    s = np.arange(6)  # the partha reconnects and resends its 4 listeners plus two new ones, one of them twice
+    g = wire.glob_id(np.full(6, 0), s)
+    g[5] = g[4]
+    first = eng.register_listeners_np(mid, g, wire.listener_netns(0, s), wire.listener_port(s))
+    assert first == before and eng.num_services() == before + 1
+    for i in range(4):
+        assert eng.lookup(int(gids[0][i])) == i
+    orc.register(0, int(g[4]), int(wire.listener_netns(0, s)[4]), int(wire.listener_port(s)[4]))
+    ev = helpers.make_resp_events(rng, 0, 3000, 5)
+    eng.handle_resp_events(mid, ev)
+    orc.resp_batch(ev.tobytes(), [0], [0])
+    eng.sync()
+    helpers.assert_hist_equal(eng.export_hist(0, 0, 5), orc.hist(), 5)
+    gs, gc, gm = eng.export_tdigest(0, 5)
+    os_, oc, om = orc.td_arrays()
+    assert (gs == os_[:5]).all() and (gc == oc[:5]).all()
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ nranks = 2 through the engine
+NH, SP, NEV = 10, 6, 4000
+CLUSTERS = ["east", "west", "north"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _feed(eng, hosts, rank_of=None):
+    """registers `hosts` and feeds every ingest path; identical bytes whatever the sharding (per-host seeds)"""
+    for c in CLUSTERS:  # same cluster order on every rank (gysketch.h)
+        eng.register_cluster(c)
+    for h in hosts:
+        mid = wire.machine_id(h)
+        eng.register_host(mid, CLUSTERS[h % 3])
+        s = np.arange(SP)
+        eng.register_listeners_np(mid, wire.glob_id(np.full(SP, h), s), wire.listener_netns(h, s), wire.listener_port(s))
+    for h in hosts:
+        rng = np.random.default_rng(1000 + h)
+        mid = wire.machine_id(h)
+        eng.handle_resp_events(mid, helpers.make_resp_events(rng, h, NEV, SP))
+        rec = wire.synth_tcp_conns(rng, 300, [h], SP, dup_frac=0.1)
+        eng.partha_tcp_conn_info(mid, wire.pack_variable(rec, [b""] * 300), 300)
+        ls = wire.synth_listener_states(rng, h, np.arange(SP))
+        eng.partha_listener_state(mid, wire.pack_variable(ls, [b""] * len(ls)), len(ls))
+        eng.handle_host_state(mid, ntasks=50 + h, nlisten=SP, ntasks_issue=h % 2)
+
+
+def _observe(eng):
+    gh = eng.export_global_hist()
+    cl = tuple(eng.clusterstate(c).as_tuple() for c in CLUSTERS)
+    return (eng.export_hll().tobytes(), eng.export_cms(0).tobytes(), eng.export_cms(1).tobytes(),
+            tuple((gh.stats[i].count, gh.stats[i].sum) for i in range(15)) + ((gh.total_count, gh.max_val_seen),), cl,
+            round(eng.distinct_flows(), 6))
+
+
+def _rank_worker(rank, port, q):
+    import torch
+    import torch.distributed as dist
+    from gyeeta_amd import capi
+    from gyeeta_amd.engine import SketchEngine, mid_buf
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        L = capi.load()
+        mine = [h for h in range(NH) if L.gys_shard_of(mid_buf(wire.machine_id(h)), 2) == rank]
+        other = [h for h in range(NH) if h not in mine]
+        eng = SketchEngine(max_hosts=NH, max_services=NH * SP, max_clusters=4, max_batch_events=1 << 14, rank=rank, nranks=2, device=0)
+        _feed(eng, mine)
+        not_owner = False
+        try:  # a host of the other shard is refused (GYS_ERR_NOT_OWNER): its partha belongs to the other madhava
+            eng.register_host(wire.machine_id(other[0]), CLUSTERS[0])
+        except capi.GysError as e:
+            not_owner = e.code == capi.ERR_NOT_OWNER
+        eng.window_close(tusec=5_000_000)   # gys_window_prepare -> all-reduce of the 4 sections (gloo) -> gys_window_finish
+        obs = _observe(eng)
+        eng.close()
+        q.put((rank, obs, len(mine), not_owner))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_window_exchange_through_engine_world2(torch_mod):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = _engine(max_hosts=NH, max_services=NH * SP, max_clusters=4, max_batch_events=1 << 14)
+    _feed(single, range(NH))
+    single.window_close(tusec=5_000_000)
+    want = _observe(single)
+    single.close()
+    assert res[0][2] > 0 and res[1][2] > 0 and res[0][2] + res[1][2] == NH
+    assert res[0][3] and res[1][3], "registering a host of the other shard must fail with GYS_ERR_NOT_OWNER"
+    names = ["hll", "cms32", "cms64", "global histogram", "cluster state", "distinct flows"]
+    for r in range(2):
+        for name, got, exp in zip(names, res[r][1], want):
+            assert got == exp, f"rank {r}: {name} differs from the single-rank run"

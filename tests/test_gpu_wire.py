@@ -109,3 +109,39 @@ def test_comm_stream_rejects_malformed():
     st = eng.handle_comm_stream(mid, good)
     assert st.nrecords == n and eng.counters()["conn_events"] == before + n
     eng.close()
+
+
+def test_comm_stream_cut_inside_a_message_resumes():
+    """a recv() chunk that ends inside a message body (complete 16-byte COMM_HEADER, incomplete body): the whole messages before it are
+    ingested, bytes_consumed points at that header, and feeding the rest from there gives the same state as the uncut stream"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    rng = np.random.default_rng(18)
+    a, b = _world(), _world()
+    mid = wire.machine_id(1)
+    msgs = []
+    for n in (700, 5, 2048):
+        rec = wire.synth_tcp_conns(rng, n, [0, 1, 2], 12, dup_frac=0.1)
+        msgs.append(wire.frame_event_notify(wire.NOTIFY_TCP_CONN, n, wire.pack_variable(rec, _tails(rng, n, 128, 0.4))))
+    ls = wire.synth_listener_states(rng, 1, np.arange(12))
+    msgs.append(wire.frame_event_notify(wire.NOTIFY_LISTENER_STATE, len(ls), wire.pack_variable(ls, _tails(rng, len(ls), 100, 0.5))))
+    stream = b"".join(msgs)
+    whole = b.handle_comm_stream(mid, stream)
+    assert whole.bytes_consumed == len(stream) and whole.nrecords == 700 + 5 + 2048 + 12
+    # cut 40 bytes into the body of the third message (8-byte aligned chunk), then 3 bytes into the header of the fourth
+    cut1 = len(msgs[0]) + len(msgs[1]) + 16 + 40
+    st = a.handle_comm_stream(mid, stream[:cut1])
+    assert st.bytes_consumed == len(msgs[0]) + len(msgs[1]) and st.nrecords == 705 and st.nmsgs_invalid == 0
+    pos = st.bytes_consumed
+    cut2 = len(stream) - len(msgs[3]) + 3
+    st = a.handle_comm_stream(mid, stream[pos:cut2])
+    assert st.bytes_consumed == len(msgs[2]) and st.nrecords == 2048
+    pos += st.bytes_consumed
+    st = a.handle_comm_stream(mid, stream[pos:])
+    assert st.bytes_consumed == len(msgs[3]) and st.nrecords == 12
+    for e in (a, b):
+        e.window_close()
+    assert _state(a) == _state(b)
+    a.close()
+    b.close()
