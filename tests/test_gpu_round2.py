@@ -63,8 +63,8 @@ def test_svc_hll_registers_bit_exact(torch_mod, oracle, resp_path):
     eng.sync()
     got = eng.export_svc_hll(0, nh * sp)
     assert (got == regs).all(), f"per-service HLL registers differ at {np.argwhere(got != regs)[:4].tolist()}"
-    assert (eng.export_hll() == orc.hll()).all()  # the global registers come out of the same hash
     eng.window_close()
+    assert (eng.export_hll() == orc.hll()).all()  # the global registers (of the closed window) come out of the same hash
     assert eng.export_svc_hll(0, nh * sp).sum() == 0  # per-window registers
     eng.close()
 

@@ -9,17 +9,18 @@ import json
 import os
 import sys
 
-NAMES = {"k_resp_host": "resp_host", "k_key_finalize": "key_finalize", "k_fold": "fold", "k_digest_merge": "digest_merge",
+NAMES = {"k_resp_host": "resp_host", "k_key_finalize": "key_finalize", "k_fold": "fold", "k_digest_merge": "digest_merge", "k_digest_bins": "digest_merge",
+         "k_cms_partial": "window_prepare", "k_cms_reduce": "window_prepare",
          "k_digest_huge": "digest_huge", "k_resp_pass1": "resp_pass1", "k_resp_scatter": "scatter", "k_window_prepare": "window_prepare"}
 
 
 def short_name(kernel, k, short):
-    """the second (SPILL) pass of k_resp_host is its own stage: template arguments <TPT, SHARED, SPILL> end in `true>` / `1>`"""
+    """the second (SPILL) pass of k_resp_host is its own stage: template arguments <TPT, SHARED, SPILL, SVCHLL>"""
     if k == "k_resp_host":
         i = kernel.find("k_resp_host<")
         if i >= 0:
-            args = kernel[i:kernel.find(">", i)]
-            if args.rstrip().endswith(("true", " 1")):
+            args = [a.strip() for a in kernel[i + len("k_resp_host<"):kernel.find(">", i)].split(",")]
+            if len(args) >= 3 and args[2] in ("true", "1"):
                 return "resp_spill"
     return short
 
