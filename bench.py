@@ -331,6 +331,17 @@ def main():
         for b in range(nbuf):
             ingested.append([args.events, 0x67796565746121 + 1000 * rank + b, args.zipf_milli, buf_uses[b]])
         qerr = quantile_error(eng, torch, ingested, nlocal, args.svcs, [mine[0], mine[-1]], [0, nlocal - 1], wire)
+    scan = None
+    if rank == 0 and nsvc and not args.no_quantile_check:  # the per-key scan on the digests (a9): p25 / p95 / p99 of EVERY service, one pass
+        eng.profile(True)
+        eng.profile_reset()
+        t0 = time.perf_counter()
+        qv = eng.scan_quantiles([0.25, 0.95, 0.99])
+        t_scan = time.perf_counter() - t0
+        sp_ = eng.profile_get().get("scan_quantiles", (0.0, 0))
+        eng.profile(False)
+        scan = {"services": nsvc, "quantiles": [0.25, 0.95, 0.99], "kernel_ms": sp_[0], "wall_ms_incl_copy_to_host": t_scan * 1e3,
+                "services_per_s": nsvc / (sp_[0] * 1e-3) if sp_[0] > 0 else None, "p99_mean_ms": float(qv[:, 2].mean())}
     host_fed = None
     if rank == 0 and world == 1 and not args.no_host_fed and nsvc:
         host_fed = host_fed_rate(eng, torch, min(args.events, 1 << 26), nlocal, args.svcs)
@@ -393,6 +404,8 @@ def main():
             out["quantile_error"] = qerr
         if host_fed is not None:
             out["host_fed"] = host_fed
+        if scan is not None:
+            out["quantile_scan"] = scan
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N = 1 only
             full, honly, desc, ref_rate, port_mt = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234)
             out["cpu_baseline"] = {"value": full, "unit": "events/s", "cores": 1, "kind": "port", "sample": desc,

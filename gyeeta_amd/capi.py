@@ -132,6 +132,7 @@ SIGNATURES = {
     "gys_query_cms": (C.c_int, [vp, C.c_uint64, C.c_int, u64p]),
     "gys_query_topn": (C.c_int, [vp, mid, C.c_int, C.POINTER(TopnEntry), u32p]),
     "gys_scan_percentiles_dev": (C.c_int, [vp, C.c_int, f32p, C.c_uint32, vp]),
+    "gys_scan_quantiles_dev": (C.c_int, [vp, f64p, C.c_uint32, vp]),
     "gys_tdigest_sql_text": (C.c_int, [vp, C.c_uint64, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_tdigest_sql_binary": (C.c_int, [vp, C.c_uint64, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_query_hist_level_stats": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(TimeHistVal), C.c_uint32, i64p, i64p, f64p]),

@@ -728,7 +728,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 				bp.count = c->merge_count + FIN_CLASS0;
 				bp.slow_list = c->merge_list_slow;
 				bp.slow_count = c->merge_count + FIN_SLOW;
-				hipLaunchKernelGGL(k_digest_bins, dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 8))), dim3(256), 0, c->stream, bp);
+				hipLaunchKernelGGL(k_digest_bins<false>, dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 8))), dim3(256), 0, c->stream, bp);
 				mp.list = c->merge_list_slow; // entries whose total weight needs 64-bit arithmetic (normally none)
 				mp.count = c->merge_count + FIN_SLOW;
 				hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
@@ -2033,6 +2033,47 @@ int gys_scan_percentiles_dev(gys_ctx *c, int which, const float *pcts, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ exports
+int gys_scan_quantiles_dev(gys_ctx *c, const double *q, uint32_t nq, double *d_out)
+{
+	if (!c || !q || !d_out || nq == 0 || nq > 16) return GYS_ERR_INVAL;
+	TDIGEST_CHECK();
+	if (!c->nsvc) return GYS_OK;
+	double *d_q = nullptr;
+	HIPCHK(hipMalloc((void **)&d_q, sizeof(double) * nq));
+	HIPCHK(hipMemcpyAsync(d_q, q, sizeof(double) * nq, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(c->merge_count + FIN_SLOW, 0, 4, c->stream));
+	MergeBP bp{};
+	bp.d = digest_params(c);
+	bp.slow_list = c->merge_list_slow;
+	bp.slow_count = c->merge_count + FIN_SLOW;
+	bp.qs = d_q;
+	bp.nq = nq;
+	bp.qout = d_out;
+	{
+		ProfScope ps(c, "scan_quantiles");
+		hipLaunchKernelGGL(k_digest_bins<true>, dim3(std::max(1u, std::min<uint32_t>(c->nsvc, (uint32_t)c->ncu * 8))), dim3(256), 0, c->stream, bp);
+	}
+	uint32_t nslow = 0;
+	HIPCHK(hipMemcpyAsync(&nslow, c->merge_count + FIN_SLOW, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipFree(d_q));
+	if (nslow) { // services whose digest weighs 2^31 or more (64-bit weights): one at a time through the general merge
+		std::vector<MergeEnt> slow(nslow);
+		HIPCHK(hipMemcpy(slow.data(), c->merge_list_slow, sizeof(MergeEnt) * nslow, hipMemcpyDeviceToHost));
+		std::vector<double> out(nq);
+		for (const MergeEnt &e : slow) {
+			int64_t sum[GYS_TD_NB];
+			uint32_t cnt[GYS_TD_NB];
+			int32_t vmin, vmax;
+			const int rc = td_merged_view(c, e.slot, sum, cnt, &vmin, &vmax);
+			if (rc) return rc;
+			for (uint32_t i = 0; i < nq; ++i) out[i] = td_quantile_host(sum, cnt, vmin, vmax, q[i]);
+			HIPCHK(hipMemcpy(d_out + (size_t)e.slot * nq, out.data(), sizeof(double) * nq, hipMemcpyHostToDevice));
+		}
+	}
+	return GYS_OK;
+}
+
 uint32_t gys_num_services(gys_ctx *c) { return c ? c->nsvc : 0; }
 uint32_t gys_num_hosts(gys_ctx *c) { return c ? (uint32_t)c->hosts.size() : 0; }
 

@@ -1375,8 +1375,50 @@ struct MergeBP {
 	uint32_t *out_cnt;
 	MergeEnt *slow_list;
 	uint32_t *slow_count;
+	// SCAN: every service [0, nsvc) instead of a list; nothing is modified; quantile i of the service's merged view goes to
+	// qout[slot * nq + i] (TCP_SOCK_HANDLER::listener_stats_update produces p25 / p95 / p99 for EVERY listener every 5 s,
+	// common/gy_socket_stat.cc:4044-4365: the per-key scan, here on the digests)
+	const double *qs;
+	uint32_t nq;
+	double *qout;
 };
 
+// quantile of compacted clusters (c_cnt / c_sum / c_wb = weight before, nc of them, N in total): the host's td_quantile_interp
+// (gys_engine.hip) and the oracle's (oracle/gy_oracle.c:669-715) term by term -- only + - * / on doubles, so the three agree bit for bit
+__device__ __forceinline__ double td_quantile_dev(const uint32_t *c_cnt, const unsigned long long *c_sum, const uint32_t *c_wb, uint32_t nc, uint32_t N,
+						  int32_t vmin, int32_t vmax, double q)
+{
+	if (!N) return 0.0;
+	if (q < 0.0) q = 0.0;
+	if (q > 1.0) q = 1.0;
+	const double t = q * (double)N;
+	uint32_t lo = 0, hi = nc; // first cluster whose centre lies above t
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (t < (double)c_wb[mid] + (double)c_cnt[mid] * 0.5) hi = mid; else lo = mid + 1;
+	}
+	double res;
+	if (lo < nc) {
+		const double mean = (double)(int64_t)c_sum[lo] / (double)c_cnt[lo];
+		const double c = (double)c_wb[lo] + (double)c_cnt[lo] * 0.5;
+		if (lo == 0) {
+			const double l = (double)vmin;
+			res = c <= 0.0 ? mean : l + (mean - l) * (t / c);
+		} else {
+			const double pm = (double)(int64_t)c_sum[lo - 1] / (double)c_cnt[lo - 1];
+			const double pc = (double)c_wb[lo - 1] + (double)c_cnt[lo - 1] * 0.5;
+			res = pm + (mean - pm) * ((t - pc) / (c - pc));
+		}
+	} else {
+		const double pm = (double)(int64_t)c_sum[nc - 1] / (double)c_cnt[nc - 1];
+		const double pc = (double)c_wb[nc - 1] + (double)c_cnt[nc - 1] * 0.5;
+		const double h = (double)vmax, span = (double)N - pc;
+		res = span <= 0.0 ? h : pm + (h - pm) * ((t - pc) / span);
+	}
+	return floor(res + 0.5); // integer-millisecond value domain
+}
+
+template <bool SCAN>
 __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 {
 	const DigestP &p = q.d;
@@ -1392,8 +1434,8 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 	__shared__ int32_t s_fmm[3];
 	__shared__ uint32_t s_wv[4], s_ws[4], s_nbig;
 	__shared__ uint64_t s_ww[4];
-	const uint32_t nent = *q.count;
-	const bool query = q.out_sum != nullptr;
+	const uint32_t nent = SCAN ? p.nsvc : *q.count;
+	const bool query = SCAN || q.out_sum != nullptr;
 	// RESP_TIME_HASH bucket of the thread's first bin and the first of its 8 bins that lies in the next bucket (8 = none): the
 	// thresholds are at least 9 apart, so 8 consecutive values touch at most two buckets
 	uint32_t bk_first = 0, bk_chg = GYS_MB_BPT;
@@ -1409,12 +1451,15 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		uint32_t tid = threadIdx.x;
 		asm volatile("" : "+v"(tid));
 		const uint32_t lane = tid & 63u, wave = tid >> 6;
-		const MergeEnt ent = q.list[w];
+		MergeEnt ent;
+		if (SCAN) ent = MergeEnt{w, min(p.td_meta[w].npend, (uint32_t)GYS_TD_PEND_CAP), 0u, 0u}; // between batches a buffer holds at most PEND_CAP values
+		else ent = q.list[w];
 		const uint32_t m = ent.nbuf + ent.mrun;
 		if (m > GYS_MERGE_CLASS0) continue; // never queued on this list (finalize_key)
 		const uint32_t slot = ent.slot;
 		const uint4 mt = *(const uint4 *)&p.td_meta[slot];
 		const uint32_t nh = query ? m : (mt.y & 0xFFFFu), nw = mt.y >> 16;
+		const uint32_t nh_mm = SCAN ? (mt.y & 0xFFFFu) : nh; // SCAN: min / max of the not yet folded words are not in td_minmax yet
 		const uint32_t nwin0 = max(nh, nw);
 		const uint32_t run0 = ent.off_end - ent.mrun;
 		// ---- loads: cluster tid, values tid + 256 k
@@ -1434,7 +1479,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 				if (i < m) wd[k] = i < ent.nbuf ? pend[i] : p.staged[run0 + (i - ent.nbuf)];
 			}
 		}
-		if (m == 0) { // nothing buffered (query of a freshly merged key): the merged view is the digest itself
+		if (m == 0 && !SCAN) { // nothing buffered (query of a freshly merged key): the merged view is the digest itself
 			if (query && tid < GYS_TD_NB) {
 				q.out_sum[(size_t)w * GYS_TD_NB + tid] = sm0;
 				q.out_cnt[(size_t)w * GYS_TD_NB + tid] = c0;
@@ -1486,6 +1531,13 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			__syncthreads();
 			continue;
 		}
+		if (SCAN && m == 0) { // the merged view is the digest itself: straight to the quantiles
+			if (tid < GYS_TD_NB) {
+				s_osum[tid] = (unsigned long long)sm0;
+				s_ocnt[tid] = c0;
+			}
+			__syncthreads();
+		} else {
 		const uint32_t pos0 = pbase + (uint32_t)__popcll(b0 & (lane ? (~0ull >> (64 - lane)) : 0ull));
 		const uint32_t e0 = (uint32_t)(wbase + inc - c0), nold = (uint32_t)nold64;
 		const uint32_t twoN = 2u * (nold + m);
@@ -1511,6 +1563,10 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			pos[k] = atomicAdd(&s_bin[mb_bin(uv)], 1u) & 0xFFFFu;
 			const bool big = uv >= GYS_MB_EXACT;
 			if (big) s_big[atomicAdd(&s_nbig, 1u)] = (i << 20) | uv;
+			if (SCAN && i >= nh_mm) {
+				lmin = min(lmin, (int32_t)uv);
+				lmax = max(lmax, (int32_t)uv);
+			}
 			if (i >= nh) { // not yet folded: histogram bucket of the key's records, CONN_BITMAP row, min / max
 				lmin = min(lmin, (int32_t)uv);
 				lmax = max(lmax, (int32_t)uv);
@@ -1528,7 +1584,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 				}
 			}
 		}
-		if (!query && m > nh) {
+		if ((!query && m > nh) || (SCAN && m > nh_mm)) {
 #pragma unroll
 			for (int d = 32; d >= 1; d >>= 1) {
 				lmin = min(lmin, __shfl_xor(lmin, d, 64));
@@ -1641,6 +1697,45 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			atomicAdd(&s_ocnt[a], 1u);
 		}
 		__syncthreads();
+		} // (SCAN && m == 0)
+		if (SCAN) {
+			// ---- quantiles of the merged view: compact the non-empty clusters (order preserving), weight before each, one thread per quantile
+			const uint32_t oc = tid < GYS_TD_NB ? s_ocnt[tid] : 0u;
+			const unsigned long long os = tid < GYS_TD_NB ? s_osum[tid] : 0ull;
+			const unsigned long long ob = __ballot(oc != 0);
+			uint32_t sc = oc;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t t = __shfl_up(sc, d, 64);
+				if ((int)lane >= d) sc += t;
+			}
+			if (lane == 63u) s_ws[wave] = sc;
+			if (lane == 0u) s_wv[wave] = (uint32_t)__popcll(ob);
+			__syncthreads();
+			uint32_t pb = 0, wb = 0, ncq = 0, Nq = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; ++k) {
+				if (k < wave) {
+					pb += s_wv[k];
+					wb += s_ws[k];
+				}
+				ncq += s_wv[k];
+				Nq += s_ws[k];
+			}
+			if (oc) {
+				const uint32_t pos = pb + (uint32_t)__popcll(ob & (lane ? (~0ull >> (64 - lane)) : 0ull));
+				s_thr[pos] = oc;                  // compacted counts
+				s_cpfx[pos] = wb + sc - oc;       // weight before
+				s_osum[pos] = os;                 // (pos <= tid: every thread read its own entry before the barrier above)
+			}
+			__syncthreads();
+			if (tid < q.nq) {
+				const int2 mm = p.td_minmax[slot];
+				q.qout[(size_t)slot * q.nq + tid] = td_quantile_dev(s_thr, s_osum, s_cpfx, ncq, Nq, min(mm.x, s_fmm[0]), max(mm.y, s_fmm[1]), q.qs[tid]);
+			}
+			__syncthreads();
+			continue;
+		}
 		// ---- write back
 		if (tid < GYS_TD_NB) {
 			int64_t *ws = query ? q.out_sum + (size_t)w * GYS_TD_NB : p.td_sum + (size_t)slot * GYS_TD_NB;

@@ -206,6 +206,15 @@ class SketchEngine:
         capi.check(self.L.gys_query_clusterstate(self.h, name.encode(), C.byref(out)))
         return out
 
+    def scan_quantiles(self, qs):
+        """t-digest quantiles of EVERY service in one device pass: [nsvc][len(qs)] float64 (gys_scan_quantiles_dev)"""
+        n = self.num_services()
+        out = self.torch.empty((max(n, 1), len(qs)), dtype=self.torch.float64, device=self.device)
+        qa = (C.c_double * len(qs))(*qs)
+        self.order()
+        capi.check(self.L.gys_scan_quantiles_dev(self.h, qa, len(qs), C.c_void_p(out.data_ptr())))
+        return out[:n].cpu().numpy()
+
     def hist_percentiles(self, glob_id, pcts, which=1):
         pd = (capi.HistData * len(pcts))()
         for i, p in enumerate(pcts):

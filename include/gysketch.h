@@ -256,6 +256,11 @@ int gys_query_topn(gys_ctx *ctx, const uint8_t machine_id[16], int kind, gys_top
 /* The "per-key scan" (TCP_SOCK_HANDLER::listener_stats_update percentile part, common/gy_socket_stat.cc:4226-4230) over ALL services
  * on the GPU: for service slot s and percentile i, d_out[s*npct + i] = bucket ceiling; which as above.  d_out is a DEVICE pointer. */
 int gys_scan_percentiles_dev(gys_ctx *ctx, int which, const float *pcts, uint32_t npct, int64_t *d_out);
+/* the same scan on the t-digests: quantile q[i] (0..1, nq <= 16) of EVERY service's merged view (clusters re-clustered with the buffered
+ * values; no state is modified), d_out[slot * nq + i] on the device -- identical, value for value, to gys_query_quantiles of that service.
+ * Replaces the per-listener p25 / p95 / p99 search of TCP_SOCK_HANDLER::listener_stats_update (common/gy_socket_stat.cc:4044-4365,
+ * percentile calls :4226-4230) for all listeners at once.  q is a HOST array, d_out a DEVICE pointer to nsvc * nq doubles. */
+int gys_scan_quantiles_dev(gys_ctx *ctx, const double *q, uint32_t nq, double *d_out);
 
 /* -------------------------------------------------------------------------------------------------------------------
  * a service's response-time t-digest in the external forms of the Postgres tdigest type, so that the reference's SQL

@@ -219,3 +219,49 @@ def test_window_exchange_through_engine_world2(torch_mod):
     for r in range(2):
         for name, got, exp in zip(names, res[r][1], want):
             assert got == exp, f"rank {r}: {name} differs from the single-rank run"
+
+
+def test_scan_quantiles_equals_per_key_queries_and_oracle(torch_mod, oracle):
+    """the per-key scan on the digests: ONE device pass gives the quantiles of every service -- keys with merged
+    clusters + buffered values, buffer-only keys, freshly merged keys (empty buffer) and keys without events -- identical to the
+    one-key query and to the oracle's merged view, and nothing is modified"""
+    import ctypes as C
+    torch = torch_mod
+    nh, sp, n = 32, 50, 1 << 19
+    eng = _engine(max_hosts=nh + 1, max_services=nh * sp + 8, max_batch_events=n)
+    orc = oracle.OracleEngine(nh * sp + 8)
+    info, gids = helpers.register_world(eng, orc, range(nh), sp)
+    ev = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
+    for rnd in range(4):  # ~330 values per key and round: most keys re-cluster in round 3, some in round 4
+        segs = eng.gen_resp_events(ev.data_ptr(), n, 777 + rnd, 0, nh, sp)
+        eng.handle_resp_events_dev(segs, ev.data_ptr(), n)
+        eng.sync()
+        orc.resp_batch(ev.cpu().numpy().tobytes(), [s.host_slot for s in segs], [s.first_event for s in segs])
+    rng = np.random.default_rng(3)
+    small = helpers.make_resp_events(rng, 5, 40, 3, bad_frac=0.0, unknown_frac=0.0)   # a few more values for three keys of host 5
+    eng.handle_resp_events(info[5][0], small)
+    orc.resp_batch(small.tobytes(), [info[5][1]], [0])
+    extra = wire.machine_id(40)  # a host whose services never see an event
+    eng.register_host(extra, "cluster0")
+    s = np.arange(4)
+    eng.register_listeners_np(extra, wire.glob_id(np.full(4, 40), s), wire.listener_netns(40, s), wire.listener_port(s))
+    nsvc = eng.num_services()
+    qs = [0.0, 0.25, 0.5, 0.95, 0.99, 1.0]
+    before = (eng.export_tdigest(0, nsvc), eng.export_tdigest_pending(0, nsvc))
+    got = eng.scan_quantiles(qs)
+    assert got.shape == (nsvc, len(qs))
+    gn, _ = before[1]
+    gs, gc, gm = before[0]
+    assert (gn > 0).any() and (gn == 0).any() and (gc.sum(axis=1) > 0).any() and ((gc.sum(axis=1) == 0) & (gn > 0)).any()
+    L = oracle.lib()
+    for slot in range(nh * sp):
+        want = [L.gyo_tdb_quantile(C.byref(orc.td(slot)), q) for q in qs]
+        assert got[slot].tolist() == want, (slot, got[slot].tolist(), want)
+    assert (got[nh * sp:] == 0.0).all()  # no events: 0, as gys_query_quantiles answers
+    for h, sv in ((0, 0), (5, 1), (31, 49)):
+        g = int(gids[h][sv])
+        assert eng.quantiles(g, qs) == got[eng.lookup(g)].tolist()
+    after = (eng.export_tdigest(0, nsvc), eng.export_tdigest_pending(0, nsvc))
+    for x, y in zip(before[0] + before[1], after[0] + after[1]):
+        assert (x == y).all()
+    eng.close()
