@@ -87,6 +87,13 @@ class TopnEntry(C.Structure):
     _fields_ = [("glob_id", C.c_uint64), ("host_slot", C.c_uint32), ("metric", C.c_uint32), ("state", C.c_uint8 * 88)]
 
 
+class TDigestSlab(C.Structure):
+    _fields_ = [("sum", C.c_int64 * TD_NB), ("cnt", C.c_uint64 * TD_NB), ("vmin", C.c_int64), ("vmax", C.c_int64)]
+
+
+ROLLUP_HOST, ROLLUP_CLUSTER, ROLLUP_GLOBAL = 0, 1, 2
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("resp_events", "resp_dropped_range", "resp_dropped_nolistener", "conn_events",
                                           "conn_unknown_service", "lstate_records", "lstate_missed", "lstate_errors", "lstate_deleted",
@@ -133,6 +140,10 @@ SIGNATURES = {
     "gys_query_topn": (C.c_int, [vp, mid, C.c_int, C.POINTER(TopnEntry), u32p]),
     "gys_scan_percentiles_dev": (C.c_int, [vp, C.c_int, f32p, C.c_uint32, vp]),
     "gys_scan_quantiles_dev": (C.c_int, [vp, f64p, C.c_uint32, vp]),
+    "gys_tdigest_rollup_dev": (C.c_int, [vp, C.c_int, vp]),
+    "gys_tdigest_merge_slabs_dev": (C.c_int, [vp, vp, C.c_uint32, vp]),
+    "gys_tdigest_slab_quantiles": (C.c_int, [vp, vp, f64p, C.c_uint32, f64p]),
+    "gys_num_clusters": (C.c_uint32, [vp]),
     "gys_tdigest_sql_text": (C.c_int, [vp, C.c_uint64, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_tdigest_sql_binary": (C.c_int, [vp, C.c_uint64, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_query_hist_level_stats": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(TimeHistVal), C.c_uint32, i64p, i64p, f64p]),

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "gys_kernels.hpp"
+#include "gys_rollup.hpp"
 
 using namespace gys;
 
@@ -2073,6 +2074,134 @@ int gys_scan_quantiles_dev(gys_ctx *c, const double *q, uint32_t nq, double *d_o
 	}
 	return GYS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ roll-up digests
+static int rollup_launch(gys_ctx *c, int kind, const std::vector<uint32_t> &off, const std::vector<uint32_t> &members, const gys_tdigest_slab *d_in,
+			 gys_tdigest_slab *d_out)
+{
+	const uint32_t ngroups = (uint32_t)off.size() - 1;
+	if (!ngroups) return GYS_OK;
+	uint32_t *d_off = nullptr, *d_mem = nullptr;
+	HIPCHK(hipMalloc((void **)&d_off, off.size() * 4));
+	HIPCHK(hipMalloc((void **)&d_mem, std::max<size_t>(members.size(), 1) * 4));
+	HIPCHK(hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
+	if (!members.empty()) HIPCHK(hipMemcpyAsync(d_mem, members.data(), members.size() * 4, hipMemcpyHostToDevice, c->stream));
+	RollupP rp{};
+	rp.d = digest_params(c);
+	rp.off = d_off;
+	rp.members = d_mem;
+	rp.kind = kind;
+	rp.in = d_in;
+	rp.out = d_out;
+	rp.ngroups = ngroups;
+	{
+		ProfScope ps(c, kind == 0 ? "rollup_services" : "rollup_slabs");
+		hipLaunchKernelGGL(k_digest_rollup, dim3(std::min<uint32_t>(ngroups, (uint32_t)c->ncu * 4)), dim3(256), 0, c->stream, rp);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(c->stream)); // the member lists are freed below
+	HIPCHK(hipFree(d_off));
+	HIPCHK(hipFree(d_mem));
+	return GYS_OK;
+}
+
+int gys_tdigest_rollup_dev(gys_ctx *c, int scope, gys_tdigest_slab *d_out)
+{
+	if (!c || !d_out || scope < GYS_ROLLUP_HOST || scope > GYS_ROLLUP_GLOBAL) return GYS_ERR_INVAL;
+	TDIGEST_CHECK();
+	const uint32_t nh = (uint32_t)c->hosts.size();
+	if (!nh) {
+		if (scope == GYS_ROLLUP_GLOBAL) HIPCHK(hipMemsetAsync(d_out, 0, sizeof(gys_tdigest_slab), c->stream));
+		return GYS_OK;
+	}
+	// host level: members = the host's services in slot order
+	std::vector<uint32_t> off(nh + 1, 0), members;
+	members.reserve(c->nsvc);
+	for (uint32_t h = 0; h < nh; ++h) {
+		std::vector<uint32_t> sl = c->host_lst[h].all_slots;
+		std::sort(sl.begin(), sl.end());
+		members.insert(members.end(), sl.begin(), sl.end());
+		off[h + 1] = (uint32_t)members.size();
+	}
+	gys_tdigest_slab *d_hosts = d_out;
+	if (scope != GYS_ROLLUP_HOST) HIPCHK(hipMalloc((void **)&d_hosts, sizeof(gys_tdigest_slab) * nh));
+	int rc = rollup_launch(c, 0, off, members, nullptr, d_hosts);
+	if (rc == GYS_OK && scope != GYS_ROLLUP_HOST) {
+		std::vector<uint32_t> goff, gmem;
+		if (scope == GYS_ROLLUP_GLOBAL) {
+			goff = {0u, nh};
+			gmem.resize(nh);
+			for (uint32_t h = 0; h < nh; ++h) gmem[h] = h;
+		} else {
+			const uint32_t ncl = (uint32_t)c->cluster_names.size();
+			goff.assign(ncl + 1, 0);
+			for (uint32_t cl = 0; cl < ncl; ++cl) {
+				for (uint32_t h = 0; h < nh; ++h)
+					if (c->host_cluster_h[h] == cl) gmem.push_back(h);
+				goff[cl + 1] = (uint32_t)gmem.size();
+			}
+		}
+		rc = rollup_launch(c, 1, goff, gmem, d_hosts, d_out);
+	}
+	if (scope != GYS_ROLLUP_HOST) HIPCHK(hipFree(d_hosts));
+	return rc;
+}
+
+int gys_tdigest_merge_slabs_dev(gys_ctx *c, const gys_tdigest_slab *d_in, uint32_t n, gys_tdigest_slab *d_out)
+{
+	if (!c || !d_in || !d_out || n == 0) return GYS_ERR_INVAL;
+	std::vector<uint32_t> off{0u, n}, mem(n);
+	for (uint32_t i = 0; i < n; ++i) mem[i] = i;
+	return rollup_launch(c, 1, off, mem, d_in, d_out);
+}
+
+int gys_tdigest_slab_quantiles(gys_ctx *c, const gys_tdigest_slab *d_slab, const double *q, uint32_t nq, double *out)
+{
+	if (!c || !d_slab || !q || !out) return GYS_ERR_INVAL;
+	gys_tdigest_slab s;
+	HIPCHK(hipMemcpyAsync(&s, d_slab, sizeof(s), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	// td_quantile_interp on the wide counters (same arithmetic: exact integer prefix weights as doubles, one division per centre)
+	uint64_t N = 0;
+	for (int k = 0; k < GYS_TD_NB; ++k) N += s.cnt[k];
+	for (uint32_t i = 0; i < nq; ++i) {
+		double r = 0.0;
+		if (N) {
+			double qq = q[i] < 0.0 ? 0.0 : (q[i] > 1.0 ? 1.0 : q[i]);
+			const double t = qq * (double)N;
+			double wbefore = 0.0, prev_c = 0.0, prev_mean = 0.0;
+			bool have_prev = false, done = false;
+			for (int k = 0; k < GYS_TD_NB && !done; ++k) {
+				if (!s.cnt[k]) continue;
+				const double mean = (double)s.sum[k] / (double)s.cnt[k];
+				const double cc = wbefore + (double)s.cnt[k] * 0.5;
+				if (t < cc) {
+					if (!have_prev) {
+						const double lo = (double)s.vmin;
+						r = cc <= 0.0 ? mean : lo + (mean - lo) * (t / cc);
+					} else {
+						r = prev_mean + (mean - prev_mean) * ((t - prev_c) / (cc - prev_c));
+					}
+					done = true;
+					break;
+				}
+				wbefore += (double)s.cnt[k];
+				prev_c = cc;
+				prev_mean = mean;
+				have_prev = true;
+			}
+			if (!done) {
+				const double hi = (double)s.vmax, span = (double)N - prev_c;
+				r = span <= 0.0 ? hi : prev_mean + (hi - prev_mean) * ((t - prev_c) / span);
+			}
+			r = std::floor(r + 0.5);
+		}
+		out[i] = r;
+	}
+	return GYS_OK;
+}
+
+uint32_t gys_num_clusters(gys_ctx *c) { return c ? (uint32_t)c->cluster_names.size() : 0; }
 
 uint32_t gys_num_services(gys_ctx *c) { return c ? c->nsvc : 0; }
 uint32_t gys_num_hosts(gys_ctx *c) { return c ? (uint32_t)c->hosts.size() : 0; }

@@ -215,6 +215,30 @@ class SketchEngine:
         capi.check(self.L.gys_scan_quantiles_dev(self.h, qa, len(qs), C.c_void_p(out.data_ptr())))
         return out[:n].cpu().numpy()
 
+    SLAB_DT = np.dtype([("sum", "<i8", capi.TD_NB), ("cnt", "<u8", capi.TD_NB), ("vmin", "<i8"), ("vmax", "<i8")])
+
+    def tdigest_rollup(self, scope):
+        """roll-up digests (gys_tdigest_rollup_dev): torch uint8 tensor of n slabs on the device + the same as a numpy record array"""
+        n = {capi.ROLLUP_HOST: self.L.gys_num_hosts(self.h), capi.ROLLUP_CLUSTER: self.L.gys_num_clusters(self.h), capi.ROLLUP_GLOBAL: 1}[scope]
+        dev = self.torch.zeros(max(n, 1) * C.sizeof(capi.TDigestSlab), dtype=self.torch.uint8, device=self.device)
+        self.order()
+        capi.check(self.L.gys_tdigest_rollup_dev(self.h, scope, C.c_void_p(dev.data_ptr())))
+        self.sync()
+        return dev, np.frombuffer(dev.cpu().numpy().tobytes(), dtype=self.SLAB_DT)[:n]
+
+    def tdigest_merge_slabs(self, dev_slabs, n):
+        out = self.torch.zeros(C.sizeof(capi.TDigestSlab), dtype=self.torch.uint8, device=self.device)
+        self.order()
+        capi.check(self.L.gys_tdigest_merge_slabs_dev(self.h, C.c_void_p(dev_slabs.data_ptr()), n, C.c_void_p(out.data_ptr())))
+        self.sync()
+        return out, np.frombuffer(out.cpu().numpy().tobytes(), dtype=self.SLAB_DT)[0]
+
+    def slab_quantiles(self, dev_slab, qs, index=0):
+        qa = (C.c_double * len(qs))(*qs)
+        out = (C.c_double * len(qs))()
+        capi.check(self.L.gys_tdigest_slab_quantiles(self.h, C.c_void_p(dev_slab.data_ptr() + index * C.sizeof(capi.TDigestSlab)), qa, len(qs), out))
+        return list(out)
+
     def hist_percentiles(self, glob_id, pcts, which=1):
         pd = (capi.HistData * len(pcts))()
         for i, p in enumerate(pcts):

@@ -263,6 +263,29 @@ int gys_scan_percentiles_dev(gys_ctx *ctx, int which, const float *pcts, uint32_
 int gys_scan_quantiles_dev(gys_ctx *ctx, const double *q, uint32_t nq, double *d_out);
 
 /* -------------------------------------------------------------------------------------------------------------------
+ * Roll-up digests: the response-time digest of a GROUP of services -- a host, a cluster, all hosts of this rank ("global") -- and the
+ * merge of such digests across ranks.  Replaces the aggregated percentile Postgres computes over a set of listeners' rows,
+ * public.tdigest_percentile(col, 100, p) (common/gy_query_common.cc:1818-1855), and feeds the fan-in of
+ * SHCONN_HANDLER::aggregate_cluster_state (server/gy_shconnhdlr.cc:4583-4720).  Definition (oracle/gy_oracle_rollup.c): left fold over
+ * the members in slot order of d := merge(d, member); a service contributes its clusters, then its buffered values; a roll-up digest
+ * contributes its clusters; 64-bit counters.  Fixed-size slab = the unit a multi-rank job all-gathers (ncclAllGather of
+ * sizeof(gys_tdigest_slab) bytes per rank) and folds in rank order with gys_tdigest_merge_slabs_dev. */
+typedef struct {
+	int64_t sum[GYS_TD_NB];
+	uint64_t cnt[GYS_TD_NB];
+	int64_t vmin, vmax; /* valid when any cnt != 0 */
+} gys_tdigest_slab;
+enum { GYS_ROLLUP_HOST = 0, GYS_ROLLUP_CLUSTER = 1, GYS_ROLLUP_GLOBAL = 2 };
+/* d_out (DEVICE): HOST: one slab per host slot [gys_num_hosts]; CLUSTER: one per registered cluster index (fold of its hosts' slabs in
+ * host-slot order); GLOBAL: one slab (fold of all host slabs in host-slot order).  No engine state is modified. */
+int gys_tdigest_rollup_dev(gys_ctx *ctx, int scope, gys_tdigest_slab *d_out);
+/* d_out[0] (DEVICE) = fold of d_in[0..n) in order (the cross-rank merge after an all-gather; also any caller-defined group) */
+int gys_tdigest_merge_slabs_dev(gys_ctx *ctx, const gys_tdigest_slab *d_in, uint32_t n, gys_tdigest_slab *d_out);
+/* quantiles q[i] (0..1) of one DEVICE slab into the HOST array out (same interpolation and rounding as gys_query_quantiles) */
+int gys_tdigest_slab_quantiles(gys_ctx *ctx, const gys_tdigest_slab *d_slab, const double *q, uint32_t nq, double *out);
+uint32_t gys_num_clusters(gys_ctx *ctx);
+
+/* -------------------------------------------------------------------------------------------------------------------
  * a service's response-time t-digest in the external forms of the Postgres tdigest type, so that the reference's SQL
  * percentile aggregation -- public.tdigest(col, 100) / public.tdigest_percentile(digest, p), common/gy_query_common.cc:1818-1855,
  * extension loaded at :3387 -- can consume engine digests ('<text>'::public.tdigest, or the binary send/recv form).

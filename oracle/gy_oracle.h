@@ -161,6 +161,20 @@ void gyo_tdb_add_batch(gyo_td_buffered *b, const int32_t *vals, size_t m);
 void gyo_tdb_merged_view(const gyo_td_buffered *b, gyo_tdigest *out); /* digest with the buffer merged in; b is not modified */
 double gyo_tdb_quantile(const gyo_td_buffered *b, double q);         /* = gyo_td_quantile(merged view) */
 
+/* ---------------------------------------------------------------- roll-up digests (gy_oracle_rollup.c): 64-bit counters */
+typedef struct {
+	int64_t sum[GYO_TD_NB];
+	uint64_t cnt[GYO_TD_NB];
+	int64_t vmin, vmax; /* valid when total > 0 */
+} gyo_td64;
+
+void gyo_td64_init(gyo_td64 *d);
+uint64_t gyo_td64_total(const gyo_td64 *d);
+void gyo_td64_merge_values(gyo_td64 *d, const int32_t *vals, size_t m);
+void gyo_td64_merge_service(gyo_td64 *d, const gyo_td_buffered *b); /* the service's clusters, then its buffered values */
+void gyo_td64_merge_td64(gyo_td64 *d, const gyo_td64 *o);
+double gyo_td64_quantile(const gyo_td64 *d, double q);
+
 /* ---------------------------------------------------------------- wire records + roll-ups */
 #define GYO_TCP_CONN_NOTIFY_SZ 280
 #define GYO_LISTENER_STATE_NOTIFY_SZ 88

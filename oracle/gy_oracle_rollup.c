@@ -1,0 +1,203 @@
+/* ORACLE (test infrastructure, CPU): roll-up digests -- the response-time digest of a GROUP of services (a host, a cluster, every
+ * host of a madhava, every madhava).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything in oracle/.
+ *
+ * What it stands for in the reference: the aggregated percentile of a group is computed by Postgres from the rows of its members,
+ * `public.tdigest_percentile(col, 100, p)` over the selected listeners (common/gy_query_common.cc:1818-1855), and the cluster-level
+ * fan-in is SHCONN_HANDLER::aggregate_cluster_state (server/gy_shconnhdlr.cc:4583-4720).  The tdigest extension is not in
+ * /root/reference => PARITY UNPINNED; the definition below is the builder's, frozen here so that "bit-exact" is defined:
+ *
+ *   rollup(group) = left fold over the members in their given order of
+ *        d := merge(d, member)        member = a service: first its clusters (weighted points at their means, gy_oracle.c
+ *                                     gyo_td_merge_digest), then its buffered values (unit points, gyo_td_merge_values);
+ *                                     member = another roll-up digest: its clusters (weighted points).
+ *   merge = the same exact-integer k-bucket merge as a service's own digest (gy_oracle.c td_merge_items): items ordered by mean
+ *   (exact rational compare), ties: old clusters first; an item whose weighted mid-point is mid2 / 2 of N goes to cluster
+ *   gyo_td_cluster(mid2, 2N).  A group's weight exceeds 32 bits (10^4 hosts x 2^29 events per window), so the counters are 64-bit.
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gy_oracle.h"
+
+void gyo_td64_init(gyo_td64 *d)
+{
+	memset(d, 0, sizeof(*d));
+	d->vmin = INT_MAX;
+	d->vmax = INT_MIN;
+}
+
+uint64_t gyo_td64_total(const gyo_td64 *d)
+{
+	uint64_t n = 0;
+	for (int i = 0; i < GYO_TD_NB; i++) n += d->cnt[i];
+	return n;
+}
+
+typedef struct {
+	int64_t sum;
+	uint64_t cnt;
+} td64_item;
+
+/* items sorted by mean (non-decreasing).  Same two passes as td_merge_items (gy_oracle.c:565-625), 64-bit counts. */
+static void td64_merge_items(gyo_td64 *d, const td64_item *items, size_t m)
+{
+	gyo_td64 out;
+	uint64_t nold = gyo_td64_total(d), nnew = 0, twoN, wold_before = 0;
+
+	for (size_t i = 0; i < m; i++) nnew += items[i].cnt;
+	if (nnew == 0) return;
+	twoN = 2 * (nold + nnew);
+	gyo_td64_init(&out);
+	out.vmin = d->vmin;
+	out.vmax = d->vmax;
+	{ /* old clusters: W = (old weight before j) + (new weight with mean strictly < mean_j) */
+		size_t p = 0;
+		uint64_t new_lt = 0;
+		for (int j = 0; j < GYO_TD_NB; j++) {
+			if (!d->cnt[j]) continue;
+			while (p < m && (__int128)items[p].sum * (__int128)d->cnt[j] < (__int128)d->sum[j] * (__int128)items[p].cnt) {
+				new_lt += items[p].cnt;
+				p++;
+			}
+			{
+				const uint64_t mid2 = 2 * (wold_before + new_lt) + d->cnt[j];
+				const uint32_t c = gyo_td_cluster(mid2, twoN);
+				out.sum[c] += d->sum[j];
+				out.cnt[c] += d->cnt[j];
+			}
+			wold_before += d->cnt[j];
+		}
+	}
+	{ /* new items: W = (new weight before i) + (old weight with mean <= mean_i) */
+		int j = 0;
+		uint64_t old_le = 0, new_before = 0;
+		for (size_t i = 0; i < m; i++) {
+			while (j < GYO_TD_NB) {
+				if (!d->cnt[j]) {
+					j++;
+					continue;
+				}
+				if ((__int128)d->sum[j] * (__int128)items[i].cnt <= (__int128)items[i].sum * (__int128)d->cnt[j]) {
+					old_le += d->cnt[j];
+					j++;
+				} else
+					break;
+			}
+			{
+				const uint64_t mid2 = 2 * (new_before + old_le) + items[i].cnt;
+				const uint32_t c = gyo_td_cluster(mid2, twoN);
+				out.sum[c] += items[i].sum;
+				out.cnt[c] += items[i].cnt;
+			}
+			new_before += items[i].cnt;
+		}
+	}
+	*d = out;
+}
+
+static int cmp_i32(const void *a, const void *b)
+{
+	const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+	return (x > y) - (x < y);
+}
+
+void gyo_td64_merge_values(gyo_td64 *d, const int32_t *vals, size_t m)
+{
+	int32_t *s;
+	td64_item *it;
+
+	if (!m) return;
+	s = (int32_t *)malloc(m * sizeof(int32_t));
+	it = (td64_item *)malloc(m * sizeof(td64_item));
+	memcpy(s, vals, m * sizeof(int32_t));
+	qsort(s, m, sizeof(int32_t), cmp_i32);
+	for (size_t i = 0; i < m; i++) {
+		it[i].sum = s[i];
+		it[i].cnt = 1;
+	}
+	td64_merge_items(d, it, m);
+	if (s[0] < d->vmin) d->vmin = s[0];
+	if (s[m - 1] > d->vmax) d->vmax = s[m - 1];
+	free(s);
+	free(it);
+}
+
+/* a service: clusters first, then the buffered values */
+void gyo_td64_merge_service(gyo_td64 *d, const gyo_td_buffered *b)
+{
+	td64_item it[GYO_TD_NB];
+	size_t m = 0;
+
+	for (int j = 0; j < GYO_TD_NB; j++) {
+		if (b->d.cnt[j]) {
+			it[m].sum = b->d.sum[j];
+			it[m].cnt = b->d.cnt[j];
+			m++;
+		}
+	}
+	if (m) {
+		td64_merge_items(d, it, m);
+		if (b->d.vmin < d->vmin) d->vmin = b->d.vmin;
+		if (b->d.vmax > d->vmax) d->vmax = b->d.vmax;
+	}
+	gyo_td64_merge_values(d, b->pend, b->npend);
+}
+
+void gyo_td64_merge_td64(gyo_td64 *d, const gyo_td64 *o)
+{
+	td64_item it[GYO_TD_NB];
+	size_t m = 0;
+
+	for (int j = 0; j < GYO_TD_NB; j++) {
+		if (o->cnt[j]) {
+			it[m].sum = o->sum[j];
+			it[m].cnt = o->cnt[j];
+			m++;
+		}
+	}
+	if (!m) return;
+	td64_merge_items(d, it, m);
+	if (o->vmin < d->vmin) d->vmin = o->vmin;
+	if (o->vmax > d->vmax) d->vmax = o->vmax;
+}
+
+/* the same interpolation as gyo_td_quantile (gy_oracle.c:669-715) on the wide counters; only + - * / on doubles */
+double gyo_td64_quantile(const gyo_td64 *d, double q)
+{
+	const uint64_t N = gyo_td64_total(d);
+	double t, wbefore = 0.0, prev_c = 0.0, prev_mean = 0.0, r;
+	int have_prev = 0;
+
+	if (!N) return 0.0;
+	if (q < 0.0) q = 0.0;
+	if (q > 1.0) q = 1.0;
+	t = q * (double)N;
+	r = (double)d->vmax;
+	for (int k = 0; k < GYO_TD_NB; k++) {
+		double c, mean;
+		if (!d->cnt[k]) continue;
+		mean = (double)d->sum[k] / (double)d->cnt[k];
+		c = wbefore + (double)d->cnt[k] * 0.5;
+		if (t < c) {
+			if (!have_prev) {
+				const double lo = (double)d->vmin;
+				r = c <= 0.0 ? mean : lo + (mean - lo) * (t / c);
+			} else {
+				r = prev_mean + (mean - prev_mean) * ((t - prev_c) / (c - prev_c));
+			}
+			goto done;
+		}
+		wbefore += (double)d->cnt[k];
+		prev_c = c;
+		prev_mean = mean;
+		have_prev = 1;
+	}
+	{
+		const double hi = (double)d->vmax, span = (double)N - prev_c;
+		r = span <= 0.0 ? hi : prev_mean + (hi - prev_mean) * ((t - prev_c) / span);
+	}
+done:
+	return floor(r + 0.5); /* integer-millisecond value domain: round half up, as gyo_td_quantile */
+}

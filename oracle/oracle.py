@@ -33,7 +33,7 @@ f32p = C.POINTER(C.c_float)
 HIST_SERIAL_DT = np.dtype([("count", "<u8"), ("sum", "<i8")])  # HIST_SERIAL as a numpy record
 
 
-SOURCES = ["gy_oracle.c", "gy_oracle_engine.c", "gy_oracle_levels.c"]
+SOURCES = ["gy_oracle.c", "gy_oracle_engine.c", "gy_oracle_levels.c", "gy_oracle_rollup.c"]
 
 
 def build_oracle(force=False):
@@ -70,6 +70,10 @@ class TDBuffered(C.Structure):
 
 BTS_MAXB = 16
 MLH_LEVELS = 4
+
+
+class TD64(C.Structure):
+    _fields_ = [("sum", C.c_int64 * TD_NB), ("cnt", C.c_uint64 * TD_NB), ("vmin", C.c_int64), ("vmax", C.c_int64)]
 
 
 class BTS(C.Structure):
@@ -163,6 +167,12 @@ def lib():
     _sig(L, "gyo_tdb_add_batch", None, [C.POINTER(TDBuffered), i32p, C.c_size_t])
     _sig(L, "gyo_tdb_merged_view", None, [C.POINTER(TDBuffered), C.POINTER(TDigest)])
     _sig(L, "gyo_tdb_quantile", C.c_double, [C.POINTER(TDBuffered), C.c_double])
+    _sig(L, "gyo_td64_init", None, [C.POINTER(TD64)])
+    _sig(L, "gyo_td64_total", C.c_uint64, [C.POINTER(TD64)])
+    _sig(L, "gyo_td64_merge_values", None, [C.POINTER(TD64), i32p, C.c_size_t])
+    _sig(L, "gyo_td64_merge_service", None, [C.POINTER(TD64), C.POINTER(TDBuffered)])
+    _sig(L, "gyo_td64_merge_td64", None, [C.POINTER(TD64), C.POINTER(TD64)])
+    _sig(L, "gyo_td64_quantile", C.c_double, [C.POINTER(TD64), C.c_double])
     _sig(L, "gyo_listener_state_rollup", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(ListenSummStats), C.POINTER(C.c_int)])
     _sig(L, "gyo_listener_state_elem_size", C.c_uint32, [C.c_void_p])
     _sig(L, "gyo_tcp_conn_elem_size", C.c_uint32, [C.c_void_p])

@@ -265,3 +265,92 @@ def test_scan_quantiles_equals_per_key_queries_and_oracle(torch_mod, oracle):
     for x, y in zip(before[0] + before[1], after[0] + after[1]):
         assert (x == y).all()
     eng.close()
+
+
+def test_tdigest_rollup_host_cluster_global_bit_exact(torch_mod, oracle):
+    """merged digests of groups of services: per host, per cluster and over all hosts, every slab equal to the
+    oracle's left fold (oracle/gy_oracle_rollup.c) bit for bit -- members with clusters + buffered values, buffer-only members,
+    empty members; then the cross-rank form: slabs of two engines holding disjoint hosts, concatenated as an all-gather would
+    and folded in rank order, equal to the oracle's fold of the two global slabs"""
+    import ctypes as C
+    torch = torch_mod
+    from gyeeta_amd import capi
+    L = oracle.lib()
+    qs = [0.01, 0.25, 0.5, 0.95, 0.99, 0.999]
+
+    def world(hosts, seed):
+        nh, sp, n = len(hosts), 40, 1 << 18
+        eng = _engine(max_hosts=nh + 1, max_services=(nh + 1) * sp, max_batch_events=n, max_clusters=4)
+        orc = oracle.OracleEngine((nh + 1) * sp)
+        for cname in ("cluster0", "cluster1", "cluster2"):
+            eng.register_cluster(cname)
+        info, gids = helpers.register_world(eng, orc, hosts, sp)
+        ev = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
+        for rnd in range(5):  # ~330 values per key and round over the first nh hosts: most keys re-cluster once, all keep a buffer
+            segs = eng.gen_resp_events(ev.data_ptr(), n, seed + rnd, 0, nh, sp)
+            eng.handle_resp_events_dev(segs, ev.data_ptr(), n)
+            eng.sync()
+            orc.resp_batch(ev.cpu().numpy().tobytes(), [s.host_slot for s in segs], [s.first_event for s in segs])
+        quiet = wire.machine_id(900 + seed)  # a host without events, and one with buffer-only services
+        eng.register_host(quiet, "cluster1")
+        s = np.arange(3)
+        eng.register_listeners_np(quiet, wire.glob_id(np.full(3, 900 + seed), s), wire.listener_netns(900 + seed, s), wire.listener_port(s))
+        for i in range(3):
+            orc.register(nh, int(wire.glob_id(900 + seed, i)), int(wire.listener_netns(900 + seed, s)[i]), int(wire.listener_port(s)[i]))
+        return eng, orc, nh, sp
+
+    def oracle_host_slabs(orc, nh, sp):
+        slabs = []
+        for h in range(nh + 1):
+            d = oracle.TD64()
+            L.gyo_td64_init(C.byref(d))
+            for k in range(sp if h < nh else 3):
+                L.gyo_td64_merge_service(C.byref(d), C.byref(orc.td(h * sp + k)))
+            slabs.append(d)
+        return slabs
+
+    def fold(slabs):
+        d = oracle.TD64()
+        L.gyo_td64_init(C.byref(d))
+        for s_ in slabs:
+            L.gyo_td64_merge_td64(C.byref(d), C.byref(s_))
+        return d
+
+    def same(rec, d):
+        ok = (rec["sum"] == np.array(d.sum[:], dtype=np.int64)).all() and (rec["cnt"] == np.array(d.cnt[:], dtype=np.uint64)).all()
+        if L.gyo_td64_total(C.byref(d)):
+            ok = ok and int(rec["vmin"]) == d.vmin and int(rec["vmax"]) == d.vmax
+        return bool(ok)
+
+    hosts_a, hosts_b = list(range(6)), list(range(6, 11))
+    globals_dev, globals_orc = [], []
+    for hosts, seed in ((hosts_a, 31), (hosts_b, 57)):
+        eng, orc, nh, sp = world(hosts, seed)
+        ohs = oracle_host_slabs(orc, nh, sp)
+        before = eng.export_tdigest(0, eng.num_services())
+        dev_h, rec_h = eng.tdigest_rollup(capi.ROLLUP_HOST)
+        assert len(rec_h) == nh + 1
+        for h in range(nh + 1):
+            assert same(rec_h[h], ohs[h]), f"host slab {h} differs"
+        assert rec_h[nh]["cnt"].sum() == 0  # the quiet host: an empty digest
+        assert eng.slab_quantiles(dev_h, qs, index=2) == [L.gyo_td64_quantile(C.byref(ohs[2]), q) for q in qs]
+        dev_c, rec_c = eng.tdigest_rollup(capi.ROLLUP_CLUSTER)
+        cl_of = [hosts[h] % 3 for h in range(nh)] + [1]  # helpers.register_world: cluster%d of (host index % 3); the quiet host: cluster1
+        for cl in range(3):
+            assert same(rec_c[cl], fold([ohs[h] for h in range(nh + 1) if cl_of[h] == cl])), f"cluster slab {cl} differs"
+        dev_g, rec_g = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)
+        og = fold(ohs)
+        assert same(rec_g[0], og)
+        assert int(rec_g[0]["cnt"].sum()) == L.gyo_td64_total(C.byref(og)) > 0
+        assert eng.slab_quantiles(dev_g, qs) == [L.gyo_td64_quantile(C.byref(og), q) for q in qs]
+        after = eng.export_tdigest(0, eng.num_services())
+        assert all((x == y).all() for x, y in zip(before, after))  # nothing modified
+        globals_dev.append(dev_g.clone())
+        globals_orc.append(og)
+        if seed == 57:  # cross-rank merge on this engine: the two ranks' global slabs as an all-gather lays them out
+            gathered = torch.cat(globals_dev)
+            dev_m, rec_m = eng.tdigest_merge_slabs(gathered, 2)
+            om = fold(globals_orc)
+            assert same(rec_m, om)
+            assert eng.slab_quantiles(dev_m, qs) == [L.gyo_td64_quantile(C.byref(om), q) for q in qs]
+        eng.close()
