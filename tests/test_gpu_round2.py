@@ -241,10 +241,15 @@ def test_scan_quantiles_equals_per_key_queries_and_oracle(torch_mod, oracle):
     small = helpers.make_resp_events(rng, 5, 40, 3, bad_frac=0.0, unknown_frac=0.0)   # a few more values for three keys of host 5
     eng.handle_resp_events(info[5][0], small)
     orc.resp_batch(small.tobytes(), [info[5][1]], [0])
-    extra = wire.machine_id(40)  # a host whose services never see an event
-    eng.register_host(extra, "cluster0")
+    extra = wire.machine_id(40)  # a host with two buffer-only services (60 events) and two that never see an event
+    xslot = eng.register_host(extra, "cluster0")
     s = np.arange(4)
     eng.register_listeners_np(extra, wire.glob_id(np.full(4, 40), s), wire.listener_netns(40, s), wire.listener_port(s))
+    for i in range(4):
+        orc.register(xslot, int(wire.glob_id(40, i)), int(wire.listener_netns(40, s)[i]), int(wire.listener_port(s)[i]))
+    few = helpers.make_resp_events(rng, 40, 60, 2, bad_frac=0.0, unknown_frac=0.0)
+    eng.handle_resp_events(extra, few)
+    orc.resp_batch(few.tobytes(), [xslot], [0])
     nsvc = eng.num_services()
     qs = [0.0, 0.25, 0.5, 0.95, 0.99, 1.0]
     before = (eng.export_tdigest(0, nsvc), eng.export_tdigest_pending(0, nsvc))
@@ -254,10 +259,10 @@ def test_scan_quantiles_equals_per_key_queries_and_oracle(torch_mod, oracle):
     gs, gc, gm = before[0]
     assert (gn > 0).any() and (gn == 0).any() and (gc.sum(axis=1) > 0).any() and ((gc.sum(axis=1) == 0) & (gn > 0)).any()
     L = oracle.lib()
-    for slot in range(nh * sp):
+    for slot in range(nh * sp + 2):
         want = [L.gyo_tdb_quantile(C.byref(orc.td(slot)), q) for q in qs]
         assert got[slot].tolist() == want, (slot, got[slot].tolist(), want)
-    assert (got[nh * sp:] == 0.0).all()  # no events: 0, as gys_query_quantiles answers
+    assert (got[nh * sp + 2:] == 0.0).all()  # no events: 0, as gys_query_quantiles answers
     for h, sv in ((0, 0), (5, 1), (31, 49)):
         g = int(gids[h][sv])
         assert eng.quantiles(g, qs) == got[eng.lookup(g)].tolist()
@@ -270,7 +275,7 @@ def test_scan_quantiles_equals_per_key_queries_and_oracle(torch_mod, oracle):
 def test_tdigest_rollup_host_cluster_global_bit_exact(torch_mod, oracle):
     """merged digests of groups of services: per host, per cluster and over all hosts, every slab equal to the
     oracle's left fold (oracle/gy_oracle_rollup.c) bit for bit -- members with clusters + buffered values, buffer-only members,
-    empty members; then the cross-rank form: slabs of two engines holding disjoint hosts, concatenated as an all-gather would
+    empty members; then the cross-rank form: slabs of two engines (two ranks' shards, different streams), concatenated as an all-gather would
     and folded in rank order, equal to the oracle's fold of the two global slabs"""
     import ctypes as C
     torch = torch_mod
@@ -322,7 +327,7 @@ def test_tdigest_rollup_host_cluster_global_bit_exact(torch_mod, oracle):
             ok = ok and int(rec["vmin"]) == d.vmin and int(rec["vmax"]) == d.vmax
         return bool(ok)
 
-    hosts_a, hosts_b = list(range(6)), list(range(6, 11))
+    hosts_a, hosts_b = list(range(6)), list(range(5))  # (the device generator draws for host indices 0..n-1: two engines = two ranks' shards)
     globals_dev, globals_orc = [], []
     for hosts, seed in ((hosts_a, 31), (hosts_b, 57)):
         eng, orc, nh, sp = world(hosts, seed)
