@@ -204,6 +204,64 @@ def pmc_traffic(kernel, events, nsvc):
             "source": t.get("source", "profiles/pmc_traffic.json")}
 
 
+def run_conn(args, rank, world):
+    """--workload conn: BASELINE.json configs[1] -- 1 000 hosts x 100 services, per window 2^24 device-resident
+    TCP_CONN_NOTIFY records (280 B fixed stride; HLL distinct flows + 2 x Count-Min + exact per-service counters) and 10^5
+    LISTENER_STATE_NOTIFY records (88 B; per-host LISTEN_SUMM_STATS roll-up, top-N), then the window close."""
+    import ctypes as C
+    from gyeeta_amd import capi, wire
+    from gyeeta_amd.engine import SketchEngine
+    nh, sp = min(args.hosts, 1000), min(args.svcs, 100)
+    nrec, chunk = 1 << 24, 1 << 22
+    eng = SketchEngine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False)
+    s_ = np.arange(sp)
+    for h in range(nh):
+        mid = wire.machine_id(h)
+        eng.register_host(mid, "cluster%d" % (h % 8))
+        eng.register_listeners_np(mid, wire.glob_id(np.full(sp, h), s_), wire.listener_netns(h, s_), wire.listener_port(s_))
+    rng = np.random.default_rng(1)
+    rec = wire.synth_tcp_conns(rng, chunk, np.arange(nh), sp, dup_frac=0.2)
+    d = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.uint8).copy()).cuda()
+    off = torch.arange(0, chunk * 280, 280, dtype=torch.int32, device="cuda")
+    ls = np.concatenate([wire.synth_listener_states(rng, h, s_) for h in range(nh)])
+    dl = torch.from_numpy(np.frombuffer(ls.tobytes(), dtype=np.uint8).copy()).cuda()
+    offl = torch.arange(0, len(ls) * 88, 88, dtype=torch.int32, device="cuda")
+    hostl = torch.from_numpy(np.repeat(np.arange(nh, dtype=np.uint32), sp).view(np.int32).copy()).cuda()
+    eng.order()
+
+    def step(i):
+        for r in range(nrec // chunk):
+            capi.check(eng.L.gys_ingest_tcp_conn_dev(eng.h, C.c_void_p(d.data_ptr()), C.c_void_p(off.data_ptr()), chunk))
+        capi.check(eng.L.gys_ingest_listener_state_dev(eng.h, C.c_void_p(dl.data_ptr()), C.c_void_p(offl.data_ptr()), C.c_void_p(hostl.data_ptr()), len(ls)))
+        eng.window_close(tusec=5_000_000 * (i + 1))
+
+    for i in range(args.warmup):
+        step(i)
+    eng.profile(True)
+    eng.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_get()
+    step_s = dt / args.steps
+    alg = 280 * nrec + 88 * len(ls)
+    kms = {k: v[0] / args.steps for k, v in prof.items()}
+    out = {"metric": "TCP_CONN_NOTIFY records/sec ingested into HLL + Count-Min (BASELINE config 2)", "value": nrec / step_s, "unit": "records/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+           "config": {"workload": "C2: %d hosts x %d services, %d TCP_CONN_NOTIFY (280 B) + %d LISTENER_STATE_NOTIFY (88 B) records per window, "
+                                  "device resident, 1 window per step" % (nh, sp, nrec, len(ls))},
+           "roofline": {"bound": "hbm", "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_step": alg, "kernel": "conn", "kernel_avg_ms": kms.get("conn"), "traffic": None,
+                        "kernels": {k: {"ms": v} for k, v in kms.items()},
+                        "note": "280 B x records + 88 B x listener records per step / whole step; k_conn_ingest is bound by device-scope atomics, not HBM"}}
+    print(json.dumps(out), flush=True)
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,7 +270,9 @@ def main():
     ap.add_argument("--hosts", type=int, default=10000, help="total hosts across all ranks")
     ap.add_argument("--svcs", type=int, default=1000, help="services per host")
     ap.add_argument("--events", type=int, default=1 << 29, help="events per rank per step (one window)")
-    ap.add_argument("--zipf-milli", type=int, default=0, help="0 = uniform over services, else Zipf s*1000 (config 5)")
+    ap.add_argument("--zipf-milli", type=int, default=0, help="0 = uniform over services, else Zipf s*1000 (config 5: --zipf-milli 1100 --hosts 25 --svcs 4000)")
+    ap.add_argument("--workload", choices=["resp", "conn"], default="resp", help="resp: C3/C4/C5 response-event stream (default); conn: C2 TCP_CONN_NOTIFY stream")
+    ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl", help="window exchange at N > 1: RCCL inside the library (default) or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quantile-check", action="store_true", help="skip the (untimed) t-digest rank-error check after the run")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the (untimed) host-fed measurement: pinned H2D copy + ingest")
@@ -237,6 +297,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.workload == "conn":
+        if rank == 0:
+            run_conn(args, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from gyeeta_amd import wire
     from gyeeta_amd.engine import SketchEngine, mid_buf
     from gyeeta_amd import capi
@@ -249,6 +316,26 @@ def main():
     nsvc = nlocal * args.svcs
     eng = SketchEngine(max_hosts=max(nlocal, 1), max_services=max(nsvc, 1), max_clusters=16, enable_tdigest=True,
                        max_batch_events=args.events, rank=rank, nranks=world, device=local_rank)
+    # window exchange at N > 1: the four register families all-reduced INSIDE the library (gys_window_close_rccl: ncclAllReduce x 4 in
+    # one group on the engine stream).  torch.distributed only carries the 128-byte communicator id (and the timing barrier).
+    exchange = "none"
+    if world > 1:
+        exchange = "torch.distributed"
+        if args.exchange == "rccl":
+            try:
+                uid = torch.zeros(capi.RCCL_UID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(eng.rccl_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, src=0)
+                eng.join_rccl(bytes(uid.cpu().numpy().tolist()))
+                exchange = "rccl_in_library"
+            except Exception as ex:  # keep the run alive on the torch path
+                print(f"bench.py rank {rank}: in-library RCCL unavailable ({ex}); using torch.distributed", file=sys.stderr)
+        ok = torch.tensor([1 if exchange == "rccl_in_library" else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks or none
+        if int(ok.item()) == 0:
+            exchange = "torch.distributed"
+    close = eng.window_close_rccl if exchange == "rccl_in_library" else eng.window_close
     for c in range(8):  # same cluster order on every rank (gysketch.h: gys_register_cluster)
         eng.register_cluster("cluster%d" % c)
     s = np.arange(args.svcs)
@@ -285,7 +372,7 @@ def main():
             sg = eng.gen_resp_events(bufs[0].data_ptr(), per, 0xdef0 + 77 * b + rank, 0, nlocal, args.svcs, 0xFFFFFFFF)
             eng.handle_resp_events_dev(sg, bufs[0].data_ptr(), per)
             ingested.append([per, 0xdef0 + 77 * b + rank, 0xFFFFFFFF, 1])
-        eng.window_close(tusec=0)
+        close(tusec=0)
         segs[0] = eng.gen_resp_events(bufs[0].data_ptr(), args.events, 0x67796565746121 + 1000 * rank, 0, nlocal, args.svcs, args.zipf_milli)
         eng.sync()
         # ... and one full buffer cycle of ordinary windows, so that every key has re-clustered at least once: a production engine's
@@ -293,14 +380,14 @@ def main():
         for i in range(args.prime_windows):
             b = i % nbuf
             eng.handle_resp_events_dev(segs[b], bufs[b].data_ptr(), args.events)
-            eng.window_close(tusec=0)
+            close(tusec=0)
             buf_uses[b] += 1
         eng.sync()
 
     def step(i):
         b = i % nbuf
         eng.handle_resp_events_dev(segs[b], bufs[b].data_ptr(), args.events)
-        eng.window_close(tusec=5_000_000 * (i + 1))
+        close(tusec=5_000_000 * (i + 1))
         buf_uses[b] += 1
 
     for i in range(args.warmup):
@@ -390,7 +477,7 @@ def main():
                        "events_per_rank_per_step": args.events, "service_keys_total": args.hosts * args.svcs,
                        "service_keys_rank0": nsvc,
                        "sketches": "exact RESP_TIME_HASH histogram + CONN_BITMAP + HLL p=14 + CMS 4x65536 + t-digest %d clusters + %d-value buffer per key" % (capi.TD_NB, capi.TD_PEND_CAP),
-                       "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world},
+                       "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world, "exchange": exchange},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": alg_bytes,
@@ -420,6 +507,7 @@ def main():
                     out["cpu_baseline"]["reference_hist_allcores_value"] = ref_rate["mt_value"]
                     out["cpu_baseline"]["reference_hist_allcores"] = ref_rate["mt_cores"]
         print(json.dumps(out), flush=True)
+    eng.leave_rccl()
     eng.close()
     bad = rank == 0 and out.get("parity_ok") is False
     if world > 1:

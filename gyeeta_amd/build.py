@@ -29,7 +29,8 @@ def build(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-Wno-unused-value", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-function", "-Wno-unused-value", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES] + [
+               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]  # the window exchange (ncclAllReduce / ncclAllGather) lives in the library
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -10,6 +10,7 @@ OK, ERR_INVAL, ERR_NOMEM, ERR_HIP, ERR_NOTFOUND, ERR_NOT_OWNER, ERR_STATE = 0, -
 MAX_BUCKETS, TD_NB, HLL_P, CMS_D, CMS_W, NSTATES, TOPN = 16, 200, 14, 4, 65536, 6, 10
 NLEVELS, LEVEL_RING = 4, 10
 TD_PEND_CAP = 768
+RCCL_UID_BYTES = 128
 KINDS = {"RESP_TIME_HASH": 0, "SEMI_LOG_HASH": 1, "SEMI_LOG_HASH_LO": 2, "DURATION_HASH": 3, "HASH_10_5000": 4, "HASH_5_250": 5,
          "HASH_1_3000": 6, "PERCENT_HASH": 7}
 
@@ -144,6 +145,11 @@ SIGNATURES = {
     "gys_tdigest_merge_slabs_dev": (C.c_int, [vp, vp, C.c_uint32, vp]),
     "gys_tdigest_slab_quantiles": (C.c_int, [vp, vp, f64p, C.c_uint32, f64p]),
     "gys_num_clusters": (C.c_uint32, [vp]),
+    "gys_rccl_unique_id": (C.c_int, [u8p]),
+    "gys_rccl_comm_create": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
+    "gys_rccl_comm_destroy": (C.c_int, [vp]),
+    "gys_window_close_rccl": (C.c_int, [vp, vp, C.c_uint64]),
+    "gys_tdigest_global_rccl": (C.c_int, [vp, vp, vp]),
     "gys_tdigest_sql_text": (C.c_int, [vp, C.c_uint64, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_tdigest_sql_binary": (C.c_int, [vp, C.c_uint64, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_query_hist_level_stats": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(TimeHistVal), C.c_uint32, i64p, i64p, f64p]),

@@ -17,6 +17,8 @@
 #include <unordered_set>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "gys_kernels.hpp"
 #include "gys_rollup.hpp"
 
@@ -2202,6 +2204,94 @@ int gys_tdigest_slab_quantiles(gys_ctx *c, const gys_tdigest_slab *d_slab, const
 }
 
 uint32_t gys_num_clusters(gys_ctx *c) { return c ? (uint32_t)c->cluster_names.size() : 0; }
+
+// ------------------------------------------------------------------------------------------------ RCCL exchange in the library
+#define NCCLCHK(expr)                                                                          \
+	do {                                                                                   \
+		const ncclResult_t r_ = (expr);                                                \
+		if (r_ != ncclSuccess) {                                                       \
+			set_err("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+			return GYS_ERR_HIP;                                                    \
+		}                                                                              \
+	} while (0)
+
+static_assert(sizeof(ncclUniqueId) == GYS_RCCL_UID_BYTES, "gysketch.h carries an ncclUniqueId as 128 opaque bytes");
+
+int gys_rccl_unique_id(uint8_t uid[GYS_RCCL_UID_BYTES])
+{
+	if (!uid) return GYS_ERR_INVAL;
+	ncclUniqueId id;
+	NCCLCHK(ncclGetUniqueId(&id));
+	memcpy(uid, &id, sizeof(id));
+	return GYS_OK;
+}
+
+int gys_rccl_comm_create(gys_ctx *c, const uint8_t uid[GYS_RCCL_UID_BYTES], int nranks, int rank, void **comm)
+{
+	if (!c || !uid || !comm || nranks < 1 || rank < 0 || rank >= nranks) return GYS_ERR_INVAL;
+	if ((uint32_t)nranks != std::max<uint32_t>(c->cfg.nranks, 1) || (uint32_t)rank != c->cfg.rank) {
+		set_err("communicator (%d of %d) does not match gys_config rank / nranks (%u of %u)", rank, nranks, c->cfg.rank, c->cfg.nranks);
+		return GYS_ERR_INVAL;
+	}
+	HIPCHK(hipSetDevice(c->device));
+	ncclUniqueId id;
+	memcpy(&id, uid, sizeof(id));
+	ncclComm_t cm = nullptr;
+	NCCLCHK(ncclCommInitRank(&cm, nranks, id, rank));
+	*comm = (void *)cm;
+	return GYS_OK;
+}
+
+int gys_rccl_comm_destroy(void *comm)
+{
+	if (!comm) return GYS_ERR_INVAL;
+	NCCLCHK(ncclCommDestroy((ncclComm_t)comm));
+	return GYS_OK;
+}
+
+int gys_window_close_rccl(gys_ctx *c, void *comm, uint64_t tusec)
+{
+	if (!c || !comm) return GYS_ERR_INVAL;
+	int rc = gys_window_prepare(c, tusec);
+	if (rc) return rc;
+	gys_reduce_section sec[4];
+	uint32_t nsec = 0;
+	rc = gys_reduce_sections(c, sec, &nsec);
+	if (rc) return rc;
+	{
+		ProfScope ps(c, "window_rccl");
+		NCCLCHK(ncclGroupStart());
+		for (uint32_t i = 0; i < nsec; ++i) {
+			const ncclDataType_t dt = sec[i].dtype == 0 ? ncclUint8 : (sec[i].dtype == 1 ? ncclUint32 : ncclInt64);
+			const ncclRedOp_t op = sec[i].op == 0 ? ncclMax : ncclSum;
+			NCCLCHK(ncclAllReduce(sec[i].dev_ptr, sec[i].dev_ptr, sec[i].nelems, dt, op, (ncclComm_t)comm, c->stream));
+		}
+		NCCLCHK(ncclGroupEnd());
+	}
+	return gys_window_finish(c);
+}
+
+int gys_tdigest_global_rccl(gys_ctx *c, void *comm, gys_tdigest_slab *d_out)
+{
+	if (!c || !comm || !d_out) return GYS_ERR_INVAL;
+	TDIGEST_CHECK();
+	int nranks = 1, rank = 0;
+	NCCLCHK(ncclCommCount((ncclComm_t)comm, &nranks));
+	NCCLCHK(ncclCommUserRank((ncclComm_t)comm, &rank));
+	gys_tdigest_slab *d_all = nullptr;
+	HIPCHK(hipMalloc((void **)&d_all, sizeof(gys_tdigest_slab) * (size_t)nranks));
+	int rc = gys_tdigest_rollup_dev(c, GYS_ROLLUP_GLOBAL, d_all + rank); // in place: this rank's slab sits at its own position
+	if (rc == GYS_OK) {
+		const ncclResult_t r = ncclAllGather(d_all + rank, d_all, sizeof(gys_tdigest_slab), ncclUint8, (ncclComm_t)comm, c->stream);
+		if (r != ncclSuccess) {
+			set_err("ncclAllGather failed: %s", ncclGetErrorString(r));
+			rc = GYS_ERR_HIP;
+		}
+	}
+	if (rc == GYS_OK) rc = gys_tdigest_merge_slabs_dev(c, d_all, (uint32_t)nranks, d_out); // (synchronises the stream)
+	hipFree(d_all);
+	return rc;
+}
 
 uint32_t gys_num_services(gys_ctx *c) { return c ? c->nsvc : 0; }
 uint32_t gys_num_hosts(gys_ctx *c) { return c ? (uint32_t)c->hosts.size() : 0; }

@@ -11,7 +11,7 @@
 //                             int nconns, uint8_t *pendptr, POOL_ALLOC_ARRAY*)            :2091
 //   bool partha_listener_state(const std::shared_ptr<PARTHA_INFO>&, const comm::LISTENER_STATE_NOTIFY*,  partha_listener_state(machine_id, pone, nconns, pendptr)
 //                             int nconns, uint8_t *pendptr, POOL_ALLOC_ARRAY*, PGConnPool&, bool) :2129
-//   void send_cluster_state() noexcept                                                    :2155  send_cluster_state(allreduce_cb)
+//   void send_cluster_state() noexcept                                                    :2155  send_cluster_state_rccl(tusec) (RCCL inside the library) / send_cluster_state(tusec, reduce_cb)
 //   TCP_SOCK_HANDLER::handle_ipv4_resp_event(tcp_ipv4_resp_event_t*, bool) (gy_socket_stat.cc:1517)  handle_ipv4_resp_events(machine_id, pevents, n)
 //   web_curr_listener_summ (server/gy_mnodehandle.cc:1628)                                       get_listener_summ(machine_id, out)
 //
@@ -39,7 +39,14 @@ public:
 	{
 		if (gys_create(&cfg, &ctx_) != GYS_OK) throw std::runtime_error(std::string("gys_create: ") + gys_last_error());
 	}
-	~GYS_MCONN_HANDLER() { gys_destroy(ctx_); }
+	~GYS_MCONN_HANDLER()
+	{
+		if (comm_) {
+			gys_sync(ctx_);
+			gys_rccl_comm_destroy(comm_);
+		}
+		gys_destroy(ctx_);
+	}
 	GYS_MCONN_HANDLER(const GYS_MCONN_HANDLER &) = delete;
 	GYS_MCONN_HANDLER &operator=(const GYS_MCONN_HANDLER &) = delete;
 
@@ -111,6 +118,20 @@ public:
 		(void)gys_window_finish(ctx_);
 	}
 
+	// The multi-GPU form: one process per GPU, every rank joins the communicator once (rank 0 makes the id with gys_rccl_unique_id and
+	// hands the 128 bytes to the others over whatever channel the deployment has) and then closes every window with the four
+	// register families all-reduced over xGMI INSIDE the library (ncclAllReduce x 4 in one ncclGroup on the context stream).
+	bool join_cluster(const uint8_t uid[GYS_RCCL_UID_BYTES], int nranks, int rank) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		return gys_rccl_comm_create(ctx_, uid, nranks, rank, &comm_) == GYS_OK;
+	}
+	void send_cluster_state_rccl(uint64_t tusec) noexcept
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		if (comm_) (void)gys_window_close_rccl(ctx_, comm_, tusec);
+	}
+
 	// web_curr_listener_summ: LISTEN_SUMM_STATS<int> of one partha (fields map 1:1 onto svcsumm JSON, gy_mfields.h:768-790)
 	bool get_listener_summ(const uint8_t machine_id[16], gys_svcsumm &out) noexcept
 	{
@@ -175,6 +196,7 @@ private:
 	}
 
 	gys_ctx *ctx_ = nullptr;
+	void *comm_ = nullptr; // ncclComm_t
 	std::mutex mu_;
 };
 

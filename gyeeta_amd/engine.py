@@ -192,6 +192,28 @@ class SketchEngine:
 
     window_close = send_cluster_state
 
+    # the same boundary with the collectives INSIDE the library (RCCL, no torch in the data path): gys_window_close_rccl
+    def join_rccl(self, uid_bytes):
+        """uid_bytes: the 128 bytes of gys_rccl_unique_id from rank 0 (every rank must call this; ncclCommInitRank is collective)"""
+        uid = (C.c_uint8 * capi.RCCL_UID_BYTES)(*uid_bytes)
+        comm = C.c_void_p()
+        capi.check(self.L.gys_rccl_comm_create(self.h, uid, max(self.nranks, 1), self.rank, C.byref(comm)))
+        self.comm = comm
+
+    def rccl_unique_id(self):
+        uid = (C.c_uint8 * capi.RCCL_UID_BYTES)()
+        capi.check(self.L.gys_rccl_unique_id(uid))
+        return bytes(uid)
+
+    def window_close_rccl(self, tusec=0):
+        capi.check(self.L.gys_window_close_rccl(self.h, self.comm, tusec))
+
+    def leave_rccl(self):
+        if getattr(self, "comm", None):
+            self.sync()
+            capi.check(self.L.gys_rccl_comm_destroy(self.comm))
+            self.comm = None
+
     def sync(self):
         capi.check(self.L.gys_sync(self.h))
 

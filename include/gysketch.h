@@ -286,6 +286,23 @@ int gys_tdigest_slab_quantiles(gys_ctx *ctx, const gys_tdigest_slab *d_slab, con
 uint32_t gys_num_clusters(gys_ctx *ctx);
 
 /* -------------------------------------------------------------------------------------------------------------------
+ * The window exchange inside the library (RCCL over xGMI; no torch, no caller-written collective).  Replaces
+ * MCONN_HANDLER::send_cluster_state -> SHCONN_HANDLER::aggregate_cluster_state (server/gy_mconnhdlr.cc:16052-16118,
+ * server/gy_shconnhdlr.cc:4583-4720): one process per GPU, every rank calls gys_window_close_rccl at the 5-s boundary.
+ * The communicator handle is an ncclComm_t carried as void* (no RCCL type in this header); a caller that already owns one
+ * (e.g. from its own ncclCommInitRank) may pass it directly. */
+#define GYS_RCCL_UID_BYTES 128
+int gys_rccl_unique_id(uint8_t uid[GYS_RCCL_UID_BYTES]);                        /* rank 0: ncclGetUniqueId; hand the bytes to every rank */
+int gys_rccl_comm_create(gys_ctx *ctx, const uint8_t uid[GYS_RCCL_UID_BYTES], int nranks, int rank, void **comm); /* ncclCommInitRank on ctx's device */
+int gys_rccl_comm_destroy(void *comm);
+/* gys_window_prepare, then the four register families of gys_reduce_sections all-reduced in place (u8 MAX, u32 SUM, i64 SUM, i64 MAX)
+ * as ONE ncclGroup on the context stream, then gys_window_finish.  Asynchronous like every other call (gys_sync to wait). */
+int gys_window_close_rccl(gys_ctx *ctx, void *comm, uint64_t tusec);
+/* the global response-time digest across ranks: this rank's GYS_ROLLUP_GLOBAL slab, ncclAllGather of the fixed-size slabs, fold in
+ * rank order (gys_tdigest_merge_slabs_dev) into d_out[0] (DEVICE) -- the same slab on every rank */
+int gys_tdigest_global_rccl(gys_ctx *ctx, void *comm, gys_tdigest_slab *d_out);
+
+/* -------------------------------------------------------------------------------------------------------------------
  * a service's response-time t-digest in the external forms of the Postgres tdigest type, so that the reference's SQL
  * percentile aggregation -- public.tdigest(col, 100) / public.tdigest_percentile(digest, p), common/gy_query_common.cc:1818-1855,
  * extension loaded at :3387 -- can consume engine digests ('<text>'::public.tdigest, or the binary send/recv form).

@@ -109,6 +109,29 @@ int main(int argc, char **argv)
 			return 17;
 		}
 	}
+	// the multi-GPU form of the window boundary with the collective INSIDE the library: a one-rank RCCL communicator (this box has
+	// one GPU) created through the C ABI; the all-reduced registers of a one-rank job equal the local ones
+	{
+		uint8_t uid[GYS_RCCL_UID_BYTES];
+		if (gys_rccl_unique_id(uid) != GYS_OK) {
+			fprintf(stderr, "gys_rccl_unique_id: %s\n", gys_last_error());
+			return 18;
+		}
+		if (!h.join_cluster(uid, 1, 0)) {
+			fprintf(stderr, "join_cluster: %s\n", gys_last_error());
+			return 19;
+		}
+		if (!h.partha_listener_state(mid, recs, 10, (const uint8_t *)(recs + 10)) || !h.partha_host_state(mid, st)) return 20;
+		h.send_cluster_state_rccl(15000000);
+		gys_cluster_state c2{};
+		gys_svcsumm s2{};
+		if (!h.get_cluster_state("prod", c2) || !h.get_listener_summ(mid, s2)) return 21;
+		if (c2.nhosts != 1 || c2.total_qps != (uint32_t)exp_qps || c2.nsvc != 10 || s2.tot_qps != exp_qps) {
+			fprintf(stderr, "rccl window: nhosts %u total_qps %u nsvc %u tot_qps %d\n", c2.nhosts, c2.total_qps, c2.nsvc, s2.tot_qps);
+			return 22;
+		}
+		printf("rccl window ok\n");
+	}
 	printf("shim ok\n");
 	return 0;
 }
