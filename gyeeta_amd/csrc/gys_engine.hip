@@ -13,6 +13,8 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -216,6 +218,22 @@ struct gys_ctx {
 	bool have_last = false;
 
 	// staging for host-buffer ingest
+	// host-pointer boundary (gys_ingest_resp_events / _tcp_conn / _listener_state): a ring of pinned host + device staging
+	// buffers.  A call copies the caller's records into a slot's pinned buffer (the caller's buffer is free when the call returns --
+	// the reference's pone points into the L1 receive buffer, valid only for the call), enqueues ONE H2D copy + the kernels and
+	// returns without waiting for the GPU; a slot is reused after the event recorded behind its kernels has fired.  Up to
+	// MAX_L2_MISC_THREADS = 16 L2 threads (server/gy_mconnhdlr.h:60) call concurrently: slots are handed out under stage_mu, the
+	// memcpy into pinned memory runs outside any lock, the enqueue (stream order, shared flags) under enq_mu.
+	struct Stage {
+		uint8_t *h = nullptr, *d = nullptr;
+		uint64_t cap = 0;
+		hipEvent_t done = nullptr;
+	};
+	static constexpr int NSTAGE = 16;
+	Stage stage[NSTAGE];
+	std::vector<int> stage_free;
+	std::mutex stage_mu, enq_mu;
+	std::condition_variable stage_cv;
 	uint8_t *dev_staging = nullptr;
 	uint64_t dev_staging_bytes = 0;
 	uint32_t *dev_offsets = nullptr;
@@ -299,6 +317,47 @@ int dev_alloc(T **p, uint64_t count, bool zero = true)
 	HIPCHK(hipMalloc((void **)p, count * sizeof(T)));
 	if (zero) HIPCHK(hipMemset(*p, 0, count * sizeof(T)));
 	return GYS_OK;
+}
+
+// ---- staging ring of the host-pointer boundary (gys_ctx::Stage)
+int stage_acquire(gys_ctx *c, uint64_t bytes, int *idx)
+{
+	int i;
+	{
+		std::unique_lock<std::mutex> lk(c->stage_mu);
+		c->stage_cv.wait(lk, [&] { return !c->stage_free.empty(); });
+		i = c->stage_free.back();
+		c->stage_free.pop_back();
+	}
+	gys_ctx::Stage &st = c->stage[i];
+	hipError_t e = hipSuccess;
+	if (!st.done) e = hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventSynchronize(st.done); // the kernels that read this slot last time are done (no-op unless the ring wrapped)
+	if (e == hipSuccess && bytes > st.cap) {
+		if (st.h) (void)hipHostFree(st.h);
+		if (st.d) (void)hipFree(st.d);
+		st.h = st.d = nullptr;
+		st.cap = align_up(std::max<uint64_t>(bytes, 1u << 20), 4096);
+		e = hipHostMalloc((void **)&st.h, st.cap, hipHostMallocDefault);
+		if (e == hipSuccess) e = hipMalloc((void **)&st.d, st.cap);
+		if (e != hipSuccess) st.cap = 0;
+	}
+	if (e != hipSuccess) {
+		set_err("staging slot: %s", hipGetErrorString(e));
+		std::lock_guard<std::mutex> lk(c->stage_mu);
+		c->stage_free.push_back(i);
+		c->stage_cv.notify_one();
+		return GYS_ERR_HIP;
+	}
+	*idx = i;
+	return GYS_OK;
+}
+
+void stage_release(gys_ctx *c, int idx)
+{
+	std::lock_guard<std::mutex> lk(c->stage_mu);
+	c->stage_free.push_back(idx);
+	c->stage_cv.notify_one();
 }
 
 int ensure_staging(gys_ctx *c, uint64_t bytes, uint32_t nrec)
@@ -937,6 +996,34 @@ int run_lstate(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, co
 	return GYS_OK;
 }
 
+// records of one variable-stride batch [batch, batch + bytes) + their offsets through a staging slot: one pinned copy, one H2D copy
+// (records, then the offsets behind them), the ingest kernel, no wait
+int ingest_staged_records(gys_ctx *c, uint32_t host, const void *batch, uint64_t bytes, const std::vector<uint32_t> &offs, bool conn)
+{
+	const uint64_t off_at = align_up(bytes, 8), total = off_at + offs.size() * 4;
+	int si;
+	int rc = stage_acquire(c, total, &si);
+	if (rc) return rc;
+	gys_ctx::Stage &st = c->stage[si];
+	memcpy(st.h, batch, bytes);
+	memcpy(st.h + off_at, offs.data(), offs.size() * 4);
+	{
+		std::lock_guard<std::mutex> g(c->enq_mu);
+		hipError_t e = hipMemcpyAsync(st.d, st.h, total, hipMemcpyHostToDevice, c->stream);
+		if (e == hipSuccess) {
+			rc = conn ? run_conn(c, st.d, (const uint32_t *)(st.d + off_at), (uint32_t)offs.size())
+				  : run_lstate(c, st.d, (const uint32_t *)(st.d + off_at), nullptr, host, (uint32_t)offs.size());
+			e = hipEventRecord(st.done, c->stream);
+		}
+		if (e != hipSuccess) {
+			set_err("ingest: %s", hipGetErrorString(e));
+			rc = GYS_ERR_HIP;
+		}
+	}
+	stage_release(c, si);
+	return rc;
+}
+
 } // namespace
 
 // ==================================================================================================== C ABI
@@ -969,6 +1056,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		return GYS_ERR_HIP;
 	}
 	gys_ctx *c = new gys_ctx();
+	for (int i = 0; i < gys_ctx::NSTAGE; ++i) c->stage_free.push_back(i);
 	c->cfg = *cfg;
 	if (cfg->device >= 0) {
 		c->device = cfg->device;
@@ -1136,6 +1224,11 @@ void gys_destroy(gys_ctx *c)
 		if (sl.xdev) hipFree(sl.xdev);
 		if (sl.done) hipEventDestroy(sl.done);
 	}
+	for (auto &st : c->stage) {
+		if (st.h) hipHostFree(st.h);
+		if (st.d) hipFree(st.d);
+		if (st.done) hipEventDestroy(st.done);
+	}
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
@@ -1296,14 +1389,27 @@ int gys_ingest_resp_events(gys_ctx *c, const uint8_t machine_id[16], const void 
 	int rc = lookup_host(c, machine_id, &host);
 	if (rc) return rc;
 	if (!nevents) return GYS_OK;
-	rc = ensure_staging(c, (uint64_t)nevents * 24, 0);
+	const uint64_t bytes = (uint64_t)nevents * 24;
+	int si;
+	rc = stage_acquire(c, bytes, &si);
 	if (rc) return rc;
-	HIPCHK(hipMemcpyAsync(c->dev_staging, ev24, (uint64_t)nevents * 24, hipMemcpyHostToDevice, c->stream));
-	gys_resp_seg seg{host, 0, 0};
-	rc = run_resp_batch(c, &seg, 1, c->dev_staging, nevents);
-	if (rc) return rc;
-	HIPCHK(hipStreamSynchronize(c->stream)); // ev24 is only valid during the call and dev_staging is reused by the next one
-	return GYS_OK;
+	gys_ctx::Stage &st = c->stage[si];
+	memcpy(st.h, ev24, bytes); // the caller's buffer is free from here on
+	{
+		std::lock_guard<std::mutex> g(c->enq_mu);
+		hipError_t e = hipMemcpyAsync(st.d, st.h, bytes, hipMemcpyHostToDevice, c->stream);
+		if (e == hipSuccess) {
+			gys_resp_seg seg{host, 0, 0};
+			rc = run_resp_batch(c, &seg, 1, st.d, nevents);
+			e = hipEventRecord(st.done, c->stream);
+		}
+		if (e != hipSuccess) {
+			set_err("gys_ingest_resp_events: %s", hipGetErrorString(e));
+			rc = GYS_ERR_HIP;
+		}
+	}
+	stage_release(c, si);
+	return rc;
 }
 
 int gys_ingest_tcp_conn_dev(gys_ctx *c, const void *d_batch, const uint32_t *d_offsets, uint32_t nconns)
@@ -1328,15 +1434,7 @@ int gys_ingest_tcp_conn(gys_ctx *c, const uint8_t machine_id[16], const void *ba
 	}, offs);
 	if (rc) return rc;
 	if (offs.empty()) return GYS_OK;
-	const uint64_t bytes = (const uint8_t *)pend - (const uint8_t *)batch;
-	rc = ensure_staging(c, bytes, (uint32_t)offs.size());
-	if (rc) return rc;
-	HIPCHK(hipMemcpyAsync(c->dev_staging, batch, bytes, hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipMemcpyAsync(c->dev_offsets, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, c->stream));
-	rc = run_conn(c, c->dev_staging, c->dev_offsets, (uint32_t)offs.size());
-	if (rc) return rc;
-	HIPCHK(hipStreamSynchronize(c->stream)); // offs is a stack-owned pageable buffer
-	return GYS_OK;
+	return ingest_staged_records(c, host, batch, (const uint8_t *)pend - (const uint8_t *)batch, offs, /*conn*/ true);
 }
 
 int gys_ingest_listener_state_dev(gys_ctx *c, const void *d_batch, const uint32_t *d_offsets, const uint32_t *d_host_slot, uint32_t nrecs)
@@ -1357,15 +1455,7 @@ int gys_ingest_listener_state(gys_ctx *c, const uint8_t machine_id[16], const vo
 	rc = walk_batch((const uint8_t *)batch, nrecs, (const uint8_t *)pend, 88, [](const uint8_t *p) { return (uint32_t)(88u + p[85] + p[86]); }, offs);
 	if (rc) return rc;
 	if (offs.empty()) return GYS_OK;
-	const uint64_t bytes = (const uint8_t *)pend - (const uint8_t *)batch;
-	rc = ensure_staging(c, bytes, (uint32_t)offs.size());
-	if (rc) return rc;
-	HIPCHK(hipMemcpyAsync(c->dev_staging, batch, bytes, hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipMemcpyAsync(c->dev_offsets, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, c->stream));
-	rc = run_lstate(c, c->dev_staging, c->dev_offsets, nullptr, host, (uint32_t)offs.size());
-	if (rc) return rc;
-	HIPCHK(hipStreamSynchronize(c->stream));
-	return GYS_OK;
+	return ingest_staged_records(c, host, batch, (const uint8_t *)pend - (const uint8_t *)batch, offs, /*conn*/ false);
 }
 
 // ------------------------------------------------------------------------------------------------ wire front-end

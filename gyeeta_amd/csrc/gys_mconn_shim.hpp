@@ -22,6 +22,7 @@
 #include <ctime>
 #include <functional>
 #include <mutex>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 
@@ -55,12 +56,12 @@ public:
 	// partha registration (PM_CONNECT) and NOTIFY_NEW_LISTENER: the two control-plane facts the data path needs
 	bool partha_register(const uint8_t machine_id[16], const char *cluster_name) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		return gys_register_host(ctx_, machine_id, cluster_name, nullptr) == GYS_OK;
 	}
 	bool partha_new_listeners(const uint8_t machine_id[16], const gys_listener_info *arr, uint32_t n) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		return gys_register_listeners(ctx_, machine_id, arr, n, nullptr) == GYS_OK;
 	}
 
@@ -68,7 +69,7 @@ public:
 	bool partha_tcp_conn_info(const uint8_t machine_id[16], const void *pone, int nconns, const uint8_t *pendptr) noexcept
 	{
 		if (!pone || nconns < 0) return false;
-		std::lock_guard<std::mutex> g(mu_); // up to 16 L2 threads call concurrently (gy_mconnhdlr.h:60); one context == one stream
+		std::shared_lock<std::shared_mutex> g(mu_); // up to 16 L2 threads call concurrently (gy_mconnhdlr.h:60); one context == one stream
 		return gys_ingest_tcp_conn(ctx_, machine_id, pone, (uint32_t)nconns, pendptr) == GYS_OK;
 	}
 
@@ -76,7 +77,7 @@ public:
 	bool partha_listener_state(const uint8_t machine_id[16], const void *pone, int nconns, const uint8_t *pendptr) noexcept
 	{
 		if (!pone || nconns < 0) return false;
-		std::lock_guard<std::mutex> g(mu_);
+		std::shared_lock<std::shared_mutex> g(mu_);
 		return gys_ingest_listener_state(ctx_, machine_id, pone, (uint32_t)nconns, pendptr) == GYS_OK;
 	}
 
@@ -84,7 +85,7 @@ public:
 	// (MCONN_HANDLER::handle_l1 -> handle_l2_misc dispatch, gy_mconnhdlr.cc:4700-4792).  nconsumed: whole messages consumed.
 	bool handle_partha_stream(const uint8_t machine_id[16], const void *pbuf, uint64_t nbytes, uint64_t *nconsumed = nullptr) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		gys_comm_stats st{};
 		const bool ok = gys_ingest_comm_stream(ctx_, machine_id, pbuf, nbytes, &st) == GYS_OK;
 		if (nconsumed) *nconsumed = st.bytes_consumed;
@@ -94,21 +95,21 @@ public:
 	// comm::HOST_STATE_NOTIFY store read by send_cluster_state (gy_mconnhdlr.cc:16052-16075)
 	bool partha_host_state(const uint8_t machine_id[16], const gys_host_state &st) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		return gys_ingest_host_state(ctx_, machine_id, &st) == GYS_OK;
 	}
 
 	// TCP_SOCK_HANDLER::handle_ipv4_resp_event for a batch of raw 24-byte events of one host
 	bool handle_ipv4_resp_events(const uint8_t machine_id[16], const void *pevents, uint32_t nevents) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::shared_lock<std::shared_mutex> g(mu_);
 		return gys_ingest_resp_events(ctx_, machine_id, pevents, nevents) == GYS_OK;
 	}
 
 	// MCONN_HANDLER::send_cluster_state (scheduled every 5000 ms, gy_mconnhdlr.cc:207-210) + the shyama-side aggregation
 	void send_cluster_state(uint64_t tusec, const ReduceFn &reduce = {}) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		if (gys_window_prepare(ctx_, tusec) != GYS_OK) return;
 		if (reduce) {
 			gys_reduce_section secs[4];
@@ -123,24 +124,24 @@ public:
 	// register families all-reduced over xGMI INSIDE the library (ncclAllReduce x 4 in one ncclGroup on the context stream).
 	bool join_cluster(const uint8_t uid[GYS_RCCL_UID_BYTES], int nranks, int rank) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		return gys_rccl_comm_create(ctx_, uid, nranks, rank, &comm_) == GYS_OK;
 	}
 	void send_cluster_state_rccl(uint64_t tusec) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		if (comm_) (void)gys_window_close_rccl(ctx_, comm_, tusec);
 	}
 
 	// web_curr_listener_summ: LISTEN_SUMM_STATS<int> of one partha (fields map 1:1 onto svcsumm JSON, gy_mfields.h:768-790)
 	bool get_listener_summ(const uint8_t machine_id[16], gys_svcsumm &out) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		return gys_query_svcsumm(ctx_, machine_id, &out) == GYS_OK;
 	}
 	bool get_cluster_state(const char *cluster, gys_cluster_state &out) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		return gys_query_clusterstate(ctx_, cluster, &out) == GYS_OK;
 	}
 
@@ -149,7 +150,7 @@ public:
 	int get_resp_level_stats(uint64_t glob_id, int level, time_t tnow, gys_time_hist_val *pstats, size_t nstats, int64_t &tcount, int64_t &tsum,
 				 double &mean_val) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		return gys_query_hist_level_stats(ctx_, glob_id, level, (uint64_t)tnow * 1000000ull, pstats, (uint32_t)nstats, &tcount, &tsum, &mean_val) == GYS_OK
 			       ? 0
 			       : -1;
@@ -159,7 +160,7 @@ public:
 	// [first_slot, first_slot + nslots), as TCP_LISTENER::get_curr_state fills it (common/gy_socket_stat.cc:2098-2112)
 	bool listener_day_stats(time_t tnow, uint32_t first_slot, uint32_t nslots, gys_listener_day_stats *pout) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		return gys_export_day_stats(ctx_, (uint64_t)tnow * 1000000ull, first_slot, nslots, pout) == GYS_OK;
 	}
 
@@ -181,7 +182,7 @@ private:
 	template <typename F>
 	bool json_call(std::string &out, F &&f) noexcept
 	{
-		std::lock_guard<std::mutex> g(mu_);
+		std::unique_lock<std::shared_mutex> g(mu_);
 		try {
 			size_t need = 0;
 			int rc = f(nullptr, 0, &need);
@@ -197,7 +198,7 @@ private:
 
 	gys_ctx *ctx_ = nullptr;
 	void *comm_ = nullptr; // ncclComm_t
-	std::mutex mu_;
+	std::shared_mutex mu_; // ingest calls share it (thread-safe among themselves inside the library); registration, window close and queries are exclusive
 };
 
 } // namespace gyeeta_amd

@@ -120,7 +120,16 @@ typedef struct {
 int gys_register_listeners(gys_ctx *ctx, const uint8_t machine_id[16], const gys_listener_info *arr, uint32_t n, uint32_t *first_slot);
 
 /* -------------------------------------------------------------------------------------------------------------------
- * ingest */
+ * ingest
+ *
+ * Host-pointer entry points (gys_ingest_resp_events, gys_ingest_tcp_conn, gys_ingest_listener_state): the caller's buffer is only
+ * read DURING the call (the reference's pone points into the L1 receive buffer, freed after the dispatch switch) and
+ * the call does NOT wait for the GPU: the records are copied into a slot of a ring of 16 pinned staging buffers, one H2D copy and
+ * the ingest kernels are enqueued, and the call returns; a slot is reused once the event recorded behind its kernels has fired.
+ * These three calls may be made concurrently from several threads (up to the reference's MAX_L2_MISC_THREADS = 16,
+ * server/gy_mconnhdlr.h:60) on the same context.  Everything else -- registration, the _dev entry points, the wire front end, the
+ * window boundary, queries and exports -- must not run concurrently with any other call on the context (gys_mconn_shim.hpp holds a
+ * shared / exclusive lock accordingly).  Results become visible to queries in stream order; gys_sync waits for them. */
 
 /* Raw response events in the eBPF layout tcp_ipv4_resp_event_t (common/gy_ebpf_kernel.h:106-111, 24 bytes: saddr,daddr,netns,
  * sport,dport (network order), lsndtime, lrcvtime).  Replaces TCP_SOCK_HANDLER::handle_ipv4_resp_event + handle_tcp_resp_event
