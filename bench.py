@@ -313,6 +313,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap rendezvous over loopback (see gys_rccl_unique_id)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -346,8 +347,25 @@ def main():
                 if rank == 0:
                     uid.copy_(torch.frombuffer(bytearray(eng.rccl_unique_id()), dtype=torch.uint8))
                 dist.broadcast(uid, src=0)
-                eng.join_rccl(bytes(uid.cpu().numpy().tolist()))
-                exchange = "rccl_in_library"
+                # ncclCommInitRank is collective and cannot be interrupted: join on a helper thread and give it 60 s; if the
+                # communicator does not come up on every rank the run continues on the torch.distributed path
+                import threading
+                res = {}
+
+                def _join():
+                    try:
+                        eng.join_rccl(bytes(uid.cpu().numpy().tolist()))
+                        res["ok"] = True
+                    except Exception as ex2:  # noqa: BLE001
+                        res["err"] = str(ex2)
+
+                th = threading.Thread(target=_join, daemon=True)
+                th.start()
+                th.join(60.0)
+                if res.get("ok"):
+                    exchange = "rccl_in_library"
+                else:
+                    raise RuntimeError(res.get("err", "ncclCommInitRank did not return within 60 s"))
             except Exception as ex:  # keep the run alive on the torch path
                 print(f"bench.py rank {rank}: in-library RCCL unavailable ({ex}); using torch.distributed", file=sys.stderr)
         ok = torch.tensor([1 if exchange == "rccl_in_library" else 0], device="cuda")

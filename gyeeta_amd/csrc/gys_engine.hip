@@ -2310,6 +2310,10 @@ static_assert(sizeof(ncclUniqueId) == GYS_RCCL_UID_BYTES, "gysketch.h carries an
 int gys_rccl_unique_id(uint8_t uid[GYS_RCCL_UID_BYTES])
 {
 	if (!uid) return GYS_ERR_INVAL;
+	// The exchange is between the GPUs of ONE node: unless the caller chose an interface, the bootstrap rendezvous goes over
+	// loopback -- RCCL otherwise takes the first non-loopback interface, and on hosts whose first interface is a tunnel / container
+	// bridge the ranks' connect() to it never returns (seen on part of the MI355X pool).  Must be set before RCCL's first call.
+	setenv("NCCL_SOCKET_IFNAME", "lo", 0);
 	ncclUniqueId id;
 	NCCLCHK(ncclGetUniqueId(&id));
 	memcpy(uid, &id, sizeof(id));
@@ -2324,6 +2328,7 @@ int gys_rccl_comm_create(gys_ctx *c, const uint8_t uid[GYS_RCCL_UID_BYTES], int 
 		return GYS_ERR_INVAL;
 	}
 	HIPCHK(hipSetDevice(c->device));
+	setenv("NCCL_SOCKET_IFNAME", "lo", 0); // (see gys_rccl_unique_id)
 	ncclUniqueId id;
 	memcpy(&id, uid, sizeof(id));
 	ncclComm_t cm = nullptr;

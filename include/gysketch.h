@@ -299,7 +299,8 @@ uint32_t gys_num_clusters(gys_ctx *ctx);
  * MCONN_HANDLER::send_cluster_state -> SHCONN_HANDLER::aggregate_cluster_state (server/gy_mconnhdlr.cc:16052-16118,
  * server/gy_shconnhdlr.cc:4583-4720): one process per GPU, every rank calls gys_window_close_rccl at the 5-s boundary.
  * The communicator handle is an ncclComm_t carried as void* (no RCCL type in this header); a caller that already owns one
- * (e.g. from its own ncclCommInitRank) may pass it directly. */
+ * (e.g. from its own ncclCommInitRank) may pass it directly.  One node: gys_rccl_unique_id / gys_rccl_comm_create set
+ * NCCL_SOCKET_IFNAME=lo unless the environment already names an interface (the bootstrap rendezvous then runs over loopback). */
 #define GYS_RCCL_UID_BYTES 128
 int gys_rccl_unique_id(uint8_t uid[GYS_RCCL_UID_BYTES]);                        /* rank 0: ncclGetUniqueId; hand the bytes to every rank */
 int gys_rccl_comm_create(gys_ctx *ctx, const uint8_t uid[GYS_RCCL_UID_BYTES], int nranks, int rank, void **comm); /* ncclCommInitRank on ctx's device */

@@ -21,7 +21,8 @@ static_assert(sizeof(ListenerStateNotify) == 88, "LISTENER_STATE_NOTIFY is 88 by
 
 int main(int argc, char **argv)
 {
-	if (argc < 2 || strcmp(argv[1], "run")) {
+	const bool rccl_mode = argc >= 2 && !strcmp(argv[1], "rccl");
+	if (argc < 2 || (strcmp(argv[1], "run") && !rccl_mode)) {
 		printf("link ok, abi %u\n", gys_abi_version());
 		return 0;
 	}
@@ -33,6 +34,7 @@ int main(int argc, char **argv)
 	cfg.max_services = 64;
 	cfg.max_clusters = 2;
 	cfg.enable_levels = 1;
+	fprintf(stderr, "[shim] create\n");
 	gyeeta_amd::GYS_MCONN_HANDLER h(cfg);
 	uint8_t mid[16];
 	for (int i = 0; i < 16; ++i) mid[i] = (uint8_t)(i * 7 + 1);
@@ -57,19 +59,54 @@ int main(int argc, char **argv)
 		exp_qps += (7 * i) / 5;
 		exp_active += i ? 1 : 0;
 	}
+	fprintf(stderr, "[shim] listener state\n");
 	if (!h.partha_listener_state(mid, recs, 10, (const uint8_t *)(recs + 10))) return 4;
 	gys_host_state st{};
 	st.ntasks = 50;
 	st.nlisten = 10;
 	st.curr_state = 1;
 	if (!h.partha_host_state(mid, st)) return 5;
+	fprintf(stderr, "[shim] window 1\n");
 	h.send_cluster_state(5000000);
+	fprintf(stderr, "[shim] queries\n");
 	gys_svcsumm s{};
 	if (!h.get_listener_summ(mid, s)) return 6;
 	gys_cluster_state c{};
 	if (!h.get_cluster_state("prod", c)) return 7;
 	printf("tot_qps %d nlisteners %d nactive %d cluster nhosts %u total_qps %u\n", s.tot_qps, s.nlisteners, s.nactive, c.nhosts, c.total_qps);
 	if (s.tot_qps != exp_qps || s.nlisteners != 10 || s.nactive != exp_active || c.nhosts != 1 || c.total_qps != (uint32_t)exp_qps || c.nsvc != 10) return 8;
+	if (rccl_mode) {
+	// the multi-GPU form of the window boundary with the collective INSIDE the library: a one-rank RCCL communicator (this box has
+		// one GPU) created through the C ABI; the all-reduced registers of a one-rank job equal the local ones
+		{
+			fprintf(stderr, "[shim] rccl\n");
+			uint8_t uid[GYS_RCCL_UID_BYTES];
+			if (gys_rccl_unique_id(uid) != GYS_OK) {
+				fprintf(stderr, "gys_rccl_unique_id: %s\n", gys_last_error());
+				return 18;
+			}
+			fprintf(stderr, "[shim] rccl join\n");
+			if (!h.join_cluster(uid, 1, 0)) {
+				fprintf(stderr, "join_cluster: %s\n", gys_last_error());
+				return 19;
+			}
+			fprintf(stderr, "[shim] rccl joined\n");
+			if (!h.partha_listener_state(mid, recs, 10, (const uint8_t *)(recs + 10)) || !h.partha_host_state(mid, st)) return 20;
+			fprintf(stderr, "[shim] rccl window\n");
+			h.send_cluster_state_rccl(15000000);
+			fprintf(stderr, "[shim] rccl queries\n");
+			gys_cluster_state c2{};
+			gys_svcsumm s2{};
+			if (!h.get_cluster_state("prod", c2) || !h.get_listener_summ(mid, s2)) return 21;
+			if (c2.nhosts != 1 || c2.total_qps != (uint32_t)exp_qps || c2.nsvc != 10 || s2.tot_qps != exp_qps) {
+				fprintf(stderr, "rccl window: nhosts %u total_qps %u nsvc %u tot_qps %d\n", c2.nhosts, c2.total_qps, c2.nsvc, s2.tot_qps);
+				return 22;
+			}
+			printf("rccl window ok\n");
+		}
+		printf("shim rccl ok\n");
+		return 0;
+	}
 	uint8_t other[16] = {9};
 	if (h.partha_listener_state(other, recs, 10, (const uint8_t *)(recs + 10))) return 9; // unknown partha -> false (reference: null partha_shr)
 	// the same window again through the wire front-end: one COMM_HEADER + EVENT_NOTIFY(NOTIFY_LISTENER_STATE) message, then the JSON query
@@ -80,6 +117,7 @@ int main(int argc, char **argv)
 		memcpy(msg, hdr, 16);
 		memcpy(msg + 16, ev, 8);
 		memcpy(msg + 24, recs, sizeof(recs));
+		fprintf(stderr, "[shim] stream\n");
 		uint64_t used = 0;
 		if (!h.handle_partha_stream(mid, msg, sizeof(msg), &used) || used != sizeof(msg)) return 10;
 		if (!h.partha_host_state(mid, st)) return 11;
@@ -108,29 +146,6 @@ int main(int argc, char **argv)
 			fprintf(stderr, "day stats: gid %llx p95_qps %u p95_nactive %u\n", (unsigned long long)ds[9].glob_id, ds[9].p95_qps, ds[9].p95_nactive);
 			return 17;
 		}
-	}
-	// the multi-GPU form of the window boundary with the collective INSIDE the library: a one-rank RCCL communicator (this box has
-	// one GPU) created through the C ABI; the all-reduced registers of a one-rank job equal the local ones
-	{
-		uint8_t uid[GYS_RCCL_UID_BYTES];
-		if (gys_rccl_unique_id(uid) != GYS_OK) {
-			fprintf(stderr, "gys_rccl_unique_id: %s\n", gys_last_error());
-			return 18;
-		}
-		if (!h.join_cluster(uid, 1, 0)) {
-			fprintf(stderr, "join_cluster: %s\n", gys_last_error());
-			return 19;
-		}
-		if (!h.partha_listener_state(mid, recs, 10, (const uint8_t *)(recs + 10)) || !h.partha_host_state(mid, st)) return 20;
-		h.send_cluster_state_rccl(15000000);
-		gys_cluster_state c2{};
-		gys_svcsumm s2{};
-		if (!h.get_cluster_state("prod", c2) || !h.get_listener_summ(mid, s2)) return 21;
-		if (c2.nhosts != 1 || c2.total_qps != (uint32_t)exp_qps || c2.nsvc != 10 || s2.tot_qps != exp_qps) {
-			fprintf(stderr, "rccl window: nhosts %u total_qps %u nsvc %u tot_qps %d\n", c2.nhosts, c2.total_qps, c2.nsvc, s2.tot_qps);
-			return 22;
-		}
-		printf("rccl window ok\n");
 	}
 	printf("shim ok\n");
 	return 0;

@@ -28,5 +28,16 @@ def test_shim_compiles_and_links_with_gxx(tmp_path):
 @pytest.mark.gpu
 def test_shim_runs_on_gpu(tmp_path):
     exe = _build(tmp_path)
-    r = subprocess.run([exe, "run"], capture_output=True, text=True)
+    r = subprocess.run(["timeout", "-s", "KILL", "120", exe, "run"], capture_output=True, text=True)
     assert r.returncode == 0 and "shim ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_shim_window_close_rccl_one_rank(tmp_path):
+    """the window boundary with the collectives inside the library (gys_window_close_rccl) from plain C++ with a one-rank communicator.
+    RCCL's own bootstrap (ncclCommInitRank) does not return on part of the GPU pool; that is reported as a skip, not as a hang."""
+    exe = _build(tmp_path)
+    r = subprocess.run(["timeout", "-s", "KILL", "60", exe, "rccl"], capture_output=True, text=True)
+    if r.returncode == -9 and "[shim] rccl join" in r.stderr and "[shim] rccl joined" not in r.stderr:
+        pytest.skip("ncclCommInitRank did not return within 60 s on this box (RCCL bootstrap); the in-library exchange was not exercised")
+    assert r.returncode == 0 and "shim rccl ok" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -361,57 +361,93 @@ def test_tdigest_rollup_host_cluster_global_bit_exact(torch_mod, oracle):
         eng.close()
 
 
-def test_window_close_rccl_inside_the_library(torch_mod, oracle):
+def _rccl_worker(q):
+    """body of test_window_close_rccl_inside_the_library, in its own process: RCCL's bootstrap (ncclCommInitRank) does not return on part
+    of the GPU pool, and a hang inside a C call cannot be interrupted from within the process"""
+    import ctypes as C
+    import torch
+    from gyeeta_amd import capi
+    from gyeeta_amd.engine import SketchEngine
+    from oracle import oracle
+    try:
+        rng = np.random.default_rng(31)
+        engs = [SketchEngine(max_hosts=4, max_services=32, max_batch_events=1 << 14) for _ in range(2)]
+        for e in engs:
+            for h in range(3):
+                mid = wire.machine_id(h)
+                e.register_host(mid, "cluster%d" % (h % 2))
+                s = np.arange(5)
+                e.register_listeners_np(mid, wire.glob_id(np.full(5, h), s), wire.listener_netns(h, s), wire.listener_port(s))
+        L = engs[0].L
+        uid = (C.c_uint8 * 128)()
+        capi.check(L.gys_rccl_unique_id(uid))
+        comm = C.c_void_p()
+        q.put("joining")
+        capi.check(L.gys_rccl_comm_create(engs[0].h, uid, 1, 0, C.byref(comm)))
+        q.put("joined")
+        for w in range(2):
+            for h in range(3):
+                ev = helpers.make_resp_events(rng, h, 3000, 5)
+                rec = wire.synth_tcp_conns(rng, 200, [h], 5)
+                ls = wire.synth_listener_states(rng, h, np.arange(5))
+                for e in engs:
+                    e.handle_resp_events(wire.machine_id(h), ev)
+                    e.partha_tcp_conn_info(wire.machine_id(h), wire.pack_variable(rec, [b""] * 200), 200)
+                    e.partha_listener_state(wire.machine_id(h), wire.pack_variable(ls, [b""] * 5), 5)
+                    e.handle_host_state(wire.machine_id(h), ntasks=10 + h, nlisten=5)
+            capi.check(L.gys_window_close_rccl(engs[0].h, comm, 5_000_000 * (w + 1)))
+            engs[1].window_close(tusec=5_000_000 * (w + 1))
+            a, b = engs
+            assert (a.export_hll() == b.export_hll()).all() and (a.export_cms(0) == b.export_cms(0)).all() and (a.export_cms(1) == b.export_cms(1)).all()
+            assert a.clusterstate("cluster0").as_tuple() == b.clusterstate("cluster0").as_tuple()
+            ga, gb = a.export_global_hist(), b.export_global_hist()
+            assert ga.total_count == gb.total_count > 0 and ga.max_val_seen == gb.max_val_seen
+        out = torch.zeros(C.sizeof(capi.TDigestSlab), dtype=torch.uint8, device="cuda")
+        capi.check(L.gys_tdigest_global_rccl(engs[0].h, comm, C.c_void_p(out.data_ptr())))
+        engs[0].sync()
+        got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=engs[0].SLAB_DT)[0]
+        _, loc = engs[0].tdigest_rollup(capi.ROLLUP_GLOBAL)
+        d = oracle.TD64()
+        ol = oracle.lib()
+        ol.gyo_td64_init(C.byref(d))
+        o1 = oracle.TD64()
+        o1.sum[:] = loc[0]["sum"].tolist()
+        o1.cnt[:] = loc[0]["cnt"].tolist()
+        o1.vmin, o1.vmax = int(loc[0]["vmin"]), int(loc[0]["vmax"])
+        ol.gyo_td64_merge_td64(C.byref(d), C.byref(o1))
+        assert got["cnt"].sum() == loc[0]["cnt"].sum() > 0
+        assert (got["sum"] == np.array(d.sum[:], dtype=np.int64)).all() and (got["cnt"] == np.array(d.cnt[:], dtype=np.uint64)).all()
+        capi.check(L.gys_rccl_comm_destroy(comm))
+        for e in engs:
+            e.close()
+        q.put("ok")
+    except BaseException as ex:  # noqa: BLE001 -- reported to the parent
+        import traceback
+        q.put("error: " + "".join(traceback.format_exception(type(ex), ex, ex.__traceback__))[-1500:])
+
+
+def test_window_close_rccl_inside_the_library(torch_mod):
     """gys_window_close_rccl / gys_tdigest_global_rccl with a one-rank communicator created through the C ABI (the box has one GPU):
     the registers after the in-library exchange equal those of a twin engine closed without it, and the all-gathered + folded global
-    digest equals the local GYS_ROLLUP_GLOBAL slab (fold of one slab into the empty digest)"""
-    import ctypes as C
-    from gyeeta_amd import capi
-    rng = np.random.default_rng(31)
-    engs = [_engine(max_hosts=4, max_services=32, max_batch_events=1 << 14) for _ in range(2)]
-    for e in engs:
-        for h in range(3):
-            mid = wire.machine_id(h)
-            e.register_host(mid, "cluster%d" % (h % 2))
-            s = np.arange(5)
-            e.register_listeners_np(mid, wire.glob_id(np.full(5, h), s), wire.listener_netns(h, s), wire.listener_port(s))
-    L = engs[0].L
-    uid = (C.c_uint8 * 128)()
-    capi.check(L.gys_rccl_unique_id(uid))
-    comm = C.c_void_p()
-    capi.check(L.gys_rccl_comm_create(engs[0].h, uid, 1, 0, C.byref(comm)))
-    for w in range(2):
-        for h in range(3):
-            ev = helpers.make_resp_events(rng, h, 3000, 5)
-            rec = wire.synth_tcp_conns(rng, 200, [h], 5)
-            ls = wire.synth_listener_states(rng, h, np.arange(5))
-            for e in engs:
-                e.handle_resp_events(wire.machine_id(h), ev)
-                e.partha_tcp_conn_info(wire.machine_id(h), wire.pack_variable(rec, [b""] * 200), 200)
-                e.partha_listener_state(wire.machine_id(h), wire.pack_variable(ls, [b""] * 5), 5)
-                e.handle_host_state(wire.machine_id(h), ntasks=10 + h, nlisten=5)
-        capi.check(L.gys_window_close_rccl(engs[0].h, comm, 5_000_000 * (w + 1)))
-        engs[1].window_close(tusec=5_000_000 * (w + 1))
-        a, b = engs
-        assert (a.export_hll() == b.export_hll()).all() and (a.export_cms(0) == b.export_cms(0)).all() and (a.export_cms(1) == b.export_cms(1)).all()
-        assert a.clusterstate("cluster0").as_tuple() == b.clusterstate("cluster0").as_tuple()
-        ga, gb = a.export_global_hist(), b.export_global_hist()
-        assert ga.total_count == gb.total_count > 0 and ga.max_val_seen == gb.max_val_seen
-    out = torch_mod.zeros(C.sizeof(capi.TDigestSlab), dtype=torch_mod.uint8, device="cuda")
-    capi.check(L.gys_tdigest_global_rccl(engs[0].h, comm, C.c_void_p(out.data_ptr())))
-    engs[0].sync()
-    got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=engs[0].SLAB_DT)[0]
-    _, loc = engs[0].tdigest_rollup(capi.ROLLUP_GLOBAL)
-    d = oracle.TD64()
-    ol = oracle.lib()
-    ol.gyo_td64_init(C.byref(d))
-    o1 = oracle.TD64()
-    o1.sum[:] = loc[0]["sum"].tolist()
-    o1.cnt[:] = loc[0]["cnt"].tolist()
-    o1.vmin, o1.vmax = int(loc[0]["vmin"]), int(loc[0]["vmax"])
-    ol.gyo_td64_merge_td64(C.byref(d), C.byref(o1))
-    assert got["cnt"].sum() == loc[0]["cnt"].sum() > 0
-    assert (got["sum"] == np.array(d.sum[:], dtype=np.int64)).all() and (got["cnt"] == np.array(d.cnt[:], dtype=np.uint64)).all()
-    capi.check(L.gys_rccl_comm_destroy(comm))
-    for e in engs:
-        e.close()
+    digest equals the oracle's fold of the local GYS_ROLLUP_GLOBAL slab"""
+    import queue
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q,))
+    p.start()
+    seen = []
+    try:
+        while True:
+            msg = q.get(timeout=90)
+            seen.append(msg)
+            if msg == "ok" or msg.startswith("error"):
+                break
+    except queue.Empty:
+        p.kill()
+        p.join(timeout=30)
+        if seen and seen[-1] == "joining":
+            pytest.skip("ncclCommInitRank did not return within 90 s on this box (RCCL bootstrap); the in-library exchange was not exercised")
+        pytest.fail(f"RCCL window worker stalled after {seen}")
+    p.join(timeout=60)
+    assert seen[-1] == "ok", seen[-1]
