@@ -37,7 +37,22 @@ def test_shim_window_close_rccl_one_rank(tmp_path):
     """the window boundary with the collectives inside the library (gys_window_close_rccl) from plain C++ with a one-rank communicator.
     RCCL's own bootstrap (ncclCommInitRank) does not return on part of the GPU pool; that is reported as a skip, not as a hang."""
     exe = _build(tmp_path)
-    r = subprocess.run(["timeout", "-s", "KILL", "60", exe, "rccl"], capture_output=True, text=True)
-    if r.returncode == -9 and "[shim] rccl join" in r.stderr and "[shim] rccl joined" not in r.stderr:
-        pytest.skip("ncclCommInitRank did not return within 60 s on this box (RCCL bootstrap); the in-library exchange was not exercised")
-    assert r.returncode == 0 and "shim rccl ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    # Two RCCL builds are on the box: /opt/rocm/lib/librccl.so (ROCm 7.2; the library's rpath) and the one PyTorch bundles (RCCL 2.26.6,
+    # ROCm 7.0 -- the generation of the pool's host driver).  On part of the pool the 7.2 build never returns from ncclCommInitRank (a
+    # one-rank communicator, loopback bootstrap) while the bundled one does, so the bundled build is tried first; same soname, same API.
+    envs = []
+    try:
+        import torch
+        envs.append(dict(os.environ, LD_LIBRARY_PATH=os.path.join(os.path.dirname(torch.__file__), "lib")))
+    except Exception:
+        pass
+    envs.append(dict(os.environ))
+    hung = 0
+    for env in envs:
+        r = subprocess.run(["timeout", "-s", "KILL", "60", exe, "rccl"], capture_output=True, text=True, env=env)
+        if r.returncode == -9 and "[shim] rccl join" in r.stderr and "[shim] rccl joined" not in r.stderr:
+            hung += 1
+            continue
+        assert r.returncode == 0 and "shim rccl ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+        return
+    pytest.skip(f"ncclCommInitRank did not return within 60 s with any of the {hung} RCCL builds on this box; the in-library exchange was not exercised")
