@@ -160,6 +160,7 @@ SIGNATURES = {
     "gys_json_svcsumm": (C.c_int, [vp, mid, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_json_svcstate": (C.c_int, [vp, mid, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_json_clusterstate": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gys_json_toplisteners": (C.c_int, [vp, mid, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_num_services": (C.c_uint32, [vp]),
     "gys_num_hosts": (C.c_uint32, [vp]),
     "gys_lookup_service": (C.c_int, [vp, C.c_uint64, u32p]),

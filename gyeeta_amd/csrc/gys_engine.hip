@@ -238,6 +238,10 @@ struct gys_ctx {
 	uint64_t dev_staging_bytes = 0;
 	uint32_t *dev_offsets = nullptr;
 	uint32_t dev_offsets_cap = 0;
+	// host -> member services (slot order) on the device, rebuilt when the registry changed (roll-ups, all-hosts top-N)
+	uint32_t *csr_off = nullptr, *csr_mem = nullptr;
+	uint64_t csr_stamp = ~0ull;
+	std::vector<uint16_t> svc_port_h; // listener port per service slot (web_curr_top_listeners "port")
 	uint32_t *topn_slot = nullptr;
 	uint64_t *topn_metric = nullptr;
 	float *dev_pcts = nullptr;
@@ -1234,7 +1238,7 @@ void gys_destroy(gys_ctx *c)
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
-			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->topn_slot,
+			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -1370,6 +1374,7 @@ int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_l
 		memcpy(cm.data(), arr[i].comm, 16);
 		c->svc_comm.push_back(cm);
 		c->svc_gid_h.push_back(arr[i].glob_id);
+		c->svc_port_h.push_back(arr[i].port);
 	}
 	c->nsvc += n;
 	return GYS_OK;
@@ -2164,6 +2169,67 @@ int gys_scan_quantiles_dev(gys_ctx *c, const double *q, uint32_t nq, double *d_o
 			HIPCHK(hipMemcpy(d_out + (size_t)e.slot * nq, out.data(), sizeof(double) * nq, hipMemcpyHostToDevice));
 		}
 	}
+	return GYS_OK;
+}
+
+// host -> member services on the device (slot order inside a host)
+static int host_csr(gys_ctx *c)
+{
+	const uint64_t stamp = ((uint64_t)c->hosts.size() << 32) | c->nsvc;
+	if (c->csr_stamp == stamp && c->csr_off) return GYS_OK;
+	const uint32_t nh = (uint32_t)c->hosts.size();
+	std::vector<uint32_t> off(nh + 1, 0), members;
+	members.reserve(c->nsvc);
+	for (uint32_t h = 0; h < nh; ++h) {
+		std::vector<uint32_t> sl = c->host_lst[h].all_slots;
+		std::sort(sl.begin(), sl.end());
+		members.insert(members.end(), sl.begin(), sl.end());
+		off[h + 1] = (uint32_t)members.size();
+	}
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (c->csr_off) HIPCHK(hipFree(c->csr_off));
+	if (c->csr_mem) HIPCHK(hipFree(c->csr_mem));
+	c->csr_off = c->csr_mem = nullptr;
+	HIPCHK(hipMalloc((void **)&c->csr_off, off.size() * 4));
+	HIPCHK(hipMalloc((void **)&c->csr_mem, std::max<size_t>(members.size(), 1) * 4));
+	HIPCHK(hipMemcpy(c->csr_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+	if (!members.empty()) HIPCHK(hipMemcpy(c->csr_mem, members.data(), members.size() * 4, hipMemcpyHostToDevice));
+	c->csr_stamp = stamp;
+	return GYS_OK;
+}
+
+// the 10 best services of EVERY host for one kind (last closed window): slots[h * GYS_TOPN + r] (GYS_NOSLOT = none), metrics likewise
+static int topn_all_hosts(gys_ctx *c, int kind, std::vector<uint32_t> &slots, std::vector<uint64_t> &metrics)
+{
+	const uint32_t nh = (uint32_t)c->hosts.size();
+	slots.assign((size_t)nh * GYS_TOPN, GYS_NOSLOT);
+	metrics.assign((size_t)nh * GYS_TOPN, 0);
+	if (!nh || !c->nsvc || c->epoch < 2) return GYS_OK;
+	int rc = host_csr(c);
+	if (rc) return rc;
+	uint32_t *d_slot = nullptr;
+	uint64_t *d_metric = nullptr;
+	HIPCHK(hipMalloc((void **)&d_slot, slots.size() * 4));
+	HIPCHK(hipMalloc((void **)&d_metric, metrics.size() * 8));
+	TopnHostsP tp{};
+	tp.svc_state = c->svc_state;
+	tp.off = c->csr_off;
+	tp.members = c->csr_mem;
+	tp.nhosts = nh;
+	tp.epoch = c->epoch - 1;
+	tp.kind = kind;
+	tp.out_slot = d_slot;
+	tp.out_metric = d_metric;
+	{
+		ProfScope ps(c, "topn_hosts");
+		hipLaunchKernelGGL(k_topn_hosts, dim3(std::min<uint32_t>(nh, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, tp);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(slots.data(), d_slot, slots.size() * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(metrics.data(), d_metric, metrics.size() * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipFree(d_slot));
+	HIPCHK(hipFree(d_metric));
 	return GYS_OK;
 }
 

@@ -2635,6 +2635,123 @@ __global__ __launch_bounds__(256) void k_wire_check(const WireMsg *msgs, uint32_
 	if (found < mm.nevents) atomicOr(status, 2u);
 }
 
+// ---------------------------------------------------------------------------------------------------- top-N of every host at once
+// The reference keeps four bounded min-heaps of 10 per partha (LISTEN_TOP_ISSUE / _QPS / _ACTIVE_CONN / _NET, server/gy_mconnhdlr.h:961,
+// comparators LISTEN_TOPN server/gy_msocket.h:720-796), filled while partha_listener_state walks the records
+// (server/gy_mconnhdlr.cc:11175-11304); web_curr_top_listeners merges the per-host queues into 50 slots for a multi-host query
+// (server/gy_mnodehandle.cc:2885-3040).  Here: one workgroup per host selects the 10 largest of its services' last-window records for one
+// kind -- every thread keeps the 10 best of its strided share in LDS, then 10 rounds of block arg-max over the 2 560 candidates.
+// Order: metric descending, ties by lower service slot (deterministic where the heap's order is arbitrary).
+struct TopnHostsP {
+	const uint8_t *svc_state;
+	const uint32_t *off, *members; // services of host h: members[off[h] .. off[h + 1])
+	uint32_t nhosts, epoch;
+	int kind;
+	uint32_t *out_slot;   // [nhosts * GYS_TOPN], GYS_NOSLOT = none
+	uint64_t *out_metric; // [nhosts * GYS_TOPN]
+};
+
+__device__ __forceinline__ bool topn_metric_of(const uint8_t *svc_state, uint32_t s, uint32_t host, uint32_t epoch, int kind, uint64_t *metric)
+{
+	const uint64_t *q = (const uint64_t *)(svc_state + (size_t)s * 96);
+	const uint64_t tag = q[11];
+	if ((uint32_t)tag != epoch || (uint32_t)(tag >> 32) != host) return false;
+	const uint32_t nqrys = (uint32_t)q[1], nactive = (uint32_t)(q[2] >> 32), kbin = (uint32_t)(q[4] >> 32), kbout = (uint32_t)q[5];
+	const uint32_t delay = (uint32_t)(q[6] >> 32); // tasks_delay_usec_ @52
+	const uint32_t state = (uint32_t)((q[9] >> 56) & 0xFF);
+	switch (kind) {
+	case 0: *metric = ((uint64_t)state << 32) | delay; return state > 2u; // is_issue: curr_state_ > STATE_OK; (state, tasks_delay) order
+	case 1: *metric = nqrys; return nqrys >= 5u;
+	case 2: *metric = nactive; return nactive >= 1u;
+	default: *metric = (uint64_t)kbin + kbout; return (kbin + kbout) > 0u;
+	}
+}
+
+// a before b in the top-N order
+__device__ __forceinline__ bool topn_before(uint64_t ma, uint32_t sa, uint64_t mb, uint32_t sb) { return ma != mb ? ma > mb : sa < sb; }
+
+__global__ __launch_bounds__(256) void k_topn_hosts(TopnHostsP p)
+{
+	__shared__ uint64_t s_m[256 * GYS_TOPN];
+	__shared__ uint32_t s_s[256 * GYS_TOPN];
+	__shared__ uint64_t s_rm[4];
+	__shared__ uint32_t s_rs[4];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	for (uint32_t h = blockIdx.x; h < p.nhosts; h += gridDim.x) {
+		uint64_t *mym = s_m + tid * GYS_TOPN;
+		uint32_t *mys = s_s + tid * GYS_TOPN;
+		for (uint32_t k = 0; k < GYS_TOPN; ++k) mys[k] = GYS_NOSLOT;
+		uint32_t n = 0;
+		for (uint32_t i = p.off[h] + tid; i < p.off[h + 1]; i += 256u) {
+			const uint32_t s = p.members[i];
+			uint64_t m;
+			if (!topn_metric_of(p.svc_state, s, h, p.epoch, p.kind, &m)) continue;
+			if (n == GYS_TOPN && !topn_before(m, s, mym[n - 1], mys[n - 1])) continue;
+			uint32_t k = n < GYS_TOPN ? n : GYS_TOPN - 1u; // insertion into the thread's sorted list
+			while (k > 0 && topn_before(m, s, mym[k - 1], mys[k - 1])) {
+				mym[k] = mym[k - 1];
+				mys[k] = mys[k - 1];
+				--k;
+			}
+			mym[k] = m;
+			mys[k] = s;
+			if (n < GYS_TOPN) ++n;
+		}
+		__syncthreads();
+		uint64_t pm = ~0ull; // the previously selected entry: every round takes the best entry strictly after it
+		uint32_t ps = 0;
+		bool first = true;
+		for (uint32_t r = 0; r < GYS_TOPN; ++r) {
+			uint64_t bm = 0;
+			uint32_t bs = GYS_NOSLOT;
+			for (uint32_t e = tid; e < 256u * GYS_TOPN; e += 256u) {
+				const uint32_t s = s_s[e];
+				if (s == GYS_NOSLOT) continue;
+				const uint64_t m = s_m[e];
+				if (!first && !topn_before(pm, ps, m, s)) continue;
+				if (bs == GYS_NOSLOT || topn_before(m, s, bm, bs)) {
+					bm = m;
+					bs = s;
+				}
+			}
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1) {
+				const uint64_t om = __shfl_xor(bm, d, 64);
+				const uint32_t os = (uint32_t)__shfl_xor((int)bs, d, 64);
+				if (os != GYS_NOSLOT && (bs == GYS_NOSLOT || topn_before(om, os, bm, bs))) {
+					bm = om;
+					bs = os;
+				}
+			}
+			if (lane == 0) {
+				s_rm[wave] = bm;
+				s_rs[wave] = bs;
+			}
+			__syncthreads();
+			bm = s_rm[0];
+			bs = s_rs[0];
+			for (uint32_t w = 1; w < 4u; ++w)
+				if (s_rs[w] != GYS_NOSLOT && (bs == GYS_NOSLOT || topn_before(s_rm[w], s_rs[w], bm, bs))) {
+					bm = s_rm[w];
+					bs = s_rs[w];
+				}
+			if (tid == 0) {
+				p.out_slot[(size_t)h * GYS_TOPN + r] = bs;
+				p.out_metric[(size_t)h * GYS_TOPN + r] = bm;
+			}
+			pm = bm;
+			ps = bs;
+			first = false;
+			__syncthreads();
+			if (bs == GYS_NOSLOT) { // fewer than N qualify: the remaining places stay empty
+				for (uint32_t r2 = r + 1 + tid; r2 < GYS_TOPN; r2 += 256u) p.out_slot[(size_t)h * GYS_TOPN + r2] = GYS_NOSLOT;
+				break;
+			}
+		}
+		__syncthreads();
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------- synthetic stream generator
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {

@@ -310,6 +310,11 @@ class SketchEngine:
     def json_svcstate(self, machine_id, madid="0" * 16, timestr=""):
         return self._json(self.L.gys_json_svcstate, mid_buf(machine_id), madid.encode(), timestr.encode())
 
+    def json_toplisteners(self, machine_id=None, flags=15, madid="0" * 16, timestr=""):
+        """web_curr_top_listeners; machine_id None = the multi-host form (50 slots per kind over all hosts)"""
+        m = mid_buf(machine_id) if machine_id is not None else None
+        return self._json(self.L.gys_json_toplisteners, m, flags, madid.encode(), timestr.encode())
+
     def json_clusterstate(self, shyamaid="0" * 16, timestr=""):
         return self._json(self.L.gys_json_clusterstate, shyamaid.encode(), timestr.encode())
 

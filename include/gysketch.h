@@ -372,6 +372,14 @@ int gys_set_host_name(gys_ctx *ctx, const uint8_t machine_id[16], const char *ho
 int gys_json_svcsumm(gys_ctx *ctx, const uint8_t machine_id[16], const char *madhava_id16, const char *timestr, char *buf, size_t buflen, size_t *needed);
 int gys_json_svcstate(gys_ctx *ctx, const uint8_t machine_id[16], const char *madhava_id16, const char *timestr, char *buf, size_t buflen, size_t *needed);
 int gys_json_clusterstate(gys_ctx *ctx, const char *shyama_id16, const char *timestr, char *buf, size_t buflen, size_t *needed);
+/* MCONN_HANDLER::web_curr_top_listeners (server/gy_mnodehandle.cc:2706-3190): {"madid":..,"topissue":[..],"topqps":[..],"topactconn":[..],
+ * "topnet":[..],"summstats":{..}[,"hostinfo":{..}]}.  machine_id: one partha's four top-10 queues (+ hostinfo); NULL: every host's queues
+ * merged into GYS_MULTI_TOPN = 50 slots per kind (MAX_MULTI_TOPN, common/gy_json_field_maps.h:481), entries carrying parid / host / madid /
+ * cluster.  Entry = the svcstate fields + ip (empty: the registry holds (netns, port)) + port.  flags: which arrays to send. */
+#define GYS_MULTI_TOPN 50
+enum { GYS_TOP_ISSUE = 1, GYS_TOP_QPS = 2, GYS_TOP_ACTCONN = 4, GYS_TOP_NET = 8, GYS_TOP_SUMMSTATS = 16 };
+int gys_json_toplisteners(gys_ctx *ctx, const uint8_t machine_id[16], uint32_t flags, const char *madhava_id16, const char *timestr, char *buf,
+			  size_t buflen, size_t *needed);
 
 /* -------------------------------------------------------------------------------------------------------------------
  * parity / checkpoint exports (host destination buffers) -- GY_HISTOGRAM::get_serialized analogue (gy_statistics.h:665-673) */

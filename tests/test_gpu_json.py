@@ -86,3 +86,83 @@ def test_json_shapes_and_values():
     rc = eng.L.gys_json_clusterstate(eng.h, b"x", b"", small, 8, C.byref(need))
     assert rc == capi.ERR_NOMEM and need.value > 8
     eng.close()
+
+
+def test_json_toplisteners_single_and_multi_host():
+    """web_curr_top_listeners (server/gy_mnodehandle.cc:2706-3190): per host the 10 best services of the last window by each of the four
+    LISTEN_TOPN orders; the multi-host form merges every host's queues into 50 slots per kind.  Expected sets are computed from the
+    ingested records with numpy (metric descending, ties by lower slot = the engine's deterministic rule)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    from gyeeta_amd import capi
+    from gyeeta_amd.engine import SketchEngine
+    rng = np.random.default_rng(11)
+    nh, sp = 9, 30
+    eng = SketchEngine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False)
+    recs = {}
+    for h in range(nh):
+        mid = wire.machine_id(h)
+        eng.register_host(mid, "cl%d" % (h % 2))
+        eng.set_host_name(mid, "host-%d" % h)
+        s = np.arange(sp)
+        eng.register_listeners(mid, wire.glob_id(np.full(sp, h), s), wire.listener_netns(h, s), wire.listener_port(s), comm=b"svc")
+    for h in range(nh - 1):  # the last host reports nothing
+        ls = wire.synth_listener_states(rng, h, np.arange(sp))
+        ls["curr_state"] = rng.integers(0, 6, sp)
+        ls["tasks_delay_usec"] = rng.integers(0, 5000, sp)
+        ls["tasks_cpudelay_usec"] = 0
+        ls["tasks_blkiodelay_usec"] = 0
+        ls["nconns_active"] = rng.integers(0, 40, sp)
+        ls["curr_kbytes_inbound"] = rng.integers(0, 300, sp)
+        ls["curr_kbytes_outbound"] = rng.integers(0, 300, sp)
+        eng.partha_listener_state(wire.machine_id(h), ls.tobytes(), sp)
+        recs[h] = ls
+    eng.window_close()
+
+    def expected(h, kind):
+        r = recs[h]
+        slot = h * sp + np.arange(sp)
+        if kind == 0:
+            ok = r["curr_state"] > 2
+            metric = (r["curr_state"].astype(np.uint64) << np.uint64(32)) | r["tasks_delay_usec"].astype(np.uint64)
+        elif kind == 1:
+            ok, metric = r["nqrys_5s"] >= 5, r["nqrys_5s"].astype(np.uint64)
+        elif kind == 2:
+            ok, metric = r["nconns_active"] >= 1, r["nconns_active"].astype(np.uint64)
+        else:
+            metric = r["curr_kbytes_inbound"].astype(np.uint64) + r["curr_kbytes_outbound"].astype(np.uint64)
+            ok = metric > 0
+        order = sorted((i for i in range(sp) if ok[i]), key=lambda i: (-int(metric[i]), int(slot[i])))[:10]
+        return [(int(metric[i]), int(slot[i]), "%016x" % int(r["glob_id"][i])) for i in order]
+
+    names = ["topissue", "topqps", "topactconn", "topnet"]
+    madid, ts = "0123456789abcdef", "2026-01-01T00:00:05+0000"
+    d = json.loads(eng.json_toplisteners(wire.machine_id(3), 15 | 16, madid, ts))
+    assert list(d.keys()) == ["madid"] + names + ["summstats", "hostinfo"]
+    for kind, nm in enumerate(names):
+        want = expected(3, kind)
+        assert [e["svcid"] for e in d[nm]] == [w[2] for w in want], nm
+        for e in d[nm]:
+            assert list(e.keys()) == SVCSTATE_COLS + ["ip", "port"] and e["time"] == ts
+    assert d["summstats"]["nsvc"] == sp and d["hostinfo"]["host"] == "host-3"
+    e0 = d["topqps"][0]
+    i0 = int(np.argmax(recs[3]["nqrys_5s"]))
+    assert e0["nqry5s"] == int(recs[3]["nqrys_5s"][i0]) and e0["port"] == int(wire.listener_port(np.arange(sp))[i0])
+    # only the requested arrays are sent; no criteria at all is an error (reference: ERR_INVALID_REQUEST)
+    d = json.loads(eng.json_toplisteners(wire.machine_id(3), 2, madid, ts))
+    assert list(d.keys()) == ["madid", "topqps", "hostinfo"]
+    with pytest.raises(capi.GysError):
+        eng.json_toplisteners(wire.machine_id(3), 16, madid, ts)
+    # multi-host: union of the hosts' top-10 queues, best 50 per kind, entries carry the host identity
+    d = json.loads(eng.json_toplisteners(None, 15 | 16, madid, ts))
+    assert list(d.keys()) == ["madid"] + names + ["summstats"]
+    for kind, nm in enumerate(names):
+        union = sorted((w for h in range(nh - 1) for w in expected(h, kind)), key=lambda w: (-w[0], w[1]))[:50]
+        assert [e["svcid"] for e in d[nm]] == [w[2] for w in union], nm
+        assert len(d[nm]) <= 50
+        for e, w in zip(d[nm], union):
+            h = w[1] // sp
+            assert list(e.keys())[:4] == ["parid", "host", "madid", "cluster"] and e["host"] == "host-%d" % h and e["cluster"] == "cl%d" % (h % 2)
+    assert d["summstats"]["nsvc"] == (nh - 1) * sp
+    eng.close()
