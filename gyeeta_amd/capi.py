@@ -20,7 +20,8 @@ class Config(C.Structure):
                 ("max_hosts", C.c_uint32), ("max_services", C.c_uint32), ("max_clusters", C.c_uint32),
                 ("enable_tdigest", C.c_uint32), ("svc_hll_p", C.c_uint32), ("resp_path", C.c_uint32),
                 ("max_batch_events", C.c_uint64), ("stream", C.c_void_p), ("reduce_arena", C.c_void_p),
-                ("reduce_arena_bytes", C.c_uint64), ("enable_levels", C.c_uint32), ("td_buf_values", C.c_uint32)]
+                ("reduce_arena_bytes", C.c_uint64), ("enable_levels", C.c_uint32), ("td_buf_values", C.c_uint32),
+                ("conn_pair_cms", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class ListenerInfo(C.Structure):
@@ -99,7 +100,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("resp_events", "resp_dropped_range", "resp_dropped_nolistener", "conn_events",
                                           "conn_unknown_service", "lstate_records", "lstate_missed", "lstate_errors", "lstate_deleted",
                                           "resp_batches_host_local", "resp_batches_general", "window_graph_launches", "resp_batches_host_split",
-                                          "td_merges", "td_merge_values")]
+                                          "td_merges", "td_merge_values", "actconn_records", "actconn_remote_listen", "actconn_unknown_listener")]
 
 
 assert C.sizeof(HistRec) == 256 and C.sizeof(TopnEntry) == 104 and C.sizeof(RespSeg) == 16 and C.sizeof(ListenerDayStats) == 48
@@ -145,6 +146,11 @@ SIGNATURES = {
     "gys_tdigest_merge_slabs_dev": (C.c_int, [vp, vp, C.c_uint32, vp]),
     "gys_tdigest_slab_quantiles": (C.c_int, [vp, vp, f64p, C.c_uint32, f64p]),
     "gys_num_clusters": (C.c_uint32, [vp]),
+    "gys_ingest_active_conns": (C.c_int, [vp, mid, vp, C.c_uint32, vp]),
+    "gys_ingest_active_conns_dev": (C.c_int, [vp, vp, C.c_uint32]),
+    "gys_query_pair_cms": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, u64p]),
+    "gys_export_pair_cms": (C.c_int, [vp, C.c_int, vp]),
+    "gys_export_active_conn_counters": (C.c_int, [vp, C.c_uint32, C.c_uint32, u64p]),
     "gys_rccl_unique_id": (C.c_int, [u8p]),
     "gys_rccl_comm_create": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
     "gys_rccl_comm_destroy": (C.c_int, [vp]),

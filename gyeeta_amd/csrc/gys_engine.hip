@@ -94,8 +94,8 @@ struct HostListeners {
 
 struct ArenaLayout {
 	uint64_t off_hll8, off_u32, n_u32, off_i64sum, n_i64sum, off_i64max, n_i64max, total;
-	uint64_t u32_cms, u32_cluster;        // element offsets inside the u32 section
-	uint64_t i64_cms, i64_ghist;          // element offsets inside the i64 SUM section
+	uint64_t u32_cms, u32_cluster, u32_pair; // element offsets inside the u32 section
+	uint64_t i64_cms, i64_ghist, i64_pair;   // element offsets inside the i64 SUM section
 };
 
 ArenaLayout arena_layout(uint32_t max_clusters)
@@ -105,11 +105,13 @@ ArenaLayout arena_layout(uint32_t max_clusters)
 	a.off_u32 = align_up((uint64_t)1 << GYS_HLL_P, 256);
 	a.u32_cms = 0;
 	a.u32_cluster = (uint64_t)GYS_CMS_D * GYS_CMS_W;
-	a.n_u32 = a.u32_cluster + (uint64_t)max_clusters * 12;
+	a.u32_pair = a.u32_cluster + align_up((uint64_t)max_clusters * 12, 64); // Count-Min pair of the (listener, client task) roll-up
+	a.n_u32 = a.u32_pair + (uint64_t)GYS_CMS_D * GYS_CMS_W;
 	a.off_i64sum = align_up(a.off_u32 + a.n_u32 * 4, 256);
 	a.i64_cms = 0;
 	a.i64_ghist = (uint64_t)GYS_CMS_D * GYS_CMS_W;
-	a.n_i64sum = a.i64_ghist + 32;
+	a.i64_pair = a.i64_ghist + 32;
+	a.n_i64sum = a.i64_pair + (uint64_t)GYS_CMS_D * GYS_CMS_W;
 	a.off_i64max = align_up(a.off_i64sum + a.n_i64sum * 8, 256);
 	a.n_i64max = 8;
 	a.total = align_up(a.off_i64max + a.n_i64max * 8, 256);
@@ -186,6 +188,7 @@ struct gys_ctx {
 	int huge_blocks = 0;
 	uint32_t *hll32 = nullptr;
 	unsigned long long *svc_ctr = nullptr;
+	unsigned long long *svc_act = nullptr; // per listener: ACTIVE_CONN_STATS rows, bytes sent / received, active connections (cumulative)
 	unsigned long long *svc_win = nullptr; // per-service window accumulators of the connection path (k_conn_ingest / k_conn_fold)
 	bool conn_dirty = false;
 	uint8_t *svc_state = nullptr;
@@ -944,6 +947,10 @@ int run_conn(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, uint
 	p.cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
 	p.cms64 = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_cms;
 	p.svc_win = c->svc_win;
+	if (c->cfg.conn_pair_cms) {
+		p.pair32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_pair;
+		p.pair64 = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_pair;
+	}
 	c->conn_dirty = true;
 	p.counters = c->counters;
 	ProfScope ps(c, "conn");
@@ -960,6 +967,23 @@ int conn_fold(gys_ctx *c)
 			   (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms, (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_cms);
 	HIPCHK(hipGetLastError());
 	c->conn_dirty = false;
+	return GYS_OK;
+}
+
+int run_actconn(gys_ctx *c, const uint8_t *d_batch, uint32_t n)
+{
+	if (!n) return GYS_OK;
+	ActConnP p{};
+	p.batch = d_batch;
+	p.n = n;
+	p.gid = c->gid_tbl;
+	p.pair32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_pair;
+	p.pair64 = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_pair;
+	p.svc_act = c->svc_act;
+	p.counters = c->counters;
+	ProfScope ps(c, "actconn");
+	hipLaunchKernelGGL(k_actconn_ingest, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
+	HIPCHK(hipGetLastError());
 	return GYS_OK;
 }
 
@@ -1105,6 +1129,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	ALLOC(c->host_cluster, H);
 	ALLOC(c->counters, 16);
 	ALLOC(c->misc, 16);
+	ALLOC(c->svc_act, S * 4);
 	ALLOC(c->topn_slot, S < 65536 ? S : 65536);
 	ALLOC(c->topn_metric, S < 65536 ? S : 65536);
 	ALLOC(c->dev_pcts, 64);
@@ -1238,7 +1263,7 @@ void gys_destroy(gys_ctx *c)
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
-			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->topn_slot,
+			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -1446,6 +1471,44 @@ int gys_ingest_listener_state_dev(gys_ctx *c, const void *d_batch, const uint32_
 {
 	if (!c || ((!d_batch || !d_offsets || !d_host_slot) && nrecs)) return GYS_ERR_INVAL;
 	return run_lstate(c, (const uint8_t *)d_batch, d_offsets, d_host_slot, 0, nrecs);
+}
+
+int gys_ingest_active_conns_dev(gys_ctx *c, const void *d_batch, uint32_t nitems)
+{
+	if (!c || (!d_batch && nitems)) return GYS_ERR_INVAL;
+	return run_actconn(c, (const uint8_t *)d_batch, nitems);
+}
+
+int gys_ingest_active_conns(gys_ctx *c, const uint8_t machine_id[16], const void *batch, uint32_t nitems, const void *pend)
+{
+	if (!c || !machine_id || (!batch && nitems) || ((uintptr_t)batch & 7u)) return GYS_ERR_INVAL;
+	uint32_t host;
+	int rc = lookup_host(c, machine_id, &host);
+	if (rc) return rc;
+	// fixed 104-byte stride; nitems is an upper bound as in the reference's loop over pconn (gy_mconnhdlr.cc:7842)
+	const uint64_t avail = pend ? (uint64_t)((const uint8_t *)pend - (const uint8_t *)batch) / 104u : nitems;
+	const uint32_t n = (uint32_t)std::min<uint64_t>(nitems, avail);
+	if (!n) return GYS_OK;
+	const uint64_t bytes = (uint64_t)n * 104u;
+	int si;
+	rc = stage_acquire(c, bytes, &si);
+	if (rc) return rc;
+	gys_ctx::Stage &st = c->stage[si];
+	memcpy(st.h, batch, bytes);
+	{
+		std::lock_guard<std::mutex> g(c->enq_mu);
+		hipError_t e = hipMemcpyAsync(st.d, st.h, bytes, hipMemcpyHostToDevice, c->stream);
+		if (e == hipSuccess) {
+			rc = run_actconn(c, st.d, n);
+			e = hipEventRecord(st.done, c->stream);
+		}
+		if (e != hipSuccess) {
+			set_err("gys_ingest_active_conns: %s", hipGetErrorString(e));
+			rc = GYS_ERR_HIP;
+		}
+	}
+	stage_release(c, si);
+	return rc;
 }
 
 int gys_ingest_listener_state(gys_ctx *c, const uint8_t machine_id[16], const void *batch, uint32_t nrecs, const void *pend)
@@ -2074,6 +2137,51 @@ int gys_query_cms(gys_ctx *c, uint64_t glob_id, int which, uint64_t *out)
 	return GYS_OK;
 }
 
+// Count-Min estimate for a (listener, client task group) pair in the last finished window: which 0 = active connections, 1 = bytes
+int gys_query_pair_cms(gys_ctx *c, uint64_t listener_glob_id, uint64_t cli_aggr_task_id, int which, uint64_t *out)
+{
+	if (!c || !out || which < 0 || which > 1) return GYS_ERR_INVAL;
+	uint64_t best = ~0ull;
+	for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
+		const uint32_t col = jhash2_4w((uint32_t)listener_glob_id, (uint32_t)(listener_glob_id >> 32), (uint32_t)cli_aggr_task_id,
+					       (uint32_t)(cli_aggr_task_id >> 32), GYS_SEED + r) & (GYS_CMS_W - 1);
+		uint64_t v = 0;
+		if (which == 0) {
+			uint32_t v32;
+			HIPCHK(hipMemcpyAsync(&v32, (const uint32_t *)(c->last + c->al.off_u32) + c->al.u32_pair + (size_t)r * GYS_CMS_W + col, 4, hipMemcpyDeviceToHost,
+					      c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));
+			v = v32;
+		} else {
+			HIPCHK(hipMemcpyAsync(&v, (const uint64_t *)(c->last + c->al.off_i64sum) + c->al.i64_pair + (size_t)r * GYS_CMS_W + col, 8,
+					      hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));
+		}
+		best = std::min(best, v);
+	}
+	*out = best;
+	return GYS_OK;
+}
+
+int gys_export_pair_cms(gys_ctx *c, int which, void *out)
+{
+	if (!c || !out || which < 0 || which > 1) return GYS_ERR_INVAL;
+	const size_t n = (size_t)GYS_CMS_D * GYS_CMS_W;
+	if (which == 0) HIPCHK(hipMemcpyAsync(out, (const uint32_t *)(c->last + c->al.off_u32) + c->al.u32_pair, n * 4, hipMemcpyDeviceToHost, c->stream));
+	else HIPCHK(hipMemcpyAsync(out, (const int64_t *)(c->last + c->al.off_i64sum) + c->al.i64_pair, n * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
+int gys_export_active_conn_counters(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint64_t *out)
+{
+	if (!c || !out || (uint64_t)first_slot + nslots > c->nsvc) return GYS_ERR_INVAL;
+	if (!nslots) return GYS_OK;
+	HIPCHK(hipMemcpyAsync(out, c->svc_act + (size_t)first_slot * 4, (size_t)nslots * 32, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return GYS_OK;
+}
+
 int gys_query_topn(gys_ctx *c, const uint8_t machine_id[16], int kind, gys_topn_entry out[GYS_TOPN], uint32_t *nout)
 {
 	if (!c || !machine_id || !out || !nout || kind < 0 || kind > 3) return GYS_ERR_INVAL;
@@ -2618,6 +2726,9 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 	out->resp_batches_host_split = c->n_batches_host_split;
 	out->td_merges = v[CTR_TD_MERGES];
 	out->td_merge_values = v[CTR_TD_MERGE_VALUES];
+	out->actconn_records = v[CTR_ACTCONN_RECORDS];
+	out->actconn_remote_listen = v[CTR_ACTCONN_REMOTE_LISTEN];
+	out->actconn_unknown_listener = v[CTR_ACTCONN_UNKNOWN];
 	return GYS_OK;
 }
 

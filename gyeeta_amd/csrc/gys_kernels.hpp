@@ -25,7 +25,7 @@ namespace gys {
 #define GYS_STAGED_WORD(tresp, cli_port) ((uint64_t)(((uint32_t)(tresp) << GYS_ROW_BITS) | ((uint32_t)(cli_port) & 0x1Fu)))
 
 enum { CTR_RESP_EVENTS = 0, CTR_RESP_DROP_RANGE, CTR_RESP_DROP_NOLISTENER, CTR_CONN_EVENTS, CTR_CONN_UNKNOWN, CTR_LSTATE_RECORDS,
-       CTR_LSTATE_MISSED, CTR_LSTATE_ERRORS, CTR_LSTATE_DELETED, CTR_TD_MERGES, CTR_TD_MERGE_VALUES, CTR_NUM };
+       CTR_LSTATE_MISSED, CTR_LSTATE_ERRORS, CTR_LSTATE_DELETED, CTR_TD_MERGES, CTR_TD_MERGE_VALUES, CTR_ACTCONN_RECORDS, CTR_ACTCONN_REMOTE_LISTEN, CTR_ACTCONN_UNKNOWN, CTR_NUM };
 
 // ---------------------------------------------------------------------------------------------------- table insert
 __global__ void k_table_insert(DevTable t, const uint64_t *keys, uint32_t first_val, uint32_t n, uint32_t *nfail)
@@ -2020,6 +2020,8 @@ struct ConnP {
 	unsigned long long *cms64;
 	unsigned long long *svc_win; // [nsvc*3] window accumulators: nconn | nclose << 32, bytes_sent, bytes_rcvd
 	uint64_t *counters;
+	uint32_t *pair32;            // gys_config.conn_pair_cms: Count-Min pair keyed by (ser_glob_id_, cli_task_aggr_id_), else nullptr
+	unsigned long long *pair64;
 };
 
 __global__ __launch_bounds__(256) void k_conn_ingest(ConnP p)
@@ -2055,6 +2057,16 @@ __global__ __launch_bounds__(256) void k_conn_ingest(ConnP p)
 	hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
 	if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
 
+	if (p.pair32) { // per-(listener, client task group) roll-up (connlistenmap_ / connclientmap_, server/gy_msocket.h:240-290)
+		const uint64_t task = *(const uint64_t *)(rec + 144); // cli_task_aggr_id_
+#pragma unroll
+		for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
+			const uint32_t col = jhash2_4w((uint32_t)ser_glob_id, (uint32_t)(ser_glob_id >> 32), (uint32_t)task, (uint32_t)(task >> 32), GYS_SEED + r) &
+					     (GYS_CMS_W - 1);
+			atomicAdd(&p.pair32[r * GYS_CMS_W + col], 1u);
+			if (bytes_sent + bytes_rcvd) atomicAdd(&p.pair64[r * GYS_CMS_W + col], (unsigned long long)(bytes_sent + bytes_rcvd));
+		}
+	}
 	const uint32_t slot = tbl_lookup(p.gid, ser_glob_id);
 	if (slot == GYS_NOSLOT) {
 		atomicAdd((unsigned long long *)&p.counters[CTR_CONN_UNKNOWN], 1ull);
@@ -2633,6 +2645,58 @@ __global__ __launch_bounds__(256) void k_wire_check(const WireMsg *msgs, uint32_
 	const uint32_t last = mm.end_slot - 1u; // records found in [pay_slot, end_slot)
 	const uint32_t found = mm.end_slot > mm.pay_slot ? rank[last] + cnt[last] - rank[mm.pay_slot] : 0u;
 	if (found < mm.nevents) atomicOr(status, 2u);
+}
+
+// ---------------------------------------------------------------------------------------------------- ACTIVE_CONN_STATS ingest
+// comm::ACTIVE_CONN_STATS (common/gy_comm_proto.h:2766-2783), 104-byte fixed stride: listener_glob_id_@0 cli_aggr_task_id_@8 ser_comm_@16
+// cli_comm_@32 remote_machine_id_@48 remote_madhava_id_@64 bytes_sent_@72 bytes_received_@80 cli_delay_msec_@88 ser_delay_msec_@92
+// max_rtt_msec_@96 active_conns_@100 flags@102 (bit 1 = is_remote_listen_); layout pinned against the reference's compiler in
+// tests/test_wire.py.  The reference turns every row into an SQL insert (insert_active_conns, server/gy_mconnhdlr.cc:7776-7960: local
+// listeners -> activeconntbl, remote listeners -> remoteconntbl); here the local-listener rows feed a Count-Min PAIR keyed by the 4 words
+// (listener id, client task group id) -- the per-(listener, client task) roll-up that replaces those rows and connlistenmap_ /
+// connclientmap_ (server/gy_msocket.h:240-290) -- and exact per-listener sums.  One thread per row.
+struct ActConnP {
+	const uint8_t *batch;
+	uint32_t n;
+	DevTable gid;
+	uint32_t *pair32;            // arena: Count-Min of active connections per pair
+	unsigned long long *pair64;  // arena: Count-Min of bytes (sent + received) per pair
+	unsigned long long *svc_act; // [nsvc*4] cumulative per listener: rows, bytes_sent, bytes_received, active connections
+	uint64_t *counters;
+};
+
+__global__ __launch_bounds__(256) void k_actconn_ingest(ActConnP p)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool in = i < p.n;
+	uint64_t w[13];
+	if (in) {
+		const uint64_t *q = (const uint64_t *)(p.batch + (size_t)i * 104u);
+#pragma unroll
+		for (int k = 0; k < 13; ++k) w[k] = q[k];
+	}
+	const bool remote = in && ((w[12] >> 49) & 1ull); // flags byte @102 = bits 48..55 of word 12, is_remote_listen_ = bit 1
+	wave_count(&p.counters[CTR_ACTCONN_RECORDS], in && !remote);
+	wave_count(&p.counters[CTR_ACTCONN_REMOTE_LISTEN], remote);
+	if (!in || remote) return;
+	const uint64_t gid = w[0], task = w[1], sent = w[9], rcvd = w[10];
+	const uint32_t act = (uint32_t)((w[12] >> 32) & 0xFFFFu); // active_conns_ @100
+#pragma unroll
+	for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
+		const uint32_t col = jhash2_4w((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)task, (uint32_t)(task >> 32), GYS_SEED + r) & (GYS_CMS_W - 1);
+		if (act) atomicAdd(&p.pair32[r * GYS_CMS_W + col], act);
+		if (sent + rcvd) atomicAdd(&p.pair64[r * GYS_CMS_W + col], (unsigned long long)(sent + rcvd));
+	}
+	const uint32_t slot = tbl_lookup(p.gid, gid);
+	if (slot == GYS_NOSLOT) {
+		atomicAdd((unsigned long long *)&p.counters[CTR_ACTCONN_UNKNOWN], 1ull);
+		return;
+	}
+	unsigned long long *a = p.svc_act + (size_t)slot * 4;
+	atomicAdd(&a[0], 1ull);
+	atomicAdd(&a[1], (unsigned long long)sent);
+	atomicAdd(&a[2], (unsigned long long)rcvd);
+	atomicAdd(&a[3], (unsigned long long)act);
 }
 
 // ---------------------------------------------------------------------------------------------------- top-N of every host at once

@@ -36,7 +36,7 @@ def mid_buf(machine_id):
 
 class SketchEngine:
     def __init__(self, max_hosts, max_services, max_clusters=16, enable_tdigest=True, svc_hll_p=0, max_batch_events=1 << 20,
-                 rank=0, nranks=1, device=None, torch_arena=True, resp_path=0, enable_levels=False, td_buf_values=0):
+                 rank=0, nranks=1, device=None, torch_arena=True, resp_path=0, enable_levels=False, td_buf_values=0, conn_pair_cms=False):
         import torch
         self.L = capi.load()
         if not torch.cuda.is_available():
@@ -55,6 +55,7 @@ class SketchEngine:
         cfg.resp_path = resp_path
         cfg.enable_levels = 1 if enable_levels else 0
         cfg.td_buf_values = td_buf_values
+        cfg.conn_pair_cms = 1 if conn_pair_cms else 0
         cfg.max_batch_events = max_batch_events
         with torch.cuda.device(self.device):
             # the engine gets its own torch stream: torch work (tensor fills / copies on the current stream, collectives) and engine work are
@@ -149,6 +150,29 @@ class SketchEngine:
         buf = np.require(buf, requirements=["A", "C"])
         p = buf.ctypes.data
         capi.check(self.L.gys_ingest_listener_state(self.h, mid_buf(machine_id), C.c_void_p(p), nrecs, C.c_void_p(p + len(buf))))
+
+    def handle_partha_active_conns(self, machine_id, batch_bytes, nitems):
+        """MCONN_HANDLER::handle_partha_active_conns(partha, pconn, nitems, pendptr)"""
+        buf = np.frombuffer(batch_bytes, dtype=np.uint8)
+        buf = np.require(buf, requirements=["A", "C"])
+        p = buf.ctypes.data
+        capi.check(self.L.gys_ingest_active_conns(self.h, mid_buf(machine_id), C.c_void_p(p), nitems, C.c_void_p(p + len(buf))))
+
+    def pair_cms(self, listener_glob_id, cli_aggr_task_id, which=0):
+        out = C.c_uint64()
+        capi.check(self.L.gys_query_pair_cms(self.h, int(listener_glob_id), int(cli_aggr_task_id), which, C.byref(out)))
+        return out.value
+
+    def export_pair_cms(self, which=0):
+        out = np.zeros((capi.CMS_D, capi.CMS_W), dtype=np.uint32 if which == 0 else np.int64)
+        capi.check(self.L.gys_export_pair_cms(self.h, which, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def export_active_conn_counters(self, first=0, n=None):
+        n = self.num_services() - first if n is None else n
+        out = np.zeros((n, 4), dtype=np.uint64)
+        capi.check(self.L.gys_export_active_conn_counters(self.h, first, n, out.ctypes.data_as(capi.u64p)))
+        return out
 
     def handle_comm_stream(self, machine_id, stream_bytes):
         """L1 + L2 of madhava for one partha connection: COMM_HEADER-framed messages -> partha_tcp_conn_info / partha_listener_state"""

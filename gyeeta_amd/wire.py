@@ -190,3 +190,34 @@ def frame_event_notify(subtype, nevents, payload, magic=PM_HDR_MAGIC, data_type=
     hdr = np.array([magic, total, data_type, total - act], dtype="<u4").tobytes()
     ev = np.array([subtype, nevents], dtype="<u4").tobytes()
     return hdr + ev + payload + b"\0" * (total - act)
+
+
+# comm::ACTIVE_CONN_STATS (common/gy_comm_proto.h:2766-2783), 104 bytes fixed stride: one row per (listener, client task group) of a
+# partha's 15-s active-connection report; flags byte @102: bit 0 cli_listener_proc_, bit 1 is_remote_listen_, bit 2 is_remote_cli_
+ACTIVE_CONN_STATS = np.dtype([("listener_glob_id", "<u8"), ("cli_aggr_task_id", "<u8"), ("ser_comm", "S16"), ("cli_comm", "S16"),
+                              ("remote_machine_id", "<u8", 2), ("remote_madhava_id", "<u8"), ("bytes_sent", "<u8"), ("bytes_received", "<u8"),
+                              ("cli_delay_msec", "<u4"), ("ser_delay_msec", "<u4"), ("max_rtt_msec", "<f4"), ("active_conns", "<u2"), ("flags", "u1"),
+                              ("tail_pad", "u1")])
+assert ACTIVE_CONN_STATS.itemsize == 104
+ACTIVE_FLAG_CLI_LISTENER_PROC, ACTIVE_FLAG_REMOTE_LISTEN, ACTIVE_FLAG_REMOTE_CLI = 1, 2, 4
+MAX_NUM_ACTIVE_CONNS = 2048
+
+
+def synth_active_conns(rng, n, host, svcs_per_host, ntasks=40, remote_listen_frac=0.25, unknown_frac=0.02):
+    """n ACTIVE_CONN_STATS rows of one host: listener x client-task-group pairs (repeats allowed: several 15-s reports), bytes ~ Pareto"""
+    rec = np.zeros(n, dtype=ACTIVE_CONN_STATS)
+    s = rng.integers(0, svcs_per_host, n)
+    rec["listener_glob_id"] = glob_id(np.full(n, host), s)
+    unk = rng.random(n) < unknown_frac
+    rec["listener_glob_id"] = np.where(unk, rng.integers(1, 1 << 62, n, dtype=np.uint64), rec["listener_glob_id"])
+    rec["cli_aggr_task_id"] = splitmix64((np.uint64(host) << np.uint64(24)) + rng.integers(0, ntasks, n).astype(np.uint64) + np.uint64(0x7A5C))
+    rec["ser_comm"] = b"svc"
+    rec["cli_comm"] = b"cli"
+    rec["bytes_sent"] = (200 * (1 + rng.pareto(1.2, n))).astype(np.uint64)
+    rec["bytes_received"] = (200 * (1 + rng.pareto(1.2, n))).astype(np.uint64)
+    rec["cli_delay_msec"] = rng.integers(0, 50, n)
+    rec["ser_delay_msec"] = rng.integers(0, 50, n)
+    rec["max_rtt_msec"] = rng.random(n).astype(np.float32) * 20
+    rec["active_conns"] = rng.integers(1, 200, n)
+    rec["flags"] = np.where(rng.random(n) < remote_listen_frac, ACTIVE_FLAG_REMOTE_LISTEN, 0) | np.where(rng.random(n) < 0.1, ACTIVE_FLAG_CLI_LISTENER_PROC, 0)
+    return rec

@@ -201,3 +201,49 @@ double gyo_td64_quantile(const gyo_td64 *d, double q)
 done:
 	return floor(r + 0.5); /* integer-millisecond value domain: round half up, as gyo_td_quantile */
 }
+
+/* ================================================================ ACTIVE_CONN_STATS roll-up
+ * comm::ACTIVE_CONN_STATS (common/gy_comm_proto.h:2766-2783, 104 bytes): one row per (listener, client task group) of a partha's
+ * 15-s report.  MCONN_HANDLER::insert_active_conns (server/gy_mconnhdlr.cc:7776-7960) splits the rows by is_remote_listen_: rows of
+ * LOCAL listeners (false) go to activeconntbl (:7842-7876), rows whose listener lives on another madhava (true) to remoteconntbl
+ * (:7888-7925); nothing is kept in memory.  The engine's replacement of those tables' per-(listener, client task) rows (and of
+ * connlistenmap_ / connclientmap_, server/gy_msocket.h:240-290): a Count-Min pair keyed by the 4 words
+ * (listener_glob_id lo, hi, cli_aggr_task_id lo, hi) -- active_conns_ into the u32 table, bytes_sent_ + bytes_received_ into the
+ * u64 table -- for the local-listener rows; out[0] = local-listener rows, out[1] = remote-listener rows.  PARITY UNPINNED (builder-defined). */
+static uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+void gyo_active_conn_sketch_batch(const uint8_t *batch, int nrec, uint32_t *pair32, uint64_t *pair64, uint64_t out[2])
+{
+	out[0] = out[1] = 0;
+	for (int i = 0; i < nrec; i++) {
+		const uint8_t *r = batch + (size_t)i * 104;
+		const uint64_t gid = rd64(r), task = rd64(r + 8), sent = rd64(r + 72), rcvd = rd64(r + 80);
+		uint16_t act;
+		memcpy(&act, r + 100, 2);
+		if (r[102] & 2) { /* is_remote_listen_ */
+			out[1]++;
+			continue;
+		}
+		out[0]++;
+		{
+			const uint32_t w[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)task, (uint32_t)(task >> 32)};
+			gyo_cms_add(pair32, w, 4, act);
+			gyo_cms64_add(pair64, w, 4, sent + rcvd);
+		}
+	}
+}
+
+/* the same pair fed by TCP_CONN_NOTIFY records (gys_config.conn_pair_cms): key (ser_glob_id_ @192, cli_task_aggr_id_ @144),
+ * one connection into the u32 table, bytes_sent_ + bytes_rcvd_ (@208, @216) into the u64 table, for every record of the batch
+ * (variable stride, common/gy_comm_proto.h:1721-1724) */
+int gyo_tcp_conn_pair_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *pair32, uint64_t *pair64)
+{
+	const uint8_t *p = batch;
+	int i;
+	for (i = 0; i < nrec && p < pend; ++i, p += gyo_tcp_conn_elem_size(p)) {
+		const uint64_t gid = rd64(p + 192), task = rd64(p + 144);
+		const uint32_t w[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)task, (uint32_t)(task >> 32)};
+		gyo_cms_add(pair32, w, 4, 1);
+		gyo_cms64_add(pair64, w, 4, rd64(p + 208) + rd64(p + 216));
+	}
+	return i;
+}

@@ -359,7 +359,25 @@ static const struct {
 	GY_REF_OFF(LISTENER_DAY_STATS, glob_id), GY_REF_OFF(LISTENER_DAY_STATS, tcount_5d), GY_REF_OFF(LISTENER_DAY_STATS, tsum_5d),
 	GY_REF_OFF(LISTENER_DAY_STATS, p95_5d_respms), GY_REF_OFF(LISTENER_DAY_STATS, p25_5d_respms), GY_REF_OFF(LISTENER_DAY_STATS, p95_qps),
 	GY_REF_OFF(LISTENER_DAY_STATS, p25_qps), GY_REF_OFF(LISTENER_DAY_STATS, p95_nactive), GY_REF_OFF(LISTENER_DAY_STATS, p25_nactive),
+	GY_REF_OFF(ACTIVE_CONN_STATS, listener_glob_id), GY_REF_OFF(ACTIVE_CONN_STATS, cli_aggr_task_id), GY_REF_OFF(ACTIVE_CONN_STATS, ser_comm),
+	GY_REF_OFF(ACTIVE_CONN_STATS, cli_comm), GY_REF_OFF(ACTIVE_CONN_STATS, remote_machine_id), GY_REF_OFF(ACTIVE_CONN_STATS, remote_madhava_id),
+	GY_REF_OFF(ACTIVE_CONN_STATS, bytes_sent), GY_REF_OFF(ACTIVE_CONN_STATS, bytes_received), GY_REF_OFF(ACTIVE_CONN_STATS, cli_delay_msec),
+	GY_REF_OFF(ACTIVE_CONN_STATS, ser_delay_msec), GY_REF_OFF(ACTIVE_CONN_STATS, max_rtt_msec), GY_REF_OFF(ACTIVE_CONN_STATS, active_conns),
 };
+// the three 1-bit flags behind active_conns_ (cli_listener_proc_, is_remote_listen_, is_remote_cli_): the byte offset and bit values as
+// the reference's compiler lays them out, read back from a zeroed record with exactly one flag set
+uint32_t ref_active_conn_flag(int which)
+{
+	comm::ACTIVE_CONN_STATS a;
+	std::memset((void *)&a, 0, sizeof(a));
+	if (which == 0) a.cli_listener_proc_ = true;
+	else if (which == 1) a.is_remote_listen_ = true;
+	else a.is_remote_cli_ = true;
+	const uint8_t *b = (const uint8_t *)&a;
+	for (size_t i = 0; i < sizeof(a); ++i)
+		if (b[i]) return (uint32_t)((i << 8) | b[i]);
+	return 0;
+}
 int ref_comm_nfields(void) { return (int)(sizeof(g_comm_offs) / sizeof(g_comm_offs[0])); }
 const char *ref_comm_field_name(int i) { return g_comm_offs[i].name; }
 size_t ref_comm_field_offset(int i) { return g_comm_offs[i].off; }
@@ -372,6 +390,7 @@ size_t ref_comm_sizeof(int which)
 	case 3: return sizeof(comm::LISTENER_STATE_NOTIFY);
 	case 4: return sizeof(comm::LISTENER_DAY_STATS);
 	case 5: return sizeof(GY_MACHINE_ID);
+	case 6: return sizeof(comm::ACTIVE_CONN_STATS);
 	default: return 0;
 	}
 }

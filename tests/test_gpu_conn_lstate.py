@@ -207,3 +207,109 @@ def test_standalone_hist_all_kinds(torch_mod, oracle, kind):
         ov, _, _, _ = oracle.hist_percentiles(kind, stats[k], total[k], [float(p) for p in pcts])
         assert gp[k].tolist() == ov
     eng.close()
+
+
+def test_active_conn_stats_pair_countmin_and_listener_sums(oracle):
+    """comm::ACTIVE_CONN_STATS roll-up (SURVEY 8f-4b; MCONN_HANDLER::handle_partha_active_conns): the Count-Min pair keyed by
+    (listener, client task group) bit-exact vs the oracle's restatement, exact per-listener sums vs numpy, remote-listener rows only
+    counted; estimates never below the exact per-pair totals (Count-Min over-estimates)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    rng = np.random.default_rng(41)
+    nh, sp = 4, 12
+    eng = _engine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False)
+    gids = {}
+    for h in range(nh):
+        mid = wire.machine_id(h)
+        eng.register_host(mid, "c")
+        s = np.arange(sp)
+        gids[h] = wire.glob_id(np.full(sp, h), s)
+        eng.register_listeners_np(mid, gids[h], wire.listener_netns(h, s), wire.listener_port(s))
+    L = oracle.lib()
+    for w in range(2):
+        p32 = np.zeros((4, 65536), dtype=np.uint32)
+        p64 = np.zeros((4, 65536), dtype=np.uint64)
+        tot = np.zeros(2, dtype=np.uint64)
+        allrec = []
+        for h in range(nh):
+            for msg in range(3):
+                n = int(rng.integers(1, 2049)) if msg else 2048  # MAX_NUM_CONNS rows per message
+                rec = wire.synth_active_conns(rng, n, h, sp)
+                raw = rec.tobytes()
+                eng.handle_partha_active_conns(wire.machine_id(h), raw, n)
+                o2 = np.zeros(2, dtype=np.uint64)
+                buf = np.frombuffer(raw, dtype=np.uint8)
+                L.gyo_active_conn_sketch_batch(oracle.ptr(buf, oracle.u8p), n, oracle.ptr(p32, oracle.u32p), oracle.ptr(p64, oracle.u64p), oracle.ptr(o2, oracle.u64p))
+                tot += o2
+                allrec.append(rec)
+        eng.window_close()
+        assert (eng.export_pair_cms(0) == p32).all()
+        assert (eng.export_pair_cms(1).view(np.uint64) == p64).all()
+        rec = np.concatenate(allrec)
+        local = (rec["flags"] & wire.ACTIVE_FLAG_REMOTE_LISTEN) == 0
+        c = eng.counters()
+        assert c["actconn_records"] == int(tot[0]) * 1 + (0 if w == 0 else prev_local) and c["actconn_remote_listen"] == int(tot[1]) + (0 if w == 0 else prev_remote)
+        prev_local, prev_remote = c["actconn_records"], c["actconn_remote_listen"]
+        # a few pairs: estimate >= exact total of the window, and == the oracle table's own estimate
+        lr = rec[local]
+        for k in rng.integers(0, len(lr), 6):
+            g, t = int(lr["listener_glob_id"][k]), int(lr["cli_aggr_task_id"][k])
+            sel = (lr["listener_glob_id"] == g) & (lr["cli_aggr_task_id"] == t)
+            assert eng.pair_cms(g, t, 0) >= int(lr["active_conns"][sel].sum())
+            assert eng.pair_cms(g, t, 1) >= int(lr["bytes_sent"][sel].sum() + lr["bytes_received"][sel].sum())
+        if w == 0:
+            first = rec
+    # exact cumulative per-listener sums over both windows
+    rec = np.concatenate([first, rec])
+    local = rec[(rec["flags"] & wire.ACTIVE_FLAG_REMOTE_LISTEN) == 0]
+    got = eng.export_active_conn_counters()
+    nunk = 0
+    for h in range(nh):
+        for s_ in range(sp):
+            sel = local["listener_glob_id"] == gids[h][s_]
+            exp = [int(sel.sum()), int(local["bytes_sent"][sel].sum()), int(local["bytes_received"][sel].sum()), int(local["active_conns"][sel].sum())]
+            assert got[h * sp + s_].tolist() == exp
+    known = np.isin(local["listener_glob_id"], np.concatenate(list(gids.values())))
+    assert eng.counters()["actconn_unknown_listener"] == int((~known).sum()) > 0
+    eng.close()
+
+
+def test_tcp_conn_pair_countmin_opt_in(oracle):
+    """gys_config.conn_pair_cms (connlistenmap_ / connclientmap_ roll-up): TCP_CONN_NOTIFY records also feed the
+    (listener, client task group) Count-Min pair, bit-exact vs the oracle; off by default (tables stay zero)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    rng = np.random.default_rng(43)
+    nh, sp, n = 3, 10, 1500
+    engs = {flag: _engine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False, conn_pair_cms=flag) for flag in (True, False)}
+    for e in engs.values():
+        for h in range(nh):
+            mid = wire.machine_id(h)
+            e.register_host(mid, "c")
+            s = np.arange(sp)
+            e.register_listeners_np(mid, wire.glob_id(np.full(sp, h), s), wire.listener_netns(h, s), wire.listener_port(s))
+    p32 = np.zeros((4, 65536), dtype=np.uint32)
+    p64 = np.zeros((4, 65536), dtype=np.uint64)
+    L = oracle.lib()
+    for h in range(nh):
+        rec = wire.synth_tcp_conns(rng, n, [h], sp, dup_frac=0.3)
+        rec["cli_task_aggr_id"] = wire.splitmix64(rng.integers(0, 25, n).astype(np.uint64) + np.uint64(h << 8))
+        tails = [bytes(rng.integers(32, 127, int(k), dtype=np.uint8).tolist()) for k in rng.integers(0, 40, n) * (rng.random(n) < 0.3)]
+        payload = wire.pack_variable(rec, tails)
+        for e in engs.values():
+            e.partha_tcp_conn_info(wire.machine_id(h), payload, n)
+        buf = np.frombuffer(payload, dtype=np.uint8)
+        got = L.gyo_tcp_conn_pair_batch(oracle.ptr(buf, oracle.u8p), n, C.cast(buf.ctypes.data + len(buf), oracle.u8p), oracle.ptr(p32, oracle.u32p),
+                                        oracle.ptr(p64, oracle.u64p))
+        assert got == n
+    for e in engs.values():
+        e.window_close()
+    assert (engs[True].export_pair_cms(0) == p32).all() and (engs[True].export_pair_cms(1).view(np.uint64) == p64).all()
+    assert p32.sum(axis=1).tolist() == [nh * n] * 4  # every row counts every connection once
+    assert engs[False].export_pair_cms(0).sum() == 0 and engs[False].export_pair_cms(1).sum() == 0
+    # the default registers are unaffected by the option
+    assert (engs[True].export_cms(0) == engs[False].export_cms(0)).all() and (engs[True].export_hll() == engs[False].export_hll()).all()
+    for e in engs.values():
+        e.close()

@@ -97,6 +97,8 @@ def test_wire_layouts_vs_reference_structs(reflib):
             assert wire.LISTENER_STATE_NOTIFY.fields[f][1] == off, name
         elif st == "LISTENER_DAY_STATS":
             assert day[f] == off, name
+        elif st == "ACTIVE_CONN_STATS":
+            assert wire.ACTIVE_CONN_STATS.fields[f][1] == off, name
         elif st == "COMM_HEADER":
             assert hdr[f] == off, name
         else:
@@ -106,6 +108,15 @@ def test_wire_layouts_vs_reference_structs(reflib):
     assert {"TCP_CONN_NOTIFY." + n for n in wire.TCP_CONN_NOTIFY.names} <= seen
     assert {"LISTENER_STATE_NOTIFY." + n for n in wire.LISTENER_STATE_NOTIFY.names if n != "tail_pad"} <= seen
     assert {"LISTENER_DAY_STATS." + n for n in day} <= seen
+    assert {"ACTIVE_CONN_STATS." + n for n in wire.ACTIVE_CONN_STATS.names if n not in ("flags", "tail_pad")} <= seen
+    # the three 1-bit flags behind active_conns_: byte offset and bit values as the reference's compiler lays the bit-fields out
+    if hasattr(R, "ref_active_conn_flag"):
+        import ctypes as C
+        R.ref_active_conn_flag.restype, R.ref_active_conn_flag.argtypes = C.c_uint32, [C.c_int]
+        off = wire.ACTIVE_CONN_STATS.fields["flags"][1]
+        assert [R.ref_active_conn_flag(i) for i in range(3)] == [(off << 8) | wire.ACTIVE_FLAG_CLI_LISTENER_PROC, (off << 8) | wire.ACTIVE_FLAG_REMOTE_LISTEN,
+                                                                 (off << 8) | wire.ACTIVE_FLAG_REMOTE_CLI]
+        assert R.ref_comm_sizeof(6) == wire.ACTIVE_CONN_STATS.itemsize == 104
     want = [wire.PM_HDR_MAGIC, wire.COMM_EVENT_NOTIFY, 1, 18, 16 << 20, wire.NOTIFY_TCP_CONN, wire.NOTIFY_LISTENER_STATE, 2048, 512, 2048,
             wire.LISTEN_FLAG_DELETE]
     assert [R.ref_comm_const(i) for i in range(11)] == want
