@@ -23,6 +23,7 @@
 
 #include "gys_kernels.hpp"
 #include "gys_rollup.hpp"
+#include "gys_huge.hpp"
 
 using namespace gys;
 
@@ -185,6 +186,11 @@ struct gys_ctx {
 	uint64_t win_graph_launches = 0;
 	int64_t i64min = INT64_MIN;   // stable host source of the graph's 8-byte copy
 	uint32_t *huge_scratch = nullptr;
+	// several-workgroups-per-key path (gys_huge.hpp): per-entry accumulators, chunk prefix, global tail list, fallback list
+	unsigned long long *huge_acc = nullptr, *huge_tail = nullptr;
+	uint32_t *huge_bm = nullptr, *huge_chunk_off = nullptr;
+	MergeEnt *huge_fb_list = nullptr;
+	uint32_t huge_maxent = 0;
 	int huge_blocks = 0;
 	uint32_t *hll32 = nullptr;
 	unsigned long long *svc_ctr = nullptr;
@@ -611,7 +617,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	unsigned long long *ghist = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
 	long long *gmax = (long long *)(c->arena + c->al.off_i64max);
 	if (td) {
-		HIPCHK(hipMemsetAsync(c->merge_count, 0, FIN_NCOUNTS * 4, c->stream)); // merge / huge list lengths, run allocation cursor
+		HIPCHK(hipMemsetAsync(c->merge_count, 0, 8 * 4, c->stream)); // merge / huge / fallback list lengths, run allocation cursor
 		c->resp_dirty = true;
 	}
 	FinP fin{};
@@ -814,12 +820,39 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		}
 	}
 	{
+		// huge keys (> 16 384 values in this call): several workgroups per key (gys_huge.hpp); what that path cannot take -- entries
+		// beyond its pool, more than 4 096 values >= 16 384 in one key -- is handed to the one-workgroup kernel through a fallback list
 		ProfScope ps(c, "digest_huge");
+		static const bool old_huge = getenv("GYS_OLD_HUGE") != nullptr; // A/B
 		HugeP h{};
 		h.d = digest_params(c);
-		h.huge_list = c->huge_list;
-		h.huge_count = c->merge_count + FIN_HUGE;
 		h.scratch = c->huge_scratch;
+		if (old_huge) {
+			h.huge_list = c->huge_list;
+			h.huge_count = c->merge_count + FIN_HUGE;
+		} else {
+			Huge2P q{};
+			q.d = h.d;
+			q.list = c->huge_list;
+			q.count = c->merge_count + FIN_HUGE;
+			q.bins = c->huge_scratch;
+			q.acc = c->huge_acc;
+			q.bm = c->huge_bm;
+			q.chunk_off = c->huge_chunk_off;
+			q.tail = c->huge_tail;
+			q.tail_count = c->merge_count + 9;
+			q.tail_cap = 1u << 20;
+			q.maxent = c->huge_maxent;
+			q.fb_list = c->huge_fb_list;
+			q.fb_count = c->merge_count + 6;
+			q.nent_used = c->merge_count + 7;
+			hipLaunchKernelGGL(k_huge_plan, dim3(1), dim3(1024), 0, c->stream, q);
+			hipLaunchKernelGGL(k_huge_clear, dim3((uint32_t)c->ncu * 8), dim3(256), 0, c->stream, q);
+			hipLaunchKernelGGL(k_huge_count, dim3((uint32_t)c->ncu * 2), dim3(1024), GYS_HB_BINS * 4, c->stream, q);
+			hipLaunchKernelGGL(k_huge_merge, dim3((uint32_t)c->ncu), dim3(1024), GYS_HB_BINS * 4, c->stream, q);
+			h.huge_list = c->huge_fb_list;
+			h.huge_count = c->merge_count + 6;
+		}
 		hipLaunchKernelGGL(k_digest_huge, dim3(c->huge_blocks), dim3(256), 0, c->stream, h);
 	}
 	HIPCHK(hipGetLastError());
@@ -1199,6 +1232,14 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1));
 		if (c->huge_blocks < 1) c->huge_blocks = 1;
 		ALLOC(c->huge_scratch, (uint64_t)c->huge_blocks * GYS_HUGE_BINS);
+		c->huge_maxent = (uint32_t)((uint64_t)c->huge_blocks * GYS_HUGE_BINS / GYS_HB_BINS); // the same scratch, 64 KiB per entry
+		ALLOC(c->huge_acc, (uint64_t)c->huge_maxent * GYS_HB_ACC);
+		ALLOC(c->huge_bm, (uint64_t)c->huge_maxent * 16);
+		ALLOC(c->huge_chunk_off, (uint64_t)c->huge_maxent + 1);
+		ALLOC(c->huge_tail, (uint64_t)1 << 20);
+		ALLOC(c->huge_fb_list, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1) + 1);
+		HIPCHK(hipFuncSetAttribute((const void *)k_huge_count, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_HB_BINS * 4));
+		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_HB_BINS * 4));
 	}
 #undef ALLOC
 	// dev_alloc zeroes with hipMemset on the NULL stream, which may still be in flight; the context stream is non-blocking, so the
@@ -1261,7 +1302,7 @@ void gys_destroy(gys_ctx *c)
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
-			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
+			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};

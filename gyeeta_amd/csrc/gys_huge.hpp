@@ -1,0 +1,461 @@
+// Huge keys -- more than GYS_MERGE_LDS_MAX (16 384) values of ONE service in one ingest call (a heavy hitter of a Zipf stream, or any key
+// of a long single-host replay: BASELINE configs 0 and 4) -- with SEVERAL workgroups per key.
+//
+// k_digest_huge (gys_kernels.hpp) gives such a key one workgroup and a 2^20-bin count array in HBM: 8 MB of scratch traffic and ~120 us
+// per key, at most 64 keys at a time (C1: 14.6 ms for 100 keys).  Here the key's run of values (written to `staged` by the spill pass) is
+// cut into chunks of 16 384 values and the work is three small kernels sized by the device-side list length:
+//   k_huge_plan   one workgroup: chunks per entry -> prefix (flat chunk index -> entry), entries beyond the pool go to the fallback list
+//   k_huge_count  one 1024-thread workgroup per chunk (persistent over the flat chunk list): exact counts of the values < 16 384 in a
+//                 64-KiB LDS image (integer-ms response times: all but ~10^-5 of them), the chunk's RESP_TIME_HASH bucket deltas read off
+//                 the image, CONN_BITMAP bits, min / max; the image is added to the entry's 64-KiB bin array in HBM (non-zero bins only);
+//                 values >= 16 384 go to a global tail list
+//   k_huge_merge  one 1024-thread workgroup per entry: bins -> LDS (+ the entry's buffered words), block scan, every bin's rank interval
+//                 intersected with the cluster rank intervals (the exact-integer assignment of k_digest_huge), tail values ranked among
+//                 themselves, records folded, clusters written back
+// The result is bit-identical to k_digest_merge / k_digest_huge (same definition, DESIGN.md "t-digest").  An entry with more than 4 096
+// tail values, entries beyond the pool, or a full tail list fall back to k_digest_huge.
+#pragma once
+
+namespace gys {
+
+#define GYS_HB_BINS 16384u      // exact one-value bins of the LDS image / of an entry's bin array
+#define GYS_HB_CHUNK 16384u     // values per chunk
+#define GYS_HB_TAIL_LDS 4096u   // tail values (>= GYS_HB_BINS) one entry may carry on this path
+#define GYS_HB_ACC 40u          // per entry: u64 [0..15] bucket counts, [16..31] bucket sums, [32] min | max << 32 (as biased u32), [33..] spare
+
+struct Huge2P {
+	DigestP d;
+	const MergeEnt *list;       // huge list (finalize_key)
+	const uint32_t *count;
+	uint32_t *bins;             // [maxent][GYS_HB_BINS]
+	unsigned long long *acc;    // [maxent][GYS_HB_ACC]
+	uint32_t *bm;               // [maxent][16]
+	uint32_t *chunk_off;        // [maxent + 1]
+	unsigned long long *tail;   // entry << 32 | value
+	uint32_t *tail_count;
+	uint32_t tail_cap, maxent;
+	MergeEnt *fb_list;          // fallback entries for k_digest_huge
+	uint32_t *fb_count;
+	uint32_t *nent_used;        // entries this path handles ( = min(count, maxent), 0 when the tail list overflowed)
+};
+
+// ---- plan + clear: chunk prefix over the entries this path takes; the rest go to the fallback list
+__global__ __launch_bounds__(1024) void k_huge_plan(Huge2P p)
+{
+	__shared__ uint32_t s_w[16];
+	const uint32_t n = *p.count, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t nuse = min(n, p.maxent);
+	uint32_t run = 0;
+	for (uint32_t base = 0; base < nuse; base += 1024u) {
+		const uint32_t e = base + tid;
+		const uint32_t c = e < nuse ? (p.list[e].mrun + GYS_HB_CHUNK - 1u) / GYS_HB_CHUNK : 0u;
+		uint32_t inc = c;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(inc, d, 64);
+			if ((int)lane >= d) inc += t;
+		}
+		if (lane == 63u) s_w[wave] = inc;
+		__syncthreads();
+		uint32_t wo = 0, tot = 0;
+		for (uint32_t k = 0; k < 16u; ++k) {
+			if (k < wave) wo += s_w[k];
+			tot += s_w[k];
+		}
+		if (e < nuse) p.chunk_off[e] = run + wo + inc - c;
+		run += tot;
+		__syncthreads();
+	}
+	if (tid == 0) {
+		p.chunk_off[nuse] = run;
+		*p.nent_used = nuse;
+		*p.tail_count = 0;
+	}
+	for (uint32_t e = nuse + tid; e < n; e += 1024u) p.fb_list[atomicAdd(p.fb_count, 1u)] = p.list[e];
+}
+
+__global__ __launch_bounds__(256) void k_huge_clear(Huge2P p)
+{
+	const uint32_t nuse = min(*p.count, p.maxent);
+	const uint64_t nb = (uint64_t)nuse * (GYS_HB_BINS / 4u), stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) ((uint4 *)p.bins)[i] = make_uint4(0, 0, 0, 0);
+	const uint64_t na = (uint64_t)nuse * GYS_HB_ACC;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride)
+		p.acc[i] = (i % GYS_HB_ACC) == 32u ? (0xFFFFFFFFull | (0ull << 32)) : 0ull; // min = +inf, max = 0 (values are >= 0)
+	const uint64_t nm = (uint64_t)nuse * 16u;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += stride) p.bm[i] = 0;
+}
+
+// ---- count: one chunk of one entry's run per workgroup
+__global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
+{
+	extern __shared__ uint32_t s_img[]; // [GYS_HB_BINS]
+	__shared__ unsigned long long s_hc[16], s_hs[16];
+	__shared__ uint32_t s_bm[16], s_mm[2];
+	const uint32_t nuse = *p.nent_used, tid = threadIdx.x;
+	if (!nuse) return;
+	const uint32_t nchunks = p.chunk_off[nuse];
+	for (uint32_t ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
+		uint32_t lo = 0, hi = nuse - 1; // entry of the flat chunk index: largest e with chunk_off[e] <= ck
+		while (lo < hi) {
+			const uint32_t mid = (lo + hi + 1) >> 1;
+			if (p.chunk_off[mid] <= ck) lo = mid; else hi = mid - 1;
+		}
+		const uint32_t e = lo;
+		const MergeEnt ent = p.list[e];
+		const uint32_t c = ck - p.chunk_off[e];
+		const uint32_t v0 = c * GYS_HB_CHUNK, v1 = min(ent.mrun, v0 + GYS_HB_CHUNK);
+		const uint32_t *run = p.d.staged + (ent.off_end - ent.mrun);
+		for (uint32_t i = tid; i < GYS_HB_BINS; i += 1024u) s_img[i] = 0;
+		if (tid < 16u) {
+			s_hc[tid] = 0;
+			s_hs[tid] = 0;
+			s_bm[tid] = 0;
+		}
+		if (tid == 0) {
+			s_mm[0] = 0xFFFFFFFFu;
+			s_mm[1] = 0;
+		}
+		__syncthreads();
+		uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
+		for (uint32_t i = v0 + tid; i < v1; i += 1024u) {
+			const uint32_t word = run[i], v = word >> GYS_ROW_BITS, row = word & 0x1Fu;
+			lmin = min(lmin, v);
+			lmax = max(lmax, v);
+			const uint32_t b = resp_bucket((int64_t)v);
+			const uint32_t bit = (1u << b) << ((row & 1u) * 16u); // CONN_BITMAP::add_response (common/gy_socket_stat.h:403-410): every run value is of the open window
+			if ((s_bm[row >> 1] & bit) == 0) atomicOr(&s_bm[row >> 1], bit);
+			if (v < GYS_HB_BINS) {
+				atomicAdd(&s_img[v], 1u);
+			} else { // bucket 14 (>= 15 001): its deltas directly; the value itself to the tail list
+				atomicAdd(&s_hc[b], 1ull);
+				atomicAdd(&s_hs[b], (unsigned long long)v);
+				const uint32_t at = atomicAdd(p.tail_count, 1u);
+				if (at < p.tail_cap) p.tail[at] = ((unsigned long long)e << 32) | v;
+			}
+		}
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1) {
+			lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64));
+			lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
+		}
+		if ((tid & 63u) == 0) {
+			atomicMin(&s_mm[0], lmin);
+			atomicMax(&s_mm[1], lmax);
+		}
+		__syncthreads();
+		// the image: into the entry's bins (non-zero only) and, bin by bin, into the bucket deltas (GY_HISTOGRAM::add_data for cnt values
+		// equal to the bin); a thread's 16 consecutive bins touch at most three buckets
+		{
+			uint32_t *gb = p.bins + (size_t)e * GYS_HB_BINS;
+			uint32_t curb = 0xFFu;
+			unsigned long long ac = 0, as = 0;
+			for (uint32_t k = 0; k < 16u; ++k) {
+				const uint32_t bin = tid * 16u + k, cnt = s_img[bin];
+				if (!cnt) continue;
+				atomicAdd(&gb[bin], cnt);
+				const uint32_t b = resp_bucket((int64_t)bin);
+				if (b != curb) {
+					if (ac) {
+						atomicAdd(&s_hc[curb], ac);
+						atomicAdd(&s_hs[curb], as);
+					}
+					curb = b;
+					ac = 0;
+					as = 0;
+				}
+				ac += cnt;
+				as += (unsigned long long)cnt * bin;
+			}
+			if (ac) {
+				atomicAdd(&s_hc[curb], ac);
+				atomicAdd(&s_hs[curb], as);
+			}
+		}
+		__syncthreads();
+		unsigned long long *ga = p.acc + (size_t)e * GYS_HB_ACC;
+		if (tid < 16u) {
+			if (s_hc[tid]) {
+				atomicAdd(&ga[tid], s_hc[tid]);
+				atomicAdd(&ga[16u + tid], s_hs[tid]);
+			}
+			if (s_bm[tid]) atomicOr(&p.bm[(size_t)e * 16u + tid], s_bm[tid]);
+		}
+		if (tid == 16u && s_mm[0] != 0xFFFFFFFFu) {
+			uint32_t *mm = (uint32_t *)&ga[32];
+			atomicMin(&mm[0], s_mm[0]);
+			atomicMax(&mm[1], s_mm[1]);
+		}
+		__syncthreads();
+	}
+}
+
+// ---- merge: one workgroup per entry
+__global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
+{
+	extern __shared__ uint32_t s_img[];           // [GYS_HB_BINS] the entry's exact value counts (run + buffered words)
+	__shared__ int64_t s_csum[GYS_TD_NB];
+	__shared__ uint32_t s_ccnt[GYS_TD_NB];
+	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
+	__shared__ uint64_t s_T[GYS_TD_NB + 1];
+	__shared__ unsigned long long s_osum[GYS_TD_NB], s_ocnt[GYS_TD_NB];
+	__shared__ uint32_t s_part[1024], s_w[16];
+	__shared__ uint32_t s_tail[GYS_HB_TAIL_LDS];
+	__shared__ unsigned long long s_ha[32], s_hw[32]; // buffered words: exact {count, sum} per bucket, all not yet folded / window part
+	__shared__ uint32_t s_bm[16];
+	__shared__ uint32_t s_nc, s_ntail, s_over;
+	__shared__ int32_t s_min, s_max, s_wmax;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t nuse = *p.nent_used;
+	const bool tail_lost = *p.tail_count > p.tail_cap; // the global tail list overflowed: every entry goes to the fallback
+	for (uint32_t e = blockIdx.x; e < nuse; e += gridDim.x) {
+		const MergeEnt ent = p.list[e];
+		if (tail_lost) {
+			if (tid == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = ent;
+			continue;
+		}
+		const uint32_t slot = ent.slot, m = ent.mrun, npend = ent.nbuf;
+		const uint4 mt = *(const uint4 *)&p.d.td_meta[slot];
+		const uint32_t nh = mt.y & 0xFFFFu, nw = mt.y >> 16, nwin0 = max(nh, nw);
+		const uint32_t *pend = p.d.td_pend + (size_t)slot * p.d.pcap;
+		const uint32_t *gb = p.bins + (size_t)e * GYS_HB_BINS;
+		for (uint32_t i = tid; i < GYS_HB_BINS / 4u; i += 1024u) ((uint4 *)s_img)[i] = ((const uint4 *)gb)[i];
+		if (tid < GYS_TD_NB) {
+			s_osum[tid] = 0;
+			s_ocnt[tid] = 0;
+		}
+		if (tid < 32u) {
+			s_ha[tid] = 0;
+			s_hw[tid] = 0;
+		}
+		if (tid >= 32u && tid < 48u) s_bm[tid - 32u] = 0;
+		if (tid == 0) {
+			const int64_t *gs = p.d.td_sum + (size_t)slot * GYS_TD_NB; // compact the non-empty old clusters (serial: <= 200, once per huge key)
+			const uint32_t *gc = p.d.td_cnt + (size_t)slot * GYS_TD_NB;
+			uint32_t nc = 0;
+			uint64_t run = 0;
+			for (uint32_t j = 0; j < GYS_TD_NB; ++j) {
+				if (gc[j]) {
+					s_csum[nc] = gs[j];
+					s_ccnt[nc] = gc[j];
+					s_cpfx[nc] = run;
+					run += gc[j];
+					nc++;
+				}
+			}
+			s_cpfx[nc] = run;
+			s_nc = nc;
+			s_ntail = 0;
+			s_over = 0;
+			s_min = INT32_MAX;
+			s_max = INT32_MIN;
+			s_wmax = INT32_MIN;
+		}
+		__syncthreads();
+		// the buffered words join the counts; their not yet folded part is folded here (the run's deltas come from k_huge_count)
+		for (uint32_t i = tid; i < npend; i += 1024u) {
+			const uint32_t word = pend[i], v = word >> GYS_ROW_BITS;
+			if (v < GYS_HB_BINS) {
+				atomicAdd(&s_img[v], 1u);
+			} else {
+				const uint32_t at = atomicAdd(&s_ntail, 1u);
+				if (at < GYS_HB_TAIL_LDS) s_tail[at] = v; else s_over = 1;
+			}
+			if (i >= nh) {
+				const uint32_t hb = resp_bucket((int64_t)v);
+				atomicAdd(&s_ha[2 * hb], 1ull);
+				atomicAdd(&s_ha[2 * hb + 1], (unsigned long long)v);
+				atomicMin(&s_min, (int32_t)v);
+				atomicMax(&s_max, (int32_t)v);
+				if (i >= nwin0) {
+					atomicAdd(&s_hw[2 * hb], 1ull);
+					atomicAdd(&s_hw[2 * hb + 1], (unsigned long long)v);
+					const uint32_t row = word & 0x1Fu;
+					atomicOr(&s_bm[row >> 1], (1u << hb) << ((row & 1u) * 16u));
+					atomicMax(&s_wmax, (int32_t)v);
+				}
+			}
+		}
+		// this entry's tail values of the run
+		{
+			const uint32_t nt = min(*p.tail_count, p.tail_cap);
+			for (uint32_t i = tid; i < nt; i += 1024u) {
+				const unsigned long long t = p.tail[i];
+				if ((uint32_t)(t >> 32) != e) continue;
+				const uint32_t at = atomicAdd(&s_ntail, 1u);
+				if (at < GYS_HB_TAIL_LDS) s_tail[at] = (uint32_t)t; else s_over = 1;
+			}
+		}
+		__syncthreads();
+		if (s_over) { // too many large values for the LDS list: the general kernel takes this entry (nothing has been modified)
+			if (tid == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = ent;
+			__syncthreads();
+			continue;
+		}
+		const uint32_t nc = s_nc, ntail = s_ntail;
+		const uint64_t nold = s_cpfx[nc];
+		const uint64_t twoN = 2ull * (nold + (uint64_t)m + (uint64_t)npend);
+		if (tid >= 1u && tid < GYS_TD_NB) s_T[tid] = td_threshold(c_td_bnd[tid], twoN);
+		if (tid == 0) s_T[GYS_TD_NB] = ~0ull;
+		// block exclusive scan of the 16 bins per thread
+		uint32_t part = 0;
+		{
+			const uint4 *b4 = (const uint4 *)(s_img + tid * 16u);
+#pragma unroll
+			for (uint32_t i = 0; i < 4u; ++i) {
+				const uint4 v = b4[i];
+				part += v.x + v.y + v.z + v.w;
+			}
+		}
+		uint32_t inc = part;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(inc, d, 64);
+			if ((int)lane >= d) inc += t;
+		}
+		if (lane == 63u) s_w[wave] = inc;
+		__syncthreads();
+		uint32_t pfx = inc - part, nlow = 0;
+		for (uint32_t k = 0; k < 16u; ++k) {
+			if (k < wave) pfx += s_w[k];
+			nlow += s_w[k];
+		}
+		s_part[tid] = pfx;
+		__syncthreads();
+		// ---- old clusters: lt = #{values v : v * cc < cs} = #{v <= (cs - 1) / cc}  (cs >= 1; none when cs <= 0)
+		if (tid < nc) {
+			const int64_t cs = s_csum[tid];
+			const uint32_t cc = s_ccnt[tid];
+			uint64_t lt = 0;
+			if (cs > 0) {
+				const int64_t vmax = (cs - 1) / (int64_t)cc;
+				if (vmax >= (int64_t)GYS_HB_BINS) {
+					lt = nlow;
+					for (uint32_t j = 0; j < ntail; ++j) lt += ((int64_t)s_tail[j] <= vmax) ? 1u : 0u;
+				} else {
+					const uint32_t owner = (uint32_t)vmax / 16u;
+					lt = s_part[owner];
+					for (uint32_t b = owner * 16u; b <= (uint32_t)vmax; ++b) lt += s_img[b];
+				}
+			}
+			const uint64_t mid2 = 2ull * (s_cpfx[tid] + lt) + (uint64_t)cc;
+			const uint32_t cl = td_cluster_of(s_T, mid2);
+			atomicAdd(&s_osum[cl], (unsigned long long)cs);
+			atomicAdd(&s_ocnt[cl], (unsigned long long)cc);
+		}
+		// ---- values bin by bin: ranks [r0, r0 + c) of value v, le = old weight with mean <= v
+		{
+			uint64_t r0 = pfx;
+			const uint32_t vbeg = tid * 16u;
+			uint32_t ci = 0; // first compacted cluster with mean > v; monotone in v
+			{
+				uint32_t lo = 0, hi = nc;
+				const int64_t v = (int64_t)vbeg;
+				while (lo < hi) {
+					const uint32_t mid = (lo + hi) >> 1;
+					if (s_csum[mid] <= v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
+				}
+				ci = lo;
+			}
+			for (uint32_t b = vbeg; b < vbeg + 16u; ++b) {
+				const uint32_t c = s_img[b];
+				if (!c) continue;
+				const int64_t v = (int64_t)b;
+				while (ci < nc && s_csum[ci] <= v * (int64_t)s_ccnt[ci]) ci++;
+				const uint64_t le = s_cpfx[ci];
+				const uint64_t first = 2ull * (r0 + le) + 1ull, last = first + 2ull * (uint64_t)(c - 1u);
+				uint32_t cl = td_cluster_of(s_T, first);
+				const uint32_t cl_last = td_cluster_of(s_T, last);
+				uint64_t rbeg = r0;
+				for (; cl <= cl_last; ++cl) {
+					uint64_t rend;
+					if (cl == cl_last) {
+						rend = r0 + c;
+					} else {
+						const uint64_t Tn = s_T[cl + 1];
+						rend = (Tn / 2ull) - le; // ranks r with 2 (r + le) + 1 < Tn
+						if (rend > r0 + c) rend = r0 + c;
+					}
+					if (rend > rbeg) {
+						const uint64_t k = rend - rbeg;
+						atomicAdd(&s_osum[cl], (unsigned long long)(k * (uint64_t)v));
+						atomicAdd(&s_ocnt[cl], (unsigned long long)k);
+						rbeg = rend;
+					}
+				}
+				r0 += c;
+			}
+		}
+		// ---- the tail values: rank among themselves (ties by list position), all values below 16 384 precede them
+		for (uint32_t j = tid; j < ntail; j += 1024u) {
+			const uint32_t v = s_tail[j];
+			uint64_t r = nlow;
+			for (uint32_t jj = 0; jj < ntail; ++jj) {
+				const uint32_t u = s_tail[jj];
+				r += (u < v || (u == v && jj < j)) ? 1u : 0u;
+			}
+			uint32_t lo = 0, hi = nc; // old weight with mean <= v
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (s_csum[mid] <= (int64_t)v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
+			}
+			const uint64_t mid2 = 2ull * (r + s_cpfx[lo]) + 1ull;
+			const uint32_t cl = td_cluster_of(s_T, mid2);
+			atomicAdd(&s_osum[cl], (unsigned long long)v);
+			atomicAdd(&s_ocnt[cl], 1ull);
+		}
+		__syncthreads();
+		if (tid < GYS_TD_NB) {
+			p.d.td_sum[(size_t)slot * GYS_TD_NB + tid] = (int64_t)s_osum[tid];
+			p.d.td_cnt[(size_t)slot * GYS_TD_NB + tid] = (uint32_t)s_ocnt[tid];
+		}
+		{
+			// the key's records: run deltas (k_huge_count: every run value is not yet folded and of the open window) + the buffered words'
+			const unsigned long long *ga = p.acc + (size_t)e * GYS_HB_ACC;
+			const uint32_t n_all = npend + m - nh, n_win = npend + m - nwin0;
+			const uint32_t *rmm = (const uint32_t *)&ga[32];
+			const int32_t amax = max(s_max, (int32_t)rmm[1]), wmaxv = max(s_wmax, (int32_t)rmm[1]);
+			const uint32_t t = tid - 128u;
+			if (tid >= 128u && t < 16u) {
+				gys_hist_serial *ap = (gys_hist_serial *)&p.d.hist_all[slot] + t, *wp = (gys_hist_serial *)&p.d.hist_win[slot] + t;
+				const bool roll = mt.w != mt.z;
+				gys_hist_serial av = *ap;
+				if (t < 15u) {
+					av.count += s_ha[2 * t] + ga[t];
+					av.sum += (int64_t)(s_ha[2 * t + 1] + ga[16u + t]);
+				} else {
+					av.count += n_all;
+					if (av.sum < (int64_t)amax) av.sum = (int64_t)amax;
+				}
+				*ap = av;
+				gys_hist_serial wv;
+				if (roll) {
+					wv.count = 0;
+					wv.sum = t < 15u ? 0 : INT64_MIN;
+				} else {
+					wv = *wp;
+				}
+				if (t < 15u) {
+					wv.count += s_hw[2 * t] + ga[t];
+					wv.sum += (int64_t)(s_hw[2 * t + 1] + ga[16u + t]);
+				} else {
+					wv.count += n_win;
+					if (wv.sum < (int64_t)wmaxv) wv.sum = (int64_t)wmaxv;
+				}
+				*wp = wv;
+				uint32_t *bp = &p.d.bitmap[(size_t)slot * 16u + t];
+				*bp = (roll ? 0u : *bp) | s_bm[t] | p.bm[(size_t)e * 16u + t];
+			}
+			__syncthreads(); // every reader of the meta record is done before thread 0 rewrites it
+			if (tid == 0) {
+				*(uint4 *)&p.d.td_meta[slot] = make_uint4(0u, 0u, mt.z, mt.z); // buffer drained; the run made the window record current
+				p.d.td_cur[slot] = 0;
+				const int2 mm = p.d.td_minmax[slot];
+				p.d.td_minmax[slot] = make_int2(min(mm.x, min(s_min, (int32_t)rmm[0])), max(mm.y, amax));
+			}
+		}
+		__syncthreads();
+	}
+}
+
+} // namespace gys
