@@ -849,7 +849,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			hipLaunchKernelGGL(k_huge_plan, dim3(1), dim3(1024), 0, c->stream, q);
 			hipLaunchKernelGGL(k_huge_clear, dim3((uint32_t)c->ncu * 8), dim3(256), 0, c->stream, q);
 			hipLaunchKernelGGL(k_huge_count, dim3((uint32_t)c->ncu * 2), dim3(1024), GYS_HB_BINS * 4, c->stream, q);
-			hipLaunchKernelGGL(k_huge_merge, dim3((uint32_t)c->ncu), dim3(1024), GYS_HB_BINS * 4, c->stream, q);
+			hipLaunchKernelGGL(k_huge_merge, dim3((uint32_t)c->ncu), dim3(1024), (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4, c->stream, q);
 			h.huge_list = c->huge_fb_list;
 			h.huge_count = c->merge_count + 6;
 		}
@@ -1218,7 +1218,8 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		c->cms_nch = (uint32_t)std::min<uint64_t>(32, (S + 65535) / 65536);
 		ALLOC(c->cms_partial, (uint64_t)c->cms_nch * GYS_CMS_D * GYS_CMS_W);
 		HIPCHK(hipFuncSetAttribute((const void *)k_cms_partial, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_CMSF_CELLS * 4));
-		ALLOC(c->huge_list, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1) + 1);
+		// (entries above merge size class 1 take the several-workgroup path: the batch itself brought such a key more than CLASS1 - PEND_CAP values)
+		ALLOC(c->huge_list, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1) + 1);
 		ALLOC(c->query_list, 4);
 		ALLOC(c->merge_count, 16);
 		ALLOC(c->query_sum, GYS_TD_NB);
@@ -1237,9 +1238,9 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		ALLOC(c->huge_bm, (uint64_t)c->huge_maxent * 16);
 		ALLOC(c->huge_chunk_off, (uint64_t)c->huge_maxent + 1);
 		ALLOC(c->huge_tail, (uint64_t)1 << 20);
-		ALLOC(c->huge_fb_list, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1) + 1);
+		ALLOC(c->huge_fb_list, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1) + 1);
 		HIPCHK(hipFuncSetAttribute((const void *)k_huge_count, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_HB_BINS * 4));
-		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_HB_BINS * 4));
+		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4));
 	}
 #undef ALLOC
 	// dev_alloc zeroes with hipMemset on the NULL stream, which may still be in flight; the context stream is non-blocking, so the

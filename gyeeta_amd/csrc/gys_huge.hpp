@@ -12,15 +12,15 @@
 //   k_huge_merge  one 1024-thread workgroup per entry: bins -> LDS (+ the entry's buffered words), block scan, every bin's rank interval
 //                 intersected with the cluster rank intervals (the exact-integer assignment of k_digest_huge), tail values ranked among
 //                 themselves, records folded, clusters written back
-// The result is bit-identical to k_digest_merge / k_digest_huge (same definition, DESIGN.md "t-digest").  An entry with more than 4 096
-// tail values, entries beyond the pool, or a full tail list fall back to k_digest_huge.
+// The result is bit-identical to k_digest_merge / k_digest_huge (same definition, DESIGN.md "t-digest").  The values >= 16 384 of an entry (up to 16 384 of them) are
+// bitonic-sorted in LDS.  An entry with more of them, entries beyond the pool, or a full global tail list fall back to k_digest_huge.
 #pragma once
 
 namespace gys {
 
 #define GYS_HB_BINS 16384u      // exact one-value bins of the LDS image / of an entry's bin array
 #define GYS_HB_CHUNK 16384u     // values per chunk
-#define GYS_HB_TAIL_LDS 4096u   // tail values (>= GYS_HB_BINS) one entry may carry on this path
+#define GYS_HB_TAIL_LDS 16384u  // tail values (>= GYS_HB_BINS) one entry may carry on this path (sorted in LDS)
 #define GYS_HB_ACC 40u          // per entry: u64 [0..15] bucket counts, [16..31] bucket sums, [32] min | max << 32 (as biased u32), [33..] spare
 
 struct Huge2P {
@@ -193,14 +193,14 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 // ---- merge: one workgroup per entry
 __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 {
-	extern __shared__ uint32_t s_img[];           // [GYS_HB_BINS] the entry's exact value counts (run + buffered words)
+	extern __shared__ uint32_t s_img[];           // [GYS_HB_BINS] the entry's exact value counts (run + buffered words), then s_tail
+	uint32_t *s_tail = s_img + GYS_HB_BINS;       // [GYS_HB_TAIL_LDS] the entry's values >= GYS_HB_BINS, sorted
 	__shared__ int64_t s_csum[GYS_TD_NB];
 	__shared__ uint32_t s_ccnt[GYS_TD_NB];
 	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
 	__shared__ uint64_t s_T[GYS_TD_NB + 1];
 	__shared__ unsigned long long s_osum[GYS_TD_NB], s_ocnt[GYS_TD_NB];
 	__shared__ uint32_t s_part[1024], s_w[16];
-	__shared__ uint32_t s_tail[GYS_HB_TAIL_LDS];
 	__shared__ unsigned long long s_ha[32], s_hw[32]; // buffered words: exact {count, sum} per bucket, all not yet folded / window part
 	__shared__ uint32_t s_bm[16];
 	__shared__ uint32_t s_nc, s_ntail, s_over;
@@ -293,6 +293,27 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 			continue;
 		}
 		const uint32_t nc = s_nc, ntail = s_ntail;
+		if (ntail > 1u) { // bitonic sort of the tail in LDS (padded to a power of two with +inf); equal values are interchangeable
+			uint32_t n2 = 2;
+			while (n2 < ntail) n2 <<= 1;
+			for (uint32_t i = ntail + tid; i < n2; i += 1024u) s_tail[i] = 0xFFFFFFFFu;
+			__syncthreads();
+			for (uint32_t k = 2; k <= n2; k <<= 1) {
+				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+					for (uint32_t i = tid; i < n2; i += 1024u) {
+						const uint32_t ixj = i ^ j;
+						if (ixj > i) {
+							const uint32_t a = s_tail[i], b = s_tail[ixj];
+							if ((a > b) == ((i & k) == 0u)) {
+								s_tail[i] = b;
+								s_tail[ixj] = a;
+							}
+						}
+					}
+					__syncthreads();
+				}
+			}
+		}
 		const uint64_t nold = s_cpfx[nc];
 		const uint64_t twoN = 2ull * (nold + (uint64_t)m + (uint64_t)npend);
 		if (tid >= 1u && tid < GYS_TD_NB) s_T[tid] = td_threshold(c_td_bnd[tid], twoN);
@@ -330,8 +351,12 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 			if (cs > 0) {
 				const int64_t vmax = (cs - 1) / (int64_t)cc;
 				if (vmax >= (int64_t)GYS_HB_BINS) {
-					lt = nlow;
-					for (uint32_t j = 0; j < ntail; ++j) lt += ((int64_t)s_tail[j] <= vmax) ? 1u : 0u;
+					uint32_t lo = 0, hi = ntail; // sorted tail: values <= vmax
+					while (lo < hi) {
+						const uint32_t mid = (lo + hi) >> 1;
+						if ((int64_t)s_tail[mid] <= vmax) lo = mid + 1; else hi = mid;
+					}
+					lt = (uint64_t)nlow + lo;
 				} else {
 					const uint32_t owner = (uint32_t)vmax / 16u;
 					lt = s_part[owner];
@@ -386,14 +411,10 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 				r0 += c;
 			}
 		}
-		// ---- the tail values: rank among themselves (ties by list position), all values below 16 384 precede them
+		// ---- the tail values: sorted, all values below 16 384 precede them
 		for (uint32_t j = tid; j < ntail; j += 1024u) {
 			const uint32_t v = s_tail[j];
-			uint64_t r = nlow;
-			for (uint32_t jj = 0; jj < ntail; ++jj) {
-				const uint32_t u = s_tail[jj];
-				r += (u < v || (u == v && jj < j)) ? 1u : 0u;
-			}
+			const uint64_t r = (uint64_t)nlow + j;
 			uint32_t lo = 0, hi = nc; // old weight with mean <= v
 			while (lo < hi) {
 				const uint32_t mid = (lo + hi) >> 1;

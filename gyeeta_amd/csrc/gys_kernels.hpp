@@ -416,7 +416,7 @@ __device__ __forceinline__ void finalize_key(const FinP &p, bool valid, uint32_t
 				if (WRITE_CUR) p.td_cur[key] = cur;
 				if (cur > GYS_TD_PEND_CAP) {
 					ent.nbuf = cur;
-					cls = cur <= GYS_MERGE_CLASS0 ? FIN_CLASS0 : cur <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_CLASS2;
+					cls = cur <= GYS_MERGE_CLASS0 ? FIN_CLASS0 : cur <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_HUGE; // (> 4096: the several-workgroup path)
 				}
 			} else { // spilled
 				*(uint4 *)&p.td_meta[key] = make_uint4(npend0, nh | (nw << 16), win_epoch, mraw.w);
@@ -432,7 +432,7 @@ __device__ __forceinline__ void finalize_key(const FinP &p, bool valid, uint32_t
 					p.host_spill[p.svc_host[key]] = p.spill_stamp;
 				}
 				const uint64_t tot = (uint64_t)npend0 + m;
-				cls = tot <= GYS_MERGE_CLASS0 ? FIN_CLASS0 : tot <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : tot <= GYS_MERGE_LDS_MAX ? FIN_CLASS2 : FIN_HUGE;
+				cls = tot <= GYS_MERGE_CLASS0 ? FIN_CLASS0 : tot <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_HUGE;
 			}
 		}
 	}
