@@ -191,6 +191,7 @@ struct gys_ctx {
 	uint32_t *huge_bm = nullptr, *huge_chunk_off = nullptr;
 	MergeEnt *huge_fb_list = nullptr;
 	uint32_t huge_maxent = 0;
+	uint64_t huge_list_cap = 0;
 	int huge_blocks = 0;
 	uint32_t *hll32 = nullptr;
 	unsigned long long *svc_ctr = nullptr;
@@ -846,10 +847,15 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			q.fb_list = c->huge_fb_list;
 			q.fb_count = c->merge_count + 6;
 			q.nent_used = c->merge_count + 7;
-			hipLaunchKernelGGL(k_huge_plan, dim3(1), dim3(1024), 0, c->stream, q);
-			hipLaunchKernelGGL(k_huge_clear, dim3((uint32_t)c->ncu * 8), dim3(256), 0, c->stream, q);
-			hipLaunchKernelGGL(k_huge_count, dim3((uint32_t)c->ncu * 2), dim3(1024), GYS_HB_BINS * 4, c->stream, q);
-			hipLaunchKernelGGL(k_huge_merge, dim3((uint32_t)c->ncu), dim3(1024), (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4, c->stream, q);
+			// the pool holds huge_maxent entries: the list is walked in rounds (a round beyond the list's end costs four empty launches)
+			const uint64_t list_cap = std::min<uint64_t>(std::min<uint64_t>(nsvc, n / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1), c->huge_list_cap);
+			for (uint64_t first = 0; first < list_cap; first += c->huge_maxent) {
+				q.first = (uint32_t)first;
+				hipLaunchKernelGGL(k_huge_plan, dim3(1), dim3(1024), 0, c->stream, q);
+				hipLaunchKernelGGL(k_huge_clear, dim3((uint32_t)c->ncu * 8), dim3(256), 0, c->stream, q);
+				hipLaunchKernelGGL(k_huge_count, dim3((uint32_t)c->ncu * 2), dim3(1024), GYS_HB_BINS * 4, c->stream, q);
+				hipLaunchKernelGGL(k_huge_merge, dim3((uint32_t)c->ncu), dim3(1024), (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4, c->stream, q);
+			}
 			h.huge_list = c->huge_fb_list;
 			h.huge_count = c->merge_count + 6;
 		}
@@ -1219,7 +1225,8 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		ALLOC(c->cms_partial, (uint64_t)c->cms_nch * GYS_CMS_D * GYS_CMS_W);
 		HIPCHK(hipFuncSetAttribute((const void *)k_cms_partial, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_CMSF_CELLS * 4));
 		// (entries above merge size class 1 take the several-workgroup path: the batch itself brought such a key more than CLASS1 - PEND_CAP values)
-		ALLOC(c->huge_list, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1) + 1);
+		c->huge_list_cap = std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1);
+		ALLOC(c->huge_list, c->huge_list_cap + 1);
 		ALLOC(c->query_list, 4);
 		ALLOC(c->merge_count, 16);
 		ALLOC(c->query_sum, GYS_TD_NB);
@@ -1232,8 +1239,10 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		ALLOC(c->staged, B);
 		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1));
 		if (c->huge_blocks < 1) c->huge_blocks = 1;
-		ALLOC(c->huge_scratch, (uint64_t)c->huge_blocks * GYS_HUGE_BINS);
-		c->huge_maxent = (uint32_t)((uint64_t)c->huge_blocks * GYS_HUGE_BINS / GYS_HB_BINS); // the same scratch, 64 KiB per entry
+		// the several-workgroup path's pool shares the scratch: 64 KiB of bins per entry, up to 16 384 entries (1 GiB) when the batches can
+		// carry that many large keys; the one-workgroup fallback needs huge_blocks x 4 MiB of it
+		c->huge_maxent = (uint32_t)std::max<uint64_t>((uint64_t)c->huge_blocks * GYS_HUGE_BINS / GYS_HB_BINS, std::min<uint64_t>(c->huge_list_cap, 16384));
+		ALLOC(c->huge_scratch, (uint64_t)c->huge_maxent * GYS_HB_BINS);
 		ALLOC(c->huge_acc, (uint64_t)c->huge_maxent * GYS_HB_ACC);
 		ALLOC(c->huge_bm, (uint64_t)c->huge_maxent * 16);
 		ALLOC(c->huge_chunk_off, (uint64_t)c->huge_maxent + 1);

@@ -34,6 +34,7 @@ struct Huge2P {
 	unsigned long long *tail;   // entry << 32 | value
 	uint32_t *tail_count;
 	uint32_t tail_cap, maxent;
+	uint32_t first;             // this launch handles entries [first, first + maxent) of the list (the pool is reused round by round)
 	MergeEnt *fb_list;          // fallback entries for k_digest_huge
 	uint32_t *fb_count;
 	uint32_t *nent_used;        // entries this path handles ( = min(count, maxent), 0 when the tail list overflowed)
@@ -44,11 +45,11 @@ __global__ __launch_bounds__(1024) void k_huge_plan(Huge2P p)
 {
 	__shared__ uint32_t s_w[16];
 	const uint32_t n = *p.count, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t nuse = min(n, p.maxent);
+	const uint32_t nuse = n > p.first ? min(n - p.first, p.maxent) : 0u;
 	uint32_t run = 0;
 	for (uint32_t base = 0; base < nuse; base += 1024u) {
 		const uint32_t e = base + tid;
-		const uint32_t c = e < nuse ? (p.list[e].mrun + GYS_HB_CHUNK - 1u) / GYS_HB_CHUNK : 0u;
+		const uint32_t c = e < nuse ? (p.list[p.first + e].mrun + GYS_HB_CHUNK - 1u) / GYS_HB_CHUNK : 0u;
 		uint32_t inc = c;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
@@ -71,12 +72,12 @@ __global__ __launch_bounds__(1024) void k_huge_plan(Huge2P p)
 		*p.nent_used = nuse;
 		*p.tail_count = 0;
 	}
-	for (uint32_t e = nuse + tid; e < n; e += 1024u) p.fb_list[atomicAdd(p.fb_count, 1u)] = p.list[e];
 }
 
 __global__ __launch_bounds__(256) void k_huge_clear(Huge2P p)
 {
-	const uint32_t nuse = min(*p.count, p.maxent);
+	const uint32_t n = *p.count;
+	const uint32_t nuse = n > p.first ? min(n - p.first, p.maxent) : 0u;
 	const uint64_t nb = (uint64_t)nuse * (GYS_HB_BINS / 4u), stride = (uint64_t)gridDim.x * blockDim.x;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) ((uint4 *)p.bins)[i] = make_uint4(0, 0, 0, 0);
 	const uint64_t na = (uint64_t)nuse * GYS_HB_ACC;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 			if (p.chunk_off[mid] <= ck) lo = mid; else hi = mid - 1;
 		}
 		const uint32_t e = lo;
-		const MergeEnt ent = p.list[e];
+		const MergeEnt ent = p.list[p.first + e];
 		const uint32_t c = ck - p.chunk_off[e];
 		const uint32_t v0 = c * GYS_HB_CHUNK, v1 = min(ent.mrun, v0 + GYS_HB_CHUNK);
 		const uint32_t *run = p.d.staged + (ent.off_end - ent.mrun);
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 	const uint32_t nuse = *p.nent_used;
 	const bool tail_lost = *p.tail_count > p.tail_cap; // the global tail list overflowed: every entry goes to the fallback
 	for (uint32_t e = blockIdx.x; e < nuse; e += gridDim.x) {
-		const MergeEnt ent = p.list[e];
+		const MergeEnt ent = p.list[p.first + e];
 		if (tail_lost) {
 			if (tid == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = ent;
 			continue;
@@ -435,9 +436,10 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 			const unsigned long long *ga = p.acc + (size_t)e * GYS_HB_ACC;
 			const uint32_t n_all = npend + m - nh, n_win = npend + m - nwin0;
 			const uint32_t *rmm = (const uint32_t *)&ga[32];
-			const int32_t amax = max(s_max, (int32_t)rmm[1]), wmaxv = max(s_wmax, (int32_t)rmm[1]);
+			const int32_t rmin = m ? (int32_t)rmm[0] : INT32_MAX, rmax = m ? (int32_t)rmm[1] : INT32_MIN; // (no run: buffered words only)
+			const int32_t amin = min(s_min, rmin), amax = max(s_max, rmax), wmaxv = max(s_wmax, rmax);
 			const uint32_t t = tid - 128u;
-			if (tid >= 128u && t < 16u) {
+			if (tid >= 128u && t < 16u && n_all) {
 				gys_hist_serial *ap = (gys_hist_serial *)&p.d.hist_all[slot] + t, *wp = (gys_hist_serial *)&p.d.hist_win[slot] + t;
 				const bool roll = mt.w != mt.z;
 				gys_hist_serial av = *ap;
@@ -449,30 +451,34 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 					if (av.sum < (int64_t)amax) av.sum = (int64_t)amax;
 				}
 				*ap = av;
-				gys_hist_serial wv;
-				if (roll) {
-					wv.count = 0;
-					wv.sum = t < 15u ? 0 : INT64_MIN;
-				} else {
-					wv = *wp;
+				if (n_win) {
+					gys_hist_serial wv;
+					if (roll) {
+						wv.count = 0;
+						wv.sum = t < 15u ? 0 : INT64_MIN;
+					} else {
+						wv = *wp;
+					}
+					if (t < 15u) {
+						wv.count += s_hw[2 * t] + ga[t];
+						wv.sum += (int64_t)(s_hw[2 * t + 1] + ga[16u + t]);
+					} else {
+						wv.count += n_win;
+						if (wv.sum < (int64_t)wmaxv) wv.sum = (int64_t)wmaxv;
+					}
+					*wp = wv;
+					uint32_t *bp = &p.d.bitmap[(size_t)slot * 16u + t];
+					*bp = (roll ? 0u : *bp) | s_bm[t] | p.bm[(size_t)e * 16u + t];
 				}
-				if (t < 15u) {
-					wv.count += s_hw[2 * t] + ga[t];
-					wv.sum += (int64_t)(s_hw[2 * t + 1] + ga[16u + t]);
-				} else {
-					wv.count += n_win;
-					if (wv.sum < (int64_t)wmaxv) wv.sum = (int64_t)wmaxv;
-				}
-				*wp = wv;
-				uint32_t *bp = &p.d.bitmap[(size_t)slot * 16u + t];
-				*bp = (roll ? 0u : *bp) | s_bm[t] | p.bm[(size_t)e * 16u + t];
 			}
 			__syncthreads(); // every reader of the meta record is done before thread 0 rewrites it
 			if (tid == 0) {
-				*(uint4 *)&p.d.td_meta[slot] = make_uint4(0u, 0u, mt.z, mt.z); // buffer drained; the run made the window record current
+				*(uint4 *)&p.d.td_meta[slot] = make_uint4(0u, 0u, mt.z, n_win ? mt.z : mt.w); // buffer drained
 				p.d.td_cur[slot] = 0;
-				const int2 mm = p.d.td_minmax[slot];
-				p.d.td_minmax[slot] = make_int2(min(mm.x, min(s_min, (int32_t)rmm[0])), max(mm.y, amax));
+				if (n_all) {
+					const int2 mm = p.d.td_minmax[slot];
+					p.d.td_minmax[slot] = make_int2(min(mm.x, amin), max(mm.y, amax));
+				}
 			}
 		}
 		__syncthreads();
