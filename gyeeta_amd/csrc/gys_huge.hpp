@@ -202,6 +202,7 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 	__shared__ uint64_t s_T[GYS_TD_NB + 1];
 	__shared__ unsigned long long s_osum[GYS_TD_NB], s_ocnt[GYS_TD_NB];
 	__shared__ uint32_t s_part[1024], s_w[16];
+	__shared__ uint64_t s_cw[4];
 	__shared__ unsigned long long s_ha[32], s_hw[32]; // buffered words: exact {count, sum} per bucket, all not yet folded / window part
 	__shared__ uint32_t s_bm[16];
 	__shared__ uint32_t s_nc, s_ntail, s_over;
@@ -230,27 +231,54 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 			s_hw[tid] = 0;
 		}
 		if (tid >= 32u && tid < 48u) s_bm[tid - 32u] = 0;
-		if (tid == 0) {
-			const int64_t *gs = p.d.td_sum + (size_t)slot * GYS_TD_NB; // compact the non-empty old clusters (serial: <= 200, once per huge key)
-			const uint32_t *gc = p.d.td_cnt + (size_t)slot * GYS_TD_NB;
-			uint32_t nc = 0;
-			uint64_t run = 0;
-			for (uint32_t j = 0; j < GYS_TD_NB; ++j) {
-				if (gc[j]) {
-					s_csum[nc] = gs[j];
-					s_ccnt[nc] = gc[j];
-					s_cpfx[nc] = run;
-					run += gc[j];
-					nc++;
+		{ // compact the non-empty old clusters (order preserving) + exclusive prefix of their weights: threads 0..255, one cluster each
+			uint32_t c0 = 0;
+			int64_t sm0 = 0;
+			if (tid < GYS_TD_NB) {
+				c0 = p.d.td_cnt[(size_t)slot * GYS_TD_NB + tid];
+				sm0 = p.d.td_sum[(size_t)slot * GYS_TD_NB + tid];
+			}
+			const unsigned long long b0 = __ballot(c0 != 0);
+			uint64_t inc64 = c0;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint64_t t = __shfl_up(inc64, d, 64);
+				if ((int)lane >= d) inc64 += t;
+			}
+			if (tid < 256u) {
+				if (lane == 63u) s_cw[wave] = inc64;
+				if (lane == 0u) s_w[wave] = (uint32_t)__popcll(b0);
+			}
+			__syncthreads();
+			if (tid < 256u) {
+				uint32_t pb = 0, ncl = 0;
+				uint64_t wb = 0, tot = 0;
+				for (uint32_t k = 0; k < 4u; ++k) {
+					if (k < wave) {
+						pb += s_w[k];
+						wb += s_cw[k];
+					}
+					ncl += s_w[k];
+					tot += s_cw[k];
+				}
+				if (c0) {
+					const uint32_t pos = pb + (uint32_t)__popcll(b0 & (lane ? (~0ull >> (64 - lane)) : 0ull));
+					s_csum[pos] = sm0;
+					s_ccnt[pos] = c0;
+					s_cpfx[pos] = wb + inc64 - c0;
+				}
+				if (tid == 0) {
+					s_cpfx[ncl] = tot;
+					s_nc = ncl;
 				}
 			}
-			s_cpfx[nc] = run;
-			s_nc = nc;
-			s_ntail = 0;
-			s_over = 0;
-			s_min = INT32_MAX;
-			s_max = INT32_MIN;
-			s_wmax = INT32_MIN;
+			if (tid == 0) {
+				s_ntail = 0;
+				s_over = 0;
+				s_min = INT32_MAX;
+				s_max = INT32_MIN;
+				s_wmax = INT32_MIN;
+			}
 		}
 		__syncthreads();
 		// the buffered words join the counts; their not yet folded part is folded here (the run's deltas come from k_huge_count)
