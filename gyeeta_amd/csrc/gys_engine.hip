@@ -853,8 +853,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 				q.first = (uint32_t)first;
 				hipLaunchKernelGGL(k_huge_plan, dim3(1), dim3(1024), 0, c->stream, q);
 				hipLaunchKernelGGL(k_huge_clear, dim3((uint32_t)c->ncu * 8), dim3(256), 0, c->stream, q);
-				hipLaunchKernelGGL(k_huge_count, dim3((uint32_t)c->ncu * 4), dim3(1024), GYS_HB_BINS * 4, c->stream, q);
-				hipLaunchKernelGGL(k_huge_merge, dim3((uint32_t)c->ncu * 2), dim3(GYS_HM_THREADS), (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4, c->stream, q);
+				hipLaunchKernelGGL(k_huge_count, dim3((uint32_t)c->ncu * 2), dim3(1024), GYS_HB_BINS * 4, c->stream, q);
+				hipLaunchKernelGGL(k_huge_merge, dim3((uint32_t)c->ncu), dim3(1024), (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4, c->stream, q);
 			}
 			h.huge_list = c->huge_fb_list;
 			h.huge_count = c->merge_count + 6;
@@ -1239,7 +1239,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		ALLOC(c->staged, B);
 		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1));
 		if (c->huge_blocks < 1) c->huge_blocks = 1;
-		// the several-workgroup path's pool shares the scratch: 32 KiB of bins per entry, up to 16 384 entries (512 MiB) when the batches can
+		// the several-workgroup path's pool shares the scratch: 64 KiB of bins per entry, up to 16 384 entries (1 GiB) when the batches can
 		// carry that many large keys; the one-workgroup fallback needs huge_blocks x 4 MiB of it
 		c->huge_maxent = (uint32_t)std::max<uint64_t>((uint64_t)c->huge_blocks * GYS_HUGE_BINS / GYS_HB_BINS, std::min<uint64_t>(c->huge_list_cap, 16384));
 		ALLOC(c->huge_scratch, (uint64_t)c->huge_maxent * GYS_HB_BINS);

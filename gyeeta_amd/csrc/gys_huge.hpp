@@ -5,23 +5,22 @@
 // per key, at most 64 keys at a time (C1: 14.6 ms for 100 keys).  Here the key's run of values (written to `staged` by the spill pass) is
 // cut into chunks of 16 384 values and the work is three small kernels sized by the device-side list length:
 //   k_huge_plan   one workgroup: chunks per entry -> prefix (flat chunk index -> entry), entries beyond the pool go to the fallback list
-//   k_huge_count  one 1024-thread workgroup per chunk (persistent over the flat chunk list): exact counts of the values < 8 192 in a
-//                 32-KiB LDS image (integer-ms response times: all but ~10^-5 of them), the chunk's RESP_TIME_HASH bucket deltas read off
-//                 the image, CONN_BITMAP bits, min / max; the image is added to the entry's 32-KiB bin array in HBM (non-zero bins only);
-//                 values >= 8 192 go to a global tail list
-//   k_huge_merge  one 512-thread workgroup per entry (two per CU): bins -> LDS (+ the entry's buffered words), block scan, every bin's rank interval
+//   k_huge_count  one 1024-thread workgroup per chunk (persistent over the flat chunk list): exact counts of the values < 16 384 in a
+//                 64-KiB LDS image (integer-ms response times: all but ~10^-5 of them), the chunk's RESP_TIME_HASH bucket deltas read off
+//                 the image, CONN_BITMAP bits, min / max; the image is added to the entry's 64-KiB bin array in HBM (non-zero bins only);
+//                 values >= 16 384 go to a global tail list
+//   k_huge_merge  one 1024-thread workgroup per entry: bins -> LDS (+ the entry's buffered words), block scan, every bin's rank interval
 //                 intersected with the cluster rank intervals (the exact-integer assignment of k_digest_huge), tail values ranked among
 //                 themselves, records folded, clusters written back
-// The result is bit-identical to k_digest_merge / k_digest_huge (same definition, DESIGN.md "t-digest").  The values >= 8 192 of an entry (up to 8 192 of them) are
+// The result is bit-identical to k_digest_merge / k_digest_huge (same definition, DESIGN.md "t-digest").  The values >= 16 384 of an entry (up to 16 384 of them) are
 // bitonic-sorted in LDS.  An entry with more of them, entries beyond the pool, or a full global tail list fall back to k_digest_huge.
 #pragma once
 
 namespace gys {
 
-#define GYS_HB_BINS 8192u       // exact one-value bins of the LDS image / of an entry's bin array
+#define GYS_HB_BINS 16384u      // exact one-value bins of the LDS image / of an entry's bin array
 #define GYS_HB_CHUNK 16384u     // values per chunk
-#define GYS_HB_TAIL_LDS 8192u   // tail values (>= GYS_HB_BINS) one entry may carry on this path (sorted in LDS)
-#define GYS_HM_THREADS 512u     // k_huge_merge: 16 bins per thread; 78 KiB of LDS -> two workgroups per CU
+#define GYS_HB_TAIL_LDS 16384u  // tail values (>= GYS_HB_BINS) one entry may carry on this path (sorted in LDS)
 #define GYS_HB_ACC 40u          // per entry: u64 [0..15] bucket counts, [16..31] bucket sums, [32] min | max << 32 (as biased u32), [33..] spare
 
 struct Huge2P {
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 			if ((s_bm[row >> 1] & bit) == 0) atomicOr(&s_bm[row >> 1], bit);
 			if (v < GYS_HB_BINS) {
 				atomicAdd(&s_img[v], 1u);
-			} else { // beyond the image: its bucket deltas directly; the value itself to the tail list
+			} else { // bucket 14 (>= 15 001): its deltas directly; the value itself to the tail list
 				atomicAdd(&s_hc[b], 1ull);
 				atomicAdd(&s_hs[b], (unsigned long long)v);
 				const uint32_t at = atomicAdd(p.tail_count, 1u);
@@ -152,8 +151,8 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 			uint32_t *gb = p.bins + (size_t)e * GYS_HB_BINS;
 			uint32_t curb = 0xFFu;
 			unsigned long long ac = 0, as = 0;
-			for (uint32_t k = 0; k < GYS_HB_BINS / 1024u; ++k) {
-				const uint32_t bin = tid * (GYS_HB_BINS / 1024u) + k, cnt = s_img[bin];
+			for (uint32_t k = 0; k < 16u; ++k) {
+				const uint32_t bin = tid * 16u + k, cnt = s_img[bin];
 				if (!cnt) continue;
 				atomicAdd(&gb[bin], cnt);
 				const uint32_t b = resp_bucket((int64_t)bin);
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 }
 
 // ---- merge: one workgroup per entry
-__global__ __launch_bounds__(GYS_HM_THREADS) void k_huge_merge(Huge2P p)
+__global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 {
 	extern __shared__ uint32_t s_img[];           // [GYS_HB_BINS] the entry's exact value counts (run + buffered words), then s_tail
 	uint32_t *s_tail = s_img + GYS_HB_BINS;       // [GYS_HB_TAIL_LDS] the entry's values >= GYS_HB_BINS, sorted
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(GYS_HM_THREADS) void k_huge_merge(Huge2P p)
 	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
 	__shared__ uint64_t s_T[GYS_TD_NB + 1];
 	__shared__ unsigned long long s_osum[GYS_TD_NB], s_ocnt[GYS_TD_NB];
-	__shared__ uint32_t s_part[GYS_HM_THREADS], s_w[GYS_HM_THREADS / 64u];
+	__shared__ uint32_t s_part[1024], s_w[16];
 	__shared__ uint64_t s_cw[4];
 	__shared__ unsigned long long s_ha[32], s_hw[32]; // buffered words: exact {count, sum} per bucket, all not yet folded / window part
 	__shared__ uint32_t s_bm[16];
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(GYS_HM_THREADS) void k_huge_merge(Huge2P p)
 		const uint32_t nh = mt.y & 0xFFFFu, nw = mt.y >> 16, nwin0 = max(nh, nw);
 		const uint32_t *pend = p.d.td_pend + (size_t)slot * p.d.pcap;
 		const uint32_t *gb = p.bins + (size_t)e * GYS_HB_BINS;
-		for (uint32_t i = tid; i < GYS_HB_BINS / 4u; i += GYS_HM_THREADS) ((uint4 *)s_img)[i] = ((const uint4 *)gb)[i];
+		for (uint32_t i = tid; i < GYS_HB_BINS / 4u; i += 1024u) ((uint4 *)s_img)[i] = ((const uint4 *)gb)[i];
 		if (tid < GYS_TD_NB) {
 			s_osum[tid] = 0;
 			s_ocnt[tid] = 0;
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(GYS_HM_THREADS) void k_huge_merge(Huge2P p)
 		}
 		__syncthreads();
 		// the buffered words join the counts; their not yet folded part is folded here (the run's deltas come from k_huge_count)
-		for (uint32_t i = tid; i < npend; i += GYS_HM_THREADS) {
+		for (uint32_t i = tid; i < npend; i += 1024u) {
 			const uint32_t word = pend[i], v = word >> GYS_ROW_BITS;
 			if (v < GYS_HB_BINS) {
 				atomicAdd(&s_img[v], 1u);
@@ -309,7 +308,7 @@ __global__ __launch_bounds__(GYS_HM_THREADS) void k_huge_merge(Huge2P p)
 		// this entry's tail values of the run
 		{
 			const uint32_t nt = min(*p.tail_count, p.tail_cap);
-			for (uint32_t i = tid; i < nt; i += GYS_HM_THREADS) {
+			for (uint32_t i = tid; i < nt; i += 1024u) {
 				const unsigned long long t = p.tail[i];
 				if ((uint32_t)(t >> 32) != e) continue;
 				const uint32_t at = atomicAdd(&s_ntail, 1u);
@@ -326,11 +325,11 @@ __global__ __launch_bounds__(GYS_HM_THREADS) void k_huge_merge(Huge2P p)
 		if (ntail > 1u) { // bitonic sort of the tail in LDS (padded to a power of two with +inf); equal values are interchangeable
 			uint32_t n2 = 2;
 			while (n2 < ntail) n2 <<= 1;
-			for (uint32_t i = ntail + tid; i < n2; i += GYS_HM_THREADS) s_tail[i] = 0xFFFFFFFFu;
+			for (uint32_t i = ntail + tid; i < n2; i += 1024u) s_tail[i] = 0xFFFFFFFFu;
 			__syncthreads();
 			for (uint32_t k = 2; k <= n2; k <<= 1) {
 				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-					for (uint32_t i = tid; i < n2; i += GYS_HM_THREADS) {
+					for (uint32_t i = tid; i < n2; i += 1024u) {
 						const uint32_t ixj = i ^ j;
 						if (ixj > i) {
 							const uint32_t a = s_tail[i], b = s_tail[ixj];
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(GYS_HM_THREADS) void k_huge_merge(Huge2P p)
 		if (lane == 63u) s_w[wave] = inc;
 		__syncthreads();
 		uint32_t pfx = inc - part, nlow = 0;
-		for (uint32_t k = 0; k < GYS_HM_THREADS / 64u; ++k) {
+		for (uint32_t k = 0; k < 16u; ++k) {
 			if (k < wave) pfx += s_w[k];
 			nlow += s_w[k];
 		}
@@ -441,8 +440,8 @@ __global__ __launch_bounds__(GYS_HM_THREADS) void k_huge_merge(Huge2P p)
 				r0 += c;
 			}
 		}
-		// ---- the tail values: sorted, all values below GYS_HB_BINS precede them
-		for (uint32_t j = tid; j < ntail; j += GYS_HM_THREADS) {
+		// ---- the tail values: sorted, all values below 16 384 precede them
+		for (uint32_t j = tid; j < ntail; j += 1024u) {
 			const uint32_t v = s_tail[j];
 			const uint64_t r = (uint64_t)nlow + j;
 			uint32_t lo = 0, hi = nc; // old weight with mean <= v
