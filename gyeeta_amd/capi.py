@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgysketch.so")
+LIB_PATH = os.environ.get("GYS_LIB") or os.path.join(HERE, "lib", "libgysketch.so")  # GYS_LIB: an A/B build of the same library
 
 OK, ERR_INVAL, ERR_NOMEM, ERR_HIP, ERR_NOTFOUND, ERR_NOT_OWNER, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 MAX_BUCKETS, TD_NB, HLL_P, CMS_D, CMS_W, NSTATES, TOPN = 16, 200, 14, 4, 65536, 6, 10
@@ -155,6 +155,7 @@ SIGNATURES = {
     "gys_rccl_comm_create": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
     "gys_rccl_comm_destroy": (C.c_int, [vp]),
     "gys_window_close_rccl": (C.c_int, [vp, vp, C.c_uint64]),
+    "gys_window_close": (C.c_int, [vp, C.c_uint64]),
     "gys_tdigest_global_rccl": (C.c_int, [vp, vp, vp]),
     "gys_tdigest_sql_text": (C.c_int, [vp, C.c_uint64, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_tdigest_sql_binary": (C.c_int, [vp, C.c_uint64, vp, C.c_size_t, C.POINTER(C.c_size_t)]),

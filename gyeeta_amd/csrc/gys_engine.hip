@@ -225,6 +225,15 @@ struct gys_ctx {
 	uint8_t *last = nullptr; // copy of the reduced arena of the last finished window (queries read this)
 	uint32_t epoch = 1;      // current window number (0 = never)
 	bool prepared = false;
+	uint32_t *d_epoch = nullptr; // device copy of `epoch` for the captured window graph
+	// gys_window_close: the WHOLE single-rank window boundary as one hipGraph per (registry shape, which folds are due)
+	struct CloseGraph {
+		hipGraph_t g = nullptr;
+		hipGraphExec_t x = nullptr;
+		uint64_t shape = 0;
+		int state = 0; // 0 not tried, 1 usable, -1 capture unavailable
+	} close_graph[4];
+	uint64_t close_graph_launches = 0;
 	bool have_last = false;
 
 	// staging for host-buffer ingest
@@ -1167,6 +1176,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	ALLOC(c->host_state_epoch, H);
 	ALLOC(c->host_cluster, H);
 	ALLOC(c->counters, 16);
+	ALLOC(c->d_epoch, 4);
 	ALLOC(c->misc, 16);
 	ALLOC(c->svc_act, S * 4);
 	ALLOC(c->topn_slot, S < 65536 ? S : 65536);
@@ -1255,6 +1265,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	// dev_alloc zeroes with hipMemset on the NULL stream, which may still be in flight; the context stream is non-blocking, so the
 	// initialisation kernels / copies below must not start before every one of those clears has landed
 	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(c->d_epoch, &c->epoch, 4, hipMemcpyHostToDevice));
 	if (cfg->enable_tdigest) {
 		hipLaunchKernelGGL(k_minmax_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->td_minmax, S);
 		static const uint32_t one = 1; // static: the source of an async copy must outlive the call
@@ -1297,6 +1308,10 @@ void gys_destroy(gys_ctx *c)
 	if (c->stream) hipStreamSynchronize(c->stream);
 	if (c->win_graph_exec) hipGraphExecDestroy(c->win_graph_exec);
 	if (c->win_graph) hipGraphDestroy(c->win_graph);
+	for (auto &cg : c->close_graph) {
+		if (cg.x) hipGraphExecDestroy(cg.x);
+		if (cg.g) hipGraphDestroy(cg.g);
+	}
 	for (auto &sl : c->seg_ring) {
 		if (sl.host) hipHostFree(sl.host);
 		if (sl.dev) hipFree(sl.dev);
@@ -1314,7 +1329,7 @@ void gys_destroy(gys_ctx *c)
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
-			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->topn_slot,
+			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -1784,6 +1799,39 @@ int gys_reduce_sections(gys_ctx *c, gys_reduce_section out[4], uint32_t *nsectio
 	return GYS_OK;
 }
 
+// the kernels of the window boundary before the exchange (no level roll): folds of the per-service window accumulators into the
+// Count-Min rows, cluster STATE_ONE sums + HLL pack, eager-mode record sweep.  dev_epoch: read the window number from device memory
+// (captured graph) instead of the launch parameter.
+static int enqueue_prepare(gys_ctx *c, bool dev_epoch)
+{
+	PrepP p{};
+	p.host_summ = c->host_summ_win;
+	p.host_state = c->host_state;
+	p.host_state_epoch = c->host_state_epoch;
+	p.host_cluster = c->host_cluster;
+	p.nhosts = (uint32_t)c->hosts.size();
+	p.epoch = c->epoch;
+	p.d_epoch = dev_epoch ? c->d_epoch : nullptr;
+	p.cluster_state = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cluster;
+	p.hll32 = c->hll32;
+	p.hll8 = c->arena + c->al.off_hll8;
+	const uint32_t nthreads = std::max<uint32_t>(p.nhosts, (1u << GYS_HLL_P) / 4u);
+	int rcf = conn_fold(c);
+	if (!rcf) rcf = resp_cms_fold(c);
+	if (rcf) return rcf;
+	hipLaunchKernelGGL(k_window_prepare, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, p);
+	if (c->nsvc && !c->cfg.enable_tdigest) {
+		// eager mode (records updated per event): all-time += window (GY_HISTOGRAM::add_histogram), window cleared, and the all-service
+		// histogram of the window reduced into the arena in the same pass over the records.  With the t-digest on, the records are
+		// folded lazily from the value buffers ("per-key value buffers" in gys_kernels.hpp) and there is nothing to sweep here.
+		long long *gh = (long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
+		hipLaunchKernelGGL(k_hist_fold, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->hist_all,
+				   c->hist_win, (uint64_t)c->nsvc, 1, gh, (long long *)(c->arena + c->al.off_i64max));
+	}
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
 int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 {
 	if (!c) return GYS_ERR_INVAL;
@@ -1795,37 +1843,35 @@ int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 		const int rcl = level_roll(c, tusec); // before the eager fold below: it needs the cumulative records WITHOUT the closing window
 		if (rcl) return rcl;
 	}
-	PrepP p{};
-	p.host_summ = c->host_summ_win;
-	p.host_state = c->host_state;
-	p.host_state_epoch = c->host_state_epoch;
-	p.host_cluster = c->host_cluster;
-	p.nhosts = (uint32_t)c->hosts.size();
-	p.epoch = c->epoch;
-	p.cluster_state = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cluster;
-	p.hll32 = c->hll32;
-	p.hll8 = c->arena + c->al.off_hll8;
-	const uint32_t nthreads = std::max<uint32_t>(p.nhosts, (1u << GYS_HLL_P) / 4u);
 	{
 		ProfScope ps(c, "window_prepare");
-		{
-			int rcf = conn_fold(c);
-			if (!rcf) rcf = resp_cms_fold(c);
-			if (rcf) return rcf;
-		}
-		hipLaunchKernelGGL(k_window_prepare, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, p);
-		if (c->nsvc && !c->cfg.enable_tdigest) {
-			// eager mode (records updated per event): all-time += window (GY_HISTOGRAM::add_histogram), window cleared, and the all-service
-			// histogram of the window reduced into the arena in the same pass over the records.  With the t-digest on, the records are
-			// folded lazily from the value buffers ("per-key value buffers" in gys_kernels.hpp) and there is nothing to sweep here.
-			long long *gh = (long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
-			hipLaunchKernelGGL(k_hist_fold, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->hist_all,
-					   c->hist_win, (uint64_t)c->nsvc, 1, gh, (long long *)(c->arena + c->al.off_i64max));
-		}
+		const int rc = enqueue_prepare(c, false);
+		if (rc) return rc;
 	}
-	HIPCHK(hipGetLastError());
 	c->prepared = true;
 	return GYS_OK;
+}
+
+// the fixed sequence that ends a window: keep the (reduced) registers for queries, start the next window from zero
+static hipError_t enqueue_finish(gys_ctx *c, hipStream_t st)
+{
+	hipError_t e;
+	if ((e = hipMemcpyAsync(c->last, c->arena, c->al.total, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(c->arena, 0, c->al.total, st)) != hipSuccess) return e;
+	if ((e = hipMemcpyAsync(c->arena + c->al.off_i64max, &c->i64min, 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(c->hll32, 0, (uint64_t)4 << GYS_HLL_P, st)) != hipSuccess) return e;
+	if (c->nsvc) {
+		// CONN_BITMAP cleared every window (secs_to_reset_ = 5); lazily (per key, on its next touch) when the per-key pass runs
+		if (!c->cfg.enable_tdigest && (e = hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * 64, st)) != hipSuccess) return e;
+		if (c->svc_hll && (e = hipMemsetAsync(c->svc_hll, 0, (uint64_t)c->nsvc << c->cfg.svc_hll_p, st)) != hipSuccess) return e;
+	}
+	const uint64_t hb = (uint64_t)c->hosts.size() * 16 * 4;
+	if (hb) {
+		if ((e = hipMemcpyAsync(c->host_summ_last, c->host_summ_win, hb, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+		if ((e = hipMemsetAsync(c->host_summ_win, 0, hb, st)) != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL(k_epoch_inc, dim3(1), dim3(1), 0, st, c->d_epoch); // the device copy of the window number follows the host's
+	return hipGetLastError();
 }
 
 int gys_window_finish(gys_ctx *c)
@@ -1840,24 +1886,7 @@ int gys_window_finish(gys_ctx *c)
 	// window for a given registry shape: it is captured into a hipGraph the first time and replayed afterwards (one launch instead
 	// of seven); any capture problem falls back to plain stream operations.
 	const uint64_t shape = ((uint64_t)c->hosts.size() << 32) | (uint64_t)c->nsvc;
-	auto enqueue = [&](hipStream_t st) -> hipError_t {
-		hipError_t e;
-		if ((e = hipMemcpyAsync(c->last, c->arena, c->al.total, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
-		if ((e = hipMemsetAsync(c->arena, 0, c->al.total, st)) != hipSuccess) return e;
-		if ((e = hipMemcpyAsync(c->arena + c->al.off_i64max, &c->i64min, 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-		if ((e = hipMemsetAsync(c->hll32, 0, (uint64_t)4 << GYS_HLL_P, st)) != hipSuccess) return e;
-		if (c->nsvc) {
-			// CONN_BITMAP cleared every window (secs_to_reset_ = 5); lazily (per key, on its next touch) when the per-key pass runs
-			if (!c->cfg.enable_tdigest && (e = hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * 64, st)) != hipSuccess) return e;
-			if (c->svc_hll && (e = hipMemsetAsync(c->svc_hll, 0, (uint64_t)c->nsvc << c->cfg.svc_hll_p, st)) != hipSuccess) return e;
-		}
-		const uint64_t hb = (uint64_t)c->hosts.size() * 16 * 4;
-		if (hb) {
-			if ((e = hipMemcpyAsync(c->host_summ_last, c->host_summ_win, hb, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
-			if ((e = hipMemsetAsync(c->host_summ_win, 0, hb, st)) != hipSuccess) return e;
-		}
-		return hipSuccess;
-	};
+	auto enqueue = [&](hipStream_t st) -> hipError_t { return enqueue_finish(c, st); };
 	if (c->win_graph_state >= 0 && (c->win_graph_state == 0 || c->win_graph_shape != shape)) {
 		if (c->win_graph_exec) hipGraphExecDestroy(c->win_graph_exec);
 		if (c->win_graph) hipGraphDestroy(c->win_graph);
@@ -1882,6 +1911,63 @@ int gys_window_finish(gys_ctx *c)
 		HIPCHK(enqueue(c->stream));
 	}
 	HIPCHK(hipGetLastError());
+	c->epoch++;
+	c->prepared = false;
+	c->have_last = true;
+	return GYS_OK;
+}
+
+// The whole single-rank window boundary as ONE captured hipGraph (BASELINE config 5: "hipGraph-captured window"): the fold kernels that
+// are due (connection accumulators, Count-Min rows of the response path), k_window_prepare, the eager-mode sweep, the copy / clear
+// sequence and the window-number increment -- captured once per (registry shape, which folds are due) and replayed with one launch.
+// Not capturable, and therefore run as gys_window_prepare + gys_window_finish: multi-level windows (the snapshot masks depend on the
+// close time) and more than one rank (the exchange sits between the two halves; gys_window_close_rccl).
+int gys_window_close(gys_ctx *c, uint64_t tusec)
+{
+	if (!c) return GYS_ERR_INVAL;
+	if (c->prepared) {
+		set_err("window already prepared");
+		return GYS_ERR_STATE;
+	}
+	static const bool no_graph = getenv("GYS_NO_CLOSE_GRAPH") != nullptr;
+	if (c->cfg.enable_levels || c->cfg.nranks > 1 || no_graph) {
+		const int rc = gys_window_prepare(c, tusec);
+		return rc ? rc : gys_window_finish(c);
+	}
+	const uint32_t key = (c->conn_dirty && c->nsvc ? 1u : 0u) | (c->resp_dirty && c->nsvc && c->resp_win ? 2u : 0u);
+	const uint64_t shape = ((uint64_t)c->hosts.size() << 32) | (uint64_t)c->nsvc;
+	gys_ctx::CloseGraph &cg = c->close_graph[key];
+	if (cg.state >= 0 && (cg.state == 0 || cg.shape != shape)) {
+		if (cg.x) hipGraphExecDestroy(cg.x);
+		if (cg.g) hipGraphDestroy(cg.g);
+		cg.x = nullptr;
+		cg.g = nullptr;
+		cg.state = -1;
+		const bool cd = c->conn_dirty, rd = c->resp_dirty;
+		if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+			const int r1 = enqueue_prepare(c, true);
+			const hipError_t e1 = enqueue_finish(c, c->stream);
+			const hipError_t e2 = hipStreamEndCapture(c->stream, &cg.g);
+			if (r1 == GYS_OK && e1 == hipSuccess && e2 == hipSuccess && cg.g && hipGraphInstantiate(&cg.x, cg.g, nullptr, nullptr, 0) == hipSuccess) {
+				cg.state = 1;
+				cg.shape = shape;
+			}
+		}
+		(void)hipGetLastError();
+		c->conn_dirty = cd; // (the folds were only recorded, not run)
+		c->resp_dirty = rd;
+	}
+	if (cg.state == 1) {
+		ProfScope ps(c, "window_close_graph");
+		HIPCHK(hipGraphLaunch(cg.x, c->stream));
+		c->conn_dirty = false;
+		c->resp_dirty = false;
+		c->close_graph_launches++;
+		c->win_graph_launches++;
+	} else {
+		const int rc = gys_window_prepare(c, tusec);
+		return rc ? rc : gys_window_finish(c);
+	}
 	c->epoch++;
 	c->prepared = false;
 	c->have_last = true;

@@ -522,6 +522,9 @@ struct HostDesc {
 #define GYS_HOST_TBL_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define GYS_EV_DROPPED 0xFFFFFFFFu
 #define GYS_HOST_THREADS 1024
+#ifndef GYS_RESP_PREFETCH
+#define GYS_RESP_PREFETCH 0
+#endif
 #define GYS_SPLIT_PART 65536u // events per part when long segments are cut (SHARED)
 
 struct RespHostP {
@@ -629,17 +632,51 @@ __global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
 		// instruction cache two CUs share); the per-event results live in registers all the same: wd / lr are shifted down by 4 per
 		// group, so that every index stays a compile-time constant and after TPT / 4 groups event g sits at wd[g].
 		uint32_t wd[TPT], lr[TPT]; // staged word (GYS_EV_DROPPED: not kept) / local index | rank inside the key's tile run << 12
+		// software pipeline (GYS_RESP_PREFETCH): the words of group g + 1 are requested before group g is processed, so that the HBM
+		// latency of the next loads runs under the ~1000 instructions of the current group instead of in front of them
+		uint64_t n0[4], n1[4], n2[4];
+		if (GYS_RESP_PREFETCH) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const uint64_t i = t0 + tid + (uint64_t)u * T;
+				n0[u] = 0; n1[u] = 0; n2[u] = 0;
+				if (i < e1) {
+					n0[u] = p.ev[3 * i];
+					n1[u] = p.ev[3 * i + 1];
+					n2[u] = p.ev[3 * i + 2];
+				}
+			}
+		}
 #pragma unroll 1
 		for (int g = 0; g < TPT; g += 4) {
 			uint64_t w0[4], w1[4], w2[4];
+			if (GYS_RESP_PREFETCH) {
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const uint64_t i = t0 + tid + (uint64_t)(g + u) * T;
-				w0[u] = 0; w1[u] = 0; w2[u] = 0;
-				if (i < e1) {
-					w0[u] = p.ev[3 * i];
-					w1[u] = p.ev[3 * i + 1];
-					w2[u] = p.ev[3 * i + 2];
+				for (int u = 0; u < 4; ++u) {
+					w0[u] = n0[u]; w1[u] = n1[u]; w2[u] = n2[u];
+				}
+				if (g + 4 < TPT) {
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const uint64_t i = t0 + tid + (uint64_t)(g + 4 + u) * T;
+						n0[u] = 0; n1[u] = 0; n2[u] = 0;
+						if (i < e1) {
+							n0[u] = p.ev[3 * i];
+							n1[u] = p.ev[3 * i + 1];
+							n2[u] = p.ev[3 * i + 2];
+						}
+					}
+				}
+			} else {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint64_t i = t0 + tid + (uint64_t)(g + u) * T;
+					w0[u] = 0; w1[u] = 0; w2[u] = 0;
+					if (i < e1) {
+						w0[u] = p.ev[3 * i];
+						w1[u] = p.ev[3 * i + 1];
+						w2[u] = p.ev[3 * i + 2];
+					}
 				}
 			}
 			uint32_t hidx[4], hrank[4], hcur[4], nwd[4], nlr[4], rare = 0;
@@ -2203,6 +2240,7 @@ struct PrepP {
 	const uint32_t *host_cluster;
 	uint32_t nhosts;
 	uint32_t epoch;
+	const uint32_t *d_epoch;        // the window number on the device (a captured graph cannot carry it as a launch parameter); nullptr: `epoch`
 	uint32_t *cluster_state;        // arena [max_clusters*12]
 	const uint32_t *hll32;
 	uint8_t *hll8;                  // arena
@@ -2210,6 +2248,8 @@ struct PrepP {
 
 // CLUSTER_STATE_ONE::update_from_state server/gy_mconnhdlr.cc:16032-16050 for every host whose host state is current
 // (send_cluster_state skips hosts without a recent state, :16068-16070)
+__global__ void k_epoch_inc(uint32_t *d_epoch) { *d_epoch += 1u; }
+
 __global__ void k_window_prepare(PrepP p)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2218,7 +2258,7 @@ __global__ void k_window_prepare(PrepP p)
 		((uint32_t *)p.hll8)[i] = (v.x & 0xFF) | ((v.y & 0xFF) << 8) | ((v.z & 0xFF) << 16) | ((v.w & 0xFF) << 24);
 	}
 	if (i >= p.nhosts) return;
-	if (p.host_state_epoch[i] != p.epoch) return;
+	if (p.host_state_epoch[i] != (p.d_epoch ? *p.d_epoch : p.epoch)) return;
 	const gys_host_state st = p.host_state[i];
 	const int32_t *s = p.host_summ + (size_t)i * 16;
 	uint32_t *c = p.cluster_state + (size_t)p.host_cluster[i] * 12;

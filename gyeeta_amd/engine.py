@@ -206,6 +206,9 @@ class SketchEngine:
 
     def send_cluster_state(self, tusec=0, group=None):
         """MCONN_HANDLER::send_cluster_state + SHCONN_HANDLER::aggregate_cluster_state: close the window on every rank."""
+        if self.nranks <= 1:  # the whole boundary as one captured hipGraph (gys_window_close)
+            capi.check(self.L.gys_window_close(self.h, tusec))
+            return
         capi.check(self.L.gys_window_prepare(self.h, tusec))
         if self.nranks > 1:
             if self.arena is None:

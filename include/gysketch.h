@@ -220,6 +220,10 @@ typedef struct {
 int gys_reduce_sections(gys_ctx *ctx, gys_reduce_section out[4], uint32_t *nsections);
 int gys_window_prepare(gys_ctx *ctx, uint64_t tusec);
 int gys_window_finish(gys_ctx *ctx);
+/* single rank: gys_window_prepare + gys_window_finish as ONE captured hipGraph (the fold kernels that are due, k_window_prepare, the
+ * copy / clear sequence, the window-number increment), captured once per registry shape and replayed with one launch per window
+ * (gys_counters.window_graph_launches).  Falls back to the two calls with multi-level windows or nranks > 1 (gys_window_close_rccl). */
+int gys_window_close(gys_ctx *ctx, uint64_t tusec);
 
 /* -------------------------------------------------------------------------------------------------------------------
  * queries (result shapes: common/gy_json_field_maps.h svcsumm :1396-1416, clusterstate :2162-2180, svcstate :1102-1135) */
