@@ -290,6 +290,7 @@ def main():
     ap.add_argument("--svcs", type=int, default=1000, help="services per host")
     ap.add_argument("--events", type=int, default=1 << 29, help="events per rank per step (one window)")
     ap.add_argument("--zipf-milli", type=int, default=0, help="0 = uniform over services, else Zipf s*1000 (config 5: --zipf-milli 1100 --hosts 25 --svcs 4000)")
+    ap.add_argument("--levels", action="store_true", help="multi-level windows on (gys_config.enable_levels: 5.4 KB more per service; the close then folds and snapshots every service)")
     ap.add_argument("--workload", choices=["resp", "conn"], default="resp", help="resp: C3/C4/C5 response-event stream (default); conn: C2 TCP_CONN_NOTIFY stream")
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl", help="window exchange at N > 1: RCCL inside the library (default) or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -335,7 +336,7 @@ def main():
     nlocal = len(mine)
     nsvc = nlocal * args.svcs
     eng = SketchEngine(max_hosts=max(nlocal, 1), max_services=max(nsvc, 1), max_clusters=16, enable_tdigest=True,
-                       max_batch_events=args.events, rank=rank, nranks=world, device=local_rank)
+                       max_batch_events=args.events, rank=rank, nranks=world, device=local_rank, enable_levels=args.levels)
     # window exchange at N > 1: the four register families all-reduced INSIDE the library (gys_window_close_rccl: ncclAllReduce x 4 in
     # one group on the engine stream).  torch.distributed only carries the 128-byte communicator id (and the timing barrier).
     exchange = "none"
@@ -513,7 +514,7 @@ def main():
                                    "1 window (ingest + window close) per step" % (args.hosts, args.svcs,
                                                                                  "uniform" if not args.zipf_milli else "zipf %.2f" % (args.zipf_milli / 1000)),
                        "events_per_rank_per_step": args.events, "service_keys_total": args.hosts * args.svcs,
-                       "service_keys_rank0": nsvc,
+                       "service_keys_rank0": nsvc, "multi_level_windows": bool(args.levels),
                        "sketches": "exact RESP_TIME_HASH histogram + CONN_BITMAP + HLL p=14 + CMS 4x65536 + t-digest %d clusters + %d-value buffer per key" % (capi.TD_NB, capi.TD_PEND_CAP),
                        "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world, "exchange": exchange},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

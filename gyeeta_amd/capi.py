@@ -189,6 +189,7 @@ SIGNATURES = {
     "gys_profile_reset": (C.c_int, [vp]),
     "gys_profile_get": (C.c_int, [vp, C.c_char_p, f64p, u64p]),
     "gys_profile_names": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "gys_debug_read_events_dev": (C.c_int, [vp, vp, C.c_uint64]),
     "gys_gen_resp_events_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RespSeg)]),
 }
 

@@ -3053,6 +3053,17 @@ int gys_profile_names(gys_ctx *c, char *buf, size_t buflen)
 }
 
 // ------------------------------------------------------------------------------------------------ synthetic generator
+int gys_debug_read_events_dev(gys_ctx *c, const void *d_ev24, uint64_t nevents)
+{
+	if (!c || !d_ev24) return GYS_ERR_INVAL;
+	if (!nevents) return GYS_OK;
+	const uint64_t per_wg = 53248; // ~ a C3 host segment (13 tiles of 4096)
+	hipLaunchKernelGGL(k_read_events, dim3((uint32_t)((nevents + per_wg - 1) / per_wg)), dim3(1024), 0, c->stream, (const uint64_t *)d_ev24, nevents, per_wg,
+			   (uint64_t *)c->counters + 15);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
 int gys_gen_resp_events_dev(gys_ctx *c, void *d_ev24, uint64_t nevents, uint64_t seed, uint32_t first_host, uint32_t nhosts, uint32_t svcs_per_host,
 			    uint32_t zipf_milli, gys_resp_seg *segs_out)
 {

@@ -2929,4 +2929,29 @@ __global__ __launch_bounds__(256) void k_gen_resp(GenP g)
 	}
 }
 
+// PMC calibration (tools/calibrate_fetch.py): reads nevents 24-byte events with EXACTLY the access pattern of k_resp_host's event phase
+// (thread t of a 1024-thread workgroup: 3 x 8-byte loads at 24 (tile + u * 1024 + t), 4 events per thread at a time) and nothing else,
+// so that rocprofv3's FETCH_SIZE for this kernel can be set against the known 24 B x nevents.
+__global__ __launch_bounds__(1024) void k_read_events(const uint64_t *ev, uint64_t n, uint64_t per_wg, uint64_t *out)
+{
+	const uint64_t e0 = (uint64_t)blockIdx.x * per_wg, e1 = min(n, e0 + per_wg);
+	uint64_t acc = 0;
+	for (uint64_t t0 = e0; t0 < e1; t0 += 4096u) {
+		uint64_t w0[4], w1[4], w2[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint64_t i = t0 + threadIdx.x + (uint64_t)u * 1024u;
+			w0[u] = 0; w1[u] = 0; w2[u] = 0;
+			if (i < e1) {
+				w0[u] = ev[3 * i];
+				w1[u] = ev[3 * i + 1];
+				w2[u] = ev[3 * i + 2];
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) acc ^= w0[u] + 3 * w1[u] + 5 * w2[u];
+	}
+	if (acc == 0x123456789ABCDEFull) out[0] = acc; // (never: keeps the loads alive)
+}
+
 } // namespace gys

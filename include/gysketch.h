@@ -458,6 +458,9 @@ int gys_profile_names(gys_ctx *ctx, char *buf, size_t buflen); /* comma separate
  * over 0..255/256 (bench.py uses one such pass before timing so that the keys' t-digest buffers start at evenly spread fill levels
  * -- with identical rates and identical start all keys would otherwise overflow in the same window) */
 #define GYS_GEN_SPREAD 0xFFFFFFFFu
+/* PMC calibration helper: reads nevents 24-byte events with the access pattern of the event kernel (3 x 8-B loads per thread at a 24-B
+ * stride) and does nothing else -- FETCH_SIZE of this launch vs the known 24 B x nevents (tools/calibrate_fetch.py) */
+int gys_debug_read_events_dev(gys_ctx *ctx, const void *d_ev24, uint64_t nevents);
 int gys_gen_resp_events_dev(gys_ctx *ctx, void *d_ev24, uint64_t nevents, uint64_t seed, uint32_t first_host, uint32_t nhosts,
 			    uint32_t svcs_per_host, uint32_t zipf_milli /* 0 = uniform, else s*1000 */, gys_resp_seg *segs_out /* host, nhosts */);
 
