@@ -663,8 +663,6 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hp.htbl = c->htbl;
 		hp.hlst = c->hlst;
 		hp.hll32 = c->hll32;
-		hp.hll_floor = c->merge_count + 10;
-		hipLaunchKernelGGL(k_hll_floor, dim3(1), dim3(1024), 0, c->stream, c->hll32, c->merge_count + 10);
 		hp.td_cur = c->td_cur;
 		hp.td_pend = c->td_pend;
 		hp.pcap = c->pcap;
