@@ -547,8 +547,8 @@ int fold_range(gys_ctx *c, uint32_t first, uint32_t n)
 template <int TPT, bool SHARED, bool SPILL>
 void launch_resp_host(gys_ctx *c, uint32_t grid, size_t dyn, const RespHostP &hp)
 {
-	if (!SPILL && hp.svc_hll_p) hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, !SPILL>), dim3(grid), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
-	else hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, false>), dim3(grid), dim3(GYS_HOST_THREADS), dyn, c->stream, hp);
+	if (!SPILL && hp.svc_hll_p) hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, !SPILL>), dim3(grid), dim3(GYS_RESP_THREADS(TPT)), dyn, c->stream, hp);
+	else hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, false>), dim3(grid), dim3(GYS_RESP_THREADS(TPT)), dyn, c->stream, hp);
 }
 
 template <int TPT, bool SHARED, bool SPILL>
@@ -652,8 +652,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	uint32_t hgrid = 0;
 	size_t dyn = 0;
 	// 16 events per thread and tile (16384-event tiles: longer per-key runs in the flush) when the LDS budget allows; GYS_TPT=8 for A/B
-	static const int tpt = [] { const char *e = getenv("GYS_TPT"); return (e && atoi(e) == 8) ? 8 : 16; }();
-	bool tpt16 = false;
+	static const int tpt = [] { const char *e = getenv("GYS_TPT"); const int v = e ? atoi(e) : 16; return (v == 8 || v == 12) ? v : 16; }();
+	bool tpt16 = false, tpt12 = false;
 	if (host_local) {
 		hp.ev = (const uint64_t *)d_ev;
 		hp.n = n;
@@ -715,14 +715,18 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			c->n_batches_host_local++;
 		}
 		tpt16 = tpt == 16 && (uint64_t)max_tbl * 8 + (uint64_t)hp.lds_key_entries * 24 + 16384u * 6u <= 150u * 1024u;
-		dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_key_entries * 24 + (size_t)(tpt16 ? 16384u : 8192u) * 6u;
+		// 512 threads x 12 events: two workgroups per CU when the host's tables leave room (<= 78 KiB per workgroup with the static part)
+		tpt12 = tpt == 12 && (uint64_t)max_tbl * 8 + (uint64_t)hp.lds_key_entries * 24 + 6144u * 6u <= 77u * 1024u;
+		dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_key_entries * 24 + (size_t)(tpt12 ? 6144u : tpt16 ? 16384u : 8192u) * 6u;
 		{
 			ProfScope ps(c, "resp_host");
 			if (host_split) {
-				if (tpt16) launch_resp_host<16, true, false>(c, hgrid, dyn, hp);
+				if (tpt12) launch_resp_host<12, true, false>(c, hgrid, dyn, hp);
+				else if (tpt16) launch_resp_host<16, true, false>(c, hgrid, dyn, hp);
 				else launch_resp_host<8, true, false>(c, hgrid, dyn, hp);
 			} else {
-				if (tpt16) launch_resp_host<16, false, false>(c, hgrid, dyn, hp);
+				if (tpt12) launch_resp_host<12, false, false>(c, hgrid, dyn, hp);
+				else if (tpt16) launch_resp_host<16, false, false>(c, hgrid, dyn, hp);
 				else launch_resp_host<8, false, false>(c, hgrid, dyn, hp);
 			}
 		}
@@ -790,7 +794,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		// second pass over the hosts that have spilled services (a workgroup of any other host returns at once): their events again,
 		// only the spilled services' values, into the runs k_key_finalize allocated in `staged`
 		ProfScope ps(c, "resp_spill");
-		if (tpt16) launch_resp_host<16, true, true>(c, hgrid, dyn, hp);
+		if (tpt12) launch_resp_host<12, true, true>(c, hgrid, dyn, hp);
+		else if (tpt16) launch_resp_host<16, true, true>(c, hgrid, dyn, hp);
 		else launch_resp_host<8, true, true>(c, hgrid, dyn, hp);
 	}
 	HIPCHK(hipGetLastError());

@@ -522,6 +522,10 @@ struct HostDesc {
 #define GYS_HOST_TBL_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define GYS_EV_DROPPED 0xFFFFFFFFu
 #define GYS_HOST_THREADS 1024
+// workgroup size of k_resp_host by tile form: 16 / 8 events per thread with 1024 threads (one workgroup per CU), or 12 events per thread
+// with 512 threads (6144-event tiles, 76 KB of LDS at 1000 listeners: TWO workgroups per CU, so that one's prologue / scan / flush phases
+// run under the other's event phase)
+#define GYS_RESP_THREADS(TPT) ((TPT) == 12 ? 512 : 1024)
 #ifndef GYS_RESP_PREFETCH
 #define GYS_RESP_PREFETCH 0
 #endif
@@ -555,9 +559,9 @@ struct RespHostP {
 };
 
 template <int TPT, bool SHARED, bool SPILL, bool SVCHLL>
-__global__ __launch_bounds__(GYS_HOST_THREADS) void k_resp_host(RespHostP p)
+__global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p)
 {
-	constexpr uint32_t T = GYS_HOST_THREADS;
+	constexpr uint32_t T = GYS_RESP_THREADS(TPT);
 	constexpr uint32_t TILE = (uint32_t)TPT * T;
 	extern __shared__ uint64_t s_dyn[];
 	__shared__ uint32_t s_wsum[T / 64];
