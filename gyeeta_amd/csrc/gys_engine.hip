@@ -790,7 +790,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		fin.batch_off = host_local ? nullptr : c->batch_off;
 		hipLaunchKernelGGL(k_key_finalize, dim3((nsvc + 255) / 256), dim3(256), 0, c->stream, fin);
 	}
-	if (host_local) {
+	// (a key spills / lands in a larger merge class only when THIS batch brought it more values than its buffer had room for: a small
+	// batch -- a partha message of a few thousand events -- cannot, and the launches for those cases are not made)
+	if (host_local && n > (uint64_t)c->pcap - GYS_TD_PEND_CAP) {
 		// second pass over the hosts that have spilled services (a workgroup of any other host returns at once): their events again,
 		// only the spilled services' values, into the runs k_key_finalize allocated in `staged`
 		ProfScope ps(c, "resp_spill");
@@ -824,17 +826,15 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 				hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
 			}
 		}
-		{
+		if (n > GYS_MERGE_CLASS0 - GYS_TD_PEND_CAP) {
 			ProfScope ps(c, "digest_merge_big");
 			mp.list = c->merge_list1;
 			mp.count = c->merge_count + FIN_CLASS1;
 			hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS1, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 3))), dim3(256), 0, c->stream, mp);
-			mp.list = c->merge_list2;
-			mp.count = c->merge_count + FIN_CLASS2;
-			hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_LDS_MAX, 1024u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(1024), 0, c->stream, mp);
+			// (entries above class 1 take the several-workgroup path below; k_digest_merge<GYS_MERGE_LDS_MAX> only serves queries)
 		}
 	}
-	{
+	if (n > GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) {
 		// huge keys (> 16 384 values in this call): several workgroups per key (gys_huge.hpp); what that path cannot take -- entries
 		// beyond its pool, more than 4 096 values >= 16 384 in one key -- is handed to the one-workgroup kernel through a fallback list
 		ProfScope ps(c, "digest_huge");
