@@ -239,7 +239,10 @@ def run_conn(args, rank, world):
         eng.register_host(mid, "cluster%d" % (h % 8))
         eng.register_listeners_np(mid, wire.glob_id(np.full(sp, h), s_), wire.listener_netns(h, s_), wire.listener_port(s_))
     rng = np.random.default_rng(1)
-    rec = wire.synth_tcp_conns(rng, chunk, np.arange(nh), sp, dup_frac=0.2)
+    if args.conn_stream == "messages":  # as madhava receives them: messages of MAX_NUM_CONNS = 2048 records, each from ONE partha
+        rec = np.concatenate([wire.synth_tcp_conns(rng, 2048, [m % nh], sp, dup_frac=0.2) for m in range(chunk // 2048)])
+    else:                               # worst case for the per-workgroup aggregation: every record from a random host
+        rec = wire.synth_tcp_conns(rng, chunk, np.arange(nh), sp, dup_frac=0.2)
     d = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.uint8).copy()).cuda()
     off = torch.arange(0, chunk * 280, 280, dtype=torch.int32, device="cuda")
     ls = np.concatenate([wire.synth_listener_states(rng, h, s_) for h in range(nh)])
@@ -272,7 +275,8 @@ def run_conn(args, rank, world):
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "int64", "data": "synthetic",
            "config": {"workload": "C2: %d hosts x %d services, %d TCP_CONN_NOTIFY (280 B) + %d LISTENER_STATE_NOTIFY (88 B) records per window, "
-                                  "device resident, 1 window per step" % (nh, sp, nrec, len(ls))},
+                                  "device resident, 1 window per step; record order: %s" % (nh, sp, nrec, len(ls),
+                                  "per-partha messages of 2048 records" if args.conn_stream == "messages" else "hosts mixed record by record")},
            "roofline": {"bound": "hbm", "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_step": alg, "kernel": "conn", "kernel_avg_ms": kms.get("conn"), "traffic": None,
                         "kernels": {k: {"ms": v} for k, v in kms.items()},
@@ -292,6 +296,7 @@ def main():
     ap.add_argument("--zipf-milli", type=int, default=0, help="0 = uniform over services, else Zipf s*1000 (config 5: --zipf-milli 1100 --hosts 25 --svcs 4000)")
     ap.add_argument("--levels", action="store_true", help="multi-level windows on (gys_config.enable_levels: 5.4 KB more per service; the close then folds and snapshots every service)")
     ap.add_argument("--workload", choices=["resp", "conn"], default="resp", help="resp: C3/C4/C5 response-event stream (default); conn: C2 TCP_CONN_NOTIFY stream")
+    ap.add_argument("--conn-stream", choices=["messages", "mixed"], default="messages", help="--workload conn: per-partha 2048-record messages (default) or hosts mixed record by record")
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl", help="window exchange at N > 1: RCCL inside the library (default) or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quantile-check", action="store_true", help="skip the (untimed) t-digest rank-error check after the run")

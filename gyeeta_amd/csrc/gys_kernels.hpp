@@ -2070,11 +2070,10 @@ struct ConnP {
 	unsigned long long *pair64;
 };
 
-__global__ __launch_bounds__(256) void k_conn_ingest(ConnP p)
+#define GYS_CONN_THREADS 1024u
+#define GYS_CONN_AGG 2048u // LDS aggregation slots per workgroup (power of two, 2 x the records of a workgroup)
+__device__ __forceinline__ void conn_one(const ConnP &p, uint32_t i, uint32_t *s_key, unsigned long long (*s_acc)[3])
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	wave_count(&p.counters[CTR_CONN_EVENTS], i < p.n);
-	if (i >= p.n) return;
 	const uint8_t *rec = p.batch + p.offsets[i];
 	uint32_t c128[4], s128[4], c32, s32;
 	uint16_t cport, sport;
@@ -2124,10 +2123,45 @@ __global__ __launch_bounds__(256) void k_conn_ingest(ConnP p)
 		}
 		return;
 	}
-	unsigned long long *c = p.svc_win + (size_t)slot * 3;
-	atomicAdd(&c[0], 1ull + (tusec_close ? (1ull << 32) : 0ull)); // a window's connection count of one service stays far below 2^32
-	if (bytes_sent) atomicAdd(&c[1], (unsigned long long)bytes_sent);
-	if (bytes_rcvd) atomicAdd(&c[2], (unsigned long long)bytes_rcvd);
+	// the workgroup's LDS entry of the service (open addressing; 2048 entries for at most 1024 records: always room)
+	uint32_t h = (slot * 0x9E3779B1u) >> 21; // top 11 bits
+	for (;;) {
+		const uint32_t prev = atomicCAS(&s_key[h], GYS_NOSLOT, slot);
+		if (prev == GYS_NOSLOT || prev == slot) break;
+		h = (h + 1u) & (GYS_CONN_AGG - 1u);
+	}
+	atomicAdd(&s_acc[h][0], 1ull + (tusec_close ? (1ull << 32) : 0ull)); // a window's connection count of one service stays far below 2^32
+	if (bytes_sent) atomicAdd(&s_acc[h][1], (unsigned long long)bytes_sent);
+	if (bytes_rcvd) atomicAdd(&s_acc[h][2], (unsigned long long)bytes_rcvd);
+}
+
+__global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
+{
+	// Records reach madhava message by message, a message = up to 2048 connections of ONE partha (comm::TCP_CONN_NOTIFY::MAX_NUM_CONNS,
+	// common/gy_comm_proto.h:1738) and a partha has a few hundred listeners at most: the 1024 records of a workgroup touch few
+	// distinct services.  Their three window accumulators are therefore summed in an LDS table keyed by service slot first and
+	// flushed with one set of device atomics per DISTINCT service of the workgroup (the kernel is bound by the device-atomic rate).
+	__shared__ uint32_t s_key[GYS_CONN_AGG];
+	__shared__ unsigned long long s_acc[GYS_CONN_AGG][3];
+	for (uint32_t k = threadIdx.x; k < GYS_CONN_AGG; k += GYS_CONN_THREADS) {
+		s_key[k] = GYS_NOSLOT;
+		s_acc[k][0] = 0;
+		s_acc[k][1] = 0;
+		s_acc[k][2] = 0;
+	}
+	__syncthreads();
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	wave_count(&p.counters[CTR_CONN_EVENTS], i < p.n);
+	if (i < p.n) conn_one(p, i, s_key, s_acc);
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < GYS_CONN_AGG; k += GYS_CONN_THREADS) {
+		const uint32_t slot = s_key[k];
+		if (slot == GYS_NOSLOT) continue;
+		unsigned long long *c = p.svc_win + (size_t)slot * 3;
+		atomicAdd(&c[0], s_acc[k][0]);
+		if (s_acc[k][1]) atomicAdd(&c[1], s_acc[k][1]);
+		if (s_acc[k][2]) atomicAdd(&c[2], s_acc[k][2]);
+	}
 }
 
 // window boundary (and counter exports): cumulative per-service counters += window accumulators; Count-Min rows of the service +=
