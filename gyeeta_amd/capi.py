@@ -162,6 +162,8 @@ SIGNATURES = {
     "gys_query_hist_level_stats": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(TimeHistVal), C.c_uint32, i64p, i64p, f64p]),
     "gys_export_hist_level": (C.c_int, [vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
     "gys_export_day_stats": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
+    "gys_query_hist_period_stats": (C.c_int, [vp, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.POINTER(TimeHistVal), C.c_uint32, i64p, i64p, f64p]),
+    "gys_export_hist_period": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_int)]),
     "gys_export_svc_hist": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_uint32, vp]),
     "gys_set_host_name": (C.c_int, [vp, mid, C.c_char_p]),
     "gys_json_svcsumm": (C.c_int, [vp, mid, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),

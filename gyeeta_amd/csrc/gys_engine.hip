@@ -277,6 +277,7 @@ struct gys_ctx {
 	// multi-level windows (cfg.enable_levels; kernels: "multi-level windows" in gys_kernels.hpp)
 	gys_hist_rec *lvl_snap = nullptr; // [2][GYS_LEVEL_RING][max_services] cumulative records at the last start of every ring bucket
 	gys_hist_rec *lvl_last = nullptr; // [max_services] the window closed last (level 0)
+	int64_t *lvl_first = nullptr;     // [max_services] time (s) of the service's first window close (firstTime_ of its series), 0: none yet
 	gys_hist_rec *qps_hist = nullptr, *act_hist = nullptr; // per-service QPS_HISTOGRAM / ACTIVE_CONN_HISTOGRAM
 	int64_t lvl_t_last = -1;          // close time (s) of the last window, -1: none yet
 
@@ -916,6 +917,8 @@ int level_roll(gys_ctx *c, uint64_t tusec)
 			if (c->lvl_t_last >= 0 && level_bucket_start(tnow, dur, j) > c->lvl_t_last) p.mask[li] |= 1u << j;
 	}
 	c->lvl_t_last = tnow;
+	p.first_sec = c->lvl_first;
+	p.tnow = tnow;
 	if (!c->nsvc) return GYS_OK;
 	ProfScope ps(c, "level_roll");
 	hipLaunchKernelGGL(k_level_roll, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
@@ -961,6 +964,75 @@ int level_view(gys_ctx *c, int level, uint64_t tusec, uint32_t first, uint32_t n
 		}
 	}
 	hipLaunchKernelGGL(k_level_view, dim3((uint32_t)(((uint64_t)n * 16 + 255) / 256)), dim3(256), 0, c->stream, p);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+// TIME_HISTOGRAM::get_stats_for_period_with_flush (common/gy_statistics.h:1378-1413) for slots [first, first + n): the interval's
+// {count, sum} per histogram bucket into d_out.  start / end are the reference's starttime / endtime + 1 (:1383).
+int level_period(gys_ctx *c, int64_t start, int64_t end, uint64_t tusec, uint32_t first, uint32_t n, gys_hist_rec *d_out, int *plevel)
+{
+	int64_t tq = (int64_t)(tusec / 1000000ull);
+	if (tq < c->lvl_t_last) tq = c->lvl_t_last; // the flush: latestTime_ of every level
+	{
+		const int rcf = fold_range(c, first, n);
+		if (rcf) return rcf;
+	}
+	LevelPeriodP p{};
+	p.win = c->hist_win;
+	p.all = c->hist_all;
+	p.meta = c->cfg.enable_tdigest ? c->td_meta : nullptr;
+	p.epoch_open = c->epoch + (c->prepared ? 1u : 0u);
+	p.first = first;
+	p.n = n;
+	p.out = d_out;
+	int level = GYS_NLEVELS - 1; // MultiLevelTimeSeries::getLevel(start): the first level that reaches back to start
+	for (int l = 0; l < GYS_NLEVELS - 1; ++l)
+		if (tq - LEVEL_SECS[l] <= start) {
+			level = l;
+			break;
+		}
+	if (plevel) *plevel = level;
+	if (level == 3) {
+		p.mode = 3;
+		p.first_sec = c->lvl_first;
+		p.start = start;
+		p.end = end;
+		p.latest = tq;
+	} else if (level == 0) {
+		// the 5-s ring has 1-s buckets: the window closed last sits in [t_last, t_last + 1) for 5 s, inside the interval or not
+		const bool held = c->lvl_t_last >= 0 && tq - c->lvl_t_last < LEVEL_SECS[0];
+		p.mode = held && start <= c->lvl_t_last && end > c->lvl_t_last ? 2 : 1;
+		p.last = c->lvl_last;
+	} else {
+		const int64_t dur = LEVEL_SECS[level], w = dur / GYS_LEVEL_RING;
+		const int64_t cur_start = level_bucket_start(tq, dur, level_bucket_idx(tq, dur));
+		auto cum_before = [&](int64_t s) -> const gys_hist_rec * { // C(s); nullptr = the cumulative record now
+			if (c->lvl_t_last < 0 || s > c->lvl_t_last) return nullptr;
+			const uint32_t j = (uint32_t)((s % dur) / w);
+			return c->lvl_snap + ((uint64_t)(level - 1) * GYS_LEVEL_RING + j) * c->cfg.max_services;
+		};
+		p.mode = 0;
+		for (int k = 0; k < GYS_LEVEL_RING; ++k) { // BucketedTimeSeries::forEachBucket(start, end, fn), oldest first
+			const int64_t bs = cur_start - (int64_t)(GYS_LEVEL_RING - 1 - k) * w;
+			int64_t bn = bs + w;
+			if (start >= bn) continue;
+			if (end <= bs) break;
+			if (bs <= tq && bn > tq) bn = tq + 1; // rangeAdjust: the bucket that holds latestTime_ ends there
+			const uint32_t i = p.nrb++;
+			if (i == 0) p.bnd[0] = cum_before(bs);
+			p.bnd[i + 1] = cum_before(bs + w);
+			if (start <= bs && end >= bn) {
+				p.whole_mask |= 1u << i;
+				p.scale[i] = 1.f;
+			} else {
+				const int64_t is = start > bs ? start : bs, ie = end < bn ? end : bn;
+				p.scale[i] = (float)(ie - is) * 1.f / (float)(bn - bs);
+			}
+		}
+		if (!p.nrb) p.mode = 1;
+	}
+	hipLaunchKernelGGL(k_level_period, dim3((uint32_t)(((uint64_t)n * 16 + 255) / 256)), dim3(256), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
 }
@@ -1207,6 +1279,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	if (cfg->enable_levels) {
 		ALLOC(c->lvl_snap, 2 * GYS_LEVEL_RING * S);
 		ALLOC(c->lvl_last, S);
+		ALLOC(c->lvl_first, S);
 		ALLOC(c->qps_hist, S);
 		ALLOC(c->act_hist, S);
 	}
@@ -1335,7 +1408,7 @@ void gys_destroy(gys_ctx *c)
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
-			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
+			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_first, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -2922,6 +2995,50 @@ int gys_query_hist_level_stats(gys_ctx *c, uint64_t glob_id, int level, uint64_t
 	if (tcount) *tcount = tc;
 	if (tsum) *tsum = ts;
 	if (mean_val) *mean_val = (double)ts / (double)(tc != 0 ? tc : 1); // :1361
+	return GYS_OK;
+}
+
+int gys_export_hist_period(gys_ctx *c, int64_t starttime, int64_t endtime, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out,
+			   int *level_used)
+{
+	RANGE_CHECK(first_slot, nslots);
+	LEVELS_CHECK();
+	if (!nslots) return GYS_OK;
+	gys_hist_rec *tmp = nullptr;
+	HIPCHK(hipMalloc((void **)&tmp, (size_t)nslots * sizeof(gys_hist_rec)));
+	int rc = level_period(c, starttime, endtime + 1, tusec, first_slot, nslots, tmp, level_used);
+	if (rc == GYS_OK) {
+		hipError_t e = hipMemcpyAsync(out, tmp, (size_t)nslots * sizeof(gys_hist_rec), hipMemcpyDeviceToHost, c->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+		if (e != hipSuccess) {
+			set_err("period export copy: %s", hipGetErrorString(e));
+			rc = GYS_ERR_HIP;
+		}
+	}
+	hipFree(tmp);
+	return rc;
+}
+
+int gys_query_hist_period_stats(gys_ctx *c, uint64_t glob_id, int64_t starttime, int64_t endtime, uint64_t tusec, gys_time_hist_val *pstats,
+				uint32_t nstats, int64_t *tcount, int64_t *tsum, double *mean_val)
+{
+	if (!c || (!pstats && nstats)) return GYS_ERR_INVAL;
+	uint32_t slot;
+	int rc = gys_lookup_service(c, glob_id, &slot);
+	if (rc) return rc;
+	gys_hist_rec h;
+	rc = gys_export_hist_period(c, starttime, endtime, tusec, slot, 1, &h, nullptr);
+	if (rc) return rc;
+	const HashDef &d = hash_def(GYS_RESP_TIME_HASH);
+	int64_t tc = 0, ts = 0;
+	for (int b = 0; b < d.nthr + 2; ++b) { // slabhist.count(start, end) / sum(start, end), common/gy_statistics.h:1395-1396
+		tc += (int64_t)h.stats[b].count;
+		ts += h.stats[b].sum;
+	}
+	for (uint32_t i = 0; i < nstats; ++i) pstats[i].data_value = level_percentile(d, h, pstats[i].percentile); // :1389-1393
+	if (tcount) *tcount = tc;
+	if (tsum) *tsum = ts;
+	if (mean_val) *mean_val = (double)ts / (double)(tc != 0 ? tc : 1); // :1398
 	return GYS_OK;
 }
 

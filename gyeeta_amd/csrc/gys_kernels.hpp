@@ -2467,6 +2467,8 @@ struct LevelRollP {
 	gys_hist_rec *last; // [stride]
 	uint64_t stride;
 	uint32_t mask[2];   // ring buckets of the 300-s / 5-day level whose start lies in (previous close, this close]
+	int64_t *first_sec; // [nsvc] time of the service's first window close = firstTime_ of its series (0: none yet)
+	int64_t tnow;
 };
 
 // records as 16 x {u64, i64}: lanes 0..14 {count, sum}, lane 15 {total_count, max_val_seen}
@@ -2496,6 +2498,7 @@ __global__ __launch_bounds__(256) void k_level_roll(LevelRollP p)
 			closing.y = k < 15u ? 0ull : (unsigned long long)INT64_MIN;
 		}
 		((ulonglong2 *)p.last)[t] = closing;
+		if (k == 15u && p.first_sec[slot] == 0) p.first_sec[slot] = p.tnow; // BucketedTimeSeries::update on an empty series
 		if (p.mask[0] | p.mask[1]) {
 			// cumulative record BEFORE the closing window: its add happens at the close time, i.e. at or after the boundary.  Lazily
 			// folded records (meta) already hold the closing window (the caller folded every service first): take it out again.
@@ -2553,6 +2556,98 @@ __global__ __launch_bounds__(256) void k_level_view(LevelViewP p)
 	} else {
 		r.x = 0;
 		r.y = k < 15u ? 0ull : cum.y;
+	}
+	((ulonglong2 *)p.out)[t] = r;
+}
+
+// TIME_HISTOGRAM::get_stats_for_period (common/gy_statistics.h:1378-1406): per histogram bucket count(start, end) / sum(start, end) of the
+// level folly's MultiLevelTimeSeries::getLevel(start) picks.  A ring bucket [s, s + w) of a level holds C(s + w) - C(s), C(x) = the
+// cumulative record of the adds before x = the snapshot taken at x (k_level_roll) or, for an x after the last close, the cumulative
+// record now; a bucket that only partly overlaps the interval is scaled by the overlapped fraction in float and truncated
+// (BucketedTimeSeries::rangeAdjust).  Which buckets overlap, their fractions and the boundary snapshots are the same for every
+// service (the host works them out once); the all-time level is one bucket [first close of the service, now + 1), scaled per service.
+#define GYS_PERIOD_MAXB GYS_LEVEL_RING
+struct LevelPeriodP {
+	const gys_hist_rec *win, *all;
+	const TdMeta *meta;
+	uint32_t epoch_open;
+	uint32_t first, n;
+	int mode;                                      // 0 ring level, 1 empty, 2 the last-window record (level 0), 3 all-time level
+	uint32_t nrb;                                  // mode 0: overlapping ring buckets, oldest first
+	const gys_hist_rec *bnd[GYS_PERIOD_MAXB + 1];  // C(start of ring bucket i), [nrb] = C(end of the last one); nullptr: the cumulative record now
+	float scale[GYS_PERIOD_MAXB];
+	uint32_t whole_mask;                           // bit i: ring bucket i lies inside the interval (taken unscaled)
+	const gys_hist_rec *last;                      // mode 2
+	const int64_t *first_sec;                      // mode 3
+	int64_t start, end, latest;                    // mode 3: [start, end) and latestTime_
+	gys_hist_rec *out;                             // [n]: stats[b] = the interval's {count, sum}, total_count = their sum, max_val_seen all-time
+};
+
+__device__ __forceinline__ long long range_adjust(long long v, float scale) { return (long long)((float)v * scale); }
+
+__global__ __launch_bounds__(256) void k_level_period(LevelPeriodP p)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool live = t < (uint64_t)p.n * 16ull;
+	const uint64_t tt = live ? t : 0; // every lane stays for the 16-lane sums below
+	const uint32_t slot = p.first + (uint32_t)(tt >> 4), k = (uint32_t)(tt & 15u);
+	const uint64_t g = (uint64_t)slot * 16ull + k;
+	ulonglong2 cum = ((const ulonglong2 *)p.all)[g];
+	const ulonglong2 w = ((const ulonglong2 *)p.win)[g];
+	if (p.meta) {
+		if (p.meta[slot].hw_epoch == p.epoch_open) { // the folded part of the OPEN window is not in any level yet
+			cum.x -= w.x;
+			if (k < 15u) cum.y -= w.y;
+		}
+	} else if (k == 15u && (long long)cum.y < (long long)w.y) {
+		cum.y = w.y;
+	}
+	long long ac = 0, as = 0;
+	if (k < 15u) {
+		if (p.mode == 0) {
+			ulonglong2 lo = p.bnd[0] ? ((const ulonglong2 *)p.bnd[0])[g] : cum;
+			for (uint32_t i = 0; i < p.nrb; ++i) {
+				const ulonglong2 hi = p.bnd[i + 1] ? ((const ulonglong2 *)p.bnd[i + 1])[g] : cum;
+				const long long c = (long long)(hi.x - lo.x), sm = (long long)(hi.y - lo.y);
+				if ((p.whole_mask >> i) & 1u) {
+					ac += c;
+					as += sm;
+				} else {
+					ac += range_adjust(c, p.scale[i]);
+					as += range_adjust(sm, p.scale[i]);
+				}
+				lo = hi;
+			}
+		} else if (p.mode == 2) {
+			const ulonglong2 r = ((const ulonglong2 *)p.last)[g];
+			ac = (long long)r.x;
+			as = (long long)r.y;
+		} else if (p.mode == 3) {
+			const int64_t bs = p.first_sec[slot];
+			int64_t bn = p.latest + 1;
+			if (bs != 0 && !(p.start >= bn) && !(p.end <= bs)) {
+				if (p.start <= bs && p.end >= bn) {
+					ac = (long long)cum.x;
+					as = (long long)cum.y;
+				} else {
+					const int64_t is = p.start > bs ? p.start : bs, ie = p.end < bn ? p.end : bn;
+					const float scale = (float)(ie - is) * 1.f / (float)(bn - bs);
+					ac = range_adjust((long long)cum.x, scale);
+					as = range_adjust((long long)cum.y, scale);
+				}
+			}
+		}
+	}
+	long long tot = ac;
+	for (int o = 1; o < 16; o <<= 1) tot += __shfl_xor(tot, o, 16);
+	if (!live) return;
+	ulonglong2 r;
+	if (k < 15u) {
+		r.x = (unsigned long long)ac;
+		r.y = (unsigned long long)as;
+	} else {
+		r.x = (unsigned long long)tot;
+		r.y = cum.y;
 	}
 	((ulonglong2 *)p.out)[t] = r;
 }

@@ -156,6 +156,17 @@ public:
 			       : -1;
 	}
 
+	// RESP_TIME_HISTOGRAM::get_stats_for_period_with_flush of one listener (common/gy_statistics.h:1378-1413)
+	int get_resp_period_stats(uint64_t glob_id, time_t starttime, time_t endtime, gys_time_hist_val *pstats, size_t nstats, int64_t &tcount, int64_t &tsum,
+				  double &mean_val, time_t tnow = time(nullptr)) noexcept
+	{
+		std::unique_lock<std::shared_mutex> g(mu_);
+		return gys_query_hist_period_stats(ctx_, glob_id, (int64_t)starttime, (int64_t)endtime, (uint64_t)tnow * 1000000ull, pstats, (uint32_t)nstats,
+						   &tcount, &tsum, &mean_val) == GYS_OK
+			       ? 0
+			       : -1;
+	}
+
 	// the NOTIFY_LISTENER_DAY_STATS payload (comm::LISTENER_DAY_STATS[], MAX_NUM_LISTENERS = 2048 per message) for service slots
 	// [first_slot, first_slot + nslots), as TCP_LISTENER::get_curr_state fills it (common/gy_socket_stat.cc:2098-2112)
 	bool listener_day_stats(time_t tnow, uint32_t first_slot, uint32_t nslots, gys_listener_day_stats *pout) noexcept

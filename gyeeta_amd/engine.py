@@ -393,6 +393,24 @@ class SketchEngine:
         capi.check(self.L.gys_query_hist_level_stats(self.h, int(glob_id), level, int(tusec), st, len(pcts), C.byref(tc), C.byref(ts), C.byref(mean)))
         return [s.data_value for s in st], tc.value, ts.value, mean.value
 
+    def export_hist_period(self, starttime, endtime, tusec, first=0, n=None):
+        """{count, sum} per histogram bucket of the seconds [starttime, endtime] as TIME_HISTOGRAM::get_stats_for_period sees them
+        (common/gy_statistics.h:1378-1406); returns (records [n][16][2], level that answered)"""
+        n = self.num_services() - first if n is None else n
+        out = np.zeros((n, 16, 2), dtype=np.int64)
+        lv = C.c_int(-1)
+        capi.check(self.L.gys_export_hist_period(self.h, int(starttime), int(endtime), int(tusec), first, n, C.c_void_p(out.ctypes.data), C.byref(lv)))
+        return out, lv.value
+
+    def query_hist_period_stats(self, glob_id, starttime, endtime, tusec, pcts):
+        st = (capi.TimeHistVal * len(pcts))()
+        for i, p in enumerate(pcts):
+            st[i].percentile = p
+        tc, ts, mean = C.c_int64(), C.c_int64(), C.c_double()
+        capi.check(self.L.gys_query_hist_period_stats(self.h, int(glob_id), int(starttime), int(endtime), int(tusec), st, len(pcts), C.byref(tc),
+                                                      C.byref(ts), C.byref(mean)))
+        return [s.data_value for s in st], tc.value, ts.value, mean.value
+
     def export_day_stats(self, tusec, first=0, n=None):
         n = self.num_services() - first if n is None else n
         out = (capi.ListenerDayStats * n)()

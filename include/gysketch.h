@@ -367,6 +367,18 @@ int gys_query_hist_level_stats(gys_ctx *ctx, uint64_t glob_id, int level, uint64
 			       int64_t *tcount, int64_t *tsum, double *mean_val);
 /* TIME_HISTOGRAM::get_level_data :1166-1200 for a range of services; out[i].max_val_seen = the all-time maximum for every level */
 int gys_export_hist_level(gys_ctx *ctx, int level, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out);
+/* TIME_HISTOGRAM::get_stats_for_period_with_flush(starttime, endtime, pstats, nstats, tcount, tsum, mean_val, tnow) :1378-1413: the
+ * statistics of the seconds [starttime, endtime], answered as folly does -- from the first level whose span reaches back to
+ * starttime (tnow - 5 / 300 / 432000 s <= starttime, else since start), its ring buckets weighted by the fraction of each that the
+ * interval covers (float, truncated: BucketedTimeSeries::rangeAdjust).  The since-start level is one bucket from the service's
+ * first window close to tnow.  tusec = tnow in microseconds.  Level 0 is the engine's tumbling window (see above), so an interval
+ * that starts within the last 5 s sees the window closed last or nothing. */
+int gys_query_hist_period_stats(gys_ctx *ctx, uint64_t glob_id, int64_t starttime, int64_t endtime, uint64_t tusec, gys_time_hist_val *pstats,
+				uint32_t nstats, int64_t *tcount, int64_t *tsum, double *mean_val);
+/* the interval's {count, sum} per histogram bucket for a range of services (slabhist.buckets_[b].count(start, end) / sum(start, end));
+ * out[i].total_count = their sum, max_val_seen = the all-time maximum; level_used (may be NULL) = the level that answered */
+int gys_export_hist_period(gys_ctx *ctx, int64_t starttime, int64_t endtime, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out,
+			   int *level_used);
 
 typedef struct {
 	uint64_t glob_id;

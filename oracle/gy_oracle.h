@@ -247,6 +247,12 @@ void gyo_mlh_level(const gyo_mlhist *h, int level, gyo_hist_serial *out /*[16]*/
 size_t gyo_slab_percentile_idx(const uint64_t *counts, size_t nb, double pct);
 void gyo_mlh_get_stats(const gyo_mlhist *h, int level, const float *pcts, size_t npct, int64_t *values, int64_t *tcount, int64_t *tsum,
 		       double *mean);
+/* TIME_HISTOGRAM::get_stats_for_period (common/gy_statistics.h:1378-1406): [starttime, endtime] in seconds; flush first */
+void gyo_bts_range(const gyo_bts *s, int64_t start, int64_t end, uint64_t *pcount, int64_t *psum); /* count(start, end) / sum(start, end) */
+int gyo_mlh_level_for_start(const gyo_mlhist *h, int b, int64_t start);
+void gyo_mlh_period(const gyo_mlhist *h, int64_t starttime, int64_t endtime, gyo_hist_serial *out /*[16]*/);
+void gyo_mlh_get_stats_for_period(const gyo_mlhist *h, int64_t starttime, int64_t endtime, const float *pcts, size_t npct, int64_t *values,
+				  int64_t *tcount, int64_t *tsum, double *mean);
 
 /* BOUNDED_PRIO_QUEUE<uint64_t, greater> (common/gy_statistics.h:356-383): returns retained values sorted descending */
 size_t gyo_topn_u64(const uint64_t *vals, size_t n, size_t maxn, uint64_t *out);

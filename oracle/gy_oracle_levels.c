@@ -231,3 +231,115 @@ void gyo_mlh_get_stats(const gyo_mlhist *h, int level, const float *pcts, size_t
 	if (tsum) *tsum = ts;
 	if (mean) *mean = (double)ts / (tc != 0 ? tc : 1);
 }
+
+/* ---------------------------------------------------------------- TIME_HISTOGRAM::get_stats_for_period (gy_statistics.h:1378-1406)
+ * = TimeseriesSlabHistogram::count / sum / getPercentileBucketIdx over [start, end) (thirdparty/TimeseriesSlabHistogram.h:131-156,
+ * :239-245, CountFromInterval :296-309), each of which asks every histogram bucket's folly::MultiLevelTimeSeries for
+ * count(start, end) / sum(start, end).  folly (absent, PARITY UNPINNED) answers that from ONE level -- the first whose span reaches
+ * back to `start`, MultiLevelTimeSeries::getLevel(start): latestTime - duration <= start, else the all-time level -- by walking that
+ * level's ring from the oldest bucket (BucketedTimeSeries::forEachBucket) and scaling a bucket that only partly overlaps the
+ * interval by the overlapped fraction in FLOAT arithmetic (BucketedTimeSeries::rangeAdjust: the bucket that holds latestTime ends at
+ * latestTime + 1; `input * scale` converts back to the integer value type by truncation).  The all-time level is one bucket
+ * [firstTime, latestTime + 1). */
+static int64_t bts_range_adjust(const gyo_bts *s, int64_t bstart, int64_t bnext, int64_t start, int64_t end, int64_t input)
+{
+	if (bstart <= s->latest_time && bnext > s->latest_time) bnext = s->latest_time + 1;
+	if (start <= bstart && end >= bnext) return input;
+	{
+		const int64_t is = start > bstart ? start : bstart, ie = end < bnext ? end : bnext;
+		const float scale = (float)(ie - is) * 1.f / (float)(bnext - bstart);
+		return (int64_t)((float)input * scale);
+	}
+}
+
+void gyo_bts_range(const gyo_bts *s, int64_t start, int64_t end, uint64_t *pcount, int64_t *psum)
+{
+	uint64_t cnt = 0;
+	int64_t sum = 0;
+	if (s->duration == 0) {
+		const int64_t bstart = s->first_time, bnext = s->latest_time + 1;
+		if (!(start >= bnext) && !(end <= bstart)) {
+			cnt += (uint64_t)bts_range_adjust(s, bstart, bnext, start, end, (int64_t)s->tot_cnt);
+			sum += bts_range_adjust(s, bstart, bnext, start, end, s->tot_sum);
+		}
+	} else {
+		/* forEachBucket: from the bucket after the latest one (it belongs to the previous cycle) round to the latest */
+		const int64_t n = (int64_t)s->nbuckets, d = s->duration;
+		const int64_t time_mod = s->latest_time % d;
+		int64_t dur_start = (s->latest_time / d) * d;
+		const int64_t scaled = time_mod * n;
+		const uint32_t latest_idx = (uint32_t)(scaled / d);
+		int64_t scaled_next = scaled - scaled % d + d;
+		uint32_t idx = latest_idx;
+		int64_t bnext;
+		dur_start -= d;
+		bnext = (scaled_next + n - 1) / n + dur_start;
+		for (;;) {
+			int64_t bstart;
+			if (++idx >= s->nbuckets) {
+				idx = 0;
+				dur_start += d;
+				scaled_next = d;
+			} else {
+				scaled_next += d;
+			}
+			bstart = bnext;
+			bnext = (scaled_next + n - 1) / n + dur_start;
+			if (!(start >= bnext)) {
+				if (end <= bstart) break;
+				cnt += (uint64_t)bts_range_adjust(s, bstart, bnext, start, end, (int64_t)s->bcnt[idx]);
+				sum += bts_range_adjust(s, bstart, bnext, start, end, s->bsum[idx]);
+			}
+			if (idx == latest_idx) break;
+		}
+	}
+	*pcount = cnt;
+	*psum = sum;
+}
+
+int gyo_mlh_level_for_start(const gyo_mlhist *h, int b, int64_t start) /* MultiLevelTimeSeries::getLevel(start) of histogram bucket b */
+{
+	for (int l = 0; l < GYO_MLH_LEVELS; l++) {
+		if (h->s[b][l].duration == 0) return l;
+		if (h->s[b][l].latest_time - h->s[b][l].duration <= start) return l;
+	}
+	return GYO_MLH_LEVELS - 1;
+}
+
+/* per histogram bucket {count, sum} over [starttime, endtime] as get_stats_for_period sees them (call gyo_mlh_flush first) */
+void gyo_mlh_period(const gyo_mlhist *h, int64_t starttime, int64_t endtime, gyo_hist_serial *out /*[16]*/)
+{
+	const int64_t start = starttime, end = endtime + 1; /* :1383 */
+	for (int b = 0; b < GYO_MAX_BUCKETS; b++) {
+		out[b].sum = 0;
+		out[b].count = 0;
+	}
+	for (int b = 0; b < h->nb; b++) {
+		uint64_t c;
+		int64_t s;
+		gyo_bts_range(&h->s[b][gyo_mlh_level_for_start(h, b, start)], start, end, &c, &s);
+		out[b].count = c;
+		out[b].sum = s;
+	}
+}
+
+void gyo_mlh_get_stats_for_period(const gyo_mlhist *h, int64_t starttime, int64_t endtime, const float *pcts, size_t npct, int64_t *values,
+				  int64_t *tcount, int64_t *tsum, double *mean)
+{
+	gyo_hist_serial lv[GYO_MAX_BUCKETS];
+	uint64_t counts[GYO_MAX_BUCKETS];
+	int64_t tc = 0, ts = 0;
+	gyo_mlh_period(h, starttime, endtime, lv);
+	for (int b = 0; b < h->nb; b++) {
+		counts[b] = lv[b].count;
+		tc += (int64_t)lv[b].count;
+		ts += lv[b].sum;
+	}
+	for (size_t i = 0; i < npct; i++) {
+		int64_t v = gyo_bucket_max_threshold(h->kind, gyo_slab_percentile_idx(counts, (size_t)h->nb, (double)pcts[i] / 100.0));
+		values[i] = v < 0 ? 0 : v; /* :1390-1392 */
+	}
+	if (tcount) *tcount = tc;
+	if (tsum) *tsum = ts;
+	if (mean) *mean = (double)ts / (tc != 0 ? tc : 1); /* :1398 */
+}

@@ -196,6 +196,9 @@ def lib():
     _sig(L, "gyo_mlh_level", None, [C.POINTER(MLHist), C.c_int, C.c_void_p])
     _sig(L, "gyo_slab_percentile_idx", C.c_size_t, [u64p, C.c_size_t, C.c_double])
     _sig(L, "gyo_mlh_get_stats", None, [C.POINTER(MLHist), C.c_int, f32p, C.c_size_t, i64p, i64p, i64p, C.POINTER(C.c_double)])
+    _sig(L, "gyo_mlh_level_for_start", C.c_int, [C.POINTER(MLHist), C.c_int, C.c_int64])
+    _sig(L, "gyo_mlh_period", None, [C.POINTER(MLHist), C.c_int64, C.c_int64, C.c_void_p])
+    _sig(L, "gyo_mlh_get_stats_for_period", None, [C.POINTER(MLHist), C.c_int64, C.c_int64, f32p, C.c_size_t, i64p, i64p, i64p, C.POINTER(C.c_double)])
     _sig(L, "gyo_engine_new", C.c_void_p, [C.c_uint32, C.c_int])
     _sig(L, "gyo_engine_free", None, [C.c_void_p])
     _sig(L, "gyo_engine_register", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint16])

@@ -60,6 +60,30 @@ class RingOracle:
             out[s, :, 1] = buf["sum"][:15]
         return out
 
+    def period(self, a, b, tq):
+        """[nsvc][15][2] of the seconds [a, b] as of tq, and the level folly answers from"""
+        out = np.zeros((self.n, 15, 2), dtype=np.int64)
+        buf = np.zeros(16, dtype=self.o.HIST_SERIAL_DT)
+        lv = -1
+        for s, h in enumerate(self.h):
+            hc = self.o.MLHist.from_buffer_copy(h)
+            self.L.gyo_mlh_flush(C.byref(hc), tq)
+            self.L.gyo_mlh_period(C.byref(hc), a, b, buf.ctypes.data)
+            out[s, :, 0] = buf["count"][:15].astype(np.int64)
+            out[s, :, 1] = buf["sum"][:15]
+            lv = self.L.gyo_mlh_level_for_start(C.byref(hc), 0, a)
+        return out, lv
+
+    def period_stats(self, s, a, b, tq, pcts):
+        hc = self.o.MLHist.from_buffer_copy(self.h[s])
+        self.L.gyo_mlh_flush(C.byref(hc), tq)
+        p = np.array(pcts, dtype=np.float32)
+        vals = np.zeros(len(pcts), dtype=np.int64)
+        tc, ts, mean = C.c_int64(), C.c_int64(), C.c_double()
+        self.L.gyo_mlh_get_stats_for_period(C.byref(hc), a, b, self.o.ptr(p, self.o.f32p), len(pcts), self.o.ptr(vals, self.o.i64p), C.byref(tc),
+                                            C.byref(ts), C.byref(mean))
+        return vals.tolist(), tc.value, ts.value, mean.value
+
     def stats(self, s, level, tq, pcts):
         hc = self.o.MLHist.from_buffer_copy(self.h[s])
         self.L.gyo_mlh_flush(C.byref(hc), tq)
@@ -69,6 +93,27 @@ class RingOracle:
         self.L.gyo_mlh_get_stats(C.byref(hc), level, self.o.ptr(p, self.o.f32p), len(pcts), self.o.ptr(vals, self.o.i64p), C.byref(tc), C.byref(ts),
                                  C.byref(mean))
         return vals.tolist(), tc.value, ts.value, mean.value
+
+
+def _check_periods(eng, ring, rng, tq, nsvc, allmax, closes5=True):
+    """get_stats_for_period at query time tq: intervals that end now / in the past / in the future, that lie inside one ring bucket,
+    straddle several, reach past the ring, and pick each of the four levels"""
+    spans = [(tq - 4, tq), (tq - 5, tq), (tq - 17, tq - 3), (tq - 60, tq), (tq - 299, tq - 31), (tq - 300, tq), (tq - 301, tq), (tq - 1000, tq - 200),
+             (tq - 43200, tq), (tq - 100000, tq - 50000), (tq - 432000, tq + 10), (tq - 432001, tq), (tq - 10**7, tq - 100), (0, tq + 5),
+             (tq + 3, tq + 9), (tq - 10**6, tq - 432000 - 50)]
+    for _ in range(4):
+        a = tq - int(rng.integers(0, 500000))
+        spans.append((a, a + int(rng.integers(0, 500000))))
+    for a, b in spans:
+        g, lv = eng.export_hist_period(a, b, tq * 1_000_000, 0, nsvc)
+        if lv == 0 and not closes5:
+            continue  # level 0 is the engine's tumbling window: folly's 5-s ring only when closes are >= 5 s apart
+        o, olv = ring.period(a, b, tq)
+        assert lv == olv, (a - tq, b - tq, lv, olv)
+        bad = np.argwhere(g[:, :15, :] != o)
+        assert bad.size == 0, f"period [{a - tq}, {b - tq}] level {lv} at t={tq}: {bad[:4].tolist()} gpu {g[tuple(bad[0][:2])]} oracle {o[tuple(bad[0][:2])]}"
+        assert (g[:, 15, 0] == o[:, :, 0].sum(axis=1)).all()
+        assert (g[:, 15, 1] == allmax).all()
 
 
 def _check_levels(eng, ring, tq, nsvc, levels, allmax):
@@ -129,9 +174,17 @@ def test_levels_match_ring_oracle(torch_mod, oracle, enable_td):
         for probe in (2, 5, 31, 299, 43201):  # later queries without a close in between
             if dt >= 5 and prev_dt >= 5 or probe >= 5:
                 _check_levels(eng, ring, t + probe, nsvc, [0, 1, 2, 3], allmax)
+        if w % 3 == 0 or dt > 40:
+            _check_periods(eng, ring, rng, t, nsvc, allmax, closes5=prev_dt >= 5 and dt >= 5)
+            _check_periods(eng, ring, rng, t + int(rng.integers(1, 400)), nsvc, allmax, closes5=prev_dt >= 5 and dt >= 5)
         if w % 4 == 0:
             s = int(rng.integers(0, nsvc))
             gid = int(gids[s // sp][s % sp])
+            for a, b in ((t - 100, t), (t - 4000, t - 20), (t - 3, t), (0, t)):
+                got = eng.query_hist_period_stats(gid, a, b, t * 1_000_000, [25.0, 50.0, 95.0, 99.0])
+                want = ring.period_stats(s, a, b, t, [25.0, 50.0, 95.0, 99.0])
+                if not (a == t - 3 and (prev_dt < 5 or dt < 5)):
+                    assert got == want, (w, s, a - t, b - t, got, want)
             for lv in (1, 2, 3):
                 got = eng.query_hist_level_stats(gid, lv, t * 1_000_000, [25.0, 50.0, 95.0, 99.0])
                 want = ring.stats(s, lv, t, [25.0, 50.0, 95.0, 99.0])

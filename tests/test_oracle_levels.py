@@ -120,3 +120,124 @@ def test_slab_percentile_rule():
     L.gyo_mlh_init(C.byref(e), oracle.RESP_TIME_HASH, NB)
     L.gyo_mlh_get_stats(C.byref(e), 2, oracle.ptr(pcts, oracle.f32p), 4, oracle.ptr(vals, oracle.i64p), C.byref(tc), C.byref(ts), C.byref(mean))
     assert vals.tolist() == [1, 1, 1, 1] and tc.value == 0 and mean.value == 0.0
+
+
+# ---------------------------------------------------------------- get_stats_for_period: count(start, end) / sum(start, end)
+def _f32_scaled(v, num, den):
+    """rangeAdjust: input * ((end - start) * 1.f / (bucket width)) in float, truncated back to the integer type"""
+    scale = np.float32(np.float32(num) * np.float32(1.0) / np.float32(den))
+    return int(np.float32(np.float32(v) * scale))
+
+
+def brute_range(adds, latest, first, level, start, end):
+    """a second statement of BucketedTimeSeries::count/sum(start, end) after update(latest): the adds grouped by the ring bucket that
+    holds them, every bucket [bs, bn) scaled by its overlap with [start, end); the bucket holding `latest` ends at latest + 1"""
+    dur = LEVEL_SECS[level]
+    if dur == 0:
+        spans = [(first, latest + 1)]
+    else:
+        nb = min(NB, dur)
+        cur = (latest % dur) * nb // dur
+        spans = []
+        for back in range(nb - 1, -1, -1):  # oldest first
+            j = cur - back
+            cyc = latest // dur
+            if j < 0:
+                j += nb
+                cyc -= 1
+            bs = cyc * dur + -(-(j * dur) // nb)
+            bn = cyc * dur + -(-((j + 1) * dur) // nb)
+            spans.append((bs, bn))
+    tc = ts = 0
+    for bs, bn in spans:
+        if start >= bn:
+            continue
+        if end <= bs:
+            break
+        c = sum(c for t, s, c in adds if bs <= t < bn)
+        s = sum(s for t, s, c in adds if bs <= t < bn)
+        if bs <= latest < bn:
+            bn = latest + 1
+        if start <= bs and end >= bn:
+            tc, ts = tc + c, ts + s
+        else:
+            num, den = min(end, bn) - max(start, bs), bn - bs
+            tc, ts = tc + _f32_scaled(c, num, den), ts + _f32_scaled(s, num, den)
+    return tc, ts
+
+
+@pytest.mark.parametrize("cadence", ["regular5", "jitter", "gaps"])
+def test_period_range_matches_definition(cadence):
+    L = oracle.lib()
+    L.gyo_bts_range.argtypes = [C.POINTER(oracle.BTS), C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
+    L.gyo_bts_range.restype = None
+    rng = np.random.default_rng(23)
+    series = [oracle.BTS() for _ in range(4)]
+    for lv, s in enumerate(series):
+        L.gyo_bts_init(C.byref(s), NB, LEVEL_SECS[lv])
+    t = 1_700_000_003
+    adds, first = [], None
+    for step in range(400):
+        if cadence == "regular5":
+            t += 5
+        elif cadence == "jitter":
+            t += int(rng.integers(1, 9))
+        else:
+            t += int(rng.choice([5, 5, 5, 40, 301, 3600, 43200 * 3, 5 * 24 * 3600 + 7]))
+        if rng.random() < 0.8:
+            sm, cnt = int(rng.integers(0, 10**9)), int(rng.integers(1, 10**6))
+            adds.append((t, sm, cnt))
+            for s in series:
+                L.gyo_bts_add(C.byref(s), t, sm, cnt)
+        for s in series:
+            L.gyo_bts_update(C.byref(s), t)
+        first = first if first is not None else t
+        if step % 3:
+            continue
+        for lv, s in enumerate(series):
+            dur = LEVEL_SECS[lv] or (t - first + 10)
+            for _ in range(6):
+                a = t - int(rng.integers(0, dur + dur // 4 + 2))
+                b = a + int(rng.integers(1, dur + 2))
+                c, sm_ = C.c_uint64(), C.c_int64()
+                L.gyo_bts_range(C.byref(s), a, b, C.byref(c), C.byref(sm_))
+                want = brute_range([x for x in adds if x[0] <= t], t, first, lv, a, b)
+                # adds older than the ring are not in it: brute_range only looks inside the ring's spans, like the ring
+                assert (c.value, sm_.value) == want, (cadence, step, lv, a - t, b - t)
+            # the whole span of the level == its totals
+            c, sm_ = C.c_uint64(), C.c_int64()
+            L.gyo_bts_range(C.byref(s), 0, t + 1, C.byref(c), C.byref(sm_))
+            assert (c.value, sm_.value) == (s.tot_cnt, s.tot_sum)
+
+
+def test_period_level_choice_and_stats():
+    """MultiLevelTimeSeries::getLevel(start): the first level whose duration reaches back to start; the percentile rule on the
+    interval counts (CountFromInterval); a period that covers a level's whole ring gives that level's get_stats"""
+    L = oracle.lib()
+    h = oracle.MLHist()
+    L.gyo_mlh_init(C.byref(h), oracle.RESP_TIME_HASH, NB)
+    rng = np.random.default_rng(5)
+    t = 1_700_000_000
+    for w in range(200):
+        t += 5
+        st = np.zeros(16, dtype=oracle.HIST_SERIAL_DT)
+        st["count"][:15] = rng.integers(0, 50, 15)
+        st["sum"][:15] = st["count"][:15] * rng.integers(1, 2000, 15)
+        L.gyo_mlh_add_hist(C.byref(h), t, st.ctypes.data, 1)
+        L.gyo_mlh_flush(C.byref(h), t)
+    assert [L.gyo_mlh_level_for_start(C.byref(h), 0, t - d) for d in (0, 5, 6, 300, 301, 432000, 432001, 10**8)] == [0, 0, 1, 1, 2, 2, 3, 3]
+    p = np.array([25.0, 50.0, 95.0, 99.0], dtype=np.float32)
+    for lv, back in ((1, 300), (2, 432000), (3, 10**8)):
+        v1, v2 = np.zeros(4, dtype=np.int64), np.zeros(4, dtype=np.int64)
+        a = [C.c_int64(), C.c_int64(), C.c_double()]
+        b = [C.c_int64(), C.c_int64(), C.c_double()]
+        L.gyo_mlh_get_stats(C.byref(h), lv, oracle.ptr(p, oracle.f32p), 4, oracle.ptr(v1, oracle.i64p), C.byref(a[0]), C.byref(a[1]), C.byref(a[2]))
+        L.gyo_mlh_get_stats_for_period(C.byref(h), t - back, t, oracle.ptr(p, oracle.f32p), 4, oracle.ptr(v2, oracle.i64p), C.byref(b[0]), C.byref(b[1]),
+                                       C.byref(b[2]))
+        assert v1.tolist() == v2.tolist() and [x.value for x in a] == [x.value for x in b], lv
+    # a sub-interval: half of a 30-s ring bucket of the 300-s level is scaled in float
+    out = np.zeros(16, dtype=oracle.HIST_SERIAL_DT)
+    L.gyo_mlh_period(C.byref(h), t - 100, t - 50, out.ctypes.data)
+    full = np.zeros(16, dtype=oracle.HIST_SERIAL_DT)
+    L.gyo_mlh_level(C.byref(h), 1, full.ctypes.data)
+    assert 0 < int(out["count"].sum()) < int(full["count"].sum())
