@@ -345,6 +345,7 @@ def main():
     # window exchange at N > 1: the four register families all-reduced INSIDE the library (gys_window_close_rccl: ncclAllReduce x 4 in
     # one group on the engine stream).  torch.distributed only carries the 128-byte communicator id (and the timing barrier).
     exchange = "none"
+    rccl_join_stuck = False
     if world > 1:
         exchange = "torch.distributed"
         if args.exchange == "rccl":
@@ -368,6 +369,7 @@ def main():
                 th = threading.Thread(target=_join, daemon=True)
                 th.start()
                 th.join(60.0)
+                rccl_join_stuck = th.is_alive()
                 if res.get("ok"):
                     exchange = "rccl_in_library"
                 else:
@@ -405,13 +407,15 @@ def main():
     # from the first warm-up window on every window carries its long-run share of merges (events / ~(PEND + events per key and window)).
     ingested = []  # (nevents, seed, zipf/spread code, times): everything the engine was fed, for the quantile-error check
     PEND = capi.TD_PEND_CAP
+    # every close is a collective at N > 1: the number of untimed windows must not depend on the rank's own share of the hosts
+    nsvc_nominal = args.hosts * args.svcs // world
     if args.prime_windows < 0:  # one full buffer cycle: PEND values at events/keys values per window, plus one
-        args.prime_windows = min(60, int(PEND * nsvc / max(args.events, 1)) + 2) if nsvc else 0
-    if not args.no_dephase and nsvc:
+        args.prime_windows = min(60, int(PEND * nsvc_nominal / max(args.events, 1)) + 2) if nsvc_nominal else 0
+    if not args.no_dephase and nsvc_nominal:
         total = nsvc * (PEND // 2 - 1)
         nb = max(1, -(-total // args.events))
         per = min(args.events, total // nb)
-        for b in range(nb):
+        for b in range(nb if per else 0):
             sg = eng.gen_resp_events(bufs[0].data_ptr(), per, 0xdef0 + 77 * b + rank, 0, nlocal, args.svcs, 0xFFFFFFFF)
             eng.handle_resp_events_dev(sg, bufs[0].data_ptr(), per)
             ingested.append([per, 0xdef0 + 77 * b + rank, 0xFFFFFFFF, 1])
@@ -563,6 +567,10 @@ def main():
     if bad:  # the north-star tolerance is part of the metric: a line that breaks it is not a result
         print("bench.py: t-digest rank error above the 0.01 tolerance", file=sys.stderr)
         sys.exit(3)
+    if rccl_join_stuck:  # a helper thread is still inside ncclCommInitRank: do not let interpreter shutdown wait on it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
