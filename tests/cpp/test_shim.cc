@@ -139,6 +139,8 @@ int main(int argc, char **argv)
 		int64_t tcount = -1, tsum = -1;
 		double mean = -1;
 		if (h.get_resp_level_stats(0x1003, 2, 10, tv, 2, tcount, tsum, mean) != 0 || tcount != 0 || tsum != 0 || tv[0].data_value != 1) return 15;
+		tcount = tsum = -1;
+		if (h.get_resp_period_stats(0x1003, 2, 9, tv, 2, tcount, tsum, mean, 10) != 0 || tcount != 0 || tsum != 0 || tv[1].data_value != 1) return 18;
 		gys_listener_day_stats ds[10];
 		if (!h.listener_day_stats(10, 0, 10, ds)) return 16;
 		// service 9: nqrys_5s = 63 -> two QPS samples of 12 (SEMI_LOG_HASH_LO bucket ceiling 50); no active connections -> ceiling 1
