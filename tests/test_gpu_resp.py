@@ -280,7 +280,7 @@ def test_resp_buffer_fill_and_merge_cycles(torch_mod, oracle, resp_path, td_buf)
     orc = oracle.OracleEngine(16)
     info, gids = helpers.register_world(eng, orc, range(nh), sp)
     # (with a 1024-entry buffer the larger batches do not fit behind the buffered values: spilled keys, merged from buffer + run)
-    sizes = [5, 40, 64, 65, 130, 255, 256, 257, 1, 700, 1024 * sp, 300, 3, 511, 9, 9, 9, 2000, 77, 895, 1, 896 * sp, 2, 4500 * sp, 20000 * sp, 30]
+    sizes = [5, 40, 64, 65, 130, 255, 256, 257, 1, 700, 1024 * sp, 300, 3, 511, 9, 9, 9, 2000, 77, 767, 1, 768 * sp, 2, 4500 * sp, 20000 * sp, 30]
     for rnd, n in enumerate(sizes):
         for h in range(nh):
             ev = helpers.make_resp_events(rng, h, n, sp if rnd % 3 else 1, lat_mu=2.0 + 0.2 * rnd, bad_frac=0.01, unknown_frac=0.01)
