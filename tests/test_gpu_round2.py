@@ -442,7 +442,7 @@ def test_window_close_rccl_inside_the_library(torch_mod):
     seen = []
     try:
         while True:
-            msg = q.get(timeout=90)
+            msg = q.get(timeout=75)
             seen.append(msg)
             if msg == "ok" or msg.startswith("error") or msg.startswith("bootstrap-failed"):
                 break
@@ -450,7 +450,7 @@ def test_window_close_rccl_inside_the_library(torch_mod):
         p.kill()
         p.join(timeout=30)
         if seen and seen[-1] in ("joining", "joined"):
-            pytest.skip(f"RCCL did not return within 90 s on this box (after {seen[-1]!r}); the in-library exchange was not exercised")
+            pytest.skip(f"RCCL did not return within 75 s on this box (after {seen[-1]!r}); the in-library exchange was not exercised")
         pytest.fail(f"RCCL window worker stalled after {seen}")
     p.join(timeout=60)
     if seen[-1].startswith("bootstrap-failed"):
