@@ -442,7 +442,7 @@ def test_window_close_rccl_inside_the_library(torch_mod):
     seen = []
     try:
         while True:
-            msg = q.get(timeout=75)
+            msg = q.get(timeout=75 if seen else 150)  # (the first message comes after the worker's own import of torch)
             seen.append(msg)
             if msg == "ok" or msg.startswith("error") or msg.startswith("bootstrap-failed"):
                 break
