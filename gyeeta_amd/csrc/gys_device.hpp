@@ -10,6 +10,14 @@
 #include "../../include/gys_tdigest_tbl.h"
 
 #define GYS_WAVE 64
+// two constructs a host compiler cannot take as they stand; tests/cpp/kemu (the CPU stand-in of the device model that runs kernel
+// LOGIC under g++) defines them its own way before this header is read
+#ifndef GYS_OPAQUE_VGPR
+#define GYS_OPAQUE_VGPR(x) asm volatile("" : "+v"(x)) // the value passes through an opaque move: nothing derived from it is loop-invariant
+#endif
+#ifndef GYS_DYN_LDS
+#define GYS_DYN_LDS(type, name) extern __shared__ type name[] // the launch's dynamic LDS
+#endif
 #define GYS_SEED 0xceedfeadu   // common/gy_common_inc.h:1112 (every reference key hash uses this initval)
 #define GYS_GOLDEN 0x9e3779b9u // common/jhash.h:37
 #define GYS_NOSLOT 0xFFFFFFFFu

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_huge_clear(Huge2P p)
 // ---- count: one chunk of one entry's run per workgroup
 __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 {
-	extern __shared__ uint32_t s_img[]; // [GYS_HB_BINS]
+	GYS_DYN_LDS(uint32_t, s_img); // [GYS_HB_BINS]
 	__shared__ unsigned long long s_hc[16], s_hs[16];
 	__shared__ uint32_t s_bm[16], s_mm[2];
 	const uint32_t nuse = *p.nent_used, tid = threadIdx.x;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 // ---- merge: one workgroup per entry
 __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 {
-	extern __shared__ uint32_t s_img[];           // [GYS_HB_BINS] the entry's exact value counts (run + buffered words), then s_tail
+	GYS_DYN_LDS(uint32_t, s_img);                 // [GYS_HB_BINS] the entry's exact value counts (run + buffered words), then s_tail
 	uint32_t *s_tail = s_img + GYS_HB_BINS;       // [GYS_HB_TAIL_LDS] the entry's values >= GYS_HB_BINS, sorted
 	__shared__ int64_t s_csum[GYS_TD_NB];
 	__shared__ uint32_t s_ccnt[GYS_TD_NB];

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_key_finalize(FinP p)
 #define GYS_CMSF_CELLS (GYS_CMS_W / 2u)
 __global__ __launch_bounds__(1024) void k_cms_partial(const uint32_t *resp_win, const uint64_t *svc_gid, uint32_t nsvc, uint32_t nch, uint32_t *partial)
 {
-	extern __shared__ uint32_t s_cells[]; // [GYS_CMSF_CELLS]
+	GYS_DYN_LDS(uint32_t, s_cells); // [GYS_CMSF_CELLS]
 	const uint32_t r = blockIdx.y >> 1, half = blockIdx.y & 1u;
 	for (uint32_t i = threadIdx.x; i < GYS_CMSF_CELLS; i += 1024u) s_cells[i] = 0;
 	__syncthreads();
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 {
 	constexpr uint32_t T = GYS_RESP_THREADS(TPT);
 	constexpr uint32_t TILE = (uint32_t)TPT * T;
-	extern __shared__ uint64_t s_dyn[];
+	GYS_DYN_LDS(uint64_t, s_dyn);
 	__shared__ uint32_t s_wsum[T / 64];
 	__shared__ uint32_t s_drop[2];
 	__shared__ uint32_t s_floor;
@@ -1495,7 +1495,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		// the thread index is re-derived per entry behind an opaque move: otherwise every LDS address, lane mask and per-bin
 		// bucket the thread uses is hoisted out of this loop and held in registers across it (> 96 VGPRs instead of < 64)
 		uint32_t tid = threadIdx.x;
-		asm volatile("" : "+v"(tid));
+		GYS_OPAQUE_VGPR(tid);
 		const uint32_t lane = tid & 63u, wave = tid >> 6;
 		MergeEnt ent;
 		if (SCAN) ent = MergeEnt{w, min(p.td_meta[w].npend, (uint32_t)GYS_TD_PEND_CAP), 0u, 0u}; // between batches a buffer holds at most PEND_CAP values
