@@ -58,8 +58,8 @@ int32_t draw(std::mt19937 &rng, double mu, double sigma)
 int main(int argc, char **argv)
 {
 	const uint32_t NT = KEMU_BINS_NT;
-	const uint32_t CAP = 4u * NT > GYS_MERGE_CLASS0 ? GYS_MERGE_CLASS0 : 4u * NT; // values one merge of this instance takes
-	const uint32_t pcap = GYS_MERGE_CLASS0 + 64u;
+	const uint32_t CAP = 4u * NT; // values one merge of this instance takes (four per thread)
+	const uint32_t pcap = CAP + 64u;
 	std::mt19937 rng(argc > 1 ? (unsigned)atoi(argv[1]) : 12345u);
 	const uint32_t S = 14;
 	std::vector<Key> keys(S);
