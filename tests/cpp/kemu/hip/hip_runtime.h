@@ -16,7 +16,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#include <condition_variable>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -42,33 +42,43 @@ namespace kemu {
 
 struct Dim3 { uint32_t x = 1, y = 1, z = 1; };
 
-struct DynBarrier { // a barrier whose participants may leave
+struct DynBarrier { // a barrier whose participants may leave (C++20: the waiters sleep on the generation word, not on a condition variable)
 	std::mutex m;
-	std::condition_variable cv;
 	int expected = 0, waiting = 0;
-	uint64_t gen = 0;
+	std::atomic<uint32_t> gen{0};
 	void reset(int n) { expected = n; waiting = 0; }
 	void arrive_wait()
 	{
-		std::unique_lock<std::mutex> l(m);
-		const uint64_t g = gen;
-		if (++waiting >= expected) {
-			waiting = 0;
-			++gen;
-			cv.notify_all();
+		uint32_t g;
+		bool release = false;
+		{
+			std::lock_guard<std::mutex> l(m);
+			g = gen.load(std::memory_order_relaxed);
+			if (++waiting >= expected) {
+				waiting = 0;
+				gen.store(g + 1, std::memory_order_release);
+				release = true;
+			}
+		}
+		if (release) {
+			gen.notify_all();
 		} else {
-			cv.wait(l, [&] { return gen != g; });
+			while (gen.load(std::memory_order_acquire) == g) gen.wait(g, std::memory_order_acquire);
 		}
 	}
 	void leave()
 	{
-		std::unique_lock<std::mutex> l(m);
-		--expected;
-		if (expected > 0 && waiting >= expected) {
-			waiting = 0;
-			++gen;
-			cv.notify_all();
+		bool release = false;
+		{
+			std::lock_guard<std::mutex> l(m);
+			--expected;
+			if (expected > 0 && waiting >= expected) {
+				waiting = 0;
+				gen.fetch_add(1, std::memory_order_release);
+				release = true;
+			}
 		}
+		if (release) gen.notify_all();
 	}
 };
 
