@@ -36,6 +36,9 @@ const uint64_t *gyo_engine_counters(const gyo_engine *e);
 #ifndef KEMU_BINS_NT
 #define KEMU_BINS_NT 256
 #endif
+#ifndef KEMU_NB
+#define KEMU_NB 6 // batches
+#endif
 
 using namespace gys;
 
@@ -110,7 +113,7 @@ int main(int argc, char **argv)
 	std::vector<unsigned long long> ghist(32, 0);
 	long long gmax = INT64_MIN;
 
-	const uint32_t NB = 6;
+	const uint32_t NB = KEMU_NB;
 	uint32_t stamp = 0;
 	uint64_t merges_seen = 0;
 	for (uint32_t batch = 0; batch < NB; ++batch) {
@@ -235,7 +238,14 @@ int main(int argc, char **argv)
 			mp.d = q.d;
 			mp.list = list1.data();
 			mp.count = &counts[FIN_CLASS1];
+#if defined(KEMU_BINS_TEMPLATE_NT)
+			q.list = list1.data(); // (the tree under test merges class 1 with the 1024-thread instance of the value-bin kernel)
+			q.count = &counts[FIN_CLASS1];
+			kemu::launch(2, 1024, 0, [&] { k_digest_bins<false, 1024u>(q); });
+			CHECK(counts[FIN_SLOW] == 0, "hand-over list not empty");
+#else
 			kemu::launch(2, 256, 0, [&] { k_digest_merge<GYS_MERGE_CLASS1, 256u>(mp); });
+#endif
 		}
 
 		// ---- compare with the oracle after the batch
