@@ -101,6 +101,26 @@ inline Wave &wave() { return g_block->waves[t_threadIdx.x >> 6]; }
 inline uint32_t lane() { return t_threadIdx.x & 63u; }
 inline void *dyn_lds() { return g_block->dyn_lds.data(); }
 
+// can this process have `n` threads at once (container limits differ)?  The tests exit with status 77 (reported as a skip) if not.
+inline bool can_run(uint32_t n)
+{
+	std::vector<std::thread> th;
+	std::atomic<bool> go{false};
+	bool ok = true;
+	try {
+		th.reserve(n);
+		for (uint32_t t = 0; t < n; ++t)
+			th.emplace_back([&] {
+				while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+			});
+	} catch (...) {
+		ok = false;
+	}
+	go.store(true, std::memory_order_release);
+	for (auto &x : th) x.join();
+	return ok;
+}
+
 // run `kernel()` for grid x block threads (1-D), one workgroup after the other
 template <class F>
 void launch(uint32_t grid, uint32_t block, size_t dyn_lds_bytes, F kernel)

@@ -58,6 +58,10 @@ int32_t draw(std::mt19937 &rng, double mu, double sigma)
 int main(int argc, char **argv)
 {
 	const uint32_t NT = KEMU_BINS_NT;
+	if (!kemu::can_run(NT)) {
+		printf("kemu: this process cannot have %u threads\n", NT);
+		return 77;
+	}
 	const uint32_t CAP = 4u * NT; // values one merge of this instance takes (four per thread)
 	const uint32_t pcap = CAP + 64u;
 	std::mt19937 rng(argc > 1 ? (unsigned)atoi(argv[1]) : 12345u);

@@ -60,6 +60,10 @@ uint16_t bswap(uint16_t v) { return (uint16_t)((v >> 8) | (v << 8)); }
 
 int main(int argc, char **argv)
 {
+	if (!kemu::can_run(1024u)) {
+		printf("kemu: this process cannot have 1024 threads\n");
+		return 77;
+	}
 	std::mt19937 rng(argc > 1 ? (unsigned)atoi(argv[1]) : 4242u);
 	constexpr uint32_t T = GYS_RESP_THREADS(KEMU_TPT), TILE = (uint32_t)KEMU_TPT * T;
 	const uint32_t NH = 3, L[NH] = {150, 37, 64};

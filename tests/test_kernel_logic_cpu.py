@@ -34,6 +34,8 @@ def kemu_bins(tmp_path_factory, oracle):
 @pytest.mark.parametrize("seed", [12345, 7, 99])
 def test_digest_bins_kernel_logic_equals_oracle(kemu_bins, seed):
     r = subprocess.run(["timeout", "-s", "KILL", "300", kemu_bins, str(seed)], capture_output=True, text=True)
+    if r.returncode == 77:
+        pytest.skip(r.stdout.strip())
     assert r.returncode == 0 and "kemu bins ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
 
 
@@ -41,4 +43,6 @@ def test_digest_bins_kernel_logic_equals_oracle(kemu_bins, seed):
 def test_resp_pipeline_kernel_logic_equals_oracle_engine(tmp_path_factory, oracle, tpt):
     exe = _build(tmp_path_factory, oracle, "test_resp.cc", "kemu_resp%d" % tpt, ["KEMU_TPT=%d" % tpt])
     r = subprocess.run(["timeout", "-s", "KILL", "900", exe, "4242"], capture_output=True, text=True)
+    if r.returncode == 77:
+        pytest.skip(r.stdout.strip())
     assert r.returncode == 0 and "kemu resp ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
