@@ -6,6 +6,9 @@ the hot kernels run on synthetic input:
   * the response-event pipeline k_resp_host (+ finalize_key) -> k_digest_bins / k_digest_merge over several batches and window
     boundaries (tests/cpp/kemu/test_resp.cc): counters, HLL registers, all-service histogram, every key's buffered values and digest and
     the records of re-clustered keys equal the oracle's sequential engine fed the same bytes.
+  * the paths of a key whose batch does not fit its buffer (tests/cpp/kemu/test_spill.cc): spill in finalize_key, the SPILL pass of
+    k_resp_host, merges from buffer + run in every size class, the several-workgroup path of gys_huge.hpp with its sorted tail and its
+    one-workgroup fallback.
 This does not replace the -m gpu parity tests (no memory model, no execution masks, no timing): it catches logic errors in kernel
 changes before GPU minutes are spent on them."""
 import os
@@ -46,3 +49,11 @@ def test_resp_pipeline_kernel_logic_equals_oracle_engine(tmp_path_factory, oracl
     if r.returncode == 77:
         pytest.skip(r.stdout.strip())
     assert r.returncode == 0 and "kemu resp ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_spill_and_huge_paths_kernel_logic_equals_oracle_engine(tmp_path_factory, oracle):
+    exe = _build(tmp_path_factory, oracle, "test_spill.cc", "kemu_spill")
+    r = subprocess.run(["timeout", "-s", "KILL", "900", exe, "777"], capture_output=True, text=True)
+    if r.returncode == 77:
+        pytest.skip(r.stdout.strip())
+    assert r.returncode == 0 and "kemu spill ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
