@@ -2,6 +2,8 @@
 # A/B of kernel variants inside ONE gpurun call (GPU minutes are charged per call: ~50 s of fixed cost each).
 #   here (no GPU):   tools/ab_libs.sh build wg6 -DGYS_BINS_WGS=6        -> gyeeta_amd/lib/libgysketch_wg6.so (travels with the snapshot)
 #   on the GPU box:  tools/ab_libs.sh bench OUTDIR [bench.py args ...]  -> one lean bench line per library found (the default one first)
+# A quarter-size run keeps the per-key rates of the default line (53.7 values per key and window) and takes a few seconds per library:
+#   tools/ab_libs.sh bench OUT --hosts 2500 --events 134217728 --steps 6 --warmup 2
 # Only compile-time switches of the HIP side can be compared this way: constants shared with the oracle / capi.py (e.g. the t-digest
 # buffer size) need their own tree.  capi.py loads $GYS_LIB when set.
 R=$(cd "$(dirname "$0")/.." && pwd)
