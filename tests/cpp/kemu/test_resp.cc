@@ -123,7 +123,11 @@ int main(int argc, char **argv)
 	for (uint32_t batch = 0; batch < NB; ++batch) {
 		// ---- a batch: every host one segment; a short one, a multi-tile one, a one-tile one; some events dropped by both filters, some
 		// with a zero address (the rolled general hash path)
+#ifdef KEMU_SPLIT // the split form: long segments cut into parts of GYS_SPLIT_PART events, several workgroups per host, k_key_finalize afterwards
+		const uint32_t nev[NH] = {GYS_SPLIT_PART + 9000u + 1000u * batch, batch == 3 ? 5u : 9000u, GYS_SPLIT_PART + 1u + batch}; // (two parts each; the second one of host 2 holds 1 .. 3 events)
+#else
 		const uint32_t nev[NH] = {33545u + 1000u * batch, batch == 3 ? 5u : 9000u, 16381u + batch}; // (16 384-event tiles: 2+ tiles / <1 tile / one tile minus 3 .. plus 2)
+#endif
 		std::vector<uint8_t> ev;
 		std::vector<gys_resp_seg> segs;
 		std::vector<uint32_t> seg_host;
@@ -203,7 +207,19 @@ int main(int argc, char **argv)
 		hp.lds_key_entries = (max_l + 1u) & ~1u;
 		hp.fin = fin;
 		const size_t dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_key_entries * 24 + (size_t)TILE * 6u;
+#ifdef KEMU_SPLIT
+		std::vector<gys_resp_seg> vsegs;
+		for (uint32_t h = 0; h < NH; ++h) {
+			const uint64_t first = segs[h].first_event, len = (h + 1 < NH ? segs[h + 1].first_event : n) - first;
+			for (uint64_t part = 0; part * GYS_SPLIT_PART < len; ++part) vsegs.push_back(gys_resp_seg{h, 0u, first + part * GYS_SPLIT_PART});
+		}
+		hp.segs = vsegs.data();
+		hp.nsegs = (uint32_t)vsegs.size();
+		kemu::launch((uint32_t)vsegs.size(), T, dyn, [&] { k_resp_host<KEMU_TPT, true, false, false>(hp); });
+		kemu::launch((nsvc + 255u) / 256u, 256, 0, [&] { k_key_finalize(fin); });
+#else
 		kemu::launch(NH, T, dyn, [&] { k_resp_host<KEMU_TPT, false, false, false>(hp); });
+#endif
 		CHECK(counts[FIN_HUGE] == 0 && counts[FIN_RUN_ALLOC] == 0, "batch %u: huge %u run words %u (the test keeps every key below 4 096 values and inside its buffer)", batch,
 		      counts[FIN_HUGE], counts[FIN_RUN_ALLOC]);
 

@@ -42,9 +42,12 @@ def test_digest_bins_kernel_logic_equals_oracle(kemu_bins, seed):
     assert r.returncode == 0 and "kemu bins ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("tpt", [16, 12], ids=["tiles-16384", "tiles-6144"])
-def test_resp_pipeline_kernel_logic_equals_oracle_engine(tmp_path_factory, oracle, tpt):
-    exe = _build(tmp_path_factory, oracle, "test_resp.cc", "kemu_resp%d" % tpt, ["KEMU_TPT=%d" % tpt])
+@pytest.mark.parametrize("tpt,split", [(16, False), (12, False), (16, True)], ids=["tiles-16384", "tiles-6144", "split-form"])
+def test_resp_pipeline_kernel_logic_equals_oracle_engine(tmp_path_factory, oracle, tpt, split):
+    """split-form: long segments cut into parts of 65 536 events, several workgroups per host reserving buffer space with device
+    atomics, k_key_finalize as its own launch"""
+    exe = _build(tmp_path_factory, oracle, "test_resp.cc", "kemu_resp%d%s" % (tpt, "s" if split else ""),
+                 ["KEMU_TPT=%d" % tpt] + (["KEMU_SPLIT", "KEMU_NB=3"] if split else []))
     r = subprocess.run(["timeout", "-s", "KILL", "900", exe, "4242"], capture_output=True, text=True)
     if r.returncode == 77:
         pytest.skip(r.stdout.strip())
