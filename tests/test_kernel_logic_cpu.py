@@ -4,13 +4,16 @@ the hot kernels run on synthetic input:
   * k_digest_bins on hand-made keys (tests/cpp/kemu/test_bins.cc): re-clustered digests, lazily folded histogram records, CONN_BITMAP
     rows, min / max and drained meta records equal the oracle's;
   * the response-event pipeline k_resp_host (+ finalize_key) -> k_digest_bins / k_digest_merge over several batches and window
-    boundaries (tests/cpp/kemu/test_resp.cc): counters, HLL registers, all-service histogram, every key's buffered values and digest and
-    the records of re-clustered keys equal the oracle's sequential engine fed the same bytes.
+    boundaries (tests/cpp/kemu/test_resp.cc) in both tile forms and in the split form (long segments cut into parts of 65 536 events,
+    several workgroups per host reserving buffer space with device atomics, k_key_finalize as its own launch): counters, HLL
+    registers, all-service histogram, every key's buffered values and digest and the records of re-clustered keys equal the oracle's
+    sequential engine fed the same bytes;
   * the paths of a key whose batch does not fit its buffer (tests/cpp/kemu/test_spill.cc): spill in finalize_key, the SPILL pass of
     k_resp_host, merges from buffer + run in every size class, the several-workgroup path of gys_huge.hpp with its sorted tail and its
     one-workgroup fallback.
 This does not replace the -m gpu parity tests (no memory model, no execution masks, no timing): it catches logic errors in kernel
-changes before GPU minutes are spent on them."""
+changes before GPU minutes are spent on them.  The programs are built and run side by side once per session (they mostly wait in
+barriers); each test below looks at one of them."""
 import os
 import subprocess
 
@@ -19,44 +22,54 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEMU = os.path.join(ROOT, "tests", "cpp", "kemu")
 
-
-def _build(tmp_path_factory, oracle, src, name, defs=()):
-    oracle.lib()  # builds oracle/liboracle.so if needed
-    exe = str(tmp_path_factory.mktemp("kemu") / name)
-    odir = os.path.join(ROOT, "oracle")
-    subprocess.check_call(["g++", "-std=c++20", "-O1", "-w", "-I" + KEMU] + ["-D" + d for d in defs] +
-                          [os.path.join(KEMU, src), "-o", exe, "-L" + odir, "-l:liboracle.so", "-Wl,-rpath," + odir, "-pthread"])
-    return exe
+# name -> (source, defines, arguments, marker of success)
+PROGRAMS = {
+    "bins-12345": ("test_bins.cc", [], ["12345"], "kemu bins ok"),
+    "bins-7": ("test_bins.cc", [], ["7"], "kemu bins ok"),
+    "bins-99": ("test_bins.cc", [], ["99"], "kemu bins ok"),
+    "resp-tiles-16384": ("test_resp.cc", ["KEMU_TPT=16"], ["4242"], "kemu resp ok"),
+    "resp-tiles-6144": ("test_resp.cc", ["KEMU_TPT=12"], ["4242"], "kemu resp ok"),
+    "resp-split-form": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_SPLIT", "KEMU_NB=3"], ["4242"], "kemu resp ok"),
+    "spill-and-huge": ("test_spill.cc", [], ["777"], "kemu spill ok"),
+}
 
 
 @pytest.fixture(scope="module")
-def kemu_bins(tmp_path_factory, oracle):
-    return _build(tmp_path_factory, oracle, "test_bins.cc", "kemu_bins")
+def kemu_results(tmp_path_factory, oracle):
+    oracle.lib()  # builds oracle/liboracle.so if needed
+    out = tmp_path_factory.mktemp("kemu")
+    odir = os.path.join(ROOT, "oracle")
+    exes, builds = {}, {}
+    for name, (src, defs, _, _) in PROGRAMS.items():
+        key = (src, tuple(defs))
+        if key in exes:
+            continue
+        exe = str(out / ("kemu_%d" % len(exes)))
+        exes[key] = exe
+        builds[key] = subprocess.Popen(["g++", "-std=c++20", "-O1", "-w", "-I" + KEMU] + ["-D" + d for d in defs] +
+                                       [os.path.join(KEMU, src), "-o", exe, "-L" + odir, "-l:liboracle.so", "-Wl,-rpath," + odir, "-pthread"],
+                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    build_log = {key: (p.communicate()[0], p.returncode) for key, p in builds.items()}
+    runs = {}
+    for name, (src, defs, args, _) in PROGRAMS.items():
+        key = (src, tuple(defs))
+        if build_log[key][1] != 0:
+            continue
+        runs[name] = subprocess.Popen(["timeout", "-s", "KILL", "1200", exes[key]] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    results = {}
+    for name, (src, defs, _, _) in PROGRAMS.items():
+        key = (src, tuple(defs))
+        if name in runs:
+            so, se = runs[name].communicate()
+            results[name] = (runs[name].returncode, so, se)
+        else:
+            results[name] = (-1, "", "build failed:\n" + build_log[key][0][-3000:])
+    return results
 
 
-@pytest.mark.parametrize("seed", [12345, 7, 99])
-def test_digest_bins_kernel_logic_equals_oracle(kemu_bins, seed):
-    r = subprocess.run(["timeout", "-s", "KILL", "300", kemu_bins, str(seed)], capture_output=True, text=True)
-    if r.returncode == 77:
-        pytest.skip(r.stdout.strip())
-    assert r.returncode == 0 and "kemu bins ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
-
-
-@pytest.mark.parametrize("tpt,split", [(16, False), (12, False), (16, True)], ids=["tiles-16384", "tiles-6144", "split-form"])
-def test_resp_pipeline_kernel_logic_equals_oracle_engine(tmp_path_factory, oracle, tpt, split):
-    """split-form: long segments cut into parts of 65 536 events, several workgroups per host reserving buffer space with device
-    atomics, k_key_finalize as its own launch"""
-    exe = _build(tmp_path_factory, oracle, "test_resp.cc", "kemu_resp%d%s" % (tpt, "s" if split else ""),
-                 ["KEMU_TPT=%d" % tpt] + (["KEMU_SPLIT", "KEMU_NB=3"] if split else []))
-    r = subprocess.run(["timeout", "-s", "KILL", "900", exe, "4242"], capture_output=True, text=True)
-    if r.returncode == 77:
-        pytest.skip(r.stdout.strip())
-    assert r.returncode == 0 and "kemu resp ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
-
-
-def test_spill_and_huge_paths_kernel_logic_equals_oracle_engine(tmp_path_factory, oracle):
-    exe = _build(tmp_path_factory, oracle, "test_spill.cc", "kemu_spill")
-    r = subprocess.run(["timeout", "-s", "KILL", "900", exe, "777"], capture_output=True, text=True)
-    if r.returncode == 77:
-        pytest.skip(r.stdout.strip())
-    assert r.returncode == 0 and "kemu spill ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+@pytest.mark.parametrize("name", list(PROGRAMS))
+def test_kernel_logic_equals_oracle(kemu_results, name):
+    rc, so, se = kemu_results[name]
+    if rc == 77:
+        pytest.skip(so.strip())
+    assert rc == 0 and PROGRAMS[name][3] in so, (rc, so[-2000:], se[-2000:])
