@@ -106,10 +106,10 @@ int main(int argc, char **argv)
 	std::vector<unsigned long long> hacc((size_t)maxent * GYS_HB_ACC), tail(1u << 16);
 
 	// per-key events of host 0 by batch (host 1 always gets 2 000 events over its 40 services: never spilled)
-	// batch 0: 500 per key (buffered) | 1: 400 (900 > 832: spilled, class 0 from buffer + run) | 2: 700 (buffered) | 3: 1 500 (spilled, class 1)
+	// batch 0: 400 per key (buffered) | 1: enough to pass the buffer's end by 20 (spilled, class 0 from buffer + run) | 2: 700 | 3: 1 500 (spilled, class 1)
 	// | 4: 21 000 per key, a twentieth of them >= 16 384 ms (spilled, the several-workgroup path in three rounds) | 5: 3 more per key
 	// | 6: 20 000 per key, ALL >= 16 384 ms for key 0 (more tail values than the LDS tail takes: the one-workgroup fallback)
-	const uint32_t per_key[] = {500, 400, 700, 1500, 21000, 3, 20000};
+	const uint32_t per_key[] = {400, pcap - 400u + 20u, 700, 1500, 21000, 3, 20000};
 	const uint32_t NB = sizeof(per_key) / sizeof(per_key[0]);
 	uint32_t stamp = 0;
 	for (uint32_t batch = 0; batch < NB; ++batch) {
