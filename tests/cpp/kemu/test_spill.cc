@@ -29,6 +29,10 @@ const gyo_td_buffered *gyo_engine_td(const gyo_engine *e, uint32_t slot);
 const uint64_t *gyo_engine_counters(const gyo_engine *e);
 }
 
+#ifndef KEMU_BINS_NT
+#define KEMU_BINS_NT 256
+#endif
+
 using namespace gys;
 
 namespace {
@@ -218,13 +222,24 @@ int main(int argc, char **argv)
 		for (uint32_t i = 0; i < counts[FIN_CLASS0]; ++i) merged.push_back(list0[i].slot);
 		for (uint32_t i = 0; i < counts[FIN_CLASS1]; ++i) merged.push_back(list1[i].slot);
 		for (uint32_t i = 0; i < counts[FIN_HUGE]; ++i) merged.push_back(listh[i].slot);
+#if defined(KEMU_BINS_TEMPLATE_NT) // (trees whose value-bin kernel is templated on the thread count)
+		kemu::launch(2, KEMU_BINS_NT, 0, [&] { k_digest_bins<false, KEMU_BINS_NT>(q); });
+#else
 		kemu::launch(2, 256, 0, [&] { k_digest_bins<false>(q); });
+#endif
 		CHECK(counts[FIN_SLOW] == 0, "hand-over list not empty");
 		MergeP mp{};
 		mp.d = q.d;
 		mp.list = list1.data();
 		mp.count = &counts[FIN_CLASS1];
+#if defined(KEMU_BINS_TEMPLATE_NT)
+		q.list = list1.data();
+		q.count = &counts[FIN_CLASS1];
+		kemu::launch(2, 1024, 0, [&] { k_digest_bins<false, 1024u>(q); });
+		CHECK(counts[FIN_SLOW] == 0, "hand-over list not empty");
+#else
 		kemu::launch(2, 256, 0, [&] { k_digest_merge<GYS_MERGE_CLASS1, 256u>(mp); });
+#endif
 		if (batch == 1) CHECK(counts[FIN_CLASS0] >= L[0], "batch 1: %u class-0 entries (spilled keys merged from buffer + run expected)", counts[FIN_CLASS0]);
 		if (batch == 3) CHECK(counts[FIN_CLASS1] == L[0], "batch 3: %u class-1 entries", counts[FIN_CLASS1]);
 		if (batch == 4 || batch == 6) CHECK(counts[FIN_HUGE] == L[0], "batch %u: %u huge entries", batch, counts[FIN_HUGE]);

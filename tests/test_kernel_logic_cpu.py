@@ -23,14 +23,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEMU = os.path.join(ROOT, "tests", "cpp", "kemu")
 
 # name -> (source, defines, arguments, marker of success)
+BINS = []  # (a tree whose value-bin kernel is templated on the thread count sets e.g. ["KEMU_BINS_NT=512", "KEMU_BINS_TEMPLATE_NT"])
 PROGRAMS = {
-    "bins-12345": ("test_bins.cc", [], ["12345"], "kemu bins ok"),
-    "bins-7": ("test_bins.cc", [], ["7"], "kemu bins ok"),
-    "bins-99": ("test_bins.cc", [], ["99"], "kemu bins ok"),
-    "resp-tiles-16384": ("test_resp.cc", ["KEMU_TPT=16"], ["4242"], "kemu resp ok"),
-    "resp-tiles-6144": ("test_resp.cc", ["KEMU_TPT=12"], ["4242"], "kemu resp ok"),
-    "resp-split-form": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_SPLIT", "KEMU_NB=3"], ["4242"], "kemu resp ok"),
-    "spill-and-huge": ("test_spill.cc", [], ["777"], "kemu spill ok"),
+    "bins-12345": ("test_bins.cc", BINS, ["12345"], "kemu bins ok"),
+    "bins-7": ("test_bins.cc", BINS, ["7"], "kemu bins ok"),
+    "bins-99": ("test_bins.cc", BINS, ["99"], "kemu bins ok"),
+    "resp-tiles-16384": ("test_resp.cc", ["KEMU_TPT=16"] + BINS, ["4242"], "kemu resp ok"),
+    "resp-tiles-6144": ("test_resp.cc", ["KEMU_TPT=12"] + BINS, ["4242"], "kemu resp ok"),
+    "resp-split-form": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_SPLIT", "KEMU_NB=3"] + BINS, ["4242"], "kemu resp ok"),
+    "spill-and-huge": ("test_spill.cc", BINS, ["777"], "kemu spill ok"),
 }
 
 
