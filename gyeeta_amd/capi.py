@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("GYS_LIB") or os.path.join(HERE, "lib", "libgysketch.s
 OK, ERR_INVAL, ERR_NOMEM, ERR_HIP, ERR_NOTFOUND, ERR_NOT_OWNER, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 MAX_BUCKETS, TD_NB, HLL_P, CMS_D, CMS_W, NSTATES, TOPN = 16, 200, 14, 4, 65536, 6, 10
 NLEVELS, LEVEL_RING = 4, 10
-TD_PEND_CAP = 768
+TD_PEND_CAP = 896
 RCCL_UID_BYTES = 128
 KINDS = {"RESP_TIME_HASH": 0, "SEMI_LOG_HASH": 1, "SEMI_LOG_HASH_LO": 2, "DURATION_HASH": 3, "HASH_10_5000": 4, "HASH_5_250": 5,
          "HASH_1_3000": 6, "PERCENT_HASH": 7}

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void k_resp_scatter(const uint64_t *ev_kv, uin
 // multi-level windows need every window's record.  The per-batch cost of a key is then 4 bytes per value plus one 16-byte meta
 // record, instead of ~1 KB of record traffic per key and batch.
 //   t-digest rule (oracle: gyo_tdb_add_batch): a batch's values of a key are appended when buffered + new <= GYS_TD_PEND_CAP, otherwise
-//   ONE merge re-clusters the digest with (buffered + new) values.  Physically the new values are always appended first (the buffer has
+//   ONE merge re-clusters the digest with (buffered + new) values; a key is also re-clustered when buffered + new + new again would
+//   exceed GYS_TDIGEST_MERGE_FAST (= merge size class 0), so that whatever a key's rate its merges stay in the fast class.  Physically the new values are always appended first (the buffer has
 //   pcap > GYS_TD_PEND_CAP entries); a key whose buffer then holds more than GYS_TD_PEND_CAP values is queued for k_digest_merge.  A key
 //   whose batch does not fit the buffer at all ("spilled") gets its batch values as a run in `staged` instead (second pass of
 //   k_resp_host over the hosts that have such keys) and is merged from buffer + run.
@@ -377,6 +378,7 @@ __global__ void k_minmax_init(int2 *mm, uint64_t n)
 // k_key_finalize (one thread per service).
 #define GYS_MERGE_CLASS0 1024u // largest (buffered + run) value count of merge size class 0 / 1 (class 2: up to GYS_MERGE_LDS_MAX)
 #define GYS_MERGE_CLASS1 4096u
+static_assert(GYS_TDIGEST_MERGE_FAST == GYS_MERGE_CLASS0, "the early re-clustering rule keeps a key's merges inside merge size class 0");
 enum { FIN_CLASS0 = 0, FIN_CLASS1, FIN_CLASS2, FIN_HUGE, FIN_RUN_ALLOC, FIN_SLOW, FIN_NCOUNTS }; // FIN_SLOW: k_digest_bins' hand-over list
 
 struct FinP {
@@ -414,7 +416,7 @@ __device__ __forceinline__ void finalize_key(const FinP &p, bool valid, uint32_t
 			if (cur <= p.pcap) {
 				*(uint4 *)&p.td_meta[key] = make_uint4(cur, nh | (nw << 16), win_epoch, mraw.w);
 				if (WRITE_CUR) p.td_cur[key] = cur;
-				if (cur > GYS_TD_PEND_CAP) {
+				if (cur > GYS_TD_PEND_CAP || cur + m > GYS_TDIGEST_MERGE_FAST) { // (the second: another batch like this one would leave the fast merge class)
 					ent.nbuf = cur;
 					cls = cur <= GYS_MERGE_CLASS0 ? FIN_CLASS0 : cur <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_HUGE; // (> 4096: the several-workgroup path)
 				}

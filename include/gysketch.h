@@ -54,7 +54,7 @@ enum {
 
 #define GYS_MAX_BUCKETS 16 /* all reference hash classes have <= 15 buckets; records are padded to 16 slots */
 #define GYS_TD_NB 200      /* t-digest clusters per key (2 x the delta = 100 the reference hands to Postgres tdigest, common/gy_query_common.cc:1855) */
-#define GYS_TD_PEND_CAP 768 /* values a key's t-digest buffers before it is re-clustered (== GYS_TDIGEST_PEND_CAP) */
+#define GYS_TD_PEND_CAP 896 /* values a key's t-digest buffers before it is re-clustered (== GYS_TDIGEST_PEND_CAP) */
 #define GYS_HLL_P 14       /* global distinct-flow HLL precision: 16384 u8 registers */
 #define GYS_CMS_D 4
 #define GYS_CMS_W 65536

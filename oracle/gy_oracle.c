@@ -732,6 +732,13 @@ void gyo_tdb_add_batch(gyo_td_buffered *b, const int32_t *vals, size_t m)
 			if (vals[i] > b->d.vmax) b->d.vmax = vals[i];
 		}
 		b->npend += (uint32_t)m;
+		/* one more batch like this one would take the buffer past the size the engine re-clusters fastest: re-cluster now (the
+		 * per-key rate decides how full a buffer gets; without this rule a key with 200 - 500 values per batch would always merge
+		 * just above that size) */
+		if ((size_t)b->npend + m > GYS_TDIGEST_MERGE_FAST) {
+			gyo_td_merge_values(&b->d, b->pend, b->npend);
+			b->npend = 0;
+		}
 	} else {
 		int32_t *all = (int32_t *)malloc(((size_t)b->npend + m) * sizeof(int32_t));
 		memcpy(all, b->pend, (size_t)b->npend * sizeof(int32_t));

@@ -146,9 +146,10 @@ void gyo_td_merge_digest(gyo_tdigest *d, const gyo_tdigest *o);
 double gyo_td_quantile(const gyo_tdigest *d, double q);
 
 /* Buffered form the engine keeps per service (the classic merging-digest buffer): up to GYO_TD_PEND_CAP values wait unmerged;
- * a batch that would overflow the buffer re-clusters the digest with (buffered + new) values in ONE merge.  The result depends
+ * a batch that would overflow the buffer re-clusters the digest with (buffered + new) values in ONE merge, and so does a batch
+ * after which ANOTHER batch of the same size would take the buffer past GYS_TDIGEST_MERGE_FAST values.  The result depends
  * only on the sequence of batch multisets, not on the order of values inside a batch.  vmin / vmax always cover buffered values. */
-#define GYO_TD_PEND_CAP 768
+#define GYO_TD_PEND_CAP 896
 typedef struct {
 	gyo_tdigest d;
 	uint32_t npend;

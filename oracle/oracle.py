@@ -61,7 +61,7 @@ class TDigest(C.Structure):
     _fields_ = [("sum", C.c_int64 * TD_NB), ("cnt", C.c_uint32 * TD_NB), ("vmin", C.c_int32), ("vmax", C.c_int32)]
 
 
-TD_PEND_CAP = 768
+TD_PEND_CAP = 896
 
 
 class TDBuffered(C.Structure):

@@ -168,17 +168,33 @@ def test_tdigest_buffered_form(oracle):
     b = oracle.TDBuffered()
     L.gyo_tdb_init(C.byref(b))
     cap = oracle.TD_PEND_CAP
-    c = np.ascontiguousarray(x[:cap - 56])
-    L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c, oracle.i32p), cap - 56)
-    assert b.npend == cap - 56 and L.gyo_td_total(C.byref(b.d)) == 0
-    c2 = np.ascontiguousarray(x[cap - 56:cap + 4])
-    L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c2, oracle.i32p), 60)  # cap + 4 > cap: one merge of all cap + 4 values
+    n1 = cap - 396
+    c = np.ascontiguousarray(x[:n1])
+    L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c, oracle.i32p), n1)
+    assert b.npend == n1 and L.gyo_td_total(C.byref(b.d)) == 0
+    c2 = np.ascontiguousarray(x[n1:cap + 4])
+    L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c2, oracle.i32p), 400)  # cap + 4 > cap: one merge of all cap + 4 values
     assert b.npend == 0 and L.gyo_td_total(C.byref(b.d)) == cap + 4
     d = oracle.TDigest()
     L.gyo_td_init(C.byref(d))
     allv = np.ascontiguousarray(x[:cap + 4][::-1])
     L.gyo_td_merge_values(C.byref(d), oracle.ptr(allv, oracle.i32p), cap + 4)
     assert list(d.cnt) == list(b.d.cnt) and list(d.sum) == list(b.d.sum)
+    # the early rule: a key is re-clustered as soon as ANOTHER batch like the last one would take its buffer past MERGE_FAST (1024)
+    # values, so a key's merges stay at or below that size whatever its rate (up to 1024 values per batch)
+    for m in (100, 215, 300, 430, 500, 512, 513, 600, 896, 897, 1024):
+        b = oracle.TDBuffered()
+        L.gyo_tdb_init(C.byref(b))
+        merged_before, sizes = 0, []
+        for i in range(0, 12 * m, m):
+            c = np.ascontiguousarray(x[i:i + m])
+            L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(c, oracle.i32p), m)
+            tot = L.gyo_td_total(C.byref(b.d))
+            if tot != merged_before:
+                sizes.append(tot - merged_before)
+                merged_before = tot
+        assert sizes and max(sizes) <= 1024, (m, sizes)
+        assert b.npend + m <= 1024 or b.npend == 0
 
 
 @pytest.mark.parametrize("nkeys,nvals,dist", [(10000, 12000, 0), (1500, 120000, 0), (4000, 12000, 1), (4000, 20000, 2), (10000, 3000, 3)],
