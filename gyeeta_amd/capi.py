@@ -100,7 +100,8 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("resp_events", "resp_dropped_range", "resp_dropped_nolistener", "conn_events",
                                           "conn_unknown_service", "lstate_records", "lstate_missed", "lstate_errors", "lstate_deleted",
                                           "resp_batches_host_local", "resp_batches_general", "window_graph_launches", "resp_batches_host_split",
-                                          "td_merges", "td_merge_values", "actconn_records", "actconn_remote_listen", "actconn_unknown_listener")]
+                                          "td_merges", "td_merge_values", "actconn_records", "actconn_remote_listen", "actconn_unknown_listener",
+                                          "stage_waits", "resp_calls_queued", "resp_submissions")]
 
 
 assert C.sizeof(HistRec) == 256 and C.sizeof(TopnEntry) == 104 and C.sizeof(RespSeg) == 16 and C.sizeof(ListenerDayStats) == 48

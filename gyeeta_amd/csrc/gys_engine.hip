@@ -6,11 +6,13 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <condition_variable>
@@ -95,11 +97,14 @@ struct HostListeners {
 
 struct ArenaLayout {
 	uint64_t off_hll8, off_u32, n_u32, off_i64sum, n_i64sum, off_i64max, n_i64max, total;
-	uint64_t u32_cms, u32_cluster, u32_pair; // element offsets inside the u32 section
-	uint64_t i64_cms, i64_ghist, i64_pair;   // element offsets inside the i64 SUM section
+	uint64_t u32_cms, u32_cluster, u32_pair, u32_misc, u32_cpair; // element offsets inside the u32 section
+	uint64_t i64_cms, i64_ghist, i64_pair, i64_cpair;             // element offsets inside the i64 SUM section
 };
 
-ArenaLayout arena_layout(uint32_t max_clusters)
+// u32_pair / i64_pair: Count-Min pair of the ACTIVE_CONN_STATS roll-up; u32_misc[0]: its local-listener rows of the window;
+// u32_cpair / i64_cpair: the TCP_CONN_NOTIFY pair roll-up, present only with gys_config.conn_pair_cms (its own tables: the two feeds
+// count different things -- a gauge of active connections vs. one per connection notification -- and must not share cells)
+ArenaLayout arena_layout(uint32_t max_clusters, bool conn_pair)
 {
 	ArenaLayout a;
 	a.off_hll8 = 0;
@@ -107,12 +112,15 @@ ArenaLayout arena_layout(uint32_t max_clusters)
 	a.u32_cms = 0;
 	a.u32_cluster = (uint64_t)GYS_CMS_D * GYS_CMS_W;
 	a.u32_pair = a.u32_cluster + align_up((uint64_t)max_clusters * 12, 64); // Count-Min pair of the (listener, client task) roll-up
-	a.n_u32 = a.u32_pair + (uint64_t)GYS_CMS_D * GYS_CMS_W;
+	a.u32_misc = a.u32_pair + (uint64_t)GYS_CMS_D * GYS_CMS_W;
+	a.u32_cpair = a.u32_misc + 64;
+	a.n_u32 = a.u32_cpair + (conn_pair ? (uint64_t)GYS_CMS_D * GYS_CMS_W : 0);
 	a.off_i64sum = align_up(a.off_u32 + a.n_u32 * 4, 256);
 	a.i64_cms = 0;
 	a.i64_ghist = (uint64_t)GYS_CMS_D * GYS_CMS_W;
 	a.i64_pair = a.i64_ghist + 32;
-	a.n_i64sum = a.i64_pair + (uint64_t)GYS_CMS_D * GYS_CMS_W;
+	a.i64_cpair = a.i64_pair + (uint64_t)GYS_CMS_D * GYS_CMS_W;
+	a.n_i64sum = a.i64_cpair + (conn_pair ? (uint64_t)GYS_CMS_D * GYS_CMS_W : 0);
 	a.off_i64max = align_up(a.off_i64sum + a.n_i64sum * 8, 256);
 	a.n_i64max = 8;
 	a.total = align_up(a.off_i64max + a.n_i64max * 8, 256);
@@ -223,6 +231,8 @@ struct gys_ctx {
 	bool own_arena = false;
 	ArenaLayout al{};
 	uint8_t *last = nullptr; // copy of the reduced arena of the last finished window (queries read this)
+	uint32_t *last_act32 = nullptr;           // ACTIVE_CONN_STATS Count-Min pair of the last window that carried such rows
+	unsigned long long *last_act64 = nullptr; // (a partha reports every 15 s, a window is 5 s)
 	uint32_t epoch = 1;      // current window number (0 = never)
 	bool prepared = false;
 	uint32_t *d_epoch = nullptr; // device copy of `epoch` for the captured window graph
@@ -250,9 +260,39 @@ struct gys_ctx {
 	};
 	static constexpr int NSTAGE = 16;
 	Stage stage[NSTAGE];
-	std::vector<int> stage_free;
+	std::deque<int> stage_free; // handed out OLDEST FIRST (pop_front / push_back): a slot's event has normally fired long before the slot comes round again
 	std::mutex stage_mu, enq_mu;
 	std::condition_variable stage_cv;
+	std::atomic<uint64_t> stage_waits{0}; // times a host-pointer call found its ring slot still in flight and waited for the GPU
+	// Submission queue of gys_ingest_resp_events ("group commit", SURVEY 8b second option): the calls of all L2 threads are concatenated
+	// into ONE pinned batch -- a segment per call -- and handed to run_resp_batch together, so that the ~12 launches of a response batch
+	// are paid once per submission instead of once per 65536-event call.  A caller reserves its place under rq.mu, copies outside any
+	// lock, and whoever finds no submission in flight submits what has accumulated (a lone caller submits its own call at once: no added
+	// latency; under load the calls that arrive during one submission form the next).  A host appears at most once per batch (its keys
+	// see their per-call value multisets in call order: the digests stay bit-identical to per-call ingestion); batches are submitted in
+	// the order they were sealed.
+	struct RespBatch {
+		uint8_t *h = nullptr, *d = nullptr;
+		uint64_t cap_events = 0, fill = 0;
+		hipEvent_t done = nullptr;
+		std::vector<gys_resp_seg> segs;
+		uint32_t writers = 0;
+		bool sealed = false;
+	};
+	struct RespQ {
+		static constexpr int NB = 4;
+		std::mutex mu;
+		std::condition_variable cv;
+		RespBatch b[NB];
+		std::deque<int> free, sealed; // sealed: awaiting submission, oldest first
+		int open = -1;
+		bool submitting = false;
+		int async_rc = 0;             // first error of a submission made on behalf of other callers; surfaces at the next call
+		std::string async_err;
+		uint64_t calls = 0, submissions = 0;
+		std::vector<uint32_t> host_stamp; // host -> stamp of the open batch it is in
+		uint32_t stamp = 0;
+	} rq;
 	uint8_t *dev_staging = nullptr;
 	uint64_t dev_staging_bytes = 0;
 	uint32_t *dev_offsets = nullptr;
@@ -350,12 +390,16 @@ int stage_acquire(gys_ctx *c, uint64_t bytes, int *idx)
 	{
 		std::unique_lock<std::mutex> lk(c->stage_mu);
 		c->stage_cv.wait(lk, [&] { return !c->stage_free.empty(); });
-		i = c->stage_free.back();
-		c->stage_free.pop_back();
+		i = c->stage_free.front();
+		c->stage_free.pop_front();
 	}
 	gys_ctx::Stage &st = c->stage[i];
-	hipError_t e = hipSuccess;
-	if (!st.done) e = hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
+	// the calling (L2) thread's current device is whatever it used last -- 0 for a fresh thread: the slot's buffers, the copy and the
+	// kernels must live on the context's device
+	hipError_t e = hipSetDevice(c->device);
+	if (e == hipSuccess && !st.done) e = hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
+	if (e == hipSuccess && hipEventQuery(st.done) == hipErrorNotReady) c->stage_waits++;
+	(void)hipGetLastError();
 	if (e == hipSuccess) e = hipEventSynchronize(st.done); // the kernels that read this slot last time are done (no-op unless the ring wrapped)
 	if (e == hipSuccess && bytes > st.cap) {
 		if (st.h) (void)hipHostFree(st.h);
@@ -1043,14 +1087,21 @@ int walk_batch(const uint8_t *batch, uint32_t n, const uint8_t *pend, uint32_t f
 {
 	const uint8_t *p = batch;
 	offs.clear();
+	if (!pend || pend < batch) {
+		set_err("batch without an end pointer");
+		return GYS_ERR_INVAL;
+	}
 	offs.reserve(n);
-	for (uint32_t i = 0; i < n && p < pend; ++i) { // the reference's loop shape (gy_mconnhdlr.cc:9130, :11175)
+	// the L1 validators' rule (TCP_CONN_NOTIFY::validate / LISTENER_STATE_NOTIFY::validate, common/gy_comm_proto.cc:859-880, :974-995):
+	// every one of the n announced records lies complete before pend and has a size that is a multiple of 8; the L2 loop
+	// `i < n && p < pend` (gy_mconnhdlr.cc:9130, :11175) only ever sees messages that passed it
+	for (uint32_t i = 0; i < n; ++i) {
 		if ((size_t)(pend - p) < fixed) {
-			set_err("truncated record %u", i);
+			set_err("batch ends before record %u of %u", i, n);
 			return GYS_ERR_INVAL;
 		}
 		const uint32_t sz = elem_size(p);
-		if ((sz & 7u) || p + sz > pend) {
+		if ((sz & 7u) || (size_t)(pend - p) < sz) {
 			set_err("record %u: bad element size %u", i, sz);
 			return GYS_ERR_INVAL;
 		}
@@ -1073,8 +1124,8 @@ int run_conn(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, uint
 	p.cms64 = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_cms;
 	p.svc_win = c->svc_win;
 	if (c->cfg.conn_pair_cms) {
-		p.pair32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_pair;
-		p.pair64 = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_pair;
+		p.pair32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cpair;
+		p.pair64 = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_cpair;
 	}
 	c->conn_dirty = true;
 	p.counters = c->counters;
@@ -1106,6 +1157,7 @@ int run_actconn(gys_ctx *c, const uint8_t *d_batch, uint32_t n)
 	p.pair64 = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_pair;
 	p.svc_act = c->svc_act;
 	p.counters = c->counters;
+	p.win_rows = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_misc;
 	ProfScope ps(c, "actconn");
 	hipLaunchKernelGGL(k_actconn_ingest, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
@@ -1177,9 +1229,181 @@ int ingest_staged_records(gys_ctx *c, uint32_t host, const void *batch, uint64_t
 	return rc;
 }
 
+
+// ---- submission queue of the host-pointer response path (gys_ctx::RespQ)
+constexpr uint64_t GYS_RQ_EVENTS = 1u << 21; // events per combined batch (48 MiB pinned + 48 MiB device each)
+
+// submits batch bi (sealed, no writers); rq.mu NOT held
+int rq_submit_one(gys_ctx *c, int bi)
+{
+	gys_ctx::RespBatch &b = c->rq.b[bi];
+	int rc = GYS_OK;
+	{
+		std::lock_guard<std::mutex> g(c->enq_mu);
+		hipError_t e = hipMemcpyAsync(b.d, b.h, b.fill * 24, hipMemcpyHostToDevice, c->stream);
+		if (e == hipSuccess) {
+			rc = run_resp_batch(c, b.segs.data(), (uint32_t)b.segs.size(), b.d, b.fill);
+			e = hipEventRecord(b.done, c->stream);
+		}
+		if (e != hipSuccess) {
+			set_err("response submission: %s", hipGetErrorString(e));
+			rc = GYS_ERR_HIP;
+		}
+	}
+	return rc;
+}
+
+// With rq.mu held (lk): submit, oldest first, every sealed batch whose writers are done -- and the open batch too when `all` or when it
+// has data, no writer and nothing else is in flight.  Returns the first error of a batch that carried the caller's own data (`mine`),
+// other errors are parked in rq.async_rc.
+int rq_drain(gys_ctx *c, std::unique_lock<std::mutex> &lk, int mine, bool all)
+{
+	gys_ctx::RespQ &q = c->rq;
+	int my_rc = GYS_OK;
+	if (q.submitting) {
+		if (!all) return GYS_OK; // the thread inside the submission picks up what accumulates
+		q.cv.wait(lk, [&] { return !q.submitting; });
+	}
+	for (;;) {
+		if (q.sealed.empty() && q.open >= 0 && q.b[q.open].fill && q.b[q.open].writers == 0) {
+			q.b[q.open].sealed = true;
+			q.sealed.push_back(q.open);
+			q.open = -1;
+		}
+		if (q.sealed.empty()) break;
+		const int bi = q.sealed.front();
+		if (q.b[bi].writers) {
+			if (!all) break; // its last writer drains
+			q.cv.wait(lk, [&] { return q.b[bi].writers == 0; });
+		}
+		q.sealed.pop_front();
+		q.submitting = true;
+		lk.unlock();
+		const int rc = rq_submit_one(c, bi);
+		lk.lock();
+		q.submitting = false;
+		q.submissions++;
+		q.b[bi].sealed = false;
+		q.b[bi].fill = 0;
+		q.b[bi].segs.clear();
+		q.free.push_back(bi);
+		q.cv.notify_all();
+		if (rc) {
+			if (bi == mine) my_rc = rc;
+			else if (!q.async_rc) {
+				q.async_rc = rc;
+				q.async_err = g_err;
+			}
+		}
+	}
+	return my_rc;
+}
+
+// everything the queue holds is on the stream when this returns (entry points other than the concurrent ingest calls start with it)
+int rq_flush(gys_ctx *c)
+{
+	gys_ctx::RespQ &q = c->rq;
+	std::unique_lock<std::mutex> lk(q.mu);
+	int rc = GYS_OK;
+	if (q.open >= 0 || !q.sealed.empty() || q.submitting) rc = rq_drain(c, lk, -1, true);
+	if (!rc && q.async_rc) {
+		rc = q.async_rc;
+		set_err("%s", q.async_err.c_str());
+		q.async_rc = 0;
+	}
+	return rc;
+}
+
+int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
+{
+	gys_ctx::RespQ &q = c->rq;
+	std::unique_lock<std::mutex> lk(q.mu);
+	if (q.async_rc) { // an earlier submission made for other callers failed: report it once
+		const int rc = q.async_rc;
+		set_err("%s", q.async_err.c_str());
+		q.async_rc = 0;
+		return rc;
+	}
+	q.calls++;
+	if (q.host_stamp.size() < c->hosts.size()) q.host_stamp.resize(c->hosts.size(), 0);
+	int bi;
+	for (;;) {
+		if (q.open < 0) {
+			q.cv.wait(lk, [&] { return !q.free.empty(); });
+			bi = q.free.front();
+			q.free.pop_front();
+			gys_ctx::RespBatch &nb = q.b[bi];
+			lk.unlock(); // (allocation / waiting for the batch's previous kernels: outside the lock; the batch is not visible yet)
+			hipError_t e = hipSuccess;
+			if (!nb.h) {
+				nb.cap_events = std::min<uint64_t>(GYS_RQ_EVENTS, std::max<uint64_t>(c->cfg.max_batch_events, 1));
+				e = hipHostMalloc((void **)&nb.h, nb.cap_events * 24, hipHostMallocDefault);
+				if (e == hipSuccess) e = hipMalloc((void **)&nb.d, nb.cap_events * 24);
+				if (e == hipSuccess) e = hipEventCreateWithFlags(&nb.done, hipEventDisableTiming);
+			}
+			if (e == hipSuccess) e = hipEventSynchronize(nb.done);
+			lk.lock();
+			if (e != hipSuccess) {
+				q.free.push_back(bi);
+				q.cv.notify_all();
+				set_err("response batch buffers: %s", hipGetErrorString(e));
+				return GYS_ERR_HIP;
+			}
+			if (q.open >= 0) { // another caller opened one meanwhile
+				q.free.push_front(bi);
+				q.cv.notify_all();
+				continue;
+			}
+			q.open = bi;
+			++q.stamp;
+		}
+		bi = q.open;
+		gys_ctx::RespBatch &b = q.b[bi];
+		if (b.fill + n <= b.cap_events && q.host_stamp[host] != q.stamp) break;
+		// no room, or the host already has a segment in this batch: seal it (submitted before anything opened later)
+		b.sealed = true;
+		q.sealed.push_back(bi);
+		q.open = -1;
+		const int rc = rq_drain(c, lk, -1, false);
+		if (rc) return rc;
+	}
+	gys_ctx::RespBatch &b = q.b[bi];
+	const uint64_t off = b.fill;
+	b.fill += n;
+	b.segs.push_back(gys_resp_seg{host, 0, off});
+	b.writers++;
+	q.host_stamp[host] = q.stamp;
+	lk.unlock();
+	memcpy(b.h + off * 24, ev24, (uint64_t)n * 24); // the caller's buffer is free from here on
+	lk.lock();
+	b.writers--;
+	if (b.writers == 0) q.cv.notify_all();
+	return rq_drain(c, lk, bi, false);
+}
+
 } // namespace
 
 // ==================================================================================================== C ABI
+// Every entry point makes the context's device the calling thread's current device first: the reference's L2 threads (and a process that
+// holds one context per GPU) call in with whatever device they used last, and allocations / launches follow the CURRENT device.
+#define GYS_ENTER_NOFLUSH(c)                                                   \
+	do {                                                                   \
+		if ((c) && hipSetDevice((c)->device) != hipSuccess) {          \
+			set_err("hipSetDevice(%d) failed", (c)->device);      \
+			return GYS_ERR_HIP;                                    \
+		}                                                              \
+	} while (0)
+// ... and, except for the host-pointer ingest calls that may run concurrently, puts whatever the response submission queue still holds
+// on the stream first (stream order = call order for everything that reads or closes state)
+#define GYS_ENTER(c)                                                           \
+	do {                                                                   \
+		GYS_ENTER_NOFLUSH(c);                                          \
+		if (c) {                                                       \
+			const int rcq_ = rq_flush(c);                          \
+			if (rcq_) return rcq_;                                 \
+		}                                                              \
+	} while (0)
+
 extern "C" {
 
 uint32_t gys_abi_version(void) { return GYS_ABI_VERSION; }
@@ -1188,7 +1412,7 @@ const char *gys_last_error(void) { return g_err; }
 uint32_t gys_machine_id_hash(const uint8_t machine_id[16]) { return (uint32_t)MachIdHash()(to_machid(machine_id)); }
 uint32_t gys_shard_of(const uint8_t machine_id[16], uint32_t nshards) { return nshards ? gys_machine_id_hash(machine_id) % nshards : 0; }
 
-uint64_t gys_reduce_arena_bytes(const gys_config *cfg) { return arena_layout(cfg ? cfg->max_clusters : 1).total; }
+uint64_t gys_reduce_arena_bytes(const gys_config *cfg) { return arena_layout(cfg ? cfg->max_clusters : 1, cfg && cfg->conn_pair_cms).total; }
 
 int gys_create(const gys_config *cfg, gys_ctx **out)
 {
@@ -1210,6 +1434,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	}
 	gys_ctx *c = new gys_ctx();
 	for (int i = 0; i < gys_ctx::NSTAGE; ++i) c->stage_free.push_back(i);
+	for (int i = 0; i < gys_ctx::RespQ::NB; ++i) c->rq.free.push_back(i);
 	c->cfg = *cfg;
 	if (cfg->device >= 0) {
 		c->device = cfg->device;
@@ -1339,6 +1564,8 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		HIPCHK(hipFuncSetAttribute((const void *)k_huge_count, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_HB_BINS * 4));
 		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4));
 	}
+	ALLOC(c->last_act32, (uint64_t)GYS_CMS_D * GYS_CMS_W);
+	ALLOC(c->last_act64, (uint64_t)GYS_CMS_D * GYS_CMS_W);
 #undef ALLOC
 	// dev_alloc zeroes with hipMemset on the NULL stream, which may still be in flight; the context stream is non-blocking, so the
 	// initialisation kernels / copies below must not start before every one of those clears has landed
@@ -1357,7 +1584,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->qps_hist, (uint64_t)0, S, (int64_t)INT32_MIN);
 		hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->act_hist, (uint64_t)0, S, (int64_t)INT32_MIN);
 	}
-	c->al = arena_layout(cfg->max_clusters);
+	c->al = arena_layout(cfg->max_clusters, cfg->conn_pair_cms != 0);
 	if (cfg->reduce_arena) {
 		if (cfg->reduce_arena_bytes < c->al.total) {
 			set_err("reduce_arena too small: %llu < %llu", (unsigned long long)cfg->reduce_arena_bytes, (unsigned long long)c->al.total);
@@ -1382,6 +1609,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 
 void gys_destroy(gys_ctx *c)
 {
+	if (c) (void)hipSetDevice(c->device);
 	if (!c) return;
 	if (c->stream) hipStreamSynchronize(c->stream);
 	if (c->win_graph_exec) hipGraphExecDestroy(c->win_graph_exec);
@@ -1397,6 +1625,11 @@ void gys_destroy(gys_ctx *c)
 		if (sl.xdev) hipFree(sl.xdev);
 		if (sl.done) hipEventDestroy(sl.done);
 	}
+	for (auto &b : c->rq.b) {
+		if (b.h) hipHostFree(b.h);
+		if (b.d) hipFree(b.d);
+		if (b.done) hipEventDestroy(b.done);
+	}
 	for (auto &st : c->stage) {
 		if (st.h) hipHostFree(st.h);
 		if (st.d) hipFree(st.d);
@@ -1407,7 +1640,7 @@ void gys_destroy(gys_ctx *c)
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
-			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
+			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_first, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -1417,6 +1650,7 @@ void gys_destroy(gys_ctx *c)
 
 int gys_sync(gys_ctx *c)
 {
+	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
@@ -1425,6 +1659,7 @@ int gys_sync(gys_ctx *c)
 // ------------------------------------------------------------------------------------------------ registration
 int gys_register_cluster(gys_ctx *c, const char *cluster_name, uint32_t *cluster_idx)
 {
+	GYS_ENTER(c);
 	if (!c || !cluster_name) return GYS_ERR_INVAL;
 	auto it = c->cluster_map.find(cluster_name);
 	if (it == c->cluster_map.end()) {
@@ -1442,6 +1677,7 @@ int gys_register_cluster(gys_ctx *c, const char *cluster_name, uint32_t *cluster
 
 int gys_register_host(gys_ctx *c, const uint8_t machine_id[16], const char *cluster_name, uint32_t *host_slot)
 {
+	GYS_ENTER(c);
 	if (!c || !machine_id) return GYS_ERR_INVAL;
 	int rc = check_owner(c, machine_id);
 	if (rc) return rc;
@@ -1478,6 +1714,7 @@ int gys_register_host(gys_ctx *c, const uint8_t machine_id[16], const char *clus
 
 int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_listener_info *arr_in, uint32_t n_in, uint32_t *first_slot)
 {
+	GYS_ENTER(c);
 	if (!c || !machine_id || (!arr_in && n_in)) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
@@ -1552,17 +1789,25 @@ int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_l
 // ------------------------------------------------------------------------------------------------ ingest
 int gys_ingest_resp_events_dev(gys_ctx *c, const gys_resp_seg *segs, uint32_t nsegs, const void *d_ev24, uint64_t nevents)
 {
+	GYS_ENTER(c);
 	if (!c || (!d_ev24 && nevents)) return GYS_ERR_INVAL;
 	return run_resp_batch(c, segs, nsegs, d_ev24, nevents);
 }
 
 int gys_ingest_resp_events(gys_ctx *c, const uint8_t machine_id[16], const void *ev24, uint32_t nevents)
 {
+	GYS_ENTER_NOFLUSH(c);
 	if (!c || !machine_id || (!ev24 && nevents)) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
 	if (rc) return rc;
 	if (!nevents) return GYS_OK;
+	static const bool no_queue = getenv("GYS_NO_RESP_QUEUE") != nullptr; // A/B: one submission per call through the staging ring
+	if (!no_queue && (uint64_t)nevents <= std::min<uint64_t>(GYS_RQ_EVENTS, c->cfg.max_batch_events))
+		return rq_ingest(c, host, ev24, nevents); // combined with the other callers' pending calls (gys_ctx::RespQ)
+	// larger than a combined batch: its own submission (after whatever the queue holds: same-host calls keep their order)
+	rc = rq_flush(c);
+	if (rc) return rc;
 	const uint64_t bytes = (uint64_t)nevents * 24;
 	int si;
 	rc = stage_acquire(c, bytes, &si);
@@ -1588,12 +1833,14 @@ int gys_ingest_resp_events(gys_ctx *c, const uint8_t machine_id[16], const void 
 
 int gys_ingest_tcp_conn_dev(gys_ctx *c, const void *d_batch, const uint32_t *d_offsets, uint32_t nconns)
 {
+	GYS_ENTER(c);
 	if (!c || ((!d_batch || !d_offsets) && nconns)) return GYS_ERR_INVAL;
 	return run_conn(c, (const uint8_t *)d_batch, d_offsets, nconns);
 }
 
 int gys_ingest_tcp_conn(gys_ctx *c, const uint8_t machine_id[16], const void *batch, uint32_t nconns, const void *pend)
 {
+	GYS_ENTER_NOFLUSH(c);
 	if (!c || !machine_id || (!batch && nconns) || ((uintptr_t)batch & 7u)) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
@@ -1613,18 +1860,21 @@ int gys_ingest_tcp_conn(gys_ctx *c, const uint8_t machine_id[16], const void *ba
 
 int gys_ingest_listener_state_dev(gys_ctx *c, const void *d_batch, const uint32_t *d_offsets, const uint32_t *d_host_slot, uint32_t nrecs)
 {
+	GYS_ENTER(c);
 	if (!c || ((!d_batch || !d_offsets || !d_host_slot) && nrecs)) return GYS_ERR_INVAL;
 	return run_lstate(c, (const uint8_t *)d_batch, d_offsets, d_host_slot, 0, nrecs);
 }
 
 int gys_ingest_active_conns_dev(gys_ctx *c, const void *d_batch, uint32_t nitems)
 {
+	GYS_ENTER(c);
 	if (!c || (!d_batch && nitems)) return GYS_ERR_INVAL;
 	return run_actconn(c, (const uint8_t *)d_batch, nitems);
 }
 
 int gys_ingest_active_conns(gys_ctx *c, const uint8_t machine_id[16], const void *batch, uint32_t nitems, const void *pend)
 {
+	GYS_ENTER_NOFLUSH(c);
 	if (!c || !machine_id || (!batch && nitems) || ((uintptr_t)batch & 7u)) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
@@ -1657,6 +1907,7 @@ int gys_ingest_active_conns(gys_ctx *c, const uint8_t machine_id[16], const void
 
 int gys_ingest_listener_state(gys_ctx *c, const uint8_t machine_id[16], const void *batch, uint32_t nrecs, const void *pend)
 {
+	GYS_ENTER_NOFLUSH(c);
 	if (!c || !machine_id || (!batch && nrecs) || ((uintptr_t)batch & 7u)) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
@@ -1759,6 +2010,7 @@ int wire_decode(gys_ctx *c, const uint8_t *d_buf, uint64_t nbytes, std::vector<W
 
 int gys_ingest_comm_stream(gys_ctx *c, const uint8_t machine_id[16], const void *buf, uint64_t nbytes, gys_comm_stats *out)
 {
+	GYS_ENTER(c);
 	if (!c || !machine_id || (!buf && nbytes) || ((uintptr_t)buf & 7u)) return GYS_ERR_INVAL; // COMM_HEADER::validate: 8-byte aligned data
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
@@ -1855,6 +2107,7 @@ int gys_ingest_comm_stream(gys_ctx *c, const uint8_t machine_id[16], const void 
 
 int gys_ingest_host_state(gys_ctx *c, const uint8_t machine_id[16], const gys_host_state *st)
 {
+	GYS_ENTER(c);
 	if (!c || !machine_id || !st) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
@@ -1868,6 +2121,7 @@ int gys_ingest_host_state(gys_ctx *c, const uint8_t machine_id[16], const gys_ho
 // ------------------------------------------------------------------------------------------------ window boundary
 int gys_reduce_sections(gys_ctx *c, gys_reduce_section out[4], uint32_t *nsections)
 {
+	GYS_ENTER(c);
 	if (!c || !out || !nsections) return GYS_ERR_INVAL;
 	out[0] = {c->arena + c->al.off_hll8, (uint64_t)1 << GYS_HLL_P, 0, 0};
 	out[1] = {c->arena + c->al.off_u32, c->al.n_u32, 1, 1};
@@ -1912,6 +2166,7 @@ static int enqueue_prepare(gys_ctx *c, bool dev_epoch)
 
 int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 {
+	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	if (c->prepared) {
 		set_err("window already prepared");
@@ -1934,6 +2189,10 @@ int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 static hipError_t enqueue_finish(gys_ctx *c, hipStream_t st)
 {
 	hipError_t e;
+	// ACTIVE_CONN_STATS tables: latched only by a window that carried rows (k_act_latch)
+	hipLaunchKernelGGL(k_act_latch, dim3(64), dim3(256), 0, st, (const uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_misc,
+			   (const uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_pair,
+			   (const unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_pair, c->last_act32, c->last_act64);
 	if ((e = hipMemcpyAsync(c->last, c->arena, c->al.total, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(c->arena, 0, c->al.total, st)) != hipSuccess) return e;
 	if ((e = hipMemcpyAsync(c->arena + c->al.off_i64max, &c->i64min, 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
@@ -1954,6 +2213,7 @@ static hipError_t enqueue_finish(gys_ctx *c, hipStream_t st)
 
 int gys_window_finish(gys_ctx *c)
 {
+	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	if (!c->prepared) {
 		set_err("gys_window_finish without gys_window_prepare");
@@ -2002,6 +2262,7 @@ int gys_window_finish(gys_ctx *c)
 // close time) and more than one rank (the exchange sits between the two halves; gys_window_close_rccl).
 int gys_window_close(gys_ctx *c, uint64_t tusec)
 {
+	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	if (c->prepared) {
 		set_err("window already prepared");
@@ -2055,6 +2316,7 @@ int gys_window_close(gys_ctx *c, uint64_t tusec)
 // ------------------------------------------------------------------------------------------------ queries
 int gys_query_svcsumm(gys_ctx *c, const uint8_t machine_id[16], gys_svcsumm *out)
 {
+	GYS_ENTER(c);
 	if (!c || !machine_id || !out) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
@@ -2075,6 +2337,7 @@ int gys_query_svcsumm(gys_ctx *c, const uint8_t machine_id[16], gys_svcsumm *out
 
 int gys_query_clusterstate(gys_ctx *c, const char *cluster_name, gys_cluster_state *out)
 {
+	GYS_ENTER(c);
 	if (!c || !cluster_name || !out) return GYS_ERR_INVAL;
 	auto it = c->cluster_map.find(cluster_name);
 	if (it == c->cluster_map.end()) {
@@ -2091,6 +2354,7 @@ int gys_query_clusterstate(gys_ctx *c, const char *cluster_name, gys_cluster_sta
 
 int gys_lookup_service(gys_ctx *c, uint64_t glob_id, uint32_t *slot)
 {
+	GYS_ENTER(c);
 	if (!c || !slot) return GYS_ERR_INVAL;
 	auto it = c->gid_map_h.find(glob_id);
 	if (it == c->gid_map_h.end()) {
@@ -2104,6 +2368,7 @@ int gys_lookup_service(gys_ctx *c, uint64_t glob_id, uint32_t *slot)
 int gys_query_hist_percentiles(gys_ctx *c, uint64_t glob_id, int which, gys_hist_data *pdata, uint32_t npct, uint64_t *total_count, int64_t *max_val,
 			       float *pavg)
 {
+	GYS_ENTER(c);
 	if (!c || !pdata || which < 0 || which > 1) return GYS_ERR_INVAL;
 	uint32_t slot;
 	int rc = gys_lookup_service(c, glob_id, &slot);
@@ -2202,6 +2467,7 @@ static int td_merged_view(gys_ctx *c, uint32_t slot, int64_t *sum, uint32_t *cnt
 
 int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t nq, double *out)
 {
+	GYS_ENTER(c);
 	if (!c || !q || !out) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
 	uint32_t slot;
@@ -2253,6 +2519,7 @@ static int td_sql_centroids(gys_ctx *c, uint64_t glob_id, double *mean, int64_t 
 
 int gys_tdigest_sql_text(gys_ctx *c, uint64_t glob_id, char *buf, size_t buflen, size_t *needed)
 {
+	GYS_ENTER(c);
 	if (!c || (!buf && buflen)) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
 	double mean[GYS_TD_NB];
@@ -2276,6 +2543,7 @@ int gys_tdigest_sql_text(gys_ctx *c, uint64_t glob_id, char *buf, size_t buflen,
 
 int gys_tdigest_sql_binary(gys_ctx *c, uint64_t glob_id, void *buf, size_t buflen, size_t *needed)
 {
+	GYS_ENTER(c);
 	if (!c || (!buf && buflen)) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
 	double mean[GYS_TD_NB];
@@ -2320,6 +2588,7 @@ static double hll_estimate_host(const uint8_t *regs, int p)
 
 int gys_query_distinct_flows(gys_ctx *c, double *out)
 {
+	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
 	std::vector<uint8_t> regs((size_t)1 << GYS_HLL_P);
 	HIPCHK(hipMemcpyAsync(regs.data(), c->last + c->al.off_hll8, regs.size(), hipMemcpyDeviceToHost, c->stream));
@@ -2330,6 +2599,7 @@ int gys_query_distinct_flows(gys_ctx *c, double *out)
 
 int gys_query_cms(gys_ctx *c, uint64_t glob_id, int which, uint64_t *out)
 {
+	GYS_ENTER(c);
 	if (!c || !out || which < 0 || which > 1) return GYS_ERR_INVAL;
 	uint64_t best = ~0ull;
 	for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
@@ -2352,24 +2622,44 @@ int gys_query_cms(gys_ctx *c, uint64_t glob_id, int which, uint64_t *out)
 	return GYS_OK;
 }
 
-// Count-Min estimate for a (listener, client task group) pair in the last finished window: which 0 = active connections, 1 = bytes
+// Count-Min estimate for a (listener, client task group) pair.  which 0 / 1: active connections / bytes of the LAST ACTIVE_CONN_STATS
+// REPORT (the tables of the last window that carried such rows); which 2 / 3: connection notifications / bytes of the TCP_CONN_NOTIFY
+// roll-up in the last finished window (gys_config.conn_pair_cms).
+static int pair_tables(gys_ctx *c, int which, const void **tbl)
+{
+	if (which < 0 || which > 3) return GYS_ERR_INVAL;
+	if (which >= 2 && !c->cfg.conn_pair_cms) {
+		set_err("gys_config.conn_pair_cms is off");
+		return GYS_ERR_STATE;
+	}
+	switch (which) {
+	case 0: *tbl = c->last_act32; break;
+	case 1: *tbl = c->last_act64; break;
+	case 2: *tbl = (const uint32_t *)(c->last + c->al.off_u32) + c->al.u32_cpair; break;
+	default: *tbl = (const uint64_t *)(c->last + c->al.off_i64sum) + c->al.i64_cpair; break;
+	}
+	return GYS_OK;
+}
+
 int gys_query_pair_cms(gys_ctx *c, uint64_t listener_glob_id, uint64_t cli_aggr_task_id, int which, uint64_t *out)
 {
-	if (!c || !out || which < 0 || which > 1) return GYS_ERR_INVAL;
+	GYS_ENTER(c);
+	if (!c || !out) return GYS_ERR_INVAL;
+	const void *tbl;
+	const int rc = pair_tables(c, which, &tbl);
+	if (rc) return rc;
 	uint64_t best = ~0ull;
 	for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
 		const uint32_t col = jhash2_4w((uint32_t)listener_glob_id, (uint32_t)(listener_glob_id >> 32), (uint32_t)cli_aggr_task_id,
 					       (uint32_t)(cli_aggr_task_id >> 32), GYS_SEED + r) & (GYS_CMS_W - 1);
 		uint64_t v = 0;
-		if (which == 0) {
+		if (!(which & 1)) {
 			uint32_t v32;
-			HIPCHK(hipMemcpyAsync(&v32, (const uint32_t *)(c->last + c->al.off_u32) + c->al.u32_pair + (size_t)r * GYS_CMS_W + col, 4, hipMemcpyDeviceToHost,
-					      c->stream));
+			HIPCHK(hipMemcpyAsync(&v32, (const uint32_t *)tbl + (size_t)r * GYS_CMS_W + col, 4, hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(hipStreamSynchronize(c->stream));
 			v = v32;
 		} else {
-			HIPCHK(hipMemcpyAsync(&v, (const uint64_t *)(c->last + c->al.off_i64sum) + c->al.i64_pair + (size_t)r * GYS_CMS_W + col, 8,
-					      hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(hipMemcpyAsync(&v, (const uint64_t *)tbl + (size_t)r * GYS_CMS_W + col, 8, hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(hipStreamSynchronize(c->stream));
 		}
 		best = std::min(best, v);
@@ -2380,16 +2670,20 @@ int gys_query_pair_cms(gys_ctx *c, uint64_t listener_glob_id, uint64_t cli_aggr_
 
 int gys_export_pair_cms(gys_ctx *c, int which, void *out)
 {
-	if (!c || !out || which < 0 || which > 1) return GYS_ERR_INVAL;
+	GYS_ENTER(c);
+	if (!c || !out) return GYS_ERR_INVAL;
+	const void *tbl;
+	const int rc = pair_tables(c, which, &tbl);
+	if (rc) return rc;
 	const size_t n = (size_t)GYS_CMS_D * GYS_CMS_W;
-	if (which == 0) HIPCHK(hipMemcpyAsync(out, (const uint32_t *)(c->last + c->al.off_u32) + c->al.u32_pair, n * 4, hipMemcpyDeviceToHost, c->stream));
-	else HIPCHK(hipMemcpyAsync(out, (const int64_t *)(c->last + c->al.off_i64sum) + c->al.i64_pair, n * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(out, tbl, n * ((which & 1) ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
 }
 
 int gys_export_active_conn_counters(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint64_t *out)
 {
+	GYS_ENTER(c);
 	if (!c || !out || (uint64_t)first_slot + nslots > c->nsvc) return GYS_ERR_INVAL;
 	if (!nslots) return GYS_OK;
 	HIPCHK(hipMemcpyAsync(out, c->svc_act + (size_t)first_slot * 4, (size_t)nslots * 32, hipMemcpyDeviceToHost, c->stream));
@@ -2399,6 +2693,7 @@ int gys_export_active_conn_counters(gys_ctx *c, uint32_t first_slot, uint32_t ns
 
 int gys_query_topn(gys_ctx *c, const uint8_t machine_id[16], int kind, gys_topn_entry out[GYS_TOPN], uint32_t *nout)
 {
+	GYS_ENTER(c);
 	if (!c || !machine_id || !out || !nout || kind < 0 || kind > 3) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
@@ -2438,6 +2733,7 @@ int gys_query_topn(gys_ctx *c, const uint8_t machine_id[16], int kind, gys_topn_
 
 int gys_scan_percentiles_dev(gys_ctx *c, int which, const float *pcts, uint32_t npct, int64_t *d_out)
 {
+	GYS_ENTER(c);
 	if (!c || !pcts || !d_out || !npct || npct > 64 || which < 0 || which > 1) return GYS_ERR_INVAL;
 	if (!c->nsvc) return GYS_OK;
 	HIPCHK(hipMemcpyAsync(c->dev_pcts, pcts, (size_t)npct * 4, hipMemcpyHostToDevice, c->stream));
@@ -2456,6 +2752,7 @@ int gys_scan_percentiles_dev(gys_ctx *c, int which, const float *pcts, uint32_t 
 // ------------------------------------------------------------------------------------------------ exports
 int gys_scan_quantiles_dev(gys_ctx *c, const double *q, uint32_t nq, double *d_out)
 {
+	GYS_ENTER(c);
 	if (!c || !q || !d_out || nq == 0 || nq > 16) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
 	if (!c->nsvc) return GYS_OK;
@@ -2588,6 +2885,7 @@ static int rollup_launch(gys_ctx *c, int kind, const std::vector<uint32_t> &off,
 
 int gys_tdigest_rollup_dev(gys_ctx *c, int scope, gys_tdigest_slab *d_out)
 {
+	GYS_ENTER(c);
 	if (!c || !d_out || scope < GYS_ROLLUP_HOST || scope > GYS_ROLLUP_GLOBAL) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
 	const uint32_t nh = (uint32_t)c->hosts.size();
@@ -2630,6 +2928,7 @@ int gys_tdigest_rollup_dev(gys_ctx *c, int scope, gys_tdigest_slab *d_out)
 
 int gys_tdigest_merge_slabs_dev(gys_ctx *c, const gys_tdigest_slab *d_in, uint32_t n, gys_tdigest_slab *d_out)
 {
+	GYS_ENTER(c);
 	if (!c || !d_in || !d_out || n == 0) return GYS_ERR_INVAL;
 	std::vector<uint32_t> off{0u, n}, mem(n);
 	for (uint32_t i = 0; i < n; ++i) mem[i] = i;
@@ -2638,6 +2937,7 @@ int gys_tdigest_merge_slabs_dev(gys_ctx *c, const gys_tdigest_slab *d_in, uint32
 
 int gys_tdigest_slab_quantiles(gys_ctx *c, const gys_tdigest_slab *d_slab, const double *q, uint32_t nq, double *out)
 {
+	GYS_ENTER(c);
 	if (!c || !d_slab || !q || !out) return GYS_ERR_INVAL;
 	gys_tdigest_slab s;
 	HIPCHK(hipMemcpyAsync(&s, d_slab, sizeof(s), hipMemcpyDeviceToHost, c->stream));
@@ -2711,6 +3011,7 @@ int gys_rccl_unique_id(uint8_t uid[GYS_RCCL_UID_BYTES])
 
 int gys_rccl_comm_create(gys_ctx *c, const uint8_t uid[GYS_RCCL_UID_BYTES], int nranks, int rank, void **comm)
 {
+	GYS_ENTER(c);
 	if (!c || !uid || !comm || nranks < 1 || rank < 0 || rank >= nranks) return GYS_ERR_INVAL;
 	if ((uint32_t)nranks != std::max<uint32_t>(c->cfg.nranks, 1) || (uint32_t)rank != c->cfg.rank) {
 		set_err("communicator (%d of %d) does not match gys_config rank / nranks (%u of %u)", rank, nranks, c->cfg.rank, c->cfg.nranks);
@@ -2735,8 +3036,10 @@ int gys_rccl_comm_destroy(void *comm)
 
 int gys_window_close_rccl(gys_ctx *c, void *comm, uint64_t tusec)
 {
+	GYS_ENTER(c);
 	if (!c || !comm) return GYS_ERR_INVAL;
-	int rc = gys_window_prepare(c, tusec);
+	int rc = GYS_OK;
+	if (!c->prepared) rc = gys_window_prepare(c, tusec); // (a call that failed in the exchange below left the window prepared: the retry resumes here)
 	if (rc) return rc;
 	gys_reduce_section sec[4];
 	uint32_t nsec = 0;
@@ -2745,18 +3048,29 @@ int gys_window_close_rccl(gys_ctx *c, void *comm, uint64_t tusec)
 	{
 		ProfScope ps(c, "window_rccl");
 		NCCLCHK(ncclGroupStart());
-		for (uint32_t i = 0; i < nsec; ++i) {
+		// from here on the group is ALWAYS closed: an error between Start and End would leave every later RCCL call of this thread
+		// inside a group that never launches
+		ncclResult_t bad = ncclSuccess;
+		for (uint32_t i = 0; i < nsec && bad == ncclSuccess; ++i) {
 			const ncclDataType_t dt = sec[i].dtype == 0 ? ncclUint8 : (sec[i].dtype == 1 ? ncclUint32 : ncclInt64);
 			const ncclRedOp_t op = sec[i].op == 0 ? ncclMax : ncclSum;
-			NCCLCHK(ncclAllReduce(sec[i].dev_ptr, sec[i].dev_ptr, sec[i].nelems, dt, op, (ncclComm_t)comm, c->stream));
+			bad = ncclAllReduce(sec[i].dev_ptr, sec[i].dev_ptr, sec[i].nelems, dt, op, (ncclComm_t)comm, c->stream);
 		}
-		NCCLCHK(ncclGroupEnd());
+		const ncclResult_t end = ncclGroupEnd();
+		if (bad == ncclSuccess) bad = end;
+		if (bad != ncclSuccess) {
+			// the window stays prepared (arena not cleared, nothing finished): the caller may retry this call -- it resumes at the
+			// exchange -- or fall back to gys_reduce_sections + its own collective + gys_window_finish
+			set_err("window exchange failed: %s", ncclGetErrorString(bad));
+			return GYS_ERR_HIP;
+		}
 	}
 	return gys_window_finish(c);
 }
 
 int gys_tdigest_global_rccl(gys_ctx *c, void *comm, gys_tdigest_slab *d_out)
 {
+	GYS_ENTER(c);
 	if (!c || !comm || !d_out) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
 	int nranks = 1, rank = 0;
@@ -2788,6 +3102,7 @@ uint32_t gys_num_hosts(gys_ctx *c) { return c ? (uint32_t)c->hosts.size() : 0; }
 
 int gys_export_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
 {
+	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	if (which < 0 || which > 1) return GYS_ERR_INVAL;
 	if (!nslots) return GYS_OK;
@@ -2808,6 +3123,7 @@ int gys_export_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots,
 
 int gys_export_conn_bitmap(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint16_t *out)
 {
+	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	{
 		const int rcf = fold_range(c, first_slot, nslots);
@@ -2827,6 +3143,7 @@ int gys_export_conn_bitmap(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uin
 
 int gys_export_hll(gys_ctx *c, uint8_t *out)
 {
+	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
 	HIPCHK(hipMemcpyAsync(out, c->last + c->al.off_hll8, (size_t)1 << GYS_HLL_P, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
@@ -2835,6 +3152,7 @@ int gys_export_hll(gys_ctx *c, uint8_t *out)
 
 int gys_export_cms(gys_ctx *c, int which, void *out)
 {
+	GYS_ENTER(c);
 	if (!c || !out || which < 0 || which > 1) return GYS_ERR_INVAL;
 	const size_t n = (size_t)GYS_CMS_D * GYS_CMS_W;
 	if (which == 0)
@@ -2847,6 +3165,7 @@ int gys_export_cms(gys_ctx *c, int which, void *out)
 
 int gys_export_global_hist(gys_ctx *c, gys_hist_rec *out)
 {
+	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
 	int64_t v[32];
 	int64_t mx;
@@ -2864,6 +3183,7 @@ int gys_export_global_hist(gys_ctx *c, gys_hist_rec *out)
 
 int gys_export_tdigest(gys_ctx *c, uint32_t first_slot, uint32_t nslots, int64_t *sums, uint32_t *cnts, int32_t *minmax)
 {
+	GYS_ENTER(c);
 	void *out = sums;
 	RANGE_CHECK(first_slot, nslots);
 	if (!c->cfg.enable_tdigest || !cnts || !minmax) return GYS_ERR_INVAL;
@@ -2880,6 +3200,7 @@ int gys_export_tdigest(gys_ctx *c, uint32_t first_slot, uint32_t nslots, int64_t
 
 int gys_export_tdigest_pending(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint32_t *npend, int32_t *pend)
 {
+	GYS_ENTER(c);
 	void *out = npend;
 	RANGE_CHECK(first_slot, nslots);
 	if (!c->cfg.enable_tdigest || !pend) return GYS_ERR_INVAL;
@@ -2899,6 +3220,7 @@ int gys_export_tdigest_pending(gys_ctx *c, uint32_t first_slot, uint32_t nslots,
 
 int gys_export_svc_counters(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint64_t *out)
 {
+	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	{
 		// mid-window: the cumulative counters must include the window so far (its Count-Min share moves into the arena a little early,
@@ -2913,6 +3235,7 @@ int gys_export_svc_counters(gys_ctx *c, uint32_t first_slot, uint32_t nslots, ui
 
 int gys_export_svc_hll(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint8_t *out)
 {
+	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	if (!c->svc_hll) return GYS_ERR_STATE;
 	HIPCHK(hipMemcpyAsync(out, c->svc_hll + ((size_t)first_slot << c->cfg.svc_hll_p), (size_t)nslots << c->cfg.svc_hll_p, hipMemcpyDeviceToHost, c->stream));
@@ -2922,6 +3245,7 @@ int gys_export_svc_hll(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint8_t
 
 int gys_get_counters(gys_ctx *c, gys_counters *out)
 {
+	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
 	uint64_t v[16];
 	HIPCHK(hipMemcpyAsync(v, c->counters, sizeof(v), hipMemcpyDeviceToHost, c->stream));
@@ -2944,6 +3268,12 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 	out->actconn_records = v[CTR_ACTCONN_RECORDS];
 	out->actconn_remote_listen = v[CTR_ACTCONN_REMOTE_LISTEN];
 	out->actconn_unknown_listener = v[CTR_ACTCONN_UNKNOWN];
+	out->stage_waits = c->stage_waits.load();
+	{
+		std::lock_guard<std::mutex> g(c->rq.mu);
+		out->resp_calls_queued = c->rq.calls;
+		out->resp_submissions = c->rq.submissions;
+	}
 	return GYS_OK;
 }
 
@@ -2956,6 +3286,7 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 
 int gys_export_hist_level(gys_ctx *c, int level, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
 {
+	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	LEVELS_CHECK();
 	if (level < 0 || level >= GYS_NLEVELS) return GYS_ERR_INVAL;
@@ -2978,6 +3309,7 @@ int gys_export_hist_level(gys_ctx *c, int level, uint64_t tusec, uint32_t first_
 int gys_query_hist_level_stats(gys_ctx *c, uint64_t glob_id, int level, uint64_t tusec, gys_time_hist_val *pstats, uint32_t nstats, int64_t *tcount,
 			       int64_t *tsum, double *mean_val)
 {
+	GYS_ENTER(c);
 	if (!c || (!pstats && nstats)) return GYS_ERR_INVAL;
 	uint32_t slot;
 	int rc = gys_lookup_service(c, glob_id, &slot);
@@ -3001,6 +3333,7 @@ int gys_query_hist_level_stats(gys_ctx *c, uint64_t glob_id, int level, uint64_t
 int gys_export_hist_period(gys_ctx *c, int64_t starttime, int64_t endtime, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out,
 			   int *level_used)
 {
+	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	LEVELS_CHECK();
 	if (!nslots) return GYS_OK;
@@ -3022,6 +3355,7 @@ int gys_export_hist_period(gys_ctx *c, int64_t starttime, int64_t endtime, uint6
 int gys_query_hist_period_stats(gys_ctx *c, uint64_t glob_id, int64_t starttime, int64_t endtime, uint64_t tusec, gys_time_hist_val *pstats,
 				uint32_t nstats, int64_t *tcount, int64_t *tsum, double *mean_val)
 {
+	GYS_ENTER(c);
 	if (!c || (!pstats && nstats)) return GYS_ERR_INVAL;
 	uint32_t slot;
 	int rc = gys_lookup_service(c, glob_id, &slot);
@@ -3044,6 +3378,7 @@ int gys_query_hist_period_stats(gys_ctx *c, uint64_t glob_id, int64_t starttime,
 
 int gys_export_day_stats(gys_ctx *c, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_listener_day_stats *out)
 {
+	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	LEVELS_CHECK();
 	if (!nslots) return GYS_OK;
@@ -3075,6 +3410,7 @@ int gys_export_day_stats(gys_ctx *c, uint64_t tusec, uint32_t first_slot, uint32
 
 int gys_export_svc_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
 {
+	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	LEVELS_CHECK();
 	if (which < 0 || which > 1) return GYS_ERR_INVAL;
@@ -3088,6 +3424,7 @@ int gys_export_svc_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nsl
 // ------------------------------------------------------------------------------------------------ standalone keyed histogram op
 int gys_hist_init_dev(gys_ctx *c, int kind, gys_hist_rec *d_hist, uint32_t nkeys)
 {
+	GYS_ENTER(c);
 	if (!c || !d_hist || kind < 0 || kind >= GYS_NUM_HASH_KINDS) return GYS_ERR_INVAL;
 	HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)nkeys * sizeof(gys_hist_rec), c->stream));
 	const int64_t mn = hash_def(kind).t_bits == 64 ? INT64_MIN : (int64_t)INT32_MIN; // std::numeric_limits<T>::min() (:563)
@@ -3098,6 +3435,7 @@ int gys_hist_init_dev(gys_ctx *c, int kind, gys_hist_rec *d_hist, uint32_t nkeys
 
 int gys_hist_add_dev(gys_ctx *c, int kind, gys_hist_rec *d_hist, uint32_t nkeys, const uint32_t *d_keyidx, const int32_t *d_vals, uint64_t n)
 {
+	GYS_ENTER(c);
 	if (!c || !d_hist || kind < 0 || kind >= GYS_NUM_HASH_KINDS || ((!d_keyidx || !d_vals) && n)) return GYS_ERR_INVAL;
 	if (!n) return GYS_OK;
 	ProfScope ps(c, "hist_add");
@@ -3108,6 +3446,7 @@ int gys_hist_add_dev(gys_ctx *c, int kind, gys_hist_rec *d_hist, uint32_t nkeys,
 
 int gys_hist_merge_dev(gys_ctx *c, gys_hist_rec *d_dst, const gys_hist_rec *d_src, uint32_t nkeys)
 {
+	GYS_ENTER(c);
 	if (!c || !d_dst || !d_src) return GYS_ERR_INVAL;
 	if (!nkeys) return GYS_OK;
 	ProfScope ps(c, "hist_merge");
@@ -3119,6 +3458,7 @@ int gys_hist_merge_dev(gys_ctx *c, gys_hist_rec *d_dst, const gys_hist_rec *d_sr
 
 int gys_hist_percentiles_dev(gys_ctx *c, int kind, const gys_hist_rec *d_hist, uint32_t nkeys, const float *pcts, uint32_t npct, int64_t *d_out)
 {
+	GYS_ENTER(c);
 	if (!c || !d_hist || !pcts || !d_out || !npct || npct > 64 || kind < 0 || kind >= GYS_NUM_HASH_KINDS) return GYS_ERR_INVAL;
 	if (!nkeys) return GYS_OK;
 	HIPCHK(hipMemcpyAsync(c->dev_pcts, pcts, (size_t)npct * 4, hipMemcpyHostToDevice, c->stream));
@@ -3133,6 +3473,7 @@ int gys_hist_percentiles_dev(gys_ctx *c, int kind, const gys_hist_rec *d_hist, u
 // ------------------------------------------------------------------------------------------------ profiling
 int gys_profile_enable(gys_ctx *c, int on)
 {
+	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	c->profile = on != 0;
 	return GYS_OK;
@@ -3140,6 +3481,7 @@ int gys_profile_enable(gys_ctx *c, int on)
 
 int gys_profile_reset(gys_ctx *c)
 {
+	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	prof_resolve(c);
@@ -3149,6 +3491,7 @@ int gys_profile_reset(gys_ctx *c)
 
 int gys_profile_get(gys_ctx *c, const char *kernel, double *total_ms, uint64_t *launches)
 {
+	GYS_ENTER(c);
 	if (!c || !kernel) return GYS_ERR_INVAL;
 	prof_resolve(c);
 	auto it = c->prof.find(kernel);
@@ -3164,6 +3507,7 @@ int gys_profile_get(gys_ctx *c, const char *kernel, double *total_ms, uint64_t *
 
 int gys_profile_names(gys_ctx *c, char *buf, size_t buflen)
 {
+	GYS_ENTER(c);
 	if (!c || !buf || !buflen) return GYS_ERR_INVAL;
 	std::string s;
 	for (auto &kv : c->prof) {
@@ -3177,6 +3521,7 @@ int gys_profile_names(gys_ctx *c, char *buf, size_t buflen)
 // ------------------------------------------------------------------------------------------------ synthetic generator
 int gys_debug_read_events_dev(gys_ctx *c, const void *d_ev24, uint64_t nevents)
 {
+	GYS_ENTER(c);
 	if (!c || !d_ev24) return GYS_ERR_INVAL;
 	if (!nevents) return GYS_OK;
 	const uint64_t per_wg = 53248; // ~ a C3 host segment (13 tiles of 4096)
@@ -3189,6 +3534,7 @@ int gys_debug_read_events_dev(gys_ctx *c, const void *d_ev24, uint64_t nevents)
 int gys_gen_resp_events_dev(gys_ctx *c, void *d_ev24, uint64_t nevents, uint64_t seed, uint32_t first_host, uint32_t nhosts, uint32_t svcs_per_host,
 			    uint32_t zipf_milli, gys_resp_seg *segs_out)
 {
+	GYS_ENTER(c);
 	if (!c || !d_ev24 || !nhosts || !svcs_per_host || !segs_out) return GYS_ERR_INVAL;
 	const bool spread = zipf_milli == GYS_GEN_SPREAD; // per-service weights 0..255/256 instead of a Zipf law
 	if (spread) zipf_milli = 0;

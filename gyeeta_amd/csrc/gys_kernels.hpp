@@ -2843,6 +2843,7 @@ struct ActConnP {
 	unsigned long long *pair64;  // arena: Count-Min of bytes (sent + received) per pair
 	unsigned long long *svc_act; // [nsvc*4] cumulative per listener: rows, bytes_sent, bytes_received, active connections
 	uint64_t *counters;
+	uint32_t *win_rows;          // arena (u32 SUM section): local-listener rows of this window, all ranks after the exchange
 };
 
 __global__ __launch_bounds__(256) void k_actconn_ingest(ActConnP p)
@@ -2857,6 +2858,10 @@ __global__ __launch_bounds__(256) void k_actconn_ingest(ActConnP p)
 	}
 	const bool remote = in && ((w[12] >> 49) & 1ull); // flags byte @102 = bits 48..55 of word 12, is_remote_listen_ = bit 1
 	wave_count(&p.counters[CTR_ACTCONN_RECORDS], in && !remote);
+	{
+		const unsigned long long b = __ballot(in && !remote);
+		if (b && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)b) - 1u) atomicAdd(p.win_rows, (uint32_t)__popcll(b));
+	}
 	wave_count(&p.counters[CTR_ACTCONN_REMOTE_LISTEN], remote);
 	if (!in || remote) return;
 	const uint64_t gid = w[0], task = w[1], sent = w[9], rcvd = w[10];
@@ -2877,6 +2882,19 @@ __global__ __launch_bounds__(256) void k_actconn_ingest(ActConnP p)
 	atomicAdd(&a[1], (unsigned long long)sent);
 	atomicAdd(&a[2], (unsigned long long)rcvd);
 	atomicAdd(&a[3], (unsigned long long)act);
+}
+
+// A partha reports its ACTIVE_CONN_STATS every 15 s, a window is 5 s: the (all-rank) tables of a window that carried such rows replace
+// the latched copy the queries read; a window without rows leaves the latched copy alone ("last report" semantics of a gauge).
+__global__ __launch_bounds__(256) void k_act_latch(const uint32_t *win_rows, const uint32_t *pair32, const unsigned long long *pair64, uint32_t *last32,
+						   unsigned long long *last64)
+{
+	if (*win_rows == 0u) return;
+	const uint32_t n = GYS_CMS_D * GYS_CMS_W;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		last32[i] = pair32[i];
+		last64[i] = pair64[i];
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------- top-N of every host at once

@@ -164,7 +164,7 @@ class SketchEngine:
         return out.value
 
     def export_pair_cms(self, which=0):
-        out = np.zeros((capi.CMS_D, capi.CMS_W), dtype=np.uint32 if which == 0 else np.int64)
+        out = np.zeros((capi.CMS_D, capi.CMS_W), dtype=np.int64 if which & 1 else np.uint32)
         capi.check(self.L.gys_export_pair_cms(self.h, which, C.c_void_p(out.ctypes.data)))
         return out
 
@@ -435,7 +435,7 @@ class SketchEngine:
         return out
 
     def export_cms(self, which=0):
-        out = np.zeros((capi.CMS_D, capi.CMS_W), dtype=np.uint32 if which == 0 else np.int64)
+        out = np.zeros((capi.CMS_D, capi.CMS_W), dtype=np.int64 if which & 1 else np.uint32)
         capi.check(self.L.gys_export_cms(self.h, which, C.c_void_p(out.ctypes.data)))
         return out
 

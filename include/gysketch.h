@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GYS_ABI_VERSION 4
+#define GYS_ABI_VERSION 5
 
 enum {
 	GYS_OK = 0,
@@ -83,7 +83,7 @@ typedef struct {
 	                           /* (costs 21 hist records = 5.4 KB of HBM per service; see "multi-level windows" below) */
 	uint32_t td_buf_values;    /* entries of a service's value buffer (GYS_TD_PEND_CAP + 64 .. 16384; 0 = sized to max_services): the values
 	                              waiting for the next t-digest merge plus room for one batch's values of the service */
-	uint32_t conn_pair_cms;    /* TCP_CONN_NOTIFY records also feed the Count-Min pair keyed by (ser_glob_id_, cli_task_aggr_id_): connections
+	uint32_t conn_pair_cms;    /* TCP_CONN_NOTIFY records also feed a Count-Min pair OF THEIR OWN keyed by (ser_glob_id_, cli_task_aggr_id_): connections
 	                              (u32 table) and bytes (u64 table) per (listener, client task group) -- the roll-up MCONN_HANDLER keeps in
 	                              connlistenmap_ / connclientmap_ (server/gy_msocket.h:240-290, filled by add_tcp_conn_cli / _ser,
 	                              server/gy_mconnhdlr.cc:8643-9050).  8 more device atomics per record; off by default */
@@ -188,9 +188,9 @@ int gys_ingest_listener_state_dev(gys_ctx *ctx, const void *d_batch, const uint3
  * partha's 15-s report of (listener, client task group) rows).  The reference formats every row into an SQL insert
  * (insert_active_conns .cc:7776-7960: is_remote_listen_ == false -> activeconntbl, true -> remoteconntbl).  Here the local-listener
  * rows update (i) a Count-Min pair keyed by (listener_glob_id_, cli_aggr_task_id_): active_conns_ (u32 table) and bytes_sent_ +
- * bytes_received_ (u64 table) -- the per-(listener, client task) roll-up that stands for those rows and for connlistenmap_ /
- * connclientmap_ (server/gy_msocket.h:240-290); both tables live in the reduce arena (all-reduced with the other registers, per
- * window) -- and (ii) exact cumulative per-listener sums.  Remote-listener rows are counted (gys_counters.actconn_remote_listen). */
+ * bytes_received_ (u64 table) -- the per-(listener, client task) roll-up that stands for those rows; both tables live in the reduce
+ * arena (all-reduced with the other registers, per window; queries read the tables of the last window that carried rows, see
+ * gys_query_pair_cms) -- and (ii) exact cumulative per-listener sums.  Remote-listener rows are counted (gys_counters.actconn_remote_listen). */
 int gys_ingest_active_conns(gys_ctx *ctx, const uint8_t machine_id[16], const void *batch, uint32_t nitems, const void *pend);
 int gys_ingest_active_conns_dev(gys_ctx *ctx, const void *d_batch, uint32_t nitems);
 
@@ -272,7 +272,12 @@ int gys_query_quantiles(gys_ctx *ctx, uint64_t glob_id, const double *q, uint32_
 int gys_query_distinct_flows(gys_ctx *ctx, double *out);
 /* Count-Min estimate for a service key: events (which = 0) or bytes (which = 1) in the last finished window */
 int gys_query_cms(gys_ctx *ctx, uint64_t glob_id, int which, uint64_t *out);
-/* Count-Min estimate for a (listener, client task group) pair in the last finished window: active connections (which = 0) or bytes (1) */
+/* Count-Min estimate for a (listener, client task group) pair.  Two roll-ups, each with its own table pair:
+ *   which 0 / 1: active connections / bytes (sent + received) of the ACTIVE_CONN_STATS rows (gys_ingest_active_conns).  A partha reports
+ *                these every 15 s and a window is 5 s: the answer comes from the tables of the LAST WINDOW THAT CARRIED SUCH ROWS on any
+ *                rank (a gauge's "last report"); windows without rows leave it alone.
+ *   which 2 / 3: connection notifications / bytes of the TCP_CONN_NOTIFY roll-up (gys_config.conn_pair_cms; GYS_ERR_STATE when off),
+ *                last finished window. */
 int gys_query_pair_cms(gys_ctx *ctx, uint64_t listener_glob_id, uint64_t cli_aggr_task_id, int which, uint64_t *out);
 
 typedef struct {
@@ -430,7 +435,7 @@ int gys_export_tdigest(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, int64
 int gys_export_tdigest_pending(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint32_t *npend /* [nslots] */,
 			       int32_t *pend /* [nslots*GYS_TD_PEND_CAP] */);
 int gys_export_svc_counters(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint64_t *out /* [nslots*4]: nconn, nclose, bytes_sent, bytes_rcvd */);
-int gys_export_pair_cms(gys_ctx *ctx, int which, void *out /* which 0: u32[D*W] active connections; which 1: i64[D*W] bytes; last finished window */);
+int gys_export_pair_cms(gys_ctx *ctx, int which, void *out /* which 0 / 2: u32[D*W]; which 1 / 3: i64[D*W]; see gys_query_pair_cms */);
 int gys_export_active_conn_counters(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint64_t *out /* [nslots*4]: rows, bytes_sent, bytes_received, active conns */);
 int gys_export_global_hist(gys_ctx *ctx, gys_hist_rec *out); /* all-service response histogram of the last finished window (all ranks) */
 int gys_export_svc_hll(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint8_t *out /* [nslots << svc_hll_p] */);
@@ -445,6 +450,9 @@ typedef struct {
 	uint64_t td_merges, td_merge_values; /* t-digest re-clusterings queued so far and the buffered values they merged */
 	uint64_t actconn_records, actconn_remote_listen, actconn_unknown_listener; /* ACTIVE_CONN_STATS rows of local listeners / of listeners on
 										      another madhava (is_remote_listen_) / of local listeners not registered */
+	uint64_t stage_waits;       /* host-pointer calls that found their staging slot still in flight and waited for the GPU (ring wrapped) */
+	uint64_t resp_calls_queued; /* gys_ingest_resp_events calls that went through the submission queue ... */
+	uint64_t resp_submissions;  /* ... and the combined batches they were submitted as (calls / submissions = calls per launch set) */
 } gys_counters;
 int gys_get_counters(gys_ctx *ctx, gys_counters *out);
 

@@ -246,6 +246,10 @@ def test_active_conn_stats_pair_countmin_and_listener_sums(oracle):
         eng.window_close()
         assert (eng.export_pair_cms(0) == p32).all()
         assert (eng.export_pair_cms(1).view(np.uint64) == p64).all()
+        # a partha reports every 15 s, a window is 5 s: two windows without ACTIVE_CONN_STATS rows leave the last report readable
+        eng.window_close()
+        eng.window_close()
+        assert (eng.export_pair_cms(0) == p32).all() and (eng.export_pair_cms(1).view(np.uint64) == p64).all()
         rec = np.concatenate(allrec)
         local = (rec["flags"] & wire.ACTIVE_FLAG_REMOTE_LISTEN) == 0
         c = eng.counters()
@@ -306,9 +310,13 @@ def test_tcp_conn_pair_countmin_opt_in(oracle):
         assert got == n
     for e in engs.values():
         e.window_close()
-    assert (engs[True].export_pair_cms(0) == p32).all() and (engs[True].export_pair_cms(1).view(np.uint64) == p64).all()
+    assert (engs[True].export_pair_cms(2) == p32).all() and (engs[True].export_pair_cms(3).view(np.uint64) == p64).all()
     assert p32.sum(axis=1).tolist() == [nh * n] * 4  # every row counts every connection once
+    # the ACTIVE_CONN_STATS tables are a different roll-up with cells of their own: connection notifications never reach them
+    assert engs[True].export_pair_cms(0).sum() == 0 and engs[True].export_pair_cms(1).sum() == 0
     assert engs[False].export_pair_cms(0).sum() == 0 and engs[False].export_pair_cms(1).sum() == 0
+    with pytest.raises(Exception):
+        engs[False].export_pair_cms(2)  # option off: GYS_ERR_STATE
     # the default registers are unaffected by the option
     assert (engs[True].export_cms(0) == engs[False].export_cms(0)).all() and (engs[True].export_hll() == engs[False].export_hll()).all()
     for e in engs.values():
