@@ -13,7 +13,9 @@ its t-digest once per ~256 values (every ~9.5 windows at ~27 events per key and 
 buffer fill levels evenly and then runs one full buffer cycle of ordinary windows, so that EVERY timed window, whatever
 --steps/--warmup, carries its long-run share of (steady-state, non-empty-digest) merges.
 
-One process per GPU (torchrun env RANK/LOCAL_RANK/WORLD_SIZE); rank 0 prints ONE JSON line.
+One process per GPU (torchrun env RANK/LOCAL_RANK/WORLD_SIZE); without a launcher `--gpus N` starts its own N ranks (self_launch).  After
+an N > 1 run every rank's reduced registers are checksummed and compared, and a small side configuration run through the same exchange is
+compared with a single-rank engine (`exchange_check` in the JSON line; a mismatch exits with status 5).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -223,6 +225,132 @@ def pmc_traffic(kernel, events, nsvc):
             "source": t.get("source", "profiles/pmc_traffic.json")}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: re-run this very command line under torch.distributed.run, one rank per
+    GPU of this node (what the driver does itself for N > 1).  Returns the launcher's exit status."""
+    import socket
+    import subprocess
+    if not args.selftest_launch:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, {have} visible on this node", file=sys.stderr)
+            return 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def digest64(*arrays):
+    """one signed 64-bit checksum of a group of byte strings / numpy arrays (order matters)"""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    for a in arrays:
+        h.update(a if isinstance(a, (bytes, bytearray)) else np.ascontiguousarray(a).tobytes())
+    return int.from_bytes(h.digest(), "little", signed=True)
+
+
+REG_FAMILIES = ["hll", "cms32", "cms64", "global_hist", "cluster_rows"]
+
+
+def observe_registers(eng, clusters):
+    """checksums of what the window exchange leaves on a rank: the reduced HLL registers, both Count-Min tables, the all-service histogram
+    and every cluster's STATE_ONE row of the last finished window.  After a correct exchange every rank holds the same five numbers."""
+    gh = eng.export_global_hist()
+    ghb = np.array([(gh.stats[i].count, gh.stats[i].sum) for i in range(15)] + [(gh.total_count, gh.max_val_seen)], dtype=np.int64)
+    cl = np.array([eng.clusterstate(c).as_tuple() for c in clusters], dtype=np.int64)
+    return [digest64(eng.export_hll()), digest64(eng.export_cms(0)), digest64(eng.export_cms(1)), digest64(ghb), digest64(cl)]
+
+
+def verify_ranks(mine, world, device):
+    """all-gather of every rank's checksums (torch.distributed, whatever backend the group has); returns (matrix [world][k], consistent)"""
+    t = torch.tensor(mine, dtype=torch.int64, device=device)
+    got = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(got, t)
+    m = [g.cpu().tolist() for g in got]
+    return m, all(row == m[0] for row in m)
+
+
+def exchange_side_check(args, rank, world, local_rank, L, main_eng, exchange, wire, SketchEngine, mid_buf):
+    """Small configuration (96 hosts x 6 services, 2 000 response events per host, fixed seeds per host) run twice: sharded over the
+    ranks through the SAME exchange path as the timed run, and -- on rank 0 -- by one single-rank engine fed all hosts.  The reduced
+    registers of every rank must equal the single-rank run's."""
+    nh, sp, nev = 96, 6, 2000
+    clusters = ["cluster%d" % c for c in range(8)]
+    mids = [wire.machine_id(h) for h in range(nh)]
+
+    def events(h):
+        rng = np.random.default_rng(7000 + h)
+        ev = np.zeros(nev, dtype=wire.RESP_EVENT)
+        s_ = rng.integers(0, sp, nev)
+        ev["saddr"] = 0x0A000001 + h
+        ev["daddr"] = rng.integers(1, 1 << 32, nev, dtype=np.uint64).astype(np.uint32)
+        ev["netns"] = wire.listener_netns(h, s_)
+        ev["sport_be"] = wire.listener_port(s_)
+        ev["dport_be"] = rng.integers(16000, 65536, nev)
+        lat = np.minimum(np.floor(rng.lognormal(3.0, 1.5, nev)), 1e6).astype(np.uint32)
+        lrcv = rng.integers(0, 1 << 32, nev, dtype=np.uint64).astype(np.uint32)
+        with np.errstate(over="ignore"):
+            ev["lsndtime"] = lrcv + lat
+        ev["lrcvtime"] = lrcv
+        return ev
+
+    def run(eng, hosts, close):
+        for c in clusters:
+            eng.register_cluster(c)
+        s_ = np.arange(sp)
+        for h in hosts:
+            eng.register_host(mids[h], clusters[h % 8])
+            eng.register_listeners_np(mids[h], wire.glob_id(np.full(sp, h), s_), wire.listener_netns(h, s_), wire.listener_port(s_))
+            eng.handle_host_state(mids[h], ntasks=10 + h, nlisten=sp)
+        for h in hosts:
+            eng.handle_resp_events(mids[h], events(h))
+        close(eng)
+        return observe_registers(eng, clusters)
+
+    mine = [h for h in range(nh) if L.gys_shard_of(mid_buf(mids[h]), world) == rank]
+    e2 = SketchEngine(max_hosts=nh, max_services=nh * sp, max_clusters=16, enable_tdigest=True, max_batch_events=1 << 16, rank=rank, nranks=world,
+                      device=local_rank)
+    if exchange == "rccl_in_library":
+        e2.comm = main_eng.comm  # the communicator of the timed run (a communicator belongs to the rank, not to a context)
+        obs = run(e2, mine, lambda e: e.window_close_rccl(tusec=5_000_000))
+        e2.comm = None
+    else:
+        obs = run(e2, mine, lambda e: e.window_close(tusec=5_000_000))
+    e2.close()
+    matrix, same = verify_ranks(obs, world, torch.device("cuda", local_rank))
+    equal_single = None
+    if rank == 0:
+        e1 = SketchEngine(max_hosts=nh, max_services=nh * sp, max_clusters=16, enable_tdigest=True, max_batch_events=1 << 16, device=local_rank)
+        want = run(e1, range(nh), lambda e: e.window_close(tusec=5_000_000))
+        e1.close()
+        equal_single = all(row == want for row in matrix)
+    return {"hosts": nh, "services_per_host": sp, "events_per_host": nev, "ranks_consistent": same, "equals_single_rank_engine": equal_single}
+
+
+def selftest_launch(args, rank, world):
+    """--selftest-launch (no GPU needed): the ranks meet over gloo and run the same checksum exchange the timed run ends with, on
+    synthetic registers -- covers the self-launch path and verify_ranks on a CPU box (tests/test_bench_launch.py)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    rng = np.random.default_rng(99)
+    regs = [digest64(rng.integers(0, 255, 1 << 14, dtype=np.uint8)) for _ in REG_FAMILIES]
+    if args.selftest_corrupt_rank == rank:
+        regs[1] ^= 1
+    matrix, same = verify_ranks(regs, world, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "exchange_check": {"ranks_seen": len(matrix), "ranks_consistent": same,
+                                                                                  "families": REG_FAMILIES}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if same else 5
+
+
 def run_conn(args, rank, world):
     """--workload conn: BASELINE.json configs[1] -- 1 000 hosts x 100 services, per window 2^24 device-resident
     TCP_CONN_NOTIFY records (280 B fixed stride; HLL distinct flows + 2 x Count-Min + exact per-service counters) and 10^5
@@ -288,8 +416,8 @@ def run_conn(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=80, help="timed windows (80 x ~12 ms: a timed region of about a second)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--hosts", type=int, default=10000, help="total hosts across all ranks")
     ap.add_argument("--svcs", type=int, default=1000, help="services per host")
     ap.add_argument("--events", type=int, default=1 << 29, help="events per rank per step (one window)")
@@ -298,6 +426,12 @@ def main():
     ap.add_argument("--workload", choices=["resp", "conn"], default="resp", help="resp: C3/C4/C5 response-event stream (default); conn: C2 TCP_CONN_NOTIFY stream")
     ap.add_argument("--conn-stream", choices=["messages", "mixed"], default="messages", help="--workload conn: per-partha 2048-record messages (default) or hosts mixed record by record")
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl", help="window exchange at N > 1: RCCL inside the library (default) or torch.distributed")
+    ap.add_argument("--rccl-lib", default="torch", help="which RCCL the library binds at N > 1 (GYS_RCCL_LIB): 'torch' = the copy PyTorch bundles "
+                    "(one RCCL per process; the ROCm 7.2 librccl's ncclCommInitRank does not return on part of the MI355X pool), 'rocm' = /opt/rocm/lib/librccl.so, or a path")
+    ap.add_argument("--strict-exchange", action="store_true", help="exit non-zero when the in-library RCCL exchange was asked for but the run fell back to torch.distributed")
+    ap.add_argument("--no-exchange-check", action="store_true", help="skip the (untimed) cross-rank register checks after an N > 1 run")
+    ap.add_argument("--selftest-launch", action="store_true", help="no GPU: only the launch path and the cross-rank checksum exchange (gloo)")
+    ap.add_argument("--selftest-corrupt-rank", type=int, default=-1, help="--selftest-launch: this rank reports a wrong checksum (the run must fail)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quantile-check", action="store_true", help="skip the (untimed) t-digest rank-error check after the run")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the (untimed) host-fed measurement: pinned H2D copy + ingest")
@@ -308,19 +442,29 @@ def main():
     ap.add_argument("--cpu-hosts", type=int, default=1000)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher around us: become one (one rank per GPU of this node)
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    if args.selftest_launch:
+        sys.exit(selftest_launch(args, rank, world))
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} needs device {local_rank}, {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap rendezvous over loopback (see gys_rccl_unique_id)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "GYS_RCCL_LIB" not in os.environ and args.rccl_lib != "rocm":  # before the library's first RCCL call (it binds with dlopen)
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so") if args.rccl_lib == "torch" else args.rccl_lib
+            if os.path.exists(cand):
+                os.environ["GYS_RCCL_LIB"] = cand
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     if args.workload == "conn":
@@ -460,6 +604,19 @@ def main():
     eng.profile(False)
     ctr1 = eng.counters()
 
+    # the exchange, checked (untimed): after the last window every rank must hold the same reduced registers, and a small side
+    # configuration run through the same exchange must equal a single-rank engine fed all of its hosts
+    xcheck = None
+    if world > 1 and not args.no_exchange_check:
+        regs = observe_registers(eng, ["cluster%d" % c for c in range(8)])
+        matrix, same = verify_ranks(regs, world, torch.device("cuda", local_rank))
+        side = exchange_side_check(args, rank, world, local_rank, L, eng, exchange, wire, SketchEngine, mid_buf)
+        xcheck = {"ranks_seen": len(matrix), "ranks_consistent": same, "families": REG_FAMILIES, "side_config": side,
+                  "ok": bool(same and side["ranks_consistent"] and side["equals_single_rank_engine"] is not False)}
+        okt = torch.tensor([1 if xcheck["ok"] else 0], device="cuda")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)  # (rank 0 alone knows the single-rank comparison)
+        xcheck["ok"] = bool(int(okt.item()))
+
     qerr = None
     if rank == 0 and not args.no_quantile_check and nsvc:
         for b in range(nbuf):
@@ -525,7 +682,10 @@ def main():
                        "events_per_rank_per_step": args.events, "service_keys_total": args.hosts * args.svcs,
                        "service_keys_rank0": nsvc, "multi_level_windows": bool(args.levels),
                        "sketches": "exact RESP_TIME_HASH histogram + CONN_BITMAP + HLL p=14 + CMS 4x65536 + t-digest %d clusters + %d-value buffer per key" % (capi.TD_NB, capi.TD_PEND_CAP),
-                       "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world, "exchange": exchange},
+                       "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world, "exchange": exchange,
+                       "exchange_requested": args.exchange if world > 1 else "none",
+                       "exchange_fallback": bool(world > 1 and args.exchange == "rccl" and exchange != "rccl_in_library"),
+                       "rccl_lib": os.environ.get("GYS_RCCL_LIB", "/opt/rocm/lib/librccl.so") if world > 1 else None},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": alg_bytes,
@@ -535,6 +695,8 @@ def main():
                          "merges_per_step": merges_step, "merge_values_per_step": mvals_step,
                          "kernels": kernels},
         }
+        if xcheck is not None:
+            out["exchange_check"] = xcheck
         if qerr is not None:
             out["quantile_error"] = qerr
         if host_fed is not None:
@@ -561,12 +723,21 @@ def main():
             out["host_fed"]["l2_threads"] = host_fed_l2_threads()  # its own context: after this engine has released the device
         print(json.dumps(out), flush=True)
     bad = rank == 0 and out.get("parity_ok") is False
+    xbad = xcheck is not None and not xcheck["ok"]
+    fell_back = world > 1 and args.exchange == "rccl" and exchange != "rccl_in_library"
     if world > 1:
         dist.barrier()  # rank 0's untimed checks take longer than the other ranks' exit path: leave together
         dist.destroy_process_group()
     if bad:  # the north-star tolerance is part of the metric: a line that breaks it is not a result
         print("bench.py: t-digest rank error above the 0.01 tolerance", file=sys.stderr)
         sys.exit(3)
+    if xbad:  # ranks that disagree after the exchange (or differ from the single-rank engine): the N-GPU line is not a result either
+        print("bench.py: cross-rank register check failed (see exchange_check in the JSON line)", file=sys.stderr)
+        sys.exit(5)
+    if fell_back:
+        print("bench.py: the in-library RCCL exchange was not available; the run used torch.distributed (exchange_fallback in the JSON line)", file=sys.stderr)
+        if args.strict_exchange:
+            sys.exit(4)
     if rccl_join_stuck:  # a helper thread is still inside ncclCommInitRank: do not let interpreter shutdown wait on it
         sys.stdout.flush()
         sys.stderr.flush()

@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
            "-Wno-unused-function", "-Wno-unused-value", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES] + [
-               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]  # the window exchange (ncclAllReduce / ncclAllGather) lives in the library
+               "-ldl", "-Wl,-rpath,/opt/rocm/lib"]  # RCCL (the window exchange inside the library) is bound at run time: dlopen("librccl.so") through this RUNPATH, or $GYS_RCCL_LIB
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

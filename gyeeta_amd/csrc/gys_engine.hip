@@ -21,6 +21,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include "gys_kernels.hpp"
@@ -2985,11 +2986,71 @@ int gys_tdigest_slab_quantiles(gys_ctx *c, const gys_tdigest_slab *d_slab, const
 uint32_t gys_num_clusters(gys_ctx *c) { return c ? (uint32_t)c->cluster_names.size() : 0; }
 
 // ------------------------------------------------------------------------------------------------ RCCL exchange in the library
+// RCCL is bound at run time (dlopen), not at link time: a process that never joins a communicator (one madhava, one GPU) does not need
+// the library at all, and a host process that already carries an RCCL of its own (PyTorch bundles one) can point the engine at THAT
+// copy instead of running two different RCCL builds side by side.  GYS_RCCL_LIB = path or soname; default "librccl.so" (found through
+// this library's RUNPATH /opt/rocm/lib).  tests/cpp/fakerccl is a stand-in with the same entry points (two ranks on one GPU).
+namespace {
+struct RcclApi {
+	void *handle = nullptr;
+	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank) CommInitRank = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclCommCount) CommCount = nullptr;
+	decltype(&ncclCommUserRank) CommUserRank = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
+	decltype(&ncclAllGather) AllGather = nullptr;
+	std::string err, path;
+};
+
+RcclApi *rccl_api()
+{
+	static RcclApi api = [] {
+		RcclApi a;
+		const char *env = getenv("GYS_RCCL_LIB");
+		a.path = env && *env ? env : "librccl.so";
+		a.handle = dlopen(a.path.c_str(), RTLD_NOW | RTLD_LOCAL);
+		if (!a.handle && !(env && *env)) a.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+		if (!a.handle) {
+			const char *e = dlerror();
+			a.err = std::string("cannot load ") + a.path + ": " + (e ? e : "?");
+			return a;
+		}
+#define GYS_RCCL_SYM(name)                                                        \
+	a.name = (decltype(a.name))dlsym(a.handle, "nccl" #name);                 \
+	if (!a.name && a.err.empty()) a.err = a.path + " has no nccl" #name;
+		GYS_RCCL_SYM(GetUniqueId)
+		GYS_RCCL_SYM(CommInitRank)
+		GYS_RCCL_SYM(CommDestroy)
+		GYS_RCCL_SYM(CommCount)
+		GYS_RCCL_SYM(CommUserRank)
+		GYS_RCCL_SYM(GetErrorString)
+		GYS_RCCL_SYM(GroupStart)
+		GYS_RCCL_SYM(GroupEnd)
+		GYS_RCCL_SYM(AllReduce)
+		GYS_RCCL_SYM(AllGather)
+#undef GYS_RCCL_SYM
+		return a;
+	}();
+	return &api;
+}
+} // namespace
+
+#define RCCL_API(R)                                            \
+	RcclApi *R = rccl_api();                               \
+	if (!R->err.empty()) {                                 \
+		set_err("RCCL unavailable: %s", R->err.c_str()); \
+		return GYS_ERR_HIP;                            \
+	}
+
 #define NCCLCHK(expr)                                                                          \
 	do {                                                                                   \
 		const ncclResult_t r_ = (expr);                                                \
 		if (r_ != ncclSuccess) {                                                       \
-			set_err("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+			set_err("%s failed: %s (%s:%d)", #expr, R->GetErrorString(r_), __FILE__, __LINE__); \
 			return GYS_ERR_HIP;                                                    \
 		}                                                                              \
 	} while (0)
@@ -3003,8 +3064,9 @@ int gys_rccl_unique_id(uint8_t uid[GYS_RCCL_UID_BYTES])
 	// loopback -- RCCL otherwise takes the first non-loopback interface, and on hosts whose first interface is a tunnel / container
 	// bridge the ranks' connect() to it never returns (seen on part of the MI355X pool).  Must be set before RCCL's first call.
 	setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+	RCCL_API(R);
 	ncclUniqueId id;
-	NCCLCHK(ncclGetUniqueId(&id));
+	NCCLCHK(R->GetUniqueId(&id));
 	memcpy(uid, &id, sizeof(id));
 	return GYS_OK;
 }
@@ -3021,8 +3083,9 @@ int gys_rccl_comm_create(gys_ctx *c, const uint8_t uid[GYS_RCCL_UID_BYTES], int 
 	setenv("NCCL_SOCKET_IFNAME", "lo", 0); // (see gys_rccl_unique_id)
 	ncclUniqueId id;
 	memcpy(&id, uid, sizeof(id));
+	RCCL_API(R);
 	ncclComm_t cm = nullptr;
-	NCCLCHK(ncclCommInitRank(&cm, nranks, id, rank));
+	NCCLCHK(R->CommInitRank(&cm, nranks, id, rank));
 	*comm = (void *)cm;
 	return GYS_OK;
 }
@@ -3030,7 +3093,8 @@ int gys_rccl_comm_create(gys_ctx *c, const uint8_t uid[GYS_RCCL_UID_BYTES], int 
 int gys_rccl_comm_destroy(void *comm)
 {
 	if (!comm) return GYS_ERR_INVAL;
-	NCCLCHK(ncclCommDestroy((ncclComm_t)comm));
+	RCCL_API(R);
+	NCCLCHK(R->CommDestroy((ncclComm_t)comm));
 	return GYS_OK;
 }
 
@@ -3038,6 +3102,7 @@ int gys_window_close_rccl(gys_ctx *c, void *comm, uint64_t tusec)
 {
 	GYS_ENTER(c);
 	if (!c || !comm) return GYS_ERR_INVAL;
+	RCCL_API(R);
 	int rc = GYS_OK;
 	if (!c->prepared) rc = gys_window_prepare(c, tusec); // (a call that failed in the exchange below left the window prepared: the retry resumes here)
 	if (rc) return rc;
@@ -3047,21 +3112,21 @@ int gys_window_close_rccl(gys_ctx *c, void *comm, uint64_t tusec)
 	if (rc) return rc;
 	{
 		ProfScope ps(c, "window_rccl");
-		NCCLCHK(ncclGroupStart());
+		NCCLCHK(R->GroupStart());
 		// from here on the group is ALWAYS closed: an error between Start and End would leave every later RCCL call of this thread
 		// inside a group that never launches
 		ncclResult_t bad = ncclSuccess;
 		for (uint32_t i = 0; i < nsec && bad == ncclSuccess; ++i) {
 			const ncclDataType_t dt = sec[i].dtype == 0 ? ncclUint8 : (sec[i].dtype == 1 ? ncclUint32 : ncclInt64);
 			const ncclRedOp_t op = sec[i].op == 0 ? ncclMax : ncclSum;
-			bad = ncclAllReduce(sec[i].dev_ptr, sec[i].dev_ptr, sec[i].nelems, dt, op, (ncclComm_t)comm, c->stream);
+			bad = R->AllReduce(sec[i].dev_ptr, sec[i].dev_ptr, sec[i].nelems, dt, op, (ncclComm_t)comm, c->stream);
 		}
-		const ncclResult_t end = ncclGroupEnd();
+		const ncclResult_t end = R->GroupEnd();
 		if (bad == ncclSuccess) bad = end;
 		if (bad != ncclSuccess) {
 			// the window stays prepared (arena not cleared, nothing finished): the caller may retry this call -- it resumes at the
 			// exchange -- or fall back to gys_reduce_sections + its own collective + gys_window_finish
-			set_err("window exchange failed: %s", ncclGetErrorString(bad));
+			set_err("window exchange failed: %s", R->GetErrorString(bad));
 			return GYS_ERR_HIP;
 		}
 	}
@@ -3074,15 +3139,16 @@ int gys_tdigest_global_rccl(gys_ctx *c, void *comm, gys_tdigest_slab *d_out)
 	if (!c || !comm || !d_out) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
 	int nranks = 1, rank = 0;
-	NCCLCHK(ncclCommCount((ncclComm_t)comm, &nranks));
-	NCCLCHK(ncclCommUserRank((ncclComm_t)comm, &rank));
+	RCCL_API(R);
+	NCCLCHK(R->CommCount((ncclComm_t)comm, &nranks));
+	NCCLCHK(R->CommUserRank((ncclComm_t)comm, &rank));
 	gys_tdigest_slab *d_all = nullptr;
 	HIPCHK(hipMalloc((void **)&d_all, sizeof(gys_tdigest_slab) * (size_t)nranks));
 	int rc = gys_tdigest_rollup_dev(c, GYS_ROLLUP_GLOBAL, d_all + rank); // in place: this rank's slab sits at its own position
 	if (rc == GYS_OK) {
-		const ncclResult_t r = ncclAllGather(d_all + rank, d_all, sizeof(gys_tdigest_slab), ncclUint8, (ncclComm_t)comm, c->stream);
+		const ncclResult_t r = R->AllGather(d_all + rank, d_all, sizeof(gys_tdigest_slab), ncclUint8, (ncclComm_t)comm, c->stream);
 		if (r != ncclSuccess) {
-			set_err("ncclAllGather failed: %s", ncclGetErrorString(r));
+			set_err("ncclAllGather failed: %s", R->GetErrorString(r));
 			rc = GYS_ERR_HIP;
 		}
 	}

@@ -1,0 +1,211 @@
+"""Round-3 parity additions:
+  * the host-pointer response path under concurrency: 16 threads (the reference's MAX_L2_MISC_THREADS, server/gy_mconnhdlr.h:60) call
+    gys_ingest_resp_events at the same time; the library combines pending calls into common submissions (submission queue) and the
+    resulting state -- histograms, digests, buffered values, HLL, Count-Min -- equals the oracle fed call by call;
+  * the staging ring of the other host-pointer calls hands its slots out oldest first (no wait for the GPU unless the ring wrapped)."""
+import threading
+
+import numpy as np
+import pytest
+
+from gyeeta_amd import wire
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: -m gpu tests must run on the MI355X box")
+    return torch
+
+
+def _engine(**kw):
+    from gyeeta_amd.engine import SketchEngine
+    return SketchEngine(**kw)
+
+
+def test_resp_calls_from_16_threads_are_combined_and_bit_exact(torch_mod, oracle):
+    nh, sp, rounds, per_call = 48, 20, 6, 3000
+    eng = _engine(max_hosts=nh, max_services=nh * sp, max_batch_events=1 << 20)
+    orc = oracle.OracleEngine(nh * sp)
+    info, gids = helpers.register_world(eng, orc, range(nh), sp)
+    rng = np.random.default_rng(2024)
+    nthreads = 16
+    # every thread owns hosts t, t + 16, t + 32 and sends `rounds` calls per host, in order (a partha's messages arrive in order on its
+    # connection; different parthas interleave freely)
+    calls = {h: [helpers.make_resp_events(rng, h, per_call + 37 * (h % 5), sp) for _ in range(rounds)] for h in range(nh)}
+    errs = []
+    start = threading.Barrier(nthreads)
+
+    def worker(t):
+        try:
+            start.wait()
+            for r in range(rounds):
+                for h in range(t, nh, nthreads):
+                    eng.handle_resp_events(info[h][0], calls[h][r])
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    eng.sync()
+    for h in range(nh):  # the oracle sees every call on its own, per host in call order (hosts are independent)
+        for r in range(rounds):
+            orc.resp_batch(calls[h][r].tobytes(), [info[h][1]], [0])
+    n = orc.nsvc
+    helpers.assert_hist_equal(eng.export_hist(0, 0, n), orc.hist(), n)
+    gs, gc, gm = eng.export_tdigest(0, n)
+    os_, oc, om = orc.td_arrays()
+    assert (gs == os_).all() and (gc == oc).all() and (gm == om).all()
+    gn, gp = eng.export_tdigest_pending(0, n)
+    on, op = orc.td_pending()
+    assert (gn == on).all() and (gp == op).all()
+    c = eng.counters()
+    assert c["resp_calls_queued"] == nh * rounds
+    assert 1 <= c["resp_submissions"] <= c["resp_calls_queued"]
+    eng.window_close()
+    assert (eng.export_hll() == orc.hll()).all() and (eng.export_cms(0) == orc.cms()).all()
+    # a lone caller is submitted at once (no added latency): every call its own submission, results visible after gys_sync
+    before = eng.counters()
+    for r in range(3):
+        eng.handle_resp_events(info[0][0], calls[0][r])
+        orc.resp_batch(calls[0][r].tobytes(), [info[0][1]], [0])
+    after = eng.counters()
+    assert after["resp_submissions"] - before["resp_submissions"] == 3
+    helpers.assert_hist_equal(eng.export_hist(0, 0, n), orc.hist(), n)
+    eng.close()
+
+
+def test_staging_ring_is_fifo(torch_mod, oracle):
+    """gys_ingest_listener_state / _tcp_conn copy into a ring of 16 pinned slots; a slot is taken oldest first, so a burst shorter
+    than the ring never waits for the GPU (gys_counters.stage_waits)"""
+    nh, sp = 4, 16
+    eng = _engine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False)
+    info, gids = helpers.register_world(eng, None, range(nh), sp)
+    rng = np.random.default_rng(5)
+    recs = [wire.synth_listener_states(rng, h, np.arange(sp)) for h in range(nh)]
+    eng.sync()
+    w0 = eng.counters()["stage_waits"]
+    for i in range(12):
+        h = i % nh
+        eng.partha_listener_state(info[h][0], recs[h].tobytes(), sp)
+    eng.sync()
+    assert eng.counters()["stage_waits"] == w0
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ in-library exchange at nranks = 2
+def _fake_rank(rank, q_uid, q_res):
+    """one rank of test_window_close_rccl_two_ranks: its shard of the hosts, the in-library exchange, what it observes afterwards"""
+    import ctypes as C
+    import os
+    import torch
+    from gyeeta_amd import capi
+    from gyeeta_amd.engine import SketchEngine, mid_buf
+    from tests.test_gpu_round2 import NH, SP, _feed, _observe
+    try:
+        torch.cuda.set_device(0)
+        L = capi.load()
+        glob = C.CDLL(os.environ["GYS_RCCL_LIB"])  # (the same handle the library's dlopen got)
+        glob.fakerccl_allreduce_calls.restype = C.c_uint64
+        glob.fakerccl_allgather_calls.restype = C.c_uint64
+        mine = [h for h in range(NH) if L.gys_shard_of(mid_buf(wire.machine_id(h)), 2) == rank]
+        eng = SketchEngine(max_hosts=NH, max_services=NH * SP, max_clusters=4, max_batch_events=1 << 14, rank=rank, nranks=2, device=0)
+        _feed(eng, mine)
+        if rank == 0:
+            uid = bytes(eng.rccl_unique_id())
+            q_uid.put(uid)
+        else:
+            uid = q_uid.get(timeout=120)
+        eng.join_rccl(uid)
+        eng.window_close_rccl(tusec=5_000_000)
+        obs = _observe(eng)
+        out = torch.zeros(C.sizeof(capi.TDigestSlab), dtype=torch.uint8, device="cuda")
+        capi.check(L.gys_tdigest_global_rccl(eng.h, eng.comm, C.c_void_p(out.data_ptr())))
+        eng.sync()
+        merged = out.cpu().numpy().tobytes()
+        dev_l, _ = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)
+        local = dev_l.cpu().numpy().tobytes()
+        calls = (int(glob.fakerccl_allreduce_calls()), int(glob.fakerccl_allgather_calls()))
+        eng.leave_rccl()
+        eng.close()
+        q_res.put((rank, "ok", obs, merged, local, calls, len(mine)))
+    except BaseException as ex:  # noqa: BLE001 -- reported to the parent
+        import traceback
+        q_res.put((rank, "error: " + "".join(traceback.format_exception(type(ex), ex, ex.__traceback__))[-2000:]))
+
+
+def test_window_close_rccl_two_ranks(torch_mod, oracle):
+    """gys_window_close_rccl and gys_tdigest_global_rccl with TWO ranks: two processes on the one GPU of the box, each
+    owning its shard of the hosts; the RCCL entry points the library calls are served by tests/cpp/fakerccl ($GYS_RCCL_LIB; RCCL itself
+    refuses two ranks on one device), which executes every all-reduce / all-gather with exactly the count, datatype, operator and
+    pointers the library passed.  Both ranks end with the registers, Count-Min tables, all-service histogram and cluster rows of a
+    single-rank engine fed all hosts, and with the same global digest = the oracle's fold of the two ranks' slabs in rank order."""
+    import ctypes as C
+    import os
+    import subprocess
+    import torch.multiprocessing as mp
+    from gyeeta_amd import capi
+    from tests.test_gpu_round2 import NH, SP, _feed, _observe
+    here = os.path.dirname(os.path.abspath(__file__))
+    fake = os.path.join(here, "cpp", "fakerccl", "libfakerccl.so")
+    if not os.path.exists(fake):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                               os.path.join(here, "cpp", "fakerccl", "fakerccl.cc"), "-o", fake, "-L/opt/rocm/lib", "-lamdhip64", "-lrt",
+                               "-Wl,-rpath,/opt/rocm/lib"])
+    ctx = mp.get_context("spawn")
+    q_uid, q_res = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_fake_rank, args=(r, q_uid, q_res)) for r in range(2)]
+    old = os.environ.get("GYS_RCCL_LIB")
+    os.environ["GYS_RCCL_LIB"] = fake  # the library binds RCCL with dlopen($GYS_RCCL_LIB) (gys_engine.hip: rccl_api); inherited by the children
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        if old is None:
+            del os.environ["GYS_RCCL_LIB"]
+        else:
+            os.environ["GYS_RCCL_LIB"] = old
+    res = sorted(q_res.get(timeout=400) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[1] == "ok", r[1]
+    for p in procs:
+        assert p.exitcode == 0
+    single = _engine(max_hosts=NH, max_services=NH * SP, max_clusters=4, max_batch_events=1 << 14)
+    _feed(single, range(NH))
+    single.window_close(tusec=5_000_000)
+    want = _observe(single)
+    assert res[0][6] > 0 and res[1][6] > 0 and res[0][6] + res[1][6] == NH
+    names = ["hll", "cms32", "cms64", "global histogram", "cluster state", "distinct flows"]
+    for r in range(2):
+        assert res[r][5][0] >= 4 and res[r][5][1] >= 1, "the library's collectives did not go through the stand-in"
+        for name, got, exp in zip(names, res[r][2], want):
+            assert got == exp, f"rank {r}: {name} differs from the single-rank run"
+    # global digest: identical on both ranks, equal to the oracle's fold of the two local slabs in rank order
+    assert res[0][3] == res[1][3]
+    L = oracle.lib()
+    d = oracle.TD64()
+    L.gyo_td64_init(C.byref(d))
+    tot = 0
+    for r in range(2):
+        loc = np.frombuffer(res[r][4], dtype=single.SLAB_DT)[0]
+        o1 = oracle.TD64()
+        o1.sum[:] = loc["sum"].tolist()
+        o1.cnt[:] = loc["cnt"].tolist()
+        o1.vmin, o1.vmax = int(loc["vmin"]), int(loc["vmax"])
+        L.gyo_td64_merge_td64(C.byref(d), C.byref(o1))
+        tot += int(loc["cnt"].sum())
+    got = np.frombuffer(res[0][3], dtype=single.SLAB_DT)[0]
+    assert int(got["cnt"].sum()) == tot > 0
+    assert (got["sum"] == np.array(d.sum[:], dtype=np.int64)).all() and (got["cnt"] == np.array(d.cnt[:], dtype=np.uint64)).all()
+    assert int(got["vmin"]) == d.vmin and int(got["vmax"]) == d.vmax
+    single.close()

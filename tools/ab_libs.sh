@@ -11,7 +11,7 @@ case "$1" in
 build)
 	tag=$2; shift 2
 	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -w "$@" -o $R/gyeeta_amd/lib/libgysketch_$tag.so \
-		$R/gyeeta_amd/csrc/gys_engine.hip -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib && echo "built libgysketch_$tag.so ($*)"
+		$R/gyeeta_amd/csrc/gys_engine.hip -ldl -Wl,-rpath,/opt/rocm/lib && echo "built libgysketch_$tag.so ($*)"
 	;;
 bench)
 	out=$2; shift 2; mkdir -p $out; cd $R
