@@ -971,6 +971,32 @@ int level_roll(gys_ctx *c, uint64_t tusec)
 	return GYS_OK;
 }
 
+// where a level's records come from at time tq (s): mode 0 = cumulative - *sub (nullptr: nothing to subtract), 1 = empty, 2 = copy of *sub
+void level_source(gys_ctx *c, int level, int64_t tq, int *mode, const gys_hist_rec **sub)
+{
+	*sub = nullptr;
+	if (level == 3) {
+		*mode = 0;
+	} else if (level == 0) {
+		// a 5-s ring keeps an add for 5 s: the window closed last, until a window's length has passed without another close
+		if (c->lvl_t_last >= 0 && tq - c->lvl_t_last < LEVEL_SECS[0]) {
+			*mode = 2;
+			*sub = c->lvl_last;
+		} else {
+			*mode = 1;
+		}
+	} else {
+		const int64_t dur = LEVEL_SECS[level];
+		const uint32_t oldest = (level_bucket_idx(tq, dur) + 1u) % GYS_LEVEL_RING;
+		if (c->lvl_t_last < 0 || level_bucket_start(tq, dur, oldest) > c->lvl_t_last) {
+			*mode = 1; // every add is older than the ring's oldest live bucket
+		} else {
+			*mode = 0;
+			*sub = c->lvl_snap + ((uint64_t)(level - 1) * GYS_LEVEL_RING + oldest) * c->cfg.max_services;
+		}
+	}
+}
+
 // device records of one level at time tusec for slots [first, first + n) into d_out
 int level_view(gys_ctx *c, int level, uint64_t tusec, uint32_t first, uint32_t n, gys_hist_rec *d_out)
 {
@@ -988,26 +1014,7 @@ int level_view(gys_ctx *c, int level, uint64_t tusec, uint32_t first, uint32_t n
 	p.first = first;
 	p.n = n;
 	p.out = d_out;
-	if (level == 3) {
-		p.mode = 0;
-	} else if (level == 0) {
-		// a 5-s ring keeps an add for 5 s: the window closed last, until a window's length has passed without another close
-		if (c->lvl_t_last >= 0 && tq - c->lvl_t_last < LEVEL_SECS[0]) {
-			p.mode = 2;
-			p.sub = c->lvl_last;
-		} else {
-			p.mode = 1;
-		}
-	} else {
-		const int64_t dur = LEVEL_SECS[level];
-		const uint32_t oldest = (level_bucket_idx(tq, dur) + 1u) % GYS_LEVEL_RING;
-		if (c->lvl_t_last < 0 || level_bucket_start(tq, dur, oldest) > c->lvl_t_last) {
-			p.mode = 1; // every add is older than the ring's oldest live bucket
-		} else {
-			p.mode = 0;
-			p.sub = c->lvl_snap + ((uint64_t)(level - 1) * GYS_LEVEL_RING + oldest) * c->cfg.max_services;
-		}
-	}
+	level_source(c, level, tq, &p.mode, &p.sub);
 	hipLaunchKernelGGL(k_level_view, dim3((uint32_t)(((uint64_t)n * 16 + 255) / 256)), dim3(256), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
@@ -3472,6 +3479,36 @@ int gys_export_day_stats(gys_ctx *c, uint64_t tusec, uint32_t first_slot, uint32
 	hipFree(lv);
 	hipFree(d_out);
 	return rc;
+}
+
+int gys_scan_listener_state_dev(gys_ctx *c, uint64_t tusec, float qps_multiple, uint32_t diffsec, void *d_notify, gys_listener_scan *d_scan)
+{
+	GYS_ENTER(c);
+	if (!c) return GYS_ERR_INVAL;
+	LEVELS_CHECK();
+	if (!c->nsvc || (!d_notify && !d_scan)) return GYS_OK;
+	int64_t tq = (int64_t)(tusec / 1000000ull);
+	if (tq < c->lvl_t_last) tq = c->lvl_t_last;
+	ListenerScanP p{};
+	p.win = c->hist_win;
+	p.all = c->hist_all;
+	p.meta = c->cfg.enable_tdigest ? c->td_meta : nullptr;
+	p.epoch_open = c->epoch + (c->prepared ? 1u : 0u);
+	p.epoch_last = p.epoch_open - 1u;
+	p.nsvc = c->nsvc;
+	for (int lv = 0; lv < GYS_NLEVELS; ++lv) level_source(c, lv, tq, &p.mode[lv], &p.sub[lv]);
+	p.qps = c->qps_hist;
+	p.act = c->act_hist;
+	p.bitmap = c->bitmap;
+	p.svc_gid = c->svc_gid;
+	p.multiple = qps_multiple;
+	p.diffsec = (float)diffsec;
+	p.notify = (uint8_t *)d_notify;
+	p.scan = d_scan;
+	ProfScope ps(c, "listener_scan");
+	hipLaunchKernelGGL(k_listener_scan, dim3((c->nsvc + 255) / 256), dim3(256), 0, c->stream, p);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
 }
 
 int gys_export_svc_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)

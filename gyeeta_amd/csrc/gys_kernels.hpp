@@ -2687,6 +2687,135 @@ __global__ __launch_bounds__(256) void k_day_stats(const gys_hist_rec *lvl5d, co
 	out[i] = o;
 }
 
+
+// ---------------------------------------------------------------------------------------------------- per-listener 5-second scan (row a9)
+// TCP_SOCK_HANDLER::listener_stats_update (common/gy_socket_stat.cc:4044-4365) walks the listener table every 5 s and turns each
+// listener's counters + histograms into one comm::LISTENER_STATE_NOTIFY; TCP_LISTENER::get_curr_state (:2030-2143) compares the 5-s p95
+// bucket with the 5-min / 5-day ones and the QPS with the QPS histogram's p25 / p95.  Here: one thread per service, everything from the
+// engine's own state -- the four time levels as (cumulative record - ring snapshot) / last closed window, the CONN_BITMAP rows of the
+// window just closed, the per-service QPS / active-connection histograms -- into one 88-byte notify record + one gys_listener_scan
+// record per service.  Nothing is modified.  The state POLICY (task / cpu / memory issue inputs, issue strings) is the caller's.
+struct ListenerScanP {
+	const gys_hist_rec *win, *all;
+	const TdMeta *meta;
+	uint32_t epoch_open; // windows before this one are in the levels
+	uint32_t epoch_last; // the window closed last (its CONN_BITMAP rows are the ones get_conn_breakup sees)
+	uint32_t nsvc;
+	int mode[GYS_NLEVELS];               // per level: 0 cumulative - sub, 1 empty, 2 copy of sub (level 0: the last closed window)
+	const gys_hist_rec *sub[GYS_NLEVELS];
+	const gys_hist_rec *qps, *act;
+	const uint32_t *bitmap;              // [nsvc * 16] u32 = 32 x u16 rows
+	const uint64_t *svc_gid;
+	float multiple;                      // TCP_SOCK_HANDLER::get_bpf_qps_multiple()
+	float diffsec;
+	uint8_t *notify;                     // [nsvc * 88] or nullptr
+	gys_listener_scan *scan;             // [nsvc] or nullptr
+};
+
+__device__ __forceinline__ uint32_t resp_bucketid_from_threshold(const HashDef &d, int64_t thr)
+{
+	for (int i = 0; i < d.nthr; ++i) // get_bucketid_from_threshold common/gy_statistics.h:517-531
+		if (d.thr[i] == thr) return (uint32_t)i + 1u;
+	return thr < 0 ? 0u : (uint32_t)d.nthr + 1u;
+}
+
+__global__ __launch_bounds__(256) void k_listener_scan(ListenerScanP p)
+{
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= p.nsvc) return;
+	const HashDef &dr = hash_def(GYS_RESP_TIME_HASH);
+	gys_listener_scan o;
+	memset(&o, 0, sizeof(o));
+	o.glob_id = p.svc_gid[slot];
+	const bool open_folded = p.meta && p.meta[slot].hw_epoch == p.epoch_open; // the folded part of the OPEN window is in no level yet
+	for (int lv = 0; lv < GYS_NLEVELS; ++lv) {
+		gys_hist_rec r;
+		int64_t ts = 0;
+		uint64_t tc = 0;
+		for (int b = 0; b < 15; ++b) {
+			uint64_t cnt = 0;
+			int64_t sum = 0;
+			if (p.mode[lv] == 2) {
+				cnt = p.sub[lv][slot].stats[b].count;
+				sum = p.sub[lv][slot].stats[b].sum;
+			} else if (p.mode[lv] == 0) {
+				cnt = p.all[slot].stats[b].count;
+				sum = p.all[slot].stats[b].sum;
+				if (open_folded) {
+					cnt -= p.win[slot].stats[b].count;
+					sum -= p.win[slot].stats[b].sum;
+				}
+				if (p.sub[lv]) {
+					cnt -= p.sub[lv][slot].stats[b].count;
+					sum -= p.sub[lv][slot].stats[b].sum;
+				}
+			}
+			r.stats[b].count = cnt;
+			r.stats[b].sum = sum;
+			tc += cnt;
+			ts += sum;
+		}
+		r.total_count = tc;
+		r.max_val_seen = 0;
+		o.tcount[lv] = (int64_t)tc; // slabhist.count(level) / sum(level), common/gy_statistics.h:1358-1359
+		o.tsum[lv] = ts;
+		o.p95_ms[lv] = (int32_t)level_percentile(dr, r, 95.0f); // RESP_STATS::stats_ {95, 99, 25}, common/gy_socket_stat.h:459-462
+		o.p99_ms[lv] = (int32_t)level_percentile(dr, r, 99.0f);
+		o.p25_ms[lv] = (int32_t)level_percentile(dr, r, 25.0f);
+	}
+	// total_queries = the listener's query counter over the interval (:4051-4052), one per response event that reached the histogram
+	// (:1581) = the 5-s level's count; curr_qps_extra = total_queries * multiple_factor / diffsec (:4109)
+	const uint32_t total_queries = (uint32_t)o.tcount[0];
+	o.last_qps = p.diffsec > 0.f ? (int32_t)((float)total_queries * p.multiple / p.diffsec) : 0;
+	{
+		const int32_t q5 = (int32_t)(o.tcount[0] / 5);
+		o.curr_qps = o.last_qps > q5 ? o.last_qps : q5; // :2083
+	}
+	o.b5 = (uint8_t)resp_bucketid_from_threshold(dr, o.p95_ms[0]); // :2085-2087
+	o.b300 = (uint8_t)resp_bucketid_from_threshold(dr, o.p95_ms[1]);
+	o.b5day = (uint8_t)resp_bucketid_from_threshold(dr, o.p95_ms[2]);
+	if (p.qps) { // HIST_DATA stats_qps[] {95, 25}, stats_active[] {95, 25} (:2053, :2089-2090)
+		int64_t dv, sum;
+		uint64_t cnt;
+		const gys_hist_rec q = p.qps[slot];
+		hist_percentile(hash_def(GYS_SEMI_LOG_HASH_LO), q, 95.0f, &dv, &sum, &cnt);
+		o.qps_p95 = (int32_t)dv;
+		hist_percentile(hash_def(GYS_SEMI_LOG_HASH_LO), q, 25.0f, &dv, &sum, &cnt);
+		o.qps_p25 = (int32_t)dv;
+		const gys_hist_rec a = p.act[slot];
+		hist_percentile(hash_def(GYS_HASH_1_3000), a, 95.0f, &dv, &sum, &cnt);
+		o.act_p95 = (int32_t)dv;
+		hist_percentile(hash_def(GYS_HASH_1_3000), a, 25.0f, &dv, &sum, &cnt);
+		o.act_p25 = (int32_t)dv;
+	}
+	// CONN_BITMAP::get_conn_breakup (common/gy_socket_stat.h:413-429): per response bucket the rows (client port & 31) that saw it in
+	// the window just closed; curr_active_conn = their maximum (:4143-4156; the inet_diag count it starts from is agent-side state)
+	if (p.meta ? p.meta[slot].hw_epoch == p.epoch_last : true) {
+		uint32_t w[16];
+		for (int i = 0; i < 16; ++i) w[i] = p.bitmap[(size_t)slot * 16u + i];
+		for (int r = 0; r < 15; ++r) {
+			uint32_t n = 0;
+			for (int i = 0; i < 16; ++i) n += ((w[i] >> r) & 1u) + ((w[i] >> (16 + r)) & 1u);
+			o.nactive_conn_arr[r] = (uint8_t)n;
+			if (o.nconn_active < n) o.nconn_active = (uint8_t)n;
+		}
+	}
+	if (p.scan) p.scan[slot] = o;
+	if (p.notify) { // :4293-4304; fields the engine cannot derive stay 0
+		uint32_t *q = (uint32_t *)(p.notify + (size_t)slot * 88u);
+		for (int i = 0; i < 22; ++i) q[i] = 0;
+		q[0] = (uint32_t)o.glob_id;
+		q[1] = (uint32_t)(o.glob_id >> 32);
+		q[2] = (uint32_t)o.tcount[0]; // nqrys_5s_ = histstat_[n5].tcount_
+		q[3] = (uint32_t)o.tsum[0];   // total_resp_5sec_ = histstat_[n5].tsum_
+		q[4] = o.nconn_active;        // nconns_ (not below the active count)
+		q[5] = o.nconn_active;        // nconns_active_ = last_chk_nconn_active_
+		q[7] = (uint32_t)o.p95_ms[0]; // p95_5s_resp_ms_
+		q[8] = (uint32_t)o.p95_ms[1]; // p95_5min_resp_ms_
+		p.notify[(size_t)slot * 88u + 79u] = o.curr_qps == 0 ? 0 /* STATE_IDLE */ : 2 /* STATE_OK */;
+	}
+}
+
 // top-N candidate filter: services of one host whose state is from the last window, with the ranked metric per kind
 // (LISTEN_TOPN comparators + admission thresholds server/gy_msocket.h:740-790, server/gy_mconnhdlr.cc:11260-11304)
 __global__ __launch_bounds__(256) void k_topn_filter(const uint8_t *svc_state, uint32_t nsvc, uint32_t host, uint32_t epoch, int kind,

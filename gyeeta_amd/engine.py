@@ -6,7 +6,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import capi
+from . import capi, wire
 
 _TORCH_DTYPES = None
 
@@ -263,6 +263,24 @@ class SketchEngine:
         self.order()
         capi.check(self.L.gys_scan_quantiles_dev(self.h, qa, len(qs), C.c_void_p(out.data_ptr())))
         return out[:n].cpu().numpy()
+
+    LSCAN_DT = np.dtype([("glob_id", "<u8"), ("tcount", "<i8", 4), ("tsum", "<i8", 4), ("p95_ms", "<i4", 4), ("p99_ms", "<i4", 4), ("p25_ms", "<i4", 4),
+                         ("last_qps", "<i4"), ("curr_qps", "<i4"), ("qps_p95", "<i4"), ("qps_p25", "<i4"), ("act_p95", "<i4"), ("act_p25", "<i4"),
+                         ("b5", "u1"), ("b300", "u1"), ("b5day", "u1"), ("nconn_active", "u1"), ("nactive_conn_arr", "u1", 15), ("reserved", "u1", 5)])
+    assert LSCAN_DT.itemsize == 168
+
+    def scan_listener_state(self, tusec, qps_multiple=1.0, diffsec=5):
+        """the per-listener 5-s scan from the engine's own state (gys_scan_listener_state_dev): (device tensor of the 88-byte
+        LISTENER_STATE_NOTIFY records, the same as a numpy record array, the gys_listener_scan records)"""
+        n = self.num_services()
+        notify = self.torch.zeros(max(n, 1) * 88, dtype=self.torch.uint8, device=self.device)
+        scan = self.torch.zeros(max(n, 1) * self.LSCAN_DT.itemsize, dtype=self.torch.uint8, device=self.device)
+        self.order()
+        capi.check(self.L.gys_scan_listener_state_dev(self.h, int(tusec), float(qps_multiple), int(diffsec), C.c_void_p(notify.data_ptr()),
+                                                      C.c_void_p(scan.data_ptr())))
+        self.sync()
+        return (notify, np.frombuffer(notify.cpu().numpy().tobytes(), dtype=wire.LISTENER_STATE_NOTIFY)[:n],
+                np.frombuffer(scan.cpu().numpy().tobytes(), dtype=self.LSCAN_DT)[:n])
 
     SLAB_DT = np.dtype([("sum", "<i8", capi.TD_NB), ("cnt", "<u8", capi.TD_NB), ("vmin", "<i8"), ("vmax", "<i8")])
 

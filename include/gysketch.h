@@ -420,6 +420,32 @@ enum { GYS_TOP_ISSUE = 1, GYS_TOP_QPS = 2, GYS_TOP_ACTCONN = 4, GYS_TOP_NET = 8,
 int gys_json_toplisteners(gys_ctx *ctx, const uint8_t machine_id[16], uint32_t flags, const char *madhava_id16, const char *timestr, char *buf,
 			  size_t buflen, size_t *needed);
 
+/* The per-listener 5-second scan from the engine's OWN state (needs gys_config.enable_levels): replaces the loop of
+ * TCP_SOCK_HANDLER::listener_stats_update (common/gy_socket_stat.cc:4044-4365) that turns every listener's counters and histograms into
+ * one comm::LISTENER_STATE_NOTIFY (common/gy_comm_proto.h:2183-2254), and the data-parallel part of TCP_LISTENER::get_curr_state
+ * (:2030-2143): the p95 bucket ids of the 5-s / 5-min / 5-day levels and the QPS / active-connection histogram percentiles it compares.
+ * Call it after the window close at `tusec` (level 0 = the window closed last).  One pass over all services, nothing is modified.
+ *   d_notify (device, 88 B x gys_num_services, or NULL): LISTENER_STATE_NOTIFY records with glob_id_, nqrys_5s_ (= the 5-s level's count),
+ *            total_resp_5sec_, nconns_ / nconns_active_ (CONN_BITMAP::get_conn_breakup maximum, common/gy_socket_stat.h:413-429),
+ *            p95_5s_resp_ms_, p95_5min_resp_ms_, curr_state_ (STATE_IDLE when the QPS is 0, else STATE_OK: the state POLICY -- task / cpu /
+ *            memory issue inputs, issue strings -- is not the engine's); every other field 0.  They can be handed to
+ *            gys_ingest_listener_state_dev as they are (host roll-up, top-N, QPS / active-connection histogram samples).
+ *   d_scan   (device, gys_listener_scan x gys_num_services, or NULL).
+ *   qps_multiple = TCP_SOCK_HANDLER::get_bpf_qps_multiple(); diffsec = seconds since the previous scan (:4046, :4109). */
+typedef struct {
+	uint64_t glob_id;
+	int64_t tcount[4], tsum[4];                 /* RESP_STATS::tcount_ / tsum_ of the 5 s / 5 min / 5 d / all-time levels */
+	int32_t p95_ms[4], p99_ms[4], p25_ms[4];    /* RESP_STATS::stats_[0..2].data_value */
+	int32_t last_qps;                           /* total_queries * multiple / diffsec (last_qps_count_) */
+	int32_t curr_qps;                           /* max(last_qps, tcount[0] / 5) */
+	int32_t qps_p95, qps_p25, act_p95, act_p25; /* GY_HISTOGRAM::get_percentiles {95, 25} of the QPS / active-connection histograms */
+	uint8_t b5, b300, b5day;                    /* get_bucketid_from_threshold<RESP_TIME_HASH>(p95 of the level) */
+	uint8_t nconn_active;                       /* max over nactive_conn_arr */
+	uint8_t nactive_conn_arr[15];               /* CONN_BITMAP::get_conn_breakup of the window closed last */
+	uint8_t reserved[5];
+} gys_listener_scan;
+int gys_scan_listener_state_dev(gys_ctx *ctx, uint64_t tusec, float qps_multiple, uint32_t diffsec, void *d_notify, gys_listener_scan *d_scan);
+
 /* -------------------------------------------------------------------------------------------------------------------
  * parity / checkpoint exports (host destination buffers) -- GY_HISTOGRAM::get_serialized analogue (gy_statistics.h:665-673) */
 uint32_t gys_num_services(gys_ctx *ctx);

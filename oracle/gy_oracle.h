@@ -255,6 +255,22 @@ void gyo_mlh_period(const gyo_mlhist *h, int64_t starttime, int64_t endtime, gyo
 void gyo_mlh_get_stats_for_period(const gyo_mlhist *h, int64_t starttime, int64_t endtime, const float *pcts, size_t npct, int64_t *values,
 				  int64_t *tcount, int64_t *tsum, double *mean);
 
+/* ---------------------------------------------------------------- per-listener 5-s scan (gy_oracle_lscan.c)
+ * the data-parallel part of TCP_SOCK_HANDLER::listener_stats_update + TCP_LISTENER::get_curr_state (common/gy_socket_stat.cc:4044-4365,
+ * :2030-2143); same layout as gys_listener_scan (include/gysketch.h) */
+typedef struct {
+	uint64_t glob_id;
+	int64_t tcount[GYO_MLH_LEVELS], tsum[GYO_MLH_LEVELS];
+	int32_t p95_ms[GYO_MLH_LEVELS], p99_ms[GYO_MLH_LEVELS], p25_ms[GYO_MLH_LEVELS];
+	int32_t last_qps, curr_qps, qps_p95, qps_p25, act_p95, act_p25;
+	uint8_t b5, b300, b5day, nconn_active;
+	uint8_t nactive_conn_arr[15];
+	uint8_t reserved[5];
+} gyo_listener_scan;
+uint32_t gyo_bucketid_from_threshold(int kind, int64_t threshold);
+void gyo_listener_scan_one(const gyo_mlhist *resp, const gyo_hist *qps, const gyo_hist *act, const uint16_t respmap[32], uint64_t glob_id,
+			   float multiple, int64_t diffsec, uint8_t notify[88], gyo_listener_scan *out);
+
 /* BOUNDED_PRIO_QUEUE<uint64_t, greater> (common/gy_statistics.h:356-383): returns retained values sorted descending */
 size_t gyo_topn_u64(const uint64_t *vals, size_t n, size_t maxn, uint64_t *out);
 

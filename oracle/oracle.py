@@ -33,7 +33,7 @@ f32p = C.POINTER(C.c_float)
 HIST_SERIAL_DT = np.dtype([("count", "<u8"), ("sum", "<i8")])  # HIST_SERIAL as a numpy record
 
 
-SOURCES = ["gy_oracle.c", "gy_oracle_engine.c", "gy_oracle_levels.c", "gy_oracle_rollup.c"]
+SOURCES = ["gy_oracle.c", "gy_oracle_engine.c", "gy_oracle_levels.c", "gy_oracle_rollup.c", "gy_oracle_lscan.c"]
 
 
 def build_oracle(force=False):
@@ -84,6 +84,18 @@ class BTS(C.Structure):
 class MLHist(C.Structure):
     _fields_ = [("kind", C.c_int), ("nb", C.c_int), ("s", (BTS * MLH_LEVELS) * MAX_BUCKETS),
                 ("cached_time", C.c_int64 * MAX_BUCKETS), ("cached", HistSerial * MAX_BUCKETS)]
+
+
+class ListenerScan(C.Structure):
+    """gyo_listener_scan == gys_listener_scan (include/gysketch.h)"""
+    _fields_ = [("glob_id", C.c_uint64), ("tcount", C.c_int64 * MLH_LEVELS), ("tsum", C.c_int64 * MLH_LEVELS),
+                ("p95_ms", C.c_int32 * MLH_LEVELS), ("p99_ms", C.c_int32 * MLH_LEVELS), ("p25_ms", C.c_int32 * MLH_LEVELS),
+                ("last_qps", C.c_int32), ("curr_qps", C.c_int32), ("qps_p95", C.c_int32), ("qps_p25", C.c_int32),
+                ("act_p95", C.c_int32), ("act_p25", C.c_int32), ("b5", C.c_uint8), ("b300", C.c_uint8), ("b5day", C.c_uint8),
+                ("nconn_active", C.c_uint8), ("nactive_conn_arr", C.c_uint8 * 15), ("reserved", C.c_uint8 * 5)]
+
+
+assert C.sizeof(ListenerScan) == 168
 
 
 class ListenSummStats(C.Structure):
@@ -196,6 +208,9 @@ def lib():
     _sig(L, "gyo_mlh_level", None, [C.POINTER(MLHist), C.c_int, C.c_void_p])
     _sig(L, "gyo_slab_percentile_idx", C.c_size_t, [u64p, C.c_size_t, C.c_double])
     _sig(L, "gyo_mlh_get_stats", None, [C.POINTER(MLHist), C.c_int, f32p, C.c_size_t, i64p, i64p, i64p, C.POINTER(C.c_double)])
+    _sig(L, "gyo_bucketid_from_threshold", C.c_uint32, [C.c_int, C.c_int64])
+    _sig(L, "gyo_listener_scan_one", None, [C.POINTER(MLHist), C.POINTER(Hist), C.POINTER(Hist), u16p, C.c_uint64, C.c_float, C.c_int64, u8p,
+                                            C.POINTER(ListenerScan)])
     _sig(L, "gyo_mlh_level_for_start", C.c_int, [C.POINTER(MLHist), C.c_int, C.c_int64])
     _sig(L, "gyo_mlh_period", None, [C.POINTER(MLHist), C.c_int64, C.c_int64, C.c_void_p])
     _sig(L, "gyo_mlh_get_stats_for_period", None, [C.POINTER(MLHist), C.c_int64, C.c_int64, f32p, C.c_size_t, i64p, i64p, i64p, C.POINTER(C.c_double)])
@@ -242,6 +257,8 @@ def ref():
     _sig(R, "ref_ns_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, C.c_uint64, C.c_int])
     _sig(R, "ref_pair_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, u8p, C.c_int, C.c_uint16])
     _sig(R, "ref_machine_id_hash", C.c_uint32, [C.c_uint64, C.c_uint64])
+    if hasattr(R, "ref_resp_bucketid_from_threshold"):
+        _sig(R, "ref_resp_bucketid_from_threshold", C.c_size_t, [C.c_int64])
     if hasattr(R, "ref_comm_sizeof"):
         _sig(R, "ref_comm_nfields", C.c_int, [])
         _sig(R, "ref_comm_field_name", C.c_char_p, [C.c_int])

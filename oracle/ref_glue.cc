@@ -167,6 +167,10 @@ uint32_t ref_machine_id_hash(uint64_t first, uint64_t second)
 	return jhash2((uint32_t *)(&machid), sizeof(machid) / sizeof(uint32_t), 0xceedfead);
 }
 
+// get_bucketid_from_threshold<RESP_TIME_HASH> (common/gy_statistics.h:517-531): what TCP_LISTENER::get_curr_state compares
+// (common/gy_socket_stat.cc:2085-2087)
+size_t ref_resp_bucketid_from_threshold(int64_t threshold) { return get_bucketid_from_threshold<RESP_TIME_HASH>(threshold); }
+
 size_t ref_sizeof(int what)
 {
 	switch (what) {

@@ -209,3 +209,82 @@ def test_window_close_rccl_two_ranks(torch_mod, oracle):
     assert (got["sum"] == np.array(d.sum[:], dtype=np.int64)).all() and (got["cnt"] == np.array(d.cnt[:], dtype=np.uint64)).all()
     assert int(got["vmin"]) == d.vmin and int(got["vmax"]) == d.vmax
     single.close()
+
+
+# ------------------------------------------------------------------------------------------------ the per-listener 5-s scan (row a9)
+def test_listener_state_scan_from_engine_state_end_to_end(torch_mod, oracle):
+    """gys_scan_listener_state_dev (TCP_SOCK_HANDLER::listener_stats_update + the data-parallel part of TCP_LISTENER::get_curr_state,
+    common/gy_socket_stat.cc:4044-4365, :2030-2143): raw response events in, one LISTENER_STATE_NOTIFY + one scan record per service out
+    of the engine's own state, equal field by field to the oracle's restatement (oracle/gy_oracle_lscan.c) driven by the folly-style
+    ring oracle, the oracle's CONN_BITMAP and its QPS / active-connection histograms; the records are then fed to
+    gys_ingest_listener_state_dev, so that raw events -> gys_json_svcstate / the host summary is one path end to end."""
+    import ctypes as C
+    import json
+    from gyeeta_amd import capi
+    from tests.test_gpu_levels import T0, RingOracle
+    rng = np.random.default_rng(909)
+    nh, sp = 3, 7
+    nsvc = nh * sp
+    eng = _engine(max_hosts=4, max_services=32, max_batch_events=1 << 15, enable_tdigest=True, enable_levels=True)
+    orc_win = oracle.OracleEngine(32, enable_td=False)  # cleared at every close: the closing window's histograms and CONN_BITMAP rows
+    info, gids = helpers.register_world(eng, orc_win, range(nh), sp)
+    ring = RingOracle(oracle, nsvc)
+    L = oracle.lib()
+    qps_h = [oracle.Hist() for _ in range(nsvc)]
+    act_h = [oracle.Hist() for _ in range(nsvc)]
+    for s in range(nsvc):
+        L.gyo_hist_init(C.byref(qps_h[s]), oracle.KINDS["SEMI_LOG_HASH_LO"])
+        L.gyo_hist_init(C.byref(act_h[s]), oracle.KINDS["HASH_1_3000"])
+    mult = 1.0
+    steps = [5] * 8 + [30, 5, 5, 301, 5, 5, 6, 5]
+    t = T0
+    for w, dt in enumerate(steps):
+        t += dt
+        for h in range(nh):
+            if w % 5 == 3 and h == 1:
+                continue  # a silent host this window: its services report zero queries
+            n = int(rng.integers(50, 3000))
+            ev = helpers.make_resp_events(rng, h, n, int(rng.integers(2, sp + 1)), lat_mu=1.5 + 0.25 * (w % 9))
+            eng.handle_resp_events(info[h][0], ev)
+            orc_win.resp_batch(ev.tobytes(), [info[h][1]], [0])
+        win = np.array(orc_win.hist()[:nsvc])
+        rows = orc_win.bitmap()[:nsvc]
+        eng.window_close(t * 1_000_000)
+        ring.close(t, win)
+        dev_notify, notify, scan = eng.scan_listener_state(t * 1_000_000, qps_multiple=mult, diffsec=dt)
+        for s in range(nsvc):
+            hc = oracle.MLHist.from_buffer_copy(ring.h[s])
+            L.gyo_mlh_flush(C.byref(hc), t)
+            want_n = np.zeros(88, dtype=np.uint8)
+            want = oracle.ListenerScan()
+            rr = np.ascontiguousarray(rows[s])
+            L.gyo_listener_scan_one(C.byref(hc), C.byref(qps_h[s]), C.byref(act_h[s]), oracle.ptr(rr, oracle.u16p), int(gids[s // sp][s % sp]),
+                                    mult, dt, oracle.ptr(want_n, oracle.u8p), C.byref(want))
+            got = scan[s]
+            assert int(got["glob_id"]) == want.glob_id
+            for f in ("tcount", "tsum", "p95_ms", "p99_ms", "p25_ms"):
+                assert got[f].tolist() == list(getattr(want, f)), (w, s, f, got[f].tolist(), list(getattr(want, f)))
+            for f in ("last_qps", "curr_qps", "qps_p95", "qps_p25", "act_p95", "act_p25", "b5", "b300", "b5day", "nconn_active"):
+                assert int(got[f]) == getattr(want, f), (w, s, f, int(got[f]), getattr(want, f))
+            assert got["nactive_conn_arr"].tolist() == list(want.nactive_conn_arr), (w, s)
+            assert notify[s].tobytes() == want_n.tobytes(), (w, s)
+        assert (scan["tcount"][:, 0] == win[:, 15, 0]).all()  # nqrys_5s_ of a service = the response events of its closed window
+        # feed the engine's own records back: host roll-up + top-N + the QPS / active-connection samples (k_lstate_ingest)
+        off = eng.torch.arange(0, nsvc * 88, 88, dtype=eng.torch.int32, device="cuda")
+        hostl = eng.torch.from_numpy(np.repeat(np.array([info[h][1] for h in range(nh)], dtype=np.int32), sp)).cuda()
+        capi.check(eng.L.gys_ingest_listener_state_dev(eng.h, C.c_void_p(dev_notify.data_ptr()), C.c_void_p(off.data_ptr()), C.c_void_p(hostl.data_ptr()), nsvc))
+        for s in range(nsvc):  # TCP_LISTENER histograms take one sample per record: nqrys_5s_ / 5 and nconns_active_ (k_lstate_ingest)
+            L.gyo_hist_add(C.byref(qps_h[s]), int(notify["nqrys_5s"][s]) // 5)
+            L.gyo_hist_add(C.byref(act_h[s]), int(notify["nconns_active"][s]))
+        orc_win.window_clear(clear_hist=True)
+    # the records of the last scan are what the web query shows after the next close
+    eng.window_close((t + 5) * 1_000_000)
+    for h in range(nh):
+        js = json.loads(eng.json_svcstate(info[h][0]))
+        by_id = {r["svcid"]: r for r in js["svcstate"]}
+        for k in range(sp):
+            s = h * sp + k
+            r = by_id["%016x" % int(gids[h][k])]
+            assert r["qps5s"] == int(notify["nqrys_5s"][s]) // 5 and r["p95resp5s"] == int(notify["p95_5s_resp_ms"][s])
+            assert r["nactive"] == int(notify["nconns_active"][s])
+    eng.close()
