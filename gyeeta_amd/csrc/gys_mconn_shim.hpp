@@ -14,6 +14,10 @@
 //   void send_cluster_state() noexcept                                                    :2155  send_cluster_state_rccl(tusec) (RCCL inside the library) / send_cluster_state(tusec, reduce_cb)
 //   TCP_SOCK_HANDLER::handle_ipv4_resp_event(tcp_ipv4_resp_event_t*, bool) (gy_socket_stat.cc:1517)  handle_ipv4_resp_events(machine_id, pevents, n)
 //   web_curr_listener_summ (server/gy_mnodehandle.cc:1628)                                       get_listener_summ(machine_id, out)
+//   bool handle_partha_active_conns(const std::shared_ptr<PARTHA_INFO>&, const comm::ACTIVE_CONN_STATS*,  handle_partha_active_conns(machine_id, pconn, nitems, pendptr)
+//                             int nitems, uint8_t *pendptr, PGConnPool&)                 :2039 (.cc:7705, dispatch :5244)
+//   bool web_curr_top_listeners(...) (server/gy_mnodehandle.cc:2706)                             web_curr_top_listeners(machine_id | nullptr, flags, madid, timestr, out)
+//   TCP_SOCK_HANDLER::listener_stats_update(servshr, cpu_issue, mem_issue) (common/gy_socket_stat.cc:3895) listener_stats_update(tnow, qps_multiple, diffsec, d_notify, d_scan)
 //
 // PARTHA_INFO is identified by its GY_MACHINE_ID (PARTHA_INFO::machine_id_, the key of partha_tbl_).
 #pragma once
@@ -90,6 +94,14 @@ public:
 		const bool ok = gys_ingest_comm_stream(ctx_, machine_id, pbuf, nbytes, &st) == GYS_OK;
 		if (nconsumed) *nconsumed = st.bytes_consumed;
 		return ok;
+	}
+
+	// MCONN_HANDLER::handle_partha_active_conns (gy_mconnhdlr.cc:7705-7772, L2 dispatch :5244): a partha's 15-s ACTIVE_CONN_STATS rows
+	bool handle_partha_active_conns(const uint8_t machine_id[16], const void *pconn, int nitems, const uint8_t *pendptr) noexcept
+	{
+		if (!pconn || nitems < 0) return false;
+		std::shared_lock<std::shared_mutex> g(mu_);
+		return gys_ingest_active_conns(ctx_, machine_id, pconn, (uint32_t)nitems, pendptr) == GYS_OK;
 	}
 
 	// comm::HOST_STATE_NOTIFY store read by send_cluster_state (gy_mconnhdlr.cc:16052-16075)
@@ -183,6 +195,20 @@ public:
 	bool web_curr_listener_state(const uint8_t machine_id[16], const char *madid, const char *timestr, std::string &out) noexcept
 	{
 		return json_call(out, [&](char *b, size_t n, size_t *need) { return gys_json_svcstate(ctx_, machine_id, madid, timestr, b, n, need); });
+	}
+	// MCONN_HANDLER::web_curr_top_listeners (server/gy_mnodehandle.cc:2706-3190): machine_id = one partha's four top-10 queues,
+	// nullptr = every host's queues merged into MAX_MULTI_TOPN = 50 slots per kind; flags: GYS_TOP_* (which arrays to send)
+	bool web_curr_top_listeners(const uint8_t *machine_id, uint32_t flags, const char *madid, const char *timestr, std::string &out) noexcept
+	{
+		return json_call(out, [&](char *b, size_t n, size_t *need) { return gys_json_toplisteners(ctx_, machine_id, flags, madid, timestr, b, n, need); });
+	}
+	// TCP_SOCK_HANDLER::listener_stats_update (common/gy_socket_stat.cc:3895-4380): the 5-s walk over every listener, from the engine's
+	// own state: d_notify = device buffer of 88 B x services (LISTENER_STATE_NOTIFY records, ready for partha_listener_state's device
+	// form), d_scan = gys_listener_scan x services; either may be nullptr.  Needs gys_config.enable_levels.
+	bool listener_stats_update(time_t tnow, float qps_multiple, uint32_t diffsec, void *d_notify, gys_listener_scan *d_scan) noexcept
+	{
+		std::unique_lock<std::shared_mutex> g(mu_);
+		return gys_scan_listener_state_dev(ctx_, (uint64_t)tnow * 1000000ull, qps_multiple, diffsec, d_notify, d_scan) == GYS_OK;
 	}
 	bool web_curr_clusterstate(const char *shyamaid, const char *timestr, std::string &out) noexcept
 	{

@@ -129,8 +129,14 @@ int gys_register_listeners(gys_ctx *ctx, const uint8_t machine_id[16], const gys
  *
  * Host-pointer entry points (gys_ingest_resp_events, gys_ingest_tcp_conn, gys_ingest_listener_state): the caller's buffer is only
  * read DURING the call (the reference's pone points into the L1 receive buffer, freed after the dispatch switch) and
- * the call does NOT wait for the GPU: the records are copied into a slot of a ring of 16 pinned staging buffers, one H2D copy and
- * the ingest kernels are enqueued, and the call returns; a slot is reused once the event recorded behind its kernels has fired.
+ * the call does NOT wait for the GPU: the records are copied into a slot of a ring of 16 pinned staging buffers (handed out oldest
+ * first), one H2D copy and the ingest kernels are enqueued, and the call returns; a slot is reused once the event recorded behind its
+ * kernels has fired (gys_counters.stage_waits counts the calls that had to wait for that).  gys_ingest_resp_events goes through a
+ * SUBMISSION QUEUE instead: the calls of all threads are concatenated into one pinned batch (a segment per call) and handed to the
+ * response pipeline together -- a lone caller's call is submitted at once, the calls that arrive while a submission is being enqueued
+ * form the next one (group commit; a host appears at most once per combined batch and batches are submitted in the order they were
+ * sealed, so every service sees its per-call value multisets in call order and the state is bit-identical to per-call ingestion).
+ * A call may therefore return before its events are on the stream; every other entry point puts the queue's content on the stream first.
  * These three calls may be made concurrently from several threads (up to the reference's MAX_L2_MISC_THREADS = 16,
  * server/gy_mconnhdlr.h:60) on the same context.  Everything else -- registration, the _dev entry points, the wire front end, the
  * window boundary, queries and exports -- must not run concurrently with any other call on the context (gys_mconn_shim.hpp holds a
@@ -154,9 +160,11 @@ int gys_ingest_resp_events_dev(gys_ctx *ctx, const gys_resp_seg *segs, uint32_t 
 /* Replaces MCONN_HANDLER::partha_tcp_conn_info(partha, TCP_CONN_NOTIFY *pone, int nconns, uint8_t *pendptr, ...)
  * (server/gy_mconnhdlr.h:2091, .cc:9052-9444): flow key PAIR_IP_PORT(nat_cli_, nat_ser_) (.cc:8707) -> distinct-flow HLL;
  * per-service connection / byte counters (connlistenmap_ roll-up .cc:9133-9319) -> exact per-service counters + CMS.
- * nconns is an UPPER BOUND, exactly as in the reference's L2 loop `for (i < nconns && p < pendptr)` (.cc:9130, :11175): records that
- * do not fit before `pend` are not an error here (L1 already validated the message); the wire front end gys_ingest_comm_stream
- * applies the L1 validators' own rule (every announced record must be present, common/gy_comm_proto.cc:880, :995). */
+ * The batch is walked like the reference's L2 loop `for (i < nconns && p < pendptr; p += get_elem_size())` (.cc:9130, :11175) under the
+ * L1 validators' rule (TCP_CONN_NOTIFY::validate / LISTENER_STATE_NOTIFY::validate, common/gy_comm_proto.cc:859-880, :974-995: the L2
+ * loop only ever sees messages that passed it): every one of the nconns announced records lies complete before `pend` and has a size
+ * that is a multiple of 8; otherwise GYS_ERR_INVAL and nothing of the batch is ingested.  `pend` must not be NULL.  (The wire front end
+ * gys_ingest_comm_stream applies the same rule on the GPU.) */
 int gys_ingest_tcp_conn(gys_ctx *ctx, const uint8_t machine_id[16], const void *batch, uint32_t nconns, const void *pend);
 /* device-resident: d_offsets[i] = byte offset of record i inside d_batch (records are variable stride: get_elem_size()) */
 int gys_ingest_tcp_conn_dev(gys_ctx *ctx, const void *d_batch, const uint32_t *d_offsets, uint32_t nconns);

@@ -18,6 +18,18 @@ struct ListenerStateNotify { // comm::LISTENER_STATE_NOTIFY, 88 bytes (common/gy
 };
 #pragma pack(pop)
 static_assert(sizeof(ListenerStateNotify) == 88, "LISTENER_STATE_NOTIFY is 88 bytes");
+#pragma pack(push, 1)
+struct ActiveConnStats { // comm::ACTIVE_CONN_STATS, 104 bytes (common/gy_comm_proto.h:2766-2783)
+	uint64_t listener_glob_id, cli_aggr_task_id;
+	char ser_comm[16], cli_comm[16];
+	uint64_t remote_machine_id[2], remote_madhava_id, bytes_sent, bytes_received;
+	uint32_t cli_delay_msec, ser_delay_msec;
+	float max_rtt_msec;
+	uint16_t active_conns;
+	uint8_t flags, tail;
+};
+#pragma pack(pop)
+static_assert(sizeof(ActiveConnStats) == 104, "ACTIVE_CONN_STATS is 104 bytes");
 
 int main(int argc, char **argv)
 {
@@ -148,6 +160,48 @@ int main(int argc, char **argv)
 			fprintf(stderr, "day stats: gid %llx p95_qps %u p95_nactive %u\n", (unsigned long long)ds[9].glob_id, ds[9].p95_qps, ds[9].p95_nactive);
 			return 17;
 		}
+	}
+	// MCONN_HANDLER::handle_partha_active_conns (gy_mconnhdlr.cc:7705): three rows of listener 0x1002, one of them on another madhava
+	{
+		alignas(8) ActiveConnStats rows[3];
+		memset(rows, 0, sizeof(rows));
+		for (int i = 0; i < 3; ++i) {
+			rows[i].listener_glob_id = 0x1002;
+			rows[i].cli_aggr_task_id = 0x77;
+			rows[i].bytes_sent = 1000;
+			rows[i].bytes_received = 500;
+			rows[i].active_conns = 4;
+		}
+		rows[2].flags = 2; // is_remote_listen_: counted, not rolled up
+		fprintf(stderr, "[shim] active conns\n");
+		if (!h.handle_partha_active_conns(mid, rows, 3, (const uint8_t *)(rows + 3))) return 23;
+		if (h.handle_partha_active_conns(other, rows, 3, (const uint8_t *)(rows + 3))) return 24; // unknown partha
+		h.send_cluster_state(15000000);
+		uint64_t conns = 0, bytes = 0;
+		if (gys_query_pair_cms(h.ctx(), 0x1002, 0x77, 0, &conns) != GYS_OK || gys_query_pair_cms(h.ctx(), 0x1002, 0x77, 1, &bytes) != GYS_OK) return 25;
+		gys_counters ctr{};
+		if (gys_get_counters(h.ctx(), &ctr) != GYS_OK) return 26;
+		if (conns != 8 || bytes != 3000 || ctr.actconn_records != 2 || ctr.actconn_remote_listen != 1) {
+			fprintf(stderr, "active conns: conns %llu bytes %llu local %llu remote %llu\n", (unsigned long long)conns, (unsigned long long)bytes,
+				(unsigned long long)ctr.actconn_records, (unsigned long long)ctr.actconn_remote_listen);
+			return 27;
+		}
+	}
+	// MCONN_HANDLER::web_curr_top_listeners (gy_mnodehandle.cc:2706): the window closed above carried no listener records -> fresh ones
+	{
+		if (!h.partha_listener_state(mid, recs, 10, (const uint8_t *)(recs + 10)) || !h.partha_host_state(mid, st)) return 28;
+		h.send_cluster_state(20000000);
+		std::string js;
+		fprintf(stderr, "[shim] top listeners\n");
+		if (!h.web_curr_top_listeners(mid, GYS_TOP_QPS | GYS_TOP_SUMMSTATS, "00112233aabbccdd", "", js)) return 29;
+		// top QPS of the host: service 9 (nqrys_5s 63 -> 12 qps) first
+		const size_t at = js.find("\"topqps\":[{");
+		if (at == std::string::npos || js.find("\"svcid\":\"0000000000001009\"", at) != js.find("\"svcid\":", at) || js.find("\"summstats\"") == std::string::npos ||
+		    js.find("\"topissue\"") != std::string::npos) {
+			fprintf(stderr, "unexpected top listeners json: %s\n", js.c_str());
+			return 30;
+		}
+		if (!h.web_curr_top_listeners(nullptr, GYS_TOP_QPS, "00112233aabbccdd", "", js) || js.find("\"topqps\":[{") == std::string::npos) return 31; // all hosts
 	}
 	printf("shim ok\n");
 	return 0;
