@@ -269,7 +269,9 @@ struct gys_ctx {
 	// into ONE pinned batch -- a segment per call -- and handed to run_resp_batch together, so that the ~12 launches of a response batch
 	// are paid once per submission instead of once per 65536-event call.  A caller reserves its place under rq.mu, copies outside any
 	// lock, and whoever finds no submission in flight submits what has accumulated (a lone caller submits its own call at once: no added
-	// latency; under load the calls that arrive during one submission form the next).  A host appears at most once per batch (its keys
+	// latency; while GYS_RQ_INFLIGHT submissions are still executing on the GPU, further calls accumulate and go out together as soon as
+	// one of them has finished -- the GPU always has the next submission queued behind the running one, and the fixed launches are
+	// amortised exactly when the GPU is the bottleneck).  A host appears at most once per batch (its keys
 	// see their per-call value multisets in call order: the digests stay bit-identical to per-call ingestion); batches are submitted in
 	// the order they were sealed.
 	struct RespBatch {
@@ -281,11 +283,11 @@ struct gys_ctx {
 		bool sealed = false;
 	};
 	struct RespQ {
-		static constexpr int NB = 4;
+		static constexpr int NB = 6;
 		std::mutex mu;
 		std::condition_variable cv;
 		RespBatch b[NB];
-		std::deque<int> free, sealed; // sealed: awaiting submission, oldest first
+		std::deque<int> free, sealed, inflight; // sealed: awaiting submission, oldest first; inflight: submitted, GPU not done yet
 		int open = -1;
 		bool submitting = false;
 		int async_rc = 0;             // first error of a submission made on behalf of other callers; surfaces at the next call
@@ -1261,9 +1263,22 @@ int rq_submit_one(gys_ctx *c, int bi)
 	return rc;
 }
 
-// With rq.mu held (lk): submit, oldest first, every sealed batch whose writers are done -- and the open batch too when `all` or when it
-// has data, no writer and nothing else is in flight.  Returns the first error of a batch that carried the caller's own data (`mine`),
-// other errors are parked in rq.async_rc.
+constexpr size_t GYS_RQ_INFLIGHT = 2; // submissions executing / queued on the GPU before new calls start to accumulate
+
+// rq.mu held: batches whose kernels have finished go back to the free list
+void rq_reap(gys_ctx *c)
+{
+	gys_ctx::RespQ &q = c->rq;
+	while (!q.inflight.empty() && hipEventQuery(q.b[q.inflight.front()].done) == hipSuccess) {
+		q.free.push_back(q.inflight.front());
+		q.inflight.pop_front();
+	}
+	(void)hipGetLastError(); // (hipErrorNotReady is not an error)
+}
+
+// With rq.mu held (lk): submit, oldest first, every sealed batch whose writers are done -- and the open batch too when `all`, or when it
+// has data, no writer, and fewer than GYS_RQ_INFLIGHT submissions are still on the GPU.  Returns the first error of a batch that
+// carried the caller's own data (`mine`), other errors are parked in rq.async_rc.
 int rq_drain(gys_ctx *c, std::unique_lock<std::mutex> &lk, int mine, bool all)
 {
 	gys_ctx::RespQ &q = c->rq;
@@ -1274,9 +1289,12 @@ int rq_drain(gys_ctx *c, std::unique_lock<std::mutex> &lk, int mine, bool all)
 	}
 	for (;;) {
 		if (q.sealed.empty() && q.open >= 0 && q.b[q.open].fill && q.b[q.open].writers == 0) {
-			q.b[q.open].sealed = true;
-			q.sealed.push_back(q.open);
-			q.open = -1;
+			rq_reap(c);
+			if (all || q.inflight.size() < GYS_RQ_INFLIGHT) {
+				q.b[q.open].sealed = true;
+				q.sealed.push_back(q.open);
+				q.open = -1;
+			}
 		}
 		if (q.sealed.empty()) break;
 		const int bi = q.sealed.front();
@@ -1294,7 +1312,7 @@ int rq_drain(gys_ctx *c, std::unique_lock<std::mutex> &lk, int mine, bool all)
 		q.b[bi].sealed = false;
 		q.b[bi].fill = 0;
 		q.b[bi].segs.clear();
-		q.free.push_back(bi);
+		q.inflight.push_back(bi);
 		q.cv.notify_all();
 		if (rc) {
 			if (bi == mine) my_rc = rc;
@@ -1337,11 +1355,22 @@ int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
 	int bi;
 	for (;;) {
 		if (q.open < 0) {
-			q.cv.wait(lk, [&] { return !q.free.empty(); });
+			rq_reap(c);
+			if (q.free.empty()) {
+				if (!q.inflight.empty()) { // every batch is on the GPU: wait for the oldest (outside the lock), then look again
+					hipEvent_t ev = q.b[q.inflight.front()].done;
+					lk.unlock();
+					(void)hipEventSynchronize(ev);
+					lk.lock();
+				} else {
+					q.cv.wait(lk, [&] { return !q.free.empty() || !q.inflight.empty(); }); // (sealed / being submitted by others)
+				}
+				continue;
+			}
 			bi = q.free.front();
 			q.free.pop_front();
 			gys_ctx::RespBatch &nb = q.b[bi];
-			lk.unlock(); // (allocation / waiting for the batch's previous kernels: outside the lock; the batch is not visible yet)
+			lk.unlock(); // (first-use allocation: outside the lock; the batch is not visible yet)
 			hipError_t e = hipSuccess;
 			if (!nb.h) {
 				nb.cap_events = std::min<uint64_t>(GYS_RQ_EVENTS, std::max<uint64_t>(c->cfg.max_batch_events, 1));
@@ -1349,7 +1378,6 @@ int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
 				if (e == hipSuccess) e = hipMalloc((void **)&nb.d, nb.cap_events * 24);
 				if (e == hipSuccess) e = hipEventCreateWithFlags(&nb.done, hipEventDisableTiming);
 			}
-			if (e == hipSuccess) e = hipEventSynchronize(nb.done);
 			lk.lock();
 			if (e != hipSuccess) {
 				q.free.push_back(bi);

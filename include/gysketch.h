@@ -133,8 +133,9 @@ int gys_register_listeners(gys_ctx *ctx, const uint8_t machine_id[16], const gys
  * first), one H2D copy and the ingest kernels are enqueued, and the call returns; a slot is reused once the event recorded behind its
  * kernels has fired (gys_counters.stage_waits counts the calls that had to wait for that).  gys_ingest_resp_events goes through a
  * SUBMISSION QUEUE instead: the calls of all threads are concatenated into one pinned batch (a segment per call) and handed to the
- * response pipeline together -- a lone caller's call is submitted at once, the calls that arrive while a submission is being enqueued
- * form the next one (group commit; a host appears at most once per combined batch and batches are submitted in the order they were
+ * response pipeline together -- with an idle GPU a call is submitted at once; while two submissions are still executing, further calls
+ * accumulate and go out together as soon as one of them has finished (group commit: the fixed launches of a response batch are paid
+ * once per submission exactly when the GPU is the bottleneck; a host appears at most once per combined batch and batches are submitted in the order they were
  * sealed, so every service sees its per-call value multisets in call order and the state is bit-identical to per-call ingestion).
  * A call may therefore return before its events are on the stream; every other entry point puts the queue's content on the stream first.
  * These three calls may be made concurrently from several threads (up to the reference's MAX_L2_MISC_THREADS = 16,

@@ -72,14 +72,21 @@ def test_resp_calls_from_16_threads_are_combined_and_bit_exact(torch_mod, oracle
     assert 1 <= c["resp_submissions"] <= c["resp_calls_queued"]
     eng.window_close()
     assert (eng.export_hll() == orc.hll()).all() and (eng.export_cms(0) == orc.cms()).all()
-    # a lone caller is submitted at once (no added latency): every call its own submission, results visible after gys_sync
+    orc.window_clear(clear_hist=True)
+    # a lone caller with an idle GPU is submitted at once (no added latency); whatever the queue still holds goes out with the next
+    # entry point that reads or closes state
+    eng.sync()
     before = eng.counters()
-    for r in range(3):
-        eng.handle_resp_events(info[0][0], calls[0][r])
+    eng.handle_resp_events(info[0][0], calls[0][0])
+    orc.resp_batch(calls[0][0].tobytes(), [info[0][1]], [0])
+    assert eng.counters()["resp_submissions"] - before["resp_submissions"] == 1
+    for r in range(1, 4):
+        eng.handle_resp_events(info[0][0], calls[0][r])  # the same host again: every call its own segment of its own batch, in call order
         orc.resp_batch(calls[0][r].tobytes(), [info[0][1]], [0])
-    after = eng.counters()
-    assert after["resp_submissions"] - before["resp_submissions"] == 3
     helpers.assert_hist_equal(eng.export_hist(0, 0, n), orc.hist(), n)
+    gs, gc, gm = eng.export_tdigest(0, n)
+    os_, oc, om = orc.td_arrays()
+    assert (gs == os_).all() and (gc == oc).all() and (gm == om).all()
     eng.close()
 
 
