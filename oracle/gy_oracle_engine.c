@@ -53,9 +53,9 @@ gyo_engine *gyo_engine_new(uint32_t max_services, int enable_td)
 	if (enable_td) {
 		e->td = (gyo_td_buffered *)malloc((size_t)max_services * sizeof(gyo_td_buffered));
 		for (uint32_t s = 0; s < max_services; s++) gyo_tdb_init(&e->td[s]);
-		e->bcnt = (uint32_t *)calloc(max_services, 4);
 		e->boff = (uint32_t *)calloc((size_t)max_services + 1, 4);
 	}
+	e->bcnt = (uint32_t *)calloc(max_services, 4);
 	return e;
 }
 
@@ -98,19 +98,8 @@ typedef struct {
 	gyo_hist_serial *ghist; /* [16] */
 	int64_t *gmax;
 	uint64_t *counters;     /* [4] */
-	int shared;             /* hll / cms are written by several threads at once: register max by CAS, counter add atomically
-	                           (max and + commute, so the registers end up exactly as in the sequential loop) */
+	int shared;             /* unused (every sink is private to its thread) */
 } resp_sinks;
-
-static void hll_add_shared(uint8_t *regs, const uint32_t *words, uint32_t nwords)
-{
-	uint32_t idx;
-	uint8_t rank;
-	gyo_hll_idx_rank(gyo_hash64(words, nwords), GYO_HLL_P, &idx, &rank);
-	uint8_t cur = __atomic_load_n(&regs[idx], __ATOMIC_RELAXED);
-	while (cur < rank && !__atomic_compare_exchange_n(&regs[idx], &cur, rank, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
-	}
-}
 
 static void cms_add_shared(uint32_t *tbl, const uint32_t *words, uint32_t nwords, uint32_t weight)
 {
@@ -164,21 +153,29 @@ static void resp_range(gyo_engine *e, const uint8_t *ev24, uint64_t i0, uint64_t
 		{
 			uint32_t w[10];
 			const uint32_t nw = gyo_pair_ip_port_words((const uint8_t *)&daddr, 0, dport, (const uint8_t *)&saddr, 0, sport, w);
-			if (k.shared) hll_add_shared(k.hll, w, nw);
-			else gyo_hll_add_words(k.hll, GYO_HLL_P, w, nw);
+			gyo_hll_add_words(k.hll, GYO_HLL_P, w, nw);
 		}
-		{
-			uint32_t gw[2];
-			gw[0] = (uint32_t)(e->svc_gid[slot] & 0xFFFFFFFFu);
-			gw[1] = (uint32_t)(e->svc_gid[slot] >> 32);
-			if (k.shared) cms_add_shared(k.cms, gw, 2, 1);
-			else gyo_cms_add(k.cms, gw, 2, 1);
-		}
+		/* Count-Min of events per service key: the table is linear in the per-service counts, so the event only counts (the
+		 * service's record is owned by this thread) and the rows are built once per batch from the counts (cms_from_counts):
+		 * the same registers as one gyo_cms_add(key, 1) per event, without four hashes and four shared counters per event */
+		e->bcnt[slot]++;
 		if (slot_of) {
 			slot_of[i] = slot;
 			val_of[i] = (int32_t)tresp;
-			e->bcnt[slot]++;
 		}
+	}
+}
+
+/* rows of the Count-Min table from the batch's per-service event counts, services [k0, k1); shared: several threads add at once */
+static void cms_from_counts(gyo_engine *e, uint32_t k0, uint32_t k1, int shared)
+{
+	for (uint32_t s = k0; s < k1; s++) {
+		if (!e->bcnt[s]) continue;
+		uint32_t gw[2];
+		gw[0] = (uint32_t)(e->svc_gid[s] & 0xFFFFFFFFu);
+		gw[1] = (uint32_t)(e->svc_gid[s] >> 32);
+		if (shared) cms_add_shared(e->cms, gw, 2, e->bcnt[s]);
+		else gyo_cms_add(e->cms, gw, 2, e->bcnt[s]);
 	}
 }
 
@@ -198,9 +195,10 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 	if (e->enable_td) {
 		slot_of = (uint32_t *)malloc((size_t)(n ? n : 1) * 4);
 		val_of = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
-		memset(e->bcnt, 0, (size_t)e->nsvc * 4);
 	}
+	memset(e->bcnt, 0, (size_t)e->nsvc * 4);
 	resp_range(e, ev24, 0, n, seg_host, seg_first, nsegs, 0, slot_of, val_of, own_sinks(e));
+	cms_from_counts(e, 0, e->nsvc, 0);
 	if (e->enable_td) {
 		/* buffered digest(key) <- add_batch(multiset of this batch's values of the key): append, or one merge of buffer + batch */
 		int32_t *staged = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
@@ -225,10 +223,11 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 
 /* The same batch on nthreads host threads ("all cores" CPU baseline): the segments (hosts) are cut into contiguous ranges, one per
  * thread -- the reference pins a partha's batches to one L2 thread the same way (server/gy_mconnhdlr.cc:16252).  Every segment must
- * be a different host (a service's records are then owned by one thread); the HLL registers and Count-Min counters shared between
- * services are updated atomically (CAS max / fetch-add: order free), the all-service histogram and the counters are kept per thread
- * and summed at the end, the per-service digests are re-clustered in parallel over service ranges.  The resulting state is identical
- * to gyo_engine_resp_batch's. */
+ * be a different host (a service's records are then owned by one thread).  Nothing shared is touched per event: every thread keeps
+ * PRIVATE HyperLogLog registers (merged by max at the end), its own all-service histogram and counters (summed at the end), the events
+ * only count per service and the Count-Min rows are built from those counts afterwards, in parallel over service ranges -- what the GPU
+ * does per workgroup.  The per-service digests are re-clustered in parallel over service ranges.  The resulting state is identical to
+ * gyo_engine_resp_batch's. */
 typedef struct {
 	gyo_engine *e;
 	const uint8_t *ev24;
@@ -243,6 +242,7 @@ typedef struct {
 	uint64_t counters[4];
 	uint32_t k0, k1; /* service range of the digest phase */
 	const uint32_t *kstart;
+	uint8_t *hll;    /* the thread's PRIVATE HyperLogLog registers (16 KiB), merged by max at the end of the pass */
 } mt_worker;
 
 static void *mt_pass1(void *arg)
@@ -250,8 +250,15 @@ static void *mt_pass1(void *arg)
 	mt_worker *w = (mt_worker *)arg;
 	if (w->s0 >= w->s1) return NULL;
 	const uint64_t i0 = w->seg_first[w->s0], i1 = w->s1 < w->nsegs ? w->seg_first[w->s1] : w->n;
-	resp_sinks k = {w->e->hll, w->e->cms, w->ghist, &w->gmax, w->counters, 1};
+	resp_sinks k = {w->hll, w->e->cms, w->ghist, &w->gmax, w->counters, 0};
 	resp_range(w->e, w->ev24, i0, i1, w->seg_host, w->seg_first, w->nsegs, w->s0, w->slot_of, w->val_of, k);
+	return NULL;
+}
+
+static void *mt_cms(void *arg) /* Count-Min rows from the per-service counts, in parallel over service ranges (one add per service and row) */
+{
+	mt_worker *w = (mt_worker *)arg;
+	cms_from_counts(w->e, w->k0, w->k1, 1);
 	return NULL;
 }
 
@@ -298,8 +305,9 @@ void gyo_engine_resp_batch_mt(gyo_engine *e, const uint8_t *ev24, uint64_t n, co
 		val_of = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
 		staged = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
 		kstart = (uint32_t *)malloc(((size_t)e->nsvc + 1) * 4);
-		memset(e->bcnt, 0, (size_t)e->nsvc * 4);
 	}
+	memset(e->bcnt, 0, (size_t)e->nsvc * 4);
+	uint8_t *hll_all = (uint8_t *)calloc((size_t)nthreads, GYO_HLL_M);
 	mt_worker *w = (mt_worker *)calloc(nthreads, sizeof(mt_worker));
 	for (uint32_t t = 0; t < nthreads; t++) {
 		w[t].e = e;
@@ -317,8 +325,12 @@ void gyo_engine_resp_batch_mt(gyo_engine *e, const uint8_t *ev24, uint64_t n, co
 		w[t].k0 = (uint32_t)((uint64_t)e->nsvc * t / nthreads);
 		w[t].k1 = (uint32_t)((uint64_t)e->nsvc * (t + 1) / nthreads);
 		w[t].kstart = kstart;
+		w[t].hll = hll_all + (size_t)t * GYO_HLL_M;
 	}
 	run_all(w, nthreads, mt_pass1);
+	run_all(w, nthreads, mt_cms);
+	for (uint32_t t = 0; t < nthreads; t++) gyo_hll_merge(e->hll, w[t].hll, GYO_HLL_P);
+	free(hll_all);
 	for (uint32_t t = 0; t < nthreads; t++) { /* the small per-thread registers: sums / max, independent of the order */
 		for (int b = 0; b < 16; b++) {
 			e->ghist[b].count += w[t].ghist[b].count;
