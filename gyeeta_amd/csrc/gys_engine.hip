@@ -766,22 +766,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		// 512 threads x 12 events: two workgroups per CU when the host's tables leave room (<= 78 KiB per workgroup with the static part)
 		tpt12 = tpt == 12 && (uint64_t)max_tbl * 8 + (uint64_t)hp.lds_key_entries * 24 + 6144u * 6u <= 77u * 1024u;
 		dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_key_entries * 24 + (size_t)(tpt12 ? 6144u : tpt16 ? 16384u : 8192u) * 6u;
-		// experiment (GYS_RESP_DIRECT = 256 / 512 / 1024 threads): the direct-append form of the host-local front end (k_resp_direct)
-		static const int direct_nt = [] { const char *e = getenv("GYS_RESP_DIRECT"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 0; }();
-		if (direct_nt && !host_split && max_len <= (1u << 20)) {
-			ProfScope ps(c, "resp_host");
-			const size_t ddyn = (size_t)max_tbl * 8 + (size_t)hp.lds_key_entries * 8;
-			const bool sh = hp.svc_hll_p != 0;
-#define GYS_LAUNCH_DIRECT(NT)                                                                                                   \
-	do {                                                                                                                \
-		if (sh) hipLaunchKernelGGL((k_resp_direct<NT, true>), dim3(hgrid), dim3(NT), ddyn, c->stream, hp);          \
-		else hipLaunchKernelGGL((k_resp_direct<NT, false>), dim3(hgrid), dim3(NT), ddyn, c->stream, hp);             \
-	} while (0)
-			if (direct_nt == 256) GYS_LAUNCH_DIRECT(256);
-			else if (direct_nt == 512) GYS_LAUNCH_DIRECT(512);
-			else GYS_LAUNCH_DIRECT(1024);
-#undef GYS_LAUNCH_DIRECT
-		} else {
+		{
 			ProfScope ps(c, "resp_host");
 			if (host_split) {
 				if (tpt12) launch_resp_host<12, true, false>(c, hgrid, dyn, hp);

@@ -514,10 +514,10 @@ __global__ __launch_bounds__(256) void k_cms_reduce(const uint32_t *partial, uin
 //   SHARED: several workgroups may hold events of the same host (long segments cut into parts, a host named by two segments): buffer
 //           space is reserved with one device atomic per (tile, key) instead of an LDS cursor.
 //   SPILL:  second pass over the hosts that have spilled keys: only those keys' events, into their runs in `staged`.
-// RESP_TIME_HASH bucket of a response time through a 1 KiB LDS table (experiment GYS_BUCKET_LUT): values below 1024 -- eleven of the
+// RESP_TIME_HASH bucket of a response time through a 1 KiB LDS table (GYS_BUCKET_LUT; r3c: -0.09 ms per window): values below 1024 -- eleven of the
 // thirteen thresholds -- take one LDS read of four packed bucket numbers, the rest two compares; resp_bucket() costs 13 compare + add pairs
 #ifndef GYS_BUCKET_LUT
-#define GYS_BUCKET_LUT 0
+#define GYS_BUCKET_LUT 1
 #endif
 __device__ __forceinline__ void resp_bucket_lut_init(uint32_t *s_bk, uint32_t tid, uint32_t nthreads)
 {
@@ -901,184 +901,6 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 			cnt += v >> 40;
 			sum += v & ((1ull << 40) - 1);
 		}
-		if (cnt) {
-			atomicAdd(&p.ghist[2 * tid], cnt);
-			atomicAdd(&p.ghist[2 * tid + 1], sum);
-			atomicAdd(&p.ghist[30], cnt);
-		}
-	}
-	if (tid == 0) {
-		if (s_gmax != INT32_MIN) atomicMax(p.gmax, (long long)s_gmax);
-		atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
-		if (s_drop[0]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_RANGE], (unsigned long long)s_drop[0]);
-		if (s_drop[1]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_NOLISTENER], (unsigned long long)s_drop[1]);
-	}
-}
-
-// ---- k_resp_direct: the host-local front end WITHOUT the tile image (experiment GYS_RESP_DIRECT, same results as k_resp_host<.,false,false>).
-// Every kept event takes its place in its service's value buffer with one LDS atomic on the service's fill cursor and writes its staged
-// word straight to HBM (a 4-byte scattered store; consecutive values of a service go to consecutive addresses, the L2 merges them).
-// No per-tile key counts, no scan, no image, no flush, no barrier inside the event loop: the waves of a workgroup run independently,
-// the per-thread state is a fraction of k_resp_host's, and the LDS holds only the host's table and cursors.
-#ifndef GYS_GH_COPIES
-#define GYS_GH_COPIES 1
-#endif
-template <int NT, bool SVCHLL>
-__global__ __launch_bounds__(NT) void k_resp_direct(RespHostP p)
-{
-	constexpr uint32_t T = NT;
-	GYS_DYN_LDS(uint64_t, s_dyn);
-	__shared__ uint32_t s_drop[2];
-	__shared__ uint32_t s_floor;
-	__shared__ unsigned long long s_gh[T / 64][GYS_GH_COPIES][16];
-	__shared__ int32_t s_gmax;
-	__shared__ uint32_t s_bk[GYS_BUCKET_LUT ? 256 : 1];
-	if (GYS_BUCKET_LUT) resp_bucket_lut_init(s_bk, threadIdx.x, T);
-	const uint32_t Lc = p.lds_key_entries;
-	uint64_t *s_tbl = s_dyn;
-	uint32_t *s_cur = (uint32_t *)(s_dyn + p.lds_tbl_entries); // [Lc] words in the key's buffer
-	uint32_t *s_slot = s_cur + Lc;                            // [Lc] service slot of the local index
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const gys_resp_seg seg = p.segs[blockIdx.x];
-	const uint64_t e0 = seg.first_event;
-	uint64_t e1 = blockIdx.x + 1 < p.nsegs ? p.segs[blockIdx.x + 1].first_event : p.n;
-	if (e1 > p.n) e1 = p.n;
-	if (e1 <= e0) return;
-	const HostDesc hd = p.hdesc[seg.host_slot];
-	const uint32_t mask = hd.mask, L = hd.nlst;
-	for (uint32_t i = tid; i <= mask; i += T) s_tbl[i] = p.htbl[hd.tbl_off + i];
-	for (uint32_t k = tid; k < L; k += T) {
-		const uint32_t slot = p.hlst[hd.lst_off + k];
-		s_slot[k] = slot;
-		s_cur[k] = p.td_cur[slot];
-	}
-	if (tid < 2) s_drop[tid] = 0;
-	for (uint32_t i = tid; i < (T / 64) * GYS_GH_COPIES * 16; i += T) ((unsigned long long *)s_gh)[i] = 0;
-	if (tid == 0) {
-		s_floor = 0xFFFFFFFFu;
-		s_gmax = INT32_MIN;
-	}
-	__syncthreads();
-	if (e1 - e0 >= 4096u) { // HLL floor (see k_resp_host)
-		uint32_t mn = 0xFFFFFFFFu;
-		const uint4 *h4 = (const uint4 *)p.hll32;
-		for (uint32_t i = tid; i < (1u << GYS_HLL_P) / 4u; i += T) {
-			const uint4 v = h4[i];
-			mn = min(min(mn, min(v.x, v.y)), min(v.z, v.w));
-		}
-#pragma unroll
-		for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
-		if (lane == 0) atomicMin(&s_floor, mn);
-	} else if (tid == 0) {
-		s_floor = 0;
-	}
-	__syncthreads();
-	const uint32_t hll_floor = s_floor;
-	const uint64_t *evb = p.ev + 3ull * e0; // events of the segment: 32-bit offsets from here
-	const uint32_t nev = (uint32_t)(e1 - e0);
-	unsigned long long *gh = s_gh[wave][lane & (GYS_GH_COPIES - 1)];
-	uint32_t ndrop_range = 0, ndrop_nol = 0;
-	int32_t tmax = INT32_MIN;
-#pragma unroll 1
-	for (uint32_t i0 = 0; i0 < nev; i0 += 4u * T) {
-		uint64_t w0[4], w1[4], w2[4];
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const uint32_t i = i0 + tid + (uint32_t)u * T;
-			w0[u] = 0; w1[u] = 0; w2[u] = 0;
-			if (i < nev) {
-				w0[u] = evb[3u * i];
-				w1[u] = evb[3u * i + 1u];
-				w2[u] = evb[3u * i + 2u];
-			}
-		}
-		uint32_t hidx[4], hrank[4], rare = 0;
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const uint32_t i = i0 + tid + (uint32_t)u * T;
-			const uint32_t saddr = (uint32_t)w0[u], daddr = (uint32_t)(w0[u] >> 32);
-			const uint32_t netns = (uint32_t)w1[u];
-			const uint16_t sport = bswap16((uint16_t)(w1[u] >> 32)), dport = bswap16((uint16_t)(w1[u] >> 48));
-			const uint32_t tresp = (uint32_t)w2[u] - (uint32_t)(w2[u] >> 32);
-			hrank[u] = 0;
-			hidx[u] = 0;
-			if (i >= nev) continue;
-			if (tresp > 1000000u) {
-				ndrop_range++;
-				continue;
-			}
-			const uint64_t key48 = ((uint64_t)netns << 16) | (uint64_t)sport;
-			uint32_t h = host_tbl_hash(key48) & mask;
-			uint32_t local = GYS_NOSLOT;
-			for (uint32_t probes = 0; probes <= mask; ++probes) {
-				const uint64_t e = s_tbl[h];
-				if ((e >> 16) == key48) {
-					local = (uint32_t)(e & 0xFFFFu);
-					break;
-				}
-				if (e == GYS_HOST_TBL_EMPTY) break;
-				h = (h + 1) & mask;
-			}
-			if (local == GYS_NOSLOT) {
-				ndrop_nol++;
-				continue;
-			}
-			// the value's place in the service's buffer; a value that does not fit is dropped here: the count ends above pcap and
-			// finalize_key spills the key (its values of this batch then come from the spill pass)
-			const uint32_t pos = atomicAdd(&s_cur[local], 1u);
-			if (pos < p.pcap) p.td_pend[(uint64_t)s_slot[local] * p.pcap + pos] = (tresp << GYS_ROW_BITS) | ((uint32_t)dport & 0x1Fu);
-			if (!SVCHLL && daddr != 0 && saddr != 0) {
-				flow_hll_idx_rank(daddr, dport, saddr, sport, &hidx[u], &hrank[u]);
-				if (hrank[u] <= hll_floor) hrank[u] = 0;
-			} else {
-				rare |= (1u << u) | (local << 8);
-			}
-			atomicAdd(&gh[resp_bucket_lut(s_bk, tresp)], (1ull << 40) | (unsigned long long)tresp);
-			tmax = max(tmax, (int32_t)tresp);
-		}
-		if (rare & 0xFu) {
-#pragma unroll 1
-			for (uint32_t u = 0; u < 4u; ++u) {
-				if (!((rare >> u) & 1u)) continue;
-				const uint32_t i = i0 + tid + u * T;
-				const uint64_t x0 = evb[3u * i], x1 = evb[3u * i + 1u];
-				const uint32_t saddr = (uint32_t)x0, daddr = (uint32_t)(x0 >> 32);
-				const uint16_t sport = bswap16((uint16_t)(x1 >> 32)), dport = bswap16((uint16_t)(x1 >> 48));
-				const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
-				uint32_t idx, rank;
-				hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
-				if (SVCHLL) { // (the listener is looked up again: keeps the four local indices out of the hot loop's registers)
-					const uint64_t key48 = ((uint64_t)(uint32_t)x1 << 16) | (uint64_t)sport;
-					uint32_t h = host_tbl_hash(key48) & mask;
-					while ((s_tbl[h] >> 16) != key48) h = (h + 1) & mask;
-					svc_hll_update(p.svc_hll, p.svc_hll_p, s_slot[(uint32_t)(s_tbl[h] & 0xFFFFu)], h64);
-				}
-				if (rank > hll_floor && p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
-			}
-		}
-#pragma unroll
-		for (int u = 0; u < 4; ++u)
-			if (hrank[u] && p.hll32[hidx[u]] < hrank[u]) atomicMax(&p.hll32[hidx[u]], hrank[u]);
-	}
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) tmax = max(tmax, __shfl_xor(tmax, d, 64));
-	if (lane == 0 && tmax != INT32_MIN) atomicMax(&s_gmax, tmax);
-	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
-	if (ndrop_nol) atomicAdd(&s_drop[1], ndrop_nol);
-	__syncthreads();
-	for (uint32_t kb = 0; kb < L; kb += T) {
-		const uint32_t k = kb + tid;
-		const bool valid = k < L;
-		finalize_key<true>(p.fin, valid, valid ? s_slot[k] : 0u, valid ? s_cur[k] : 0u, lane);
-	}
-	if (tid < 15u) {
-		unsigned long long cnt = 0, sum = 0;
-		for (uint32_t w = 0; w < T / 64; ++w)
-			for (uint32_t cp = 0; cp < GYS_GH_COPIES; ++cp) {
-				const unsigned long long v = s_gh[w][cp][tid];
-				cnt += v >> 40;
-				sum += v & ((1ull << 40) - 1);
-			}
 		if (cnt) {
 			atomicAdd(&p.ghist[2 * tid], cnt);
 			atomicAdd(&p.ghist[2 * tid + 1], sum);
@@ -1604,7 +1426,7 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 //   Weights are 32-bit here (total weight < 2^31: thresholds and mid-points fit a u32); an entry beyond that is handed to the
 //   general kernel through slow_list.
 #ifndef GYS_MB_PACKED
-#define GYS_MB_PACKED 0 // experiment: values accumulate into a packed {count, sum} word (one LDS atomic instead of two)
+#define GYS_MB_PACKED 1 // values accumulate into a packed {count, sum} word: one LDS atomic per value instead of two (r3c: -0.09 ms per window)
 #endif
 #define GYS_MB_EXACT 1024u
 #define GYS_MB_BINS 2048u // 1024 one-value bins + 10 octaves x 64 cells (values < 2^20), padded to 8 bins per thread
