@@ -92,9 +92,15 @@ struct HostListeners {
 	uint32_t tbl_off = 0, tbl_cap = 0, lst_off = 0;
 	bool on_device = false;
 	bool overflow = false;       // more listeners than the LDS path supports (or pools exhausted): general pipeline only
+	// A host with more than GYS_HOST_MAX_LOCAL listeners is cut into `sub.size()` PARTS (a power of two): a listener belongs to part
+	// host_part_of(key48), every part has a sub-table of its own (the members above are then unused) and its own descriptor
+	// hdesc[sub_desc + part]; k_resp_host runs one workgroup per (segment, part), each resolving only its part's events.
+	std::vector<HostListeners> sub;
+	uint32_t sub_desc = 0;
 };
 
-#define GYS_HOST_MAX_LOCAL 2048u // listeners per host the LDS sub-table path supports (32 KB LDS table + 48 KB per-key areas + the tile image)
+#define GYS_HOST_MAX_LOCAL 2048u // listeners per sub-table the LDS path supports (32 KB LDS table + 48 KB per-key areas + the tile image)
+#define GYS_HOST_MAX_PARTS 16u   // ... and parts per host: up to 32768 listeners per host on the host-local path
 
 struct ArenaLayout {
 	uint64_t off_hll8, off_u32, n_u32, off_i64sum, n_i64sum, off_i64max, n_i64max, total;
@@ -157,7 +163,8 @@ struct gys_ctx {
 	uint64_t htbl_used = 0, htbl_cap = 0, hlst_used = 0, hlst_cap = 0;
 	uint64_t *htbl = nullptr; // pool of per-host sub-tables
 	uint32_t *hlst = nullptr; // pool of per-host local index -> slot lists
-	HostDesc *hdesc = nullptr;
+	HostDesc *hdesc = nullptr; // [max_hosts] by host slot, then hdesc_ext_cap descriptors of the parts of many-listener hosts
+	uint32_t hdesc_ext_used = 0, hdesc_ext_cap = 0;
 
 	// device state
 	DevTable lk_tbl{}, gid_tbl{};
@@ -504,15 +511,17 @@ void host_tbl_put(HostListeners &hl, uint64_t key48, uint32_t local)
 	hl.tbl[h] = (key48 << 16) | (uint64_t)local;
 }
 
-// (re)uploads one host's sub-table, slot list and descriptor; regions only ever grow, an outgrown region is abandoned in the pool
-// (geometric growth: the abandoned total stays below the final size, which is what the pool capacity accounts for)
-int host_lst_upload(gys_ctx *c, uint32_t host)
+inline uint32_t host_part_of(uint64_t key48, uint32_t nparts) { return (host_tbl_hash(key48) >> 21) & (nparts - 1u); }
+
+// (re)uploads one sub-table, its slot list and its descriptor hdesc[desc]; regions only ever grow, an outgrown region is abandoned in
+// the pool (geometric growth: the abandoned total stays below the final size, which is what the pool capacity accounts for).
+// Returns false when the pools are exhausted.
+int host_tbl_upload(gys_ctx *c, HostListeners &hl, uint32_t desc, uint32_t part, uint32_t nparts, bool *ok)
 {
-	HostListeners &hl = c->host_lst[host];
-	if (hl.overflow) return GYS_OK;
+	*ok = true;
 	if (!hl.on_device || hl.tbl.size() > hl.tbl_cap) {
 		if (c->htbl_used + hl.tbl.size() > c->htbl_cap || c->hlst_used + hl.tbl.size() / 2 > c->hlst_cap) {
-			hl.overflow = true; // pools exhausted: this host keeps working through the general pipeline
+			*ok = false;
 			return GYS_OK;
 		}
 		hl.tbl_off = (uint32_t)c->htbl_used;
@@ -524,10 +533,65 @@ int host_lst_upload(gys_ctx *c, uint32_t host)
 	}
 	HIPCHK(hipMemcpyAsync(c->htbl + hl.tbl_off, hl.tbl.data(), hl.tbl.size() * 8, hipMemcpyHostToDevice, c->stream));
 	if (!hl.slots.empty()) HIPCHK(hipMemcpyAsync(c->hlst + hl.lst_off, hl.slots.data(), hl.slots.size() * 4, hipMemcpyHostToDevice, c->stream));
-	const HostDesc hd{hl.tbl_off, (uint32_t)hl.tbl.size() - 1, (uint32_t)hl.slots.size(), hl.lst_off};
-	HIPCHK(hipMemcpyAsync(c->hdesc + host, &hd, sizeof(hd), hipMemcpyHostToDevice, c->stream));
+	const HostDesc hd{hl.tbl_off, (uint32_t)hl.tbl.size() - 1, (uint32_t)hl.slots.size(), hl.lst_off, part, nparts - 1u, {0u, 0u}};
+	HIPCHK(hipMemcpyAsync(c->hdesc + desc, &hd, sizeof(hd), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream)); // hd is a stack object
 	return GYS_OK;
+}
+
+int host_lst_upload(gys_ctx *c, uint32_t host)
+{
+	HostListeners &hl = c->host_lst[host];
+	if (hl.overflow) return GYS_OK;
+	bool ok = true;
+	if (hl.sub.empty()) {
+		const int rc = host_tbl_upload(c, hl, host, 0, 1, &ok);
+		if (rc) return rc;
+	} else {
+		for (uint32_t p = 0; p < hl.sub.size() && ok; ++p) {
+			const int rc = host_tbl_upload(c, hl.sub[p], c->cfg.max_hosts + hl.sub_desc + p, p, (uint32_t)hl.sub.size(), &ok);
+			if (rc) return rc;
+		}
+	}
+	if (!ok) hl.overflow = true; // pools exhausted: this host keeps working through the general pipeline
+	return GYS_OK;
+}
+
+// one listener into one sub-table (grown and rehashed at half full)
+void host_tbl_insert(HostListeners &t, uint64_t key48, uint32_t slot)
+{
+	const uint32_t local = (uint32_t)t.slots.size();
+	t.slots.push_back(slot);
+	t.keys.push_back(key48);
+	if (t.slots.size() * 2 > t.tbl.size()) {
+		t.tbl.assign(next_pow2(std::max<uint64_t>(16, t.slots.size() * 2)), GYS_HOST_TBL_EMPTY);
+		for (uint32_t l = 0; l < t.keys.size(); ++l) host_tbl_put(t, t.keys[l], l);
+	} else {
+		host_tbl_put(t, key48, local);
+	}
+}
+
+// cuts the host's listeners into nparts sub-tables (from one table, or from fewer parts); false: no descriptor room / too many parts
+bool host_lst_repartition(gys_ctx *c, HostListeners &hl, uint32_t nparts)
+{
+	if (nparts > GYS_HOST_MAX_PARTS || c->hdesc_ext_used + nparts > c->hdesc_ext_cap) return false;
+	std::vector<std::pair<uint64_t, uint32_t>> all;
+	if (hl.sub.empty()) {
+		for (uint32_t l = 0; l < hl.keys.size(); ++l) all.emplace_back(hl.keys[l], hl.slots[l]);
+	} else {
+		for (const HostListeners &t : hl.sub)
+			for (uint32_t l = 0; l < t.keys.size(); ++l) all.emplace_back(t.keys[l], t.slots[l]);
+	}
+	hl.tbl.clear();
+	hl.slots.clear();
+	hl.keys.clear();
+	hl.sub.assign(nparts, HostListeners{});
+	hl.sub_desc = c->hdesc_ext_used; // (the descriptors of the previous cut are abandoned, like outgrown table regions)
+	c->hdesc_ext_used += nparts;
+	for (const auto &kv : all) host_tbl_insert(hl.sub[host_part_of(kv.first, nparts)], kv.first, kv.second);
+	for (HostListeners &t : hl.sub)
+		if (t.tbl.empty()) t.tbl.assign(16, GYS_HOST_TBL_EMPTY);
+	return true;
 }
 
 int host_lst_add(gys_ctx *c, uint32_t host, const gys_listener_info *arr, uint32_t n, uint32_t first_slot)
@@ -536,24 +600,20 @@ int host_lst_add(gys_ctx *c, uint32_t host, const gys_listener_info *arr, uint32
 	if (hl.overflow) return GYS_OK;
 	for (uint32_t i = 0; i < n; ++i) {
 		const uint64_t key48 = host_key48(arr[i].netns, arr[i].port);
-		const int64_t pos = host_tbl_find(hl, key48);
+		HostListeners *t = hl.sub.empty() ? &hl : &hl.sub[host_part_of(key48, (uint32_t)hl.sub.size())];
+		const int64_t pos = host_tbl_find(*t, key48);
 		if (pos >= 0) { // re-registration of a listener tuple rebinds it to the newest slot (same rule as the global table)
-			hl.slots[(uint32_t)(hl.tbl[(size_t)pos] & 0xFFFFu)] = first_slot + i;
+			t->slots[(uint32_t)(t->tbl[(size_t)pos] & 0xFFFFu)] = first_slot + i;
 			continue;
 		}
-		if (hl.slots.size() >= GYS_HOST_MAX_LOCAL) {
-			hl.overflow = true; // too many listeners for the LDS sub-table: batches with this host take the general pipeline
-			return GYS_OK;
+		while (t->slots.size() >= GYS_HOST_MAX_LOCAL) { // the (part of the) host is full: twice the parts
+			if (!host_lst_repartition(c, hl, hl.sub.empty() ? 2u : (uint32_t)hl.sub.size() * 2u)) {
+				hl.overflow = true; // beyond what the LDS sub-tables take: batches with this host use the general pipeline
+				return GYS_OK;
+			}
+			t = &hl.sub[host_part_of(key48, (uint32_t)hl.sub.size())];
 		}
-		const uint32_t local = (uint32_t)hl.slots.size();
-		hl.slots.push_back(first_slot + i);
-		hl.keys.push_back(key48);
-		if (hl.slots.size() * 2 > hl.tbl.size()) {
-			hl.tbl.assign(next_pow2(std::max<uint64_t>(16, hl.slots.size() * 2)), GYS_HOST_TBL_EMPTY);
-			for (uint32_t l = 0; l < hl.keys.size(); ++l) host_tbl_put(hl, hl.keys[l], l);
-		} else {
-			host_tbl_put(hl, key48, local);
-		}
+		host_tbl_insert(*t, key48, first_slot + i);
 	}
 	return host_lst_upload(c, host);
 }
@@ -649,25 +709,37 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 
 	// ---- front end choice: host-local (one workgroup per host segment, LDS sub-table + tile-wise LDS counting sort straight into the
 	// services' value buffers) when every segment is a distinct host with an LDS-sized listener table; otherwise the general front end
-	bool host_local = td && c->cfg.resp_path != 1 && c->nsvc != 0, host_split = false;
+	bool host_local = td && c->cfg.resp_path != 1 && c->nsvc != 0, host_split = false, host_parts = false;
 	uint32_t max_tbl = 16, max_l = 1;
-	uint64_t max_len = 0;
+	uint64_t max_len = 0, nwg = 0;
 	if (host_local) {
 		c->batch_stamp++;
 		for (uint32_t s = 0; s < nsegs && host_local; ++s) {
 			const uint32_t host = segs_host[s].host_slot;
 			const HostListeners &hl = c->host_lst[host];
 			const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - segs_host[s].first_event;
-			if (c->host_seen[host] == c->batch_stamp || hl.overflow || !hl.on_device) host_local = false;
+			if (c->host_seen[host] == c->batch_stamp || hl.overflow) host_local = false;
 			c->host_seen[host] = c->batch_stamp;
 			max_len = std::max(max_len, len);
-			max_tbl = std::max<uint32_t>(max_tbl, (uint32_t)hl.tbl.size());
-			max_l = std::max<uint32_t>(max_l, (uint32_t)hl.slots.size());
+			if (hl.sub.empty()) {
+				if (!hl.on_device) host_local = false;
+				max_tbl = std::max<uint32_t>(max_tbl, (uint32_t)hl.tbl.size());
+				max_l = std::max<uint32_t>(max_l, (uint32_t)hl.slots.size());
+				nwg += 1;
+			} else { // a many-listener host: one workgroup per part of its listeners
+				host_parts = true;
+				for (const HostListeners &t : hl.sub) {
+					if (!t.on_device) host_local = false;
+					max_tbl = std::max<uint32_t>(max_tbl, (uint32_t)t.tbl.size());
+					max_l = std::max<uint32_t>(max_l, (uint32_t)t.slots.size());
+				}
+				nwg += hl.sub.size();
+			}
 		}
 		// few hosts with long segments: one workgroup per segment would leave most of the chip idle, so the segments are cut into parts
 		// of GYS_SPLIT_PART events (SHARED form: buffer space reserved with device atomics).  A workgroup walks ~0.35 G events/s.
-		const double t_host = (double)((nsegs + c->ncu - 1) / c->ncu) * (double)max_len / 0.35e9;
-		const double t_split = (double)n / 40.0e9 + 20e-6;
+		const double t_host = (double)((nwg + c->ncu - 1) / c->ncu) * (double)max_len / 0.35e9;
+		const double t_split = (double)n * (double)std::max<uint64_t>(nwg, 1) / (double)std::max<uint32_t>(nsegs, 1) / 40.0e9 + 20e-6;
 		if (host_local && max_len > GYS_SPLIT_PART && (c->cfg.resp_path == 3 || (c->cfg.resp_path == 0 && t_split < t_host))) host_split = true;
 	}
 	const uint32_t nsvc = c->nsvc;
@@ -732,11 +804,14 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hp.lds_tbl_entries = max_tbl;
 		hp.lds_key_entries = (uint32_t)align_up(max_l, 2);
 		hgrid = nsegs;
-		if (host_split) {
+		if (host_split || host_parts) {
+			// virtual segments: every segment cut into parts of GYS_SPLIT_PART events (host_split) and, for a many-listener host, one
+			// entry per part of its listeners (reserved = descriptor index + 1), the listener parts of one piece next to each other
 			uint64_t nparts = 0;
 			for (uint32_t s = 0; s < nsegs; ++s) {
 				const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - segs_host[s].first_event;
-				nparts += (len + GYS_SPLIT_PART - 1) / GYS_SPLIT_PART;
+				const uint64_t pieces = host_split ? (len + GYS_SPLIT_PART - 1) / GYS_SPLIT_PART : (len ? 1 : 0);
+				nparts += pieces * std::max<size_t>(c->host_lst[segs_host[s].host_slot].sub.size(), 1);
 			}
 			const uint64_t xbytes = nparts * sizeof(gys_resp_seg);
 			if (xbytes > slot.xcap) {
@@ -752,13 +827,23 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			for (uint32_t s = 0; s < nsegs; ++s) {
 				const uint64_t first = segs_host[s].first_event;
 				const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - first;
-				for (uint64_t q = 0; q * GYS_SPLIT_PART < len; ++q) vseg[v++] = gys_resp_seg{segs_host[s].host_slot, 0u, first + q * GYS_SPLIT_PART};
+				const HostListeners &hl = c->host_lst[segs_host[s].host_slot];
+				const uint64_t step = host_split ? (uint64_t)GYS_SPLIT_PART : std::max<uint64_t>(len, 1);
+				for (uint64_t q = 0; q * step < len; ++q) {
+					if (hl.sub.empty()) {
+						vseg[v++] = gys_resp_seg{segs_host[s].host_slot, 0u, first + q * step};
+					} else {
+						for (uint32_t lp = 0; lp < hl.sub.size(); ++lp)
+							vseg[v++] = gys_resp_seg{segs_host[s].host_slot, c->cfg.max_hosts + hl.sub_desc + lp + 1u, first + q * step};
+					}
+				}
 			}
-			HIPCHK(hipMemcpyAsync(slot.xdev, slot.xhost, xbytes, hipMemcpyHostToDevice, c->stream));
+			HIPCHK(hipMemcpyAsync(slot.xdev, slot.xhost, v * sizeof(gys_resp_seg), hipMemcpyHostToDevice, c->stream));
 			hp.segs = (const gys_resp_seg *)slot.xdev;
-			hp.nsegs = (uint32_t)nparts;
-			hgrid = (uint32_t)nparts;
-			c->n_batches_host_split++;
+			hp.nsegs = (uint32_t)v;
+			hgrid = (uint32_t)v;
+			if (host_split) c->n_batches_host_split++;
+			else c->n_batches_host_local++;
 		} else {
 			c->n_batches_host_local++;
 		}
@@ -1524,7 +1609,8 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	c->hlst_cap = 4 * S + 16 * H;
 	ALLOC(c->htbl, c->htbl_cap);
 	ALLOC(c->hlst, c->hlst_cap);
-	ALLOC(c->hdesc, H);
+	c->hdesc_ext_cap = (uint32_t)(S / GYS_HOST_MAX_LOCAL) * 4u + 64u; // parts of many-listener hosts (incl. abandoned cuts)
+	ALLOC(c->hdesc, H + c->hdesc_ext_cap);
 	ALLOC(c->svc_host, S);
 	ALLOC(c->host_spill, H);
 	c->host_lst.reserve(H);

@@ -538,6 +538,9 @@ struct HostDesc {
 	uint32_t mask;     // sub-table capacity - 1 (power of two)
 	uint32_t nlst;     // local listener indices in use
 	uint32_t lst_off;  // first entry of the host's local index -> service slot list in the list pool
+	uint32_t part;     // a host with more listeners than one sub-table takes is cut into parts: this descriptor's part ...
+	uint32_t pmask;    // ... of pmask + 1 (a power of two); a listener key belongs to part (host_tbl_hash(key) >> 21) & pmask
+	uint32_t pad[2];
 };
 
 #define GYS_HOST_TBL_EMPTY 0xFFFFFFFFFFFFFFFFull
@@ -604,11 +607,16 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const gys_resp_seg seg = p.segs[blockIdx.x];
 	const uint64_t e0 = seg.first_event;
-	uint64_t e1 = blockIdx.x + 1 < p.nsegs ? p.segs[blockIdx.x + 1].first_event : p.n;
+	// (the workgroups of one segment of a many-listener host -- one per part of its listeners, seg.reserved = descriptor index + 1 --
+	// sit next to each other with the same first event: the segment ends where the next entry with another start begins)
+	uint32_t nx = blockIdx.x + 1;
+	if (seg.reserved)
+		while (nx < p.nsegs && p.segs[nx].reserved && p.segs[nx].host_slot == seg.host_slot && p.segs[nx].first_event == e0) ++nx;
+	uint64_t e1 = nx < p.nsegs ? p.segs[nx].first_event : p.n;
 	if (e1 > p.n) e1 = p.n;
 	if (e1 <= e0) return;
 	if (SPILL && p.host_spill[seg.host_slot] != p.spill_stamp) return;
-	const HostDesc hd = p.hdesc[seg.host_slot];
+	const HostDesc hd = p.hdesc[seg.reserved ? seg.reserved - 1u : seg.host_slot];
 	const uint32_t mask = hd.mask, L = hd.nlst;
 	for (uint32_t i = tid; i <= mask; i += T) s_tbl[i] = p.htbl[hd.tbl_off + i];
 	for (uint32_t k = tid; k < L; k += T) {
@@ -726,11 +734,13 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 				hidx[u] = 0;
 				if (i >= e1) continue;
 				if (tresp > 1000000u) { // "Ignore responses > 1000 sec or negative" (:1521-1524)
-					ndrop_range++;
+					if (hd.part == 0u) ndrop_range++; // (counted once per event: by the workgroup of part 0)
 					continue;
 				}
 				const uint64_t key48 = ((uint64_t)netns << 16) | (uint64_t)sport;
-				uint32_t h = host_tbl_hash(key48) & mask;
+				const uint32_t hk = host_tbl_hash(key48);
+				if (((hk >> 21) & hd.pmask) != hd.part) continue; // a listener of another part of this host: that part's workgroup has it
+				uint32_t h = hk & mask;
 				uint32_t local = GYS_NOSLOT;
 				for (uint32_t probes = 0; probes <= mask; ++probes) {
 					const uint64_t e = s_tbl[h];
@@ -909,7 +919,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 	}
 	if (tid == 0) {
 		if (s_gmax != INT32_MIN) atomicMax(p.gmax, (long long)s_gmax);
-		atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
+		if (hd.part == 0u) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_EVENTS], (unsigned long long)(e1 - e0));
 		if (s_drop[0]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_RANGE], (unsigned long long)s_drop[0]);
 		if (s_drop[1]) atomicAdd((unsigned long long *)&p.counters[CTR_RESP_DROP_NOLISTENER], (unsigned long long)s_drop[1]);
 	}
