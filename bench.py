@@ -430,7 +430,9 @@ def main():
     ap.add_argument("--svcs", type=int, default=1000, help="services per host")
     ap.add_argument("--events", type=int, default=1 << 29, help="events per rank per step (one window)")
     ap.add_argument("--zipf-milli", type=int, default=0, help="0 = uniform over services, else Zipf s*1000 (config 5: --zipf-milli 1100 --hosts 25 --svcs 4000)")
-    ap.add_argument("--levels", action="store_true", help="multi-level windows on (gys_config.enable_levels: 5.4 KB more per service; the close then folds and snapshots every service)")
+    ap.add_argument("--levels", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
+                    help="multi-level windows (gys_config.enable_levels): 1 = 5 s / 300 s / 5 d / all (every close folds every touched service), "
+                         "2 = without the 5-s level (services touched only when a 30-s ring boundary is crossed)")
     ap.add_argument("--workload", choices=["resp", "conn"], default="resp", help="resp: C3/C4/C5 response-event stream (default); conn: C2 TCP_CONN_NOTIFY stream")
     ap.add_argument("--conn-stream", choices=["messages", "mixed"], default="messages", help="--workload conn: per-partha 2048-record messages (default) or hosts mixed record by record")
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl", help="window exchange at N > 1: RCCL inside the library (default) or torch.distributed")
@@ -688,7 +690,7 @@ def main():
                                    "1 window (ingest + window close) per step" % (args.hosts, args.svcs,
                                                                                  "uniform" if not args.zipf_milli else "zipf %.2f" % (args.zipf_milli / 1000)),
                        "events_per_rank_per_step": args.events, "service_keys_total": args.hosts * args.svcs,
-                       "service_keys_rank0": nsvc, "multi_level_windows": bool(args.levels),
+                       "service_keys_rank0": nsvc, "multi_level_windows": int(args.levels),
                        "sketches": "exact RESP_TIME_HASH histogram + CONN_BITMAP + HLL p=14 + CMS 4x65536 + t-digest %d clusters + %d-value buffer per key" % (capi.TD_NB, capi.TD_PEND_CAP),
                        "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world, "exchange": exchange,
                        "exchange_requested": args.exchange if world > 1 else "none",

@@ -1030,28 +1030,36 @@ int level_roll(gys_ctx *c, uint64_t tusec)
 {
 	int64_t tnow = (int64_t)(tusec / 1000000ull);
 	if (tnow < c->lvl_t_last) tnow = c->lvl_t_last; // time does not go backwards (BucketedTimeSeries::update)
-	{
-		const int rcf = fold_range(c, 0, c->nsvc); // every service's closing-window record must be complete
-		if (rcf) return rcf;
-	}
 	LevelRollP p{};
-	p.win = c->hist_win;
-	p.all = c->hist_all;
-	p.meta = c->cfg.enable_tdigest ? c->td_meta : nullptr;
-	p.epoch = c->epoch;
-	p.nsvc = c->nsvc;
-	p.snap = c->lvl_snap;
-	p.last = c->lvl_last;
-	p.stride = c->cfg.max_services;
 	for (int li = 0; li < 2; ++li) {
 		const int64_t dur = LEVEL_SECS[li + 1];
 		for (uint32_t j = 0; j < GYS_LEVEL_RING; ++j)
 			if (c->lvl_t_last >= 0 && level_bucket_start(tnow, dur, j) > c->lvl_t_last) p.mask[li] |= 1u << j;
 	}
 	c->lvl_t_last = tnow;
+	if (!c->nsvc) return GYS_OK;
+	const bool keep_last = c->cfg.enable_levels == 1; // enable_levels = 2: no 5-s level (nothing per key unless a ring boundary was crossed)
+	if (!keep_last && !(p.mask[0] | p.mask[1])) {
+		// no snapshot due: only the time of a service's first window close (firstTime_ of its series) is kept up
+		ProfScope ps(c, "level_roll");
+		hipLaunchKernelGGL(k_level_first, dim3(grid_for(c->nsvc, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, c->lvl_first, c->nsvc, tnow);
+		HIPCHK(hipGetLastError());
+		return GYS_OK;
+	}
+	{
+		const int rcf = fold_range(c, 0, c->nsvc); // every service's closing-window record must be complete
+		if (rcf) return rcf;
+	}
+	p.win = c->hist_win;
+	p.all = c->hist_all;
+	p.meta = c->cfg.enable_tdigest ? c->td_meta : nullptr;
+	p.epoch = c->epoch;
+	p.nsvc = c->nsvc;
+	p.snap = c->lvl_snap;
+	p.last = keep_last ? c->lvl_last : nullptr;
+	p.stride = c->cfg.max_services;
 	p.first_sec = c->lvl_first;
 	p.tnow = tnow;
-	if (!c->nsvc) return GYS_OK;
 	ProfScope ps(c, "level_roll");
 	hipLaunchKernelGGL(k_level_roll, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
@@ -1066,7 +1074,7 @@ void level_source(gys_ctx *c, int level, int64_t tq, int *mode, const gys_hist_r
 		*mode = 0;
 	} else if (level == 0) {
 		// a 5-s ring keeps an add for 5 s: the window closed last, until a window's length has passed without another close
-		if (c->lvl_t_last >= 0 && tq - c->lvl_t_last < LEVEL_SECS[0]) {
+		if (c->cfg.enable_levels == 1 && c->lvl_t_last >= 0 && tq - c->lvl_t_last < LEVEL_SECS[0]) {
 			*mode = 2;
 			*sub = c->lvl_last;
 		} else {
@@ -1126,7 +1134,7 @@ int level_period(gys_ctx *c, int64_t start, int64_t end, uint64_t tusec, uint32_
 	p.n = n;
 	p.out = d_out;
 	int level = GYS_NLEVELS - 1; // MultiLevelTimeSeries::getLevel(start): the first level that reaches back to start
-	for (int l = 0; l < GYS_NLEVELS - 1; ++l)
+	for (int l = c->cfg.enable_levels == 1 ? 0 : 1; l < GYS_NLEVELS - 1; ++l) // (enable_levels = 2: no 5-s level, the 300-s ring answers)
 		if (tq - LEVEL_SECS[l] <= start) {
 			level = l;
 			break;
@@ -1625,7 +1633,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_levels) {
 		ALLOC(c->lvl_snap, 2 * GYS_LEVEL_RING * S);
-		ALLOC(c->lvl_last, S);
+		ALLOC(c->lvl_last, cfg->enable_levels == 1 ? S : 1);
 		ALLOC(c->lvl_first, S);
 		ALLOC(c->qps_hist, S);
 		ALLOC(c->act_hist, S);
@@ -1701,7 +1709,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_win, (uint64_t)0, S, (int64_t)INT64_MIN);
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_all, (uint64_t)0, S, (int64_t)INT64_MIN);
 	if (cfg->enable_levels) {
-		hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->lvl_last, (uint64_t)0, S, (int64_t)INT64_MIN);
+		if (cfg->enable_levels == 1) hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->lvl_last, (uint64_t)0, S, (int64_t)INT64_MIN);
 		// GY_HISTOGRAM<int, ...>: max_val_seen_ starts at std::numeric_limits<int>::min()
 		hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->qps_hist, (uint64_t)0, S, (int64_t)INT32_MIN);
 		hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->act_hist, (uint64_t)0, S, (int64_t)INT32_MIN);
@@ -3470,6 +3478,11 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 		set_err("gys_config.enable_levels was not set");              \
 		return GYS_ERR_STATE;                                         \
 	}
+#define LEVEL0_CHECK(level)                                                                   \
+	if ((level) == 0 && c->cfg.enable_levels != 1) {                                       \
+		set_err("the 5-s level is not kept with gys_config.enable_levels = 2");        \
+		return GYS_ERR_STATE;                                                          \
+	}
 
 int gys_export_hist_level(gys_ctx *c, int level, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
 {
@@ -3477,6 +3490,7 @@ int gys_export_hist_level(gys_ctx *c, int level, uint64_t tusec, uint32_t first_
 	RANGE_CHECK(first_slot, nslots);
 	LEVELS_CHECK();
 	if (level < 0 || level >= GYS_NLEVELS) return GYS_ERR_INVAL;
+	LEVEL0_CHECK(level);
 	if (!nslots) return GYS_OK;
 	gys_hist_rec *tmp = nullptr;
 	HIPCHK(hipMalloc((void **)&tmp, (size_t)nslots * sizeof(gys_hist_rec)));
@@ -3600,6 +3614,7 @@ int gys_scan_listener_state_dev(gys_ctx *c, uint64_t tusec, float qps_multiple, 
 	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	LEVELS_CHECK();
+	LEVEL0_CHECK(0);
 	if (!c->nsvc || (!d_notify && !d_scan)) return GYS_OK;
 	int64_t tq = (int64_t)(tusec / 1000000ull);
 	if (tq < c->lvl_t_last) tq = c->lvl_t_last;

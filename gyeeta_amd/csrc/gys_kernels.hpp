@@ -2555,7 +2555,7 @@ __global__ __launch_bounds__(256) void k_level_roll(LevelRollP p)
 			closing.x = 0;
 			closing.y = k < 15u ? 0ull : (unsigned long long)INT64_MIN;
 		}
-		((ulonglong2 *)p.last)[t] = closing;
+		if (p.last) ((ulonglong2 *)p.last)[t] = closing;
 		if (k == 15u && p.first_sec[slot] == 0) p.first_sec[slot] = p.tnow; // BucketedTimeSeries::update on an empty series
 		if (p.mask[0] | p.mask[1]) {
 			// cumulative record BEFORE the closing window: its add happens at the close time, i.e. at or after the boundary.  Lazily
@@ -2572,6 +2572,13 @@ __global__ __launch_bounds__(256) void k_level_roll(LevelRollP p)
 				}
 		}
 	}
+}
+
+// enable_levels = 2, a close that crosses no ring boundary: only firstTime_ of a service's series (the time of its first window close)
+__global__ __launch_bounds__(256) void k_level_first(int64_t *first_sec, uint32_t nsvc, int64_t tnow)
+{
+	for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nsvc; s += gridDim.x * blockDim.x)
+		if (first_sec[s] == 0) first_sec[s] = tnow;
 }
 
 struct LevelViewP {

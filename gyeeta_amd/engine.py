@@ -53,7 +53,7 @@ class SketchEngine:
         cfg.enable_tdigest = 1 if enable_tdigest else 0
         cfg.svc_hll_p = svc_hll_p
         cfg.resp_path = resp_path
-        cfg.enable_levels = 1 if enable_levels else 0
+        cfg.enable_levels = int(enable_levels)  # False / True / 2 (without the 5-s level)
         cfg.td_buf_values = td_buf_values
         cfg.conn_pair_cms = 1 if conn_pair_cms else 0
         cfg.max_batch_events = max_batch_events

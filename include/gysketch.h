@@ -79,8 +79,13 @@ typedef struct {
 	void *stream;              /* hipStream_t to run on; NULL = the context creates its own */
 	void *reduce_arena;        /* optional caller-owned DEVICE buffer for the all-reducible registers (e.g. a torch tensor so */
 	uint64_t reduce_arena_bytes; /* that torch.distributed/RCCL can reduce it in place); NULL = the context allocates it  */
-	uint32_t enable_levels;    /* multi-level windows (5 s / 300 s / 5 days / all) + per-service QPS / active-connection histograms */
-	                           /* (costs 21 hist records = 5.4 KB of HBM per service; see "multi-level windows" below) */
+	uint32_t enable_levels;    /* multi-level windows + per-service QPS / active-connection histograms (see "multi-level windows" below):
+	                              1 = all four levels (5 s / 300 s / 5 days / all; 21 hist records = 5.4 KB of HBM per service; every window
+	                                  close brings the records of every service touched in the window up to date -- what the reference's 5-s
+	                                  flush does per listener);
+	                              2 = without the 5-s level (300 s / 5 days / all): a close touches the services only when it crosses a ring
+	                                  boundary (every 30 s); level 0 and gys_scan_listener_state_dev answer GYS_ERR_STATE, a period that
+	                                  folly would answer from the 5-s ring is answered from the 300-s ring */
 	uint32_t td_buf_values;    /* entries of a service's value buffer (GYS_TD_PEND_CAP + 64 .. 16384; 0 = sized to max_services): the values
 	                              waiting for the next t-digest merge plus room for one batch's values of the service */
 	uint32_t conn_pair_cms;    /* TCP_CONN_NOTIFY records also feed a Count-Min pair OF THEIR OWN keyed by (ser_glob_id_, cli_task_aggr_id_): connections

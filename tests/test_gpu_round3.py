@@ -357,3 +357,49 @@ def test_many_listener_hosts_stay_on_the_host_local_path(torch_mod, oracle, resp
     oh, omax = orc.ghist()
     assert [gh.stats[i].count for i in range(15)] == oh[:15, 0].tolist() and gh.total_count == oh[15, 0] and gh.max_val_seen == omax
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ levels without the 5-s level
+def test_levels_mode2_without_the_5s_level(torch_mod, oracle):
+    """gys_config.enable_levels = 2: the 300-s / 5-day / all-time levels equal the folly-style ring oracle at every close and between
+    closes although a close only touches the services when it crosses a ring boundary; level 0 and the listener scan are refused"""
+    from gyeeta_amd import capi
+    from tests.test_gpu_levels import T0, RingOracle, _check_levels
+    rng = np.random.default_rng(5)
+    nh, sp = 2, 6
+    nsvc = nh * sp
+    eng = _engine(max_hosts=4, max_services=32, max_batch_events=1 << 14, enable_tdigest=True, enable_levels=2)
+    orc_win = oracle.OracleEngine(32, enable_td=False)
+    orc_all = oracle.OracleEngine(32, enable_td=False)
+    info, gids = helpers.register_world(eng, orc_win, range(nh), sp)
+    helpers.register_world(None, orc_all, range(nh), sp)
+    ring = RingOracle(oracle, nsvc)
+    steps = [5] * 14 + [7, 3, 5, 5, 40, 5, 5, 301, 5, 5, 5, 43200, 5, 5] + [5] * 8
+    t = T0
+    for w, dt in enumerate(steps):
+        t += dt
+        for h in range(nh):
+            if rng.random() < 0.8:
+                ev = helpers.make_resp_events(rng, h, int(rng.integers(1, 600)), int(rng.integers(1, sp + 1)), lat_mu=2.0 + 0.1 * (w % 20))
+                eng.handle_resp_events(info[h][0], ev)
+                for o in (orc_win, orc_all):
+                    o.resp_batch(ev.tobytes(), [info[h][1]], [0])
+        win = np.array(orc_win.hist()[:nsvc])
+        eng.window_close(t * 1_000_000)
+        ring.close(t, win)
+        allmax = np.array(orc_all.hist()[:nsvc])[:, 15, 1]
+        _check_levels(eng, ring, t, nsvc, [1, 2, 3], allmax)
+        if w % 3 == 1:
+            _check_levels(eng, ring, t + int(rng.integers(1, 300)), nsvc, [1, 2, 3], allmax)
+        if w % 4 == 0:
+            s = int(rng.integers(0, nsvc))
+            gid = int(gids[s // sp][s % sp])
+            for a, b in ((t - 100, t), (t - 4000, t - 20), (0, t)):  # (periods the 300-s ring or a longer level answers)
+                assert eng.query_hist_period_stats(gid, a, b, t * 1_000_000, [25.0, 95.0]) == ring.period_stats(s, a, b, t, [25.0, 95.0])
+        orc_win.window_clear(clear_hist=True)
+        orc_all.window_clear(clear_hist=False)
+    with pytest.raises(capi.GysError):
+        eng.export_hist_level(0, t * 1_000_000, 0, nsvc)
+    with pytest.raises(capi.GysError):
+        eng.scan_listener_state(t * 1_000_000)
+    eng.close()
