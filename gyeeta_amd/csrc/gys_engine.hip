@@ -1685,7 +1685,12 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		// the several-workgroup path's pool shares the scratch: 64 KiB of bins per entry, up to 16 384 entries (1 GiB) when the batches can
 		// carry that many large keys; the one-workgroup fallback needs huge_blocks x 4 MiB of it
 		c->huge_maxent = (uint32_t)std::max<uint64_t>((uint64_t)c->huge_blocks * GYS_HUGE_BINS / GYS_HB_BINS, std::min<uint64_t>(c->huge_list_cap, 16384));
-		ALLOC(c->huge_scratch, (uint64_t)c->huge_maxent * GYS_HB_BINS);
+		const uint64_t scratch_entries = c->huge_maxent;
+		if (const char *e = getenv("GYS_HUGE_MAXENT")) { // tests: a small pool, so that a modest batch walks its large keys in several rounds
+			const long v = atol(e);
+			if (v >= 1 && (uint64_t)v < c->huge_maxent) c->huge_maxent = (uint32_t)v;
+		}
+		ALLOC(c->huge_scratch, scratch_entries * GYS_HB_BINS);
 		ALLOC(c->huge_acc, (uint64_t)c->huge_maxent * GYS_HB_ACC);
 		ALLOC(c->huge_bm, (uint64_t)c->huge_maxent * 16);
 		ALLOC(c->huge_chunk_off, (uint64_t)c->huge_maxent + 1);
