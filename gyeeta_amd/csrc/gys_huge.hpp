@@ -204,6 +204,7 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 	__shared__ uint32_t s_part[1024], s_w[16];
 	__shared__ uint64_t s_cw[4];
 	__shared__ unsigned long long s_ha[32], s_hw[32]; // buffered words: exact {count, sum} per bucket, all not yet folded / window part
+	__shared__ unsigned long long s_pa[16][16], s_pw[16][16]; // ... accumulated per wave first (packed count : 24 | sum : 40)
 	__shared__ uint32_t s_bm[16];
 	__shared__ uint32_t s_nc, s_ntail, s_over;
 	__shared__ int32_t s_min, s_max, s_wmax;
@@ -281,27 +282,62 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 			}
 		}
 		__syncthreads();
-		// the buffered words join the counts; their not yet folded part is folded here (the run's deltas come from k_huge_count)
-		for (uint32_t i = tid; i < npend; i += 1024u) {
-			const uint32_t word = pend[i], v = word >> GYS_ROW_BITS;
-			if (v < GYS_HB_BINS) {
-				atomicAdd(&s_img[v], 1u);
-			} else {
-				const uint32_t at = atomicAdd(&s_ntail, 1u);
-				if (at < GYS_HB_TAIL_LDS) s_tail[at] = v; else s_over = 1;
+		// the buffered words join the counts; their not yet folded part is folded here (the run's deltas come from k_huge_count).
+		// A large key's buffer holds up to 16 384 words and nearly all of them land in a handful of histogram buckets: per-value
+		// atomics on ONE set of bucket accumulators / one min / one max serialise the whole workgroup on a few LDS addresses (136 us per
+		// key measured on the C5 shape).  So: packed {count : 24 | sum : 40} adds into per-WAVE rows (a wave's 1024 values x 10^6 fit
+		// the sum field), the extremes in registers with one reduction per wave, bitmap bits tested before they are set.
+		{
+			unsigned long long *pa = s_pa[wave], *pw = s_pw[wave];
+			if (lane < 16u) {
+				pa[lane] = 0;
+				pw[lane] = 0;
 			}
-			if (i >= nh) {
-				const uint32_t hb = resp_bucket((int64_t)v);
-				atomicAdd(&s_ha[2 * hb], 1ull);
-				atomicAdd(&s_ha[2 * hb + 1], (unsigned long long)v);
-				atomicMin(&s_min, (int32_t)v);
-				atomicMax(&s_max, (int32_t)v);
-				if (i >= nwin0) {
-					atomicAdd(&s_hw[2 * hb], 1ull);
-					atomicAdd(&s_hw[2 * hb + 1], (unsigned long long)v);
-					const uint32_t row = word & 0x1Fu;
-					atomicOr(&s_bm[row >> 1], (1u << hb) << ((row & 1u) * 16u));
-					atomicMax(&s_wmax, (int32_t)v);
+			GYS_WAVE_SYNC();
+			int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmx = INT32_MIN;
+			for (uint32_t i = tid; i < npend; i += 1024u) {
+				const uint32_t word = pend[i], v = word >> GYS_ROW_BITS;
+				if (v < GYS_HB_BINS) {
+					atomicAdd(&s_img[v], 1u);
+				} else {
+					const uint32_t at = atomicAdd(&s_ntail, 1u);
+					if (at < GYS_HB_TAIL_LDS) s_tail[at] = v; else s_over = 1;
+				}
+				if (i >= nh) {
+					const uint32_t hb = resp_bucket((int64_t)v);
+					const unsigned long long one = GYS_PACK_ONE | (unsigned long long)v;
+					atomicAdd(&pa[hb], one);
+					lmin = min(lmin, (int32_t)v);
+					lmax = max(lmax, (int32_t)v);
+					if (i >= nwin0) {
+						atomicAdd(&pw[hb], one);
+						const uint32_t row = word & 0x1Fu, bit = (1u << hb) << ((row & 1u) * 16u);
+						if ((s_bm[row >> 1] & bit) == 0u) atomicOr(&s_bm[row >> 1], bit);
+						wmx = max(wmx, (int32_t)v);
+					}
+				}
+			}
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1) {
+				lmin = min(lmin, __shfl_xor(lmin, d, 64));
+				lmax = max(lmax, __shfl_xor(lmax, d, 64));
+				wmx = max(wmx, __shfl_xor(wmx, d, 64));
+			}
+			if (lane == 0u) {
+				if (lmin != INT32_MAX) atomicMin(&s_min, lmin);
+				if (lmax != INT32_MIN) atomicMax(&s_max, lmax);
+				if (wmx != INT32_MIN) atomicMax(&s_wmax, wmx);
+			}
+			GYS_WAVE_SYNC();
+			if (lane < 16u) { // the wave's row into the workgroup's {count, sum} pairs
+				const unsigned long long a = pa[lane], w = pw[lane];
+				if (a) {
+					atomicAdd(&s_ha[2 * lane], a >> 40);
+					atomicAdd(&s_ha[2 * lane + 1], GYS_PACK_SUM(a));
+				}
+				if (w) {
+					atomicAdd(&s_hw[2 * lane], w >> 40);
+					atomicAdd(&s_hw[2 * lane + 1], GYS_PACK_SUM(w));
 				}
 			}
 		}
