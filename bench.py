@@ -230,7 +230,9 @@ def pmc_traffic(kernel, events, nsvc):
     if not k:
         return None
     return {"bytes": k["fetch_bytes"] + k["write_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
-            "source": t.get("source", "profiles/pmc_traffic.json")}
+            "source": t.get("source", "profiles/pmc_traffic.json"), "measured_in_this_run": False,
+            "source_commit": t.get("source_commit"), "note": "counter passes are separate rocprofv3 runs (profiles/pmc_traffic.json); "
+            "source_commit = the tree they were taken on, compare with build_commit of this line"}
 
 
 def self_launch(args):
@@ -240,7 +242,7 @@ def self_launch(args):
     import subprocess
     if not args.selftest_launch:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < args.gpus:
+        if have < (1 if args.share_device else args.gpus):
             print(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, {have} visible on this node", file=sys.stderr)
             return 2
     sk = socket.socket()
@@ -284,7 +286,7 @@ def verify_ranks(mine, world, device):
     return m, all(row == m[0] for row in m)
 
 
-def exchange_side_check(args, rank, world, local_rank, L, main_eng, exchange, wire, SketchEngine, mid_buf):
+def exchange_side_check(args, rank, world, local_rank, L, main_eng, exchange, wire, SketchEngine, mid_buf, cdev):
     """Small configuration (96 hosts x 6 services, 2 000 response events per host, fixed seeds per host) run twice: sharded over the
     ranks through the SAME exchange path as the timed run, and -- on rank 0 -- by one single-rank engine fed all hosts.  The reduced
     registers of every rank must equal the single-rank run's."""
@@ -331,7 +333,7 @@ def exchange_side_check(args, rank, world, local_rank, L, main_eng, exchange, wi
     else:
         obs = run(e2, mine, lambda e: e.window_close(tusec=5_000_000))
     e2.close()
-    matrix, same = verify_ranks(obs, world, torch.device("cuda", local_rank))
+    matrix, same = verify_ranks(obs, world, cdev)
     equal_single = None
     if rank == 0:
         e1 = SketchEngine(max_hosts=nh, max_services=nh * sp, max_clusters=16, enable_tdigest=True, max_batch_events=1 << 16, device=local_rank)
@@ -440,6 +442,8 @@ def main():
                     "(one RCCL per process; the ROCm 7.2 librccl's ncclCommInitRank does not return on part of the MI355X pool), 'rocm' = /opt/rocm/lib/librccl.so, or a path")
     ap.add_argument("--strict-exchange", action="store_true", help="exit non-zero when the in-library RCCL exchange was asked for but the run fell back to torch.distributed")
     ap.add_argument("--no-exchange-check", action="store_true", help="skip the (untimed) cross-rank register checks after an N > 1 run")
+    ap.add_argument("--share-device", action="store_true", help="test mode for a one-GPU box: every rank runs on device 0, the ranks meet over gloo and the "
+                    "library's RCCL entry points are served by tests/cpp/fakerccl (RCCL refuses two ranks on one device); exercises the whole N > 1 flow")
     ap.add_argument("--selftest-launch", action="store_true", help="no GPU: only the launch path and the cross-rank checksum exchange (gloo)")
     ap.add_argument("--selftest-corrupt-rank", type=int, default=-1, help="--selftest-launch: this rank reports a wrong checksum (the run must fail)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -463,19 +467,26 @@ def main():
         sys.exit(2)
     if args.selftest_launch:
         sys.exit(selftest_launch(args, rank, world))
+    if args.share_device:
+        local_rank = 0
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
         print(f"bench.py: rank {rank} needs device {local_rank}, {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
+    cdev = torch.device("cpu") if args.share_device else torch.device("cuda", local_rank)  # where the few control-plane collectives run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap rendezvous over loopback (see gys_rccl_unique_id)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if "GYS_RCCL_LIB" not in os.environ and args.rccl_lib != "rocm":  # before the library's first RCCL call (it binds with dlopen)
+        if "GYS_RCCL_LIB" not in os.environ and args.rccl_lib != "rocm" and not args.share_device:  # before the library's first RCCL call (it binds with dlopen)
             cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so") if args.rccl_lib == "torch" else args.rccl_lib
             if os.path.exists(cand):
                 os.environ["GYS_RCCL_LIB"] = cand
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_device:
+            os.environ.setdefault("GYS_RCCL_LIB", os.path.join(ROOT, "tests", "cpp", "fakerccl", "libfakerccl.so"))
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     if args.workload == "conn":
         if rank == 0:
@@ -504,7 +515,7 @@ def main():
         exchange = "torch.distributed"
         if args.exchange == "rccl":
             try:
-                uid = torch.zeros(capi.RCCL_UID_BYTES, dtype=torch.uint8, device="cuda")
+                uid = torch.zeros(capi.RCCL_UID_BYTES, dtype=torch.uint8, device=cdev)
                 if rank == 0:
                     uid.copy_(torch.frombuffer(bytearray(eng.rccl_unique_id()), dtype=torch.uint8))
                 dist.broadcast(uid, src=0)
@@ -530,7 +541,7 @@ def main():
                     raise RuntimeError(res.get("err", "ncclCommInitRank did not return within 60 s"))
             except Exception as ex:  # keep the run alive on the torch path
                 print(f"bench.py rank {rank}: in-library RCCL unavailable ({ex}); using torch.distributed", file=sys.stderr)
-        ok = torch.tensor([1 if exchange == "rccl_in_library" else 0], device="cuda")
+        ok = torch.tensor([1 if exchange == "rccl_in_library" else 0], device=cdev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks or none
         if int(ok.item()) == 0:
             exchange = "torch.distributed"
@@ -607,7 +618,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = eng.profile_get()
@@ -619,11 +630,11 @@ def main():
     xcheck = None
     if world > 1 and not args.no_exchange_check:
         regs = observe_registers(eng, ["cluster%d" % c for c in range(8)])
-        matrix, same = verify_ranks(regs, world, torch.device("cuda", local_rank))
-        side = exchange_side_check(args, rank, world, local_rank, L, eng, exchange, wire, SketchEngine, mid_buf)
+        matrix, same = verify_ranks(regs, world, cdev)
+        side = exchange_side_check(args, rank, world, local_rank, L, eng, exchange, wire, SketchEngine, mid_buf, cdev)
         xcheck = {"ranks_seen": len(matrix), "ranks_consistent": same, "families": REG_FAMILIES, "side_config": side,
                   "ok": bool(same and side["ranks_consistent"] and side["equals_single_rank_engine"] is not False)}
-        okt = torch.tensor([1 if xcheck["ok"] else 0], device="cuda")
+        okt = torch.tensor([1 if xcheck["ok"] else 0], device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)  # (rank 0 alone knows the single-rank comparison)
         xcheck["ok"] = bool(int(okt.item()))
 
@@ -681,8 +692,13 @@ def main():
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
             metric = "events/sec ingested + p50/p99 quantile error vs reference"
+        try:
+            from gyeeta_amd.build import build_commit
+            bc = build_commit()
+        except Exception:
+            bc = None
         out = {
-            "metric": metric,
+            "metric": metric, "build_commit": bc,
             "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic", "parity_ok": parity_ok,

@@ -17,6 +17,28 @@ def hipcc():
     return "hipcc"
 
 
+COMMIT_PATH = os.path.join(LIB_DIR, "build_commit.txt")
+
+
+def stamp_commit():
+    """which source tree the library was built from (the GPU box gets the built .so but not .git): `git rev-parse HEAD` + "+dirty" when
+    tracked files differ from it; read back by bench.py (build_commit) and tools/pmc_traffic.py (source_commit of the counter passes)"""
+    try:
+        root = os.path.dirname(HERE)
+        head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        dirty = subprocess.call(["git", "-C", root, "diff", "--quiet", "HEAD", "--", "gyeeta_amd", "include", "bench.py"], stderr=subprocess.DEVNULL) != 0
+        open(COMMIT_PATH, "w").write(head + ("+dirty" if dirty else "") + "\n")
+    except Exception:
+        pass
+
+
+def build_commit():
+    try:
+        return open(COMMIT_PATH).read().strip()
+    except Exception:
+        return None
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
@@ -34,6 +56,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    stamp_commit()
     return LIB_PATH
 
 

@@ -58,7 +58,13 @@ def per_kernel(root, counter, skip):
 fetch_dir, write_dir, events, keys, skip, outp = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
 f = per_kernel(fetch_dir, "FETCH_SIZE", skip)
 w = per_kernel(write_dir, "WRITE_SIZE", skip)
-res = {"events_per_launch": events, "service_keys": keys,
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:
+    from gyeeta_amd.build import build_commit
+    commit = build_commit()
+except Exception:
+    commit = None
+res = {"events_per_launch": events, "service_keys": keys, "source_commit": commit,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py; KiB -> bytes, FETCH_SIZE x2 (gfx950 correction)",
        "kernels": {k: {"fetch_bytes": int(f.get(k, 0) * 1024 * 2), "write_bytes": int(w.get(k, 0) * 1024)} for k in sorted(set(f) | set(w))}}
 json.dump(res, open(outp, "w"), indent=1)
