@@ -204,6 +204,7 @@ struct gys_ctx {
 	uint32_t *huge_scratch = nullptr;
 	// several-workgroups-per-key path (gys_huge.hpp): per-entry accumulators, chunk prefix, global tail list, fallback list
 	unsigned long long *huge_acc = nullptr, *huge_tail = nullptr;
+	uint32_t *huge_tb_list = nullptr;
 	uint32_t *huge_bm = nullptr, *huge_chunk_off = nullptr;
 	MergeEnt *huge_fb_list = nullptr;
 	uint32_t huge_maxent = 0;
@@ -994,6 +995,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			q.fb_list = c->huge_fb_list;
 			q.fb_count = c->merge_count + 6;
 			q.nent_used = c->merge_count + 7;
+			q.tb_list = c->huge_tb_list;
+			q.tb_count = c->merge_count + 10;
 			// the pool holds huge_maxent entries: the list is walked in rounds (a round beyond the list's end costs four empty launches)
 			const uint64_t list_cap = std::min<uint64_t>(std::min<uint64_t>(nsvc, n / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1), c->huge_list_cap);
 			for (uint64_t first = 0; first < list_cap; first += c->huge_maxent) {
@@ -1001,7 +1004,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 				hipLaunchKernelGGL(k_huge_plan, dim3(1), dim3(1024), 0, c->stream, q);
 				hipLaunchKernelGGL(k_huge_clear, dim3((uint32_t)c->ncu * 8), dim3(256), 0, c->stream, q);
 				hipLaunchKernelGGL(k_huge_count, dim3((uint32_t)c->ncu * 2), dim3(1024), GYS_HB_BINS * 4, c->stream, q);
-				hipLaunchKernelGGL(k_huge_merge, dim3((uint32_t)c->ncu), dim3(1024), (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4, c->stream, q);
+				// tier A: two 512-thread workgroups per CU (79 KiB of LDS each); tier B: whatever tier A handed over (usually nothing)
+				hipLaunchKernelGGL((k_huge_merge<512, GYS_HB_TAIL_A, false>), dim3((uint32_t)c->ncu * 2), dim3(512), (GYS_HB_BINS + GYS_HB_TAIL_A) * 4, c->stream, q);
+				hipLaunchKernelGGL((k_huge_merge<1024, GYS_HB_TAIL_LDS, true>), dim3((uint32_t)c->ncu), dim3(1024), (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4, c->stream, q);
 			}
 			h.huge_list = c->huge_fb_list;
 			h.huge_count = c->merge_count + 6;
@@ -1695,9 +1700,11 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		ALLOC(c->huge_bm, (uint64_t)c->huge_maxent * 16);
 		ALLOC(c->huge_chunk_off, (uint64_t)c->huge_maxent + 1);
 		ALLOC(c->huge_tail, (uint64_t)1 << 20);
+		ALLOC(c->huge_tb_list, (uint64_t)c->huge_maxent);
 		ALLOC(c->huge_fb_list, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1) + 1);
 		HIPCHK(hipFuncSetAttribute((const void *)k_huge_count, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_HB_BINS * 4));
-		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4));
+		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge<512, GYS_HB_TAIL_A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (GYS_HB_BINS + GYS_HB_TAIL_A) * 4));
+		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge<1024, GYS_HB_TAIL_LDS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4));
 	}
 	ALLOC(c->last_act32, (uint64_t)GYS_CMS_D * GYS_CMS_W);
 	ALLOC(c->last_act64, (uint64_t)GYS_CMS_D * GYS_CMS_W);
@@ -1773,7 +1780,7 @@ void gys_destroy(gys_ctx *c)
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
-			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
+			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_first, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};

@@ -9,7 +9,7 @@
 //                 64-KiB LDS image (integer-ms response times: all but ~10^-5 of them), the chunk's RESP_TIME_HASH bucket deltas read off
 //                 the image, CONN_BITMAP bits, min / max; the image is added to the entry's 64-KiB bin array in HBM (non-zero bins only);
 //                 values >= 16 384 go to a global tail list
-//   k_huge_merge  one 1024-thread workgroup per entry: bins -> LDS (+ the entry's buffered words), block scan, every bin's rank interval
+//   k_huge_merge  one workgroup per entry (two tiers: 512 threads / 512 tail values with two workgroups per CU, then 1024 / 16 384): bins -> LDS (+ the entry's buffered words), block scan, every bin's rank interval
 //                 intersected with the cluster rank intervals (the exact-integer assignment of k_digest_huge), tail values ranked among
 //                 themselves, records folded, clusters written back
 // The result is bit-identical to k_digest_merge / k_digest_huge (same definition, DESIGN.md "t-digest").  The values >= 16 384 of an entry (up to 16 384 of them) are
@@ -20,7 +20,8 @@ namespace gys {
 
 #define GYS_HB_BINS 16384u      // exact one-value bins of the LDS image / of an entry's bin array
 #define GYS_HB_CHUNK 16384u     // values per chunk
-#define GYS_HB_TAIL_LDS 16384u  // tail values (>= GYS_HB_BINS) one entry may carry on this path (sorted in LDS)
+#define GYS_HB_TAIL_LDS 16384u  // tail values (>= GYS_HB_BINS) one entry may carry on this path (sorted in LDS): tier B of k_huge_merge
+#define GYS_HB_TAIL_A 512u      // ... tier A (two workgroups per CU)
 #define GYS_HB_ACC 40u          // per entry: u64 [0..15] bucket counts, [16..31] bucket sums, [32] min | max << 32 (as biased u32), [33..] spare
 
 struct Huge2P {
@@ -38,6 +39,8 @@ struct Huge2P {
 	MergeEnt *fb_list;          // fallback entries for k_digest_huge
 	uint32_t *fb_count;
 	uint32_t *nent_used;        // entries this path handles ( = min(count, maxent), 0 when the tail list overflowed)
+	uint32_t *tb_list;          // [maxent] pool entries k_huge_merge's tier A hands to tier B (more tail values than tier A's LDS list takes)
+	uint32_t *tb_count;
 };
 
 // ---- plan + clear: chunk prefix over the entries this path takes; the rest go to the fallback list
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(1024) void k_huge_plan(Huge2P p)
 		p.chunk_off[nuse] = run;
 		*p.nent_used = nuse;
 		*p.tail_count = 0;
+		*p.tb_count = 0;
 	}
 }
 
@@ -191,28 +195,36 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 	}
 }
 
-// ---- merge: one workgroup per entry
-__global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
+// ---- merge: one workgroup per entry.  Two tiers (VERDICT r2 "tier the huge path"): a merge is a chain of dependent steps (entry -> meta /
+// clusters / bins -> LDS passes -> write-back), so ONE resident workgroup per CU leaves the CU idle through every global-memory latency
+// of the chain.  Tier A -- 512 threads, room for 512 tail values: 79 KiB of LDS, TWO workgroups per CU -- takes every entry; the rare
+// entry with more values >= 16 384 than that is handed to tier B (1024 threads, 16 384 tail values, the whole LDS of a CU) through
+// tb_list, and only what overflows THAT goes to the one-workgroup-per-key fallback (k_digest_huge).
+template <uint32_t NT, uint32_t TAIL, bool FROM_LIST>
+__global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 {
+	constexpr uint32_t BPT = GYS_HB_BINS / NT;    // bins per thread in the scan
 	GYS_DYN_LDS(uint32_t, s_img);                 // [GYS_HB_BINS] the entry's exact value counts (run + buffered words), then s_tail
-	uint32_t *s_tail = s_img + GYS_HB_BINS;       // [GYS_HB_TAIL_LDS] the entry's values >= GYS_HB_BINS, sorted
+	uint32_t *s_tail = s_img + GYS_HB_BINS;       // [TAIL] the entry's values >= GYS_HB_BINS, sorted
 	__shared__ int64_t s_csum[GYS_TD_NB];
 	__shared__ uint32_t s_ccnt[GYS_TD_NB];
 	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
 	__shared__ uint64_t s_T[GYS_TD_NB + 1];
 	__shared__ unsigned long long s_osum[GYS_TD_NB], s_ocnt[GYS_TD_NB];
-	__shared__ uint32_t s_part[1024], s_w[16];
+	__shared__ uint32_t s_part[NT], s_w[NT / 64];
 	__shared__ uint64_t s_cw[4];
 	__shared__ unsigned long long s_ha[32], s_hw[32]; // buffered words: exact {count, sum} per bucket, all not yet folded / window part
-	__shared__ unsigned long long s_pa[16][16], s_pw[16][16]; // ... accumulated per wave first (packed count : 24 | sum : 40)
+	__shared__ unsigned long long s_pa[NT / 64][16], s_pw[NT / 64][16]; // ... accumulated per wave first (packed count : 24 | sum : 40)
 	__shared__ uint32_t s_bm[16];
 	__shared__ uint32_t s_nc, s_ntail, s_over;
 	__shared__ int32_t s_min, s_max, s_wmax;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t nuse = *p.nent_used;
+	const uint32_t nuse = FROM_LIST ? *p.tb_count : *p.nent_used;
 	const bool tail_lost = *p.tail_count > p.tail_cap; // the global tail list overflowed: every entry goes to the fallback
-	for (uint32_t e = blockIdx.x; e < nuse; e += gridDim.x) {
+	for (uint32_t ei = blockIdx.x; ei < nuse; ei += gridDim.x) {
+		const uint32_t e = FROM_LIST ? p.tb_list[ei] : ei; // (tier B: the pool entries tier A handed over)
 		const MergeEnt ent = p.list[p.first + e];
+		if (tail_lost && FROM_LIST) continue; // (tier A has sent them to the fallback already)
 		if (tail_lost) {
 			if (tid == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = ent;
 			continue;
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 		const uint32_t nh = mt.y & 0xFFFFu, nw = mt.y >> 16, nwin0 = max(nh, nw);
 		const uint32_t *pend = p.d.td_pend + (size_t)slot * p.d.pcap;
 		const uint32_t *gb = p.bins + (size_t)e * GYS_HB_BINS;
-		for (uint32_t i = tid; i < GYS_HB_BINS / 4u; i += 1024u) ((uint4 *)s_img)[i] = ((const uint4 *)gb)[i];
+		for (uint32_t i = tid; i < GYS_HB_BINS / 4u; i += NT) ((uint4 *)s_img)[i] = ((const uint4 *)gb)[i];
 		if (tid < GYS_TD_NB) {
 			s_osum[tid] = 0;
 			s_ocnt[tid] = 0;
@@ -295,13 +307,13 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 			}
 			GYS_WAVE_SYNC();
 			int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmx = INT32_MIN;
-			for (uint32_t i = tid; i < npend; i += 1024u) {
+			for (uint32_t i = tid; i < npend; i += NT) {
 				const uint32_t word = pend[i], v = word >> GYS_ROW_BITS;
 				if (v < GYS_HB_BINS) {
 					atomicAdd(&s_img[v], 1u);
 				} else {
 					const uint32_t at = atomicAdd(&s_ntail, 1u);
-					if (at < GYS_HB_TAIL_LDS) s_tail[at] = v; else s_over = 1;
+					if (at < TAIL) s_tail[at] = v; else s_over = 1;
 				}
 				if (i >= nh) {
 					const uint32_t hb = resp_bucket((int64_t)v);
@@ -344,16 +356,19 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 		// this entry's tail values of the run
 		{
 			const uint32_t nt = min(*p.tail_count, p.tail_cap);
-			for (uint32_t i = tid; i < nt; i += 1024u) {
+			for (uint32_t i = tid; i < nt; i += NT) {
 				const unsigned long long t = p.tail[i];
 				if ((uint32_t)(t >> 32) != e) continue;
 				const uint32_t at = atomicAdd(&s_ntail, 1u);
-				if (at < GYS_HB_TAIL_LDS) s_tail[at] = (uint32_t)t; else s_over = 1;
+				if (at < TAIL) s_tail[at] = (uint32_t)t; else s_over = 1;
 			}
 		}
 		__syncthreads();
-		if (s_over) { // too many large values for the LDS list: the general kernel takes this entry (nothing has been modified)
-			if (tid == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = ent;
+		if (s_over) { // too many large values for this tier's LDS list (nothing has been modified): the next tier takes the entry
+			if (tid == 0) {
+				if (!FROM_LIST && TAIL < GYS_HB_TAIL_LDS) p.tb_list[atomicAdd(p.tb_count, 1u)] = e;
+				else p.fb_list[atomicAdd(p.fb_count, 1u)] = ent;
+			}
 			__syncthreads();
 			continue;
 		}
@@ -361,11 +376,11 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 		if (ntail > 1u) { // bitonic sort of the tail in LDS (padded to a power of two with +inf); equal values are interchangeable
 			uint32_t n2 = 2;
 			while (n2 < ntail) n2 <<= 1;
-			for (uint32_t i = ntail + tid; i < n2; i += 1024u) s_tail[i] = 0xFFFFFFFFu;
+			for (uint32_t i = ntail + tid; i < n2; i += NT) s_tail[i] = 0xFFFFFFFFu;
 			__syncthreads();
 			for (uint32_t k = 2; k <= n2; k <<= 1) {
 				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-					for (uint32_t i = tid; i < n2; i += 1024u) {
+					for (uint32_t i = tid; i < n2; i += NT) {
 						const uint32_t ixj = i ^ j;
 						if (ixj > i) {
 							const uint32_t a = s_tail[i], b = s_tail[ixj];
@@ -386,9 +401,9 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 		// block exclusive scan of the 16 bins per thread
 		uint32_t part = 0;
 		{
-			const uint4 *b4 = (const uint4 *)(s_img + tid * 16u);
+			const uint4 *b4 = (const uint4 *)(s_img + tid * BPT);
 #pragma unroll
-			for (uint32_t i = 0; i < 4u; ++i) {
+			for (uint32_t i = 0; i < BPT / 4u; ++i) {
 				const uint4 v = b4[i];
 				part += v.x + v.y + v.z + v.w;
 			}
@@ -402,7 +417,7 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 		if (lane == 63u) s_w[wave] = inc;
 		__syncthreads();
 		uint32_t pfx = inc - part, nlow = 0;
-		for (uint32_t k = 0; k < 16u; ++k) {
+		for (uint32_t k = 0; k < NT / 64u; ++k) {
 			if (k < wave) pfx += s_w[k];
 			nlow += s_w[k];
 		}
@@ -423,9 +438,9 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 					}
 					lt = (uint64_t)nlow + lo;
 				} else {
-					const uint32_t owner = (uint32_t)vmax / 16u;
+					const uint32_t owner = (uint32_t)vmax / BPT;
 					lt = s_part[owner];
-					for (uint32_t b = owner * 16u; b <= (uint32_t)vmax; ++b) lt += s_img[b];
+					for (uint32_t b = owner * BPT; b <= (uint32_t)vmax; ++b) lt += s_img[b];
 				}
 			}
 			const uint64_t mid2 = 2ull * (s_cpfx[tid] + lt) + (uint64_t)cc;
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 		// ---- values bin by bin: ranks [r0, r0 + c) of value v, le = old weight with mean <= v
 		{
 			uint64_t r0 = pfx;
-			const uint32_t vbeg = tid * 16u;
+			const uint32_t vbeg = tid * BPT;
 			uint32_t ci = 0; // first compacted cluster with mean > v; monotone in v
 			{
 				uint32_t lo = 0, hi = nc;
@@ -447,7 +462,7 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 				}
 				ci = lo;
 			}
-			for (uint32_t b = vbeg; b < vbeg + 16u; ++b) {
+			for (uint32_t b = vbeg; b < vbeg + BPT; ++b) {
 				const uint32_t c = s_img[b];
 				if (!c) continue;
 				const int64_t v = (int64_t)b;
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(1024) void k_huge_merge(Huge2P p)
 			}
 		}
 		// ---- the tail values: sorted, all values below 16 384 precede them
-		for (uint32_t j = tid; j < ntail; j += 1024u) {
+		for (uint32_t j = tid; j < ntail; j += NT) {
 			const uint32_t v = s_tail[j];
 			const uint64_t r = (uint64_t)nlow + j;
 			uint32_t lo = 0, hi = nc; // old weight with mean <= v

@@ -37,6 +37,7 @@ using namespace gys;
 
 namespace {
 int fails = 0;
+unsigned tier_b_entries = 0; // pool entries k_huge_merge's tier A handed to tier B over the whole run
 #define CHECK(c, ...)                                               \
 	do {                                                        \
 		if (!(c)) {                                         \
@@ -259,12 +260,17 @@ int main(int argc, char **argv)
 			hq.fb_list = fb.data();
 			hq.fb_count = &counts[6];
 			hq.nent_used = &counts[7];
+			std::vector<uint32_t> tb(maxent + 1);
+			hq.tb_list = tb.data();
+			hq.tb_count = &counts[10];
 			for (uint32_t first = 0; first < L[0]; first += maxent) {
 				hq.first = first;
 				kemu::launch(1, 1024, 0, [&] { k_huge_plan(hq); });
 				kemu::launch(2, 256, 0, [&] { k_huge_clear(hq); });
 				kemu::launch(2, 1024, GYS_HB_BINS * 4, [&] { k_huge_count(hq); });
-				kemu::launch(2, 1024, (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4, [&] { k_huge_merge(hq); });
+				kemu::launch(2, 512, (GYS_HB_BINS + GYS_HB_TAIL_A) * 4, [&] { k_huge_merge<512, GYS_HB_TAIL_A, false>(hq); });
+				tier_b_entries += counts[10];
+				kemu::launch(2, 1024, (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4, [&] { k_huge_merge<1024, GYS_HB_TAIL_LDS, true>(hq); });
 			}
 			if (batch == 6) CHECK(counts[6] >= 1, "batch 6: the key with 20 000 tail values was not handed to the fallback");
 			HugeP hf{};
@@ -308,6 +314,10 @@ int main(int argc, char **argv)
 		printf("%d checks failed\n", fails);
 		return 1;
 	}
-	printf("kemu spill ok\n");
+	if (!tier_b_entries) {
+		printf("no entry went through tier B of k_huge_merge\n");
+		return 1;
+	}
+	printf("kemu spill ok (tier B entries: %u)\n", tier_b_entries);
 	return 0;
 }
