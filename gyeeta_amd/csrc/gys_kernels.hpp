@@ -1640,15 +1640,13 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		s_T[tid] = (tid >= 1u && tid < GYS_TD_NB) ? (uint32_t)td_threshold(c_td_bnd[tid], (uint64_t)twoN) : (tid ? 0xFFFFFFFFu : 0u);
 		// ---- values, pass 1: bin count (-> arrival order inside the bin), list of large values, window part of the fold
 		const bool fold_scan = !query && nh == 0u; // the all-time deltas of the one-value bins come from the scan
-		uint32_t pos[4];
 		int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmax = INT32_MIN;
 #pragma unroll
 		for (uint32_t k = 0; k < 4u; ++k) {
 			const uint32_t i = tid + 256u * k;
-			pos[k] = 0;
 			if (i >= m) continue;
 			const uint32_t uv = wd[k] >> GYS_ROW_BITS;
-			pos[k] = atomicAdd(&s_bin[mb_bin(uv)], 1u) & 0xFFFFu;
+			atomicAdd(&s_bin[mb_bin(uv)], 1u); // (no rank inside the bin is needed: equal values are interchangeable, pass 2 works per bin)
 			const bool big = uv >= GYS_MB_EXACT;
 			if (big) s_big[atomicAdd(&s_nbig, 1u)] = (i << 20) | uv;
 			if (SCAN && i >= nh_mm) {
@@ -1747,24 +1745,34 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			atomicAdd(&s_osum[a], (unsigned long long)sm0);
 			atomicAdd(&s_ocnt[a], c0);
 		}
-		// ---- values, pass 2: rank and gap from the scanned bin
+		// ---- values, pass 2, PER BIN: the c values of a one-value bin are equal, so they take the consecutive mid-points
+		// first, first + 2, ... and only the cluster boundaries that fall between them matter: one threshold search per NON-EMPTY BIN
+		// (integer-millisecond response times repeat: ~860 buffered values hold ~200 distinct ones) instead of one per value, and one
+		// packed add per (bin, output cluster).  Thread t takes bins t, t + 256, t + 512, t + 768: the busy low bins spread over all waves.
 #pragma unroll
-		for (uint32_t k = 0; k < 4u; ++k) {
-			const uint32_t i = tid + 256u * k;
-			const uint32_t uv = wd[k] >> GYS_ROW_BITS;
-			if (i >= m || uv >= GYS_MB_EXACT) continue;
-			const uint32_t bw = s_bin[uv];
-			const uint32_t mid2 = 2u * ((bw & 0xFFFFu) + pos[k] + s_cpfx[bw >> 16]) + 1u;
+		for (uint32_t k = 0; k < GYS_MB_EXACT / 256u; ++k) {
+			const uint32_t b = tid + 256u * k;
+			const uint32_t bw = s_bin[b], c = (s_bin[b + 1u] & 0xFFFFu) - (bw & 0xFFFFu);
+			if (!c) continue;
+			uint32_t mid2 = 2u * ((bw & 0xFFFFu) + s_cpfx[bw >> 16]) + 1u;
 			uint32_t a = 0;
 #pragma unroll
 			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
 				if (mid2 >= s_T[a + step]) a += step;
+			uint32_t rem = c;
+			while (rem) { // (nearly always one round: a cluster spans far more mid-points than a bin's values)
+				const uint32_t Tn = s_T[a + 1u]; // first mid-point of the next cluster (~0 after the last)
+				const uint32_t kk = min(rem, (Tn - mid2 + 1u) >> 1); // values with mid2 + 2 r < Tn
 #if GYS_MB_PACKED
-			atomicAdd(&s_oval[a], GYS_PACK_ONE | (unsigned long long)uv);
+				atomicAdd(&s_oval[a], ((unsigned long long)kk << 40) | (unsigned long long)(kk * b));
 #else
-			atomicAdd(&s_osum[a], (unsigned long long)uv);
-			atomicAdd(&s_ocnt[a], 1u);
+				atomicAdd(&s_osum[a], (unsigned long long)(kk * b));
+				atomicAdd(&s_ocnt[a], kk);
 #endif
+				rem -= kk;
+				mid2 += 2u * kk;
+				++a;
+			}
 		}
 		// the (few) large values, one per thread from the list: rank inside the cell by comparison with the other large values, gap by
 		// search over the cluster thresholds
