@@ -1634,6 +1634,9 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	HIPCHK((resp_host_lds_attr<16, false, false>()));
 	HIPCHK((resp_host_lds_attr<16, true, false>()));
 	HIPCHK((resp_host_lds_attr<16, true, true>()));
+	HIPCHK((resp_host_lds_attr<12, false, false>())); // (GYS_TPT=12: up to 77 KiB of dynamic LDS)
+	HIPCHK((resp_host_lds_attr<12, true, false>()));
+	HIPCHK((resp_host_lds_attr<12, true, true>()));
 	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_levels) {

@@ -1438,6 +1438,9 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 #ifndef GYS_MB_PACKED
 #define GYS_MB_PACKED 1 // values accumulate into a packed {count, sum} word: one LDS atomic per value instead of two (r3c: -0.09 ms per window)
 #endif
+#ifndef GYS_MB_SKIP
+#define GYS_MB_SKIP 0 // TIMING EXPERIMENTS ONLY (results are wrong): 1 no per-bin pass, 2 no old-cluster / large-value placement, 4 no value pass 1,
+#endif                //   8 no bin scan, 16 no write-back, 32 nothing after the loads
 #define GYS_MB_EXACT 1024u
 #define GYS_MB_BINS 2048u // 1024 one-value bins + 10 octaves x 64 cells (values < 2^20), padded to 8 bins per thread
 #define GYS_MB_BPT 8u
@@ -1564,6 +1567,10 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 				if (i < m) wd[k] = i < ent.nbuf ? pend[i] : p.staged[run0 + (i - ent.nbuf)];
 			}
 		}
+		if (GYS_MB_SKIP & 32) { // (the loads stay live: an impossible value writes them out)
+			if ((wd[0] ^ wd[1] ^ wd[2] ^ wd[3] ^ c0 ^ (uint32_t)sm0) == 0xDEADBEEFu) p.td_cur[slot] = 1;
+			continue;
+		}
 		if (m == 0 && !SCAN) { // nothing buffered (query of a freshly merged key): the merged view is the digest itself
 			if (query && tid < GYS_TD_NB) {
 				q.out_sum[(size_t)w * GYS_TD_NB + tid] = sm0;
@@ -1644,7 +1651,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 #pragma unroll
 		for (uint32_t k = 0; k < 4u; ++k) {
 			const uint32_t i = tid + 256u * k;
-			if (i >= m) continue;
+			if (i >= m || (GYS_MB_SKIP & 4)) continue;
 			const uint32_t uv = wd[k] >> GYS_ROW_BITS;
 			atomicAdd(&s_bin[mb_bin(uv)], 1u); // (no rank inside the bin is needed: equal values are interchangeable, pass 2 works per bin)
 			const bool big = uv >= GYS_MB_EXACT;
@@ -1685,7 +1692,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		}
 		__syncthreads();
 		// ---- one scan over the bins: thread t owns bins [8t, 8t + 8)
-		{
+		if (!(GYS_MB_SKIP & 8)) {
 			uint32_t bv[GYS_MB_BPT], own = 0;
 			{
 				const uint4 lo4 = ((const uint4 *)s_bin)[2u * tid], hi4 = ((const uint4 *)s_bin)[2u * tid + 1u]; // two 16-byte reads per lane
@@ -1728,7 +1735,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		__syncthreads();
 		const uint32_t nbig = s_nbig;
 		// ---- old clusters: preceded by the old weight before them and by the values below their mean
-		if (c0) {
+		if (c0 && !(GYS_MB_SKIP & 2)) {
 			uint32_t nb = s_bin[mb_bin(thr)] & 0xFFFFu;
 			if (thr >= GYS_MB_EXACT) {
 				const uint32_t sh = (31u - (uint32_t)__clz((int)thr)) - 6u;
@@ -1753,7 +1760,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		for (uint32_t k = 0; k < GYS_MB_EXACT / 256u; ++k) {
 			const uint32_t b = tid + 256u * k;
 			const uint32_t bw = s_bin[b], c = (s_bin[b + 1u] & 0xFFFFu) - (bw & 0xFFFFu);
-			if (!c) continue;
+			if (!c || (GYS_MB_SKIP & 1)) continue;
 			uint32_t mid2 = 2u * ((bw & 0xFFFFu) + s_cpfx[bw >> 16]) + 1u;
 			uint32_t a = 0;
 #pragma unroll
@@ -1776,7 +1783,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		}
 		// the (few) large values, one per thread from the list: rank inside the cell by comparison with the other large values, gap by
 		// search over the cluster thresholds
-		for (uint32_t j = tid; j < nbig; j += 256u) {
+		for (uint32_t j = tid; j < ((GYS_MB_SKIP & 2) ? 0u : nbig); j += 256u) {
 			const uint32_t me = s_big[j], uv = me & 0xFFFFFu, i = me >> 20;
 			const uint32_t sh = (31u - (uint32_t)__clz((int)uv)) - 6u;
 			uint32_t r = s_bin[mb_bin(uv)] & 0xFFFFu;
@@ -1849,6 +1856,14 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			continue;
 		}
 		// ---- write back
+		if (GYS_MB_SKIP & 16) {
+			if (tid == 208u && !query) { // (the buffer still has to drain, or the next windows would queue the key forever)
+				*(uint4 *)&p.td_meta[slot] = make_uint4(0u, 0u, mt.z, mt.w);
+				p.td_cur[slot] = 0;
+			}
+			__syncthreads();
+			continue;
+		}
 		if (tid < GYS_TD_NB) {
 			int64_t *ws = query ? q.out_sum + (size_t)w * GYS_TD_NB : p.td_sum + (size_t)slot * GYS_TD_NB;
 			uint32_t *wc = query ? q.out_cnt + (size_t)w * GYS_TD_NB : p.td_cnt + (size_t)slot * GYS_TD_NB;
