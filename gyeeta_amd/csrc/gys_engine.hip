@@ -1690,9 +1690,9 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 		ALLOC(c->staged, B);
 		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1));
 		if (c->huge_blocks < 1) c->huge_blocks = 1;
-		// the several-workgroup path's pool shares the scratch: 64 KiB of bins per entry, up to 16 384 entries (1 GiB) when the batches can
+		// the several-workgroup path's pool shares the scratch: 64 KiB of bins per entry, up to 262 144 entries (16 GiB of 288) when the batches can
 		// carry that many large keys; the one-workgroup fallback needs huge_blocks x 4 MiB of it
-		c->huge_maxent = (uint32_t)std::max<uint64_t>((uint64_t)c->huge_blocks * GYS_HUGE_BINS / GYS_HB_BINS, std::min<uint64_t>(c->huge_list_cap, 16384));
+		c->huge_maxent = (uint32_t)std::max<uint64_t>((uint64_t)c->huge_blocks * GYS_HUGE_BINS / GYS_HB_BINS, std::min<uint64_t>(c->huge_list_cap, 262144)); // <= 16 GiB of bins: one round for a 2^29-event batch (167 773 possible entries) instead of eleven sets of empty launches
 		const uint64_t scratch_entries = c->huge_maxent;
 		if (const char *e = getenv("GYS_HUGE_MAXENT")) { // tests: a small pool, so that a modest batch walks its large keys in several rounds
 			const long v = atol(e);
