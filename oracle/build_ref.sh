@@ -77,6 +77,14 @@ public:
 };
 }
 EOF
+# LISTEN_SUMM_STATS<T> (server/gy_msocket.h:839-883) and CLUSTER_STATE_ONE (server/gy_mconnhdlr.cc:16032-16050) are small self-contained
+# classes inside files that cannot be compiled here (folly, liburcu, boost, Postgres).  Their TEXT is cut out of the reference where it
+# lies into the throw-away dir -- from the class head to the first "};" at the start of a line -- and compiled by ref_glue.cc
+# (#if __has_include): the reference's own update() / update_from_state(), pinned without the files around them.
+awk '/^template <typename T = int>/{hold=$0; next} /^class LISTEN_SUMM_STATS/{print hold; on=1} on{print} on&&/^};/{exit} {hold=""}' "$REF/server/gy_msocket.h" > "$T/ref_listen_summ_stats.h"
+awk '/^struct CLUSTER_STATE_ONE : public comm::MS_CLUSTER_STATE::STATE_ONE/{on=1} on{print} on&&/^};/{exit}' "$REF/server/gy_mconnhdlr.cc" > "$T/ref_cluster_state_one.h"
+grep -q "void update(const comm::LISTENER_STATE_NOTIFY" "$T/ref_listen_summ_stats.h" || rm -f "$T/ref_listen_summ_stats.h" "$T/ref_cluster_state_one.h"
+grep -q "update_from_state" "$T/ref_cluster_state_one.h" 2>/dev/null || rm -f "$T/ref_listen_summ_stats.h" "$T/ref_cluster_state_one.h"
 # the forced includes paper over gcc-8 era transitive-include assumptions in gy_common_inc.h
 g++ -std=c++17 -O2 -D_GNU_SOURCE -DNDEBUG -DTASK_COMM_LEN=16 -pthread -fno-strict-aliasing -fPIC -shared -w \
 	-include string -include string_view -include optional -include vector -include algorithm -include functional \

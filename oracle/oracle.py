@@ -257,6 +257,11 @@ def ref():
     _sig(R, "ref_ns_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, C.c_uint64, C.c_int])
     _sig(R, "ref_pair_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, u8p, C.c_int, C.c_uint16])
     _sig(R, "ref_machine_id_hash", C.c_uint32, [C.c_uint64, C.c_uint64])
+    if hasattr(R, "ref_has_summ_stats"):
+        _sig(R, "ref_has_summ_stats", C.c_int, [])
+        if R.ref_has_summ_stats():
+            _sig(R, "ref_listen_summ_update", None, [C.c_void_p, C.c_int, C.POINTER(C.c_int32)])
+            _sig(R, "ref_cluster_state_update", None, [u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int32)])
     if hasattr(R, "ref_resp_bucketid_from_threshold"):
         _sig(R, "ref_resp_bucketid_from_threshold", C.c_size_t, [C.c_int64])
     if hasattr(R, "ref_comm_sizeof"):

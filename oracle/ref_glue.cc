@@ -30,6 +30,15 @@
 #include "gy_statistics.h"
 #include "gy_inet_inc.h"
 #include "gy_comm_proto.h"       // wire structs + validators (gy_comm_proto.cc is compiled next to this file, see build_ref.sh)
+#if __has_include("ref_listen_summ_stats.h") && __has_include("ref_cluster_state_one.h")
+#define GYREF_HAS_SUMM 1
+namespace gyeeta {
+#include "ref_listen_summ_stats.h"  // the reference's LISTEN_SUMM_STATS<T>, text cut out of server/gy_msocket.h by build_ref.sh
+#include "ref_cluster_state_one.h"  // the reference's CLUSTER_STATE_ONE, text cut out of server/gy_mconnhdlr.cc
+}
+#else
+#define GYREF_HAS_SUMM 0
+#endif
 #include "SlabHistogramBucket.h" // thirdparty/ (in tree): folly::detail::SlabHistogramBuckets, the container behind TimeseriesSlabHistogram
 
 namespace gyeeta {
@@ -170,6 +179,38 @@ uint32_t ref_machine_id_hash(uint64_t first, uint64_t second)
 // get_bucketid_from_threshold<RESP_TIME_HASH> (common/gy_statistics.h:517-531): what TCP_LISTENER::get_curr_state compares
 // (common/gy_socket_stat.cc:2085-2087)
 size_t ref_resp_bucketid_from_threshold(int64_t threshold) { return get_bucketid_from_threshold<RESP_TIME_HASH>(threshold); }
+
+// LISTEN_SUMM_STATS<int>::update (server/gy_msocket.h:856-868) over n fixed-size LISTENER_STATE_NOTIFY records and
+// CLUSTER_STATE_ONE::update_from_state (server/gy_mconnhdlr.cc:16034-16049): the reference's own classes, cut out by build_ref.sh
+int ref_has_summ_stats(void) { return GYREF_HAS_SUMM; }
+#if GYREF_HAS_SUMM
+void ref_listen_summ_update(const uint8_t *recs88, int n, int32_t out[13])
+{
+	LISTEN_SUMM_STATS<int> s;
+	for (int i = 0; i < n; ++i) {
+		comm::LISTENER_STATE_NOTIFY r;
+		std::memcpy((void *)&r, recs88 + (size_t)i * sizeof(r), sizeof(r));
+		if (r.curr_state_ <= OBJ_STATE_E::STATE_DOWN) s.update(r); // (the guard of the caller, server/gy_mconnhdlr.cc:11252-11258)
+	}
+	for (int i = 0; i < 6; ++i) out[i] = s.nstates_[i];
+	out[6] = s.tot_qps_; out[7] = s.tot_act_conn_; out[8] = s.tot_kb_inbound_; out[9] = s.tot_kb_outbound_; out[10] = s.tot_ser_errors_;
+	out[11] = s.nlisteners_; out[12] = s.nactive_;
+}
+void ref_cluster_state_update(uint32_t st[11], uint32_t ntasks_issue, uint32_t ntasks, uint32_t nlisten_issue, uint32_t nlisten, int cpu_issue, int mem_issue,
+			      const int32_t summ[13])
+{
+	CLUSTER_STATE_ONE c;
+	std::memcpy((void *)static_cast<comm::MS_CLUSTER_STATE::STATE_ONE *>(&c), st, 44);
+	comm::HOST_STATE_NOTIFY h;
+	h.ntasks_issue_ = ntasks_issue; h.ntasks_ = ntasks; h.nlisten_issue_ = nlisten_issue; h.nlisten_ = nlisten; h.cpu_issue_ = !!cpu_issue; h.mem_issue_ = !!mem_issue;
+	LISTEN_SUMM_STATS<int> s;
+	for (int i = 0; i < 6; ++i) s.nstates_[i] = summ[i];
+	s.tot_qps_ = summ[6]; s.tot_act_conn_ = summ[7]; s.tot_kb_inbound_ = summ[8]; s.tot_kb_outbound_ = summ[9]; s.tot_ser_errors_ = summ[10];
+	s.nlisteners_ = summ[11]; s.nactive_ = summ[12];
+	c.update_from_state(h, s);
+	std::memcpy(st, (const void *)static_cast<const comm::MS_CLUSTER_STATE::STATE_ONE *>(&c), 44);
+}
+#endif
 
 size_t ref_sizeof(int what)
 {

@@ -240,3 +240,50 @@ def test_cluster_state_one_vs_reference(reflib, oracle):
         oa, ob = oracle.ClusterStateOne(*a.tolist()), oracle.ClusterStateOne(*b.tolist())
         L.gyo_cluster_state_add(C.byref(oa), C.byref(ob))
         assert list(oa.as_tuple()) == ra.tolist()  # wraps modulo 2^32 like the reference's uint32_t sums
+
+
+def test_listen_summ_stats_and_cluster_state_one_equal_the_reference_classes(oracle, reflib):
+    """LISTEN_SUMM_STATS<int>::update (server/gy_msocket.h:856-868) and CLUSTER_STATE_ONE::update_from_state
+    (server/gy_mconnhdlr.cc:16034-16049): the reference's own classes -- their text cut out of files that cannot be compiled here and
+    built into oracle/_ref by oracle/build_ref.sh -- against the oracle's restatements (gyo_listener_state_rollup,
+    gyo_cluster_state_update) on random record batches incl. invalid states, zero / huge query counts and counter wrap-around"""
+    import ctypes as C
+    import numpy as np
+    from gyeeta_amd import wire
+    if not hasattr(reflib, "ref_has_summ_stats") or not reflib.ref_has_summ_stats():
+        import pytest
+        pytest.skip("oracle/_ref built without the two server-side classes")
+    L = oracle.lib()
+    rng = np.random.default_rng(1234)
+    for trial in range(40):
+        n = int(rng.integers(0, 600))
+        rec = np.zeros(n, dtype=wire.LISTENER_STATE_NOTIFY)
+        rec["glob_id"] = rng.integers(1, 1 << 62, n, dtype=np.uint64)
+        big = trial % 5 == 0
+        rec["nqrys_5s"] = rng.integers(0, (1 << 32) if big else 5000, n, dtype=np.uint64).astype(np.uint32)
+        rec["nqrys_5s"][rng.random(n) < 0.2] = 0
+        for f in ("nconns_active", "curr_kbytes_inbound", "curr_kbytes_outbound", "ser_errors"):
+            rec[f] = rng.integers(0, (1 << 31) if big else 100000, n, dtype=np.uint64).astype(np.uint32)
+        rec["curr_state"] = rng.integers(0, 9 if trial % 3 == 0 else 6, n)  # states above STATE_DOWN are skipped by the caller
+        raw = rec.tobytes()
+        buf = np.frombuffer(raw, dtype=np.uint8) if n else np.zeros(1, dtype=np.uint8)
+        want = (C.c_int32 * 13)()
+        reflib.ref_listen_summ_update(buf.ctypes.data, n, want)
+        summ = oracle.ListenSummStats()
+        nerr = C.c_int(0)
+        L.gyo_listener_state_rollup(oracle.ptr(buf, oracle.u8p), n, C.cast(buf.ctypes.data + n * 88, oracle.u8p), C.byref(summ), C.byref(nerr))
+        assert list(summ.as_tuple()) == list(want), (trial, summ.as_tuple(), list(want))
+        assert nerr.value == int((rec["curr_state"] > 5).sum())
+        # one host into a cluster row that already holds something
+        st0 = rng.integers(0, 1 << 31, 11, dtype=np.uint64).astype(np.uint32)
+        a = st0.copy()
+        hs = [int(x) for x in rng.integers(0, 5000, 4)] + [int(rng.integers(0, 2)), int(rng.integers(0, 2))]
+        if trial % 4 == 0:
+            hs[0] = 0
+            hs[2] = 0
+        reflib.ref_cluster_state_update(oracle.ptr(a, oracle.u32p), hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], want)
+        b = oracle.ClusterStateOne()
+        for i, (name, _) in enumerate(b._fields_):
+            setattr(b, name, int(st0[i]))
+        L.gyo_cluster_state_update(C.byref(b), hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], C.byref(summ))
+        assert [getattr(b, nm) for nm, _ in b._fields_] == a.tolist(), (trial, hs)
