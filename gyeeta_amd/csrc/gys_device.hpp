@@ -106,9 +106,21 @@ __host__ __device__ __forceinline__ uint32_t jhash2_u64(uint64_t key, uint32_t i
 	return c;
 }
 
-// slot hash of the per-host listener sub-tables (an engine-internal structure: k_resp_host probes it once per event, so it is a
-// multiplicative hash -- one 64-bit multiply -- instead of the 36-instruction jhash mix; keys are (netns << 16 | port))
-__host__ __device__ __forceinline__ uint32_t host_tbl_hash(uint64_t key48) { return (uint32_t)((key48 * 0x9E3779B97F4A7C15ull) >> 32); }
+// slot hash of the per-host listener sub-tables (an engine-internal structure: k_resp_host probes it once per event).  Round 3: ONE 32-bit
+// multiply per event -- the port enters through a 24-bit multiply (full rate on CDNA; a 32 x 32 multiply is a quarter-rate instruction and
+// the earlier 64-bit multiplicative hash took three of them); the high half is folded down before the multiply (name spaces that differ
+// in their high bits only) and the product's high bits onto its low bits after it.  Checked on arithmetic progressions of ports / name
+// spaces, grids and random keys: probe lengths of a random function at both load factors.  The part of a many-listener host comes from
+// bits 21.. of the product (the fold keeps the slots of one part spread over its whole table).
+__host__ __device__ __forceinline__ uint32_t host_tbl_hash(uint32_t netns, uint32_t port)
+{
+	uint32_t x = netns ^ ((port & 0xFFFFu) * 0x9E3779u);
+	x ^= x >> 16;
+	return x * 0x85EBCA6Bu;
+}
+__host__ __device__ __forceinline__ uint32_t host_tbl_hash(uint64_t key48) { return host_tbl_hash((uint32_t)(key48 >> 16), (uint32_t)(key48 & 0xFFFFu)); }
+__host__ __device__ __forceinline__ uint32_t host_tbl_slot(uint32_t hk, uint32_t mask) { return (hk ^ (hk >> 13)) & mask; }
+__host__ __device__ __forceinline__ uint32_t host_tbl_part(uint32_t hk, uint32_t pmask) { return (hk >> 21) & pmask; }
 
 // ------------------------------------------------------------------------------------------------ bucket hashes
 struct HashDef {

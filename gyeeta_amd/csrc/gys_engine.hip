@@ -161,6 +161,7 @@ struct gys_ctx {
 	uint32_t batch_stamp = 0;
 	uint64_t n_batches_host_local = 0, n_batches_general = 0, n_batches_host_split = 0;
 	uint64_t htbl_used = 0, htbl_cap = 0, hlst_used = 0, hlst_cap = 0;
+	uint32_t resp_dyn_max = 0; // dynamic LDS a k_resp_host launch may use (160 KiB minus the kernel's static part)
 	uint64_t *htbl = nullptr; // pool of per-host sub-tables
 	uint32_t *hlst = nullptr; // pool of per-host local index -> slot lists
 	HostDesc *hdesc = nullptr; // [max_hosts] by host slot, then hdesc_ext_cap descriptors of the parts of many-listener hosts
@@ -494,7 +495,7 @@ int64_t host_tbl_find(const HostListeners &hl, uint64_t key48)
 {
 	if (hl.tbl.empty()) return -1;
 	const uint32_t mask = (uint32_t)hl.tbl.size() - 1;
-	uint32_t h = host_tbl_hash(key48) & mask;
+	uint32_t h = host_tbl_slot(host_tbl_hash(key48), mask);
 	for (uint32_t probes = 0; probes <= mask; ++probes) {
 		const uint64_t e = hl.tbl[h];
 		if (e == GYS_HOST_TBL_EMPTY) return -1;
@@ -507,12 +508,22 @@ int64_t host_tbl_find(const HostListeners &hl, uint64_t key48)
 void host_tbl_put(HostListeners &hl, uint64_t key48, uint32_t local)
 {
 	const uint32_t mask = (uint32_t)hl.tbl.size() - 1;
-	uint32_t h = host_tbl_hash(key48) & mask;
+	uint32_t h = host_tbl_slot(host_tbl_hash(key48), mask);
 	while (hl.tbl[h] != GYS_HOST_TBL_EMPTY) h = (h + 1) & mask;
 	hl.tbl[h] = (key48 << 16) | (uint64_t)local;
 }
 
-inline uint32_t host_part_of(uint64_t key48, uint32_t nparts) { return (host_tbl_hash(key48) >> 21) & (nparts - 1u); }
+inline uint32_t host_part_of(uint64_t key48, uint32_t nparts) { return host_tbl_part(host_tbl_hash(key48), nparts - 1u); }
+
+// capacity of a sub-table of n listeners: a QUARTER full while that is at most GYS_HOST_TBL_SPARSE entries (32 KiB of LDS; 97 % of the
+// events then find their listener in the two entries k_resp_host reads at once), half full above (up to 8192 entries for 4096 listeners)
+#define GYS_HOST_TBL_SPARSE 4096u
+inline uint32_t host_tbl_capacity(size_t n)
+{
+	static const uint32_t sparse = [] { const char *e = getenv("GYS_TBL_SPARSE"); return e ? (uint32_t)atoi(e) : GYS_HOST_TBL_SPARSE; }(); // (A/B: 0 = half full always)
+	const uint32_t c4 = next_pow2(std::max<uint64_t>(16, (uint64_t)n * 4));
+	return c4 <= sparse ? c4 : std::max<uint32_t>(std::min<uint32_t>(sparse, c4), next_pow2(std::max<uint64_t>(16, (uint64_t)n * 2)));
+}
 
 // (re)uploads one sub-table, its slot list and its descriptor hdesc[desc]; regions only ever grow, an outgrown region is abandoned in
 // the pool (geometric growth: the abandoned total stays below the final size, which is what the pool capacity accounts for).
@@ -564,8 +575,8 @@ void host_tbl_insert(HostListeners &t, uint64_t key48, uint32_t slot)
 	const uint32_t local = (uint32_t)t.slots.size();
 	t.slots.push_back(slot);
 	t.keys.push_back(key48);
-	if (t.slots.size() * 2 > t.tbl.size()) {
-		t.tbl.assign(next_pow2(std::max<uint64_t>(16, t.slots.size() * 2)), GYS_HOST_TBL_EMPTY);
+	if (host_tbl_capacity(t.slots.size()) > t.tbl.size()) {
+		t.tbl.assign(host_tbl_capacity(t.slots.size()), GYS_HOST_TBL_EMPTY);
 		for (uint32_t l = 0; l < t.keys.size(); ++l) host_tbl_put(t, t.keys[l], l);
 	} else {
 		host_tbl_put(t, key48, local);
@@ -660,13 +671,22 @@ void launch_resp_host(gys_ctx *c, uint32_t grid, size_t dyn, const RespHostP &hp
 	else hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, false>), dim3(grid), dim3(GYS_RESP_THREADS(TPT)), dyn, c->stream, hp);
 }
 
+// dynamic LDS a k_resp_host launch may ask for: the CU's 160 KiB minus the instance's own static part (read from the code object, so that
+// a kernel change cannot silently push a launch over the limit); *dyn_max ends as the smallest such room over the instances
 template <int TPT, bool SHARED, bool SPILL>
-hipError_t resp_host_lds_attr()
+hipError_t resp_host_lds_attr(uint32_t *dyn_max)
 {
-	hipError_t e = hipFuncSetAttribute((const void *)k_resp_host<TPT, SHARED, SPILL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-	if (e == hipSuccess && !SPILL)
-		e = hipFuncSetAttribute((const void *)k_resp_host<TPT, SHARED, SPILL, !SPILL>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-	return e;
+	for (int svchll = 0; svchll < (SPILL ? 1 : 2); ++svchll) {
+		const void *fn = svchll ? (const void *)k_resp_host<TPT, SHARED, SPILL, !SPILL> : (const void *)k_resp_host<TPT, SHARED, SPILL, false>;
+		hipFuncAttributes fa{};
+		hipError_t e = hipFuncGetAttributes(&fa, fn);
+		if (e != hipSuccess) return e;
+		const uint32_t room = (160u * 1024u - (uint32_t)fa.sharedSizeBytes) & ~255u;
+		e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)room);
+		if (e != hipSuccess) return e;
+		*dyn_max = std::min(*dyn_max, room);
+	}
+	return hipSuccess;
 }
 
 // resp pipeline on a device-resident batch
@@ -848,10 +868,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		} else {
 			c->n_batches_host_local++;
 		}
-		tpt16 = tpt == 16 && (uint64_t)max_tbl * 8 + (uint64_t)hp.lds_key_entries * 24 + 16384u * 6u <= 150u * 1024u;
-		// 512 threads x 12 events: two workgroups per CU when the host's tables leave room (<= 78 KiB per workgroup with the static part)
-		tpt12 = tpt == 12 && (uint64_t)max_tbl * 8 + (uint64_t)hp.lds_key_entries * 24 + 6144u * 6u <= 77u * 1024u;
-		dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_key_entries * 24 + (size_t)(tpt12 ? 6144u : tpt16 ? 16384u : 8192u) * 6u;
+		tpt16 = tpt == 16 && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 16384u) <= c->resp_dyn_max;
+		// 512 threads x 12 events: two workgroups per CU when the host's tables leave room (half a CU's LDS per workgroup with the static part)
+		tpt12 = tpt == 12 && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 6144u) <= c->resp_dyn_max / 2u - 2048u;
+		dyn = resp_host_lds_bytes(max_tbl, hp.lds_key_entries, tpt12 ? 6144u : tpt16 ? 16384u : 8192u);
 		{
 			ProfScope ps(c, "resp_host");
 			if (host_split) {
@@ -1618,8 +1638,8 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	ALLOC(c->topn_slot, S < 65536 ? S : 65536);
 	ALLOC(c->topn_metric, S < 65536 ? S : 65536);
 	ALLOC(c->dev_pcts, 64);
-	c->htbl_cap = 8 * S + 32 * H; // every host's live sub-table (<= 4 L + 16 entries) plus its outgrown regions (< the live one)
-	c->hlst_cap = 4 * S + 16 * H;
+	c->htbl_cap = 16 * S + 64 * H; // every host's live sub-table (<= 8 L + 16 entries: a quarter full) plus its outgrown regions (< the live one)
+	c->hlst_cap = 8 * S + 32 * H;
 	ALLOC(c->htbl, c->htbl_cap);
 	ALLOC(c->hlst, c->hlst_cap);
 	c->hdesc_ext_cap = (uint32_t)(S / GYS_HOST_MAX_LOCAL) * 4u + 64u; // parts of many-listener hosts (incl. abandoned cuts)
@@ -1628,15 +1648,16 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	ALLOC(c->host_spill, H);
 	c->host_lst.reserve(H);
 	// k_resp_host: up to 4096 sub-table entries (32 KiB) + 2048 x 24 B of per-key areas (48 KiB) + the tile image (48 or 96 KiB)
-	HIPCHK((resp_host_lds_attr<8, false, false>()));
-	HIPCHK((resp_host_lds_attr<8, true, false>()));
-	HIPCHK((resp_host_lds_attr<8, true, true>()));
-	HIPCHK((resp_host_lds_attr<16, false, false>()));
-	HIPCHK((resp_host_lds_attr<16, true, false>()));
-	HIPCHK((resp_host_lds_attr<16, true, true>()));
-	HIPCHK((resp_host_lds_attr<12, false, false>())); // (GYS_TPT=12: up to 77 KiB of dynamic LDS)
-	HIPCHK((resp_host_lds_attr<12, true, false>()));
-	HIPCHK((resp_host_lds_attr<12, true, true>()));
+	c->resp_dyn_max = 160u * 1024u;
+	HIPCHK((resp_host_lds_attr<8, false, false>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<8, true, false>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<8, true, true>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<16, false, false>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<16, true, false>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<16, true, true>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<12, false, false>(&c->resp_dyn_max))); // (GYS_TPT=12: half of the room per workgroup, two per CU)
+	HIPCHK((resp_host_lds_attr<12, true, false>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<12, true, true>(&c->resp_dyn_max)));
 	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_levels) {

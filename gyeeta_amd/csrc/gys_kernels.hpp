@@ -550,9 +550,6 @@ struct HostDesc {
 // with 512 threads (6144-event tiles, 76 KB of LDS at 1000 listeners: TWO workgroups per CU, so that one's prologue / scan / flush phases
 // run under the other's event phase)
 #define GYS_RESP_THREADS(TPT) ((TPT) == 12 ? 512 : 1024)
-#ifndef GYS_RESP_PREFETCH
-#define GYS_RESP_PREFETCH 0
-#endif
 #define GYS_SPLIT_PART 65536u // events per part when long segments are cut (SHARED)
 
 struct RespHostP {
@@ -582,28 +579,49 @@ struct RespHostP {
 	uint32_t dbg;              // timing experiments only (GYS_DBG): 1 no flush, 2 no image, 4 no HLL, 8 no all-service histogram, 16 no key counts
 };
 
+// LDS layout of one k_resp_host launch (bytes; shared by the engine and the tests): listener sub-table (+ 2 entries: the copy of entry 0
+// behind the last one lets a probe read two consecutive entries with one instruction), per-key areas (24 B per local index), tile image
+// (+ 2 entries: a parking place for the lanes of a short last round)
+__host__ __device__ __forceinline__ size_t resp_host_lds_bytes(uint32_t tbl_entries, uint32_t key_entries, uint32_t tile)
+{
+	return ((size_t)tbl_entries + 2u) * 8u + (size_t)key_entries * 24u + ((size_t)tile + 2u) * 6u;
+}
+
+#ifndef GYS_RESP_DBG
+#define GYS_RESP_DBG 0 // 1: RespHostP.dbg switches parts of the kernel off (timing experiments only, tools/r3h_phases.sh)
+#endif
+#define GYS_HQ_CAP 512u // HLL candidates queued per tile (late in a window ~0.1 % of a tile's events qualify; the queue is drained by the first GYS_HQ_CAP threads)
+#define GYS_DST_BIAS 65536ull // > the largest tile: (first word of a key's piece) - (start of its run in the image) + bias is positive
+#ifndef GYS_OPAQUE_LOADED4
+#define GYS_OPAQUE_LOADED4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+#endif
+#define GYS_MEM_FENCE() asm volatile("" ::: "memory") // compiler-only: memory operations are not moved across it (keeps a batch of LDS reads in front of the stores / the next batch)
+
 template <int TPT, bool SHARED, bool SPILL, bool SVCHLL>
 __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p)
 {
 	constexpr uint32_t T = GYS_RESP_THREADS(TPT);
 	constexpr uint32_t TILE = (uint32_t)TPT * T;
+	constexpr bool DBG = GYS_RESP_DBG != 0;
 	GYS_DYN_LDS(uint64_t, s_dyn);
 	__shared__ uint32_t s_wsum[T / 64];
 	__shared__ uint32_t s_drop[2];
-	__shared__ uint32_t s_floor;
+	__shared__ uint32_t s_floor[2]; // HLL floor of the even / odd tiles (refreshed per tile)
 	__shared__ unsigned long long s_gh[T / 64][16]; // per wave and bucket: count << 40 | sum of the wave's events since the last flush
 	__shared__ int32_t s_gmax;
 	__shared__ uint32_t s_bk[GYS_BUCKET_LUT ? 256 : 1];
+	__shared__ uint32_t s_hq[SPILL ? 1 : GYS_HQ_CAP]; // the tile's HLL candidates: register index | rank << 16
+	__shared__ uint32_t s_hqn;
+	__shared__ uint32_t s_park[64]; // the rank atomic of an event that is not kept lands here (one word per lane: no same-address serialisation)
 	if (GYS_BUCKET_LUT && !SPILL) resp_bucket_lut_init(s_bk, threadIdx.x, T);
 	const uint32_t Lc = p.lds_key_entries;
-	uint64_t *s_tbl = s_dyn;
-	uint64_t *s_base = s_dyn + p.lds_tbl_entries;  // [Lc] destination index of the key's piece of the tile (~0: dropped)
-	uint32_t *s_cur = (uint32_t *)(s_base + Lc);   // [Lc] words in the key's buffer (SPILL: non-zero = spilled key)
-	uint32_t *s_slot = s_cur + Lc;                 // [Lc] service slot of the local index
-	uint32_t *s_tcnt = s_slot + Lc;                // [Lc] the tile's values of the key
-	uint32_t *s_tstart = s_tcnt + Lc;              // [Lc] start of the key's run inside the tile image
-	uint32_t *s_val = s_tstart + Lc;               // [TILE] staged words grouped by key
-	uint16_t *s_key = (uint16_t *)(s_val + TILE);  // [TILE] local index of each image entry
+	uint64_t *s_tbl = s_dyn;                            // [lds_tbl_entries + 2]
+	uint64_t *s_dst = s_dyn + p.lds_tbl_entries + 2u;   // [Lc] index into dst (+ GYS_DST_BIAS) the key's piece of the tile would have if it started at image entry 0 (0: piece dropped)
+	uint32_t *s_cur = (uint32_t *)(s_dst + Lc);         // [Lc] words in the key's buffer (SPILL: non-zero = spilled key)
+	uint32_t *s_slot = s_cur + Lc;                      // [Lc] service slot of the local index
+	uint32_t *s_ts2 = s_slot + Lc;                      // [2][Lc] (even / odd tiles) the tile's values of the key (low half; the rank counter of the event phase) | start of its run in the image << 16
+	uint32_t *s_val = s_ts2 + 2u * Lc;                  // [TILE + 2] staged words grouped by key
+	uint16_t *s_key = (uint16_t *)(s_val + TILE + 2u);  // [TILE + 2] local index of each image entry
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const gys_resp_seg seg = p.segs[blockIdx.x];
 	const uint64_t e0 = seg.first_event;
@@ -624,19 +642,27 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 		const uint32_t c = p.td_cur[slot];
 		s_slot[k] = slot;
 		s_cur[k] = SPILL ? (c & GYS_SPILL_BIT) : c;
+		s_ts2[k] = 0;
+		s_ts2[Lc + k] = 0;
 	}
 	if (tid < 2) s_drop[tid] = 0;
 	if (tid < (T / 64) * 16) ((unsigned long long *)s_gh)[tid] = 0;
 	if (tid == 0) {
-		s_floor = SPILL ? 0u : 0xFFFFFFFFu;
+		s_hqn = 0;
+		s_floor[0] = SPILL ? 0u : 0xFFFFFFFFu;
+		s_floor[1] = 0xFFFFFFFFu;
 		s_gmax = INT32_MIN;
+		s_tbl[mask + 1u] = p.htbl[hd.tbl_off]; // a probe reads entries h and h + 1 at once
+		s_val[TILE] = 0;                       // the parking entry of the flush
+		s_key[TILE] = 0;
 	}
 	__syncthreads();
-	// HLL floor: a register can only grow, so min over the register file (read once per workgroup; stale L1 lines only lower it) is a
-	// lower bound for the rest of the window -- events whose rank does not exceed it skip the register read altogether.  Late in a
-	// window that is all but ~2^-floor of the events; without it every event pays a random 4-byte read.  (Per WORKGROUP, not per
-	// launch: a window's registers start at zero, so a launch-wide floor taken before the first workgroup is 0 for the whole batch --
-	// measured: 7.0 instead of 6.2 ms.)
+	// HLL floor: a register can only grow, so min over the register file (stale L1 lines only lower it) is a lower bound for what follows
+	// -- events whose rank does not exceed it skip the register access altogether.  Late in a window that is all but ~2^-floor of the
+	// events; without it every event pays a random 4-byte read.  Taken per WORKGROUP at its start (a window's registers start at zero, so
+	// a launch-wide floor taken before the first workgroup is 0 for the whole batch -- measured: 7.0 instead of 6.2 ms) and, round 3,
+	// REFRESHED PER TILE (tile t + 2 runs on the minimum taken behind tile t -- two tiles on, so that no barrier of its own is needed): the first workgroups of a window start with floor 0 and used to keep it for their whole segment -- with few,
+	// long segments (the per-rank load of an 8-GPU run: 1250 hosts x 429 000 events) that was a fifth of the batch reading a register per event.
 	if (!SPILL) {
 		if (e1 - e0 >= 4096u) {
 			uint32_t mn = 0xFFFFFFFFu;
@@ -647,139 +673,185 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 			}
 #pragma unroll
 			for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
-			if (lane == 0) atomicMin(&s_floor, mn);
+			if (lane == 0) atomicMin(&s_floor[0], mn);
 		} else if (tid == 0) {
-			s_floor = 0;
+			s_floor[0] = 0;
 		}
 		__syncthreads();
+		if (tid == 0) s_floor[1] = s_floor[0]; // (tiles 0 and 1 run on the floor taken here; tile t + 2 on the one refreshed behind tile t)
 	}
-	const uint32_t hll_floor = s_floor;
+	uint32_t hll_floor = 0;
 	const uint32_t K = (L + T - 1) / T;
 	const uint32_t klo = min(L, tid * K), khi = min(L, klo + K);
 	uint32_t *const dst = SPILL ? p.staged : p.td_pend;
+	uint32_t *const dstb = dst - GYS_DST_BIAS; // (only ever indexed with biased indices: see s_dst)
 
-	uint32_t ndrop_range = 0, ndrop_nol = 0, tile_no = 0;
+	uint32_t ndrop_range = 0, ndrop_nol = 0, tile_no = 0, dbg_sink = 0;
 	int32_t tmax = INT32_MIN;
 	for (uint64_t t0 = e0; t0 < e1; t0 += TILE, ++tile_no) {
-		for (uint32_t k = tid; k < L; k += T) s_tcnt[k] = 0;
-		__syncthreads();
-		// ---- resolve, filter, rank: 4 events per thread at a time, phase by phase (all event loads, then the arithmetic, then the HLL
-		// register reads, then the updates) so that each wave keeps several HBM requests in flight.  The loop over the groups of 4 is
+		// (no barrier here: the event phase of this tile touches nothing the flush of the previous one reads -- the per-key counters are
+		// double-buffered and were cleared two phases ago, the floor and the candidate queue were settled behind barriers of the
+		// previous tile; a wave that is done flushing starts on its next events while the others still flush)
+		uint32_t *const s_ts = s_ts2 + (tile_no & 1u) * Lc;
+		if (!SPILL) hll_floor = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_floor[tile_no & 1u]);
+		// ---- resolve, filter, rank: 4 events per thread at a time, each step for all four before the next one (event loads, listener
+		// probes, hashes, HLL register reads, rank atomics), in straight-line predicated code: the LDS / HBM round trips of the four
+		// events overlap instead of following each other (the branchy per-event form of round 2 compiled to one exposed LDS latency per
+		// probe and event).  Events are addressed by a 32-bit offset from the tile's (uniform) base.  The loop over the groups of 4 is
 		// NOT unrolled (one copy of the event code instead of TPT / 4: the unrolled form was > 100 KB of instructions, twice the
 		// instruction cache two CUs share); the per-event results live in registers all the same: wd / lr are shifted down by 4 per
 		// group, so that every index stays a compile-time constant and after TPT / 4 groups event g sits at wd[g].
+		const uint64_t left = e1 - t0;
+		const uint32_t rem = left < (uint64_t)TILE ? (uint32_t)left : TILE; // events of this tile (> 0)
+		const uint64_t *const tb = p.ev + 3u * t0;
 		uint32_t wd[TPT], lr[TPT]; // staged word (GYS_EV_DROPPED: not kept) / local index | rank inside the key's tile run << 12
 #pragma unroll
-		for (int u = 0; u < TPT; ++u) wd[u] = GYS_EV_DROPPED; // (a short last tile leaves the group loop early: unused places must read as dropped)
-		// software pipeline (GYS_RESP_PREFETCH): the words of group g + 1 are requested before group g is processed, so that the HBM
-		// latency of the next loads runs under the ~1000 instructions of the current group instead of in front of them
-		uint64_t n0[4], n1[4], n2[4];
-		if (GYS_RESP_PREFETCH) {
-#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const uint64_t i = t0 + tid + (uint64_t)u * T;
-				n0[u] = 0; n1[u] = 0; n2[u] = 0;
-				if (i < e1) {
-					n0[u] = p.ev[3 * i];
-					n1[u] = p.ev[3 * i + 1];
-					n2[u] = p.ev[3 * i + 2];
-				}
-			}
+		for (int u = 0; u < TPT; ++u) {
+			wd[u] = GYS_EV_DROPPED; // (a short last tile leaves the group loop early: unused places must read as dropped)
+			lr[u] = 0;
 		}
 #pragma unroll 1
 		for (int g = 0; g < TPT; g += 4) {
-			if (t0 + (uint64_t)g * T >= e1) break; // the segment's last tile is usually short (C3: 53 687 events = 3.28 tiles): no empty groups
+			if ((uint32_t)g * T >= rem) break; // the segment's last tile is usually short (C3: 53 687 events = 3.28 tiles): no empty groups
 			uint64_t w0[4], w1[4], w2[4];
-			if (GYS_RESP_PREFETCH) {
+			bool in[4];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					w0[u] = n0[u]; w1[u] = n1[u]; w2[u] = n2[u];
-				}
-				if (g + 4 < TPT) {
+			for (int u = 0; u < 4; ++u) {
+				const uint32_t o = (uint32_t)(g + u) * T + tid;
+				in[u] = o < rem;
+				const uint32_t oo = in[u] ? o : 0u; // (lanes past the end read the tile's first event and ignore it: no branch around the loads)
+				w0[u] = tb[3u * oo];
+				w1[u] = tb[3u * oo + 1u];
+				w2[u] = tb[3u * oo + 2u];
+			}
+			// (all twelve words pass through one opaque statement: the four events' loads are issued before the first word is used -- the
+			// scheduler otherwise waits for event 0 and starts on its fields before the loads of events 1..3 are even issued.  Requesting
+			// the NEXT group's words before this group is processed was measured twice (r3j, r3l / r3n: 1.95 against 1.80 ms at quarter
+			// size): slower -- the extra live registers spill and every vmcnt wait of the group then also waits for the prefetch)
+			GYS_OPAQUE_LOADED4(w0);
+			GYS_OPAQUE_LOADED4(w1);
+			GYS_OPAQUE_LOADED4(w2);
+			// struct ipv4_tuple_t {u32 saddr, daddr, netns; u16 sport, dport;} + u32 lsndtime, lrcvtime  (24 bytes)
+			uint32_t tresp[4], local[4];
+			uint64_t ea[4], eb[4];
+			bool ok[4], more[4];
 #pragma unroll
-					for (int u = 0; u < 4; ++u) {
-						const uint64_t i = t0 + tid + (uint64_t)(g + 4 + u) * T;
-						n0[u] = 0; n1[u] = 0; n2[u] = 0;
-						if (i < e1) {
-							n0[u] = p.ev[3 * i];
-							n1[u] = p.ev[3 * i + 1];
-							n2[u] = p.ev[3 * i + 2];
+			for (int u = 0; u < 4; ++u) {
+				const uint32_t netns = (uint32_t)w1[u];
+				const uint32_t sport = (uint32_t)bswap16((uint16_t)(w1[u] >> 32)); // ntohs :1526-1527
+				tresp[u] = (uint32_t)w2[u] - (uint32_t)(w2[u] >> 32);               // lsndtime - lrcvtime (:1519)
+				const bool range_ok = tresp[u] <= 1000000u;                         // "Ignore responses > 1000 sec or negative" (:1521-1524)
+				if (in[u] && !range_ok && hd.part == 0u) ndrop_range++;              // (counted once per event: by the workgroup of part 0)
+				const uint32_t hk = host_tbl_hash(netns, sport);
+				// (a listener of another part of this host: that part's workgroup has the event)
+				ok[u] = in[u] && range_ok && host_tbl_part(hk, hd.pmask) == hd.part;
+				const uint32_t h = host_tbl_slot(hk, mask);
+				ea[u] = s_tbl[h];
+				eb[u] = s_tbl[h + 1u];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				// entry = netns : 32 | port : 16 | local index : 16 -- compared as two 32-bit words
+				const uint32_t netns = (uint32_t)w1[u], sport = (uint32_t)bswap16((uint16_t)(w1[u] >> 32));
+				const uint32_t alo = (uint32_t)ea[u], ahi = (uint32_t)(ea[u] >> 32), blo = (uint32_t)eb[u], bhi = (uint32_t)(eb[u] >> 32);
+				const bool hit_a = ahi == netns && (alo >> 16) == sport, hit_b = bhi == netns && (blo >> 16) == sport;
+				const bool end_a = (alo & ahi) == 0xFFFFFFFFu, end_b = (blo & bhi) == 0xFFFFFFFFu;
+				uint32_t l = (hit_b && !end_a) ? (blo & 0xFFFFu) : GYS_NOSLOT;
+				l = hit_a ? (alo & 0xFFFFu) : l;
+				local[u] = l;
+				more[u] = ok[u] && !hit_a && !hit_b && !end_a && !end_b;
+			}
+			// third and later probes: 3 % of the events at a quarter-full table (one in eight at a half-full one)
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				if (more[u]) {
+					const uint64_t key48 = ((uint64_t)(uint32_t)w1[u] << 16) | (uint64_t)bswap16((uint16_t)(w1[u] >> 32));
+					uint32_t h = (host_tbl_slot(host_tbl_hash((uint32_t)(key48 >> 16), (uint32_t)(key48 & 0xFFFFu)), mask) + 2u) & mask;
+					for (uint32_t probes = 2; probes <= mask; ++probes) {
+						const uint64_t e = s_tbl[h];
+						if ((e >> 16) == key48) {
+							local[u] = (uint32_t)(e & 0xFFFFu);
+							break;
 						}
-					}
-				}
-			} else {
-#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const uint64_t i = t0 + tid + (uint64_t)(g + u) * T;
-					w0[u] = 0; w1[u] = 0; w2[u] = 0;
-					if (i < e1) {
-						w0[u] = p.ev[3 * i];
-						w1[u] = p.ev[3 * i + 1];
-						w2[u] = p.ev[3 * i + 2];
+						if (e == GYS_HOST_TBL_EMPTY) break;
+						h = (h + 1) & mask;
 					}
 				}
 			}
-			uint32_t hidx[4], hrank[4], hcur[4], nwd[4], nlr[4], rare = 0;
+			uint32_t nwd[4], nlr[4], hidx[4], hrank[4], hcur[4], rare = 0;
+			bool kept[4];
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
-				const uint64_t i = t0 + tid + (uint64_t)(g + u) * T;
-				// struct ipv4_tuple_t {u32 saddr, daddr, netns; u16 sport, dport;} + u32 lsndtime, lrcvtime  (24 bytes)
+				kept[u] = ok[u] && local[u] != GYS_NOSLOT;
+				if (ok[u] && local[u] == GYS_NOSLOT) ndrop_nol++; // no such listener: the reference ignores the event too (:1671-1676 miss path)
+				nlr[u] = kept[u] ? local[u] : 0u;
+			}
+			if (SPILL) {
+				uint32_t sc[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) sc[u] = s_cur[nlr[u]];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) kept[u] = kept[u] && sc[u] != 0u; // (else the key's values already sit in its buffer)
+			}
+			// the LDS operations of the four events first, all in flight at once: the RESP_TIME_HASH bucket of each response time (table read)
+			// and the event's rank inside its key's run of the tile (one returning atomic each; a place that kept nothing parks on a spare
+			// word) -- their latency runs under the flow hashes below, which are pinned behind them by the opaque statement
+			uint32_t bk[4], rk12[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const uint32_t dport = (uint32_t)bswap16((uint16_t)(w1[u] >> 48));
+				nwd[u] = kept[u] ? ((tresp[u] << GYS_ROW_BITS) | (dport & 0x1Fu)) : GYS_EV_DROPPED;
+				bk[u] = 15u; // (s_gh[.][15] is a spare cell)
+				if (!SPILL) {
+					const uint32_t b = resp_bucket_lut(s_bk, tresp[u]); // (read for every lane: no branch)
+					bk[u] = kept[u] ? b : 15u;
+				}
+			}
+			if (SPILL && !(kept[0] || kept[1] || kept[2] || kept[3])) continue; // (second pass: most groups hold no event of a spilled key; wd / lr already read as dropped)
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				uint32_t *const cell = (kept[u] && !(DBG && (p.dbg & 16u))) ? &s_ts[nlr[u]] : &s_park[lane];
+				rk12[u] = atomicAdd(cell, 1u);
+			}
+			if (!SPILL) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					// all-service histogram of the window (GY_HISTOGRAM::add_data on the aggregate): one packed LDS add per event
+					// (a place that kept nothing adds into the spare cell, which nobody reads: the add itself stays unconditional)
+					if (!(DBG && (p.dbg & 8u))) atomicAdd(&s_gh[wave][bk[u]], (1ull << 40) | (unsigned long long)tresp[u]);
+					tmax = max(tmax, kept[u] ? (int32_t)tresp[u] : INT32_MIN);
+				}
+				GYS_OPAQUE_LOADED4(w0);
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
 				const uint32_t saddr = (uint32_t)w0[u], daddr = (uint32_t)(w0[u] >> 32);
-				const uint32_t netns = (uint32_t)w1[u];
-				const uint16_t sport = bswap16((uint16_t)(w1[u] >> 32)), dport = bswap16((uint16_t)(w1[u] >> 48)); // ntohs :1526-1527
-				const uint32_t tresp = (uint32_t)w2[u] - (uint32_t)(w2[u] >> 32); // lsndtime - lrcvtime (:1519)
-				nwd[u] = GYS_EV_DROPPED;
-				nlr[u] = 0;
+				const uint16_t sport = bswap16((uint16_t)(w1[u] >> 32)), dport = bswap16((uint16_t)(w1[u] >> 48));
 				hrank[u] = 0;
 				hidx[u] = 0;
-				if (i >= e1) continue;
-				if (tresp > 1000000u) { // "Ignore responses > 1000 sec or negative" (:1521-1524)
-					if (hd.part == 0u) ndrop_range++; // (counted once per event: by the workgroup of part 0)
-					continue;
-				}
-				const uint64_t key48 = ((uint64_t)netns << 16) | (uint64_t)sport;
-				const uint32_t hk = host_tbl_hash(key48);
-				if (((hk >> 21) & hd.pmask) != hd.part) continue; // a listener of another part of this host: that part's workgroup has it
-				uint32_t h = hk & mask;
-				uint32_t local = GYS_NOSLOT;
-				for (uint32_t probes = 0; probes <= mask; ++probes) {
-					const uint64_t e = s_tbl[h];
-					if ((e >> 16) == key48) {
-						local = (uint32_t)(e & 0xFFFFu);
-						break;
-					}
-					if (e == GYS_HOST_TBL_EMPTY) break;
-					h = (h + 1) & mask;
-				}
-				if (local == GYS_NOSLOT) {
-					ndrop_nol++; // no such listener: the reference ignores the event too (:1671-1676 miss path)
-					continue;
-				}
-				if (SPILL && !s_cur[local]) continue; // the key's values already sit in its buffer
-				nwd[u] = (tresp << GYS_ROW_BITS) | ((uint32_t)dport & 0x1Fu);
-				nlr[u] = local;
 				if (!SPILL) {
-					// both ends IPv4 and no per-service registers: index and rank from the first hash half (flow_hll_idx_rank).  Everything
-					// else (0.0.0.0 / IPv6-mapped ends hash as 7 / 10 words; the per-service registers need all 64 bits) is rare or a
-					// non-default configuration and goes through ONE rolled copy of the general code below
-					if (p.dbg & 4u) {
+					// both ends IPv4 and no per-service registers: index and rank from the first hash half (flow_hll_idx_rank), computed for
+					// every lane (no branch; the result of a lane that kept nothing is discarded).  Everything else (0.0.0.0 / IPv6-mapped
+					// ends hash as 7 / 10 words; the per-service registers need all 64 bits) is rare or a non-default configuration and
+					// goes through ONE rolled copy of the general code below
+					if (DBG && (p.dbg & 4u)) {
 					} else if (!SVCHLL && daddr != 0 && saddr != 0) {
-						flow_hll_idx_rank(daddr, dport, saddr, sport, &hidx[u], &hrank[u]);
-						if (hrank[u] <= hll_floor) hrank[u] = 0; // cannot raise any register
-					} else {
+						uint32_t ix, rk;
+						flow_hll_idx_rank(daddr, dport, saddr, sport, &ix, &rk);
+						const bool up = kept[u] && rk > hll_floor; // (a rank at or below the floor cannot raise any register)
+						hidx[u] = up ? ix : 0u;
+						hrank[u] = up ? rk : 0u;
+					} else if (kept[u]) {
 						rare |= 1u << u;
 					}
-					// all-service histogram of the window (GY_HISTOGRAM::add_data on the aggregate): one packed LDS add per event
-					if (!(p.dbg & 8u)) atomicAdd(&s_gh[wave][resp_bucket_lut(s_bk, tresp)], (1ull << 40) | (unsigned long long)tresp);
-					tmax = max(tmax, (int32_t)tresp);
 				}
 			}
 			if (!SPILL && rare) {
 #pragma unroll 1
 				for (uint32_t u = 0; u < 4u; ++u) {
 					if (!((rare >> u) & 1u)) continue;
-					const uint64_t i = t0 + tid + (uint64_t)((uint32_t)g + u) * T;
-					const uint64_t x0 = p.ev[3 * i], x1 = p.ev[3 * i + 1]; // (re-read: keeps the four events' words out of this loop's registers)
+					const uint32_t o = ((uint32_t)g + u) * T + tid;
+					const uint64_t x0 = tb[3u * o], x1 = tb[3u * o + 1u]; // (re-read: keeps the four events' words out of this loop's registers)
 					const uint32_t saddr = (uint32_t)x0, daddr = (uint32_t)(x0 >> 32);
 					const uint16_t sport = bswap16((uint16_t)(x1 >> 32)), dport = bswap16((uint16_t)(x1 >> 48));
 					const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
@@ -792,16 +864,35 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 					if (rank > hll_floor && p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
 				}
 			}
-			if (!SPILL) {
+			// HLL register traffic is taken OUT of the event loop: an event whose rank exceeds the floor only queues {register, rank} in LDS;
+			// the queue is drained once per tile (below: one batch of register reads, the rare atomicMax behind them).  Measured (r3m): with the
+			// read-first register access inside this loop the waves of a tile waited on L2 / memory-side round trips in most groups -- 14 %
+			// of the kernel, against 5 % for the hashes themselves.  A full queue (the first workgroups of a window run with floor 0: every
+			// event qualifies) falls back to the access in place.
+			if (DBG && (p.dbg & 32u)) { // (timing only: hashes computed, no register traffic)
+				dbg_sink |= hrank[0] ^ hrank[1] ^ hrank[2] ^ hrank[3] ^ hidx[0] ^ hidx[1] ^ hidx[2] ^ hidx[3];
+			} else if (!SPILL && (hrank[0] | hrank[1] | hrank[2] | hrank[3])) {
+				uint32_t at[4];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) hcur[u] = hrank[u] ? p.hll32[hidx[u]] : 0xFFu; // read-first: most events do not raise the register
+				for (int u = 0; u < 4; ++u) at[u] = hrank[u] ? atomicAdd(&s_hqn, 1u) : 0u;
+				bool direct = false;
 #pragma unroll
-				for (int u = 0; u < 4; ++u)
-					if (hcur[u] < hrank[u]) atomicMax(&p.hll32[hidx[u]], hrank[u]);
+				for (int u = 0; u < 4; ++u) {
+					if (hrank[u]) {
+						if (at[u] < GYS_HQ_CAP) s_hq[at[u]] = hidx[u] | (hrank[u] << 16);
+						else direct = true;
+					}
+				}
+				if (direct) {
+#pragma unroll
+					for (int u = 0; u < 4; ++u) hcur[u] = (hrank[u] && at[u] >= GYS_HQ_CAP) ? p.hll32[hidx[u]] : 0xFFu; // read-first: most events do not raise the register
+#pragma unroll
+					for (int u = 0; u < 4; ++u)
+						if (hcur[u] < hrank[u]) atomicMax(&p.hll32[hidx[u]], hrank[u]);
+				}
 			}
 #pragma unroll
-			for (int u = 0; u < 4; ++u)
-				if (nwd[u] != GYS_EV_DROPPED && !(p.dbg & 16u)) nlr[u] |= atomicAdd(&s_tcnt[nlr[u]], 1u) << 12;
+			for (int u = 0; u < 4; ++u) nlr[u] |= kept[u] ? (rk12[u] << 12) : 0u;
 #pragma unroll
 			for (int j = 0; j + 4 < TPT; ++j) {
 				wd[j] = wd[j + 4];
@@ -814,10 +905,19 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 			}
 		}
 		__syncthreads();
+		// ---- the tile's queued HLL candidates: one per thread, the register read is in flight under the scan below
+		uint32_t hq_e = 0, hq_cur = 0xFFu;
+		if (!SPILL) {
+			const uint32_t nq = min(s_hqn, (uint32_t)GYS_HQ_CAP);
+			if (tid < nq) {
+				hq_e = s_hq[tid];
+				hq_cur = p.hll32[hq_e & 0xFFFFu];
+			}
+		}
 		// ---- exclusive scan of the tile's per-key counts -> run starts inside the image; every key's piece gets its destination
 		{
 			uint32_t sum = 0;
-			for (uint32_t k = klo; k < khi; ++k) sum += s_tcnt[k];
+			for (uint32_t k = klo; k < khi; ++k) sum += s_ts[k];
 			uint32_t inc = sum;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
@@ -826,11 +926,33 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 			}
 			if (lane == 63) s_wsum[wave] = inc;
 			__syncthreads();
+			if (!SPILL && tid == 0) {
+				s_hqn = 0; // (every thread has read the queue length; the next event phase is two barriers away)
+				if (t0 + 2ull * TILE < e1) s_floor[tile_no & 1u] = 0xFFFFFFFFu; // (read by every thread at the top of this tile; refilled behind this tile's flush for tile t + 2)
+			}
+			{
+				uint32_t *const s_tn = s_ts2 + ((tile_no + 1u) & 1u) * Lc; // the next tile's counters: last touched before the previous tile's image barrier
+				for (uint32_t k = klo; k < khi; ++k) s_tn[k] = 0;
+			}
+			if (!SPILL && (tile_no & 63u) == 63u && tid < 15u) { // keep the packed per-wave sums far from their 40-bit field (no wave adds to them between the event phase and the image barrier)
+				unsigned long long cnt = 0, sum = 0;
+				for (uint32_t w = 0; w < T / 64; ++w) {
+					const unsigned long long v = s_gh[w][tid];
+					cnt += v >> 40;
+					sum += v & ((1ull << 40) - 1);
+					s_gh[w][tid] = 0;
+				}
+				if (cnt) {
+					atomicAdd(&p.ghist[2 * tid], cnt);
+					atomicAdd(&p.ghist[2 * tid + 1], sum);
+					atomicAdd(&p.ghist[30], cnt);
+				}
+			}
 			uint32_t run = inc - sum;
 			for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
 			for (uint32_t k = klo; k < khi; ++k) {
-				const uint32_t c = s_tcnt[k];
-				s_tstart[k] = run;
+				const uint32_t c = s_ts[k];
+				s_ts[k] = c | (run << 16);
 				if (c) {
 					uint64_t base = ~0ull;
 					if (SPILL) {
@@ -846,52 +968,75 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p
 						// a piece that does not fit is dropped: the key's count ends above pcap, k_key_finalize then spills the key
 						if ((uint64_t)b + c <= (uint64_t)p.pcap) base = (uint64_t)s_slot[k] * p.pcap + b;
 					}
-					s_base[k] = base;
+					// image entry e of this key goes to dst[base + (e - run)]: kept as the (biased, hence never zero) index entry 0 would have
+					s_dst[k] = base != ~0ull ? base + GYS_DST_BIAS - run : 0ull;
 				}
 				run += c;
 			}
 		}
 		__syncthreads();
+		{
+			uint32_t ts[TPT];
 #pragma unroll
-		for (int u = 0; u < TPT; ++u) {
-			if (wd[u] == GYS_EV_DROPPED || (p.dbg & 2u)) continue;
-			const uint32_t local = lr[u] & 0xFFFu;
-			const uint32_t pos = s_tstart[local] + (lr[u] >> 12);
-			s_val[pos] = wd[u];
-			s_key[pos] = (uint16_t)local;
+			for (int u = 0; u < TPT; ++u) ts[u] = s_ts[lr[u] & 0xFFFu]; // (all reads first: one LDS round trip for the tile's 16 events, not 16)
+			GYS_MEM_FENCE();
+#pragma unroll
+			for (int u = 0; u < TPT; ++u) { // (no branch: a place that kept nothing writes the parking entry -- local index 0, as the flush expects there)
+				const bool keep = wd[u] != GYS_EV_DROPPED && !(DBG && (p.dbg & 2u));
+				const uint32_t pos = keep ? (ts[u] >> 16) + (lr[u] >> 12) : TILE;
+				s_val[pos] = wd[u];
+				s_key[pos] = (uint16_t)(lr[u] & 0xFFFu);
+			}
 		}
 		__syncthreads();
+		if (!SPILL && hq_cur < (hq_e >> 16)) atomicMax(&p.hll32[hq_e & 0xFFFFu], hq_e >> 16); // (the register read has had two phases to arrive)
 		{
 			uint32_t ntile = 0; // kept events of the tile (every thread computes it from the wave sums)
 #pragma unroll
 			for (uint32_t w = 0; w < T / 64; ++w) ntile += s_wsum[w];
-			if (p.dbg & 3u) ntile = 0;
-			for (uint32_t e = tid; e < ntile; e += T) {
-				const uint32_t k = s_key[e];
-				const uint64_t base = s_base[k];
-				if (base != ~0ull) dst[base + (e - s_tstart[k])] = s_val[e];
+			if (DBG && (p.dbg & 3u)) ntile = 0;
+			// consecutive image entries -> consecutive lanes -> consecutive addresses inside a key's piece.  8 entries per thread and round:
+			// keys and values of all eight, then the eight destinations, then the stores (two LDS round trips per round, not three per entry)
+			constexpr int FU = 8;
+			for (uint32_t eb0 = 0; eb0 < ntile; eb0 += (uint32_t)FU * T) {
+				uint32_t kk[FU], vv[FU];
+				uint64_t dd[FU];
+#pragma unroll
+				for (int j = 0; j < FU; ++j) {
+					const uint32_t e = eb0 + (uint32_t)j * T + tid;
+					const uint32_t ee = e < ntile ? e : TILE; // (past the end: the parking entry)
+					kk[j] = s_key[ee];
+					vv[j] = s_val[ee];
+				}
+				GYS_MEM_FENCE();
+#pragma unroll
+				for (int j = 0; j < FU; ++j) dd[j] = s_dst[kk[j]];
+				GYS_MEM_FENCE();
+#pragma unroll
+				for (int j = 0; j < FU; ++j) {
+					const uint32_t e = eb0 + (uint32_t)j * T + tid;
+					if (e < ntile && dd[j]) dstb[dd[j] + e] = vv[j];
+				}
+			}
+			// the next tile's HLL floor: the register file is re-read (L2 hits: every workgroup reads the same 64 KiB; behind the flush --
+			// held across it, the 16 registers of the four loads spill)
+			if (!SPILL && t0 + 2ull * TILE < e1) {
+				constexpr uint32_t NF = (1u << GYS_HLL_P) / 4u / T;
+				uint4 fv[NF];
+#pragma unroll
+				for (uint32_t j = 0; j < NF; ++j) fv[j] = ((const uint4 *)p.hll32)[tid + j * T];
+				uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+				for (uint32_t j = 0; j < NF; ++j) mn = min(min(mn, min(fv[j].x, fv[j].y)), min(fv[j].z, fv[j].w));
+#pragma unroll
+				for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
+				if (lane == 0) atomicMin(&s_floor[tile_no & 1u], mn);
 			}
 		}
-		if (!SPILL && (tile_no & 63u) == 63u) { // keep the packed per-wave sums far from their 40-bit field
-			__syncthreads();
-			if (tid < 15u) {
-				unsigned long long cnt = 0, sum = 0;
-				for (uint32_t w = 0; w < T / 64; ++w) {
-					const unsigned long long v = s_gh[w][tid];
-					cnt += v >> 40;
-					sum += v & ((1ull << 40) - 1);
-					s_gh[w][tid] = 0;
-				}
-				if (cnt) {
-					atomicAdd(&p.ghist[2 * tid], cnt);
-					atomicAdd(&p.ghist[2 * tid + 1], sum);
-					atomicAdd(&p.ghist[30], cnt);
-				}
-			}
-		}
-		// (the next tile's first barrier orders this tile's flush before the image is rewritten)
+		// (the next tile's event-phase barrier orders this tile's flush before destinations and image are rewritten)
 	}
 	if (SPILL) return;
+	if (DBG && dbg_sink == 0xDEADBEEFu) p.counters[CTR_RESP_EVENTS] = 1; // (keeps the hashes of the timing-only variant alive)
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) tmax = max(tmax, __shfl_xor(tmax, d, 64));
 	if (lane == 0 && tmax != INT32_MIN) atomicMax(&s_gmax, tmax);

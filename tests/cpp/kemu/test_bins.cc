@@ -5,6 +5,7 @@
 // part of the buffer already folded / belonging to an earlier window, with values arriving through a run in `staged` (spilled key),
 // and the hand-over of an entry whose weight needs 64-bit arithmetic.  Build + run: tests/test_kernel_logic_cpu.py.
 #define GYS_OPAQUE_VGPR(x) asm volatile("" : "+r"(x))
+#define GYS_OPAQUE_LOADED4(a) asm volatile("" : "+r"(a[0]), "+r"(a[1]), "+r"(a[2]), "+r"(a[3]))
 #define GYS_DYN_LDS(type, name) type *name = (type *)kemu::dyn_lds()
 #include "../../../gyeeta_amd/csrc/gys_kernels.hpp"
 

@@ -5,6 +5,7 @@
 // all-service histogram, every key's buffered values (as multisets) and digest, the per-window event counts, and for every key that
 // has just been re-clustered its complete histogram record.  Build + run: tests/test_kernel_logic_cpu.py.
 #define GYS_OPAQUE_VGPR(x) asm volatile("" : "+r"(x))
+#define GYS_OPAQUE_LOADED4(a) asm volatile("" : "+r"(a[0]), "+r"(a[1]), "+r"(a[2]), "+r"(a[3]))
 #define GYS_DYN_LDS(type, name) type *name = (type *)kemu::dyn_lds()
 #include "../../../gyeeta_amd/csrc/gys_kernels.hpp"
 
@@ -88,7 +89,7 @@ int main(int argc, char **argv)
 			const int slot = gyo_engine_register(orc, h, 0x100000ull * (h + 1) + s, netns, port);
 			CHECK(slot == (int)(slot0 + s), "oracle slot %d", slot);
 			const uint64_t key48 = ((uint64_t)netns << 16) | port;
-			uint32_t at = host_tbl_hash(key48) & d.mask;
+			uint32_t at = host_tbl_slot(host_tbl_hash(key48), d.mask);
 			while (htbl[d.tbl_off + at] != GYS_HOST_TBL_EMPTY) at = (at + 1) & d.mask;
 			htbl[d.tbl_off + at] = (key48 << 16) | s;
 			hlst.push_back(slot0 + s);
@@ -206,7 +207,7 @@ int main(int argc, char **argv)
 		hp.lds_tbl_entries = max_tbl;
 		hp.lds_key_entries = (max_l + 1u) & ~1u;
 		hp.fin = fin;
-		const size_t dyn = (size_t)max_tbl * 8 + (size_t)hp.lds_key_entries * 24 + (size_t)TILE * 6u;
+		const size_t dyn = resp_host_lds_bytes(max_tbl, hp.lds_key_entries, TILE);
 #ifdef KEMU_SPLIT
 		std::vector<gys_resp_seg> vsegs;
 		for (uint32_t h = 0; h < NH; ++h) {
