@@ -216,6 +216,14 @@ def host_fed_l2_threads(nthreads=16, secs=2.0):
         return {"error": str(ex)[:300]}
 
 
+def _kernel_sources():
+    try:
+        from gyeeta_amd.build import sources_sha
+        return sources_sha()
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel, events, nsvc):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by
     tools/pmc_collect.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
@@ -231,8 +239,11 @@ def pmc_traffic(kernel, events, nsvc):
         return None
     return {"bytes": k["fetch_bytes"] + k["write_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
             "source": t.get("source", "profiles/pmc_traffic.json"), "measured_in_this_run": False,
-            "source_commit": t.get("source_commit"), "note": "counter passes are separate rocprofv3 runs (profiles/pmc_traffic.json); "
-            "source_commit = the tree they were taken on, compare with build_commit of this line"}
+            "source_commit": t.get("source_commit"), "source_kernels": t.get("source_kernels"),
+            "same_kernels_as_this_run": (t.get("source_kernels") == _kernel_sources()) if t.get("source_kernels") else None,
+            "note": "counter passes are separate rocprofv3 runs (profiles/pmc_traffic.json); source_commit = the tree they were taken on; "
+            "source_kernels / kernel_sources = sha256 over the library's source files (equal: the counters are of these very kernels, "
+            "whatever documentation commits lie between)"}
 
 
 def self_launch(args):
@@ -698,7 +709,7 @@ def main():
         except Exception:
             bc = None
         out = {
-            "metric": metric, "build_commit": bc,
+            "metric": metric, "build_commit": bc, "kernel_sources": _kernel_sources(),
             "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic", "parity_ok": parity_ok,

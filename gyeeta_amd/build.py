@@ -27,16 +27,34 @@ def stamp_commit():
         root = os.path.dirname(HERE)
         head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
         dirty = subprocess.call(["git", "-C", root, "diff", "--quiet", "HEAD", "--", "gyeeta_amd", "include", "bench.py"], stderr=subprocess.DEVNULL) != 0
-        open(COMMIT_PATH, "w").write(head + ("+dirty" if dirty else "") + "\n")
+        open(COMMIT_PATH, "w").write(head + ("+dirty" if dirty else "") + " " + _hash_sources() + "\n")
     except Exception:
         pass
 
 
 def build_commit():
     try:
-        return open(COMMIT_PATH).read().strip()
+        return open(COMMIT_PATH).read().strip().split()[0]
     except Exception:
         return None
+
+
+def sources_sha():
+    """sha256 (first 16 hex digits) over the library's source files (DEPS): the same for two builds of the same kernels whatever commits
+    lie between them (a documentation commit moves HEAD, not the kernels) -- written next to the commit at build time, compared by
+    bench.py between the library it runs (kernel_sources) and the tree profiles/pmc_traffic.json was taken on (source_kernels)"""
+    try:
+        return open(COMMIT_PATH).read().strip().split()[1]
+    except Exception:
+        return None
+
+
+def _hash_sources():
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        h.update(open(os.path.join(CSRC, d), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def needs_build():

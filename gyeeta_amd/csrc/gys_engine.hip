@@ -792,8 +792,11 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	RespHostP hp{};
 	uint32_t hgrid = 0;
 	size_t dyn = 0;
-	// 16 events per thread and tile (16384-event tiles: longer per-key runs in the flush) when the LDS budget allows; GYS_TPT=8 for A/B
-	static const int tpt = [] { const char *e = getenv("GYS_TPT"); const int v = e ? atoi(e) : 16; return (v == 8 || v == 12) ? v : 16; }();
+	// tile form: 512 threads x 12 events (6144-event tiles) when the batch's tables leave room for TWO such workgroups per CU (hosts of up
+	// to ~500 listeners: one workgroup's load / scan / flush phases run under the other's event phase -- r3t: 1.59 against 1.79 ms at 480
+	// listeners per host); else 1024 threads x 16 events (16384-event tiles, one workgroup per CU: 1000-listener hosts -- there the two-
+	// workgroup form needs half-full tables and 6-value pieces and loses, r3l / r3n); else 1024 x 8.  GYS_TPT = 8 / 12 / 16 pins a form (A/B).
+	static const int tpt = [] { const char *e = getenv("GYS_TPT"); const int v = e ? atoi(e) : 0; return (v == 8 || v == 12 || v == 16) ? v : 0; }();
 	bool tpt16 = false, tpt12 = false;
 	if (host_local) {
 		hp.ev = (const uint64_t *)d_ev;
@@ -868,9 +871,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		} else {
 			c->n_batches_host_local++;
 		}
-		tpt16 = tpt == 16 && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 16384u) <= c->resp_dyn_max;
-		// 512 threads x 12 events: two workgroups per CU when the host's tables leave room (half a CU's LDS per workgroup with the static part)
-		tpt12 = tpt == 12 && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 6144u) <= c->resp_dyn_max / 2u - 2048u;
+		// (two workgroups per CU: each gets half of the CU's LDS -- resp_dyn_max is 160 KiB minus ONE static part)
+		tpt12 = (tpt == 12 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 6144u) + 160u * 1024u - c->resp_dyn_max <= 80u * 1024u;
+		tpt16 = !tpt12 && (tpt == 16 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 16384u) <= c->resp_dyn_max;
 		dyn = resp_host_lds_bytes(max_tbl, hp.lds_key_entries, tpt12 ? 6144u : tpt16 ? 16384u : 8192u);
 		{
 			ProfScope ps(c, "resp_host");

@@ -598,7 +598,7 @@ __host__ __device__ __forceinline__ size_t resp_host_lds_bytes(uint32_t tbl_entr
 #define GYS_MEM_FENCE() asm volatile("" ::: "memory") // compiler-only: memory operations are not moved across it (keeps a batch of LDS reads in front of the stores / the next batch)
 
 template <int TPT, bool SHARED, bool SPILL, bool SVCHLL>
-__global__ __launch_bounds__(GYS_RESP_THREADS(TPT)) void k_resp_host(RespHostP p)
+__global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHostP p) // (4 waves per SIMD: one 1024-thread workgroup or two 512-thread ones per CU)
 {
 	constexpr uint32_t T = GYS_RESP_THREADS(TPT);
 	constexpr uint32_t TILE = (uint32_t)TPT * T;
