@@ -2299,40 +2299,54 @@ struct ConnP {
 	unsigned long long *pair64;
 };
 
-#define GYS_CONN_THREADS 1024u
-#define GYS_CONN_AGG 2048u // LDS aggregation slots per workgroup (power of two, 2 x the records of a workgroup)
-__device__ __forceinline__ void conn_one(const ConnP &p, uint32_t i, uint32_t *s_key, unsigned long long (*s_acc)[3])
+#define GYS_CONN_THREADS 512u
+#define GYS_CONN_RECS 1024u // records per workgroup (two rounds of GYS_CONN_THREADS)
+#define GYS_CONN_AGG 2048u  // LDS aggregation slots per workgroup (power of two, 2 x the records of a workgroup)
+#ifndef GYS_CONN_SKIP
+#define GYS_CONN_SKIP 0 // TIMING EXPERIMENTS ONLY (results are wrong): 1 no flow hash / HLL, 2 nothing after the HLL, 4 no LDS aggregation, 8 loads only, 16 hash but no register access
+#endif
+// the words of a record the roll-up needs (the record's bytes [64, 224) staged in LDS: offsets below are relative to byte 64)
+struct ConnRec {
+	uint64_t a0, a1, a2, a3; // nat_cli_ @64: ip128 (16 B), ip32 @16, port @24
+	uint64_t b0, b1, b2, b3; // nat_ser_ @96
+	uint64_t tusec_close;    // @136
+	uint64_t task;           // @144 cli_task_aggr_id_
+	uint64_t ser_glob_id;    // @192
+	uint64_t bytes_sent, bytes_rcvd; // @208, @216
+};
+
+__device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, uint32_t *s_key, unsigned long long (*s_acc)[3])
 {
-	const uint8_t *rec = p.batch + p.offsets[i];
 	uint32_t c128[4], s128[4], c32, s32;
 	uint16_t cport, sport;
 	// flow key: PAIR_IP_PORT(nat_cli_, nat_ser_)  (server/gy_mconnhdlr.cc:8707)
-	{
-		// records start 8-byte aligned (COMM_HEADER::validate common/gy_comm_proto.cc:23-26) -> use 8-byte loads
-		const uint64_t *q = (const uint64_t *)(rec + 64);
-		const uint64_t a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-		c128[0] = (uint32_t)a0; c128[1] = (uint32_t)(a0 >> 32); c128[2] = (uint32_t)a1; c128[3] = (uint32_t)(a1 >> 32);
-		c32 = (uint32_t)a2;
-		cport = (uint16_t)a3;
-		const uint64_t *r = (const uint64_t *)(rec + 96);
-		const uint64_t b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3];
-		s128[0] = (uint32_t)b0; s128[1] = (uint32_t)(b0 >> 32); s128[2] = (uint32_t)b1; s128[3] = (uint32_t)(b1 >> 32);
-		s32 = (uint32_t)b2;
-		sport = (uint16_t)b3;
-	}
-	const uint64_t tusec_close = *(const uint64_t *)(rec + 136);
-	const uint64_t ser_glob_id = *(const uint64_t *)(rec + 192);
-	const uint64_t bytes_sent = *(const uint64_t *)(rec + 208), bytes_rcvd = *(const uint64_t *)(rec + 216);
+	c128[0] = (uint32_t)rc.a0; c128[1] = (uint32_t)(rc.a0 >> 32); c128[2] = (uint32_t)rc.a1; c128[3] = (uint32_t)(rc.a1 >> 32);
+	c32 = (uint32_t)rc.a2;
+	cport = (uint16_t)rc.a3;
+	s128[0] = (uint32_t)rc.b0; s128[1] = (uint32_t)(rc.b0 >> 32); s128[2] = (uint32_t)rc.b1; s128[3] = (uint32_t)(rc.b1 >> 32);
+	s32 = (uint32_t)rc.b2;
+	sport = (uint16_t)rc.b3;
+	const uint64_t tusec_close = rc.tusec_close, ser_glob_id = rc.ser_glob_id, bytes_sent = rc.bytes_sent, bytes_rcvd = rc.bytes_rcvd;
 
-	uint32_t w[10];
-	const uint32_t nw = pair_words(c32, c128, cport, s32, s128, sport, w);
-	const uint64_t h64 = hash64<10>(w, nw);
-	uint32_t idx, rank;
-	hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
-	if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
+	if (GYS_CONN_SKIP & 8) { // (timing experiments only: the record's words are read, nothing else)
+		if ((c128[0] ^ c128[3] ^ s128[1] ^ c32 ^ s32 ^ cport ^ sport ^ (uint32_t)tusec_close ^ (uint32_t)ser_glob_id ^ (uint32_t)bytes_sent ^ (uint32_t)bytes_rcvd) == 0xDEADBEEFu)
+			p.counters[CTR_CONN_UNKNOWN] = 1;
+		return;
+	}
+	if (!(GYS_CONN_SKIP & 1)) {
+		uint32_t w[10];
+		const uint32_t nw = pair_words(c32, c128, cport, s32, s128, sport, w);
+		const uint64_t h64 = hash64<10>(w, nw);
+		uint32_t idx, rank;
+		hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
+		if (GYS_CONN_SKIP & 16) { // (hash only)
+			if ((idx ^ rank) == 0xDEADBEEFu) p.counters[CTR_CONN_UNKNOWN] = 1;
+		} else if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
+	}
+	if (GYS_CONN_SKIP & 2) return;
 
 	if (p.pair32) { // per-(listener, client task group) roll-up (connlistenmap_ / connclientmap_, server/gy_msocket.h:240-290)
-		const uint64_t task = *(const uint64_t *)(rec + 144); // cli_task_aggr_id_
+		const uint64_t task = rc.task;
 #pragma unroll
 		for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
 			const uint32_t col = jhash2_4w((uint32_t)ser_glob_id, (uint32_t)(ser_glob_id >> 32), (uint32_t)task, (uint32_t)(task >> 32), GYS_SEED + r) &
@@ -2352,6 +2366,10 @@ __device__ __forceinline__ void conn_one(const ConnP &p, uint32_t i, uint32_t *s
 		}
 		return;
 	}
+	if (GYS_CONN_SKIP & 4) {
+		if (slot == 0xDEADBEEFu) p.counters[CTR_CONN_UNKNOWN] = 1;
+		return;
+	}
 	// the workgroup's LDS entry of the service (open addressing; 2048 entries for at most 1024 records: always room)
 	uint32_t h = (slot * 0x9E3779B1u) >> 21; // top 11 bits
 	for (;;) {
@@ -2364,14 +2382,25 @@ __device__ __forceinline__ void conn_one(const ConnP &p, uint32_t i, uint32_t *s
 	if (bytes_rcvd) atomicAdd(&s_acc[h][2], (unsigned long long)bytes_rcvd);
 }
 
+// Round 3: the records are read THROUGH LDS.  Round 2 had every lane read its own 280-byte record with thirteen 8-byte loads at a 280-byte
+// stride: every load instruction of a wave touched 64 different lines, each line was asked for by up to seven instructions in a row while
+// still in flight, and reading alone took 3.3 of the kernel's 3.4 ms (r3v: 1.4 TB/s).  Now a wave reads the bytes [64, 224) of its 64
+// records as 640 sixteen-byte pieces -- lane l of load t takes piece 64 t + l, i.e. ten neighbouring lanes cover one record's 160 bytes
+// and a load instruction covers ~6.4 records -- through each record's own offset (no assumption that records are contiguous or of equal
+// size), parks them in its private LDS region at a 168-byte record stride (8-byte accesses at that stride spread over all banks), and
+// every lane then reads its record's thirteen words from LDS.  A workgroup is 512 threads and walks TWO rounds of 512 records, so that
+// the LDS aggregation of the service accumulators still spans 1024 consecutive records (a partha's message is 2048 records of few services).
+#define GYS_CONN_STAGE_STRIDE 168u // bytes per staged record (160 used)
+#define GYS_CONN_ROUNDS (GYS_CONN_RECS / GYS_CONN_THREADS)
 __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 {
 	// Records reach madhava message by message, a message = up to 2048 connections of ONE partha (comm::TCP_CONN_NOTIFY::MAX_NUM_CONNS,
 	// common/gy_comm_proto.h:1738) and a partha has a few hundred listeners at most: the 1024 records of a workgroup touch few
 	// distinct services.  Their three window accumulators are therefore summed in an LDS table keyed by service slot first and
-	// flushed with one set of device atomics per DISTINCT service of the workgroup (the kernel is bound by the device-atomic rate).
+	// flushed with one set of device atomics per DISTINCT service of the workgroup.
 	__shared__ uint32_t s_key[GYS_CONN_AGG];
 	__shared__ unsigned long long s_acc[GYS_CONN_AGG][3];
+	__shared__ __align__(16) uint8_t s_stage[GYS_CONN_THREADS / 64u][64u * GYS_CONN_STAGE_STRIDE];
 	for (uint32_t k = threadIdx.x; k < GYS_CONN_AGG; k += GYS_CONN_THREADS) {
 		s_key[k] = GYS_NOSLOT;
 		s_acc[k][0] = 0;
@@ -2379,10 +2408,56 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 		s_acc[k][2] = 0;
 	}
 	__syncthreads();
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	wave_count(&p.counters[CTR_CONN_EVENTS], i < p.n);
-	if (i < p.n) conn_one(p, i, s_key, s_acc);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint8_t *const st = s_stage[wave];
+#pragma unroll 1
+	for (uint32_t round = 0; round < GYS_CONN_ROUNDS; ++round) {
+		const uint32_t i0 = blockIdx.x * GYS_CONN_RECS + round * GYS_CONN_THREADS + wave * 64u; // the wave's first record
+		if (i0 >= p.n) break;
+		const uint32_t i = i0 + lane;
+		const uint32_t nrec = min(64u, p.n - i0);
+		const uint32_t off = p.offsets[i < p.n ? i : p.n - 1u];
+		// ---- 640 pieces of 16 bytes: piece q = 10 r + j is bytes [64 + 16 j, 80 + 16 j) of the wave's record r
+		uint4 pc[10];
+#pragma unroll
+		for (uint32_t t = 0; t < 10u; ++t) {
+			const uint32_t q = t * 64u + lane;
+			const uint32_t r = (q * 6554u) >> 16; // q / 10 for q < 640
+			const uint32_t j = q - r * 10u;
+			const uint32_t ro = (uint32_t)__shfl((int)off, (int)min(r, nrec - 1u), 64); // (a piece past the wave's last record re-reads that record)
+			const uint32_t *src = (const uint32_t *)(p.batch + ro + 64u + 16u * j); // records start 8-byte aligned (COMM_HEADER::validate common/gy_comm_proto.cc:23-26)
+			pc[t] = make_uint4(src[0], src[1], src[2], src[3]);
+		}
+#pragma unroll
+		for (uint32_t t = 0; t < 10u; ++t) {
+			const uint32_t q = t * 64u + lane;
+			const uint32_t r = (q * 6554u) >> 16;
+			const uint32_t j = q - r * 10u;
+			uint64_t *dst = (uint64_t *)(st + r * GYS_CONN_STAGE_STRIDE + 16u * j);
+			dst[0] = (uint64_t)pc[t].x | ((uint64_t)pc[t].y << 32);
+			dst[1] = (uint64_t)pc[t].z | ((uint64_t)pc[t].w << 32);
+		}
+		GYS_WAVE_SYNC();
+		if (i < p.n) {
+			const uint64_t *rw = (const uint64_t *)(st + lane * GYS_CONN_STAGE_STRIDE);
+			ConnRec rc;
+			rc.a0 = rw[0]; rc.a1 = rw[1]; rc.a2 = rw[2]; rc.a3 = rw[3];
+			rc.b0 = rw[4]; rc.b1 = rw[5]; rc.b2 = rw[6]; rc.b3 = rw[7];
+			rc.tusec_close = rw[9];   // @136 = 64 + 72
+			rc.task = rw[10];         // @144
+			rc.ser_glob_id = rw[16];  // @192 = 64 + 128
+			rc.bytes_sent = rw[18];   // @208
+			rc.bytes_rcvd = rw[19];   // @216
+			conn_one(p, rc, s_key, s_acc);
+		}
+		GYS_WAVE_SYNC(); // (the region is rewritten by the next round)
+	}
 	__syncthreads();
+	if (threadIdx.x == 0) { // records of this workgroup: ONE add per workgroup (round 2 added once per wave: 2.6 x 10^5 adds on one address per 2^24 records)
+		const uint64_t first = (uint64_t)blockIdx.x * GYS_CONN_RECS;
+		const uint64_t cnt = first < p.n ? min((uint64_t)GYS_CONN_RECS, (uint64_t)p.n - first) : 0ull;
+		if (cnt) atomicAdd((unsigned long long *)&p.counters[CTR_CONN_EVENTS], (unsigned long long)cnt);
+	}
 	for (uint32_t k = threadIdx.x; k < GYS_CONN_AGG; k += GYS_CONN_THREADS) {
 		const uint32_t slot = s_key[k];
 		if (slot == GYS_NOSLOT) continue;
