@@ -396,11 +396,12 @@ struct FinP {
 	uint64_t *counters;
 };
 
+// the per-key part: meta record, window event count, spill; returns the merge size class the key is queued for (-1: none) and its entry
 template <bool WRITE_CUR>
-__device__ __forceinline__ void finalize_key(const FinP &p, bool valid, uint32_t key, uint32_t cur, uint32_t lane)
+__device__ __forceinline__ int finalize_one(const FinP &p, bool valid, uint32_t key, uint32_t cur, MergeEnt &ent)
 {
 	int cls = -1;
-	MergeEnt ent{};
+	ent = MergeEnt{};
 	if (valid) {
 		const uint4 mraw = *(const uint4 *)&p.td_meta[key];
 		const uint32_t npend0 = mraw.x;
@@ -438,34 +439,78 @@ __device__ __forceinline__ void finalize_key(const FinP &p, bool valid, uint32_t
 			}
 		}
 	}
-	const unsigned long long any = __ballot(cls >= 0);
-	if (!any) return;
+	return cls;
+}
+
+// Workgroup-collective end of batch for up to KMAX keys per thread.  The merge lists' cursors and the two statistics counters are ONE
+// address each for the whole chip: device-scope atomics on one address execute one after the other, ~10 ns apiece (measured on the
+// connection path, r3w: 2.6 x 10^5 per-wave adds on one counter were 2.4 of that kernel's 3.3 ms).  Round 2 reserved list places with one
+// returning atomic per WAVE and class (1.6 x 10^5 per 2^29-event batch on each of three addresses); now places are counted in LDS and
+// the workgroup takes its share of a list with one atomic per class (10^4 per batch), the statistics likewise.
+struct FinWg {
+	uint32_t cnt[4], base[4], nmerge;
+	unsigned long long nvals;
+};
+
+template <bool WRITE_CUR, int KMAX>
+__device__ __forceinline__ void finalize_keys_wg(const FinP &p, FinWg *sf, uint32_t tid, uint32_t lane, const bool (&valid)[KMAX], const uint32_t (&key)[KMAX],
+						 const uint32_t (&cur)[KMAX])
+{
+	if (tid < 4u) sf->cnt[tid] = 0;
+	if (tid == 4u) {
+		sf->nmerge = 0;
+		sf->nvals = 0;
+	}
+	__syncthreads();
+	int cls[KMAX];
+	MergeEnt ent[KMAX];
+	uint32_t pos[KMAX];
 	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		const unsigned long long nb = __ballot(cls == c);
-		if (nb) {
-			uint32_t at = 0;
-			if (lane == 0) at = atomicAdd(&p.counts[c], (uint32_t)__popcll(nb));
-			at = (uint32_t)__shfl((int)at, 0, 64);
-			if (cls == c) p.list[c][at + (uint32_t)__popcll(nb & below)] = ent;
+	for (int j = 0; j < KMAX; ++j) {
+		cls[j] = finalize_one<WRITE_CUR>(p, valid[j], key[j], cur[j], ent[j]);
+		pos[j] = 0;
+		const unsigned long long any = __ballot(cls[j] >= 0);
+		if (any) { // (wave-uniform)
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const unsigned long long nb = __ballot(cls[j] == c);
+				if (nb) {
+					uint32_t at = 0;
+					if (lane == 0) at = atomicAdd(&sf->cnt[c], (uint32_t)__popcll(nb));
+					at = (uint32_t)__shfl((int)at, 0, 64);
+					if (cls[j] == c) pos[j] = at + (uint32_t)__popcll(nb & below);
+				}
+			}
+			// statistics: re-clusterings queued and the values they carry
+			uint32_t nv = cls[j] >= 0 ? ent[j].nbuf + ent[j].mrun : 0u;
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1) nv += (uint32_t)__shfl_xor((int)nv, d, 64);
+			if (lane == 0) {
+				atomicAdd(&sf->nmerge, (uint32_t)__popcll(any));
+				atomicAdd(&sf->nvals, (unsigned long long)nv);
+			}
 		}
 	}
-	// statistics: re-clusterings queued and the values they carry (one pair of atomics per wave)
-	uint32_t nv = cls >= 0 ? ent.nbuf + ent.mrun : 0u;
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) nv += (uint32_t)__shfl_xor((int)nv, d, 64);
-	if (lane == 0) {
-		atomicAdd((unsigned long long *)&p.counters[CTR_TD_MERGES], (unsigned long long)__popcll(any));
-		atomicAdd((unsigned long long *)&p.counters[CTR_TD_MERGE_VALUES], (unsigned long long)nv);
+	__syncthreads();
+	if (tid < 4u && sf->cnt[tid]) sf->base[tid] = atomicAdd(&p.counts[tid], sf->cnt[tid]);
+	if (tid == 4u && sf->nmerge) {
+		atomicAdd((unsigned long long *)&p.counters[CTR_TD_MERGES], (unsigned long long)sf->nmerge);
+		atomicAdd((unsigned long long *)&p.counters[CTR_TD_MERGE_VALUES], sf->nvals);
 	}
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < KMAX; ++j)
+		if (cls[j] >= 0) p.list[cls[j]][sf->base[cls[j]] + pos[j]] = ent[j];
 }
 
 __global__ __launch_bounds__(256) void k_key_finalize(FinP p)
 {
-	const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool valid = key < p.nsvc;
-	finalize_key<false>(p, valid, key, valid ? p.td_cur[key] : 0u, threadIdx.x & 63u);
+	__shared__ FinWg s_fin;
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool valid[1] = {k < p.nsvc};
+	const uint32_t key[1] = {k}, cur[1] = {valid[0] ? p.td_cur[k] : 0u};
+	finalize_keys_wg<false, 1>(p, &s_fin, threadIdx.x, threadIdx.x & 63u, valid, key, cur);
 }
 
 // ---------------------------------------------------------------------------------------------------- Count-Min rows of the window
@@ -612,6 +657,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 	__shared__ uint32_t s_bk[GYS_BUCKET_LUT ? 256 : 1];
 	__shared__ uint32_t s_hq[SPILL ? 1 : GYS_HQ_CAP]; // the tile's HLL candidates: register index | rank << 16
 	__shared__ uint32_t s_hqn;
+	__shared__ FinWg s_fin;
 	__shared__ uint32_t s_park[64]; // the rank atomic of an event that is not kept lands here (one word per lane: no same-address serialisation)
 	if (GYS_BUCKET_LUT && !SPILL) resp_bucket_lut_init(s_bk, threadIdx.x, T);
 	const uint32_t Lc = p.lds_key_entries;
@@ -1043,24 +1089,36 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
 	if (ndrop_nol) atomicAdd(&s_drop[1], ndrop_nol);
 	__syncthreads();
-	if (!SHARED) // the host's keys are this workgroup's alone: their end-of-batch bookkeeping happens here (no pass over all services)
-		for (uint32_t kb = 0; kb < L; kb += T) {
-			const uint32_t k = kb + tid;
-			const bool valid = k < L;
-			finalize_key<true>(p.fin, valid, valid ? s_slot[k] : 0u, valid ? s_cur[k] : 0u, lane);
-		}
-	if (tid < 15u) {
+	if (tid < 64u) { // (wave 0: the 15 bucket sums, and their total with ONE add -- fifteen adds on the one total cell per workgroup were 1.5 x 10^5 per batch on one address)
 		unsigned long long cnt = 0, sum = 0;
-		for (uint32_t w = 0; w < T / 64; ++w) {
-			const unsigned long long v = s_gh[w][tid];
-			cnt += v >> 40;
-			sum += v & ((1ull << 40) - 1);
+		if (tid < 15u) {
+			for (uint32_t w = 0; w < T / 64; ++w) {
+				const unsigned long long v = s_gh[w][tid];
+				cnt += v >> 40;
+				sum += v & ((1ull << 40) - 1);
+			}
+			if (cnt) {
+				atomicAdd(&p.ghist[2 * tid], cnt);
+				atomicAdd(&p.ghist[2 * tid + 1], sum);
+			}
 		}
-		if (cnt) {
-			atomicAdd(&p.ghist[2 * tid], cnt);
-			atomicAdd(&p.ghist[2 * tid + 1], sum);
-			atomicAdd(&p.ghist[30], cnt);
+		unsigned long long tot = cnt;
+#pragma unroll
+		for (int d = 8; d >= 1; d >>= 1) tot += (unsigned long long)__shfl_xor((long long)tot, d, 64);
+		if (tid == 0 && tot) atomicAdd(&p.ghist[30], tot);
+	}
+	if (!SHARED) { // the host's keys are this workgroup's alone: their end-of-batch bookkeeping happens here (no pass over all services)
+		constexpr int KMAX = (int)(2048u / T); // (GYS_HOST_MAX_LOCAL listeners per sub-table at most)
+		bool fvalid[KMAX];
+		uint32_t fkey[KMAX], fcur[KMAX];
+#pragma unroll
+		for (int j = 0; j < KMAX; ++j) {
+			const uint32_t k = (uint32_t)j * T + tid;
+			fvalid[j] = k < L;
+			fkey[j] = fvalid[j] ? s_slot[k] : 0u;
+			fcur[j] = fvalid[j] ? s_cur[k] : 0u;
 		}
+		finalize_keys_wg<true, KMAX>(p.fin, &s_fin, tid, lane, fvalid, fkey, fcur);
 	}
 	if (tid == 0) {
 		if (s_gmax != INT32_MIN) atomicMax(p.gmax, (long long)s_gmax);
