@@ -19,10 +19,12 @@
 namespace gys {
 
 #define GYS_HB_BINS 16384u      // exact one-value bins of the LDS image / of an entry's bin array
-#define GYS_HB_CHUNK 16384u     // values per chunk
+#ifndef GYS_HB_CHUNK
+#define GYS_HB_CHUNK 131072u    // values per chunk (round 3: 16 384 before -- every chunk ends with one device atomic per non-zero bin of its image, ~1500 per chunk
+#endif                          // whatever its size: the C5 window paid 5 x 10^7 of them, 4.8 ms; eight times the values per chunk, an eighth of the adds)
 #define GYS_HB_TAIL_LDS 16384u  // tail values (>= GYS_HB_BINS) one entry may carry on this path (sorted in LDS): tier B of k_huge_merge
 #define GYS_HB_TAIL_A 512u      // ... tier A (two workgroups per CU)
-#define GYS_HB_ACC 40u          // per entry: u64 [0..15] bucket counts, [16..31] bucket sums, [32] min | max << 32 (as biased u32), [33..] spare
+#define GYS_HB_ACC 40u          // per entry: u64 [0..15] bucket counts, [16..31] bucket sums, [32] min | max << 32 (as biased u32), [33] tail values of the entry in the global list, [34..] spare
 
 struct Huge2P {
 	DigestP d;
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 				atomicAdd(&s_hs[b], (unsigned long long)v);
 				const uint32_t at = atomicAdd(p.tail_count, 1u);
 				if (at < p.tail_cap) p.tail[at] = ((unsigned long long)e << 32) | v;
+				atomicAdd(&p.acc[(size_t)e * GYS_HB_ACC + 33u], 1ull); // the entry's own count of tail values: an entry without any skips the list
 			}
 		}
 #pragma unroll
@@ -153,12 +156,14 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 		// equal to the bin); a thread's 16 consecutive bins touch at most three buckets
 		{
 			uint32_t *gb = p.bins + (size_t)e * GYS_HB_BINS;
+			const bool only = p.chunk_off[e + 1u] - p.chunk_off[e] == 1u; // the entry's only chunk: its (cleared) bins are written, not added to
 			uint32_t curb = 0xFFu;
 			unsigned long long ac = 0, as = 0;
 			for (uint32_t k = 0; k < 16u; ++k) {
 				const uint32_t bin = tid * 16u + k, cnt = s_img[bin];
 				if (!cnt) continue;
-				atomicAdd(&gb[bin], cnt);
+				if (only) gb[bin] = cnt;
+				else atomicAdd(&gb[bin], cnt);
 				const uint32_t b = resp_bucket((int64_t)bin);
 				if (b != curb) {
 					if (ac) {
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
 	__shared__ uint64_t s_T[GYS_TD_NB + 1];
 	__shared__ unsigned long long s_osum[GYS_TD_NB], s_ocnt[GYS_TD_NB];
-	__shared__ uint32_t s_part[NT], s_w[NT / 64];
+	__shared__ uint32_t s_w[NT / 64];
 	__shared__ uint64_t s_cw[4];
 	__shared__ unsigned long long s_ha[32], s_hw[32]; // buffered words: exact {count, sum} per bucket, all not yet folded / window part
 	__shared__ unsigned long long s_pa[NT / 64][16], s_pw[NT / 64][16]; // ... accumulated per wave first (packed count : 24 | sum : 40)
@@ -353,8 +358,9 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 				}
 			}
 		}
-		// this entry's tail values of the run
-		{
+		// this entry's tail values of the run (round 3: only an entry that HAS values in the global list walks it -- every one of the ~10^4
+		// entries of a Zipf window used to read the whole list, tens of thousands of words, to find none of its own)
+		if (p.acc[(size_t)e * GYS_HB_ACC + 33u]) {
 			const uint32_t nt = min(*p.tail_count, p.tail_cap);
 			for (uint32_t i = tid; i < nt; i += NT) {
 				const unsigned long long t = p.tail[i];
@@ -421,7 +427,18 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			if (k < wave) pfx += s_w[k];
 			nlow += s_w[k];
 		}
-		s_part[tid] = pfx;
+		// the counts become exclusive prefixes IN PLACE (count of bin b = next prefix - this one): the passes below then take their bins
+		// interleaved -- a key's values sit in the first thousand or two of the 16 384 bins, i.e. in the contiguous ranges of ONE wave's
+		// threads, which walked them one after the other while the other waves of the workgroup had nothing to do (170 us per key on the
+		// C5 shape, r3z)
+		{
+			uint32_t run = pfx;
+			for (uint32_t b = tid * BPT; b < tid * BPT + BPT; ++b) {
+				const uint32_t c = s_img[b];
+				s_img[b] = run;
+				run += c;
+			}
+		}
 		__syncthreads();
 		// ---- old clusters: lt = #{values v : v * cc < cs} = #{v <= (cs - 1) / cc}  (cs >= 1; none when cs <= 0)
 		if (tid < nc) {
@@ -438,9 +455,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 					}
 					lt = (uint64_t)nlow + lo;
 				} else {
-					const uint32_t owner = (uint32_t)vmax / BPT;
-					lt = s_part[owner];
-					for (uint32_t b = owner * BPT; b <= (uint32_t)vmax; ++b) lt += s_img[b];
+					lt = (uint32_t)vmax + 1u < GYS_HB_BINS ? s_img[(uint32_t)vmax + 1u] : nlow; // values <= vmax = prefix of the next bin
 				}
 			}
 			const uint64_t mid2 = 2ull * (s_cpfx[tid] + lt) + (uint64_t)cc;
@@ -448,47 +463,41 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			atomicAdd(&s_osum[cl], (unsigned long long)cs);
 			atomicAdd(&s_ocnt[cl], (unsigned long long)cc);
 		}
-		// ---- values bin by bin: ranks [r0, r0 + c) of value v, le = old weight with mean <= v
-		{
-			uint64_t r0 = pfx;
-			const uint32_t vbeg = tid * BPT;
-			uint32_t ci = 0; // first compacted cluster with mean > v; monotone in v
+		// ---- values bin by bin (thread t: bins t, t + NT, ...): ranks [r0, r0 + c) of value v, le = old weight with mean <= v
+		for (uint32_t b = tid; b < GYS_HB_BINS; b += NT) {
+			const uint32_t r0b = s_img[b];
+			const uint32_t c = (b + 1u < GYS_HB_BINS ? s_img[b + 1u] : nlow) - r0b;
+			if (!c) continue;
+			const int64_t v = (int64_t)b;
+			uint32_t ci; // first compacted cluster with mean > v
 			{
 				uint32_t lo = 0, hi = nc;
-				const int64_t v = (int64_t)vbeg;
 				while (lo < hi) {
 					const uint32_t mid = (lo + hi) >> 1;
 					if (s_csum[mid] <= v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
 				}
 				ci = lo;
 			}
-			for (uint32_t b = vbeg; b < vbeg + BPT; ++b) {
-				const uint32_t c = s_img[b];
-				if (!c) continue;
-				const int64_t v = (int64_t)b;
-				while (ci < nc && s_csum[ci] <= v * (int64_t)s_ccnt[ci]) ci++;
-				const uint64_t le = s_cpfx[ci];
-				const uint64_t first = 2ull * (r0 + le) + 1ull, last = first + 2ull * (uint64_t)(c - 1u);
-				uint32_t cl = td_cluster_of(s_T, first);
-				const uint32_t cl_last = td_cluster_of(s_T, last);
-				uint64_t rbeg = r0;
-				for (; cl <= cl_last; ++cl) {
-					uint64_t rend;
-					if (cl == cl_last) {
-						rend = r0 + c;
-					} else {
-						const uint64_t Tn = s_T[cl + 1];
-						rend = (Tn / 2ull) - le; // ranks r with 2 (r + le) + 1 < Tn
-						if (rend > r0 + c) rend = r0 + c;
-					}
-					if (rend > rbeg) {
-						const uint64_t k = rend - rbeg;
-						atomicAdd(&s_osum[cl], (unsigned long long)(k * (uint64_t)v));
-						atomicAdd(&s_ocnt[cl], (unsigned long long)k);
-						rbeg = rend;
-					}
+			const uint64_t r0 = r0b, le = s_cpfx[ci];
+			const uint64_t first = 2ull * (r0 + le) + 1ull, last = first + 2ull * (uint64_t)(c - 1u);
+			uint32_t cl = td_cluster_of(s_T, first);
+			const uint32_t cl_last = td_cluster_of(s_T, last);
+			uint64_t rbeg = r0;
+			for (; cl <= cl_last; ++cl) {
+				uint64_t rend;
+				if (cl == cl_last) {
+					rend = r0 + c;
+				} else {
+					const uint64_t Tn = s_T[cl + 1];
+					rend = (Tn / 2ull) - le; // ranks r with 2 (r + le) + 1 < Tn
+					if (rend > r0 + c) rend = r0 + c;
 				}
-				r0 += c;
+				if (rend > rbeg) {
+					const uint64_t k = rend - rbeg;
+					atomicAdd(&s_osum[cl], (unsigned long long)(k * (uint64_t)v));
+					atomicAdd(&s_ocnt[cl], (unsigned long long)k);
+					rbeg = rend;
+				}
 			}
 		}
 		// ---- the tail values: sorted, all values below 16 384 precede them
