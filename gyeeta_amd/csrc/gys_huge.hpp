@@ -379,7 +379,11 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			continue;
 		}
 		const uint32_t nc = s_nc, ntail = s_ntail;
-		if (ntail > 1u) { // bitonic sort of the tail in LDS (padded to a power of two with +inf); equal values are interchangeable
+		// tier B (up to 16 384 tail values): bitonic sort of the tail in LDS; tier A (up to 512): no sort at all -- a value's rank among the
+		// tail values and a cluster's count of tail values below its mean are counted by reading the short list (every lane reads the same
+		// word: a broadcast), which takes one barrier instead of the up to 45 of the sorting network
+		constexpr bool SORT_TAIL = TAIL > 1024u;
+		if (SORT_TAIL && ntail > 1u) { // (padded to a power of two with +inf); equal values are interchangeable
 			uint32_t n2 = 2;
 			while (n2 < ntail) n2 <<= 1;
 			for (uint32_t i = ntail + tid; i < n2; i += NT) s_tail[i] = 0xFFFFFFFFu;
@@ -448,10 +452,15 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			if (cs > 0) {
 				const int64_t vmax = (cs - 1) / (int64_t)cc;
 				if (vmax >= (int64_t)GYS_HB_BINS) {
-					uint32_t lo = 0, hi = ntail; // sorted tail: values <= vmax
-					while (lo < hi) {
-						const uint32_t mid = (lo + hi) >> 1;
-						if ((int64_t)s_tail[mid] <= vmax) lo = mid + 1; else hi = mid;
+					uint32_t lo = 0; // tail values <= vmax
+					if (SORT_TAIL) {
+						uint32_t hi = ntail;
+						while (lo < hi) {
+							const uint32_t mid = (lo + hi) >> 1;
+							if ((int64_t)s_tail[mid] <= vmax) lo = mid + 1; else hi = mid;
+						}
+					} else {
+						for (uint32_t i = 0; i < ntail; ++i) lo += (int64_t)s_tail[i] <= vmax ? 1u : 0u;
 					}
 					lt = (uint64_t)nlow + lo;
 				} else {
@@ -503,7 +512,15 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 		// ---- the tail values: sorted, all values below 16 384 precede them
 		for (uint32_t j = tid; j < ntail; j += NT) {
 			const uint32_t v = s_tail[j];
-			const uint64_t r = (uint64_t)nlow + j;
+			uint32_t rk = j; // position among the tail values in ascending order (ties: by place in the list -- equal values are interchangeable)
+			if (!SORT_TAIL) {
+				rk = 0;
+				for (uint32_t i = 0; i < ntail; ++i) {
+					const uint32_t u = s_tail[i];
+					rk += (u < v || (u == v && i < j)) ? 1u : 0u;
+				}
+			}
+			const uint64_t r = (uint64_t)nlow + rk;
 			uint32_t lo = 0, hi = nc; // old weight with mean <= v
 			while (lo < hi) {
 				const uint32_t mid = (lo + hi) >> 1;

@@ -1738,7 +1738,9 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 
 	// (Reading the NEXT list entry one iteration ahead and touching one word of every line the next merge will read -- clusters, buffered
 	// words, records, meta: a key's digest is cold, three dependent HBM round trips per merge -- was measured in round 3 (r3p): 5.22
-	// against 4.68 ms per window.  The merges are bound by the requests the memory system takes, not by their latency; removed again.)
+	// against 4.68 ms per window.  A plain software pipeline -- the next entry's meta / cluster / four values requested behind pass 1 of
+	// the current merge, no extra requests -- was slower as well (r3ab: 5.12 against 4.82 ms: 64 VGPRs with two spills).  The merges are
+	// not bound by the latency of their loads; both removed again.)
 	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
 		// the thread index is re-derived per entry behind an opaque move: otherwise every LDS address, lane mask and per-bin
 		// bucket the thread uses is hoisted out of this loop and held in registers across it (> 96 VGPRs instead of < 64)
