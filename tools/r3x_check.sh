@@ -18,5 +18,5 @@ run head_q libgysketch_head.so $Q
 run new_q libgysketch.so $Q
 run head_default libgysketch_head.so --steps 20 --warmup 5 --no-quantile-check
 run new_default libgysketch.so --steps 20 --warmup 5
-run head_c5 libgysketch_head.so --zipf-milli 1100 --hosts 50 --svcs 2000 --steps 8 --warmup 2 --no-quantile-check
-run new_c5 libgysketch.so --zipf-milli 1100 --hosts 50 --svcs 2000 --steps 8 --warmup 2 --no-quantile-check
+
+
