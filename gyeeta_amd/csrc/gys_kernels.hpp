@@ -528,11 +528,25 @@ __global__ __launch_bounds__(1024) void k_cms_partial(const uint32_t *resp_win, 
 	__syncthreads();
 	const uint32_t per = (nsvc + nch - 1u) / nch;
 	const uint32_t first = blockIdx.x * per, last = min(nsvc, first + per);
-	for (uint32_t s = first + threadIdx.x; s < last; s += 1024u) {
-		const uint32_t m = resp_win[s];
-		if (!m) continue;
-		const uint32_t col = jhash2_u64(svc_gid[s], GYS_SEED + r) & (GYS_CMS_W - 1);
-		if ((col / GYS_CMSF_CELLS) == half) atomicAdd(&s_cells[col % GYS_CMSF_CELLS], m);
+	// eight services per thread and round, all sixteen loads in flight before the first is used (round 3: the one-service loop exposed
+	// one load latency per service -- 305 of them in a row per thread at 10^7 services, 0.31 ms for a pass that moves 120 MB)
+	constexpr uint32_t U = 8;
+	for (uint32_t s0 = first + threadIdx.x; s0 < last; s0 += 1024u * U) {
+		uint32_t m[U];
+		uint64_t g[U];
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) {
+			const uint32_t s = s0 + u * 1024u;
+			const uint32_t sc = s < last ? s : first; // (past the end: the chunk's first service, ignored below)
+			m[u] = resp_win[sc];
+			g[u] = svc_gid[sc];
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) {
+			if (s0 + u * 1024u >= last || !m[u]) continue;
+			const uint32_t col = jhash2_u64(g[u], GYS_SEED + r) & (GYS_CMS_W - 1);
+			if ((col / GYS_CMSF_CELLS) == half) atomicAdd(&s_cells[col % GYS_CMSF_CELLS], m[u]);
+		}
 	}
 	__syncthreads();
 	uint32_t *out = partial + ((size_t)blockIdx.x * GYS_CMS_D + r) * GYS_CMS_W + half * GYS_CMSF_CELLS;
@@ -1740,7 +1754,9 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 	// words, records, meta: a key's digest is cold, three dependent HBM round trips per merge -- was measured in round 3 (r3p): 5.22
 	// against 4.68 ms per window.  A plain software pipeline -- the next entry's meta / cluster / four values requested behind pass 1 of
 	// the current merge, no extra requests -- was slower as well (r3ab: 5.12 against 4.82 ms: 64 VGPRs with two spills).  The merges are
-	// not bound by the latency of their loads; both removed again.)
+	// not bound by the latency of their loads; both removed again.  Third form (r3af): meta record + cluster + values requested together and
+	// waited for once (hipcc waits for the meta record before it issues the data loads: three dependent round trips become two): 4.81
+	// against 4.84 ms -- no difference; with the next list entry held in registers across the merge as well: 4.92.  Not kept either.)
 	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
 		// the thread index is re-derived per entry behind an opaque move: otherwise every LDS address, lane mask and per-bin
 		// bucket the thread uses is hoisted out of this loop and held in registers across it (> 96 VGPRs instead of < 64)
