@@ -437,7 +437,7 @@ def run_conn(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=80, help="timed windows (80 x ~12 ms: a timed region of about a second)")
+    ap.add_argument("--steps", type=int, default=100, help="timed windows (100 x ~10.4 ms: a timed region of about a second)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--hosts", type=int, default=10000, help="total hosts across all ranks")
     ap.add_argument("--svcs", type=int, default=1000, help="services per host")
