@@ -10,7 +10,10 @@ the hot kernels run on synthetic input:
     sequential engine fed the same bytes;
   * the paths of a key whose batch does not fit its buffer (tests/cpp/kemu/test_spill.cc): spill in finalize_key, the SPILL pass of
     k_resp_host, merges from buffer + run in every size class, the several-workgroup path of gys_huge.hpp with its sorted tail and its
-    one-workgroup fallback.
+    one-workgroup fallback;
+  * the TCP_CONN_NOTIFY roll-up k_conn_ingest + k_conn_fold (tests/cpp/kemu/test_conn.cc): variable-stride v4 / v6 records read as
+    16-byte pieces through LDS, per-workgroup aggregation of the service accumulators, record counts around the wave / round /
+    workgroup boundaries, known and unknown services, with and without the (listener, client task group) pair tables.
 This does not replace the -m gpu parity tests (no memory model, no execution masks, no timing): it catches logic errors in kernel
 changes before GPU minutes are spent on them.  The programs are built and run side by side once per session (they mostly wait in
 barriers); each test below looks at one of them."""
@@ -32,6 +35,8 @@ PROGRAMS = {
     "resp-tiles-6144": ("test_resp.cc", ["KEMU_TPT=12"] + BINS, ["4242"], "kemu resp ok"),
     "resp-split-form": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_SPLIT", "KEMU_NB=3"] + BINS, ["4242"], "kemu resp ok"),
     "spill-and-huge": ("test_spill.cc", BINS, ["777"], "kemu spill ok"),
+    "conn-31": ("test_conn.cc", [], ["31"], "kemu conn ok"),
+    "conn-77": ("test_conn.cc", [], ["77"], "kemu conn ok"),
 }
 
 
