@@ -85,8 +85,9 @@ awk '/^template <typename T = int>/{hold=$0; next} /^class LISTEN_SUMM_STATS/{pr
 awk '/^struct CLUSTER_STATE_ONE : public comm::MS_CLUSTER_STATE::STATE_ONE/{on=1} on{print} on&&/^};/{exit}' "$REF/server/gy_mconnhdlr.cc" > "$T/ref_cluster_state_one.h"
 grep -q "void update(const comm::LISTENER_STATE_NOTIFY" "$T/ref_listen_summ_stats.h" || rm -f "$T/ref_listen_summ_stats.h" "$T/ref_cluster_state_one.h"
 grep -q "update_from_state" "$T/ref_cluster_state_one.h" 2>/dev/null || rm -f "$T/ref_listen_summ_stats.h" "$T/ref_cluster_state_one.h"
-# the forced includes paper over gcc-8 era transitive-include assumptions in gy_common_inc.h
-g++ -std=c++17 -O2 -D_GNU_SOURCE -DNDEBUG -DTASK_COMM_LEN=16 -pthread -fno-strict-aliasing -fPIC -shared -w \
+# the forced includes paper over gcc-8 era transitive-include assumptions in gy_common_inc.h; -fno-strict-aliasing -fno-strict-overflow are
+# the reference's own COMMFLAGS (Makefile.common:42)
+g++ -std=c++17 -O2 -D_GNU_SOURCE -DNDEBUG -DTASK_COMM_LEN=16 -pthread -fno-strict-aliasing -fno-strict-overflow -fPIC -shared -w \
 	-include string -include string_view -include optional -include vector -include algorithm -include functional \
 	-include chrono -include array -include tuple -include utility \
 	-I"$T" -I"$REF/common" -I"$REF/thirdparty" "$HERE/ref_glue.cc" "$T/gy_comm_proto.cc" -o "$OUT/libgyref.so"

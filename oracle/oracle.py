@@ -40,7 +40,9 @@ def build_oracle(force=False):
     deps = [os.path.join(HERE, f) for f in SOURCES + ["gy_oracle.h"]] + [os.path.join(HERE, "..", "include", "gys_tdigest_tbl.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-pthread", "-o", LIB_PATH] + [os.path.join(HERE, f) for f in SOURCES] + ["-lm"])
+    # -fno-strict-overflow -fno-strict-aliasing: the reference's own flags (Makefile.common:42): its int sums (LISTEN_SUMM_STATS<int>,
+    # server/gy_msocket.h:844-865) wrap, and so must the restatement's -- UBSan reports them as signed overflow otherwise
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-pthread", "-fno-strict-overflow", "-fno-strict-aliasing", "-o", LIB_PATH] + [os.path.join(HERE, f) for f in SOURCES] + ["-lm"])
     return LIB_PATH
 
 
