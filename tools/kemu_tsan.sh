@@ -1,13 +1,17 @@
 #!/bin/bash
-# The emulated kernels (tests/cpp/kemu) under ThreadSanitizer: LDS / global accesses of a kernel that are ordered neither by a barrier
-# nor by an atomic show up as data races.  Expected reports, all idempotent by construction: the read-before-atomicMax of the HLL
-# registers in k_resp_host / k_conn_ingest and the read-before-atomicOr of CONN_BITMAP words in k_huge_count / k_digest_huge (a register / word only
-# grows: a stale read costs at most a redundant atomic), and same-value stores by several threads (finalize_key: the host's spill stamp;
-# k_huge_merge: s_over = 1).  ~10 minutes on 8 cores.
+# The emulated kernels (tests/cpp/kemu) under a sanitizer: tools/kemu_tsan.sh [thread|address]   (default thread)
+#   thread:  LDS / global accesses of a kernel that are ordered neither by a barrier nor by an atomic show up as data races.  Expected
+#            reports, all idempotent by construction: the read-before-atomicMax of the HLL registers in k_resp_host / k_conn_ingest and
+#            the read-before-atomicOr of CONN_BITMAP words in k_huge_count / k_digest_huge (a register / word only grows: a stale read
+#            costs at most a redundant atomic), and same-value stores by several threads (finalize_key: the host's spill stamp;
+#            k_huge_merge: s_over = 1).  ~10 minutes on 8 cores.
+#   address: an index past the end of a __shared__ array (a function-local static here, red zones around it), of the dynamic LDS block
+#            or of a global buffer aborts the program.  Expected: no report.  ~6 minutes.
+SAN=${1:-thread}
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
 python -c "from oracle import oracle; oracle.lib()" || exit 1
 for t in bins resp spill conn cms; do
-	g++ -std=c++20 -O1 -g -w -fsanitize=thread -DKEMU_NB=4 -Itests/cpp/kemu tests/cpp/kemu/test_$t.cc -o /tmp/kemu_${t}_tsan -Loracle -l:liboracle.so -Wl,-rpath,$R/oracle -pthread || exit 1
-	TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" timeout 1800 /tmp/kemu_${t}_tsan > /tmp/kemu_${t}_tsan.log 2>&1
-	echo "== $t"; grep -E "SUMMARY|kemu $t ok|FAIL" /tmp/kemu_${t}_tsan.log | sort | uniq -c
+	g++ -std=c++20 -O1 -g -w -fsanitize=$SAN -DKEMU_NB=4 -Itests/cpp/kemu tests/cpp/kemu/test_$t.cc -o /tmp/kemu_${t}_$SAN -Loracle -l:liboracle.so -Wl,-rpath,$R/oracle -pthread || exit 1
+	TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=0" timeout 2400 /tmp/kemu_${t}_$SAN > /tmp/kemu_${t}_$SAN.log 2>&1
+	echo "== $t"; grep -E "SUMMARY|ERROR: AddressSanitizer|kemu $t ok|FAIL" /tmp/kemu_${t}_$SAN.log | sort | uniq -c
 done
