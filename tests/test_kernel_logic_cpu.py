@@ -14,7 +14,11 @@ the hot kernels run on synthetic input:
   * the TCP_CONN_NOTIFY roll-up k_conn_ingest + k_conn_fold (tests/cpp/kemu/test_conn.cc): variable-stride v4 / v6 records read as
     16-byte pieces through LDS, per-workgroup aggregation of the service accumulators, record counts around the wave / round /
     workgroup boundaries, known and unknown services, with and without the (listener, client task group) pair tables;
-  * the window's Count-Min rows k_cms_partial + k_cms_reduce (tests/cpp/kemu/test_cms.cc) with ragged, short and empty chunks.
+  * the window's Count-Min rows k_cms_partial + k_cms_reduce (tests/cpp/kemu/test_cms.cc) with ragged, short and empty chunks;
+  * the wire front-end's record walk k_wire_* + the scan kernels (tests/cpp/kemu/test_wire.cc) on message streams with corrupted length
+    fields, record counts and paddings: "malformed" exactly when the oracle's restatement of the reference's validators rejects a
+    message, the serial walk's offsets otherwise (tools/kemu_tsan.sh address runs it under AddressSanitizer: no corrupted length makes
+    a kernel index outside the stream or its work arrays).
 This does not replace the -m gpu parity tests (no memory model, no execution masks, no timing): it catches logic errors in kernel
 changes before GPU minutes are spent on them.  The programs are built and run side by side once per session (they mostly wait in
 barriers); each test below looks at one of them."""
@@ -39,6 +43,8 @@ PROGRAMS = {
     "conn-31": ("test_conn.cc", [], ["31"], "kemu conn ok"),
     "conn-77": ("test_conn.cc", [], ["77"], "kemu conn ok"),
     "cms-rows": ("test_cms.cc", [], ["5"], "kemu cms ok"),
+    "wire-corrupted-11": ("test_wire.cc", [], ["11"], "kemu wire ok"),
+    "wire-corrupted-23": ("test_wire.cc", [], ["23"], "kemu wire ok"),
 }
 
 
