@@ -18,7 +18,9 @@ the hot kernels run on synthetic input:
   * the wire front-end's record walk k_wire_* + the scan kernels (tests/cpp/kemu/test_wire.cc) on message streams with corrupted length
     fields, record counts and paddings: "malformed" exactly when the oracle's restatement of the reference's validators rejects a
     message, the serial walk's offsets otherwise (tools/kemu_tsan.sh address runs it under AddressSanitizer: no corrupted length makes
-    a kernel index outside the stream or its work arrays).
+    a kernel index outside the stream or its work arrays);
+  * the LISTENER_STATE_NOTIFY roll-up k_lstate_ingest and the ACTIVE_CONN_STATS roll-up k_actconn_ingest (tests/cpp/kemu/test_lstate.cc)
+    on records whose bytes are random except the listener id (any state, any flags, counters whose int sums wrap).
 This does not replace the -m gpu parity tests (no memory model, no execution masks, no timing): it catches logic errors in kernel
 changes before GPU minutes are spent on them.  The programs are built and run side by side once per session (they mostly wait in
 barriers); each test below looks at one of them."""
@@ -45,6 +47,8 @@ PROGRAMS = {
     "cms-rows": ("test_cms.cc", [], ["5"], "kemu cms ok"),
     "wire-corrupted-11": ("test_wire.cc", [], ["11"], "kemu wire ok"),
     "wire-corrupted-23": ("test_wire.cc", [], ["23"], "kemu wire ok"),
+    "lstate-actconn-random-3": ("test_lstate.cc", [], ["3"], "kemu lstate ok"),
+    "lstate-actconn-random-4": ("test_lstate.cc", [], ["4"], "kemu lstate ok"),
 }
 
 
