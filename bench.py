@@ -224,6 +224,24 @@ def _kernel_sources():
         return None
 
 
+def _device_code():
+    try:
+        from gyeeta_amd.build import device_code_sha
+        return device_code_sha()
+    except Exception:
+        return None
+
+
+def _same_kernels(t):
+    """are the counters in profiles/pmc_traffic.json of the kernels this run executes?  The device code itself when both sides carry its
+    hash (.rodata + .text of the gfx950 code object: a host-only change of gys_engine.hip does not move it), else the source files."""
+    if t.get("device_code") and _device_code():
+        return t["device_code"] == _device_code()
+    if t.get("source_kernels"):
+        return t["source_kernels"] == _kernel_sources()
+    return None
+
+
 def pmc_traffic(kernel, events, nsvc):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by
     tools/pmc_collect.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
@@ -239,11 +257,12 @@ def pmc_traffic(kernel, events, nsvc):
         return None
     return {"bytes": k["fetch_bytes"] + k["write_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
             "source": t.get("source", "profiles/pmc_traffic.json"), "measured_in_this_run": False,
-            "source_commit": t.get("source_commit"), "source_kernels": t.get("source_kernels"),
-            "same_kernels_as_this_run": (t.get("source_kernels") == _kernel_sources()) if t.get("source_kernels") else None,
+            "source_commit": t.get("source_commit"), "source_kernels": t.get("source_kernels"), "device_code": t.get("device_code"),
+            "same_kernels_as_this_run": _same_kernels(t),
             "note": "counter passes are separate rocprofv3 runs (profiles/pmc_traffic.json); source_commit = the tree they were taken on; "
-            "source_kernels / kernel_sources = sha256 over the library's source files (equal: the counters are of these very kernels, "
-            "whatever documentation commits lie between)"}
+            "device_code = sha256 over .rodata + .text of the library's gfx950 code object (equal to this line's device_code: the counters "
+            "are of these very kernels, whatever documentation or host-only commits lie between); source_kernels / kernel_sources = the "
+            "same over the library's source files"}
 
 
 def self_launch(args):
@@ -709,7 +728,7 @@ def main():
         except Exception:
             bc = None
         out = {
-            "metric": metric, "build_commit": bc, "kernel_sources": _kernel_sources(),
+            "metric": metric, "build_commit": bc, "kernel_sources": _kernel_sources(), "device_code": _device_code(),
             "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic", "parity_ok": parity_ok,

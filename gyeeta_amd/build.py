@@ -27,7 +27,7 @@ def stamp_commit():
         root = os.path.dirname(HERE)
         head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
         dirty = subprocess.call(["git", "-C", root, "diff", "--quiet", "HEAD", "--", "gyeeta_amd", "include", "bench.py"], stderr=subprocess.DEVNULL) != 0
-        open(COMMIT_PATH, "w").write(head + ("+dirty" if dirty else "") + " " + _hash_sources() + "\n")
+        open(COMMIT_PATH, "w").write(head + ("+dirty" if dirty else "") + " " + _hash_sources() + " " + (_hash_device_code(LIB_PATH) or "-") + "\n")
     except Exception:
         pass
 
@@ -47,6 +47,47 @@ def sources_sha():
         return open(COMMIT_PATH).read().strip().split()[1]
     except Exception:
         return None
+
+
+def device_code_sha():
+    """sha256 (first 16 hex digits) over the .rodata (kernel descriptors, constant tables) and .text (the kernels' ISA) sections of the
+    gfx950 code object inside the library: the identity of the KERNELS themselves.  Two builds of the same sources give the same value
+    (the rest of the code object -- notes, symbol tables -- carries per-build names and does not), and a change that only touches host
+    code of gys_engine.hip leaves it alone where sources_sha() moves.  bench.py compares it between the library it runs (device_code) and
+    the library profiles/pmc_traffic.json was taken with."""
+    try:
+        f = open(COMMIT_PATH).read().strip().split()
+        if len(f) > 2 and f[2] != "-":
+            return f[2]
+    except Exception:
+        pass
+    return _hash_device_code(LIB_PATH)
+
+
+def _hash_device_code(lib_path):
+    import hashlib
+    import shutil
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tmp = tempfile.mkdtemp(prefix="gys_devcode_")
+    try:
+        fat, elf = os.path.join(tmp, "fatbin"), os.path.join(tmp, "gfx950.elf")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib_path], stderr=subprocess.DEVNULL)
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               "--input=" + fat, "--output=" + elf], stderr=subprocess.DEVNULL)
+        h = hashlib.sha256()
+        for sec in (".rodata", ".text"):
+            out = os.path.join(tmp, "sec")
+            subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=" + sec, elf, out], stderr=subprocess.DEVNULL)
+            data = open(out, "rb").read()
+            if not data:
+                return None
+            h.update(data)
+        return h.hexdigest()[:16]
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _hash_sources():

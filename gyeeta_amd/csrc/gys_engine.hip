@@ -2251,6 +2251,15 @@ int gys_ingest_comm_stream(gys_ctx *c, const uint8_t machine_id[16], const void 
 					set_err("nevents_ %u over the per-message limit", nevents);
 					return GYS_ERR_INVAL;
 				}
+				// every record is at least its fixed part, so a message that announces more records than its payload can hold fails the
+				// validators' walk (:859-880, :974-995) whatever its bytes say.  Rejected HERE, before any kernel: the offset list is sized by
+				// the sum of the announced counts, and a long stream of header-only messages announcing 2 048 records each could wrap that sum
+				if ((uint64_t)nevents * (is_conn ? 280u : 88u) > (uint64_t)act - 24u) {
+					st.nmsgs_invalid++;
+					if (out) *out = st;
+					set_err("nevents_ %u records cannot lie in %u payload bytes", nevents, act - 24u);
+					return GYS_ERR_INVAL;
+				}
 				WireMsg m{};
 				m.pay_slot = (uint32_t)((p - (const uint8_t *)buf) + 24) / 8u;
 				m.end_slot = (uint32_t)((p - (const uint8_t *)buf) + act) / 8u; // act_len is a multiple of 8 for well-formed messages

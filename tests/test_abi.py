@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -87,3 +88,39 @@ def test_shard_function_is_reference_machine_id_hash(capi, oracle):
         assert L.gys_machine_id_hash(mid_buf(mid)) == ref
         for n in (1, 2, 4, 8):
             assert L.gys_shard_of(mid_buf(mid), n) == ref % n
+
+
+def test_build_stamp_names_sources_and_device_code():
+    """gyeeta_amd/lib/build_commit.txt = "<commit>[+dirty] <sha256-16 of the source files> <sha256-16 of the gfx950 code object's .rodata + .text>":
+    the device-code hash is what bench.py compares with profiles/pmc_traffic.json (roofline.traffic.same_kernels_as_this_run); it is a
+    property of the built library alone (recomputed here from the .so) and does not move when the stamp is rewritten"""
+    import re
+    from gyeeta_amd import build
+    build.build()
+    if build.build_commit() is None:
+        build.stamp_commit()
+    src, dev = build.sources_sha(), build.device_code_sha()
+    assert src and re.fullmatch(r"[0-9a-f]{16}", src), src
+    assert dev and re.fullmatch(r"[0-9a-f]{16}", dev), dev
+    assert build._hash_device_code(build.LIB_PATH) == dev
+    assert src == build._hash_sources()
+
+
+def test_bench_compares_counter_evidence_by_device_code():
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(b)
+    finally:
+        sys.argv = argv
+    dev = b._device_code()
+    assert dev
+    assert b._same_kernels({"device_code": dev, "source_kernels": "0" * 16}) is True      # same kernels, sources moved (host-only change)
+    assert b._same_kernels({"device_code": "f" * 16, "source_kernels": b._kernel_sources()}) is False
+    assert b._same_kernels({"source_kernels": b._kernel_sources()}) is True                # older evidence files: source files only
+    assert b._same_kernels({}) is None
+    t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert isinstance(b._same_kernels(t), bool)

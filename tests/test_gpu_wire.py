@@ -97,6 +97,8 @@ def test_comm_stream_rejects_malformed():
     rejected(good[:4] + np.array([len(good) + 4], dtype="<u4").tobytes() + good[8:])             # total_sz_ not a multiple of 8 / overruns
     rejected(wire.frame_event_notify(wire.NOTIFY_TCP_CONN, 2049, payload))                       # nevents_ > MAX_NUM_CONNS
     rejected(wire.frame_event_notify(wire.NOTIFY_TCP_CONN, n + 1, payload))                      # fewer records than nevents_
+    rejected(wire.frame_event_notify(wire.NOTIFY_TCP_CONN, 2048, b""))                           # a header-only message announcing 2 048 records
+    rejected(good + wire.frame_event_notify(wire.NOTIFY_TCP_CONN, n, payload[:280 * n - 8]))     # more records than the payload can hold, behind a good message
     bad = bytearray(payload)
     bad[272:274] = (3).to_bytes(2, "little")  # first record: cmdline 3 + padding 0 -> size not a multiple of 8 ("Padding issue")
     bad[279] = 0

@@ -60,12 +60,13 @@ f = per_kernel(fetch_dir, "FETCH_SIZE", skip)
 w = per_kernel(write_dir, "WRITE_SIZE", skip)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 try:
-    from gyeeta_amd.build import build_commit, sources_sha
+    from gyeeta_amd.build import build_commit, sources_sha, device_code_sha
     commit = build_commit()
     ksha = sources_sha()
+    dsha = device_code_sha()
 except Exception:
-    commit = ksha = None
-res = {"events_per_launch": events, "service_keys": keys, "source_commit": commit, "source_kernels": ksha,
+    commit = ksha = dsha = None
+res = {"events_per_launch": events, "service_keys": keys, "source_commit": commit, "source_kernels": ksha, "device_code": dsha,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py; KiB -> bytes, FETCH_SIZE x2 (gfx950 correction)",
        "kernels": {k: {"fetch_bytes": int(f.get(k, 0) * 1024 * 2), "write_bytes": int(w.get(k, 0) * 1024)} for k in sorted(set(f) | set(w))}}
 json.dump(res, open(outp, "w"), indent=1)
