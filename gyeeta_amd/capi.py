@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GYS_LIB") or os.path.join(HERE, "lib", "libgysketch.so")  # GYS_LIB: an A/B build of the same library
 
-OK, ERR_INVAL, ERR_NOMEM, ERR_HIP, ERR_NOTFOUND, ERR_NOT_OWNER, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_INVAL, ERR_NOMEM, ERR_HIP, ERR_NOTFOUND, ERR_NOT_OWNER, ERR_STATE, ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7
 MAX_BUCKETS, TD_NB, HLL_P, CMS_D, CMS_W, NSTATES, TOPN = 16, 200, 14, 4, 65536, 6, 10
 NLEVELS, LEVEL_RING = 4, 10
 TD_PEND_CAP = 896

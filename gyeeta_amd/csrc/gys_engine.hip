@@ -1226,6 +1226,10 @@ int walk_batch(const uint8_t *batch, uint32_t n, const uint8_t *pend, uint32_t f
 		set_err("batch without an end pointer");
 		return GYS_ERR_INVAL;
 	}
+	if ((uint64_t)n * fixed > (uint64_t)(pend - batch)) { // (before anything is sized by n: every record is at least its fixed part)
+		set_err("%u records cannot lie in a batch of %zu bytes", n, (size_t)(pend - batch));
+		return GYS_ERR_INVAL;
+	}
 	offs.reserve(n);
 	// the L1 validators' rule (TCP_CONN_NOTIFY::validate / LISTENER_STATE_NOTIFY::validate, common/gy_comm_proto.cc:859-880, :974-995):
 	// every one of the n announced records lies complete before pend and has a size that is a multiple of 8; the L2 loop
@@ -1578,6 +1582,26 @@ int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
 		}                                                              \
 	} while (0)
 
+// "Nothing throws across the boundary" (include/gysketch.h): the host side uses std::vector / std::string / std::thread, whose failures
+// are C++ exceptions.  Every int-returning entry point is a function-try-block that turns them into an error code + gys_last_error() text.
+#define GYS_CATCH_ALL                                                                                  \
+	catch (const std::bad_alloc &)                                                                 \
+	{                                                                                              \
+		set_err("out of host memory");                                                         \
+		return GYS_ERR_NOMEM;                                                                  \
+	}                                                                                              \
+	catch (const std::exception &ex_)                                                              \
+	{                                                                                              \
+		set_err("internal error: %s", ex_.what());                                             \
+		return GYS_ERR_INTERNAL;                                                               \
+	}                                                                                              \
+	catch (...)                                                                                    \
+	{                                                                                              \
+		set_err("internal error");                                                             \
+		return GYS_ERR_INTERNAL;                                                               \
+	}
+
+
 extern "C" {
 
 uint32_t gys_abi_version(void) { return GYS_ABI_VERSION; }
@@ -1589,7 +1613,7 @@ uint32_t gys_shard_of(const uint8_t machine_id[16], uint32_t nshards) { return n
 uint64_t gys_reduce_arena_bytes(const gys_config *cfg) { return arena_layout(cfg ? cfg->max_clusters : 1, cfg && cfg->conn_pair_cms).total; }
 
 int gys_create(const gys_config *cfg, gys_ctx **out)
-{
+try {
 	if (!cfg || !out || cfg->struct_size != sizeof(gys_config)) {
 		set_err("bad config (struct_size %u, expected %zu)", cfg ? cfg->struct_size : 0, sizeof(gys_config));
 		return GYS_ERR_INVAL;
@@ -1792,7 +1816,7 @@ int gys_create(const gys_config *cfg, gys_ctx **out)
 	HIPCHK(hipStreamSynchronize(c->stream));
 	*out = c;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 void gys_destroy(gys_ctx *c)
 {
@@ -1839,16 +1863,16 @@ void gys_destroy(gys_ctx *c)
 }
 
 int gys_sync(gys_ctx *c)
-{
+try {
 	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ registration
 int gys_register_cluster(gys_ctx *c, const char *cluster_name, uint32_t *cluster_idx)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !cluster_name) return GYS_ERR_INVAL;
 	auto it = c->cluster_map.find(cluster_name);
@@ -1863,10 +1887,10 @@ int gys_register_cluster(gys_ctx *c, const char *cluster_name, uint32_t *cluster
 	}
 	if (cluster_idx) *cluster_idx = it->second;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_register_host(gys_ctx *c, const uint8_t machine_id[16], const char *cluster_name, uint32_t *host_slot)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !machine_id) return GYS_ERR_INVAL;
 	int rc = check_owner(c, machine_id);
@@ -1900,10 +1924,10 @@ int gys_register_host(gys_ctx *c, const uint8_t machine_id[16], const char *clus
 	HIPCHK(hipStreamSynchronize(c->stream));
 	if (host_slot) *host_slot = slot;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_listener_info *arr_in, uint32_t n_in, uint32_t *first_slot)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !machine_id || (!arr_in && n_in)) return GYS_ERR_INVAL;
 	uint32_t host;
@@ -1974,18 +1998,18 @@ int gys_register_listeners(gys_ctx *c, const uint8_t machine_id[16], const gys_l
 	}
 	c->nsvc += n;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ ingest
 int gys_ingest_resp_events_dev(gys_ctx *c, const gys_resp_seg *segs, uint32_t nsegs, const void *d_ev24, uint64_t nevents)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || (!d_ev24 && nevents)) return GYS_ERR_INVAL;
 	return run_resp_batch(c, segs, nsegs, d_ev24, nevents);
-}
+} GYS_CATCH_ALL
 
 int gys_ingest_resp_events(gys_ctx *c, const uint8_t machine_id[16], const void *ev24, uint32_t nevents)
-{
+try {
 	GYS_ENTER_NOFLUSH(c);
 	if (!c || !machine_id || (!ev24 && nevents)) return GYS_ERR_INVAL;
 	uint32_t host;
@@ -2019,17 +2043,17 @@ int gys_ingest_resp_events(gys_ctx *c, const uint8_t machine_id[16], const void 
 	}
 	stage_release(c, si);
 	return rc;
-}
+} GYS_CATCH_ALL
 
 int gys_ingest_tcp_conn_dev(gys_ctx *c, const void *d_batch, const uint32_t *d_offsets, uint32_t nconns)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || ((!d_batch || !d_offsets) && nconns)) return GYS_ERR_INVAL;
 	return run_conn(c, (const uint8_t *)d_batch, d_offsets, nconns);
-}
+} GYS_CATCH_ALL
 
 int gys_ingest_tcp_conn(gys_ctx *c, const uint8_t machine_id[16], const void *batch, uint32_t nconns, const void *pend)
-{
+try {
 	GYS_ENTER_NOFLUSH(c);
 	if (!c || !machine_id || (!batch && nconns) || ((uintptr_t)batch & 7u)) return GYS_ERR_INVAL;
 	uint32_t host;
@@ -2046,24 +2070,24 @@ int gys_ingest_tcp_conn(gys_ctx *c, const uint8_t machine_id[16], const void *ba
 	if (rc) return rc;
 	if (offs.empty()) return GYS_OK;
 	return ingest_staged_records(c, host, batch, (const uint8_t *)pend - (const uint8_t *)batch, offs, /*conn*/ true);
-}
+} GYS_CATCH_ALL
 
 int gys_ingest_listener_state_dev(gys_ctx *c, const void *d_batch, const uint32_t *d_offsets, const uint32_t *d_host_slot, uint32_t nrecs)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || ((!d_batch || !d_offsets || !d_host_slot) && nrecs)) return GYS_ERR_INVAL;
 	return run_lstate(c, (const uint8_t *)d_batch, d_offsets, d_host_slot, 0, nrecs);
-}
+} GYS_CATCH_ALL
 
 int gys_ingest_active_conns_dev(gys_ctx *c, const void *d_batch, uint32_t nitems)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || (!d_batch && nitems)) return GYS_ERR_INVAL;
 	return run_actconn(c, (const uint8_t *)d_batch, nitems);
-}
+} GYS_CATCH_ALL
 
 int gys_ingest_active_conns(gys_ctx *c, const uint8_t machine_id[16], const void *batch, uint32_t nitems, const void *pend)
-{
+try {
 	GYS_ENTER_NOFLUSH(c);
 	if (!c || !machine_id || (!batch && nitems) || ((uintptr_t)batch & 7u)) return GYS_ERR_INVAL;
 	uint32_t host;
@@ -2093,10 +2117,10 @@ int gys_ingest_active_conns(gys_ctx *c, const uint8_t machine_id[16], const void
 	}
 	stage_release(c, si);
 	return rc;
-}
+} GYS_CATCH_ALL
 
 int gys_ingest_listener_state(gys_ctx *c, const uint8_t machine_id[16], const void *batch, uint32_t nrecs, const void *pend)
-{
+try {
 	GYS_ENTER_NOFLUSH(c);
 	if (!c || !machine_id || (!batch && nrecs) || ((uintptr_t)batch & 7u)) return GYS_ERR_INVAL;
 	uint32_t host;
@@ -2109,7 +2133,7 @@ int gys_ingest_listener_state(gys_ctx *c, const uint8_t machine_id[16], const vo
 	if (rc) return rc;
 	if (offs.empty()) return GYS_OK;
 	return ingest_staged_records(c, host, batch, (const uint8_t *)pend - (const uint8_t *)batch, offs, /*conn*/ false);
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ wire front-end
 // COMM_HEADER / EVENT_NOTIFY framing as an unmodified partha sends it to madhava (common/gy_comm_proto.h:336-420, :486-500).  The
@@ -2199,7 +2223,7 @@ int wire_decode(gys_ctx *c, const uint8_t *d_buf, uint64_t nbytes, std::vector<W
 } // namespace
 
 int gys_ingest_comm_stream(gys_ctx *c, const uint8_t machine_id[16], const void *buf, uint64_t nbytes, gys_comm_stats *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !machine_id || (!buf && nbytes) || ((uintptr_t)buf & 7u)) return GYS_ERR_INVAL; // COMM_HEADER::validate: 8-byte aligned data
 	uint32_t host;
@@ -2302,10 +2326,10 @@ int gys_ingest_comm_stream(gys_ctx *c, const uint8_t machine_id[16], const void 
 	}
 	if (out) *out = st;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_ingest_host_state(gys_ctx *c, const uint8_t machine_id[16], const gys_host_state *st)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !machine_id || !st) return GYS_ERR_INVAL;
 	uint32_t host;
@@ -2315,11 +2339,11 @@ int gys_ingest_host_state(gys_ctx *c, const uint8_t machine_id[16], const gys_ho
 	HIPCHK(hipMemcpyAsync(c->host_state_epoch + host, &c->epoch, 4, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ window boundary
 int gys_reduce_sections(gys_ctx *c, gys_reduce_section out[4], uint32_t *nsections)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !out || !nsections) return GYS_ERR_INVAL;
 	out[0] = {c->arena + c->al.off_hll8, (uint64_t)1 << GYS_HLL_P, 0, 0};
@@ -2328,7 +2352,7 @@ int gys_reduce_sections(gys_ctx *c, gys_reduce_section out[4], uint32_t *nsectio
 	out[3] = {c->arena + c->al.off_i64max, c->al.n_i64max, 2, 0};
 	*nsections = 4;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // the kernels of the window boundary before the exchange (no level roll): folds of the per-service window accumulators into the
 // Count-Min rows, cluster STATE_ONE sums + HLL pack, eager-mode record sweep.  dev_epoch: read the window number from device memory
@@ -2364,7 +2388,7 @@ static int enqueue_prepare(gys_ctx *c, bool dev_epoch)
 }
 
 int gys_window_prepare(gys_ctx *c, uint64_t tusec)
-{
+try {
 	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	if (c->prepared) {
@@ -2382,7 +2406,7 @@ int gys_window_prepare(gys_ctx *c, uint64_t tusec)
 	}
 	c->prepared = true;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // the fixed sequence that ends a window: keep the (reduced) registers for queries, start the next window from zero
 static hipError_t enqueue_finish(gys_ctx *c, hipStream_t st)
@@ -2411,7 +2435,7 @@ static hipError_t enqueue_finish(gys_ctx *c, hipStream_t st)
 }
 
 int gys_window_finish(gys_ctx *c)
-{
+try {
 	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	if (!c->prepared) {
@@ -2452,7 +2476,7 @@ int gys_window_finish(gys_ctx *c)
 	c->prepared = false;
 	c->have_last = true;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // The whole single-rank window boundary as ONE captured hipGraph (BASELINE config 5: "hipGraph-captured window"): the fold kernels that
 // are due (connection accumulators, Count-Min rows of the response path), k_window_prepare, the eager-mode sweep, the copy / clear
@@ -2460,7 +2484,7 @@ int gys_window_finish(gys_ctx *c)
 // Not capturable, and therefore run as gys_window_prepare + gys_window_finish: multi-level windows (the snapshot masks depend on the
 // close time) and more than one rank (the exchange sits between the two halves; gys_window_close_rccl).
 int gys_window_close(gys_ctx *c, uint64_t tusec)
-{
+try {
 	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	if (c->prepared) {
@@ -2510,11 +2534,11 @@ int gys_window_close(gys_ctx *c, uint64_t tusec)
 	c->prepared = false;
 	c->have_last = true;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ queries
 int gys_query_svcsumm(gys_ctx *c, const uint8_t machine_id[16], gys_svcsumm *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !machine_id || !out) return GYS_ERR_INVAL;
 	uint32_t host;
@@ -2532,10 +2556,10 @@ int gys_query_svcsumm(gys_ctx *c, const uint8_t machine_id[16], gys_svcsumm *out
 	out->nlisteners = s[11];
 	out->nactive = s[12];
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_query_clusterstate(gys_ctx *c, const char *cluster_name, gys_cluster_state *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !cluster_name || !out) return GYS_ERR_INVAL;
 	auto it = c->cluster_map.find(cluster_name);
@@ -2549,10 +2573,10 @@ int gys_query_clusterstate(gys_ctx *c, const char *cluster_name, gys_cluster_sta
 	HIPCHK(hipStreamSynchronize(c->stream));
 	memcpy(out, v, sizeof(*out));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_lookup_service(gys_ctx *c, uint64_t glob_id, uint32_t *slot)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !slot) return GYS_ERR_INVAL;
 	auto it = c->gid_map_h.find(glob_id);
@@ -2562,11 +2586,11 @@ int gys_lookup_service(gys_ctx *c, uint64_t glob_id, uint32_t *slot)
 	}
 	*slot = it->second;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_query_hist_percentiles(gys_ctx *c, uint64_t glob_id, int which, gys_hist_data *pdata, uint32_t npct, uint64_t *total_count, int64_t *max_val,
 			       float *pavg)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !pdata || which < 0 || which > 1) return GYS_ERR_INVAL;
 	uint32_t slot;
@@ -2586,7 +2610,7 @@ int gys_query_hist_percentiles(gys_ctx *c, uint64_t glob_id, int which, gys_hist
 	}
 	for (uint32_t i = 0; i < npct; ++i) hist_percentile(d, h, pdata[i].percentile, &pdata[i].data_value, &pdata[i].sum, &pdata[i].count);
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // quantile of an exact-integer digest: interpolation between cluster centres; only + - * / on doubles (matches oracle bit-for-bit)
 static double td_quantile_interp(const int64_t *sum, const uint32_t *cnt, int32_t vmin, int32_t vmax, double q)
@@ -2665,7 +2689,7 @@ static int td_merged_view(gys_ctx *c, uint32_t slot, int64_t *sum, uint32_t *cnt
 	}
 
 int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t nq, double *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !q || !out) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
@@ -2679,7 +2703,7 @@ int gys_query_quantiles(gys_ctx *c, uint64_t glob_id, const double *q, uint32_t 
 	if (rc) return rc;
 	for (uint32_t i = 0; i < nq; ++i) out[i] = td_quantile_host(sum, cnt, vmin, vmax, q[i]);
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ Postgres tdigest forms
 // The reference aggregates percentiles in SQL with the tdigest extension (tvondra/tdigest, not in /root/reference and unpinned:
@@ -2717,7 +2741,7 @@ static int td_sql_centroids(gys_ctx *c, uint64_t glob_id, double *mean, int64_t 
 }
 
 int gys_tdigest_sql_text(gys_ctx *c, uint64_t glob_id, char *buf, size_t buflen, size_t *needed)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || (!buf && buflen)) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
@@ -2738,10 +2762,10 @@ int gys_tdigest_sql_text(gys_ctx *c, uint64_t glob_id, char *buf, size_t buflen,
 	if (out.size() + 1 > buflen) return GYS_ERR_NOMEM;
 	memcpy(buf, out.c_str(), out.size() + 1);
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_tdigest_sql_binary(gys_ctx *c, uint64_t glob_id, void *buf, size_t buflen, size_t *needed)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || (!buf && buflen)) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
@@ -2768,7 +2792,7 @@ int gys_tdigest_sql_binary(gys_ctx *c, uint64_t glob_id, void *buf, size_t bufle
 		be((uint64_t)count[i], 8);
 	}
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 static double hll_estimate_host(const uint8_t *regs, int p)
 {
@@ -2786,7 +2810,7 @@ static double hll_estimate_host(const uint8_t *regs, int p)
 }
 
 int gys_query_distinct_flows(gys_ctx *c, double *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
 	std::vector<uint8_t> regs((size_t)1 << GYS_HLL_P);
@@ -2794,10 +2818,10 @@ int gys_query_distinct_flows(gys_ctx *c, double *out)
 	HIPCHK(hipStreamSynchronize(c->stream));
 	*out = hll_estimate_host(regs.data(), GYS_HLL_P);
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_query_cms(gys_ctx *c, uint64_t glob_id, int which, uint64_t *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !out || which < 0 || which > 1) return GYS_ERR_INVAL;
 	uint64_t best = ~0ull;
@@ -2819,7 +2843,7 @@ int gys_query_cms(gys_ctx *c, uint64_t glob_id, int which, uint64_t *out)
 	}
 	*out = best;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // Count-Min estimate for a (listener, client task group) pair.  which 0 / 1: active connections / bytes of the LAST ACTIVE_CONN_STATS
 // REPORT (the tables of the last window that carried such rows); which 2 / 3: connection notifications / bytes of the TCP_CONN_NOTIFY
@@ -2841,7 +2865,7 @@ static int pair_tables(gys_ctx *c, int which, const void **tbl)
 }
 
 int gys_query_pair_cms(gys_ctx *c, uint64_t listener_glob_id, uint64_t cli_aggr_task_id, int which, uint64_t *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
 	const void *tbl;
@@ -2865,10 +2889,10 @@ int gys_query_pair_cms(gys_ctx *c, uint64_t listener_glob_id, uint64_t cli_aggr_
 	}
 	*out = best;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_pair_cms(gys_ctx *c, int which, void *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
 	const void *tbl;
@@ -2878,20 +2902,20 @@ int gys_export_pair_cms(gys_ctx *c, int which, void *out)
 	HIPCHK(hipMemcpyAsync(out, tbl, n * ((which & 1) ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_active_conn_counters(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint64_t *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !out || (uint64_t)first_slot + nslots > c->nsvc) return GYS_ERR_INVAL;
 	if (!nslots) return GYS_OK;
 	HIPCHK(hipMemcpyAsync(out, c->svc_act + (size_t)first_slot * 4, (size_t)nslots * 32, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_query_topn(gys_ctx *c, const uint8_t machine_id[16], int kind, gys_topn_entry out[GYS_TOPN], uint32_t *nout)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !machine_id || !out || !nout || kind < 0 || kind > 3) return GYS_ERR_INVAL;
 	uint32_t host;
@@ -2928,10 +2952,10 @@ int gys_query_topn(gys_ctx *c, const uint8_t machine_id[16], int kind, gys_topn_
 	}
 	*nout = k;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_scan_percentiles_dev(gys_ctx *c, int which, const float *pcts, uint32_t npct, int64_t *d_out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !pcts || !d_out || !npct || npct > 64 || which < 0 || which > 1) return GYS_ERR_INVAL;
 	if (!c->nsvc) return GYS_OK;
@@ -2946,11 +2970,11 @@ int gys_scan_percentiles_dev(gys_ctx *c, int which, const float *pcts, uint32_t 
 			   c->cfg.enable_tdigest ? c->td_meta : nullptr, c->epoch, which, c->nsvc, c->dev_pcts, npct, d_out);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ exports
 int gys_scan_quantiles_dev(gys_ctx *c, const double *q, uint32_t nq, double *d_out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !q || !d_out || nq == 0 || nq > 16) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
@@ -2989,7 +3013,7 @@ int gys_scan_quantiles_dev(gys_ctx *c, const double *q, uint32_t nq, double *d_o
 		}
 	}
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // host -> member services on the device (slot order inside a host)
 static int host_csr(gys_ctx *c)
@@ -3083,7 +3107,7 @@ static int rollup_launch(gys_ctx *c, int kind, const std::vector<uint32_t> &off,
 }
 
 int gys_tdigest_rollup_dev(gys_ctx *c, int scope, gys_tdigest_slab *d_out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !d_out || scope < GYS_ROLLUP_HOST || scope > GYS_ROLLUP_GLOBAL) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
@@ -3123,19 +3147,19 @@ int gys_tdigest_rollup_dev(gys_ctx *c, int scope, gys_tdigest_slab *d_out)
 	}
 	if (scope != GYS_ROLLUP_HOST) HIPCHK(hipFree(d_hosts));
 	return rc;
-}
+} GYS_CATCH_ALL
 
 int gys_tdigest_merge_slabs_dev(gys_ctx *c, const gys_tdigest_slab *d_in, uint32_t n, gys_tdigest_slab *d_out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !d_in || !d_out || n == 0) return GYS_ERR_INVAL;
 	std::vector<uint32_t> off{0u, n}, mem(n);
 	for (uint32_t i = 0; i < n; ++i) mem[i] = i;
 	return rollup_launch(c, 1, off, mem, d_in, d_out);
-}
+} GYS_CATCH_ALL
 
 int gys_tdigest_slab_quantiles(gys_ctx *c, const gys_tdigest_slab *d_slab, const double *q, uint32_t nq, double *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !d_slab || !q || !out) return GYS_ERR_INVAL;
 	gys_tdigest_slab s;
@@ -3179,7 +3203,7 @@ int gys_tdigest_slab_quantiles(gys_ctx *c, const gys_tdigest_slab *d_slab, const
 		out[i] = r;
 	}
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 uint32_t gys_num_clusters(gys_ctx *c) { return c ? (uint32_t)c->cluster_names.size() : 0; }
 
@@ -3256,7 +3280,7 @@ RcclApi *rccl_api()
 static_assert(sizeof(ncclUniqueId) == GYS_RCCL_UID_BYTES, "gysketch.h carries an ncclUniqueId as 128 opaque bytes");
 
 int gys_rccl_unique_id(uint8_t uid[GYS_RCCL_UID_BYTES])
-{
+try {
 	if (!uid) return GYS_ERR_INVAL;
 	// The exchange is between the GPUs of ONE node: unless the caller chose an interface, the bootstrap rendezvous goes over
 	// loopback -- RCCL otherwise takes the first non-loopback interface, and on hosts whose first interface is a tunnel / container
@@ -3267,10 +3291,10 @@ int gys_rccl_unique_id(uint8_t uid[GYS_RCCL_UID_BYTES])
 	NCCLCHK(R->GetUniqueId(&id));
 	memcpy(uid, &id, sizeof(id));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_rccl_comm_create(gys_ctx *c, const uint8_t uid[GYS_RCCL_UID_BYTES], int nranks, int rank, void **comm)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !uid || !comm || nranks < 1 || rank < 0 || rank >= nranks) return GYS_ERR_INVAL;
 	if ((uint32_t)nranks != std::max<uint32_t>(c->cfg.nranks, 1) || (uint32_t)rank != c->cfg.rank) {
@@ -3286,18 +3310,18 @@ int gys_rccl_comm_create(gys_ctx *c, const uint8_t uid[GYS_RCCL_UID_BYTES], int 
 	NCCLCHK(R->CommInitRank(&cm, nranks, id, rank));
 	*comm = (void *)cm;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_rccl_comm_destroy(void *comm)
-{
+try {
 	if (!comm) return GYS_ERR_INVAL;
 	RCCL_API(R);
 	NCCLCHK(R->CommDestroy((ncclComm_t)comm));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_window_close_rccl(gys_ctx *c, void *comm, uint64_t tusec)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !comm) return GYS_ERR_INVAL;
 	RCCL_API(R);
@@ -3329,10 +3353,10 @@ int gys_window_close_rccl(gys_ctx *c, void *comm, uint64_t tusec)
 		}
 	}
 	return gys_window_finish(c);
-}
+} GYS_CATCH_ALL
 
 int gys_tdigest_global_rccl(gys_ctx *c, void *comm, gys_tdigest_slab *d_out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !comm || !d_out) return GYS_ERR_INVAL;
 	TDIGEST_CHECK();
@@ -3353,7 +3377,7 @@ int gys_tdigest_global_rccl(gys_ctx *c, void *comm, gys_tdigest_slab *d_out)
 	if (rc == GYS_OK) rc = gys_tdigest_merge_slabs_dev(c, d_all, (uint32_t)nranks, d_out); // (synchronises the stream)
 	hipFree(d_all);
 	return rc;
-}
+} GYS_CATCH_ALL
 
 uint32_t gys_num_services(gys_ctx *c) { return c ? c->nsvc : 0; }
 uint32_t gys_num_hosts(gys_ctx *c) { return c ? (uint32_t)c->hosts.size() : 0; }
@@ -3365,7 +3389,7 @@ uint32_t gys_num_hosts(gys_ctx *c) { return c ? (uint32_t)c->hosts.size() : 0; }
 	}
 
 int gys_export_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
-{
+try {
 	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	if (which < 0 || which > 1) return GYS_ERR_INVAL;
@@ -3383,10 +3407,10 @@ int gys_export_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots,
 	hipFree(tmp);
 	HIPCHK(e);
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_conn_bitmap(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint16_t *out)
-{
+try {
 	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	{
@@ -3403,19 +3427,19 @@ int gys_export_conn_bitmap(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uin
 	for (size_t i = 0; i < meta.size(); ++i)
 		if (meta[i].hw_epoch != c->epoch) memset(out + i * 32, 0, 64);
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_hll(gys_ctx *c, uint8_t *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
 	HIPCHK(hipMemcpyAsync(out, c->last + c->al.off_hll8, (size_t)1 << GYS_HLL_P, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_cms(gys_ctx *c, int which, void *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !out || which < 0 || which > 1) return GYS_ERR_INVAL;
 	const size_t n = (size_t)GYS_CMS_D * GYS_CMS_W;
@@ -3425,10 +3449,10 @@ int gys_export_cms(gys_ctx *c, int which, void *out)
 		HIPCHK(hipMemcpyAsync(out, (const int64_t *)(c->last + c->al.off_i64sum) + c->al.i64_cms, n * 8, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_global_hist(gys_ctx *c, gys_hist_rec *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
 	int64_t v[32];
@@ -3443,10 +3467,10 @@ int gys_export_global_hist(gys_ctx *c, gys_hist_rec *out)
 	out->total_count = (uint64_t)v[30];
 	out->max_val_seen = mx;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_tdigest(gys_ctx *c, uint32_t first_slot, uint32_t nslots, int64_t *sums, uint32_t *cnts, int32_t *minmax)
-{
+try {
 	GYS_ENTER(c);
 	void *out = sums;
 	RANGE_CHECK(first_slot, nslots);
@@ -3460,10 +3484,10 @@ int gys_export_tdigest(gys_ctx *c, uint32_t first_slot, uint32_t nslots, int64_t
 	HIPCHK(hipMemcpyAsync(minmax, c->td_minmax + first_slot, (size_t)nslots * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_tdigest_pending(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint32_t *npend, int32_t *pend)
-{
+try {
 	GYS_ENTER(c);
 	void *out = npend;
 	RANGE_CHECK(first_slot, nslots);
@@ -3480,10 +3504,10 @@ int gys_export_tdigest_pending(gys_ctx *c, uint32_t first_slot, uint32_t nslots,
 			pend[(size_t)i * GYS_TD_PEND_CAP + k] = k < meta[i].npend ? (int32_t)((uint32_t)pend[(size_t)i * GYS_TD_PEND_CAP + k] >> GYS_ROW_BITS) : 0;
 	}
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_svc_counters(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint64_t *out)
-{
+try {
 	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	{
@@ -3495,20 +3519,20 @@ int gys_export_svc_counters(gys_ctx *c, uint32_t first_slot, uint32_t nslots, ui
 	HIPCHK(hipMemcpyAsync(out, c->svc_ctr + (size_t)first_slot * 4, (size_t)nslots * 32, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_svc_hll(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint8_t *out)
-{
+try {
 	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	if (!c->svc_hll) return GYS_ERR_STATE;
 	HIPCHK(hipMemcpyAsync(out, c->svc_hll + ((size_t)first_slot << c->cfg.svc_hll_p), (size_t)nslots << c->cfg.svc_hll_p, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_get_counters(gys_ctx *c, gys_counters *out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
 	uint64_t v[16];
@@ -3539,7 +3563,7 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 		out->resp_submissions = c->rq.submissions;
 	}
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ multi-level windows
 #define LEVELS_CHECK()                                                        \
@@ -3554,7 +3578,7 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 	}
 
 int gys_export_hist_level(gys_ctx *c, int level, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
-{
+try {
 	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	LEVELS_CHECK();
@@ -3574,11 +3598,11 @@ int gys_export_hist_level(gys_ctx *c, int level, uint64_t tusec, uint32_t first_
 	}
 	hipFree(tmp);
 	return rc;
-}
+} GYS_CATCH_ALL
 
 int gys_query_hist_level_stats(gys_ctx *c, uint64_t glob_id, int level, uint64_t tusec, gys_time_hist_val *pstats, uint32_t nstats, int64_t *tcount,
 			       int64_t *tsum, double *mean_val)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || (!pstats && nstats)) return GYS_ERR_INVAL;
 	uint32_t slot;
@@ -3598,11 +3622,11 @@ int gys_query_hist_level_stats(gys_ctx *c, uint64_t glob_id, int level, uint64_t
 	if (tsum) *tsum = ts;
 	if (mean_val) *mean_val = (double)ts / (double)(tc != 0 ? tc : 1); // :1361
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_hist_period(gys_ctx *c, int64_t starttime, int64_t endtime, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out,
 			   int *level_used)
-{
+try {
 	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	LEVELS_CHECK();
@@ -3620,11 +3644,11 @@ int gys_export_hist_period(gys_ctx *c, int64_t starttime, int64_t endtime, uint6
 	}
 	hipFree(tmp);
 	return rc;
-}
+} GYS_CATCH_ALL
 
 int gys_query_hist_period_stats(gys_ctx *c, uint64_t glob_id, int64_t starttime, int64_t endtime, uint64_t tusec, gys_time_hist_val *pstats,
 				uint32_t nstats, int64_t *tcount, int64_t *tsum, double *mean_val)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || (!pstats && nstats)) return GYS_ERR_INVAL;
 	uint32_t slot;
@@ -3644,10 +3668,10 @@ int gys_query_hist_period_stats(gys_ctx *c, uint64_t glob_id, int64_t starttime,
 	if (tsum) *tsum = ts;
 	if (mean_val) *mean_val = (double)ts / (double)(tc != 0 ? tc : 1); // :1398
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_day_stats(gys_ctx *c, uint64_t tusec, uint32_t first_slot, uint32_t nslots, gys_listener_day_stats *out)
-{
+try {
 	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	LEVELS_CHECK();
@@ -3676,10 +3700,10 @@ int gys_export_day_stats(gys_ctx *c, uint64_t tusec, uint32_t first_slot, uint32
 	hipFree(lv);
 	hipFree(d_out);
 	return rc;
-}
+} GYS_CATCH_ALL
 
 int gys_scan_listener_state_dev(gys_ctx *c, uint64_t tusec, float qps_multiple, uint32_t diffsec, void *d_notify, gys_listener_scan *d_scan)
-{
+try {
 	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	LEVELS_CHECK();
@@ -3707,10 +3731,10 @@ int gys_scan_listener_state_dev(gys_ctx *c, uint64_t tusec, float qps_multiple, 
 	hipLaunchKernelGGL(k_listener_scan, dim3((c->nsvc + 255) / 256), dim3(256), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_export_svc_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out)
-{
+try {
 	GYS_ENTER(c);
 	RANGE_CHECK(first_slot, nslots);
 	LEVELS_CHECK();
@@ -3720,11 +3744,11 @@ int gys_export_svc_hist(gys_ctx *c, int which, uint32_t first_slot, uint32_t nsl
 	HIPCHK(hipMemcpyAsync(out, src, (size_t)nslots * sizeof(gys_hist_rec), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ standalone keyed histogram op
 int gys_hist_init_dev(gys_ctx *c, int kind, gys_hist_rec *d_hist, uint32_t nkeys)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !d_hist || kind < 0 || kind >= GYS_NUM_HASH_KINDS) return GYS_ERR_INVAL;
 	HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)nkeys * sizeof(gys_hist_rec), c->stream));
@@ -3732,10 +3756,10 @@ int gys_hist_init_dev(gys_ctx *c, int kind, gys_hist_rec *d_hist, uint32_t nkeys
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(nkeys, 256, 2048)), dim3(256), 0, c->stream, d_hist, (uint64_t)0, (uint64_t)nkeys, mn);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_hist_add_dev(gys_ctx *c, int kind, gys_hist_rec *d_hist, uint32_t nkeys, const uint32_t *d_keyidx, const int32_t *d_vals, uint64_t n)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !d_hist || kind < 0 || kind >= GYS_NUM_HASH_KINDS || ((!d_keyidx || !d_vals) && n)) return GYS_ERR_INVAL;
 	if (!n) return GYS_OK;
@@ -3743,10 +3767,10 @@ int gys_hist_add_dev(gys_ctx *c, int kind, gys_hist_rec *d_hist, uint32_t nkeys,
 	hipLaunchKernelGGL(k_hist_add, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, kind, d_hist, nkeys, d_keyidx, d_vals, n);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_hist_merge_dev(gys_ctx *c, gys_hist_rec *d_dst, const gys_hist_rec *d_src, uint32_t nkeys)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !d_dst || !d_src) return GYS_ERR_INVAL;
 	if (!nkeys) return GYS_OK;
@@ -3755,10 +3779,10 @@ int gys_hist_merge_dev(gys_ctx *c, gys_hist_rec *d_dst, const gys_hist_rec *d_sr
 			   (gys_hist_rec *)d_src, (uint64_t)nkeys, 0, (long long *)nullptr, (long long *)nullptr);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_hist_percentiles_dev(gys_ctx *c, int kind, const gys_hist_rec *d_hist, uint32_t nkeys, const float *pcts, uint32_t npct, int64_t *d_out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !d_hist || !pcts || !d_out || !npct || npct > 64 || kind < 0 || kind >= GYS_NUM_HASH_KINDS) return GYS_ERR_INVAL;
 	if (!nkeys) return GYS_OK;
@@ -3769,29 +3793,29 @@ int gys_hist_percentiles_dev(gys_ctx *c, int kind, const gys_hist_rec *d_hist, u
 	hipLaunchKernelGGL(k_hist_percentiles, dim3((uint32_t)((t + 255) / 256)), dim3(256), 0, c->stream, kind, d_hist, nkeys, c->dev_pcts, npct, d_out);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ profiling
 int gys_profile_enable(gys_ctx *c, int on)
-{
+try {
 	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	c->profile = on != 0;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_profile_reset(gys_ctx *c)
-{
+try {
 	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	prof_resolve(c);
 	c->prof.clear();
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_profile_get(gys_ctx *c, const char *kernel, double *total_ms, uint64_t *launches)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !kernel) return GYS_ERR_INVAL;
 	prof_resolve(c);
@@ -3804,10 +3828,10 @@ int gys_profile_get(gys_ctx *c, const char *kernel, double *total_ms, uint64_t *
 	if (total_ms) *total_ms = it->second.total_ms;
 	if (launches) *launches = it->second.launches;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_profile_names(gys_ctx *c, char *buf, size_t buflen)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !buf || !buflen) return GYS_ERR_INVAL;
 	std::string s;
@@ -3817,11 +3841,11 @@ int gys_profile_names(gys_ctx *c, char *buf, size_t buflen)
 	}
 	snprintf(buf, buflen, "%s", s.c_str());
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ synthetic generator
 int gys_debug_read_events_dev(gys_ctx *c, const void *d_ev24, uint64_t nevents)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !d_ev24) return GYS_ERR_INVAL;
 	if (!nevents) return GYS_OK;
@@ -3830,11 +3854,11 @@ int gys_debug_read_events_dev(gys_ctx *c, const void *d_ev24, uint64_t nevents)
 			   (uint64_t *)c->counters + 15);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_gen_resp_events_dev(gys_ctx *c, void *d_ev24, uint64_t nevents, uint64_t seed, uint32_t first_host, uint32_t nhosts, uint32_t svcs_per_host,
 			    uint32_t zipf_milli, gys_resp_seg *segs_out)
-{
+try {
 	GYS_ENTER(c);
 	if (!c || !d_ev24 || !nhosts || !svcs_per_host || !segs_out) return GYS_ERR_INVAL;
 	const bool spread = zipf_milli == GYS_GEN_SPREAD; // per-service weights 0..255/256 instead of a Zipf law
@@ -3878,7 +3902,7 @@ int gys_gen_resp_events_dev(gys_ctx *c, void *d_ev24, uint64_t nevents, uint64_t
 	if (nevents) hipLaunchKernelGGL(k_gen_resp, dim3(grid_for(nevents, 256, 4096)), dim3(256), 0, c->stream, g);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 } // extern "C"
 

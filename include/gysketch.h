@@ -36,7 +36,8 @@ enum {
 	GYS_ERR_HIP = -3,       /* HIP runtime error (gys_last_error() has the text) */
 	GYS_ERR_NOTFOUND = -4,  /* unknown host / service */
 	GYS_ERR_NOT_OWNER = -5, /* host is sharded to another rank (jhash2(machine_id) % nranks != rank) */
-	GYS_ERR_STATE = -6      /* call sequence error (e.g. window_finish without window_prepare) */
+	GYS_ERR_STATE = -6,     /* call sequence error (e.g. window_finish without window_prepare) */
+	GYS_ERR_INTERNAL = -7   /* a C++ exception other than an allocation failure inside the library (never crosses the boundary) */
 };
 
 /* bucket-hash kinds == the reference's hash classes, common/gy_statistics.h:1565-2063 */
