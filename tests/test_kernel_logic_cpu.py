@@ -20,7 +20,9 @@ the hot kernels run on synthetic input:
     message, the serial walk's offsets otherwise (tools/kemu_tsan.sh address runs it under AddressSanitizer: no corrupted length makes
     a kernel index outside the stream or its work arrays);
   * the LISTENER_STATE_NOTIFY roll-up k_lstate_ingest and the ACTIVE_CONN_STATS roll-up k_actconn_ingest (tests/cpp/kemu/test_lstate.cc)
-    on records whose bytes are random except the listener id (any state, any flags, counters whose int sums wrap).
+    on records whose bytes are random except the listener id (any state, any flags, counters whose int sums wrap);
+  * the per-host top-10 selection k_topn_hosts and the candidate filter k_topn_filter (tests/cpp/kemu/test_topn.cc): hosts of 0 ... 2 700
+    listeners, ties, stale and foreign records, all four kinds.
 This does not replace the -m gpu parity tests (no memory model, no execution masks, no timing): it catches logic errors in kernel
 changes before GPU minutes are spent on them.  The programs are built and run side by side once per session (they mostly wait in
 barriers); each test below looks at one of them."""
@@ -49,6 +51,7 @@ PROGRAMS = {
     "wire-corrupted-23": ("test_wire.cc", [], ["23"], "kemu wire ok"),
     "lstate-actconn-random-3": ("test_lstate.cc", [], ["3"], "kemu lstate ok"),
     "lstate-actconn-random-4": ("test_lstate.cc", [], ["4"], "kemu lstate ok"),
+    "topn-17": ("test_topn.cc", [], ["17"], "kemu topn ok"),
 }
 
 
