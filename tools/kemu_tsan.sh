@@ -4,7 +4,12 @@
 #            reports, all idempotent by construction: the read-before-atomicMax of the HLL registers in k_resp_host / k_conn_ingest and
 #            the read-before-atomicOr of CONN_BITMAP words in k_huge_count / k_digest_huge (a register / word only grows: a stale read
 #            costs at most a redundant atomic), and same-value stores by several threads (finalize_key: the host's spill stamp;
-#            k_huge_merge: s_over = 1).  ~10 minutes on 8 cores.
+#            k_huge_merge: s_over = 1); the read-before-atomicMax of a histogram's max_val_seen (hist_add_atomic); k_wire_round's mark[]
+#            (a slot marked DURING a doubling round may already pass its mark on in that round: marks only grow and everything that gets
+#            marked is a true record start of the chain, so a round can only run ahead); and ONE report that is a real limit, not an
+#            idempotent pattern: k_lstate_ingest's 96-byte store of a listener's kept state when TWO records of one call name the same
+#            listener (the test feeds such calls on purpose) -- one thread per record, no winner is chosen, see DESIGN.md section 10.
+#            ~12 minutes on 8 cores.
 #   address: an index past the end of a __shared__ array (a function-local static here, red zones around it), of the dynamic LDS block
 #            or of a global buffer aborts the program.  Expected: no report.  ~6 minutes.
 SAN=${1:-thread}
