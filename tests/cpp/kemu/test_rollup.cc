@@ -1,0 +1,172 @@
+// TEST INFRASTRUCTURE (CPU): the LOGIC of the roll-up digests k_digest_rollup (gyeeta_amd/csrc/gys_rollup.hpp) under the CPU stand-in of
+// the device model: the digest of a GROUP of services (kind 0: a left fold over the members of d := merge(d, member's clusters), then the
+// member's buffered values) and of a group of roll-up slabs (kind 1: the cross-rank fold), with 64-bit counters -- groups of 0, 1 and many
+// members, members without clusters, without buffered values and without anything, all-equal values, values >= 1024 ms, and a group
+// whose weight passes 2^32 -- equal, cluster by cluster, to the oracle's gyo_td64_merge_service / gyo_td64_merge_td64 folds
+// (oracle/gy_oracle_rollup.c), minimum / maximum included.  Build + run: tests/test_kernel_logic_cpu.py.
+#define GYS_OPAQUE_VGPR(x) asm volatile("" : "+r"(x))
+#define GYS_OPAQUE_LOADED4(a) asm volatile("" : "+r"(a[0]), "+r"(a[1]), "+r"(a[2]), "+r"(a[3]))
+#define GYS_DYN_LDS(type, name) type *name = (type *)kemu::dyn_lds()
+#include "../../../gyeeta_amd/csrc/gys_kernels.hpp"
+#include "../../../gyeeta_amd/csrc/gys_rollup.hpp"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <random>
+
+#include "../../../oracle/gy_oracle.h"
+
+using namespace gys;
+
+namespace {
+int fails = 0;
+#define CHECK(c, ...)                                               \
+	do {                                                        \
+		if (!(c)) {                                         \
+			if (fails++ < 20) {                         \
+				printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+				printf(__VA_ARGS__);                \
+				printf("\n");                       \
+			}                                           \
+		}                                                   \
+	} while (0)
+int32_t draw(std::mt19937 &rng, double mu, double sigma)
+{
+	std::normal_distribution<double> n(mu, sigma);
+	const double v = floor(exp(n(rng)));
+	return (int32_t)(v < 0 ? 0 : v > 1000000.0 ? 1000000.0 : v);
+}
+void compare(const char *what, uint32_t g, const gys_tdigest_slab &got, const gyo_td64 &want)
+{
+	uint64_t tot = 0;
+	for (int j = 0; j < GYO_TD_NB; ++j) {
+		CHECK(got.cnt[j] == want.cnt[j] && got.sum[j] == want.sum[j], "%s group %u cluster %d: {%llu, %lld}, oracle {%llu, %lld}", what, g, j, (unsigned long long)got.cnt[j],
+		      (long long)got.sum[j], (unsigned long long)want.cnt[j], (long long)want.sum[j]);
+		tot += want.cnt[j];
+	}
+	if (tot) CHECK(got.vmin == want.vmin && got.vmax == want.vmax, "%s group %u: min / max %lld %lld, oracle %lld %lld", what, g, (long long)got.vmin, (long long)got.vmax,
+		       (long long)want.vmin, (long long)want.vmax);
+}
+} // namespace
+
+int main(int argc, char **argv)
+{
+	if (!kemu::can_run(256u)) {
+		printf("kemu: this process cannot have 256 threads\n");
+		return 77;
+	}
+	std::mt19937 rng(argc > 1 ? (unsigned)atoi(argv[1]) : 9u);
+	const uint32_t S = 36, pcap = GYS_TD_PEND_CAP + 64u;
+	std::vector<gyo_td_buffered> svc(S);
+	std::vector<int64_t> td_sum((size_t)S * GYS_TD_NB, 0);
+	std::vector<uint32_t> td_cnt((size_t)S * GYS_TD_NB, 0), td_pend((size_t)S * pcap, 0xDEADBEEFu);
+	std::vector<TdMeta> meta(S);
+	std::vector<int2> minmax(S);
+	for (uint32_t s = 0; s < S; ++s) {
+		gyo_td_buffered &b = svc[s];
+		gyo_tdb_init(&b);
+		const double mu = 1.0 + 0.2 * s, sigma = s % 3 == 2 ? 2.0 : 0.9; // (the last services: most values >= 1024 ms)
+		if (s % 7 == 3) {
+			// nothing at all
+		} else if (s % 7 == 5) { // huge weights: three of these in a group pass 2^32
+			for (int j = 0; j < GYO_TD_NB; ++j) {
+				b.d.cnt[j] = 9000000u + 1000u * s;
+				b.d.sum[j] = (int64_t)b.d.cnt[j] * (5 + 3 * j + (int)s);
+			}
+			b.d.vmin = 5;
+			b.d.vmax = 5 + 3 * GYO_TD_NB + (int)s;
+		} else {
+			const uint32_t nbatches = s % 7 == 0 ? 1u : 2u + rng() % 6u; // (one small batch: buffered values only, no clusters yet)
+			for (uint32_t k = 0; k < nbatches; ++k) {
+				std::vector<int32_t> v(s % 7 == 0 ? 40u : 100u + rng() % 700u);
+				for (auto &x : v) x = s == 8 ? 37 : draw(rng, mu, sigma); // service 8: all values equal
+				gyo_tdb_add_batch(&b, v.data(), v.size());
+			}
+			if (s % 7 == 1) { // no buffered values: everything merged
+				gyo_tdigest mv;
+				gyo_tdb_merged_view(&b, &mv);
+				b.d = mv;
+				b.npend = 0;
+			}
+		}
+		for (int j = 0; j < GYO_TD_NB; ++j) {
+			td_sum[(size_t)s * GYS_TD_NB + j] = b.d.sum[j];
+			td_cnt[(size_t)s * GYS_TD_NB + j] = b.d.cnt[j];
+		}
+		for (uint32_t i = 0; i < b.npend; ++i) td_pend[(size_t)s * pcap + i] = ((uint32_t)b.pend[i] << GYS_ROW_BITS) | (rng() & 31u);
+		meta[s] = TdMeta{};
+		meta[s].npend = b.npend;
+		minmax[s] = gyo_td_total(&b.d) ? make_int2(b.d.vmin, b.d.vmax) : make_int2(INT32_MAX, INT32_MIN);
+	}
+	// groups of services: empty, one member, a few, many, one with the three heavy services (5, 12, 19, 26, 33 are heavy)
+	std::vector<std::vector<uint32_t>> groups = {{}, {4}, {3}, {0, 1, 2}, {5, 12, 19, 26}, {8, 8, 9}, {}};
+	{
+		std::vector<uint32_t> all(S);
+		for (uint32_t s = 0; s < S; ++s) all[s] = s;
+		groups.push_back(all);
+		std::vector<uint32_t> rev(all.rbegin(), all.rend()); // (the fold is ordered: the reverse order is another digest)
+		groups.push_back(rev);
+	}
+	std::vector<uint32_t> off(1, 0), members;
+	for (auto &g : groups) {
+		members.insert(members.end(), g.begin(), g.end());
+		off.push_back((uint32_t)members.size());
+	}
+	if (members.empty()) members.push_back(0);
+	const uint32_t NG = (uint32_t)groups.size();
+	std::vector<gys_tdigest_slab> slabs(NG);
+	memset(slabs.data(), 0xAB, sizeof(gys_tdigest_slab) * NG);
+	RollupP q{};
+	q.d.td_sum = td_sum.data();
+	q.d.td_cnt = td_cnt.data();
+	q.d.td_meta = meta.data();
+	q.d.td_minmax = minmax.data();
+	q.d.td_pend = td_pend.data();
+	q.d.pcap = pcap;
+	q.d.nsvc = S;
+	q.off = off.data();
+	q.members = members.data();
+	q.kind = 0;
+	q.out = slabs.data();
+	q.ngroups = NG;
+	kemu::launch(3, 256, 0, [&] { k_digest_rollup(q); }); // (fewer workgroups than groups: they loop)
+	std::vector<gyo_td64> want(NG);
+	uint64_t heavy = 0;
+	for (uint32_t g = 0; g < NG; ++g) {
+		gyo_td64_init(&want[g]);
+		for (uint32_t s : groups[g]) gyo_td64_merge_service(&want[g], &svc[s]);
+		compare("services", g, slabs[g], want[g]);
+		heavy = std::max(heavy, gyo_td64_total(&want[g]));
+	}
+	CHECK(heavy > (1ull << 32), "no group passed 2^32 (%llu)", (unsigned long long)heavy);
+	// groups of slabs (the cross-rank fold): the slabs above, in two orders and with an empty one in the middle
+	std::vector<std::vector<uint32_t>> sg = {{3, 4, 7}, {7, 0, 4, 3}, {0}, {}, {8, 7}};
+	std::vector<uint32_t> soff(1, 0), smem;
+	for (auto &g : sg) {
+		smem.insert(smem.end(), g.begin(), g.end());
+		soff.push_back((uint32_t)smem.size());
+	}
+	std::vector<gys_tdigest_slab> out2(sg.size());
+	RollupP q2 = q;
+	q2.kind = 1;
+	q2.in = slabs.data();
+	q2.off = soff.data();
+	q2.members = smem.data();
+	q2.out = out2.data();
+	q2.ngroups = (uint32_t)sg.size();
+	kemu::launch((uint32_t)sg.size(), 256, 0, [&] { k_digest_rollup(q2); });
+	for (uint32_t g = 0; g < sg.size(); ++g) {
+		gyo_td64 w;
+		gyo_td64_init(&w);
+		for (uint32_t m : sg[g]) gyo_td64_merge_td64(&w, &want[m]);
+		compare("slabs", g, out2[g], w);
+	}
+	if (fails) {
+		printf("kemu rollup: %d FAILURES\n", fails);
+		return 1;
+	}
+	printf("kemu rollup ok: %u groups of services (heaviest %llu values), %zu groups of slabs\n", NG, (unsigned long long)heavy, sg.size());
+	return 0;
+}

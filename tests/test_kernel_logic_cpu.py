@@ -22,7 +22,9 @@ the hot kernels run on synthetic input:
   * the LISTENER_STATE_NOTIFY roll-up k_lstate_ingest and the ACTIVE_CONN_STATS roll-up k_actconn_ingest (tests/cpp/kemu/test_lstate.cc)
     on records whose bytes are random except the listener id (any state, any flags, counters whose int sums wrap);
   * the per-host top-10 selection k_topn_hosts and the candidate filter k_topn_filter (tests/cpp/kemu/test_topn.cc): hosts of 0 ... 2 700
-    listeners, ties, stale and foreign records, all four kinds.
+    listeners, ties, stale and foreign records, all four kinds;
+  * the roll-up digests k_digest_rollup (tests/cpp/kemu/test_rollup.cc): groups of services and groups of slabs folded in order, 64-bit
+    weights beyond 2^32, members without clusters / without buffered values / empty.
 This does not replace the -m gpu parity tests (no memory model, no execution masks, no timing): it catches logic errors in kernel
 changes before GPU minutes are spent on them.  The programs are built and run side by side once per session (they mostly wait in
 barriers); each test below looks at one of them."""
@@ -52,6 +54,8 @@ PROGRAMS = {
     "lstate-actconn-random-3": ("test_lstate.cc", [], ["3"], "kemu lstate ok"),
     "lstate-actconn-random-4": ("test_lstate.cc", [], ["4"], "kemu lstate ok"),
     "topn-17": ("test_topn.cc", [], ["17"], "kemu topn ok"),
+    "rollup-9": ("test_rollup.cc", [], ["9"], "kemu rollup ok"),
+    "rollup-10": ("test_rollup.cc", [], ["10"], "kemu rollup ok"),
 }
 
 
