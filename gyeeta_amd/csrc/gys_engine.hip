@@ -218,6 +218,8 @@ struct gys_ctx {
 	unsigned long long *svc_win = nullptr; // per-service window accumulators of the connection path (k_conn_ingest / k_conn_fold)
 	bool conn_dirty = false;
 	uint8_t *svc_state = nullptr;
+	unsigned long long *svc_claim = nullptr; // [S] k_lstate_ingest / k_lstate_keep: last record of a call per listener
+	uint32_t lstate_launch = 0;
 	uint8_t *svc_hll = nullptr;
 	int32_t *host_summ_win = nullptr, *host_summ_last = nullptr;
 	gys_host_state *host_state = nullptr;
@@ -1335,7 +1337,11 @@ int run_lstate(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, co
 	p.qps_hist = c->qps_hist;
 	p.act_hist = c->act_hist;
 	ProfScope ps(c, "lstate");
+	p.claim = c->svc_claim;
+	if (++c->lstate_launch == 0) c->lstate_launch = 1; // (enq_mu or the exclusive call lock is held; 0 = the cleared claim table)
+	p.launch = c->lstate_launch;
 	hipLaunchKernelGGL(k_lstate_ingest, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
+	hipLaunchKernelGGL(k_lstate_keep, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
 }
@@ -1670,6 +1676,7 @@ try {
 	ALLOC(c->svc_ctr, S * 4);
 	ALLOC(c->svc_win, S * 3);
 	ALLOC(c->svc_state, S * 96);
+	ALLOC(c->svc_claim, S * 8);
 	ALLOC(c->hll32, (uint64_t)1 << GYS_HLL_P);
 	ALLOC(c->host_summ_win, H * 16);
 	ALLOC(c->host_summ_last, H * 16);
@@ -1852,7 +1859,7 @@ void gys_destroy(gys_ctx *c)
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
-			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
+			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_claim, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_first, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};

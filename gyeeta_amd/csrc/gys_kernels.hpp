@@ -2598,6 +2598,8 @@ struct LStateP {
 	uint32_t epoch;
 	uint64_t *counters;
 	gys_hist_rec *qps_hist, *act_hist; // per service (levels enabled) or nullptr
+	unsigned long long *claim;         // [nsvc] launch << 32 | (record index + 1) of the LAST record of the call that names the listener
+	uint32_t launch;                   // number of this ingest call (never 0)
 };
 
 __global__ __launch_bounds__(256) void k_lstate_ingest(LStateP p)
@@ -2624,7 +2626,7 @@ __global__ __launch_bounds__(256) void k_lstate_ingest(LStateP p)
 	}
 	if (query_flags == 0xC0u) { // LISTEN_FLAG_DELETE :11194
 		atomicAdd((unsigned long long *)&p.counters[CTR_LSTATE_DELETED], 1ull);
-		*(uint32_t *)(p.svc_state + (size_t)slot * 96 + 88) = 0; // state no longer current
+		atomicMax(&p.claim[slot], ((unsigned long long)p.launch << 32) | (unsigned long long)(i + 1u)); // (k_lstate_keep: state no longer current)
 		return;
 	}
 	if (curr_state > 5u) { // :11250-11256
@@ -2642,17 +2644,41 @@ __global__ __launch_bounds__(256) void k_lstate_ingest(LStateP p)
 	if (ser_errors) atomicAdd(&s[10], (int32_t)ser_errors);
 	atomicAdd(&s[11], 1);
 	if (nqrys_5s) atomicAdd(&s[12], 1);
-	// MTCP_LISTENER::set_state server/gy_msocket.h:1410-1437: keep the 88-byte record
-	uint64_t *d = (uint64_t *)(p.svc_state + (size_t)slot * 96);
-#pragma unroll
-	for (int k = 0; k < 11; ++k) d[k] = w[k];
-	d[11] = (uint64_t)p.epoch | ((uint64_t)host << 32);
+	// MTCP_LISTENER::set_state server/gy_msocket.h:1410-1437 keeps the 88-byte record; the reference walks a message serially, so when
+	// several records of one call name the listener (a backlog of 5-s messages in one buffer) the LAST one stays, whole: the records
+	// claim the listener here and the owner of the claim stores in k_lstate_keep
+	atomicMax(&p.claim[slot], ((unsigned long long)p.launch << 32) | (unsigned long long)(i + 1u));
 	if (p.qps_hist) {
 		// the per-listener QPS_HISTOGRAM / ACTIVE_CONN_HISTOGRAM behind LISTENER_DAY_STATS (common/gy_socket_stat.h:548-549, :633-635;
 		// one sample per 5-s state record: gy_socket_stat.cc:4109-4127), fed from the record's own nqrys_5s_/5 and nconns_active_
 		hist_add_atomic(hash_def(GYS_SEMI_LOG_HASH_LO), GYS_SEMI_LOG_HASH_LO, &p.qps_hist[slot], (int64_t)(int32_t)(nqrys_5s / 5u));
 		hist_add_atomic(hash_def(GYS_HASH_1_3000), GYS_HASH_1_3000, &p.act_hist[slot], (int64_t)(int32_t)nconns_active);
 	}
+}
+
+// second pass of a LISTENER_STATE_NOTIFY call: the record that holds its listener's claim (the last one of the call in stream order) stores
+// the kept state -- or, for a record flagged LISTEN_FLAG_DELETE, marks the state as no longer current
+__global__ __launch_bounds__(256) void k_lstate_keep(LStateP p)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= p.n) return;
+	const uint64_t *q = (const uint64_t *)(p.batch + p.offsets[i]);
+	const uint64_t glob_id = q[0], w9 = q[9], w10 = q[10];
+	const uint32_t curr_state = (uint32_t)((w9 >> 56) & 0xFF), query_flags = (uint32_t)((w10 >> 32) & 0xFF);
+	const uint32_t slot = tbl_lookup(p.gid, glob_id);
+	if (slot == GYS_NOSLOT) return;
+	const bool del = query_flags == 0xC0u;
+	if (!del && curr_state > 5u) return; // (skipped by the walk: never claimed)
+	if (p.claim[slot] != (((unsigned long long)p.launch << 32) | (unsigned long long)(i + 1u))) return;
+	uint64_t *d = (uint64_t *)(p.svc_state + (size_t)slot * 96);
+	if (del) {
+		*(uint32_t *)(d + 11) = 0;
+		return;
+	}
+	const uint32_t host = p.host_slot ? p.host_slot[i] : p.single_host;
+#pragma unroll
+	for (int k = 0; k < 11; ++k) d[k] = q[k];
+	d[11] = (uint64_t)p.epoch | ((uint64_t)host << 32);
 }
 
 // ---------------------------------------------------------------------------------------------------- window boundary

@@ -56,6 +56,7 @@ int main(int argc, char **argv)
 	std::vector<gyo_listen_summ_stats> want_summ(NHOSTS);
 	memset(want_summ.data(), 0, sizeof(gyo_listen_summ_stats) * NHOSTS);
 	std::vector<uint64_t> counters(CTR_NUM, 0);
+	std::vector<unsigned long long> claim(NSVC, 0);
 	std::vector<gys_hist_rec> qps_hist(NSVC), act_hist(NSVC);
 	std::vector<gyo_hist> o_qps(NSVC), o_act(NSVC);
 	memset(qps_hist.data(), 0, sizeof(gys_hist_rec) * NSVC);
@@ -133,19 +134,19 @@ int main(int argc, char **argv)
 		p.counters = counters.data();
 		p.qps_hist = qps_hist.data();
 		p.act_hist = act_hist.data();
+		p.claim = claim.data();
+		p.launch = epoch;
 		kemu::launch((n + 255u) / 256u, 256, 0, [&] { k_lstate_ingest(p); });
-		// two records of one listener in one call: the kept state is the LAST writer's in the reference's serial walk, any of them on the
-		// device (one thread per record) -- compare the state only for listeners named once in the call
-		std::vector<uint32_t> named(NSVC, 0);
-		for (uint32_t i = 0; i < n; ++i) {
-			uint64_t g;
-			memcpy(&g, (const uint8_t *)raw.data() + offsets[i], 8);
-			for (uint32_t s = 0; s < NSVC; ++s)
-				if (gids[s] == g) ++named[s];
-		}
+		kemu::launch((n + 255u) / 256u, 256, 0, [&] { k_lstate_keep(p); });
+		// several records of one listener in one call: the LAST one in stream order stays, whole (the reference's serial walk) -- want_state
+		// was built in that order above
 		for (uint32_t s = 0; s < NSVC; ++s) {
-			if (named[s] == 1) CHECK(!memcmp(&svc_state[s * 96], &want_state[s * 96], 96), "epoch %u: kept state of listener %u differs", epoch, s);
-			else memcpy(&want_state[s * 96], &svc_state[s * 96], 96); // (several records: take the device's choice as the base of the next call)
+			uint32_t got_ep, want_ep;
+			memcpy(&got_ep, &svc_state[s * 96 + 88], 4);
+			memcpy(&want_ep, &want_state[s * 96 + 88], 4);
+			// (a listener whose last record was a delete has no current state: only the cleared window number means anything)
+			if (want_ep == 0) CHECK(got_ep == 0, "epoch %u: listener %u was deleted last, its state is still marked current", epoch, s);
+			else CHECK(!memcmp(&svc_state[s * 96], &want_state[s * 96], 96), "epoch %u: kept state of listener %u differs", epoch, s);
 		}
 	}
 	CHECK(counters[CTR_LSTATE_RECORDS] == want_rec && counters[CTR_LSTATE_MISSED] == want_missed && counters[CTR_LSTATE_DELETED] == want_deleted &&
