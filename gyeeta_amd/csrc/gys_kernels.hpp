@@ -1980,29 +1980,51 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		// first, first + 2, ... and only the cluster boundaries that fall between them matter: one threshold search per NON-EMPTY BIN
 		// (integer-millisecond response times repeat: ~860 buffered values hold ~200 distinct ones) instead of one per value, and one
 		// packed add per (bin, output cluster).  Thread t takes bins t, t + 256, t + 512, t + 768: the busy low bins spread over all waves.
-#pragma unroll
-		for (uint32_t k = 0; k < GYS_MB_EXACT / 256u; ++k) {
-			const uint32_t b = tid + 256u * k;
-			const uint32_t bw = s_bin[b], c = (s_bin[b + 1u] & 0xFFFFu) - (bw & 0xFFFFu);
-			if (!c || (GYS_MB_SKIP & 1)) continue;
-			uint32_t mid2 = 2u * ((bw & 0xFFFFu) + s_cpfx[bw >> 16]) + 1u;
-			uint32_t a = 0;
-#pragma unroll
-			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
-				if (mid2 >= s_T[a + step]) a += step;
-			uint32_t rem = c;
-			while (rem) { // (nearly always one round: a cluster spans far more mid-points than a bin's values)
-				const uint32_t Tn = s_T[a + 1u]; // first mid-point of the next cluster (~0 after the last)
-				const uint32_t kk = min(rem, (Tn - mid2 + 1u) >> 1); // values with mid2 + 2 r < Tn
-#if GYS_MB_PACKED
-				atomicAdd(&s_oval[a], ((unsigned long long)kk << 40) | (unsigned long long)(kk * b));
-#else
-				atomicAdd(&s_osum[a], (unsigned long long)(kk * b));
-				atomicAdd(&s_ocnt[a], kk);
+#ifndef GYS_MB_GROUP
+#define GYS_MB_GROUP 2u // the thread's four bins searched GROUP at a time (1, 2 or 4): the 8 dependent LDS reads of one threshold search overlap the others'
 #endif
-				rem -= kk;
-				mid2 += 2u * kk;
-				++a;
+		constexpr uint32_t MBG = SCAN ? 1u : GYS_MB_GROUP; // (the scan form sits at 63 VGPRs: left as it was)
+#pragma unroll
+		for (uint32_t k0 = 0; k0 < GYS_MB_EXACT / 256u; k0 += MBG) {
+			uint32_t bq[MBG], cq[MBG], mq[MBG], aq[MBG], call = 0;
+#pragma unroll
+			for (uint32_t u = 0; u < MBG; ++u) {
+				bq[u] = tid + 256u * (k0 + u);
+				const uint32_t bw = s_bin[bq[u]];
+				cq[u] = (GYS_MB_SKIP & 1) ? 0u : (s_bin[bq[u] + 1u] & 0xFFFFu) - (bw & 0xFFFFu);
+				mq[u] = 2u * ((bw & 0xFFFFu) + s_cpfx[bw >> 16]) + 1u;
+				aq[u] = 0;
+				call |= cq[u];
+			}
+			if (!call) continue;
+#pragma unroll
+			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1) {
+				uint32_t tq[MBG];
+#pragma unroll
+				for (uint32_t u = 0; u < MBG; ++u) tq[u] = s_T[aq[u] + step];
+#pragma unroll
+				for (uint32_t u = 0; u < MBG; ++u)
+					if (mq[u] >= tq[u]) aq[u] += step;
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < MBG; ++u) GYS_OPAQUE_VGPR(aq[u]); // (the searches stay in this block: sunk into the `while (rem)` bodies below they would run one after the other)
+#pragma unroll
+			for (uint32_t u = 0; u < MBG; ++u) {
+				uint32_t rem = cq[u], mid2 = mq[u], a = aq[u];
+				const uint32_t b = bq[u];
+				while (rem) { // (nearly always one round: a cluster spans far more mid-points than a bin's values)
+					const uint32_t Tn = s_T[a + 1u]; // first mid-point of the next cluster (~0 after the last)
+					const uint32_t kk = min(rem, (Tn - mid2 + 1u) >> 1); // values with mid2 + 2 r < Tn
+#if GYS_MB_PACKED
+					atomicAdd(&s_oval[a], ((unsigned long long)kk << 40) | (unsigned long long)(kk * b));
+#else
+					atomicAdd(&s_osum[a], (unsigned long long)(kk * b));
+					atomicAdd(&s_ocnt[a], kk);
+#endif
+					rem -= kk;
+					mid2 += 2u * kk;
+					++a;
+				}
 			}
 		}
 		// the (few) large values, one per thread from the list: rank inside the cell by comparison with the other large values, gap by
