@@ -1959,7 +1959,12 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		__syncthreads();
 		const uint32_t nbig = s_nbig;
 		// ---- old clusters: preceded by the old weight before them and by the values below their mean
-		if (c0 && !(GYS_MB_SKIP & 2)) {
+#ifndef GYS_MB_FUSE_OLD
+#define GYS_MB_FUSE_OLD 0 // 1: the old cluster's threshold search runs in lockstep with the searches of the thread's first group of bins
+#endif
+		uint32_t mid2_old = 0;
+		const bool has_old = c0 && !(GYS_MB_SKIP & 2);
+		if (has_old) {
 			uint32_t nb = s_bin[mb_bin(thr)] & 0xFFFFu;
 			if (thr >= GYS_MB_EXACT) {
 				const uint32_t sh = (31u - (uint32_t)__clz((int)thr)) - 6u;
@@ -1969,12 +1974,16 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 				}
 			}
 			const uint32_t mid2 = 2u * (e0 + nb) + c0;
+#if GYS_MB_FUSE_OLD
+			mid2_old = mid2; // (searched below, in lockstep with the thread's first group of bins)
+#else
 			uint32_t a = 0;
 #pragma unroll
 			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
 				if (mid2 >= s_T[a + step]) a += step;
 			atomicAdd(&s_osum[a], (unsigned long long)sm0);
 			atomicAdd(&s_ocnt[a], c0);
+#endif
 		}
 		// ---- values, pass 2, PER BIN: the c values of a one-value bin are equal, so they take the consecutive mid-points
 		// first, first + 2, ... and only the cluster boundaries that fall between them matter: one threshold search per NON-EMPTY BIN
@@ -1996,18 +2005,29 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 				aq[u] = 0;
 				call |= cq[u];
 			}
-			if (!call) continue;
+			const bool fuse = GYS_MB_FUSE_OLD && !SCAN && k0 == 0u;
+			if (!call && !(fuse && has_old)) continue;
+			uint32_t a_old = 0;
 #pragma unroll
 			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1) {
-				uint32_t tq[MBG];
+				uint32_t tq[MBG], t_old = 0;
 #pragma unroll
 				for (uint32_t u = 0; u < MBG; ++u) tq[u] = s_T[aq[u] + step];
+				if (fuse) t_old = s_T[a_old + step];
 #pragma unroll
 				for (uint32_t u = 0; u < MBG; ++u)
 					if (mq[u] >= tq[u]) aq[u] += step;
+				if (fuse && mid2_old >= t_old) a_old += step;
 			}
 #pragma unroll
 			for (uint32_t u = 0; u < MBG; ++u) GYS_OPAQUE_VGPR(aq[u]); // (the searches stay in this block: sunk into the `while (rem)` bodies below they would run one after the other)
+			if (fuse) {
+				GYS_OPAQUE_VGPR(a_old);
+				if (has_old) {
+					atomicAdd(&s_osum[a_old], (unsigned long long)sm0);
+					atomicAdd(&s_ocnt[a_old], c0);
+				}
+			}
 #pragma unroll
 			for (uint32_t u = 0; u < MBG; ++u) {
 				uint32_t rem = cq[u], mid2 = mq[u], a = aq[u];
