@@ -1959,7 +1959,12 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		__syncthreads();
 		const uint32_t nbig = s_nbig;
 		// ---- old clusters: preceded by the old weight before them and by the values below their mean
-		if (c0 && !(GYS_MB_SKIP & 2)) {
+#ifndef GYS_MB_FUSE_OLD
+#define GYS_MB_FUSE_OLD 0 // 1: the old cluster's threshold search runs in lockstep with the searches of the thread's first group of bins
+#endif
+		uint32_t mid2_old = 0;
+		const bool has_old = c0 && !(GYS_MB_SKIP & 2);
+		if (has_old) {
 			uint32_t nb = s_bin[mb_bin(thr)] & 0xFFFFu;
 			if (thr >= GYS_MB_EXACT) {
 				const uint32_t sh = (31u - (uint32_t)__clz((int)thr)) - 6u;
@@ -1969,40 +1974,77 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 				}
 			}
 			const uint32_t mid2 = 2u * (e0 + nb) + c0;
+#if GYS_MB_FUSE_OLD
+			mid2_old = mid2; // (searched below, in lockstep with the thread's first group of bins)
+#else
 			uint32_t a = 0;
 #pragma unroll
 			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
 				if (mid2 >= s_T[a + step]) a += step;
 			atomicAdd(&s_osum[a], (unsigned long long)sm0);
 			atomicAdd(&s_ocnt[a], c0);
+#endif
 		}
 		// ---- values, pass 2, PER BIN: the c values of a one-value bin are equal, so they take the consecutive mid-points
 		// first, first + 2, ... and only the cluster boundaries that fall between them matter: one threshold search per NON-EMPTY BIN
 		// (integer-millisecond response times repeat: ~860 buffered values hold ~200 distinct ones) instead of one per value, and one
 		// packed add per (bin, output cluster).  Thread t takes bins t, t + 256, t + 512, t + 768: the busy low bins spread over all waves.
-#pragma unroll
-		for (uint32_t k = 0; k < GYS_MB_EXACT / 256u; ++k) {
-			const uint32_t b = tid + 256u * k;
-			const uint32_t bw = s_bin[b], c = (s_bin[b + 1u] & 0xFFFFu) - (bw & 0xFFFFu);
-			if (!c || (GYS_MB_SKIP & 1)) continue;
-			uint32_t mid2 = 2u * ((bw & 0xFFFFu) + s_cpfx[bw >> 16]) + 1u;
-			uint32_t a = 0;
-#pragma unroll
-			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
-				if (mid2 >= s_T[a + step]) a += step;
-			uint32_t rem = c;
-			while (rem) { // (nearly always one round: a cluster spans far more mid-points than a bin's values)
-				const uint32_t Tn = s_T[a + 1u]; // first mid-point of the next cluster (~0 after the last)
-				const uint32_t kk = min(rem, (Tn - mid2 + 1u) >> 1); // values with mid2 + 2 r < Tn
-#if GYS_MB_PACKED
-				atomicAdd(&s_oval[a], ((unsigned long long)kk << 40) | (unsigned long long)(kk * b));
-#else
-				atomicAdd(&s_osum[a], (unsigned long long)(kk * b));
-				atomicAdd(&s_ocnt[a], kk);
+#ifndef GYS_MB_GROUP
+#define GYS_MB_GROUP 2u // the thread's four bins searched GROUP at a time (1, 2 or 4): the 8 dependent LDS reads of one threshold search overlap the others'
 #endif
-				rem -= kk;
-				mid2 += 2u * kk;
-				++a;
+		constexpr uint32_t MBG = SCAN ? 1u : GYS_MB_GROUP; // (the scan form sits at 63 VGPRs: left as it was)
+#pragma unroll
+		for (uint32_t k0 = 0; k0 < GYS_MB_EXACT / 256u; k0 += MBG) {
+			uint32_t bq[MBG], cq[MBG], mq[MBG], aq[MBG], call = 0;
+#pragma unroll
+			for (uint32_t u = 0; u < MBG; ++u) {
+				bq[u] = tid + 256u * (k0 + u);
+				const uint32_t bw = s_bin[bq[u]];
+				cq[u] = (GYS_MB_SKIP & 1) ? 0u : (s_bin[bq[u] + 1u] & 0xFFFFu) - (bw & 0xFFFFu);
+				mq[u] = 2u * ((bw & 0xFFFFu) + s_cpfx[bw >> 16]) + 1u;
+				aq[u] = 0;
+				call |= cq[u];
+			}
+			const bool fuse = GYS_MB_FUSE_OLD && !SCAN && k0 == 0u;
+			if (!call && !(fuse && has_old)) continue;
+			uint32_t a_old = 0;
+#pragma unroll
+			for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1) {
+				uint32_t tq[MBG], t_old = 0;
+#pragma unroll
+				for (uint32_t u = 0; u < MBG; ++u) tq[u] = s_T[aq[u] + step];
+				if (fuse) t_old = s_T[a_old + step];
+#pragma unroll
+				for (uint32_t u = 0; u < MBG; ++u)
+					if (mq[u] >= tq[u]) aq[u] += step;
+				if (fuse && mid2_old >= t_old) a_old += step;
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < MBG; ++u) GYS_OPAQUE_VGPR(aq[u]); // (the searches stay in this block: sunk into the `while (rem)` bodies below they would run one after the other)
+			if (fuse) {
+				GYS_OPAQUE_VGPR(a_old);
+				if (has_old) {
+					atomicAdd(&s_osum[a_old], (unsigned long long)sm0);
+					atomicAdd(&s_ocnt[a_old], c0);
+				}
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < MBG; ++u) {
+				uint32_t rem = cq[u], mid2 = mq[u], a = aq[u];
+				const uint32_t b = bq[u];
+				while (rem) { // (nearly always one round: a cluster spans far more mid-points than a bin's values)
+					const uint32_t Tn = s_T[a + 1u]; // first mid-point of the next cluster (~0 after the last)
+					const uint32_t kk = min(rem, (Tn - mid2 + 1u) >> 1); // values with mid2 + 2 r < Tn
+#if GYS_MB_PACKED
+					atomicAdd(&s_oval[a], ((unsigned long long)kk << 40) | (unsigned long long)(kk * b));
+#else
+					atomicAdd(&s_osum[a], (unsigned long long)(kk * b));
+					atomicAdd(&s_ocnt[a], kk);
+#endif
+					rem -= kk;
+					mid2 += 2u * kk;
+					++a;
+				}
 			}
 		}
 		// the (few) large values, one per thread from the list: rank inside the cell by comparison with the other large values, gap by
