@@ -265,6 +265,83 @@ def pmc_traffic(kernel, events, nsvc):
             "same over the library's source files"}
 
 
+def scope_of_kernel(k):
+    """the profile scope (gys_engine.hip ProfScope) a compact kernel name of profiles/pmc_traffic.json belongs to -- tools/pmc_workload.py's rule"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_workload", os.path.join(ROOT, "tools", "pmc_workload.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.scope_of(k)
+
+
+def workload_traffic(name, scope, units_per_step):
+    """HBM bytes per STEP of the kernels of one profile scope in the sub-run `name`, from the committed counter passes of that sub-run
+    (profiles/pmc_traffic.json `workloads`, written by tools/pmc_workload.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    the same command).  None when the passes were taken on another workload size."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"][name]
+    except Exception:
+        return None
+    if t.get("units_per_step") not in (None, units_per_step):
+        return None
+    ks = {k: v for k, v in t.get("kernels", {}).items() if v.get("scope") == scope}
+    if not ks:
+        return None
+    fb = sum(v["fetch_bytes"] for v in ks.values())
+    wb = sum(v["write_bytes"] for v in ks.values())
+    return {"bytes": fb + wb, "fetch_bytes": fb, "write_bytes": wb, "kernels": sorted(ks), "per": "step", "source": "profiles/pmc_traffic.json workloads." + name,
+            "measured_in_this_run": False, "source_commit": t.get("source_commit"), "device_code": t.get("device_code"),
+            "same_kernels_as_this_run": _same_kernels(t)}
+
+
+SUB_CONFIGS = [  # (name, BASELINE.json config it stands for, bench.py arguments): the other configurations, run after the default line
+    ("c2_conn", "configs[1]: 1k hosts x 100 services, HLL distinct-flow + CMS on TCP_CONN_NOTIFY records",
+     ["--workload", "conn", "--steps", "40", "--warmup", "4"]),
+    ("c1", "configs[0] shape: 1 host x 100 services, 2^26 response events per window",
+     ["--hosts", "1", "--svcs", "100", "--events", str(1 << 26), "--steps", "20", "--warmup", "5", "--nbuf", "2"]),
+    ("c5_zipf", "configs[4] shape: 10^5 services, Zipf 1.1, one hipGraph-captured window close per 2^29-event batch",
+     ["--zipf-milli", "1100", "--hosts", "50", "--svcs", "2000", "--steps", "20", "--warmup", "5", "--nbuf", "2"]),
+]
+
+
+def run_sub_configs(names):
+    """The other BASELINE configurations as short sub-runs of this very script (`--sub <name>`: no CPU baseline, no host-fed leg, no
+    quantile scan), each in a process of its own after this run's engine has released the device; their lines are trimmed to the fields
+    a reader needs (rate, step time, roofline with the dominant kernel's HIP-event time and counter traffic, parity)."""
+    import subprocess
+    out = {}
+    for name, what, argv in SUB_CONFIGS:
+        if names and name not in names:
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--sub", name] + argv, capture_output=True, text=True, timeout=420)
+            line = None
+            for ln in reversed((r.stdout or "").strip().splitlines()):
+                if ln.startswith("{"):
+                    line = json.loads(ln)
+                    break
+            if line is None:
+                out[name] = {"error": ((r.stderr or "") + (r.stdout or "")).strip()[-400:], "rc": r.returncode}
+                continue
+            rf = line.get("roofline", {})
+            ent = {"stands_for": what, "command": "bench.py " + " ".join(argv), "value": line.get("value"), "unit": line.get("unit"),
+                   "ms_per_step": line.get("ms_per_step"), "steps": line.get("steps"), "workload": line.get("config", {}).get("workload"),
+                   "parity_ok": line.get("parity_ok"), "rc": r.returncode, "wall_s": round(time.perf_counter() - t0, 1),
+                   "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_step", "kernel", "kernel_avg_ms",
+                                                        "kernel_frac", "kernel_frac_measured_bytes", "traffic", "note") if k in rf}}
+            ent["roofline"]["kernels"] = {k: {kk: vv for kk, vv in v.items() if kk in ("ms", "launches_per_step", "frac", "achieved_GBps", "traffic")}
+                                          for k, v in rf.get("kernels", {}).items() if v.get("ms", 0) >= 0.01}
+            if "quantile_error" in line:
+                ent["quantile_error"] = {k: line["quantile_error"][k] for k in ("keys_checked", "p50_rank_err_max", "p99_rank_err_max")}
+            if "checks" in line:
+                ent["checks"] = line["checks"]
+            out[name] = ent
+        except Exception as ex:  # a sub-run never takes the default line down
+            out[name] = {"error": str(ex)[:300]}
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher around it: re-run this very command line under torch.distributed.run, one rank per
     GPU of this node (what the driver does itself for N > 1).  Returns the launcher's exit status."""
@@ -393,8 +470,10 @@ def selftest_launch(args, rank, world):
 
 def run_conn(args, rank, world):
     """--workload conn: BASELINE.json configs[1] -- 1 000 hosts x 100 services, per window 2^24 device-resident
-    TCP_CONN_NOTIFY records (280 B fixed stride; HLL distinct flows + 2 x Count-Min + exact per-service counters) and 10^5
-    LISTENER_STATE_NOTIFY records (88 B; per-host LISTEN_SUMM_STATS roll-up, top-N), then the window close."""
+    TCP_CONN_NOTIFY records (280 B fixed stride; HLL distinct flows + 2 x Count-Min + exact per-service connection counters) and 10^5
+    LISTENER_STATE_NOTIFY records (88 B; per-host LISTEN_SUMM_STATS roll-up, top-N), then the window close.  The records describe
+    connections with a life cycle (open + close notifications, accepting and connecting halves, loopback: wire.synth_tcp_conns); after the
+    timed region the per-service counters are checked against the generator's connection table (`checks`)."""
     import ctypes as C
     from gyeeta_amd import capi, wire
     from gyeeta_amd.engine import SketchEngine
@@ -407,10 +486,14 @@ def run_conn(args, rank, world):
         eng.register_host(mid, "cluster%d" % (h % 8))
         eng.register_listeners_np(mid, wire.glob_id(np.full(sp, h), s_), wire.listener_netns(h, s_), wire.listener_port(s_))
     rng = np.random.default_rng(1)
-    if args.conn_stream == "messages":  # as madhava receives them: messages of MAX_NUM_CONNS = 2048 records, each from ONE partha
-        rec = np.concatenate([wire.synth_tcp_conns(rng, 2048, [m % nh], sp, dup_frac=0.2) for m in range(chunk // 2048)])
-    else:                               # worst case for the per-workgroup aggregation: every record from a random host
-        rec = wire.synth_tcp_conns(rng, chunk, np.arange(nh), sp, dup_frac=0.2)
+    truth = {}
+    rec = wire.synth_tcp_conns(rng, chunk, np.arange(nh), sp, dup_frac=0.2, truth=truth)
+    if args.conn_stream == "messages":
+        # as madhava receives them: message after message, each from ONE partha (TCP_CONN_NOTIFY::MAX_NUM_CONNS = 2048 records per message):
+        # the records grouped by the listener's host (its address is 10.<host>), ~2 messages per host and chunk
+        host_of = rec["nat_ser"]["ip32_be"].astype("<u4").view(">u4").astype(np.int64) & 0xFFFFFF
+        rec = rec[np.argsort(host_of, kind="stable")]
+    # else: worst case for the per-workgroup aggregation: every record from a random host (the generator's own order)
     d = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.uint8).copy()).cuda()
     off = torch.arange(0, chunk * 280, 280, dtype=torch.int32, device="cuda")
     ls = np.concatenate([wire.synth_listener_states(rng, h, s_) for h in range(nh)])
@@ -436,21 +519,59 @@ def run_conn(args, rank, world):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = eng.profile_get()
+    eng.profile(False)
     step_s = dt / args.steps
     alg = 280 * nrec + 88 * len(ls)
     kms = {k: v[0] / args.steps for k, v in prof.items()}
+    name = args.sub or "c2_conn"
+    kernels = {}
+    for k, ms in kms.items():
+        ent = {"ms": ms, "launches_per_step": prof[k][1] / args.steps}
+        kb = {"conn": 280 * nrec, "lstate": 88 * len(ls)}.get(k)
+        if kb and ms > 0:
+            ent["algorithmic_bytes"] = kb
+            ent["achieved_GBps"] = kb / (ms * 1e-3) / 1e9
+            ent["frac"] = ent["achieved_GBps"] / HBM_PEAK_GBS
+        tr = workload_traffic(name, k, nrec) if args.conn_stream == "messages" else None
+        if tr is not None:
+            ent["traffic"] = tr
+        kernels[k] = ent
+    # parity inside the bench: every window ingested the same chunk nrec / chunk times -> per-service counters = (windows x repeats) x the
+    # generator's connection table, the walk tallies likewise
+    windows = args.warmup + args.steps
+    reps = windows * (nrec // chunk)
+    ctr = eng.export_svc_counters()
+    slot = truth["conn_host"].astype(np.int64) * sp + truth["conn_svc"]
+    want_conn = np.bincount(slot, minlength=nh * sp) * reps
+    want_close = np.bincount(slot[truth["conn_closed"]], minlength=nh * sp) * reps
+    c = eng.counters()
+    checks = {"connections_per_chunk": int(len(slot)), "records_per_chunk": chunk,
+              "svc_nconn_equals_connection_table": bool((ctr[:, 0].astype(np.int64) == want_conn).all()),
+              "svc_nclose_equals_connection_table": bool((ctr[:, 1].astype(np.int64) == want_close).all()),
+              "walk_tallies": {k: int(c[k]) for k in ("conn_events", "conn_new", "conn_closed", "conn_closed_no_notify", "conn_client_side")},
+              "tallies_consistent": bool(c["conn_events"] == c["conn_new"] + c["conn_closed"] == reps * chunk)}
+    parity_ok = bool(checks["svc_nconn_equals_connection_table"] and checks["svc_nclose_equals_connection_table"] and checks["tallies_consistent"])
+    conn_ent = kernels.get("conn", {})
+    tr = conn_ent.get("traffic")
     out = {"metric": "TCP_CONN_NOTIFY records/sec ingested into HLL + Count-Min (BASELINE config 2)", "value": nrec / step_s, "unit": "records/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+           "vs_baseline": None, "dtype": "int64", "data": "synthetic", "parity_ok": parity_ok, "checks": checks,
+           "device_code": _device_code(),
            "config": {"workload": "C2: %d hosts x %d services, %d TCP_CONN_NOTIFY (280 B) + %d LISTENER_STATE_NOTIFY (88 B) records per window, "
                                   "device resident, 1 window per step; record order: %s" % (nh, sp, nrec, len(ls),
-                                  "per-partha messages of 2048 records" if args.conn_stream == "messages" else "hosts mixed record by record")},
+                                  "per-partha messages" if args.conn_stream == "messages" else "hosts mixed record by record")},
            "roofline": {"bound": "hbm", "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_step": alg, "kernel": "conn", "kernel_avg_ms": kms.get("conn"), "traffic": None,
-                        "kernels": {k: {"ms": v} for k, v in kms.items()},
-                        "note": "280 B x records + 88 B x listener records per step / whole step; k_conn_ingest reads the records through LDS (round 3; reading alone runs at 5.7 TB/s) -- hashes, table probe and the per-workgroup aggregation make up the rest"}}
+                        "algorithmic_bytes_per_step": alg, "kernel": "conn", "kernel_avg_ms": kms.get("conn"), "kernel_frac": conn_ent.get("frac"),
+                        "kernel_frac_measured_bytes": (tr["bytes"] / (kms["conn"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr and kms.get("conn") else None,
+                        "traffic": tr, "kernels": kernels,
+                        "note": "frac = (280 B x records + 88 B x listener records) / WHOLE step (SURVEY 8d: whole struct lines are fetched); kernel_frac = 280 B x "
+                                "records / k_conn_ingest's HIP-event time; kernel_frac_measured_bytes = the same kernel's counter traffic (FETCH_SIZE x 2 + "
+                                "WRITE_SIZE per step) / its time: k_conn_ingest asks for bytes [64, 224) and [264, 280) of each record only"}}
     print(json.dumps(out), flush=True)
     eng.close()
+    if not parity_ok:
+        print("bench.py: connection counters differ from the generator's connection table", file=sys.stderr)
+        sys.exit(3)
 
 
 def main():
@@ -476,6 +597,9 @@ def main():
                     "library's RCCL entry points are served by tests/cpp/fakerccl (RCCL refuses two ranks on one device); exercises the whole N > 1 flow")
     ap.add_argument("--selftest-launch", action="store_true", help="no GPU: only the launch path and the cross-rank checksum exchange (gloo)")
     ap.add_argument("--selftest-corrupt-rank", type=int, default=-1, help="--selftest-launch: this rank reports a wrong checksum (the run must fail)")
+    ap.add_argument("--sub", default="", help="this run is the sub-run <name> of a default line (run_sub_configs): no CPU baseline, no host-fed leg, no quantile scan")
+    ap.add_argument("--configs", default="auto", help="sub-runs of the other BASELINE configurations appended to the default line under `configs`: "
+                    "'auto' = all of them when this is the default single-GPU workload, 'none', or a comma-separated list of c2_conn,c1,c5_zipf")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quantile-check", action="store_true", help="skip the (untimed) t-digest rank-error check after the run")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the (untimed) host-fed measurement: pinned H2D copy + ingest")
@@ -486,6 +610,9 @@ def main():
     ap.add_argument("--cpu-hosts", type=int, default=1000)
     args = ap.parse_args()
 
+    if args.sub:
+        args.no_cpu_baseline = args.no_host_fed = True
+        args.configs = "none"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher around us: become one (one rank per GPU of this node)
         sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -674,7 +801,7 @@ def main():
             ingested.append([args.events, 0x67796565746121 + 1000 * rank + b, args.zipf_milli, buf_uses[b]])
         qerr = quantile_error(eng, torch, ingested, nlocal, args.svcs, [mine[0], mine[-1]], [0, nlocal - 1], wire)
     scan = None
-    if rank == 0 and nsvc and not args.no_quantile_check:  # the per-key scan on the digests (a9): p25 / p95 / p99 of EVERY service, one pass
+    if rank == 0 and nsvc and not args.no_quantile_check and not args.sub:  # the per-key scan on the digests (a9): p25 / p95 / p99 of EVERY service, one pass
         eng.profile(True)
         eng.profile_reset()
         t0 = time.perf_counter()
@@ -710,7 +837,7 @@ def main():
                 ent["algorithmic_bytes"] = kalg[k]
                 ent["achieved_GBps"] = kalg[k] / (ms * 1e-3) / 1e9
                 ent["frac"] = ent["achieved_GBps"] / HBM_PEAK_GBS
-            tr = pmc_traffic(k, args.events, nsvc)
+            tr = workload_traffic(args.sub, k, args.events) if args.sub else pmc_traffic(k, args.events, nsvc)
             if tr is not None:
                 ent["traffic"] = tr
             kernels[k] = ent
@@ -778,6 +905,13 @@ def main():
     if rank == 0:
         if isinstance(out.get("host_fed"), dict) and out["host_fed"].get("l2_threads") == "deferred":
             out["host_fed"]["l2_threads"] = host_fed_l2_threads()  # its own context: after this engine has released the device
+        # the other BASELINE configurations (C2 connection records, C1 and C5 shapes) as short sub-runs, each in its own process: appended to
+        # the default single-GPU line only (a sub-run never changes `value`; its failure is reported inside `configs`)
+        default_shape = (world == 1 and args.hosts == 10000 and args.svcs == 1000 and args.events == (1 << 29) and not args.zipf_milli and not args.levels)
+        if args.configs != "none" and (default_shape or args.configs != "auto"):
+            bufs.clear()  # (this run's resident event batches: the sub-runs bring their own)
+            torch.cuda.empty_cache()
+            out["configs"] = run_sub_configs([] if args.configs in ("auto", "all") else args.configs.split(","))
         print(json.dumps(out), flush=True)
     bad = rank == 0 and out.get("parity_ok") is False
     xbad = xcheck is not None and not xcheck["ok"]

@@ -101,7 +101,8 @@ class Counters(C.Structure):
                                           "conn_unknown_service", "lstate_records", "lstate_missed", "lstate_errors", "lstate_deleted",
                                           "resp_batches_host_local", "resp_batches_general", "window_graph_launches", "resp_batches_host_split",
                                           "td_merges", "td_merge_values", "actconn_records", "actconn_remote_listen", "actconn_unknown_listener",
-                                          "stage_waits", "resp_calls_queued", "resp_submissions")]
+                                          "stage_waits", "resp_calls_queued", "resp_submissions", "conn_new", "conn_closed",
+                                          "conn_closed_no_notify", "conn_client_side")]
 
 
 assert C.sizeof(HistRec) == 256 and C.sizeof(TopnEntry) == 104 and C.sizeof(RespSeg) == 16 and C.sizeof(ListenerDayStats) == 48

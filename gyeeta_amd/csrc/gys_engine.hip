@@ -110,7 +110,8 @@ struct ArenaLayout {
 
 // u32_pair / i64_pair: Count-Min pair of the ACTIVE_CONN_STATS roll-up; u32_misc[0]: its local-listener rows of the window;
 // u32_cpair / i64_cpair: the TCP_CONN_NOTIFY pair roll-up, present only with gys_config.conn_pair_cms (its own tables: the two feeds
-// count different things -- a gauge of active connections vs. one per connection notification -- and must not share cells)
+// count different things -- a gauge of active connections vs. closed connections -- and must not share cells): two table pairs, the
+// listener side (connlistenmap_: records of the accepting partha) and behind it the client side (connclientmap_: connect-only records)
 ArenaLayout arena_layout(uint32_t max_clusters, bool conn_pair)
 {
 	ArenaLayout a;
@@ -121,13 +122,13 @@ ArenaLayout arena_layout(uint32_t max_clusters, bool conn_pair)
 	a.u32_pair = a.u32_cluster + align_up((uint64_t)max_clusters * 12, 64); // Count-Min pair of the (listener, client task) roll-up
 	a.u32_misc = a.u32_pair + (uint64_t)GYS_CMS_D * GYS_CMS_W;
 	a.u32_cpair = a.u32_misc + 64;
-	a.n_u32 = a.u32_cpair + (conn_pair ? (uint64_t)GYS_CMS_D * GYS_CMS_W : 0);
+	a.n_u32 = a.u32_cpair + (conn_pair ? (uint64_t)2 * GYS_CMS_D * GYS_CMS_W : 0); // listener-side tables, then client-side tables
 	a.off_i64sum = align_up(a.off_u32 + a.n_u32 * 4, 256);
 	a.i64_cms = 0;
 	a.i64_ghist = (uint64_t)GYS_CMS_D * GYS_CMS_W;
 	a.i64_pair = a.i64_ghist + 32;
 	a.i64_cpair = a.i64_pair + (uint64_t)GYS_CMS_D * GYS_CMS_W;
-	a.n_i64sum = a.i64_cpair + (conn_pair ? (uint64_t)GYS_CMS_D * GYS_CMS_W : 0);
+	a.n_i64sum = a.i64_cpair + (conn_pair ? (uint64_t)2 * GYS_CMS_D * GYS_CMS_W : 0);
 	a.off_i64max = align_up(a.off_i64sum + a.n_i64sum * 8, 256);
 	a.n_i64max = 8;
 	a.total = align_up(a.off_i64max + a.n_i64max * 8, 256);
@@ -244,8 +245,10 @@ struct gys_ctx {
 	bool own_arena = false;
 	ArenaLayout al{};
 	uint8_t *last = nullptr; // copy of the reduced arena of the last finished window (queries read this)
-	uint32_t *last_act32 = nullptr;           // ACTIVE_CONN_STATS Count-Min pair of the last window that carried such rows
-	unsigned long long *last_act64 = nullptr; // (a partha reports every 15 s, a window is 5 s)
+	uint32_t *last_act32 = nullptr;           // ACTIVE_CONN_STATS Count-Min pair the queries read: per-cell maximum over the tables of the
+	unsigned long long *last_act64 = nullptr; // last GYS_ACT_RING windows (a partha reports every 15 s, a window is 5 s; k_act_latch)
+	uint32_t *ring_act32 = nullptr, *act_live = nullptr;
+	unsigned long long *ring_act64 = nullptr;
 	uint32_t epoch = 1;      // current window number (0 = never)
 	bool prepared = false;
 	uint32_t *d_epoch = nullptr; // device copy of `epoch` for the captured window graph
@@ -731,6 +734,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		HIPCHK(hipMalloc((void **)&slot.dev, (uint64_t)slot.cap * sizeof(gys_resp_seg)));
 	}
 	memcpy(slot.host, segs_host, (uint64_t)nsegs * sizeof(gys_resp_seg));
+	// `reserved` is the engine's own part-descriptor index (descriptor + 1, written only into the engine-built segment lists below): whatever
+	// the caller left in the field must never reach k_resp_host's hdesc[] lookup
+	for (uint32_t s = 0; s < nsegs; ++s) ((gys_resp_seg *)slot.host)[s].reserved = 0;
 	HIPCHK(hipMemcpyAsync(slot.dev, slot.host, (uint64_t)nsegs * sizeof(gys_resp_seg), hipMemcpyHostToDevice, c->stream));
 	const gys_resp_seg *segs_dev = slot.dev;
 
@@ -1267,6 +1273,8 @@ int run_conn(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, uint
 	if (c->cfg.conn_pair_cms) {
 		p.pair32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cpair;
 		p.pair64 = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_cpair;
+		p.cpair32 = p.pair32 + (uint64_t)GYS_CMS_D * GYS_CMS_W;
+		p.cpair64 = p.pair64 + (uint64_t)GYS_CMS_D * GYS_CMS_W;
 	}
 	c->conn_dirty = true;
 	p.counters = c->counters;
@@ -1416,7 +1424,15 @@ constexpr size_t GYS_RQ_INFLIGHT = 2; // submissions executing / queued on the G
 void rq_reap(gys_ctx *c)
 {
 	gys_ctx::RespQ &q = c->rq;
-	while (!q.inflight.empty() && hipEventQuery(q.b[q.inflight.front()].done) == hipSuccess) {
+	// anything but "not ready" ends a submission's stay on the in-flight list: an event in an error state never turns into hipSuccess, and
+	// a head that is never reaped would leave every later caller waiting once the free list has drained
+	while (!q.inflight.empty()) {
+		const hipError_t e = hipEventQuery(q.b[q.inflight.front()].done);
+		if (e == hipErrorNotReady) break;
+		if (e != hipSuccess && !q.async_rc) {
+			q.async_rc = GYS_ERR_HIP;
+			q.async_err = std::string("response submission: ") + hipGetErrorString(e);
+		}
 		q.free.push_back(q.inflight.front());
 		q.inflight.pop_front();
 	}
@@ -1519,12 +1535,21 @@ int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
 			gys_ctx::RespBatch &nb = q.b[bi];
 			lk.unlock(); // (first-use allocation: outside the lock; the batch is not visible yet)
 			hipError_t e = hipSuccess;
-			if (!nb.h) {
+			if (!nb.h || !nb.d || !nb.done || !nb.copied) {
 				nb.cap_events = std::min<uint64_t>(GYS_RQ_EVENTS, std::max<uint64_t>(c->cfg.max_batch_events, 1));
-				e = hipHostMalloc((void **)&nb.h, nb.cap_events * 24, hipHostMallocDefault);
-				if (e == hipSuccess) e = hipMalloc((void **)&nb.d, nb.cap_events * 24);
-				if (e == hipSuccess) e = hipEventCreateWithFlags(&nb.done, hipEventDisableTiming);
-				if (e == hipSuccess) e = hipEventCreateWithFlags(&nb.copied, hipEventDisableTiming);
+				if (!nb.h) e = hipHostMalloc((void **)&nb.h, nb.cap_events * 24, hipHostMallocDefault);
+				if (e == hipSuccess && !nb.d) e = hipMalloc((void **)&nb.d, nb.cap_events * 24);
+				if (e == hipSuccess && !nb.done) e = hipEventCreateWithFlags(&nb.done, hipEventDisableTiming);
+				if (e == hipSuccess && !nb.copied) e = hipEventCreateWithFlags(&nb.copied, hipEventDisableTiming);
+				if (e != hipSuccess) { // all four or none: a half-built batch must not look usable to the next caller
+					if (nb.h) (void)hipHostFree(nb.h);
+					if (nb.d) (void)hipFree(nb.d);
+					if (nb.done) (void)hipEventDestroy(nb.done);
+					if (nb.copied) (void)hipEventDestroy(nb.copied);
+					nb.h = nullptr;
+					nb.d = nullptr;
+					nb.done = nb.copied = nullptr;
+				}
 			}
 			lk.lock();
 			if (e != hipSuccess) {
@@ -1683,7 +1708,7 @@ try {
 	ALLOC(c->host_state, H);
 	ALLOC(c->host_state_epoch, H);
 	ALLOC(c->host_cluster, H);
-	ALLOC(c->counters, 16);
+	ALLOC(c->counters, 32);
 	ALLOC(c->d_epoch, 4);
 	ALLOC(c->misc, 16);
 	ALLOC(c->svc_act, S * 4);
@@ -1784,6 +1809,9 @@ try {
 	}
 	ALLOC(c->last_act32, (uint64_t)GYS_CMS_D * GYS_CMS_W);
 	ALLOC(c->last_act64, (uint64_t)GYS_CMS_D * GYS_CMS_W);
+	ALLOC(c->ring_act32, (uint64_t)GYS_ACT_RING * GYS_CMS_D * GYS_CMS_W);
+	ALLOC(c->ring_act64, (uint64_t)GYS_ACT_RING * GYS_CMS_D * GYS_CMS_W);
+	ALLOC(c->act_live, 2);
 #undef ALLOC
 	// dev_alloc zeroes with hipMemset on the NULL stream, which may still be in flight; the context stream is non-blocking, so the
 	// initialisation kernels / copies below must not start before every one of those clears has landed
@@ -1861,7 +1889,7 @@ void gys_destroy(gys_ctx *c)
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_claim, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
-			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
+			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->ring_act32, c->ring_act64, c->act_live, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_first, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -2419,10 +2447,10 @@ try {
 static hipError_t enqueue_finish(gys_ctx *c, hipStream_t st)
 {
 	hipError_t e;
-	// ACTIVE_CONN_STATS tables: latched only by a window that carried rows (k_act_latch)
-	hipLaunchKernelGGL(k_act_latch, dim3(64), dim3(256), 0, st, (const uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_misc,
+	// ACTIVE_CONN_STATS tables: the window's tables enter a ring of the last three windows, the queries read the per-cell maximum (k_act_latch)
+	hipLaunchKernelGGL(k_act_latch, dim3(64), dim3(256), 0, st, (const uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_misc, c->d_epoch, c->act_live,
 			   (const uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_pair,
-			   (const unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_pair, c->last_act32, c->last_act64);
+			   (const unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_pair, c->ring_act32, c->ring_act64, c->last_act32, c->last_act64);
 	if ((e = hipMemcpyAsync(c->last, c->arena, c->al.total, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(c->arena, 0, c->al.total, st)) != hipSuccess) return e;
 	if ((e = hipMemcpyAsync(c->arena + c->al.off_i64max, &c->i64min, 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
@@ -2852,12 +2880,12 @@ try {
 	return GYS_OK;
 } GYS_CATCH_ALL
 
-// Count-Min estimate for a (listener, client task group) pair.  which 0 / 1: active connections / bytes of the LAST ACTIVE_CONN_STATS
-// REPORT (the tables of the last window that carried such rows); which 2 / 3: connection notifications / bytes of the TCP_CONN_NOTIFY
-// roll-up in the last finished window (gys_config.conn_pair_cms).
+// Count-Min estimate for a (listener, client task group) pair.  which 0 / 1: active connections / bytes of the ACTIVE_CONN_STATS reports of
+// the last three windows (per-cell maximum, k_act_latch); which 2 / 3 and 4 / 5: closed connections / bytes of the TCP_CONN_NOTIFY roll-up
+// in the last finished window, listener side (connlistenmap_) and client side (connclientmap_) (gys_config.conn_pair_cms).
 static int pair_tables(gys_ctx *c, int which, const void **tbl)
 {
-	if (which < 0 || which > 3) return GYS_ERR_INVAL;
+	if (which < 0 || which > 5) return GYS_ERR_INVAL;
 	if (which >= 2 && !c->cfg.conn_pair_cms) {
 		set_err("gys_config.conn_pair_cms is off");
 		return GYS_ERR_STATE;
@@ -2866,7 +2894,9 @@ static int pair_tables(gys_ctx *c, int which, const void **tbl)
 	case 0: *tbl = c->last_act32; break;
 	case 1: *tbl = c->last_act64; break;
 	case 2: *tbl = (const uint32_t *)(c->last + c->al.off_u32) + c->al.u32_cpair; break;
-	default: *tbl = (const uint64_t *)(c->last + c->al.off_i64sum) + c->al.i64_cpair; break;
+	case 3: *tbl = (const uint64_t *)(c->last + c->al.off_i64sum) + c->al.i64_cpair; break;
+	case 4: *tbl = (const uint32_t *)(c->last + c->al.off_u32) + c->al.u32_cpair + (uint64_t)GYS_CMS_D * GYS_CMS_W; break;
+	default: *tbl = (const uint64_t *)(c->last + c->al.off_i64sum) + c->al.i64_cpair + (uint64_t)GYS_CMS_D * GYS_CMS_W; break;
 	}
 	return GYS_OK;
 }
@@ -3542,7 +3572,8 @@ int gys_get_counters(gys_ctx *c, gys_counters *out)
 try {
 	GYS_ENTER(c);
 	if (!c || !out) return GYS_ERR_INVAL;
-	uint64_t v[16];
+	uint64_t v[32];
+	static_assert(CTR_NUM <= 31, "counter block (the last word is the sink of k_read_events)");
 	HIPCHK(hipMemcpyAsync(v, c->counters, sizeof(v), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	out->resp_events = v[CTR_RESP_EVENTS];
@@ -3550,6 +3581,10 @@ try {
 	out->resp_dropped_nolistener = v[CTR_RESP_DROP_NOLISTENER];
 	out->conn_events = v[CTR_CONN_EVENTS];
 	out->conn_unknown_service = v[CTR_CONN_UNKNOWN];
+	out->conn_new = v[CTR_CONN_NEW];
+	out->conn_closed = v[CTR_CONN_CLOSED];
+	out->conn_closed_no_notify = v[CTR_CONN_CLOSED_NO_NOTIFY];
+	out->conn_client_side = v[CTR_CONN_CLI_SIDE];
 	out->lstate_records = v[CTR_LSTATE_RECORDS];
 	out->lstate_missed = v[CTR_LSTATE_MISSED];
 	out->lstate_errors = v[CTR_LSTATE_ERRORS];
@@ -3858,7 +3893,7 @@ try {
 	if (!nevents) return GYS_OK;
 	const uint64_t per_wg = 53248; // ~ a C3 host segment (13 tiles of 4096)
 	hipLaunchKernelGGL(k_read_events, dim3((uint32_t)((nevents + per_wg - 1) / per_wg)), dim3(1024), 0, c->stream, (const uint64_t *)d_ev24, nevents, per_wg,
-			   (uint64_t *)c->counters + 15);
+			   (uint64_t *)c->counters + 31);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
 } GYS_CATCH_ALL

@@ -25,7 +25,8 @@ namespace gys {
 #define GYS_STAGED_WORD(tresp, cli_port) ((uint64_t)(((uint32_t)(tresp) << GYS_ROW_BITS) | ((uint32_t)(cli_port) & 0x1Fu)))
 
 enum { CTR_RESP_EVENTS = 0, CTR_RESP_DROP_RANGE, CTR_RESP_DROP_NOLISTENER, CTR_CONN_EVENTS, CTR_CONN_UNKNOWN, CTR_LSTATE_RECORDS,
-       CTR_LSTATE_MISSED, CTR_LSTATE_ERRORS, CTR_LSTATE_DELETED, CTR_TD_MERGES, CTR_TD_MERGE_VALUES, CTR_ACTCONN_RECORDS, CTR_ACTCONN_REMOTE_LISTEN, CTR_ACTCONN_UNKNOWN, CTR_NUM };
+       CTR_LSTATE_MISSED, CTR_LSTATE_ERRORS, CTR_LSTATE_DELETED, CTR_TD_MERGES, CTR_TD_MERGE_VALUES, CTR_ACTCONN_RECORDS, CTR_ACTCONN_REMOTE_LISTEN, CTR_ACTCONN_UNKNOWN,
+       CTR_CONN_NEW, CTR_CONN_CLOSED, CTR_CONN_CLOSED_NO_NOTIFY, CTR_CONN_CLI_SIDE, CTR_NUM };
 
 // ---------------------------------------------------------------------------------------------------- table insert
 __global__ void k_table_insert(DevTable t, const uint64_t *keys, uint32_t first_val, uint32_t n, uint32_t *nfail)
@@ -2402,7 +2403,25 @@ __device__ __forceinline__ void wave_count(uint64_t *ctr, bool pred)
 // still update the Count-Min tables directly.
 // comm::TCP_CONN_NOTIFY (common/gy_comm_proto.h:1665-1742), 280 fixed bytes:
 //   IP_PORT cli_@0 ser_@32 nat_cli_@64 nat_ser_@96 (each: ip128 @0, ip32 @16, aftype @20, flags @22, port @24)
-//   tusec_start_@128 tusec_close_@136 ... ser_glob_id_@192 ... bytes_sent_@208 bytes_rcvd_@216 ... cli_cmdline_len_@272 flags@274.. padding_len_@279
+//   tusec_start_@128 tusec_close_@136 cli_task_aggr_id_@144 ... ser_glob_id_@192 ... bytes_sent_@208 bytes_rcvd_@216 ... cli_cmdline_len_@272
+//   is_tcp_connect_event_@274 is_tcp_accept_event_@275 is_loopback_conn_@276 is_pre_existing_@277 notified_before_@278 padding_len_@279
+//
+// A CONNECTION IS COUNTED ONCE (round 4; server/gy_mconnhdlr.cc:9129-9181).  A partha reports a connection when it opens (tusec_close_ = 0:
+// the walk's `nnew`) and again when it closes with notified_before_ set, or -- a short-lived one -- only at its close with notified_before_
+// clear (`nclosed_no_not`); the connecting and the accepting partha each report their own half (is_tcp_connect_event_ /
+// is_tcp_accept_event_; both flags on one record = a loopback connection, reported once, :A.3).  So:
+//   * the walk's own tallies: conn_new (+1 per open record), conn_closed (+1 per record with tusec_close_), conn_closed_no_notify;
+//   * a record is LISTENER SIDE when is_tcp_accept_event_ is set (a loopback record included) or when neither flag is (the walk hands a
+//     record that is not a connect event to add_tcp_conn_ser, :9333); it is CLIENT SIDE when only is_tcp_connect_event_ is set;
+//   * per-service counters / window accumulators / the service Count-Min rows take LISTENER-SIDE records only: nconn += !notified_before_
+//     (every connection exactly once: at its open record, or at the only record a short-lived one has), nclose += (tusec_close_ != 0), bytes
+//     as reported (zero on an open record); the client half of the same connection names the same ser_glob_id_ once the pairing has
+//     resolved it and would count the connection a second time -- it only moves conn_client_side;
+//   * the pair Count-Min (gys_config.conn_pair_cms) follows connlistenmap_ / connclientmap_ (:9226-9319): a CLOSED record with bytes adds
+//     one connection + its bytes to the listener-side tables when ser_glob_id_ != 0 and is_tcp_accept_event_, to the client-side tables when
+//     it is connect-only and cli_task_aggr_id_ != 0 (the reference's `connpeer` gate -- a brand-new connection the join table has not
+//     resolved yet -- belongs to the flow join, which the sketches replace: DESIGN section 7);
+//   * the distinct-flow HyperLogLog takes every record (it is idempotent: both halves and both notifications hash to the same flow key).
 struct ConnP {
 	const uint8_t *batch;
 	const uint32_t *offsets;
@@ -2413,8 +2432,10 @@ struct ConnP {
 	unsigned long long *cms64;
 	unsigned long long *svc_win; // [nsvc*3] window accumulators: nconn | nclose << 32, bytes_sent, bytes_rcvd
 	uint64_t *counters;
-	uint32_t *pair32;            // gys_config.conn_pair_cms: Count-Min pair keyed by (ser_glob_id_, cli_task_aggr_id_), else nullptr
+	uint32_t *pair32;            // gys_config.conn_pair_cms: Count-Min pair keyed by (ser_glob_id_, cli_task_aggr_id_), else nullptr: listener side ...
 	unsigned long long *pair64;
+	uint32_t *cpair32;           // ... and client side
+	unsigned long long *cpair64;
 };
 
 #define GYS_CONN_THREADS 512u
@@ -2423,7 +2444,7 @@ struct ConnP {
 #ifndef GYS_CONN_SKIP
 #define GYS_CONN_SKIP 0 // TIMING EXPERIMENTS ONLY (results are wrong): 1 no flow hash / HLL, 2 nothing after the HLL, 4 no LDS aggregation, 8 loads only, 16 hash but no register access
 #endif
-// the words of a record the roll-up needs (the record's bytes [64, 224) staged in LDS: offsets below are relative to byte 64)
+// the words of a record the roll-up needs (the record's bytes [64, 224) and [264, 280) staged in LDS)
 struct ConnRec {
 	uint64_t a0, a1, a2, a3; // nat_cli_ @64: ip128 (16 B), ip32 @16, port @24
 	uint64_t b0, b1, b2, b3; // nat_ser_ @96
@@ -2431,9 +2452,23 @@ struct ConnRec {
 	uint64_t task;           // @144 cli_task_aggr_id_
 	uint64_t ser_glob_id;    // @192
 	uint64_t bytes_sent, bytes_rcvd; // @208, @216
+	uint64_t flags;          // @272: cli_cmdline_len_ (2 bytes), the five bool bytes @274..278, padding_len_
 };
+// the flag bytes inside ConnRec::flags (byte k of the word = record byte 272 + k)
+#define GYS_CONN_F_CONNECT(w) (((w) >> 16) & 0xFFull)
+#define GYS_CONN_F_ACCEPT(w) (((w) >> 24) & 0xFFull)
+#define GYS_CONN_F_NOTIFIED(w) (((w) >> 48) & 0xFFull)
 
-__device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, uint32_t *s_key, unsigned long long (*s_acc)[3])
+// per-workgroup tallies of the walk (LDS), flushed with one device atomic each by k_conn_ingest
+enum { CONN_T_NEW = 0, CONN_T_CLOSED, CONN_T_CLOSED_NO_NOTIFY, CONN_T_CLI_SIDE, CONN_T_UNKNOWN, CONN_T_NUM };
+
+__device__ __forceinline__ void conn_tally(uint32_t *s_tally, int which, bool pred)
+{
+	const unsigned long long b = __ballot(pred);
+	if (b && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)b) - 1)) atomicAdd(&s_tally[which], (uint32_t)__popcll(b));
+}
+
+__device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool live, uint32_t *s_key, unsigned long long (*s_acc)[3], uint32_t *s_tally)
 {
 	uint32_t c128[4], s128[4], c32, s32;
 	uint16_t cport, sport;
@@ -2445,6 +2480,16 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, uint
 	s32 = (uint32_t)rc.b2;
 	sport = (uint16_t)rc.b3;
 	const uint64_t tusec_close = rc.tusec_close, ser_glob_id = rc.ser_glob_id, bytes_sent = rc.bytes_sent, bytes_rcvd = rc.bytes_rcvd;
+	const bool closed = tusec_close != 0, fresh = GYS_CONN_F_NOTIFIED(rc.flags) == 0, accept = GYS_CONN_F_ACCEPT(rc.flags) != 0,
+		   connect = GYS_CONN_F_CONNECT(rc.flags) != 0;
+	const bool listener_side = accept || !connect;
+
+	// (wave-uniform control flow up to here: the tallies are ballots over the whole wave, `live` = the lane holds a record)
+	conn_tally(s_tally, CONN_T_NEW, live && !closed);                  // nnew :9327
+	conn_tally(s_tally, CONN_T_CLOSED, live && closed);                // nclosed :9133
+	conn_tally(s_tally, CONN_T_CLOSED_NO_NOTIFY, live && closed && fresh); // nclosed_no_not :9135-9137
+	conn_tally(s_tally, CONN_T_CLI_SIDE, live && !listener_side);
+	if (!live) return;
 
 	if (GYS_CONN_SKIP & 8) { // (timing experiments only: the record's words are read, nothing else)
 		if ((c128[0] ^ c128[3] ^ s128[1] ^ c32 ^ s32 ^ cport ^ sport ^ (uint32_t)tusec_close ^ (uint32_t)ser_glob_id ^ (uint32_t)bytes_sent ^ (uint32_t)bytes_rcvd) == 0xDEADBEEFu)
@@ -2463,24 +2508,36 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, uint
 	}
 	if (GYS_CONN_SKIP & 2) return;
 
-	if (p.pair32) { // per-(listener, client task group) roll-up (connlistenmap_ / connclientmap_, server/gy_msocket.h:240-290)
+	if (p.pair32 && closed && (bytes_sent + bytes_rcvd) != 0) { // connlistenmap_ / connclientmap_ :9226-9319 (server/gy_msocket.h:240-290)
 		const uint64_t task = rc.task;
+		uint32_t *t32 = nullptr;
+		unsigned long long *t64 = nullptr;
+		if (ser_glob_id && accept) {
+			t32 = p.pair32;
+			t64 = p.pair64;
+		} else if (!accept && connect && task) {
+			t32 = p.cpair32;
+			t64 = p.cpair64;
+		}
+		if (t32) {
 #pragma unroll
-		for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
-			const uint32_t col = jhash2_4w((uint32_t)ser_glob_id, (uint32_t)(ser_glob_id >> 32), (uint32_t)task, (uint32_t)(task >> 32), GYS_SEED + r) &
-					     (GYS_CMS_W - 1);
-			atomicAdd(&p.pair32[r * GYS_CMS_W + col], 1u);
-			if (bytes_sent + bytes_rcvd) atomicAdd(&p.pair64[r * GYS_CMS_W + col], (unsigned long long)(bytes_sent + bytes_rcvd));
+			for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
+				const uint32_t col = jhash2_4w((uint32_t)ser_glob_id, (uint32_t)(ser_glob_id >> 32), (uint32_t)task, (uint32_t)(task >> 32), GYS_SEED + r) &
+						     (GYS_CMS_W - 1);
+				atomicAdd(&t32[r * GYS_CMS_W + col], 1u);
+				atomicAdd(&t64[r * GYS_CMS_W + col], (unsigned long long)(bytes_sent + bytes_rcvd));
+			}
 		}
 	}
+	if (!listener_side) return; // the client half: the accepting partha's record carries the connection into the service's counters
 	const uint32_t slot = tbl_lookup(p.gid, ser_glob_id);
 	if (slot == GYS_NOSLOT) {
-		atomicAdd((unsigned long long *)&p.counters[CTR_CONN_UNKNOWN], 1ull);
+		atomicAdd(&s_tally[CONN_T_UNKNOWN], 1u);
 #pragma unroll
 		for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
 			const uint32_t col = jhash2_u64(ser_glob_id, GYS_SEED + r) & (GYS_CMS_W - 1);
-			atomicAdd(&p.cms32[r * GYS_CMS_W + col], 1u);
-			atomicAdd(&p.cms64[r * GYS_CMS_W + col], (unsigned long long)(bytes_sent + bytes_rcvd));
+			if (fresh) atomicAdd(&p.cms32[r * GYS_CMS_W + col], 1u);
+			if (bytes_sent + bytes_rcvd) atomicAdd(&p.cms64[r * GYS_CMS_W + col], (unsigned long long)(bytes_sent + bytes_rcvd));
 		}
 		return;
 	}
@@ -2488,6 +2545,8 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, uint
 		if (slot == 0xDEADBEEFu) p.counters[CTR_CONN_UNKNOWN] = 1;
 		return;
 	}
+	const unsigned long long cnt = (fresh ? 1ull : 0ull) + (closed ? (1ull << 32) : 0ull);
+	if (!(cnt | bytes_sent | bytes_rcvd)) return; // (an open record repeated with notified_before_: nothing to add)
 	// the workgroup's LDS entry of the service (open addressing; 2048 entries for at most 1024 records: always room)
 	uint32_t h = (slot * 0x9E3779B1u) >> 21; // top 11 bits
 	for (;;) {
@@ -2495,7 +2554,7 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, uint
 		if (prev == GYS_NOSLOT || prev == slot) break;
 		h = (h + 1u) & (GYS_CONN_AGG - 1u);
 	}
-	atomicAdd(&s_acc[h][0], 1ull + (tusec_close ? (1ull << 32) : 0ull)); // a window's connection count of one service stays far below 2^32
+	if (cnt) atomicAdd(&s_acc[h][0], cnt); // a window's connection count of one service stays far below 2^32
 	if (bytes_sent) atomicAdd(&s_acc[h][1], (unsigned long long)bytes_sent);
 	if (bytes_rcvd) atomicAdd(&s_acc[h][2], (unsigned long long)bytes_rcvd);
 }
@@ -2504,12 +2563,14 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, uint
 // stride: every load instruction of a wave touched 64 different lines, each line was asked for by up to seven instructions in a row while
 // still in flight, and reading alone took 3.3 of the kernel's 3.4 ms (r3v: 1.4 TB/s).  Now a wave reads the bytes [64, 224) of its 64
 // records as 640 sixteen-byte pieces -- lane l of load t takes piece 64 t + l, i.e. ten neighbouring lanes cover one record's 160 bytes
-// and a load instruction covers ~6.4 records -- through each record's own offset (no assumption that records are contiguous or of equal
-// size), parks them in its private LDS region at a 168-byte record stride (8-byte accesses at that stride spread over all banks), and
-// every lane then reads its record's thirteen words from LDS.  A workgroup is 512 threads and walks TWO rounds of 512 records, so that
+// and a load instruction covers ~6.4 records -- plus (round 4) the 16 bytes [264, 280) that hold the flag bytes as an eleventh piece per
+// record (704 pieces, eleven neighbouring lanes per record), through each record's own offset (no assumption that records are contiguous
+// or of equal size), parks them in its private LDS region at a 184-byte record stride (8-byte accesses at that stride spread over all
+// banks), and every lane then reads its record's fourteen words from LDS.  A workgroup is 512 threads and walks TWO rounds of 512 records, so that
 // the LDS aggregation of the service accumulators still spans 1024 consecutive records (a partha's message is 2048 records of few services).
-#define GYS_CONN_STAGE_STRIDE 168u // bytes per staged record (160 used)
+#define GYS_CONN_STAGE_STRIDE 184u // bytes per staged record (176 used: bytes [64, 224) at 0, bytes [264, 280) at 160)
 #define GYS_CONN_ROUNDS (GYS_CONN_RECS / GYS_CONN_THREADS)
+#define GYS_CONN_PIECES 11u
 __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 {
 	// Records reach madhava message by message, a message = up to 2048 connections of ONE partha (comm::TCP_CONN_NOTIFY::MAX_NUM_CONNS,
@@ -2518,6 +2579,7 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 	// flushed with one set of device atomics per DISTINCT service of the workgroup.
 	__shared__ uint32_t s_key[GYS_CONN_AGG];
 	__shared__ unsigned long long s_acc[GYS_CONN_AGG][3];
+	__shared__ uint32_t s_tally[CONN_T_NUM];
 	__shared__ __align__(16) uint8_t s_stage[GYS_CONN_THREADS / 64u][64u * GYS_CONN_STAGE_STRIDE];
 	for (uint32_t k = threadIdx.x; k < GYS_CONN_AGG; k += GYS_CONN_THREADS) {
 		s_key[k] = GYS_NOSLOT;
@@ -2525,6 +2587,7 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 		s_acc[k][1] = 0;
 		s_acc[k][2] = 0;
 	}
+	if (threadIdx.x < CONN_T_NUM) s_tally[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint8_t *const st = s_stage[wave];
@@ -2535,28 +2598,28 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 		const uint32_t i = i0 + lane;
 		const uint32_t nrec = min(64u, p.n - i0);
 		const uint32_t off = p.offsets[i < p.n ? i : p.n - 1u];
-		// ---- 640 pieces of 16 bytes: piece q = 10 r + j is bytes [64 + 16 j, 80 + 16 j) of the wave's record r
-		uint4 pc[10];
+		// ---- 704 pieces of 16 bytes: piece q = 11 r + j is bytes [64 + 16 j, 80 + 16 j) of the wave's record r for j < 10, its bytes [264, 280) for j = 10
+		uint4 pc[GYS_CONN_PIECES];
 #pragma unroll
-		for (uint32_t t = 0; t < 10u; ++t) {
+		for (uint32_t t = 0; t < GYS_CONN_PIECES; ++t) {
 			const uint32_t q = t * 64u + lane;
-			const uint32_t r = (q * 6554u) >> 16; // q / 10 for q < 640
-			const uint32_t j = q - r * 10u;
+			const uint32_t r = (q * 5958u) >> 16; // q / 11 for q < 704
+			const uint32_t j = q - r * GYS_CONN_PIECES;
 			const uint32_t ro = (uint32_t)__shfl((int)off, (int)min(r, nrec - 1u), 64); // (a piece past the wave's last record re-reads that record)
-			const uint32_t *src = (const uint32_t *)(p.batch + ro + 64u + 16u * j); // records start 8-byte aligned (COMM_HEADER::validate common/gy_comm_proto.cc:23-26)
+			const uint32_t *src = (const uint32_t *)(p.batch + ro + (j < 10u ? 64u + 16u * j : 264u)); // records start 8-byte aligned (COMM_HEADER::validate common/gy_comm_proto.cc:23-26)
 			pc[t] = make_uint4(src[0], src[1], src[2], src[3]);
 		}
 #pragma unroll
-		for (uint32_t t = 0; t < 10u; ++t) {
+		for (uint32_t t = 0; t < GYS_CONN_PIECES; ++t) {
 			const uint32_t q = t * 64u + lane;
-			const uint32_t r = (q * 6554u) >> 16;
-			const uint32_t j = q - r * 10u;
+			const uint32_t r = (q * 5958u) >> 16;
+			const uint32_t j = q - r * GYS_CONN_PIECES;
 			uint64_t *dst = (uint64_t *)(st + r * GYS_CONN_STAGE_STRIDE + 16u * j);
 			dst[0] = (uint64_t)pc[t].x | ((uint64_t)pc[t].y << 32);
 			dst[1] = (uint64_t)pc[t].z | ((uint64_t)pc[t].w << 32);
 		}
 		GYS_WAVE_SYNC();
-		if (i < p.n) {
+		{
 			const uint64_t *rw = (const uint64_t *)(st + lane * GYS_CONN_STAGE_STRIDE);
 			ConnRec rc;
 			rc.a0 = rw[0]; rc.a1 = rw[1]; rc.a2 = rw[2]; rc.a3 = rw[3];
@@ -2566,7 +2629,8 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 			rc.ser_glob_id = rw[16];  // @192 = 64 + 128
 			rc.bytes_sent = rw[18];   // @208
 			rc.bytes_rcvd = rw[19];   // @216
-			conn_one(p, rc, s_key, s_acc);
+			rc.flags = rw[21];        // @272 (staged at 160 + 8)
+			conn_one(p, rc, i < p.n, s_key, s_acc, s_tally);
 		}
 		GYS_WAVE_SYNC(); // (the region is rewritten by the next round)
 	}
@@ -2576,11 +2640,16 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 		const uint64_t cnt = first < p.n ? min((uint64_t)GYS_CONN_RECS, (uint64_t)p.n - first) : 0ull;
 		if (cnt) atomicAdd((unsigned long long *)&p.counters[CTR_CONN_EVENTS], (unsigned long long)cnt);
 	}
+	if (threadIdx.x < CONN_T_NUM && s_tally[threadIdx.x]) { // ... and one per tally of the walk
+		const int ctr = threadIdx.x == CONN_T_NEW ? CTR_CONN_NEW : threadIdx.x == CONN_T_CLOSED ? CTR_CONN_CLOSED :
+				threadIdx.x == CONN_T_CLOSED_NO_NOTIFY ? CTR_CONN_CLOSED_NO_NOTIFY : threadIdx.x == CONN_T_CLI_SIDE ? CTR_CONN_CLI_SIDE : CTR_CONN_UNKNOWN;
+		atomicAdd((unsigned long long *)&p.counters[ctr], (unsigned long long)s_tally[threadIdx.x]);
+	}
 	for (uint32_t k = threadIdx.x; k < GYS_CONN_AGG; k += GYS_CONN_THREADS) {
 		const uint32_t slot = s_key[k];
 		if (slot == GYS_NOSLOT) continue;
 		unsigned long long *c = p.svc_win + (size_t)slot * 3;
-		atomicAdd(&c[0], s_acc[k][0]);
+		if (s_acc[k][0]) atomicAdd(&c[0], s_acc[k][0]);
 		if (s_acc[k][1]) atomicAdd(&c[1], s_acc[k][1]);
 		if (s_acc[k][2]) atomicAdd(&c[2], s_acc[k][2]);
 	}
@@ -3466,16 +3535,38 @@ __global__ __launch_bounds__(256) void k_actconn_ingest(ActConnP p)
 	atomicAdd(&a[3], (unsigned long long)act);
 }
 
-// A partha reports its ACTIVE_CONN_STATS every 15 s, a window is 5 s: the (all-rank) tables of a window that carried such rows replace
-// the latched copy the queries read; a window without rows leaves the latched copy alone ("last report" semantics of a gauge).
-__global__ __launch_bounds__(256) void k_act_latch(const uint32_t *win_rows, const uint32_t *pair32, const unsigned long long *pair64, uint32_t *last32,
+// A partha reports its ACTIVE_CONN_STATS every 15 s (server/gy_mconnhdlr.cc:7714: a 4-s tolerance on a 15-s cadence) on a phase of its own, a
+// window is 5 s: one window only carries the parthas that reported in it.  The (all-rank) tables of the last GYS_ACT_RING = 3 windows are
+// kept in a ring and the queries read their PER-CELL MAXIMUM: a pair reported anywhere in the last 15 s reads back at least its reported
+// value (the Count-Min guarantee "never below" holds across the report period; a partha whose report lands in two of the three windows is
+// not counted twice, which a per-cell sum would do), and a pair not reported for three windows ages out -- the gauge's "last report".
+// `live[w & 1]` = windows until the ring is all zero again: an engine that never sees such rows pays one 4-byte read per window.
+#define GYS_ACT_RING 3u
+__global__ __launch_bounds__(256) void k_act_latch(const uint32_t *win_rows, const uint32_t *d_epoch, uint32_t *live, const uint32_t *pair32,
+						   const unsigned long long *pair64, uint32_t *ring32, unsigned long long *ring64, uint32_t *last32,
 						   unsigned long long *last64)
 {
-	if (*win_rows == 0u) return;
-	const uint32_t n = GYS_CMS_D * GYS_CMS_W;
+	const uint32_t w = *d_epoch, cur = live[w & 1u], rows = *win_rows;
+	if (blockIdx.x == 0 && threadIdx.x == 0) live[(w + 1u) & 1u] = rows ? GYS_ACT_RING : (cur ? cur - 1u : 0u); // (read by the NEXT window's launch)
+	if (rows == 0u && cur == 0u) return;
+	const uint32_t n = GYS_CMS_D * GYS_CMS_W, me = w % GYS_ACT_RING;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		last32[i] = pair32[i];
-		last64[i] = pair64[i];
+		const uint32_t v32 = pair32[i];
+		const unsigned long long v64 = pair64[i];
+		ring32[(size_t)me * n + i] = v32;
+		ring64[(size_t)me * n + i] = v64;
+		uint32_t m32 = v32;
+		unsigned long long m64 = v64;
+#pragma unroll
+		for (uint32_t k = 0; k < GYS_ACT_RING; ++k) {
+			if (k == me) continue;
+			const uint32_t a = ring32[(size_t)k * n + i];
+			const unsigned long long b = ring64[(size_t)k * n + i];
+			m32 = a > m32 ? a : m32;
+			m64 = b > m64 ? b : m64;
+		}
+		last32[i] = m32;
+		last64[i] = m64;
 	}
 }
 

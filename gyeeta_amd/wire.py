@@ -108,42 +108,104 @@ def pack_variable(fixed, tails):
     return bytes(out)
 
 
-def synth_tcp_conns(rng, n, hosts, svcs_per_host, dup_frac=0.2, v6_frac=0.0, close_frac=0.5):
-    """SURVEY 8d C2 flow stream: cli IP uniform in 10/8, cli port uniform 16000-65535, ser = (host IP, svc port); dup_frac of the
-    tuples repeat an earlier tuple (reconnects); bytes ~ Pareto(1.2, 200).  hosts: array of host indices to draw from."""
-    rec = np.zeros(n, dtype=TCP_CONN_NOTIFY)
-    h = rng.choice(np.asarray(hosts), n)
-    s = rng.integers(0, svcs_per_host, n)
-    cli_ip = (0x0A000000 | rng.integers(0, 1 << 24, n)).astype(">u4").view("<u4")
-    cli_port = rng.integers(16000, 65536, n).astype(np.uint16)
-    ndup = int(n * dup_frac)
-    if ndup and n > ndup:
-        src = rng.integers(0, n - ndup, ndup)
-        idx = np.arange(n - ndup, n)
-        for a in (h, s, cli_ip, cli_port):
+def synth_tcp_conns(rng, n, hosts, svcs_per_host, dup_frac=0.2, v6_frac=0.0, close_frac=0.5, both_halves_frac=0.25, loopback_frac=0.05,
+                    truth=None):
+    """SURVEY 8d C2 flow stream as parthas report it: exactly n TCP_CONN_NOTIFY records that describe CONNECTIONS with a life cycle
+    (server/gy_mconnhdlr.cc:9129-9341; common/gy_socket_stat.cc:1738-1787):
+      * tuple: cli IP uniform in 10/8, cli port uniform 16000-65535, ser = (host IP, svc port); dup_frac of the connections reuse an
+        earlier connection's tuple (reconnects: a new connection on a flow seen before);
+      * life cycle: close_frac / 2 of the connections are short-lived (ONE record: closed, notified_before_ clear), close_frac / 2 are
+        reported when they open AND when they close inside the batch (TWO records: open, then closed with notified_before_ set), the
+        rest are still open (ONE open record); bytes ~ Pareto(1.2, 200) ride on the closing record only;
+      * halves: every record above comes from the ACCEPTING partha (is_tcp_accept_event_); both_halves_frac of the connections are also
+        reported by the CONNECTING partha (the same records again with is_tcp_connect_event_ only, ser_glob_id_ known for 70 % of
+        them), loopback_frac are same-host connections reported once with both flags and is_loopback_conn_.
+    hosts: array of host indices to draw the listeners from.  Records are shuffled.  `truth` (a dict) receives the per-CONNECTION arrays
+    conn_host / conn_svc / conn_closed / conn_bytes_sent / conn_bytes_rcvd (what an exact connection table would hold)."""
+    p_short, p_pair = close_frac / 2, close_frac / 2
+    # draw n connections (always enough: a connection is at least one record), then keep the prefix whose records fit and fill the
+    # remainder with one-record connections
+    kind = rng.choice(3, n, p=[p_short, p_pair, 1 - p_short - p_pair])        # 0 short-lived, 1 open + close, 2 still open
+    u = rng.random(n)
+    half = np.where(u < loopback_frac, 2, np.where(u < loopback_frac + both_halves_frac, 1, 0))  # 0 accept only, 1 both halves, 2 loopback
+    nrec_c = np.where(kind == 1, 2, 1) * np.where(half == 1, 2, 1)
+    cum = np.cumsum(nrec_c)
+    nc = int(np.searchsorted(cum, n, side="right"))
+    fill = n - (int(cum[nc - 1]) if nc else 0)
+    kind = np.concatenate([kind[:nc], np.zeros(fill, dtype=kind.dtype)])
+    half = np.concatenate([half[:nc], np.zeros(fill, dtype=half.dtype)])
+    nc += fill
+    h = rng.choice(np.asarray(hosts), nc)
+    s_ = rng.integers(0, svcs_per_host, nc)
+    cli_ip = (0x0A000000 | rng.integers(0, 1 << 24, nc)).astype(">u4").view("<u4")
+    cli_port = rng.integers(16000, 65536, nc).astype(np.uint16)
+    ndup = int(nc * dup_frac)
+    if ndup and nc > ndup:
+        src = rng.integers(0, nc - ndup, ndup)
+        idx = np.arange(nc - ndup, nc)
+        for a in (h, s_, cli_ip, cli_port):
             a[idx] = a[src]
-    ser_ip = (0x0A000000 | (h.astype(np.int64) & 0xFFFFFF)).astype(">u4").view("<u4")
-    ser_port = listener_port(s)
-    for f in ("cli", "nat_cli"):
-        set_ip_port(rec[f], ip32_be=cli_ip, port=cli_port)
-    for f in ("ser", "nat_ser"):
-        set_ip_port(rec[f], ip32_be=ser_ip, port=ser_port)
-    nv6 = int(n * v6_frac)
+    closed_c = kind != 2
+    sent_c = np.where(closed_c, ((rng.pareto(1.2, nc) + 1) * 200).astype(np.uint64), 0).astype(np.uint64)
+    rcvd_c = np.where(closed_c, ((rng.pareto(1.2, nc) + 1) * 200).astype(np.uint64), 0).astype(np.uint64)
+    task_c = (np.uint64(0x7A5C000000000000) + rng.integers(0, 64, nc).astype(np.uint64))
+    resolved_c = rng.random(nc) < 0.7
+    if truth is not None:
+        truth.update(conn_host=h.copy(), conn_svc=s_.copy(), conn_closed=closed_c.copy(), conn_bytes_sent=sent_c.copy(), conn_bytes_rcvd=rcvd_c.copy())
+    # expand into records: (connection, is the closing record, notified_before, is the connecting half)
+    ci, isclose, notified, clihalf = [], [], [], []
+    allc = np.arange(nc)
+    for halfsel, cflag in ((allc, False), (allc[half == 1], True)):
+        k = kind[halfsel]
+        a = halfsel[k == 0]          # short-lived: one closing record, never notified before
+        b = halfsel[k == 1]          # open record + closing record (notified before)
+        c = halfsel[k == 2]          # still open
+        for conns, cl, nb in ((a, True, False), (b, False, False), (b, True, True), (c, False, False)):
+            ci.append(conns)
+            isclose.append(np.full(len(conns), cl))
+            notified.append(np.full(len(conns), nb))
+            clihalf.append(np.full(len(conns), cflag))
+    ci, isclose, notified, clihalf = (np.concatenate(x) for x in (ci, isclose, notified, clihalf))
+    assert len(ci) == n, (len(ci), n)
+    perm = rng.permutation(n)
+    ci, isclose, notified, clihalf = ci[perm], isclose[perm], notified[perm], clihalf[perm]
+    rec = np.zeros(n, dtype=TCP_CONN_NOTIFY)
+    hh, ss = h[ci], s_[ci]
+    ser_ip = (0x0A000000 | (hh.astype(np.int64) & 0xFFFFFF)).astype(">u4").view("<u4")
+    ser_port = listener_port(ss)
+    cli_arr = np.zeros(n, dtype=IP_PORT)  # (contiguous 32-byte elements: filling the fields of the 280-byte records in place is 5 x slower)
+    ser_arr = np.zeros(n, dtype=IP_PORT)
+    set_ip_port(cli_arr, ip32_be=cli_ip[ci], port=cli_port[ci])
+    set_ip_port(ser_arr, ip32_be=ser_ip, port=ser_port)
+    nv6 = int(nc * v6_frac)
     if nv6:
-        idx = rng.choice(n, nv6, replace=False)
-        ip6 = rng.integers(0, 256, (nv6, 16), dtype=np.uint8)
-        ip6[:, 0] = 0x20
-        sub = rec["nat_cli"][idx]
-        set_ip_port(sub, ip128=ip6, port=cli_port[idx])
-        rec["nat_cli"][idx] = sub
-        rec["cli"][idx] = sub
-    rec["ser_glob_id"] = glob_id(h, s)
-    rec["tusec_start"] = 1_700_000_000_000_000 + np.arange(n, dtype=np.uint64)
-    closed = rng.random(n) < close_frac
-    rec["tusec_close"] = np.where(closed, rec["tusec_start"] + 1000, 0)
-    rec["bytes_sent"] = np.where(closed, ((rng.pareto(1.2, n) + 1) * 200).astype(np.uint64), 0)
-    rec["bytes_rcvd"] = np.where(closed, ((rng.pareto(1.2, n) + 1) * 200).astype(np.uint64), 0)
-    rec["is_tcp_accept_event"] = 1
+        c6 = rng.choice(nc, nv6, replace=False)        # per CONNECTION: every record of it carries the same v6 client address
+        ip6_c = np.zeros((nc, 16), dtype=np.uint8)
+        ip6_c[c6] = rng.integers(0, 256, (nv6, 16), dtype=np.uint8)
+        ip6_c[c6, 0] = 0x20
+        isv6 = np.zeros(nc, dtype=bool)
+        isv6[c6] = True
+        idx = np.nonzero(isv6[ci])[0]
+        sub = cli_arr[idx]
+        set_ip_port(sub, ip128=ip6_c[ci[idx]], port=cli_port[ci[idx]])
+        cli_arr[idx] = sub
+    rec["cli"] = cli_arr
+    rec["nat_cli"] = cli_arr
+    rec["ser"] = ser_arr
+    rec["nat_ser"] = ser_arr
+    gid = glob_id(hh, ss)
+    rec["ser_glob_id"] = np.where(clihalf & ~resolved_c[ci], np.uint64(0), gid)
+    rec["cli_task_aggr_id"] = np.where(clihalf | resolved_c[ci], task_c[ci], np.uint64(0))
+    rec["tusec_start"] = 1_700_000_000_000_000 + ci.astype(np.uint64)
+    rec["tusec_close"] = np.where(isclose, rec["tusec_start"] + 1000, 0)
+    rec["bytes_sent"] = np.where(isclose, sent_c[ci], 0)
+    rec["bytes_rcvd"] = np.where(isclose, rcvd_c[ci], 0)
+    loop = half[ci] == 2
+    rec["is_tcp_connect_event"] = (clihalf | loop).astype(np.uint8)
+    rec["is_tcp_accept_event"] = (~clihalf).astype(np.uint8)
+    rec["is_loopback_conn"] = loop.astype(np.uint8)
+    rec["is_pre_existing"] = (rng.random(n) < 0.02).astype(np.uint8)
+    rec["notified_before"] = notified.astype(np.uint8)
     rec["cli_comm"] = b"client"
     rec["ser_comm"] = b"server"
     return rec

@@ -157,7 +157,7 @@ int gys_ingest_resp_events(gys_ctx *ctx, const uint8_t machine_id[16], const voi
 
 typedef struct {
 	uint32_t host_slot;   /* from gys_register_host */
-	uint32_t reserved;
+	uint32_t reserved;    /* ignored on input (the engine clears its copy; it uses the field for its own per-part segment lists) */
 	uint64_t first_event; /* index of this host's first event; segments sorted ascending, host's events contiguous */
 } gys_resp_seg;
 
@@ -204,7 +204,7 @@ int gys_ingest_listener_state_dev(gys_ctx *ctx, const void *d_batch, const uint3
  * (insert_active_conns .cc:7776-7960: is_remote_listen_ == false -> activeconntbl, true -> remoteconntbl).  Here the local-listener
  * rows update (i) a Count-Min pair keyed by (listener_glob_id_, cli_aggr_task_id_): active_conns_ (u32 table) and bytes_sent_ +
  * bytes_received_ (u64 table) -- the per-(listener, client task) roll-up that stands for those rows; both tables live in the reduce
- * arena (all-reduced with the other registers, per window; queries read the tables of the last window that carried rows, see
+ * arena (all-reduced with the other registers, per window; queries read the per-cell maximum of the last three windows' tables, see
  * gys_query_pair_cms) -- and (ii) exact cumulative per-listener sums.  Remote-listener rows are counted (gys_counters.actconn_remote_listen). */
 int gys_ingest_active_conns(gys_ctx *ctx, const uint8_t machine_id[16], const void *batch, uint32_t nitems, const void *pend);
 int gys_ingest_active_conns_dev(gys_ctx *ctx, const void *d_batch, uint32_t nitems);
@@ -285,14 +285,19 @@ int gys_query_hist_percentiles(gys_ctx *ctx, uint64_t glob_id, int which, gys_hi
 int gys_query_quantiles(gys_ctx *ctx, uint64_t glob_id, const double *q, uint32_t nq, double *out);
 /* distinct flows seen (global HLL over PAIR_IP_PORT keys; after gys_window_finish: the all-rank estimate) */
 int gys_query_distinct_flows(gys_ctx *ctx, double *out);
-/* Count-Min estimate for a service key: events (which = 0) or bytes (which = 1) in the last finished window */
+/* Count-Min estimate for a service key in the last finished window: which = 0 response events + NEW CONNECTIONS of the service (one per
+ * connection, accepting side: see gys_export_svc_counters), which = 1 connection bytes (sent + received) */
 int gys_query_cms(gys_ctx *ctx, uint64_t glob_id, int which, uint64_t *out);
 /* Count-Min estimate for a (listener, client task group) pair.  Two roll-ups, each with its own table pair:
  *   which 0 / 1: active connections / bytes (sent + received) of the ACTIVE_CONN_STATS rows (gys_ingest_active_conns).  A partha reports
- *                these every 15 s and a window is 5 s: the answer comes from the tables of the LAST WINDOW THAT CARRIED SUCH ROWS on any
- *                rank (a gauge's "last report"); windows without rows leave it alone.
- *   which 2 / 3: connection notifications / bytes of the TCP_CONN_NOTIFY roll-up (gys_config.conn_pair_cms; GYS_ERR_STATE when off),
- *                last finished window. */
+ *                these every 15 s on a phase of its own and a window is 5 s: the answer is the PER-CELL MAXIMUM over the (all-rank) tables
+ *                of the last three finished windows -- a pair reported anywhere in the last 15 s reads back at least its reported value
+ *                (Count-Min never under-estimates), a partha whose report fell into two of the three windows is not counted twice, and a
+ *                pair not reported for three windows reads 0 again (a gauge's "last report").
+ *   which 2 / 3: closed connections / their bytes of the TCP_CONN_NOTIFY roll-up, LISTENER side = the reference's connlistenmap_
+ *                (server/gy_mconnhdlr.cc:9226-9245: records with tusec_close_, bytes > 0, ser_glob_id_ and is_tcp_accept_event_), last
+ *                finished window (gys_config.conn_pair_cms; GYS_ERR_STATE when off);
+ *   which 4 / 5: the same for the CLIENT side = connclientmap_ (:9290-9312: closed, bytes > 0, connect-only, cli_task_aggr_id_ != 0). */
 int gys_query_pair_cms(gys_ctx *ctx, uint64_t listener_glob_id, uint64_t cli_aggr_task_id, int which, uint64_t *out);
 
 typedef struct {
@@ -475,8 +480,13 @@ int gys_export_tdigest(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, int64
 /* values a service's t-digest still buffers unmerged (unordered; only the first npend[i] entries of row i are meaningful) */
 int gys_export_tdigest_pending(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint32_t *npend /* [nslots] */,
 			       int32_t *pend /* [nslots*GYS_TD_PEND_CAP] */);
-int gys_export_svc_counters(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint64_t *out /* [nslots*4]: nconn, nclose, bytes_sent, bytes_rcvd */);
-int gys_export_pair_cms(gys_ctx *ctx, int which, void *out /* which 0 / 2: u32[D*W]; which 1 / 3: i64[D*W]; see gys_query_pair_cms */);
+/* per-service connection counters of the TCP_CONN_NOTIFY roll-up, [nslots*4]: nconn, nclose, bytes_sent, bytes_rcvd.  CONNECTIONS, not
+ * records: only the ACCEPTING partha's records count (is_tcp_accept_event_, a loopback record included; the connecting half names the
+ * same ser_glob_id_ and would count the connection twice), nconn += 1 on a record with notified_before_ clear (the open notification, or
+ * the only record of a short-lived connection), nclose += 1 on a record with tusec_close_ set, bytes as reported (server/gy_mconnhdlr.cc:
+ * 9129-9181).  gys_query_cms(which 0 / 1) estimates the same nconn / bytes per service for the last finished window. */
+int gys_export_svc_counters(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint64_t *out);
+int gys_export_pair_cms(gys_ctx *ctx, int which, void *out /* which 0 / 2 / 4: u32[D*W]; which 1 / 3 / 5: i64[D*W]; see gys_query_pair_cms */);
 int gys_export_active_conn_counters(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint64_t *out /* [nslots*4]: rows, bytes_sent, bytes_received, active conns */);
 int gys_export_global_hist(gys_ctx *ctx, gys_hist_rec *out); /* all-service response histogram of the last finished window (all ranks) */
 int gys_export_svc_hll(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint8_t *out /* [nslots << svc_hll_p] */);
@@ -494,6 +504,12 @@ typedef struct {
 	uint64_t stage_waits;       /* host-pointer calls that found their staging slot still in flight and waited for the GPU (ring wrapped) */
 	uint64_t resp_calls_queued; /* gys_ingest_resp_events calls that went through the submission queue ... */
 	uint64_t resp_submissions;  /* ... and the combined batches they were submitted as (calls / submissions = calls per launch set) */
+	/* the tallies MCONN_HANDLER::partha_tcp_conn_info keeps while it walks a message (server/gy_mconnhdlr.cc:9133-9137, :9327: nnew,
+	 * nclosed, nclosed_no_not), summed over all messages: open notifications / records with tusec_close_ / closes of connections
+	 * whose open was never notified.  conn_new + conn_closed_no_notify = connection HALVES seen (each connection is reported by its
+	 * accepting and by its connecting partha); conn_client_side = records of the connecting half only (is_tcp_connect_event_ without
+	 * is_tcp_accept_event_), which do not enter the per-service counters (see gys_export_svc_counters). */
+	uint64_t conn_new, conn_closed, conn_closed_no_notify, conn_client_side;
 } gys_counters;
 int gys_get_counters(gys_ctx *ctx, gys_counters *out);
 

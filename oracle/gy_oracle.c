@@ -887,8 +887,22 @@ int gyo_tcp_conn_decode(const uint8_t *batch, int nrec, const uint8_t *pend, uin
 	return i;
 }
 
-/* whole-batch form of the TCP_CONN_NOTIFY roll-up used by the engine: walk (:9130), flow key into the distinct-flow HLL, service key
- * (ser_glob_id_) into the Count-Min rows (connection count and bytes_sent_ + bytes_rcvd_).  Returns the records walked. */
+/* The five bool bytes of a TCP_CONN_NOTIFY record (common/gy_comm_proto.h:1700-1704, @274..278) and what the walk of
+ * MCONN_HANDLER::partha_tcp_conn_info makes of them (server/gy_mconnhdlr.cc:9129-9341):
+ *   conn_closed = !!tusec_close_ (:9131); a closed record counts nclosed, and nclosed_no_not when notified_before_ is clear (:9133-9137);
+ *   an open record counts nnew (:9327) and goes to add_tcp_conn_cli when is_tcp_connect_event_, else to add_tcp_conn_ser (:9329-9339);
+ *   the per-listener close roll-up connlistenmap_ takes closed records with bytes whose ser_glob_id_ is set and is_tcp_accept_event_
+ *   (:9226-9245), the per-client one connclientmap_ those that are connect-only with cli_task_aggr_id_ set (:9290-9312).
+ * A connection is thus reported once when it opens and once when it closes (or once only, at its close, when it was short-lived), by each
+ * of its two halves; is_loopback_conn_ = both flags on the one record of a same-host connection (common/gy_socket_stat.cc:1738-1787). */
+static int conn_closed(const uint8_t *p) { return rd_u64(p + 136) != 0; }
+static int conn_fresh(const uint8_t *p) { return p[278] == 0; }               /* notified_before_ clear */
+static int conn_listener_side(const uint8_t *p) { return p[275] != 0 || p[274] == 0; } /* accept event, or not a connect event (:9333) */
+
+/* whole-batch form of the TCP_CONN_NOTIFY roll-up used by the engine: walk (:9130), flow key into the distinct-flow HLL (every record:
+ * both halves and both notifications of a connection carry the same NAT-translated tuple), service key (ser_glob_id_) into the Count-Min
+ * rows ONCE PER CONNECTION: the listener-side record whose notified_before_ is clear adds the connection, listener-side records add their
+ * bytes_sent_ + bytes_rcvd_ (zero while a connection is open).  Returns the records walked. */
 int gyo_tcp_conn_sketch_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint8_t *hll, uint32_t *cms32, uint64_t *cms64)
 {
 	const uint8_t *p = batch;
@@ -899,17 +913,63 @@ int gyo_tcp_conn_sketch_batch(const uint8_t *batch, int nrec, const uint8_t *pen
 		int c6, s6;
 		uint16_t cport, sport;
 		uint32_t w[10], gw[2], nw;
-		uint64_t gid;
+		uint64_t gid, bytes;
 
 		rd_ip_port(p + 64, &cip, &c6, &cport);
 		rd_ip_port(p + 96, &sip, &s6, &sport);
 		nw = gyo_pair_ip_port_words(cip, c6, cport, sip, s6, sport, w);
 		gyo_hll_add_words(hll, GYO_HLL_P, w, nw);
+		if (!conn_listener_side(p)) continue;
 		gid = rd_u64(p + 192);
 		gw[0] = (uint32_t)(gid & 0xFFFFFFFFu);
 		gw[1] = (uint32_t)(gid >> 32);
-		gyo_cms_add(cms32, gw, 2, 1);
-		gyo_cms64_add(cms64, gw, 2, rd_u64(p + 208) + rd_u64(p + 216));
+		if (conn_fresh(p)) gyo_cms_add(cms32, gw, 2, 1);
+		bytes = rd_u64(p + 208) + rd_u64(p + 216);
+		if (bytes) gyo_cms64_add(cms64, gw, 2, bytes);
+	}
+	return i;
+}
+
+/* the walk's own tallies (its DEBUG line :9431-9437): out[0] nnew, out[1] nclosed, out[2] nclosed_no_not, out[3] records of the
+ * connecting half only (added to, not cleared) */
+int gyo_tcp_conn_walk_tallies(const uint8_t *batch, int nrec, const uint8_t *pend, uint64_t out[4])
+{
+	const uint8_t *p = batch;
+	int i;
+
+	for (i = 0; i < nrec && p < pend; ++i, p += gyo_tcp_conn_elem_size(p)) {
+		if (conn_closed(p)) {
+			out[1]++;
+			if (conn_fresh(p)) out[2]++;
+		} else
+			out[0]++;
+		if (!conn_listener_side(p)) out[3]++;
+	}
+	return i;
+}
+
+/* per-service connection counters the engine exports (gys_export_svc_counters): ctr[4 s + {0,1,2,3}] = connections, closes, bytes sent,
+ * bytes received of service gids[s], from the listener-side records only; *unknown += listener-side records of services not in gids */
+int gyo_tcp_conn_svc_counters(const uint8_t *batch, int nrec, const uint8_t *pend, const uint64_t *gids, uint32_t ngids, uint64_t *ctr, uint64_t *unknown)
+{
+	const uint8_t *p = batch;
+	int i;
+
+	for (i = 0; i < nrec && p < pend; ++i, p += gyo_tcp_conn_elem_size(p)) {
+		const uint64_t gid = rd_u64(p + 192);
+		uint32_t s;
+
+		if (!conn_listener_side(p)) continue;
+		for (s = 0; s < ngids && gids[s] != gid; ++s)
+			;
+		if (s == ngids) {
+			(*unknown)++;
+			continue;
+		}
+		ctr[4 * s + 0] += conn_fresh(p);
+		ctr[4 * s + 1] += conn_closed(p);
+		ctr[4 * s + 2] += rd_u64(p + 208);
+		ctr[4 * s + 3] += rd_u64(p + 216);
 	}
 	return i;
 }

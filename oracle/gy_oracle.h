@@ -175,7 +175,7 @@ void gyo_td64_merge_values(gyo_td64 *d, const int32_t *vals, size_t m);
 void gyo_td64_merge_service(gyo_td64 *d, const gyo_td_buffered *b); /* the service's clusters, then its buffered values */
 void gyo_td64_merge_td64(gyo_td64 *d, const gyo_td64 *o);
 double gyo_td64_quantile(const gyo_td64 *d, double q);
-int gyo_tcp_conn_pair_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *pair32, uint64_t *pair64);
+int gyo_tcp_conn_pair_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *pair32, uint64_t *pair64, uint32_t *cpair32, uint64_t *cpair64);
 void gyo_active_conn_sketch_batch(const uint8_t *batch, int nrec, uint32_t *pair32 /*[D*W]*/, uint64_t *pair64 /*[D*W]*/, uint64_t out[2]);
 
 /* ---------------------------------------------------------------- wire records + roll-ups */
@@ -209,6 +209,8 @@ int gyo_listener_state_validate(const uint8_t *msg);
 int gyo_tcp_conn_decode(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *keywords /*[nrec*10]*/, uint32_t *nwords,
 			uint64_t *ser_glob_id, uint64_t *bytes_sent, uint64_t *bytes_rcvd, uint8_t *flags);
 int gyo_tcp_conn_sketch_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint8_t *hll, uint32_t *cms32, uint64_t *cms64);
+int gyo_tcp_conn_walk_tallies(const uint8_t *batch, int nrec, const uint8_t *pend, uint64_t out[4]);
+int gyo_tcp_conn_svc_counters(const uint8_t *batch, int nrec, const uint8_t *pend, const uint64_t *gids, uint32_t ngids, uint64_t *ctr, uint64_t *unknown);
 void gyo_cluster_state_update(gyo_cluster_state_one *c, uint32_t ntasks_issue, uint32_t ntasks, uint32_t nlisten_issue,
 			      uint32_t nlisten, uint32_t cpu_issue, uint32_t mem_issue, const gyo_listen_summ_stats *summ);
 void gyo_cluster_state_add(gyo_cluster_state_one *dst, const gyo_cluster_state_one *src);

@@ -232,18 +232,28 @@ void gyo_active_conn_sketch_batch(const uint8_t *batch, int nrec, uint32_t *pair
 	}
 }
 
-/* the same pair fed by TCP_CONN_NOTIFY records (gys_config.conn_pair_cms): key (ser_glob_id_ @192, cli_task_aggr_id_ @144),
- * one connection into the u32 table, bytes_sent_ + bytes_rcvd_ (@208, @216) into the u64 table, for every record of the batch
- * (variable stride, common/gy_comm_proto.h:1721-1724) */
-int gyo_tcp_conn_pair_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *pair32, uint64_t *pair64)
+/* the same kind of pair fed by TCP_CONN_NOTIFY records (gys_config.conn_pair_cms): key (ser_glob_id_ @192, cli_task_aggr_id_
+ * @144).  It follows the reference's close roll-ups (server/gy_mconnhdlr.cc:9182, :9226-9245, :9290-9312): only a record with tusec_close_
+ * (@136) and bytes_sent_ + bytes_rcvd_ > 0 (@208, @216) counts -- one connection into the u32 table, its bytes into the u64 table -- into the
+ * LISTENER-side tables (connlistenmap_) when ser_glob_id_ != 0 and is_tcp_accept_event_ (@275), into the CLIENT-side tables (connclientmap_)
+ * when it is connect-only (@274 set, @275 clear) with cli_task_aggr_id_ != 0.  (The reference's `connpeer` gate depends on its flow-join
+ * table and is not restated: out of scope with the join.)  Variable stride, common/gy_comm_proto.h:1721-1724. */
+int gyo_tcp_conn_pair_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *pair32, uint64_t *pair64, uint32_t *cpair32, uint64_t *cpair64)
 {
 	const uint8_t *p = batch;
 	int i;
 	for (i = 0; i < nrec && p < pend; ++i, p += gyo_tcp_conn_elem_size(p)) {
-		const uint64_t gid = rd64(p + 192), task = rd64(p + 144);
+		const uint64_t gid = rd64(p + 192), task = rd64(p + 144), bytes = rd64(p + 208) + rd64(p + 216);
 		const uint32_t w[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)task, (uint32_t)(task >> 32)};
-		gyo_cms_add(pair32, w, 4, 1);
-		gyo_cms64_add(pair64, w, 4, rd64(p + 208) + rd64(p + 216));
+		const int connect = p[274] != 0, accept = p[275] != 0;
+		if (rd64(p + 136) == 0 || bytes == 0) continue;
+		if (gid && accept) {
+			gyo_cms_add(pair32, w, 4, 1);
+			gyo_cms64_add(pair64, w, 4, bytes);
+		} else if (!accept && connect && task) {
+			gyo_cms_add(cpair32, w, 4, 1);
+			gyo_cms64_add(cpair64, w, 4, bytes);
+		}
 	}
 	return i;
 }

@@ -188,7 +188,7 @@ def lib():
     _sig(L, "gyo_td64_merge_td64", None, [C.POINTER(TD64), C.POINTER(TD64)])
     _sig(L, "gyo_td64_quantile", C.c_double, [C.POINTER(TD64), C.c_double])
     _sig(L, "gyo_active_conn_sketch_batch", None, [u8p, C.c_int, u32p, u64p, u64p])
-    _sig(L, "gyo_tcp_conn_pair_batch", C.c_int, [u8p, C.c_int, u8p, u32p, u64p])
+    _sig(L, "gyo_tcp_conn_pair_batch", C.c_int, [u8p, C.c_int, u8p, u32p, u64p, u32p, u64p])
     _sig(L, "gyo_listener_state_rollup", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(ListenSummStats), C.POINTER(C.c_int)])
     _sig(L, "gyo_listener_state_elem_size", C.c_uint32, [C.c_void_p])
     _sig(L, "gyo_tcp_conn_elem_size", C.c_uint32, [C.c_void_p])
@@ -197,6 +197,8 @@ def lib():
     _sig(L, "gyo_listener_state_validate", C.c_int, [C.c_void_p])
     _sig(L, "gyo_tcp_conn_decode", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u32p, u32p, u64p, u64p, u64p, u8p])
     _sig(L, "gyo_tcp_conn_sketch_batch", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u8p, u32p, u64p])
+    _sig(L, "gyo_tcp_conn_walk_tallies", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u64p])
+    _sig(L, "gyo_tcp_conn_svc_counters", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint32, u64p, u64p])
     _sig(L, "gyo_cluster_state_update", None, [C.POINTER(ClusterStateOne)] + [C.c_uint32] * 6 + [C.POINTER(ListenSummStats)])
     _sig(L, "gyo_cluster_state_add", None, [C.POINTER(ClusterStateOne), C.POINTER(ClusterStateOne)])
     _sig(L, "gyo_topn_u64", C.c_size_t, [u64p, C.c_size_t, C.c_size_t, u64p])

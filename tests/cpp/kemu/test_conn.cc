@@ -83,15 +83,15 @@ int main(int argc, char **argv)
 	}
 
 	const uint32_t NREG = 1u << GYS_HLL_P, NCMS = GYS_CMS_D * GYS_CMS_W;
-	std::vector<uint32_t> hll32(NREG, 0), cms32(NCMS, 0), pair32(NCMS, 0);
-	std::vector<unsigned long long> cms64(NCMS, 0), pair64(NCMS, 0), svc_win(NSVC * 3, 0), svc_ctr(NSVC * 4, 0);
+	std::vector<uint32_t> hll32(NREG, 0), cms32(NCMS, 0), pair32(NCMS, 0), cpair32(NCMS, 0);
+	std::vector<unsigned long long> cms64(NCMS, 0), pair64(NCMS, 0), cpair64(NCMS, 0), svc_win(NSVC * 3, 0), svc_ctr(NSVC * 4, 0);
 	std::vector<uint64_t> counters(CTR_NUM, 0);
-	// the oracle's side + sums taken here
+	// the oracle's side: its serial walk of the same bytes (flag bytes included: a connection counts once, on its listener side)
 	std::vector<uint8_t> o_hll(NREG, 0);
-	std::vector<uint32_t> o_cms32(NCMS, 0), o_pair32(NCMS, 0);
-	std::vector<uint64_t> o_cms64(NCMS, 0), o_pair64(NCMS, 0);
+	std::vector<uint32_t> o_cms32(NCMS, 0), o_pair32(NCMS, 0), o_cpair32(NCMS, 0);
+	std::vector<uint64_t> o_cms64(NCMS, 0), o_pair64(NCMS, 0), o_cpair64(NCMS, 0);
 	std::vector<uint64_t> want_ctr(NSVC * 4, 0);
-	uint64_t want_events = 0, want_unknown = 0;
+	uint64_t want_events = 0, want_unknown = 0, want_tally[4] = {0, 0, 0, 0};
 
 	const uint32_t sizes[] = {1, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 1600, 2500};
 	uint32_t call = 0;
@@ -124,20 +124,23 @@ int main(int argc, char **argv)
 			const uint16_t cmdlen = (uint16_t)(rng() % 41u);
 			const uint8_t pad = (uint8_t)((8u - cmdlen % 8u) % 8u);
 			put16(r + 272, cmdlen);
+			// the five bool bytes: connect / accept / loopback / pre-existing / notified-before (any non-zero byte is `true`)
+			const uint32_t side = rng() % 8u; // 0-3 accepting half, 4-5 connecting half, 6 loopback (both), 7 neither
+			r[274] = (side >= 4u && side <= 6u) ? (uint8_t)(1u + rng() % 3u) : 0;
+			r[275] = (side <= 3u || side == 6u) ? 1 : 0;
+			r[276] = side == 6u;
+			r[277] = (rng() % 9u) == 0;
+			r[278] = (rng() % 3u) == 0 ? (uint8_t)(1u + rng() % 200u) : 0;
 			r[279] = pad;
 			for (uint32_t k = 0; k < (uint32_t)cmdlen + pad; ++k) r[280 + k] = (uint8_t)rng(); // (bytes the roll-up never looks at)
 			off += 280u + cmdlen + pad;
 			++want_events;
-			if (s < NSVC) {
-				want_ctr[s * 4 + 0] += 1;
-				want_ctr[s * 4 + 1] += rd64(r + 136) ? 1 : 0;
-				want_ctr[s * 4 + 2] += sent;
-				want_ctr[s * 4 + 3] += rcvd;
-			} else
-				++want_unknown;
 		}
 		CHECK(gyo_tcp_conn_sketch_batch(batch, (int)n, batch + off, o_hll.data(), o_cms32.data(), o_cms64.data()) == (int)n, "oracle walk of %u records", n);
-		if (with_pair) CHECK(gyo_tcp_conn_pair_batch(batch, (int)n, batch + off, o_pair32.data(), o_pair64.data()) == (int)n, "oracle pair walk");
+		CHECK(gyo_tcp_conn_walk_tallies(batch, (int)n, batch + off, want_tally) == (int)n, "oracle tallies");
+		CHECK(gyo_tcp_conn_svc_counters(batch, (int)n, batch + off, gids.data(), NSVC, want_ctr.data(), &want_unknown) == (int)n, "oracle service counters");
+		if (with_pair)
+			CHECK(gyo_tcp_conn_pair_batch(batch, (int)n, batch + off, o_pair32.data(), o_pair64.data(), o_cpair32.data(), o_cpair64.data()) == (int)n, "oracle pair walk");
 
 		ConnP p{};
 		p.batch = batch;
@@ -151,9 +154,17 @@ int main(int argc, char **argv)
 		p.counters = counters.data();
 		p.pair32 = with_pair ? pair32.data() : nullptr;
 		p.pair64 = with_pair ? pair64.data() : nullptr;
+		p.cpair32 = with_pair ? cpair32.data() : nullptr;
+		p.cpair64 = with_pair ? cpair64.data() : nullptr;
 		kemu::launch((n + GYS_CONN_RECS - 1u) / GYS_CONN_RECS, GYS_CONN_THREADS, 0, [&] { k_conn_ingest(p); });
 		CHECK(counters[CTR_CONN_EVENTS] == want_events, "n %u: events %llu, want %llu", n, (unsigned long long)counters[CTR_CONN_EVENTS], (unsigned long long)want_events);
 		CHECK(counters[CTR_CONN_UNKNOWN] == want_unknown, "n %u: unknown %llu, want %llu", n, (unsigned long long)counters[CTR_CONN_UNKNOWN], (unsigned long long)want_unknown);
+		CHECK(counters[CTR_CONN_NEW] == want_tally[0] && counters[CTR_CONN_CLOSED] == want_tally[1] && counters[CTR_CONN_CLOSED_NO_NOTIFY] == want_tally[2] &&
+			      counters[CTR_CONN_CLI_SIDE] == want_tally[3],
+		      "n %u: walk tallies new %llu closed %llu closed-without-notify %llu client-side %llu, want %llu %llu %llu %llu", n,
+		      (unsigned long long)counters[CTR_CONN_NEW], (unsigned long long)counters[CTR_CONN_CLOSED], (unsigned long long)counters[CTR_CONN_CLOSED_NO_NOTIFY],
+		      (unsigned long long)counters[CTR_CONN_CLI_SIDE], (unsigned long long)want_tally[0], (unsigned long long)want_tally[1],
+		      (unsigned long long)want_tally[2], (unsigned long long)want_tally[3]);
 		for (uint32_t k = 0; k < NREG; ++k) CHECK(hll32[k] == o_hll[k], "n %u: HLL register %u is %u, oracle %u", n, k, hll32[k], o_hll[k]);
 		if (call % 3u == 0) { // a window boundary every third call: the accumulators of several calls fold at once
 			kemu::launch((NSVC + 255u) / 256u, 256, 0, [&] { k_conn_fold(svc_win.data(), svc_ctr.data(), gids.data(), NSVC, cms32.data(), cms64.data()); });
@@ -168,6 +179,8 @@ int main(int argc, char **argv)
 		for (uint32_t k = 0; k < NCMS; ++k) {
 			CHECK(pair32[k] == o_pair32[k], "n %u: pair32[%u] %u, oracle %u", n, k, pair32[k], o_pair32[k]);
 			CHECK(pair64[k] == o_pair64[k], "n %u: pair64[%u] %llu, oracle %llu", n, k, pair64[k], (unsigned long long)o_pair64[k]);
+			CHECK(cpair32[k] == o_cpair32[k], "n %u: client-side pair32[%u] %u, oracle %u", n, k, cpair32[k], o_cpair32[k]);
+			CHECK(cpair64[k] == o_cpair64[k], "n %u: client-side pair64[%u] %llu, oracle %llu", n, k, cpair64[k], (unsigned long long)o_cpair64[k]);
 		}
 	}
 	kemu::launch((NSVC + 255u) / 256u, 256, 0, [&] { k_conn_fold(svc_win.data(), svc_ctr.data(), gids.data(), NSVC, cms32.data(), cms64.data()); });

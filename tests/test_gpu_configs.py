@@ -282,7 +282,8 @@ def test_c2_conn_and_listener_state_full_size(torch_mod, oracle):
     nh, sp, n = 1000, 100, 1 << 20
     eng = _engine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False)
     mids = _register_bulk(eng, nh, sp)
-    rec = wire.synth_tcp_conns(rng, n, np.arange(nh), sp, dup_frac=0.2, v6_frac=0.05)
+    truth = {}
+    rec = wire.synth_tcp_conns(rng, n, np.arange(nh), sp, dup_frac=0.2, v6_frac=0.05, truth=truth)
     raw = rec.tobytes()
     d_batch = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda()
     d_off = torch.arange(0, n * 280, 280, dtype=torch.int32, device="cuda")
@@ -311,15 +312,15 @@ def test_c2_conn_and_listener_state_full_size(torch_mod, oracle):
     assert (eng.export_hll() == hll).all()
     assert (eng.export_cms(0).ravel() == cms32).all()
     assert (eng.export_cms(1).ravel().astype(np.uint64) == cms64).all()
-    # exact per-service counters vs numpy group-by on ser_glob_id_
+    # exact per-service counters vs the generator's CONNECTION table (slot = h * sp + s): every connection once -- whether it was
+    # reported at its open and again at its close, by one half or by both, or as a loopback record -- with its closes and its bytes
     ctr = eng.export_svc_counters()
-    slot_of = {int(g): h * sp + s for h in range(nh) for s, g in enumerate(wire.glob_id(np.full(sp, h), np.arange(sp)))}
-    slots = np.array([slot_of[int(g)] for g in rec["ser_glob_id"]])
-    assert (ctr[:, 0] == np.bincount(slots, minlength=nh * sp)).all()
-    assert (ctr[:, 1] == np.bincount(slots, weights=(rec["tusec_close"] != 0), minlength=nh * sp).astype(np.uint64)).all()
-    for col, f in ((2, "bytes_sent"), (3, "bytes_rcvd")):
+    slots = truth["conn_host"].astype(np.int64) * sp + truth["conn_svc"]
+    assert (ctr[:, 0] == np.bincount(slots, minlength=nh * sp)).all() and len(slots) < n
+    assert (ctr[:, 1] == np.bincount(slots[truth["conn_closed"]], minlength=nh * sp)).all()
+    for col, f in ((2, "conn_bytes_sent"), (3, "conn_bytes_rcvd")):
         exp = np.zeros(nh * sp, dtype=np.uint64)
-        np.add.at(exp, slots, rec[f])
+        np.add.at(exp, slots, truth[f])
         assert (ctr[:, col] == exp).all()
     # distinct flows vs the exact tuple set
     keys = np.concatenate([np.ascontiguousarray(rec[f]).view(np.uint8).reshape(n, 32) for f in ("nat_cli", "nat_ser")], axis=1)

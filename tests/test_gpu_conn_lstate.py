@@ -38,18 +38,28 @@ def _oracle_conn(oracle, batch, n, hll, cms32, cms64, known):
                                 oracle.ptr(gid, oracle.u64p), oracle.ptr(bs, oracle.u64p), oracle.ptr(br, oracle.u64p), oracle.ptr(fl, oracle.u8p))
     assert got == n
     ctr = {}
+    nlistener = 0
     for i in range(n):
         w = kw[i * 10:i * 10 + nw[i]]
         L.gyo_hll_add_words(oracle.ptr(hll, oracle.u8p), 14, oracle.ptr(w, oracle.u32p), int(nw[i]))
+        # flag bits of gyo_tcp_conn_decode: 1 connect event, 2 accept event, 4 loopback, 8 pre-existing, 16 notified before.  A connection counts
+        # once: on the record of its ACCEPTING half (or of neither kind: the walk treats it as the server's, gy_mconnhdlr.cc:9333) whose
+        # notified_before_ is clear
+        f = int(fl[i])
+        if not ((f & 2) or not (f & 1)):
+            continue
+        nlistener += 1
         gw = oracle.glob_id_words(int(gid[i]))
-        L.gyo_cms_add(oracle.ptr(cms32, oracle.u32p), oracle.ptr(gw, oracle.u32p), 2, 1)
-        L.gyo_cms64_add(oracle.ptr(cms64, oracle.u64p), oracle.ptr(gw, oracle.u32p), 2, int(bs[i]) + int(br[i]))
+        if not (f & 16):
+            L.gyo_cms_add(oracle.ptr(cms32, oracle.u32p), oracle.ptr(gw, oracle.u32p), 2, 1)
+        if int(bs[i]) + int(br[i]):
+            L.gyo_cms64_add(oracle.ptr(cms64, oracle.u64p), oracle.ptr(gw, oracle.u32p), 2, int(bs[i]) + int(br[i]))
         if int(gid[i]) in known:
             c = ctr.setdefault(int(gid[i]), [0, 0, 0, 0])
-            c[0] += 1
+            c[0] += 0 if (f & 16) else 1
             c[2] += int(bs[i])
             c[3] += int(br[i])
-    return ctr, gid
+    return ctr, gid, nlistener
 
 
 def test_tcp_conn_info_v4_v6_variable_stride(torch_mod, oracle):
@@ -64,6 +74,8 @@ def test_tcp_conn_info_v4_v6_variable_stride(torch_mod, oracle):
     exact = {}
     nclose = {}
     tuples = set()
+    nlistener = nknown = 0
+    tally = np.zeros(4, dtype=np.uint64)
     for rnd in range(3):
         for h in range(nh):
             n = int(rng.integers(1, 2049))  # MAX_NUM_CONNS = 2048 per message
@@ -71,14 +83,20 @@ def test_tcp_conn_info_v4_v6_variable_stride(torch_mod, oracle):
             tails = [bytes(rng.integers(32, 127, int(k), dtype=np.uint8).tolist()) for k in rng.integers(0, 257, n) * (rng.random(n) < 0.3)]
             batch = wire.pack_variable(rec, tails)
             eng.partha_tcp_conn_info(info[h][0], batch, n)
-            ctr, gid = _oracle_conn(oracle, batch, n, hll, cms32, cms64, known)
+            ctr, gid, nl = _oracle_conn(oracle, batch, n, hll, cms32, cms64, known)
+            nlistener += nl
+            bb = np.frombuffer(batch, dtype=np.uint8)
+            assert oracle.lib().gyo_tcp_conn_walk_tallies(bb.ctypes.data, n, bb.ctypes.data + len(bb), oracle.ptr(tally, oracle.u64p)) == n
             for g, c in ctr.items():
                 e = exact.setdefault(g, [0, 0, 0, 0])
                 for k in range(4):
                     e[k] += c[k]
             for i in range(n):
-                if int(rec["ser_glob_id"][i]) in known and rec["tusec_close"][i]:
-                    nclose[int(rec["ser_glob_id"][i])] = nclose.get(int(rec["ser_glob_id"][i]), 0) + 1
+                lis = rec["is_tcp_accept_event"][i] or not rec["is_tcp_connect_event"][i]
+                if lis and int(rec["ser_glob_id"][i]) in known:
+                    nknown += 1
+                    if rec["tusec_close"][i]:
+                        nclose[int(rec["ser_glob_id"][i])] = nclose.get(int(rec["ser_glob_id"][i]), 0) + 1
                 tuples.add((rec["nat_cli"][i].tobytes(), rec["nat_ser"][i].tobytes()))
     eng.window_close()
     assert (eng.export_hll() == hll).all()
@@ -89,7 +107,10 @@ def test_tcp_conn_info_v4_v6_variable_stride(torch_mod, oracle):
         s = eng.lookup(g)
         assert ctrs[s].tolist() == [e[0], nclose.get(g, 0), e[2], e[3]]
     c = eng.counters()
-    assert c["conn_unknown_service"] > 0 and c["conn_events"] == sum(v[0] for v in exact.values()) + c["conn_unknown_service"]
+    assert c["conn_unknown_service"] > 0 and nlistener == nknown + c["conn_unknown_service"]
+    # the walk's own tallies (nnew / nclosed / nclosed_no_not of gy_mconnhdlr.cc:9133-9137, :9327) and the connecting-half records
+    assert [c["conn_new"], c["conn_closed"], c["conn_closed_no_notify"], c["conn_client_side"]] == tally.tolist()
+    assert c["conn_events"] == c["conn_new"] + c["conn_closed"] and c["conn_client_side"] == c["conn_events"] - nlistener > 0
     # HLL estimate vs the exact distinct flow count (ground truth = exact set over the key bytes): p=14 -> ~0.8 % std error
     est = eng.distinct_flows()
     assert abs(est - len(tuples)) / len(tuples) < 0.05
@@ -279,6 +300,62 @@ def test_active_conn_stats_pair_countmin_and_listener_sums(oracle):
     eng.close()
 
 
+def test_active_conn_stats_staggered_reports_stay_visible_for_three_windows(oracle):
+    """Parthas report ACTIVE_CONN_STATS every 15 s on phases of their own and a window is 5 s (server/gy_mconnhdlr.cc:7714): a window carries
+    only the hosts that reported in it.  The queries read the per-cell MAXIMUM of the last three windows' tables: every host that reported in
+    the last 15 s is visible with at least its reported value (Count-Min never under-estimates), a host that reported twice inside the three
+    windows is not counted twice, and a host silent for three windows ages out.  Expected tables: numpy max over the oracle's per-window tables."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    rng = np.random.default_rng(47)
+    nh, sp = 3, 8
+    eng = _engine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False)
+    for h in range(nh):
+        mid = wire.machine_id(h)
+        eng.register_host(mid, "c")
+        s = np.arange(sp)
+        eng.register_listeners_np(mid, wire.glob_id(np.full(sp, h), s), wire.listener_netns(h, s), wire.listener_port(s))
+    L = oracle.lib()
+    # which hosts report in which window: host h on phase h of the 15-s cycle, host 0 once more out of turn (window 4), then silence
+    plan = [[0], [1], [2], [0], [0, 1], [2], [], [], [], [], [1]]
+    tabs32, tabs64, recs = [], [], []
+    for w, hosts in enumerate(plan):
+        p32 = np.zeros((4, 65536), dtype=np.uint32)
+        p64 = np.zeros((4, 65536), dtype=np.uint64)
+        wrec = {}
+        for h in hosts:
+            n = int(rng.integers(200, 900))
+            rec = wire.synth_active_conns(rng, n, h, sp)
+            raw = rec.tobytes()
+            eng.handle_partha_active_conns(wire.machine_id(h), raw, n)
+            o2 = np.zeros(2, dtype=np.uint64)
+            buf = np.frombuffer(raw, dtype=np.uint8)
+            L.gyo_active_conn_sketch_batch(oracle.ptr(buf, oracle.u8p), n, oracle.ptr(p32, oracle.u32p), oracle.ptr(p64, oracle.u64p), oracle.ptr(o2, oracle.u64p))
+            wrec[h] = rec[(rec["flags"] & wire.ACTIVE_FLAG_REMOTE_LISTEN) == 0]
+        tabs32.append(p32)
+        tabs64.append(p64)
+        recs.append(wrec)
+        eng.window_close()
+        lo = max(0, w - 2)
+        want32 = np.maximum.reduce(tabs32[lo:w + 1])
+        want64 = np.maximum.reduce(tabs64[lo:w + 1])
+        assert (eng.export_pair_cms(0) == want32).all(), w
+        assert (eng.export_pair_cms(1).view(np.uint64) == want64).all(), w
+        # every host that reported within the last three windows: its LATEST report reads back at least its exact per-pair totals
+        latest = {}
+        for ww in range(lo, w + 1):
+            latest.update(recs[ww])
+        for h, lr in latest.items():
+            for k in rng.integers(0, len(lr), 4):
+                g, t = int(lr["listener_glob_id"][k]), int(lr["cli_aggr_task_id"][k])
+                sel = (lr["listener_glob_id"] == g) & (lr["cli_aggr_task_id"] == t)
+                assert eng.pair_cms(g, t, 0) >= int(lr["active_conns"][sel].sum()), (w, h)
+        if w == 9:  # four windows of silence: everything has aged out
+            assert not eng.export_pair_cms(0).any() and not eng.export_pair_cms(1).any()
+    eng.close()
+
+
 def test_tcp_conn_pair_countmin_opt_in(oracle):
     """gys_config.conn_pair_cms (connlistenmap_ / connclientmap_ roll-up): TCP_CONN_NOTIFY records also feed the
     (listener, client task group) Count-Min pair, bit-exact vs the oracle; off by default (tables stay zero)"""
@@ -296,22 +373,31 @@ def test_tcp_conn_pair_countmin_opt_in(oracle):
             e.register_listeners_np(mid, wire.glob_id(np.full(sp, h), s), wire.listener_netns(h, s), wire.listener_port(s))
     p32 = np.zeros((4, 65536), dtype=np.uint32)
     p64 = np.zeros((4, 65536), dtype=np.uint64)
+    c32 = np.zeros((4, 65536), dtype=np.uint32)
+    c64 = np.zeros((4, 65536), dtype=np.uint64)
     L = oracle.lib()
+    nlis = ncli = 0
     for h in range(nh):
         rec = wire.synth_tcp_conns(rng, n, [h], sp, dup_frac=0.3)
         rec["cli_task_aggr_id"] = wire.splitmix64(rng.integers(0, 25, n).astype(np.uint64) + np.uint64(h << 8))
+        # what connlistenmap_ / connclientmap_ take (gy_mconnhdlr.cc:9182, :9226, :9290): closed records with bytes, by half
+        cb = (rec["tusec_close"] != 0) & (rec["bytes_sent"] + rec["bytes_rcvd"] > 0)
+        nlis += int((cb & (rec["is_tcp_accept_event"] != 0) & (rec["ser_glob_id"] != 0)).sum())
+        ncli += int((cb & (rec["is_tcp_accept_event"] == 0) & (rec["is_tcp_connect_event"] != 0)).sum())
         tails = [bytes(rng.integers(32, 127, int(k), dtype=np.uint8).tolist()) for k in rng.integers(0, 40, n) * (rng.random(n) < 0.3)]
         payload = wire.pack_variable(rec, tails)
         for e in engs.values():
             e.partha_tcp_conn_info(wire.machine_id(h), payload, n)
         buf = np.frombuffer(payload, dtype=np.uint8)
         got = L.gyo_tcp_conn_pair_batch(oracle.ptr(buf, oracle.u8p), n, C.cast(buf.ctypes.data + len(buf), oracle.u8p), oracle.ptr(p32, oracle.u32p),
-                                        oracle.ptr(p64, oracle.u64p))
+                                        oracle.ptr(p64, oracle.u64p), oracle.ptr(c32, oracle.u32p), oracle.ptr(c64, oracle.u64p))
         assert got == n
     for e in engs.values():
         e.window_close()
     assert (engs[True].export_pair_cms(2) == p32).all() and (engs[True].export_pair_cms(3).view(np.uint64) == p64).all()
-    assert p32.sum(axis=1).tolist() == [nh * n] * 4  # every row counts every connection once
+    assert (engs[True].export_pair_cms(4) == c32).all() and (engs[True].export_pair_cms(5).view(np.uint64) == c64).all()
+    # every row counts every closed connection once, on the side that reported it
+    assert p32.sum(axis=1).tolist() == [nlis] * 4 and c32.sum(axis=1).tolist() == [ncli] * 4 and nlis > 0 and ncli > 0
     # the ACTIVE_CONN_STATS tables are a different roll-up with cells of their own: connection notifications never reach them
     assert engs[True].export_pair_cms(0).sum() == 0 and engs[True].export_pair_cms(1).sum() == 0
     assert engs[False].export_pair_cms(0).sum() == 0 and engs[False].export_pair_cms(1).sum() == 0

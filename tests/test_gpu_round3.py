@@ -445,7 +445,8 @@ def test_c5_bench_shape_large_keys_over_several_pool_rounds(torch_mod, oracle, m
 
 def test_c2_full_record_count(torch_mod, oracle):
     """BASELINE config 2 at its full 2^24 TCP_CONN_NOTIFY records per window (16 device-resident chunks of 2^20; 1 000 hosts x 100
-    services): HLL and both Count-Min tables bit-exact vs the C oracle over all chunks, per-service connection counters vs numpy"""
+    services): HLL and both Count-Min tables bit-exact vs the C oracle over all chunks; per-service connection counters == the number of
+    CONNECTIONS the generator made (open + close notifications, accepting and connecting halves, loopback records: each connection once)"""
     import ctypes as C
     from gyeeta_amd import capi
     torch = torch_mod
@@ -461,9 +462,13 @@ def test_c2_full_record_count(torch_mod, oracle):
     cms32 = np.zeros(4 * 65536, dtype=np.uint32)
     cms64 = np.zeros(4 * 65536, dtype=np.uint64)
     nconn = np.zeros(nh * sp, dtype=np.int64)
+    nclose = np.zeros(nh * sp, dtype=np.int64)
+    tally = np.zeros(4, dtype=np.uint64)
+    nconns_total = 0
     d_off = torch.arange(0, chunk * 280, 280, dtype=torch.int32, device="cuda")
     for k in range(nchunks):
-        rec = wire.synth_tcp_conns(rng, chunk, np.arange(nh), sp, dup_frac=0.2, v6_frac=0.05)
+        truth = {}
+        rec = wire.synth_tcp_conns(rng, chunk, np.arange(nh), sp, dup_frac=0.2, v6_frac=0.05, truth=truth)
         raw = rec.tobytes()
         d_batch = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda()
         eng.order()
@@ -471,20 +476,21 @@ def test_c2_full_record_count(torch_mod, oracle):
         buf = np.frombuffer(raw, dtype=np.uint8)
         assert oracle.lib().gyo_tcp_conn_sketch_batch(buf.ctypes.data, chunk, buf.ctypes.data + len(buf), oracle.ptr(hll, oracle.u8p),
                                                        oracle.ptr(cms32, oracle.u32p), oracle.ptr(cms64, oracle.u64p)) == chunk
-        g = rec["ser_glob_id"]
-        # wire.glob_id(h, s) is one-to-one with the registration order: slot = h * sp + s
-        if k == 0:
-            gid_all = np.concatenate([wire.glob_id(np.full(sp, h), s_) for h in range(nh)])
-            order = np.argsort(gid_all)
-            gid_sorted = gid_all[order]
-        pos = np.searchsorted(gid_sorted, g)
-        known = (pos < len(gid_sorted)) & (gid_sorted[np.minimum(pos, len(gid_sorted) - 1)] == g)
-        nconn += np.bincount(order[pos[known]], minlength=nh * sp)
+        assert oracle.lib().gyo_tcp_conn_walk_tallies(buf.ctypes.data, chunk, buf.ctypes.data + len(buf), oracle.ptr(tally, oracle.u64p)) == chunk
+        # ground truth = the generator's connection table (registration order: slot = h * sp + s), not the records' flag bytes
+        slot = truth["conn_host"].astype(np.int64) * sp + truth["conn_svc"]
+        nconn += np.bincount(slot, minlength=nh * sp)
+        nclose += np.bincount(slot[truth["conn_closed"]], minlength=nh * sp)
+        nconns_total += len(slot)
         eng.sync()  # (the chunk's device buffer is released by torch once it goes out of scope)
     eng.window_close()
     assert (eng.export_hll() == hll).all()
     assert (eng.export_cms(0).ravel() == cms32).all()
     assert (eng.export_cms(1).ravel().astype(np.uint64) == cms64).all()
-    assert (eng.export_svc_counters()[:, 0].astype(np.int64) == nconn).all()
-    assert eng.counters()["conn_events"] == chunk * nchunks
+    ctr = eng.export_svc_counters()
+    assert (ctr[:, 0].astype(np.int64) == nconn).all() and int(ctr[:, 0].sum()) == nconns_total < chunk * nchunks
+    assert (ctr[:, 1].astype(np.int64) == nclose).all()
+    c = eng.counters()
+    assert c["conn_events"] == chunk * nchunks
+    assert [c["conn_new"], c["conn_closed"], c["conn_closed_no_notify"], c["conn_client_side"]] == tally.tolist()
     eng.close()
