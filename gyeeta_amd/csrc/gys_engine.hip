@@ -27,6 +27,7 @@
 #include "gys_kernels.hpp"
 #include "gys_rollup.hpp"
 #include "gys_huge.hpp"
+#include "gys_svcquery.hpp"
 
 using namespace gys;
 
@@ -323,6 +324,14 @@ struct gys_ctx {
 	std::vector<uint16_t> svc_port_h; // listener port per service slot (web_curr_top_listeners "port")
 	uint32_t *topn_slot = nullptr;
 	uint64_t *topn_metric = nullptr;
+	// filtered multi-host listener-state query (gys_svcquery.hpp): scratch, grow-only
+	unsigned long long *q_cand_key = nullptr, *q_out_keys = nullptr;
+	uint32_t *q_cand_slot = nullptr, *q_misc = nullptr, *q_host_mask = nullptr;
+	int32_t *q_set = nullptr;
+	uint8_t *q_out_rows = nullptr;
+	long long *q_acc = nullptr;
+	unsigned long long *q_cnt = nullptr;
+	uint64_t q_cand_cap = 0, q_out_cap = 0, q_mask_cap = 0, q_set_cap = 0, q_acc_cap = 0;
 	float *dev_pcts = nullptr;
 	float *zipf_cdf = nullptr;
 	uint32_t zipf_n = 0, zipf_milli = 0;
@@ -1889,7 +1898,7 @@ void gys_destroy(gys_ctx *c)
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_claim, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
-			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->ring_act32, c->ring_act64, c->act_live, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
+			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->ring_act32, c->ring_act64, c->act_live, c->q_cand_key, c->q_out_keys, c->q_cand_slot, c->q_misc, c->q_host_mask, c->q_set, c->q_out_rows, c->q_acc, c->q_cnt, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_first, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -3949,3 +3958,4 @@ try {
 } // extern "C"
 
 #include "gys_json.hpp"
+#include "gys_svcquery_host.hpp"

@@ -1991,7 +1991,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		// (integer-millisecond response times repeat: ~860 buffered values hold ~200 distinct ones) instead of one per value, and one
 		// packed add per (bin, output cluster).  Thread t takes bins t, t + 256, t + 512, t + 768: the busy low bins spread over all waves.
 #ifndef GYS_MB_GROUP
-#define GYS_MB_GROUP 2u // the thread's four bins searched GROUP at a time (1, 2 or 4): the 8 dependent LDS reads of one threshold search overlap the others'
+#define GYS_MB_GROUP 1u // the thread's four bins searched GROUP at a time (1, 2 or 4): with 2 / 4 the 8 dependent LDS reads of one threshold search overlap the others' -- measured in round 4 (profiles/r4a_ab_paired_search_and_tests.txt): 4.71 / 4.75 / 4.85 ms for 2 / 1 / 4 at full size, 1.265 / 1.255 / 1.281 at quarter size: no gain, the per-bin pass is not bound by that chain; 1 = the plain form stays the default
 #endif
 		constexpr uint32_t MBG = SCAN ? 1u : GYS_MB_GROUP; // (the scan form sits at 63 VGPRs: left as it was)
 #pragma unroll
