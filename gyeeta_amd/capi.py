@@ -96,6 +96,31 @@ class TDigestSlab(C.Structure):
 ROLLUP_HOST, ROLLUP_CLUSTER, ROLLUP_GLOBAL = 0, 1, 2
 
 
+class SvcTerm(C.Structure):   # gys_svc_term
+    _fields_ = [("col", C.c_uint8), ("comp", C.c_uint8), ("group", C.c_uint8), ("reserved", C.c_uint8), ("nvalues", C.c_uint32),
+                ("set_first", C.c_uint32), ("reserved2", C.c_uint32), ("value", C.c_int64)]
+
+
+class SvcFilter(C.Structure):  # gys_svc_filter
+    _fields_ = [("terms", C.POINTER(SvcTerm)), ("nterms", C.c_uint32), ("nset_values", C.c_uint32), ("set_values", C.POINTER(C.c_int64)),
+                ("group_oper", C.c_uint8 * 8), ("top_oper", C.c_uint8), ("reserved", C.c_uint8 * 3), ("nmachine_ids", C.c_uint32),
+                ("machine_ids", C.POINTER(C.c_uint8))]
+
+
+class SvcRow(C.Structure):     # gys_svc_row
+    _fields_ = [("slot", C.c_uint32), ("host_slot", C.c_uint32), ("rec", C.c_uint8 * 88)]
+
+
+class SvcAggrRow(C.Structure):  # gys_svc_aggr_row
+    _fields_ = [("group", C.c_uint32), ("ncols", C.c_uint32), ("count", C.c_uint64), ("sum", C.c_int64 * 8), ("min", C.c_int64 * 8), ("max", C.c_int64 * 8)]
+
+
+SVC_COLS = ["qps5s", "nqry5s", "resp5s", "p95resp5s", "p95resp5m", "nconns", "nactive", "nprocs", "kbin15s", "kbout15s", "sererr", "clierr", "delayus",
+            "cpudelus", "iodelus", "vmdelus", "usercpu", "syscpu", "rssmb", "nissue", "state", "issue", "ishttp"]  # GYS_SVC_COL_* in order
+COMP = {"=": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "bit2": 6, "bit3": 7, "in": 12, "notin": 13}  # GYS_COMP_* (COMPARATORS_E numbering)
+AOPER = {"sum": 1, "avg": 2, "max": 3, "min": 4, "count": 5, "bool_or": 9, "bool_and": 10}  # GYS_AOPER_* (AGGR_OPER_E numbering)
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("resp_events", "resp_dropped_range", "resp_dropped_nolistener", "conn_events",
                                           "conn_unknown_service", "lstate_records", "lstate_missed", "lstate_errors", "lstate_deleted",
@@ -106,6 +131,7 @@ class Counters(C.Structure):
 
 
 assert C.sizeof(HistRec) == 256 and C.sizeof(TopnEntry) == 104 and C.sizeof(RespSeg) == 16 and C.sizeof(ListenerDayStats) == 48
+assert C.sizeof(SvcTerm) == 24 and C.sizeof(SvcRow) == 96 and C.sizeof(SvcAggrRow) == 208
 
 vp, u8p, u32p, u64p, i64p, i32p, f32p, f64p = (C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                                C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double))
@@ -173,6 +199,11 @@ SIGNATURES = {
     "gys_json_svcstate": (C.c_int, [vp, mid, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_json_clusterstate": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gys_json_toplisteners": (C.c_int, [vp, mid, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gys_query_svcstate_scan": (C.c_int, [vp, C.POINTER(SvcFilter), C.c_int, C.c_int, C.c_uint32, C.POINTER(SvcRow), u32p, u64p]),
+    "gys_json_svcstate_multihost": (C.c_int, [vp, C.POINTER(SvcFilter), C.c_int, C.c_int, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t,
+                                              C.POINTER(C.c_size_t)]),
+    "gys_query_svcstate_aggr": (C.c_int, [vp, C.POINTER(SvcFilter), C.c_int, u8p, C.c_uint32, C.POINTER(SvcAggrRow), C.c_uint32, u32p]),
+    "gys_svc_aggr_value": (C.c_int, [C.POINTER(SvcAggrRow), C.c_uint32, C.c_int, f64p]),
     "gys_num_services": (C.c_uint32, [vp]),
     "gys_num_hosts": (C.c_uint32, [vp]),
     "gys_lookup_service": (C.c_int, [vp, C.c_uint64, u32p]),

@@ -331,7 +331,7 @@ struct gys_ctx {
 	uint8_t *q_out_rows = nullptr;
 	long long *q_acc = nullptr;
 	unsigned long long *q_cnt = nullptr;
-	uint64_t q_cand_cap = 0, q_out_cap = 0, q_mask_cap = 0, q_set_cap = 0, q_acc_cap = 0;
+	uint64_t q_cand_cap = 0, q_slot_cap = 0, q_out_cap = 0, q_okeys_cap = 0, q_mask_cap = 0, q_set_cap = 0, q_acc_cap = 0, q_cnt_cap = 0;
 	float *dev_pcts = nullptr;
 	float *zipf_cdf = nullptr;
 	uint32_t zipf_n = 0, zipf_milli = 0;

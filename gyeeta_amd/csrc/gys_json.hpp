@@ -124,6 +124,56 @@ void hostinfo_object(gys_ctx *c, JsonBuf &j, uint32_t host, const char *madid)
 	j.obj_close();
 }
 
+// one svcstate object in the reference's column order (json_db_svcstate_arr common/gy_json_field_maps.h:1102-1135, values as
+// SvcStateFields::print_field writes them server/gy_mfields.h:1560-1700); multi = the four host columns first (get_all_column_list)
+void svcstate_object(gys_ctx *c, JsonBuf &j, const uint8_t *r, uint32_t slot, uint32_t host, bool multi, const char *mad, const char *timestr)
+{
+	auto u32 = [&](int off) { uint32_t v; memcpy(&v, r + off, 4); return v; };
+	uint64_t glob_id;
+	memcpy(&glob_id, r, 8);
+	uint16_t ntasks_issue;
+	memcpy(&ntasks_issue, r + 76, 2);
+	const uint32_t nq = u32(8);
+	char idbuf[24];
+	snprintf(idbuf, sizeof(idbuf), "%016llx", (unsigned long long)glob_id);
+	j.obj_open();
+	if (multi) {
+		j.kstr("parid", machid_string(c->hosts[host]));
+		j.kstr("host", c->host_names[host]);
+		j.kstr("madid", mad, 16);
+		j.kstr("cluster", c->cluster_names[c->host_cluster_h[host]]);
+	}
+	j.kstr("time", timestr ? timestr : "", 64);
+	j.kstr("svcid", idbuf, 16);
+	j.kstr("name", c->svc_comm[slot].data(), 16);
+	j.ku("qps5s", nq / 5);
+	j.ku("nqry5s", nq);
+	j.ku("resp5s", u32(12) / (nq > 0 ? nq : 1));
+	j.ku("p95resp5s", u32(28));
+	j.ku("p95resp5m", u32(32));
+	j.ku("nconns", u32(16));
+	j.ku("nactive", u32(20));
+	j.ku("nprocs", u32(24));
+	j.ku("kbin15s", u32(36));
+	j.ku("kbout15s", u32(40));
+	j.ku("sererr", u32(44));
+	j.ku("clierr", u32(48));
+	j.ku("delayus", u32(52));
+	j.ku("cpudelus", u32(56));
+	j.ku("iodelus", u32(60));
+	// int64_t vmdelus = the UNSIGNED 32-bit difference of the three fields; printed when > 0 (server/gy_mfields.h:1648-1654): the wrapped value
+	j.ku("vmdelus", (uint32_t)(u32(52) - u32(56) - u32(60)));
+	j.ku("usercpu", u32(64));
+	j.ku("syscpu", u32(68));
+	j.ku("rssmb", u32(72));
+	j.ku("nissue", ntasks_issue);
+	j.kstr("state", state_string(r[79]), 8);
+	j.ku("issue", r[80]);
+	j.kb("ishttp", r[78] != 0);
+	j.kstr("desc", "", 0); // the variable-length issue string is not retained by the engine
+	j.obj_close();
+}
+
 } // namespace
 
 extern "C" {
@@ -194,48 +244,13 @@ int gys_json_svcstate(gys_ctx *c, const uint8_t machine_id[16], const char *madh
 		HIPCHK(hipStreamSynchronize(c->stream));
 		for (uint32_t slot : hl.all_slots) {
 			const uint8_t *r = recs.data() + (size_t)(slot - lo) * 96;
-			auto u32 = [&](int off) { uint32_t v; memcpy(&v, r + off, 4); return v; };
 			uint64_t glob_id, tag;
 			memcpy(&glob_id, r, 8);
 			memcpy(&tag, r + 88, 8);
 			const uint32_t ep = (uint32_t)tag;
 			// the reference lists listeners whose state is at most 10 s old (:4660 min_stats_tusec): the current or the last window here
 			if (ep == 0 || ep + 1 < c->epoch || (uint32_t)(tag >> 32) != host || glob_id != c->svc_gid_h[slot]) continue;
-			uint16_t ntasks_issue;
-			memcpy(&ntasks_issue, r + 76, 2);
-			const uint32_t nq = u32(8);
-			const long long vmdel = (long long)u32(52) - (long long)u32(56) - (long long)u32(60);
-			char idbuf[24];
-			snprintf(idbuf, sizeof(idbuf), "%016llx", (unsigned long long)glob_id);
-			j.obj_open();
-			j.kstr("time", timestr ? timestr : "", 64);
-			j.kstr("svcid", idbuf, 16);
-			j.kstr("name", c->svc_comm[slot].data(), 16);
-			j.ku("qps5s", nq / 5);
-			j.ku("nqry5s", nq);
-			j.ku("resp5s", u32(12) / (nq > 0 ? nq : 1));
-			j.ku("p95resp5s", u32(28));
-			j.ku("p95resp5m", u32(32));
-			j.ku("nconns", u32(16));
-			j.ku("nactive", u32(20));
-			j.ku("nprocs", u32(24));
-			j.ku("kbin15s", u32(36));
-			j.ku("kbout15s", u32(40));
-			j.ku("sererr", u32(44));
-			j.ku("clierr", u32(48));
-			j.ku("delayus", u32(52));
-			j.ku("cpudelus", u32(56));
-			j.ku("iodelus", u32(60));
-			j.ku("vmdelus", vmdel > 0 ? (unsigned long long)vmdel : 0ull);
-			j.ku("usercpu", u32(64));
-			j.ku("syscpu", u32(68));
-			j.ku("rssmb", u32(72));
-			j.ku("nissue", ntasks_issue);
-			j.kstr("state", state_string(r[79]), 8);
-			j.ku("issue", r[80]);
-			j.kb("ishttp", r[78] != 0);
-			j.kstr("desc", "", 0); // the variable-length issue string is not retained by the engine
-			j.obj_close();
+			svcstate_object(c, j, r, slot, host, false, mad, timestr);
 		}
 	}
 	j.arr_close();

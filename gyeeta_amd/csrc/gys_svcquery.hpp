@@ -102,8 +102,7 @@ __device__ __forceinline__ bool svc_term_match(const SvcTerm &t, int32_t v, cons
 	case SVC_COMP_BIT3: return (v & 7) == 7;
 	case SVC_COMP_IN:
 	case SVC_COMP_NOTIN: {
-		const bool bret = t.comp == SVC_COMP_IN;
-		if (!set_values) return false;
+		const bool bret = t.comp == SVC_COMP_IN; // (an empty value list: IN matches nothing, NOTIN everything)
 		for (uint32_t i = 0; i < t.nvalues; ++i)
 			if (set_values[t.set_first + i] == v) return bret;
 		return !bret;

@@ -1,0 +1,300 @@
+// gys_svcquery_host.hpp -- host side of the filtered multi-host listener-state query (kernels: gys_svcquery.hpp).  Included once by
+// gys_engine.hip behind gys_json.hpp (uses gys_ctx and the JSON writer).
+//
+//   gys_query_svcstate_scan       MCONN_HANDLER::web_curr_listener_state with QUERY_OPTIONS{criteria_, maxrecs_, sortcolarr_[0], sortdir_[0],
+//                                 is_multihost_}  server/gy_mnodehandle.cc:4650-4900, common/gy_query_common.h:24-140
+//   gys_json_svcstate_multihost   the same as JSON: {"madid", "svcstate":[{parid, host, madid, cluster, <json_db_svcstate_arr columns>}...]}
+//                                 (multi-host column list: QUERY_OPTIONS::get_all_column_list common/gy_query_common.h:418-437)
+//   gys_query_svcstate_aggr       the aggregation operators AGGR_OPER_E (common/gy_json_field_maps.h:114-129) over the matching records
+#pragma once
+
+namespace {
+
+template <typename T>
+int q_grow(T **p, uint64_t *cap, uint64_t need)
+{
+	if (*cap >= need && *p) return GYS_OK;
+	if (*p) HIPCHK(hipFree(*p));
+	*p = nullptr;
+	*cap = 0;
+	const uint64_t n = std::max<uint64_t>(need, 1);
+	HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+	*cap = n;
+	return GYS_OK;
+}
+
+// q_misc layout (u32 words): [0] candidate cursor, [1] want, [2] out count, [4..5] prefix (u64), [8 .. 8 + 2048) digit histogram
+constexpr uint32_t QM_CURSOR = 0, QM_WANT = 1, QM_OUT = 2, QM_PREFIX = 4, QM_HIST = 8, QM_WORDS = 8 + GYS_SVCQ_RADIX;
+
+// validates the caller's filter and fills the kernel-side copy (terms converted to the column's own type, as the reference converts a
+// criterion to the field's type before comparing: match_num_criterian<int>, `pnumarray_[i].get<Num>()` common/gy_query_criteria.h:1243-1283)
+template <typename P>
+int q_fill_filter(gys_ctx *c, const gys_svc_filter *f, P &p)
+{
+	p.svc_state = c->svc_state;
+	p.svc_host = c->svc_host;
+	p.svc_gid = c->svc_gid;
+	p.nsvc = c->nsvc;
+	p.epoch = c->epoch;
+	p.host_mask = nullptr;
+	p.set_values = nullptr;
+	p.nterms = 0;
+	p.ngroups = 0;
+	p.top_oper = 0;
+	memset(p.group_oper, 0, sizeof(p.group_oper));
+	if (!f) return GYS_OK;
+	if (f->nterms > GYS_SVCQ_MAX_TERMS || (f->nterms && !f->terms)) {
+		set_err("filter: at most %u terms", GYS_SVCQ_MAX_TERMS);
+		return GYS_ERR_INVAL;
+	}
+	std::vector<int32_t> setv;
+	for (uint32_t i = 0; i < f->nterms; ++i) {
+		const gys_svc_term &t = f->terms[i];
+		const bool in = t.comp == GYS_COMP_IN || t.comp == GYS_COMP_NOTIN;
+		if (t.col >= GYS_SVC_NCOLS || t.group >= GYS_SVCQ_MAX_GROUPS || !(t.comp <= GYS_COMP_BIT3 || in)) {
+			set_err("filter term %u: column %u / comparator %u / group %u out of range", i, t.col, t.comp, t.group);
+			return GYS_ERR_INVAL;
+		}
+		if (in && ((uint64_t)t.set_first + t.nvalues > f->nset_values || (t.nvalues && !f->set_values))) {
+			set_err("filter term %u: value set outside set_values", i);
+			return GYS_ERR_INVAL;
+		}
+		SvcTerm &d = p.terms[i];
+		d.col = t.col;
+		d.comp = t.comp;
+		d.group = t.group;
+		d.pad = 0;
+		d.nvalues = in ? t.nvalues : 0;
+		d.set_first = (uint32_t)setv.size();
+		// the column's own type: int16_t for `issue` (server/gy_mfields.h:1435), int for the others
+		auto conv = [&](int64_t v) -> int32_t { return t.col == GYS_SVC_COL_ISSUE ? (int32_t)(int16_t)v : (int32_t)v; };
+		d.value = conv(t.value);
+		for (uint32_t k = 0; k < d.nvalues; ++k) setv.push_back(conv(f->set_values[t.set_first + k]));
+		p.ngroups = std::max<uint32_t>(p.ngroups, (uint32_t)t.group + 1u);
+	}
+	p.nterms = f->nterms;
+	for (uint32_t g = 0; g < GYS_SVCQ_MAX_GROUPS; ++g) p.group_oper[g] = f->group_oper[g] ? 1 : 0;
+	p.top_oper = f->top_oper ? 1u : 0u;
+	if (!setv.empty()) {
+		int rc = q_grow(&c->q_set, &c->q_set_cap, setv.size());
+		if (rc) return rc;
+		HIPCHK(hipMemcpyAsync(c->q_set, setv.data(), setv.size() * 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream)); // (setv is a local)
+		p.set_values = c->q_set;
+	}
+	if (f->nmachine_ids) { // the query names its hosts (is_multihost_ with host criteria: the walk over partha_tbl_ :4790-4860)
+		if (!f->machine_ids) return GYS_ERR_INVAL;
+		const uint64_t words = ((uint64_t)c->hosts.size() + 31) / 32 + 1;
+		std::vector<uint32_t> mask(words, 0);
+		for (uint32_t i = 0; i < f->nmachine_ids; ++i) {
+			uint32_t h;
+			if (lookup_host(c, f->machine_ids + (size_t)i * 16, &h) == GYS_OK) mask[h >> 5] |= 1u << (h & 31u); // (an unknown host matches nothing)
+		}
+		int rc = q_grow(&c->q_host_mask, &c->q_mask_cap, words);
+		if (rc) return rc;
+		HIPCHK(hipMemcpyAsync(c->q_host_mask, mask.data(), words * 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		p.host_mask = c->q_host_mask;
+	}
+	return GYS_OK;
+}
+
+// runs the scan; rows (ordered) and keys land in host vectors
+int q_scan(gys_ctx *c, const gys_svc_filter *f, int sort_col, int sort_desc, uint32_t maxrecs, std::vector<gys_svc_row> &rows, uint64_t *nmatched)
+{
+	rows.clear();
+	if (nmatched) *nmatched = 0;
+	if (sort_col >= (int)GYS_SVC_NCOLS) {
+		set_err("sort column %d out of range", sort_col);
+		return GYS_ERR_INVAL;
+	}
+	if (!c->nsvc || !maxrecs) return GYS_OK;
+	int rc;
+	static_assert(sizeof(gys_svc_row) == 96, "row layout");
+	if ((rc = q_grow(&c->q_cand_key, &c->q_cand_cap, c->nsvc)) != GYS_OK) return rc;
+	if ((rc = q_grow(&c->q_cand_slot, &c->q_slot_cap, c->nsvc)) != GYS_OK) return rc;
+	if (!c->q_misc) HIPCHK(hipMalloc((void **)&c->q_misc, QM_WORDS * 4));
+	HIPCHK(hipMemsetAsync(c->q_misc, 0, QM_WORDS * 4, c->stream));
+	const uint32_t k = (uint32_t)std::min<uint64_t>(maxrecs, c->nsvc);
+	if ((rc = q_grow(&c->q_out_rows, &c->q_out_cap, (uint64_t)k * 96)) != GYS_OK) return rc;
+	if ((rc = q_grow(&c->q_out_keys, &c->q_okeys_cap, k)) != GYS_OK) return rc;
+	ProfScope ps(c, "svc_filter");
+	SvcFilterP p{};
+	if ((rc = q_fill_filter(c, f, p)) != GYS_OK) return rc;
+	p.sort_col = sort_col;
+	p.sort_desc = sort_desc ? 1u : 0u;
+	p.cand_key = c->q_cand_key;
+	p.cand_slot = c->q_cand_slot;
+	p.cursor = c->q_misc + QM_CURSOR;
+	const uint32_t per_wg = GYS_SVCQ_THREADS * GYS_SVCQ_PER_THREAD;
+	hipLaunchKernelGGL(k_svc_filter, dim3((c->nsvc + per_wg - 1) / per_wg), dim3(GYS_SVCQ_THREADS), 0, c->stream, p);
+	uint32_t ncand = 0;
+	HIPCHK(hipMemcpyAsync(&ncand, c->q_misc + QM_CURSOR, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (nmatched) *nmatched = ncand;
+	if (!ncand) return GYS_OK;
+	const uint32_t ntake = std::min(ncand, k);
+	const bool select = ncand > k;
+	if (select) { // exact top-k: the k-th largest key, 11 bits per round, every round's bin chosen on the device
+		SvcSelectP sp{};
+		sp.cand_key = c->q_cand_key;
+		sp.ncand = c->q_misc + QM_CURSOR;
+		sp.hist = c->q_misc + QM_HIST;
+		sp.prefix = (unsigned long long *)(c->q_misc + QM_PREFIX);
+		sp.want = c->q_misc + QM_WANT;
+		HIPCHK(hipMemcpyAsync(c->q_misc + QM_WANT, &k, 4, hipMemcpyHostToDevice, c->stream));
+		const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)ncand + 256u * 16u - 1) / (256u * 16u), (uint64_t)c->ncu * 4);
+		static const uint32_t shifts[GYS_SVCQ_ROUNDS] = {53, 42, 31, 20, 9, 0}, widths[GYS_SVCQ_ROUNDS] = {11, 11, 11, 11, 11, 9};
+		for (uint32_t r = 0; r < GYS_SVCQ_ROUNDS; ++r) {
+			sp.shift = shifts[r];
+			sp.bits = widths[r];
+			hipLaunchKernelGGL(k_svc_hist, dim3(std::max(1u, grid)), dim3(256), 0, c->stream, sp);
+			hipLaunchKernelGGL(k_svc_pick, dim3(1), dim3(256), 0, c->stream, sp);
+		}
+	}
+	SvcGatherP gp{};
+	gp.svc_state = c->svc_state;
+	gp.cand_key = c->q_cand_key;
+	gp.cand_slot = c->q_cand_slot;
+	gp.ncand = c->q_misc + QM_CURSOR;
+	gp.threshold = select ? (const unsigned long long *)(c->q_misc + QM_PREFIX) : nullptr;
+	gp.maxout = k;
+	gp.out_count = c->q_misc + QM_OUT;
+	gp.out_rows = c->q_out_rows;
+	gp.out_keys = c->q_out_keys;
+	const uint32_t ggrid = (uint32_t)std::min<uint64_t>(((uint64_t)ncand + 255u) / 256u, (uint64_t)c->ncu * 8);
+	hipLaunchKernelGGL(k_svc_gather, dim3(std::max(1u, ggrid)), dim3(256), 0, c->stream, gp);
+	HIPCHK(hipGetLastError());
+	uint32_t nout = 0;
+	HIPCHK(hipMemcpyAsync(&nout, c->q_misc + QM_OUT, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (nout != ntake) {
+		set_err("svcstate scan: selected %u records, expected %u", nout, ntake);
+		return GYS_ERR_INTERNAL;
+	}
+	std::vector<gys_svc_row> raw(nout);
+	std::vector<unsigned long long> keys(nout);
+	HIPCHK(hipMemcpyAsync(raw.data(), c->q_out_rows, (uint64_t)nout * 96, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(keys.data(), c->q_out_keys, (uint64_t)nout * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	std::vector<uint32_t> order(nout);
+	for (uint32_t i = 0; i < nout; ++i) order[i] = i;
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] > keys[b]; }); // (keys are unique)
+	rows.resize(nout);
+	for (uint32_t i = 0; i < nout; ++i) rows[i] = raw[order[i]];
+	return GYS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int gys_query_svcstate_scan(gys_ctx *c, const gys_svc_filter *f, int sort_col, int sort_desc, uint32_t maxrecs, gys_svc_row *out, uint32_t *nout,
+			    uint64_t *nmatched)
+try {
+	GYS_ENTER(c);
+	if (!c || !nout || (maxrecs && !out)) return GYS_ERR_INVAL;
+	*nout = 0;
+	std::vector<gys_svc_row> rows;
+	const int rc = q_scan(c, f, sort_col, sort_desc, maxrecs, rows, nmatched);
+	if (rc) return rc;
+	if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(gys_svc_row));
+	*nout = (uint32_t)rows.size();
+	return GYS_OK;
+} GYS_CATCH_ALL
+
+int gys_json_svcstate_multihost(gys_ctx *c, const gys_svc_filter *f, int sort_col, int sort_desc, uint32_t maxrecs, const char *madhava_id16,
+				const char *timestr, char *buf, size_t buflen, size_t *needed)
+try {
+	GYS_ENTER(c);
+	if (!c) return GYS_ERR_INVAL;
+	std::vector<gys_svc_row> rows;
+	const int rc = q_scan(c, f, sort_col, sort_desc, maxrecs, rows, nullptr);
+	if (rc) return rc;
+	const char *mad = madhava_id16 ? madhava_id16 : "";
+	JsonBuf j;
+	j.s += '{';
+	j.kstr("madid", mad, 16);
+	j.arr_open("svcstate");
+	for (const gys_svc_row &r : rows) svcstate_object(c, j, r.rec, r.slot, r.host_slot, true, mad, timestr);
+	j.arr_close();
+	j.s += '}';
+	return json_out(j, buf, buflen, needed);
+} GYS_CATCH_ALL
+
+int gys_query_svcstate_aggr(gys_ctx *c, const gys_svc_filter *f, int group_by, const uint8_t *cols, uint32_t ncols, gys_svc_aggr_row *out, uint32_t maxrows,
+			    uint32_t *nrows)
+try {
+	GYS_ENTER(c);
+	if (!c || !nrows || (maxrows && !out) || (ncols && !cols) || ncols > GYS_SVCQ_MAX_AGGR || group_by < 0 || group_by > 2) return GYS_ERR_INVAL;
+	*nrows = 0;
+	for (uint32_t a = 0; a < ncols; ++a)
+		if (cols[a] >= GYS_SVC_NCOLS) return GYS_ERR_INVAL;
+	const uint32_t ngroups = group_by == 0 ? 1u : group_by == 1 ? (uint32_t)c->hosts.size() : (uint32_t)c->cluster_names.size();
+	if (!c->nsvc || !ngroups) return GYS_OK;
+	const uint32_t nc = std::max(ncols, 1u);
+	int rc;
+	if ((rc = q_grow(&c->q_acc, &c->q_acc_cap, (uint64_t)ngroups * nc * 3)) != GYS_OK) return rc;
+	if ((rc = q_grow(&c->q_cnt, &c->q_cnt_cap, ngroups)) != GYS_OK) return rc;
+	std::vector<long long> init((size_t)ngroups * nc * 3);
+	for (size_t i = 0; i < init.size(); i += 3) {
+		init[i] = 0;
+		init[i + 1] = std::numeric_limits<long long>::max();
+		init[i + 2] = std::numeric_limits<long long>::min();
+	}
+	HIPCHK(hipMemcpyAsync(c->q_acc, init.data(), init.size() * 8, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(c->q_cnt, 0, (uint64_t)ngroups * 8, c->stream));
+	ProfScope ps(c, "svc_aggr");
+	SvcAggrP p{};
+	if ((rc = q_fill_filter(c, f, p)) != GYS_OK) return rc;
+	p.group_by = (uint32_t)group_by;
+	p.host_cluster = c->host_cluster;
+	p.ncols = ncols;
+	for (uint32_t a = 0; a < ncols; ++a) p.cols[a] = cols[a];
+	p.acc = c->q_acc;
+	p.count = c->q_cnt;
+	const uint32_t per_wg = GYS_SVCQ_THREADS * GYS_SVCQ_PER_THREAD;
+	hipLaunchKernelGGL(k_svc_aggr, dim3((c->nsvc + per_wg - 1) / per_wg), dim3(GYS_SVCQ_THREADS), 0, c->stream, p);
+	HIPCHK(hipGetLastError());
+	std::vector<unsigned long long> cnt(ngroups);
+	HIPCHK(hipMemcpyAsync(init.data(), c->q_acc, init.size() * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(cnt.data(), c->q_cnt, (uint64_t)ngroups * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	uint32_t n = 0;
+	for (uint32_t g = 0; g < ngroups; ++g) {
+		if (!cnt[g]) continue; // a group without a matching record has no row (SQL GROUP BY)
+		if (n < maxrows) {
+			gys_svc_aggr_row &r = out[n];
+			memset(&r, 0, sizeof(r));
+			r.group = g;
+			r.ncols = ncols;
+			r.count = cnt[g];
+			for (uint32_t a = 0; a < ncols; ++a) {
+				const long long *v = &init[((size_t)g * nc + a) * 3];
+				r.sum[a] = v[0];
+				r.min[a] = v[1];
+				r.max[a] = v[2];
+			}
+		}
+		++n;
+	}
+	*nrows = n; // (more than maxrows: the caller sees how many there are)
+	return GYS_OK;
+} GYS_CATCH_ALL
+
+int gys_svc_aggr_value(const gys_svc_aggr_row *row, uint32_t col_index, int oper, double *out)
+{
+	if (!row || !out || col_index >= GYS_SVC_MAX_AGGR || (oper != GYS_AOPER_COUNT && col_index >= row->ncols)) return GYS_ERR_INVAL;
+	switch (oper) { // AGGR_OPER_E common/gy_json_field_maps.h:114-129
+	case GYS_AOPER_SUM: *out = (double)row->sum[col_index]; return GYS_OK;
+	case GYS_AOPER_AVG: *out = row->count ? (double)row->sum[col_index] / (double)row->count : 0.0; return GYS_OK;
+	case GYS_AOPER_MAX: *out = (double)row->max[col_index]; return GYS_OK;
+	case GYS_AOPER_MIN: *out = (double)row->min[col_index]; return GYS_OK;
+	case GYS_AOPER_COUNT: *out = (double)row->count; return GYS_OK;
+	case GYS_AOPER_BOOL_OR: *out = row->max[col_index] != 0 || row->min[col_index] != 0 ? 1.0 : 0.0; return GYS_OK;   // some value is non-zero
+	case GYS_AOPER_BOOL_AND: *out = (row->min[col_index] > 0 || row->max[col_index] < 0) ? 1.0 : 0.0; return GYS_OK; // no value is zero (exact for the >= 0 columns)
+	default: return GYS_ERR_INVAL; // percentile / first / last: not order-free reductions of one pass (not built)
+	}
+}
+
+} // extern "C"

@@ -360,6 +360,72 @@ class SketchEngine:
         m = mid_buf(machine_id) if machine_id is not None else None
         return self._json(self.L.gys_json_toplisteners, m, flags, madid.encode(), timestr.encode())
 
+    def _svc_filter(self, terms, group_oper=(), top_oper="and", machine_ids=None):
+        """terms: [(column name, comparator, value or list of values, group = 0)]; group_oper: per group "and" / "or"; -> (SvcFilter, keep-alive)"""
+        terms = list(terms or [])
+        arr = (capi.SvcTerm * max(len(terms), 1))()
+        setv = []
+        for i, t in enumerate(terms):
+            col, comp, val = t[0], t[1], t[2]
+            arr[i].col = capi.SVC_COLS.index(col)
+            arr[i].comp = capi.COMP[comp]
+            arr[i].group = t[3] if len(t) > 3 else 0
+            if comp in ("in", "notin"):
+                arr[i].set_first = len(setv)
+                arr[i].nvalues = len(val)
+                setv += [int(v) for v in val]
+            elif comp not in ("bit2", "bit3"):
+                arr[i].value = int(val)
+        f = capi.SvcFilter()
+        f.terms = arr
+        f.nterms = len(terms)
+        sv = (C.c_int64 * max(len(setv), 1))(*setv)
+        f.set_values = sv
+        f.nset_values = len(setv)
+        for g, o in enumerate(group_oper):
+            f.group_oper[g] = 1 if o == "or" else 0
+        f.top_oper = 1 if top_oper == "or" else 0
+        mids = None
+        if machine_ids:
+            mids = (C.c_uint8 * (16 * len(machine_ids)))(*b"".join(machine_ids))
+            f.machine_ids = mids
+            f.nmachine_ids = len(machine_ids)
+        return f, (arr, sv, mids)
+
+    def svcstate_scan(self, terms=None, group_oper=(), top_oper="and", sort_col=None, sort_desc=True, maxrecs=1000, machine_ids=None):
+        """gys_query_svcstate_scan -> (slots, host slots, records as a numpy array of wire.LISTENER_STATE_NOTIFY, number matched)"""
+        f, keep = self._svc_filter(terms, group_oper, top_oper, machine_ids)
+        out = (capi.SvcRow * max(maxrecs, 1))()
+        nout, nm = C.c_uint32(), C.c_uint64()
+        capi.check(self.L.gys_query_svcstate_scan(self.h, C.byref(f), -1 if sort_col is None else capi.SVC_COLS.index(sort_col), 1 if sort_desc else 0,
+                                                  maxrecs, out, C.byref(nout), C.byref(nm)))
+        raw = np.frombuffer(out, dtype=np.uint8, count=nout.value * 96).reshape(nout.value, 96)
+        slots = raw[:, 0:4].copy().view(np.uint32).ravel()
+        hosts = raw[:, 4:8].copy().view(np.uint32).ravel()
+        recs = raw[:, 8:96].copy().view(wire.LISTENER_STATE_NOTIFY).ravel()
+        return slots, hosts, recs, nm.value
+
+    def json_svcstate_multihost(self, terms=None, group_oper=(), top_oper="and", sort_col=None, sort_desc=True, maxrecs=1000, machine_ids=None,
+                                madid="0" * 16, timestr=""):
+        f, keep = self._svc_filter(terms, group_oper, top_oper, machine_ids)
+        return self._json(self.L.gys_json_svcstate_multihost, C.byref(f), -1 if sort_col is None else capi.SVC_COLS.index(sort_col), 1 if sort_desc else 0,
+                          maxrecs, madid.encode(), timestr.encode())
+
+    def svcstate_aggr(self, cols, group_by=0, terms=None, group_oper=(), top_oper="and", machine_ids=None, maxrows=None):
+        """gys_query_svcstate_aggr -> list of (group, count, {col: (sum, min, max)})"""
+        f, keep = self._svc_filter(terms, group_oper, top_oper, machine_ids)
+        ca = (C.c_uint8 * max(len(cols), 1))(*[capi.SVC_COLS.index(c) for c in cols])
+        if maxrows is None:
+            maxrows = 1 if group_by == 0 else 1 << 16
+        out = (capi.SvcAggrRow * max(maxrows, 1))()
+        n = C.c_uint32()
+        capi.check(self.L.gys_query_svcstate_aggr(self.h, C.byref(f), group_by, ca, len(cols), out, maxrows, C.byref(n)))
+        res = []
+        for i in range(min(n.value, maxrows)):
+            r = out[i]
+            res.append((r.group, r.count, {c: (r.sum[a], r.min[a], r.max[a]) for a, c in enumerate(cols)}))
+        return res
+
     def json_clusterstate(self, shyamaid="0" * 16, timestr=""):
         return self._json(self.L.gys_json_clusterstate, shyamaid.encode(), timestr.encode())
 

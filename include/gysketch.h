@@ -440,6 +440,71 @@ enum { GYS_TOP_ISSUE = 1, GYS_TOP_QPS = 2, GYS_TOP_ACTCONN = 4, GYS_TOP_NET = 8,
 int gys_json_toplisteners(gys_ctx *ctx, const uint8_t machine_id[16], uint32_t flags, const char *madhava_id16, const char *timestr, char *buf,
 			  size_t buflen, size_t *needed);
 
+/* ---- QUERY_OPTIONS on the live listener table: multi-host filter / sort / maxrecs and the aggregation operators --------------------------
+ * Replaces the listener walk of MCONN_HANDLER::web_curr_listener_state (server/gy_mnodehandle.cc:4650-4900: every MTCP_LISTENER of every
+ * partha under RCU, a SvcStateFields per listener, `filter_match` per row, `nrecs >= maxrecs`) for criteria on the numeric columns of
+ * json_db_svcstate_arr (common/gy_json_field_maps.h:1102-1135): ONE device pass over the kept state records of all services.
+ * Columns (SvcStateFields::get_num_field server/gy_mfields.h:1402-1440; every one is compared as an `int`, `issue` as int16_t; `state` is the
+ * numeric OBJ_STATE_E a filter names through statefromjson, `ishttp` 0 / 1): */
+enum { GYS_SVC_COL_QPS5S = 0, GYS_SVC_COL_NQRY5S, GYS_SVC_COL_RESP5S, GYS_SVC_COL_P95RESP5S, GYS_SVC_COL_P95RESP5M, GYS_SVC_COL_NCONNS,
+       GYS_SVC_COL_NACTIVE, GYS_SVC_COL_NPROCS, GYS_SVC_COL_KBIN15S, GYS_SVC_COL_KBOUT15S, GYS_SVC_COL_SERERR, GYS_SVC_COL_CLIERR,
+       GYS_SVC_COL_DELAYUS, GYS_SVC_COL_CPUDELUS, GYS_SVC_COL_IODELUS, GYS_SVC_COL_VMDELUS, GYS_SVC_COL_USERCPU, GYS_SVC_COL_SYSCPU,
+       GYS_SVC_COL_RSSMB, GYS_SVC_COL_NISSUE, GYS_SVC_COL_STATE, GYS_SVC_COL_ISSUE, GYS_SVC_COL_ISHTTP, GYS_SVC_NCOLS };
+/* comparators: the numeric members of COMPARATORS_E with its numbering (common/gy_query_criteria.h:28-46; match_num_criterian :1243-1290) */
+enum { GYS_COMP_EQ = 0, GYS_COMP_NEQ, GYS_COMP_LT, GYS_COMP_LE, GYS_COMP_GT, GYS_COMP_GE, GYS_COMP_BIT2, GYS_COMP_BIT3, GYS_COMP_IN = 12, GYS_COMP_NOTIN = 13 };
+#define GYS_SVC_MAX_TERMS 16
+#define GYS_SVC_MAX_GROUPS 8
+#define GYS_SVC_MAX_AGGR 8
+typedef struct {
+	uint8_t col;        /* GYS_SVC_COL_* */
+	uint8_t comp;       /* GYS_COMP_* */
+	uint8_t group;      /* criteria group of the term: 0 = CRITERIA_SET::l1_grp_, 1.. = its L2 groups (< GYS_SVC_MAX_GROUPS) */
+	uint8_t reserved;
+	uint32_t nvalues;   /* GYS_COMP_IN / NOTIN: the values are set_values[set_first .. set_first + nvalues) of the filter */
+	uint32_t set_first;
+	uint32_t reserved2;
+	int64_t value;      /* the other comparators: converted to the column's own type before the compare, as the reference does */
+} gys_svc_term;
+typedef struct {
+	const gys_svc_term *terms;
+	uint32_t nterms;                         /* 0 = no criteria: every current record is listed (CRIT_SKIP) */
+	uint32_t nset_values;
+	const int64_t *set_values;
+	uint8_t group_oper[GYS_SVC_MAX_GROUPS];  /* per group: 0 = all its terms must match (OPER_AND), 1 = any (OPER_OR); match_criteria_group :1535-1605 */
+	uint8_t top_oper;                        /* how the groups combine: 0 = AND, 1 = OR (CRITERIA_SET::l1_oper_, match_criteria :1806-1900) */
+	uint8_t reserved[3];
+	uint32_t nmachine_ids;                   /* 0 = all hosts (is_multihost_); else only the listeners of these parthas ... */
+	const uint8_t *machine_ids;              /* ... nmachine_ids x 16 bytes */
+} gys_svc_filter;
+typedef struct {
+	uint32_t slot, host_slot; /* service slot (gys_lookup_service) and host slot (gys_register_host) */
+	uint8_t rec[88];          /* the kept comm::LISTENER_STATE_NOTIFY of the listener */
+} gys_svc_row;
+/* The records whose state is current (this or the last window: the reference lists states at most 10 s old, :4660) and that pass the
+ * filter; at most maxrecs of them, ordered by sort_col (GYS_SVC_COL_*; descending when sort_desc) and then by service slot -- sort_col < 0:
+ * by service slot (registration order; the reference's order is that of its hash-table walk).  When more records match than maxrecs the
+ * FIRST maxrecs of that order are returned (an exact top-k on the device).  *nmatched = records that matched. */
+int gys_query_svcstate_scan(gys_ctx *ctx, const gys_svc_filter *filter, int sort_col, int sort_desc, uint32_t maxrecs, gys_svc_row *out,
+			    uint32_t *nout, uint64_t *nmatched);
+/* the same as the reference's multi-host JSON: {"madid":..,"svcstate":[{"parid","host","madid","cluster", then the json_db_svcstate_arr
+ * columns}, ...]} (column list of a multi-host query: QUERY_OPTIONS::get_all_column_list common/gy_query_common.h:418-437) */
+int gys_json_svcstate_multihost(gys_ctx *ctx, const gys_svc_filter *filter, int sort_col, int sort_desc, uint32_t maxrecs,
+				const char *madhava_id16, const char *timestr, char *buf, size_t buflen, size_t *needed);
+/* AGGR_OPER_E (common/gy_json_field_maps.h:114-129) over the records that pass the filter, grouped by nothing (group_by 0: one row,
+ * group 0), by host (1: group = host slot) or by cluster (2: group = cluster index in registration order).  One row per group that has a
+ * matching record, in group order; every row carries count and, per requested column, the exact 64-bit sum, min and max, from which
+ * gys_svc_aggr_value derives the operator: sum, avg (sum / count), max, min, count, bool_or, bool_and.  (percentile / first / last are
+ * not one-pass order-free reductions and are not built.)  *nrows = rows there are (may exceed maxrows; only maxrows are written). */
+enum { GYS_AOPER_SUM = 1, GYS_AOPER_AVG, GYS_AOPER_MAX, GYS_AOPER_MIN, GYS_AOPER_COUNT, GYS_AOPER_BOOL_OR = 9, GYS_AOPER_BOOL_AND = 10 };
+typedef struct {
+	uint32_t group, ncols;
+	uint64_t count;
+	int64_t sum[GYS_SVC_MAX_AGGR], min[GYS_SVC_MAX_AGGR], max[GYS_SVC_MAX_AGGR];
+} gys_svc_aggr_row;
+int gys_query_svcstate_aggr(gys_ctx *ctx, const gys_svc_filter *filter, int group_by, const uint8_t *cols, uint32_t ncols, gys_svc_aggr_row *out,
+			    uint32_t maxrows, uint32_t *nrows);
+int gys_svc_aggr_value(const gys_svc_aggr_row *row, uint32_t col_index, int oper, double *out);
+
 /* The per-listener 5-second scan from the engine's OWN state (needs gys_config.enable_levels): replaces the loop of
  * TCP_SOCK_HANDLER::listener_stats_update (common/gy_socket_stat.cc:4044-4365) that turns every listener's counters and histograms into
  * one comm::LISTENER_STATE_NOTIFY (common/gy_comm_proto.h:2183-2254), and the data-parallel part of TCP_LISTENER::get_curr_state

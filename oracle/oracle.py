@@ -33,7 +33,7 @@ f32p = C.POINTER(C.c_float)
 HIST_SERIAL_DT = np.dtype([("count", "<u8"), ("sum", "<i8")])  # HIST_SERIAL as a numpy record
 
 
-SOURCES = ["gy_oracle.c", "gy_oracle_engine.c", "gy_oracle_levels.c", "gy_oracle_rollup.c", "gy_oracle_lscan.c"]
+SOURCES = ["gy_oracle.c", "gy_oracle_engine.c", "gy_oracle_levels.c", "gy_oracle_rollup.c", "gy_oracle_lscan.c", "gy_oracle_query.c"]
 
 
 def build_oracle(force=False):

@@ -232,6 +232,7 @@ static inline void __builtin_amdgcn_wave_barrier() { kemu::wave().bar.arrive_wai
 #define __expf(x) expf(x)
 
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned int x) { return __builtin_popcount(x); }
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }

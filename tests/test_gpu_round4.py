@@ -1,0 +1,243 @@
+"""GPU parity, round 4: the filtered multi-host listener-state query (QUERY_OPTIONS on the live table: criteria groups, sort, maxrecs, host
+subset, AGGR_OPER_E reductions) against numpy on the records the test fed; the checker restates SvcStateFields::get_num_field
+(server/gy_mfields.h:1402-1440) and CRITERIA_SET::match_criteria (common/gy_query_criteria.h:1535-1605, :1806-1900) independently of the
+kernel."""
+import json
+
+import numpy as np
+import pytest
+
+from gyeeta_amd import capi, wire
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(**kw):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible")
+    from gyeeta_amd.engine import SketchEngine
+    return SketchEngine(**kw)
+
+
+def col_values(rec, col):
+    """the column as the reference compares it: an `int` built from the wire field (unsigned arithmetic first), int16_t for `issue`"""
+    nq = rec["nqrys_5s"].astype(np.uint32)
+    u = {
+        "qps5s": nq // 5, "nqry5s": nq, "resp5s": rec["total_resp_5sec"].astype(np.uint32) // np.maximum(nq, 1),
+        "p95resp5s": rec["p95_5s_resp_ms"], "p95resp5m": rec["p95_5min_resp_ms"], "nconns": rec["nconns"], "nactive": rec["nconns_active"],
+        "nprocs": rec["ntasks"], "kbin15s": rec["curr_kbytes_inbound"], "kbout15s": rec["curr_kbytes_outbound"], "sererr": rec["ser_errors"],
+        "clierr": rec["cli_errors"], "delayus": rec["tasks_delay_usec"], "cpudelus": rec["tasks_cpudelay_usec"], "iodelus": rec["tasks_blkiodelay_usec"],
+        "usercpu": rec["tasks_user_cpu"], "syscpu": rec["tasks_sys_cpu"], "rssmb": rec["tasks_rss_mb"], "nissue": rec["ntasks_issue"],
+        "state": rec["curr_state"], "issue": rec["curr_issue"], "ishttp": (rec["is_http_svc"] != 0),
+    }
+    if col == "vmdelus":
+        with np.errstate(over="ignore"):
+            v = rec["tasks_delay_usec"].astype(np.uint32) - rec["tasks_cpudelay_usec"].astype(np.uint32) - rec["tasks_blkiodelay_usec"].astype(np.uint32)
+        return v.view(np.int32).astype(np.int64)
+    return u[col].astype(np.uint32).view(np.int32).astype(np.int64) if col not in ("issue", "ishttp") else u[col].astype(np.int64)
+
+
+def match(rec, terms, group_oper=(), top_oper="and"):
+    """CRITERIA_SET::match_criteria for criteria of one subsystem: per group all / any of its terms, groups combined by top_oper"""
+    if not terms:
+        return np.ones(len(rec), dtype=bool)
+    groups = {}
+    for t in terms:
+        col, comp, val = t[0], t[1], t[2]
+        g = t[3] if len(t) > 3 else 0
+        v = col_values(rec, col)
+        conv = (lambda x: int(np.int16(np.int64(x) & 0xFFFF)) if False else int(x))
+        if comp in ("in", "notin"):
+            m = np.isin(v, [conv(x) for x in val])
+            m = m if comp == "in" else ~m
+        elif comp == "bit2":
+            m = (v & 3) == 3
+        elif comp == "bit3":
+            m = (v & 7) == 7
+        else:
+            c = conv(val)
+            m = {"=": v == c, "!=": v != c, "<": v < c, "<=": v <= c, ">": v > c, ">=": v >= c}[comp]
+        groups.setdefault(g, []).append(m)
+    res = []
+    for g, ms in sorted(groups.items()):
+        o = group_oper[g] if g < len(group_oper) else "and"
+        res.append(np.logical_or.reduce(ms) if o == "or" else np.logical_and.reduce(ms))
+    return np.logical_or.reduce(res) if top_oper == "or" else np.logical_and.reduce(res)
+
+
+def test_svcstate_filter_sort_topk_and_aggregation_equal_numpy():
+    rng = np.random.default_rng(404)
+    nh, sp = 40, 50
+    eng = _engine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False, max_clusters=4)
+    for cname in ("cl0", "cl1", "cl2"):
+        eng.register_cluster(cname)
+    mids = [wire.machine_id(h) for h in range(nh)]
+    s_ = np.arange(sp)
+    for h in range(nh):
+        eng.register_host(mids[h], "cl%d" % (h % 3))
+        eng.set_host_name(mids[h], "host%03d" % h)
+        eng.register_listeners_np(mids[h], wire.glob_id(np.full(sp, h), s_), wire.listener_netns(h, s_), wire.listener_port(s_))
+
+    def states(h):
+        r = wire.synth_listener_states(rng, h, s_)
+        n = len(r)
+        # widen the value ranges the synthetic generator leaves narrow, incl. values whose `int` view is negative and delay fields whose
+        # unsigned difference wraps
+        r["cli_errors"] = rng.integers(0, 9, n)
+        r["tasks_cpudelay_usec"] = rng.integers(0, 150000, n)
+        r["tasks_blkiodelay_usec"] = rng.integers(0, 50000, n)
+        r["tasks_user_cpu"] = rng.integers(0, 400, n)
+        r["tasks_sys_cpu"] = rng.integers(0, 100, n)
+        r["tasks_rss_mb"] = rng.integers(1, 60000, n)
+        r["ntasks_issue"] = rng.integers(0, 4, n)
+        r["curr_issue"] = rng.integers(0, 20, n)
+        r["is_http_svc"] = rng.integers(0, 2, n)
+        big = rng.random(n) < 0.03
+        r["curr_kbytes_inbound"] = np.where(big, 0xF0000000 + rng.integers(0, 1000, n), r["curr_kbytes_inbound"])
+        return r
+
+    latest = {}
+    for h in range(nh):  # window A: every host
+        r = states(h)
+        eng.partha_listener_state(mids[h], r.tobytes(), sp)
+        latest[h] = r
+    eng.window_close()
+    for h in range(30):  # window B: hosts 0..29 report again -- the others' states will be two windows old
+        r = states(h)
+        r["query_flags"][7] = wire.LISTEN_FLAG_DELETE  # ... and every host deletes one listener
+        eng.partha_listener_state(mids[h], r.tobytes(), sp)
+        latest[h] = r
+    eng.window_close()
+    for h in range(5):  # the open window: hosts 0..4 already reported
+        r = states(h)
+        eng.partha_listener_state(mids[h], r.tobytes(), sp)
+        latest[h] = r
+    eng.sync()
+    # what is current: hosts 0..29, minus the listeners deleted in window B that did not report again
+    rec = np.concatenate([latest[h] for h in range(30)])
+    slot = np.concatenate([np.arange(sp) + h * sp for h in range(30)])
+    host = np.repeat(np.arange(30), sp)
+    alive = np.ones(len(rec), dtype=bool)
+    for h in range(5, 30):
+        alive[h * sp + 7] = False
+    rec, slot, host = rec[alive], slot[alive], host[alive]
+
+    q50 = int(np.median(col_values(rec, "qps5s")))
+    cases = [
+        dict(terms=None),
+        dict(terms=[("qps5s", ">", q50), ("p95resp5s", ">=", 60)]),
+        dict(terms=[("state", "=", 3), ("sererr", ">", 2), ("nissue", "!=", 0)], group_oper=["or"]),
+        dict(terms=[("nactive", "in", [0, 3, 7, 11]), ("kbin15s", "<", 0)], group_oper=["or"]),      # kbin15s < 0: the u32 values above 2^31 as `int`
+        dict(terms=[("issue", "notin", [1, 2, 3]), ("vmdelus", "<", 0), ("ishttp", "=", 1)]),
+        dict(terms=[("nconns", "bit2", 0), ("nprocs", "bit3", 0, 1), ("rssmb", ">", 50000, 1)], group_oper=["and", "or"], top_oper="or"),
+        dict(terms=[("qps5s", ">", q50, 0), ("resp5s", "<=", 20, 0), ("usercpu", ">", 300, 1), ("syscpu", ">", 80, 1), ("delayus", ">=", 50000, 2)],
+             group_oper=["and", "or", "and"], top_oper="and"),
+        dict(terms=[("qps5s", ">=", 0)], machine_ids=[mids[3], mids[17], mids[35], wire.machine_id(999)]),  # host 35: stale, 999: unknown
+    ]
+    for ci, case in enumerate(cases):
+        m = match(rec, case.get("terms"), case.get("group_oper", ()), case.get("top_oper", "and"))
+        if case.get("machine_ids"):
+            m &= np.isin(host, [3, 17])
+        for sort_col, desc in ((None, True), ("qps5s", True), ("p95resp5s", False), ("kbin15s", True), ("vmdelus", False)):
+            if sort_col is None:
+                order = np.argsort(slot[m], kind="stable")
+            else:
+                v = col_values(rec[m], sort_col)
+                order = np.lexsort((slot[m], -v if desc else v))
+            want_slots = slot[m][order]
+            want_recs = rec[m][order]
+            for maxrecs in (len(rec) + 5, 17, 1):
+                gs, gh, gr, nm = eng.svcstate_scan(case.get("terms"), case.get("group_oper", ()), case.get("top_oper", "and"), sort_col, desc, maxrecs,
+                                                   case.get("machine_ids"))
+                assert nm == int(m.sum()), (ci, sort_col, maxrecs, nm, int(m.sum()))
+                k = min(maxrecs, len(want_slots))
+                assert gs.tolist() == want_slots[:k].tolist(), (ci, sort_col, desc, maxrecs)
+                assert (gh == gs // sp).all()
+                assert gr.tobytes() == want_recs[:k].tobytes(), (ci, sort_col, maxrecs)
+        # the aggregation operators over the same matching set: global, per host, per cluster
+        cols = ["qps5s", "resp5s", "kbin15s", "vmdelus", "ishttp", "nactive"]
+        for group_by, gkey in ((0, np.zeros(len(rec), dtype=np.int64)), (1, host), (2, host % 3)):
+            got = eng.svcstate_aggr(cols, group_by, case.get("terms"), case.get("group_oper", ()), case.get("top_oper", "and"), case.get("machine_ids"))
+            want = []
+            for g in np.unique(gkey[m]):
+                sel = m & (gkey == g)
+                want.append((int(g), int(sel.sum()), {c: (int(col_values(rec[sel], c).sum()), int(col_values(rec[sel], c).min()), int(col_values(rec[sel], c).max()))
+                                                    for c in cols}))
+            assert got == want, (ci, group_by)
+    # operator values from a row (AGGR_OPER_E)
+    import ctypes as C
+    f, keep = eng._svc_filter(None)
+    ca = (C.c_uint8 * 2)(capi.SVC_COLS.index("qps5s"), capi.SVC_COLS.index("ishttp"))
+    row = (capi.SvcAggrRow * 1)()
+    n = C.c_uint32()
+    capi.check(eng.L.gys_query_svcstate_aggr(eng.h, C.byref(f), 0, ca, 2, row, 1, C.byref(n)))
+    q = col_values(rec, "qps5s")
+    out = C.c_double()
+    for oper, want in (("sum", float(q.sum())), ("avg", float(q.sum()) / len(q)), ("max", float(q.max())), ("min", float(q.min())), ("count", float(len(q)))):
+        capi.check(eng.L.gys_svc_aggr_value(row, 0, capi.AOPER[oper], C.byref(out)))
+        assert out.value == want, oper
+    capi.check(eng.L.gys_svc_aggr_value(row, 1, capi.AOPER["bool_or"], C.byref(out)))
+    assert out.value == 1.0
+    capi.check(eng.L.gys_svc_aggr_value(row, 1, capi.AOPER["bool_and"], C.byref(out)))
+    assert out.value == 0.0
+    # the multi-host JSON: envelope, the four host columns first, then the reference's svcstate columns; values of the top rows
+    from tests import test_gpu_json as tj
+    js = json.loads(eng.json_svcstate_multihost([("qps5s", ">", q50)], sort_col="qps5s", sort_desc=True, maxrecs=25, madid="ab" * 8, timestr="T"))
+    assert list(js.keys()) == ["madid", "svcstate"] and js["madid"] == "ab" * 8 and len(js["svcstate"]) == 25
+    m = match(rec, [("qps5s", ">", q50)])
+    v = col_values(rec[m], "qps5s")
+    order = np.lexsort((slot[m], -v))
+    for i, row_ in enumerate(js["svcstate"]):
+        assert list(row_.keys()) == ["parid", "host", "madid", "cluster"] + tj.SVCSTATE_COLS
+        s0 = int(slot[m][order][i])
+        r0 = rec[m][order][i]
+        assert row_["svcid"] == "%016x" % int(r0["glob_id"]) and row_["qps5s"] == int(r0["nqrys_5s"]) // 5 and row_["host"] == "host%03d" % (s0 // sp)
+        assert row_["parid"] == "%016x%016x" % (int.from_bytes(mids[s0 // sp][:8], "little"), int.from_bytes(mids[s0 // sp][8:], "little"))
+        assert row_["cluster"] == "cl%d" % ((s0 // sp) % 3)
+        with np.errstate(over="ignore"):
+            vm = int((np.uint32(r0["tasks_delay_usec"]) - np.uint32(r0["tasks_cpudelay_usec"]) - np.uint32(r0["tasks_blkiodelay_usec"])))
+        assert row_["vmdelus"] == vm  # the unsigned 32-bit difference, as the reference prints it (server/gy_mfields.h:1648-1654)
+    # bad arguments
+    with pytest.raises(capi.GysError):
+        eng.svcstate_scan([("qps5s", ">", 1, 9)])
+    eng.close()
+
+
+def test_svcstate_scan_at_scale_top_1000_of_many_services():
+    """10^6 services over 1 000 hosts: filter + exact top-1000 by a column equals numpy; the kernel time is printed (bench.py reports the
+    10^7-service figure)"""
+    import torch
+    rng = np.random.default_rng(405)
+    nh, sp = 1000, 1000
+    eng = _engine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False)
+    s_ = np.arange(sp)
+    recs = []
+    for h in range(nh):
+        mid = wire.machine_id(h)
+        eng.register_host(mid, "c")
+        eng.register_listeners_np(mid, wire.glob_id(np.full(sp, h), s_), wire.listener_netns(h, s_), wire.listener_port(s_))
+    # one device-resident call for all hosts
+    rec = np.concatenate([wire.synth_listener_states(rng, h, s_) for h in range(0, nh, 50)])  # 20 hosts' worth of distinct records ...
+    rec = np.tile(rec, 50)                                                                  # ... repeated (values), with every service's own id
+    rec["glob_id"] = np.concatenate([wire.glob_id(np.full(sp, h), s_) for h in range(nh)])
+    rec["nqrys_5s"] = rng.integers(0, 1 << 22, len(rec))
+    d = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.uint8).copy()).cuda()
+    off = torch.arange(0, len(rec) * 88, 88, dtype=torch.int32, device="cuda")
+    hostl = torch.from_numpy(np.repeat(np.arange(nh, dtype=np.uint32), sp).view(np.int32).copy()).cuda()
+    import ctypes as C
+    eng.order()
+    capi.check(eng.L.gys_ingest_listener_state_dev(eng.h, C.c_void_p(d.data_ptr()), C.c_void_p(off.data_ptr()), C.c_void_p(hostl.data_ptr()), len(rec)))
+    eng.window_close()
+    ok = rec["curr_state"] <= 5
+    m = match(rec, [("qps5s", ">", 1000), ("p95resp5s", ">", 30)]) & ok
+    v = col_values(rec[m], "qps5s")
+    slot = np.arange(len(rec))
+    order = np.lexsort((slot[m], -v))[:1000]
+    eng.profile(True)
+    eng.profile_reset()
+    gs, gh, gr, nm = eng.svcstate_scan([("qps5s", ">", 1000), ("p95resp5s", ">", 30)], sort_col="qps5s", sort_desc=True, maxrecs=1000)
+    prof = eng.profile_get()
+    assert nm == int(m.sum()) and gs.tolist() == slot[m][order].tolist()
+    print("svc_filter: %d services, %d matched, top-1000 in %.3f ms (kernels)" % (len(rec), nm, prof["svc_filter"][0]))
+    eng.close()

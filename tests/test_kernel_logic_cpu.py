@@ -23,6 +23,8 @@ the hot kernels run on synthetic input:
     on records whose bytes are random except the listener id (any state, any flags, counters whose int sums wrap);
   * the per-host top-10 selection k_topn_hosts and the candidate filter k_topn_filter (tests/cpp/kemu/test_topn.cc): hosts of 0 ... 2 700
     listeners, ties, stale and foreign records, all four kinds;
+  * the filtered multi-host listener-state query (tests/cpp/kemu/test_svcquery.cc): k_svc_filter, the radix selection, k_svc_gather and
+    k_svc_aggr on random records / filters / sorts / maxrecs against the oracle's serial walk (oracle/gy_oracle_query.c);
   * the roll-up digests k_digest_rollup (tests/cpp/kemu/test_rollup.cc): groups of services and groups of slabs folded in order, 64-bit
     weights beyond 2^32, members without clusters / without buffered values / empty.
 This does not replace the -m gpu parity tests (no memory model, no execution masks, no timing): it catches logic errors in kernel
@@ -56,6 +58,8 @@ PROGRAMS = {
     "topn-17": ("test_topn.cc", [], ["17"], "kemu topn ok"),
     "rollup-9": ("test_rollup.cc", [], ["9"], "kemu rollup ok"),
     "rollup-10": ("test_rollup.cc", [], ["10"], "kemu rollup ok"),
+    "svcquery-5": ("test_svcquery.cc", [], ["5"], "kemu svcquery ok"),
+    "svcquery-6": ("test_svcquery.cc", [], ["6"], "kemu svcquery ok"),
 }
 
 
