@@ -184,6 +184,13 @@ struct gys_ctx {
 	uint32_t *td_run = nullptr;      // spilled services: fill cursor of the run in `staged`
 	uint32_t *svc_host = nullptr;    // host slot of each service
 	uint32_t *host_spill = nullptr;  // per host: batch stamp of the last batch in which one of its services spilled
+	// predicted runs (k_prespill): start / end of a service's predicted run, the values its last batch brought, "worth predicting" flags of
+	// the previous / this batch, hosts of the running batch, keys whose run goes into the buffer after all
+	uint32_t *td_run0 = nullptr, *td_run1 = nullptr, *td_prevm = nullptr, *pre_hot = nullptr, *host_batch = nullptr;
+	MergeEnt *append_list = nullptr;
+	uint64_t append_cap = 0, staged_cap = 0;
+	uint32_t pre_seq = 0; // k_prespill launches so far (parity = which pre_hot word it reads)
+	bool prespill = false;
 	uint32_t spill_stamp = 0;
 	uint32_t pcap = 0;
 	MergeEnt *merge_list = nullptr, *merge_list_slow = nullptr, *merge_list1 = nullptr, *merge_list2 = nullptr, *huge_list = nullptr, *query_list = nullptr;
@@ -810,6 +817,17 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		fin.host_spill = c->host_spill;
 		fin.counters = c->counters;
 	}
+	// predicted runs: only for the host-local front end, and only when the batch is large enough for a key to overflow a buffer at all
+	const bool pre = td && host_local && c->prespill && n > (uint64_t)c->pcap - GYS_TD_PEND_CAP;
+	if (td && c->prespill) {
+		fin.td_run0 = c->td_run0;
+		fin.td_run1 = c->td_run1;
+		fin.td_prevm = c->td_prevm;
+		fin.hot = c->pre_hot;
+		fin.hot_wr = pre ? ((c->pre_seq & 1u) ^ 1u) : (c->pre_seq & 1u); // the word the NEXT k_prespill reads (this batch's own one, if any, reads the other)
+		fin.append_list = c->append_list;
+		HIPCHK(hipMemsetAsync(c->merge_count + FIN_APPEND, 0, 4, c->stream));
+	}
 	RespHostP hp{};
 	uint32_t hgrid = 0;
 	size_t dyn = 0;
@@ -832,6 +850,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hp.td_pend = c->td_pend;
 		hp.pcap = c->pcap;
 		hp.td_run = c->td_run;
+		hp.td_run1 = c->td_run1;
+		hp.run_delta = (long long)(((intptr_t)c->staged - (intptr_t)c->td_pend) / 4);
 		hp.staged = c->staged;
 		hp.host_spill = c->host_spill;
 		hp.spill_stamp = ++c->spill_stamp;
@@ -896,6 +916,28 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		tpt12 = (tpt == 12 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 6144u) + 160u * 1024u - c->resp_dyn_max <= 80u * 1024u;
 		tpt16 = !tpt12 && (tpt == 16 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 16384u) <= c->resp_dyn_max;
 		dyn = resp_host_lds_bytes(max_tbl, hp.lds_key_entries, tpt12 ? 6144u : tpt16 ? 16384u : 8192u);
+		if (pre) {
+			// runs for the keys whose last batch, repeated, would overflow their buffer (nothing but a flag read when no key was that large)
+			ProfScope ps(c, "prespill");
+			PreSpillP pp{};
+			pp.td_cur = c->td_cur;
+			pp.td_prevm = c->td_prevm;
+			pp.td_run = c->td_run;
+			pp.td_run0 = c->td_run0;
+			pp.td_run1 = c->td_run1;
+			pp.counts = c->merge_count;
+			pp.hot = c->pre_hot;
+			pp.hot_rd = c->pre_seq & 1u;
+			pp.svc_host = c->svc_host;
+			pp.host_batch = c->host_batch;
+			pp.batch_stamp = c->batch_stamp;
+			pp.nsvc = nsvc;
+			pp.pcap = c->pcap;
+			pp.run_limit = (uint32_t)std::min<uint64_t>(c->staged_cap - std::min<uint64_t>(n, c->staged_cap), 0xFFFFFFFFull); // the exact runs of the fall-back (<= n words) keep their room
+			++c->pre_seq;
+			hipLaunchKernelGGL(k_mark_hosts, dim3((nsegs + 255) / 256), dim3(256), 0, c->stream, segs_dev, nsegs, c->host_batch, c->batch_stamp);
+			hipLaunchKernelGGL(k_prespill, dim3((nsvc + 255) / 256), dim3(256), 0, c->stream, pp);
+		}
 		{
 			ProfScope ps(c, "resp_host");
 			if (host_split) {
@@ -968,6 +1010,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		fin.batch_off = host_local ? nullptr : c->batch_off;
 		hipLaunchKernelGGL(k_key_finalize, dim3((nsvc + 255) / 256), dim3(256), 0, c->stream, fin);
 	}
+	if (pre) // keys whose predicted run fits their buffer after all: the run is copied behind the buffered values (before the merges read either)
+		hipLaunchKernelGGL(k_run_append, dim3((uint32_t)c->ncu), dim3(256), 0, c->stream, c->append_list, c->merge_count + FIN_APPEND, c->staged, c->td_pend, c->pcap);
 	// (a key spills / lands in a larger merge class only when THIS batch brought it more values than its buffer had room for: a small
 	// batch -- a partha message of a few thousand events -- cannot, and the launches for those cases are not made)
 	if (host_local && n > (uint64_t)c->pcap - GYS_TD_PEND_CAP) {
@@ -1794,7 +1838,23 @@ try {
 		ALLOC(c->scan_block_sums, (S + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE + 1);
 		ALLOC(c->ev_kv, B);
 		c->ev_kv_cap = B;
-		ALLOC(c->staged, B);
+		// `staged`: the runs of one batch.  With predicted runs (k_prespill) a batch may need the predicted runs (<= 9/8 B: the last batch's
+		// counts plus an eighth) AND the exact runs of the keys the prediction missed (<= B): 9/4 B + slack, while indices stay 32-bit
+		c->prespill = getenv("GYS_NO_PRESPILL") == nullptr && B * 9 / 4 + (1u << 20) < (1ull << 32);
+		c->staged_cap = c->prespill ? B * 9 / 4 + (1u << 20) : B;
+		if ((rc = dev_alloc(&c->staged, c->staged_cap, false)) != GYS_OK) { // (runs are written before they are read)
+			gys_destroy(c);
+			return rc;
+		}
+		if (c->prespill) {
+			ALLOC(c->td_run0, S);
+			ALLOC(c->td_run1, S);
+			ALLOC(c->td_prevm, S);
+			ALLOC(c->pre_hot, 2);
+			ALLOC(c->host_batch, H);
+			c->append_cap = std::min<uint64_t>(S, B / (c->pcap - GYS_TD_PEND_CAP) + 1) + 1;
+			ALLOC(c->append_list, c->append_cap);
+		}
 		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1));
 		if (c->huge_blocks < 1) c->huge_blocks = 1;
 		// the several-workgroup path's pool shares the scratch: 64 KiB of bins per entry, up to 262 144 entries (16 GiB of 288) when the batches can
@@ -1895,7 +1955,7 @@ void gys_destroy(gys_ctx *c)
 	}
 	prof_resolve(c);
 	void *ptrs[] = {c->lk_tbl.ent, c->gid_tbl.ent, c->svc_gid, c->hist_win, c->hist_all, c->bitmap, c->td_sum,
-			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
+			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->td_run0, c->td_run1, c->td_prevm, c->pre_hot, c->host_batch, c->append_list, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_claim, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->ring_act32, c->ring_act64, c->act_live, c->q_cand_key, c->q_out_keys, c->q_cand_slot, c->q_misc, c->q_host_mask, c->q_set, c->q_out_rows, c->q_acc, c->q_cnt, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,

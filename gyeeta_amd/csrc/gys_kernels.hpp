@@ -355,6 +355,7 @@ static_assert(GYS_TD_PEND_CAP == GYS_TDIGEST_PEND_CAP, "gysketch.h and gys_tdige
 static_assert(GYS_TD_NB == GYS_TDIGEST_NB && GYS_TD_NB <= 256, "the merge kernels hold one cluster per thread of a 256-thread group");
 
 #define GYS_SPILL_BIT 0x80000000u // td_cur[slot]: the key's values of the running batch go to a run in `staged`, not to its buffer
+#define GYS_RESPILL_BIT 0x40000000u // ... and that run is filled by the SECOND pass over the host's events (set with GYS_SPILL_BIT at the end of the first)
 #define GYS_MERGE_LDS_MAX 16384u  // largest (buffered + run) value count k_digest_merge handles; larger keys go to k_digest_huge
 #define GYS_PCAP_MAX 16384u
 
@@ -381,6 +382,7 @@ __global__ void k_minmax_init(int2 *mm, uint64_t n)
 #define GYS_MERGE_CLASS1 4096u
 static_assert(GYS_TDIGEST_MERGE_FAST == GYS_MERGE_CLASS0, "the early re-clustering rule keeps a key's merges inside merge size class 0");
 enum { FIN_CLASS0 = 0, FIN_CLASS1, FIN_CLASS2, FIN_HUGE, FIN_RUN_ALLOC, FIN_SLOW, FIN_NCOUNTS }; // FIN_SLOW: k_digest_bins' hand-over list
+#define FIN_APPEND 12 // counts[FIN_APPEND]: length of the append list (keys whose predicted run turned out to fit their buffer; 6..10: the large-key path)
 
 struct FinP {
 	uint32_t *td_cur;
@@ -395,6 +397,15 @@ struct FinP {
 	uint32_t *host_spill;
 	uint32_t spill_stamp;
 	uint64_t *counters;
+	// predicted runs (round 4; nullptr = off): a key whose LAST batch alone would overflow its buffer again gets a run BEFORE the event pass
+	// (k_prespill), so that the pass writes its values once -- a stationary heavy key (a Zipf head) no longer costs a second walk of its
+	// host's events.  td_run0 / td_run1: start and end of the key's predicted run; td_prevm: values the key's last batch brought;
+	// hot[hot_wr]: set when some key's batch was large enough to be predicted next time (read by the next k_prespill);
+	// append_list: keys whose predicted run has to be copied into the buffer after all (the batch was smaller than predicted)
+	const uint32_t *td_run0, *td_run1;
+	uint32_t *td_prevm, *hot;
+	uint32_t hot_wr;
+	MergeEnt *append_list;
 };
 
 // the per-key part: meta record, window event count, spill; returns the merge size class the key is queued for (-1: none) and its entry
@@ -406,6 +417,18 @@ __device__ __forceinline__ int finalize_one(const FinP &p, bool valid, uint32_t 
 	if (valid) {
 		const uint4 mraw = *(const uint4 *)&p.td_meta[key];
 		const uint32_t npend0 = mraw.x;
+		// a key with a predicted run (k_prespill set GYS_SPILL_BIT before the event pass): its count is the run's fill, `cur` stayed at
+		// npend0 | bit.  The run holds every value only if every piece found room (the cursor counts on past the end, pieces are dropped)
+		const bool pre = (cur & GYS_SPILL_BIT) != 0u;
+		uint32_t run0 = 0;
+		bool run_ok = false;
+		if (pre) {
+			run0 = p.td_run0[key];
+			const uint32_t fill = p.td_run[key];
+			run_ok = fill <= p.td_run1[key];
+			cur = npend0 + (fill - run0);
+			if (fill == run0) p.td_cur[key] = npend0; // predicted, but the batch had nothing for the key
+		}
 		if (cur != npend0) {
 			const uint32_t m = cur - npend0;
 			uint32_t nh = mraw.y & 0xFFFFu, nw = mraw.y >> 16, win_epoch = mraw.z;
@@ -414,22 +437,36 @@ __device__ __forceinline__ int finalize_one(const FinP &p, bool valid, uint32_t 
 				win_epoch = p.epoch;
 			}
 			p.resp_win[key] += m; // the key is owned by this thread for the batch
+			if (p.td_prevm) {
+				p.td_prevm[key] = m;
+				if (m > p.pcap - GYS_TD_PEND_CAP) p.hot[p.hot_wr] = 1u; // (same value from every writer)
+			}
 			ent.slot = key;
-			if (cur <= p.pcap) {
+			if (cur <= p.pcap && (!pre || run_ok)) {
+				if (pre) {
+					// predicted too high: the batch fits the buffer after all, and the rule below (append, re-cluster only past
+					// GYS_TD_PEND_CAP) is defined on the buffer -- the run's values are copied behind the buffered ones (k_run_append)
+					const uint32_t at = atomicAdd(&p.counts[FIN_APPEND], 1u);
+					p.append_list[at] = MergeEnt{key, npend0, m, run0 + m};
+				}
 				*(uint4 *)&p.td_meta[key] = make_uint4(cur, nh | (nw << 16), win_epoch, mraw.w);
-				if (WRITE_CUR) p.td_cur[key] = cur;
+				if (WRITE_CUR || pre) p.td_cur[key] = cur;
 				if (cur > GYS_TD_PEND_CAP || cur + m > GYS_TDIGEST_MERGE_FAST) { // (the second: another batch like this one would leave the fast merge class)
 					ent.nbuf = cur;
 					cls = cur <= GYS_MERGE_CLASS0 ? FIN_CLASS0 : cur <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_HUGE; // (> 4096: the several-workgroup path)
 				}
 			} else { // spilled
 				*(uint4 *)&p.td_meta[key] = make_uint4(npend0, nh | (nw << 16), win_epoch, mraw.w);
-				p.td_cur[key] = npend0 | GYS_SPILL_BIT;
 				ent.nbuf = npend0;
 				ent.mrun = m;
-				if (p.batch_off) {
+				if (pre && run_ok) { // the predicted run holds the batch: no second pass for this key
+					p.td_cur[key] = npend0 | GYS_SPILL_BIT;
+					ent.off_end = run0 + m;
+				} else if (p.batch_off) {
+					p.td_cur[key] = npend0 | GYS_SPILL_BIT;
 					ent.off_end = p.batch_off[key];
-				} else {
+				} else { // not predicted, or more values than the predicted run had room for: an exact run, filled by the second pass
+					p.td_cur[key] = npend0 | GYS_SPILL_BIT | GYS_RESPILL_BIT;
 					const uint32_t start = atomicAdd(&p.counts[FIN_RUN_ALLOC], m);
 					p.td_run[key] = start;
 					ent.off_end = start + m;
@@ -512,6 +549,87 @@ __global__ __launch_bounds__(256) void k_key_finalize(FinP p)
 	const bool valid[1] = {k < p.nsvc};
 	const uint32_t key[1] = {k}, cur[1] = {valid[0] ? p.td_cur[k] : 0u};
 	finalize_keys_wg<false, 1>(p, &s_fin, threadIdx.x, threadIdx.x & 63u, valid, key, cur);
+}
+
+// ---------------------------------------------------------------------------------------------------- predicted runs
+// Before the event pass of a batch: a service of one of the batch's hosts whose LAST batch, repeated, would not fit its buffer gets a
+// run in `staged` sized for that count plus an eighth (+ 32), and GYS_SPILL_BIT in td_cur -- the event pass then appends the key's
+// pieces to the run instead of dropping them for a second walk.  What the prediction misses is caught after the pass (finalize_one):
+// more values than the run holds -> exact run + second pass as before; fewer than the buffer has room for -> the run is copied into the
+// buffer (k_run_append).  The digest state only depends on the key's value multiset per call, so the result is the same either way.
+struct PreSpillP {
+	uint32_t *td_cur;
+	const uint32_t *td_prevm;
+	uint32_t *td_run, *td_run0, *td_run1;
+	uint32_t *counts;            // [FIN_RUN_ALLOC]: bump cursor into `staged`
+	uint32_t *hot;               // [2]
+	uint32_t hot_rd;             // hot[hot_rd]: did the previous batch see a key worth predicting?  (hot[hot_rd ^ 1] is cleared for this batch's end)
+	const uint32_t *svc_host, *host_batch;
+	uint32_t batch_stamp;        // host_batch[h] == batch_stamp: host h has a segment in this batch
+	uint32_t nsvc, pcap, run_limit; // run_limit: predicted runs end below it (the exact runs of the fall-back need the rest of `staged`)
+};
+
+__global__ __launch_bounds__(256) void k_prespill(PreSpillP p)
+{
+	__shared__ uint32_t s_w[4], s_base;
+	if (blockIdx.x == 0 && threadIdx.x == 0) p.hot[p.hot_rd ^ 1u] = 0u;
+	if (p.hot[p.hot_rd] == 0u) return; // (uniform: nothing to predict -- the usual case costs one 4-byte read per workgroup)
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t cap = 0, npend0 = 0;
+	if (s < p.nsvc) {
+		const uint32_t prev = p.td_prevm[s];
+		if (prev > p.pcap - GYS_TD_PEND_CAP && p.host_batch[p.svc_host[s]] == p.batch_stamp) {
+			npend0 = p.td_cur[s];
+			if (!(npend0 & GYS_SPILL_BIT) && (uint64_t)npend0 + prev > (uint64_t)p.pcap) cap = prev + (prev >> 3) + 32u;
+		}
+	}
+	// one cursor atomic per workgroup
+	uint32_t inc = cap;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+		if ((int)lane >= d) inc += o;
+	}
+	if (lane == 63u) s_w[wave] = inc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0;
+		for (uint32_t k = 0; k < 4u; ++k) {
+			const uint32_t c = s_w[k];
+			s_w[k] = tot;
+			tot += c;
+		}
+		s_base = tot ? atomicAdd(&p.counts[FIN_RUN_ALLOC], tot) : 0u;
+	}
+	__syncthreads();
+	if (cap) {
+		const uint32_t start = s_base + s_w[wave] + inc - cap;
+		if ((uint64_t)start + cap <= (uint64_t)p.run_limit) { // (else: no prediction for this key; the words stay unused)
+			p.td_run[s] = start;
+			p.td_run0[s] = start;
+			p.td_run1[s] = start + cap;
+			p.td_cur[s] = npend0 | GYS_SPILL_BIT;
+		}
+	}
+}
+
+// the hosts of a batch (the first-pass segments' host slots) get the batch's stamp
+__global__ __launch_bounds__(256) void k_mark_hosts(const gys_resp_seg *segs, uint32_t nsegs, uint32_t *host_batch, uint32_t stamp)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nsegs) host_batch[segs[i].host_slot] = stamp;
+}
+
+// keys whose predicted run has to go into the buffer after all: staged[off_end - mrun .. off_end) -> td_pend[slot * pcap + nbuf ..]; one wave per entry
+__global__ __launch_bounds__(256) void k_run_append(const MergeEnt *list, const uint32_t *count, const uint32_t *staged, uint32_t *td_pend, uint32_t pcap)
+{
+	const uint32_t n = *count, lane = threadIdx.x & 63u;
+	for (uint32_t e = blockIdx.x * 4u + (threadIdx.x >> 6); e < n; e += gridDim.x * 4u) {
+		const MergeEnt ent = list[e];
+		const uint32_t *src = staged + (ent.off_end - ent.mrun);
+		uint32_t *dst = td_pend + (size_t)ent.slot * pcap + ent.nbuf;
+		for (uint32_t i = lane; i < ent.mrun; i += 64u) dst[i] = src[i];
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------- Count-Min rows of the window
@@ -624,7 +742,9 @@ struct RespHostP {
 	uint32_t *td_cur;       // per service: words in its buffer including this batch's (SHARED: reserved with device atomics)
 	uint32_t *td_pend;
 	uint32_t pcap;
-	uint32_t *td_run;       // SPILL: per spilled service the fill cursor of its run in `staged`
+	uint32_t *td_run;       // per service with a run in `staged`: the run's fill cursor (SPILL pass: the exact run; first pass: the predicted run)
+	const uint32_t *td_run1; // first pass: end of a key's predicted run (keys whose td_cur carries GYS_SPILL_BIT at the start of the pass; nullptr: none)
+	long long run_delta;    // staged - td_pend in 4-byte words: a predicted run's index as an index into td_pend (the flush has ONE base pointer)
 	uint32_t *staged;
 	const uint32_t *host_spill; // SPILL: hosts with spilled keys carry spill_stamp
 	uint32_t spill_stamp;
@@ -650,6 +770,7 @@ __host__ __device__ __forceinline__ size_t resp_host_lds_bytes(uint32_t tbl_entr
 #ifndef GYS_RESP_DBG
 #define GYS_RESP_DBG 0 // 1: RespHostP.dbg switches parts of the kernel off (timing experiments only, tools/r3h_phases.sh)
 #endif
+#define GYS_GH_STRIDE 17u // cells per lane slot of the all-service histogram (15 buckets + the spare cell + 1: an odd stride)
 #define GYS_HQ_CAP 512u // HLL candidates queued per tile (late in a window ~0.1 % of a tile's events qualify; the queue is drained by the first GYS_HQ_CAP threads)
 #define GYS_DST_BIAS 65536ull // > the largest tile: (first word of a key's piece) - (start of its run in the image) + bias is positive
 #ifndef GYS_OPAQUE_LOADED4
@@ -667,7 +788,12 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 	__shared__ uint32_t s_wsum[T / 64];
 	__shared__ uint32_t s_drop[2];
 	__shared__ uint32_t s_floor[2]; // HLL floor of the even / odd tiles (refreshed per tile)
-	__shared__ unsigned long long s_gh[T / 64][16]; // per wave and bucket: count << 40 | sum of the wave's events since the last flush
+	// all-service histogram of the window, packed count << 40 | sum per cell.  Round 4: the cells are per (LANE SLOT, bucket), not per (wave,
+	// bucket): the 64 lanes of one add hit at most 15 buckets, i.e. a handful of addresses each taken by many lanes, and LDS atomics on one
+	// address execute one after the other -- measured (profiles/r4b_lds_conflicts_by_access_and_stagger.txt) 36 % of the kernel's bank-conflict
+	// cycles and a quarter of its LDS-active cycles.  Lane l adds into slot l & 15: lanes of one bucket spread over 16 cells; the slot stride
+	// of 17 cells puts the 16 slots of a bucket on 16 different bank pairs.  (Same 2 KB of LDS as the per-wave form: the waves share the cells.)
+	__shared__ unsigned long long s_gh[16 * GYS_GH_STRIDE];
 	__shared__ int32_t s_gmax;
 	__shared__ uint32_t s_bk[GYS_BUCKET_LUT ? 256 : 1];
 	__shared__ uint32_t s_hq[SPILL ? 1 : GYS_HQ_CAP]; // the tile's HLL candidates: register index | rank << 16
@@ -702,12 +828,12 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 		const uint32_t slot = p.hlst[hd.lst_off + k];
 		const uint32_t c = p.td_cur[slot];
 		s_slot[k] = slot;
-		s_cur[k] = SPILL ? (c & GYS_SPILL_BIT) : c;
+		s_cur[k] = SPILL ? (c & GYS_RESPILL_BIT) : c; // (first pass: a key with a predicted run carries GYS_SPILL_BIT here)
 		s_ts2[k] = 0;
 		s_ts2[Lc + k] = 0;
 	}
 	if (tid < 2) s_drop[tid] = 0;
-	if (tid < (T / 64) * 16) ((unsigned long long *)s_gh)[tid] = 0;
+	if (tid < 16u * GYS_GH_STRIDE) s_gh[tid] = 0;
 	if (tid == 0) {
 		s_hqn = 0;
 		s_floor[0] = SPILL ? 0u : 0xFFFFFFFFu;
@@ -879,7 +1005,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 				for (int u = 0; u < 4; ++u) {
 					// all-service histogram of the window (GY_HISTOGRAM::add_data on the aggregate): one packed LDS add per event
 					// (a place that kept nothing adds into the spare cell, which nobody reads: the add itself stays unconditional)
-					if (!(DBG && (p.dbg & 8u))) atomicAdd(&s_gh[wave][bk[u]], (1ull << 40) | (unsigned long long)tresp[u]);
+					if (!(DBG && (p.dbg & 8u))) atomicAdd(&s_gh[(lane & 15u) * GYS_GH_STRIDE + bk[u]], (1ull << 40) | (unsigned long long)tresp[u]);
 					tmax = max(tmax, kept[u] ? (int32_t)tresp[u] : INT32_MIN);
 				}
 				GYS_OPAQUE_LOADED4(w0);
@@ -997,11 +1123,11 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 			}
 			if (!SPILL && (tile_no & 63u) == 63u && tid < 15u) { // keep the packed per-wave sums far from their 40-bit field (no wave adds to them between the event phase and the image barrier)
 				unsigned long long cnt = 0, sum = 0;
-				for (uint32_t w = 0; w < T / 64; ++w) {
-					const unsigned long long v = s_gh[w][tid];
+				for (uint32_t w = 0; w < 16u; ++w) {
+					const unsigned long long v = s_gh[w * GYS_GH_STRIDE + tid];
 					cnt += v >> 40;
 					sum += v & ((1ull << 40) - 1);
-					s_gh[w][tid] = 0;
+					s_gh[w * GYS_GH_STRIDE + tid] = 0;
 				}
 				if (cnt) {
 					atomicAdd(&p.ghist[2 * tid], cnt);
@@ -1019,15 +1145,18 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 					if (SPILL) {
 						base = (uint64_t)atomicAdd(&p.td_run[s_slot[k]], c);
 					} else {
-						uint32_t b;
-						if (SHARED) {
-							b = atomicAdd(&p.td_cur[s_slot[k]], c);
+						uint32_t b = s_cur[k];
+						if (b & GYS_SPILL_BIT) {
+							// the key has a predicted run (k_prespill): the piece goes there, the run's cursor counts the key's values of the
+							// batch; a piece past the run's end is dropped and the end-of-batch pass falls back to an exact run + second pass
+							const uint32_t r = atomicAdd(&p.td_run[s_slot[k]], c);
+							if (r + c <= p.td_run1[s_slot[k]]) base = (uint64_t)(p.run_delta + (long long)r);
 						} else {
-							b = s_cur[k];
-							s_cur[k] = b + c;
+							if (SHARED) b = atomicAdd(&p.td_cur[s_slot[k]], c);
+							else s_cur[k] = b + c;
+							// a piece that does not fit is dropped: the key's count ends above pcap, k_key_finalize then spills the key
+							if ((uint64_t)b + c <= (uint64_t)p.pcap) base = (uint64_t)s_slot[k] * p.pcap + b;
 						}
-						// a piece that does not fit is dropped: the key's count ends above pcap, k_key_finalize then spills the key
-						if ((uint64_t)b + c <= (uint64_t)p.pcap) base = (uint64_t)s_slot[k] * p.pcap + b;
 					}
 					// image entry e of this key goes to dst[base + (e - run)]: kept as the (biased, hence never zero) index entry 0 would have
 					s_dst[k] = base != ~0ull ? base + GYS_DST_BIAS - run : 0ull;
@@ -1107,8 +1236,8 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 	if (tid < 64u) { // (wave 0: the 15 bucket sums, and their total with ONE add -- fifteen adds on the one total cell per workgroup were 1.5 x 10^5 per batch on one address)
 		unsigned long long cnt = 0, sum = 0;
 		if (tid < 15u) {
-			for (uint32_t w = 0; w < T / 64; ++w) {
-				const unsigned long long v = s_gh[w][tid];
+			for (uint32_t w = 0; w < 16u; ++w) {
+				const unsigned long long v = s_gh[w * GYS_GH_STRIDE + tid];
 				cnt += v >> 40;
 				sum += v & ((1ull << 40) - 1);
 			}
@@ -1758,6 +1887,8 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 	// not bound by the latency of their loads; both removed again.  Third form (r3af): meta record + cluster + values requested together and
 	// waited for once (hipcc waits for the meta record before it issues the data loads: three dependent round trips become two): 4.81
 	// against 4.84 ms -- no difference; with the next list entry held in registers across the merge as well: 4.92.  Not kept either.)
+	// (Round 4, r4b: a start delay of 0..7 x 2 us by a hash of the workgroup number -- in case a CU's eight merges run in step and use the
+	// memory path, the LDS and the VALUs one after the other -- changed nothing: 4.84 against 4.82 ms.  Removed.)
 	for (uint32_t w = blockIdx.x; w < nent; w += gridDim.x) {
 		// the thread index is re-derived per entry behind an opaque move: otherwise every LDS address, lane mask and per-bin
 		// bucket the thread uses is hoisted out of this loop and held in registers across it (> 96 VGPRs instead of < 64)

@@ -106,6 +106,11 @@ int main(int argc, char **argv)
 	std::vector<uint64_t> counters(CTR_NUM, 0);
 	std::vector<unsigned long long> ghist(32, 0);
 	long long gmax = INT64_MIN;
+#ifdef KEMU_PRESPILL
+	std::vector<uint32_t> td_run0(nsvc, 0), td_run1(nsvc, 0), td_prevm(nsvc, 0), pre_hot(2, 0), host_batch(NH, 0);
+	std::vector<MergeEnt> append_list(nsvc + 1);
+	uint32_t pre_seq = 0, n_pre_inplace = 0, n_pre_append = 0, n_pre_fallback = 0;
+#endif
 	// the pools of the several-workgroup path (2 entries at a time: a third huge key goes through a second round) and of the fallback
 	const uint32_t maxent = 2, huge_blocks = 1;
 	std::vector<uint32_t> hbins((size_t)maxent * GYS_HB_BINS), hbm((size_t)maxent * 16), chunk_off(maxent + 1), scratch((size_t)huge_blocks * GYS_HUGE_BINS, 0);
@@ -115,7 +120,10 @@ int main(int argc, char **argv)
 	// batch 0: 400 per key (buffered) | 1: enough to pass the buffer's end by 20 (spilled, class 0 from buffer + run) | 2: 700 | 3: 1 500 (spilled, class 1)
 	// | 4: 21 000 per key, a twentieth of them >= 16 384 ms (spilled, the several-workgroup path in three rounds) | 5: 3 more per key
 	// | 6: 20 000 per key, ALL >= 16 384 ms for key 0 (more tail values than the LDS tail takes: the one-workgroup fallback)
-	const uint32_t per_key[] = {400, pcap - 400u + 20u, 700, 1500, 21000, 3, 20000};
+	// | 7, 8: 1 500 and 1 600 per key (spilled, class 1): with predicted runs (KEMU_PRESPILL: k_prespill before the event pass) these two find
+	// their values in the predicted run -- no second pass; batch 4 overflows its predicted run (1 719 words for 21 000 values: the exact-run
+	// fall-back), batch 5 under-runs it (3 values for a run predicted from 21 000: the run is copied into the buffer, k_run_append)
+	const uint32_t per_key[] = {400, pcap - 400u + 20u, 700, 1500, 21000, 3, 20000, 1500, 1600};
 	const uint32_t NB = sizeof(per_key) / sizeof(per_key[0]);
 	uint32_t stamp = 0;
 	for (uint32_t batch = 0; batch < NB; ++batch) {
@@ -173,6 +181,38 @@ int main(int argc, char **argv)
 		fin.host_spill = host_spill.data();
 		fin.spill_stamp = ++stamp;
 		fin.counters = counters.data();
+#ifdef KEMU_PRESPILL
+		fin.td_run0 = td_run0.data();
+		fin.td_run1 = td_run1.data();
+		fin.td_prevm = td_prevm.data();
+		fin.hot = pre_hot.data();
+		fin.hot_wr = (pre_seq & 1u) ^ 1u;
+		fin.append_list = append_list.data();
+		counts[FIN_APPEND] = 0;
+		{
+			PreSpillP pp{};
+			pp.td_cur = td_cur.data();
+			pp.td_prevm = td_prevm.data();
+			pp.td_run = td_run.data();
+			pp.td_run0 = td_run0.data();
+			pp.td_run1 = td_run1.data();
+			pp.counts = counts.data();
+			pp.hot = pre_hot.data();
+			pp.hot_rd = pre_seq & 1u;
+			pp.svc_host = svc_host.data();
+			pp.host_batch = host_batch.data();
+			pp.batch_stamp = stamp + 1u;
+			pp.nsvc = nsvc;
+			pp.pcap = pcap;
+			pp.run_limit = (uint32_t)(staged.size() - n);
+			++pre_seq;
+			kemu::launch(1, 256, 0, [&] { k_mark_hosts(segs.data(), NH, host_batch.data(), stamp + 1u); });
+			kemu::launch((nsvc + 255u) / 256u, 256, 0, [&] { k_prespill(pp); });
+		}
+		uint32_t npred = 0;
+		for (uint32_t s = 0; s < nsvc; ++s) npred += (td_cur[s] & GYS_SPILL_BIT) ? 1u : 0u;
+		CHECK(npred == ((batch == 4 || batch == 5 || batch == 7 || batch == 8) ? L[0] : 0u), "batch %u: %u keys got a predicted run", batch, npred);
+#endif
 		RespHostP hp{};
 		hp.ev = ev64.data();
 		hp.n = n;
@@ -186,6 +226,10 @@ int main(int argc, char **argv)
 		hp.td_pend = td_pend.data();
 		hp.pcap = pcap;
 		hp.td_run = td_run.data();
+#ifdef KEMU_PRESPILL
+		hp.td_run1 = td_run1.data();
+		hp.run_delta = (long long)(((intptr_t)staged.data() - (intptr_t)td_pend.data()) / 4);
+#endif
 		hp.staged = staged.data();
 		hp.host_spill = host_spill.data();
 		hp.spill_stamp = stamp;
@@ -198,7 +242,20 @@ int main(int argc, char **argv)
 		const size_t dyn = resp_host_lds_bytes(max_tbl, hp.lds_key_entries, TILE);
 		kemu::launch(NH, T, dyn, [&] { k_resp_host<TPT, false, false, false>(hp); });
 		CHECK(counts[FIN_RUN_ALLOC] <= staged.size(), "run area too small");
+#ifdef KEMU_PRESPILL
+		// batches 7 and 8 are predicted right (no second pass), batch 4 overflows its predicted runs (second pass), batch 5's runs go into the buffers
 		const bool expect_spill = batch == 1 || batch == 3 || batch == 4 || batch == 6;
+		if (batch == 5) {
+			CHECK(counts[FIN_APPEND] == L[0], "batch 5: %u keys on the append list", counts[FIN_APPEND]);
+			n_pre_append += counts[FIN_APPEND];
+		} else
+			CHECK(counts[FIN_APPEND] == 0, "batch %u: %u keys on the append list", batch, counts[FIN_APPEND]);
+		if (batch == 7 || batch == 8) n_pre_inplace += L[0];
+		if (batch == 4) n_pre_fallback += L[0];
+		kemu::launch(2, 256, 0, [&] { k_run_append(append_list.data(), &counts[FIN_APPEND], staged.data(), td_pend.data(), pcap); });
+#else
+		const bool expect_spill = batch == 1 || batch == 3 || batch == 4 || batch == 6 || batch == 7 || batch == 8;
+#endif
 		CHECK((host_spill[0] == stamp) == expect_spill && host_spill[1] != stamp, "batch %u: host 0 %s flagged as spilled", batch, host_spill[0] == stamp ? "is" : "is not");
 		// second pass over the hosts that have spilled keys: their values into the runs
 		kemu::launch(NH, T, dyn, [&] { k_resp_host<TPT, true, true, false>(hp); });
@@ -243,7 +300,7 @@ int main(int argc, char **argv)
 		kemu::launch(2, 256, 0, [&] { k_digest_merge<GYS_MERGE_CLASS1, 256u>(mp); });
 #endif
 		if (batch == 1) CHECK(counts[FIN_CLASS0] >= L[0], "batch 1: %u class-0 entries (spilled keys merged from buffer + run expected)", counts[FIN_CLASS0]);
-		if (batch == 3) CHECK(counts[FIN_CLASS1] == L[0], "batch 3: %u class-1 entries", counts[FIN_CLASS1]);
+		if (batch == 3 || batch == 7 || batch == 8) CHECK(counts[FIN_CLASS1] == L[0], "batch %u: %u class-1 entries", batch, counts[FIN_CLASS1]);
 		if (batch == 4 || batch == 6) CHECK(counts[FIN_HUGE] == L[0], "batch %u: %u huge entries", batch, counts[FIN_HUGE]);
 		if (counts[FIN_HUGE]) {
 			Huge2P hq{};
@@ -319,6 +376,9 @@ int main(int argc, char **argv)
 		printf("no entry went through tier B of k_huge_merge\n");
 		return 1;
 	}
+#ifdef KEMU_PRESPILL
+	printf("predicted runs: %u keys merged from their predicted run, %u copied into the buffer, %u fell back to the second pass\n", n_pre_inplace, n_pre_append, n_pre_fallback);
+#endif
 	printf("kemu spill ok (tier B entries: %u)\n", tier_b_entries);
 	return 0;
 }

@@ -48,6 +48,7 @@ PROGRAMS = {
     "resp-tiles-6144": ("test_resp.cc", ["KEMU_TPT=12"] + BINS, ["4242"], "kemu resp ok"),
     "resp-split-form": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_SPLIT", "KEMU_NB=3"] + BINS, ["4242"], "kemu resp ok"),
     "spill-and-huge": ("test_spill.cc", BINS, ["777"], "kemu spill ok"),
+    "spill-predicted-runs": ("test_spill.cc", ["KEMU_PRESPILL"] + BINS, ["778"], "kemu spill ok"),
     "conn-31": ("test_conn.cc", [], ["31"], "kemu conn ok"),
     "conn-77": ("test_conn.cc", [], ["77"], "kemu conn ok"),
     "cms-rows": ("test_cms.cc", [], ["5"], "kemu cms ok"),
