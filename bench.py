@@ -336,6 +336,8 @@ def run_sub_configs(names):
                 ent["quantile_error"] = {k: line["quantile_error"][k] for k in ("keys_checked", "p50_rank_err_max", "p99_rank_err_max")}
             if "checks" in line:
                 ent["checks"] = line["checks"]
+            if "cpu_baseline" in line:
+                ent["cpu_baseline"] = line["cpu_baseline"]
             out[name] = ent
         except Exception as ex:  # a sub-run never takes the default line down
             out[name] = {"error": str(ex)[:300]}
@@ -468,6 +470,61 @@ def selftest_launch(args, rank, world):
     return 0 if same else 5
 
 
+def conn_cpu_baseline(rec, ordered_by_host, est_distinct):
+    """CPU legs of the C2 workload on a bounded sample (one 2^22-record chunk of the same bytes): (i) kind "port" = the
+    oracle's walk into HyperLogLog + Count-Min registers (what the GPU registers are compared with bit for bit), one thread; (ii) kind
+    "reference" = the EXACT answer from the reference's own classes (oracle/_ref: every record's PAIR_IP_PORT(nat_cli_, nat_ser_) into an
+    unordered_set hashed with PAIR_IP_PORT::get_hash -- the stand-in for the RCU table glob_tcp_conn_tbl_ -- plus per-listener counters in an
+    unordered_map<glob_id, ..., GY_JHASHER>), one thread and all host threads (records of one partha to one thread).  Medians of 5 / 3."""
+    from oracle import oracle as o
+    n = len(rec)
+    buf = np.frombuffer(rec.tobytes(), dtype=np.uint8)
+    end = buf.ctypes.data + len(buf)
+    out = {"unit": "records/s", "sample": "%d TCP_CONN_NOTIFY records (one chunk of the timed run's bytes), warm, median of 5 (exact single-thread leg: of 3)" % n,
+           "cores": 1, "kind": "port"}
+    L = o.lib()
+    rates = []
+    for _ in range(5):
+        hll = np.zeros(1 << 14, dtype=np.uint8)
+        c32 = np.zeros(4 * 65536, dtype=np.uint32)
+        c64 = np.zeros(4 * 65536, dtype=np.uint64)
+        t0 = time.perf_counter()
+        L.gyo_tcp_conn_sketch_batch(buf.ctypes.data, n, end, o.ptr(hll, o.u8p), o.ptr(c32, o.u32p), o.ptr(c64, o.u64p))
+        rates.append(n / (time.perf_counter() - t0))
+    out["value"] = sorted(rates)[2]
+    R = o.ref()
+    if R is not None and hasattr(R, "ref_conn_exact_new"):
+        ex = {"kind": "reference", "form": "unordered_set<PAIR_IP_PORT, PAIR_IP_PORT::get_hash> of the NAT-translated tuples + unordered_map<glob_id, counters, GY_JHASHER>"}
+        rates = []
+        for _ in range(3):
+            x = R.ref_conn_exact_new()
+            t0 = time.perf_counter()
+            R.ref_conn_exact_batch(x, buf.ctypes.data, n, end)
+            rates.append(n / (time.perf_counter() - t0))
+            ex["distinct_flows_exact"] = int(R.ref_conn_exact_distinct(x))
+            R.ref_conn_exact_free(x)
+        ex["value"] = sorted(rates)[1]
+        ex["cores"] = 1
+        if est_distinct is not None:
+            ex["hll_estimate_engine_window"] = est_distinct
+        ncores = os.cpu_count() or 1
+        if ordered_by_host and ncores > 1:
+            host_of = rec["nat_ser"]["ip32_be"].astype("<u4").view(">u4").astype(np.int64) & 0xFFFFFF
+            first = np.concatenate([[0], np.flatnonzero(np.diff(host_of)) + 1]).astype(np.uint64)
+            rates = []
+            dd, nc = np.zeros(1, dtype=np.uint64), np.zeros(1, dtype=np.uint64)
+            for _ in range(5):
+                t0 = time.perf_counter()
+                R.ref_conn_exact_batch_mt(buf.ctypes.data, o.ptr(first, o.u64p), len(first), n, ncores, o.ptr(dd, o.u64p), o.ptr(nc, o.u64p))
+                rates.append(n / (time.perf_counter() - t0))
+            ex["allcores_value"] = sorted(rates)[2]
+            ex["allcores"] = ncores
+            ex["allcores_distinct_flows"] = int(dd[0])
+            ex["allcores_connections"] = int(nc[0])
+        out["reference_exact"] = ex
+    return out
+
+
 def run_conn(args, rank, world):
     """--workload conn: BASELINE.json configs[1] -- 1 000 hosts x 100 services, per window 2^24 device-resident
     TCP_CONN_NOTIFY records (280 B fixed stride; HLL distinct flows + 2 x Count-Min + exact per-service connection counters) and 10^5
@@ -567,6 +624,16 @@ def run_conn(args, rank, world):
                         "note": "frac = (280 B x records + 88 B x listener records) / WHOLE step (SURVEY 8d: whole struct lines are fetched); kernel_frac = 280 B x "
                                 "records / k_conn_ingest's HIP-event time; kernel_frac_measured_bytes = the same kernel's counter traffic (FETCH_SIZE x 2 + "
                                 "WRITE_SIZE per step) / its time: k_conn_ingest asks for bytes [64, 224) and [264, 280) of each record only"}}
+    if not args.no_cpu_baseline or args.sub:  # (a sub-run keeps this bounded CPU leg: ~2 s)
+        try:
+            est = None
+            try:
+                est = float(eng.distinct_flows())
+            except Exception:
+                pass
+            out["cpu_baseline"] = conn_cpu_baseline(rec, args.conn_stream == "messages", est)
+        except Exception as ex:  # never take the line down
+            out["cpu_baseline"] = {"error": str(ex)[:300]}
     print(json.dumps(out), flush=True)
     eng.close()
     if not parity_ok:
@@ -593,6 +660,9 @@ def main():
                     "(one RCCL per process; the ROCm 7.2 librccl's ncclCommInitRank does not return on part of the MI355X pool), 'rocm' = /opt/rocm/lib/librccl.so, or a path")
     ap.add_argument("--strict-exchange", action="store_true", help="exit non-zero when the in-library RCCL exchange was asked for but the run fell back to torch.distributed")
     ap.add_argument("--no-exchange-check", action="store_true", help="skip the (untimed) cross-rank register checks after an N > 1 run")
+    ap.add_argument("--global-digest-every", type=int, default=4, help="N > 1 with the in-library exchange: every K-th timed window also builds the GLOBAL "
+                    "response-time digest across the ranks (gys_tdigest_global_rccl: this rank's roll-up slab, ncclAllGather, fold in rank order) inside "
+                    "the timed region; 0 = never")
     ap.add_argument("--share-device", action="store_true", help="test mode for a one-GPU box: every rank runs on device 0, the ranks meet over gloo and the "
                     "library's RCCL entry points are served by tests/cpp/fakerccl (RCCL refuses two ranks on one device); exercises the whole N > 1 flow")
     ap.add_argument("--selftest-launch", action="store_true", help="no GPU: only the launch path and the cross-rank checksum exchange (gloo)")
@@ -634,6 +704,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap rendezvous over loopback (see gys_rccl_unique_id)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")        # a communicator that does not come up says why on stderr (captured by the launcher's log)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "GYS_RCCL_LIB" not in os.environ and args.rccl_lib != "rocm" and not args.share_device:  # before the library's first RCCL call (it binds with dlopen)
             cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so") if args.rccl_lib == "torch" else args.rccl_lib
@@ -753,10 +824,21 @@ def main():
             buf_uses[b] += 1
         eng.sync()
 
+    gd_slab = None
+    gd_calls = 0
+    if exchange == "rccl_in_library" and args.global_digest_every > 0:
+        import ctypes as C
+        gd_slab = torch.zeros(C.sizeof(capi.TDigestSlab), dtype=torch.uint8, device="cuda")
+
     def step(i):
+        nonlocal gd_calls
         b = i % nbuf
         eng.handle_resp_events_dev(segs[b], bufs[b].data_ptr(), args.events)
         close(tusec=5_000_000 * (i + 1))
+        if gd_slab is not None and i % args.global_digest_every == args.global_digest_every - 1:
+            # the fifth register family: per-(host, service) digests stay rank-local, the GLOBAL digest crosses the ranks as fixed-size slabs
+            capi.check(eng.L.gys_tdigest_global_rccl(eng.h, eng.comm, C.c_void_p(gd_slab.data_ptr())))
+            gd_calls += 1
         buf_uses[b] += 1
 
     for i in range(args.warmup):
@@ -790,7 +872,18 @@ def main():
         matrix, same = verify_ranks(regs, world, cdev)
         side = exchange_side_check(args, rank, world, local_rank, L, eng, exchange, wire, SketchEngine, mid_buf, cdev)
         xcheck = {"ranks_seen": len(matrix), "ranks_consistent": same, "families": REG_FAMILIES, "side_config": side,
-                  "ok": bool(same and side["ranks_consistent"] and side["equals_single_rank_engine"] is not False)}
+                  "ok": bool(same and side["ranks_consistent"] and side["equals_single_rank_engine"] is not False),
+                  # how the exchange came up: which RCCL the library bound, whether ncclCommInitRank returned inside the watchdog's 60 s on
+                  # this rank, and the global-digest exchanges that ran inside the timed region
+                  "exchange": exchange, "rccl_lib": os.environ.get("GYS_RCCL_LIB", "/opt/rocm/lib/librccl.so"),
+                  "rccl_join": "stuck (watchdog expired; torch.distributed used)" if rccl_join_stuck else ("ok" if exchange == "rccl_in_library" else "not used / failed"),
+                  "global_digest_exchanges_timed": gd_calls, "global_digest_every": args.global_digest_every if gd_slab is not None else 0}
+        if gd_slab is not None and gd_calls:
+            # every rank folded the same slabs in the same order: the merged global digest must be identical on all ranks
+            gsum = digest64(gd_slab.cpu().numpy())
+            gm, gsame = verify_ranks([gsum], world, cdev)
+            xcheck["global_digest_consistent"] = gsame
+            xcheck["ok"] = bool(xcheck["ok"] and gsame)
         okt = torch.tensor([1 if xcheck["ok"] else 0], device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)  # (rank 0 alone knows the single-rank comparison)
         xcheck["ok"] = bool(int(okt.item()))

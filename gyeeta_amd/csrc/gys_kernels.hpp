@@ -580,7 +580,11 @@ __global__ __launch_bounds__(256) void k_prespill(PreSpillP p)
 		const uint32_t prev = p.td_prevm[s];
 		if (prev > p.pcap - GYS_TD_PEND_CAP && p.host_batch[p.svc_host[s]] == p.batch_stamp) {
 			npend0 = p.td_cur[s];
-			if (!(npend0 & GYS_SPILL_BIT) && (uint64_t)npend0 + prev > (uint64_t)p.pcap) cap = prev + (prev >> 3) + 32u;
+			// (predicted with the run's own margin: a key whose batches end just below the buffer's end one time and just above it the next
+			// would otherwise take the second pass every other batch -- r4c: 0.93 ms of second walks left on the Zipf shape; a run that
+			// turns out to fit the buffer only costs its copy)
+			const uint32_t want = prev + (prev >> 3) + 32u;
+			if (!(npend0 & GYS_SPILL_BIT) && (uint64_t)npend0 + want > (uint64_t)p.pcap) cap = want;
 		}
 	}
 	// one cursor atomic per workgroup

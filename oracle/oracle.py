@@ -310,6 +310,14 @@ def ref():
         _sig(R, "ref_keyed_total", C.c_uint64, [C.c_void_p, C.c_uint32])
         if hasattr(R, "ref_keyed_resp_batch_mt"):
             _sig(R, "ref_keyed_resp_batch_mt", C.c_uint64, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32, C.c_uint32])
+    if hasattr(R, "ref_conn_exact_new"):  # the exact connection table (PAIR_IP_PORT set + per-listener counters) behind the C2 CPU baseline
+        _sig(R, "ref_conn_exact_new", C.c_void_p, [])
+        _sig(R, "ref_conn_exact_free", None, [C.c_void_p])
+        _sig(R, "ref_conn_exact_batch", C.c_uint64, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p])
+        _sig(R, "ref_conn_exact_batch_mt", C.c_uint64, [C.c_void_p, u64p, C.c_uint32, C.c_uint64, C.c_uint32, u64p, u64p])
+        _sig(R, "ref_conn_exact_distinct", C.c_uint64, [C.c_void_p])
+        _sig(R, "ref_conn_exact_services", C.c_uint64, [C.c_void_p])
+        _sig(R, "ref_conn_exact_get", C.c_int, [C.c_void_p, C.c_uint64, u64p])
     _ref = R
     return R
 

@@ -26,6 +26,7 @@
 //                                        way TIME_HISTOGRAM constructs its slab histogram (common/gy_statistics.h:1106-1108)
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include "gy_common_inc.h"
 #include "gy_statistics.h"
 #include "gy_inet_inc.h"
@@ -353,6 +354,88 @@ uint64_t ref_keyed_resp_batch_mt(void *p, const uint8_t *ev24, uint64_t n, const
 	return tot;
 }
 uint64_t ref_keyed_total(void *p, uint32_t idx) { return static_cast<RefKeyed *>(p)->hist[idx].get_total_count(); }
+
+// ---- the exact CPU answer to what the HyperLogLog / Count-Min of the TCP_CONN_NOTIFY roll-up estimate (kind
+// "reference"): every record's flow key is the reference's own PAIR_IP_PORT(nat_cli_, nat_ser_) (server/gy_mconnhdlr.cc:8707) in an
+// unordered_set hashed with PAIR_IP_PORT::get_hash (common/gy_inet_inc.h:225-247) -- the stand-in for glob_tcp_conn_tbl_, an RCU hash table
+// keyed the same way -- and the per-listener counters sit in an unordered_map<glob_id, ..., GY_JHASHER> (listen_tbl_).  Records are walked
+// with the reference's stride rule (get_elem_size); a connection is counted as the walk of partha_tcp_conn_info counts it (:9129-9341).
+struct RefPairHash {
+	size_t operator()(const PAIR_IP_PORT &p) const noexcept { return p.get_hash(); }
+};
+struct RefConnCtr {
+	uint64_t nconn = 0, nclose = 0, bytes_sent = 0, bytes_rcvd = 0;
+};
+struct RefConnExact {
+	std::unordered_set<PAIR_IP_PORT, RefPairHash> flows;
+	std::unordered_map<uint64_t, RefConnCtr, GY_JHASHER<uint64_t>> svc;
+};
+void *ref_conn_exact_new(void) { return new RefConnExact(); }
+void ref_conn_exact_free(void *p) { delete static_cast<RefConnExact *>(p); }
+uint64_t ref_conn_exact_batch(void *p, const uint8_t *batch, uint64_t nrec, const uint8_t *pend)
+{
+	RefConnExact *x = static_cast<RefConnExact *>(p);
+	const uint8_t *q = batch;
+	uint64_t i = 0;
+	for (; i < nrec && q < pend; ++i) {
+		const comm::TCP_CONN_NOTIFY *c = reinterpret_cast<const comm::TCP_CONN_NOTIFY *>(q);
+		x->flows.emplace(c->nat_cli_, c->nat_ser_);
+		if (c->is_tcp_accept_event_ || !c->is_tcp_connect_event_) { // the accepting half (or neither: add_tcp_conn_ser, :9333)
+			RefConnCtr &r = x->svc[c->ser_glob_id_];
+			r.nconn += !c->notified_before_;
+			r.nclose += !!c->tusec_close_;
+			r.bytes_sent += c->bytes_sent_;
+			r.bytes_rcvd += c->bytes_rcvd_;
+		}
+		q += c->get_elem_size();
+	}
+	return i;
+}
+// the same on nthreads host threads over contiguous ranges of FIXED-STRIDE records (bench.py's device batches are 280-byte records grouped by
+// partha): every thread keeps a set and a map of its own (a partha's connections reach one L2 thread, server/gy_mconnhdlr.cc:16252); the
+// distinct-flow count is the sum of the sets' sizes when no flow key spans two ranges -- the caller passes ranges cut at host boundaries
+uint64_t ref_conn_exact_batch_mt(const uint8_t *batch, const uint64_t *range_first, uint32_t nranges, uint64_t nrec, uint32_t nthreads, uint64_t *distinct,
+				 uint64_t *nconn)
+{
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > nranges) nthreads = nranges;
+	std::vector<uint64_t> d(nthreads, 0), nc(nthreads, 0), walked(nthreads, 0);
+	std::vector<std::thread> th;
+	for (uint32_t t = 0; t < nthreads; ++t)
+		th.emplace_back([&, t]() {
+			const uint32_t r0 = (uint32_t)((uint64_t)nranges * t / nthreads), r1 = (uint32_t)((uint64_t)nranges * (t + 1) / nthreads);
+			if (r0 >= r1) return;
+			const uint64_t e0 = range_first[r0], e1 = r1 < nranges ? range_first[r1] : nrec;
+			RefConnExact x;
+			walked[t] = ref_conn_exact_batch(&x, batch + e0 * sizeof(comm::TCP_CONN_NOTIFY), e1 - e0, batch + e1 * sizeof(comm::TCP_CONN_NOTIFY));
+			d[t] = x.flows.size();
+			for (const auto &kv : x.svc) nc[t] += kv.second.nconn;
+		});
+	for (auto &x : th) x.join();
+	uint64_t w = 0;
+	*distinct = 0;
+	*nconn = 0;
+	for (uint32_t t = 0; t < nthreads; ++t) {
+		w += walked[t];
+		*distinct += d[t];
+		*nconn += nc[t];
+	}
+	return w;
+}
+uint64_t ref_conn_exact_distinct(void *p) { return static_cast<RefConnExact *>(p)->flows.size(); }
+uint64_t ref_conn_exact_services(void *p) { return static_cast<RefConnExact *>(p)->svc.size(); }
+int ref_conn_exact_get(void *p, uint64_t glob_id, uint64_t out[4])
+{
+	RefConnExact *x = static_cast<RefConnExact *>(p);
+	auto it = x->svc.find(glob_id);
+	if (it == x->svc.end()) return 0;
+	out[0] = it->second.nconn;
+	out[1] = it->second.nclose;
+	out[2] = it->second.bytes_sent;
+	out[3] = it->second.bytes_rcvd;
+	return 1;
+}
+
 
 // the slab-histogram bucket container of TIME_HISTOGRAM<RESP_TIME_HASH, ...>, with a bare counter as the bucket type
 struct SlabCount {
