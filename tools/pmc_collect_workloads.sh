@@ -8,7 +8,7 @@ O=$R/gpurun_out/$1; shift
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 NAMES=${@:-c2_conn c1 c5_zipf}
-cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
+[ -f $O/pmc_traffic.json ] || cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null  # (tools/profile_round.sh with the same outdir has just written the default workload's passes: keep them)
 for name in $NAMES; do
   case $name in
     c2_conn) ARGS="--workload conn"; UNITS=$((1<<24)); UNIT=records ;;
