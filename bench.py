@@ -892,7 +892,8 @@ def main():
     if rank == 0 and not args.no_quantile_check and nsvc:
         for b in range(nbuf):
             ingested.append([args.events, 0x67796565746121 + 1000 * rank + b, args.zipf_milli, buf_uses[b]])
-        qerr = quantile_error(eng, torch, ingested, nlocal, args.svcs, [mine[0], mine[-1]], [0, nlocal - 1], wire)
+        qh, qs = ([mine[0]], [0]) if nlocal == 1 else ([mine[0], mine[-1]], [0, nlocal - 1])  # first and last host of the rank (one host: once)
+        qerr = quantile_error(eng, torch, ingested, nlocal, args.svcs, qh, qs, wire)
     scan = None
     if rank == 0 and nsvc and not args.no_quantile_check and not args.sub:  # the per-key scan on the digests (a9): p25 / p95 / p99 of EVERY service, one pass
         eng.profile(True)

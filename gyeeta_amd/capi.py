@@ -127,7 +127,7 @@ class Counters(C.Structure):
                                           "resp_batches_host_local", "resp_batches_general", "window_graph_launches", "resp_batches_host_split",
                                           "td_merges", "td_merge_values", "actconn_records", "actconn_remote_listen", "actconn_unknown_listener",
                                           "stage_waits", "resp_calls_queued", "resp_submissions", "conn_new", "conn_closed",
-                                          "conn_closed_no_notify", "conn_client_side")]
+                                          "conn_closed_no_notify", "conn_client_side", "resp_tail_flushes")]
 
 
 assert C.sizeof(HistRec) == 256 and C.sizeof(TopnEntry) == 104 and C.sizeof(RespSeg) == 16 and C.sizeof(ListenerDayStats) == 48
@@ -217,6 +217,7 @@ SIGNATURES = {
     "gys_export_global_hist": (C.c_int, [vp, C.POINTER(HistRec)]),
     "gys_export_svc_hll": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
     "gys_get_counters": (C.c_int, [vp, C.POINTER(Counters)]),
+    "gys_resp_queue_pending": (C.c_int, [vp, u64p]),
     "gys_hist_init_dev": (C.c_int, [vp, C.c_int, vp, C.c_uint32]),
     "gys_hist_add_dev": (C.c_int, [vp, C.c_int, vp, C.c_uint32, vp, vp, C.c_uint64]),
     "gys_hist_merge_dev": (C.c_int, [vp, vp, vp, C.c_uint32]),

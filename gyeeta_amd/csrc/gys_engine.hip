@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include <deque>
 #include <map>
 #include <string>
+#include <thread>
 #include <condition_variable>
 #include <mutex>
 #include <unordered_map>
@@ -320,6 +322,12 @@ struct gys_ctx {
 		uint64_t calls = 0, submissions = 0;
 		std::vector<uint32_t> host_stamp; // host -> stamp of the open batch it is in
 		uint32_t stamp = 0;
+		// the tail of a burst: calls that found GYS_RQ_INFLIGHT submissions on the GPU left their events in the open batch, and after the
+		// burst nobody calls again -- a flusher thread (started with the first queued call) submits that batch once a submission has retired
+		std::condition_variable fcv;
+		std::thread flusher;
+		bool flusher_on = false, stop = false;
+		uint64_t tail_flushes = 0;
 	} rq;
 	uint8_t *dev_staging = nullptr;
 	uint64_t dev_staging_bytes = 0;
@@ -1556,10 +1564,36 @@ int rq_flush(gys_ctx *c)
 	return rc;
 }
 
+// flusher thread of the submission queue: sleeps until a call leaves events behind in the open batch, then tries every 200 us to submit
+// it (rq_drain submits only while fewer than GYS_RQ_INFLIGHT submissions are on the GPU); an error lands in rq.async_rc for the next caller
+void rq_flusher(gys_ctx *c)
+{
+	gys_ctx::RespQ &q = c->rq;
+	(void)hipSetDevice(c->device);
+	std::unique_lock<std::mutex> lk(q.mu);
+	for (;;) {
+		q.fcv.wait(lk, [&] { return q.stop || (q.open >= 0 && q.b[q.open].fill != 0); });
+		if (q.stop) break;
+		lk.unlock();
+		std::this_thread::sleep_for(std::chrono::microseconds(200));
+		lk.lock();
+		if (q.stop) break;
+		if (q.open >= 0 && q.b[q.open].fill && q.b[q.open].writers == 0 && !q.submitting) {
+			const uint64_t before = q.submissions;
+			(void)rq_drain(c, lk, -1, false);
+			if (q.submissions != before) q.tail_flushes++;
+		}
+	}
+}
+
 int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
 {
 	gys_ctx::RespQ &q = c->rq;
 	std::unique_lock<std::mutex> lk(q.mu);
+	if (!q.flusher_on) {
+		q.flusher_on = true;
+		q.flusher = std::thread(rq_flusher, c);
+	}
 	if (q.async_rc) { // an earlier submission made for other callers failed: report it once
 		const int rc = q.async_rc;
 		set_err("%s", q.async_err.c_str());
@@ -1640,7 +1674,9 @@ int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
 	lk.lock();
 	b.writers--;
 	if (b.writers == 0) q.cv.notify_all();
-	return rq_drain(c, lk, bi, false);
+	const int rc = rq_drain(c, lk, bi, false);
+	if (q.open >= 0 && q.b[q.open].fill) q.fcv.notify_one(); // events stay behind in the open batch: the flusher sees to them if no call follows
+	return rc;
 }
 
 } // namespace
@@ -1838,10 +1874,10 @@ try {
 		ALLOC(c->scan_block_sums, (S + GYS_SCAN_TILE - 1) / GYS_SCAN_TILE + 1);
 		ALLOC(c->ev_kv, B);
 		c->ev_kv_cap = B;
-		// `staged`: the runs of one batch.  With predicted runs (k_prespill) a batch may need the predicted runs (<= 9/8 B: the last batch's
-		// counts plus an eighth) AND the exact runs of the keys the prediction missed (<= B): 9/4 B + slack, while indices stay 32-bit
-		c->prespill = getenv("GYS_NO_PRESPILL") == nullptr && B * 9 / 4 + (1u << 20) < (1ull << 32);
-		c->staged_cap = c->prespill ? B * 9 / 4 + (1u << 20) : B;
+		// `staged`: the runs of one batch.  With predicted runs (k_prespill) a batch may need the predicted runs (the last batch's counts
+		// plus a quarter, + 64 per key) AND the exact runs of the keys the prediction missed (<= B): 5/2 B + slack, while indices stay 32-bit
+		c->prespill = getenv("GYS_NO_PRESPILL") == nullptr && B * 5 / 2 + (1u << 24) < (1ull << 32);
+		c->staged_cap = c->prespill ? B * 5 / 2 + (1u << 24) : B;
 		if ((rc = dev_alloc(&c->staged, c->staged_cap, false)) != GYS_OK) { // (runs are written before they are read)
 			gys_destroy(c);
 			return rc;
@@ -1926,6 +1962,15 @@ void gys_destroy(gys_ctx *c)
 {
 	if (c) (void)hipSetDevice(c->device);
 	if (!c) return;
+	if (c->rq.flusher_on) {
+		{
+			std::lock_guard<std::mutex> g(c->rq.mu);
+			c->rq.stop = true;
+		}
+		c->rq.fcv.notify_all();
+		if (c->rq.flusher.joinable()) c->rq.flusher.join();
+		c->rq.flusher_on = false;
+	}
 	if (c->stream) hipStreamSynchronize(c->stream);
 	if (c->win_graph_exec) hipGraphExecDestroy(c->win_graph_exec);
 	if (c->win_graph) hipGraphDestroy(c->win_graph);
@@ -3672,7 +3717,20 @@ try {
 		std::lock_guard<std::mutex> g(c->rq.mu);
 		out->resp_calls_queued = c->rq.calls;
 		out->resp_submissions = c->rq.submissions;
+		out->resp_tail_flushes = c->rq.tail_flushes;
 	}
+	return GYS_OK;
+} GYS_CATCH_ALL
+
+int gys_resp_queue_pending(gys_ctx *c, uint64_t *events)
+try {
+	if (!c || !events) return GYS_ERR_INVAL;
+	gys_ctx::RespQ &q = c->rq;
+	std::lock_guard<std::mutex> g(q.mu);
+	uint64_t n = 0;
+	if (q.open >= 0) n += q.b[q.open].fill;
+	for (int bi : q.sealed) n += q.b[bi].fill;
+	*events = n;
 	return GYS_OK;
 } GYS_CATCH_ALL
 

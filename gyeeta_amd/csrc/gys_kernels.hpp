@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void k_key_finalize(FinP p)
 
 // ---------------------------------------------------------------------------------------------------- predicted runs
 // Before the event pass of a batch: a service of one of the batch's hosts whose LAST batch, repeated, would not fit its buffer gets a
-// run in `staged` sized for that count plus an eighth (+ 32), and GYS_SPILL_BIT in td_cur -- the event pass then appends the key's
+// run in `staged` sized for that count plus a quarter (+ 64), and GYS_SPILL_BIT in td_cur -- the event pass then appends the key's
 // pieces to the run instead of dropping them for a second walk.  What the prediction misses is caught after the pass (finalize_one):
 // more values than the run holds -> exact run + second pass as before; fewer than the buffer has room for -> the run is copied into the
 // buffer (k_run_append).  The digest state only depends on the key's value multiset per call, so the result is the same either way.
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void k_prespill(PreSpillP p)
 			// (predicted with the run's own margin: a key whose batches end just below the buffer's end one time and just above it the next
 			// would otherwise take the second pass every other batch -- r4c: 0.93 ms of second walks left on the Zipf shape; a run that
 			// turns out to fit the buffer only costs its copy)
-			const uint32_t want = prev + (prev >> 3) + 32u;
+			const uint32_t want = prev + (prev >> 2) + 64u; // (a quarter + 64: a 500-value key's batches vary by +-22 (1 sigma): 8 sigma of room)
 			if (!(npend0 & GYS_SPILL_BIT) && (uint64_t)npend0 + want > (uint64_t)p.pcap) cap = want;
 		}
 	}
@@ -773,6 +773,9 @@ __host__ __device__ __forceinline__ size_t resp_host_lds_bytes(uint32_t tbl_entr
 
 #ifndef GYS_RESP_DBG
 #define GYS_RESP_DBG 0 // 1: RespHostP.dbg switches parts of the kernel off (timing experiments only, tools/r3h_phases.sh)
+#endif
+#ifndef GYS_GH_PER_WAVE
+#define GYS_GH_PER_WAVE 0 // A/B: 1 = the cells per (wave, bucket) of rounds 1 - 3
 #endif
 #define GYS_GH_STRIDE 17u // cells per lane slot of the all-service histogram (15 buckets + the spare cell + 1: an odd stride)
 #define GYS_HQ_CAP 512u // HLL candidates queued per tile (late in a window ~0.1 % of a tile's events qualify; the queue is drained by the first GYS_HQ_CAP threads)
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 				for (int u = 0; u < 4; ++u) {
 					// all-service histogram of the window (GY_HISTOGRAM::add_data on the aggregate): one packed LDS add per event
 					// (a place that kept nothing adds into the spare cell, which nobody reads: the add itself stays unconditional)
-					if (!(DBG && (p.dbg & 8u))) atomicAdd(&s_gh[(lane & 15u) * GYS_GH_STRIDE + bk[u]], (1ull << 40) | (unsigned long long)tresp[u]);
+					if (!(DBG && (p.dbg & 8u))) atomicAdd(&s_gh[(GYS_GH_PER_WAVE ? wave : (lane & 15u)) * GYS_GH_STRIDE + bk[u]], (1ull << 40) | (unsigned long long)tresp[u]);
 					tmax = max(tmax, kept[u] ? (int32_t)tresp[u] : INT32_MIN);
 				}
 				GYS_OPAQUE_LOADED4(w0);

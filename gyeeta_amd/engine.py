@@ -559,6 +559,11 @@ class SketchEngine:
         capi.check(self.L.gys_export_svc_hll(self.h, first, n, C.c_void_p(out.ctypes.data)))
         return out
 
+    def resp_queue_pending(self):
+        out = C.c_uint64()
+        capi.check(self.L.gys_resp_queue_pending(self.h, C.byref(out)))
+        return out.value
+
     def counters(self):
         out = capi.Counters()
         capi.check(self.L.gys_get_counters(self.h, C.byref(out)))

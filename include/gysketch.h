@@ -575,8 +575,13 @@ typedef struct {
 	 * accepting and by its connecting partha); conn_client_side = records of the connecting half only (is_tcp_connect_event_ without
 	 * is_tcp_accept_event_), which do not enter the per-service counters (see gys_export_svc_counters). */
 	uint64_t conn_new, conn_closed, conn_closed_no_notify, conn_client_side;
+	uint64_t resp_tail_flushes; /* submissions made by the queue's flusher thread: the tail of a burst of gys_ingest_resp_events calls that
+				     * found the GPU busy is submitted ~200 us after a submission retires, without waiting for the next call */
 } gys_counters;
 int gys_get_counters(gys_ctx *ctx, gys_counters *out);
+/* response events the submission queue of gys_ingest_resp_events still holds on the HOST side (copied out of the callers' buffers, not yet
+ * submitted to the GPU).  Unlike every other entry point this one does not flush the queue: it is the way to watch it drain. */
+int gys_resp_queue_pending(gys_ctx *ctx, uint64_t *events);
 
 /* -------------------------------------------------------------------------------------------------------------------
  * standalone keyed histogram op (rows a1/a2/a4 of SURVEY 8a for ANY hash kind): nkeys histograms of `kind`, caller-owned DEVICE

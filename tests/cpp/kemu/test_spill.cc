@@ -121,8 +121,9 @@ int main(int argc, char **argv)
 	// | 4: 21 000 per key, a twentieth of them >= 16 384 ms (spilled, the several-workgroup path in three rounds) | 5: 3 more per key
 	// | 6: 20 000 per key, ALL >= 16 384 ms for key 0 (more tail values than the LDS tail takes: the one-workgroup fallback)
 	// | 7, 8: 1 500 and 1 600 per key (spilled, class 1): with predicted runs (KEMU_PRESPILL: k_prespill before the event pass) these two find
-	// their values in the predicted run -- no second pass; batch 4 overflows its predicted run (1 719 words for 21 000 values: the exact-run
-	// fall-back), batch 5 under-runs it (3 values for a run predicted from 21 000: the run is copied into the buffer, k_run_append)
+	// their values in the predicted run -- no second pass; batches 1 and 4 overflow their predicted runs (564 words for 580 values, 1 939 for
+	// 21 000: the exact-run fall-back), batch 5 under-runs it (3 values for a run predicted from 21 000: the run is copied into the buffer,
+	// k_run_append)
 	const uint32_t per_key[] = {400, pcap - 400u + 20u, 700, 1500, 21000, 3, 20000, 1500, 1600};
 	const uint32_t NB = sizeof(per_key) / sizeof(per_key[0]);
 	uint32_t stamp = 0;
@@ -211,7 +212,7 @@ int main(int argc, char **argv)
 		}
 		uint32_t npred = 0;
 		for (uint32_t s = 0; s < nsvc; ++s) npred += (td_cur[s] & GYS_SPILL_BIT) ? 1u : 0u;
-		CHECK(npred == ((batch == 4 || batch == 5 || batch == 7 || batch == 8) ? L[0] : 0u), "batch %u: %u keys got a predicted run", batch, npred);
+		CHECK(npred == ((batch == 1 || batch == 4 || batch == 5 || batch == 7 || batch == 8) ? L[0] : 0u), "batch %u: %u keys got a predicted run", batch, npred);
 #endif
 		RespHostP hp{};
 		hp.ev = ev64.data();
@@ -243,7 +244,7 @@ int main(int argc, char **argv)
 		kemu::launch(NH, T, dyn, [&] { k_resp_host<TPT, false, false, false>(hp); });
 		CHECK(counts[FIN_RUN_ALLOC] <= staged.size(), "run area too small");
 #ifdef KEMU_PRESPILL
-		// batches 7 and 8 are predicted right (no second pass), batch 4 overflows its predicted runs (second pass), batch 5's runs go into the buffers
+		// batches 7 and 8 are predicted right (no second pass), batches 1 and 4 overflow their predicted runs (second pass), batch 5's runs go into the buffers
 		const bool expect_spill = batch == 1 || batch == 3 || batch == 4 || batch == 6;
 		if (batch == 5) {
 			CHECK(counts[FIN_APPEND] == L[0], "batch 5: %u keys on the append list", counts[FIN_APPEND]);
@@ -251,7 +252,7 @@ int main(int argc, char **argv)
 		} else
 			CHECK(counts[FIN_APPEND] == 0, "batch %u: %u keys on the append list", batch, counts[FIN_APPEND]);
 		if (batch == 7 || batch == 8) n_pre_inplace += L[0];
-		if (batch == 4) n_pre_fallback += L[0];
+		if (batch == 1 || batch == 4) n_pre_fallback += L[0];
 		kemu::launch(2, 256, 0, [&] { k_run_append(append_list.data(), &counts[FIN_APPEND], staged.data(), td_pend.data(), pcap); });
 #else
 		const bool expect_spill = batch == 1 || batch == 3 || batch == 4 || batch == 6 || batch == 7 || batch == 8;
