@@ -843,8 +843,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	// to ~500 listeners: one workgroup's load / scan / flush phases run under the other's event phase -- r3t: 1.59 against 1.79 ms at 480
 	// listeners per host); else 1024 threads x 16 events (16384-event tiles, one workgroup per CU: 1000-listener hosts -- there the two-
 	// workgroup form needs half-full tables and 6-value pieces and loses, r3l / r3n); else 1024 x 8.  GYS_TPT = 8 / 12 / 16 pins a form (A/B).
-	static const int tpt = [] { const char *e = getenv("GYS_TPT"); const int v = e ? atoi(e) : 0; return (v == 8 || v == 12 || v == 16) ? v : 0; }();
-	bool tpt16 = false, tpt12 = false;
+	static const int tpt = [] { const char *e = getenv("GYS_TPT"); const int v = e ? atoi(e) : 0; return (v == 8 || v == 12 || v == 16 || v == 32) ? v : 0; }();
+	bool tpt16 = false, tpt12 = false, tpt32 = false;
 	if (host_local) {
 		hp.ev = (const uint64_t *)d_ev;
 		hp.n = n;
@@ -922,7 +922,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		}
 		// (two workgroups per CU: each gets half of the CU's LDS -- resp_dyn_max is 160 KiB minus ONE static part)
 		tpt12 = (tpt == 12 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 6144u) + 160u * 1024u - c->resp_dyn_max <= 80u * 1024u;
-		tpt16 = !tpt12 && (tpt == 16 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 16384u) <= c->resp_dyn_max;
+		tpt16 = !tpt12 && (tpt == 16 || tpt == 32 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 16384u) <= c->resp_dyn_max;
+		// GYS_TPT=32 (experiment): the fused first pass as 512 threads x 32 events with the next group's events prefetched into registers --
+		// the same 16 384-event tile and LDS layout as the 1024 x 16 form, which the split form and the second pass keep using
+		tpt32 = tpt16 && tpt == 32 && !host_split;
 		dyn = resp_host_lds_bytes(max_tbl, hp.lds_key_entries, tpt12 ? 6144u : tpt16 ? 16384u : 8192u);
 		if (pre) {
 			// runs for the keys whose last batch, repeated, would overflow their buffer (nothing but a flag read when no key was that large)
@@ -954,6 +957,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 				else launch_resp_host<8, true, false>(c, hgrid, dyn, hp);
 			} else {
 				if (tpt12) launch_resp_host<12, false, false>(c, hgrid, dyn, hp);
+				else if (tpt32) launch_resp_host<32, false, false>(c, hgrid, dyn, hp);
 				else if (tpt16) launch_resp_host<16, false, false>(c, hgrid, dyn, hp);
 				else launch_resp_host<8, false, false>(c, hgrid, dyn, hp);
 			}
@@ -1819,6 +1823,7 @@ try {
 	HIPCHK((resp_host_lds_attr<8, true, false>(&c->resp_dyn_max)));
 	HIPCHK((resp_host_lds_attr<8, true, true>(&c->resp_dyn_max)));
 	HIPCHK((resp_host_lds_attr<16, false, false>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<32, false, false>(&c->resp_dyn_max)));
 	HIPCHK((resp_host_lds_attr<16, true, false>(&c->resp_dyn_max)));
 	HIPCHK((resp_host_lds_attr<16, true, true>(&c->resp_dyn_max)));
 	HIPCHK((resp_host_lds_attr<12, false, false>(&c->resp_dyn_max))); // (GYS_TPT=12: half of the room per workgroup, two per CU)

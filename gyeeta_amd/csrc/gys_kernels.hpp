@@ -731,7 +731,11 @@ struct HostDesc {
 // workgroup size of k_resp_host by tile form: 16 / 8 events per thread with 1024 threads (one workgroup per CU), or 12 events per thread
 // with 512 threads (6144-event tiles, 76 KB of LDS at 1000 listeners: TWO workgroups per CU, so that one's prologue / scan / flush phases
 // run under the other's event phase)
-#define GYS_RESP_THREADS(TPT) ((TPT) == 12 ? 512 : 1024)
+#define GYS_RESP_THREADS(TPT) (((TPT) == 12 || (TPT) == 32) ? 512 : 1024)
+// TPT = 32 (round 4, experiment behind GYS_TPT=32): 512 threads x 32 events = the same 16 384-event tile as 1024 x 16, ONE workgroup per CU
+// at two waves per SIMD, i.e. a budget of 256 VGPRs -- room to hold the NEXT group's twelve event words in registers while the current
+// group is processed (at 128 VGPRs that prefetch spilled and lost, r3j / r3l / r3n), across the tile boundary too
+#define GYS_RESP_WAVES_PER_SIMD(TPT) ((TPT) == 32 ? 2 : 4)
 #define GYS_SPLIT_PART 65536u // events per part when long segments are cut (SHARED)
 
 struct RespHostP {
@@ -786,7 +790,7 @@ __host__ __device__ __forceinline__ size_t resp_host_lds_bytes(uint32_t tbl_entr
 #define GYS_MEM_FENCE() asm volatile("" ::: "memory") // compiler-only: memory operations are not moved across it (keeps a batch of LDS reads in front of the stores / the next batch)
 
 template <int TPT, bool SHARED, bool SPILL, bool SVCHLL>
-__global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHostP p) // (4 waves per SIMD: one 1024-thread workgroup or two 512-thread ones per CU)
+__global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)) void k_resp_host(RespHostP p) // (4 waves per SIMD: one 1024-thread workgroup or two 512-thread ones per CU; TPT = 32: 2)
 {
 	constexpr uint32_t T = GYS_RESP_THREADS(TPT);
 	constexpr uint32_t TILE = (uint32_t)TPT * T;
@@ -882,6 +886,24 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 
 	uint32_t ndrop_range = 0, ndrop_nol = 0, tile_no = 0, dbg_sink = 0;
 	int32_t tmax = INT32_MIN;
+	// PF: the twelve words of the NEXT group of four events per thread are requested while the current group is processed and wait in
+	// n0 / n1 / n2 (the group after a tile's last one is the next tile's first: its loads run under the scan / image / flush phases)
+	constexpr bool PF = TPT == 32 && !SPILL;
+	uint64_t n0[4], n1[4], n2[4];
+	auto pf_issue = [&](const uint64_t *base, uint32_t first_o, uint32_t lim) {
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t o = first_o + (uint32_t)u * T + tid;
+			const uint32_t oo = o < lim ? o : 0u; // (lanes past the end read the tile's first event and ignore it)
+			n0[u] = base[3u * oo];
+			n1[u] = base[3u * oo + 1u];
+			n2[u] = base[3u * oo + 2u];
+		}
+	};
+	if (PF) {
+		const uint64_t left0 = e1 - e0;
+		pf_issue(p.ev + 3u * e0, 0u, left0 < (uint64_t)TILE ? (uint32_t)left0 : TILE);
+	}
 	for (uint64_t t0 = e0; t0 < e1; t0 += TILE, ++tile_no) {
 		// (no barrier here: the event phase of this tile touches nothing the flush of the previous one reads -- the per-key counters are
 		// double-buffered and were cleared two phases ago, the floor and the candidate queue were settled behind barriers of the
@@ -909,14 +931,32 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), 4) void k_resp_host(RespHost
 			if ((uint32_t)g * T >= rem) break; // the segment's last tile is usually short (C3: 53 687 events = 3.28 tiles): no empty groups
 			uint64_t w0[4], w1[4], w2[4];
 			bool in[4];
+			if (PF) {
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const uint32_t o = (uint32_t)(g + u) * T + tid;
-				in[u] = o < rem;
-				const uint32_t oo = in[u] ? o : 0u; // (lanes past the end read the tile's first event and ignore it: no branch around the loads)
-				w0[u] = tb[3u * oo];
-				w1[u] = tb[3u * oo + 1u];
-				w2[u] = tb[3u * oo + 2u];
+				for (int u = 0; u < 4; ++u) {
+					in[u] = (uint32_t)(g + u) * T + tid < rem;
+					w0[u] = n0[u];
+					w1[u] = n1[u];
+					w2[u] = n2[u];
+				}
+				// the group that runs next: this tile's, or the first one of the next tile
+				const uint32_t g2 = (uint32_t)g + 4u;
+				if (g2 < (uint32_t)TPT && g2 * T < rem) {
+					pf_issue(tb, g2 * T, rem);
+				} else if (t0 + TILE < e1) {
+					const uint64_t left2 = e1 - t0 - TILE;
+					pf_issue(tb + 3u * TILE, 0u, left2 < (uint64_t)TILE ? (uint32_t)left2 : TILE);
+				}
+			} else {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t o = (uint32_t)(g + u) * T + tid;
+					in[u] = o < rem;
+					const uint32_t oo = in[u] ? o : 0u; // (lanes past the end read the tile's first event and ignore it: no branch around the loads)
+					w0[u] = tb[3u * oo];
+					w1[u] = tb[3u * oo + 1u];
+					w2[u] = tb[3u * oo + 2u];
+				}
 			}
 			// (all twelve words pass through one opaque statement: the four events' loads are issued before the first word is used -- the
 			// scheduler otherwise waits for event 0 and starts on its fields before the loads of events 1..3 are even issued.  Requesting

@@ -46,6 +46,7 @@ PROGRAMS = {
     "bins-99": ("test_bins.cc", BINS, ["99"], "kemu bins ok"),
     "resp-tiles-16384": ("test_resp.cc", ["KEMU_TPT=16"] + BINS, ["4242"], "kemu resp ok"),
     "resp-tiles-6144": ("test_resp.cc", ["KEMU_TPT=12"] + BINS, ["4242"], "kemu resp ok"),
+    "resp-512x32-prefetch": ("test_resp.cc", ["KEMU_TPT=32"] + BINS, ["4242"], "kemu resp ok"),
     "resp-split-form": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_SPLIT", "KEMU_NB=3"] + BINS, ["4242"], "kemu resp ok"),
     "spill-and-huge": ("test_spill.cc", BINS, ["777"], "kemu spill ok"),
     "spill-predicted-runs": ("test_spill.cc", ["KEMU_PRESPILL"] + BINS, ["778"], "kemu spill ok"),
