@@ -196,6 +196,22 @@ public:
 	{
 		return json_call(out, [&](char *b, size_t n, size_t *need) { return gys_json_svcstate(ctx_, machine_id, madid, timestr, b, n, need); });
 	}
+	// MCONN_HANDLER::web_curr_listener_state with QUERY_OPTIONS (server/gy_mnodehandle.cc:4650-4900; common/gy_query_common.h:24-140): the
+	// multi-host form -- criteria on the numeric svcstate columns (filter: groups of terms as CRITERIA_SET holds them, nullptr = none),
+	// one sort column (GYS_SVC_COL_*, -1 = service order), maxrecs; one pass over the kept states of every listener on the device
+	bool web_curr_listener_state_multihost(const gys_svc_filter *filter, int sort_col, bool sort_desc, uint32_t maxrecs, const char *madid,
+					       const char *timestr, std::string &out) noexcept
+	{
+		return json_call(out, [&](char *b, size_t n, size_t *need) {
+			return gys_json_svcstate_multihost(ctx_, filter, sort_col, sort_desc ? 1 : 0, maxrecs, madid, timestr, b, n, need);
+		});
+	}
+	// the aggregation operators (AGGR_OPER_E, common/gy_json_field_maps.h:114-129) over the matching listeners: group_by 0 all / 1 host / 2 cluster
+	bool aggr_listener_state(const gys_svc_filter *filter, int group_by, const uint8_t *cols, uint32_t ncols, gys_svc_aggr_row *out, uint32_t maxrows,
+				 uint32_t *nrows) noexcept
+	{
+		return gys_query_svcstate_aggr(ctx_, filter, group_by, cols, ncols, out, maxrows, nrows) == GYS_OK;
+	}
 	// MCONN_HANDLER::web_curr_top_listeners (server/gy_mnodehandle.cc:2706-3190): machine_id = one partha's four top-10 queues,
 	// nullptr = every host's queues merged into MAX_MULTI_TOPN = 50 slots per kind; flags: GYS_TOP_* (which arrays to send)
 	bool web_curr_top_listeners(const uint8_t *machine_id, uint32_t flags, const char *madid, const char *timestr, std::string &out) noexcept

@@ -167,7 +167,7 @@ def test_c3_full_size_properties(torch_mod, oracle):
     assert eng.export_hist(0, 5_000_000, 1000)[:, :15].sum() == 0
     slice_compare(False)
     # ---- the slice again after its keys have re-clustered inside the 10^7-key engine: 24 batches aimed at the first 25 hosts
-    # (~42 values per key and batch: every key crosses the 768-value buffer once, i.e. 25 000 merges of steady-state size), two windows
+    # (~42 values per key and batch: every key crosses the 896-value buffer once, i.e. 25 000 merges of steady-state size), two windows
     nb = 1 << 21  # (~84 values per key and batch: every key passes its buffer size with a wide margin)
     for r in range(24):
         sg = eng.gen_resp_events(bufs[0].data_ptr(), nb, 0xC300 + r, 0, 25, sp)

@@ -47,7 +47,7 @@ def test_td64_service_merge_is_clusters_then_buffer(oracle):
     rng = np.random.default_rng(6)
     b = oracle.TDBuffered()
     L.gyo_tdb_init(C.byref(b))
-    for n in (500, 500, 300):  # 500 buffered, 1000 > 768: one merge, then 300 buffered
+    for n in (500, 500, 300):  # 500 buffered, 1000 > 896: one merge, then 300 buffered
         v = _vals(rng, n)
         L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(v, oracle.i32p), len(v))
     assert b.npend == 300 and L.gyo_td_total(C.byref(b.d)) == 1000
