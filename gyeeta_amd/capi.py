@@ -104,7 +104,8 @@ class SvcTerm(C.Structure):   # gys_svc_term
 class SvcFilter(C.Structure):  # gys_svc_filter
     _fields_ = [("terms", C.POINTER(SvcTerm)), ("nterms", C.c_uint32), ("nset_values", C.c_uint32), ("set_values", C.POINTER(C.c_int64)),
                 ("group_oper", C.c_uint8 * 8), ("top_oper", C.c_uint8), ("reserved", C.c_uint8 * 3), ("nmachine_ids", C.c_uint32),
-                ("machine_ids", C.POINTER(C.c_uint8))]
+                ("machine_ids", C.POINTER(C.c_uint8)), ("svcids", C.POINTER(C.c_uint64)), ("nsvcids", C.c_uint32), ("nclusters", C.c_uint32),
+                ("clusters", C.POINTER(C.c_char_p))]
 
 
 class SvcRow(C.Structure):     # gys_svc_row

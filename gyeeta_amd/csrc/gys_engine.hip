@@ -341,12 +341,12 @@ struct gys_ctx {
 	uint64_t *topn_metric = nullptr;
 	// filtered multi-host listener-state query (gys_svcquery.hpp): scratch, grow-only
 	unsigned long long *q_cand_key = nullptr, *q_out_keys = nullptr;
-	uint32_t *q_cand_slot = nullptr, *q_misc = nullptr, *q_host_mask = nullptr;
+	uint32_t *q_cand_slot = nullptr, *q_misc = nullptr, *q_host_mask = nullptr, *q_slot_list = nullptr;
 	int32_t *q_set = nullptr;
 	uint8_t *q_out_rows = nullptr;
 	long long *q_acc = nullptr;
 	unsigned long long *q_cnt = nullptr;
-	uint64_t q_cand_cap = 0, q_slot_cap = 0, q_out_cap = 0, q_okeys_cap = 0, q_mask_cap = 0, q_set_cap = 0, q_acc_cap = 0, q_cnt_cap = 0;
+	uint64_t q_cand_cap = 0, q_slot_cap = 0, q_out_cap = 0, q_okeys_cap = 0, q_mask_cap = 0, q_set_cap = 0, q_acc_cap = 0, q_cnt_cap = 0, q_slist_cap = 0;
 	float *dev_pcts = nullptr;
 	float *zipf_cdf = nullptr;
 	uint32_t zipf_n = 0, zipf_milli = 0;
@@ -1411,7 +1411,11 @@ int run_lstate(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, co
 	p.act_hist = c->act_hist;
 	ProfScope ps(c, "lstate");
 	p.claim = c->svc_claim;
-	if (++c->lstate_launch == 0) c->lstate_launch = 1; // (enq_mu or the exclusive call lock is held; 0 = the cleared claim table)
+	if (++c->lstate_launch == 0) { // (enq_mu or the exclusive call lock is held; 0 = the cleared claim table)
+		// the call counter wrapped (2^32 calls: weeks of a large site's messages): claims of old calls would now outrank every new one
+		c->lstate_launch = 1;
+		HIPCHK(hipMemsetAsync(c->svc_claim, 0, (uint64_t)c->cfg.max_services * 8, c->stream));
+	}
 	p.launch = c->lstate_launch;
 	hipLaunchKernelGGL(k_lstate_ingest, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
 	hipLaunchKernelGGL(k_lstate_keep, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
@@ -1794,7 +1798,7 @@ try {
 	ALLOC(c->svc_ctr, S * 4);
 	ALLOC(c->svc_win, S * 3);
 	ALLOC(c->svc_state, S * 96);
-	ALLOC(c->svc_claim, S * 8);
+	ALLOC(c->svc_claim, S);
 	ALLOC(c->hll32, (uint64_t)1 << GYS_HLL_P);
 	ALLOC(c->host_summ_win, H * 16);
 	ALLOC(c->host_summ_last, H * 16);
@@ -2008,7 +2012,7 @@ void gys_destroy(gys_ctx *c)
 			c->td_cnt, c->td_meta, c->td_minmax, c->td_pend, c->td_cur, c->td_run, c->td_run0, c->td_run1, c->td_prevm, c->pre_hot, c->host_batch, c->append_list, c->svc_host, c->host_spill, c->merge_list, c->merge_list_slow, c->merge_list1, c->merge_list2, c->resp_win, c->cms_partial, c->huge_list, c->query_list, c->merge_count, c->query_sum, c->query_cnt,
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_claim, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
-			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->ring_act32, c->ring_act64, c->act_live, c->q_cand_key, c->q_out_keys, c->q_cand_slot, c->q_misc, c->q_host_mask, c->q_set, c->q_out_rows, c->q_acc, c->q_cnt, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
+			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->ring_act32, c->ring_act64, c->act_live, c->q_cand_key, c->q_out_keys, c->q_cand_slot, c->q_misc, c->q_host_mask, c->q_slot_list, c->q_set, c->q_out_rows, c->q_acc, c->q_cnt, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
 			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_first, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);

@@ -43,6 +43,8 @@ struct SvcFilterP {
 	const uint64_t *svc_gid;  // [nsvc]
 	uint32_t nsvc, epoch;
 	const uint32_t *host_mask; // bit h set = host h is part of the query, or nullptr = every host (is_multihost_)
+	const uint32_t *slot_list; // the query names its listeners (svcid = / in: the reference's direct-lookup path :4754-4860): their slots, ascending;
+	uint32_t nitems;           // ... nitems of them -- or nullptr and nitems = nsvc: every slot
 	const int32_t *set_values;
 	uint32_t nterms, ngroups;
 	SvcTerm terms[GYS_SVCQ_MAX_TERMS];
@@ -176,11 +178,15 @@ __global__ __launch_bounds__(GYS_SVCQ_THREADS) void k_svc_filter(SvcFilterP p)
 	const uint32_t first = blockIdx.x * (GYS_SVCQ_THREADS * GYS_SVCQ_PER_THREAD);
 	unsigned long long keys[GYS_SVCQ_PER_THREAD];
 	uint32_t mine = 0; // bit k: record k of this thread matched
+	uint32_t slots[GYS_SVCQ_PER_THREAD];
 #pragma unroll
 	for (uint32_t k = 0; k < GYS_SVCQ_PER_THREAD; ++k) {
-		const uint32_t slot = first + k * GYS_SVCQ_THREADS + threadIdx.x;
+		const uint32_t item = first + k * GYS_SVCQ_THREADS + threadIdx.x;
 		keys[k] = 0;
-		if (slot < p.nsvc) {
+		slots[k] = 0;
+		if (item < p.nitems) {
+			const uint32_t slot = p.slot_list ? p.slot_list[item] : item;
+			slots[k] = slot;
 			uint32_t w[24], host;
 			if (svc_load_current(p, slot, w, &host) && svc_filter_match(p, w)) {
 				const uint32_t v = p.sort_col >= 0 ? ((uint32_t)svc_col_value(w, (uint32_t)p.sort_col) ^ 0x80000000u) : 0u;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(GYS_SVCQ_THREADS) void k_svc_filter(SvcFilterP p)
 	for (uint32_t k = 0; k < GYS_SVCQ_PER_THREAD; ++k) {
 		if (mine & (1u << k)) {
 			p.cand_key[at] = keys[k];
-			p.cand_slot[at] = first + k * GYS_SVCQ_THREADS + threadIdx.x;
+			p.cand_slot[at] = slots[k];
 			++at;
 		}
 	}
@@ -349,6 +355,8 @@ struct SvcAggrP {
 	const uint64_t *svc_gid;
 	uint32_t nsvc, epoch;
 	const uint32_t *host_mask;
+	const uint32_t *slot_list;
+	uint32_t nitems;
 	const int32_t *set_values;
 	uint32_t nterms, ngroups;
 	SvcTerm terms[GYS_SVCQ_MAX_TERMS];
@@ -383,8 +391,9 @@ __global__ __launch_bounds__(GYS_SVCQ_THREADS) void k_svc_aggr(SvcAggrP p)
 	const uint32_t first = blockIdx.x * (GYS_SVCQ_THREADS * GYS_SVCQ_PER_THREAD);
 #pragma unroll 1
 	for (uint32_t k = 0; k < GYS_SVCQ_PER_THREAD; ++k) {
-		const uint32_t slot = first + k * GYS_SVCQ_THREADS + threadIdx.x;
-		if (slot >= p.nsvc) continue;
+		const uint32_t item = first + k * GYS_SVCQ_THREADS + threadIdx.x;
+		if (item >= p.nitems) continue;
+		const uint32_t slot = p.slot_list ? p.slot_list[item] : item;
 		uint32_t w[24], host;
 		if (!svc_load_current(p, slot, w, &host) || !svc_filter_match(p, w)) continue;
 		const uint32_t grp = p.group_by == 0u ? 0u : p.group_by == 1u ? host : p.host_cluster[host];

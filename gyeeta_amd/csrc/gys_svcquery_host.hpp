@@ -37,6 +37,8 @@ int q_fill_filter(gys_ctx *c, const gys_svc_filter *f, P &p)
 	p.nsvc = c->nsvc;
 	p.epoch = c->epoch;
 	p.host_mask = nullptr;
+	p.slot_list = nullptr;
+	p.nitems = c->nsvc;
 	p.set_values = nullptr;
 	p.nterms = 0;
 	p.ngroups = 0;
@@ -82,19 +84,46 @@ int q_fill_filter(gys_ctx *c, const gys_svc_filter *f, P &p)
 		HIPCHK(hipStreamSynchronize(c->stream)); // (setv is a local)
 		p.set_values = c->q_set;
 	}
-	if (f->nmachine_ids) { // the query names its hosts (is_multihost_ with host criteria: the walk over partha_tbl_ :4790-4860)
-		if (!f->machine_ids) return GYS_ERR_INVAL;
+	if (f->nmachine_ids || f->nclusters) { // the query names its hosts (is_multihost_ with host criteria: the walk over partha_tbl_ :4790-4860) and / or clusters
+		if ((f->nmachine_ids && !f->machine_ids) || (f->nclusters && !f->clusters)) return GYS_ERR_INVAL;
 		const uint64_t words = ((uint64_t)c->hosts.size() + 31) / 32 + 1;
-		std::vector<uint32_t> mask(words, 0);
+		std::vector<uint32_t> mask(words, f->nmachine_ids ? 0u : ~0u);
 		for (uint32_t i = 0; i < f->nmachine_ids; ++i) {
 			uint32_t h;
 			if (lookup_host(c, f->machine_ids + (size_t)i * 16, &h) == GYS_OK) mask[h >> 5] |= 1u << (h & 31u); // (an unknown host matches nothing)
+		}
+		if (f->nclusters) {
+			std::vector<uint8_t> want(c->cluster_names.size(), 0);
+			for (uint32_t i = 0; i < f->nclusters; ++i) {
+				auto it = f->clusters[i] ? c->cluster_map.find(f->clusters[i]) : c->cluster_map.end();
+				if (it != c->cluster_map.end()) want[it->second] = 1; // (an unknown cluster matches nothing)
+			}
+			for (uint32_t h = 0; h < c->hosts.size(); ++h)
+				if (!want[c->host_cluster_h[h]]) mask[h >> 5] &= ~(1u << (h & 31u));
 		}
 		int rc = q_grow(&c->q_host_mask, &c->q_mask_cap, words);
 		if (rc) return rc;
 		HIPCHK(hipMemcpyAsync(c->q_host_mask, mask.data(), words * 4, hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
 		p.host_mask = c->q_host_mask;
+	}
+	if (f->nsvcids) { // the query names its listeners: only their slots are visited
+		if (!f->svcids) return GYS_ERR_INVAL;
+		std::vector<uint32_t> slots;
+		for (uint32_t i = 0; i < f->nsvcids; ++i) {
+			auto it = c->gid_map_h.find(f->svcids[i]);
+			if (it != c->gid_map_h.end()) slots.push_back(it->second);
+		}
+		std::sort(slots.begin(), slots.end());
+		slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+		int rc = q_grow(&c->q_slot_list, &c->q_slist_cap, slots.size());
+		if (rc) return rc;
+		if (!slots.empty()) {
+			HIPCHK(hipMemcpyAsync(c->q_slot_list, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));
+		}
+		p.slot_list = c->q_slot_list;
+		p.nitems = (uint32_t)slots.size();
 	}
 	return GYS_OK;
 }
@@ -127,7 +156,7 @@ int q_scan(gys_ctx *c, const gys_svc_filter *f, int sort_col, int sort_desc, uin
 	p.cand_slot = c->q_cand_slot;
 	p.cursor = c->q_misc + QM_CURSOR;
 	const uint32_t per_wg = GYS_SVCQ_THREADS * GYS_SVCQ_PER_THREAD;
-	hipLaunchKernelGGL(k_svc_filter, dim3((c->nsvc + per_wg - 1) / per_wg), dim3(GYS_SVCQ_THREADS), 0, c->stream, p);
+	hipLaunchKernelGGL(k_svc_filter, dim3(std::max(1u, (p.nitems + per_wg - 1) / per_wg)), dim3(GYS_SVCQ_THREADS), 0, c->stream, p);
 	uint32_t ncand = 0;
 	HIPCHK(hipMemcpyAsync(&ncand, c->q_misc + QM_CURSOR, 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
@@ -254,7 +283,7 @@ try {
 	p.acc = c->q_acc;
 	p.count = c->q_cnt;
 	const uint32_t per_wg = GYS_SVCQ_THREADS * GYS_SVCQ_PER_THREAD;
-	hipLaunchKernelGGL(k_svc_aggr, dim3((c->nsvc + per_wg - 1) / per_wg), dim3(GYS_SVCQ_THREADS), 0, c->stream, p);
+	hipLaunchKernelGGL(k_svc_aggr, dim3(std::max(1u, (p.nitems + per_wg - 1) / per_wg)), dim3(GYS_SVCQ_THREADS), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
 	std::vector<unsigned long long> cnt(ngroups);
 	HIPCHK(hipMemcpyAsync(init.data(), c->q_acc, init.size() * 8, hipMemcpyDeviceToHost, c->stream));

@@ -360,7 +360,7 @@ class SketchEngine:
         m = mid_buf(machine_id) if machine_id is not None else None
         return self._json(self.L.gys_json_toplisteners, m, flags, madid.encode(), timestr.encode())
 
-    def _svc_filter(self, terms, group_oper=(), top_oper="and", machine_ids=None):
+    def _svc_filter(self, terms, group_oper=(), top_oper="and", machine_ids=None, svcids=None, clusters=None):
         """terms: [(column name, comparator, value or list of values, group = 0)]; group_oper: per group "and" / "or"; -> (SvcFilter, keep-alive)"""
         terms = list(terms or [])
         arr = (capi.SvcTerm * max(len(terms), 1))()
@@ -390,11 +390,21 @@ class SketchEngine:
             mids = (C.c_uint8 * (16 * len(machine_ids)))(*b"".join(machine_ids))
             f.machine_ids = mids
             f.nmachine_ids = len(machine_ids)
-        return f, (arr, sv, mids)
+        ids = cl = None
+        if svcids is not None and len(svcids):
+            ids = (C.c_uint64 * len(svcids))(*[int(x) for x in svcids])
+            f.svcids = ids
+            f.nsvcids = len(svcids)
+        if clusters:
+            cl = (C.c_char_p * len(clusters))(*[x.encode() for x in clusters])
+            f.clusters = cl
+            f.nclusters = len(clusters)
+        return f, (arr, sv, mids, ids, cl)
 
-    def svcstate_scan(self, terms=None, group_oper=(), top_oper="and", sort_col=None, sort_desc=True, maxrecs=1000, machine_ids=None):
+    def svcstate_scan(self, terms=None, group_oper=(), top_oper="and", sort_col=None, sort_desc=True, maxrecs=1000, machine_ids=None, svcids=None,
+                      clusters=None):
         """gys_query_svcstate_scan -> (slots, host slots, records as a numpy array of wire.LISTENER_STATE_NOTIFY, number matched)"""
-        f, keep = self._svc_filter(terms, group_oper, top_oper, machine_ids)
+        f, keep = self._svc_filter(terms, group_oper, top_oper, machine_ids, svcids, clusters)
         out = (capi.SvcRow * max(maxrecs, 1))()
         nout, nm = C.c_uint32(), C.c_uint64()
         capi.check(self.L.gys_query_svcstate_scan(self.h, C.byref(f), -1 if sort_col is None else capi.SVC_COLS.index(sort_col), 1 if sort_desc else 0,
@@ -411,9 +421,9 @@ class SketchEngine:
         return self._json(self.L.gys_json_svcstate_multihost, C.byref(f), -1 if sort_col is None else capi.SVC_COLS.index(sort_col), 1 if sort_desc else 0,
                           maxrecs, madid.encode(), timestr.encode())
 
-    def svcstate_aggr(self, cols, group_by=0, terms=None, group_oper=(), top_oper="and", machine_ids=None, maxrows=None):
+    def svcstate_aggr(self, cols, group_by=0, terms=None, group_oper=(), top_oper="and", machine_ids=None, maxrows=None, svcids=None, clusters=None):
         """gys_query_svcstate_aggr -> list of (group, count, {col: (sum, min, max)})"""
-        f, keep = self._svc_filter(terms, group_oper, top_oper, machine_ids)
+        f, keep = self._svc_filter(terms, group_oper, top_oper, machine_ids, svcids, clusters)
         ca = (C.c_uint8 * max(len(cols), 1))(*[capi.SVC_COLS.index(c) for c in cols])
         if maxrows is None:
             maxrows = 1 if group_by == 0 else 1 << 16

@@ -475,6 +475,11 @@ typedef struct {
 	uint8_t reserved[3];
 	uint32_t nmachine_ids;                   /* 0 = all hosts (is_multihost_); else only the listeners of these parthas ... */
 	const uint8_t *machine_ids;              /* ... nmachine_ids x 16 bytes */
+	/* criteria on the string columns that select rather than compare (all three AND with each other and with the terms): */
+	const uint64_t *svcids;                  /* svcid = / in (...): only these listeners -- the reference's direct-lookup path      */
+	uint32_t nsvcids;                        /*   (server/gy_mnodehandle.cc:4754-4860); 0 = not restricted; unknown ids match nothing */
+	uint32_t nclusters;                      /* cluster = / in (...): only hosts of these clusters (names as registered); 0 = not restricted */
+	const char *const *clusters;
 } gys_svc_filter;
 typedef struct {
 	uint32_t slot, host_slot; /* service slot (gys_lookup_service) and host slot (gys_register_host) */

@@ -221,10 +221,10 @@ int gyo_svc_filter_match(const uint8_t rec[88], const gyo_svc_term *terms, uint3
 			 int top_oper);
 uint32_t gyo_svcstate_scan(const uint8_t *svc_state, uint32_t nsvc, uint32_t epoch, const uint32_t *svc_host, const uint64_t *svc_gid, const uint8_t *host_in,
 			   const gyo_svc_term *terms, uint32_t nterms, const int64_t *set_values, const uint8_t group_oper[8], int top_oper, int sort_col,
-			   int sort_desc, uint32_t maxrecs, uint32_t *out_slots, uint64_t *nmatched);
+			   int sort_desc, uint32_t maxrecs, uint32_t *out_slots, uint64_t *nmatched, const uint32_t *slot_list, uint32_t nlist);
 void gyo_svcstate_aggr(const uint8_t *svc_state, uint32_t nsvc, uint32_t epoch, const uint32_t *svc_host, const uint64_t *svc_gid, const uint8_t *host_in,
 		       const gyo_svc_term *terms, uint32_t nterms, const int64_t *set_values, const uint8_t group_oper[8], int top_oper, int group_by,
-		       const uint32_t *host_cluster, const uint8_t *cols, uint32_t ncols, int64_t *acc, uint64_t *count);
+		       const uint32_t *host_cluster, const uint8_t *cols, uint32_t ncols, int64_t *acc, uint64_t *count, const uint32_t *slot_list, uint32_t nlist);
 int gyo_tcp_conn_walk_tallies(const uint8_t *batch, int nrec, const uint8_t *pend, uint64_t out[4]);
 int gyo_tcp_conn_svc_counters(const uint8_t *batch, int nrec, const uint8_t *pend, const uint64_t *gids, uint32_t ngids, uint64_t *ctr, uint64_t *unknown);
 void gyo_cluster_state_update(gyo_cluster_state_one *c, uint32_t ntasks_issue, uint32_t ntasks, uint32_t nlisten_issue,

@@ -140,11 +140,15 @@ static int q_cmp(const void *a, const void *b)
  * Returns the number written; *nmatched = records that matched. */
 uint32_t gyo_svcstate_scan(const uint8_t *svc_state, uint32_t nsvc, uint32_t epoch, const uint32_t *svc_host, const uint64_t *svc_gid, const uint8_t *host_in,
 			   const gyo_svc_term *terms, uint32_t nterms, const int64_t *set_values, const uint8_t group_oper[8], int top_oper, int sort_col,
-			   int sort_desc, uint32_t maxrecs, uint32_t *out_slots, uint64_t *nmatched)
+			   int sort_desc, uint32_t maxrecs, uint32_t *out_slots, uint64_t *nmatched, const uint32_t *slot_list, uint32_t nlist)
 {
-	q_cand *c = (q_cand *)malloc(sizeof(q_cand) * (nsvc ? nsvc : 1));
+	/* slot_list != NULL: the query names its listeners (svcid = / in: the direct-lookup path of web_curr_listener_state :4754-4860) --
+	 * only these slots are visited */
+	const uint32_t nitems = slot_list ? nlist : nsvc;
+	q_cand *c = (q_cand *)malloc(sizeof(q_cand) * (nitems ? nitems : 1));
 	uint32_t n = 0;
-	for (uint32_t s = 0; s < nsvc; s++) {
+	for (uint32_t it = 0; it < nitems; it++) {
+		const uint32_t s = slot_list ? slot_list[it] : it;
 		const uint8_t *r = svc_state + (size_t)s * 96;
 		if (!q_current(svc_state, s, epoch, svc_host, svc_gid, host_in)) continue;
 		if (!gyo_svc_filter_match(r, terms, nterms, set_values, group_oper, top_oper)) continue;
@@ -165,9 +169,11 @@ uint32_t gyo_svcstate_scan(const uint8_t *svc_state, uint32_t nsvc, uint32_t epo
  * INT64_MIN), count: [ngroups] */
 void gyo_svcstate_aggr(const uint8_t *svc_state, uint32_t nsvc, uint32_t epoch, const uint32_t *svc_host, const uint64_t *svc_gid, const uint8_t *host_in,
 		       const gyo_svc_term *terms, uint32_t nterms, const int64_t *set_values, const uint8_t group_oper[8], int top_oper, int group_by,
-		       const uint32_t *host_cluster, const uint8_t *cols, uint32_t ncols, int64_t *acc, uint64_t *count)
+		       const uint32_t *host_cluster, const uint8_t *cols, uint32_t ncols, int64_t *acc, uint64_t *count, const uint32_t *slot_list, uint32_t nlist)
 {
-	for (uint32_t s = 0; s < nsvc; s++) {
+	const uint32_t nitems = slot_list ? nlist : nsvc;
+	for (uint32_t it = 0; it < nitems; it++) {
+		const uint32_t s = slot_list ? slot_list[it] : it;
 		const uint8_t *r = svc_state + (size_t)s * 96;
 		if (!q_current(svc_state, s, epoch, svc_host, svc_gid, host_in)) continue;
 		if (!gyo_svc_filter_match(r, terms, nterms, set_values, group_oper, top_oper)) continue;

@@ -130,6 +130,15 @@ int main(int argc, char **argv)
 			}
 			p.host_mask = mask.data();
 		}
+		// the query names its listeners in every fourth query: a sorted list of slots (svcid = / in)
+		std::vector<uint32_t> slot_list;
+		const bool named = q % 4u == 3u;
+		if (named) {
+			for (uint32_t s2 = 0; s2 < NSVC; ++s2)
+				if (rng() % 7u == 0) slot_list.push_back(s2);
+			p.slot_list = slot_list.data();
+		}
+		p.nitems = named ? (uint32_t)slot_list.size() : NSVC;
 		p.sort_col = (rng() % 4u == 0) ? -1 : (int32_t)(rng() % SVC_NCOLS);
 		p.sort_desc = rng() % 2u;
 		p.cand_key = cand_key.data();
@@ -137,12 +146,13 @@ int main(int argc, char **argv)
 		std::fill(misc.begin(), misc.end(), 0u);
 		p.cursor = &misc[0];
 		const uint32_t per_wg = GYS_SVCQ_THREADS * GYS_SVCQ_PER_THREAD;
-		kemu::launch((NSVC + per_wg - 1) / per_wg, GYS_SVCQ_THREADS, 0, [&] { k_svc_filter(p); });
+		kemu::launch(std::max(1u, (p.nitems + per_wg - 1) / per_wg), GYS_SVCQ_THREADS, 0, [&] { k_svc_filter(p); });
 		const uint32_t ncand = misc[0];
 		for (uint32_t maxrecs : {NSVC, 1u + (uint32_t)(rng() % 60u), 1u}) {
 			uint64_t nm = 0;
 			const uint32_t want_n = gyo_svcstate_scan(state.data(), NSVC, EPOCH, svc_host.data(), svc_gid.data(), subset ? host_in.data() : nullptr, ot.data(), nterms,
-								   osetv.data(), goper, top_oper, p.sort_col, (int)p.sort_desc, maxrecs, out_slots_o.data(), &nm);
+								   osetv.data(), goper, top_oper, p.sort_col, (int)p.sort_desc, maxrecs, out_slots_o.data(), &nm, named ? slot_list.data() : nullptr,
+								   (uint32_t)slot_list.size());
 			CHECK(ncand == nm, "query %u: %u candidates, the oracle matched %llu", q, ncand, (unsigned long long)nm);
 			const uint32_t k = std::min(maxrecs, NSVC);
 			const bool select = ncand > k;
@@ -201,6 +211,8 @@ int main(int argc, char **argv)
 			a.nsvc = NSVC;
 			a.epoch = EPOCH;
 			a.host_mask = p.host_mask;
+			a.slot_list = p.slot_list;
+			a.nitems = p.nitems;
 			a.set_values = p.set_values;
 			a.nterms = p.nterms;
 			a.ngroups = p.ngroups;
@@ -223,9 +235,10 @@ int main(int argc, char **argv)
 			std::vector<uint64_t> ocnt(ngroups, 0);
 			a.acc = acc.data();
 			a.count = cnt.data();
-			kemu::launch((NSVC + per_wg - 1) / per_wg, GYS_SVCQ_THREADS, 0, [&] { k_svc_aggr(a); });
+			kemu::launch(std::max(1u, (a.nitems + per_wg - 1) / per_wg), GYS_SVCQ_THREADS, 0, [&] { k_svc_aggr(a); });
 			gyo_svcstate_aggr(state.data(), NSVC, EPOCH, svc_host.data(), svc_gid.data(), subset ? host_in.data() : nullptr, ot.data(), nterms, osetv.data(), goper,
-					  top_oper, group_by, host_cluster.data(), cols, ncols, (int64_t *)oacc.data(), ocnt.data());
+					  top_oper, group_by, host_cluster.data(), cols, ncols, (int64_t *)oacc.data(), ocnt.data(), named ? slot_list.data() : nullptr,
+					  (uint32_t)slot_list.size());
 			for (uint32_t g = 0; g < ngroups; ++g) {
 				CHECK(cnt[g] == ocnt[g], "query %u group_by %d: group %u counts %llu, the oracle %llu", q, group_by, g, cnt[g], (unsigned long long)ocnt[g]);
 				if (!ocnt[g]) continue;

@@ -134,11 +134,19 @@ def test_svcstate_filter_sort_topk_and_aggregation_equal_numpy():
         dict(terms=[("qps5s", ">", q50, 0), ("resp5s", "<=", 20, 0), ("usercpu", ">", 300, 1), ("syscpu", ">", 80, 1), ("delayus", ">=", 50000, 2)],
              group_oper=["and", "or", "and"], top_oper="and"),
         dict(terms=[("qps5s", ">=", 0)], machine_ids=[mids[3], mids[17], mids[35], wire.machine_id(999)]),  # host 35: stale, 999: unknown
+        # the query names its listeners (svcid = / in: the reference's direct-lookup path) -- some current, one deleted, one stale, one unknown
+        dict(terms=[("nconns", ">=", 0)], svcids=[int(wire.glob_id(h_, s__)) for h_, s__ in ((0, 3), (2, 7), (9, 7), (9, 8), (29, 49), (33, 1))] + [12345]),
+        dict(terms=[("qps5s", ">", q50)], clusters=["cl1", "nosuchcluster"]),
+        dict(terms=None, clusters=["cl0", "cl2"], machine_ids=[mids[0], mids[1], mids[2], mids[3]]),          # hosts 0, 2, 3 (cl0, cl2, cl0)
     ]
     for ci, case in enumerate(cases):
         m = match(rec, case.get("terms"), case.get("group_oper", ()), case.get("top_oper", "and"))
         if case.get("machine_ids"):
-            m &= np.isin(host, [3, 17])
+            m &= np.isin(host, [h_ for h_ in range(30) if any(mids[h_] == x for x in case["machine_ids"])])
+        if case.get("clusters"):
+            m &= np.isin(host % 3, [int(c_[2:]) for c_ in case["clusters"] if c_.startswith("cl")])
+        if case.get("svcids"):
+            m &= np.isin(rec["glob_id"], np.array(case["svcids"], dtype=np.uint64))
         for sort_col, desc in ((None, True), ("qps5s", True), ("p95resp5s", False), ("kbin15s", True), ("vmdelus", False)):
             if sort_col is None:
                 order = np.argsort(slot[m], kind="stable")
@@ -149,7 +157,7 @@ def test_svcstate_filter_sort_topk_and_aggregation_equal_numpy():
             want_recs = rec[m][order]
             for maxrecs in (len(rec) + 5, 17, 1):
                 gs, gh, gr, nm = eng.svcstate_scan(case.get("terms"), case.get("group_oper", ()), case.get("top_oper", "and"), sort_col, desc, maxrecs,
-                                                   case.get("machine_ids"))
+                                                   case.get("machine_ids"), case.get("svcids"), case.get("clusters"))
                 assert nm == int(m.sum()), (ci, sort_col, maxrecs, nm, int(m.sum()))
                 k = min(maxrecs, len(want_slots))
                 assert gs.tolist() == want_slots[:k].tolist(), (ci, sort_col, desc, maxrecs)
@@ -158,7 +166,8 @@ def test_svcstate_filter_sort_topk_and_aggregation_equal_numpy():
         # the aggregation operators over the same matching set: global, per host, per cluster
         cols = ["qps5s", "resp5s", "kbin15s", "vmdelus", "ishttp", "nactive"]
         for group_by, gkey in ((0, np.zeros(len(rec), dtype=np.int64)), (1, host), (2, host % 3)):
-            got = eng.svcstate_aggr(cols, group_by, case.get("terms"), case.get("group_oper", ()), case.get("top_oper", "and"), case.get("machine_ids"))
+            got = eng.svcstate_aggr(cols, group_by, case.get("terms"), case.get("group_oper", ()), case.get("top_oper", "and"), case.get("machine_ids"),
+                                    svcids=case.get("svcids"), clusters=case.get("clusters"))
             want = []
             for g in np.unique(gkey[m]):
                 sel = m & (gkey == g)
