@@ -1417,8 +1417,12 @@ int run_lstate(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, co
 		HIPCHK(hipMemsetAsync(c->svc_claim, 0, (uint64_t)c->cfg.max_services * 8, c->stream));
 	}
 	p.launch = c->lstate_launch;
-	hipLaunchKernelGGL(k_lstate_ingest, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
-	hipLaunchKernelGGL(k_lstate_keep, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
+	if (n <= GYS_LSTATE_FUSED_MAX) { // a partha's message: one launch (the per-message path is launch-bound)
+		hipLaunchKernelGGL(k_lstate_both, dim3(1), dim3(GYS_LSTATE_FUSED_MAX), 0, c->stream, p);
+	} else {
+		hipLaunchKernelGGL(k_lstate_ingest, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
+		hipLaunchKernelGGL(k_lstate_keep, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
+	}
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
 }

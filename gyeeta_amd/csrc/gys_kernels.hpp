@@ -2622,7 +2622,7 @@ struct ConnP {
 #ifndef GYS_CONN_SKIP
 #define GYS_CONN_SKIP 0 // TIMING EXPERIMENTS ONLY (results are wrong): 1 no flow hash / HLL, 2 nothing after the HLL, 4 no LDS aggregation, 8 loads only, 16 hash but no register access
 #endif
-// the words of a record the roll-up needs (the record's bytes [64, 224) and [264, 280) staged in LDS)
+// the words of a record the roll-up needs (nine 16-byte pieces of the record staged in LDS: GYS_CONN_PIECE_OFF)
 struct ConnRec {
 	uint64_t a0, a1, a2, a3; // nat_cli_ @64: ip128 (16 B), ip32 @16, port @24
 	uint64_t b0, b1, b2, b3; // nat_ser_ @96
@@ -2739,16 +2739,20 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool
 
 // Round 3: the records are read THROUGH LDS.  Round 2 had every lane read its own 280-byte record with thirteen 8-byte loads at a 280-byte
 // stride: every load instruction of a wave touched 64 different lines, each line was asked for by up to seven instructions in a row while
-// still in flight, and reading alone took 3.3 of the kernel's 3.4 ms (r3v: 1.4 TB/s).  Now a wave reads the bytes [64, 224) of its 64
-// records as 640 sixteen-byte pieces -- lane l of load t takes piece 64 t + l, i.e. ten neighbouring lanes cover one record's 160 bytes
-// and a load instruction covers ~6.4 records -- plus (round 4) the 16 bytes [264, 280) that hold the flag bytes as an eleventh piece per
-// record (704 pieces, eleven neighbouring lanes per record), through each record's own offset (no assumption that records are contiguous
-// or of equal size), parks them in its private LDS region at a 184-byte record stride (8-byte accesses at that stride spread over all
-// banks), and every lane then reads its record's fourteen words from LDS.  A workgroup is 512 threads and walks TWO rounds of 512 records, so that
+// still in flight, and reading alone took 3.3 of the kernel's 3.4 ms (r3v: 1.4 TB/s).  Now a wave reads what the roll-up needs of its 64
+// records as sixteen-byte pieces -- lane l of load t takes piece 64 t + l, i.e. neighbouring lanes cover one record and a load instruction
+// covers ~7 records.  Round 3 read the ten pieces of [64, 224); round 4 needs the flag bytes too and reads NINE pieces per record: the
+// eight that hold a field of the roll-up plus [264, 280) (GYS_CONN_PIECE_OFF; eleven were 1.31 ms, r4d) -- through each record's own
+// offset (no assumption that records are contiguous or of equal size), parks them in its private LDS region at a 152-byte record stride
+// (8-byte accesses at that stride spread over all banks), and every lane then reads its record's fourteen words from LDS.  A workgroup is 512 threads and walks TWO rounds of 512 records, so that
 // the LDS aggregation of the service accumulators still spans 1024 consecutive records (a partha's message is 2048 records of few services).
-#define GYS_CONN_STAGE_STRIDE 184u // bytes per staged record (176 used: bytes [64, 224) at 0, bytes [264, 280) at 160)
+#define GYS_CONN_STAGE_STRIDE 152u // bytes per staged record (144 used: nine 16-byte pieces)
 #define GYS_CONN_ROUNDS (GYS_CONN_RECS / GYS_CONN_THREADS)
-#define GYS_CONN_PIECES 11u
+#define GYS_CONN_PIECES 9u
+// record offset of piece j: [64, 144) = nat_cli_, nat_ser_, tusec_start_ / tusec_close_ (j = 0..4), [144, 160) = cli_task_aggr_id_ (5),
+// [192, 208) = ser_glob_id_ (6), [208, 224) = bytes_sent_ / bytes_rcvd_ (7), [264, 280) = the flag bytes (8) -- the two pieces [160, 192)
+// (cli_madhava_id_, cli_ser_machine_id_: nothing the roll-up reads) are not fetched as pieces of their own
+#define GYS_CONN_PIECE_OFF(j) (64u + 16u * (j) + ((j) >= 6u ? 32u : 0u) + ((j) == 8u ? 40u : 0u))
 __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 {
 	// Records reach madhava message by message, a message = up to 2048 connections of ONE partha (comm::TCP_CONN_NOTIFY::MAX_NUM_CONNS,
@@ -2776,21 +2780,21 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 		const uint32_t i = i0 + lane;
 		const uint32_t nrec = min(64u, p.n - i0);
 		const uint32_t off = p.offsets[i < p.n ? i : p.n - 1u];
-		// ---- 704 pieces of 16 bytes: piece q = 11 r + j is bytes [64 + 16 j, 80 + 16 j) of the wave's record r for j < 10, its bytes [264, 280) for j = 10
+		// ---- 576 pieces of 16 bytes: piece q = 9 r + j is bytes [GYS_CONN_PIECE_OFF(j), + 16) of the wave's record r
 		uint4 pc[GYS_CONN_PIECES];
 #pragma unroll
 		for (uint32_t t = 0; t < GYS_CONN_PIECES; ++t) {
 			const uint32_t q = t * 64u + lane;
-			const uint32_t r = (q * 5958u) >> 16; // q / 11 for q < 704
+			const uint32_t r = (q * 7282u) >> 16; // q / 9 for q < 576
 			const uint32_t j = q - r * GYS_CONN_PIECES;
 			const uint32_t ro = (uint32_t)__shfl((int)off, (int)min(r, nrec - 1u), 64); // (a piece past the wave's last record re-reads that record)
-			const uint32_t *src = (const uint32_t *)(p.batch + ro + (j < 10u ? 64u + 16u * j : 264u)); // records start 8-byte aligned (COMM_HEADER::validate common/gy_comm_proto.cc:23-26)
+			const uint32_t *src = (const uint32_t *)(p.batch + ro + GYS_CONN_PIECE_OFF(j)); // records start 8-byte aligned (COMM_HEADER::validate common/gy_comm_proto.cc:23-26)
 			pc[t] = make_uint4(src[0], src[1], src[2], src[3]);
 		}
 #pragma unroll
 		for (uint32_t t = 0; t < GYS_CONN_PIECES; ++t) {
 			const uint32_t q = t * 64u + lane;
-			const uint32_t r = (q * 5958u) >> 16;
+			const uint32_t r = (q * 7282u) >> 16;
 			const uint32_t j = q - r * GYS_CONN_PIECES;
 			uint64_t *dst = (uint64_t *)(st + r * GYS_CONN_STAGE_STRIDE + 16u * j);
 			dst[0] = (uint64_t)pc[t].x | ((uint64_t)pc[t].y << 32);
@@ -2802,12 +2806,12 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 			ConnRec rc;
 			rc.a0 = rw[0]; rc.a1 = rw[1]; rc.a2 = rw[2]; rc.a3 = rw[3];
 			rc.b0 = rw[4]; rc.b1 = rw[5]; rc.b2 = rw[6]; rc.b3 = rw[7];
-			rc.tusec_close = rw[9];   // @136 = 64 + 72
-			rc.task = rw[10];         // @144
-			rc.ser_glob_id = rw[16];  // @192 = 64 + 128
-			rc.bytes_sent = rw[18];   // @208
-			rc.bytes_rcvd = rw[19];   // @216
-			rc.flags = rw[21];        // @272 (staged at 160 + 8)
+			rc.tusec_close = rw[9];   // @136: piece 4, second half
+			rc.task = rw[10];         // @144: piece 5
+			rc.ser_glob_id = rw[12];  // @192: piece 6
+			rc.bytes_sent = rw[14];   // @208: piece 7
+			rc.bytes_rcvd = rw[15];   // @216
+			rc.flags = rw[17];        // @272: piece 8, second half
 			conn_one(p, rc, i < p.n, s_key, s_acc, s_tally);
 		}
 		GYS_WAVE_SYNC(); // (the region is rewritten by the next round)
@@ -2891,10 +2895,8 @@ struct LStateP {
 	uint32_t launch;                   // number of this ingest call (never 0)
 };
 
-__global__ __launch_bounds__(256) void k_lstate_ingest(LStateP p)
+__device__ __forceinline__ void lstate_ingest_one(const LStateP &p, uint32_t i)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= p.n) return;
 	const uint8_t *rec = p.batch + p.offsets[i];
 	const uint64_t *q = (const uint64_t *)rec; // 8-byte aligned records
 	uint64_t w[11];
@@ -2947,10 +2949,8 @@ __global__ __launch_bounds__(256) void k_lstate_ingest(LStateP p)
 
 // second pass of a LISTENER_STATE_NOTIFY call: the record that holds its listener's claim (the last one of the call in stream order) stores
 // the kept state -- or, for a record flagged LISTEN_FLAG_DELETE, marks the state as no longer current
-__global__ __launch_bounds__(256) void k_lstate_keep(LStateP p)
+__device__ __forceinline__ void lstate_keep_one(const LStateP &p, uint32_t i)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= p.n) return;
 	const uint64_t *q = (const uint64_t *)(p.batch + p.offsets[i]);
 	const uint64_t glob_id = q[0], w9 = q[9], w10 = q[10];
 	const uint32_t curr_state = (uint32_t)((w9 >> 56) & 0xFF), query_flags = (uint32_t)((w10 >> 32) & 0xFF);
@@ -2968,6 +2968,29 @@ __global__ __launch_bounds__(256) void k_lstate_keep(LStateP p)
 #pragma unroll
 	for (int k = 0; k < 11; ++k) d[k] = q[k];
 	d[11] = (uint64_t)p.epoch | ((uint64_t)host << 32);
+}
+
+__global__ __launch_bounds__(256) void k_lstate_ingest(LStateP p)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < p.n) lstate_ingest_one(p, i);
+}
+
+__global__ __launch_bounds__(256) void k_lstate_keep(LStateP p)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < p.n) lstate_keep_one(p, i);
+}
+
+// a partha's message (<= 512 records, comm::LISTENER_STATE_NOTIFY::MAX_NUM_LISTENERS) in ONE launch: both passes by one workgroup, the claims of
+// the first settled at the workgroup barrier (device-scope atomics on the claim words, read back by threads of the same workgroup)
+#define GYS_LSTATE_FUSED_MAX 1024u
+__global__ __launch_bounds__(GYS_LSTATE_FUSED_MAX) void k_lstate_both(LStateP p)
+{
+	const uint32_t i = threadIdx.x;
+	if (i < p.n) lstate_ingest_one(p, i);
+	__syncthreads();
+	if (i < p.n) lstate_keep_one(p, i);
 }
 
 // ---------------------------------------------------------------------------------------------------- window boundary

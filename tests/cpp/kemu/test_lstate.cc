@@ -136,8 +136,12 @@ int main(int argc, char **argv)
 		p.act_hist = act_hist.data();
 		p.claim = claim.data();
 		p.launch = epoch;
-		kemu::launch((n + 255u) / 256u, 256, 0, [&] { k_lstate_ingest(p); });
-		kemu::launch((n + 255u) / 256u, 256, 0, [&] { k_lstate_keep(p); });
+		if (n <= GYS_LSTATE_FUSED_MAX && (epoch & 1u)) { // (as run_lstate launches a message: both passes in one workgroup -- every other call here)
+			kemu::launch(1, GYS_LSTATE_FUSED_MAX, 0, [&] { k_lstate_both(p); });
+		} else {
+			kemu::launch((n + 255u) / 256u, 256, 0, [&] { k_lstate_ingest(p); });
+			kemu::launch((n + 255u) / 256u, 256, 0, [&] { k_lstate_keep(p); });
+		}
 		// several records of one listener in one call: the LAST one in stream order stays, whole (the reference's serial walk) -- want_state
 		// was built in that order above
 		for (uint32_t s = 0; s < NSVC; ++s) {
