@@ -179,17 +179,17 @@ void svcstate_object(gys_ctx *c, JsonBuf &j, const uint8_t *r, uint32_t slot, ui
 extern "C" {
 
 int gys_set_host_name(gys_ctx *c, const uint8_t machine_id[16], const char *hostname)
-{
+try {
 	if (!c || !machine_id || !hostname) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
 	if (rc) return rc;
 	c->host_names[host] = hostname;
 	return GYS_OK;
-}
+} GYS_CATCH_ALL
 
 int gys_json_svcsumm(gys_ctx *c, const uint8_t machine_id[16], const char *madhava_id16, const char *timestr, char *buf, size_t buflen, size_t *needed)
-{
+try {
 	if (!c || !machine_id) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
@@ -222,10 +222,11 @@ int gys_json_svcsumm(gys_ctx *c, const uint8_t machine_id[16], const char *madha
 	hostinfo_object(c, j, host, mad);
 	j.s += '}';
 	return json_out(j, buf, buflen, needed);
-}
+} GYS_CATCH_ALL
 
 int gys_json_svcstate(gys_ctx *c, const uint8_t machine_id[16], const char *madhava_id16, const char *timestr, char *buf, size_t buflen, size_t *needed)
-{
+try {
+	GYS_ENTER(c);
 	if (!c || !machine_id) return GYS_ERR_INVAL;
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
@@ -257,10 +258,11 @@ int gys_json_svcstate(gys_ctx *c, const uint8_t machine_id[16], const char *madh
 	hostinfo_object(c, j, host, mad);
 	j.s += '}';
 	return json_out(j, buf, buflen, needed);
-}
+} GYS_CATCH_ALL
 
 int gys_json_clusterstate(gys_ctx *c, const char *shyama_id16, const char *timestr, char *buf, size_t buflen, size_t *needed)
-{
+try {
+	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	const size_t nc = c->cluster_names.size();
 	std::vector<uint32_t> v(nc * 12 + 1);
@@ -299,7 +301,7 @@ int gys_json_clusterstate(gys_ctx *c, const char *shyama_id16, const char *times
 	j.arr_close();
 	j.s += '}';
 	return json_out(j, buf, buflen, needed);
-}
+} GYS_CATCH_ALL
 
 // web_curr_top_listeners (server/gy_mnodehandle.cc:2706-3190).  machine_id != NULL: the single-host form (the host's four top-10 queues,
 // optional summstats, hostinfo); NULL: the multi-host form -- every host's queues merged into MAX_MULTI_TOPN = 50 slots per kind
@@ -357,7 +359,8 @@ static void top_entry(gys_ctx *c, JsonBuf &j, const uint8_t *r, uint32_t slot, u
 
 int gys_json_toplisteners(gys_ctx *c, const uint8_t machine_id[16], uint32_t flags, const char *madhava_id16, const char *timestr, char *buf, size_t buflen,
 			  size_t *needed)
-{
+try {
+	GYS_ENTER(c);
 	if (!c) return GYS_ERR_INVAL;
 	if (!(flags & (GYS_TOP_ISSUE | GYS_TOP_QPS | GYS_TOP_ACTCONN | GYS_TOP_NET))) {
 		set_err("Top Listeners Query : Query requested with no valid Top criteria"); // (:2757)
@@ -432,6 +435,6 @@ int gys_json_toplisteners(gys_ctx *c, const uint8_t machine_id[16], uint32_t fla
 	if (!multi) hostinfo_object(c, j, host, mad);
 	j.s += '}';
 	return json_out(j, buf, buflen, needed);
-}
+} GYS_CATCH_ALL
 
 } // extern "C"
