@@ -206,6 +206,15 @@ public:
 			return gys_json_svcstate_multihost(ctx_, filter, sort_col, sort_desc ? 1 : 0, maxrecs, madid, timestr, b, n, need);
 		});
 	}
+	// MCONN_HANDLER::web_curr_listener_summ, multi-host form (server/gy_mnodehandle.cc:1628-1690): every partha with a recent listener state
+	// whose LISTEN_SUMM_STATS row passes the criteria (terms name GYS_SUMM_COL_*)
+	bool web_curr_listener_summ_multihost(const gys_svc_filter *filter, int sort_col, bool sort_desc, uint32_t maxrecs, const char *madid,
+					      const char *timestr, std::string &out) noexcept
+	{
+		return json_call(out, [&](char *b, size_t n, size_t *need) {
+			return gys_json_svcsumm_multihost(ctx_, filter, sort_col, sort_desc ? 1 : 0, maxrecs, madid, timestr, b, n, need);
+		});
+	}
 	// the aggregation operators (AGGR_OPER_E, common/gy_json_field_maps.h:114-129) over the matching listeners: group_by 0 all / 1 host / 2 cluster
 	bool aggr_listener_state(const gys_svc_filter *filter, int group_by, const uint8_t *cols, uint32_t ncols, gys_svc_aggr_row *out, uint32_t maxrows,
 				 uint32_t *nrows) noexcept

@@ -311,6 +311,123 @@ try {
 	return GYS_OK;
 } GYS_CATCH_ALL
 
+// CRITERIA_SET::match_criteria (common/gy_query_criteria.h:1535-1605, :1806-1900) on one host's LISTEN_SUMM_STATS<int> row (the 13 numeric
+// columns of json_db_svcsumm_arr: SvcSummFields::get_num_field server/gy_mfields.h:768-790) -- the host-side twin of svc_filter_match
+static bool summ_filter_match(const gys_svc_filter *f, const int32_t row[GYS_SUMM_NCOLS])
+{
+	if (!f || f->nterms == 0) return true;
+	uint32_t pass = 0, fail = 0, seen = 0;
+	for (uint32_t i = 0; i < f->nterms; ++i) {
+		const gys_svc_term &t = f->terms[i];
+		const uint32_t bit = 1u << t.group;
+		seen |= bit;
+		const int32_t v = row[t.col], crit = (int32_t)t.value;
+		bool m = false;
+		switch (t.comp) {
+		case GYS_COMP_EQ: m = v == crit; break;
+		case GYS_COMP_NEQ: m = v != crit; break;
+		case GYS_COMP_LT: m = v < crit; break;
+		case GYS_COMP_LE: m = v <= crit; break;
+		case GYS_COMP_GT: m = v > crit; break;
+		case GYS_COMP_GE: m = v >= crit; break;
+		case GYS_COMP_BIT2: m = (v & 3) == 3; break;
+		case GYS_COMP_BIT3: m = (v & 7) == 7; break;
+		default: { // IN / NOTIN
+			bool found = false;
+			for (uint32_t k = 0; k < t.nvalues; ++k) found = found || (int32_t)f->set_values[t.set_first + k] == v;
+			m = t.comp == GYS_COMP_IN ? found : !found;
+		}
+		}
+		if (f->group_oper[t.group]) {
+			if (m) pass |= bit;
+		} else if (!m)
+			fail |= bit;
+	}
+	uint32_t gpass = 0;
+	for (uint32_t g = 0; g < GYS_SVC_MAX_GROUPS; ++g) {
+		const uint32_t bit = 1u << g;
+		if (!(seen & bit)) continue;
+		if (f->group_oper[g] ? (pass & bit) != 0 : (fail & bit) == 0) gpass |= bit;
+	}
+	return f->top_oper ? gpass != 0 : gpass == seen;
+}
+
+int gys_json_svcsumm_multihost(gys_ctx *c, const gys_svc_filter *f, int sort_col, int sort_desc, uint32_t maxrecs, const char *madhava_id16,
+			       const char *timestr, char *buf, size_t buflen, size_t *needed)
+try {
+	GYS_ENTER(c);
+	if (!c || sort_col >= (int)GYS_SUMM_NCOLS) return GYS_ERR_INVAL;
+	if (f) {
+		if (f->nterms > GYS_SVC_MAX_TERMS || (f->nterms && !f->terms)) return GYS_ERR_INVAL;
+		for (uint32_t i = 0; i < f->nterms; ++i) {
+			const gys_svc_term &t = f->terms[i];
+			const bool in = t.comp == GYS_COMP_IN || t.comp == GYS_COMP_NOTIN;
+			if (t.col >= GYS_SUMM_NCOLS || t.group >= GYS_SVC_MAX_GROUPS || !(t.comp <= GYS_COMP_BIT3 || in) ||
+			    (in && ((uint64_t)t.set_first + t.nvalues > f->nset_values || (t.nvalues && !f->set_values)))) {
+				set_err("summary filter term %u out of range", i);
+				return GYS_ERR_INVAL;
+			}
+		}
+	}
+	const uint32_t nh = (uint32_t)c->hosts.size();
+	std::vector<int32_t> summ((size_t)nh * 16);
+	if (nh) {
+		HIPCHK(hipMemcpyAsync(summ.data(), c->host_summ_last, (size_t)nh * 64, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
+	// the hosts of the query (machine ids and / or clusters), as the device query builds its host mask
+	std::vector<uint8_t> in_host(nh, (f && f->nmachine_ids) ? 0 : 1);
+	if (f && f->nmachine_ids) {
+		if (!f->machine_ids) return GYS_ERR_INVAL;
+		for (uint32_t i = 0; i < f->nmachine_ids; ++i) {
+			uint32_t h;
+			if (lookup_host(c, f->machine_ids + (size_t)i * 16, &h) == GYS_OK) in_host[h] = 1;
+		}
+	}
+	if (f && f->nclusters) {
+		if (!f->clusters) return GYS_ERR_INVAL;
+		std::vector<uint8_t> want(c->cluster_names.size(), 0);
+		for (uint32_t i = 0; i < f->nclusters; ++i) {
+			auto it = f->clusters[i] ? c->cluster_map.find(f->clusters[i]) : c->cluster_map.end();
+			if (it != c->cluster_map.end()) want[it->second] = 1;
+		}
+		for (uint32_t h = 0; h < nh; ++h)
+			if (!want[c->host_cluster_h[h]]) in_host[h] = 0;
+	}
+	std::vector<uint32_t> rows;
+	for (uint32_t h = 0; h < nh; ++h) {
+		const int32_t *r = &summ[(size_t)h * 16];
+		if (!in_host[h] || r[GYS_SUMM_COL_NSVC] == 0) continue; // no listener state of this host in the last window: its data is not recent (:1656)
+		if (summ_filter_match(f, r)) rows.push_back(h);
+	}
+	if (sort_col >= 0)
+		std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) {
+			const int32_t x = summ[(size_t)a * 16 + sort_col], y = summ[(size_t)b * 16 + sort_col];
+			return sort_desc ? x > y : x < y;
+		});
+	if (rows.size() > maxrecs) rows.resize(maxrecs);
+	const char *mad = madhava_id16 ? madhava_id16 : "";
+	JsonBuf j;
+	j.s += '{';
+	j.kstr("madid", mad, 16);
+	j.arr_open("summstats");
+	for (uint32_t h : rows) {
+		const int32_t *r = &summ[(size_t)h * 16];
+		j.obj_open();
+		j.kstr("parid", machid_string(c->hosts[h]));
+		j.kstr("host", c->host_names[h]);
+		j.kstr("madid", mad, 16);
+		j.kstr("cluster", c->cluster_names[c->host_cluster_h[h]]);
+		j.kstr("time", timestr ? timestr : "", 64);
+		static const char *names[GYS_SUMM_NCOLS] = {"nidle", "ngood", "nok", "nbad", "nsevere", "ndown", "totqps", "totaconn", "totkbin", "totkbout", "totsererr", "nsvc", "nactive"};
+		for (int k = 0; k < (int)GYS_SUMM_NCOLS; ++k) j.ki(names[k], r[k]);
+		j.obj_close();
+	}
+	j.arr_close();
+	j.s += '}';
+	return json_out(j, buf, buflen, needed);
+} GYS_CATCH_ALL
+
 int gys_svc_aggr_value(const gys_svc_aggr_row *row, uint32_t col_index, int oper, double *out)
 {
 	if (!row || !out || col_index >= GYS_SVC_MAX_AGGR || (oper != GYS_AOPER_COUNT && col_index >= row->ncols)) return GYS_ERR_INVAL;

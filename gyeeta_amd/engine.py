@@ -360,14 +360,20 @@ class SketchEngine:
         m = mid_buf(machine_id) if machine_id is not None else None
         return self._json(self.L.gys_json_toplisteners, m, flags, madid.encode(), timestr.encode())
 
-    def _svc_filter(self, terms, group_oper=(), top_oper="and", machine_ids=None, svcids=None, clusters=None):
+    def json_svcsumm_multihost(self, terms=None, group_oper=(), top_oper="and", sort_col=None, sort_desc=True, maxrecs=1 << 30, machine_ids=None,
+                               clusters=None, madid="0" * 16, timestr=""):
+        f, keep = self._svc_filter(terms, group_oper, top_oper, machine_ids, None, clusters, cols=capi.SUMM_COLS)
+        return self._json(self.L.gys_json_svcsumm_multihost, C.byref(f), -1 if sort_col is None else capi.SUMM_COLS.index(sort_col), 1 if sort_desc else 0,
+                          maxrecs, madid.encode(), timestr.encode())
+
+    def _svc_filter(self, terms, group_oper=(), top_oper="and", machine_ids=None, svcids=None, clusters=None, cols=None):
         """terms: [(column name, comparator, value or list of values, group = 0)]; group_oper: per group "and" / "or"; -> (SvcFilter, keep-alive)"""
         terms = list(terms or [])
         arr = (capi.SvcTerm * max(len(terms), 1))()
         setv = []
         for i, t in enumerate(terms):
             col, comp, val = t[0], t[1], t[2]
-            arr[i].col = capi.SVC_COLS.index(col)
+            arr[i].col = (cols or capi.SVC_COLS).index(col)
             arr[i].comp = capi.COMP[comp]
             arr[i].group = t[3] if len(t) > 3 else 0
             if comp in ("in", "notin"):

@@ -509,6 +509,16 @@ typedef struct {
 int gys_query_svcstate_aggr(gys_ctx *ctx, const gys_svc_filter *filter, int group_by, const uint8_t *cols, uint32_t ncols, gys_svc_aggr_row *out,
 			    uint32_t maxrows, uint32_t *nrows);
 int gys_svc_aggr_value(const gys_svc_aggr_row *row, uint32_t col_index, int oper, double *out);
+/* The multi-host form of web_curr_listener_summ (server/gy_mnodehandle.cc:1628-1690: the walk over partha_tbl_, SvcSummFields::filter_match per
+ * host, hosts whose listener state is older than 10 s skipped): {"madid":..,"summstats":[{"parid","host","madid","cluster", then the
+ * json_db_svcsumm_arr columns}, ...]} for every host that reported listener states in the last finished window and passes the filter.  The
+ * filter is a gys_svc_filter whose terms name the numeric columns of json_db_svcsumm_arr (common/gy_json_field_maps.h:1396-1416):
+ * GYS_SUMM_COL_*; machine_ids / clusters select hosts, svcids is ignored.  Rows in host-slot order, or sorted by sort_col (then host slot);
+ * at most maxrecs rows.  (A few thousand 52-byte rows: filtered on the host side after one copy of the per-host summaries.) */
+enum { GYS_SUMM_COL_NIDLE = 0, GYS_SUMM_COL_NGOOD, GYS_SUMM_COL_NOK, GYS_SUMM_COL_NBAD, GYS_SUMM_COL_NSEVERE, GYS_SUMM_COL_NDOWN, GYS_SUMM_COL_TOTQPS,
+       GYS_SUMM_COL_TOTACONN, GYS_SUMM_COL_TOTKBIN, GYS_SUMM_COL_TOTKBOUT, GYS_SUMM_COL_TOTSERERR, GYS_SUMM_COL_NSVC, GYS_SUMM_COL_NACTIVE, GYS_SUMM_NCOLS };
+int gys_json_svcsumm_multihost(gys_ctx *ctx, const gys_svc_filter *filter, int sort_col, int sort_desc, uint32_t maxrecs, const char *madhava_id16,
+			       const char *timestr, char *buf, size_t buflen, size_t *needed);
 
 /* The per-listener 5-second scan from the engine's OWN state (needs gys_config.enable_levels): replaces the loop of
  * TCP_SOCK_HANDLER::listener_stats_update (common/gy_socket_stat.cc:4044-4365) that turns every listener's counters and histograms into

@@ -213,6 +213,75 @@ def test_svcstate_filter_sort_topk_and_aggregation_equal_numpy():
     eng.close()
 
 
+def test_svcsumm_multihost_filter_equals_numpy():
+    """web_curr_listener_summ, multi-host form: every host that reported in the last window, filtered on the LISTEN_SUMM_STATS columns,
+    sorted, capped; envelope and column order of the reference (host columns first, then json_db_svcsumm_arr)"""
+    from tests import test_gpu_json as tj
+    rng = np.random.default_rng(77)
+    nh, sp = 24, 30
+    eng = _engine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False, max_clusters=4)
+    mids = [wire.machine_id(h) for h in range(nh)]
+    s_ = np.arange(sp)
+    for h in range(nh):
+        eng.register_host(mids[h], "cl%d" % (h % 3))
+        eng.set_host_name(mids[h], "host%03d" % h)
+        eng.register_listeners_np(mids[h], wire.glob_id(np.full(sp, h), s_), wire.listener_netns(h, s_), wire.listener_port(s_))
+    want = {}
+    for h in range(nh):
+        if h % 7 == 6:
+            continue  # these hosts send nothing in the window: not listed
+        ls = wire.synth_listener_states(rng, h, s_, bad_state_frac=0.05)
+        eng.partha_listener_state(mids[h], ls.tobytes(), sp)
+        ok = ls["curr_state"] <= 5
+        st = np.bincount(ls["curr_state"][ok], minlength=6)[:6]
+        want[h] = [int(x) for x in st] + [int((ls["nqrys_5s"][ok] // 5).sum()), int(ls["nconns_active"][ok].sum()), int(ls["curr_kbytes_inbound"][ok].sum()),
+                                          int(ls["curr_kbytes_outbound"][ok].sum()), int(ls["ser_errors"][ok].sum()), int(ok.sum()), int((ls["nqrys_5s"][ok] > 0).sum())]
+    eng.window_close()
+    cols = capi.SUMM_COLS
+    rows = np.array([want[h] for h in sorted(want)], dtype=np.int64)
+    hosts = np.array(sorted(want))
+    medq = int(np.median(rows[:, cols.index("totqps")]))
+    cases = [
+        dict(),
+        dict(terms=[("totqps", ">", medq)]),
+        dict(terms=[("nbad", ">", 2), ("nsevere", ">=", 2)], group_oper=["or"], sort_col="totaconn", sort_desc=True),
+        dict(terms=[("totsererr", "<", 60, 0), ("nactive", ">=", 20, 1), ("ndown", "=", 0, 1)], group_oper=["and", "and"], top_oper="or", sort_col="totkbin", sort_desc=False, maxrecs=5),
+        dict(terms=[("nsvc", ">=", 1)], clusters=["cl2"], sort_col="totqps"),
+        dict(machine_ids=[mids[1], mids[6], mids[9]]),  # host 6 sent nothing
+    ]
+    for ci, case in enumerate(cases):
+        m = np.ones(len(rows), dtype=bool)
+        if case.get("terms"):
+            groups = {}
+            for t in case["terms"]:
+                v = rows[:, cols.index(t[0])]
+                mm = {"=": v == t[2], "!=": v != t[2], "<": v < t[2], "<=": v <= t[2], ">": v > t[2], ">=": v >= t[2]}[t[1]]
+                groups.setdefault(t[3] if len(t) > 3 else 0, []).append(mm)
+            res = []
+            for g, ms in sorted(groups.items()):
+                o = case.get("group_oper", ["and"] * 8)[g]
+                res.append(np.logical_or.reduce(ms) if o == "or" else np.logical_and.reduce(ms))
+            m = np.logical_or.reduce(res) if case.get("top_oper") == "or" else np.logical_and.reduce(res)
+        if case.get("clusters"):
+            m &= np.isin(hosts % 3, [int(c_[2:]) for c_ in case["clusters"]])
+        if case.get("machine_ids"):
+            m &= np.isin(hosts, [h for h in range(nh) if any(mids[h] == x for x in case["machine_ids"])])
+        sel = np.nonzero(m)[0]
+        if case.get("sort_col"):
+            v = rows[sel, cols.index(case["sort_col"])]
+            sel = sel[np.argsort(-v if case.get("sort_desc", True) else v, kind="stable")]
+        sel = sel[:case.get("maxrecs", 1 << 30)]
+        js = json.loads(eng.json_svcsumm_multihost(case.get("terms"), case.get("group_oper", ()), case.get("top_oper", "and"), case.get("sort_col"),
+                                                   case.get("sort_desc", True), case.get("maxrecs", 1 << 30), case.get("machine_ids"), case.get("clusters"),
+                                                   madid="cd" * 8, timestr="T"))
+        assert list(js.keys()) == ["madid", "summstats"] and js["madid"] == "cd" * 8
+        assert [r["host"] for r in js["summstats"]] == ["host%03d" % hosts[i] for i in sel], ci
+        for r, i in zip(js["summstats"], sel):
+            assert list(r.keys()) == ["parid", "host", "madid", "cluster"] + tj.SVCSUMM_COLS
+            assert [r[c_] for c_ in cols] == rows[i].tolist() and r["cluster"] == "cl%d" % (hosts[i] % 3)
+    eng.close()
+
+
 def test_svcstate_scan_at_scale_top_1000_of_many_services():
     """10^6 services over 1 000 hosts: filter + exact top-1000 by a column equals numpy; the kernel time is printed (bench.py reports the
     10^7-service figure)"""

@@ -85,3 +85,13 @@ def test_filter_query_tables_equal_the_reference():
     for k, v in capi.AOPER.items():  # ... and the header's GYS_AOPER_* carry the same numbers
         mm = re.search(r"GYS_AOPER_" + k.upper() + r"(?:\s*=\s*(\d+))?", hdr)
         assert mm, k
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not mounted")
+def test_summary_query_columns_equal_the_reference():
+    """gys_json_svcsumm_multihost: GYS_SUMM_COL_* are the numeric columns of json_db_svcsumm_arr in the reference's order"""
+    from gyeeta_amd import capi
+    assert _ref_columns("json_db_svcsumm_arr") == ["time"] + capi.SUMM_COLS
+    hdr = open(os.path.join(ROOT, "include", "gysketch.h")).read()
+    names = re.findall(r"GYS_SUMM_COL_(\w+)", re.search(r"enum \{ GYS_SUMM_COL_NIDLE = 0,(.*?)GYS_SUMM_NCOLS \};", hdr, re.S).group(0))
+    assert [n.lower() for n in names] == capi.SUMM_COLS
