@@ -2749,6 +2749,9 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool
 #define GYS_CONN_STAGE_STRIDE 152u // bytes per staged record (144 used: nine 16-byte pieces)
 #define GYS_CONN_ROUNDS (GYS_CONN_RECS / GYS_CONN_THREADS)
 #define GYS_CONN_PIECES 9u
+#ifndef GYS_CONN_PREFETCH
+#define GYS_CONN_PREFETCH 1
+#endif
 // record offset of piece j: [64, 144) = nat_cli_, nat_ser_, tusec_start_ / tusec_close_ (j = 0..4), [144, 160) = cli_task_aggr_id_ (5),
 // [192, 208) = ser_glob_id_ (6), [208, 224) = bytes_sent_ / bytes_rcvd_ (7), [264, 280) = the flag bytes (8) -- the two pieces [160, 192)
 // (cli_madhava_id_, cli_ser_machine_id_: nothing the roll-up reads) are not fetched as pieces of their own
@@ -2773,15 +2776,16 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint8_t *const st = s_stage[wave];
-#pragma unroll 1
-	for (uint32_t round = 0; round < GYS_CONN_ROUNDS; ++round) {
-		const uint32_t i0 = blockIdx.x * GYS_CONN_RECS + round * GYS_CONN_THREADS + wave * 64u; // the wave's first record
-		if (i0 >= p.n) break;
+	// ---- 576 pieces of 16 bytes per wave and round: piece q = 9 r + j is bytes [GYS_CONN_PIECE_OFF(j), + 16) of the wave's record r.
+	// The pieces of round k + 1 are REQUESTED right after round k's were stored to the LDS, so that they are in flight
+	// while round k is hashed and tallied (GYS_CONN_PREFETCH 0 = round 4's order: request, store, work, request ...).
+	uint4 pc[GYS_CONN_PIECES];
+	auto request = [&](uint32_t round) {
+		const uint32_t i0 = blockIdx.x * GYS_CONN_RECS + round * GYS_CONN_THREADS + wave * 64u;
+		if (round >= GYS_CONN_ROUNDS || i0 >= p.n) return;
 		const uint32_t i = i0 + lane;
 		const uint32_t nrec = min(64u, p.n - i0);
 		const uint32_t off = p.offsets[i < p.n ? i : p.n - 1u];
-		// ---- 576 pieces of 16 bytes: piece q = 9 r + j is bytes [GYS_CONN_PIECE_OFF(j), + 16) of the wave's record r
-		uint4 pc[GYS_CONN_PIECES];
 #pragma unroll
 		for (uint32_t t = 0; t < GYS_CONN_PIECES; ++t) {
 			const uint32_t q = t * 64u + lane;
@@ -2791,6 +2795,14 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 			const uint32_t *src = (const uint32_t *)(p.batch + ro + GYS_CONN_PIECE_OFF(j)); // records start 8-byte aligned (COMM_HEADER::validate common/gy_comm_proto.cc:23-26)
 			pc[t] = make_uint4(src[0], src[1], src[2], src[3]);
 		}
+	};
+	if (GYS_CONN_PREFETCH) request(0);
+#pragma unroll 1
+	for (uint32_t round = 0; round < GYS_CONN_ROUNDS; ++round) {
+		const uint32_t i0 = blockIdx.x * GYS_CONN_RECS + round * GYS_CONN_THREADS + wave * 64u; // the wave's first record
+		if (i0 >= p.n) break;
+		const uint32_t i = i0 + lane;
+		if (!GYS_CONN_PREFETCH) request(round);
 #pragma unroll
 		for (uint32_t t = 0; t < GYS_CONN_PIECES; ++t) {
 			const uint32_t q = t * 64u + lane;
@@ -2800,6 +2812,7 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 			dst[0] = (uint64_t)pc[t].x | ((uint64_t)pc[t].y << 32);
 			dst[1] = (uint64_t)pc[t].z | ((uint64_t)pc[t].w << 32);
 		}
+		if (GYS_CONN_PREFETCH) request(round + 1u);
 		GYS_WAVE_SYNC();
 		{
 			const uint64_t *rw = (const uint64_t *)(st + lane * GYS_CONN_STAGE_STRIDE);
@@ -2895,7 +2908,43 @@ struct LStateP {
 	uint32_t launch;                   // number of this ingest call (never 0)
 };
 
-__device__ __forceinline__ void lstate_ingest_one(const LStateP &p, uint32_t i)
+// Per-workgroup LDS roll-up of the walk's sums (round 4, after r4g): the records of one partha arrive together, so the 256 records of a
+// workgroup name two or three hosts, and round 3's eight device-scope adds per record (plus one per record on the call's record counter)
+// lined up on a handful of addresses -- 70 of the call's 86 us at 10^5 records.  Hosts claim one of 64 LDS rows (open addressing, eight
+// probes; a record that finds none adds to the device rows directly) and the rows are added to LISTEN_SUMM_STATS once per workgroup.
+#define GYS_LS_AGG 64u
+struct LStateAgg {
+	uint32_t hk[GYS_LS_AGG];
+	int32_t hs[GYS_LS_AGG][13];
+	uint32_t cnt[3]; // missed, deleted, errors
+};
+__device__ __forceinline__ void lstate_agg_init(LStateAgg &a)
+{
+	for (uint32_t k = threadIdx.x; k < GYS_LS_AGG; k += blockDim.x) {
+		a.hk[k] = GYS_NOSLOT;
+#pragma unroll
+		for (int j = 0; j < 13; ++j) a.hs[k][j] = 0;
+	}
+	if (threadIdx.x < 3) a.cnt[threadIdx.x] = 0;
+	__syncthreads();
+}
+__device__ __forceinline__ void lstate_agg_flush(const LStateP &p, LStateAgg &a, uint32_t first)
+{
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < GYS_LS_AGG * 13u; k += blockDim.x) {
+		const uint32_t row = k / 13u, j = k - row * 13u;
+		const int32_t v = a.hs[row][j];
+		if (v && a.hk[row] != GYS_NOSLOT) atomicAdd(&p.host_summ[(size_t)a.hk[row] * 16 + j], v);
+	}
+	if (threadIdx.x < 3 && a.cnt[threadIdx.x]) {
+		const int ctr = threadIdx.x == 0 ? CTR_LSTATE_MISSED : threadIdx.x == 1 ? CTR_LSTATE_DELETED : CTR_LSTATE_ERRORS;
+		atomicAdd((unsigned long long *)&p.counters[ctr], (unsigned long long)a.cnt[threadIdx.x]);
+	}
+	if (threadIdx.x == 3 && first < p.n)
+		atomicAdd((unsigned long long *)&p.counters[CTR_LSTATE_RECORDS], (unsigned long long)min((uint32_t)blockDim.x, p.n - first));
+}
+
+__device__ __forceinline__ void lstate_ingest_one(const LStateP &p, uint32_t i, LStateAgg &a)
 {
 	const uint8_t *rec = p.batch + p.offsets[i];
 	const uint64_t *q = (const uint64_t *)rec; // 8-byte aligned records
@@ -2908,33 +2957,51 @@ __device__ __forceinline__ void lstate_ingest_one(const LStateP &p, uint32_t i)
 	const uint32_t kb_in = (uint32_t)(w[4] >> 32), kb_out = (uint32_t)w[5], ser_errors = (uint32_t)(w[5] >> 32);
 	const uint32_t curr_state = (uint32_t)((w[9] >> 56) & 0xFF);  // byte 79
 	const uint32_t query_flags = (uint32_t)((w[10] >> 32) & 0xFF); // byte 84
-	atomicAdd((unsigned long long *)&p.counters[CTR_LSTATE_RECORDS], 1ull);
 
 	const uint32_t slot = tbl_lookup(p.gid, glob_id); // listen_tbl_.lookup_single_elem_locked(glob_id, get_uint64_hash(glob_id)) :11183
 	if (slot == GYS_NOSLOT) {
-		atomicAdd((unsigned long long *)&p.counters[CTR_LSTATE_MISSED], 1ull); // nmissed++ :11185-11188
+		atomicAdd(&a.cnt[0], 1u); // nmissed++ :11185-11188
 		return;
 	}
 	if (query_flags == 0xC0u) { // LISTEN_FLAG_DELETE :11194
-		atomicAdd((unsigned long long *)&p.counters[CTR_LSTATE_DELETED], 1ull);
+		atomicAdd(&a.cnt[1], 1u);
 		atomicMax(&p.claim[slot], ((unsigned long long)p.launch << 32) | (unsigned long long)(i + 1u)); // (k_lstate_keep: state no longer current)
 		return;
 	}
 	if (curr_state > 5u) { // :11250-11256
-		atomicAdd((unsigned long long *)&p.counters[CTR_LSTATE_ERRORS], 1ull);
+		atomicAdd(&a.cnt[2], 1u);
 		return;
 	}
 	const uint32_t host = p.host_slot ? p.host_slot[i] : p.single_host;
-	int32_t *s = p.host_summ + (size_t)host * 16;
+	uint32_t row = (host * 0x9E3779B1u) >> 26;
+	bool lds = false;
+#pragma unroll 1
+	for (int t = 0; t < 8; ++t, row = (row + 1u) & (GYS_LS_AGG - 1u)) {
+		const uint32_t prev = atomicCAS(&a.hk[row], GYS_NOSLOT, host);
+		if (prev == GYS_NOSLOT || prev == host) { lds = true; break; }
+	}
 	// LISTEN_SUMM_STATS::update server/gy_msocket.h:853-865 (per-record integer quotient nqrys_5s_/5)
-	atomicAdd(&s[curr_state], 1);
-	if (nqrys_5s / 5u) atomicAdd(&s[6], (int32_t)(nqrys_5s / 5u));
-	if (nconns_active) atomicAdd(&s[7], (int32_t)nconns_active);
-	if (kb_in) atomicAdd(&s[8], (int32_t)kb_in);
-	if (kb_out) atomicAdd(&s[9], (int32_t)kb_out);
-	if (ser_errors) atomicAdd(&s[10], (int32_t)ser_errors);
-	atomicAdd(&s[11], 1);
-	if (nqrys_5s) atomicAdd(&s[12], 1);
+	if (lds) {
+		int32_t *s = a.hs[row];
+		atomicAdd(&s[curr_state], 1);
+		if (nqrys_5s / 5u) atomicAdd(&s[6], (int32_t)(nqrys_5s / 5u));
+		if (nconns_active) atomicAdd(&s[7], (int32_t)nconns_active);
+		if (kb_in) atomicAdd(&s[8], (int32_t)kb_in);
+		if (kb_out) atomicAdd(&s[9], (int32_t)kb_out);
+		if (ser_errors) atomicAdd(&s[10], (int32_t)ser_errors);
+		atomicAdd(&s[11], 1);
+		if (nqrys_5s) atomicAdd(&s[12], 1);
+	} else {
+		int32_t *s = p.host_summ + (size_t)host * 16;
+		atomicAdd(&s[curr_state], 1);
+		if (nqrys_5s / 5u) atomicAdd(&s[6], (int32_t)(nqrys_5s / 5u));
+		if (nconns_active) atomicAdd(&s[7], (int32_t)nconns_active);
+		if (kb_in) atomicAdd(&s[8], (int32_t)kb_in);
+		if (kb_out) atomicAdd(&s[9], (int32_t)kb_out);
+		if (ser_errors) atomicAdd(&s[10], (int32_t)ser_errors);
+		atomicAdd(&s[11], 1);
+		if (nqrys_5s) atomicAdd(&s[12], 1);
+	}
 	// MTCP_LISTENER::set_state server/gy_msocket.h:1410-1437 keeps the 88-byte record; the reference walks a message serially, so when
 	// several records of one call name the listener (a backlog of 5-s messages in one buffer) the LAST one stays, whole: the records
 	// claim the listener here and the owner of the claim stores in k_lstate_keep
@@ -2972,8 +3039,11 @@ __device__ __forceinline__ void lstate_keep_one(const LStateP &p, uint32_t i)
 
 __global__ __launch_bounds__(256) void k_lstate_ingest(LStateP p)
 {
+	__shared__ LStateAgg s_agg;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < p.n) lstate_ingest_one(p, i);
+	lstate_agg_init(s_agg);
+	if (i < p.n) lstate_ingest_one(p, i, s_agg);
+	lstate_agg_flush(p, s_agg, blockIdx.x * blockDim.x);
 }
 
 __global__ __launch_bounds__(256) void k_lstate_keep(LStateP p)
@@ -2987,8 +3057,11 @@ __global__ __launch_bounds__(256) void k_lstate_keep(LStateP p)
 #define GYS_LSTATE_FUSED_MAX 1024u
 __global__ __launch_bounds__(GYS_LSTATE_FUSED_MAX) void k_lstate_both(LStateP p)
 {
+	__shared__ LStateAgg s_agg;
 	const uint32_t i = threadIdx.x;
-	if (i < p.n) lstate_ingest_one(p, i);
+	lstate_agg_init(s_agg);
+	if (i < p.n) lstate_ingest_one(p, i, s_agg);
+	lstate_agg_flush(p, s_agg, 0u);
 	__syncthreads();
 	if (i < p.n) lstate_keep_one(p, i);
 }

@@ -41,7 +41,7 @@ int main(int argc, char **argv)
 		return 77;
 	}
 	std::mt19937 rng(argc > 1 ? (unsigned)atoi(argv[1]) : 3u);
-	const uint32_t NSVC = 50, NUNKNOWN = 6, NHOSTS = 3;
+	const uint32_t NSVC = 50, NUNKNOWN = 6, NHOSTS = 600;
 	std::vector<uint64_t> gids(NSVC + NUNKNOWN);
 	for (auto &g : gids) g = ((uint64_t)rng() << 32) | rng();
 	uint32_t cap = 128;
@@ -70,7 +70,7 @@ int main(int argc, char **argv)
 	CHECK(gyo_hist_nbuckets(GYO_SEMI_LOG_HASH_LO) <= 15 && gyo_hist_nbuckets(GYO_HASH_1_3000) <= 15, "a 15-bucket record cannot hold these histograms");
 	uint64_t want_rec = 0, want_missed = 0, want_deleted = 0, want_errors = 0;
 
-	for (uint32_t epoch = 1; epoch <= 4; ++epoch) {
+	for (uint32_t epoch = 1; epoch <= 6; ++epoch) {
 		const uint32_t n = epoch == 1 ? 1u : 200u + rng() % 400u;
 		std::vector<uint64_t> raw;
 		std::vector<uint32_t> offsets(n), host_slot(n);
@@ -94,7 +94,8 @@ int main(int argc, char **argv)
 			}
 			r[85] = (uint8_t)var;
 			r[86] = (uint8_t)pad;
-			host_slot[i] = epoch == 2 ? 1u : rng() % NHOSTS; // (call 2 goes through the single-host form)
+			// (call 2 goes through the single-host form; calls 5 and 6 name more hosts per workgroup than the LDS roll-up has rows: some records add to the device rows directly)
+			host_slot[i] = epoch == 2 ? 1u : epoch >= 5 ? rng() % NHOSTS : rng() % 3u;
 			// ---- expectation, record by record (server/gy_mconnhdlr.cc:11175-11256)
 			++want_rec;
 			if (s >= NSVC) {
