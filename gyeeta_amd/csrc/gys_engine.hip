@@ -1344,7 +1344,8 @@ int run_conn(gys_ctx *c, const uint8_t *d_batch, const uint32_t *d_offsets, uint
 	c->conn_dirty = true;
 	p.counters = c->counters;
 	ProfScope ps(c, "conn");
-	hipLaunchKernelGGL(k_conn_ingest, dim3((n + GYS_CONN_RECS - 1) / GYS_CONN_RECS), dim3(GYS_CONN_THREADS), 0, c->stream, p);
+	p.span = conn_span(n, c->ncu);
+	hipLaunchKernelGGL(k_conn_ingest, dim3((n + p.span - 1) / p.span), dim3(GYS_CONN_THREADS), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
 }

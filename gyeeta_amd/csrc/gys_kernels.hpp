@@ -2614,15 +2614,34 @@ struct ConnP {
 	unsigned long long *pair64;
 	uint32_t *cpair32;           // ... and client side
 	unsigned long long *cpair64;
+	uint32_t span;               // records per workgroup (conn_span: a multiple of 64)
 };
 
-#define GYS_CONN_THREADS 512u
-#define GYS_CONN_RECS 1024u // records per workgroup (two rounds of GYS_CONN_THREADS)
-#define GYS_CONN_AGG 2048u  // LDS aggregation slots per workgroup (power of two, 2 x the records of a workgroup)
+#ifndef GYS_CONN_THREADS
+#define GYS_CONN_THREADS 768u // twelve waves: what 160 KB of LDS hold at 7.5 KB of staged records per wave + the aggregation table
+#endif
+#define GYS_CONN_RECS (2u * GYS_CONN_THREADS) // records per workgroup of a SMALL call: two rounds of GYS_CONN_THREADS
+#ifndef GYS_CONN_SPAN
+#define GYS_CONN_SPAN (8u * GYS_CONN_THREADS) // ... and about this many in a large one (conn_span)
+#endif
+#define GYS_CONN_AGG 2048u // LDS aggregation slots per workgroup (power of two)
+#define GYS_CONN_AGG_SHIFT 21
+// Records per workgroup.  The services of a workgroup's records are added to the device accumulators once per workgroup, and those
+// device-scope adds are what the kernel pays for beside its reads (r4j: half the records per workgroup, 1.19 -> 1.38 ms; r4k: four times,
+// 1.156 -> 1.118 ms with a third of the last dispatch round idle).  So a large call gives a workgroup ~6144 records -- in as many workgroups
+// as fill every CU the same number of times (one workgroup per CU is resident: the LDS) -- and a call too small for that keeps 1536.
+static inline uint32_t conn_span(uint32_t n, uint32_t ncu)
+{
+	if (!ncu || (uint64_t)n <= (uint64_t)ncu * GYS_CONN_RECS) return GYS_CONN_RECS;
+	const uint64_t per_pass = (uint64_t)ncu * GYS_CONN_SPAN;
+	const uint64_t grid = (((uint64_t)n + per_pass - 1) / per_pass) * ncu;
+	const uint64_t span = ((uint64_t)n + grid - 1) / grid;
+	return (uint32_t)((span + 63u) & ~63ull);
+}
 #ifndef GYS_CONN_SKIP
 #define GYS_CONN_SKIP 0 // TIMING EXPERIMENTS ONLY (results are wrong): 1 no flow hash / HLL, 2 nothing after the HLL, 4 no LDS aggregation, 8 loads only, 16 hash but no register access
 #endif
-// the words of a record the roll-up needs (nine 16-byte pieces of the record staged in LDS: GYS_CONN_PIECE_OFF)
+// the words of a record the roll-up needs (the fourteen 8-byte units of the record staged in LDS: GYS_CONN_UNIT_OFF)
 struct ConnRec {
 	uint64_t a0, a1, a2, a3; // nat_cli_ @64: ip128 (16 B), ip32 @16, port @24
 	uint64_t b0, b1, b2, b3; // nat_ser_ @96
@@ -2725,12 +2744,24 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool
 	}
 	const unsigned long long cnt = (fresh ? 1ull : 0ull) + (closed ? (1ull << 32) : 0ull);
 	if (!(cnt | bytes_sent | bytes_rcvd)) return; // (an open record repeated with notified_before_: nothing to add)
-	// the workgroup's LDS entry of the service (open addressing; 2048 entries for at most 1024 records: always room)
-	uint32_t h = (slot * 0x9E3779B1u) >> 21; // top 11 bits
-	for (;;) {
+	// the workgroup's LDS entry of the service: open addressing, 2048 entries.  The records of a partha arrive together, so the thousands of
+	// records of a workgroup name a few hundred services; when they do not (hosts mixed record by record) the table fills: past three
+	// quarters a record probes twice, below that sixteen times, and one that finds no entry adds to the device accumulators directly
+	uint32_t *const s_fill = s_tally + CONN_T_NUM; // entries of the table in use
+	uint32_t h = (slot * 0x9E3779B1u) >> GYS_CONN_AGG_SHIFT;
+	const uint32_t probes = *(volatile uint32_t *)s_fill >= GYS_CONN_AGG / 4u * 3u ? 2u : 16u;
+	for (uint32_t t = 0;; ++t) {
 		const uint32_t prev = atomicCAS(&s_key[h], GYS_NOSLOT, slot);
+		if (prev == GYS_NOSLOT) atomicAdd(s_fill, 1u);
 		if (prev == GYS_NOSLOT || prev == slot) break;
 		h = (h + 1u) & (GYS_CONN_AGG - 1u);
+		if (t + 1u == probes) {
+			unsigned long long *c = p.svc_win + (size_t)slot * 3;
+			if (cnt) atomicAdd(&c[0], cnt);
+			if (bytes_sent) atomicAdd(&c[1], (unsigned long long)bytes_sent);
+			if (bytes_rcvd) atomicAdd(&c[2], (unsigned long long)bytes_rcvd);
+			return;
+		}
 	}
 	if (cnt) atomicAdd(&s_acc[h][0], cnt); // a window's connection count of one service stays far below 2^32
 	if (bytes_sent) atomicAdd(&s_acc[h][1], (unsigned long long)bytes_sent);
@@ -2740,22 +2771,23 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool
 // Round 3: the records are read THROUGH LDS.  Round 2 had every lane read its own 280-byte record with thirteen 8-byte loads at a 280-byte
 // stride: every load instruction of a wave touched 64 different lines, each line was asked for by up to seven instructions in a row while
 // still in flight, and reading alone took 3.3 of the kernel's 3.4 ms (r3v: 1.4 TB/s).  Now a wave reads what the roll-up needs of its 64
-// records as sixteen-byte pieces -- lane l of load t takes piece 64 t + l, i.e. neighbouring lanes cover one record and a load instruction
-// covers ~7 records.  Round 3 read the ten pieces of [64, 224); round 4 needs the flag bytes too and reads NINE pieces per record: the
-// eight that hold a field of the roll-up plus [264, 280) (GYS_CONN_PIECE_OFF; eleven were 1.31 ms, r4d) -- through each record's own
-// offset (no assumption that records are contiguous or of equal size), parks them in its private LDS region at a 152-byte record stride
-// (8-byte accesses at that stride spread over all banks), and every lane then reads its record's fourteen words from LDS.  A workgroup is 512 threads and walks TWO rounds of 512 records, so that
-// the LDS aggregation of the service accumulators still spans 1024 consecutive records (a partha's message is 2048 records of few services).
-#define GYS_CONN_STAGE_STRIDE 152u // bytes per staged record (144 used: nine 16-byte pieces)
-#define GYS_CONN_ROUNDS (GYS_CONN_RECS / GYS_CONN_THREADS)
-#define GYS_CONN_PIECES 9u
+// records in small units laid out across the lanes -- lane l of load t takes unit 64 t + l, i.e. neighbouring lanes cover one record --
+// through each record's own offset (no assumption that records are contiguous or of equal size), parks them in its private LDS region,
+// and every lane then reads its record's fourteen words from LDS.  Round 3 read ten 16-byte pieces ([64, 224)), round 4 at first nine
+// (the eight that hold a field of the roll-up plus the flag bytes [264, 280); eleven were 1.31 ms, r4d) at a 152-byte staged stride with
+// eight waves per CU.  After r4h the staged record is the FOURTEEN 8-byte words the roll-up reads and nothing else (112 of those 144
+// bytes): 7.5 KB per wave instead of 9.5, so that TWELVE waves fit a CU's LDS beside the aggregation table, and the kernel -- bound by the
+// latency of its record reads at two waves per SIMD -- has three per SIMD in flight (r4i: 1.26 -> 1.155 ms per 2^24 records; the same
+// staging at eight waves 1.24).  A workgroup is 768 threads and walks its span of records (conn_span) in rounds of 768.
+#define GYS_CONN_STAGE_STRIDE 120u // bytes per staged record (112 used; 30 words: 8-byte accesses at this stride spread over all banks)
+#define GYS_CONN_UNITS 14u
 #ifndef GYS_CONN_PREFETCH
 #define GYS_CONN_PREFETCH 1
 #endif
-// record offset of piece j: [64, 144) = nat_cli_, nat_ser_, tusec_start_ / tusec_close_ (j = 0..4), [144, 160) = cli_task_aggr_id_ (5),
-// [192, 208) = ser_glob_id_ (6), [208, 224) = bytes_sent_ / bytes_rcvd_ (7), [264, 280) = the flag bytes (8) -- the two pieces [160, 192)
-// (cli_madhava_id_, cli_ser_machine_id_: nothing the roll-up reads) are not fetched as pieces of their own
-#define GYS_CONN_PIECE_OFF(j) (64u + 16u * (j) + ((j) >= 6u ? 32u : 0u) + ((j) == 8u ? 40u : 0u))
+// record offset of unit k: [64, 128) = nat_cli_, nat_ser_ (k = 0..7), 136 tusec_close_ (8), 144 cli_task_aggr_id_ (9), 208 bytes_sent_ (10),
+// 216 bytes_rcvd_ (11), 192 ser_glob_id_ (12), 272 the flag bytes (13)
+#define GYS_CONN_UNIT_OFF(k) ((k) < 8u ? 64u + 8u * (k) : 8u * (uint32_t)((0x22181B1A1211ull >> (((k) - 8u) * 8u)) & 0xFFull))
+static_assert((GYS_CONN_THREADS / 64u) * 64u * GYS_CONN_STAGE_STRIDE + GYS_CONN_AGG * 28u + 64u <= 160u * 1024u, "k_conn_ingest: LDS");
 __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 {
 	// Records reach madhava message by message, a message = up to 2048 connections of ONE partha (comm::TCP_CONN_NOTIFY::MAX_NUM_CONNS,
@@ -2764,7 +2796,7 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 	// flushed with one set of device atomics per DISTINCT service of the workgroup.
 	__shared__ uint32_t s_key[GYS_CONN_AGG];
 	__shared__ unsigned long long s_acc[GYS_CONN_AGG][3];
-	__shared__ uint32_t s_tally[CONN_T_NUM];
+	__shared__ uint32_t s_tally[CONN_T_NUM + 1]; // (+ the table's fill count)
 	__shared__ __align__(16) uint8_t s_stage[GYS_CONN_THREADS / 64u][64u * GYS_CONN_STAGE_STRIDE];
 	for (uint32_t k = threadIdx.x; k < GYS_CONN_AGG; k += GYS_CONN_THREADS) {
 		s_key[k] = GYS_NOSLOT;
@@ -2772,45 +2804,47 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 		s_acc[k][1] = 0;
 		s_acc[k][2] = 0;
 	}
-	if (threadIdx.x < CONN_T_NUM) s_tally[threadIdx.x] = 0;
+	if (threadIdx.x <= CONN_T_NUM) s_tally[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint8_t *const st = s_stage[wave];
-	// ---- 576 pieces of 16 bytes per wave and round: piece q = 9 r + j is bytes [GYS_CONN_PIECE_OFF(j), + 16) of the wave's record r.
-	// The pieces of round k + 1 are REQUESTED right after round k's were stored to the LDS, so that they are in flight
-	// while round k is hashed and tallied (GYS_CONN_PREFETCH 0 = round 4's order: request, store, work, request ...).
-	uint4 pc[GYS_CONN_PIECES];
+	const uint64_t first64 = (uint64_t)blockIdx.x * p.span;
+	if (first64 >= p.n) return; // (uniform: the grid is ceil(n / span))
+	const uint32_t first = (uint32_t)first64, end = (uint32_t)min((uint64_t)p.n, first64 + p.span); // the workgroup's records [first, end)
+	// ---- 896 units of 8 bytes per wave and round: unit q = 14 r + k is bytes [GYS_CONN_UNIT_OFF(k), + 8) of the wave's record r, so that
+	// neighbouring lanes cover one record and a load instruction covers ~4.6 records (each lane reading its own record at the 280-byte stride
+	// was 3.3 ms, r3v).  The units of round k + 1 are REQUESTED right after round k's were stored to the LDS, so that they are in flight
+	// while round k is hashed and tallied (GYS_CONN_PREFETCH 0: request, store, work, request ...; 1.35 against 1.29 ms, r4h).
+	uint2 pc[GYS_CONN_UNITS];
 	auto request = [&](uint32_t round) {
-		const uint32_t i0 = blockIdx.x * GYS_CONN_RECS + round * GYS_CONN_THREADS + wave * 64u;
-		if (round >= GYS_CONN_ROUNDS || i0 >= p.n) return;
+		const uint32_t i0 = first + round * GYS_CONN_THREADS + wave * 64u;
+		if (i0 >= end) return;
 		const uint32_t i = i0 + lane;
-		const uint32_t nrec = min(64u, p.n - i0);
-		const uint32_t off = p.offsets[i < p.n ? i : p.n - 1u];
+		const uint32_t nrec = min(64u, end - i0);
+		const uint32_t off = p.offsets[i < end ? i : end - 1u];
 #pragma unroll
-		for (uint32_t t = 0; t < GYS_CONN_PIECES; ++t) {
+		for (uint32_t t = 0; t < GYS_CONN_UNITS; ++t) {
 			const uint32_t q = t * 64u + lane;
-			const uint32_t r = (q * 7282u) >> 16; // q / 9 for q < 576
-			const uint32_t j = q - r * GYS_CONN_PIECES;
-			const uint32_t ro = (uint32_t)__shfl((int)off, (int)min(r, nrec - 1u), 64); // (a piece past the wave's last record re-reads that record)
-			const uint32_t *src = (const uint32_t *)(p.batch + ro + GYS_CONN_PIECE_OFF(j)); // records start 8-byte aligned (COMM_HEADER::validate common/gy_comm_proto.cc:23-26)
-			pc[t] = make_uint4(src[0], src[1], src[2], src[3]);
+			const uint32_t r = (q * 4682u) >> 16; // q / 14 for q < 896
+			const uint32_t k = q - r * GYS_CONN_UNITS;
+			const uint32_t ro = (uint32_t)__shfl((int)off, (int)min(r, nrec - 1u), 64); // (a unit past the wave's last record re-reads that record)
+			const uint32_t *src = (const uint32_t *)(p.batch + ro + GYS_CONN_UNIT_OFF(k)); // records start 8-byte aligned (COMM_HEADER::validate common/gy_comm_proto.cc:23-26)
+			pc[t] = make_uint2(src[0], src[1]);
 		}
 	};
 	if (GYS_CONN_PREFETCH) request(0);
 #pragma unroll 1
-	for (uint32_t round = 0; round < GYS_CONN_ROUNDS; ++round) {
-		const uint32_t i0 = blockIdx.x * GYS_CONN_RECS + round * GYS_CONN_THREADS + wave * 64u; // the wave's first record
-		if (i0 >= p.n) break;
+	for (uint32_t round = 0;; ++round) {
+		const uint32_t i0 = first + round * GYS_CONN_THREADS + wave * 64u; // the wave's first record
+		if (i0 >= end) break;
 		const uint32_t i = i0 + lane;
 		if (!GYS_CONN_PREFETCH) request(round);
 #pragma unroll
-		for (uint32_t t = 0; t < GYS_CONN_PIECES; ++t) {
+		for (uint32_t t = 0; t < GYS_CONN_UNITS; ++t) {
 			const uint32_t q = t * 64u + lane;
-			const uint32_t r = (q * 7282u) >> 16;
-			const uint32_t j = q - r * GYS_CONN_PIECES;
-			uint64_t *dst = (uint64_t *)(st + r * GYS_CONN_STAGE_STRIDE + 16u * j);
-			dst[0] = (uint64_t)pc[t].x | ((uint64_t)pc[t].y << 32);
-			dst[1] = (uint64_t)pc[t].z | ((uint64_t)pc[t].w << 32);
+			const uint32_t r = (q * 4682u) >> 16;
+			const uint32_t k = q - r * GYS_CONN_UNITS;
+			*(uint64_t *)(st + r * GYS_CONN_STAGE_STRIDE + 8u * k) = (uint64_t)pc[t].x | ((uint64_t)pc[t].y << 32);
 		}
 		if (GYS_CONN_PREFETCH) request(round + 1u);
 		GYS_WAVE_SYNC();
@@ -2819,21 +2853,19 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 			ConnRec rc;
 			rc.a0 = rw[0]; rc.a1 = rw[1]; rc.a2 = rw[2]; rc.a3 = rw[3];
 			rc.b0 = rw[4]; rc.b1 = rw[5]; rc.b2 = rw[6]; rc.b3 = rw[7];
-			rc.tusec_close = rw[9];   // @136: piece 4, second half
-			rc.task = rw[10];         // @144: piece 5
-			rc.ser_glob_id = rw[12];  // @192: piece 6
-			rc.bytes_sent = rw[14];   // @208: piece 7
-			rc.bytes_rcvd = rw[15];   // @216
-			rc.flags = rw[17];        // @272: piece 8, second half
-			conn_one(p, rc, i < p.n, s_key, s_acc, s_tally);
+			rc.tusec_close = rw[8];   // @136
+			rc.task = rw[9];          // @144
+			rc.bytes_sent = rw[10];   // @208
+			rc.bytes_rcvd = rw[11];   // @216
+			rc.ser_glob_id = rw[12];  // @192
+			rc.flags = rw[13];        // @272
+			conn_one(p, rc, i < end, s_key, s_acc, s_tally);
 		}
 		GYS_WAVE_SYNC(); // (the region is rewritten by the next round)
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) { // records of this workgroup: ONE add per workgroup (round 2 added once per wave: 2.6 x 10^5 adds on one address per 2^24 records)
-		const uint64_t first = (uint64_t)blockIdx.x * GYS_CONN_RECS;
-		const uint64_t cnt = first < p.n ? min((uint64_t)GYS_CONN_RECS, (uint64_t)p.n - first) : 0ull;
-		if (cnt) atomicAdd((unsigned long long *)&p.counters[CTR_CONN_EVENTS], (unsigned long long)cnt);
+		atomicAdd((unsigned long long *)&p.counters[CTR_CONN_EVENTS], (unsigned long long)(end - first));
 	}
 	if (threadIdx.x < CONN_T_NUM && s_tally[threadIdx.x]) { // ... and one per tally of the walk
 		const int ctr = threadIdx.x == CONN_T_NEW ? CTR_CONN_NEW : threadIdx.x == CONN_T_CLOSED ? CTR_CONN_CLOSED :

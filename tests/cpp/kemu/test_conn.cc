@@ -68,7 +68,10 @@ int main(int argc, char **argv)
 		return 77;
 	}
 	std::mt19937 rng(argc > 1 ? (unsigned)atoi(argv[1]) : 31u);
-	const uint32_t NSVC = 37, NUNKNOWN = 5;
+	// argv[2]: number of services (5000: the records of a workgroup name more services than its LDS table has entries -- some add to the
+	// device accumulators directly); argv[3]: CUs conn_span plans for (1: a large call is few workgroups of many rounds, the last one ragged)
+	const uint32_t NSVC = argc > 2 ? (uint32_t)atoi(argv[2]) : 37u, NUNKNOWN = 5;
+	const uint32_t NCU = argc > 3 ? (uint32_t)atoi(argv[3]) : 1u;
 	std::vector<uint64_t> gids(NSVC + NUNKNOWN);
 	for (uint32_t s = 0; s < gids.size(); ++s) gids[s] = 0xABCD000000000000ull + 0x10001ull * (s + 1) + ((uint64_t)rng() << 20);
 
@@ -93,7 +96,7 @@ int main(int argc, char **argv)
 	std::vector<uint64_t> want_ctr(NSVC * 4, 0);
 	uint64_t want_events = 0, want_unknown = 0, want_tally[4] = {0, 0, 0, 0};
 
-	const uint32_t sizes[] = {1, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 1600, 2500};
+	const uint32_t sizes[] = {1, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 1535, 1536, 1537, 1600, 2500, 7000, 13000};
 	uint32_t call = 0;
 	for (uint32_t n : sizes) {
 		const bool with_pair = (call++ & 1u) != 0; // every other call also feeds the (listener, client task group) pair
@@ -156,7 +159,9 @@ int main(int argc, char **argv)
 		p.pair64 = with_pair ? pair64.data() : nullptr;
 		p.cpair32 = with_pair ? cpair32.data() : nullptr;
 		p.cpair64 = with_pair ? cpair64.data() : nullptr;
-		kemu::launch((n + GYS_CONN_RECS - 1u) / GYS_CONN_RECS, GYS_CONN_THREADS, 0, [&] { k_conn_ingest(p); });
+		p.span = conn_span(n, NCU);
+		CHECK(p.span % 64u == 0 && p.span >= GYS_CONN_RECS, "conn_span(%u, %u) = %u", n, NCU, p.span);
+		kemu::launch((n + p.span - 1u) / p.span, GYS_CONN_THREADS, 0, [&] { k_conn_ingest(p); });
 		CHECK(counters[CTR_CONN_EVENTS] == want_events, "n %u: events %llu, want %llu", n, (unsigned long long)counters[CTR_CONN_EVENTS], (unsigned long long)want_events);
 		CHECK(counters[CTR_CONN_UNKNOWN] == want_unknown, "n %u: unknown %llu, want %llu", n, (unsigned long long)counters[CTR_CONN_UNKNOWN], (unsigned long long)want_unknown);
 		CHECK(counters[CTR_CONN_NEW] == want_tally[0] && counters[CTR_CONN_CLOSED] == want_tally[1] && counters[CTR_CONN_CLOSED_NO_NOTIFY] == want_tally[2] &&

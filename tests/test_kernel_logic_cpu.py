@@ -52,6 +52,9 @@ PROGRAMS = {
     "spill-predicted-runs": ("test_spill.cc", ["KEMU_PRESPILL"] + BINS, ["778"], "kemu spill ok"),
     "conn-31": ("test_conn.cc", [], ["31"], "kemu conn ok"),
     "conn-77": ("test_conn.cc", [], ["77"], "kemu conn ok"),
+    # 5000 services: a workgroup's records name more of them than its LDS table holds (direct device adds); 3 CUs: other spans
+    "conn-full-table": ("test_conn.cc", [], ["5", "5000", "1"], "kemu conn ok"),
+    "conn-3-cus": ("test_conn.cc", [], ["9", "300", "3"], "kemu conn ok"),
     "cms-rows": ("test_cms.cc", [], ["5"], "kemu cms ok"),
     "wire-corrupted-11": ("test_wire.cc", [], ["11"], "kemu wire ok"),
     "wire-corrupted-23": ("test_wire.cc", [], ["23"], "kemu wire ok"),
