@@ -129,7 +129,8 @@ class Counters(C.Structure):
                                           "resp_batches_host_local", "resp_batches_general", "window_graph_launches", "resp_batches_host_split",
                                           "td_merges", "td_merge_values", "actconn_records", "actconn_remote_listen", "actconn_unknown_listener",
                                           "stage_waits", "resp_calls_queued", "resp_submissions", "conn_new", "conn_closed",
-                                          "conn_closed_no_notify", "conn_client_side", "resp_tail_flushes")]
+                                          "conn_closed_no_notify", "conn_client_side", "resp_tail_flushes", "conn_calls_queued", "conn_submissions",
+                                          "lstate_calls_queued", "lstate_submissions", "rec_tail_flushes")]
 
 
 assert C.sizeof(HistRec) == 256 and C.sizeof(TopnEntry) == 104 and C.sizeof(RespSeg) == 16 and C.sizeof(ListenerDayStats) == 48

@@ -329,6 +329,36 @@ struct gys_ctx {
 		bool flusher_on = false, stop = false;
 		uint64_t tail_flushes = 0;
 	} rq;
+	// Submission queues of the host-pointer TCP_CONN_NOTIFY and LISTENER_STATE_NOTIFY calls (round 4; the same group commit as RespQ).
+	// Through the 16-slot staging ring every partha message cost its own H2D copy, two event records, a stream wait and a launch -- five
+	// runtime calls of ~5 us each under enq_mu for a 2048-record (0.57 MB) or 512-record (45 KB) message: 69 M connection records/s and
+	// 24 M listener records/s from 16 threads, a third and a twentieth of what the link carries, with the ring wrapping all the time
+	// (gys_counters.stage_waits).  Now the messages of all threads are appended to ONE pinned batch -- records, then an offset (and, for
+	// listener states, the sender's host slot) per record -- and a batch is copied and launched once.  A lone caller's message still goes
+	// out at once; messages accumulate only while GYS_RQ_INFLIGHT submissions are on the GPU.  Records keep the order in which the calls
+	// reserved their place, so "the last record of a listener wins" holds across the messages of a batch as it does across calls.
+	struct RecBatch {
+		uint8_t *h = nullptr, *d = nullptr; // [records: cap_bytes][offset per record: u32 x cap_recs][host slot per record: u32 x cap_recs]
+		uint64_t cap_bytes = 0, fill = 0;
+		uint32_t cap_recs = 0, nrec = 0;
+		hipEvent_t done = nullptr, copied = nullptr;
+		uint32_t writers = 0;
+	};
+	struct RecQ {
+		static constexpr int NB = 4;
+		bool conn = false; // TCP_CONN_NOTIFY (else LISTENER_STATE_NOTIFY)
+		std::mutex mu;
+		std::condition_variable cv, fcv;
+		RecBatch b[NB];
+		std::deque<int> free, sealed, inflight;
+		int open = -1;
+		bool submitting = false;
+		int async_rc = 0;
+		std::string async_err;
+		uint64_t calls = 0, submissions = 0, tail_flushes = 0;
+		std::thread flusher;
+		bool flusher_on = false, stop = false;
+	} cq[2]; // [0] connections, [1] listener states
 	uint8_t *dev_staging = nullptr;
 	uint64_t dev_staging_bytes = 0;
 	uint32_t *dev_offsets = nullptr;
@@ -1692,6 +1722,231 @@ int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
 	return rc;
 }
 
+// ---- submission queues of the host-pointer connection / listener-state calls (gys_ctx::RecQ; the logic of rq_* above)
+constexpr uint64_t GYS_CQ_CONN_BYTES = 16u << 20, GYS_CQ_LSTATE_BYTES = 4u << 20; // record bytes per combined batch
+
+int recq_submit_one(gys_ctx *c, gys_ctx::RecQ &q, int bi)
+{
+	gys_ctx::RecBatch &b = q.b[bi];
+	int rc = GYS_OK;
+	std::lock_guard<std::mutex> g(c->enq_mu);
+	hipStream_t cs = c->copy_stream ? c->copy_stream : c->stream;
+	const uint64_t off_at = b.cap_bytes, host_at = b.cap_bytes + (uint64_t)b.cap_recs * 4;
+	hipError_t e = hipMemcpyAsync(b.d, b.h, b.fill, hipMemcpyHostToDevice, cs);
+	if (e == hipSuccess) e = hipMemcpyAsync(b.d + off_at, b.h + off_at, (uint64_t)b.nrec * 4, hipMemcpyHostToDevice, cs);
+	if (e == hipSuccess && !q.conn) e = hipMemcpyAsync(b.d + host_at, b.h + host_at, (uint64_t)b.nrec * 4, hipMemcpyHostToDevice, cs);
+	if (e == hipSuccess && c->copy_stream) {
+		e = hipEventRecord(b.copied, c->copy_stream);
+		if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, b.copied, 0);
+	}
+	if (e == hipSuccess) {
+		rc = q.conn ? run_conn(c, b.d, (const uint32_t *)(b.d + off_at), b.nrec)
+			    : run_lstate(c, b.d, (const uint32_t *)(b.d + off_at), (const uint32_t *)(b.d + host_at), 0, b.nrec);
+		e = hipEventRecord(b.done, c->stream);
+	}
+	if (e != hipSuccess) {
+		set_err("record submission: %s", hipGetErrorString(e));
+		rc = GYS_ERR_HIP;
+	}
+	return rc;
+}
+
+void recq_reap(gys_ctx::RecQ &q) // q.mu held
+{
+	while (!q.inflight.empty()) {
+		const hipError_t e = hipEventQuery(q.b[q.inflight.front()].done);
+		if (e == hipErrorNotReady) break;
+		if (e != hipSuccess && !q.async_rc) {
+			q.async_rc = GYS_ERR_HIP;
+			q.async_err = std::string("record submission: ") + hipGetErrorString(e);
+		}
+		q.free.push_back(q.inflight.front());
+		q.inflight.pop_front();
+	}
+	(void)hipGetLastError();
+}
+
+// q.mu held (lk): as rq_drain
+int recq_drain(gys_ctx *c, gys_ctx::RecQ &q, std::unique_lock<std::mutex> &lk, int mine, bool all)
+{
+	int my_rc = GYS_OK;
+	if (q.submitting) {
+		if (!all) return GYS_OK;
+		q.cv.wait(lk, [&] { return !q.submitting; });
+	}
+	for (;;) {
+		if (q.sealed.empty() && q.open >= 0 && q.b[q.open].nrec && q.b[q.open].writers == 0) {
+			recq_reap(q);
+			if (all || q.inflight.size() < GYS_RQ_INFLIGHT) {
+				q.sealed.push_back(q.open);
+				q.open = -1;
+			}
+		}
+		if (q.sealed.empty()) break;
+		const int bi = q.sealed.front();
+		if (q.b[bi].writers) {
+			if (!all) break; // its last writer drains
+			q.cv.wait(lk, [&] { return q.b[bi].writers == 0; });
+		}
+		q.sealed.pop_front();
+		q.submitting = true;
+		lk.unlock();
+		const int rc = recq_submit_one(c, q, bi);
+		lk.lock();
+		q.submitting = false;
+		q.submissions++;
+		q.b[bi].fill = 0;
+		q.b[bi].nrec = 0;
+		q.inflight.push_back(bi);
+		q.cv.notify_all();
+		if (rc) {
+			if (bi == mine) my_rc = rc;
+			else if (!q.async_rc) {
+				q.async_rc = rc;
+				q.async_err = g_err;
+			}
+		}
+	}
+	return my_rc;
+}
+
+int recq_flush(gys_ctx *c, gys_ctx::RecQ &q)
+{
+	std::unique_lock<std::mutex> lk(q.mu);
+	int rc = GYS_OK;
+	if (q.open >= 0 || !q.sealed.empty() || q.submitting) rc = recq_drain(c, q, lk, -1, true);
+	if (!rc && q.async_rc) {
+		rc = q.async_rc;
+		set_err("%s", q.async_err.c_str());
+		q.async_rc = 0;
+	}
+	return rc;
+}
+
+void recq_flusher(gys_ctx *c, gys_ctx::RecQ *qp) // the tail of a burst: as rq_flusher
+{
+	gys_ctx::RecQ &q = *qp;
+	(void)hipSetDevice(c->device);
+	std::unique_lock<std::mutex> lk(q.mu);
+	for (;;) {
+		q.fcv.wait(lk, [&] { return q.stop || (q.open >= 0 && q.b[q.open].nrec != 0); });
+		if (q.stop) break;
+		lk.unlock();
+		std::this_thread::sleep_for(std::chrono::microseconds(200));
+		lk.lock();
+		if (q.stop) break;
+		if (q.open >= 0 && q.b[q.open].nrec && q.b[q.open].writers == 0 && !q.submitting) {
+			const uint64_t before = q.submissions;
+			(void)recq_drain(c, q, lk, -1, false);
+			if (q.submissions != before) q.tail_flushes++;
+		}
+	}
+}
+
+// one message: `bytes` of records at `batch`, offs[i] = offset of record i in it; host = the sender's slot
+int recq_ingest(gys_ctx *c, gys_ctx::RecQ &q, uint32_t host, const void *batch, uint64_t bytes, const std::vector<uint32_t> &offs)
+{
+	const uint64_t cap_bytes = q.conn ? GYS_CQ_CONN_BYTES : GYS_CQ_LSTATE_BYTES, need = align_up(bytes, 8);
+	const uint32_t cap_recs = (uint32_t)(cap_bytes / (q.conn ? 280u : 88u)), n = (uint32_t)offs.size();
+	if (need > cap_bytes / 2 || n > cap_recs / 2) {
+		// a call of many messages' size (a replayed backlog): on its own through the staging ring -- behind what the queue holds
+		const int rc = recq_flush(c, q);
+		return rc ? rc : ingest_staged_records(c, host, batch, bytes, offs, q.conn);
+	}
+	std::unique_lock<std::mutex> lk(q.mu);
+	if (!q.flusher_on) {
+		q.flusher_on = true;
+		q.flusher = std::thread(recq_flusher, c, &q);
+	}
+	if (q.async_rc) {
+		const int rc = q.async_rc;
+		set_err("%s", q.async_err.c_str());
+		q.async_rc = 0;
+		return rc;
+	}
+	q.calls++;
+	int bi;
+	for (;;) {
+		if (q.open < 0) {
+			recq_reap(q);
+			if (q.free.empty()) {
+				if (!q.inflight.empty()) {
+					hipEvent_t ev = q.b[q.inflight.front()].done;
+					lk.unlock();
+					(void)hipEventSynchronize(ev);
+					lk.lock();
+				} else {
+					q.cv.wait(lk, [&] { return !q.free.empty() || !q.inflight.empty(); });
+				}
+				continue;
+			}
+			bi = q.free.front();
+			q.free.pop_front();
+			gys_ctx::RecBatch &nb = q.b[bi];
+			lk.unlock(); // (first-use allocation outside the lock; the batch is not visible yet)
+			hipError_t e = hipSuccess;
+			if (!nb.h || !nb.d || !nb.done || !nb.copied) {
+				const uint64_t total = cap_bytes + (uint64_t)cap_recs * 8;
+				if (!nb.h) e = hipHostMalloc((void **)&nb.h, total, hipHostMallocDefault);
+				if (e == hipSuccess && !nb.d) e = hipMalloc((void **)&nb.d, total);
+				if (e == hipSuccess && !nb.done) e = hipEventCreateWithFlags(&nb.done, hipEventDisableTiming);
+				if (e == hipSuccess && !nb.copied) e = hipEventCreateWithFlags(&nb.copied, hipEventDisableTiming);
+				if (e != hipSuccess) { // all four or none
+					if (nb.h) (void)hipHostFree(nb.h);
+					if (nb.d) (void)hipFree(nb.d);
+					if (nb.done) (void)hipEventDestroy(nb.done);
+					if (nb.copied) (void)hipEventDestroy(nb.copied);
+					nb.h = nb.d = nullptr;
+					nb.done = nb.copied = nullptr;
+				} else {
+					nb.cap_bytes = cap_bytes;
+					nb.cap_recs = cap_recs;
+				}
+			}
+			lk.lock();
+			if (e != hipSuccess) {
+				q.free.push_back(bi);
+				q.cv.notify_all();
+				set_err("record batch buffers: %s", hipGetErrorString(e));
+				return GYS_ERR_HIP;
+			}
+			if (q.open >= 0) { // another caller opened one meanwhile
+				q.free.push_front(bi);
+				q.cv.notify_all();
+				continue;
+			}
+			q.open = bi;
+		}
+		bi = q.open;
+		gys_ctx::RecBatch &b = q.b[bi];
+		if (b.fill + need <= b.cap_bytes && b.nrec + n <= b.cap_recs) break;
+		q.sealed.push_back(bi); // no room: submitted before anything opened later
+		q.open = -1;
+		const int rc = recq_drain(c, q, lk, -1, false);
+		if (rc) return rc;
+	}
+	gys_ctx::RecBatch &b = q.b[bi];
+	const uint64_t at = b.fill;
+	const uint32_t r0 = b.nrec;
+	b.fill += need;
+	b.nrec += n;
+	b.writers++;
+	lk.unlock();
+	memcpy(b.h + at, batch, bytes); // the caller's buffer is free from here on
+	uint32_t *o = (uint32_t *)(b.h + b.cap_bytes) + r0;
+	for (uint32_t i = 0; i < n; ++i) o[i] = offs[i] + (uint32_t)at;
+	if (!q.conn) {
+		uint32_t *hs = (uint32_t *)(b.h + b.cap_bytes) + b.cap_recs + r0;
+		for (uint32_t i = 0; i < n; ++i) hs[i] = host;
+	}
+	lk.lock();
+	b.writers--;
+	if (b.writers == 0) q.cv.notify_all();
+	const int rc = recq_drain(c, q, lk, bi, false);
+	if (q.open >= 0 && q.b[q.open].nrec) q.fcv.notify_one();
+	return rc;
+}
+
 } // namespace
 
 // ==================================================================================================== C ABI
@@ -1710,7 +1965,9 @@ int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
 	do {                                                                   \
 		GYS_ENTER_NOFLUSH(c);                                          \
 		if (c) {                                                       \
-			const int rcq_ = rq_flush(c);                          \
+			int rcq_ = rq_flush(c);                                \
+			if (!rcq_) rcq_ = recq_flush(c, (c)->cq[0]);           \
+			if (!rcq_) rcq_ = recq_flush(c, (c)->cq[1]);           \
 			if (rcq_) return rcq_;                                 \
 		}                                                              \
 	} while (0)
@@ -1766,6 +2023,9 @@ try {
 	gys_ctx *c = new gys_ctx();
 	for (int i = 0; i < gys_ctx::NSTAGE; ++i) c->stage_free.push_back(i);
 	for (int i = 0; i < gys_ctx::RespQ::NB; ++i) c->rq.free.push_back(i);
+	c->cq[0].conn = true;
+	for (auto &q : c->cq)
+		for (int i = 0; i < gys_ctx::RecQ::NB; ++i) q.free.push_back(i);
 	c->cfg = *cfg;
 	if (cfg->device >= 0) {
 		c->device = cfg->device;
@@ -1985,6 +2245,16 @@ void gys_destroy(gys_ctx *c)
 		if (c->rq.flusher.joinable()) c->rq.flusher.join();
 		c->rq.flusher_on = false;
 	}
+	for (auto &q : c->cq) {
+		if (!q.flusher_on) continue;
+		{
+			std::lock_guard<std::mutex> g(q.mu);
+			q.stop = true;
+		}
+		q.fcv.notify_all();
+		if (q.flusher.joinable()) q.flusher.join();
+		q.flusher_on = false;
+	}
 	if (c->stream) hipStreamSynchronize(c->stream);
 	if (c->win_graph_exec) hipGraphExecDestroy(c->win_graph_exec);
 	if (c->win_graph) hipGraphDestroy(c->win_graph);
@@ -2005,6 +2275,13 @@ void gys_destroy(gys_ctx *c)
 		if (b.done) hipEventDestroy(b.done);
 		if (b.copied) hipEventDestroy(b.copied);
 	}
+	for (auto &q : c->cq)
+		for (auto &b : q.b) {
+			if (b.h) hipHostFree(b.h);
+			if (b.d) hipFree(b.d);
+			if (b.done) hipEventDestroy(b.done);
+			if (b.copied) hipEventDestroy(b.copied);
+		}
 	if (c->copy_stream) hipStreamDestroy(c->copy_stream);
 	for (auto &st : c->stage) {
 		if (st.h) hipHostFree(st.h);
@@ -2232,7 +2509,7 @@ try {
 	}, offs);
 	if (rc) return rc;
 	if (offs.empty()) return GYS_OK;
-	return ingest_staged_records(c, host, batch, (const uint8_t *)pend - (const uint8_t *)batch, offs, /*conn*/ true);
+	return recq_ingest(c, c->cq[0], host, batch, (uint64_t)((const uint8_t *)pend - (const uint8_t *)batch), offs);
 } GYS_CATCH_ALL
 
 int gys_ingest_listener_state_dev(gys_ctx *c, const void *d_batch, const uint32_t *d_offsets, const uint32_t *d_host_slot, uint32_t nrecs)
@@ -2295,7 +2572,7 @@ try {
 	rc = walk_batch((const uint8_t *)batch, nrecs, (const uint8_t *)pend, 88, [](const uint8_t *p) { return (uint32_t)(88u + p[85] + p[86]); }, offs);
 	if (rc) return rc;
 	if (offs.empty()) return GYS_OK;
-	return ingest_staged_records(c, host, batch, (const uint8_t *)pend - (const uint8_t *)batch, offs, /*conn*/ false);
+	return recq_ingest(c, c->cq[1], host, batch, (uint64_t)((const uint8_t *)pend - (const uint8_t *)batch), offs);
 } GYS_CATCH_ALL
 
 // ------------------------------------------------------------------------------------------------ wire front-end
@@ -3732,6 +4009,18 @@ try {
 		out->resp_calls_queued = c->rq.calls;
 		out->resp_submissions = c->rq.submissions;
 		out->resp_tail_flushes = c->rq.tail_flushes;
+	}
+	{
+		std::lock_guard<std::mutex> g(c->cq[0].mu);
+		out->conn_calls_queued = c->cq[0].calls;
+		out->conn_submissions = c->cq[0].submissions;
+		out->rec_tail_flushes = c->cq[0].tail_flushes;
+	}
+	{
+		std::lock_guard<std::mutex> g(c->cq[1].mu);
+		out->lstate_calls_queued = c->cq[1].calls;
+		out->lstate_submissions = c->cq[1].submissions;
+		out->rec_tail_flushes += c->cq[1].tail_flushes;
 	}
 	return GYS_OK;
 } GYS_CATCH_ALL

@@ -137,8 +137,13 @@ int gys_register_listeners(gys_ctx *ctx, const uint8_t machine_id[16], const gys
  * read DURING the call (the reference's pone points into the L1 receive buffer, freed after the dispatch switch) and
  * the call does NOT wait for the GPU: the records are copied into a slot of a ring of 16 pinned staging buffers (handed out oldest
  * first), one H2D copy and the ingest kernels are enqueued, and the call returns; a slot is reused once the event recorded behind its
- * kernels has fired (gys_counters.stage_waits counts the calls that had to wait for that).  gys_ingest_resp_events goes through a
- * SUBMISSION QUEUE instead: the calls of all threads are concatenated into one pinned batch (a segment per call) and handed to the
+ * kernels has fired (gys_counters.stage_waits counts the calls that had to wait for that) -- this is the path of
+ * gys_ingest_active_conns and of a connection / listener-state call of many messages' size (> 8 MiB / 2 MiB of records).  A partha's
+ * TCP_CONN_NOTIFY and LISTENER_STATE_NOTIFY messages (gys_ingest_tcp_conn, gys_ingest_listener_state) go through SUBMISSION QUEUES of
+ * their own: the messages of all threads are appended to one pinned batch (records + an offset and the sender's host slot per record)
+ * that is copied and launched once; records keep the order in which the calls arrived, so the last state record of a listener wins
+ * across the messages of a batch as it does across calls (gys_counters.conn_calls_queued / conn_submissions, lstate_*).
+ * gys_ingest_resp_events goes through a SUBMISSION QUEUE as well: the calls of all threads are concatenated into one pinned batch (a segment per call) and handed to the
  * response pipeline together -- with an idle GPU a call is submitted at once; while two submissions are still executing, further calls
  * accumulate and go out together as soon as one of them has finished (group commit: the fixed launches of a response batch are paid
  * once per submission exactly when the GPU is the bottleneck; a host appears at most once per combined batch and batches are submitted in the order they were
@@ -592,6 +597,9 @@ typedef struct {
 	uint64_t conn_new, conn_closed, conn_closed_no_notify, conn_client_side;
 	uint64_t resp_tail_flushes; /* submissions made by the queue's flusher thread: the tail of a burst of gys_ingest_resp_events calls that
 				     * found the GPU busy is submitted ~200 us after a submission retires, without waiting for the next call */
+	/* gys_ingest_tcp_conn / gys_ingest_listener_state calls that went through their submission queues, the combined batches they were
+	 * submitted as, and the submissions made by those queues' flusher threads */
+	uint64_t conn_calls_queued, conn_submissions, lstate_calls_queued, lstate_submissions, rec_tail_flushes;
 } gys_counters;
 int gys_get_counters(gys_ctx *ctx, gys_counters *out);
 /* response events the submission queue of gys_ingest_resp_events still holds on the HOST side (copied out of the callers' buffers, not yet

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from gyeeta_amd import capi, wire
+from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
@@ -377,3 +378,77 @@ def test_submission_queue_tail_is_flushed_without_another_call():
         states.append((gs.tobytes(), gc.tobytes(), gm.tobytes(), gn.tobytes(), gp.tobytes(), h_all.tobytes(), eng.counters()["resp_events"]))
         eng.close()
     assert states[0] == states[1]
+
+
+def test_conn_and_listener_state_calls_from_16_threads_are_combined_and_equal_sequential_calls(oracle):
+    """gys_ingest_tcp_conn / gys_ingest_listener_state from 16 threads go through their submission queues (several parthas' messages per
+    H2D copy + launch); the state must equal the same messages sent one by one from one thread -- registers, counters, per-host
+    summaries, and the kept 88-byte state of every listener (a partha's messages keep their order: the last one wins)."""
+    import threading
+    from gyeeta_amd.engine import SketchEngine
+    nh, sp, rounds, nthreads = 48, 40, 5, 16
+    rng = np.random.default_rng(77)
+    engs = [SketchEngine(max_hosts=nh, max_services=nh * sp, enable_tdigest=False) for _ in range(2)]
+    infos = [helpers.register_world(e, None, range(nh), sp)[0] for e in engs]
+    conn_msgs, ls_msgs = {}, {}
+    for h in range(nh):
+        conn_msgs[h], ls_msgs[h] = [], []
+        for r in range(rounds):
+            n = int(rng.integers(900, 2049))
+            rec = wire.synth_tcp_conns(rng, n, [h], sp, dup_frac=0.2, v6_frac=0.1)
+            tails = [bytes(rng.integers(32, 127, int(k), dtype=np.uint8).tolist()) for k in rng.integers(0, 65, n) * (rng.random(n) < 0.2)]
+            conn_msgs[h].append((wire.pack_variable(rec, tails), n))
+            ls = wire.synth_listener_states(rng, h, np.arange(sp), delete_frac=0.02, bad_state_frac=0.02)
+            ls_msgs[h].append((wire.pack_variable(ls, [b"x" * int(k) for k in rng.integers(0, 9, sp)]), sp))
+    # sequential engine: one thread, message by message
+    for h in range(nh):
+        for r in range(rounds):
+            engs[1].partha_tcp_conn_info(infos[1][h][0], *conn_msgs[h][r])
+            engs[1].partha_listener_state(infos[1][h][0], *ls_msgs[h][r])
+    errs = []
+    start = threading.Barrier(nthreads)
+
+    def worker(t):
+        try:
+            start.wait()
+            for r in range(rounds):
+                for h in range(t, nh, nthreads):  # a partha's messages arrive in order on its connection
+                    engs[0].partha_tcp_conn_info(infos[0][h][0], *conn_msgs[h][r])
+                    engs[0].partha_listener_state(infos[0][h][0], *ls_msgs[h][r])
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    c0, c1 = engs[0].counters(), engs[1].counters()
+    for k in ("conn_events", "conn_unknown_service", "conn_new", "conn_closed", "conn_closed_no_notify", "conn_client_side",
+              "lstate_records", "lstate_missed", "lstate_errors", "lstate_deleted"):
+        assert c0[k] == c1[k], k
+    assert c0["conn_calls_queued"] == c0["lstate_calls_queued"] == nh * rounds == c1["conn_calls_queued"]
+    assert 1 <= c0["conn_submissions"] <= nh * rounds and 1 <= c0["lstate_submissions"] <= nh * rounds
+    assert 1 <= c1["conn_submissions"] <= nh * rounds  # (a lone caller's message goes out at once unless two submissions are still on the GPU)
+    # kept states of every listener, before the window closes
+    s0, h0, r0, n0 = engs[0].svcstate_scan(maxrecs=nh * sp + 10)  # (no sort column: by service slot)
+    s1, h1, r1, n1 = engs[1].svcstate_scan(maxrecs=nh * sp + 10)
+    assert n0 == n1 == len(s0) == len(s1) and n0 > 0.9 * nh * sp
+    assert (s0 == s1).all() and (h0 == h1).all() and r0.tobytes() == r1.tobytes()
+    for e in engs:
+        e.window_close()
+    assert (engs[0].export_hll() == engs[1].export_hll()).all()
+    for w in (0, 1):
+        assert (engs[0].export_cms(w) == engs[1].export_cms(w)).all()
+    assert (engs[0].export_svc_counters() == engs[1].export_svc_counters()).all()
+    for h in range(nh):
+        assert engs[0].svcsumm(infos[0][h][0]).as_tuple() == engs[1].svcsumm(infos[1][h][0]).as_tuple()
+    # a call of many messages' size bypasses the queue (behind what it holds) and is still counted and ingested
+    big = wire.synth_tcp_conns(rng, 40000, list(range(nh)), sp, dup_frac=0.1)
+    before = engs[0].counters()
+    engs[0].partha_tcp_conn_info(infos[0][0][0], wire.pack_variable(big, None), len(big))
+    after = engs[0].counters()
+    assert after["conn_events"] - before["conn_events"] == len(big) and after["conn_calls_queued"] == before["conn_calls_queued"]
+    for e in engs:
+        e.close()

@@ -163,9 +163,12 @@ int main(int argc, char **argv)
 	gys_counters ctr{};
 	gys_get_counters(h.ctx(), &ctr);
 	printf(", \"counters\": {\"conn_events\": %llu, \"lstate_records\": %llu, \"resp_events\": %llu, \"conn_unknown_service\": %llu, \"lstate_missed\": %llu, \"resp_dropped_nolistener\": %llu, "
-	       "\"resp_calls_queued\": %llu, \"resp_submissions\": %llu, \"stage_waits\": %llu}}\n",
+	       "\"resp_calls_queued\": %llu, \"resp_submissions\": %llu, \"conn_calls_queued\": %llu, \"conn_submissions\": %llu, "
+	       "\"lstate_calls_queued\": %llu, \"lstate_submissions\": %llu, \"stage_waits\": %llu}}\n",
 	       (unsigned long long)ctr.conn_events, (unsigned long long)ctr.lstate_records, (unsigned long long)ctr.resp_events,
 	       (unsigned long long)ctr.conn_unknown_service, (unsigned long long)ctr.lstate_missed, (unsigned long long)ctr.resp_dropped_nolistener,
-	       (unsigned long long)ctr.resp_calls_queued, (unsigned long long)ctr.resp_submissions, (unsigned long long)ctr.stage_waits);
+	       (unsigned long long)ctr.resp_calls_queued, (unsigned long long)ctr.resp_submissions, (unsigned long long)ctr.conn_calls_queued,
+	       (unsigned long long)ctr.conn_submissions, (unsigned long long)ctr.lstate_calls_queued, (unsigned long long)ctr.lstate_submissions,
+	       (unsigned long long)ctr.stage_waits);
 	return 0;
 }
