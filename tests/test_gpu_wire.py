@@ -26,7 +26,9 @@ def _world(resp=False):
 
 def _state(eng):
     return (eng.export_hll().tobytes(), eng.export_cms(0).tobytes(), eng.export_cms(1).tobytes(), eng.export_svc_counters().tobytes(),
-            tuple(eng.svcsumm(wire.machine_id(h)).as_tuple() for h in range(3)), eng.counters(),
+            tuple(eng.svcsumm(wire.machine_id(h)).as_tuple() for h in range(3)),
+            # (the counters of what was ingested -- not of how the host-pointer calls were queued and submitted)
+            {k: v for k, v in eng.counters().items() if not k.endswith(("_queued", "_submissions", "_flushes", "stage_waits"))},
             # the kept LISTENER_STATE record of every listener: a stream that holds several messages of one partha names a listener several
             # times in ONE launch -- the last record in stream order stays, whole, as after the per-message calls (k_lstate_keep)
             tuple(eng.json_svcstate(wire.machine_id(h)) for h in range(3)))
