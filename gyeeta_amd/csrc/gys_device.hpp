@@ -265,6 +265,7 @@ struct DevTable {
 // (server/gy_mconnhdlr.cc:11180-11183)
 __device__ __forceinline__ uint32_t tbl_lookup(const DevTable &t, uint64_t key)
 {
+	if (key == GYS_EMPTY_KEY) return GYS_NOSLOT; // (never registered: gys_register_listeners refuses it -- and it would match a free entry below)
 	uint32_t h = get_uint64_hash(key) & t.mask;
 	for (uint32_t probes = 0; probes <= t.mask; ++probes) {
 		const uint4 e = *(const uint4 *)&t.ent[h];

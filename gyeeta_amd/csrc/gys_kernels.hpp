@@ -2618,14 +2618,16 @@ struct ConnP {
 };
 
 #ifndef GYS_CONN_THREADS
-#define GYS_CONN_THREADS 768u // twelve waves: what 160 KB of LDS hold at 7.5 KB of staged records per wave + the aggregation table
+#define GYS_CONN_THREADS 1024u // sixteen waves: 7.5 KB of staged records per wave + a 1024-entry service table + the HLL candidates = 158 of 160 KB
 #endif
 #define GYS_CONN_RECS (2u * GYS_CONN_THREADS) // records per workgroup of a SMALL call: two rounds of GYS_CONN_THREADS
 #ifndef GYS_CONN_SPAN
 #define GYS_CONN_SPAN (8u * GYS_CONN_THREADS) // ... and about this many in a large one (conn_span)
 #endif
-#define GYS_CONN_AGG 2048u // LDS aggregation slots per workgroup (power of two)
-#define GYS_CONN_AGG_SHIFT 21
+#ifndef GYS_CONN_AGG_BITS
+#define GYS_CONN_AGG_BITS 10u // (2048 entries at twelve waves: 1.02 against 0.98 ms, and 1.64 against 1.44 ms on the mixed stream, r4x)
+#endif
+#define GYS_CONN_AGG (1u << GYS_CONN_AGG_BITS) // LDS aggregation slots per workgroup
 // Records per workgroup.  The services of a workgroup's records are added to the device accumulators once per workgroup, and those
 // device-scope adds are what the kernel pays for beside its reads (r4j: half the records per workgroup, 1.19 -> 1.38 ms; r4k: four times,
 // 1.156 -> 1.118 ms with a third of the last dispatch round idle).  So a large call gives a workgroup ~6144 records -- in as many workgroups
@@ -2665,7 +2667,34 @@ __device__ __forceinline__ void conn_tally(uint32_t *s_tally, int which, bool pr
 	if (b && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)b) - 1)) atomicAdd(&s_tally[which], (uint32_t)__popcll(b));
 }
 
-__device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool live, uint32_t *s_key, unsigned long long (*s_acc)[3], uint32_t *s_tally)
+// a listener-side record whose service found no LDS entry (table full) or whose glob_id equals the table's empty mark: the service is looked
+// up and the device accumulators are added to directly (what every record did before the per-workgroup table)
+__device__ __forceinline__ void conn_direct(const ConnP &p, uint64_t ser_glob_id, bool fresh, bool closed, uint64_t bytes_sent, uint64_t bytes_rcvd, uint32_t *s_tally)
+{
+	const uint32_t slot = tbl_lookup(p.gid, ser_glob_id);
+	if (slot == GYS_NOSLOT) {
+		atomicAdd(&s_tally[CONN_T_UNKNOWN], 1u);
+#pragma unroll
+		for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
+			const uint32_t col = jhash2_u64(ser_glob_id, GYS_SEED + r) & (GYS_CMS_W - 1);
+			if (fresh) atomicAdd(&p.cms32[r * GYS_CMS_W + col], 1u);
+			if (bytes_sent + bytes_rcvd) atomicAdd(&p.cms64[r * GYS_CMS_W + col], (unsigned long long)(bytes_sent + bytes_rcvd));
+		}
+		return;
+	}
+	const unsigned long long cnt = (fresh ? 1ull : 0ull) + (closed ? (1ull << 32) : 0ull);
+	unsigned long long *c = p.svc_win + (size_t)slot * 3;
+	if (cnt) atomicAdd(&c[0], cnt);
+	if (bytes_sent) atomicAdd(&c[1], (unsigned long long)bytes_sent);
+	if (bytes_rcvd) atomicAdd(&c[2], (unsigned long long)bytes_rcvd);
+}
+
+#define GYS_CONN_EMPTY (~0ull)  // empty entry of the workgroup's service table (a record that names this glob_id goes the direct way)
+#ifndef GYS_CONN_HQ
+#define GYS_CONN_HQ 512u       // HLL candidates a workgroup parks before it reads a register
+#endif
+#define GYS_CONN_CNT_BITS 21u   // per-entry counts: records with notified_before_ clear | closes | records, 21 bits each (a workgroup walks < 2^21 records)
+__device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool live, unsigned long long *s_gid, unsigned long long (*s_acc)[3], uint32_t *s_tally, uint32_t *s_hq)
 {
 	uint32_t c128[4], s128[4], c32, s32;
 	uint16_t cport, sport;
@@ -2696,12 +2725,24 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool
 	if (!(GYS_CONN_SKIP & 1)) {
 		uint32_t w[10];
 		const uint32_t nw = pair_words(c32, c128, cport, s32, s128, sport, w);
-		const uint64_t h64 = hash64<10>(w, nw);
+		uint64_t h64 = hash64<10>(w, nw);
+#ifdef GYS_CONN_EXTRA_HASH // TIMING EXPERIMENT ONLY (results are wrong): the flow hash GYS_CONN_EXTRA_HASH more times, chained
+		for (int x = 0; x < GYS_CONN_EXTRA_HASH; ++x) {
+			w[0] ^= (uint32_t)h64;
+			h64 ^= hash64<10>(w, nw);
+		}
+#endif
 		uint32_t idx, rank;
 		hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
 		if (GYS_CONN_SKIP & 16) { // (hash only)
 			if ((idx ^ rank) == 0xDEADBEEFu) p.counters[CTR_CONN_UNKNOWN] = 1;
-		} else if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
+		} else if (rank > s_tally[CONN_T_NUM + 1]) { // (at or below the workgroup's floor: no register is lower)
+			// NO global read the record's walk depends on: a read here waits (vmcnt counts in order) for the NEXT round's record words
+			// requested just before, i.e. it takes the prefetch's cover away.  The candidate is parked and checked at the workgroup's end.
+			const uint32_t q = atomicAdd(&s_tally[CONN_T_NUM + 2], 1u);
+			if (q < GYS_CONN_HQ) s_hq[q] = idx | (rank << 16);
+			else if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
+		}
 	}
 	if (GYS_CONN_SKIP & 2) return;
 
@@ -2727,43 +2768,36 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool
 		}
 	}
 	if (!listener_side) return; // the client half: the accepting partha's record carries the connection into the service's counters
-	const uint32_t slot = tbl_lookup(p.gid, ser_glob_id);
-	if (slot == GYS_NOSLOT) {
-		atomicAdd(&s_tally[CONN_T_UNKNOWN], 1u);
-#pragma unroll
-		for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
-			const uint32_t col = jhash2_u64(ser_glob_id, GYS_SEED + r) & (GYS_CMS_W - 1);
-			if (fresh) atomicAdd(&p.cms32[r * GYS_CMS_W + col], 1u);
-			if (bytes_sent + bytes_rcvd) atomicAdd(&p.cms64[r * GYS_CMS_W + col], (unsigned long long)(bytes_sent + bytes_rcvd));
-		}
-		return;
-	}
 	if (GYS_CONN_SKIP & 4) {
-		if (slot == 0xDEADBEEFu) p.counters[CTR_CONN_UNKNOWN] = 1;
+		if (ser_glob_id == 0xDEADBEEFu) p.counters[CTR_CONN_UNKNOWN] = 1;
 		return;
 	}
-	const unsigned long long cnt = (fresh ? 1ull : 0ull) + (closed ? (1ull << 32) : 0ull);
-	if (!(cnt | bytes_sent | bytes_rcvd)) return; // (an open record repeated with notified_before_: nothing to add)
-	// the workgroup's LDS entry of the service: open addressing, 2048 entries.  The records of a partha arrive together, so the thousands of
-	// records of a workgroup name a few hundred services; when they do not (hosts mixed record by record) the table fills: past three
-	// quarters a record probes twice, below that sixteen times, and one that finds no entry adds to the device accumulators directly
+	// the workgroup's LDS entry of the service, keyed by ser_glob_id_ itself: open addressing, 1024 entries of {glob_id, counts, bytes
+	// sent, bytes received}.  The glob_id -> slot lookup (a dependent global read, see above) happens once per ENTRY when the workgroup
+	// flushes, not once per record.  The records of a partha arrive together, so the thousands of records of a workgroup name a few
+	// hundred services; when they do not (hosts mixed record by record) the table fills: past three quarters a record probes twice,
+	// below that sixteen times, and one that finds no entry goes the direct way.
+	const unsigned long long add0 = (fresh ? 1ull : 0ull) | (closed ? 1ull << GYS_CONN_CNT_BITS : 0ull) | (1ull << (2u * GYS_CONN_CNT_BITS));
 	uint32_t *const s_fill = s_tally + CONN_T_NUM; // entries of the table in use
-	uint32_t h = (slot * 0x9E3779B1u) >> GYS_CONN_AGG_SHIFT;
-	const uint32_t probes = *(volatile uint32_t *)s_fill >= GYS_CONN_AGG / 4u * 3u ? 2u : 16u;
+	uint32_t h = (uint32_t)((ser_glob_id * 0x9E3779B97F4A7C15ull) >> (64u - GYS_CONN_AGG_BITS));
+	// (a relaxed atomic load, NOT a volatile one: hipcc turns a volatile read through this pointer into a FLAT load followed by
+	// s_waitcnt vmcnt(0) -- which waits for the next round's fourteen record loads in the middle of this round's work, r4s / r4t)
+	const uint32_t probes = __atomic_load_n(s_fill, __ATOMIC_RELAXED) >= GYS_CONN_AGG / 4u * 3u ? 2u : 16u;
+	if (ser_glob_id == GYS_CONN_EMPTY) {
+		conn_direct(p, ser_glob_id, fresh, closed, bytes_sent, bytes_rcvd, s_tally);
+		return;
+	}
 	for (uint32_t t = 0;; ++t) {
-		const uint32_t prev = atomicCAS(&s_key[h], GYS_NOSLOT, slot);
-		if (prev == GYS_NOSLOT) atomicAdd(s_fill, 1u);
-		if (prev == GYS_NOSLOT || prev == slot) break;
+		const unsigned long long prev = atomicCAS(&s_gid[h], GYS_CONN_EMPTY, (unsigned long long)ser_glob_id);
+		if (prev == GYS_CONN_EMPTY) atomicAdd(s_fill, 1u);
+		if (prev == GYS_CONN_EMPTY || prev == ser_glob_id) break;
 		h = (h + 1u) & (GYS_CONN_AGG - 1u);
 		if (t + 1u == probes) {
-			unsigned long long *c = p.svc_win + (size_t)slot * 3;
-			if (cnt) atomicAdd(&c[0], cnt);
-			if (bytes_sent) atomicAdd(&c[1], (unsigned long long)bytes_sent);
-			if (bytes_rcvd) atomicAdd(&c[2], (unsigned long long)bytes_rcvd);
+			conn_direct(p, ser_glob_id, fresh, closed, bytes_sent, bytes_rcvd, s_tally);
 			return;
 		}
 	}
-	if (cnt) atomicAdd(&s_acc[h][0], cnt); // a window's connection count of one service stays far below 2^32
+	atomicAdd(&s_acc[h][0], add0);
 	if (bytes_sent) atomicAdd(&s_acc[h][1], (unsigned long long)bytes_sent);
 	if (bytes_rcvd) atomicAdd(&s_acc[h][2], (unsigned long long)bytes_rcvd);
 }
@@ -2778,50 +2812,79 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool
 // eight waves per CU.  After r4h the staged record is the FOURTEEN 8-byte words the roll-up reads and nothing else (112 of those 144
 // bytes): 7.5 KB per wave instead of 9.5, so that TWELVE waves fit a CU's LDS beside the aggregation table, and the kernel -- bound by the
 // latency of its record reads at two waves per SIMD -- has three per SIMD in flight (r4i: 1.26 -> 1.155 ms per 2^24 records; the same
-// staging at eight waves 1.24).  A workgroup is 768 threads and walks its span of records (conn_span) in rounds of 768.
+// staging at eight waves 1.24).  Without the prefetch registers (r4w) the kernel needs 120 VGPRs, and with a 1024-entry service table
+// SIXTEEN waves fit (r4x: 1.02 -> 0.98 ms).  A workgroup is 1024 threads and walks its span of records (conn_span) in rounds of 1024.
 #define GYS_CONN_STAGE_STRIDE 120u // bytes per staged record (112 used; 30 words: 8-byte accesses at this stride spread over all banks)
 #define GYS_CONN_UNITS 14u
 #ifndef GYS_CONN_PREFETCH
-#define GYS_CONN_PREFETCH 1
+#define GYS_CONN_PREFETCH 0 // 1: the units of round k + 1 are requested before round k is worked on (see k_conn_ingest)
+#endif
+#ifndef GYS_CONN_FLOOR
+#define GYS_CONN_FLOOR 1
 #endif
 // record offset of unit k: [64, 128) = nat_cli_, nat_ser_ (k = 0..7), 136 tusec_close_ (8), 144 cli_task_aggr_id_ (9), 208 bytes_sent_ (10),
 // 216 bytes_rcvd_ (11), 192 ser_glob_id_ (12), 272 the flag bytes (13)
 #define GYS_CONN_UNIT_OFF(k) ((k) < 8u ? 64u + 8u * (k) : 8u * (uint32_t)((0x22181B1A1211ull >> (((k) - 8u) * 8u)) & 0xFFull))
-static_assert((GYS_CONN_THREADS / 64u) * 64u * GYS_CONN_STAGE_STRIDE + GYS_CONN_AGG * 28u + 64u <= 160u * 1024u, "k_conn_ingest: LDS");
+static_assert((GYS_CONN_THREADS / 64u) * 64u * GYS_CONN_STAGE_STRIDE + GYS_CONN_AGG * 32u + GYS_CONN_HQ * 4u + 64u <= 160u * 1024u, "k_conn_ingest: LDS");
 __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 {
 	// Records reach madhava message by message, a message = up to 2048 connections of ONE partha (comm::TCP_CONN_NOTIFY::MAX_NUM_CONNS,
 	// common/gy_comm_proto.h:1738) and a partha has a few hundred listeners at most: the 1024 records of a workgroup touch few
-	// distinct services.  Their three window accumulators are therefore summed in an LDS table keyed by service slot first and
-	// flushed with one set of device atomics per DISTINCT service of the workgroup.
-	__shared__ uint32_t s_key[GYS_CONN_AGG];
+	// distinct services.  Their three window accumulators are therefore summed in an LDS table keyed by the service's glob_id first and
+	// flushed with one lookup and one set of device atomics per DISTINCT service of the workgroup.
+	__shared__ unsigned long long s_gid[GYS_CONN_AGG];
 	__shared__ unsigned long long s_acc[GYS_CONN_AGG][3];
-	__shared__ uint32_t s_tally[CONN_T_NUM + 1]; // (+ the table's fill count)
+	__shared__ uint32_t s_hq[GYS_CONN_HQ];       // parked HLL candidates: register index | rank << 16
+	__shared__ uint32_t s_tally[CONN_T_NUM + 3]; // (+ the table's fill count, + the HLL floor, + the parked candidates)
 	__shared__ __align__(16) uint8_t s_stage[GYS_CONN_THREADS / 64u][64u * GYS_CONN_STAGE_STRIDE];
+	uint32_t fl = 0xFFFFFFFFu;
+	if (!(GYS_CONN_SKIP & 1) && GYS_CONN_FLOOR)
+		for (uint32_t k = threadIdx.x; k < (1u << GYS_HLL_P); k += GYS_CONN_THREADS) fl = min(fl, p.hll32[k]);
+	else if (!GYS_CONN_FLOOR) fl = 0; // (A/B: every record reads its register)
 	for (uint32_t k = threadIdx.x; k < GYS_CONN_AGG; k += GYS_CONN_THREADS) {
-		s_key[k] = GYS_NOSLOT;
+		s_gid[k] = GYS_CONN_EMPTY;
 		s_acc[k][0] = 0;
 		s_acc[k][1] = 0;
 		s_acc[k][2] = 0;
 	}
 	if (threadIdx.x <= CONN_T_NUM) s_tally[threadIdx.x] = 0;
+	if (threadIdx.x == CONN_T_NUM + 1) s_tally[threadIdx.x] = 0xFFFFFFFFu;
+	if (threadIdx.x == CONN_T_NUM + 2) s_tally[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	{
+		// HLL floor of the workgroup: the lowest of the 2^14 registers as they stand now (64 KB, read side by side, in flight while the
+		// table above was cleared).  A register only grows, so a record whose rank is at or below the floor cannot change its register
+		// and does not read it -- after the first few thousand flows of a window that is nearly every record, and the dependent
+		// register read behind the flow hash was 0.15 of the kernel's 1.05 ms (r4q).
+#pragma unroll
+		for (int d = 32; d; d >>= 1) fl = min(fl, (uint32_t)__shfl_xor((int)fl, d, 64));
+		if (lane == 0) atomicMin(&s_tally[CONN_T_NUM + 1], fl);
+		__syncthreads();
+	}
 	uint8_t *const st = s_stage[wave];
 	const uint64_t first64 = (uint64_t)blockIdx.x * p.span;
 	if (first64 >= p.n) return; // (uniform: the grid is ceil(n / span))
 	const uint32_t first = (uint32_t)first64, end = (uint32_t)min((uint64_t)p.n, first64 + p.span); // the workgroup's records [first, end)
 	// ---- 896 units of 8 bytes per wave and round: unit q = 14 r + k is bytes [GYS_CONN_UNIT_OFF(k), + 8) of the wave's record r, so that
 	// neighbouring lanes cover one record and a load instruction covers ~4.6 records (each lane reading its own record at the 280-byte stride
-	// was 3.3 ms, r3v).  The units of round k + 1 are REQUESTED right after round k's were stored to the LDS, so that they are in flight
-	// while round k is hashed and tallied (GYS_CONN_PREFETCH 0: request, store, work, request ...; 1.35 against 1.29 ms, r4h).
+	// was 3.3 ms, r3v).  GYS_CONN_PREFETCH 1 requests the units of round k + 1 right after round k's were stored to the LDS.  That paid at
+	// eight waves per CU (1.35 -> 1.29 ms, r4h); at twelve waves, with nothing in the walk waiting for a global read any more, the waves
+	// cover each other and the early request costs: 1.06 with, 1.02 ms without (r4v / r4w; the r4n kernel, whose walk read the HLL register
+	// and the glob_id table per record, was 1.05 with and 1.07 without) -- so it is off.
+	// The record offsets of a round are loaded one round before its units are requested: the unit addresses depend on them, and a load
+	// issued at request time put its whole latency in front of the fourteen unit loads (s_waitcnt vmcnt(0) before the first shuffle).
 	uint2 pc[GYS_CONN_UNITS];
-	auto request = [&](uint32_t round) {
+	auto load_off = [&](uint32_t round) -> uint32_t {
+		const uint32_t i0 = first + round * GYS_CONN_THREADS + wave * 64u;
+		if (i0 >= end) return 0u;
+		const uint32_t i = i0 + lane;
+		return p.offsets[i < end ? i : end - 1u];
+	};
+	auto request = [&](uint32_t round, uint32_t off) {
 		const uint32_t i0 = first + round * GYS_CONN_THREADS + wave * 64u;
 		if (i0 >= end) return;
-		const uint32_t i = i0 + lane;
 		const uint32_t nrec = min(64u, end - i0);
-		const uint32_t off = p.offsets[i < end ? i : end - 1u];
 #pragma unroll
 		for (uint32_t t = 0; t < GYS_CONN_UNITS; ++t) {
 			const uint32_t q = t * 64u + lane;
@@ -2832,13 +2895,22 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 			pc[t] = make_uint2(src[0], src[1]);
 		}
 	};
-	if (GYS_CONN_PREFETCH) request(0);
+	uint32_t off_nx = load_off(0);
+	if (GYS_CONN_PREFETCH) {
+		const uint32_t o = off_nx;
+		off_nx = load_off(1);
+		request(0, o);
+	}
 #pragma unroll 1
 	for (uint32_t round = 0;; ++round) {
 		const uint32_t i0 = first + round * GYS_CONN_THREADS + wave * 64u; // the wave's first record
 		if (i0 >= end) break;
 		const uint32_t i = i0 + lane;
-		if (!GYS_CONN_PREFETCH) request(round);
+		if (!GYS_CONN_PREFETCH) {
+			const uint32_t o = off_nx;
+			off_nx = load_off(round + 1u);
+			request(round, o);
+		}
 #pragma unroll
 		for (uint32_t t = 0; t < GYS_CONN_UNITS; ++t) {
 			const uint32_t q = t * 64u + lane;
@@ -2846,7 +2918,11 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 			const uint32_t k = q - r * GYS_CONN_UNITS;
 			*(uint64_t *)(st + r * GYS_CONN_STAGE_STRIDE + 8u * k) = (uint64_t)pc[t].x | ((uint64_t)pc[t].y << 32);
 		}
-		if (GYS_CONN_PREFETCH) request(round + 1u);
+		if (GYS_CONN_PREFETCH) {
+			const uint32_t o = off_nx;
+			off_nx = load_off(round + 2u);
+			request(round + 1u, o);
+		}
 		GYS_WAVE_SYNC();
 		{
 			const uint64_t *rw = (const uint64_t *)(st + lane * GYS_CONN_STAGE_STRIDE);
@@ -2859,11 +2935,43 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 			rc.bytes_rcvd = rw[11];   // @216
 			rc.ser_glob_id = rw[12];  // @192
 			rc.flags = rw[13];        // @272
-			conn_one(p, rc, i < end, s_key, s_acc, s_tally);
+			conn_one(p, rc, i < end, s_gid, s_acc, s_tally, s_hq);
 		}
 		GYS_WAVE_SYNC(); // (the region is rewritten by the next round)
 	}
 	__syncthreads();
+	// ---- the workgroup's flush: everything that reads global state the walk did not wait for
+	{
+		const uint32_t nq = min(s_tally[CONN_T_NUM + 2], GYS_CONN_HQ); // parked HLL candidates
+		for (uint32_t q = threadIdx.x; q < nq; q += GYS_CONN_THREADS) {
+			const uint32_t e = s_hq[q], idx = e & 0xFFFFu, rank = e >> 16;
+			if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
+		}
+	}
+	for (uint32_t k = threadIdx.x; k < GYS_CONN_AGG; k += GYS_CONN_THREADS) {
+		const uint64_t gid = s_gid[k];
+		if (gid == GYS_CONN_EMPTY) continue;
+		constexpr unsigned long long M = (1ull << GYS_CONN_CNT_BITS) - 1ull;
+		const unsigned long long a0 = s_acc[k][0], nconn = a0 & M, nclose = (a0 >> GYS_CONN_CNT_BITS) & M, nrec = a0 >> (2u * GYS_CONN_CNT_BITS);
+		const unsigned long long sent = s_acc[k][1], rcvd = s_acc[k][2];
+		const uint32_t slot = tbl_lookup(p.gid, gid);
+		if (slot == GYS_NOSLOT) { // as conn_direct, for all of the entry's records at once (the Count-Min adds of a record commute)
+			atomicAdd(&s_tally[CONN_T_UNKNOWN], (uint32_t)nrec);
+#pragma unroll
+			for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
+				const uint32_t col = jhash2_u64(gid, GYS_SEED + r) & (GYS_CMS_W - 1);
+				if (nconn) atomicAdd(&p.cms32[r * GYS_CMS_W + col], (uint32_t)nconn);
+				if (sent + rcvd) atomicAdd(&p.cms64[r * GYS_CMS_W + col], sent + rcvd);
+			}
+			continue;
+		}
+		unsigned long long *c = p.svc_win + (size_t)slot * 3;
+		const unsigned long long cnt = nconn | (nclose << 32); // a window's connection count of one service stays far below 2^32
+		if (cnt) atomicAdd(&c[0], cnt);
+		if (sent) atomicAdd(&c[1], sent);
+		if (rcvd) atomicAdd(&c[2], rcvd);
+	}
+	__syncthreads(); // (the flush adds to the unknown-service tally)
 	if (threadIdx.x == 0) { // records of this workgroup: ONE add per workgroup (round 2 added once per wave: 2.6 x 10^5 adds on one address per 2^24 records)
 		atomicAdd((unsigned long long *)&p.counters[CTR_CONN_EVENTS], (unsigned long long)(end - first));
 	}
@@ -2871,14 +2979,6 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 		const int ctr = threadIdx.x == CONN_T_NEW ? CTR_CONN_NEW : threadIdx.x == CONN_T_CLOSED ? CTR_CONN_CLOSED :
 				threadIdx.x == CONN_T_CLOSED_NO_NOTIFY ? CTR_CONN_CLOSED_NO_NOTIFY : threadIdx.x == CONN_T_CLI_SIDE ? CTR_CONN_CLI_SIDE : CTR_CONN_UNKNOWN;
 		atomicAdd((unsigned long long *)&p.counters[ctr], (unsigned long long)s_tally[threadIdx.x]);
-	}
-	for (uint32_t k = threadIdx.x; k < GYS_CONN_AGG; k += GYS_CONN_THREADS) {
-		const uint32_t slot = s_key[k];
-		if (slot == GYS_NOSLOT) continue;
-		unsigned long long *c = p.svc_win + (size_t)slot * 3;
-		if (s_acc[k][0]) atomicAdd(&c[0], s_acc[k][0]);
-		if (s_acc[k][1]) atomicAdd(&c[1], s_acc[k][1]);
-		if (s_acc[k][2]) atomicAdd(&c[2], s_acc[k][2]);
 	}
 }
 

@@ -74,6 +74,7 @@ int main(int argc, char **argv)
 	const uint32_t NCU = argc > 3 ? (uint32_t)atoi(argv[3]) : 1u;
 	std::vector<uint64_t> gids(NSVC + NUNKNOWN);
 	for (uint32_t s = 0; s < gids.size(); ++s) gids[s] = 0xABCD000000000000ull + 0x10001ull * (s + 1) + ((uint64_t)rng() << 20);
+	gids[NSVC + 1] = ~0ull; // (an unregistered service whose glob_id IS the empty mark of the tables: no entry may match it)
 
 	// the engine's glob-id table (open addressing on get_uint64_hash, 16-byte entries)
 	uint32_t cap = 1;
@@ -91,6 +92,10 @@ int main(int argc, char **argv)
 	std::vector<uint64_t> counters(CTR_NUM, 0);
 	// the oracle's side: its serial walk of the same bytes (flag bytes included: a connection counts once, on its listener side)
 	std::vector<uint8_t> o_hll(NREG, 0);
+	// a run on more than one CU's plan starts from registers of a window well under way (every register 1..3: the workgroups' HLL floor
+	// is above zero and records of low rank skip their register), the default run from cleared ones
+	if (NCU > 1)
+		for (uint32_t k = 0; k < NREG; ++k) hll32[k] = o_hll[k] = (uint8_t)(1u + rng() % 3u);
 	std::vector<uint32_t> o_cms32(NCMS, 0), o_pair32(NCMS, 0), o_cpair32(NCMS, 0);
 	std::vector<uint64_t> o_cms64(NCMS, 0), o_pair64(NCMS, 0), o_cpair64(NCMS, 0);
 	std::vector<uint64_t> want_ctr(NSVC * 4, 0);
