@@ -2725,13 +2725,7 @@ __device__ __forceinline__ void conn_one(const ConnP &p, const ConnRec &rc, bool
 	if (!(GYS_CONN_SKIP & 1)) {
 		uint32_t w[10];
 		const uint32_t nw = pair_words(c32, c128, cport, s32, s128, sport, w);
-		uint64_t h64 = hash64<10>(w, nw);
-#ifdef GYS_CONN_EXTRA_HASH // TIMING EXPERIMENT ONLY (results are wrong): the flow hash GYS_CONN_EXTRA_HASH more times, chained
-		for (int x = 0; x < GYS_CONN_EXTRA_HASH; ++x) {
-			w[0] ^= (uint32_t)h64;
-			h64 ^= hash64<10>(w, nw);
-		}
-#endif
+		const uint64_t h64 = hash64<10>(w, nw);
 		uint32_t idx, rank;
 		hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
 		if (GYS_CONN_SKIP & 16) { // (hash only)

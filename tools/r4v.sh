@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call 21: does k_conn_ingest's work overlap its record reads?  default; without the prefetch (pf0); with the flow hash three
-# times over (xh2: results wrong, time only) with and without prefetch; record reads + staging only (sk8) with and without prefetch
+# times over (xh2 = -DGYS_CONN_EXTRA_HASH=2, a switch that existed for this call only: results wrong, time only) with and without prefetch; record reads + staging only (sk8) with and without prefetch
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4v; mkdir -p $O; cd $R
 for lib in libgysketch libgysketch_pf0 libgysketch_xh2 libgysketch_xh2pf0 libgysketch_sk8 libgysketch_sk8pf0; do
 	f=$O/conn_$lib.json
