@@ -6,16 +6,17 @@
 #            costs at most a redundant atomic), and same-value stores by several threads (finalize_key: the host's spill stamp;
 #            k_huge_merge: s_over = 1); the read-before-atomicMax of a histogram's max_val_seen (hist_add_atomic); k_wire_round's mark[]
 #            (a slot marked DURING a doubling round may already pass its mark on in that round: marks only grow and everything that gets
-#            marked is a true record start of the chain, so a round can only run ahead); and ONE report that is a real limit, not an
-#            idempotent pattern: k_lstate_ingest's 96-byte store of a listener's kept state when TWO records of one call name the same
-#            listener (the test feeds such calls on purpose) -- one thread per record, no winner is chosen, see DESIGN.md section 10.
+#            marked is a true record start of the chain, so a round can only run ahead); k_conn_ingest's relaxed read of its LDS table's
+#            fill count beside the atomic adds to it (a stale count only changes how many probes a record tries).  Round 3's one REAL
+#            report -- k_lstate_ingest's 96-byte store of a listener's kept state when two records of one call name the same listener --
+#            is gone since round 4 (64-bit atomicMax claim + k_lstate_keep: the owner of the claim stores).
 #            ~12 minutes on 8 cores.
 #   address: an index past the end of a __shared__ array (a function-local static here, red zones around it), of the dynamic LDS block
 #            or of a global buffer aborts the program.  Expected: no report.  ~6 minutes.
 SAN=${1:-thread}
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
 python -c "from oracle import oracle; oracle.lib()" || exit 1
-for t in bins resp spill conn cms wire lstate topn rollup; do
+for t in bins resp spill conn cms wire lstate topn rollup svcquery; do
 	g++ -std=c++20 -O1 -g -w -fsanitize=$SAN -DKEMU_NB=4 -Itests/cpp/kemu tests/cpp/kemu/test_$t.cc -o /tmp/kemu_${t}_$SAN -Loracle -l:liboracle.so -Wl,-rpath,$R/oracle -pthread || exit 1
 	TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=0" timeout 2400 /tmp/kemu_${t}_$SAN > /tmp/kemu_${t}_$SAN.log 2>&1
 	echo "== $t"; grep -E "SUMMARY|ERROR: AddressSanitizer|kemu $t ok|FAIL" /tmp/kemu_${t}_$SAN.log | sort | uniq -c
