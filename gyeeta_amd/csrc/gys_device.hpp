@@ -261,6 +261,100 @@ struct DevTable {
 	uint32_t mask;
 };
 
+// ---- wave-wide (64 lanes) scans and reductions on the DPP path.  __shfl_up / __shfl_xor compile to ds_bpermute_b32 -- an LDS instruction
+// with ~100 cycles of latency, so the usual six-step loop is a 600-cycle dependent chain -- the DPP forms are VALU moves between lanes
+// (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast:15 and row_bcast:31 across the rows: the sequence LLVM's own atomic
+// optimizer emits for gfx9).  Only where all 64 lanes are active (every call site sits in wave-uniform code).  A host build (the g++ shim,
+// tests/cpp/kemu) takes the shuffle loop.
+#define GYS_DPP_STEP(x, op, ident)                                                                             \
+	do {                                                                                                   \
+		x = op(x, __builtin_amdgcn_update_dpp((int)(ident), x, 0x111, 0xf, 0xf, false)); /* row_shr:1 */   \
+		x = op(x, __builtin_amdgcn_update_dpp((int)(ident), x, 0x112, 0xf, 0xf, false)); /* row_shr:2 */   \
+		x = op(x, __builtin_amdgcn_update_dpp((int)(ident), x, 0x114, 0xf, 0xf, false)); /* row_shr:4 */   \
+		x = op(x, __builtin_amdgcn_update_dpp((int)(ident), x, 0x118, 0xf, 0xf, false)); /* row_shr:8 */   \
+		x = op(x, __builtin_amdgcn_update_dpp((int)(ident), x, 0x142, 0xa, 0xf, false)); /* row_bcast:15 -> rows 1, 3 */ \
+		x = op(x, __builtin_amdgcn_update_dpp((int)(ident), x, 0x143, 0xc, 0xf, false)); /* row_bcast:31 -> rows 2, 3 */ \
+	} while (0)
+#define GYS_DPP_ADD(a, b) ((int)((uint32_t)(a) + (uint32_t)(b)))
+#define GYS_DPP_UMIN(a, b) ((int)min((uint32_t)(a), (uint32_t)(b)))
+#define GYS_DPP_UMAX(a, b) ((int)max((uint32_t)(a), (uint32_t)(b)))
+#define GYS_DPP_SMIN(a, b) (min((int)(a), (int)(b)))
+#define GYS_DPP_SMAX(a, b) (max((int)(a), (int)(b)))
+
+// inclusive prefix sum over the lanes of the wave
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+	int x = (int)v;
+	GYS_DPP_STEP(x, GYS_DPP_ADD, 0);
+	return (uint32_t)x;
+#else
+	const uint32_t lane = threadIdx.x & 63u;
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t t = __shfl_up(v, d, 64);
+		if ((int)lane >= d) v += t;
+	}
+	return v;
+#endif
+}
+// ... of 64-bit values: both halves travel by DPP, the add is a 64-bit one
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+#define GYS_DPP64(ctrl, rmask)                                                                                     \
+	do {                                                                                                       \
+		const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, ctrl, rmask, 0xf, false);         \
+		const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), ctrl, rmask, 0xf, false); \
+		v += (uint64_t)lo_ | ((uint64_t)hi_ << 32);                                                        \
+	} while (0)
+	GYS_DPP64(0x111, 0xf);
+	GYS_DPP64(0x112, 0xf);
+	GYS_DPP64(0x114, 0xf);
+	GYS_DPP64(0x118, 0xf);
+	GYS_DPP64(0x142, 0xa);
+	GYS_DPP64(0x143, 0xc);
+#undef GYS_DPP64
+	return v;
+#else
+	const uint32_t lane = threadIdx.x & 63u;
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint64_t t = __shfl_up(v, d, 64);
+		if ((int)lane >= d) v += t;
+	}
+	return v;
+#endif
+}
+// the value of lane 63 (after wave_incl_scan_u32: the wave's total), the same in every lane
+__device__ __forceinline__ uint32_t wave_last_u32(uint32_t v)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#else
+	return (uint32_t)__shfl((int)v, 63, 64);
+#endif
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_last_u32(wave_incl_scan_u32(v)); }
+#ifdef __HIP_DEVICE_COMPILE__
+#define GYS_WAVE_REDUCE(name, type, op, ident)                          \
+	__device__ __forceinline__ type name(type v)                    \
+	{                                                               \
+		int x = (int)v;                                         \
+		GYS_DPP_STEP(x, op, ident);                             \
+		return (type)__builtin_amdgcn_readlane(x, 63);          \
+	}
+#else
+#define GYS_WAVE_REDUCE(name, type, op, ident)                                              \
+	__device__ __forceinline__ type name(type v)                                        \
+	{                                                                                   \
+		for (int d = 32; d >= 1; d >>= 1) v = (type)op(v, __shfl_xor(v, d, 64));    \
+		return v;                                                                   \
+	}
+#endif
+GYS_WAVE_REDUCE(wave_min_u32, uint32_t, GYS_DPP_UMIN, 0xFFFFFFFFu)
+GYS_WAVE_REDUCE(wave_max_u32, uint32_t, GYS_DPP_UMAX, 0u)
+GYS_WAVE_REDUCE(wave_min_i32, int32_t, GYS_DPP_SMIN, 0x7FFFFFFF)
+GYS_WAVE_REDUCE(wave_max_i32, int32_t, GYS_DPP_SMAX, (int)0x80000000)
+
 // probe hash = the reference's own 64-bit-id hash (get_uint64_hash) so bucket choice mirrors listen_tbl_ lookups
 // (server/gy_mconnhdlr.cc:11180-11183)
 __device__ __forceinline__ uint32_t tbl_lookup(const DevTable &t, uint64_t key)

@@ -1127,6 +1127,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			q.nent_used = c->merge_count + 7;
 			q.tb_list = c->huge_tb_list;
 			q.tb_count = c->merge_count + 10;
+#ifdef GYS_HUGE_TIMING
+			q.dbg = (unsigned long long *)c->counters + 20;
+#endif
 			// the pool holds huge_maxent entries: the list is walked in rounds (a round beyond the list's end costs four empty launches)
 			const uint64_t list_cap = std::min<uint64_t>(std::min<uint64_t>(nsvc, n / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1), c->huge_list_cap);
 			for (uint64_t first = 0; first < list_cap; first += c->huge_maxent) {
@@ -3981,6 +3984,9 @@ try {
 	static_assert(CTR_NUM <= 31, "counter block (the last word is the sink of k_read_events)");
 	HIPCHK(hipMemcpyAsync(v, c->counters, sizeof(v), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+#ifdef GYS_HUGE_TIMING
+	fprintf(stderr, "GYS_HUGE_TIMING ticks: load %llu words+tail %llu scan %llu assign %llu writeback %llu | entries %llu npend %llu nc %llu\n", (unsigned long long)v[20], (unsigned long long)v[21], (unsigned long long)v[22], (unsigned long long)v[23], (unsigned long long)v[24], (unsigned long long)v[25], (unsigned long long)v[26], (unsigned long long)v[27]);
+#endif
 	out->resp_events = v[CTR_RESP_EVENTS];
 	out->resp_dropped_range = v[CTR_RESP_DROP_RANGE];
 	out->resp_dropped_nolistener = v[CTR_RESP_DROP_NOLISTENER];

@@ -43,6 +43,9 @@ struct Huge2P {
 	uint32_t *nent_used;        // entries this path handles ( = min(count, maxent), 0 when the tail list overflowed)
 	uint32_t *tb_list;          // [maxent] pool entries k_huge_merge's tier A hands to tier B (more tail values than tier A's LDS list takes)
 	uint32_t *tb_count;
+#ifdef GYS_HUGE_TIMING // EXPERIMENT builds only: shader-clock ticks per phase of k_huge_merge, summed over entries (thread 0 of a workgroup)
+	unsigned long long *dbg;
+#endif
 };
 
 // ---- plan + clear: chunk prefix over the entries this path takes; the rest go to the fallback list
@@ -142,11 +145,8 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 				atomicAdd(&p.acc[(size_t)e * GYS_HB_ACC + 33u], 1ull); // the entry's own count of tail values: an entry without any skips the list
 			}
 		}
-#pragma unroll
-		for (int d = 32; d >= 1; d >>= 1) {
-			lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64));
-			lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
-		}
+		lmin = wave_min_u32(lmin);
+		lmax = wave_max_u32(lmax);
 		if ((tid & 63u) == 0) {
 			atomicMin(&s_mm[0], lmin);
 			atomicMax(&s_mm[1], lmax);
@@ -208,12 +208,12 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 template <uint32_t NT, uint32_t TAIL, bool FROM_LIST>
 __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 {
-	constexpr uint32_t BPT = GYS_HB_BINS / NT;    // bins per thread in the scan
 	GYS_DYN_LDS(uint32_t, s_img);                 // [GYS_HB_BINS] the entry's exact value counts (run + buffered words), then s_tail
 	uint32_t *s_tail = s_img + GYS_HB_BINS;       // [TAIL] the entry's values >= GYS_HB_BINS, sorted
 	__shared__ int64_t s_csum[GYS_TD_NB];
 	__shared__ uint32_t s_ccnt[GYS_TD_NB];
 	__shared__ uint64_t s_cpfx[GYS_TD_NB + 1];
+	__shared__ uint32_t s_cthr[GYS_TD_NB]; // compacted old cluster c has mean <= v  <=>  v >= s_cthr[c] = ceil(sum / count) (0 when the sum is not positive): the searches compare one word
 	__shared__ uint64_t s_T[GYS_TD_NB + 1];
 	__shared__ unsigned long long s_osum[GYS_TD_NB], s_ocnt[GYS_TD_NB];
 	__shared__ uint32_t s_w[NT / 64];
@@ -234,6 +234,13 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			if (tid == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = ent;
 			continue;
 		}
+#ifdef GYS_HUGE_TIMING
+		unsigned long long tk[6];
+		tk[0] = __builtin_amdgcn_s_memtime();
+#define GYS_HT(k) do { if (tid == 0) tk[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GYS_HT(k) do { } while (0)
+#endif
 		const uint32_t slot = ent.slot, m = ent.mrun, npend = ent.nbuf;
 		const uint4 mt = *(const uint4 *)&p.d.td_meta[slot];
 		const uint32_t nh = mt.y & 0xFFFFu, nw = mt.y >> 16, nwin0 = max(nh, nw);
@@ -257,12 +264,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 				sm0 = p.d.td_sum[(size_t)slot * GYS_TD_NB + tid];
 			}
 			const unsigned long long b0 = __ballot(c0 != 0);
-			uint64_t inc64 = c0;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint64_t t = __shfl_up(inc64, d, 64);
-				if ((int)lane >= d) inc64 += t;
-			}
+			const uint64_t inc64 = wave_incl_scan_u64(c0);
 			if (tid < 256u) {
 				if (lane == 63u) s_cw[wave] = inc64;
 				if (lane == 0u) s_w[wave] = (uint32_t)__popcll(b0);
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 					s_csum[pos] = sm0;
 					s_ccnt[pos] = c0;
 					s_cpfx[pos] = wb + inc64 - c0;
+					s_cthr[pos] = sm0 <= 0 ? 0u : (uint32_t)min((uint64_t)0xFFFFFFFFull, ((uint64_t)sm0 + c0 - 1u) / c0);
 				}
 				if (tid == 0) {
 					s_cpfx[ncl] = tot;
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			}
 		}
 		__syncthreads();
+		GYS_HT(1);
 		// the buffered words join the counts; their not yet folded part is folded here (the run's deltas come from k_huge_count).
 		// A large key's buffer holds up to 16 384 words and nearly all of them land in a handful of histogram buckets: per-value
 		// atomics on ONE set of bucket accumulators / one min / one max serialise the whole workgroup on a few LDS addresses (136 us per
@@ -312,34 +316,64 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			}
 			GYS_WAVE_SYNC();
 			int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmx = INT32_MIN;
-			for (uint32_t i = tid; i < npend; i += NT) {
-				const uint32_t word = pend[i], v = word >> GYS_ROW_BITS;
-				if (v < GYS_HB_BINS) {
-					atomicAdd(&s_img[v], 1u);
-				} else {
-					const uint32_t at = atomicAdd(&s_ntail, 1u);
-					if (at < TAIL) s_tail[at] = v; else s_over = 1;
+			// (eight loads in flight per thread: with one load per iteration in front of the LDS atomics every iteration waited out a whole
+			// global-memory round trip -- a quarter of a large key's merge at ~5 500 buffered words per key, r4z)
+			for (uint32_t i0 = 0; i0 < npend; i0 += 8u * NT) {
+				uint32_t wv[8];
+#pragma unroll
+				for (uint32_t u = 0; u < 8u; ++u) {
+					const uint32_t i = i0 + u * NT + tid;
+					wv[u] = i < npend ? pend[i] : 0u;
 				}
-				if (i >= nh) {
-					const uint32_t hb = resp_bucket((int64_t)v);
-					const unsigned long long one = GYS_PACK_ONE | (unsigned long long)v;
-					atomicAdd(&pa[hb], one);
-					lmin = min(lmin, (int32_t)v);
-					lmax = max(lmax, (int32_t)v);
-					if (i >= nwin0) {
-						atomicAdd(&pw[hb], one);
-						const uint32_t row = word & 0x1Fu, bit = (1u << hb) << ((row & 1u) * 16u);
-						if ((s_bm[row >> 1] & bit) == 0u) atomicOr(&s_bm[row >> 1], bit);
-						wmx = max(wmx, (int32_t)v);
+				// class of a word: 0 nothing to fold (folded before, or past the end), 1 not yet folded but of an earlier window (row pa),
+				// 2 of the open window (row pw; the fold of ALL not yet folded words is pa + pw).  The thread's eight words are combined per
+				// (class, bucket) in registers first: a large key's words sit in two or three buckets, and per-word adds lined the whole
+				// workgroup up on those few LDS addresses (same-address LDS atomics run a lane at a time: a quarter of the merge, r4z / r4ab)
+				uint32_t key[8];
+				unsigned long long one[8];
+#pragma unroll
+				for (uint32_t u = 0; u < 8u; ++u) {
+					const uint32_t i = i0 + u * NT + tid;
+					key[u] = 0xFFu;
+					one[u] = 0;
+					if (i >= npend) continue;
+					const uint32_t word = wv[u], v = word >> GYS_ROW_BITS;
+					if (v < GYS_HB_BINS) {
+						atomicAdd(&s_img[v], 1u);
+					} else {
+						const uint32_t at = atomicAdd(&s_ntail, 1u);
+						if (at < TAIL) s_tail[at] = v; else s_over = 1;
+					}
+					if (i >= nh) {
+						const uint32_t hb = resp_bucket((int64_t)v);
+						one[u] = GYS_PACK_ONE | (unsigned long long)v;
+						lmin = min(lmin, (int32_t)v);
+						lmax = max(lmax, (int32_t)v);
+						key[u] = hb;
+						if (i >= nwin0) {
+							key[u] = hb | 16u;
+							const uint32_t row = word & 0x1Fu, bit = (1u << hb) << ((row & 1u) * 16u);
+							if ((s_bm[row >> 1] & bit) == 0u) atomicOr(&s_bm[row >> 1], bit);
+							wmx = max(wmx, (int32_t)v);
+						}
 					}
 				}
-			}
 #pragma unroll
-			for (int d = 32; d >= 1; d >>= 1) {
-				lmin = min(lmin, __shfl_xor(lmin, d, 64));
-				lmax = max(lmax, __shfl_xor(lmax, d, 64));
-				wmx = max(wmx, __shfl_xor(wmx, d, 64));
+				for (uint32_t u = 0; u < 8u; ++u) {
+					if (key[u] == 0xFFu) continue;
+					unsigned long long acc = one[u];
+#pragma unroll
+					for (uint32_t w = u + 1u; w < 8u; ++w)
+						if (key[w] == key[u]) {
+							acc += one[w];
+							key[w] = 0xFFu;
+						}
+					atomicAdd((key[u] & 16u) ? &pw[key[u] & 15u] : &pa[key[u]], acc);
+				}
 			}
+			lmin = wave_min_i32(lmin);
+			lmax = wave_max_i32(lmax);
+			wmx = wave_max_i32(wmx);
 			if (lane == 0u) {
 				if (lmin != INT32_MAX) atomicMin(&s_min, lmin);
 				if (lmax != INT32_MIN) atomicMax(&s_max, lmax);
@@ -347,7 +381,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			}
 			GYS_WAVE_SYNC();
 			if (lane < 16u) { // the wave's row into the workgroup's {count, sum} pairs
-				const unsigned long long a = pa[lane], w = pw[lane];
+				const unsigned long long w = pw[lane], a = pa[lane] + w; // (all not yet folded = of earlier windows + of the open one)
 				if (a) {
 					atomicAdd(&s_ha[2 * lane], a >> 40);
 					atomicAdd(&s_ha[2 * lane + 1], GYS_PACK_SUM(a));
@@ -370,6 +404,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			}
 		}
 		__syncthreads();
+		GYS_HT(2);
 		if (s_over) { // too many large values for this tier's LDS list (nothing has been modified): the next tier takes the entry
 			if (tid == 0) {
 				if (!FROM_LIST && TAIL < GYS_HB_TAIL_LDS) p.tb_list[atomicAdd(p.tb_count, 1u)] = e;
@@ -408,42 +443,40 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 		const uint64_t twoN = 2ull * (nold + (uint64_t)m + (uint64_t)npend);
 		if (tid >= 1u && tid < GYS_TD_NB) s_T[tid] = td_threshold(c_td_bnd[tid], twoN);
 		if (tid == 0) s_T[GYS_TD_NB] = ~0ull;
-		// block exclusive scan of the 16 bins per thread
-		uint32_t part = 0;
+		// ---- the counts become exclusive prefixes IN PLACE (count of bin b = next prefix - this one).  Every wave takes a contiguous
+		// sixteenth / eighth of the bins 64 at a time -- lanes side by side, a wave scan, the carry in a scalar -- and adds the waves
+		// before it in a second sweep (four bins per lane and step).  (Round 3 gave every THREAD 32 consecutive bins: a stride of 32 words puts the 64 lanes of a wave
+		// on two LDS banks, and the three sweeps of that layout were a third of a large key's merge, r4z.)
+		uint32_t nlow = 0;
 		{
-			const uint4 *b4 = (const uint4 *)(s_img + tid * BPT);
-#pragma unroll
-			for (uint32_t i = 0; i < BPT / 4u; ++i) {
-				const uint4 v = b4[i];
-				part += v.x + v.y + v.z + v.w;
+			constexpr uint32_t NW = NT / 64u, PER_WAVE = GYS_HB_BINS / NW;
+			const uint32_t wb = wave * PER_WAVE;
+			uint32_t carry = 0;
+			for (uint32_t r = 0; r < PER_WAVE; r += 256u) { // four consecutive bins per lane: a quarter of the wave scans
+				uint4 *q4 = (uint4 *)(s_img + wb + r + lane * 4u);
+				const uint4 c4 = *q4;
+				const uint32_t c = c4.x + c4.y + c4.z + c4.w;
+				const uint32_t inc = wave_incl_scan_u32(c);
+				const uint32_t e0 = carry + inc - c;
+				*q4 = make_uint4(e0, e0 + c4.x, e0 + c4.x + c4.y, e0 + c4.x + c4.y + c4.z);
+				carry += wave_last_u32(inc);
 			}
-		}
-		uint32_t inc = part;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t t = __shfl_up(inc, d, 64);
-			if ((int)lane >= d) inc += t;
-		}
-		if (lane == 63u) s_w[wave] = inc;
-		__syncthreads();
-		uint32_t pfx = inc - part, nlow = 0;
-		for (uint32_t k = 0; k < NT / 64u; ++k) {
-			if (k < wave) pfx += s_w[k];
-			nlow += s_w[k];
-		}
-		// the counts become exclusive prefixes IN PLACE (count of bin b = next prefix - this one): the passes below then take their bins
-		// interleaved -- a key's values sit in the first thousand or two of the 16 384 bins, i.e. in the contiguous ranges of ONE wave's
-		// threads, which walked them one after the other while the other waves of the workgroup had nothing to do (170 us per key on the
-		// C5 shape, r3z)
-		{
-			uint32_t run = pfx;
-			for (uint32_t b = tid * BPT; b < tid * BPT + BPT; ++b) {
-				const uint32_t c = s_img[b];
-				s_img[b] = run;
-				run += c;
+			if (lane == 0u) s_w[wave] = carry;
+			__syncthreads();
+			uint32_t woff = 0;
+			for (uint32_t k = 0; k < NW; ++k) {
+				if (k < wave) woff += s_w[k];
+				nlow += s_w[k];
 			}
+			if (woff)
+				for (uint32_t r = 0; r < PER_WAVE; r += 256u) {
+					uint4 *q4 = (uint4 *)(s_img + wb + r + lane * 4u);
+					const uint4 c4 = *q4;
+					*q4 = make_uint4(c4.x + woff, c4.y + woff, c4.z + woff, c4.w + woff);
+				}
 		}
 		__syncthreads();
+		GYS_HT(3);
 		// ---- old clusters: lt = #{values v : v * cc < cs} = #{v <= (cs - 1) / cc}  (cs >= 1; none when cs <= 0)
 		if (tid < nc) {
 			const int64_t cs = s_csum[tid];
@@ -472,40 +505,66 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			atomicAdd(&s_osum[cl], (unsigned long long)cs);
 			atomicAdd(&s_ocnt[cl], (unsigned long long)cc);
 		}
-		// ---- values bin by bin (thread t: bins t, t + NT, ...): ranks [r0, r0 + c) of value v, le = old weight with mean <= v
-		for (uint32_t b = tid; b < GYS_HB_BINS; b += NT) {
-			const uint32_t r0b = s_img[b];
-			const uint32_t c = (b + 1u < GYS_HB_BINS ? s_img[b + 1u] : nlow) - r0b;
-			if (!c) continue;
-			const int64_t v = (int64_t)b;
-			uint32_t ci; // first compacted cluster with mean > v
-			{
-				uint32_t lo = 0, hi = nc;
-				while (lo < hi) {
-					const uint32_t mid = (lo + hi) >> 1;
-					if (s_csum[mid] <= v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
-				}
-				ci = lo;
+		// ---- values bin by bin (thread t: bins t, t + NT, ...): ranks [r0, r0 + c) of value v, le = old weight with mean <= v.
+		// Two bins per thread and round, the three searches of either written as eight fixed steps (no data-dependent branch): a search is
+		// a chain of dependent LDS reads, and with one bin per round and `continue` on an empty one the 32 rounds of a large key's long
+		// sparse tail of bins each cost a full chain for a few live lanes (the pass was 36 % of the merge, r4z) -- now the two chains of a
+		// round overlap and there are 16 rounds.
+		for (uint32_t b0 = tid; b0 < GYS_HB_BINS; b0 += 2u * NT) {
+			uint32_t bb[2], r0b[2], cc[2];
+#pragma unroll
+			for (int u = 0; u < 2; ++u) {
+				bb[u] = b0 + (uint32_t)u * NT;
+				r0b[u] = s_img[bb[u]];
+				cc[u] = (bb[u] + 1u < GYS_HB_BINS ? s_img[bb[u] + 1u] : nlow) - r0b[u];
 			}
-			const uint64_t r0 = r0b, le = s_cpfx[ci];
-			const uint64_t first = 2ull * (r0 + le) + 1ull, last = first + 2ull * (uint64_t)(c - 1u);
-			uint32_t cl = td_cluster_of(s_T, first);
-			const uint32_t cl_last = td_cluster_of(s_T, last);
-			uint64_t rbeg = r0;
-			for (; cl <= cl_last; ++cl) {
-				uint64_t rend;
-				if (cl == cl_last) {
-					rend = r0 + c;
-				} else {
-					const uint64_t Tn = s_T[cl + 1];
-					rend = (Tn / 2ull) - le; // ranks r with 2 (r + le) + 1 < Tn
-					if (rend > r0 + c) rend = r0 + c;
+			if (!(cc[0] | cc[1])) continue;
+			uint32_t ci[2] = {0u, 0u}; // first compacted cluster with mean > v
+#pragma unroll
+			for (uint32_t step = 128u; step; step >>= 1) {
+#pragma unroll
+				for (int u = 0; u < 2; ++u) {
+					const uint32_t np = ci[u] + step;
+					if (np <= nc && s_cthr[np - 1u] <= bb[u]) ci[u] = np;
 				}
-				if (rend > rbeg) {
-					const uint64_t k = rend - rbeg;
-					atomicAdd(&s_osum[cl], (unsigned long long)(k * (uint64_t)v));
-					atomicAdd(&s_ocnt[cl], (unsigned long long)k);
-					rbeg = rend;
+			}
+			uint64_t le[2], first[2], last[2];
+			uint32_t cl[2] = {0u, 0u}, cl_last[2] = {0u, 0u};
+#pragma unroll
+			for (int u = 0; u < 2; ++u) {
+				le[u] = s_cpfx[ci[u]];
+				first[u] = 2ull * ((uint64_t)r0b[u] + le[u]) + 1ull;
+				last[u] = first[u] + 2ull * (uint64_t)(cc[u] ? cc[u] - 1u : 0u);
+			}
+#pragma unroll
+			for (uint32_t step = 128u; step; step >>= 1) { // td_cluster_of(s_T, .) for the four rank ends at once
+#pragma unroll
+				for (int u = 0; u < 2; ++u) {
+					const uint32_t n1 = cl[u] + step, n2 = cl_last[u] + step;
+					if (n1 <= GYS_TD_NB - 1u && first[u] >= s_T[n1]) cl[u] = n1;
+					if (n2 <= GYS_TD_NB - 1u && last[u] >= s_T[n2]) cl_last[u] = n2;
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < 2; ++u) {
+				if (!cc[u]) continue;
+				const uint64_t r0 = r0b[u], v = bb[u];
+				uint64_t rbeg = r0;
+				for (uint32_t k = cl[u]; k <= cl_last[u]; ++k) {
+					uint64_t rend;
+					if (k == cl_last[u]) {
+						rend = r0 + cc[u];
+					} else {
+						const uint64_t Tn = s_T[k + 1];
+						rend = (Tn / 2ull) - le[u]; // ranks r with 2 (r + le) + 1 < Tn
+						if (rend > r0 + cc[u]) rend = r0 + cc[u];
+					}
+					if (rend > rbeg) {
+						const uint64_t n = rend - rbeg;
+						atomicAdd(&s_osum[k], (unsigned long long)(n * v));
+						atomicAdd(&s_ocnt[k], (unsigned long long)n);
+						rbeg = rend;
+					}
 				}
 			}
 		}
@@ -524,7 +583,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			uint32_t lo = 0, hi = nc; // old weight with mean <= v
 			while (lo < hi) {
 				const uint32_t mid = (lo + hi) >> 1;
-				if (s_csum[mid] <= (int64_t)v * (int64_t)s_ccnt[mid]) lo = mid + 1; else hi = mid;
+				if (s_cthr[mid] <= v) lo = mid + 1; else hi = mid;
 			}
 			const uint64_t mid2 = 2ull * (r + s_cpfx[lo]) + 1ull;
 			const uint32_t cl = td_cluster_of(s_T, mid2);
@@ -532,6 +591,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			atomicAdd(&s_ocnt[cl], 1ull);
 		}
 		__syncthreads();
+		GYS_HT(4);
 		if (tid < GYS_TD_NB) {
 			p.d.td_sum[(size_t)slot * GYS_TD_NB + tid] = (int64_t)s_osum[tid];
 			p.d.td_cnt[(size_t)slot * GYS_TD_NB + tid] = (uint32_t)s_ocnt[tid];
@@ -587,6 +647,15 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			}
 		}
 		__syncthreads();
+#ifdef GYS_HUGE_TIMING
+		if (tid == 0 && !FROM_LIST) {
+			tk[5] = __builtin_amdgcn_s_memtime();
+			for (int k = 0; k < 5; ++k) atomicAdd(&p.dbg[k], tk[k + 1] - tk[k]);
+			atomicAdd(&p.dbg[5], 1ull);
+			atomicAdd(&p.dbg[6], (unsigned long long)npend);
+			atomicAdd(&p.dbg[7], (unsigned long long)nc);
+		}
+#endif
 	}
 }
 

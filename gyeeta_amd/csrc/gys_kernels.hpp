@@ -239,14 +239,9 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *s_wave, uint32_t *total)
 {
-	// inclusive wave scan by shuffles, then 4 wave totals through LDS
+	// inclusive wave scan (DPP), then 4 wave totals through LDS
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	uint32_t inc = v;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t t = __shfl_up(inc, d, 64);
-		if ((int)lane >= d) inc += t;
-	}
+	const uint32_t inc = wave_incl_scan_u32(v);
 	if (lane == 63) s_wave[wave] = inc;
 	__syncthreads();
 	uint32_t woff = 0, tot = 0;
@@ -588,12 +583,7 @@ __global__ __launch_bounds__(256) void k_prespill(PreSpillP p)
 		}
 	}
 	// one cursor atomic per workgroup
-	uint32_t inc = cap;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
-		if ((int)lane >= d) inc += o;
-	}
+	const uint32_t inc = wave_incl_scan_u32(cap);
 	if (lane == 63u) s_w[wave] = inc;
 	__syncthreads();
 	if (threadIdx.x == 0) {
@@ -869,8 +859,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 				const uint4 v = h4[i];
 				mn = min(min(mn, min(v.x, v.y)), min(v.z, v.w));
 			}
-#pragma unroll
-			for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
+			mn = wave_min_u32(mn);
 			if (lane == 0) atomicMin(&s_floor[0], mn);
 		} else if (tid == 0) {
 			s_floor[0] = 0;
@@ -1152,12 +1141,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 		{
 			uint32_t sum = 0;
 			for (uint32_t k = klo; k < khi; ++k) sum += s_ts[k];
-			uint32_t inc = sum;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t t = __shfl_up(inc, d, 64);
-				if ((int)lane >= d) inc += t;
-			}
+			const uint32_t inc = wave_incl_scan_u32(sum); // (DPP: the shuffle loop was six dependent ds_bpermute round trips per tile)
 			if (lane == 63) s_wsum[wave] = inc;
 			__syncthreads();
 			if (!SPILL && tid == 0) {
@@ -1265,8 +1249,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 				uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
 				for (uint32_t j = 0; j < NF; ++j) mn = min(min(mn, min(fv[j].x, fv[j].y)), min(fv[j].z, fv[j].w));
-#pragma unroll
-				for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
+				mn = wave_min_u32(mn);
 				if (lane == 0) atomicMin(&s_floor[tile_no & 1u], mn);
 			}
 		}
@@ -1274,8 +1257,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 	}
 	if (SPILL) return;
 	if (DBG && dbg_sink == 0xDEADBEEFu) p.counters[CTR_RESP_EVENTS] = 1; // (keeps the hashes of the timing-only variant alive)
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) tmax = max(tmax, __shfl_xor(tmax, d, 64));
+	tmax = wave_max_i32(tmax);
 	if (lane == 0 && tmax != INT32_MIN) atomicMax(&s_gmax, tmax);
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
 	if (ndrop_nol) atomicAdd(&s_drop[1], ndrop_nol);
@@ -1621,12 +1603,7 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 		{
 			const unsigned long long b0 = __ballot(c0 != 0);
 			const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-			uint64_t inc = c0;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint64_t t = __shfl_up(inc, d, 64);
-				if ((int)lane >= d) inc += t;
-			}
+			const uint64_t inc = wave_incl_scan_u64(c0);
 			if (lane == 63u) s_ww[wave] = inc;
 			if (lane == 0u) s_wv[wave] = (uint32_t)__popcll(b0);
 			__syncthreads();
@@ -1708,12 +1685,9 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 				}
 			}
 			if (!query && m > nh) {
-#pragma unroll
-				for (int d = 32; d >= 1; d >>= 1) {
-					lmin = min(lmin, __shfl_xor(lmin, d, 64));
-					lmax = max(lmax, __shfl_xor(lmax, d, 64));
-					wmax = max(wmax, __shfl_xor(wmax, d, 64));
-				}
+				lmin = wave_min_i32(lmin);
+				lmax = wave_max_i32(lmax);
+				wmax = wave_max_i32(wmax);
 				if (lane == 0) {
 					if (lmin != INT32_MAX) atomicMin(&s_fmm[0], lmin);
 					if (lmax != INT32_MIN) atomicMax(&s_fmm[1], lmax);
@@ -1734,15 +1708,7 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 				own += t[k];
 				gown += gcl[k];
 			}
-			uint32_t inc = own, ginc = gown;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t u = __shfl_up(inc, d, 64), gu = __shfl_up(ginc, d, 64);
-				if ((int)lane >= d) {
-					inc += u;
-					ginc += gu;
-				}
-			}
+			const uint32_t inc = wave_incl_scan_u32(own), ginc = wave_incl_scan_u32(gown);
 			uint32_t ex = inc - own, gex = ginc - gown;
 #pragma unroll
 			for (int k = 0; k < 5; ++k) {
@@ -2004,12 +1970,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		}
 		// compaction of the non-empty clusters (order preserving) + exclusive prefix of their weights
 		const unsigned long long b0 = __ballot(c0 != 0);
-		uint64_t inc = c0;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint64_t t = __shfl_up(inc, d, 64);
-			if ((int)lane >= d) inc += t;
-		}
+		const uint64_t inc = wave_incl_scan_u64(c0);
 		if (lane == 63u) s_ww[wave] = inc;
 		if (lane == 0u) s_wv[wave] = (uint32_t)__popcll(b0);
 		__syncthreads();
@@ -2081,12 +2042,9 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			}
 		}
 		if ((!query && m > nh) || (SCAN && m > nh_mm)) {
-#pragma unroll
-			for (int d = 32; d >= 1; d >>= 1) {
-				lmin = min(lmin, __shfl_xor(lmin, d, 64));
-				lmax = max(lmax, __shfl_xor(lmax, d, 64));
-				wmax = max(wmax, __shfl_xor(wmax, d, 64));
-			}
+			lmin = wave_min_i32(lmin);
+			lmax = wave_max_i32(lmax);
+			wmax = wave_max_i32(wmax);
 			if (lane == 0) {
 				if (lmin != INT32_MAX) atomicMin(&s_fmm[0], lmin);
 				if (lmax != INT32_MIN) atomicMax(&s_fmm[1], lmax);
@@ -2104,12 +2062,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			}
 #pragma unroll
 			for (uint32_t k = 0; k < GYS_MB_BPT; ++k) own += bv[k];
-			uint32_t sc = own;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t t = __shfl_up(sc, d, 64);
-				if ((int)lane >= d) sc += t;
-			}
+			const uint32_t sc = wave_incl_scan_u32(own);
 			if (lane == 63u) s_ws[wave] = sc;
 			__syncthreads();
 			uint32_t run = sc - own;
@@ -2267,12 +2220,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			const uint32_t oc = tid < GYS_TD_NB ? s_ocnt[tid] : 0u;
 			const unsigned long long os = tid < GYS_TD_NB ? s_osum[tid] : 0ull;
 			const unsigned long long ob = __ballot(oc != 0);
-			uint32_t sc = oc;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t t = __shfl_up(sc, d, 64);
-				if ((int)lane >= d) sc += t;
-			}
+			const uint32_t sc = wave_incl_scan_u32(oc);
 			if (lane == 63u) s_ws[wave] = sc;
 			if (lane == 0u) s_wv[wave] = (uint32_t)__popcll(ob);
 			__syncthreads();
@@ -2851,8 +2799,7 @@ __global__ __launch_bounds__(GYS_CONN_THREADS) void k_conn_ingest(ConnP p)
 		// table above was cleared).  A register only grows, so a record whose rank is at or below the floor cannot change its register
 		// and does not read it -- after the first few thousand flows of a window that is nearly every record, and the dependent
 		// register read behind the flow hash was 0.15 of the kernel's 1.05 ms (r4q).
-#pragma unroll
-		for (int d = 32; d; d >>= 1) fl = min(fl, (uint32_t)__shfl_xor((int)fl, d, 64));
+		fl = wave_min_u32(fl);
 		if (lane == 0) atomicMin(&s_tally[CONN_T_NUM + 1], fl);
 		__syncthreads();
 	}
