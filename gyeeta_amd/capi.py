@@ -119,7 +119,7 @@ class SvcAggrRow(C.Structure):  # gys_svc_aggr_row
 SVC_COLS = ["qps5s", "nqry5s", "resp5s", "p95resp5s", "p95resp5m", "nconns", "nactive", "nprocs", "kbin15s", "kbout15s", "sererr", "clierr", "delayus",
             "cpudelus", "iodelus", "vmdelus", "usercpu", "syscpu", "rssmb", "nissue", "state", "issue", "ishttp"]  # GYS_SVC_COL_* in order
 SUMM_COLS = ["nidle", "ngood", "nok", "nbad", "nsevere", "ndown", "totqps", "totaconn", "totkbin", "totkbout", "totsererr", "nsvc", "nactive"]  # GYS_SUMM_COL_*
-COMP = {"=": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "bit2": 6, "bit3": 7, "in": 12, "notin": 13}  # GYS_COMP_* (COMPARATORS_E numbering)
+COMP = {"=": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "bit2": 6, "bit3": 7, "substr": 8, "notsubstr": 9, "like": 10, "notlike": 11, "in": 12, "notin": 13}  # GYS_COMP_* (COMPARATORS_E numbering)
 AOPER = {"sum": 1, "avg": 2, "max": 3, "min": 4, "count": 5, "bool_or": 9, "bool_and": 10}  # GYS_AOPER_* (AGGR_OPER_E numbering)
 
 
@@ -207,6 +207,7 @@ SIGNATURES = {
                                               C.POINTER(C.c_size_t)]),
     "gys_query_svcstate_aggr": (C.c_int, [vp, C.POINTER(SvcFilter), C.c_int, u8p, C.c_uint32, C.POINTER(SvcAggrRow), C.c_uint32, u32p]),
     "gys_svc_aggr_value": (C.c_int, [C.POINTER(SvcAggrRow), C.c_uint32, C.c_int, f64p]),
+    "gys_svc_ids_by_name": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, u64p, C.c_uint32, u32p]),
     "gys_json_svcsumm_multihost": (C.c_int, [vp, C.POINTER(SvcFilter), C.c_int, C.c_int, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t,
                                              C.POINTER(C.c_size_t)]),
     "gys_num_services": (C.c_uint32, [vp]),

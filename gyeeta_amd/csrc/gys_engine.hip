@@ -19,6 +19,7 @@
 #include <thread>
 #include <condition_variable>
 #include <mutex>
+#include <regex>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>

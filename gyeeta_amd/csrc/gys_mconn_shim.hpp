@@ -215,6 +215,28 @@ public:
 			return gys_json_svcsumm_multihost(ctx_, filter, sort_col, sort_desc ? 1 : 0, maxrecs, madid, timestr, b, n, need);
 		});
 	}
+	// a string criterion on the service name ({ svcstate.name like 'post' }: CRITERION_ONE::match_str_criterian common/gy_query_criteria.h:1335-1383)
+	// resolved into the service ids a filter's `svcids` takes; comp = GYS_COMP_EQ / NEQ / SUBSTR / NOTSUBSTR / LIKE / NOTLIKE / IN / NOTIN
+	bool svc_ids_by_name(int comp, const std::vector<std::string> &patterns, std::vector<uint64_t> &ids) noexcept
+	{
+		try {
+			std::shared_lock<std::shared_mutex> g(mu_);
+			std::vector<const char *> p;
+			for (const auto &s : patterns) p.push_back(s.c_str());
+			uint32_t n = 0;
+			ids.resize(1024);
+			int rc = gys_svc_ids_by_name(ctx_, comp, p.data(), (uint32_t)p.size(), ids.data(), (uint32_t)ids.size(), &n);
+			if (rc == GYS_ERR_NOMEM) {
+				ids.resize(n);
+				rc = gys_svc_ids_by_name(ctx_, comp, p.data(), (uint32_t)p.size(), ids.data(), (uint32_t)ids.size(), &n);
+			}
+			if (rc != GYS_OK) return false;
+			ids.resize(n);
+			return true;
+		} catch (...) {
+			return false;
+		}
+	}
 	// the aggregation operators (AGGR_OPER_E, common/gy_json_field_maps.h:114-129) over the matching listeners: group_by 0 all / 1 host / 2 cluster
 	bool aggr_listener_state(const gys_svc_filter *filter, int group_by, const uint8_t *cols, uint32_t ncols, gys_svc_aggr_row *out, uint32_t maxrows,
 				 uint32_t *nrows) noexcept

@@ -428,6 +428,57 @@ try {
 	return json_out(j, buf, buflen, needed);
 } GYS_CATCH_ALL
 
+// string criterion on the service name (CRITERION_ONE::match_str_criterian common/gy_query_criteria.h:1335-1383), resolved on the host
+// into the service ids the device filter takes (gys_svc_filter.svcids)
+int gys_svc_ids_by_name(gys_ctx *c, int comp, const char *const *patterns, uint32_t npatterns, uint64_t *out_ids, uint32_t cap, uint32_t *nout)
+try {
+	GYS_ENTER_NOFLUSH(c);
+	if (!c || !nout || (!out_ids && cap) || !patterns || !npatterns) return GYS_ERR_INVAL;
+	for (uint32_t i = 0; i < npatterns; ++i)
+		if (!patterns[i]) return GYS_ERR_INVAL;
+	const bool neg = comp == GYS_COMP_NEQ || comp == GYS_COMP_NOTSUBSTR || comp == GYS_COMP_NOTLIKE || comp == GYS_COMP_NOTIN;
+	const int base = comp == GYS_COMP_NEQ ? GYS_COMP_EQ : comp == GYS_COMP_NOTSUBSTR ? GYS_COMP_SUBSTR : comp == GYS_COMP_NOTLIKE ? GYS_COMP_LIKE :
+			 comp == GYS_COMP_NOTIN ? GYS_COMP_IN : comp;
+	if (base != GYS_COMP_EQ && base != GYS_COMP_SUBSTR && base != GYS_COMP_LIKE && base != GYS_COMP_IN) {
+		set_err("gys_svc_ids_by_name: comparator %d is not a string comparator", comp);
+		return GYS_ERR_INVAL;
+	}
+	std::regex re;
+	if (base == GYS_COMP_LIKE) {
+		try {
+			re = std::regex(patterns[0], std::regex::ECMAScript | std::regex::optimize);
+		} catch (const std::regex_error &e) {
+			set_err("gys_svc_ids_by_name: invalid regular expression: %s", e.what());
+			return GYS_ERR_INVAL;
+		}
+	}
+	const size_t plen0 = strlen(patterns[0]);
+	uint32_t n = 0;
+	for (uint32_t slot = 0; slot < c->nsvc; ++slot) {
+		const char *name = c->svc_comm[slot].data();
+		const size_t len = strnlen(name, 16);
+		bool hit = false;
+		switch (base) {
+		case GYS_COMP_EQ: hit = len == plen0 && !memcmp(name, patterns[0], len); break;
+		case GYS_COMP_SUBSTR: hit = plen0 <= len && memmem(name, len, patterns[0], plen0) != nullptr; break;
+		case GYS_COMP_LIKE: hit = std::regex_search(name, name + len, re); break;
+		default:
+			for (uint32_t i = 0; i < npatterns && !hit; ++i) hit = strlen(patterns[i]) == len && !memcmp(name, patterns[i], len);
+			break;
+		}
+		if (hit != neg) {
+			if (n < cap) out_ids[n] = c->svc_gid_h[slot];
+			++n;
+		}
+	}
+	*nout = n;
+	if (n > cap) {
+		set_err("gys_svc_ids_by_name: %u services match, room for %u", n, cap);
+		return GYS_ERR_NOMEM;
+	}
+	return GYS_OK;
+} GYS_CATCH_ALL
+
 int gys_svc_aggr_value(const gys_svc_aggr_row *row, uint32_t col_index, int oper, double *out)
 {
 	if (!row || !out || col_index >= GYS_SVC_MAX_AGGR || (oper != GYS_AOPER_COUNT && col_index >= row->ncols)) return GYS_ERR_INVAL;

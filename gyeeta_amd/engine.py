@@ -407,6 +407,16 @@ class SketchEngine:
             f.nclusters = len(clusters)
         return f, (arr, sv, mids, ids, cl)
 
+    def svc_ids_by_name(self, comp, patterns):
+        """gys_svc_ids_by_name: glob_ids of the registered services whose process name matches the string criterion (for svcids=...)"""
+        pats = [patterns] if isinstance(patterns, (str, bytes)) else list(patterns)
+        arr = (C.c_char_p * len(pats))(*[p if isinstance(p, bytes) else p.encode() for p in pats])
+        cap = max(self.num_services(), 1)
+        out = np.zeros(cap, dtype=np.uint64)
+        n = C.c_uint32()
+        capi.check(self.L.gys_svc_ids_by_name(self.h, capi.COMP[comp], arr, len(pats), out.ctypes.data_as(capi.u64p), cap, C.byref(n)))
+        return out[:n.value].copy()
+
     def svcstate_scan(self, terms=None, group_oper=(), top_oper="and", sort_col=None, sort_desc=True, maxrecs=1000, machine_ids=None, svcids=None,
                       clusters=None):
         """gys_query_svcstate_scan -> (slots, host slots, records as a numpy array of wire.LISTENER_STATE_NOTIFY, number matched)"""

@@ -496,6 +496,15 @@ typedef struct {
  * FIRST maxrecs of that order are returned (an exact top-k on the device).  *nmatched = records that matched. */
 int gys_query_svcstate_scan(gys_ctx *ctx, const gys_svc_filter *filter, int sort_col, int sort_desc, uint32_t maxrecs, gys_svc_row *out,
 			    uint32_t *nout, uint64_t *nmatched);
+/* A criterion on the service's NAME (SvcStateFields "name" / "svcname": a string field, server/gy_mfields.h): the glob_ids of the
+ * registered services whose process name (gys_listener_info.comm) matches -- to be handed to gys_svc_filter.svcids.  comp = the
+ * reference's string comparators with its numbering (COMPARATORS_E common/gy_query_criteria.h:28-45; match_str_criterian :1335-1383):
+ * GYS_COMP_EQ / NEQ (whole name), GYS_COMP_SUBSTR / NOTSUBSTR (memmem), GYS_COMP_LIKE / NOTLIKE (a regular expression matched anywhere in
+ * the name, as RE2::PartialMatch -- here std::regex, ECMAScript syntax; an invalid expression is GYS_ERR_INVAL as the reference's
+ * ERR_INVALID_REQUEST), GYS_COMP_IN / NOTIN (any / none of npatterns whole names).  The other comparators use patterns[0].  Host-side:
+ * the names never leave the host.  *nout = services that match; GYS_ERR_NOMEM when that exceeds cap (the first cap are written). */
+enum { GYS_COMP_SUBSTR = 8, GYS_COMP_NOTSUBSTR = 9, GYS_COMP_LIKE = 10, GYS_COMP_NOTLIKE = 11 };
+int gys_svc_ids_by_name(gys_ctx *ctx, int comp, const char *const *patterns, uint32_t npatterns, uint64_t *out_ids, uint32_t cap, uint32_t *nout);
 /* the same as the reference's multi-host JSON: {"madid":..,"svcstate":[{"parid","host","madid","cluster", then the json_db_svcstate_arr
  * columns}, ...]} (column list of a multi-host query: QUERY_OPTIONS::get_all_column_list common/gy_query_common.h:418-437) */
 int gys_json_svcstate_multihost(gys_ctx *ctx, const gys_svc_filter *filter, int sort_col, int sort_desc, uint32_t maxrecs,

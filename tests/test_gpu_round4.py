@@ -452,3 +452,47 @@ def test_conn_and_listener_state_calls_from_16_threads_are_combined_and_equal_se
     assert after["conn_events"] - before["conn_events"] == len(big) and after["conn_calls_queued"] == before["conn_calls_queued"]
     for e in engs:
         e.close()
+
+
+def test_service_name_criterion_resolves_to_service_ids():
+    """gys_svc_ids_by_name: the reference's string comparators on the service name (CRITERION_ONE::match_str_criterian,
+    common/gy_query_criteria.h:1335-1383: = / != whole name, substr / notsubstr memmem, like / notlike a regular expression matched
+    anywhere, in / notin whole names) against python's own string operations; the ids then select rows of the filtered query."""
+    import re
+    eng = _engine(max_hosts=4, max_services=256, enable_tdigest=False)
+    names = [b"nginx", b"postgres", b"post-worker", b"redis-server", b"java", b"x" * 16, b"envoy", b"post"]  # (a 16-byte name has no terminator)
+    gid_name = {}
+    rng = np.random.default_rng(5)
+    for h in range(3):
+        mid = wire.machine_id(h)
+        eng.register_host(mid, "c0")
+        for k, nm in enumerate(names):
+            s = np.arange(4) + 4 * k
+            gids = wire.glob_id(np.full(4, h), s)
+            eng.register_listeners(mid, gids, wire.listener_netns(h, s), wire.listener_port(s), comm=nm)
+            for g in gids:
+                gid_name[int(g)] = nm.decode()
+    cases = [("=", ["post"], lambda n: n == "post"), ("!=", ["post"], lambda n: n != "post"),
+             ("substr", ["post"], lambda n: "post" in n), ("notsubstr", ["post"], lambda n: "post" not in n),
+             ("like", ["^post.*r$"], lambda n: re.search("^post.*r$", n) is not None), ("notlike", ["^(nginx|envoy)$"], lambda n: re.search("^(nginx|envoy)$", n) is None),
+             ("like", ["x{16}"], lambda n: re.search("x{16}", n) is not None),
+             ("in", ["java", "redis-server", "nope"], lambda n: n in ("java", "redis-server")), ("notin", ["java", "post"], lambda n: n not in ("java", "post")),
+             ("substr", ["a-name-longer-than-16-bytes"], lambda n: False)]
+    for comp, pats, pred in cases:
+        got = set(int(x) for x in eng.svc_ids_by_name(comp, pats))
+        want = {g for g, n in gid_name.items() if pred(n)}
+        assert got == want, (comp, pats, len(got), len(want))
+    with pytest.raises(capi.GysError):
+        eng.svc_ids_by_name("like", ["(unclosed"])
+    with pytest.raises(capi.GysError):
+        eng.svc_ids_by_name("<", ["post"])
+    # the ids select rows of the filtered multi-host query: states of every listener, then { name substr 'post' and qps5s >= 0 }
+    for h in range(3):
+        ls = wire.synth_listener_states(rng, h, np.arange(4 * len(names)))
+        eng.partha_listener_state(wire.machine_id(h), wire.pack_variable(ls, None), len(ls))
+    ids = eng.svc_ids_by_name("substr", "post")
+    slots, hosts, recs, nm = eng.svcstate_scan(terms=[("qps5s", ">=", 0)], maxrecs=1000, svcids=ids)
+    assert nm == len(slots) > 0 and set(int(g) for g in recs["glob_id"]) <= set(int(x) for x in ids)
+    _, _, recs_all, nall = eng.svcstate_scan(terms=[("qps5s", ">=", 0)], maxrecs=1000)
+    assert set(int(g) for g in recs["glob_id"]) == {int(g) for g in recs_all["glob_id"] if "post" in gid_name[int(g)]}
+    eng.close()
