@@ -74,9 +74,16 @@ def test_filter_query_tables_equal_the_reference():
     assert [n.lower() for n in names] == capi.SVC_COLS
     comp = _ref_enum("/root/reference/common/gy_query_criteria.h", "COMPARATORS_E")
     ref_comp = {"=": "COMP_EQ", "!=": "COMP_NEQ", "<": "COMP_LT", "<=": "COMP_LE", ">": "COMP_GT", ">=": "COMP_GE", "bit2": "COMP_BIT2", "bit3": "COMP_BIT3",
-                "in": "COMP_IN", "notin": "COMP_NOTIN"}
+                "substr": "COMP_SUBSTR", "notsubstr": "COMP_NOTSUBSTR", "like": "COMP_LIKE", "notlike": "COMP_NOTLIKE", "in": "COMP_IN", "notin": "COMP_NOTIN"}
     for k, v in capi.COMP.items():
         assert comp[ref_comp[k]] == v, k
+    for cname, v in comp.items():  # ... and every GYS_COMP_* of the header carries the reference's number
+        if cname == "COMP_MAX":
+            continue
+        mm = re.search(r"GYS_" + cname + r"\b(?:\s*=\s*(\d+))?", hdr)
+        assert mm, cname
+        if mm.group(1) is not None:
+            assert int(mm.group(1)) == v, cname
     aop = _ref_enum(REF, "AGGR_OPER_E")
     ref_aop = {"sum": "AOPER_SUM", "avg": "AOPER_AVG", "max": "AOPER_MAX", "min": "AOPER_MIN", "count": "AOPER_COUNT", "bool_or": "AOPER_BOOL_OR",
                "bool_and": "AOPER_BOOL_AND"}
