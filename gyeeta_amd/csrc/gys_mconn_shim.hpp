@@ -237,6 +237,27 @@ public:
 			return false;
 		}
 	}
+	// ... on the host name ({ svcstate.host substr 'db' }): the machine ids (16 bytes each) a filter's `machine_ids` takes
+	bool machine_ids_by_hostname(int comp, const std::vector<std::string> &patterns, std::vector<uint8_t> &ids16) noexcept
+	{
+		try {
+			std::shared_lock<std::shared_mutex> g(mu_);
+			std::vector<const char *> p;
+			for (const auto &s : patterns) p.push_back(s.c_str());
+			uint32_t n = 0;
+			ids16.resize(16 * 256);
+			int rc = gys_machine_ids_by_hostname(ctx_, comp, p.data(), (uint32_t)p.size(), ids16.data(), (uint32_t)(ids16.size() / 16), &n);
+			if (rc == GYS_ERR_NOMEM) {
+				ids16.resize((size_t)16 * n);
+				rc = gys_machine_ids_by_hostname(ctx_, comp, p.data(), (uint32_t)p.size(), ids16.data(), n, &n);
+			}
+			if (rc != GYS_OK) return false;
+			ids16.resize((size_t)16 * n);
+			return true;
+		} catch (...) {
+			return false;
+		}
+	}
 	// the aggregation operators (AGGR_OPER_E, common/gy_json_field_maps.h:114-129) over the matching listeners: group_by 0 all / 1 host / 2 cluster
 	bool aggr_listener_state(const gys_svc_filter *filter, int group_by, const uint8_t *cols, uint32_t ncols, gys_svc_aggr_row *out, uint32_t maxrows,
 				 uint32_t *nrows) noexcept

@@ -428,45 +428,69 @@ try {
 	return json_out(j, buf, buflen, needed);
 } GYS_CATCH_ALL
 
-// string criterion on the service name (CRITERION_ONE::match_str_criterian common/gy_query_criteria.h:1335-1383), resolved on the host
-// into the service ids the device filter takes (gys_svc_filter.svcids)
+} // extern "C"
+
+namespace {
+// CRITERION_ONE::match_str_criterian (common/gy_query_criteria.h:1335-1383) for one comparator and its pattern(s), compiled once
+struct StrCriterion {
+	int base = 0;
+	bool neg = false;
+	std::regex re;
+	std::vector<std::string> pats;
+	int init(int comp, const char *const *patterns, uint32_t npatterns, const char *who)
+	{
+		if (!patterns || !npatterns) return GYS_ERR_INVAL;
+		for (uint32_t i = 0; i < npatterns; ++i) {
+			if (!patterns[i]) return GYS_ERR_INVAL;
+			pats.emplace_back(patterns[i]);
+		}
+		neg = comp == GYS_COMP_NEQ || comp == GYS_COMP_NOTSUBSTR || comp == GYS_COMP_NOTLIKE || comp == GYS_COMP_NOTIN;
+		base = comp == GYS_COMP_NEQ ? GYS_COMP_EQ : comp == GYS_COMP_NOTSUBSTR ? GYS_COMP_SUBSTR : comp == GYS_COMP_NOTLIKE ? GYS_COMP_LIKE :
+		       comp == GYS_COMP_NOTIN ? GYS_COMP_IN : comp;
+		if (base != GYS_COMP_EQ && base != GYS_COMP_SUBSTR && base != GYS_COMP_LIKE && base != GYS_COMP_IN) {
+			set_err("%s: comparator %d is not a string comparator", who, comp);
+			return GYS_ERR_INVAL;
+		}
+		if (base == GYS_COMP_LIKE) {
+			try {
+				re = std::regex(pats[0], std::regex::ECMAScript | std::regex::optimize);
+			} catch (const std::regex_error &e) {
+				set_err("%s: invalid regular expression: %s", who, e.what());
+				return GYS_ERR_INVAL;
+			}
+		}
+		return GYS_OK;
+	}
+	bool match(const char *s, size_t len) const
+	{
+		bool hit = false;
+		switch (base) {
+		case GYS_COMP_EQ: hit = len == pats[0].size() && !memcmp(s, pats[0].data(), len); break;
+		case GYS_COMP_SUBSTR: hit = pats[0].size() <= len && memmem(s, len, pats[0].data(), pats[0].size()) != nullptr; break;
+		case GYS_COMP_LIKE: hit = std::regex_search(s, s + len, re); break;
+		default:
+			for (size_t i = 0; i < pats.size() && !hit; ++i) hit = pats[i].size() == len && !memcmp(s, pats[i].data(), len);
+			break;
+		}
+		return hit != neg;
+	}
+};
+} // namespace
+
+extern "C" {
+
+// string criterion on the service name, resolved on the host into the service ids the device filter takes (gys_svc_filter.svcids)
 int gys_svc_ids_by_name(gys_ctx *c, int comp, const char *const *patterns, uint32_t npatterns, uint64_t *out_ids, uint32_t cap, uint32_t *nout)
 try {
 	GYS_ENTER_NOFLUSH(c);
-	if (!c || !nout || (!out_ids && cap) || !patterns || !npatterns) return GYS_ERR_INVAL;
-	for (uint32_t i = 0; i < npatterns; ++i)
-		if (!patterns[i]) return GYS_ERR_INVAL;
-	const bool neg = comp == GYS_COMP_NEQ || comp == GYS_COMP_NOTSUBSTR || comp == GYS_COMP_NOTLIKE || comp == GYS_COMP_NOTIN;
-	const int base = comp == GYS_COMP_NEQ ? GYS_COMP_EQ : comp == GYS_COMP_NOTSUBSTR ? GYS_COMP_SUBSTR : comp == GYS_COMP_NOTLIKE ? GYS_COMP_LIKE :
-			 comp == GYS_COMP_NOTIN ? GYS_COMP_IN : comp;
-	if (base != GYS_COMP_EQ && base != GYS_COMP_SUBSTR && base != GYS_COMP_LIKE && base != GYS_COMP_IN) {
-		set_err("gys_svc_ids_by_name: comparator %d is not a string comparator", comp);
-		return GYS_ERR_INVAL;
-	}
-	std::regex re;
-	if (base == GYS_COMP_LIKE) {
-		try {
-			re = std::regex(patterns[0], std::regex::ECMAScript | std::regex::optimize);
-		} catch (const std::regex_error &e) {
-			set_err("gys_svc_ids_by_name: invalid regular expression: %s", e.what());
-			return GYS_ERR_INVAL;
-		}
-	}
-	const size_t plen0 = strlen(patterns[0]);
+	if (!c || !nout || (!out_ids && cap)) return GYS_ERR_INVAL;
+	StrCriterion sc;
+	const int rc = sc.init(comp, patterns, npatterns, "gys_svc_ids_by_name");
+	if (rc) return rc;
 	uint32_t n = 0;
 	for (uint32_t slot = 0; slot < c->nsvc; ++slot) {
 		const char *name = c->svc_comm[slot].data();
-		const size_t len = strnlen(name, 16);
-		bool hit = false;
-		switch (base) {
-		case GYS_COMP_EQ: hit = len == plen0 && !memcmp(name, patterns[0], len); break;
-		case GYS_COMP_SUBSTR: hit = plen0 <= len && memmem(name, len, patterns[0], plen0) != nullptr; break;
-		case GYS_COMP_LIKE: hit = std::regex_search(name, name + len, re); break;
-		default:
-			for (uint32_t i = 0; i < npatterns && !hit; ++i) hit = strlen(patterns[i]) == len && !memcmp(name, patterns[i], len);
-			break;
-		}
-		if (hit != neg) {
+		if (sc.match(name, strnlen(name, 16))) {
 			if (n < cap) out_ids[n] = c->svc_gid_h[slot];
 			++n;
 		}
@@ -474,6 +498,30 @@ try {
 	*nout = n;
 	if (n > cap) {
 		set_err("gys_svc_ids_by_name: %u services match, room for %u", n, cap);
+		return GYS_ERR_NOMEM;
+	}
+	return GYS_OK;
+} GYS_CATCH_ALL
+
+// ... and on the host name (gys_set_host_name; PARTHA_INFO::hostname_, the "host" column): the machine ids for gys_svc_filter.machine_ids
+int gys_machine_ids_by_hostname(gys_ctx *c, int comp, const char *const *patterns, uint32_t npatterns, uint8_t *out_ids16, uint32_t cap, uint32_t *nout)
+try {
+	GYS_ENTER_NOFLUSH(c);
+	if (!c || !nout || (!out_ids16 && cap)) return GYS_ERR_INVAL;
+	StrCriterion sc;
+	const int rc = sc.init(comp, patterns, npatterns, "gys_machine_ids_by_hostname");
+	if (rc) return rc;
+	uint32_t n = 0;
+	for (size_t h = 0; h < c->hosts.size(); ++h) {
+		const std::string &name = c->host_names[h];
+		if (sc.match(name.data(), name.size())) {
+			if (n < cap) memcpy(out_ids16 + (size_t)n * 16, &c->hosts[h], 16);
+			++n;
+		}
+	}
+	*nout = n;
+	if (n > cap) {
+		set_err("gys_machine_ids_by_hostname: %u hosts match, room for %u", n, cap);
 		return GYS_ERR_NOMEM;
 	}
 	return GYS_OK;

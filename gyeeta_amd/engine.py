@@ -417,6 +417,16 @@ class SketchEngine:
         capi.check(self.L.gys_svc_ids_by_name(self.h, capi.COMP[comp], arr, len(pats), out.ctypes.data_as(capi.u64p), cap, C.byref(n)))
         return out[:n.value].copy()
 
+    def machine_ids_by_hostname(self, comp, patterns):
+        """gys_machine_ids_by_hostname: machine ids (16 bytes each) of the registered hosts whose name matches (for machine_ids=...)"""
+        pats = [patterns] if isinstance(patterns, (str, bytes)) else list(patterns)
+        arr = (C.c_char_p * len(pats))(*[p if isinstance(p, bytes) else p.encode() for p in pats])
+        cap = 1 << 16
+        out = np.zeros(cap * 16, dtype=np.uint8)
+        n = C.c_uint32()
+        capi.check(self.L.gys_machine_ids_by_hostname(self.h, capi.COMP[comp], arr, len(pats), out.ctypes.data_as(capi.u8p), cap, C.byref(n)))
+        return [out[16 * i:16 * i + 16].tobytes() for i in range(n.value)]
+
     def svcstate_scan(self, terms=None, group_oper=(), top_oper="and", sort_col=None, sort_desc=True, maxrecs=1000, machine_ids=None, svcids=None,
                       clusters=None):
         """gys_query_svcstate_scan -> (slots, host slots, records as a numpy array of wire.LISTENER_STATE_NOTIFY, number matched)"""

@@ -505,6 +505,9 @@ int gys_query_svcstate_scan(gys_ctx *ctx, const gys_svc_filter *filter, int sort
  * the names never leave the host.  *nout = services that match; GYS_ERR_NOMEM when that exceeds cap (the first cap are written). */
 enum { GYS_COMP_SUBSTR = 8, GYS_COMP_NOTSUBSTR = 9, GYS_COMP_LIKE = 10, GYS_COMP_NOTLIKE = 11 };
 int gys_svc_ids_by_name(gys_ctx *ctx, int comp, const char *const *patterns, uint32_t npatterns, uint64_t *out_ids, uint32_t cap, uint32_t *nout);
+/* ... and on the HOST name (gys_set_host_name: PARTHA_INFO::hostname_, the "host" column): the machine ids of the registered hosts whose
+ * name matches, 16 bytes each, for gys_svc_filter.machine_ids (a host without a name has the empty name). */
+int gys_machine_ids_by_hostname(gys_ctx *ctx, int comp, const char *const *patterns, uint32_t npatterns, uint8_t *out_ids16, uint32_t cap, uint32_t *nout);
 /* the same as the reference's multi-host JSON: {"madid":..,"svcstate":[{"parid","host","madid","cluster", then the json_db_svcstate_arr
  * columns}, ...]} (column list of a multi-host query: QUERY_OPTIONS::get_all_column_list common/gy_query_common.h:418-437) */
 int gys_json_svcstate_multihost(gys_ctx *ctx, const gys_svc_filter *filter, int sort_col, int sort_desc, uint32_t maxrecs,

@@ -495,4 +495,16 @@ def test_service_name_criterion_resolves_to_service_ids():
     assert nm == len(slots) > 0 and set(int(g) for g in recs["glob_id"]) <= set(int(x) for x in ids)
     _, _, recs_all, nall = eng.svcstate_scan(terms=[("qps5s", ">=", 0)], maxrecs=1000)
     assert set(int(g) for g in recs["glob_id"]) == {int(g) for g in recs_all["glob_id"] if "post" in gid_name[int(g)]}
+    # the same comparators on the host name -> machine ids for the filter
+    hn = {0: "db-east-1", 1: "web-east-2", 2: "db-west-1"}
+    for h, name in hn.items():
+        eng.set_host_name(wire.machine_id(h), name)
+    for comp, pats, pred in (("substr", ["db-"], lambda n: "db-" in n), ("like", ["east-[0-9]$"], lambda n: re.search("east-[0-9]$", n) is not None),
+                             ("!=", ["web-east-2"], lambda n: n != "web-east-2"), ("in", ["db-west-1", "x"], lambda n: n in ("db-west-1", "x")),
+                             ("notsubstr", ["e"], lambda n: "e" not in n)):
+        got = set(eng.machine_ids_by_hostname(comp, pats))
+        assert got == {bytes(wire.machine_id(h)) for h, n in hn.items() if pred(n)}, (comp, pats)
+    mids = eng.machine_ids_by_hostname("substr", "db-")
+    _, hosts_sel, _, nsel = eng.svcstate_scan(maxrecs=1000, machine_ids=mids)
+    assert nsel > 0 and set(int(x) for x in hosts_sel) == {0, 2}
     eng.close()
