@@ -487,14 +487,46 @@ try {
 	StrCriterion sc;
 	const int rc = sc.init(comp, patterns, npatterns, "gys_svc_ids_by_name");
 	if (rc) return rc;
+	// the registry holds up to 10^7 names and a regular-expression search costs ~1 us: slot ranges on the host's cores, results in slot order
+	const uint32_t nsvc = c->nsvc;
+	const uint32_t nthr = nsvc < (1u << 16) ? 1u : std::min<uint32_t>(32u, std::max(1u, std::thread::hardware_concurrency()));
+	std::vector<std::vector<uint32_t>> hits(nthr);
+	auto scan = [&](uint32_t t) {
+		const uint32_t lo = (uint32_t)((uint64_t)nsvc * t / nthr), hi = (uint32_t)((uint64_t)nsvc * (t + 1) / nthr);
+		for (uint32_t slot = lo; slot < hi; ++slot) {
+			const char *name = c->svc_comm[slot].data();
+			if (sc.match(name, strnlen(name, 16))) hits[t].push_back(slot);
+		}
+	};
+	if (nthr == 1) {
+		scan(0);
+	} else {
+		std::vector<std::thread> th;
+		std::atomic<bool> failed{false};
+		try {
+			for (uint32_t t = 0; t < nthr; ++t)
+				th.emplace_back([&, t] {
+					try {
+						scan(t);
+					} catch (...) {
+						failed = true;
+					}
+				});
+		} catch (...) { // (a thread that could not be started: the ones that run are joined below before anything unwinds)
+			failed = true;
+		}
+		for (auto &x : th) x.join();
+		if (failed) {
+			set_err("gys_svc_ids_by_name: could not scan the registry (threads / memory)");
+			return GYS_ERR_NOMEM;
+		}
+	}
 	uint32_t n = 0;
-	for (uint32_t slot = 0; slot < c->nsvc; ++slot) {
-		const char *name = c->svc_comm[slot].data();
-		if (sc.match(name, strnlen(name, 16))) {
+	for (uint32_t t = 0; t < nthr; ++t)
+		for (uint32_t slot : hits[t]) {
 			if (n < cap) out_ids[n] = c->svc_gid_h[slot];
 			++n;
 		}
-	}
 	*nout = n;
 	if (n > cap) {
 		set_err("gys_svc_ids_by_name: %u services match, room for %u", n, cap);
