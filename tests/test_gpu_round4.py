@@ -319,6 +319,10 @@ def test_svcstate_scan_at_scale_top_1000_of_many_services():
     prof = eng.profile_get()
     assert nm == int(m.sum()) and gs.tolist() == slot[m][order].tolist()
     print("svc_filter: %d services, %d matched, top-1000 in %.3f ms (kernels)" % (len(rec), nm, prof["svc_filter"][0]))
+    # a name criterion over the whole registry (slot ranges on the host's cores from 2^16 services on): ids in registration order
+    ids = eng.svc_ids_by_name("like", "^sv.$")
+    assert len(ids) == nh * sp and (ids == rec["glob_id"]).all()
+    assert len(eng.svc_ids_by_name("substr", "nginx")) == 0
     eng.close()
 
 
