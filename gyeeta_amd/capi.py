@@ -207,6 +207,7 @@ SIGNATURES = {
                                               C.POINTER(C.c_size_t)]),
     "gys_query_svcstate_aggr": (C.c_int, [vp, C.POINTER(SvcFilter), C.c_int, u8p, C.c_uint32, C.POINTER(SvcAggrRow), C.c_uint32, u32p]),
     "gys_svc_aggr_value": (C.c_int, [C.POINTER(SvcAggrRow), C.c_uint32, C.c_int, f64p]),
+    "gys_query_svcstate_percentiles": (C.c_int, [vp, C.POINTER(SvcFilter), C.c_int, f64p, C.c_uint32, i64p, u64p]),
     "gys_svc_ids_by_name": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, u64p, C.c_uint32, u32p]),
     "gys_machine_ids_by_hostname": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, u8p, C.c_uint32, u32p]),
     "gys_json_svcsumm_multihost": (C.c_int, [vp, C.POINTER(SvcFilter), C.c_int, C.c_int, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t,

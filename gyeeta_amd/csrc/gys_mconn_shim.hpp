@@ -215,6 +215,12 @@ public:
 			return gys_json_svcsumm_multihost(ctx_, filter, sort_col, sort_desc ? 1 : 0, maxrecs, madid, timestr, b, n, need);
 		});
 	}
+	// AOPER_PERCENTILE of one column over the matching listeners (discrete percentiles, exact)
+	bool aggr_listener_state_percentiles(const gys_svc_filter *filter, int col, const double *pcts, uint32_t npcts, int64_t *out, uint64_t *nmatched) noexcept
+	{
+		std::unique_lock<std::shared_mutex> g(mu_);
+		return gys_query_svcstate_percentiles(ctx_, filter, col, pcts, npcts, out, nmatched) == GYS_OK;
+	}
 	// a string criterion on the service name ({ svcstate.name like 'post' }: CRITERION_ONE::match_str_criterian common/gy_query_criteria.h:1335-1383)
 	// resolved into the service ids a filter's `svcids` takes; comp = GYS_COMP_EQ / NEQ / SUBSTR / NOTSUBSTR / LIKE / NOTLIKE / IN / NOTIN
 	bool svc_ids_by_name(int comp, const std::vector<std::string> &patterns, std::vector<uint64_t> &ids) noexcept
@@ -262,6 +268,7 @@ public:
 	bool aggr_listener_state(const gys_svc_filter *filter, int group_by, const uint8_t *cols, uint32_t ncols, gys_svc_aggr_row *out, uint32_t maxrows,
 				 uint32_t *nrows) noexcept
 	{
+		std::unique_lock<std::shared_mutex> g(mu_); // (a query: not concurrent with ingest calls)
 		return gys_query_svcstate_aggr(ctx_, filter, group_by, cols, ncols, out, maxrows, nrows) == GYS_OK;
 	}
 	// MCONN_HANDLER::web_curr_top_listeners (server/gy_mnodehandle.cc:2706-3190): machine_id = one partha's four top-10 queues,

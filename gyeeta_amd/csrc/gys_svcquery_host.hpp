@@ -559,6 +559,71 @@ try {
 	return GYS_OK;
 } GYS_CATCH_ALL
 
+// AOPER_PERCENTILE over the records that pass the filter: the discrete percentile of one column -- the smallest value with at least
+// pcts[i] (0 < p <= 1) of the matching records at or below it -- by the exact radix selection of the sorted scan (the candidate keys carry
+// the column in their upper half; nothing is gathered or sorted)
+int gys_query_svcstate_percentiles(gys_ctx *c, const gys_svc_filter *f, int col, const double *pcts, uint32_t npcts, int64_t *out, uint64_t *nmatched)
+try {
+	GYS_ENTER(c);
+	if (!c || !pcts || !out || !npcts || col < 0 || col >= (int)GYS_SVC_NCOLS) return GYS_ERR_INVAL;
+	for (uint32_t i = 0; i < npcts; ++i)
+		if (!(pcts[i] > 0.0 && pcts[i] <= 1.0)) {
+			set_err("gys_query_svcstate_percentiles: percentile %u is not in (0, 1]", i);
+			return GYS_ERR_INVAL;
+		}
+	if (nmatched) *nmatched = 0;
+	for (uint32_t i = 0; i < npcts; ++i) out[i] = 0;
+	if (!c->nsvc) return GYS_OK;
+	int rc;
+	if ((rc = q_grow(&c->q_cand_key, &c->q_cand_cap, c->nsvc)) != GYS_OK) return rc;
+	if ((rc = q_grow(&c->q_cand_slot, &c->q_slot_cap, c->nsvc)) != GYS_OK) return rc;
+	if (!c->q_misc) HIPCHK(hipMalloc((void **)&c->q_misc, QM_WORDS * 4));
+	HIPCHK(hipMemsetAsync(c->q_misc, 0, QM_WORDS * 4, c->stream));
+	ProfScope ps(c, "svc_filter");
+	SvcFilterP p{};
+	if ((rc = q_fill_filter(c, f, p)) != GYS_OK) return rc;
+	p.sort_col = col;
+	p.sort_desc = 1u;
+	p.cand_key = c->q_cand_key;
+	p.cand_slot = c->q_cand_slot;
+	p.cursor = c->q_misc + QM_CURSOR;
+	const uint32_t per_wg = GYS_SVCQ_THREADS * GYS_SVCQ_PER_THREAD;
+	hipLaunchKernelGGL(k_svc_filter, dim3(std::max(1u, (p.nitems + per_wg - 1) / per_wg)), dim3(GYS_SVCQ_THREADS), 0, c->stream, p);
+	uint32_t ncand = 0;
+	HIPCHK(hipMemcpyAsync(&ncand, c->q_misc + QM_CURSOR, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (nmatched) *nmatched = ncand;
+	if (!ncand) return GYS_OK;
+	SvcSelectP sp{};
+	sp.cand_key = c->q_cand_key;
+	sp.ncand = c->q_misc + QM_CURSOR;
+	sp.hist = c->q_misc + QM_HIST;
+	sp.prefix = (unsigned long long *)(c->q_misc + QM_PREFIX);
+	sp.want = c->q_misc + QM_WANT;
+	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)ncand + 256u * 16u - 1) / (256u * 16u), (uint64_t)c->ncu * 4);
+	static const uint32_t shifts[GYS_SVCQ_ROUNDS] = {53, 42, 31, 20, 9, 0}, widths[GYS_SVCQ_ROUNDS] = {11, 11, 11, 11, 11, 9};
+	std::vector<unsigned long long> keys(npcts);
+	for (uint32_t i = 0; i < npcts; ++i) {
+		// rank r = ceil(p N) from the bottom (1-based) = the (N - r + 1)-th largest key
+		uint64_t r = (uint64_t)std::ceil(pcts[i] * (double)ncand);
+		r = std::min<uint64_t>(std::max<uint64_t>(r, 1), ncand);
+		const uint32_t k = (uint32_t)(ncand - r + 1);
+		HIPCHK(hipMemsetAsync(c->q_misc + QM_PREFIX, 0, 8, c->stream));
+		HIPCHK(hipMemcpyAsync(c->q_misc + QM_WANT, &k, 4, hipMemcpyHostToDevice, c->stream));
+		for (uint32_t rd = 0; rd < GYS_SVCQ_ROUNDS; ++rd) {
+			sp.shift = shifts[rd];
+			sp.bits = widths[rd];
+			hipLaunchKernelGGL(k_svc_hist, dim3(std::max(1u, grid)), dim3(256), 0, c->stream, sp);
+			hipLaunchKernelGGL(k_svc_pick, dim3(1), dim3(256), 0, c->stream, sp);
+		}
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(&keys[i], c->q_misc + QM_PREFIX, 8, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream)); // (k lives on this stack frame until its copy has been made)
+	}
+	for (uint32_t i = 0; i < npcts; ++i) out[i] = (int64_t)(int32_t)((uint32_t)(keys[i] >> 32) ^ 0x80000000u);
+	return GYS_OK;
+} GYS_CATCH_ALL
+
 int gys_svc_aggr_value(const gys_svc_aggr_row *row, uint32_t col_index, int oper, double *out)
 {
 	if (!row || !out || col_index >= GYS_SVC_MAX_AGGR || (oper != GYS_AOPER_COUNT && col_index >= row->ncols)) return GYS_ERR_INVAL;
@@ -570,7 +635,7 @@ int gys_svc_aggr_value(const gys_svc_aggr_row *row, uint32_t col_index, int oper
 	case GYS_AOPER_COUNT: *out = (double)row->count; return GYS_OK;
 	case GYS_AOPER_BOOL_OR: *out = row->max[col_index] != 0 || row->min[col_index] != 0 ? 1.0 : 0.0; return GYS_OK;   // some value is non-zero
 	case GYS_AOPER_BOOL_AND: *out = (row->min[col_index] > 0 || row->max[col_index] < 0) ? 1.0 : 0.0; return GYS_OK; // no value is zero (exact for the >= 0 columns)
-	default: return GYS_ERR_INVAL; // percentile / first / last: not order-free reductions of one pass (not built)
+	default: return GYS_ERR_INVAL; // percentile: gys_query_svcstate_percentiles; first / last: no meaning on one snapshot (not built)
 	}
 }
 

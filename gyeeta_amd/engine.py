@@ -407,6 +407,16 @@ class SketchEngine:
             f.nclusters = len(clusters)
         return f, (arr, sv, mids, ids, cl)
 
+    def svcstate_percentiles(self, col, pcts, terms=None, group_oper=(), top_oper="and", machine_ids=None, svcids=None, clusters=None):
+        """gys_query_svcstate_percentiles -> (values (int64 array), number matched)"""
+        f, keep = self._svc_filter(terms, group_oper, top_oper, machine_ids, svcids, clusters)
+        p = np.ascontiguousarray(pcts, dtype=np.float64)
+        out = np.zeros(len(p), dtype=np.int64)
+        nm = C.c_uint64()
+        capi.check(self.L.gys_query_svcstate_percentiles(self.h, C.byref(f), capi.SVC_COLS.index(col), p.ctypes.data_as(capi.f64p), len(p),
+                                                          out.ctypes.data_as(capi.i64p), C.byref(nm)))
+        return out, nm.value
+
     def svc_ids_by_name(self, comp, patterns):
         """gys_svc_ids_by_name: glob_ids of the registered services whose process name matches the string criterion (for svcids=...)"""
         pats = [patterns] if isinstance(patterns, (str, bytes)) else list(patterns)

@@ -515,8 +515,8 @@ int gys_json_svcstate_multihost(gys_ctx *ctx, const gys_svc_filter *filter, int 
 /* AGGR_OPER_E (common/gy_json_field_maps.h:114-129) over the records that pass the filter, grouped by nothing (group_by 0: one row,
  * group 0), by host (1: group = host slot) or by cluster (2: group = cluster index in registration order).  One row per group that has a
  * matching record, in group order; every row carries count and, per requested column, the exact 64-bit sum, min and max, from which
- * gys_svc_aggr_value derives the operator: sum, avg (sum / count), max, min, count, bool_or, bool_and.  (percentile / first / last are
- * not one-pass order-free reductions and are not built.)  *nrows = rows there are (may exceed maxrows; only maxrows are written). */
+ * gys_svc_aggr_value derives the operator: sum, avg (sum / count), max, min, count, bool_or, bool_and.  (percentile: see
+ * gys_query_svcstate_percentiles; first / last have no meaning on one snapshot of the live table and are not built.)  *nrows = rows there are (may exceed maxrows; only maxrows are written). */
 enum { GYS_AOPER_SUM = 1, GYS_AOPER_AVG, GYS_AOPER_MAX, GYS_AOPER_MIN, GYS_AOPER_COUNT, GYS_AOPER_BOOL_OR = 9, GYS_AOPER_BOOL_AND = 10 };
 typedef struct {
 	uint32_t group, ncols;
@@ -526,6 +526,11 @@ typedef struct {
 int gys_query_svcstate_aggr(gys_ctx *ctx, const gys_svc_filter *filter, int group_by, const uint8_t *cols, uint32_t ncols, gys_svc_aggr_row *out,
 			    uint32_t maxrows, uint32_t *nrows);
 int gys_svc_aggr_value(const gys_svc_aggr_row *row, uint32_t col_index, int oper, double *out);
+/* AOPER_PERCENTILE (AGGR_OPER_E common/gy_json_field_maps.h:114-129) of ONE column over all records that pass the filter: out[i] = the
+ * discrete percentile pcts[i] (0 < p <= 1: the smallest value with at least that fraction of the matching records at or below it, SQL
+ * percentile_disc), exact -- the k-th key of the sorted scan found by the same radix selection, nothing gathered.  *nmatched = records
+ * that matched (0: out[] is zero).  For a percentile per host or cluster, name the group in the filter (machine_ids / clusters). */
+int gys_query_svcstate_percentiles(gys_ctx *ctx, const gys_svc_filter *filter, int col, const double *pcts, uint32_t npcts, int64_t *out, uint64_t *nmatched);
 /* The multi-host form of web_curr_listener_summ (server/gy_mnodehandle.cc:1628-1690: the walk over partha_tbl_, SvcSummFields::filter_match per
  * host, hosts whose listener state is older than 10 s skipped): {"madid":..,"summstats":[{"parid","host","madid","cluster", then the
  * json_db_svcsumm_arr columns}, ...]} for every host that reported listener states in the last finished window and passes the filter.  The

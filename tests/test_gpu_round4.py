@@ -148,6 +148,18 @@ def test_svcstate_filter_sort_topk_and_aggregation_equal_numpy():
             m &= np.isin(host % 3, [int(c_[2:]) for c_ in case["clusters"] if c_.startswith("cl")])
         if case.get("svcids"):
             m &= np.isin(rec["glob_id"], np.array(case["svcids"], dtype=np.uint64))
+        # AOPER_PERCENTILE: the discrete percentile of a column over the matching records (percentile_disc: the ceil(p N)-th smallest)
+        pcts = [0.01, 0.25, 0.5, 0.95, 0.99, 1.0, 1e-9]
+        for pcol in ("qps5s", "kbin15s", "vmdelus", "state"):
+            got, nm_p = eng.svcstate_percentiles(pcol, pcts, case.get("terms"), case.get("group_oper", ()), case.get("top_oper", "and"),
+                                                  case.get("machine_ids"), case.get("svcids"), case.get("clusters"))
+            assert nm_p == int(m.sum()), (ci, pcol)
+            if nm_p:
+                sv = np.sort(col_values(rec[m], pcol).astype(np.int64))
+                want_p = [int(sv[min(max(int(np.ceil(p_ * nm_p)), 1), nm_p) - 1]) for p_ in pcts]
+                assert got.tolist() == want_p, (ci, pcol, got.tolist(), want_p)
+            else:
+                assert not got.any()
         for sort_col, desc in ((None, True), ("qps5s", True), ("p95resp5s", False), ("kbin15s", True), ("vmdelus", False)):
             if sort_col is None:
                 order = np.argsort(slot[m], kind="stable")
