@@ -26,6 +26,8 @@ int gyo_engine_register(gyo_engine *e, uint32_t host_slot, uint64_t glob_id, uin
 void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs);
 const gyo_hist_serial *gyo_engine_hist(const gyo_engine *e);
 const uint8_t *gyo_engine_hll(const gyo_engine *e);
+const uint16_t *gyo_engine_bitmap(const gyo_engine *e);
+void gyo_engine_window_clear(gyo_engine *e, int clear_hist);
 const gyo_td_buffered *gyo_engine_td(const gyo_engine *e, uint32_t slot);
 const uint64_t *gyo_engine_counters(const gyo_engine *e);
 }
@@ -65,6 +67,7 @@ int main(int argc, char **argv)
 	uint32_t nsvc = L[0] + L[1];
 
 	gyo_engine *orc = gyo_engine_new(nsvc + 8, 1);
+	gyo_engine *orcw = gyo_engine_new(nsvc + 8, 0); // the same stream with the records cleared at every window roll: what hist_win / CONN_BITMAP must show
 	std::vector<HostDesc> hdesc(NH);
 	std::vector<uint64_t> htbl;
 	std::vector<uint32_t> hlst, svc_host(nsvc);
@@ -78,6 +81,7 @@ int main(int argc, char **argv)
 			const uint32_t netns = 0xF0000000u + 4u * h;
 			const uint16_t port = (uint16_t)(1024 + s);
 			gyo_engine_register(orc, h, 0x100000ull * (h + 1) + s, netns, port);
+			gyo_engine_register(orcw, h, 0x100000ull * (h + 1) + s, netns, port);
 			const uint64_t key48 = ((uint64_t)netns << 16) | port;
 			uint32_t at = host_tbl_slot(host_tbl_hash(key48), d.mask);
 			while (htbl[d.tbl_off + at] != GYS_HOST_TBL_EMPTY) at = (at + 1) & d.mask;
@@ -126,8 +130,18 @@ int main(int argc, char **argv)
 	// k_run_append)
 	const uint32_t per_key[] = {400, pcap - 400u + 20u, 700, 1500, 21000, 3, 20000, 1500, 1600};
 	const uint32_t NB = sizeof(per_key) / sizeof(per_key[0]);
-	uint32_t stamp = 0;
+	uint32_t stamp = 0, epoch = 1;
 	for (uint32_t batch = 0; batch < NB; ++batch) {
+		// window rolls (round 4): before batches 1, 3, 6 and 8 a window closes -- the keys' buffers then hold words of the window before (not
+		// yet folded: the fold is lazy; 400 words before batch 1 = a k_digest_bins merge, 700 before batch 3 = k_digest_merge<4096>, 3 before
+		// batch 6 = the large-key path and its fallback), and the merge of the next batch must put them into the all-time record only
+		// while the new window's words also go to hist_win / CONN_BITMAP (classes 1 and 2 of the merges' buffered-word passes)
+		if (batch == 1 || batch == 3 || batch == 6 || batch == 8) {
+			++epoch;
+			gyo_engine_window_clear(orc, 0);
+			gyo_engine_window_clear(orcw, 1);
+			std::fill(hll32.begin(), hll32.end(), 0u);
+		}
 		std::vector<uint8_t> ev;
 		std::vector<gys_resp_seg> segs;
 		std::vector<uint32_t> seg_host;
@@ -163,6 +177,7 @@ int main(int argc, char **argv)
 		std::vector<uint64_t> ev64(n * 3);
 		memcpy(ev64.data(), ev.data(), n * 24);
 		gyo_engine_resp_batch(orc, ev.data(), n, seg_host.data(), seg_first.data(), NH);
+		gyo_engine_resp_batch(orcw, ev.data(), n, seg_host.data(), seg_first.data(), NH);
 
 		std::fill(counts.begin(), counts.end(), 0u);
 		FinP fin{};
@@ -170,7 +185,7 @@ int main(int argc, char **argv)
 		fin.td_meta = meta.data();
 		fin.nsvc = nsvc;
 		fin.pcap = pcap;
-		fin.epoch = 1;
+		fin.epoch = epoch;
 		fin.resp_win = resp_win.data();
 		fin.list[FIN_CLASS0] = list0.data();
 		fin.list[FIN_CLASS1] = list1.data();
@@ -364,11 +379,29 @@ int main(int argc, char **argv)
 				CHECK(hist_all[s].stats[b].count == oh[(size_t)s * 16 + b].count && hist_all[s].stats[b].sum == oh[(size_t)s * 16 + b].sum, "batch %u key %u all-time bucket %d: {%llu, %lld} want {%llu, %lld}",
 				      batch, s, b, (unsigned long long)hist_all[s].stats[b].count, (long long)hist_all[s].stats[b].sum, (unsigned long long)oh[(size_t)s * 16 + b].count, (long long)oh[(size_t)s * 16 + b].sum);
 			CHECK(hist_all[s].total_count == oh[(size_t)s * 16 + 15].count && hist_all[s].max_val_seen == oh[(size_t)s * 16 + 15].sum, "batch %u key %u all-time total / max", batch, s);
+			// the window's record and CONN_BITMAP rows of a key that was just merged (its buffer is drained: everything is folded); a key
+			// whose records belong to an earlier window shows an empty window
+			{
+				const gyo_hist_serial *ow = gyo_engine_hist(orcw) + (size_t)s * 16;
+				const uint16_t *ob = gyo_engine_bitmap(orcw) + (size_t)s * 32;
+				const bool cur = meta[s].hw_epoch == epoch;
+				for (int b = 0; b < 15; ++b) {
+					const unsigned long long gc = cur ? hist_win[s].stats[b].count : 0ull;
+					const long long gs = cur ? hist_win[s].stats[b].sum : 0ll;
+					CHECK(gc == ow[b].count && gs == ow[b].sum, "batch %u key %u window bucket %d: {%llu, %lld} want {%llu, %lld}", batch, s, b, gc, gs, (unsigned long long)ow[b].count, (long long)ow[b].sum);
+				}
+				CHECK((cur ? hist_win[s].total_count : 0ull) == ow[15].count && (cur ? hist_win[s].max_val_seen : INT64_MIN) == ow[15].sum, "batch %u key %u window total / max", batch, s);
+				for (int g = 0; g < 16; ++g) {
+					const uint32_t want = (uint32_t)ob[2 * g] | ((uint32_t)ob[2 * g + 1] << 16);
+					CHECK((cur ? bitmap[(size_t)s * 16 + g] : 0u) == want, "batch %u key %u CONN_BITMAP rows %d, %d: %08x want %08x", batch, s, 2 * g, 2 * g + 1, cur ? bitmap[(size_t)s * 16 + g] : 0u, want);
+				}
+			}
 			const gyo_td_buffered *ot = gyo_engine_td(orc, s);
 			CHECK(minmax[s].x == ot->d.vmin && minmax[s].y == ot->d.vmax, "batch %u key %u min/max {%d, %d} want {%d, %d}", batch, s, minmax[s].x, minmax[s].y, ot->d.vmin, ot->d.vmax);
 		}
 	}
 	gyo_engine_free(orc);
+	gyo_engine_free(orcw);
 	if (fails) {
 		printf("%d checks failed\n", fails);
 		return 1;
