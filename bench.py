@@ -985,6 +985,9 @@ def main():
                          "algorithmic_bytes_per_step": alg_bytes,
                          "note": "frac = 24 B x events / WHOLE step (all kernels of the window); per-kernel figures under `kernels`",
                          "kernel": dom[0], "kernel_avg_ms": dom[1], "kernel_frac": dom_ent.get("frac"),
+                         # SURVEY 8(d)'s own figure for the dominant kernel: 24 B x events / its average launch time (kernel_frac counts the
+                         # 4-byte staged word the event kernel also writes per event: 28 B)
+                         "kernel_frac_24B": (alg_bytes / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom[0] == "resp_host" and dom[1] > 0 else None,
                          "traffic": dom_ent.get("traffic"),
                          "merges_per_step": merges_step, "merge_values_per_step": mvals_step,
                          "kernels": kernels},
