@@ -25,7 +25,8 @@ class Config(C.Structure):
 
 
 class ListenerInfo(C.Structure):
-    _fields_ = [("glob_id", C.c_uint64), ("netns", C.c_uint32), ("port", C.c_uint16), ("reserved", C.c_uint16), ("comm", C.c_char * 16)]
+    _fields_ = [("glob_id", C.c_uint64), ("netns", C.c_uint32), ("port", C.c_uint16), ("is_any_ip", C.c_uint8), ("addr_is_v6", C.c_uint8),
+                ("comm", C.c_char * 16), ("addr", C.c_uint8 * 16)]
 
 
 class RespSeg(C.Structure):
@@ -155,6 +156,8 @@ SIGNATURES = {
     "gys_register_listeners": (C.c_int, [vp, mid, C.POINTER(ListenerInfo), C.c_uint32, u32p]),
     "gys_ingest_resp_events": (C.c_int, [vp, mid, vp, C.c_uint32]),
     "gys_ingest_resp_events_dev": (C.c_int, [vp, C.POINTER(RespSeg), C.c_uint32, vp, C.c_uint64]),
+    "gys_ingest_resp_events_v6": (C.c_int, [vp, mid, C.c_char_p, C.c_uint32]),
+    "gys_ingest_resp_events_v6_dev": (C.c_int, [vp, C.POINTER(RespSeg), C.c_uint32, vp, C.c_uint64]),
     "gys_ingest_tcp_conn": (C.c_int, [vp, mid, vp, C.c_uint32, vp]),
     "gys_ingest_tcp_conn_dev": (C.c_int, [vp, vp, vp, C.c_uint32]),
     "gys_ingest_listener_state": (C.c_int, [vp, mid, vp, C.c_uint32, vp]),

@@ -420,6 +420,54 @@ __host__ __device__ __forceinline__ uint32_t pair_words(uint32_t cip32, const ui
 	return n;
 }
 
+// ------------------------------------------------------------------------------------------------ listener addresses
+// GY_IP_ADDR::set_ip(unsigned __int128) (common/gy_common_inc.h:10686-10692) zeroes ip32_be_ and then calls get_ipv6_type_flags
+// (:11040-11129), which stores the IPv4 address an IPv6 address EMBEDS into embedded_ipv4_ -- the same storage as ip32_be_ (the union at
+// :10497-10500).  An address of 2002::/16 (6to4: bytes 2..5), ::ffff:a.b.c.d (mapped: bytes 12..15) or 64:ff9b::/32 (NAT64: bytes 12..15)
+// therefore ends with ip32_be_ = the embedded address, hashes as those 4 bytes (get_as_inaddr :10950-10959) and compares equal to that
+// IPv4 address (operator== :10629-10636).  a = the 16 address bytes as four words loaded in memory order.  Returns that ip32_be_ (0: none).
+__host__ __device__ __forceinline__ uint32_t ip6_embedded_v4(const uint32_t (&a)[4])
+{
+	if ((a[0] | a[1] | a[2] | a[3]) == 0u) return 0u;                    // :: (IPv6_ANY)
+	if ((a[0] | a[1] | a[2]) == 0u && a[3] == 0x01000000u) return 0u;    // ::1
+	if ((a[0] & 0xF0u) == 0x20u)                                         // 2000::/4: only 2002::/16 carries an address
+		return (a[0] & 0xFFFFu) == 0x0220u ? ((a[0] >> 16) | (a[1] << 16)) : 0u;
+	if ((a[0] | a[1]) == 0u && a[2] == 0xFFFF0000u) return a[3];         // ::ffff:a.b.c.d
+	if (a[0] == 0x9BFF6400u) return a[3];                                // 64:ff9b::/32 (the check at :11098 reads the first four bytes only)
+	return 0u;
+}
+
+// one listener of a (netns, port) key that needs more than the key to be told apart: bound to an address, or not alone on its key.
+// operator==(shared_ptr<TCP_LISTENER>, NS_IP_PORT) (common/gy_socket_stat.h:708-714): inode and port equal (the table key here) and
+// is_any_ip_ || listener address == event address, the addresses compared as GY_IP_ADDR::operator== does (:10629-10636: by ip32_be_ when
+// either side has one, else by the 16 bytes).  The candidates of a key stand in registration order and the first match wins (the
+// reference's lookup_single_elem walks the hash chain from its oldest entry: liburcu's _cds_lfht_add puts a node behind the nodes of
+// equal hash that are already there -- that library is not part of the reference tree, its published behaviour is restated).
+struct ListenerCand {
+	uint32_t ip32;     // ip32_be_ of the listener's address (an IPv4 address, or the one its IPv6 address embeds)
+	uint32_t flags;    // bit 0: is_any_ip_; bit 1: last candidate of the key
+	uint32_t local;    // local index inside the host's (part's) sub-table
+	uint32_t slot;     // service slot
+	uint32_t ip128[4]; // ip128_be_ (zero for an IPv4 address)
+};
+static_assert(sizeof(ListenerCand) == 32, "two 16-byte loads per candidate");
+#define GYS_LOCAL_GROUP 0x8000u      // sub-table entry: the low 15 bits index the host's candidate region instead of naming a local index
+#define GYS_SLOT_GROUP 0x80000000u   // global listener table value: the low 31 bits index the candidate pool
+
+__device__ __forceinline__ bool cand_resolve(const ListenerCand *cand, uint32_t idx, uint32_t e32, const uint32_t (&e128)[4], uint32_t *local, uint32_t *slot)
+{
+	for (;; ++idx) {
+		const uint4 a = ((const uint4 *)cand)[2u * idx], b = ((const uint4 *)cand)[2u * idx + 1u];
+		const bool same = (a.x | e32) ? a.x == e32 : (b.x == e128[0] && b.y == e128[1] && b.z == e128[2] && b.w == e128[3]);
+		if ((a.y & 1u) || same) {
+			*local = a.z;
+			*slot = a.w;
+			return true;
+		}
+		if (a.y & 2u) return false;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ t-digest cluster thresholds
 __constant__ uint64_t c_td_bnd[GYS_TDIGEST_NB + 1] = GYS_TDIGEST_BND_INIT;
 static const uint64_t h_td_bnd[GYS_TDIGEST_NB + 1] = GYS_TDIGEST_BND_INIT;

@@ -101,6 +101,25 @@ struct HostListeners {
 	// hdesc[sub_desc + part]; k_resp_host runs one workgroup per (segment, part), each resolving only its part's events.
 	std::vector<HostListeners> sub;
 	uint32_t sub_desc = 0;
+	// Keys with CANDIDATES (host level; a part's sub-table only holds the entries): a (netns, port) key whose listener is bound to an address, or
+	// that has more than one listener.  chain[key48] = its listeners in registration order; `cands` = the device records of all chains
+	// (a region of the candidate pool, rebuilt when a chain changes); a key that is not in `chain` has ONE any-address listener and its
+	// sub-table entry names the local index directly, as before.
+	struct LAddr {
+		uint32_t ip32 = 0;
+		uint32_t ip128[4] = {0, 0, 0, 0};
+		bool any = true;
+	};
+	struct ChainEnt {
+		uint32_t slot;
+		LAddr a;
+	};
+	std::unordered_map<uint64_t, std::vector<ChainEnt>> chain;
+	std::vector<ListenerCand> cands;
+	std::unordered_map<uint64_t, uint32_t> cand_first; // key48 -> first record of its chain in `cands`
+	uint32_t cand_off = 0, cand_cap = 0;
+	bool dirty = false;                                 // a chain changed: tables and candidate region are rebuilt at the end of the registration call
+	std::unordered_map<uint64_t, uint32_t> okey;        // overflow hosts (no sub-tables): key48 -> slot of the key's one any-address listener
 };
 
 #define GYS_HOST_MAX_LOCAL 2048u // listeners per sub-table the LDS path supports (32 KB LDS table + 48 KB per-key areas + the tile image)
@@ -171,6 +190,8 @@ struct gys_ctx {
 	uint64_t *htbl = nullptr; // pool of per-host sub-tables
 	uint32_t *hlst = nullptr; // pool of per-host local index -> slot lists
 	HostDesc *hdesc = nullptr; // [max_hosts] by host slot, then hdesc_ext_cap descriptors of the parts of many-listener hosts
+	ListenerCand *cand_pool = nullptr; // candidate records of the keys that need the server address (allocated on first use)
+	uint64_t cand_used = 0, cand_cap = 0;
 	uint32_t hdesc_ext_used = 0, hdesc_ext_cap = 0;
 
 	// device state
@@ -569,6 +590,7 @@ int64_t host_tbl_find(const HostListeners &hl, uint64_t key48)
 	return -1;
 }
 
+// `local`: a local index, or GYS_LOCAL_GROUP | first candidate of the key's chain
 void host_tbl_put(HostListeners &hl, uint64_t key48, uint32_t local)
 {
 	const uint32_t mask = (uint32_t)hl.tbl.size() - 1;
@@ -592,7 +614,7 @@ inline uint32_t host_tbl_capacity(size_t n)
 // (re)uploads one sub-table, its slot list and its descriptor hdesc[desc]; regions only ever grow, an outgrown region is abandoned in
 // the pool (geometric growth: the abandoned total stays below the final size, which is what the pool capacity accounts for).
 // Returns false when the pools are exhausted.
-int host_tbl_upload(gys_ctx *c, HostListeners &hl, uint32_t desc, uint32_t part, uint32_t nparts, bool *ok)
+int host_tbl_upload(gys_ctx *c, HostListeners &hl, uint32_t desc, uint32_t part, uint32_t nparts, uint32_t cand_off, bool *ok)
 {
 	*ok = true;
 	if (!hl.on_device || hl.tbl.size() > hl.tbl_cap) {
@@ -609,9 +631,33 @@ int host_tbl_upload(gys_ctx *c, HostListeners &hl, uint32_t desc, uint32_t part,
 	}
 	HIPCHK(hipMemcpyAsync(c->htbl + hl.tbl_off, hl.tbl.data(), hl.tbl.size() * 8, hipMemcpyHostToDevice, c->stream));
 	if (!hl.slots.empty()) HIPCHK(hipMemcpyAsync(c->hlst + hl.lst_off, hl.slots.data(), hl.slots.size() * 4, hipMemcpyHostToDevice, c->stream));
-	const HostDesc hd{hl.tbl_off, (uint32_t)hl.tbl.size() - 1, (uint32_t)hl.slots.size(), hl.lst_off, part, nparts - 1u, {0u, 0u}};
+	const HostDesc hd{hl.tbl_off, (uint32_t)hl.tbl.size() - 1, (uint32_t)hl.slots.size(), hl.lst_off, part, nparts - 1u, cand_off, 0u};
 	HIPCHK(hipMemcpyAsync(c->hdesc + desc, &hd, sizeof(hd), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream)); // hd is a stack object
+	return GYS_OK;
+}
+
+// the host's candidate region: allocated in the pool on first use (the pool itself on the first listener that needs it: a context whose
+// listeners are all alone on their key and any-address never pays for it), re-allocated (twice the size) when outgrown
+int host_cands_upload(gys_ctx *c, HostListeners &hl)
+{
+	if (hl.cands.empty()) return GYS_OK;
+	if (!c->cand_pool) {
+		c->cand_cap = 4ull * c->cfg.max_services + 64ull * c->cfg.max_hosts;
+		HIPCHK(hipMalloc((void **)&c->cand_pool, c->cand_cap * sizeof(ListenerCand)));
+	}
+	if (hl.cands.size() > hl.cand_cap) {
+		const uint64_t want = std::max<uint64_t>(16, next_pow2(hl.cands.size()));
+		if (c->cand_used + want > c->cand_cap) {
+			set_err("listener candidate pool exhausted");
+			return GYS_ERR_NOMEM;
+		}
+		hl.cand_off = (uint32_t)c->cand_used;
+		hl.cand_cap = (uint32_t)want;
+		c->cand_used += want;
+	}
+	HIPCHK(hipMemcpyAsync(c->cand_pool + hl.cand_off, hl.cands.data(), hl.cands.size() * sizeof(ListenerCand), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
 	return GYS_OK;
 }
 
@@ -621,11 +667,11 @@ int host_lst_upload(gys_ctx *c, uint32_t host)
 	if (hl.overflow) return GYS_OK;
 	bool ok = true;
 	if (hl.sub.empty()) {
-		const int rc = host_tbl_upload(c, hl, host, 0, 1, &ok);
+		const int rc = host_tbl_upload(c, hl, host, 0, 1, hl.cand_off, &ok);
 		if (rc) return rc;
 	} else {
 		for (uint32_t p = 0; p < hl.sub.size() && ok; ++p) {
-			const int rc = host_tbl_upload(c, hl.sub[p], c->cfg.max_hosts + hl.sub_desc + p, p, (uint32_t)hl.sub.size(), &ok);
+			const int rc = host_tbl_upload(c, hl.sub[p], c->cfg.max_hosts + hl.sub_desc + p, p, (uint32_t)hl.sub.size(), hl.cand_off, &ok);
 			if (rc) return rc;
 		}
 	}
@@ -633,18 +679,76 @@ int host_lst_upload(gys_ctx *c, uint32_t host)
 	return GYS_OK;
 }
 
-// one listener into one sub-table (grown and rehashed at half full)
-void host_tbl_insert(HostListeners &t, uint64_t key48, uint32_t slot)
+// one listener into one sub-table (grown and rehashed at half full).  `top`: the host (holder of the chains): with chains around, a
+// rehash has to know which keys' entries name a candidate region -- the whole host is rebuilt at the end of the registration call instead
+void host_tbl_insert(HostListeners &top, HostListeners &t, uint64_t key48, uint32_t slot)
 {
 	const uint32_t local = (uint32_t)t.slots.size();
 	t.slots.push_back(slot);
 	t.keys.push_back(key48);
+	// (the plain entries are kept current in any case -- later listeners of the same call look their key up in them; entries of keys with
+	// candidates are put right by host_rebuild at the end of the call)
 	if (host_tbl_capacity(t.slots.size()) > t.tbl.size()) {
 		t.tbl.assign(host_tbl_capacity(t.slots.size()), GYS_HOST_TBL_EMPTY);
 		for (uint32_t l = 0; l < t.keys.size(); ++l) host_tbl_put(t, t.keys[l], l);
+		if (!top.chain.empty()) top.dirty = true;
 	} else {
 		host_tbl_put(t, key48, local);
 	}
+}
+
+// all tables of a host and its candidate records from the locals and the chains (after a chain changed)
+void host_rebuild(HostListeners &hl)
+{
+	hl.cands.clear();
+	hl.cand_first.clear();
+	auto one = [&](HostListeners &t) {
+		t.tbl.assign(std::max<size_t>(t.tbl.size(), host_tbl_capacity(t.slots.size())), GYS_HOST_TBL_EMPTY);
+		std::unordered_map<uint32_t, uint32_t> local_of; // slot -> local, for the locals of keys with candidates
+		for (uint32_t l = 0; l < t.keys.size(); ++l)
+			if (hl.chain.count(t.keys[l])) local_of[t.slots[l]] = l;
+		for (uint32_t l = 0; l < t.keys.size(); ++l) {
+			const uint64_t key48 = t.keys[l];
+			auto ch = hl.chain.find(key48);
+			if (ch == hl.chain.end()) {
+				host_tbl_put(t, key48, l);
+				continue;
+			}
+			if (hl.cand_first.count(key48)) continue; // (the key's entry was made when its first local came by)
+			const uint32_t first = (uint32_t)hl.cands.size();
+			hl.cand_first[key48] = first;
+			for (size_t k = 0; k < ch->second.size(); ++k) {
+				const HostListeners::ChainEnt &e = ch->second[k];
+				ListenerCand cd{};
+				cd.ip32 = e.a.ip32;
+				cd.flags = (e.a.any ? 1u : 0u) | (k + 1 == ch->second.size() ? 2u : 0u);
+				auto lo = local_of.find(e.slot);
+				cd.local = lo != local_of.end() ? lo->second : 0u;
+				cd.slot = e.slot;
+				memcpy(cd.ip128, e.a.ip128, 16);
+				hl.cands.push_back(cd);
+			}
+			host_tbl_put(t, key48, GYS_LOCAL_GROUP | first);
+		}
+	};
+	if (hl.overflow) { // (no sub-tables: only the records, for the global table)
+		for (auto &kv : hl.chain) {
+			hl.cand_first[kv.first] = (uint32_t)hl.cands.size();
+			for (size_t k = 0; k < kv.second.size(); ++k) {
+				ListenerCand cd{};
+				cd.ip32 = kv.second[k].a.ip32;
+				cd.flags = (kv.second[k].a.any ? 1u : 0u) | (k + 1 == kv.second.size() ? 2u : 0u);
+				cd.slot = kv.second[k].slot;
+				memcpy(cd.ip128, kv.second[k].a.ip128, 16);
+				hl.cands.push_back(cd);
+			}
+		}
+	} else if (hl.sub.empty()) {
+		one(hl);
+	} else {
+		for (HostListeners &t : hl.sub) one(t);
+	}
+	hl.dirty = false;
 }
 
 // cuts the host's listeners into nparts sub-tables (from one table, or from fewer parts); false: no descriptor room / too many parts
@@ -664,32 +768,139 @@ bool host_lst_repartition(gys_ctx *c, HostListeners &hl, uint32_t nparts)
 	hl.sub.assign(nparts, HostListeners{});
 	hl.sub_desc = c->hdesc_ext_used; // (the descriptors of the previous cut are abandoned, like outgrown table regions)
 	c->hdesc_ext_used += nparts;
-	for (const auto &kv : all) host_tbl_insert(hl.sub[host_part_of(kv.first, nparts)], kv.first, kv.second);
+	for (const auto &kv : all) host_tbl_insert(hl, hl.sub[host_part_of(kv.first, nparts)], kv.first, kv.second);
 	for (HostListeners &t : hl.sub)
 		if (t.tbl.empty()) t.tbl.assign(16, GYS_HOST_TBL_EMPTY);
+	if (!hl.chain.empty()) hl.dirty = true;
 	return true;
+}
+
+// GY_IP_ADDR of a registered listener (set_ip(uint32_t) / set_ip(unsigned __int128), common/gy_common_inc.h:10673-10692)
+inline HostListeners::LAddr listener_addr(const gys_listener_info &li)
+{
+	HostListeners::LAddr a;
+	a.any = li.is_any_ip != 0;
+	if (a.any) return a;
+	if (li.addr_is_v6) {
+		memcpy(a.ip128, li.addr, 16);
+		a.ip32 = ip6_embedded_v4(a.ip128);
+	} else {
+		memcpy(&a.ip32, li.addr, 4);
+	}
+	return a;
+}
+inline bool laddr_equal(const HostListeners::LAddr &x, const HostListeners::LAddr &y) // GY_IP_ADDR::operator== (common/gy_common_inc.h:10629-10636)
+{
+	return (x.ip32 | y.ip32) ? x.ip32 == y.ip32 : memcmp(x.ip128, y.ip128, 16) == 0;
+}
+
+// the local index that holds `slot` in the table of key48 gets `new_slot` (a listener replaced in place)
+void host_rebind_local(HostListeners &hl, uint64_t key48, uint32_t slot, uint32_t new_slot)
+{
+	if (hl.overflow) return;
+	HostListeners &t = hl.sub.empty() ? hl : hl.sub[host_part_of(key48, (uint32_t)hl.sub.size())];
+	for (uint32_t l = 0; l < t.slots.size(); ++l)
+		if (t.slots[l] == slot && t.keys[l] == key48) {
+			t.slots[l] = new_slot;
+			return;
+		}
 }
 
 int host_lst_add(gys_ctx *c, uint32_t host, const gys_listener_info *arr, uint32_t n, uint32_t first_slot)
 {
 	HostListeners &hl = c->host_lst[host];
-	if (hl.overflow) return GYS_OK;
-	for (uint32_t i = 0; i < n; ++i) {
-		const uint64_t key48 = host_key48(arr[i].netns, arr[i].port);
+	auto new_local = [&](uint64_t key48, uint32_t slot) { // false: the host left the LDS path
+		if (hl.overflow) return false;
 		HostListeners *t = hl.sub.empty() ? &hl : &hl.sub[host_part_of(key48, (uint32_t)hl.sub.size())];
-		const int64_t pos = host_tbl_find(*t, key48);
-		if (pos >= 0) { // re-registration of a listener tuple rebinds it to the newest slot (same rule as the global table)
-			t->slots[(uint32_t)(t->tbl[(size_t)pos] & 0xFFFFu)] = first_slot + i;
-			continue;
-		}
 		while (t->slots.size() >= GYS_HOST_MAX_LOCAL) { // the (part of the) host is full: twice the parts
 			if (!host_lst_repartition(c, hl, hl.sub.empty() ? 2u : (uint32_t)hl.sub.size() * 2u)) {
-				hl.overflow = true; // beyond what the LDS sub-tables take: batches with this host use the general pipeline
-				return GYS_OK;
+				// beyond what the LDS sub-tables take: batches with this host use the general pipeline.  The keys of its any-address
+				// listeners move to a flat map (what a later registration on the same key has to find)
+				hl.overflow = true;
+				auto take = [&](const HostListeners &s) {
+					for (uint32_t l = 0; l < s.keys.size(); ++l)
+						if (!hl.chain.count(s.keys[l])) hl.okey[s.keys[l]] = s.slots[l];
+				};
+				if (hl.sub.empty()) take(hl);
+				else for (const HostListeners &s : hl.sub) take(s);
+				return false;
 			}
 			t = &hl.sub[host_part_of(key48, (uint32_t)hl.sub.size())];
 		}
-		host_tbl_insert(*t, key48, first_slot + i);
+		host_tbl_insert(hl, *t, key48, slot);
+		return true;
+	};
+	for (uint32_t i = 0; i < n; ++i) {
+		const uint64_t key48 = host_key48(arr[i].netns, arr[i].port);
+		const uint32_t slot = first_slot + i;
+		const HostListeners::LAddr a = listener_addr(arr[i]);
+		auto ch = hl.chain.find(key48);
+		if (ch != hl.chain.end()) {
+			// insert_or_replace (common/gy_socket_stat.cc:1372, :7779) under operator==(listener, NS_IP_PORT) (gy_socket_stat.h:708-714): the first
+			// listener of the key that is any-address or bound to the new one's address is replaced in place, else the new one goes last
+			bool replaced = false;
+			for (HostListeners::ChainEnt &e : ch->second) {
+				if (e.a.any || laddr_equal(e.a, a)) {
+					host_rebind_local(hl, key48, e.slot, slot);
+					e.slot = slot;
+					e.a = a;
+					replaced = true;
+					break;
+				}
+			}
+			if (!replaced) {
+				ch->second.push_back(HostListeners::ChainEnt{slot, a});
+				if (!hl.overflow) new_local(key48, slot);
+			}
+			hl.dirty = true;
+			continue;
+		}
+		// the key has no candidates: no listener yet, or one any-address listener (which every new listener of the key replaces)
+		uint32_t old_slot = GYS_NOSLOT;
+		if (hl.overflow) {
+			auto it = hl.okey.find(key48);
+			if (it != hl.okey.end()) old_slot = it->second;
+		} else {
+			HostListeners *t = hl.sub.empty() ? &hl : &hl.sub[host_part_of(key48, (uint32_t)hl.sub.size())];
+			const int64_t pos = host_tbl_find(*t, key48);
+			if (pos >= 0) {
+				uint32_t &ls = t->slots[(uint32_t)(t->tbl[(size_t)pos] & (GYS_LOCAL_GROUP - 1u))];
+				old_slot = ls;
+				ls = slot; // (re-registration of a listener tuple rebinds it to the newest slot)
+			}
+		}
+		if (old_slot != GYS_NOSLOT) {
+			if (hl.overflow && a.any) hl.okey[key48] = slot;
+		} else if (!hl.overflow) {
+			new_local(key48, slot);
+			if (hl.overflow && a.any) hl.okey[key48] = slot; // (the host left the LDS path with this very listener)
+		} else if (a.any) {
+			hl.okey[key48] = slot;
+		}
+		if (!a.any) { // bound to an address: the key gets candidates
+			hl.okey.erase(key48);
+			hl.chain[key48].push_back(HostListeners::ChainEnt{slot, a});
+			hl.dirty = true;
+		}
+	}
+	if (hl.dirty) {
+		host_rebuild(hl);
+		const int rc = host_cands_upload(c, hl);
+		if (rc) return rc;
+		// the global table (general pipeline): a key with candidates points at its chain's records
+		std::vector<uint64_t> kv;
+		for (const auto &cf : hl.cand_first) {
+			kv.push_back(listener_key(host, (uint32_t)(cf.first >> 16), (uint16_t)(cf.first & 0xFFFFu)));
+			kv.push_back((uint64_t)(GYS_SLOT_GROUP | (hl.cand_off + cf.second)));
+		}
+		if (!kv.empty()) {
+			const uint32_t nk = (uint32_t)(kv.size() / 2);
+			const int rs = ensure_staging(c, kv.size() * 8, 0);
+			if (rs) return rs;
+			HIPCHK(hipMemcpyAsync(c->dev_staging, kv.data(), kv.size() * 8, hipMemcpyHostToDevice, c->stream));
+			hipLaunchKernelGGL(k_table_set, dim3((nk + 255) / 256), dim3(256), 0, c->stream, c->lk_tbl, (const uint64_t *)c->dev_staging, nk);
+			HIPCHK(hipStreamSynchronize(c->stream));
+		}
 	}
 	return host_lst_upload(c, host);
 }
@@ -728,20 +939,29 @@ int fold_range(gys_ctx *c, uint32_t first, uint32_t n)
 	return GYS_OK;
 }
 
-template <int TPT, bool SHARED, bool SPILL>
+template <int TPT, bool SHARED, bool SPILL, int MODE = 0>
 void launch_resp_host(gys_ctx *c, uint32_t grid, size_t dyn, const RespHostP &hp)
 {
-	if (!SPILL && hp.svc_hll_p) hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, !SPILL>), dim3(grid), dim3(GYS_RESP_THREADS(TPT)), dyn, c->stream, hp);
-	else hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, false>), dim3(grid), dim3(GYS_RESP_THREADS(TPT)), dyn, c->stream, hp);
+	// (IPv6 events: every kept event takes the rolled general hash path anyway, so ONE instance -- the one with the per-service register code,
+	// which checks svc_hll_p at run time there -- serves both configurations)
+	if (!SPILL && (hp.svc_hll_p || MODE == 2)) hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, !SPILL, MODE>), dim3(grid), dim3(GYS_RESP_THREADS(TPT)), dyn, c->stream, hp);
+	else hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, false, MODE>), dim3(grid), dim3(GYS_RESP_THREADS(TPT)), dyn, c->stream, hp);
+}
+// mode 1 / 2 (keys with candidates / IPv6 events) exist in the 1024 x 16 tile form only (batches whose tables do not fit it take the general front end)
+template <bool SHARED, bool SPILL>
+void launch_resp_host_mode(gys_ctx *c, int mode, uint32_t grid, size_t dyn, const RespHostP &hp)
+{
+	if (mode == 2) launch_resp_host<16, SHARED, SPILL, 2>(c, grid, dyn, hp);
+	else launch_resp_host<16, SHARED, SPILL, 1>(c, grid, dyn, hp);
 }
 
 // dynamic LDS a k_resp_host launch may ask for: the CU's 160 KiB minus the instance's own static part (read from the code object, so that
 // a kernel change cannot silently push a launch over the limit); *dyn_max ends as the smallest such room over the instances
-template <int TPT, bool SHARED, bool SPILL>
+template <int TPT, bool SHARED, bool SPILL, int MODE = 0>
 hipError_t resp_host_lds_attr(uint32_t *dyn_max)
 {
-	for (int svchll = 0; svchll < (SPILL ? 1 : 2); ++svchll) {
-		const void *fn = svchll ? (const void *)k_resp_host<TPT, SHARED, SPILL, !SPILL> : (const void *)k_resp_host<TPT, SHARED, SPILL, false>;
+	for (int svchll = (MODE == 2 && !SPILL) ? 1 : 0; svchll < (SPILL ? 1 : 2); ++svchll) {
+		const void *fn = svchll ? (const void *)k_resp_host<TPT, SHARED, SPILL, !SPILL, MODE> : (const void *)k_resp_host<TPT, SHARED, SPILL, false, MODE>;
 		hipFuncAttributes fa{};
 		hipError_t e = hipFuncGetAttributes(&fa, fn);
 		if (e != hipSuccess) return e;
@@ -754,7 +974,8 @@ hipError_t resp_host_lds_attr(uint32_t *dyn_max)
 }
 
 // resp pipeline on a device-resident batch
-int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, const void *d_ev, uint64_t n)
+// v6: the events are 48-byte tcp_ipv6_resp_event_t (handle_ipv6_resp_event, common/gy_socket_stat.cc:1535-1551)
+int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, const void *d_ev, uint64_t n, bool v6 = false)
 {
 	if (n == 0) return GYS_OK;
 	if (nsegs == 0 || !segs_host || segs_host[0].first_event != 0) {
@@ -800,11 +1021,13 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	bool host_local = td && c->cfg.resp_path != 1 && c->nsvc != 0, host_split = false, host_parts = false;
 	uint32_t max_tbl = 16, max_l = 1;
 	uint64_t max_len = 0, nwg = 0;
+	bool cands = false; // some host of the batch has keys with candidates: the instances that resolve them by the server address
 	if (host_local) {
 		c->batch_stamp++;
 		for (uint32_t s = 0; s < nsegs && host_local; ++s) {
 			const uint32_t host = segs_host[s].host_slot;
 			const HostListeners &hl = c->host_lst[host];
+			cands = cands || !hl.chain.empty();
 			const uint64_t len = (s + 1 < nsegs ? segs_host[s + 1].first_event : n) - segs_host[s].first_event;
 			if (c->host_seen[host] == c->batch_stamp || hl.overflow) host_local = false;
 			c->host_seen[host] = c->batch_stamp;
@@ -830,6 +1053,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		const double t_split = (double)n * (double)std::max<uint64_t>(nwg, 1) / (double)std::max<uint32_t>(nsegs, 1) / 40.0e9 + 20e-6;
 		if (host_local && max_len > GYS_SPLIT_PART && (c->cfg.resp_path == 3 || (c->cfg.resp_path == 0 && t_split < t_host))) host_split = true;
 	}
+	const int mode = v6 ? 2 : cands ? 1 : 0;
+	if (host_local && mode != 0 && resp_host_lds_bytes(max_tbl, (uint32_t)align_up(max_l, 2), 16384u) > c->resp_dyn_max) host_local = host_split = false; // (those instances exist in the 16 384-event tile form only)
 	const uint32_t nsvc = c->nsvc;
 	uint32_t *cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
 	unsigned long long *ghist = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
@@ -884,6 +1109,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hp.hdesc = c->hdesc;
 		hp.htbl = c->htbl;
 		hp.hlst = c->hlst;
+		hp.cand = c->cand_pool;
 		hp.hll32 = c->hll32;
 		hp.td_cur = c->td_cur;
 		hp.td_pend = c->td_pend;
@@ -952,8 +1178,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			c->n_batches_host_local++;
 		}
 		// (two workgroups per CU: each gets half of the CU's LDS -- resp_dyn_max is 160 KiB minus ONE static part)
-		tpt12 = (tpt == 12 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 6144u) + 160u * 1024u - c->resp_dyn_max <= 80u * 1024u;
-		tpt16 = !tpt12 && (tpt == 16 || tpt == 32 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 16384u) <= c->resp_dyn_max;
+		tpt12 = mode == 0 && (tpt == 12 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 6144u) + 160u * 1024u - c->resp_dyn_max <= 80u * 1024u;
+		tpt16 = !tpt12 && (mode != 0 || tpt == 16 || tpt == 32 || tpt == 0) && resp_host_lds_bytes(max_tbl, hp.lds_key_entries, 16384u) <= c->resp_dyn_max;
 		// GYS_TPT=32 (experiment): the fused first pass as 512 threads x 32 events with the next group's events prefetched into registers --
 		// the same 16 384-event tile and LDS layout as the 1024 x 16 form, which the split form and the second pass keep using
 		tpt32 = tpt16 && tpt == 32 && !host_split;
@@ -982,7 +1208,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		}
 		{
 			ProfScope ps(c, "resp_host");
-			if (host_split) {
+			if (mode != 0) {
+				if (host_split) launch_resp_host_mode<true, false>(c, mode, hgrid, dyn, hp);
+				else launch_resp_host_mode<false, false>(c, mode, hgrid, dyn, hp);
+			} else if (host_split) {
 				if (tpt12) launch_resp_host<12, true, false>(c, hgrid, dyn, hp);
 				else if (tpt16) launch_resp_host<16, true, false>(c, hgrid, dyn, hp);
 				else launch_resp_host<8, true, false>(c, hgrid, dyn, hp);
@@ -997,6 +1226,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		c->n_batches_general++;
 		RespP1 p{};
 		p.ev = (const uint64_t *)d_ev;
+		p.cand = c->cand_pool;
 		p.n = n;
 		p.segs = segs_dev;
 		p.nsegs = nsegs;
@@ -1015,7 +1245,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		p.gmax = gmax;
 		{
 			ProfScope ps(c, "resp_pass1");
-			hipLaunchKernelGGL(k_resp_pass1, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
+			if (v6) hipLaunchKernelGGL(k_resp_pass1<true>, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
+			else hipLaunchKernelGGL(k_resp_pass1<false>, dim3(grid_for(n, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
 		}
 		HIPCHK(hipGetLastError());
 		if (!td || nsvc == 0) {
@@ -1061,7 +1292,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		// second pass over the hosts that have spilled services (a workgroup of any other host returns at once): their events again,
 		// only the spilled services' values, into the runs k_key_finalize allocated in `staged`
 		ProfScope ps(c, "resp_spill");
-		if (tpt12) launch_resp_host<12, true, true>(c, hgrid, dyn, hp);
+		if (mode != 0) launch_resp_host_mode<true, true>(c, mode, hgrid, dyn, hp);
+		else if (tpt12) launch_resp_host<12, true, true>(c, hgrid, dyn, hp);
 		else if (tpt16) launch_resp_host<16, true, true>(c, hgrid, dyn, hp);
 		else launch_resp_host<8, true, true>(c, hgrid, dyn, hp);
 	}
@@ -2063,7 +2295,7 @@ try {
 	ALLOC(c->svc_gid, S);
 	ALLOC(c->hist_win, S);
 	ALLOC(c->hist_all, S);
-	ALLOC(c->bitmap, S * 16);
+	ALLOC(c->bitmap, S * GYS_BM_WORDS);
 	ALLOC(c->svc_ctr, S * 4);
 	ALLOC(c->svc_win, S * 3);
 	ALLOC(c->svc_state, S * 96);
@@ -2102,6 +2334,12 @@ try {
 	HIPCHK((resp_host_lds_attr<12, false, false>(&c->resp_dyn_max))); // (GYS_TPT=12: half of the room per workgroup, two per CU)
 	HIPCHK((resp_host_lds_attr<12, true, false>(&c->resp_dyn_max)));
 	HIPCHK((resp_host_lds_attr<12, true, true>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<16, false, false, 1>(&c->resp_dyn_max))); // keys with candidates (bound-address listeners)
+	HIPCHK((resp_host_lds_attr<16, true, false, 1>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<16, true, true, 1>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<16, false, false, 2>(&c->resp_dyn_max))); // IPv6 events
+	HIPCHK((resp_host_lds_attr<16, true, false, 2>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<16, true, true, 2>(&c->resp_dyn_max)));
 	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_levels) {
@@ -2181,7 +2419,7 @@ try {
 		}
 		ALLOC(c->huge_scratch, scratch_entries * GYS_HB_BINS);
 		ALLOC(c->huge_acc, (uint64_t)c->huge_maxent * GYS_HB_ACC);
-		ALLOC(c->huge_bm, (uint64_t)c->huge_maxent * 16);
+		ALLOC(c->huge_bm, (uint64_t)c->huge_maxent * GYS_BM_WORDS);
 		ALLOC(c->huge_chunk_off, (uint64_t)c->huge_maxent + 1);
 		ALLOC(c->huge_tail, (uint64_t)1 << 20);
 		ALLOC(c->huge_tb_list, (uint64_t)c->huge_maxent);
@@ -2299,7 +2537,7 @@ void gys_destroy(gys_ctx *c)
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_claim, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->ring_act32, c->ring_act64, c->act_live, c->q_cand_key, c->q_out_keys, c->q_cand_slot, c->q_misc, c->q_host_mask, c->q_slot_list, c->q_set, c->q_out_rows, c->q_acc, c->q_cnt, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
-			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_first, c->qps_hist, c->act_hist, c->own_arena ? c->arena : nullptr};
+			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_first, c->qps_hist, c->act_hist, c->cand_pool, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -2482,6 +2720,47 @@ try {
 		}
 		if (e != hipSuccess) {
 			set_err("gys_ingest_resp_events: %s", hipGetErrorString(e));
+			rc = GYS_ERR_HIP;
+		}
+	}
+	stage_release(c, si);
+	return rc;
+} GYS_CATCH_ALL
+
+int gys_ingest_resp_events_v6_dev(gys_ctx *c, const gys_resp_seg *segs, uint32_t nsegs, const void *d_ev48, uint64_t nevents)
+try {
+	GYS_ENTER(c);
+	if (!c || (!d_ev48 && nevents) || ((uintptr_t)d_ev48 & 7u)) return GYS_ERR_INVAL;
+	return run_resp_batch(c, segs, nsegs, d_ev48, nevents, true);
+} GYS_CATCH_ALL
+
+int gys_ingest_resp_events_v6(gys_ctx *c, const uint8_t machine_id[16], const void *ev48, uint32_t nevents)
+try {
+	GYS_ENTER_NOFLUSH(c);
+	if (!c || !machine_id || (!ev48 && nevents)) return GYS_ERR_INVAL;
+	uint32_t host;
+	int rc = lookup_host(c, machine_id, &host);
+	if (rc) return rc;
+	if (!nevents) return GYS_OK;
+	// its own submission, behind whatever the IPv4 queue holds (a service's per-call value multisets keep the order of the calls)
+	rc = rq_flush(c);
+	if (rc) return rc;
+	const uint64_t bytes = (uint64_t)nevents * 48;
+	int si;
+	rc = stage_acquire(c, bytes, &si);
+	if (rc) return rc;
+	gys_ctx::Stage &st = c->stage[si];
+	memcpy(st.h, ev48, bytes); // the caller's buffer is free from here on
+	{
+		std::lock_guard<std::mutex> g(c->enq_mu);
+		hipError_t e = hipMemcpyAsync(st.d, st.h, bytes, hipMemcpyHostToDevice, c->stream);
+		if (e == hipSuccess) {
+			gys_resp_seg seg{host, 0, 0};
+			rc = run_resp_batch(c, &seg, 1, st.d, nevents, true);
+			e = hipEventRecord(st.done, c->stream);
+		}
+		if (e != hipSuccess) {
+			set_err("gys_ingest_resp_events_v6: %s", hipGetErrorString(e));
 			rc = GYS_ERR_HIP;
 		}
 	}
@@ -2866,7 +3145,7 @@ static hipError_t enqueue_finish(gys_ctx *c, hipStream_t st)
 	if ((e = hipMemsetAsync(c->hll32, 0, (uint64_t)4 << GYS_HLL_P, st)) != hipSuccess) return e;
 	if (c->nsvc) {
 		// CONN_BITMAP cleared every window (secs_to_reset_ = 5); lazily (per key, on its next touch) when the per-key pass runs
-		if (!c->cfg.enable_tdigest && (e = hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * 64, st)) != hipSuccess) return e;
+		if (!c->cfg.enable_tdigest && (e = hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * GYS_BM_WORDS * 4, st)) != hipSuccess) return e;
 		if (c->svc_hll && (e = hipMemsetAsync(c->svc_hll, 0, (uint64_t)c->nsvc << c->cfg.svc_hll_p, st)) != hipSuccess) return e;
 	}
 	const uint64_t hb = (uint64_t)c->hosts.size() * 16 * 4;
@@ -3863,7 +4142,7 @@ try {
 		const int rcf = fold_range(c, first_slot, nslots);
 		if (rcf) return rcf;
 	}
-	HIPCHK(hipMemcpyAsync(out, c->bitmap + (size_t)first_slot * 16, (size_t)nslots * 64, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(out, c->bitmap + (size_t)first_slot * GYS_BM_WORDS, (size_t)nslots * GYS_BM_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
 	std::vector<TdMeta> meta;
 	if (c->cfg.enable_tdigest) { // rows of a key that has not been touched in the current window are logically cleared
 		meta.resize(nslots);
@@ -3871,7 +4150,7 @@ try {
 	}
 	HIPCHK(hipStreamSynchronize(c->stream));
 	for (size_t i = 0; i < meta.size(); ++i)
-		if (meta[i].hw_epoch != c->epoch) memset(out + i * 32, 0, 64);
+		if (meta[i].hw_epoch != c->epoch) memset(out + i * 2 * GYS_BM_WORDS, 0, GYS_BM_WORDS * 4);
 	return GYS_OK;
 } GYS_CATCH_ALL
 

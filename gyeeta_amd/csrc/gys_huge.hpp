@@ -32,7 +32,7 @@ struct Huge2P {
 	const uint32_t *count;
 	uint32_t *bins;             // [maxent][GYS_HB_BINS]
 	unsigned long long *acc;    // [maxent][GYS_HB_ACC]
-	uint32_t *bm;               // [maxent][16]
+	uint32_t *bm;               // [maxent][GYS_BM_WORDS]
 	uint32_t *chunk_off;        // [maxent + 1]
 	unsigned long long *tail;   // entry << 32 | value
 	uint32_t *tail_count;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_huge_clear(Huge2P p)
 	const uint64_t na = (uint64_t)nuse * GYS_HB_ACC;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride)
 		p.acc[i] = (i % GYS_HB_ACC) == 32u ? (0xFFFFFFFFull | (0ull << 32)) : 0ull; // min = +inf, max = 0 (values are >= 0)
-	const uint64_t nm = (uint64_t)nuse * 16u;
+	const uint64_t nm = (uint64_t)nuse * GYS_BM_WORDS;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += stride) p.bm[i] = 0;
 }
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 {
 	GYS_DYN_LDS(uint32_t, s_img); // [GYS_HB_BINS]
 	__shared__ unsigned long long s_hc[16], s_hs[16];
-	__shared__ uint32_t s_bm[16], s_mm[2];
+	__shared__ uint32_t s_bm[GYS_BM_WORDS], s_mm[2];
 	const uint32_t nuse = *p.nent_used, tid = threadIdx.x;
 	if (!nuse) return;
 	const uint32_t nchunks = p.chunk_off[nuse];
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 			s_hc[tid] = 0;
 			s_hs[tid] = 0;
 			s_bm[tid] = 0;
+			s_bm[tid + 16u] = 0;
 		}
 		if (tid == 0) {
 			s_mm[0] = 0xFFFFFFFFu;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 		__syncthreads();
 		uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
 		for (uint32_t i = v0 + tid; i < v1; i += 1024u) {
-			const uint32_t word = run[i], v = word >> GYS_ROW_BITS, row = word & 0x1Fu;
+			const uint32_t word = run[i], v = word >> GYS_ROW_BITS, row = word & GYS_ROW_MASK;
 			lmin = min(lmin, v);
 			lmax = max(lmax, v);
 			const uint32_t b = resp_bucket((int64_t)v);
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 				atomicAdd(&ga[tid], s_hc[tid]);
 				atomicAdd(&ga[16u + tid], s_hs[tid]);
 			}
-			if (s_bm[tid]) atomicOr(&p.bm[(size_t)e * 16u + tid], s_bm[tid]);
+			if (s_bm[tid]) atomicOr(&p.bm[(size_t)e * GYS_BM_WORDS + tid], s_bm[tid]);
+			if (s_bm[tid + 16u]) atomicOr(&p.bm[(size_t)e * GYS_BM_WORDS + 16u + tid], s_bm[tid + 16u]);
 		}
 		if (tid == 16u && s_mm[0] != 0xFFFFFFFFu) {
 			uint32_t *mm = (uint32_t *)&ga[32];
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 	__shared__ uint64_t s_cw[4];
 	__shared__ unsigned long long s_ha[32], s_hw[32]; // buffered words: exact {count, sum} per bucket, all not yet folded / window part
 	__shared__ unsigned long long s_pa[NT / 64][16], s_pw[NT / 64][16]; // ... accumulated per wave first (packed count : 24 | sum : 40)
-	__shared__ uint32_t s_bm[16];
+	__shared__ uint32_t s_bm[GYS_BM_WORDS];
 	__shared__ uint32_t s_nc, s_ntail, s_over;
 	__shared__ int32_t s_min, s_max, s_wmax;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 			s_ha[tid] = 0;
 			s_hw[tid] = 0;
 		}
-		if (tid >= 32u && tid < 48u) s_bm[tid - 32u] = 0;
+		if (tid >= 32u && tid < 32u + GYS_BM_WORDS) s_bm[tid - 32u] = 0;
 		{ // compact the non-empty old clusters (order preserving) + exclusive prefix of their weights: threads 0..255, one cluster each
 			uint32_t c0 = 0;
 			int64_t sm0 = 0;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 						key[u] = hb;
 						if (i >= nwin0) {
 							key[u] = hb | 16u;
-							const uint32_t row = word & 0x1Fu, bit = (1u << hb) << ((row & 1u) * 16u);
+							const uint32_t row = word & GYS_ROW_MASK, bit = (1u << hb) << ((row & 1u) * 16u);
 							if ((s_bm[row >> 1] & bit) == 0u) atomicOr(&s_bm[row >> 1], bit);
 							wmx = max(wmx, (int32_t)v);
 						}
@@ -632,8 +634,9 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 						if (wv.sum < (int64_t)wmaxv) wv.sum = (int64_t)wmaxv;
 					}
 					*wp = wv;
-					uint32_t *bp = &p.d.bitmap[(size_t)slot * 16u + t];
-					*bp = (roll ? 0u : *bp) | s_bm[t] | p.bm[(size_t)e * 16u + t];
+					uint32_t *bp = &p.d.bitmap[(size_t)slot * GYS_BM_WORDS + t];
+					*bp = (roll ? 0u : *bp) | s_bm[t] | p.bm[(size_t)e * GYS_BM_WORDS + t];
+					bp[16] = (roll ? 0u : bp[16]) | s_bm[t + 16u] | p.bm[(size_t)e * GYS_BM_WORDS + 16u + t];
 				}
 			}
 			__syncthreads(); // every reader of the meta record is done before thread 0 rewrites it

@@ -19,10 +19,17 @@ namespace gys {
 
 #define GYS_HUGE_VALUE_BITS 20     // resp values are <= 1,000,000 < 2^20 (drop filter common/gy_socket_stat.cc:1521-1524)
 #define GYS_HUGE_BINS (1u << GYS_HUGE_VALUE_BITS)
-// staged word of one accepted event: (response ms << 5) | CONN_BITMAP row (cli_port & 0x1F, common/gy_socket_stat.h:403-410).
+// staged word of one accepted event: (response ms << 6) | family << 5 | CONN_BITMAP row (cli_port & 0x1F, common/gy_socket_stat.h:403-410).
+// family = 1 for an IPv6 response event: the reference keeps resp_bitmap_v4_ and resp_bitmap_v6_ apart (common/gy_socket_stat.cc:1579-1588)
+// and adds their per-bucket row counts (:4144-4149), so the 64 "rows" of a service are 32 IPv4 rows + 32 IPv6 rows; the histogram and the
+// query count are shared by the families (:1800 both caches flush into resp_hist_, :4050-4051).
 // Sorting the words sorts by value; the digest kernels, which see all of a key's words, also produce the key's bitmap rows.
-#define GYS_ROW_BITS 5
+#define GYS_ROW_BITS 6
+#define GYS_ROW_MASK 0x3Fu
+#define GYS_ROW_V6 0x20u
+#define GYS_BM_WORDS 32u // u32 words of CONN_BITMAP rows per service: words 0..15 = the 32 u16 rows of resp_bitmap_v4_, 16..31 = resp_bitmap_v6_
 #define GYS_STAGED_WORD(tresp, cli_port) ((uint64_t)(((uint32_t)(tresp) << GYS_ROW_BITS) | ((uint32_t)(cli_port) & 0x1Fu)))
+#define GYS_STAGED_WORD_FAM(tresp, cli_port, v6) ((uint32_t)(((uint32_t)(tresp) << GYS_ROW_BITS) | ((v6) ? GYS_ROW_V6 : 0u) | ((uint32_t)(cli_port) & 0x1Fu)))
 
 enum { CTR_RESP_EVENTS = 0, CTR_RESP_DROP_RANGE, CTR_RESP_DROP_NOLISTENER, CTR_CONN_EVENTS, CTR_CONN_UNKNOWN, CTR_LSTATE_RECORDS,
        CTR_LSTATE_MISSED, CTR_LSTATE_ERRORS, CTR_LSTATE_DELETED, CTR_TD_MERGES, CTR_TD_MERGE_VALUES, CTR_ACTCONN_RECORDS, CTR_ACTCONN_REMOTE_LISTEN, CTR_ACTCONN_UNKNOWN,
@@ -44,6 +51,23 @@ __global__ void k_table_insert(DevTable t, const uint64_t *keys, uint32_t first_
 		h = (h + 1) & t.mask;
 	}
 	atomicAdd(nfail, 1u);
+}
+
+// kv[2 i] = key, kv[2 i + 1] = value: the key (inserted if new) gets exactly that value
+__global__ void k_table_set(DevTable t, const uint64_t *kv, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t key = kv[2u * i];
+	uint32_t h = get_uint64_hash(key) & t.mask;
+	for (uint32_t probes = 0; probes <= t.mask; ++probes) {
+		const unsigned long long prev = atomicCAS((unsigned long long *)&t.ent[h].key, (unsigned long long)GYS_EMPTY_KEY, (unsigned long long)key);
+		if (prev == GYS_EMPTY_KEY || prev == key) {
+			t.ent[h].val = (uint32_t)kv[2u * i + 1u];
+			return;
+		}
+		h = (h + 1) & t.mask;
+	}
 }
 
 __global__ void k_fill_u64(uint64_t *p, uint64_t v, uint64_t n)
@@ -122,15 +146,28 @@ __device__ __forceinline__ void hll_update_event(uint32_t *hll32, uint8_t *svc_h
 	if (hll32[idx] < rank) atomicMax(&hll32[idx], rank);
 }
 
+// IPv6 response event (tcp_ipv6_resp_event_t, common/gy_ebpf_kernel.h:113-118; ipv6_tuple_t partha/gy_ebpf_kernel_struct.h:37-44), 48 bytes:
+// u128 saddr, u128 daddr, u32 netns, u16 sport, u16 dport (network order), u32 lsndtime, u32 lrcvtime = six 8-byte words, the last two
+// laid out like words 1 and 2 of the 24-byte IPv4 event.  Flow key as for IPv4: PAIR_IP_PORT(cli = daddr:dport, ser = saddr:sport), each
+// address through GY_IP_ADDR(unsigned __int128) (handle_ipv6_resp_event, common/gy_socket_stat.cc:1535-1551).
+#define GYS_EV6_WORDS 6u
+__device__ __forceinline__ uint64_t flow_hash64_v6(const uint32_t (&d)[4], uint16_t dport, const uint32_t (&sa)[4], uint16_t sport)
+{
+	uint32_t w[10];
+	const uint32_t nw = pair_words(ip6_embedded_v4(d), d, dport, ip6_embedded_v4(sa), sa, sport, w);
+	return hash64<10>(w, nw);
+}
+
 struct RespP1 {
-	const uint64_t *ev;       // 3 x u64 per event (tcp_ipv4_resp_event_t, common/gy_ebpf_kernel.h:106-111)
+	const uint64_t *ev;       // 3 x u64 per event (tcp_ipv4_resp_event_t, common/gy_ebpf_kernel.h:106-111); V6: 6 x u64 (tcp_ipv6_resp_event_t :113-118)
+	const ListenerCand *cand; // candidate pool: a table value with GYS_SLOT_GROUP indexes it
 	uint64_t n;
 	const gys_resp_seg *segs; // device copy
 	uint32_t nsegs;
 	DevTable lk;
 	const uint64_t *svc_gid;
 	gys_hist_rec *hist_win;
-	uint32_t *bitmap;         // [nsvc*16] u32 = 32 x u16 CONN_BITMAP rows
+	uint32_t *bitmap;         // [nsvc*GYS_BM_WORDS] u32 = 32 x u16 CONN_BITMAP rows per family
 	uint32_t *hll32;          // [1<<14]
 	uint32_t *cms32;          // arena [D*W]
 	uint32_t *batch_cnt;      // nullptr when the t-digest is off
@@ -152,6 +189,7 @@ __device__ __forceinline__ uint32_t find_seg(const gys_resp_seg *segs, uint32_t 
 	return lo;
 }
 
+template <bool V6>
 __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 {
 	__shared__ unsigned int s_ctr[3];
@@ -166,8 +204,22 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
-		// struct ipv4_tuple_t {u32 saddr, daddr, netns; u16 sport, dport;} + u32 lsndtime, lrcvtime  (24 bytes)
-		const uint64_t w0 = p.ev[3 * i], w1 = p.ev[3 * i + 1], w2 = p.ev[3 * i + 2];
+		// struct ipv4_tuple_t {u32 saddr, daddr, netns; u16 sport, dport;} + u32 lsndtime, lrcvtime  (24 bytes); IPv6: the two addresses
+		// are 16 bytes each, the rest has the same layout behind them (48 bytes)
+		uint32_t sa6[4] = {0u, 0u, 0u, 0u}, da6[4] = {0u, 0u, 0u, 0u};
+		uint64_t w0 = 0, w1, w2;
+		if (V6) {
+			const uint64_t *e = p.ev + GYS_EV6_WORDS * i;
+			const uint64_t a0 = e[0], a1 = e[1], d0 = e[2], d1 = e[3];
+			sa6[0] = (uint32_t)a0; sa6[1] = (uint32_t)(a0 >> 32); sa6[2] = (uint32_t)a1; sa6[3] = (uint32_t)(a1 >> 32);
+			da6[0] = (uint32_t)d0; da6[1] = (uint32_t)(d0 >> 32); da6[2] = (uint32_t)d1; da6[3] = (uint32_t)(d1 >> 32);
+			w1 = e[4];
+			w2 = e[5];
+		} else {
+			w0 = p.ev[3 * i];
+			w1 = p.ev[3 * i + 1];
+			w2 = p.ev[3 * i + 2];
+		}
 		const uint32_t saddr = (uint32_t)w0, daddr = (uint32_t)(w0 >> 32);
 		const uint32_t netns = (uint32_t)w1;
 		const uint16_t sport = bswap16((uint16_t)(w1 >> 32)), dport = bswap16((uint16_t)(w1 >> 48)); // ntohs :1526-1527
@@ -180,7 +232,11 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 			atomicAdd(&s_ctr[1], 1u);
 		} else {
 			const uint32_t host_slot = p.segs[find_seg(p.segs, p.nsegs, i)].host_slot;
-			const uint32_t slot = tbl_lookup(p.lk, listener_key(host_slot, netns, sport));
+			uint32_t slot = tbl_lookup(p.lk, listener_key(host_slot, netns, sport));
+			if (slot != GYS_NOSLOT && (slot & GYS_SLOT_GROUP)) { // the key has candidates: the server address picks the listener (gy_socket_stat.h:708-714)
+				uint32_t lc, sl;
+				slot = cand_resolve(p.cand, slot & ~GYS_SLOT_GROUP, V6 ? ip6_embedded_v4(sa6) : saddr, sa6, &lc, &sl) ? sl : GYS_NOSLOT;
+			}
 			if (slot == GYS_NOSLOT) {
 				atomicAdd(&s_ctr[2], 1u); // no such listener: the reference ignores the event too (:1671-1676 miss path)
 			} else {
@@ -200,15 +256,23 @@ __global__ __launch_bounds__(256) void k_resp_pass1(RespP1 p)
 				}
 				// CONN_BITMAP::add_response: respmap_[cli_port & 0x1F].set(bucket) (common/gy_socket_stat.h:403-410)
 				if (!fused) {
-					const uint32_t row = dport & 0x1Fu;
+					const uint32_t row = (dport & 0x1Fu) | (V6 ? GYS_ROW_V6 : 0u);
 					const uint32_t bit = (1u << b) << ((row & 1u) * 16u);
-					uint32_t *wp = &p.bitmap[(size_t)slot * 16u + (row >> 1)];
+					uint32_t *wp = &p.bitmap[(size_t)slot * GYS_BM_WORDS + (row >> 1)];
 					if ((*wp & bit) == 0) atomicOr(wp, bit);
 				}
-				hll_update_event(p.hll32, p.svc_hll, p.svc_hll_p, slot, daddr, dport, saddr, sport);
+				if (V6) {
+					const uint64_t h64 = flow_hash64_v6(da6, dport, sa6, sport);
+					uint32_t idx, rank;
+					hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
+					if (p.svc_hll_p) svc_hll_update(p.svc_hll, p.svc_hll_p, slot, h64);
+					if (p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
+				} else {
+					hll_update_event(p.hll32, p.svc_hll, p.svc_hll_p, slot, daddr, dport, saddr, sport);
+				}
 				if (fused) {
 					atomicAdd(&p.batch_cnt[slot], 1u);
-					kv = ((uint64_t)slot << 32) | GYS_STAGED_WORD(tresp, dport);
+					kv = ((uint64_t)slot << 32) | (uint64_t)GYS_STAGED_WORD_FAM(tresp, dport, V6);
 					atomicAdd(&s_gh[threadIdx.x >> 6][b], (1ull << 40) | (unsigned long long)tresp);
 					tmax = max(tmax, (int)tresp);
 				}
@@ -326,7 +390,7 @@ __global__ __launch_bounds__(256) void k_resp_scatter(const uint64_t *ev_kv, uin
 }
 
 // ---------------------------------------------------------------------------------------------------- per-key value buffers
-// Every service owns a buffer of `pcap` staged words (td_pend[slot * pcap ..], word = response ms << 5 | CONN_BITMAP row).  A batch's
+// Every service owns a buffer of `pcap` staged words (td_pend[slot * pcap ..], word = response ms << 6 | family << 5 | CONN_BITMAP row).  A batch's
 // accepted events are APPENDED to their key's buffer and nothing else of the key is touched per event: the key's exact histogram
 // record, its CONN_BITMAP rows and its min / max are pure functions of the appended values, so they are brought up to date lazily
 // ("fold") -- when the buffer is drained by a t-digest merge, before a query / export reads them, or at a window close when the
@@ -712,7 +776,8 @@ struct HostDesc {
 	uint32_t lst_off;  // first entry of the host's local index -> service slot list in the list pool
 	uint32_t part;     // a host with more listeners than one sub-table takes is cut into parts: this descriptor's part ...
 	uint32_t pmask;    // ... of pmask + 1 (a power of two); a listener key belongs to part (host_tbl_hash(key) >> 21) & pmask
-	uint32_t pad[2];
+	uint32_t cand_off; // first record of the host's region in the candidate pool (sub-table entries with GYS_LOCAL_GROUP index it)
+	uint32_t pad;
 };
 
 #define GYS_HOST_TBL_EMPTY 0xFFFFFFFFFFFFFFFFull
@@ -734,8 +799,9 @@ struct RespHostP {
 	const gys_resp_seg *segs;
 	uint32_t nsegs;
 	const HostDesc *hdesc;
-	const uint64_t *htbl;   // entries: (netns:32 | port:16) << 16 | local index:16
+	const uint64_t *htbl;   // entries: (netns:32 | port:16) << 16 | local index:16 (GYS_LOCAL_GROUP set: index into the host's candidate region)
 	const uint32_t *hlst;
+	const ListenerCand *cand; // candidate pool (MODE != 0)
 	uint32_t *hll32;
 	uint32_t *td_cur;       // per service: words in its buffer including this batch's (SHARED: reserved with device atomics)
 	uint32_t *td_pend;
@@ -779,12 +845,18 @@ __host__ __device__ __forceinline__ size_t resp_host_lds_bytes(uint32_t tbl_entr
 #endif
 #define GYS_MEM_FENCE() asm volatile("" ::: "memory") // compiler-only: memory operations are not moved across it (keeps a batch of LDS reads in front of the stores / the next batch)
 
-template <int TPT, bool SHARED, bool SPILL, bool SVCHLL>
+// MODE 0: IPv4 events, every listener of the batch's hosts alone on its (netns, port) key and bound to the any-address (the instance of the
+// measured configurations: nothing below costs it an instruction); 1: IPv4 events, keys with candidates (bound-address listeners) are
+// resolved by the event's server address; 2: IPv6 events (48 bytes; flow hash through the general word packing, candidates as in 1)
+template <int TPT, bool SHARED, bool SPILL, bool SVCHLL, int MODE = 0>
 __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)) void k_resp_host(RespHostP p) // (4 waves per SIMD: one 1024-thread workgroup or two 512-thread ones per CU; TPT = 32: 2)
 {
 	constexpr uint32_t T = GYS_RESP_THREADS(TPT);
 	constexpr uint32_t TILE = (uint32_t)TPT * T;
 	constexpr bool DBG = GYS_RESP_DBG != 0;
+	constexpr bool V6 = MODE == 2;
+	constexpr uint32_t SW = V6 ? GYS_EV6_WORDS : 3u; // 8-byte words per event
+	static_assert(MODE == 0 || TPT != 32, "the register-prefetch form exists for the plain IPv4 instance only");
 	GYS_DYN_LDS(uint64_t, s_dyn);
 	__shared__ uint32_t s_wsum[T / 64];
 	__shared__ uint32_t s_drop[2];
@@ -908,7 +980,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 		// group, so that every index stays a compile-time constant and after TPT / 4 groups event g sits at wd[g].
 		const uint64_t left = e1 - t0;
 		const uint32_t rem = left < (uint64_t)TILE ? (uint32_t)left : TILE; // events of this tile (> 0)
-		const uint64_t *const tb = p.ev + 3u * t0;
+		const uint64_t *const tb = p.ev + (uint64_t)SW * t0;
 		uint32_t wd[TPT], lr[TPT]; // staged word (GYS_EV_DROPPED: not kept) / local index | rank inside the key's tile run << 12
 #pragma unroll
 		for (int u = 0; u < TPT; ++u) {
@@ -942,9 +1014,15 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 					const uint32_t o = (uint32_t)(g + u) * T + tid;
 					in[u] = o < rem;
 					const uint32_t oo = in[u] ? o : 0u; // (lanes past the end read the tile's first event and ignore it: no branch around the loads)
-					w0[u] = tb[3u * oo];
-					w1[u] = tb[3u * oo + 1u];
-					w2[u] = tb[3u * oo + 2u];
+					if (V6) { // the name space / ports word and the times word; the addresses are read where they are needed (candidates, flow hash)
+						w0[u] = 0;
+						w1[u] = tb[GYS_EV6_WORDS * oo + 4u];
+						w2[u] = tb[GYS_EV6_WORDS * oo + 5u];
+					} else {
+						w0[u] = tb[3u * oo];
+						w1[u] = tb[3u * oo + 1u];
+						w2[u] = tb[3u * oo + 2u];
+					}
 				}
 			}
 			// (all twelve words pass through one opaque statement: the four events' loads are issued before the first word is used -- the
@@ -1001,6 +1079,24 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 					}
 				}
 			}
+			if (MODE != 0) {
+				// a key with candidates: the event's server address picks the listener (first match in registration order), or nobody
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					if (ok[u] && local[u] != GYS_NOSLOT && (local[u] & GYS_LOCAL_GROUP)) {
+						uint32_t e32, e128[4] = {0u, 0u, 0u, 0u}, lc = 0, sl = 0;
+						if (V6) {
+							const uint32_t o = (uint32_t)(g + u) * T + tid;
+							const uint64_t x0 = tb[GYS_EV6_WORDS * o], x1 = tb[GYS_EV6_WORDS * o + 1u];
+							e128[0] = (uint32_t)x0; e128[1] = (uint32_t)(x0 >> 32); e128[2] = (uint32_t)x1; e128[3] = (uint32_t)(x1 >> 32);
+							e32 = ip6_embedded_v4(e128);
+						} else {
+							e32 = (uint32_t)w0[u]; // saddr: GY_IP_ADDR(uint32_t) (:1529)
+						}
+						local[u] = cand_resolve(p.cand + hd.cand_off, local[u] & (GYS_LOCAL_GROUP - 1u), e32, e128, &lc, &sl) ? lc : GYS_NOSLOT;
+					}
+				}
+			}
 			uint32_t nwd[4], nlr[4], hidx[4], hrank[4], hcur[4], rare = 0;
 			bool kept[4];
 #pragma unroll
@@ -1023,7 +1119,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				const uint32_t dport = (uint32_t)bswap16((uint16_t)(w1[u] >> 48));
-				nwd[u] = kept[u] ? ((tresp[u] << GYS_ROW_BITS) | (dport & 0x1Fu)) : GYS_EV_DROPPED;
+				nwd[u] = kept[u] ? ((tresp[u] << GYS_ROW_BITS) | (V6 ? GYS_ROW_V6 : 0u) | (dport & 0x1Fu)) : GYS_EV_DROPPED;
 				bk[u] = 15u; // (s_gh[.][15] is a spare cell)
 				if (!SPILL) {
 					const uint32_t b = resp_bucket_lut(s_bk, tresp[u]); // (read for every lane: no branch)
@@ -1058,7 +1154,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 					// ends hash as 7 / 10 words; the per-service registers need all 64 bits) is rare or a non-default configuration and
 					// goes through ONE rolled copy of the general code below
 					if (DBG && (p.dbg & 4u)) {
-					} else if (!SVCHLL && daddr != 0 && saddr != 0) {
+					} else if (!V6 && !SVCHLL && daddr != 0 && saddr != 0) {
 						uint32_t ix, rk;
 						flow_hll_idx_rank(daddr, dport, saddr, sport, &ix, &rk);
 						const bool up = kept[u] && rk > hll_floor; // (a rank at or below the floor cannot raise any register)
@@ -1074,13 +1170,22 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 				for (uint32_t u = 0; u < 4u; ++u) {
 					if (!((rare >> u) & 1u)) continue;
 					const uint32_t o = ((uint32_t)g + u) * T + tid;
-					const uint64_t x0 = tb[3u * o], x1 = tb[3u * o + 1u]; // (re-read: keeps the four events' words out of this loop's registers)
-					const uint32_t saddr = (uint32_t)x0, daddr = (uint32_t)(x0 >> 32);
-					const uint16_t sport = bswap16((uint16_t)(x1 >> 32)), dport = bswap16((uint16_t)(x1 >> 48));
-					const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
+					uint64_t h64;
+					if (V6) {
+						const uint64_t a0 = tb[GYS_EV6_WORDS * o], a1 = tb[GYS_EV6_WORDS * o + 1u], d0 = tb[GYS_EV6_WORDS * o + 2u], d1 = tb[GYS_EV6_WORDS * o + 3u],
+							       x4 = tb[GYS_EV6_WORDS * o + 4u];
+						const uint32_t sa[4] = {(uint32_t)a0, (uint32_t)(a0 >> 32), (uint32_t)a1, (uint32_t)(a1 >> 32)};
+						const uint32_t da[4] = {(uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32)};
+						h64 = flow_hash64_v6(da, bswap16((uint16_t)(x4 >> 48)), sa, bswap16((uint16_t)(x4 >> 32)));
+					} else {
+						const uint64_t x0 = tb[3u * o], x1 = tb[3u * o + 1u]; // (re-read: keeps the four events' words out of this loop's registers)
+						const uint32_t saddr = (uint32_t)x0, daddr = (uint32_t)(x0 >> 32);
+						const uint16_t sport = bswap16((uint16_t)(x1 >> 32)), dport = bswap16((uint16_t)(x1 >> 48));
+						h64 = flow_hash64(daddr, dport, saddr, sport);
+					}
 					uint32_t idx, rank;
 					hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
-					if (SVCHLL) {
+					if (SVCHLL && p.svc_hll_p) {
 						const uint32_t l = u == 0u ? nlr[0] : u == 1u ? nlr[1] : u == 2u ? nlr[2] : nlr[3];
 						svc_hll_update(p.svc_hll, p.svc_hll_p, s_slot[l], h64);
 					}
@@ -1352,7 +1457,7 @@ struct DigestP {
 	uint32_t pcap, nsvc;
 	const uint32_t *staged;
 	gys_hist_rec *hist_win, *hist_all;
-	uint32_t *bitmap;   // [nsvc*16] u32 = 32 x u16 CONN_BITMAP rows (common/gy_socket_stat.h:390-454)
+	uint32_t *bitmap;   // [nsvc*GYS_BM_WORDS] u32 = 32 x u16 CONN_BITMAP rows of resp_bitmap_v4_, then of resp_bitmap_v6_ (common/gy_socket_stat.h:390-454)
 };
 
 // wave-synchronous LDS hand-off: DS operations of one wave execute in order; this only stops the compiler from moving them
@@ -1373,7 +1478,7 @@ struct DigestP {
 //   window record: a record of an older window is dropped first (the reference clears the 5-s state on its timer,
 //   GY_HISTOGRAM::clear :630-636; here a key rolls when the first values of a later window are folded), then += dw; same for the rows.
 __device__ __forceinline__ void fold_records(const DigestP &p, uint32_t slot, uint32_t g, bool roll, unsigned long long da, unsigned long long dw,
-					     uint32_t n_all, uint32_t n_win, int32_t max_all, int32_t max_win, uint32_t bm)
+					     uint32_t n_all, uint32_t n_win, int32_t max_all, int32_t max_win, uint32_t bm, uint32_t bm6)
 {
 	uint4 *ap = (uint4 *)&p.hist_all[slot] + g, *wp = (uint4 *)&p.hist_win[slot] + g;
 	if (n_all) {
@@ -1403,9 +1508,13 @@ __device__ __forceinline__ void fold_records(const DigestP &p, uint32_t slot, ui
 			if ((int64_t)hi < (int64_t)max_win) hi = (uint64_t)(int64_t)max_win;
 		}
 		if (roll || g == 15u || dw) *wp = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-		uint32_t *bp = &p.bitmap[(size_t)slot * 16u + g];
+		uint32_t *bp = &p.bitmap[(size_t)slot * GYS_BM_WORDS + g];
 		const uint32_t old = roll ? 0u : *bp;
 		if (roll || (old | bm) != old) *bp = old | bm;
+		// the IPv6 rows (resp_bitmap_v6_) sit behind the IPv4 ones in the same 128-byte line; a roll has to clear what an earlier window left
+		const uint32_t old6 = bp[16];
+		const uint32_t new6 = (roll ? 0u : old6) | bm6;
+		if (new6 != old6) bp[16] = new6;
 	}
 }
 
@@ -1421,7 +1530,7 @@ __global__ __launch_bounds__(256) void k_fold(FoldP q)
 {
 	const DigestP &p = q.d;
 	__shared__ unsigned long long s_a_[16][16], s_w_[16][16];
-	__shared__ uint32_t s_bm_[16][16];
+	__shared__ uint32_t s_bm_[16][GYS_BM_WORDS];
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	const uint32_t row = lane >> 4, g = lane & 15u;
 	unsigned long long *s_a = s_a_[wv * 4u + row], *s_w = s_w_[wv * 4u + row];
@@ -1448,6 +1557,7 @@ __global__ __launch_bounds__(256) void k_fold(FoldP q)
 			s_a[g] = 0;
 			s_w[g] = 0;
 			s_bm[g] = 0;
+			s_bm[g + 16u] = 0;
 			GYS_WAVE_SYNC();
 			const uint32_t *pend = p.td_pend + (size_t)slot * p.pcap;
 			const uint32_t mmax = max(max((uint32_t)__shfl((int)m, 0, 64), (uint32_t)__shfl((int)m, 16, 64)),
@@ -1465,7 +1575,7 @@ __global__ __launch_bounds__(256) void k_fold(FoldP q)
 					lmax = max(lmax, v);
 					if (i >= nwin0) {
 						atomicAdd(&s_w[b], one);
-						const uint32_t r = w & 0x1Fu; // CONN_BITMAP::add_response: respmap_[row].set(bucket) (common/gy_socket_stat.h:403-410)
+						const uint32_t r = w & GYS_ROW_MASK; // CONN_BITMAP::add_response: respmap_[row].set(bucket) (common/gy_socket_stat.h:403-410); rows 32..63: resp_bitmap_v6_
 						atomicOr(&s_bm[r >> 1], (1u << b) << ((r & 1u) * 16u));
 						wmax = max(wmax, v);
 					}
@@ -1481,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_fold(FoldP q)
 			if (m) {
 				const uint32_t n_win = npend > nwin0 ? npend - nwin0 : 0u;
 				const bool roll = mt.w != mt.z;
-				fold_records(p, slot, g, roll, s_a[g], s_w[g], m, n_win, lmax, wmax, s_bm[g]);
+				fold_records(p, slot, g, roll, s_a[g], s_w[g], m, n_win, lmax, wmax, s_bm[g], s_bm[g + 16u]);
 				if (g == 0) {
 					*(uint4 *)&p.td_meta[slot] = make_uint4(npend, npend | (nw << 16), mt.z, n_win ? mt.z : mt.w);
 					const int2 mm = p.td_minmax[slot];
@@ -1563,7 +1673,7 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 	__shared__ uint32_t s_ioff[GYS_IVL + 1];  // exclusive prefix of s_icnt (s_ioff[i + 1] = values in intervals 0..i)
 	__shared__ uint32_t s_clt[GYS_IVL];       // s_clt[c + 1] = values below the mean of compacted cluster c (prefix of the per-cluster-gap counts)
 	__shared__ unsigned long long s_fa[16], s_fw[16]; // fold: packed bucket deltas of the not yet folded values (all / window part)
-	__shared__ uint32_t s_fbm[16];
+	__shared__ uint32_t s_fbm[GYS_BM_WORDS];
 	__shared__ int32_t s_fmm[3];              // fold: min, max (all), max (window part)
 	__shared__ uint32_t s_wv[2 * (NT / 64) + 2];
 	__shared__ uint64_t s_ww[NT / 64];
@@ -1638,6 +1748,7 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 			s_fa[tid] = 0;
 			s_fw[tid] = 0;
 			s_fbm[tid] = 0;
+			s_fbm[tid + 16u] = 0;
 		}
 		if (tid == 0) {
 			s_fmm[0] = INT32_MAX;
@@ -1678,7 +1789,7 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 					lmax = max(lmax, (int32_t)uv);
 					if (i >= nwin0) {
 						atomicAdd(&s_fw[b], one);
-						const uint32_t r = word & 0x1Fu;
+						const uint32_t r = word & GYS_ROW_MASK;
 						atomicOr(&s_fbm[r >> 1], (1u << b) << ((r & 1u) * 16u));
 						wmax = max(wmax, (int32_t)uv);
 					}
@@ -1768,7 +1879,7 @@ __global__ __launch_bounds__(NT) void k_digest_merge(MergeP q)
 		}
 		if (!query) {
 			const uint32_t n_all = m - nh, n_win = m > nwin0 ? m - nwin0 : 0u;
-			if (tid < 16u && n_all) fold_records(p, slot, tid, mt.w != mt.z, s_fa[tid], s_fw[tid], n_all, n_win, s_fmm[1], s_fmm[2], s_fbm[tid]);
+			if (tid < 16u && n_all) fold_records(p, slot, tid, mt.w != mt.z, s_fa[tid], s_fw[tid], n_all, n_win, s_fmm[1], s_fmm[2], s_fbm[tid], s_fbm[tid + 16u]);
 			if (tid == 16u) {
 				*(uint4 *)&p.td_meta[slot] = make_uint4(0u, 0u, mt.z, n_win ? mt.z : mt.w); // buffer drained
 				p.td_cur[slot] = 0;
@@ -1878,7 +1989,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 	__shared__ unsigned long long s_oval[GYS_TD_NB]; // the VALUES that land in an output cluster: {count : 24 | sum : 40}, one LDS atomic per value
 #endif
 	__shared__ unsigned long long s_fa[16], s_fw[16];
-	__shared__ uint32_t s_fbm[16];
+	__shared__ uint32_t s_fbm[GYS_BM_WORDS];
 	__shared__ int32_t s_fmm[3];
 	__shared__ uint32_t s_wv[4], s_ws[4], s_nbig;
 	__shared__ uint64_t s_ww[4];
@@ -1961,6 +2072,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			s_fa[tid] = 0;
 			s_fw[tid] = 0;
 			s_fbm[tid] = 0;
+			s_fbm[tid + 16u] = 0;
 		}
 		if (tid == 0) {
 			s_fmm[0] = INT32_MAX;
@@ -2034,7 +2146,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 					if (big || !fold_scan) atomicAdd(&s_fa[b], one);
 					if (win) {
 						atomicAdd(&s_fw[b], one);
-						const uint32_t r = wd[k] & 0x1Fu;
+						const uint32_t r = wd[k] & GYS_ROW_MASK;
 						atomicOr(&s_fbm[r >> 1], (1u << b) << ((r & 1u) * 16u));
 						wmax = max(wmax, (int32_t)uv);
 					}
@@ -2266,7 +2378,7 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		if (!query) {
 			const uint32_t n_all = m - nh, n_win = m > nwin0 ? m - nwin0 : 0u;
 			if (tid >= 192u && tid < 208u && n_all)
-				fold_records(p, slot, tid - 192u, mt.w != mt.z, s_fa[tid - 192u], s_fw[tid - 192u], n_all, n_win, s_fmm[1], s_fmm[2], s_fbm[tid - 192u]);
+				fold_records(p, slot, tid - 192u, mt.w != mt.z, s_fa[tid - 192u], s_fw[tid - 192u], n_all, n_win, s_fmm[1], s_fmm[2], s_fbm[tid - 192u], s_fbm[tid - 176u]);
 			if (tid == 208u) {
 				*(uint4 *)&p.td_meta[slot] = make_uint4(0u, 0u, mt.z, n_win ? mt.z : mt.w); // buffer drained
 				p.td_cur[slot] = 0;
@@ -2302,7 +2414,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 	__shared__ uint32_t s_part[256];
 	__shared__ uint32_t s_wave[4];
 	__shared__ unsigned long long s_ha[32], s_hw[32]; // exact {count, sum} per bucket of all values / of the window part
-	__shared__ uint32_t s_bm[16];
+	__shared__ uint32_t s_bm[GYS_BM_WORDS];
 	__shared__ uint32_t s_nc;
 	__shared__ int32_t s_min, s_max, s_wmax;
 	uint32_t *bins = p.scratch + (size_t)blockIdx.x * GYS_HUGE_BINS;
@@ -2328,7 +2440,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 			s_ha[threadIdx.x] = 0;
 			s_hw[threadIdx.x] = 0;
 		}
-		if (threadIdx.x >= 160u && threadIdx.x < 176u) s_bm[threadIdx.x - 160u] = 0;
+		if (threadIdx.x >= 160u && threadIdx.x < 160u + GYS_BM_WORDS) s_bm[threadIdx.x - 160u] = 0;
 		if (threadIdx.x == 0) {
 			// compact non-empty old clusters (serial: <= 200 entries, once per huge key)
 			const int64_t *gs = p.d.td_sum + (size_t)slot * GYS_TD_NB;
@@ -2372,7 +2484,7 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 					if (i >= nwin0) {
 						atomicAdd(&s_hw[2 * hb], 1ull);
 						atomicAdd(&s_hw[2 * hb + 1], (unsigned long long)v);
-						const uint32_t row = word & 0x1Fu;
+						const uint32_t row = word & GYS_ROW_MASK;
 						const uint32_t bit = (1u << hb) << ((row & 1u) * 16u);
 						if ((s_bm[row >> 1] & bit) == 0) atomicOr(&s_bm[row >> 1], bit);
 						wmax = max(wmax, (int32_t)v);
@@ -2498,8 +2610,9 @@ __global__ __launch_bounds__(256) void k_digest_huge(HugeP p)
 						if (wv.sum < (int64_t)s_wmax) wv.sum = (int64_t)s_wmax;
 					}
 					*wp = wv;
-					uint32_t *bp = &p.d.bitmap[(size_t)slot * 16u + t];
+					uint32_t *bp = &p.d.bitmap[(size_t)slot * GYS_BM_WORDS + t];
 					*bp = (roll ? 0u : *bp) | s_bm[t];
+					bp[16] = (roll ? 0u : bp[16]) | s_bm[t + 16u];
 				}
 			}
 			__syncthreads(); // every reader of the meta record is done before thread 0 rewrites it
@@ -3573,7 +3686,7 @@ struct ListenerScanP {
 	int mode[GYS_NLEVELS];               // per level: 0 cumulative - sub, 1 empty, 2 copy of sub (level 0: the last closed window)
 	const gys_hist_rec *sub[GYS_NLEVELS];
 	const gys_hist_rec *qps, *act;
-	const uint32_t *bitmap;              // [nsvc * 16] u32 = 32 x u16 rows
+	const uint32_t *bitmap;              // [nsvc * GYS_BM_WORDS] u32 = 32 x u16 IPv4 rows, 32 x u16 IPv6 rows
 	const uint64_t *svc_gid;
 	float multiple;                      // TCP_SOCK_HANDLER::get_bpf_qps_multiple()
 	float diffsec;
@@ -3660,11 +3773,12 @@ __global__ __launch_bounds__(256) void k_listener_scan(ListenerScanP p)
 	// CONN_BITMAP::get_conn_breakup (common/gy_socket_stat.h:413-429): per response bucket the rows (client port & 31) that saw it in
 	// the window just closed; curr_active_conn = their maximum (:4143-4156; the inet_diag count it starts from is agent-side state)
 	if (p.meta ? p.meta[slot].hw_epoch == p.epoch_last : true) {
-		uint32_t w[16];
-		for (int i = 0; i < 16; ++i) w[i] = p.bitmap[(size_t)slot * 16u + i];
+		// (nactive_conn_arr_[r] = ipv4_conn[r] + ipv6_conn[r], :4147: the IPv6 rows are words 16..31 of the service)
+		uint32_t w[GYS_BM_WORDS];
+		for (uint32_t i = 0; i < GYS_BM_WORDS; ++i) w[i] = p.bitmap[(size_t)slot * GYS_BM_WORDS + i];
 		for (int r = 0; r < 15; ++r) {
 			uint32_t n = 0;
-			for (int i = 0; i < 16; ++i) n += ((w[i] >> r) & 1u) + ((w[i] >> (16 + r)) & 1u);
+			for (uint32_t i = 0; i < GYS_BM_WORDS; ++i) n += ((w[i] >> r) & 1u) + ((w[i] >> (16 + r)) & 1u);
 			o.nactive_conn_arr[r] = (uint8_t)n;
 			if (o.nconn_active < n) o.nconn_active = (uint8_t)n;
 		}

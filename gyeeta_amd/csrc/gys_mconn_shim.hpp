@@ -13,6 +13,7 @@
 //                             int nconns, uint8_t *pendptr, POOL_ALLOC_ARRAY*, PGConnPool&, bool) :2129
 //   void send_cluster_state() noexcept                                                    :2155  send_cluster_state_rccl(tusec) (RCCL inside the library) / send_cluster_state(tusec, reduce_cb)
 //   TCP_SOCK_HANDLER::handle_ipv4_resp_event(tcp_ipv4_resp_event_t*, bool) (gy_socket_stat.cc:1517)  handle_ipv4_resp_events(machine_id, pevents, n)
+//   TCP_SOCK_HANDLER::handle_ipv6_resp_event(tcp_ipv6_resp_event_t*, bool) (gy_socket_stat.cc:1535)  handle_ipv6_resp_events(machine_id, pevents, n)
 //   web_curr_listener_summ (server/gy_mnodehandle.cc:1628)                                       get_listener_summ(machine_id, out)
 //   bool handle_partha_active_conns(const std::shared_ptr<PARTHA_INFO>&, const comm::ACTIVE_CONN_STATS*,  handle_partha_active_conns(machine_id, pconn, nitems, pendptr)
 //                             int nitems, uint8_t *pendptr, PGConnPool&)                 :2039 (.cc:7705, dispatch :5244)
@@ -116,6 +117,13 @@ public:
 	{
 		std::shared_lock<std::shared_mutex> g(mu_);
 		return gys_ingest_resp_events(ctx_, machine_id, pevents, nevents) == GYS_OK;
+	}
+
+	// TCP_SOCK_HANDLER::handle_ipv6_resp_event (gy_socket_stat.cc:1535) for a batch of raw 48-byte tcp_ipv6_resp_event_t of one host
+	bool handle_ipv6_resp_events(const uint8_t machine_id[16], const void *pevents, uint32_t nevents) noexcept
+	{
+		std::shared_lock<std::shared_mutex> g(mu_);
+		return gys_ingest_resp_events_v6(ctx_, machine_id, pevents, nevents) == GYS_OK;
 	}
 
 	// MCONN_HANDLER::send_cluster_state (scheduled every 5000 ms, gy_mconnhdlr.cc:207-210) + the shyama-side aggregation

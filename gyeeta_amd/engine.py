@@ -105,7 +105,8 @@ class SketchEngine:
     def owns(self, machine_id):
         return self.L.gys_shard_of(mid_buf(machine_id), self.nranks) == self.rank
 
-    def register_listeners(self, machine_id, glob_ids, netns, ports, comm=b"svc"):
+    def register_listeners(self, machine_id, glob_ids, netns, ports, comm=b"svc", addrs=None):
+        """addrs: per listener None (an any-address listener: NEW_LISTENER::is_any_ip_) or the 4 / 16 address bytes it is bound to"""
         n = len(glob_ids)
         arr = (capi.ListenerInfo * n)()
         for i in range(n):
@@ -113,16 +114,24 @@ class SketchEngine:
             arr[i].netns = int(netns[i])
             arr[i].port = int(ports[i])
             arr[i].comm = comm
+            a = addrs[i] if addrs is not None else None
+            arr[i].is_any_ip = 1 if a is None else 0
+            if a is not None:
+                a = bytes(a)
+                arr[i].addr_is_v6 = 1 if len(a) == 16 else 0
+                arr[i].addr = (C.c_uint8 * 16)(*(a + bytes(16))[:16])
         first = C.c_uint32()
         capi.check(self.L.gys_register_listeners(self.h, mid_buf(machine_id), arr, n, C.byref(first)))
         return first.value
 
+    LISTENER_INFO_DT = np.dtype([("glob_id", "<u8"), ("netns", "<u4"), ("port", "<u2"), ("is_any_ip", "u1"), ("addr_is_v6", "u1"), ("comm", "S16"),
+                                 ("addr", "u1", (16,))])
+
     def register_listeners_np(self, machine_id, glob_ids, netns, ports):
-        """bulk variant: fills the gys_listener_info array through numpy (no per-element python loop)"""
+        """bulk variant: fills the gys_listener_info array through numpy (no per-element python loop); any-address listeners"""
         n = len(glob_ids)
-        dt = np.dtype([("glob_id", "<u8"), ("netns", "<u4"), ("port", "<u2"), ("reserved", "<u2"), ("comm", "S16")])
-        a = np.zeros(n, dtype=dt)
-        a["glob_id"], a["netns"], a["port"], a["comm"] = glob_ids, netns, ports, b"svc"
+        a = np.zeros(n, dtype=self.LISTENER_INFO_DT)
+        a["glob_id"], a["netns"], a["port"], a["comm"], a["is_any_ip"] = glob_ids, netns, ports, b"svc", 1
         first = C.c_uint32()
         capi.check(self.L.gys_register_listeners(self.h, mid_buf(machine_id), a.ctypes.data_as(C.POINTER(capi.ListenerInfo)), n, C.byref(first)))
         return first.value
@@ -132,6 +141,15 @@ class SketchEngine:
         """TCP_SOCK_HANDLER::handle_ipv4_resp_event for a host batch (numpy RESP_EVENT array or bytes)"""
         b = events.tobytes() if hasattr(events, "tobytes") else bytes(events)
         capi.check(self.L.gys_ingest_resp_events(self.h, mid_buf(machine_id), b, len(b) // 24))
+
+    def handle_resp_events_v6(self, machine_id, events):
+        """TCP_SOCK_HANDLER::handle_ipv6_resp_event for a host batch (numpy RESP_EVENT6 array or bytes)"""
+        b = events.tobytes() if hasattr(events, "tobytes") else bytes(events)
+        capi.check(self.L.gys_ingest_resp_events_v6(self.h, mid_buf(machine_id), b, len(b) // 48))
+
+    def handle_resp_events_v6_dev(self, segs, d_ev, nevents):
+        self.order()
+        capi.check(self.L.gys_ingest_resp_events_v6_dev(self.h, segs, len(segs), C.c_void_p(d_ev), nevents))
 
     def handle_resp_events_dev(self, segs, d_ev, nevents):
         self.order()
@@ -555,7 +573,7 @@ class SketchEngine:
 
     def export_conn_bitmap(self, first=0, n=None):
         n = self.num_services() - first if n is None else n
-        out = np.zeros((n, 32), dtype=np.uint16)
+        out = np.zeros((n, 64), dtype=np.uint16)  # rows 0..31: resp_bitmap_v4_, 32..63: resp_bitmap_v6_
         capi.check(self.L.gys_export_conn_bitmap(self.h, first, n, C.c_void_p(out.ctypes.data)))
         return out
 

@@ -38,6 +38,11 @@ assert LISTENER_STATE_NOTIFY.fields["curr_state"][1] == 79 and LISTENER_STATE_NO
 RESP_EVENT = np.dtype([("saddr", "<u4"), ("daddr", "<u4"), ("netns", "<u4"), ("sport_be", ">u2"), ("dport_be", ">u2"),
                        ("lsndtime", "<u4"), ("lrcvtime", "<u4")])
 assert RESP_EVENT.itemsize == 24
+# tcp_ipv6_resp_event_t (common/gy_ebpf_kernel.h:113-118; ipv6_tuple_t partha/gy_ebpf_kernel_struct.h:37-44): 16-byte saddr / daddr, the rest
+# laid out as in the IPv4 event
+RESP_EVENT6 = np.dtype([("saddr", "u1", (16,)), ("daddr", "u1", (16,)), ("netns", "<u4"), ("sport_be", ">u2"), ("dport_be", ">u2"),
+                        ("lsndtime", "<u4"), ("lrcvtime", "<u4")])
+assert RESP_EVENT6.itemsize == 48
 
 LISTEN_FLAG_DELETE = 0xC0
 

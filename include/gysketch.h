@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GYS_ABI_VERSION 5
+#define GYS_ABI_VERSION 6
 
 enum {
 	GYS_OK = 0,
@@ -121,9 +121,23 @@ typedef struct {
 	uint64_t glob_id;   /* TCP_LISTENER::glob_id_ (opaque 64-bit id on the wire) */
 	uint32_t netns;     /* network namespace inode as carried by the eBPF tuple (partha/gy_ebpf_kernel_struct.h:28-35) */
 	uint16_t port;      /* listener port, host order */
-	uint16_t reserved;
+	uint8_t is_any_ip;  /* comm::NEW_LISTENER::is_any_ip_ (common/gy_comm_proto.h:1539; TCP_LISTENER::is_any_ip_ = addr.is_any_address(),
+	                       common/gy_socket_stat.cc:1796): non-zero = the listener takes the events of every address of its (netns, port) */
+	uint8_t addr_is_v6; /* is_any_ip == 0: addr is an in6_addr (16 bytes) when non-zero, else an in_addr in addr[0..3] (network order) */
 	char comm[16];      /* TASK_COMM_LEN process name (LISTEN_TOPN::comm_) */
+	uint8_t addr[16];   /* is_any_ip == 0: the address the listener is bound to -- NEW_LISTENER::ns_ip_port_.ip_port_.ipaddr_.  A response event
+	                       reaches the listener only when its server address equals this one the way GY_IP_ADDR::operator== compares
+	                       (common/gy_common_inc.h:10629-10636: an IPv6 address that embeds an IPv4 one -- ::ffff:a.b.c.d, 2002::/16,
+	                       64:ff9b::/32 -- equals that IPv4 address); ignored when is_any_ip != 0 */
 } gys_listener_info;
+
+/* Listener lookup of a response event (replaces listener_tbl_.lookup_single_elem(ser_nsipport, hash ignoring the IP) with the comparator
+ * operator==(shared_ptr<TCP_LISTENER>, NS_IP_PORT), common/gy_socket_stat.cc:1671, common/gy_socket_stat.h:708-714): among the listeners
+ * registered for the host with the event's (netns, server port), in registration order, the first one that is_any_ip or is bound to the
+ * event's server address takes the event; if none does the event is dropped (gys_counters.resp_dropped_nolistener).  Registration follows
+ * insert_or_replace (common/gy_socket_stat.cc:1372, :7779): a new listener REPLACES, in place, the first registered listener of its
+ * (netns, port) that is_any_ip or is bound to the same address -- that listener's slot keeps its state but gets no further response events
+ * -- and is appended behind the others otherwise. */
 
 /* assigns consecutive service slots [*first_slot, *first_slot + n) to the listeners the engine does not know yet.  A glob_id that is
  * already registered (a partha resends its listeners after a reconnect) keeps its slot and all of its state, and repeats inside one call
@@ -168,6 +182,19 @@ typedef struct {
 
 /* device-resident multi-host batch: d_ev24 is a DEVICE pointer to nevents 24-byte events; segs is a HOST array */
 int gys_ingest_resp_events_dev(gys_ctx *ctx, const gys_resp_seg *segs, uint32_t nsegs, const void *d_ev24, uint64_t nevents);
+
+/* IPv6 response events in the eBPF layout tcp_ipv6_resp_event_t (common/gy_ebpf_kernel.h:113-118, 48 bytes: ipv6_tuple_t
+ * {u128 saddr, u128 daddr, u32 netns, u16 sport, u16 dport (network order)} partha/gy_ebpf_kernel_struct.h:37-44, then lsndtime, lrcvtime).
+ * Replaces TCP_SOCK_HANDLER::handle_ipv6_resp_event (common/gy_socket_stat.cc:1535-1551) -> handle_tcp_resp_event(is_ipv4 = false): the same
+ * filter, listener lookup and RESP_TIME_HASH bucket as the IPv4 form; the histogram and the query count are the listener's shared ones
+ * (resp_cache_v6_ flushes into the same resp_hist_, :1800; curr_query_v4_ + curr_query_v6_, :4050-4051), the CONN_BITMAP rows are the
+ * listener's resp_bitmap_v6_ (:1587; rows 32..63 of gys_export_conn_bitmap, added to the IPv4 rows' counts per bucket as :4144-4149 does).
+ * Flow key: PAIR_IP_PORT(daddr:dport, saddr:sport) with both addresses through GY_IP_ADDR(unsigned __int128) -- an address that embeds an
+ * IPv4 one hashes and compares as that IPv4 address (common/gy_common_inc.h:11040-11129, :10950-10959).  The reference has one perf buffer and
+ * one handler thread per family (PROBE_TCP_RESPONSE_IPv4 / _IPv6, common/gy_socket_stat.cc:101-102): a stream is handed over as calls of
+ * one family each.  The host-pointer form is its own submission (it does not join the IPv4 submission queue, it runs behind it). */
+int gys_ingest_resp_events_v6(gys_ctx *ctx, const uint8_t machine_id[16], const void *ev48, uint32_t nevents);
+int gys_ingest_resp_events_v6_dev(gys_ctx *ctx, const gys_resp_seg *segs, uint32_t nsegs, const void *d_ev48, uint64_t nevents);
 
 /* Replaces MCONN_HANDLER::partha_tcp_conn_info(partha, TCP_CONN_NOTIFY *pone, int nconns, uint8_t *pendptr, ...)
  * (server/gy_mconnhdlr.h:2091, .cc:9052-9444): flow key PAIR_IP_PORT(nat_cli_, nat_ser_) (.cc:8707) -> distinct-flow HLL;
@@ -574,7 +601,8 @@ uint32_t gys_num_services(gys_ctx *ctx);
 uint32_t gys_num_hosts(gys_ctx *ctx);
 int gys_lookup_service(gys_ctx *ctx, uint64_t glob_id, uint32_t *slot);
 int gys_export_hist(gys_ctx *ctx, int which, uint32_t first_slot, uint32_t nslots, gys_hist_rec *out);
-int gys_export_conn_bitmap(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint16_t *out /* [nslots*32] */);
+/* CONN_BITMAP rows of the open window: per service 32 u16 rows of resp_bitmap_v4_ followed by the 32 rows of resp_bitmap_v6_ (common/gy_socket_stat.h:645, :665) */
+int gys_export_conn_bitmap(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint16_t *out /* [nslots*64] */);
 int gys_export_hll(gys_ctx *ctx, uint8_t *out /* [1 << GYS_HLL_P] */);
 int gys_export_cms(gys_ctx *ctx, int which, void *out /* which 0: u32[D*W]; which 1: i64[D*W] */);
 int gys_export_tdigest(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, int64_t *sums /* [nslots*100] */, uint32_t *cnts /* [nslots*100] */,

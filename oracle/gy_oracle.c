@@ -102,21 +102,60 @@ uint32_t gyo_jhash_1word(uint32_t a, uint32_t initval) { return gyo_jhash_3words
 uint32_t gyo_get_uint32_hash(uint32_t k) { return gyo_jhash_1word(k, GYO_SEED); }
 uint32_t gyo_get_uint64_hash(uint64_t k) { return gyo_jhash_2words((uint32_t)(k & 0xFFFFFFFFu), (uint32_t)(k >> 32), GYO_SEED); }
 
-/* GY_IP_ADDR::get_as_inaddr common/gy_common_inc.h:10950-10959: IPv4 (ip32_be_ != 0) -> 4 bytes else the 16 ip128 bytes.
- * An IPv4 address of 0.0.0.0 therefore hashes as 16 zero bytes ("IP Any Address will be considered as IPv6"). */
+/* GY_IP_ADDR as the reference builds it from raw address bytes: set_ip(uint32_t) common/gy_common_inc.h:10673-10679 (ip128_be_ = 0,
+ * ip32_be_ = the address) / set_ip(unsigned __int128) :10686-10692 (ip32_be_ = 0, then get_ipv6_type_flags() :11040-11129).  ip32_be_ and
+ * embedded_ipv4_ are ONE storage (the union at :10497-10500), and get_ipv6_type_flags stores the IPv4 address an IPv6 address embeds into
+ * embedded_ipv4_: 2002::/16 (6to4, bytes 2..5 :11064-11069), ::ffff:a.b.c.d (bytes 12..15 :11079-11094), 64:ff9b::/32 (NAT64, bytes 12..15
+ * :11096-11104) -- checked in that order, after :: (:11047-11050) and ::1 (:11052-11060), and an address of 2000::/4 that is not 2002::/16
+ * returns before the later checks (:11062-11077).  Such an address therefore carries ip32_be_ = the embedded IPv4 address.
+ * Out: *ip32 = ip32_be_ (as the 4 address bytes read as a native u32), ip128 = the 16 bytes of ip128_be_.  Returns is_any_address()
+ * (:10915-10918: ipflags_ & (IPv4_ANY | IPv6_ANY), i.e. 0.0.0.0 :11135-11138 or ::). */
+int gyo_ip_norm(const uint8_t *ip, int is_v6, uint32_t *ip32, uint8_t ip128[16])
+{
+	static const uint8_t zero[16];
+
+	if (!is_v6) {
+		memcpy(ip32, ip, 4);
+		memset(ip128, 0, 16);
+		return *ip32 == 0;
+	}
+	memcpy(ip128, ip, 16);
+	*ip32 = 0;
+	if (!memcmp(ip, zero, 16)) return 1;                                     /* IPv6_ANY */
+	if (!memcmp(ip, zero, 15) && ip[15] == 1) return 0;                      /* ::1 */
+	if ((ip[0] & 0xF0) == 0x20) {
+		if (ip[0] == 0x20 && ip[1] == 0x02) memcpy(ip32, ip + 2, 4);     /* 2002:: */
+		return 0;
+	}
+	if (!memcmp(ip, zero, 8) && ip[8] == 0 && ip[9] == 0 && ip[10] == 0xFF && ip[11] == 0xFF) { /* ::ffff:1.2.3.4 */
+		memcpy(ip32, ip + 12, 4);
+		return 0;
+	}
+	if (ip[0] == 0 && ip[1] == 0x64 && ip[2] == 0xFF && ip[3] == 0x9B) memcpy(ip32, ip + 12, 4); /* 64:ff9b:: */
+	return 0;
+}
+
+/* GY_IP_ADDR::operator== common/gy_common_inc.h:10629-10636: by ip32_be_ when either side has one, else by the 16 bytes */
+int gyo_ip_equal(uint32_t a32, const uint8_t a128[16], uint32_t b32, const uint8_t b128[16])
+{
+	if (a32 || b32) return a32 == b32;
+	return memcmp(a128, b128, 16) == 0;
+}
+
+/* GY_IP_ADDR::get_as_inaddr common/gy_common_inc.h:10950-10959: ip32_be_ != 0 -> those 4 bytes, else the 16 ip128 bytes.
+ * An IPv4 address of 0.0.0.0 therefore hashes as 16 zero bytes ("IP Any Address will be considered as IPv6"), and an IPv6 address that
+ * embeds an IPv4 one as that IPv4 address ("IPv4 Mapped IPv6 addresses will be returned as IPv4"). */
 static int gyo_inaddr(const uint8_t *ip, int is_v6, uint8_t *buf)
 {
-	if (!is_v6) {
-		uint32_t v4;
-		memcpy(&v4, ip, 4);
-		if (v4) {
-			memcpy(buf, ip, 4);
-			return 4;
-		}
-		memset(buf, 0, 16); /* set_ip(uint32) zeroes ip128_be_ gy_common_inc.h:10673-10679 */
-		return 16;
+	uint32_t ip32;
+	uint8_t ip128[16];
+
+	gyo_ip_norm(ip, is_v6, &ip32, ip128);
+	if (ip32) {
+		memcpy(buf, &ip32, 4);
+		return 4;
 	}
-	memcpy(buf, ip, 16); /* set_ip(__int128) sets ip32_be_ = 0 :10686-10692 */
+	memcpy(buf, ip128, 16);
 	return 16;
 }
 
@@ -401,6 +440,17 @@ void gyo_keyed_hist_ingest(int kind, const uint32_t *keyidx, const int32_t *vals
 
 /* CONN_BITMAP::add_response / get_conn_breakup common/gy_socket_stat.h:403-431 */
 void gyo_conn_bitmap_add(uint16_t respmap[32], uint16_t cli_port, uint8_t bucket) { respmap[cli_port & 0x1F] |= (uint16_t)(1u << bucket); }
+
+/* the listener's number per bucket: nactive_conn_arr_[r] = ipv4_conn[r] + ipv6_conn[r] (common/gy_socket_stat.cc:4141-4149) over
+ * resp_bitmap_v4_ (rows 0..31 here) and resp_bitmap_v6_ (rows 32..63) */
+void gyo_conn_bitmap_breakup2(const uint16_t respmap[64], uint8_t nconn_arr[15])
+{
+	uint8_t a[15], b[15];
+
+	gyo_conn_bitmap_breakup(respmap, a);
+	gyo_conn_bitmap_breakup(respmap + 32, b);
+	for (int j = 0; j < 15; j++) nconn_arr[j] = (uint8_t)(a[j] + b[j]);
+}
 
 void gyo_conn_bitmap_breakup(const uint16_t respmap[32], uint8_t nconn_arr[15])
 {

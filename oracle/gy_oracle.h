@@ -106,6 +106,9 @@ void gyo_keyed_hist_ingest(int kind, const uint32_t *keyidx, const int32_t *vals
 /* CONN_BITMAP (common/gy_socket_stat.h:390-454): respmap[32] of 15-bit masks, slot = cli_port & 0x1F */
 void gyo_conn_bitmap_add(uint16_t respmap[32], uint16_t cli_port, uint8_t bucket);
 void gyo_conn_bitmap_breakup(const uint16_t respmap[32], uint8_t nconn_arr[15]);
+void gyo_conn_bitmap_breakup2(const uint16_t respmap[64], uint8_t nconn_arr[15]);
+int gyo_ip_norm(const uint8_t *ip, int is_v6, uint32_t *ip32, uint8_t ip128[16]);
+int gyo_ip_equal(uint32_t a32, const uint8_t a128[16], uint32_t b32, const uint8_t b128[16]);
 
 /* ---------------------------------------------------------------- HLL / CMS (builder-defined, frozen in DESIGN.md) */
 #define GYO_HLL_P 14
@@ -286,7 +289,7 @@ typedef struct {
 	uint8_t reserved[5];
 } gyo_listener_scan;
 uint32_t gyo_bucketid_from_threshold(int kind, int64_t threshold);
-void gyo_listener_scan_one(const gyo_mlhist *resp, const gyo_hist *qps, const gyo_hist *act, const uint16_t respmap[32], uint64_t glob_id,
+void gyo_listener_scan_one(const gyo_mlhist *resp, const gyo_hist *qps, const gyo_hist *act, const uint16_t respmap[64], uint64_t glob_id,
 			   float multiple, int64_t diffsec, uint8_t notify[88], gyo_listener_scan *out);
 
 /* BOUNDED_PRIO_QUEUE<uint64_t, greater> (common/gy_statistics.h:356-383): returns retained values sorted descending */

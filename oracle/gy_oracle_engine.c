@@ -17,10 +17,16 @@ typedef struct gyo_engine {
 	uint32_t max_services, nsvc, mask;
 	int enable_td;
 	uint64_t *keys; /* listener keys, ~0 = empty */
-	uint32_t *vals;
+	uint32_t *vals; /* first listener (service slot) of the key's chain */
 	uint64_t *svc_gid;
+	/* the listeners of one (host, netns, port) key in registration order -- the order in which lookup_single_elem meets the nodes of one hash
+	 * chain (the table is hashed ignoring the IP, common/gy_socket_stat.cc:1671; liburcu appends a node behind the equal-hash nodes already
+	 * there -- not part of the reference tree, restated from its published behaviour); l_next = next listener of the key, ~0 = end */
+	uint32_t *l_next, *l_ip32;
+	uint8_t *l_ip128; /* [nsvc*16] */
+	uint8_t *l_any;   /* TCP_LISTENER::is_any_ip_ */
 	gyo_hist_serial *hist; /* [nsvc*16]; slot 15 = {total_count, (int64) max_val_seen} */
-	uint16_t *bitmap;      /* [nsvc*32] */
+	uint16_t *bitmap;      /* [nsvc*64]: 32 rows of resp_bitmap_v4_, 32 rows of resp_bitmap_v6_ (common/gy_socket_stat.h:645, :665) */
 	uint8_t hll[GYO_HLL_M];
 	uint32_t *cms;         /* [D*W] */
 	gyo_hist_serial ghist[16];
@@ -46,7 +52,11 @@ gyo_engine *gyo_engine_new(uint32_t max_services, int enable_td)
 	e->vals = (uint32_t *)calloc(cap, 4);
 	e->svc_gid = (uint64_t *)calloc(max_services, 8);
 	e->hist = (gyo_hist_serial *)calloc((size_t)max_services * 16, sizeof(gyo_hist_serial));
-	e->bitmap = (uint16_t *)calloc((size_t)max_services * 32, 2);
+	e->bitmap = (uint16_t *)calloc((size_t)max_services * 64, 2);
+	e->l_next = (uint32_t *)malloc((size_t)max_services * 4);
+	e->l_ip32 = (uint32_t *)calloc(max_services, 4);
+	e->l_ip128 = (uint8_t *)calloc((size_t)max_services, 16);
+	e->l_any = (uint8_t *)calloc(max_services, 1);
 	e->cms = (uint32_t *)calloc((size_t)GYO_CMS_D * GYO_CMS_W, 4);
 	e->gmax = LONG_MIN;
 	for (uint32_t s = 0; s < max_services; s++) e->hist[(size_t)s * 16 + 15].sum = LONG_MIN;
@@ -62,27 +72,68 @@ gyo_engine *gyo_engine_new(uint32_t max_services, int enable_td)
 void gyo_engine_free(gyo_engine *e)
 {
 	if (!e) return;
-	free(e->keys); free(e->vals); free(e->svc_gid); free(e->hist); free(e->bitmap); free(e->cms); free(e->td); free(e->bcnt); free(e->boff);
+	free(e->keys); free(e->vals); free(e->svc_gid); free(e->l_next); free(e->l_ip32); free(e->l_ip128); free(e->l_any); free(e->hist); free(e->bitmap); free(e->cms); free(e->td); free(e->bcnt); free(e->boff);
 	free(e);
+}
+
+/* A listener with an address.  Registration follows insert_or_replace (common/gy_socket_stat.cc:1372, :7779) under the table's comparator
+ * operator==(shared_ptr<TCP_LISTENER>, NS_IP_PORT) (common/gy_socket_stat.h:708-714): the first listener of the key that is_any_ip_ or is
+ * bound to the new listener's address is replaced IN PLACE (its position in the chain goes to the new listener, its own slot keeps its
+ * state but is no longer reachable); otherwise the new listener goes behind the others. */
+int gyo_engine_register_addr(gyo_engine *e, uint32_t host_slot, uint64_t glob_id, uint32_t netns, uint16_t port, const uint8_t *ip, int is_v6, int is_any)
+{
+	const uint64_t k = lkey(host_slot, netns, port);
+	uint32_t h = gyo_get_uint64_hash(k) & e->mask;
+	const uint32_t s = e->nsvc;
+	uint32_t n32 = 0;
+	uint8_t n128[16] = {0};
+
+	if (e->nsvc >= e->max_services) return -1;
+	if (!is_any) gyo_ip_norm(ip, is_v6, &n32, n128);
+	e->l_ip32[s] = n32;
+	memcpy(e->l_ip128 + (size_t)s * 16, n128, 16);
+	e->l_any[s] = (uint8_t)(is_any != 0);
+	e->l_next[s] = 0xFFFFFFFFu;
+	e->svc_gid[s] = glob_id;
+	while (e->keys[h] != ~0ull && e->keys[h] != k) h = (h + 1) & e->mask;
+	if (e->keys[h] == ~0ull) {
+		e->keys[h] = k;
+		e->vals[h] = s;
+	} else {
+		uint32_t *link = &e->vals[h];
+		for (;;) {
+			const uint32_t cur = *link;
+			if (cur == 0xFFFFFFFFu) { /* nobody matched: appended */
+				*link = s;
+				break;
+			}
+			if (e->l_any[cur] || gyo_ip_equal(e->l_ip32[cur], e->l_ip128 + (size_t)cur * 16, n32, n128)) { /* replaced in place */
+				e->l_next[s] = e->l_next[cur];
+				*link = s;
+				break;
+			}
+			link = &e->l_next[cur];
+		}
+	}
+	return (int)e->nsvc++;
 }
 
 int gyo_engine_register(gyo_engine *e, uint32_t host_slot, uint64_t glob_id, uint32_t netns, uint16_t port)
 {
-	const uint64_t k = lkey(host_slot, netns, port);
-	uint32_t h = gyo_get_uint64_hash(k) & e->mask;
-	if (e->nsvc >= e->max_services) return -1;
-	while (e->keys[h] != ~0ull && e->keys[h] != k) h = (h + 1) & e->mask;
-	e->keys[h] = k;
-	e->vals[h] = e->nsvc;
-	e->svc_gid[e->nsvc] = glob_id;
-	return (int)e->nsvc++;
+	return gyo_engine_register_addr(e, host_slot, glob_id, netns, port, NULL, 0, 1);
 }
 
-static uint32_t lookup(const gyo_engine *e, uint64_t k)
+/* listener_tbl_.lookup_single_elem(ser_nsipport, hash ignoring the IP) (common/gy_socket_stat.cc:1671): the first listener of the key for
+ * which operator==(listener, ser_nsipport) holds (common/gy_socket_stat.h:708-714); e32 / e128 = the event's server address as GY_IP_ADDR */
+static uint32_t lookup(const gyo_engine *e, uint64_t k, uint32_t e32, const uint8_t e128[16])
 {
 	uint32_t h = gyo_get_uint64_hash(k) & e->mask;
 	for (;;) {
-		if (e->keys[h] == k) return e->vals[h];
+		if (e->keys[h] == k) {
+			for (uint32_t s = e->vals[h]; s != 0xFFFFFFFFu; s = e->l_next[s])
+				if (e->l_any[s] || gyo_ip_equal(e->l_ip32[s], e->l_ip128 + (size_t)s * 16, e32, e128)) return s;
+			return 0xFFFFFFFFu;
+		}
 		if (e->keys[h] == ~0ull) return 0xFFFFFFFFu;
 		h = (h + 1) & e->mask;
 	}
@@ -111,16 +162,21 @@ static void cms_add_shared(uint32_t *tbl, const uint32_t *words, uint32_t nwords
 /* events [i0, i1) of a batch; seg = index of the segment containing i0.  slot_of / val_of (NULL without t-digests) get one entry
  * per event; bcnt[slot] counts the kept events of each service. */
 static void resp_range(gyo_engine *e, const uint8_t *ev24, uint64_t i0, uint64_t i1, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs,
-		       uint32_t seg, uint32_t *slot_of, int32_t *val_of, resp_sinks k)
+		       uint32_t seg, uint32_t *slot_of, int32_t *val_of, resp_sinks k, int v6)
 {
+	/* v6: 48-byte tcp_ipv6_resp_event_t (common/gy_ebpf_kernel.h:113-118): 16-byte saddr, 16-byte daddr, then netns / ports / times laid out
+	 * as in the 24-byte IPv4 event (handle_ipv6_resp_event common/gy_socket_stat.cc:1535-1551) */
+	const size_t stride = v6 ? 48 : 24, al = v6 ? 16 : 4;
 	for (uint64_t i = i0; i < i1; i++) {
-		const uint8_t *p = ev24 + i * 24;
-		uint32_t saddr, daddr, netns, lsnd, lrcv, tresp, slot, b;
+		const uint8_t *p = ev24 + i * stride;
+		const uint8_t *psaddr = p, *pdaddr = p + al, *q = p + 2 * al;
+		uint32_t netns, lsnd, lrcv, tresp, slot, b, s32;
 		uint16_t sport_be, dport_be, sport, dport;
+		uint8_t s128[16];
 
-		memcpy(&saddr, p, 4); memcpy(&daddr, p + 4, 4); memcpy(&netns, p + 8, 4);
-		memcpy(&sport_be, p + 12, 2); memcpy(&dport_be, p + 14, 2);
-		memcpy(&lsnd, p + 16, 4); memcpy(&lrcv, p + 20, 4);
+		memcpy(&netns, q, 4);
+		memcpy(&sport_be, q + 4, 2); memcpy(&dport_be, q + 6, 2);
+		memcpy(&lsnd, q + 8, 4); memcpy(&lrcv, q + 12, 4);
 		while (seg + 1 < nsegs && seg_first[seg + 1] <= i) seg++;
 		if (slot_of) slot_of[i] = 0xFFFFFFFFu;
 		k.counters[0]++;
@@ -131,7 +187,8 @@ static void resp_range(gyo_engine *e, const uint8_t *ev24, uint64_t i0, uint64_t
 		}
 		sport = bswap16(sport_be);                /* ntohs :1526-1527 */
 		dport = bswap16(dport_be);
-		slot = lookup(e, lkey(seg_host[seg], netns, sport)); /* listener_tbl_ lookup ignoring the IP :1671 */
+		gyo_ip_norm(psaddr, v6, &s32, s128);      /* NS_IP_PORT nsipport(pevent->tup.saddr, ...) :1529 / :1547 */
+		slot = lookup(e, lkey(seg_host[seg], netns, sport), s32, s128); /* listener_tbl_ lookup: hash ignoring the IP, comparator with it :1671 */
 		if (slot == 0xFFFFFFFFu) {
 			k.counters[2]++;
 			continue;
@@ -145,14 +202,14 @@ static void resp_range(gyo_engine *e, const uint8_t *ev24, uint64_t i0, uint64_t
 			h[15].count++;                    /* total_count_ */
 			if (h[15].sum < (int64_t)tresp) h[15].sum = (int64_t)tresp; /* max_val_seen_ */
 		}
-		gyo_conn_bitmap_add(&e->bitmap[(size_t)slot * 32], dport, (uint8_t)b); /* resp_bitmap_v4_.add_response */
+		gyo_conn_bitmap_add(&e->bitmap[(size_t)slot * 64 + (v6 ? 32 : 0)], dport, (uint8_t)b); /* resp_bitmap_v4_ / _v6_.add_response :1580, :1587 */
 		k.ghist[b].count++;
 		k.ghist[b].sum += (int64_t)tresp;
 		k.ghist[15].count++;
 		if (*k.gmax < (int64_t)tresp) *k.gmax = (int64_t)tresp;
 		{
 			uint32_t w[10];
-			const uint32_t nw = gyo_pair_ip_port_words((const uint8_t *)&daddr, 0, dport, (const uint8_t *)&saddr, 0, sport, w);
+			const uint32_t nw = gyo_pair_ip_port_words(pdaddr, v6, dport, psaddr, v6, sport, w);
 			gyo_hll_add_words(k.hll, GYO_HLL_P, w, nw);
 		}
 		/* Count-Min of events per service key: the table is linear in the per-service counts, so the event only counts (the
@@ -187,7 +244,7 @@ static resp_sinks own_sinks(gyo_engine *e)
 
 /* One batch of 24-byte tcp_ipv4_resp_event_t (common/gy_ebpf_kernel.h:106-111); segment s covers events
  * [seg_first[s], seg_first[s+1]) of host seg_host[s]. */
-void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs)
+static void resp_batch_fam(gyo_engine *e, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs, int v6)
 {
 	uint32_t *slot_of = NULL;
 	int32_t *val_of = NULL;
@@ -197,7 +254,7 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 		val_of = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
 	}
 	memset(e->bcnt, 0, (size_t)e->nsvc * 4);
-	resp_range(e, ev24, 0, n, seg_host, seg_first, nsegs, 0, slot_of, val_of, own_sinks(e));
+	resp_range(e, ev24, 0, n, seg_host, seg_first, nsegs, 0, slot_of, val_of, own_sinks(e), v6);
 	cms_from_counts(e, 0, e->nsvc, 0);
 	if (e->enable_td) {
 		/* buffered digest(key) <- add_batch(multiset of this batch's values of the key): append, or one merge of buffer + batch */
@@ -219,6 +276,18 @@ void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const
 		free(slot_of);
 		free(val_of);
 	}
+}
+
+void gyo_engine_resp_batch(gyo_engine *e, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs)
+{
+	resp_batch_fam(e, ev24, n, seg_host, seg_first, nsegs, 0);
+}
+
+/* One batch of 48-byte tcp_ipv6_resp_event_t (common/gy_ebpf_kernel.h:113-118) -- handle_ipv6_resp_event (common/gy_socket_stat.cc:1535-1551):
+ * the listener's shared histogram / query count / digest, its resp_bitmap_v6_ rows */
+void gyo_engine_resp_batch_v6(gyo_engine *e, const uint8_t *ev48, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs)
+{
+	resp_batch_fam(e, ev48, n, seg_host, seg_first, nsegs, 1);
 }
 
 /* The same batch on nthreads host threads ("all cores" CPU baseline): the segments (hosts) are cut into contiguous ranges, one per
@@ -251,7 +320,7 @@ static void *mt_pass1(void *arg)
 	if (w->s0 >= w->s1) return NULL;
 	const uint64_t i0 = w->seg_first[w->s0], i1 = w->s1 < w->nsegs ? w->seg_first[w->s1] : w->n;
 	resp_sinks k = {w->hll, w->e->cms, w->ghist, &w->gmax, w->counters, 0};
-	resp_range(w->e, w->ev24, i0, i1, w->seg_host, w->seg_first, w->nsegs, w->s0, w->slot_of, w->val_of, k);
+	resp_range(w->e, w->ev24, i0, i1, w->seg_host, w->seg_first, w->nsegs, w->s0, w->slot_of, w->val_of, k, 0);
 	return NULL;
 }
 
@@ -371,7 +440,12 @@ void gyo_engine_resp_batch_histonly(gyo_engine *e, const uint8_t *ev24, uint64_t
 		while (seg + 1 < nsegs && seg_first[seg + 1] <= i) seg++;
 		tresp = lsnd - lrcv;
 		if (tresp > 1000000u) continue;
-		slot = lookup(e, lkey(seg_host[seg], netns, bswap16(sport_be)));
+		{
+			uint32_t s32;
+			uint8_t s128[16];
+			gyo_ip_norm(p, 0, &s32, s128);
+			slot = lookup(e, lkey(seg_host[seg], netns, bswap16(sport_be)), s32, s128);
+		}
 		if (slot == 0xFFFFFFFFu) continue;
 		b = gyo_bucket(GYO_RESP_TIME_HASH, (int64_t)tresp);
 		{
@@ -381,7 +455,7 @@ void gyo_engine_resp_batch_histonly(gyo_engine *e, const uint8_t *ev24, uint64_t
 			h[15].count++;
 			if (h[15].sum < (int64_t)tresp) h[15].sum = (int64_t)tresp;
 		}
-		gyo_conn_bitmap_add(&e->bitmap[(size_t)slot * 32], bswap16(dport_be), (uint8_t)b);
+		gyo_conn_bitmap_add(&e->bitmap[(size_t)slot * 64], bswap16(dport_be), (uint8_t)b);
 	}
 }
 
@@ -397,7 +471,7 @@ const uint64_t *gyo_engine_counters(const gyo_engine *e) { return e->counters; }
 /* window roll: clear the windowed sketches (CONN_BITMAP secs_to_reset_ = 5; HLL/CMS are per window) keeping histograms/digests */
 void gyo_engine_window_clear(gyo_engine *e, int clear_hist)
 {
-	memset(e->bitmap, 0, (size_t)e->max_services * 64);
+	memset(e->bitmap, 0, (size_t)e->max_services * 128);
 	memset(e->hll, 0, sizeof(e->hll));
 	memset(e->cms, 0, (size_t)GYO_CMS_D * GYO_CMS_W * 4);
 	memset(e->ghist, 0, sizeof(e->ghist));

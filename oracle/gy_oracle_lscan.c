@@ -24,9 +24,9 @@ uint32_t gyo_bucketid_from_threshold(int kind, int64_t threshold)
 }
 
 /* One listener.  resp: its TIME_HISTOGRAM flushed to the scan time; qps / act: its QPS_HISTOGRAM / ACTIVE_CONN_HISTOGRAM;
- * respmap: its CONN_BITMAP rows of the window just closed; multiple / diffsec: get_bpf_qps_multiple() and the seconds since the
+ * respmap: its CONN_BITMAP rows of the window just closed (32 rows of resp_bitmap_v4_, then 32 of resp_bitmap_v6_); multiple / diffsec: get_bpf_qps_multiple() and the seconds since the
  * previous scan (:4046, :4109).  Fills the notify record's derivable fields (everything else zero) and the scan record. */
-void gyo_listener_scan_one(const gyo_mlhist *resp, const gyo_hist *qps, const gyo_hist *act, const uint16_t respmap[32], uint64_t glob_id,
+void gyo_listener_scan_one(const gyo_mlhist *resp, const gyo_hist *qps, const gyo_hist *act, const uint16_t respmap[64], uint64_t glob_id,
 			   float multiple, int64_t diffsec, uint8_t notify[88], gyo_listener_scan *out)
 {
 	static const float pcts[3] = {95.0f, 99.0f, 25.0f}; /* RESP_STATS::stats_ (common/gy_socket_stat.h:459-462) */
@@ -68,7 +68,7 @@ void gyo_listener_scan_one(const gyo_mlhist *resp, const gyo_hist *qps, const gy
 	}
 	/* :4143-4156: nactive_conn_arr_[r] = rows of the CONN_BITMAP with bit r; curr_active_conn = their maximum (the inet_diag count
 	 * nconn_recent_active_ it starts from is agent-side state the engine does not hold: it starts from 0) */
-	gyo_conn_bitmap_breakup(respmap, out->nactive_conn_arr);
+	gyo_conn_bitmap_breakup2(respmap, out->nactive_conn_arr); /* ipv4_conn[r] + ipv6_conn[r] :4144-4149 */
 	for (int r = 0; r < 15; r++)
 		if (out->nconn_active < out->nactive_conn_arr[r]) out->nconn_active = out->nactive_conn_arr[r];
 	/* :4293-4304 the notify record */

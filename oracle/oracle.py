@@ -222,6 +222,11 @@ def lib():
     _sig(L, "gyo_engine_free", None, [C.c_void_p])
     _sig(L, "gyo_engine_register", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint16])
     _sig(L, "gyo_engine_resp_batch", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
+    _sig(L, "gyo_engine_register_addr", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint16, u8p, C.c_int, C.c_int])
+    _sig(L, "gyo_engine_resp_batch_v6", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
+    _sig(L, "gyo_ip_norm", C.c_int, [u8p, C.c_int, u32p, u8p])
+    _sig(L, "gyo_ip_equal", C.c_int, [C.c_uint32, u8p, C.c_uint32, u8p])
+    _sig(L, "gyo_conn_bitmap_breakup2", None, [u16p, u8p])
     _sig(L, "gyo_engine_resp_batch_histonly", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
     _sig(L, "gyo_engine_resp_batch_mt", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32, C.c_uint32])
     _sig(L, "gyo_td_stress", None, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.POINTER(C.c_double)])
@@ -261,6 +266,10 @@ def ref():
     _sig(R, "ref_ns_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, C.c_uint64, C.c_int])
     _sig(R, "ref_pair_ip_port_hash", C.c_uint32, [u8p, C.c_int, C.c_uint16, u8p, C.c_int, C.c_uint16])
     _sig(R, "ref_machine_id_hash", C.c_uint32, [C.c_uint64, C.c_uint64])
+    if hasattr(R, "ref_ip_addr_norm"):
+        _sig(R, "ref_ip_addr_norm", C.c_int, [u8p, C.c_int, u32p, u8p, u8p, u32p])
+        _sig(R, "ref_ip_addr_equal", C.c_int, [u8p, C.c_int, u8p, C.c_int])
+        _sig(R, "ref_listener_match", C.c_int, [u8p, C.c_int, C.c_uint16, C.c_uint64, C.c_int, u8p, C.c_int, C.c_uint16, C.c_uint64])
     if hasattr(R, "ref_has_summ_stats"):
         _sig(R, "ref_has_summ_stats", C.c_int, [])
         if R.ref_has_summ_stats():
@@ -405,6 +414,20 @@ class OracleEngine:
         assert s >= 0
         return s
 
+    def register_addr(self, host_slot, glob_id, netns, port, addr=None, is_v6=False):
+        """addr: None = an any-address listener (is_any_ip_), else the 4 / 16 address bytes the listener is bound to"""
+        buf = (C.c_uint8 * 16)(*(bytes(addr) + bytes(16))[:16]) if addr is not None else (C.c_uint8 * 16)()
+        s = self.L.gyo_engine_register_addr(self.h, int(host_slot), int(glob_id), int(netns), int(port), buf, int(bool(is_v6)), int(addr is None))
+        assert s >= 0
+        return s
+
+    def resp_batch_v6(self, ev_bytes, seg_host, seg_first):
+        """48-byte tcp_ipv6_resp_event_t events"""
+        ev = np.frombuffer(ev_bytes, dtype=np.uint8)
+        sh = np.ascontiguousarray(seg_host, dtype=np.uint32)
+        sf = np.ascontiguousarray(seg_first, dtype=np.uint64)
+        self.L.gyo_engine_resp_batch_v6(self.h, ev.ctypes.data, len(ev) // 48, ptr(sh, u32p), ptr(sf, u64p), len(sh))
+
     def resp_batch(self, ev_bytes, seg_host, seg_first, histonly=False, nthreads=1):
         """nthreads > 1: the same batch with the segments (distinct hosts) cut into per-thread ranges; identical resulting state"""
         ev = np.frombuffer(ev_bytes, dtype=np.uint8)
@@ -429,7 +452,7 @@ class OracleEngine:
         return self._arr(self.L.gyo_engine_hist(self.h), np.int64, (self.nsvc, 16, 2))
 
     def bitmap(self):
-        return self._arr(self.L.gyo_engine_bitmap(self.h), np.uint16, (self.nsvc, 32))
+        return self._arr(self.L.gyo_engine_bitmap(self.h), np.uint16, (self.nsvc, 64))  # rows 0..31 resp_bitmap_v4_, 32..63 resp_bitmap_v6_
 
     def hll(self):
         return self._arr(self.L.gyo_engine_hll(self.h), np.uint8, (1 << HLL_P,))

@@ -171,6 +171,32 @@ uint32_t ref_pair_ip_port_hash(const uint8_t *cip, int c6, uint16_t cport, const
 	return PAIR_IP_PORT(IP_PORT(mk_ip(cip, c6), cport), IP_PORT(mk_ip(sip, s6), sport)).get_hash();
 }
 
+// GY_IP_ADDR built from raw address bytes the way the response-event handlers build theirs (GY_IP_ADDR(uint32_t) for tup.saddr,
+// common/gy_socket_stat.cc:1529; GY_IP_ADDR(unsigned __int128) :1547): its ip32_be_ (shared with embedded_ipv4_), its 16 ip128 bytes, what
+// get_as_inaddr hands to the hashes, and is_any_address()
+int ref_ip_addr_norm(const uint8_t *ip, int is_v6, uint32_t *ip32, uint8_t ip128[16], uint8_t inaddr[16], uint32_t *inaddr_len)
+{
+	const GY_IP_ADDR a = mk_ip(ip, is_v6);
+	*ip32 = a.get_ipv4_be();
+	const unsigned __int128 v6 = a.get_ipv6_addr_be();
+	std::memcpy(ip128, &v6, 16);
+	std::memset(inaddr, 0, 16);
+	*inaddr_len = (uint32_t)a.get_as_inaddr(inaddr);
+	return a.is_any_address() ? 1 : 0;
+}
+
+int ref_ip_addr_equal(const uint8_t *a, int a6, const uint8_t *b, int b6) { return mk_ip(a, a6) == mk_ip(b, b6); }
+
+// the comparator the listener table is searched with: operator==(const std::shared_ptr<TCP_LISTENER> &, const NS_IP_PORT &)
+// (common/gy_socket_stat.h:708-714).  TCP_LISTENER itself cannot be compiled here (its header needs liburcu / folly / the task handler);
+// the expression is evaluated on the reference's own NS_IP_PORT / GY_IP_ADDR objects: listener.ns_ip_port_ = NS_IP_PORT(laddr, lport, lns),
+// listener.is_any_ip_ as given (= addr.is_any_address() at construction, common/gy_socket_stat.cc:1796), ser = the event's NS_IP_PORT
+int ref_listener_match(const uint8_t *lip, int l6, uint16_t lport, uint64_t lns, int l_is_any, const uint8_t *eip, int e6, uint16_t eport, uint64_t ens)
+{
+	const NS_IP_PORT l(mk_ip(lip, l6), lport, (ino_t)lns), ser(mk_ip(eip, e6), eport, (ino_t)ens);
+	return ((l.inode_ == ser.inode_) && (l.ip_port_.port_ == ser.ip_port_.port_) && (l_is_any || (l.ip_port_.ipaddr_ == ser.ip_port_.ipaddr_))) ? 1 : 0;
+}
+
 uint32_t ref_machine_id_hash(uint64_t first, uint64_t second)
 {
 	std::pair<uint64_t, uint64_t> machid(first, second);

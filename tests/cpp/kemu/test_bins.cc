@@ -30,7 +30,7 @@ struct Key {
 	std::vector<uint32_t> rows;
 	uint32_t nbuf, mrun, nh, nw, win_epoch, hw_epoch;
 	gyo_hist all0, win0; // records before
-	uint32_t bm0[16];
+	uint32_t bm0[GYS_BM_WORDS];
 	int32_t mn0, mx0;
 };
 
@@ -69,7 +69,7 @@ int main(int argc, char **argv)
 	const uint32_t S = 14;
 	std::vector<Key> keys(S);
 	std::vector<int64_t> td_sum((size_t)S * GYS_TD_NB, 0);
-	std::vector<uint32_t> td_cnt((size_t)S * GYS_TD_NB, 0), td_pend((size_t)S * pcap, 0xDEADBEEFu), td_cur(S, 0), staged(1u << 16, 0), bitmap((size_t)S * 16, 0);
+	std::vector<uint32_t> td_cnt((size_t)S * GYS_TD_NB, 0), td_pend((size_t)S * pcap, 0xDEADBEEFu), td_cur(S, 0), staged(1u << 16, 0), bitmap((size_t)S * GYS_BM_WORDS, 0);
 	std::vector<TdMeta> meta(S);
 	std::vector<int2> minmax(S);
 	std::vector<gys_hist_rec> hist_all(S), hist_win(S);
@@ -112,7 +112,7 @@ int main(int argc, char **argv)
 		k.rows.resize(m);
 		for (uint32_t i = 0; i < m; ++i) {
 			k.vals[i] = s == 6 ? 37 : draw(rng, mu, sigma); // key 6: all values equal (every value ties with every other)
-			k.rows[i] = (uint32_t)(rng() & 31u);
+			k.rows[i] = (uint32_t)(rng() & (s % 3 == 0 ? 31u : 63u)); // (rows 32..63: the IPv6 family's rows; every third key has IPv4 events only)
 		}
 		// fold state of the buffered words: [0, nh) already folded, [0, nw) arrived in windows before win_epoch
 		k.win_epoch = 7;
@@ -131,6 +131,7 @@ int main(int argc, char **argv)
 		if (k.hw_epoch != k.win_epoch) { // some older window's record sits there
 			gyo_hist_add(&k.win0, 123);
 			k.bm0[3] = 0x00010002u;
+			k.bm0[21] = 0x00400001u; // (IPv6 rows of the older window: a roll has to clear them too)
 		}
 		// device-side images
 		for (int j = 0; j < GYO_TD_NB; ++j) {
@@ -161,7 +162,7 @@ int main(int argc, char **argv)
 		hist_all[s].max_val_seen = k.all0.total_count ? k.all0.max_val_seen : INT64_MIN;
 		hist_win[s].total_count = k.win0.total_count;
 		hist_win[s].max_val_seen = k.win0.total_count ? k.win0.max_val_seen : INT64_MIN;
-		memcpy(&bitmap[(size_t)s * 16], k.bm0, sizeof(k.bm0));
+		memcpy(&bitmap[(size_t)s * GYS_BM_WORDS], k.bm0, sizeof(k.bm0));
 		list[s] = MergeEnt{s, k.nbuf, k.mrun, off_end};
 	}
 
@@ -205,7 +206,7 @@ int main(int argc, char **argv)
 		// records: every not yet folded value into the all-time record; the values of window win_epoch into the window record (rolled first
 		// when it belonged to an older window) and into the CONN_BITMAP rows
 		gyo_hist all = k.all0, win = k.win0;
-		uint32_t bm[16];
+		uint32_t bm[GYS_BM_WORDS];
 		memcpy(bm, k.bm0, sizeof(bm));
 		int32_t mn = k.mn0, mx = k.mx0;
 		const uint32_t nwin0 = std::max(k.nh, k.nw);
@@ -233,7 +234,7 @@ int main(int argc, char **argv)
 		if (all.total_count) CHECK(hist_all[s].max_val_seen == all.max_val_seen, "key %u all-time max %lld want %lld", s, (long long)hist_all[s].max_val_seen, (long long)all.max_val_seen);
 		CHECK(hist_win[s].total_count == win.total_count, "key %u window total %llu want %llu", s, (unsigned long long)hist_win[s].total_count, (unsigned long long)win.total_count);
 		if (any_win) CHECK(hist_win[s].max_val_seen == win.max_val_seen, "key %u window max %lld want %lld", s, (long long)hist_win[s].max_val_seen, (long long)win.max_val_seen);
-		for (int g = 0; g < 16; ++g) CHECK(bitmap[(size_t)s * 16 + g] == bm[g], "key %u bitmap word %d: %08x want %08x", s, g, bitmap[(size_t)s * 16 + g], bm[g]);
+		for (int g = 0; g < (int)GYS_BM_WORDS; ++g) CHECK(bitmap[(size_t)s * GYS_BM_WORDS + g] == bm[g], "key %u bitmap word %d: %08x want %08x", s, g, bitmap[(size_t)s * GYS_BM_WORDS + g], bm[g]);
 		CHECK(minmax[s].x == mn && minmax[s].y == mx, "key %u min/max {%d, %d} want {%d, %d}", s, minmax[s].x, minmax[s].y, mn, mx);
 		// the buffer is drained; the window bookkeeping moves on
 		CHECK(meta[s].npend == 0 && meta[s].nh == 0 && meta[s].nw == 0 && meta[s].win_epoch == k.win_epoch && meta[s].hw_epoch == (any_win ? k.win_epoch : k.hw_epoch) && td_cur[s] == 0,

@@ -96,7 +96,7 @@ int main(int argc, char **argv)
 	}
 
 	std::vector<int64_t> td_sum((size_t)nsvc * GYS_TD_NB, 0);
-	std::vector<uint32_t> td_cnt((size_t)nsvc * GYS_TD_NB, 0), td_pend((size_t)nsvc * pcap, 0), td_cur(nsvc + 64, 0), td_run(nsvc, 0), staged(1u << 21, 0), bitmap((size_t)nsvc * 16, 0),
+	std::vector<uint32_t> td_cnt((size_t)nsvc * GYS_TD_NB, 0), td_pend((size_t)nsvc * pcap, 0), td_cur(nsvc + 64, 0), td_run(nsvc, 0), staged(1u << 21, 0), bitmap((size_t)nsvc * GYS_BM_WORDS, 0),
 		hll32(1u << GYS_HLL_P, 0), resp_win(nsvc, 0), host_spill(NH, 0), counts(16, 0);
 	std::vector<TdMeta> meta(nsvc, TdMeta{0, 0, 0, 0, 0});
 	std::vector<int2> minmax(nsvc, make_int2(INT32_MAX, INT32_MIN));
@@ -117,7 +117,7 @@ int main(int argc, char **argv)
 #endif
 	// the pools of the several-workgroup path (2 entries at a time: a third huge key goes through a second round) and of the fallback
 	const uint32_t maxent = 2, huge_blocks = 1;
-	std::vector<uint32_t> hbins((size_t)maxent * GYS_HB_BINS), hbm((size_t)maxent * 16), chunk_off(maxent + 1), scratch((size_t)huge_blocks * GYS_HUGE_BINS, 0);
+	std::vector<uint32_t> hbins((size_t)maxent * GYS_HB_BINS), hbm((size_t)maxent * GYS_BM_WORDS), chunk_off(maxent + 1), scratch((size_t)huge_blocks * GYS_HUGE_BINS, 0);
 	std::vector<unsigned long long> hacc((size_t)maxent * GYS_HB_ACC), tail(1u << 16);
 
 	// per-key events of host 0 by batch (host 1 always gets 2 000 events over its 40 services: never spilled)
@@ -383,7 +383,7 @@ int main(int argc, char **argv)
 			// whose records belong to an earlier window shows an empty window
 			{
 				const gyo_hist_serial *ow = gyo_engine_hist(orcw) + (size_t)s * 16;
-				const uint16_t *ob = gyo_engine_bitmap(orcw) + (size_t)s * 32;
+				const uint16_t *ob = gyo_engine_bitmap(orcw) + (size_t)s * 64;
 				const bool cur = meta[s].hw_epoch == epoch;
 				for (int b = 0; b < 15; ++b) {
 					const unsigned long long gc = cur ? hist_win[s].stats[b].count : 0ull;
@@ -391,9 +391,9 @@ int main(int argc, char **argv)
 					CHECK(gc == ow[b].count && gs == ow[b].sum, "batch %u key %u window bucket %d: {%llu, %lld} want {%llu, %lld}", batch, s, b, gc, gs, (unsigned long long)ow[b].count, (long long)ow[b].sum);
 				}
 				CHECK((cur ? hist_win[s].total_count : 0ull) == ow[15].count && (cur ? hist_win[s].max_val_seen : INT64_MIN) == ow[15].sum, "batch %u key %u window total / max", batch, s);
-				for (int g = 0; g < 16; ++g) {
+				for (int g = 0; g < (int)GYS_BM_WORDS; ++g) {
 					const uint32_t want = (uint32_t)ob[2 * g] | ((uint32_t)ob[2 * g + 1] << 16);
-					CHECK((cur ? bitmap[(size_t)s * 16 + g] : 0u) == want, "batch %u key %u CONN_BITMAP rows %d, %d: %08x want %08x", batch, s, 2 * g, 2 * g + 1, cur ? bitmap[(size_t)s * 16 + g] : 0u, want);
+					CHECK((cur ? bitmap[(size_t)s * GYS_BM_WORDS + g] : 0u) == want, "batch %u key %u CONN_BITMAP rows %d, %d: %08x want %08x", batch, s, 2 * g, 2 * g + 1, cur ? bitmap[(size_t)s * GYS_BM_WORDS + g] : 0u, want);
 				}
 			}
 			const gyo_td_buffered *ot = gyo_engine_td(orc, s);

@@ -57,6 +57,7 @@ int main(int argc, char **argv)
 		li[i].glob_id = 0x1000 + i;
 		li[i].netns = 4026531840u;
 		li[i].port = (uint16_t)(8000 + i);
+		li[i].is_any_ip = 1;
 		snprintf(li[i].comm, sizeof(li[i].comm), "svc%d", i);
 	}
 	if (!h.partha_new_listeners(mid, li.data(), 10)) return 3;

@@ -7,7 +7,10 @@ the hot kernels run on synthetic input:
     boundaries (tests/cpp/kemu/test_resp.cc) in both tile forms and in the split form (long segments cut into parts of 65 536 events,
     several workgroups per host reserving buffer space with device atomics, k_key_finalize as its own launch): counters, HLL
     registers, all-service histogram, every key's buffered values and digest and the records of re-clustered keys equal the oracle's
-    sequential engine fed the same bytes;
+    sequential engine fed the same bytes; the same with bound-address listeners and several listeners per (netns, port) key (KEMU_MODE=1:
+    the event's server address picks the listener, common/gy_socket_stat.h:708-714) and with batches of 48-byte IPv6 events in between
+    (KEMU_MODE=2: handle_ipv6_resp_event, resp_bitmap_v6_ rows, addresses that embed an IPv4 one), window records and CONN_BITMAP rows of both
+    families against an oracle engine cleared at the window boundaries;
   * the paths of a key whose batch does not fit its buffer (tests/cpp/kemu/test_spill.cc): spill in finalize_key, the SPILL pass of
     k_resp_host, merges from buffer + run in every size class, the several-workgroup path of gys_huge.hpp with its sorted tail and its
     one-workgroup fallback;
@@ -48,6 +51,11 @@ PROGRAMS = {
     "resp-tiles-6144": ("test_resp.cc", ["KEMU_TPT=12"] + BINS, ["4242"], "kemu resp ok"),
     "resp-512x32-prefetch": ("test_resp.cc", ["KEMU_TPT=32"] + BINS, ["4242"], "kemu resp ok"),
     "resp-split-form": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_SPLIT", "KEMU_NB=3"] + BINS, ["4242"], "kemu resp ok"),
+    # keys with candidates (bound-address listeners, two listeners on one port): the event's server address picks the listener
+    "resp-bound-address": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_MODE=1"] + BINS, ["4243"], "kemu resp ok"),
+    # the same world, batches alternating between IPv4 events and 48-byte IPv6 events (resp_bitmap_v6_ rows, embedded IPv4 addresses)
+    "resp-ipv6-mixed": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_MODE=2"] + BINS, ["4244"], "kemu resp ok"),
+    "resp-ipv6-split-form": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_MODE=2", "KEMU_SPLIT", "KEMU_NB=4"] + BINS, ["4245"], "kemu resp ok"),
     "spill-and-huge": ("test_spill.cc", BINS, ["777"], "kemu spill ok"),
     "spill-predicted-runs": ("test_spill.cc", ["KEMU_PRESPILL"] + BINS, ["778"], "kemu spill ok"),
     "conn-31": ("test_conn.cc", [], ["31"], "kemu conn ok"),

@@ -41,9 +41,12 @@ def test_listener_scan_one_against_numpy(oracle):
         L.gyo_mlh_flush(C.byref(h), t)
         last = np.stack([st["count"][:15].astype(np.int64), st["sum"][:15]], axis=1)
         tot += last
-    rows = np.zeros(32, dtype=np.uint16)
+    rows = np.zeros(64, dtype=np.uint16)  # 32 rows of resp_bitmap_v4_, 32 rows of resp_bitmap_v6_
     for port, bucket in ((1000, 3), (1001, 3), (1033, 3), (77, 9), (78, 9), (5, 0)):
         L.gyo_conn_bitmap_add(oracle.ptr(rows, oracle.u16p), port, bucket)
+    rows6 = rows[32:]
+    for port, bucket in ((1000, 3), (40, 9), (41, 12)):  # IPv6 clients: their own bitmap, counts added per bucket (gy_socket_stat.cc:4144-4149)
+        L.gyo_conn_bitmap_add(oracle.ptr(rows6, oracle.u16p), port, bucket)
     notify = np.zeros(88, dtype=np.uint8)
     out = oracle.ListenerScan()
     L.gyo_listener_scan_one(C.byref(h), C.byref(qps), C.byref(act), oracle.ptr(rows, oracle.u16p), 0xabcdef0123, 2.5, 5, oracle.ptr(notify, oracle.u8p), C.byref(out))
@@ -64,10 +67,10 @@ def test_listener_scan_one_against_numpy(oracle):
     assert out.last_qps == int(np.float32(np.float32(nq) * np.float32(2.5)) / np.float32(5.0))
     assert out.curr_qps == max(out.last_qps, nq // 5)
     assert out.b5 == (thr.index(out.p95_ms[0]) + 1 if out.p95_ms[0] in thr else 14)
-    assert list(out.nactive_conn_arr) == [1, 0, 0, 2, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0] and out.nconn_active == 2
+    assert list(out.nactive_conn_arr) == [1, 0, 0, 3, 0, 0, 0, 0, 0, 3, 0, 0, 1, 0, 0] and out.nconn_active == 3
     # (ports 1001 and 1033 share row 9: two distinct rows saw bucket 3)
     rec = np.frombuffer(notify.tobytes(), dtype=np.dtype([("glob_id", "<u8"), ("nqrys_5s", "<u4"), ("total_resp_5sec", "<u4"), ("nconns", "<u4"),
                                                         ("nconns_active", "<u4"), ("ntasks", "<u4"), ("p95_5s", "<u4"), ("p95_5m", "<u4")]), count=1)[0]
     assert int(rec["glob_id"]) == 0xabcdef0123 and int(rec["nqrys_5s"]) == nq and int(rec["total_resp_5sec"]) == int(last[:, 1].sum()) & 0xFFFFFFFF
-    assert int(rec["nconns_active"]) == 2 and int(rec["p95_5s"]) == out.p95_ms[0] and int(rec["p95_5m"]) == out.p95_ms[1]
+    assert int(rec["nconns_active"]) == 3 and int(rec["p95_5s"]) == out.p95_ms[0] and int(rec["p95_5m"]) == out.p95_ms[1]
     assert notify[79] == 2

@@ -58,6 +58,7 @@ int main(int argc, char **argv)
 			li[s].glob_id = glob_id(host, s);
 			li[s].netns = 0xF0000000u + 4u * host;
 			li[s].port = (uint16_t)(1024 + s);
+			li[s].is_any_ip = 1;
 			snprintf(li[s].comm, sizeof(li[s].comm), "svc%u", s);
 		}
 		if (!h.partha_new_listeners(mid, li.data(), SP)) return 3;
