@@ -947,12 +947,17 @@ void launch_resp_host(gys_ctx *c, uint32_t grid, size_t dyn, const RespHostP &hp
 	if (!SPILL && (hp.svc_hll_p || MODE == 2)) hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, !SPILL, MODE>), dim3(grid), dim3(GYS_RESP_THREADS(TPT)), dyn, c->stream, hp);
 	else hipLaunchKernelGGL((k_resp_host<TPT, SHARED, SPILL, false, MODE>), dim3(grid), dim3(GYS_RESP_THREADS(TPT)), dyn, c->stream, hp);
 }
-// mode 1 / 2 (keys with candidates / IPv6 events) exist in the 1024 x 16 tile form only (batches whose tables do not fit it take the general front end)
+// mode 1 / 2 (keys with candidates / IPv6 events) exist in the 1024-thread tile forms (16 384 or 8 192 events)
 template <bool SHARED, bool SPILL>
-void launch_resp_host_mode(gys_ctx *c, int mode, uint32_t grid, size_t dyn, const RespHostP &hp)
+void launch_resp_host_mode(gys_ctx *c, int mode, bool tpt16, uint32_t grid, size_t dyn, const RespHostP &hp)
 {
-	if (mode == 2) launch_resp_host<16, SHARED, SPILL, 2>(c, grid, dyn, hp);
-	else launch_resp_host<16, SHARED, SPILL, 1>(c, grid, dyn, hp);
+	if (mode == 2) {
+		if (tpt16) launch_resp_host<16, SHARED, SPILL, 2>(c, grid, dyn, hp);
+		else launch_resp_host<8, SHARED, SPILL, 2>(c, grid, dyn, hp);
+	} else {
+		if (tpt16) launch_resp_host<16, SHARED, SPILL, 1>(c, grid, dyn, hp);
+		else launch_resp_host<8, SHARED, SPILL, 1>(c, grid, dyn, hp);
+	}
 }
 
 // dynamic LDS a k_resp_host launch may ask for: the CU's 160 KiB minus the instance's own static part (read from the code object, so that
@@ -1054,7 +1059,6 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		if (host_local && max_len > GYS_SPLIT_PART && (c->cfg.resp_path == 3 || (c->cfg.resp_path == 0 && t_split < t_host))) host_split = true;
 	}
 	const int mode = v6 ? 2 : cands ? 1 : 0;
-	if (host_local && mode != 0 && resp_host_lds_bytes(max_tbl, (uint32_t)align_up(max_l, 2), 16384u) > c->resp_dyn_max) host_local = host_split = false; // (those instances exist in the 16 384-event tile form only)
 	const uint32_t nsvc = c->nsvc;
 	uint32_t *cms32 = (uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_cms;
 	unsigned long long *ghist = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
@@ -1209,8 +1213,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		{
 			ProfScope ps(c, "resp_host");
 			if (mode != 0) {
-				if (host_split) launch_resp_host_mode<true, false>(c, mode, hgrid, dyn, hp);
-				else launch_resp_host_mode<false, false>(c, mode, hgrid, dyn, hp);
+				if (host_split) launch_resp_host_mode<true, false>(c, mode, tpt16, hgrid, dyn, hp);
+				else launch_resp_host_mode<false, false>(c, mode, tpt16, hgrid, dyn, hp);
 			} else if (host_split) {
 				if (tpt12) launch_resp_host<12, true, false>(c, hgrid, dyn, hp);
 				else if (tpt16) launch_resp_host<16, true, false>(c, hgrid, dyn, hp);
@@ -1292,7 +1296,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		// second pass over the hosts that have spilled services (a workgroup of any other host returns at once): their events again,
 		// only the spilled services' values, into the runs k_key_finalize allocated in `staged`
 		ProfScope ps(c, "resp_spill");
-		if (mode != 0) launch_resp_host_mode<true, true>(c, mode, hgrid, dyn, hp);
+		if (mode != 0) launch_resp_host_mode<true, true>(c, mode, tpt16, hgrid, dyn, hp);
 		else if (tpt12) launch_resp_host<12, true, true>(c, hgrid, dyn, hp);
 		else if (tpt16) launch_resp_host<16, true, true>(c, hgrid, dyn, hp);
 		else launch_resp_host<8, true, true>(c, hgrid, dyn, hp);
@@ -2340,6 +2344,12 @@ try {
 	HIPCHK((resp_host_lds_attr<16, false, false, 2>(&c->resp_dyn_max))); // IPv6 events
 	HIPCHK((resp_host_lds_attr<16, true, false, 2>(&c->resp_dyn_max)));
 	HIPCHK((resp_host_lds_attr<16, true, true, 2>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<8, false, false, 1>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<8, true, false, 1>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<8, true, true, 1>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<8, false, false, 2>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<8, true, false, 2>(&c->resp_dyn_max)));
+	HIPCHK((resp_host_lds_attr<8, true, true, 2>(&c->resp_dyn_max)));
 	c->host_seen.reserve(H);
 	if (cfg->svc_hll_p) ALLOC(c->svc_hll, S << cfg->svc_hll_p);
 	if (cfg->enable_levels) {

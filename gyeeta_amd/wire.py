@@ -79,11 +79,30 @@ def listener_port(s):
     return (1024 + np.asarray(s, dtype=np.int64) % 60000).astype(np.uint16)
 
 
+def ip6_embedded_v4(a):
+    """ip32_be_ of GY_IP_ADDR(unsigned __int128) for address bytes a[..., 16]: get_ipv6_type_flags (common/gy_common_inc.h:11040-11129) stores the
+    IPv4 address an IPv6 address embeds -- 2002::/16 (bytes 2..5), ::ffff:a.b.c.d and 64:ff9b::/32 (bytes 12..15) -- into embedded_ipv4_"""
+    a = np.asarray(a, dtype=np.uint8).reshape(-1, 16)
+    u = lambda b: b[:, 0].astype(np.uint32) | (b[:, 1].astype(np.uint32) << 8) | (b[:, 2].astype(np.uint32) << 16) | (b[:, 3].astype(np.uint32) << 24)
+    any_ = ~a.any(axis=1)
+    loop = ~a[:, :15].any(axis=1) & (a[:, 15] == 1)
+    g2 = (a[:, 0] & 0xF0) == 0x20
+    six4 = g2 & (a[:, 0] == 0x20) & (a[:, 1] == 0x02)
+    mapped = ~a[:, :10].any(axis=1) & (a[:, 10] == 0xFF) & (a[:, 11] == 0xFF)
+    nat64 = (a[:, 0] == 0) & (a[:, 1] == 0x64) & (a[:, 2] == 0xFF) & (a[:, 3] == 0x9B)
+    out = np.zeros(len(a), dtype=np.uint32)
+    live = ~any_ & ~loop
+    out = np.where(live & six4, u(a[:, 2:6]), out)
+    out = np.where(live & ~g2 & mapped, u(a[:, 12:16]), out)
+    out = np.where(live & ~g2 & ~mapped & nat64, u(a[:, 12:16]), out)
+    return out
+
+
 def set_ip_port(arr, ip32_be=None, ip128=None, port=0):
     """fills an IP_PORT field array the way GY_IP_ADDR::set_ip does (common/gy_common_inc.h:10673-10692)"""
     if ip128 is not None:
         arr["ip128"] = ip128
-        arr["ip32_be"] = 0
+        arr["ip32_be"] = ip6_embedded_v4(np.asarray(arr["ip128"]))  # (embedded_ipv4_ shares its storage with ip32_be_, :10497-10500)
         arr["aftype"] = AF_INET6
     else:
         arr["ip128"] = 0

@@ -198,23 +198,35 @@ uint32_t gyo_ns_ip_port_hash(const uint8_t *ip, int is_v6, uint16_t port, uint64
 }
 
 /* PAIR_IP_PORT::get_hash common/gy_inet_inc.h:225-247 : [cli inaddr][cli port LE]00 00[ser inaddr][ser port LE]00 00 */
-uint32_t gyo_pair_ip_port_words(const uint8_t *cip, int c6, uint16_t cport, const uint8_t *sip, int s6, uint16_t sport,
-				uint32_t out[10])
+/* the same from two GY_IP_ADDR OBJECTS (their ip32_be_ and ip128_be_ members as they stand): what get_as_inaddr reads */
+uint32_t gyo_pair_words_obj(uint32_t c32, const uint8_t c128[16], uint16_t cport, uint32_t s32, const uint8_t s128[16], uint16_t sport, uint32_t out[10])
 {
 	uint8_t buf[48];
-	int len = gyo_inaddr(cip, c6, buf);
+	int len = 0;
 
+	if (c32) { memcpy(buf, &c32, 4); len = 4; } else { memcpy(buf, c128, 16); len = 16; }
 	memcpy(buf + len, &cport, 2);
 	len += 2;
 	buf[len++] = 0;
 	buf[len++] = 0;
-	len += gyo_inaddr(sip, s6, buf + len);
+	if (s32) { memcpy(buf + len, &s32, 4); len += 4; } else { memcpy(buf + len, s128, 16); len += 16; }
 	memcpy(buf + len, &sport, 2);
 	len += 2;
 	buf[len++] = 0;
 	buf[len++] = 0;
 	memcpy(out, buf, (size_t)len);
 	return (uint32_t)len / 4;
+}
+
+uint32_t gyo_pair_ip_port_words(const uint8_t *cip, int c6, uint16_t cport, const uint8_t *sip, int s6, uint16_t sport,
+				uint32_t out[10])
+{
+	uint32_t c32, s32;
+	uint8_t c128[16], s128[16];
+
+	gyo_ip_norm(cip, c6, &c32, c128); /* the objects as the reference builds them from raw address bytes */
+	gyo_ip_norm(sip, s6, &s32, s128);
+	return gyo_pair_words_obj(c32, c128, cport, s32, s128, sport, out);
 }
 
 uint32_t gyo_pair_ip_port_hash(const uint8_t *cip, int c6, uint16_t cport, const uint8_t *sip, int s6, uint16_t sport)
@@ -900,17 +912,12 @@ int gyo_listener_state_rollup(const uint8_t *batch, int nrec, const uint8_t *pen
 	return i;
 }
 
-/* IP_PORT object at rec+off (32 bytes: ip128 @0, ip32 @16, aftype @20, flags @22, port @24) -> (ip ptr, is_v6, port) */
-static void rd_ip_port(const uint8_t *p, const uint8_t **ip, int *is_v6, uint16_t *port)
+/* IP_PORT object at rec+off (32 bytes: ip128 @0, ip32 @16, aftype @20, flags @22, port @24) as the sender's GY_IP_ADDR stands in the record: the
+ * receiver hashes the object it was sent (get_as_inaddr reads the ip32_be_ / ip128_be_ members, it does not rebuild them) */
+static void rd_ip_port(const uint8_t *p, const uint8_t **ip128, uint32_t *ip32, uint16_t *port)
 {
-	const uint32_t ip32 = rd_u32(p + 16);
-	if (ip32) {
-		*ip = p + 16;
-		*is_v6 = 0;
-	} else {
-		*ip = p;
-		*is_v6 = 1;
-	}
+	*ip32 = rd_u32(p + 16);
+	*ip128 = p;
 	*port = rd_u16(p + 24);
 }
 
@@ -923,12 +930,12 @@ int gyo_tcp_conn_decode(const uint8_t *batch, int nrec, const uint8_t *pend, uin
 
 	for (i = 0; i < nrec && p < pend; ++i, p += gyo_tcp_conn_elem_size(p)) {
 		const uint8_t *cip, *sip;
-		int c6, s6;
+		uint32_t c32, s32;
 		uint16_t cport, sport;
 
-		rd_ip_port(p + 64, &cip, &c6, &cport);
-		rd_ip_port(p + 96, &sip, &s6, &sport);
-		nwords[i] = gyo_pair_ip_port_words(cip, c6, cport, sip, s6, sport, keywords + (size_t)i * 10);
+		rd_ip_port(p + 64, &cip, &c32, &cport);
+		rd_ip_port(p + 96, &sip, &s32, &sport);
+		nwords[i] = gyo_pair_words_obj(c32, cip, cport, s32, sip, sport, keywords + (size_t)i * 10);
 		ser_glob_id[i] = rd_u64(p + 192);
 		bytes_sent[i] = rd_u64(p + 208);
 		bytes_rcvd[i] = rd_u64(p + 216);
@@ -960,14 +967,14 @@ int gyo_tcp_conn_sketch_batch(const uint8_t *batch, int nrec, const uint8_t *pen
 
 	for (i = 0; i < nrec && p < pend; ++i, p += gyo_tcp_conn_elem_size(p)) {
 		const uint8_t *cip, *sip;
-		int c6, s6;
+		uint32_t c32, s32;
 		uint16_t cport, sport;
 		uint32_t w[10], gw[2], nw;
 		uint64_t gid, bytes;
 
-		rd_ip_port(p + 64, &cip, &c6, &cport);
-		rd_ip_port(p + 96, &sip, &s6, &sport);
-		nw = gyo_pair_ip_port_words(cip, c6, cport, sip, s6, sport, w);
+		rd_ip_port(p + 64, &cip, &c32, &cport);
+		rd_ip_port(p + 96, &sip, &s32, &sport);
+		nw = gyo_pair_words_obj(c32, cip, cport, s32, sip, sport, w);
 		gyo_hll_add_words(hll, GYO_HLL_P, w, nw);
 		if (!conn_listener_side(p)) continue;
 		gid = rd_u64(p + 192);

@@ -108,6 +108,7 @@ void gyo_conn_bitmap_add(uint16_t respmap[32], uint16_t cli_port, uint8_t bucket
 void gyo_conn_bitmap_breakup(const uint16_t respmap[32], uint8_t nconn_arr[15]);
 void gyo_conn_bitmap_breakup2(const uint16_t respmap[64], uint8_t nconn_arr[15]);
 int gyo_ip_norm(const uint8_t *ip, int is_v6, uint32_t *ip32, uint8_t ip128[16]);
+uint32_t gyo_pair_words_obj(uint32_t c32, const uint8_t c128[16], uint16_t cport, uint32_t s32, const uint8_t s128[16], uint16_t sport, uint32_t out[10]);
 int gyo_ip_equal(uint32_t a32, const uint8_t a128[16], uint32_t b32, const uint8_t b128[16]);
 
 /* ---------------------------------------------------------------- HLL / CMS (builder-defined, frozen in DESIGN.md) */
