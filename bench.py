@@ -35,13 +35,13 @@ EVENT_BYTES = 24          # algorithmic bytes per event (raw tcp_ipv4
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed):
+def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0):
     """The oracle's sequential restatement of the same hot loop ("port"), timed on one host core on a bounded sample of the
     same stream shape (same generator, same bytes).  Returns (full_ev_s, histonly_ev_s, sample description)."""
     from gyeeta_amd import wire
     from oracle import oracle as o
     nsvc = total_hosts_sample * svcs
-    orc = o.OracleEngine(nsvc)
+    orc = o.OracleEngine(nsvc, td_cap=td_cap)
     orc2 = o.OracleEngine(nsvc, enable_td=False)
     for h in range(total_hosts_sample):
         s = np.arange(svcs)
@@ -67,7 +67,7 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed):
     try:  # the full port again on every host core (hosts cut into per-thread ranges; identical resulting state, tests/test_oracle_sketches.py)
         ncores = os.cpu_count() or 1
         if ncores > 1:
-            orc3 = o.OracleEngine(nsvc)
+            orc3 = o.OracleEngine(nsvc, td_cap=td_cap)
             for h in range(total_hosts_sample):
                 s = np.arange(svcs)
                 g = wire.glob_id(np.full(svcs, h), s)
@@ -678,6 +678,7 @@ def main():
     ap.add_argument("--no-host-fed", action="store_true", help="skip the (untimed) host-fed measurement: pinned H2D copy + ingest")
     ap.add_argument("--no-dephase", action="store_true", help="skip the untimed pass that spreads the keys' buffer fill levels")
     ap.add_argument("--prime-windows", type=int, default=-1, help="untimed ordinary windows after the de-phase pass (-1: one buffer cycle)")
+    ap.add_argument("--td-pend-cap", type=int, default=0, help="gys_config.td_pend_cap: values a service's digest buffers before it is re-clustered (0 = the library default, 896; up to 3968)")
     ap.add_argument("--nbuf", type=int, default=6, help="distinct device-resident event batches the windows cycle through")
     ap.add_argument("--cpu-events", type=int, default=1 << 26)
     ap.add_argument("--cpu-hosts", type=int, default=1000)
@@ -737,7 +738,7 @@ def main():
     nlocal = len(mine)
     nsvc = nlocal * args.svcs
     eng = SketchEngine(max_hosts=max(nlocal, 1), max_services=max(nsvc, 1), max_clusters=16, enable_tdigest=True,
-                       max_batch_events=args.events, rank=rank, nranks=world, device=local_rank, enable_levels=args.levels)
+                       max_batch_events=args.events, rank=rank, nranks=world, device=local_rank, enable_levels=args.levels, td_pend_cap=args.td_pend_cap)
     # window exchange at N > 1: the four register families all-reduced INSIDE the library (gys_window_close_rccl: ncclAllReduce x 4 in
     # one group on the engine stream).  torch.distributed only carries the 128-byte communicator id (and the timing barrier).
     exchange = "none"
@@ -802,11 +803,11 @@ def main():
     # events per key on average, drawn with per-service weights spread over 0..255/256, leaves the fill levels evenly spread, so that
     # from the first warm-up window on every window carries its long-run share of merges (events / ~(PEND + events per key and window)).
     ingested = []  # (nevents, seed, zipf/spread code, times): everything the engine was fed, for the quantile-error check
-    PEND = capi.TD_PEND_CAP
+    PEND = eng.L.gys_td_pend_cap(eng.h)
     # every close is a collective at N > 1: the number of untimed windows must not depend on the rank's own share of the hosts
     nsvc_nominal = args.hosts * args.svcs // world
     if args.prime_windows < 0:  # one full buffer cycle: PEND values at events/keys values per window, plus one
-        args.prime_windows = min(60, int(PEND * nsvc_nominal / max(args.events, 1)) + 2) if nsvc_nominal else 0
+        args.prime_windows = min(100, int(PEND * nsvc_nominal / max(args.events, 1)) + 2) if nsvc_nominal else 0
     if not args.no_dephase and nsvc_nominal:
         total = nsvc * (PEND // 2 - 1)
         nb = max(1, -(-total // args.events))
@@ -974,8 +975,8 @@ def main():
                                    "1 window (ingest + window close) per step" % (args.hosts, args.svcs,
                                                                                  "uniform" if not args.zipf_milli else "zipf %.2f" % (args.zipf_milli / 1000)),
                        "events_per_rank_per_step": args.events, "service_keys_total": args.hosts * args.svcs,
-                       "service_keys_rank0": nsvc, "multi_level_windows": int(args.levels),
-                       "sketches": "exact RESP_TIME_HASH histogram + CONN_BITMAP + HLL p=14 + CMS 4x65536 + t-digest %d clusters + %d-value buffer per key" % (capi.TD_NB, capi.TD_PEND_CAP),
+                       "service_keys_rank0": nsvc, "multi_level_windows": int(args.levels), "td_pend_cap": int(PEND),
+                       "sketches": "exact RESP_TIME_HASH histogram + CONN_BITMAP + HLL p=14 + CMS 4x65536 + t-digest %d clusters + %d-value buffer per key" % (capi.TD_NB, PEND),
                        "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world, "exchange": exchange,
                        "exchange_requested": args.exchange if world > 1 else "none",
                        "exchange_fallback": bool(world > 1 and args.exchange == "rccl" and exchange != "rccl_in_library"),
@@ -1001,7 +1002,7 @@ def main():
         if scan is not None:
             out["quantile_scan"] = scan
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N = 1 only
-            full, honly, desc, ref_rate, port_mt = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234)
+            full, honly, desc, ref_rate, port_mt = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234, td_cap=args.td_pend_cap)
             out["cpu_baseline"] = {"value": full, "unit": "events/s", "cores": 1, "kind": "port", "sample": desc,
                                    "histonly_value": honly}
             if port_mt is not None:  # the same full port (histogram + bitmap + HLL + CMS + t-digest) on all host threads

@@ -21,7 +21,7 @@ class Config(C.Structure):
                 ("enable_tdigest", C.c_uint32), ("svc_hll_p", C.c_uint32), ("resp_path", C.c_uint32),
                 ("max_batch_events", C.c_uint64), ("stream", C.c_void_p), ("reduce_arena", C.c_void_p),
                 ("reduce_arena_bytes", C.c_uint64), ("enable_levels", C.c_uint32), ("td_buf_values", C.c_uint32),
-                ("conn_pair_cms", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("conn_pair_cms", C.c_uint32), ("td_pend_cap", C.c_uint32)]
 
 
 class ListenerInfo(C.Structure):
@@ -131,7 +131,7 @@ class Counters(C.Structure):
                                           "td_merges", "td_merge_values", "actconn_records", "actconn_remote_listen", "actconn_unknown_listener",
                                           "stage_waits", "resp_calls_queued", "resp_submissions", "conn_new", "conn_closed",
                                           "conn_closed_no_notify", "conn_client_side", "resp_tail_flushes", "conn_calls_queued", "conn_submissions",
-                                          "lstate_calls_queued", "lstate_submissions", "rec_tail_flushes")]
+                                          "lstate_calls_queued", "lstate_submissions", "rec_tail_flushes", "resp_run_overflow")]
 
 
 assert C.sizeof(HistRec) == 256 and C.sizeof(TopnEntry) == 104 and C.sizeof(RespSeg) == 16 and C.sizeof(ListenerDayStats) == 48
@@ -144,6 +144,7 @@ mid = u8p  # machine id: 16 bytes
 # name -> (restype, argtypes): must list EVERY function include/gysketch.h declares (tests/test_abi.py checks the header against this)
 SIGNATURES = {
     "gys_abi_version": (C.c_uint32, []),
+    "gys_td_pend_cap": (C.c_uint32, [vp]),
     "gys_last_error": (C.c_char_p, []),
     "gys_reduce_arena_bytes": (C.c_uint64, [C.POINTER(Config)]),
     "gys_create": (C.c_int, [C.POINTER(Config), C.POINTER(vp)]),

@@ -217,6 +217,7 @@ struct gys_ctx {
 	bool prespill = false;
 	uint32_t spill_stamp = 0;
 	uint32_t pcap = 0;
+	uint32_t pend_cap = GYS_TD_PEND_CAP, merge_fast = GYS_TDIGEST_MERGE_FAST; // the t-digest rule's buffer size (gys_config.td_pend_cap) and its fast merge class
 	MergeEnt *merge_list = nullptr, *merge_list_slow = nullptr, *merge_list1 = nullptr, *merge_list2 = nullptr, *huge_list = nullptr, *query_list = nullptr;
 	uint32_t *merge_count = nullptr; // [FIN_*]: merge list lengths by size class, huge list length, run allocation cursor; [8] = 1 (query list)
 	uint32_t *resp_win = nullptr;    // per service: response events of the open window (-> Count-Min rows at the window boundary)
@@ -915,6 +916,7 @@ inline DigestP digest_params(gys_ctx *c)
 	d.td_pend = c->td_pend;
 	d.td_cur = c->td_cur;
 	d.pcap = c->pcap;
+	d.pend_cap = c->pend_cap;
 	d.nsvc = c->nsvc;
 	d.staged = c->staged;
 	d.hist_win = c->hist_win;
@@ -1073,6 +1075,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		fin.td_meta = c->td_meta;
 		fin.nsvc = c->nsvc;
 		fin.pcap = c->pcap;
+		fin.pend_cap = c->pend_cap;
+		fin.merge_fast = c->merge_fast;
 		fin.epoch = c->epoch;
 		fin.resp_win = c->resp_win;
 		fin.list[FIN_CLASS0] = c->merge_list;
@@ -1084,9 +1088,10 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		fin.svc_host = c->svc_host;
 		fin.host_spill = c->host_spill;
 		fin.counters = c->counters;
+		fin.staged_cap = (uint32_t)std::min<uint64_t>(c->staged_cap, 0xFFFFFFFFull);
 	}
 	// predicted runs: only for the host-local front end, and only when the batch is large enough for a key to overflow a buffer at all
-	const bool pre = td && host_local && c->prespill && n > (uint64_t)c->pcap - GYS_TD_PEND_CAP;
+	const bool pre = td && host_local && c->prespill && n > (uint64_t)c->pcap - c->pend_cap;
 	if (td && c->prespill) {
 		fin.td_run0 = c->td_run0;
 		fin.td_run1 = c->td_run1;
@@ -1094,6 +1099,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		fin.hot = c->pre_hot;
 		fin.hot_wr = pre ? ((c->pre_seq & 1u) ^ 1u) : (c->pre_seq & 1u); // the word the NEXT k_prespill reads (this batch's own one, if any, reads the other)
 		fin.append_list = c->append_list;
+		fin.append_cap = (uint32_t)c->append_cap;
+		fin.td_pend = c->td_pend;
+		fin.staged = c->staged;
 		HIPCHK(hipMemsetAsync(c->merge_count + FIN_APPEND, 0, 4, c->stream));
 	}
 	RespHostP hp{};
@@ -1205,6 +1213,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			pp.batch_stamp = c->batch_stamp;
 			pp.nsvc = nsvc;
 			pp.pcap = c->pcap;
+			pp.pend_cap = c->pend_cap;
 			pp.run_limit = (uint32_t)std::min<uint64_t>(c->staged_cap - std::min<uint64_t>(n, c->staged_cap), 0xFFFFFFFFull); // the exact runs of the fall-back (<= n words) keep their room
 			++c->pre_seq;
 			hipLaunchKernelGGL(k_mark_hosts, dim3((nsegs + 255) / 256), dim3(256), 0, c->stream, segs_dev, nsegs, c->host_batch, c->batch_stamp);
@@ -1292,7 +1301,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		hipLaunchKernelGGL(k_run_append, dim3((uint32_t)c->ncu), dim3(256), 0, c->stream, c->append_list, c->merge_count + FIN_APPEND, c->staged, c->td_pend, c->pcap);
 	// (a key spills / lands in a larger merge class only when THIS batch brought it more values than its buffer had room for: a small
 	// batch -- a partha message of a few thousand events -- cannot, and the launches for those cases are not made)
-	if (host_local && n > (uint64_t)c->pcap - GYS_TD_PEND_CAP) {
+	if (host_local && n > (uint64_t)c->pcap - c->pend_cap) {
 		// second pass over the hosts that have spilled services (a workgroup of any other host returns at once): their events again,
 		// only the spilled services' values, into the runs k_key_finalize allocated in `staged`
 		ProfScope ps(c, "resp_spill");
@@ -1312,7 +1321,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			static const bool old_merge = getenv("GYS_OLD_MERGE") != nullptr; // A/B: the general kernel for class 0 as well
 			mp.list = c->merge_list;
 			mp.count = c->merge_count + FIN_CLASS0;
-			if (old_merge) {
+			if (old_merge && c->merge_fast <= GYS_MERGE_CLASS0) {
 				hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 7))), dim3(256), 0, c->stream, mp);
 			} else {
 				MergeBP bp{};
@@ -1321,13 +1330,17 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 				bp.count = c->merge_count + FIN_CLASS0;
 				bp.slow_list = c->merge_list_slow;
 				bp.slow_count = c->merge_count + FIN_SLOW;
-				hipLaunchKernelGGL(k_digest_bins<false>, dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 8))), dim3(256), 0, c->stream, bp);
-				mp.list = c->merge_list_slow; // entries whose total weight needs 64-bit arithmetic (normally none)
+				const dim3 bgrid(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 8)));
+				if (c->merge_fast <= 1024u) hipLaunchKernelGGL((k_digest_bins<false, 4u>), bgrid, dim3(256), 0, c->stream, bp);
+				else if (c->merge_fast <= 2048u) hipLaunchKernelGGL((k_digest_bins<false, 8u>), bgrid, dim3(256), 0, c->stream, bp);
+				else hipLaunchKernelGGL((k_digest_bins<false, 16u>), bgrid, dim3(256), 0, c->stream, bp);
+				mp.list = c->merge_list_slow; // entries whose total weight needs 64-bit arithmetic, or with more large values than the bin kernel's list holds (normally none)
 				mp.count = c->merge_count + FIN_SLOW;
-				hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
+				if (c->merge_fast <= GYS_MERGE_CLASS0) hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
+				else hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS1, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
 			}
 		}
-		if (n > GYS_MERGE_CLASS0 - GYS_TD_PEND_CAP) {
+		if (c->merge_fast < GYS_MERGE_CLASS1 && n > c->merge_fast - c->pend_cap) {
 			ProfScope ps(c, "digest_merge_big");
 			mp.list = c->merge_list1;
 			mp.count = c->merge_count + FIN_CLASS1;
@@ -1335,7 +1348,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			// (entries above class 1 take the several-workgroup path below; k_digest_merge<GYS_MERGE_LDS_MAX> only serves queries)
 		}
 	}
-	if (n > GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) {
+	if (n > GYS_MERGE_CLASS1 - c->pend_cap) {
 		// huge keys (> 16 384 values in this call): several workgroups per key (gys_huge.hpp); what that path cannot take -- entries
 		// beyond its pool, more than 4 096 values >= 16 384 in one key -- is handed to the one-workgroup kernel through a fallback list
 		ProfScope ps(c, "digest_huge");
@@ -1368,7 +1381,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			q.dbg = (unsigned long long *)c->counters + 20;
 #endif
 			// the pool holds huge_maxent entries: the list is walked in rounds (a round beyond the list's end costs four empty launches)
-			const uint64_t list_cap = std::min<uint64_t>(std::min<uint64_t>(nsvc, n / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1), c->huge_list_cap);
+			const uint64_t list_cap = std::min<uint64_t>(std::min<uint64_t>(nsvc, n / (GYS_MERGE_CLASS1 - c->pend_cap) + 1), c->huge_list_cap);
 			for (uint64_t first = 0; first < list_cap; first += c->huge_maxent) {
 				q.first = (uint32_t)first;
 				hipLaunchKernelGGL(k_huge_plan, dim3(1), dim3(1024), 0, c->stream, q);
@@ -2250,7 +2263,8 @@ try {
 	}
 	if (!cfg->max_hosts || !cfg->max_services || cfg->max_hosts > 65534 || !cfg->max_clusters || cfg->nranks == 0 || cfg->rank >= cfg->nranks ||
 	    (cfg->svc_hll_p && (cfg->svc_hll_p < 4 || cfg->svc_hll_p > 10)) ||
-	    (cfg->td_buf_values && (cfg->td_buf_values < GYS_TD_PEND_CAP + 64u || cfg->td_buf_values > GYS_PCAP_MAX))) {
+	    (cfg->td_pend_cap && (cfg->td_pend_cap < 64u || cfg->td_pend_cap > GYS_TD_PEND_CAP_MAX)) ||
+	    (cfg->td_buf_values && (cfg->td_buf_values < (cfg->td_pend_cap ? cfg->td_pend_cap : GYS_TD_PEND_CAP) + 64u || cfg->td_buf_values > GYS_PCAP_MAX))) {
 		set_err("bad config values");
 		return GYS_ERR_INVAL;
 	}
@@ -2363,11 +2377,15 @@ try {
 		const uint64_t B = cfg->max_batch_events ? cfg->max_batch_events : 1;
 		// value buffer of a service: GYS_TD_PEND_CAP values wait for a merge, the rest is room for one batch's values of the service
 		// (a batch that does not fit takes the slower spill path); sized to the services, within ~40 GiB unless the caller says otherwise
+		c->pend_cap = cfg->td_pend_cap ? cfg->td_pend_cap : GYS_TD_PEND_CAP;
+		// the fast merge class: the smallest k_digest_bins instance (merges of 1024 / 2048 / 4096 values) that leaves 128 values of room above the
+		// buffer size (896 -> 1024 = GYS_TDIGEST_MERGE_FAST); a service is re-clustered early when another batch like its last would pass it
+		c->merge_fast = c->pend_cap + 128u <= 1024u ? 1024u : c->pend_cap + 128u <= 2048u ? 2048u : 4096u;
 		if (cfg->td_buf_values) {
 			c->pcap = cfg->td_buf_values;
 		} else {
 			const uint64_t fit = ((40ull << 30) / (4 * S)) / 256 * 256;
-			c->pcap = (uint32_t)std::min<uint64_t>(GYS_PCAP_MAX, std::max<uint64_t>(1024, fit));
+			c->pcap = (uint32_t)std::min<uint64_t>(GYS_PCAP_MAX, std::max<uint64_t>(align_up(c->merge_fast, 256), fit));
 		}
 		ALLOC(c->td_sum, S * GYS_TD_NB);
 		ALLOC(c->td_cnt, S * GYS_TD_NB);
@@ -2382,14 +2400,14 @@ try {
 		ALLOC(c->merge_list, std::min<uint64_t>(S, B) + 1);
 		ALLOC(c->merge_list_slow, std::min<uint64_t>(S, B) + 1);
 		// a key lands in a larger merge size class only when the batch itself brought it more than CLASS0 - PEND_CAP values
-		ALLOC(c->merge_list1, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS0 - GYS_TD_PEND_CAP) + 1) + 1);
-		ALLOC(c->merge_list2, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1) + 1);
+		ALLOC(c->merge_list1, std::min<uint64_t>(S, B / (c->merge_fast - c->pend_cap) + 1) + 1);
+		ALLOC(c->merge_list2, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - c->pend_cap) + 1) + 1);
 		ALLOC(c->resp_win, S);
 		c->cms_nch = (uint32_t)std::min<uint64_t>(32, (S + 65535) / 65536);
 		ALLOC(c->cms_partial, (uint64_t)c->cms_nch * GYS_CMS_D * GYS_CMS_W);
 		HIPCHK(hipFuncSetAttribute((const void *)k_cms_partial, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_CMSF_CELLS * 4));
 		// (entries above merge size class 1 take the several-workgroup path: the batch itself brought such a key more than CLASS1 - PEND_CAP values)
-		c->huge_list_cap = std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1);
+		c->huge_list_cap = std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - c->pend_cap) + 1);
 		ALLOC(c->huge_list, c->huge_list_cap + 1);
 		ALLOC(c->query_list, 4);
 		ALLOC(c->merge_count, 16);
@@ -2414,7 +2432,7 @@ try {
 			ALLOC(c->td_prevm, S);
 			ALLOC(c->pre_hot, 2);
 			ALLOC(c->host_batch, H);
-			c->append_cap = std::min<uint64_t>(S, B / (c->pcap - GYS_TD_PEND_CAP) + 1) + 1;
+			c->append_cap = S + 1; // (a key has at most one entry per batch; the keys of a batch are not bounded by its size: predictions come from EARLIER batches)
 			ALLOC(c->append_list, c->append_cap);
 		}
 		c->huge_blocks = (int)std::min<uint64_t>(64, std::min<uint64_t>(S, B / GYS_MERGE_LDS_MAX + 1));
@@ -2433,7 +2451,7 @@ try {
 		ALLOC(c->huge_chunk_off, (uint64_t)c->huge_maxent + 1);
 		ALLOC(c->huge_tail, (uint64_t)1 << 20);
 		ALLOC(c->huge_tb_list, (uint64_t)c->huge_maxent);
-		ALLOC(c->huge_fb_list, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - GYS_TD_PEND_CAP) + 1) + 1);
+		ALLOC(c->huge_fb_list, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - c->pend_cap) + 1) + 1);
 		HIPCHK(hipFuncSetAttribute((const void *)k_huge_count, hipFuncAttributeMaxDynamicSharedMemorySize, GYS_HB_BINS * 4));
 		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge<512, GYS_HB_TAIL_A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (GYS_HB_BINS + GYS_HB_TAIL_A) * 4));
 		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge<1024, GYS_HB_TAIL_LDS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4));
@@ -3727,7 +3745,10 @@ try {
 	bp.qout = d_out;
 	{
 		ProfScope ps(c, "scan_quantiles");
-		hipLaunchKernelGGL(k_digest_bins<true>, dim3(std::max(1u, std::min<uint32_t>(c->nsvc, (uint32_t)c->ncu * 8))), dim3(256), 0, c->stream, bp);
+		const dim3 sgrid(std::max(1u, std::min<uint32_t>(c->nsvc, (uint32_t)c->ncu * 8)));
+		if (c->pend_cap <= 1024u) hipLaunchKernelGGL((k_digest_bins<true, 4u>), sgrid, dim3(256), 0, c->stream, bp);
+		else if (c->pend_cap <= 2048u) hipLaunchKernelGGL((k_digest_bins<true, 8u>), sgrid, dim3(256), 0, c->stream, bp);
+		else hipLaunchKernelGGL((k_digest_bins<true, 16u>), sgrid, dim3(256), 0, c->stream, bp);
 	}
 	uint32_t nslow = 0;
 	HIPCHK(hipMemcpyAsync(&nslow, c->merge_count + FIN_SLOW, 4, hipMemcpyDeviceToHost, c->stream));
@@ -3832,7 +3853,10 @@ static int rollup_launch(gys_ctx *c, int kind, const std::vector<uint32_t> &off,
 	rp.ngroups = ngroups;
 	{
 		ProfScope ps(c, kind == 0 ? "rollup_services" : "rollup_slabs");
-		hipLaunchKernelGGL(k_digest_rollup, dim3(std::min<uint32_t>(ngroups, (uint32_t)c->ncu * 4)), dim3(256), 0, c->stream, rp);
+		const dim3 rgrid(std::min<uint32_t>(ngroups, (uint32_t)c->ncu * 4));
+		if (c->pend_cap <= 1024u) hipLaunchKernelGGL(k_digest_rollup<4u>, rgrid, dim3(256), 0, c->stream, rp);
+		else if (c->pend_cap <= 2048u) hipLaunchKernelGGL(k_digest_rollup<8u>, rgrid, dim3(256), 0, c->stream, rp);
+		else hipLaunchKernelGGL(k_digest_rollup<16u>, rgrid, dim3(256), 0, c->stream, rp);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(c->stream)); // the member lists are freed below
@@ -4221,6 +4245,8 @@ try {
 	return GYS_OK;
 } GYS_CATCH_ALL
 
+uint32_t gys_td_pend_cap(gys_ctx *c) { return c ? c->pend_cap : 0u; }
+
 int gys_export_tdigest_pending(gys_ctx *c, uint32_t first_slot, uint32_t nslots, uint32_t *npend, int32_t *pend)
 try {
 	GYS_ENTER(c);
@@ -4229,14 +4255,14 @@ try {
 	if (!c->cfg.enable_tdigest || !pend) return GYS_ERR_INVAL;
 	std::vector<TdMeta> meta(nslots);
 	HIPCHK(hipMemcpyAsync(meta.data(), c->td_meta + first_slot, (size_t)nslots * sizeof(TdMeta), hipMemcpyDeviceToHost, c->stream));
-	// a service buffers at most GYS_TD_PEND_CAP values between batches (the rest of its pcap-entry buffer is room for a batch)
-	HIPCHK(hipMemcpy2DAsync(pend, (size_t)GYS_TD_PEND_CAP * 4, c->td_pend + (size_t)first_slot * c->pcap, (size_t)c->pcap * 4, (size_t)GYS_TD_PEND_CAP * 4, nslots,
-				hipMemcpyDeviceToHost, c->stream));
+	// a service buffers at most td_pend_cap values between batches (the rest of its pcap-entry buffer is room for a batch)
+	const size_t cap = c->pend_cap;
+	HIPCHK(hipMemcpy2DAsync(pend, cap * 4, c->td_pend + (size_t)first_slot * c->pcap, (size_t)c->pcap * 4, cap * 4, nslots, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	for (uint32_t i = 0; i < nslots; ++i) {
 		npend[i] = meta[i].npend;
-		for (uint32_t k = 0; k < GYS_TD_PEND_CAP; ++k) // staged words: value << 5 | CONN_BITMAP row
-			pend[(size_t)i * GYS_TD_PEND_CAP + k] = k < meta[i].npend ? (int32_t)((uint32_t)pend[(size_t)i * GYS_TD_PEND_CAP + k] >> GYS_ROW_BITS) : 0;
+		for (uint32_t k = 0; k < cap; ++k) // staged words: value << 6 | family << 5 | CONN_BITMAP row
+			pend[(size_t)i * cap + k] = k < meta[i].npend ? (int32_t)((uint32_t)pend[(size_t)i * cap + k] >> GYS_ROW_BITS) : 0;
 	}
 	return GYS_OK;
 } GYS_CATCH_ALL
@@ -4286,6 +4312,7 @@ try {
 	out->conn_closed = v[CTR_CONN_CLOSED];
 	out->conn_closed_no_notify = v[CTR_CONN_CLOSED_NO_NOTIFY];
 	out->conn_client_side = v[CTR_CONN_CLI_SIDE];
+	out->resp_run_overflow = v[CTR_RESP_RUN_OVERFLOW];
 	out->lstate_records = v[CTR_LSTATE_RECORDS];
 	out->lstate_missed = v[CTR_LSTATE_MISSED];
 	out->lstate_errors = v[CTR_LSTATE_ERRORS];

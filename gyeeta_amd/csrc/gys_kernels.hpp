@@ -33,7 +33,7 @@ namespace gys {
 
 enum { CTR_RESP_EVENTS = 0, CTR_RESP_DROP_RANGE, CTR_RESP_DROP_NOLISTENER, CTR_CONN_EVENTS, CTR_CONN_UNKNOWN, CTR_LSTATE_RECORDS,
        CTR_LSTATE_MISSED, CTR_LSTATE_ERRORS, CTR_LSTATE_DELETED, CTR_TD_MERGES, CTR_TD_MERGE_VALUES, CTR_ACTCONN_RECORDS, CTR_ACTCONN_REMOTE_LISTEN, CTR_ACTCONN_UNKNOWN,
-       CTR_CONN_NEW, CTR_CONN_CLOSED, CTR_CONN_CLOSED_NO_NOTIFY, CTR_CONN_CLI_SIDE, CTR_NUM };
+       CTR_CONN_NEW, CTR_CONN_CLOSED, CTR_CONN_CLOSED_NO_NOTIFY, CTR_CONN_CLI_SIDE, CTR_RESP_RUN_OVERFLOW, CTR_NUM };
 
 // ---------------------------------------------------------------------------------------------------- table insert
 __global__ void k_table_insert(DevTable t, const uint64_t *keys, uint32_t first_val, uint32_t n, uint32_t *nfail)
@@ -439,7 +439,7 @@ __global__ void k_minmax_init(int2 *mm, uint64_t n)
 // k_key_finalize (one thread per service).
 #define GYS_MERGE_CLASS0 1024u // largest (buffered + run) value count of merge size class 0 / 1 (class 2: up to GYS_MERGE_LDS_MAX)
 #define GYS_MERGE_CLASS1 4096u
-static_assert(GYS_TDIGEST_MERGE_FAST == GYS_MERGE_CLASS0, "the early re-clustering rule keeps a key's merges inside merge size class 0");
+static_assert(GYS_TDIGEST_MERGE_FAST == GYS_MERGE_CLASS0, "the early re-clustering rule keeps a key's merges inside merge size class 0 (default buffer size)");
 enum { FIN_CLASS0 = 0, FIN_CLASS1, FIN_CLASS2, FIN_HUGE, FIN_RUN_ALLOC, FIN_SLOW, FIN_NCOUNTS }; // FIN_SLOW: k_digest_bins' hand-over list
 #define FIN_APPEND 12 // counts[FIN_APPEND]: length of the append list (keys whose predicted run turned out to fit their buffer; 6..10: the large-key path)
 
@@ -447,6 +447,7 @@ struct FinP {
 	uint32_t *td_cur;
 	TdMeta *td_meta;
 	uint32_t nsvc, pcap, epoch;
+	uint32_t pend_cap, merge_fast; // the t-digest rule's two numbers (gys_config.td_pend_cap; merge_fast = pend_cap + 128 = the largest merge of size class 0)
 	uint32_t *resp_win;        // per service: response events of the open window
 	MergeEnt *list[4];         // merge lists by size class, [FIN_HUGE] = the huge list
 	uint32_t *counts;          // [FIN_NCOUNTS]: list lengths, bump cursor into `staged`
@@ -465,6 +466,10 @@ struct FinP {
 	uint32_t *td_prevm, *hot;
 	uint32_t hot_wr;
 	MergeEnt *append_list;
+	uint32_t append_cap;       // entries of append_list (one per service: a key has at most one entry per batch); past it the thread copies the run itself
+	uint32_t staged_cap;       // words of `staged`: an exact run must end inside it
+	uint32_t *td_pend;
+	const uint32_t *staged;
 };
 
 // the per-key part: meta record, window event count, spill; returns the merge size class the key is queued for (-1: none) and its entry
@@ -486,7 +491,10 @@ __device__ __forceinline__ int finalize_one(const FinP &p, bool valid, uint32_t 
 			const uint32_t fill = p.td_run[key];
 			run_ok = fill <= p.td_run1[key];
 			cur = npend0 + (fill - run0);
-			if (fill == run0) p.td_cur[key] = npend0; // predicted, but the batch had nothing for the key
+			if (fill == run0) {
+				p.td_cur[key] = npend0; // predicted, but the batch had nothing for the key ...
+				p.td_prevm[key] = 0u;   // ... and is not predicted again on the strength of some earlier batch (td_prevm is only written for keys with values)
+			}
 		}
 		if (cur != npend0) {
 			const uint32_t m = cur - npend0;
@@ -498,7 +506,7 @@ __device__ __forceinline__ int finalize_one(const FinP &p, bool valid, uint32_t 
 			p.resp_win[key] += m; // the key is owned by this thread for the batch
 			if (p.td_prevm) {
 				p.td_prevm[key] = m;
-				if (m > p.pcap - GYS_TD_PEND_CAP) p.hot[p.hot_wr] = 1u; // (same value from every writer)
+				if (m > p.pcap - p.pend_cap) p.hot[p.hot_wr] = 1u; // (same value from every writer)
 			}
 			ent.slot = key;
 			if (cur <= p.pcap && (!pre || run_ok)) {
@@ -506,13 +514,18 @@ __device__ __forceinline__ int finalize_one(const FinP &p, bool valid, uint32_t 
 					// predicted too high: the batch fits the buffer after all, and the rule below (append, re-cluster only past
 					// GYS_TD_PEND_CAP) is defined on the buffer -- the run's values are copied behind the buffered ones (k_run_append)
 					const uint32_t at = atomicAdd(&p.counts[FIN_APPEND], 1u);
-					p.append_list[at] = MergeEnt{key, npend0, m, run0 + m};
+					if (at < p.append_cap) {
+						p.append_list[at] = MergeEnt{key, npend0, m, run0 + m};
+					} else { // (the list has an entry per service: not reached; the copy itself is what must not be lost)
+						atomicAdd(&p.counts[FIN_APPEND], 0xFFFFFFFFu); // (- 1: k_run_append walks the list by this count)
+						for (uint32_t i = 0; i < m; ++i) p.td_pend[(size_t)key * p.pcap + npend0 + i] = p.staged[run0 + i];
+					}
 				}
 				*(uint4 *)&p.td_meta[key] = make_uint4(cur, nh | (nw << 16), win_epoch, mraw.w);
 				if (WRITE_CUR || pre) p.td_cur[key] = cur;
-				if (cur > GYS_TD_PEND_CAP || cur + m > GYS_TDIGEST_MERGE_FAST) { // (the second: another batch like this one would leave the fast merge class)
+				if (cur > p.pend_cap || cur + m > p.merge_fast) { // (the second: another batch like this one would leave the fast merge class)
 					ent.nbuf = cur;
-					cls = cur <= GYS_MERGE_CLASS0 ? FIN_CLASS0 : cur <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_HUGE; // (> 4096: the several-workgroup path)
+					cls = cur <= p.merge_fast ? FIN_CLASS0 : cur <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_HUGE; // (> 4096: the several-workgroup path)
 				}
 			} else { // spilled
 				*(uint4 *)&p.td_meta[key] = make_uint4(npend0, nh | (nw << 16), win_epoch, mraw.w);
@@ -525,14 +538,23 @@ __device__ __forceinline__ int finalize_one(const FinP &p, bool valid, uint32_t 
 					p.td_cur[key] = npend0 | GYS_SPILL_BIT;
 					ent.off_end = p.batch_off[key];
 				} else { // not predicted, or more values than the predicted run had room for: an exact run, filled by the second pass
-					p.td_cur[key] = npend0 | GYS_SPILL_BIT | GYS_RESPILL_BIT;
+					// (the exact runs of a batch take <= n words, n = the batch's events, and the predicted runs end at staged_cap - n (run_limit),
+					// with the cursor counting ACCEPTED predictions only: an exact run ends inside `staged`.  Checked all the same -- a run that
+					// did not is not written, the key keeps its buffered values and the batch's values of this key are counted as lost.)
 					const uint32_t start = atomicAdd(&p.counts[FIN_RUN_ALLOC], m);
+					if ((uint64_t)start + m > (uint64_t)p.staged_cap) {
+						atomicAdd((unsigned long long *)&p.counters[CTR_RESP_RUN_OVERFLOW], (unsigned long long)m);
+						p.td_cur[key] = npend0;
+						ent = MergeEnt{};
+						return -1;
+					}
+					p.td_cur[key] = npend0 | GYS_SPILL_BIT | GYS_RESPILL_BIT;
 					p.td_run[key] = start;
 					ent.off_end = start + m;
 					p.host_spill[p.svc_host[key]] = p.spill_stamp;
 				}
 				const uint64_t tot = (uint64_t)npend0 + m;
-				cls = tot <= GYS_MERGE_CLASS0 ? FIN_CLASS0 : tot <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_HUGE;
+				cls = tot <= p.merge_fast ? FIN_CLASS0 : tot <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_HUGE;
 			}
 		}
 	}
@@ -626,6 +648,7 @@ struct PreSpillP {
 	const uint32_t *svc_host, *host_batch;
 	uint32_t batch_stamp;        // host_batch[h] == batch_stamp: host h has a segment in this batch
 	uint32_t nsvc, pcap, run_limit; // run_limit: predicted runs end below it (the exact runs of the fall-back need the rest of `staged`)
+	uint32_t pend_cap;
 };
 
 __global__ __launch_bounds__(256) void k_prespill(PreSpillP p)
@@ -637,7 +660,7 @@ __global__ __launch_bounds__(256) void k_prespill(PreSpillP p)
 	uint32_t cap = 0, npend0 = 0;
 	if (s < p.nsvc) {
 		const uint32_t prev = p.td_prevm[s];
-		if (prev > p.pcap - GYS_TD_PEND_CAP && p.host_batch[p.svc_host[s]] == p.batch_stamp) {
+		if (prev > p.pcap - p.pend_cap && p.host_batch[p.svc_host[s]] == p.batch_stamp) {
 			npend0 = p.td_cur[s];
 			// (predicted with the run's own margin: a key whose batches end just below the buffer's end one time and just above it the next
 			// would otherwise take the second pass every other batch -- r4c: 0.93 ms of second walks left on the Zipf shape; a run that
@@ -657,17 +680,30 @@ __global__ __launch_bounds__(256) void k_prespill(PreSpillP p)
 			s_w[k] = tot;
 			tot += c;
 		}
-		s_base = tot ? atomicAdd(&p.counts[FIN_RUN_ALLOC], tot) : 0u;
+		// the cursor only ever counts ACCEPTED runs (compare-and-swap: a workgroup whose runs would end past run_limit takes nothing --
+		// the exact runs of the fall-back start at the cursor and need the rest of `staged`; a plain add could also carry the 32-bit
+		// cursor around when many keys are predicted at once)
+		uint32_t base = 0xFFFFFFFFu;
+		if (tot) {
+			uint32_t old = p.counts[FIN_RUN_ALLOC];
+			while ((uint64_t)old + tot <= (uint64_t)p.run_limit) {
+				const uint32_t prev = atomicCAS(&p.counts[FIN_RUN_ALLOC], old, old + tot);
+				if (prev == old) {
+					base = old;
+					break;
+				}
+				old = prev;
+			}
+		}
+		s_base = base;
 	}
 	__syncthreads();
-	if (cap) {
+	if (cap && s_base != 0xFFFFFFFFu) { // (else: no prediction for this workgroup's keys)
 		const uint32_t start = s_base + s_w[wave] + inc - cap;
-		if ((uint64_t)start + cap <= (uint64_t)p.run_limit) { // (else: no prediction for this key; the words stay unused)
-			p.td_run[s] = start;
-			p.td_run0[s] = start;
-			p.td_run1[s] = start + cap;
-			p.td_cur[s] = npend0 | GYS_SPILL_BIT;
-		}
+		p.td_run[s] = start;
+		p.td_run0[s] = start;
+		p.td_run1[s] = start + cap;
+		p.td_cur[s] = npend0 | GYS_SPILL_BIT;
 	}
 }
 
@@ -1455,6 +1491,7 @@ struct DigestP {
 	uint32_t *td_pend;  // [nsvc*pcap] staged words
 	uint32_t *td_cur;
 	uint32_t pcap, nsvc;
+	uint32_t pend_cap;  // values a key buffers between batches at most (gys_config.td_pend_cap)
 	const uint32_t *staged;
 	gys_hist_rec *hist_win, *hist_all;
 	uint32_t *bitmap;   // [nsvc*GYS_BM_WORDS] u32 = 32 x u16 CONN_BITMAP rows of resp_bitmap_v4_, then of resp_bitmap_v6_ (common/gy_socket_stat.h:390-454)
@@ -1974,12 +2011,18 @@ __device__ __forceinline__ double td_quantile_dev(const uint32_t *c_cnt, const u
 	return floor(res + 0.5); // integer-millisecond value domain
 }
 
-template <bool SCAN>
+// VPT: buffered + run values per thread the instance takes (merges of up to 256 VPT values: 4 for the default buffer of 896 values, 8 / 16 for
+// gys_config.td_pend_cap up to 1920 / 3968).  The work of a merge is almost all per BIN and per CLUSTER (a value costs its load and one to
+// three LDS atomics), so a buffer four times the size means a quarter of the merges at little more than the old cost each.
+#define GYS_MB_BIG_CAP 1024u // large values (>= GYS_MB_EXACT) the list holds; a merge with more of them goes to the general kernel (slow_list)
+template <bool SCAN, uint32_t VPT = 4u>
 __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 {
 	const DigestP &p = q.d;
+	static_assert(VPT == 4u || VPT == 8u || VPT == 16u, "merges of 1024 / 2048 / 4096 values");
 	__shared__ __align__(16) uint32_t s_bin[GYS_MB_BINS];
-	__shared__ uint32_t s_big[GYS_MERGE_CLASS0]; // values >= GYS_MB_EXACT: index << 20 | value
+	constexpr uint32_t BIG_CAP = SCAN ? 256u * VPT : GYS_MB_BIG_CAP; // (the all-service scan has no hand-over list: its list holds any merge)
+	__shared__ uint32_t s_big[BIG_CAP]; // values >= GYS_MB_EXACT: index << 20 | value
 	__shared__ uint32_t s_thr[GYS_NBP];          // compacted non-empty old clusters: ceil(sum / count), padded with ~0
 	__shared__ uint32_t s_cpfx[GYS_NBP + 1];     // old weight before compacted cluster c
 	__shared__ uint32_t s_T[GYS_NBP];            // T_j, j = 1..NB-1; [0] = 0, [NB..] = ~0
@@ -2020,10 +2063,10 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		GYS_OPAQUE_VGPR(tid);
 		const uint32_t lane = tid & 63u, wave = tid >> 6;
 		MergeEnt ent;
-		if (SCAN) ent = MergeEnt{w, min(p.td_meta[w].npend, (uint32_t)GYS_TD_PEND_CAP), 0u, 0u}; // between batches a buffer holds at most PEND_CAP values
+		if (SCAN) ent = MergeEnt{w, min(p.td_meta[w].npend, p.pend_cap), 0u, 0u}; // between batches a buffer holds at most pend_cap values
 		else ent = q.list[w];
 		const uint32_t m = ent.nbuf + ent.mrun;
-		if (m > GYS_MERGE_CLASS0) continue; // never queued on this list (finalize_key)
+		if (m > 256u * VPT) continue; // never queued on this list (finalize_key)
 		const uint32_t slot = ent.slot;
 		const uint4 mt = *(const uint4 *)&p.td_meta[slot];
 		const uint32_t nh = query ? m : (mt.y & 0xFFFFu), nw = mt.y >> 16;
@@ -2037,18 +2080,21 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			c0 = p.td_cnt[(size_t)slot * GYS_TD_NB + tid];
 			sm0 = p.td_sum[(size_t)slot * GYS_TD_NB + tid];
 		}
-		uint32_t wd[4];
+		uint32_t wd[VPT];
 		{
 			const uint32_t *pend = p.td_pend + (size_t)slot * p.pcap;
 #pragma unroll
-			for (uint32_t k = 0; k < 4u; ++k) {
+			for (uint32_t k = 0; k < VPT; ++k) {
 				const uint32_t i = tid + 256u * k;
 				wd[k] = 0;
 				if (i < m) wd[k] = i < ent.nbuf ? pend[i] : p.staged[run0 + (i - ent.nbuf)];
 			}
 		}
 		if (GYS_MB_SKIP & 32) { // (the loads stay live: an impossible value writes them out)
-			if ((wd[0] ^ wd[1] ^ wd[2] ^ wd[3] ^ c0 ^ (uint32_t)sm0) == 0xDEADBEEFu) p.td_cur[slot] = 1;
+			uint32_t x = c0 ^ (uint32_t)sm0;
+#pragma unroll
+			for (uint32_t k = 0; k < VPT; ++k) x ^= wd[k];
+			if (x == 0xDEADBEEFu) p.td_cur[slot] = 1;
 			continue;
 		}
 		if (m == 0 && !SCAN) { // nothing buffered (query of a freshly merged key): the merged view is the digest itself
@@ -2125,13 +2171,16 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 		const bool fold_scan = !query && nh == 0u; // the all-time deltas of the one-value bins come from the scan
 		int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmax = INT32_MIN;
 #pragma unroll
-		for (uint32_t k = 0; k < 4u; ++k) {
+		for (uint32_t k = 0; k < VPT; ++k) {
 			const uint32_t i = tid + 256u * k;
 			if (i >= m || (GYS_MB_SKIP & 4)) continue;
 			const uint32_t uv = wd[k] >> GYS_ROW_BITS;
 			atomicAdd(&s_bin[mb_bin(uv)], 1u); // (no rank inside the bin is needed: equal values are interchangeable, pass 2 works per bin)
 			const bool big = uv >= GYS_MB_EXACT;
-			if (big) s_big[atomicAdd(&s_nbig, 1u)] = (i << 20) | uv;
+			if (big) {
+				const uint32_t at = atomicAdd(&s_nbig, 1u);
+				if (256u * VPT <= BIG_CAP || at < BIG_CAP) s_big[at] = (i << 20) | uv;
+			}
 			if (SCAN && i >= nh_mm) {
 				lmin = min(lmin, (int32_t)uv);
 				lmax = max(lmax, (int32_t)uv);
@@ -2164,6 +2213,11 @@ __global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
 			}
 		}
 		__syncthreads();
+		if (256u * VPT > BIG_CAP && s_nbig > BIG_CAP) { // more large values than the list holds (a key whose responses take seconds): the general kernel's job
+			if (tid == 0) q.slow_list[atomicAdd(q.slow_count, 1u)] = ent;
+			__syncthreads();
+			continue;
+		}
 		// ---- one scan over the bins: thread t owns bins [8t, 8t + 8)
 		if (!(GYS_MB_SKIP & 8)) {
 			uint32_t bv[GYS_MB_BPT], own = 0;

@@ -81,6 +81,8 @@ __device__ __forceinline__ uint32_t cluster_of_u64(const uint64_t *T, uint64_t m
 	return a;
 }
 
+// VPT: buffered values of a member per thread (4: buffers of up to 1024 values -- the default td_pend_cap; 8 / 16 for larger ones)
+template <uint32_t VPT = 4u>
 __global__ __launch_bounds__(256) void k_digest_rollup(RollupP q)
 {
 	const DigestP &p = q.d;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void k_digest_rollup(RollupP q)
 	__shared__ uint64_t s_T[GYS_NBP];
 	__shared__ unsigned long long o_sum[GYS_NBP], o_cnt[GYS_NBP];
 	__shared__ __align__(16) uint32_t s_bin[GYS_MB_BINS];
-	__shared__ uint32_t s_big[GYS_MERGE_CLASS0];
+	__shared__ uint32_t s_big[256u * VPT];
 	__shared__ uint32_t s_thr[GYS_NBP];
 	__shared__ uint32_t s_wv[4], s_ws[4], s_nbig;
 	__shared__ uint64_t s_ww[4];
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void k_digest_rollup(RollupP q)
 					ncn = p.td_cnt[(size_t)mem * GYS_TD_NB + tid];
 					ns = p.td_sum[(size_t)mem * GYS_TD_NB + tid];
 				}
-				npend = min(p.td_meta[mem].npend, (uint32_t)GYS_MERGE_CLASS0);
+				npend = min(p.td_meta[mem].npend, 256u * VPT);
 			} else if (tid < GYS_TD_NB) {
 				ncn = q.in[mem].cnt[tid];
 				ns = q.in[mem].sum[tid];
@@ -174,11 +176,11 @@ __global__ __launch_bounds__(256) void k_digest_rollup(RollupP q)
 			}
 			if (!npend) continue;
 			// ---------------- step B: the member's buffered values as unit points (value bins, see k_digest_bins)
-			uint32_t wd[4];
+			uint32_t wd[VPT];
 			{
 				const uint32_t *pend = p.td_pend + (size_t)mem * p.pcap;
 #pragma unroll
-				for (uint32_t k = 0; k < 4u; ++k) {
+				for (uint32_t k = 0; k < VPT; ++k) {
 					const uint32_t i = tid + 256u * k;
 					wd[k] = i < npend ? pend[i] : 0u;
 				}
@@ -200,10 +202,10 @@ __global__ __launch_bounds__(256) void k_digest_rollup(RollupP q)
 				s_thr[tid] = thr;
 				atomicAdd(&s_bin[mb_bin(thr)], 1u << 16);
 			}
-			uint32_t pos[4];
+			uint32_t pos[VPT];
 			int32_t lmin = INT32_MAX, lmax = INT32_MIN;
 #pragma unroll
-			for (uint32_t k = 0; k < 4u; ++k) {
+			for (uint32_t k = 0; k < VPT; ++k) {
 				const uint32_t i = tid + 256u * k;
 				pos[k] = 0;
 				if (i >= npend) continue;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void k_digest_rollup(RollupP q)
 				atomicAdd(&o_cnt[cl], (unsigned long long)c_cnt[tid]);
 			}
 #pragma unroll
-			for (uint32_t k = 0; k < 4u; ++k) {
+			for (uint32_t k = 0; k < VPT; ++k) {
 				const uint32_t i = tid + 256u * k;
 				const uint32_t uv = wd[k] >> GYS_ROW_BITS;
 				if (i >= npend || uv >= GYS_MB_EXACT) continue;

@@ -36,7 +36,7 @@ def mid_buf(machine_id):
 
 class SketchEngine:
     def __init__(self, max_hosts, max_services, max_clusters=16, enable_tdigest=True, svc_hll_p=0, max_batch_events=1 << 20,
-                 rank=0, nranks=1, device=None, torch_arena=True, resp_path=0, enable_levels=False, td_buf_values=0, conn_pair_cms=False):
+                 rank=0, nranks=1, device=None, torch_arena=True, resp_path=0, enable_levels=False, td_buf_values=0, conn_pair_cms=False, td_pend_cap=0):
         import torch
         self.L = capi.load()
         if not torch.cuda.is_available():
@@ -55,6 +55,7 @@ class SketchEngine:
         cfg.resp_path = resp_path
         cfg.enable_levels = int(enable_levels)  # False / True / 2 (without the 5-s level)
         cfg.td_buf_values = td_buf_values
+        cfg.td_pend_cap = td_pend_cap
         cfg.conn_pair_cms = 1 if conn_pair_cms else 0
         cfg.max_batch_events = max_batch_events
         with torch.cuda.device(self.device):
@@ -604,7 +605,7 @@ class SketchEngine:
         """(npend [n], pend [n][CAP]): each row's live prefix sorted ascending, the rest -1 (the buffer itself is unordered)"""
         n = self.num_services() - first if n is None else n
         npend = np.zeros(n, dtype=np.uint32)
-        pend = np.zeros((n, capi.TD_PEND_CAP), dtype=np.int32)
+        pend = np.zeros((n, self.L.gys_td_pend_cap(self.h)), dtype=np.int32)
         capi.check(self.L.gys_export_tdigest_pending(self.h, first, n, C.c_void_p(npend.ctypes.data), C.c_void_p(pend.ctypes.data)))
         out = np.full_like(pend, -1)
         for i in range(n):

@@ -55,7 +55,8 @@ enum {
 
 #define GYS_MAX_BUCKETS 16 /* all reference hash classes have <= 15 buckets; records are padded to 16 slots */
 #define GYS_TD_NB 200      /* t-digest clusters per key (2 x the delta = 100 the reference hands to Postgres tdigest, common/gy_query_common.cc:1855) */
-#define GYS_TD_PEND_CAP 896 /* values a key's t-digest buffers before it is re-clustered (== GYS_TDIGEST_PEND_CAP) */
+#define GYS_TD_PEND_CAP 896 /* values a key's t-digest buffers before it is re-clustered, by default (== GYS_TDIGEST_PEND_CAP); gys_config.td_pend_cap */
+#define GYS_TD_PEND_CAP_MAX 3968 /* + 128 = 4096: the largest merge the one-workgroup value-bin kernel takes */
 #define GYS_HLL_P 14       /* global distinct-flow HLL precision: 16384 u8 registers */
 #define GYS_CMS_D 4
 #define GYS_CMS_W 65536
@@ -87,13 +88,19 @@ typedef struct {
 	                              2 = without the 5-s level (300 s / 5 days / all): a close touches the services only when it crosses a ring
 	                                  boundary (every 30 s); level 0 and gys_scan_listener_state_dev answer GYS_ERR_STATE, a period that
 	                                  folly would answer from the 5-s ring is answered from the 300-s ring */
-	uint32_t td_buf_values;    /* entries of a service's value buffer (GYS_TD_PEND_CAP + 64 .. 16384; 0 = sized to max_services): the values
+	uint32_t td_buf_values;    /* entries of a service's value buffer (td_pend_cap + 64 .. 16384; 0 = sized to max_services): the values
 	                              waiting for the next t-digest merge plus room for one batch's values of the service */
 	uint32_t conn_pair_cms;    /* TCP_CONN_NOTIFY records also feed a Count-Min pair OF THEIR OWN keyed by (ser_glob_id_, cli_task_aggr_id_): connections
 	                              (u32 table) and bytes (u64 table) per (listener, client task group) -- the roll-up MCONN_HANDLER keeps in
 	                              connlistenmap_ / connclientmap_ (server/gy_msocket.h:240-290, filled by add_tcp_conn_cli / _ser,
 	                              server/gy_mconnhdlr.cc:8643-9050).  8 more device atomics per record; off by default */
-	uint32_t reserved0;
+	uint32_t td_pend_cap;      /* values a service's t-digest buffers before it is re-clustered: 0 = GYS_TD_PEND_CAP (896), else 64 .. GYS_TD_PEND_CAP_MAX.
+	                              A batch's values of a service are appended while buffered + new <= td_pend_cap, otherwise ONE merge re-clusters
+	                              the digest with all of them (and a service whose next batch of the same size would pass the fast merge size -- the
+	                              smallest of 1024 / 2048 / 4096 values that is >= td_pend_cap + 128 -- is merged at once).  A merge costs almost the same whatever it carries (its work is per cluster and per value bin), so a
+	                              larger buffer means proportionally fewer merges per window: 3968 at 54 values per service and window = a merge
+	                              every ~70 windows instead of every ~17, for 4 x 3968 bytes more HBM per service.  The digest state is a function
+	                              of the per-call value multisets AND of this number (the CPU oracle takes the same parameter). */
 } gys_config;
 
 /* -------------------------------------------------------------------------------------------------------------------
@@ -609,7 +616,8 @@ int gys_export_tdigest(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, int64
 		       int32_t *minmax /* [nslots*2] */);
 /* values a service's t-digest still buffers unmerged (unordered; only the first npend[i] entries of row i are meaningful) */
 int gys_export_tdigest_pending(gys_ctx *ctx, uint32_t first_slot, uint32_t nslots, uint32_t *npend /* [nslots] */,
-			       int32_t *pend /* [nslots*GYS_TD_PEND_CAP] */);
+			       int32_t *pend /* [nslots * gys_td_pend_cap(ctx)] */);
+uint32_t gys_td_pend_cap(gys_ctx *ctx); /* the context's td_pend_cap (GYS_TD_PEND_CAP when the configuration left it 0) */
 /* per-service connection counters of the TCP_CONN_NOTIFY roll-up, [nslots*4]: nconn, nclose, bytes_sent, bytes_rcvd.  CONNECTIONS, not
  * records: only the ACCEPTING partha's records count (is_tcp_accept_event_, a loopback record included; the connecting half names the
  * same ser_glob_id_ and would count the connection twice), nconn += 1 on a record with notified_before_ clear (the open notification, or
@@ -645,6 +653,7 @@ typedef struct {
 	/* gys_ingest_tcp_conn / gys_ingest_listener_state calls that went through their submission queues, the combined batches they were
 	 * submitted as, and the submissions made by those queues' flusher threads */
 	uint64_t conn_calls_queued, conn_submissions, lstate_calls_queued, lstate_submissions, rec_tail_flushes;
+	uint64_t resp_run_overflow; /* response values a batch could not place (a run past the end of the batch staging area): 0 by construction, checked in the kernel */
 } gys_counters;
 int gys_get_counters(gys_ctx *ctx, gys_counters *out);
 /* response events the submission queue of gys_ingest_resp_events still holds on the HOST side (copied out of the callers' buffers, not yet

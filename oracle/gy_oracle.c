@@ -782,14 +782,36 @@ void gyo_tdb_init(gyo_td_buffered *b)
 	gyo_td_init(&b->d);
 }
 
+void gyo_tdb_init_cap(gyo_td_buffered *b, uint32_t cap)
+{
+	gyo_tdb_init(b);
+	b->cap = cap;
+	if (cap > GYO_TD_PEND_CAP) b->ext = (int32_t *)malloc((size_t)cap * sizeof(int32_t));
+}
+
+void gyo_tdb_free(gyo_td_buffered *b)
+{
+	free(b->ext);
+	b->ext = NULL;
+}
+
+static uint32_t tdb_cap(const gyo_td_buffered *b) { return b->cap ? b->cap : GYO_TD_PEND_CAP; }
+static int32_t *tdb_buf(gyo_td_buffered *b) { return b->ext ? b->ext : b->pend; }
+const int32_t *gyo_tdb_values(const gyo_td_buffered *b) { return b->ext ? b->ext : b->pend; }
+
 uint64_t gyo_tdb_total(const gyo_td_buffered *b) { return gyo_td_total(&b->d) + b->npend; }
 
 void gyo_tdb_add_batch(gyo_td_buffered *b, const int32_t *vals, size_t m)
 {
+	/* the engine's fast merge class for this buffer size: the smallest of 1024 / 2048 / 4096 values that leaves 128 of room (896 -> 1024 =
+	 * GYS_TDIGEST_MERGE_FAST) */
+	const size_t cap = tdb_cap(b), fast = cap + 128 <= 1024 ? 1024 : cap + 128 <= 2048 ? 2048 : 4096;
+	int32_t *buf = tdb_buf(b);
+
 	if (!m) return;
-	if ((size_t)b->npend + m <= GYO_TD_PEND_CAP) {
+	if ((size_t)b->npend + m <= cap) {
 		for (size_t i = 0; i < m; i++) {
-			b->pend[b->npend + i] = vals[i];
+			buf[b->npend + i] = vals[i];
 			if (vals[i] < b->d.vmin) b->d.vmin = vals[i];
 			if (vals[i] > b->d.vmax) b->d.vmax = vals[i];
 		}
@@ -797,13 +819,13 @@ void gyo_tdb_add_batch(gyo_td_buffered *b, const int32_t *vals, size_t m)
 		/* one more batch like this one would take the buffer past the size the engine re-clusters fastest: re-cluster now (the
 		 * per-key rate decides how full a buffer gets; without this rule a key with 200 - 500 values per batch would always merge
 		 * just above that size) */
-		if ((size_t)b->npend + m > GYS_TDIGEST_MERGE_FAST) {
-			gyo_td_merge_values(&b->d, b->pend, b->npend);
+		if ((size_t)b->npend + m > fast) {
+			gyo_td_merge_values(&b->d, buf, b->npend);
 			b->npend = 0;
 		}
 	} else {
 		int32_t *all = (int32_t *)malloc(((size_t)b->npend + m) * sizeof(int32_t));
-		memcpy(all, b->pend, (size_t)b->npend * sizeof(int32_t));
+		memcpy(all, buf, (size_t)b->npend * sizeof(int32_t));
 		memcpy(all + b->npend, vals, m * sizeof(int32_t));
 		gyo_td_merge_values(&b->d, all, (size_t)b->npend + m);
 		b->npend = 0;
@@ -814,7 +836,7 @@ void gyo_tdb_add_batch(gyo_td_buffered *b, const int32_t *vals, size_t m)
 void gyo_tdb_merged_view(const gyo_td_buffered *b, gyo_tdigest *out)
 {
 	*out = b->d;
-	if (b->npend) gyo_td_merge_values(out, b->pend, b->npend);
+	if (b->npend) gyo_td_merge_values(out, gyo_tdb_values(b), b->npend);
 }
 
 double gyo_tdb_quantile(const gyo_td_buffered *b, double q)

@@ -158,9 +158,16 @@ typedef struct {
 	gyo_tdigest d;
 	uint32_t npend;
 	int32_t pend[GYO_TD_PEND_CAP];
+	/* a buffer size other than the default (gys_config.td_pend_cap; gyo_tdb_init_cap): cap = its size (0 = GYO_TD_PEND_CAP) and, when it is larger
+	 * than the array above, ext = the buffer (owned: gyo_tdb_free) */
+	uint32_t cap;
+	int32_t *ext;
 } gyo_td_buffered;
 
 void gyo_tdb_init(gyo_td_buffered *b);
+void gyo_tdb_init_cap(gyo_td_buffered *b, uint32_t cap); /* cap: 64 .. 3968 */
+void gyo_tdb_free(gyo_td_buffered *b);
+const int32_t *gyo_tdb_values(const gyo_td_buffered *b); /* the npend buffered values */
 uint64_t gyo_tdb_total(const gyo_td_buffered *b);       /* merged + buffered */
 void gyo_tdb_add_batch(gyo_td_buffered *b, const int32_t *vals, size_t m);
 void gyo_tdb_merged_view(const gyo_td_buffered *b, gyo_tdigest *out); /* digest with the buffer merged in; b is not modified */

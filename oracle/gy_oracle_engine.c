@@ -39,7 +39,11 @@ typedef struct gyo_engine {
 
 static uint64_t lkey(uint32_t host, uint32_t netns, uint16_t port) { return ((uint64_t)host << 48) | ((uint64_t)netns << 16) | port; }
 
-gyo_engine *gyo_engine_new(uint32_t max_services, int enable_td)
+/* td_cap: the digests' buffer size (gys_config.td_pend_cap); 0 = the default GYO_TD_PEND_CAP */
+gyo_engine *gyo_engine_new_cap(uint32_t max_services, int enable_td, uint32_t td_cap);
+gyo_engine *gyo_engine_new(uint32_t max_services, int enable_td) { return gyo_engine_new_cap(max_services, enable_td, 0); }
+
+gyo_engine *gyo_engine_new_cap(uint32_t max_services, int enable_td, uint32_t td_cap)
 {
 	gyo_engine *e = (gyo_engine *)calloc(1, sizeof(*e));
 	uint32_t cap = 1;
@@ -62,7 +66,10 @@ gyo_engine *gyo_engine_new(uint32_t max_services, int enable_td)
 	for (uint32_t s = 0; s < max_services; s++) e->hist[(size_t)s * 16 + 15].sum = LONG_MIN;
 	if (enable_td) {
 		e->td = (gyo_td_buffered *)malloc((size_t)max_services * sizeof(gyo_td_buffered));
-		for (uint32_t s = 0; s < max_services; s++) gyo_tdb_init(&e->td[s]);
+		for (uint32_t s = 0; s < max_services; s++) {
+			if (td_cap) gyo_tdb_init_cap(&e->td[s], td_cap);
+			else gyo_tdb_init(&e->td[s]);
+		}
 		e->boff = (uint32_t *)calloc((size_t)max_services + 1, 4);
 	}
 	e->bcnt = (uint32_t *)calloc(max_services, 4);
@@ -72,6 +79,8 @@ gyo_engine *gyo_engine_new(uint32_t max_services, int enable_td)
 void gyo_engine_free(gyo_engine *e)
 {
 	if (!e) return;
+	if (e->td)
+		for (uint32_t s = 0; s < e->max_services; s++) gyo_tdb_free(&e->td[s]);
 	free(e->keys); free(e->vals); free(e->svc_gid); free(e->l_next); free(e->l_ip32); free(e->l_ip128); free(e->l_any); free(e->hist); free(e->bitmap); free(e->cms); free(e->td); free(e->bcnt); free(e->boff);
 	free(e);
 }

@@ -142,7 +142,7 @@ void gyo_td64_merge_service(gyo_td64 *d, const gyo_td_buffered *b)
 		if (b->d.vmin < d->vmin) d->vmin = b->d.vmin;
 		if (b->d.vmax > d->vmax) d->vmax = b->d.vmax;
 	}
-	gyo_td64_merge_values(d, b->pend, b->npend);
+	gyo_td64_merge_values(d, gyo_tdb_values(b), b->npend);
 }
 
 void gyo_td64_merge_td64(gyo_td64 *d, const gyo_td64 *o)

@@ -67,7 +67,12 @@ TD_PEND_CAP = 896
 
 
 class TDBuffered(C.Structure):
-    _fields_ = [("d", TDigest), ("npend", C.c_uint32), ("pend", C.c_int32 * TD_PEND_CAP)]
+    _fields_ = [("d", TDigest), ("npend", C.c_uint32), ("pend", C.c_int32 * TD_PEND_CAP), ("cap", C.c_uint32), ("ext", C.POINTER(C.c_int32))]
+
+    def values(self):
+        """the npend buffered values (a buffer larger than the default lives behind ext)"""
+        src = self.ext if bool(self.ext) else self.pend
+        return np.array(src[:self.npend], dtype=np.int32)
 
 
 BTS_MAXB = 16
@@ -219,6 +224,10 @@ def lib():
     _sig(L, "gyo_mlh_period", None, [C.POINTER(MLHist), C.c_int64, C.c_int64, C.c_void_p])
     _sig(L, "gyo_mlh_get_stats_for_period", None, [C.POINTER(MLHist), C.c_int64, C.c_int64, f32p, C.c_size_t, i64p, i64p, i64p, C.POINTER(C.c_double)])
     _sig(L, "gyo_engine_new", C.c_void_p, [C.c_uint32, C.c_int])
+    _sig(L, "gyo_engine_new_cap", C.c_void_p, [C.c_uint32, C.c_int, C.c_uint32])
+    _sig(L, "gyo_tdb_init_cap", None, [C.POINTER(TDBuffered), C.c_uint32])
+    _sig(L, "gyo_tdb_free", None, [C.POINTER(TDBuffered)])
+    _sig(L, "gyo_tdb_values", C.POINTER(C.c_int32), [C.POINTER(TDBuffered)])
     _sig(L, "gyo_engine_free", None, [C.c_void_p])
     _sig(L, "gyo_engine_register", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint16])
     _sig(L, "gyo_engine_resp_batch", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
@@ -399,9 +408,10 @@ def td_to_arrays(d):
 class OracleEngine:
     """python handle on the sequential CPU restatement of the response-event hot path (gy_oracle_engine.c)"""
 
-    def __init__(self, max_services, enable_td=True):
+    def __init__(self, max_services, enable_td=True, td_cap=0):
         self.L = lib()
-        self.h = self.L.gyo_engine_new(max_services, 1 if enable_td else 0)
+        self.td_cap = td_cap or TD_PEND_CAP
+        self.h = self.L.gyo_engine_new_cap(max_services, 1 if enable_td else 0, td_cap)
         self.enable_td = enable_td
 
     def __del__(self):
@@ -483,11 +493,13 @@ class OracleEngine:
         """buffered (unmerged) values of every service, each row sorted ascending and padded with -1: (npend [n], pend [n][CAP])"""
         n = self.nsvc
         npend = np.zeros(n, dtype=np.uint32)
-        pend = np.full((n, TD_PEND_CAP), -1, dtype=np.int32)
+        pend = np.full((n, self.td_cap), -1, dtype=np.int32)
         for s in range(n):
             b = self.td(s)
             npend[s] = b.npend
-            pend[s, :b.npend] = np.sort(np.frombuffer(b.pend, dtype=np.int32)[:b.npend])
+            if b.npend:
+                src = self.L.gyo_tdb_values(C.byref(b))
+                pend[s, :b.npend] = np.sort(np.ctypeslib.as_array(src, shape=(b.npend,)))
         return npend, pend
 
     def counters(self):

@@ -20,6 +20,7 @@
 extern "C" {
 struct gyo_engine;
 gyo_engine *gyo_engine_new(uint32_t max_services, int enable_td);
+gyo_engine *gyo_engine_new_cap(uint32_t max_services, int enable_td, uint32_t td_cap);
 void gyo_engine_free(gyo_engine *e);
 int gyo_engine_register(gyo_engine *e, uint32_t host_slot, uint64_t glob_id, uint32_t netns, uint16_t port);
 int gyo_engine_register_addr(gyo_engine *e, uint32_t host_slot, uint64_t glob_id, uint32_t netns, uint16_t port, const uint8_t *ip, int is_v6, int is_any);
@@ -50,6 +51,13 @@ const uint64_t *gyo_engine_counters(const gyo_engine *e);
 #ifndef KEMU_MODE
 #define KEMU_MODE 0
 #endif
+// KEMU_PEND_CAP: the digests' buffer size (gys_config.td_pend_cap): 896 = the default (merges of up to 1024 values, k_digest_bins<., 4>),
+// up to 1920 -> k_digest_bins<., 8>, up to 3968 -> k_digest_bins<., 16>
+#ifndef KEMU_PEND_CAP
+#define KEMU_PEND_CAP GYS_TD_PEND_CAP
+#endif
+#define KEMU_FAST (KEMU_PEND_CAP + 128u <= 1024u ? 1024u : KEMU_PEND_CAP + 128u <= 2048u ? 2048u : 4096u)
+#define KEMU_VPT (KEMU_FAST <= 1024u ? 4u : KEMU_FAST <= 2048u ? 8u : 16u)
 
 using namespace gys;
 
@@ -91,12 +99,12 @@ int main(int argc, char **argv)
 #else
 	const uint32_t NH = 3, L[NH] = {150, 37, 64};
 #endif
-	const uint32_t pcap = GYS_MERGE_CLASS0 + 128u > GYS_TD_PEND_CAP + 256u ? GYS_MERGE_CLASS0 + 128u : GYS_TD_PEND_CAP + 256u;
+	const uint32_t pcap = KEMU_FAST + 128u;
 	uint32_t nsvc = 0;
 	for (uint32_t h = 0; h < NH; ++h) nsvc += L[h];
 
 	// ---- registration: oracle engine + the host-local structures k_resp_host reads
-	gyo_engine *orc = gyo_engine_new(nsvc + 8, 1), *orcw = gyo_engine_new(nsvc + 8, 1); // orcw: cleared at the window boundaries
+	gyo_engine *orc = gyo_engine_new_cap(nsvc + 8, 1, KEMU_PEND_CAP), *orcw = gyo_engine_new_cap(nsvc + 8, 1, KEMU_PEND_CAP); // orcw: cleared at the window boundaries
 	std::vector<ListenerCand> cands;
 	std::vector<HostDesc> hdesc(NH);
 	std::vector<uint64_t> htbl;
@@ -263,6 +271,8 @@ int main(int argc, char **argv)
 		fin.td_meta = meta.data();
 		fin.nsvc = nsvc;
 		fin.pcap = pcap;
+		fin.pend_cap = KEMU_PEND_CAP;
+		fin.merge_fast = KEMU_FAST;
 		fin.epoch = epoch;
 		fin.resp_win = resp_win.data();
 		fin.list[FIN_CLASS0] = list0.data();
@@ -336,6 +346,7 @@ int main(int argc, char **argv)
 		q.d.td_pend = td_pend.data();
 		q.d.td_cur = td_cur.data();
 		q.d.pcap = pcap;
+		q.d.pend_cap = KEMU_PEND_CAP;
 		q.d.nsvc = nsvc;
 		q.d.staged = staged.data();
 		q.d.hist_win = hist_win.data();
@@ -348,7 +359,7 @@ int main(int argc, char **argv)
 #if defined(KEMU_BINS_TEMPLATE_NT)
 		kemu::launch(2, KEMU_BINS_NT, 0, [&] { k_digest_bins<false, KEMU_BINS_NT>(q); });
 #else
-		kemu::launch(2, KEMU_BINS_NT, 0, [&] { k_digest_bins<false>(q); });
+		kemu::launch(2, KEMU_BINS_NT, 0, [&] { k_digest_bins<false, KEMU_VPT>(q); });
 #endif
 		CHECK(counts[FIN_SLOW] == 0, "hand-over list not empty");
 		if (counts[FIN_CLASS1]) { // keys whose batch took them past the fast class: the cluster-gap kernel
@@ -385,7 +396,7 @@ int main(int argc, char **argv)
 			const gyo_td_buffered *ot = gyo_engine_td(orc, s);
 			CHECK(meta[s].npend == ot->npend && (td_cur[s] & ~GYS_SPILL_BIT) == ot->npend, "batch %u key %u buffered %u (cur %u) want %u", batch, s, meta[s].npend, td_cur[s], ot->npend);
 			if (meta[s].npend == ot->npend) {
-				std::vector<int32_t> a(ot->npend), b(ot->pend, ot->pend + ot->npend);
+				std::vector<int32_t> a(ot->npend), b(gyo_tdb_values(ot), gyo_tdb_values(ot) + ot->npend);
 				for (uint32_t i = 0; i < ot->npend; ++i) a[i] = (int32_t)(td_pend[(size_t)s * pcap + i] >> GYS_ROW_BITS);
 				std::sort(a.begin(), a.end());
 				std::sort(b.begin(), b.end());

@@ -125,6 +125,7 @@ int main(int argc, char **argv)
 	q.d.td_minmax = minmax.data();
 	q.d.td_pend = td_pend.data();
 	q.d.pcap = pcap;
+	q.d.pend_cap = GYS_TD_PEND_CAP;
 	q.d.nsvc = S;
 	q.off = off.data();
 	q.members = members.data();

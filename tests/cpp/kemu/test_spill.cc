@@ -36,6 +36,10 @@ const uint64_t *gyo_engine_counters(const gyo_engine *e);
 #define KEMU_BINS_NT 256
 #endif
 
+#ifndef KEMU_APPEND_CAP
+#define KEMU_APPEND_CAP 3u
+#endif
+
 using namespace gys;
 
 namespace {
@@ -185,6 +189,8 @@ int main(int argc, char **argv)
 		fin.td_meta = meta.data();
 		fin.nsvc = nsvc;
 		fin.pcap = pcap;
+		fin.pend_cap = GYS_TD_PEND_CAP;
+		fin.merge_fast = GYS_TDIGEST_MERGE_FAST;
 		fin.epoch = epoch;
 		fin.resp_win = resp_win.data();
 		fin.list[FIN_CLASS0] = list0.data();
@@ -197,6 +203,7 @@ int main(int argc, char **argv)
 		fin.host_spill = host_spill.data();
 		fin.spill_stamp = ++stamp;
 		fin.counters = counters.data();
+		fin.staged_cap = (uint32_t)staged.size();
 #ifdef KEMU_PRESPILL
 		fin.td_run0 = td_run0.data();
 		fin.td_run1 = td_run1.data();
@@ -204,6 +211,10 @@ int main(int argc, char **argv)
 		fin.hot = pre_hot.data();
 		fin.hot_wr = (pre_seq & 1u) ^ 1u;
 		fin.append_list = append_list.data();
+		// (the append list is shorter than the keys batch 5 puts on it: the rest is copied by the finalizing threads themselves)
+		fin.append_cap = KEMU_APPEND_CAP;
+		fin.td_pend = td_pend.data();
+		fin.staged = staged.data();
 		counts[FIN_APPEND] = 0;
 		{
 			PreSpillP pp{};
@@ -220,14 +231,17 @@ int main(int argc, char **argv)
 			pp.batch_stamp = stamp + 1u;
 			pp.nsvc = nsvc;
 			pp.pcap = pcap;
-			pp.run_limit = (uint32_t)(staged.size() - n);
+			pp.pend_cap = GYS_TD_PEND_CAP;
+			// (batch 7: no room for predicted runs -- the cursor stays where it is and the keys take the exact-run fall-back)
+			pp.run_limit = batch == 7 ? 100u : (uint32_t)(staged.size() - n);
 			++pre_seq;
 			kemu::launch(1, 256, 0, [&] { k_mark_hosts(segs.data(), NH, host_batch.data(), stamp + 1u); });
 			kemu::launch((nsvc + 255u) / 256u, 256, 0, [&] { k_prespill(pp); });
 		}
 		uint32_t npred = 0;
 		for (uint32_t s = 0; s < nsvc; ++s) npred += (td_cur[s] & GYS_SPILL_BIT) ? 1u : 0u;
-		CHECK(npred == ((batch == 1 || batch == 4 || batch == 5 || batch == 7 || batch == 8) ? L[0] : 0u), "batch %u: %u keys got a predicted run", batch, npred);
+		CHECK(npred == ((batch == 1 || batch == 4 || batch == 5 || batch == 8) ? L[0] : 0u), "batch %u: %u keys got a predicted run", batch, npred);
+		if (batch == 7) CHECK(counts[FIN_RUN_ALLOC] == 0, "batch 7: the cursor moved by %u though no run was accepted", counts[FIN_RUN_ALLOC]);
 #endif
 		RespHostP hp{};
 		hp.ev = ev64.data();
@@ -260,13 +274,13 @@ int main(int argc, char **argv)
 		CHECK(counts[FIN_RUN_ALLOC] <= staged.size(), "run area too small");
 #ifdef KEMU_PRESPILL
 		// batches 7 and 8 are predicted right (no second pass), batches 1 and 4 overflow their predicted runs (second pass), batch 5's runs go into the buffers
-		const bool expect_spill = batch == 1 || batch == 3 || batch == 4 || batch == 6;
+		const bool expect_spill = batch == 1 || batch == 3 || batch == 4 || batch == 6 || batch == 7;
 		if (batch == 5) {
-			CHECK(counts[FIN_APPEND] == L[0], "batch 5: %u keys on the append list", counts[FIN_APPEND]);
-			n_pre_append += counts[FIN_APPEND];
+			CHECK(counts[FIN_APPEND] == std::min<uint32_t>(L[0], KEMU_APPEND_CAP), "batch 5: %u keys on the append list", counts[FIN_APPEND]);
+			n_pre_append += L[0];
 		} else
 			CHECK(counts[FIN_APPEND] == 0, "batch %u: %u keys on the append list", batch, counts[FIN_APPEND]);
-		if (batch == 7 || batch == 8) n_pre_inplace += L[0];
+		if (batch == 8) n_pre_inplace += L[0];
 		if (batch == 1 || batch == 4) n_pre_fallback += L[0];
 		kemu::launch(2, 256, 0, [&] { k_run_append(append_list.data(), &counts[FIN_APPEND], staged.data(), td_pend.data(), pcap); });
 #else
@@ -284,6 +298,7 @@ int main(int argc, char **argv)
 		q.d.td_pend = td_pend.data();
 		q.d.td_cur = td_cur.data();
 		q.d.pcap = pcap;
+		q.d.pend_cap = GYS_TD_PEND_CAP;
 		q.d.nsvc = nsvc;
 		q.d.staged = staged.data();
 		q.d.hist_win = hist_win.data();

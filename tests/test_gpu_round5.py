@@ -362,3 +362,49 @@ def test_duplicate_listener_records_through_the_device_entry_point(torch_mod, or
             assert eng.svcsumm(info[h][0]).as_tuple() == summ[h].as_tuple(), "host %d summary" % h
         eng.window_close()  # (a state stays current for the window after its own: the next round starts two windows on)
     eng.close()
+
+
+@pytest.mark.parametrize("cap", [1920, 3968, 3072])
+def test_larger_digest_buffers_equal_the_oracle_with_the_same_buffer(torch_mod, oracle, cap):
+    """gys_config.td_pend_cap: the digests buffer more values between re-clusterings (merges of up to 2048 / 4096 values through the larger
+    instances of the value-bin kernel).  State after every round == the oracle engine built with the same buffer size; the all-service
+    quantile scan, a roll-up digest and single-service quantiles read the larger buffers as well."""
+    torch = torch_mod
+    rng = np.random.default_rng(60 + cap)
+    nh, sp = 3, 40
+    eng = _engine(max_hosts=4, max_services=nh * sp, max_batch_events=1 << 20, td_pend_cap=cap)
+    orc = oracle.OracleEngine(nh * sp, td_cap=cap)
+    assert eng.L.gys_td_pend_cap(eng.h) == cap
+    info, gids = helpers.register_world(eng, orc, range(nh), sp)
+    L = oracle.lib()
+    merges0 = 0
+    for rnd in range(9):
+        for h in range(nh):
+            # ~400 .. 1600 values per service and call: several calls fill a buffer, some calls overflow the fast merge class at once (class 1 / several-workgroup paths)
+            n = int(rng.integers(400, 1600)) * sp if rnd != 6 else 5000 * sp
+            ev = helpers.make_resp_events(rng, h, n, sp, lat_mu=3.0 + 0.8 * h, lat_sigma=1.7)
+            eng.handle_resp_events(info[h][0], ev)
+            orc.resp_batch(ev.tobytes(), [info[h][1]], [0])
+        eng.sync()
+        n = orc.nsvc
+        gs, gc, gm = eng.export_tdigest(0, n)
+        os_, oc, om = orc.td_arrays()
+        assert (gc == oc).all() and (gs == os_).all() and (gm == om).all(), "round %d" % rnd
+        gn, gp = eng.export_tdigest_pending(0, n)
+        on, op = orc.td_pending()
+        assert gp.shape == op.shape == (n, cap)
+        assert (gn == on).all() and (gp == op).all()
+        helpers.assert_hist_equal(eng.export_hist(0, 0, n), orc.hist(), n)
+    assert int(gn.max()) > 1024 or cap < 1024  # the larger buffers are really in use
+    c = eng.counters()
+    assert c["td_merges"] > 0
+    # single-service quantiles (merged view through the query kernel) and the all-service scan (k_digest_bins<SCAN, VPT>)
+    qs = [0.25, 0.5, 0.95, 0.99]
+    for h in range(nh):
+        for s in (0, sp // 2, sp - 1):
+            g = int(gids[h][s])
+            assert eng.quantiles(g, qs) == [L.gyo_tdb_quantile(C.byref(orc.td(eng.lookup(g))), q) for q in qs]
+    got = np.asarray(eng.scan_quantiles(qs)).reshape(orc.nsvc, len(qs))
+    want = np.array([[L.gyo_tdb_quantile(C.byref(orc.td(s)), q) for q in qs] for s in range(orc.nsvc)])
+    assert (got == want).all()
+    eng.close()

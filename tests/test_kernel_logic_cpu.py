@@ -47,10 +47,16 @@ PROGRAMS = {
     "bins-12345": ("test_bins.cc", BINS, ["12345"], "kemu bins ok"),
     "bins-7": ("test_bins.cc", BINS, ["7"], "kemu bins ok"),
     "bins-99": ("test_bins.cc", BINS, ["99"], "kemu bins ok"),
+    # the instances for larger buffers (gys_config.td_pend_cap): merges of up to 2048 / 4096 values, hand-over of merges with more large values than the list holds
+    "bins-2048-values": ("test_bins.cc", ["KEMU_BINS_VPT=8"] + BINS, ["12345"], "kemu bins ok"),
+    "bins-4096-values": ("test_bins.cc", ["KEMU_BINS_VPT=16"] + BINS, ["12345"], "kemu bins ok"),
     "resp-tiles-16384": ("test_resp.cc", ["KEMU_TPT=16"] + BINS, ["4242"], "kemu resp ok"),
     "resp-tiles-6144": ("test_resp.cc", ["KEMU_TPT=12"] + BINS, ["4242"], "kemu resp ok"),
     "resp-512x32-prefetch": ("test_resp.cc", ["KEMU_TPT=32"] + BINS, ["4242"], "kemu resp ok"),
     "resp-split-form": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_SPLIT", "KEMU_NB=3"] + BINS, ["4242"], "kemu resp ok"),
+    # the whole pipeline with td_pend_cap 1536 / 3072 (fast merge classes of 2048 / 4096 values) against the oracle engine with the same buffer size
+    "resp-pend-cap-1536": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_PEND_CAP=1536", "KEMU_NB=12"] + BINS, ["4246"], "kemu resp ok"),
+    "resp-pend-cap-3072": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_PEND_CAP=3072", "KEMU_NB=18"] + BINS, ["4247"], "kemu resp ok"),
     # keys with candidates (bound-address listeners, two listeners on one port): the event's server address picks the listener
     "resp-bound-address": ("test_resp.cc", ["KEMU_TPT=16", "KEMU_MODE=1"] + BINS, ["4243"], "kemu resp ok"),
     # the same world, batches alternating between IPv4 events and 48-byte IPv6 events (resp_bitmap_v6_ rows, embedded IPv4 addresses)
