@@ -302,6 +302,9 @@ SUB_CONFIGS = [  # (name, BASELINE.json config it stands for, bench.py arguments
      ["--hosts", "1", "--svcs", "100", "--events", str(1 << 26), "--steps", "20", "--warmup", "5", "--nbuf", "2"]),
     ("c5_zipf", "configs[4] shape: 10^5 services, Zipf 1.1, one hipGraph-captured window close per 2^29-event batch",
      ["--zipf-milli", "1100", "--hosts", "50", "--svcs", "2000", "--steps", "20", "--warmup", "5", "--nbuf", "2"]),
+    ("c3_levels", "configs[2] with the multi-level windows on (5 s / 300 s / 5 days / all per service: what the reference's 5-s flush does per listener, "
+                  "common/gy_socket_stat.cc:4163-4172 + TIME_HISTOGRAM levels common/gy_statistics.h:1082-1551)",
+     ["--levels", "1", "--steps", "24", "--warmup", "6", "--nbuf", "2"]),
 ]
 
 
@@ -678,7 +681,8 @@ def main():
     ap.add_argument("--no-host-fed", action="store_true", help="skip the (untimed) host-fed measurement: pinned H2D copy + ingest")
     ap.add_argument("--no-dephase", action="store_true", help="skip the untimed pass that spreads the keys' buffer fill levels")
     ap.add_argument("--prime-windows", type=int, default=-1, help="untimed ordinary windows after the de-phase pass (-1: one buffer cycle)")
-    ap.add_argument("--td-pend-cap", type=int, default=0, help="gys_config.td_pend_cap: values a service's digest buffers before it is re-clustered (0 = the library default, 896; up to 3968)")
+    ap.add_argument("--td-pend-cap", type=int, default=1920, help="gys_config.td_pend_cap: values a service's digest buffers before it is re-clustered (0 = the library default, 896; up to 3968).  "
+                    "1920: merges of up to 2048 values -- half the merges per window of the 896-value buffer at 2/3 of their total time (profiles/r5e_*, r5f_*)")
     ap.add_argument("--nbuf", type=int, default=6, help="distinct device-resident event batches the windows cycle through")
     ap.add_argument("--cpu-events", type=int, default=1 << 26)
     ap.add_argument("--cpu-hosts", type=int, default=1000)
@@ -923,6 +927,14 @@ def main():
         eng.profile(False)
         scan = {"services": nsvc, "quantiles": [0.25, 0.95, 0.99], "kernel_ms": sp_[0], "wall_ms_incl_copy_to_host": t_scan * 1e3,
                 "services_per_s": nsvc / (sp_[0] * 1e-3) if sp_[0] > 0 else None, "p99_mean_ms": float(qv[:, 2].mean())}
+        try:  # the global response-time digest of this rank (what the C4 global query costs per rank before the slabs cross the ranks): every host's services rolled up, then the hosts
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, gslab = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)
+            scan["global_rollup_ms"] = (time.perf_counter() - t0) * 1e3
+            scan["global_rollup_weight"] = int(gslab["cnt"].sum())
+        except Exception as ex:  # noqa: BLE001
+            scan["global_rollup_error"] = str(ex)[:200]
     host_fed = None
     if rank == 0 and world == 1 and not args.no_host_fed and nsvc:
         host_fed = host_fed_rate(eng, torch, min(args.events, 1 << 26), nlocal, args.svcs)

@@ -936,7 +936,25 @@ int fold_range(gys_ctx *c, uint32_t first, uint32_t n)
 	f.n = n;
 	ProfScope ps(c, "fold");
 	const uint32_t nchunks = (n + 63u) / 64u;
-	hipLaunchKernelGGL(k_fold, dim3(std::min<uint32_t>((nchunks + 3u) / 4u, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, f);
+	hipLaunchKernelGGL(k_fold<false>, dim3(std::min<uint32_t>((nchunks + 3u) / 4u, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, f);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+}
+
+// window close with the 5-s level: every service's records are brought up to date AND its closing-window record goes to lvl_last in the same pass
+int fold_close_levels(gys_ctx *c, int64_t tnow)
+{
+	FoldP f{};
+	f.d = digest_params(c);
+	f.first = 0;
+	f.n = c->nsvc;
+	f.last = c->lvl_last;
+	f.first_sec = c->lvl_first;
+	f.tnow = tnow;
+	f.epoch = c->epoch;
+	ProfScope ps(c, "fold");
+	const uint32_t nchunks = (c->nsvc + 63u) / 64u;
+	hipLaunchKernelGGL(k_fold<true>, dim3(std::min<uint32_t>((nchunks + 3u) / 4u, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, f);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
 }
@@ -1434,17 +1452,25 @@ int level_roll(gys_ctx *c, uint64_t tusec)
 		HIPCHK(hipGetLastError());
 		return GYS_OK;
 	}
+	// every service's closing-window record must be complete; with lazily folded records and the 5-s level the fold pass itself leaves level 0
+	// (and the services' first close time) behind: k_level_roll then only runs when a ring boundary was crossed (every 6th close), for the snapshots
+	// (GYS_FUSED_LAST: level 0 written by the fold pass itself, k_fold<true>, instead of by k_level_roll in a pass of its own.  Measured in round 5
+	// (profiles/r5i_levels_fused_vs_separate.txt): fold 2.74 -> 4.68 ms for the 1.07 ms of k_level_roll it replaces -- the fold walks 4 keys per
+	// wave and round and waits for its stores at every round; one more 256-byte store per key in that loop costs more than a streaming pass.  Off.)
+	static const bool fused_env = getenv("GYS_FUSED_LAST") != nullptr;
+	const bool fused_last = keep_last && c->cfg.enable_tdigest && fused_env;
 	{
-		const int rcf = fold_range(c, 0, c->nsvc); // every service's closing-window record must be complete
+		const int rcf = fused_last ? fold_close_levels(c, tnow) : fold_range(c, 0, c->nsvc);
 		if (rcf) return rcf;
 	}
+	if (fused_last && !(p.mask[0] | p.mask[1])) return GYS_OK;
 	p.win = c->hist_win;
 	p.all = c->hist_all;
 	p.meta = c->cfg.enable_tdigest ? c->td_meta : nullptr;
 	p.epoch = c->epoch;
 	p.nsvc = c->nsvc;
 	p.snap = c->lvl_snap;
-	p.last = keep_last ? c->lvl_last : nullptr;
+	p.last = keep_last && !fused_last ? c->lvl_last : nullptr;
 	p.stride = c->cfg.max_services;
 	p.first_sec = c->lvl_first;
 	p.tnow = tnow;

@@ -879,6 +879,30 @@ __host__ __device__ __forceinline__ size_t resp_host_lds_bytes(uint32_t tbl_entr
 #ifndef GYS_OPAQUE_LOADED4
 #define GYS_OPAQUE_LOADED4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
 #endif
+// the event words are read once: a non-temporal load leaves the L2 to the lines the flush is still filling (a key's piece of ~16 words ends inside
+// a 128-byte line that the key's next piece, one tile later, completes -- evicted in between, the line is written twice)
+#ifndef GYS_EV_NT
+#define GYS_EV_NT 0 // (r5f: 5.30 -> 5.80 ms with non-temporal event loads: the three 8-byte words of an event come from one line, the second and third read want it cached)
+#endif
+#ifndef GYS_EV_X3
+#define GYS_EV_X3 0 // (r5g: 5.27 -> 5.60 ms with two fully coalesced 12-byte loads per event + a DPP swap of halves between neighbouring lanes instead of the three strided 8-byte loads: the loads are not what the event phase waits for, the extra moves and registers cost more than the request efficiency gains)
+#endif
+struct __attribute__((packed, aligned(4))) Ev3 {
+	uint32_t x, y, z;
+};
+__device__ __forceinline__ uint32_t gys_swap_pair(uint32_t v) // the neighbouring lane's value (lanes 2j <-> 2j + 1): DPP quad_perm [1, 0, 3, 2]
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+#else
+	return (uint32_t)__shfl_xor((int)v, 1, 64);
+#endif
+}
+#if GYS_EV_NT
+#define GYS_EV_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define GYS_EV_LOAD(p) (*(p))
+#endif
 #define GYS_MEM_FENCE() asm volatile("" ::: "memory") // compiler-only: memory operations are not moved across it (keeps a batch of LDS reads in front of the stores / the next batch)
 
 // MODE 0: IPv4 events, every listener of the batch's hosts alone on its (netns, port) key and bound to the any-address (the instance of the
@@ -1054,10 +1078,28 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 						w0[u] = 0;
 						w1[u] = tb[GYS_EV6_WORDS * oo + 4u];
 						w2[u] = tb[GYS_EV6_WORDS * oo + 5u];
+					} else if (GYS_EV_X3) {
+						// Two 12-byte loads per lane instead of three 8-byte ones with a 24-byte stride: lane l of a wave reads HALF-events --
+						// load A the halves of the block's events 0..31 (lane 2j: first half of event j, lane 2j + 1: its second half), load B
+						// those of events 32..63 -- so every load instruction covers 768 contiguous bytes (six full lines; the strided form touches
+						// twelve lines per instruction and each line three times).  Neighbouring lanes then swap halves (DPP quad_perm): the even
+						// lane ends with event j, the odd lane with event 32 + j.
+						const uint32_t e_blk = (uint32_t)(g + u) * T + (tid & ~63u), par = lane & 1u;
+						const uint32_t ev_a = e_blk + (lane >> 1), ev_b = ev_a + 32u;
+						const Ev3 *hp = (const Ev3 *)tb;
+						const Ev3 a = hp[ev_a < rem ? 2u * ev_a + par : par], b = hp[ev_b < rem ? 2u * ev_b + par : par];
+						const uint32_t xa0 = gys_swap_pair(a.x), xa1 = gys_swap_pair(a.y), xa2 = gys_swap_pair(a.z);
+						const uint32_t xb0 = gys_swap_pair(b.x), xb1 = gys_swap_pair(b.y), xb2 = gys_swap_pair(b.z);
+						const uint32_t d0 = par ? xb0 : a.x, d1 = par ? xb1 : a.y, d2 = par ? xb2 : a.z; // first half: saddr, daddr, netns
+						const uint32_t d3 = par ? b.x : xa0, d4 = par ? b.y : xa1, d5 = par ? b.z : xa2; // second half: ports, lsndtime, lrcvtime
+						in[u] = (par ? ev_b : ev_a) < rem;
+						w0[u] = (uint64_t)d0 | ((uint64_t)d1 << 32);
+						w1[u] = (uint64_t)d2 | ((uint64_t)d3 << 32);
+						w2[u] = (uint64_t)d4 | ((uint64_t)d5 << 32);
 					} else {
-						w0[u] = tb[3u * oo];
-						w1[u] = tb[3u * oo + 1u];
-						w2[u] = tb[3u * oo + 2u];
+						w0[u] = GYS_EV_LOAD(&tb[3u * oo]);
+						w1[u] = GYS_EV_LOAD(&tb[3u * oo + 1u]);
+						w2[u] = GYS_EV_LOAD(&tb[3u * oo + 2u]);
 					}
 				}
 			}
@@ -1205,7 +1247,8 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 #pragma unroll 1
 				for (uint32_t u = 0; u < 4u; ++u) {
 					if (!((rare >> u) & 1u)) continue;
-					const uint32_t o = ((uint32_t)g + u) * T + tid;
+					// (the event this lane holds in place u of the group: see the load above)
+					const uint32_t o = (GYS_EV_X3 && !V6 && !PF) ? ((uint32_t)g + u) * T + (tid & ~63u) + (lane >> 1) + ((lane & 1u) ? 32u : 0u) : ((uint32_t)g + u) * T + tid;
 					uint64_t h64;
 					if (V6) {
 						const uint64_t a0 = tb[GYS_EV6_WORDS * o], a1 = tb[GYS_EV6_WORDS * o + 1u], d0 = tb[GYS_EV6_WORDS * o + 2u], d1 = tb[GYS_EV6_WORDS * o + 3u],
@@ -1515,7 +1558,7 @@ struct DigestP {
 //   window record: a record of an older window is dropped first (the reference clears the 5-s state on its timer,
 //   GY_HISTOGRAM::clear :630-636; here a key rolls when the first values of a later window are folded), then += dw; same for the rows.
 __device__ __forceinline__ void fold_records(const DigestP &p, uint32_t slot, uint32_t g, bool roll, unsigned long long da, unsigned long long dw,
-					     uint32_t n_all, uint32_t n_win, int32_t max_all, int32_t max_win, uint32_t bm, uint32_t bm6)
+					     uint32_t n_all, uint32_t n_win, int32_t max_all, int32_t max_win, uint32_t bm, uint32_t bm6, uint4 *win_out = nullptr)
 {
 	uint4 *ap = (uint4 *)&p.hist_all[slot] + g, *wp = (uint4 *)&p.hist_win[slot] + g;
 	if (n_all) {
@@ -1545,6 +1588,7 @@ __device__ __forceinline__ void fold_records(const DigestP &p, uint32_t slot, ui
 			if ((int64_t)hi < (int64_t)max_win) hi = (uint64_t)(int64_t)max_win;
 		}
 		if (roll || g == 15u || dw) *wp = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+		if (win_out) *win_out = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)); // (lane g's pair of the window record as it stands now)
 		uint32_t *bp = &p.bitmap[(size_t)slot * GYS_BM_WORDS + g];
 		const uint32_t old = roll ? 0u : *bp;
 		if (roll || (old | bm) != old) *bp = old | bm;
@@ -1561,8 +1605,17 @@ __device__ __forceinline__ void fold_records(const DigestP &p, uint32_t slot, ui
 struct FoldP {
 	DigestP d;
 	uint32_t first, n;
+	// LEVELS (window close with the 5-s level, gys_config.enable_levels = 1): the same pass leaves the closing window's record of EVERY service
+	// of the range in last[] (level 0: the window closed last; a service without values in the closing window gets the empty record) and
+	// the time of a service's first window close in first_sec[] -- what k_level_roll did in a pass of its own (a second read of every
+	// window record, 272 of ~1 600 bytes per service and close)
+	gys_hist_rec *last;
+	int64_t *first_sec;
+	int64_t tnow;
+	uint32_t epoch; // the window being closed
 };
 
+template <bool LEVELS>
 __global__ __launch_bounds__(256) void k_fold(FoldP q)
 {
 	const DigestP &p = q.d;
@@ -1577,12 +1630,14 @@ __global__ __launch_bounds__(256) void k_fold(FoldP q)
 		const uint32_t rel = chunk * 64u + lane;
 		uint4 mraw = make_uint4(0, 0, 0, 0);
 		if (rel < q.n) mraw = *(const uint4 *)&p.td_meta[q.first + rel];
-		const unsigned long long todo = __ballot(mraw.x > (mraw.y & 0xFFFFu));
+		const unsigned long long todo = LEVELS ? __ballot(rel < q.n) : __ballot(mraw.x > (mraw.y & 0xFFFFu));
+		if (LEVELS && rel < q.n && q.first_sec[q.first + rel] == 0) q.first_sec[q.first + rel] = q.tnow; // BucketedTimeSeries::update on an empty series (one coalesced access per chunk: inside the per-key rounds below the read would be one more dependent round trip per round)
 		if (!todo) continue;
 		for (uint32_t rd = 0; rd < 16u; ++rd) {
 			if (!((todo >> (4u * rd)) & 0xFull)) continue;
 			const uint32_t k = rd * 4u + row;
 			const uint32_t slot = q.first + chunk * 64u + k;
+			const bool live = chunk * 64u + k < q.n; // (LEVELS: every service of the range is visited; a short last chunk has rows past the end)
 			uint4 mt;
 			mt.x = (uint32_t)__shfl((int)mraw.x, (int)k, 64);
 			mt.y = (uint32_t)__shfl((int)mraw.y, (int)k, 64);
@@ -1625,14 +1680,30 @@ __global__ __launch_bounds__(256) void k_fold(FoldP q)
 				wmax = max(wmax, __shfl_xor(wmax, d, 64));
 			}
 			GYS_WAVE_SYNC();
+			uint32_t hw_now = mt.w; // window the record in hist_win belongs to once this key is done
+			uint4 wrec = make_uint4(0, 0, 0, 0);
+			bool have_wrec = false;
 			if (m) {
 				const uint32_t n_win = npend > nwin0 ? npend - nwin0 : 0u;
 				const bool roll = mt.w != mt.z;
-				fold_records(p, slot, g, roll, s_a[g], s_w[g], m, n_win, lmax, wmax, s_bm[g], s_bm[g + 16u]);
+				fold_records(p, slot, g, roll, s_a[g], s_w[g], m, n_win, lmax, wmax, s_bm[g], s_bm[g + 16u], LEVELS ? &wrec : nullptr);
+				have_wrec = n_win != 0u;
+				if (n_win) hw_now = mt.z;
 				if (g == 0) {
 					*(uint4 *)&p.td_meta[slot] = make_uint4(npend, npend | (nw << 16), mt.z, n_win ? mt.z : mt.w);
 					const int2 mm = p.td_minmax[slot];
 					if (lmin < mm.x || lmax > mm.y) p.td_minmax[slot] = make_int2(min(mm.x, lmin), max(mm.y, lmax));
+				}
+			}
+			if (LEVELS && live) {
+				// level 0 = the closing window's record: the window record when it belongs to the closing window (just folded, or folded
+				// earlier in the window by a merge / a query), the empty record otherwise (k_level_roll's `closing`)
+				uint4 *lp = (uint4 *)&q.last[slot] + g;
+				if (hw_now == q.epoch) {
+					if (!have_wrec) wrec = *((const uint4 *)&p.hist_win[slot] + g);
+					*lp = wrec;
+				} else {
+					*lp = g < 15u ? make_uint4(0, 0, 0, 0) : make_uint4(0, 0, 0, 0x80000000u); // {0, INT64_MIN}: total_count_, max_val_seen_
 				}
 			}
 			GYS_WAVE_SYNC();
@@ -2015,8 +2086,11 @@ __device__ __forceinline__ double td_quantile_dev(const uint32_t *c_cnt, const u
 // gys_config.td_pend_cap up to 1920 / 3968).  The work of a merge is almost all per BIN and per CLUSTER (a value costs its load and one to
 // three LDS atomics), so a buffer four times the size means a quarter of the merges at little more than the old cost each.
 #define GYS_MB_BIG_CAP 1024u // large values (>= GYS_MB_EXACT) the list holds; a merge with more of them goes to the general kernel (slow_list)
+#ifndef GYS_MB_WAVES16
+#define GYS_MB_WAVES16 5 // waves per SIMD the 4096-value instance is compiled for (8: 64 VGPRs -- sixteen values per thread then spill to scratch)
+#endif
 template <bool SCAN, uint32_t VPT = 4u>
-__global__ __launch_bounds__(256, 8) void k_digest_bins(MergeBP q)
+__global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_digest_bins(MergeBP q)
 {
 	const DigestP &p = q.d;
 	static_assert(VPT == 4u || VPT == 8u || VPT == 16u, "merges of 1024 / 2048 / 4096 values");
