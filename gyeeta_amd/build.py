@@ -7,7 +7,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgysketch.so")
 SOURCES = ["gys_engine.hip"]
-DEPS = ["gys_engine.hip", "gys_kernels.hpp", "gys_rollup.hpp", "gys_huge.hpp", "gys_device.hpp", "gys_json.hpp", "gys_svcquery.hpp", "gys_svcquery_host.hpp", "gys_mconn_shim.hpp", "../../include/gysketch.h", "../../include/gys_tdigest_tbl.h"]
+DEPS = ["gys_engine.hip", "gys_kernels.hpp", "gys_rollup.hpp", "gys_huge.hpp", "gys_device.hpp", "gys_json.hpp", "gys_svcquery.hpp", "gys_svcquery_host.hpp", "gys_regex.hpp", "gys_mconn_shim.hpp", "../../include/gysketch.h", "../../include/gys_tdigest_tbl.h"]
 
 
 def hipcc():

@@ -19,7 +19,6 @@
 #include <thread>
 #include <condition_variable>
 #include <mutex>
-#include <regex>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -143,14 +142,14 @@ ArenaLayout arena_layout(uint32_t max_clusters, bool conn_pair)
 	a.u32_cms = 0;
 	a.u32_cluster = (uint64_t)GYS_CMS_D * GYS_CMS_W;
 	a.u32_pair = a.u32_cluster + align_up((uint64_t)max_clusters * 12, 64); // Count-Min pair of the (listener, client task) roll-up
-	a.u32_misc = a.u32_pair + (uint64_t)GYS_CMS_D * GYS_CMS_W;
+	a.u32_misc = a.u32_pair + 2ull * GYS_CMS_D * GYS_CMS_W; // (local-listener rows' table, then the remote-listener rows')
 	a.u32_cpair = a.u32_misc + 64;
 	a.n_u32 = a.u32_cpair + (conn_pair ? (uint64_t)2 * GYS_CMS_D * GYS_CMS_W : 0); // listener-side tables, then client-side tables
 	a.off_i64sum = align_up(a.off_u32 + a.n_u32 * 4, 256);
 	a.i64_cms = 0;
 	a.i64_ghist = (uint64_t)GYS_CMS_D * GYS_CMS_W;
 	a.i64_pair = a.i64_ghist + 32;
-	a.i64_cpair = a.i64_pair + (uint64_t)GYS_CMS_D * GYS_CMS_W;
+	a.i64_cpair = a.i64_pair + 2ull * GYS_CMS_D * GYS_CMS_W;
 	a.n_i64sum = a.i64_cpair + (conn_pair ? (uint64_t)2 * GYS_CMS_D * GYS_CMS_W : 0);
 	a.off_i64max = align_up(a.off_i64sum + a.n_i64sum * 8, 256);
 	a.n_i64max = 8;
@@ -2482,10 +2481,10 @@ try {
 		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge<512, GYS_HB_TAIL_A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (GYS_HB_BINS + GYS_HB_TAIL_A) * 4));
 		HIPCHK(hipFuncSetAttribute((const void *)k_huge_merge<1024, GYS_HB_TAIL_LDS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (GYS_HB_BINS + GYS_HB_TAIL_LDS) * 4));
 	}
-	ALLOC(c->last_act32, (uint64_t)GYS_CMS_D * GYS_CMS_W);
-	ALLOC(c->last_act64, (uint64_t)GYS_CMS_D * GYS_CMS_W);
-	ALLOC(c->ring_act32, (uint64_t)GYS_ACT_RING * GYS_CMS_D * GYS_CMS_W);
-	ALLOC(c->ring_act64, (uint64_t)GYS_ACT_RING * GYS_CMS_D * GYS_CMS_W);
+	ALLOC(c->last_act32, 2ull * GYS_CMS_D * GYS_CMS_W);
+	ALLOC(c->last_act64, 2ull * GYS_CMS_D * GYS_CMS_W);
+	ALLOC(c->ring_act32, 2ull * GYS_ACT_RING * GYS_CMS_D * GYS_CMS_W);
+	ALLOC(c->ring_act64, 2ull * GYS_ACT_RING * GYS_CMS_D * GYS_CMS_W);
 	ALLOC(c->act_live, 2);
 #undef ALLOC
 	// dev_alloc zeroes with hipMemset on the NULL stream, which may still be in flight; the context stream is non-blocking, so the
@@ -3624,10 +3623,19 @@ try {
 
 // Count-Min estimate for a (listener, client task group) pair.  which 0 / 1: active connections / bytes of the ACTIVE_CONN_STATS reports of
 // the last three windows (per-cell maximum, k_act_latch); which 2 / 3 and 4 / 5: closed connections / bytes of the TCP_CONN_NOTIFY roll-up
-// in the last finished window, listener side (connlistenmap_) and client side (connclientmap_) (gys_config.conn_pair_cms).
+// in the last finished window, listener side (connlistenmap_) and client side (connclientmap_) (gys_config.conn_pair_cms); which 6 / 7: as 0 / 1
+// for the ACTIVE_CONN_STATS rows whose listener lives on another madhava (is_remote_listen_: the reference's remoteconntbl rows).
 static int pair_tables(gys_ctx *c, int which, const void **tbl)
 {
-	if (which < 0 || which > 5) return GYS_ERR_INVAL;
+	if (which < 0 || which > 7) return GYS_ERR_INVAL;
+	if (which == 6) {
+		*tbl = c->last_act32 + (uint64_t)GYS_CMS_D * GYS_CMS_W;
+		return GYS_OK;
+	}
+	if (which == 7) {
+		*tbl = c->last_act64 + (uint64_t)GYS_CMS_D * GYS_CMS_W;
+		return GYS_OK;
+	}
 	if (which >= 2 && !c->cfg.conn_pair_cms) {
 		set_err("gys_config.conn_pair_cms is off");
 		return GYS_ERR_STATE;
@@ -4728,4 +4736,5 @@ try {
 } // extern "C"
 
 #include "gys_json.hpp"
+#include "gys_regex.hpp"
 #include "gys_svcquery_host.hpp"

@@ -184,7 +184,8 @@ try {
 	uint32_t host;
 	int rc = lookup_host(c, machine_id, &host);
 	if (rc) return rc;
-	c->host_names[host] = hostname;
+	// PARTHA_INFO::hostname_ is a char[MAX_DOMAINNAME_SIZE] filled with GY_STRNCPY (a longer name is cut): the name criteria walk these strings
+	c->host_names[host].assign(hostname, strnlen(hostname, 255));
 	return GYS_OK;
 } GYS_CATCH_ALL
 

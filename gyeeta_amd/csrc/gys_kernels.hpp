@@ -4079,8 +4079,8 @@ struct ActConnP {
 	const uint8_t *batch;
 	uint32_t n;
 	DevTable gid;
-	uint32_t *pair32;            // arena: Count-Min of active connections per pair
-	unsigned long long *pair64;  // arena: Count-Min of bytes (sent + received) per pair
+	uint32_t *pair32;            // arena: Count-Min of active connections per pair: [D*W] rows of LOCAL listeners, then [D*W] rows whose listener lives on another madhava (is_remote_listen_)
+	unsigned long long *pair64;  // arena: Count-Min of bytes (sent + received) per pair, same two tables
 	unsigned long long *svc_act; // [nsvc*4] cumulative per listener: rows, bytes_sent, bytes_received, active connections
 	uint64_t *counters;
 	uint32_t *win_rows;          // arena (u32 SUM section): local-listener rows of this window, all ranks after the exchange
@@ -4099,19 +4099,23 @@ __global__ __launch_bounds__(256) void k_actconn_ingest(ActConnP p)
 	const bool remote = in && ((w[12] >> 49) & 1ull); // flags byte @102 = bits 48..55 of word 12, is_remote_listen_ = bit 1
 	wave_count(&p.counters[CTR_ACTCONN_RECORDS], in && !remote);
 	{
-		const unsigned long long b = __ballot(in && !remote);
+		const unsigned long long b = __ballot(in); // (rows of either kind keep the ring of the last windows' tables alive, k_act_latch)
 		if (b && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)b) - 1u) atomicAdd(p.win_rows, (uint32_t)__popcll(b));
 	}
 	wave_count(&p.counters[CTR_ACTCONN_REMOTE_LISTEN], remote);
-	if (!in || remote) return;
+	if (!in) return;
 	const uint64_t gid = w[0], task = w[1], sent = w[9], rcvd = w[10];
 	const uint32_t act = (uint32_t)((w[12] >> 32) & 0xFFFFu); // active_conns_ @100
+	// rows of a listener on another madhava (insert_active_conns: -> remoteconntbl, server/gy_mconnhdlr.cc:7888-7925): the same roll-up into
+	// tables of their own (behind the local ones) -- the client side's view of (remote listener, client task group)
+	const uint32_t tb = remote ? GYS_CMS_D * GYS_CMS_W : 0u;
 #pragma unroll
 	for (uint32_t r = 0; r < GYS_CMS_D; ++r) {
 		const uint32_t col = jhash2_4w((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)task, (uint32_t)(task >> 32), GYS_SEED + r) & (GYS_CMS_W - 1);
-		if (act) atomicAdd(&p.pair32[r * GYS_CMS_W + col], act);
-		if (sent + rcvd) atomicAdd(&p.pair64[r * GYS_CMS_W + col], (unsigned long long)(sent + rcvd));
+		if (act) atomicAdd(&p.pair32[tb + r * GYS_CMS_W + col], act);
+		if (sent + rcvd) atomicAdd(&p.pair64[tb + r * GYS_CMS_W + col], (unsigned long long)(sent + rcvd));
 	}
+	if (remote) return; // (the listener is not one of this engine's services)
 	const uint32_t slot = tbl_lookup(p.gid, gid);
 	if (slot == GYS_NOSLOT) {
 		atomicAdd((unsigned long long *)&p.counters[CTR_ACTCONN_UNKNOWN], 1ull);
@@ -4138,7 +4142,7 @@ __global__ __launch_bounds__(256) void k_act_latch(const uint32_t *win_rows, con
 	const uint32_t w = *d_epoch, cur = live[w & 1u], rows = *win_rows;
 	if (blockIdx.x == 0 && threadIdx.x == 0) live[(w + 1u) & 1u] = rows ? GYS_ACT_RING : (cur ? cur - 1u : 0u); // (read by the NEXT window's launch)
 	if (rows == 0u && cur == 0u) return;
-	const uint32_t n = GYS_CMS_D * GYS_CMS_W, me = w % GYS_ACT_RING;
+	const uint32_t n = 2u * GYS_CMS_D * GYS_CMS_W, me = w % GYS_ACT_RING; // (the local-listener tables and the remote-listener ones behind them)
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t v32 = pair32[i];
 		const unsigned long long v64 = pair64[i];

@@ -435,7 +435,7 @@ namespace {
 struct StrCriterion {
 	int base = 0;
 	bool neg = false;
-	std::regex re;
+	gysre::Regex re; // linear-time matcher (gys_regex.hpp): the reference's RE2::PartialMatch never backtracks either
 	std::vector<std::string> pats;
 	int init(int comp, const char *const *patterns, uint32_t npatterns, const char *who)
 	{
@@ -452,10 +452,9 @@ struct StrCriterion {
 			return GYS_ERR_INVAL;
 		}
 		if (base == GYS_COMP_LIKE) {
-			try {
-				re = std::regex(pats[0], std::regex::ECMAScript | std::regex::optimize);
-			} catch (const std::regex_error &e) {
-				set_err("%s: invalid regular expression: %s", who, e.what());
+			std::string why;
+			if (!re.compile(pats[0], &why)) { // (RE2 fails the criterion the same way: "Invalid regex", common/gy_query_criteria.h:347-352)
+				set_err("%s: invalid regular expression: %s", who, why.c_str());
 				return GYS_ERR_INVAL;
 			}
 		}
@@ -467,7 +466,7 @@ struct StrCriterion {
 		switch (base) {
 		case GYS_COMP_EQ: hit = len == pats[0].size() && !memcmp(s, pats[0].data(), len); break;
 		case GYS_COMP_SUBSTR: hit = pats[0].size() <= len && memmem(s, len, pats[0].data(), pats[0].size()) != nullptr; break;
-		case GYS_COMP_LIKE: hit = std::regex_search(s, s + len, re); break;
+		case GYS_COMP_LIKE: hit = re.search(s, len); break;
 		default:
 			for (size_t i = 0; i < pats.size() && !hit; ++i) hit = pats[i].size() == len && !memcmp(s, pats[i].data(), len);
 			break;

@@ -244,7 +244,9 @@ int gys_ingest_listener_state_dev(gys_ctx *ctx, const void *d_batch, const uint3
  * rows update (i) a Count-Min pair keyed by (listener_glob_id_, cli_aggr_task_id_): active_conns_ (u32 table) and bytes_sent_ +
  * bytes_received_ (u64 table) -- the per-(listener, client task) roll-up that stands for those rows; both tables live in the reduce
  * arena (all-reduced with the other registers, per window; queries read the per-cell maximum of the last three windows' tables, see
- * gys_query_pair_cms) -- and (ii) exact cumulative per-listener sums.  Remote-listener rows are counted (gys_counters.actconn_remote_listen). */
+ * gys_query_pair_cms) -- and (ii) exact cumulative per-listener sums.  Remote-listener rows (is_remote_listen_: the listener lives on another
+ * madhava, server/gy_mconnhdlr.cc:7888-7925 -> remoteconntbl) are rolled up the same way into a Count-Min pair of their own (gys_query_pair_cms
+ * which 6 / 7) and counted (gys_counters.actconn_remote_listen); they name no service of this engine, so there are no per-listener sums for them. */
 int gys_ingest_active_conns(gys_ctx *ctx, const uint8_t machine_id[16], const void *batch, uint32_t nitems, const void *pend);
 int gys_ingest_active_conns_dev(gys_ctx *ctx, const void *d_batch, uint32_t nitems);
 
@@ -534,8 +536,9 @@ int gys_query_svcstate_scan(gys_ctx *ctx, const gys_svc_filter *filter, int sort
  * registered services whose process name (gys_listener_info.comm) matches -- to be handed to gys_svc_filter.svcids.  comp = the
  * reference's string comparators with its numbering (COMPARATORS_E common/gy_query_criteria.h:28-45; match_str_criterian :1335-1383):
  * GYS_COMP_EQ / NEQ (whole name), GYS_COMP_SUBSTR / NOTSUBSTR (memmem), GYS_COMP_LIKE / NOTLIKE (a regular expression matched anywhere in
- * the name, as RE2::PartialMatch -- here std::regex, ECMAScript syntax; an invalid expression is GYS_ERR_INVAL as the reference's
- * ERR_INVALID_REQUEST), GYS_COMP_IN / NOTIN (any / none of npatterns whole names).  The other comparators use patterns[0].  Host-side:
+ * the name, as RE2::PartialMatch -- here a linear-time automaton search over bytes (gys_regex.hpp) with RE2's syntax minus its Unicode
+ * classes, \\C and \\Q..\\E; never a backtracking search: a pattern from a web query cannot stall the criterion; an invalid or unsupported
+ * expression is GYS_ERR_INVAL as the reference's ERR_INVALID_REQUEST), GYS_COMP_IN / NOTIN (any / none of npatterns whole names).  The other comparators use patterns[0].  Host-side:
  * the names never leave the host.  *nout = services that match; GYS_ERR_NOMEM when that exceeds cap (the first cap are written). */
 enum { GYS_COMP_SUBSTR = 8, GYS_COMP_NOTSUBSTR = 9, GYS_COMP_LIKE = 10, GYS_COMP_NOTLIKE = 11 };
 int gys_svc_ids_by_name(gys_ctx *ctx, int comp, const char *const *patterns, uint32_t npatterns, uint64_t *out_ids, uint32_t cap, uint32_t *nout);

@@ -188,6 +188,7 @@ void gyo_td64_merge_td64(gyo_td64 *d, const gyo_td64 *o);
 double gyo_td64_quantile(const gyo_td64 *d, double q);
 int gyo_tcp_conn_pair_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *pair32, uint64_t *pair64, uint32_t *cpair32, uint64_t *cpair64);
 void gyo_active_conn_sketch_batch(const uint8_t *batch, int nrec, uint32_t *pair32 /*[D*W]*/, uint64_t *pair64 /*[D*W]*/, uint64_t out[2]);
+void gyo_active_conn_sketch_batch2(const uint8_t *batch, int nrec, uint32_t *pair32, uint64_t *pair64, uint32_t *rpair32, uint64_t *rpair64, uint64_t out[2]);
 
 /* ---------------------------------------------------------------- wire records + roll-ups */
 #define GYO_TCP_CONN_NOTIFY_SZ 280

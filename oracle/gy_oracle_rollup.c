@@ -211,25 +211,31 @@ done:
  * (listener_glob_id lo, hi, cli_aggr_task_id lo, hi) -- active_conns_ into the u32 table, bytes_sent_ + bytes_received_ into the
  * u64 table -- for the local-listener rows; out[0] = local-listener rows, out[1] = remote-listener rows.  PARITY UNPINNED (builder-defined). */
 static uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
-void gyo_active_conn_sketch_batch(const uint8_t *batch, int nrec, uint32_t *pair32, uint64_t *pair64, uint64_t out[2])
+/* rpair32 / rpair64 (may be NULL): the same roll-up of the remote-listener rows (-> remoteconntbl :7888-7925) into tables of their own */
+void gyo_active_conn_sketch_batch2(const uint8_t *batch, int nrec, uint32_t *pair32, uint64_t *pair64, uint32_t *rpair32, uint64_t *rpair64, uint64_t out[2])
 {
 	out[0] = out[1] = 0;
 	for (int i = 0; i < nrec; i++) {
 		const uint8_t *r = batch + (size_t)i * 104;
 		const uint64_t gid = rd64(r), task = rd64(r + 8), sent = rd64(r + 72), rcvd = rd64(r + 80);
+		const uint32_t w[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)task, (uint32_t)(task >> 32)};
 		uint16_t act;
 		memcpy(&act, r + 100, 2);
 		if (r[102] & 2) { /* is_remote_listen_ */
 			out[1]++;
+			if (rpair32) gyo_cms_add(rpair32, w, 4, act);
+			if (rpair64) gyo_cms64_add(rpair64, w, 4, sent + rcvd);
 			continue;
 		}
 		out[0]++;
-		{
-			const uint32_t w[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)task, (uint32_t)(task >> 32)};
-			gyo_cms_add(pair32, w, 4, act);
-			gyo_cms64_add(pair64, w, 4, sent + rcvd);
-		}
+		gyo_cms_add(pair32, w, 4, act);
+		gyo_cms64_add(pair64, w, 4, sent + rcvd);
 	}
+}
+
+void gyo_active_conn_sketch_batch(const uint8_t *batch, int nrec, uint32_t *pair32, uint64_t *pair64, uint64_t out[2])
+{
+	gyo_active_conn_sketch_batch2(batch, nrec, pair32, pair64, NULL, NULL, out);
 }
 
 /* the same kind of pair fed by TCP_CONN_NOTIFY records (gys_config.conn_pair_cms): key (ser_glob_id_ @192, cli_task_aggr_id_

@@ -193,6 +193,7 @@ def lib():
     _sig(L, "gyo_td64_merge_td64", None, [C.POINTER(TD64), C.POINTER(TD64)])
     _sig(L, "gyo_td64_quantile", C.c_double, [C.POINTER(TD64), C.c_double])
     _sig(L, "gyo_active_conn_sketch_batch", None, [u8p, C.c_int, u32p, u64p, u64p])
+    _sig(L, "gyo_active_conn_sketch_batch2", None, [u8p, C.c_int, u32p, u64p, u32p, u64p, u64p])
     _sig(L, "gyo_tcp_conn_pair_batch", C.c_int, [u8p, C.c_int, u8p, u32p, u64p, u32p, u64p])
     _sig(L, "gyo_listener_state_rollup", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(ListenSummStats), C.POINTER(C.c_int)])
     _sig(L, "gyo_listener_state_elem_size", C.c_uint32, [C.c_void_p])

@@ -181,9 +181,9 @@ int main(int argc, char **argv)
 	// ------------------------------------------------------------------------------------------------ ACTIVE_CONN_STATS rows
 	{
 		const uint32_t NCMS = GYS_CMS_D * GYS_CMS_W;
-		std::vector<uint32_t> pair32(NCMS, 0), o32(NCMS, 0), win_rows(4, 0);
-		std::vector<unsigned long long> pair64(NCMS, 0), svc_act(NSVC * 4, 0), want_act(NSVC * 4, 0);
-		std::vector<uint64_t> o64(NCMS, 0), ctr(CTR_NUM, 0);
+		std::vector<uint32_t> pair32(2 * NCMS, 0), o32(2 * NCMS, 0), win_rows(4, 0); // (the local-listener rows' table, then the remote-listener rows')
+		std::vector<unsigned long long> pair64(2 * NCMS, 0), svc_act(NSVC * 4, 0), want_act(NSVC * 4, 0);
+		std::vector<uint64_t> o64(2 * NCMS, 0), ctr(CTR_NUM, 0);
 		uint64_t want_local = 0, want_remote = 0, want_unknown = 0;
 		for (uint32_t call = 0; call < 3; ++call) {
 			const uint32_t n = call == 0 ? 1u : 100u + rng() % 500u;
@@ -216,7 +216,7 @@ int main(int argc, char **argv)
 				want_act[s * 4 + 3] += act;
 			}
 			uint64_t out[2];
-			gyo_active_conn_sketch_batch(b, (int)n, o32.data(), o64.data(), out);
+			gyo_active_conn_sketch_batch2(b, (int)n, o32.data(), o64.data(), o32.data() + NCMS, o64.data() + NCMS, out);
 			ActConnP p{};
 			p.batch = b;
 			p.n = n;
@@ -228,10 +228,10 @@ int main(int argc, char **argv)
 			p.win_rows = win_rows.data();
 			kemu::launch((n + 255u) / 256u, 256, 0, [&] { k_actconn_ingest(p); });
 		}
-		CHECK(ctr[CTR_ACTCONN_RECORDS] == want_local && ctr[CTR_ACTCONN_REMOTE_LISTEN] == want_remote && ctr[CTR_ACTCONN_UNKNOWN] == want_unknown && win_rows[0] == want_local,
+		CHECK(ctr[CTR_ACTCONN_RECORDS] == want_local && ctr[CTR_ACTCONN_REMOTE_LISTEN] == want_remote && ctr[CTR_ACTCONN_UNKNOWN] == want_unknown && win_rows[0] == want_local + want_remote,
 		      "active-conn counters %llu %llu %llu rows %u, want %llu %llu %llu", (unsigned long long)ctr[CTR_ACTCONN_RECORDS], (unsigned long long)ctr[CTR_ACTCONN_REMOTE_LISTEN],
 		      (unsigned long long)ctr[CTR_ACTCONN_UNKNOWN], win_rows[0], (unsigned long long)want_local, (unsigned long long)want_remote, (unsigned long long)want_unknown);
-		for (uint32_t k = 0; k < NCMS; ++k) CHECK(pair32[k] == o32[k] && pair64[k] == o64[k], "active-conn pair cell %u: %u / %llu, oracle %u / %llu", k, pair32[k], pair64[k], o32[k], (unsigned long long)o64[k]);
+		for (uint32_t k = 0; k < 2 * NCMS; ++k) CHECK(pair32[k] == o32[k] && pair64[k] == o64[k], "active-conn pair cell %u: %u / %llu, oracle %u / %llu", k, pair32[k], pair64[k], o32[k], (unsigned long long)o64[k]);
 		for (uint32_t k = 0; k < NSVC * 4; ++k) CHECK(svc_act[k] == want_act[k], "listener %u active-conn sum %u: %llu, want %llu", k / 4, k % 4, svc_act[k], want_act[k]);
 		nsamples += want_local;
 	}

@@ -251,6 +251,8 @@ def test_active_conn_stats_pair_countmin_and_listener_sums(oracle):
     for w in range(2):
         p32 = np.zeros((4, 65536), dtype=np.uint32)
         p64 = np.zeros((4, 65536), dtype=np.uint64)
+        r32 = np.zeros((4, 65536), dtype=np.uint32)  # the rows whose listener lives on another madhava (is_remote_listen_ -> remoteconntbl): tables of their own
+        r64 = np.zeros((4, 65536), dtype=np.uint64)
         tot = np.zeros(2, dtype=np.uint64)
         allrec = []
         for h in range(nh):
@@ -261,16 +263,19 @@ def test_active_conn_stats_pair_countmin_and_listener_sums(oracle):
                 eng.handle_partha_active_conns(wire.machine_id(h), raw, n)
                 o2 = np.zeros(2, dtype=np.uint64)
                 buf = np.frombuffer(raw, dtype=np.uint8)
-                L.gyo_active_conn_sketch_batch(oracle.ptr(buf, oracle.u8p), n, oracle.ptr(p32, oracle.u32p), oracle.ptr(p64, oracle.u64p), oracle.ptr(o2, oracle.u64p))
+                L.gyo_active_conn_sketch_batch2(oracle.ptr(buf, oracle.u8p), n, oracle.ptr(p32, oracle.u32p), oracle.ptr(p64, oracle.u64p),
+                                                oracle.ptr(r32, oracle.u32p), oracle.ptr(r64, oracle.u64p), oracle.ptr(o2, oracle.u64p))
                 tot += o2
                 allrec.append(rec)
         eng.window_close()
         assert (eng.export_pair_cms(0) == p32).all()
         assert (eng.export_pair_cms(1).view(np.uint64) == p64).all()
+        assert r32.any() and (eng.export_pair_cms(6) == r32).all() and (eng.export_pair_cms(7).view(np.uint64) == r64).all()
         # a partha reports every 15 s, a window is 5 s: two windows without ACTIVE_CONN_STATS rows leave the last report readable
         eng.window_close()
         eng.window_close()
         assert (eng.export_pair_cms(0) == p32).all() and (eng.export_pair_cms(1).view(np.uint64) == p64).all()
+        assert (eng.export_pair_cms(6) == r32).all() and (eng.export_pair_cms(7).view(np.uint64) == r64).all()
         rec = np.concatenate(allrec)
         local = (rec["flags"] & wire.ACTIVE_FLAG_REMOTE_LISTEN) == 0
         c = eng.counters()
@@ -283,6 +288,12 @@ def test_active_conn_stats_pair_countmin_and_listener_sums(oracle):
             sel = (lr["listener_glob_id"] == g) & (lr["cli_aggr_task_id"] == t)
             assert eng.pair_cms(g, t, 0) >= int(lr["active_conns"][sel].sum())
             assert eng.pair_cms(g, t, 1) >= int(lr["bytes_sent"][sel].sum() + lr["bytes_received"][sel].sum())
+        rr = rec[~local]
+        for k in rng.integers(0, len(rr), 4):  # remote-listener pairs: never below what was reported
+            g, t = int(rr["listener_glob_id"][k]), int(rr["cli_aggr_task_id"][k])
+            sel = (rr["listener_glob_id"] == g) & (rr["cli_aggr_task_id"] == t)
+            assert eng.pair_cms(g, t, 6) >= int(rr["active_conns"][sel].sum())
+            assert eng.pair_cms(g, t, 7) >= int(rr["bytes_sent"][sel].sum() + rr["bytes_received"][sel].sum())
         if w == 0:
             first = rec
     # exact cumulative per-listener sums over both windows

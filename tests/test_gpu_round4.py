@@ -520,6 +520,20 @@ def test_service_name_criterion_resolves_to_service_ids():
                              ("notsubstr", ["e"], lambda n: "e" not in n)):
         got = set(eng.machine_ids_by_hostname(comp, pats))
         assert got == {bytes(wire.machine_id(h)) for h, n in hn.items() if pred(n)}, (comp, pats)
+    # `like` is an automaton search (the reference: RE2): patterns a backtracking matcher needs exponential time for answer at once, on a
+    # host name of the longest kind; RE2's syntax ((?i), [[:digit:]], \\z) is taken, what RE2 rejects (back-references, look-around) is rejected
+    import time
+    eng.set_host_name(wire.machine_id(1), "a" * 250 + "!" + "tail-that-is-cut-at-255-bytes")
+    t0 = time.perf_counter()
+    for pat in ("(a+)+$", "(a|aa)+$", "(a*)*b", "(.*a){25}x"):
+        assert eng.machine_ids_by_hostname("like", [pat]) == []
+    assert time.perf_counter() - t0 < 0.5
+    assert set(eng.machine_ids_by_hostname("like", ["(?i)^A{250}!tail$"])) == {bytes(wire.machine_id(1))}  # (cut at 255 bytes: 250 + '!' + 'tail')
+    assert set(eng.machine_ids_by_hostname("like", ["^db-[[:alpha:]]+-[[:digit:]]\\z"])) == {bytes(wire.machine_id(0)), bytes(wire.machine_id(2))}
+    for bad in ("(a)\\1", "(?=db)", "\\pL+", "a{2000}"):
+        with pytest.raises(capi.GysError):
+            eng.machine_ids_by_hostname("like", [bad])
+    eng.set_host_name(wire.machine_id(1), hn[1])
     mids = eng.machine_ids_by_hostname("substr", "db-")
     _, hosts_sel, _, nsel = eng.svcstate_scan(maxrecs=1000, machine_ids=mids)
     assert nsel > 0 and set(int(x) for x in hosts_sel) == {0, 2}
