@@ -1895,8 +1895,12 @@ void rq_flusher(gys_ctx *c)
 	for (;;) {
 		q.fcv.wait(lk, [&] { return q.stop || (q.open >= 0 && q.b[q.open].fill != 0); });
 		if (q.stop) break;
+		// the GPU is the bottleneck while GYS_RQ_INFLIGHT submissions are on it: wait for the oldest one's event (outside the lock) rather than
+		// wake every 200 us to find nothing to do; otherwise give the burst 200 us to bring more calls before its tail goes out
+		hipEvent_t busy = q.inflight.size() >= GYS_RQ_INFLIGHT ? q.b[q.inflight.front()].done : nullptr;
 		lk.unlock();
-		std::this_thread::sleep_for(std::chrono::microseconds(200));
+		if (busy) (void)hipEventSynchronize(busy);
+		else std::this_thread::sleep_for(std::chrono::microseconds(200));
 		lk.lock();
 		if (q.stop) break;
 		if (q.open >= 0 && q.b[q.open].fill && q.b[q.open].writers == 0 && !q.submitting) {
@@ -1915,12 +1919,8 @@ int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
 		q.flusher_on = true;
 		q.flusher = std::thread(rq_flusher, c);
 	}
-	if (q.async_rc) { // an earlier submission made for other callers failed: report it once
-		const int rc = q.async_rc;
-		set_err("%s", q.async_err.c_str());
-		q.async_rc = 0;
-		return rc;
-	}
+	// (an earlier submission made for other callers may have failed: that error is reported once, by the first call that comes by -- AFTER
+	// the caller's own events have been queued below, never instead of them)
 	q.calls++;
 	if (q.host_stamp.size() < c->hosts.size()) q.host_stamp.resize(c->hosts.size(), 0);
 	int bi;
@@ -1995,8 +1995,13 @@ int rq_ingest(gys_ctx *c, uint32_t host, const void *ev24, uint32_t n)
 	lk.lock();
 	b.writers--;
 	if (b.writers == 0) q.cv.notify_all();
-	const int rc = rq_drain(c, lk, bi, false);
+	int rc = rq_drain(c, lk, bi, false);
 	if (q.open >= 0 && q.b[q.open].fill) q.fcv.notify_one(); // events stay behind in the open batch: the flusher sees to them if no call follows
+	if (!rc && q.async_rc) { // an earlier submission made for other callers (or by the flusher) failed: reported once, this call's events are queued all the same
+		rc = q.async_rc;
+		set_err("%s", q.async_err.c_str());
+		q.async_rc = 0;
+	}
 	return rc;
 }
 
@@ -2109,8 +2114,10 @@ void recq_flusher(gys_ctx *c, gys_ctx::RecQ *qp) // the tail of a burst: as rq_f
 	for (;;) {
 		q.fcv.wait(lk, [&] { return q.stop || (q.open >= 0 && q.b[q.open].nrec != 0); });
 		if (q.stop) break;
+		hipEvent_t busy = q.inflight.size() >= GYS_RQ_INFLIGHT ? q.b[q.inflight.front()].done : nullptr; // (as rq_flusher)
 		lk.unlock();
-		std::this_thread::sleep_for(std::chrono::microseconds(200));
+		if (busy) (void)hipEventSynchronize(busy);
+		else std::this_thread::sleep_for(std::chrono::microseconds(200));
 		lk.lock();
 		if (q.stop) break;
 		if (q.open >= 0 && q.b[q.open].nrec && q.b[q.open].writers == 0 && !q.submitting) {
@@ -2136,12 +2143,7 @@ int recq_ingest(gys_ctx *c, gys_ctx::RecQ &q, uint32_t host, const void *batch, 
 		q.flusher_on = true;
 		q.flusher = std::thread(recq_flusher, c, &q);
 	}
-	if (q.async_rc) {
-		const int rc = q.async_rc;
-		set_err("%s", q.async_err.c_str());
-		q.async_rc = 0;
-		return rc;
-	}
+	// (a parked error of an earlier submission is reported after this message has been queued, see rq_ingest)
 	q.calls++;
 	int bi;
 	for (;;) {
@@ -2220,8 +2222,13 @@ int recq_ingest(gys_ctx *c, gys_ctx::RecQ &q, uint32_t host, const void *batch, 
 	lk.lock();
 	b.writers--;
 	if (b.writers == 0) q.cv.notify_all();
-	const int rc = recq_drain(c, q, lk, bi, false);
+	int rc = recq_drain(c, q, lk, bi, false);
 	if (q.open >= 0 && q.b[q.open].nrec) q.fcv.notify_one();
+	if (!rc && q.async_rc) { // (as rq_ingest: another submission's error, reported once; this message is queued)
+		rc = q.async_rc;
+		set_err("%s", q.async_err.c_str());
+		q.async_rc = 0;
+	}
 	return rc;
 }
 
