@@ -35,93 +35,111 @@ EVENT_BYTES = 24          # algorithmic bytes per event (raw tcp_ipv4
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0):
-    """The oracle's sequential restatement of the same hot loop ("port"), timed on one host core on a bounded sample of the
-    same stream shape (same generator, same bytes).  Returns (full_ev_s, histonly_ev_s, sample description)."""
+def _mem_available_bytes():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1):
+    """The oracle's sequential restatement of the same hot loop ("port") and the reference's own GY_HISTOGRAM loop (oracle/_ref), timed on the
+    host's cores on a bounded sample of the same stream shape (same generator, same bytes): `reps` runs each (the median is reported; every
+    repetition ingests the same batch again, as a next window would), one core and all cores.  Returns a dict, or None when the host has
+    not the memory for the port's per-key state (6.3 KB + 4 B x (td_cap - 896) per key)."""
     from gyeeta_amd import wire
     from oracle import oracle as o
     nsvc = total_hosts_sample * svcs
+    cap = td_cap or o.TD_PEND_CAP
+    need = nsvc * (6400 + 4 * max(0, cap - o.TD_PEND_CAP) + 600) + nevents * 40
+    avail = _mem_available_bytes()
+    if avail is not None and avail < 1.6 * need:
+        print(f"bench.py: CPU legs at {nsvc} keys skipped: they need ~{need >> 30} GiB of host memory, {avail >> 30} GiB available", file=sys.stderr)
+        return None
+    med = lambda xs: sorted(xs)[len(xs) // 2]
     orc = o.OracleEngine(nsvc, td_cap=td_cap)
     orc2 = o.OracleEngine(nsvc, enable_td=False)
+    s = np.arange(svcs)
     for h in range(total_hosts_sample):
-        s = np.arange(svcs)
-        g = wire.glob_id(np.full(svcs, h), s)
-        ns = wire.listener_netns(h, s)
-        pt = wire.listener_port(s)
-        for i in range(svcs):
-            orc.register(h, int(g[i]), int(ns[i]), int(pt[i]))
-            orc2.register(h, int(g[i]), int(ns[i]), int(pt[i]))
+        g, ns, pt = wire.glob_id(np.full(svcs, h), s), wire.listener_netns(h, s), wire.listener_port(s)
+        orc.register_bulk(h, g, ns, pt)
+        orc2.register_bulk(h, g, ns, pt)
     ev = torch.empty(nevents * 24, dtype=torch.uint8, device="cuda")
     segs = eng.gen_resp_events(ev.data_ptr(), nevents, seed, 0, total_hosts_sample, svcs)
     eng.sync()
     host = ev.cpu().numpy().tobytes()
     del ev
-    sh = [s.host_slot for s in segs]
-    sf = [s.first_event for s in segs]
-    t0 = time.perf_counter()
-    orc.resp_batch(host, sh, sf)
-    t1 = time.perf_counter()
-    orc2.resp_batch(host, sh, sf, histonly=True)
-    t2 = time.perf_counter()
-    port_mt = None
+    sh = [sg.host_slot for sg in segs]
+    sf = [sg.first_event for sg in segs]
+    ncores = os.cpu_count() or 1
+    out = {"keys": nsvc, "events": nevents, "runs": reps, "td_pend_cap": cap, "cores_all": ncores}
+    if reps > 1:  # (a first pass pays for the page faults of the per-key state: not timed)
+        orc.resp_batch(host, sh, sf)
+        orc2.resp_batch(host, sh, sf, histonly=True)
+    full, honly = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        orc.resp_batch(host, sh, sf)
+        t1 = time.perf_counter()
+        orc2.resp_batch(host, sh, sf, histonly=True)
+        t2 = time.perf_counter()
+        full.append(nevents / (t1 - t0))
+        honly.append(nevents / (t2 - t1))
+    out["port"], out["histonly"] = med(full), med(honly)
+    del orc2
     try:  # the full port again on every host core (hosts cut into per-thread ranges; identical resulting state, tests/test_oracle_sketches.py)
-        ncores = os.cpu_count() or 1
         if ncores > 1:
-            orc3 = o.OracleEngine(nsvc, td_cap=td_cap)
-            for h in range(total_hosts_sample):
-                s = np.arange(svcs)
-                g = wire.glob_id(np.full(svcs, h), s)
-                ns = wire.listener_netns(h, s)
-                pt = wire.listener_port(s)
-                for i in range(svcs):
-                    orc3.register(h, int(g[i]), int(ns[i]), int(pt[i]))
             rates = []
-            for _ in range(5):  # median of 5 (the digests keep growing: every repetition ingests the same batch again, as a next window would)
+            for _ in range(5):
                 t7 = time.perf_counter()
-                orc3.resp_batch(host, sh, sf, nthreads=ncores)
-                t8 = time.perf_counter()
-                rates.append(nevents / (t8 - t7))
-            port_mt = {"value": sorted(rates)[2], "cores": ncores, "runs": 5,
-                       "form": "hosts cut into per-thread ranges; per-thread private HLL registers, all-service histogram and counters merged once "
-                               "per batch; Count-Min rows built from per-service counts; digests re-clustered in parallel over service ranges"}
-            del orc3
+                orc.resp_batch(host, sh, sf, nthreads=ncores)
+                rates.append(nevents / (time.perf_counter() - t7))
+            out["port_allcores"] = med(rates)
+            out["port_allcores_form"] = ("hosts cut into per-thread ranges; per-thread private HLL registers, all-service histogram and counters merged once "
+                                         "per batch; Count-Min rows built from per-service counts; digests re-clustered in parallel over service ranges")
     except Exception as ex:  # never let the optional leg take the JSON line down
         print(f"bench.py: all-cores port baseline skipped: {ex}", file=sys.stderr)
-    desc = (f"{nevents} events over {total_hosts_sample} hosts x {svcs} services ({nsvc} keys: a tenth of the GPU run's 10^7 -- the port's per-key state is "
-            f"6.5 KB and its registration loop runs in Python), one batch, single thread once (the one-core legs take 4 - 10 s each), all-core legs median of 5, "
-            f"gcc -O2; full = hist+bitmap+HLL+CMS+t-digest, histonly = the reference's own per-event work")
+    del orc
     # the reference's OWN classes on the same bytes (oracle/_ref: GY_HISTOGRAM<int64_t, RESP_TIME_HASH>::add_data behind an
     # unordered_map with GY_JHASHER standing in for the RCU listener table): kind "reference"
-    ref_rate = None
     R = o.ref()
     if R is not None and hasattr(R, "ref_keyed_new"):
         k = R.ref_keyed_new()
         for h in range(total_hosts_sample):
-            s = np.arange(svcs)
-            ns = wire.listener_netns(h, s)
-            pt = wire.listener_port(s)
-            for i in range(svcs):
-                R.ref_keyed_register(k, h, int(ns[i]), int(pt[i]))
+            ns = np.ascontiguousarray(wire.listener_netns(h, s), dtype=np.uint32)
+            pt = np.ascontiguousarray(wire.listener_port(s), dtype=np.uint16)
+            if hasattr(R, "ref_keyed_register_bulk"):
+                R.ref_keyed_register_bulk(k, h, o.ptr(ns, o.u32p), pt.ctypes.data_as(ctypes_u16p()), svcs)
+            else:
+                for i in range(svcs):
+                    R.ref_keyed_register(k, h, int(ns[i]), int(pt[i]))
         buf = np.frombuffer(host, dtype=np.uint8)
         sh_a = np.ascontiguousarray(sh, dtype=np.uint32)
         sf_a = np.ascontiguousarray(sf, dtype=np.uint64)
-        t3 = time.perf_counter()
-        added = R.ref_keyed_resp_batch(k, buf.ctypes.data, nevents, o.ptr(sh_a, o.u32p), o.ptr(sf_a, o.u64p), len(sh_a))
-        t4 = time.perf_counter()
+        rates, added = [], 0
+        for _ in range(reps + (1 if reps > 1 else 0)):
+            t3 = time.perf_counter()
+            added = R.ref_keyed_resp_batch(k, buf.ctypes.data, nevents, o.ptr(sh_a, o.u32p), o.ptr(sf_a, o.u64p), len(sh_a))
+            rates.append(nevents / (time.perf_counter() - t3))
         if added:
-            ref_rate = {"value": nevents / (t4 - t3), "cores": 1}
-        ncores = os.cpu_count() or 1
+            out["reference_hist"] = med(rates[1:] if reps > 1 else rates)
         if added and ncores > 1 and hasattr(R, "ref_keyed_resp_batch_mt"):  # the same loop on every host core, hosts cut into ranges
             rates = []
             for _ in range(5):
                 t5 = time.perf_counter()
                 R.ref_keyed_resp_batch_mt(k, buf.ctypes.data, nevents, o.ptr(sh_a, o.u32p), o.ptr(sf_a, o.u64p), len(sh_a), ncores)
-                t6 = time.perf_counter()
-                rates.append(nevents / (t6 - t5))
-            ref_rate["mt_value"] = sorted(rates)[2]
-            ref_rate["mt_cores"] = ncores
+                rates.append(nevents / (time.perf_counter() - t5))
+            out["reference_hist_allcores"] = med(rates)
         R.ref_keyed_free(k)
-    return nevents / (t1 - t0), nevents / (t2 - t1), desc, ref_rate, port_mt
+    return out
+
+
+def ctypes_u16p():
+    import ctypes
+    return ctypes.POINTER(ctypes.c_uint16)
 
 
 def quantile_error(eng, torch, ingested, nlocal, svcs, host_ids, host_slots, wire):
@@ -686,6 +704,8 @@ def main():
     ap.add_argument("--nbuf", type=int, default=6, help="distinct device-resident event batches the windows cycle through")
     ap.add_argument("--cpu-events", type=int, default=1 << 26)
     ap.add_argument("--cpu-hosts", type=int, default=1000)
+    ap.add_argument("--cpu-hosts-full", type=int, default=10000, help="hosts of the CPU legs at the metric's own key count (x --svcs keys; skipped when the host lacks the memory)")
+    ap.add_argument("--cpu-events-full", type=int, default=1 << 25)
     args = ap.parse_args()
 
     if args.sub:
@@ -1013,20 +1033,33 @@ def main():
             out["host_fed"] = host_fed
         if scan is not None:
             out["quantile_scan"] = scan
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N = 1 only
-            full, honly, desc, ref_rate, port_mt = cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234, td_cap=args.td_pend_cap)
-            out["cpu_baseline"] = {"value": full, "unit": "events/s", "cores": 1, "kind": "port", "sample": desc,
-                                   "histonly_value": honly}
-            if port_mt is not None:  # the same full port (histogram + bitmap + HLL + CMS + t-digest) on all host threads
-                out["cpu_baseline"]["allcores_value"] = port_mt["value"]
-                out["cpu_baseline"]["allcores"] = port_mt["cores"]
-                out["cpu_baseline"]["allcores_form"] = port_mt["form"]
-            if ref_rate is not None:  # the reference's own GY_HISTOGRAM + GY_JHASHER compiled from /root/reference (oracle/_ref)
-                out["cpu_baseline"]["reference_hist_value"] = ref_rate["value"]
-                out["cpu_baseline"]["reference_hist_kind"] = "reference"
-                if "mt_value" in ref_rate:
-                    out["cpu_baseline"]["reference_hist_allcores_value"] = ref_rate["mt_value"]
-                    out["cpu_baseline"]["reference_hist_allcores"] = ref_rate["mt_cores"]
+        if not args.no_cpu_baseline and world == 1:  # the CPU legs are timed on rank 0 at N = 1 only
+            # the metric's own key count first (10^7 keys when the workload has them and the host has the memory: median of 5), then the
+            # 10^6-key sample of the earlier rounds beside it
+            legs = []
+            big_hosts = min(args.cpu_hosts_full, args.hosts)
+            if big_hosts > args.cpu_hosts:
+                legs.append(("full_keys", cpu_baseline(eng, big_hosts, args.svcs, args.cpu_events_full, 0x1235, td_cap=args.td_pend_cap, reps=5)))
+            legs.append(("sample", cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234, td_cap=args.td_pend_cap, reps=1)))
+            legs = [(k, v) for k, v in legs if v is not None]
+            if legs:
+                name, m = legs[0]
+                out["cpu_baseline"] = {
+                    "value": m["port"], "unit": "events/s", "cores": 1, "kind": "port",
+                    "sample": ("%d events over %d service keys (%s), td_pend_cap %d; one core: median of %d run(s); all cores (%d threads): median of 5; gcc -O2; "
+                               "value = the full port (hist + bitmap + HLL + CMS + t-digest), histonly = the reference's own per-event work, reference_hist = "
+                               "the reference's GY_HISTOGRAM loop compiled from its sources (oracle/_ref)")
+                              % (m["events"], m["keys"], "the metric's own key count" if name == "full_keys" else "a tenth of the GPU run's keys", m["td_pend_cap"], m["runs"], m["cores_all"]),
+                    "histonly_value": m["histonly"]}
+                cb = out["cpu_baseline"]
+                if "port_allcores" in m:  # the same full port on all host threads
+                    cb["allcores_value"], cb["allcores"], cb["allcores_form"] = m["port_allcores"], m["cores_all"], m["port_allcores_form"]
+                if "reference_hist" in m:
+                    cb["reference_hist_value"], cb["reference_hist_kind"] = m["reference_hist"], "reference"
+                if "reference_hist_allcores" in m:
+                    cb["reference_hist_allcores_value"], cb["reference_hist_allcores"] = m["reference_hist_allcores"], m["cores_all"]
+                for k2, m2 in legs[1:]:  # the other sample, whole
+                    cb["sample_%d_keys" % m2["keys"]] = {kk: vv for kk, vv in m2.items() if kk != "port_allcores_form"}
     eng.leave_rccl()
     eng.close()
     if rank == 0:

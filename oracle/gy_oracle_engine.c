@@ -132,6 +132,15 @@ int gyo_engine_register(gyo_engine *e, uint32_t host_slot, uint64_t glob_id, uin
 	return gyo_engine_register_addr(e, host_slot, glob_id, netns, port, NULL, 0, 1);
 }
 
+/* n any-address listeners of one host in one call (bench.py registers 10^7 of them); returns the first slot or -1 */
+int gyo_engine_register_bulk(gyo_engine *e, uint32_t host_slot, const uint64_t *glob_id, const uint32_t *netns, const uint16_t *port, uint32_t n)
+{
+	const int first = (int)e->nsvc;
+	for (uint32_t i = 0; i < n; i++)
+		if (gyo_engine_register_addr(e, host_slot, glob_id[i], netns[i], port[i], NULL, 0, 1) < 0) return -1;
+	return first;
+}
+
 /* listener_tbl_.lookup_single_elem(ser_nsipport, hash ignoring the IP) (common/gy_socket_stat.cc:1671): the first listener of the key for
  * which operator==(listener, ser_nsipport) holds (common/gy_socket_stat.h:708-714); e32 / e128 = the event's server address as GY_IP_ADDR */
 static uint32_t lookup(const gyo_engine *e, uint64_t k, uint32_t e32, const uint8_t e128[16])

@@ -232,6 +232,7 @@ def lib():
     _sig(L, "gyo_engine_free", None, [C.c_void_p])
     _sig(L, "gyo_engine_register", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint16])
     _sig(L, "gyo_engine_resp_batch", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
+    _sig(L, "gyo_engine_register_bulk", C.c_int, [C.c_void_p, C.c_uint32, u64p, u32p, C.POINTER(C.c_uint16), C.c_uint32])
     _sig(L, "gyo_engine_register_addr", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint16, u8p, C.c_int, C.c_int])
     _sig(L, "gyo_engine_resp_batch_v6", None, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
     _sig(L, "gyo_ip_norm", C.c_int, [u8p, C.c_int, u32p, u8p])
@@ -325,6 +326,8 @@ def ref():
         _sig(R, "ref_keyed_new", C.c_void_p, [])
         _sig(R, "ref_keyed_free", None, [C.c_void_p])
         _sig(R, "ref_keyed_register", C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint16])
+        if hasattr(R, "ref_keyed_register_bulk"):
+            _sig(R, "ref_keyed_register_bulk", None, [C.c_void_p, C.c_uint32, u32p, C.POINTER(C.c_uint16), C.c_uint32])
         _sig(R, "ref_keyed_resp_batch", C.c_uint64, [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u64p, C.c_uint32])
         _sig(R, "ref_keyed_total", C.c_uint64, [C.c_void_p, C.c_uint32])
         if hasattr(R, "ref_keyed_resp_batch_mt"):
@@ -424,6 +427,15 @@ class OracleEngine:
         s = self.L.gyo_engine_register(self.h, int(host_slot), int(glob_id), int(netns), int(port))
         assert s >= 0
         return s
+
+    def register_bulk(self, host_slot, glob_ids, netns, ports):
+        """n any-address listeners of one host in one call"""
+        g = np.ascontiguousarray(glob_ids, dtype=np.uint64)
+        ns = np.ascontiguousarray(netns, dtype=np.uint32)
+        pt = np.ascontiguousarray(ports, dtype=np.uint16)
+        first = self.L.gyo_engine_register_bulk(self.h, int(host_slot), ptr(g, u64p), ptr(ns, u32p), pt.ctypes.data_as(C.POINTER(C.c_uint16)), len(g))
+        assert first >= 0
+        return first
 
     def register_addr(self, host_slot, glob_id, netns, port, addr=None, is_v6=False):
         """addr: None = an any-address listener (is_any_ip_), else the 4 / 16 address bytes the listener is bound to"""

@@ -330,6 +330,10 @@ uint32_t ref_keyed_register(void *p, uint32_t host, uint32_t netns, uint16_t por
 	k->tbl.emplace(key, idx);
 	return idx;
 }
+void ref_keyed_register_bulk(void *p, uint32_t host, const uint32_t *netns, const uint16_t *port, uint32_t n)
+{
+	for (uint32_t i = 0; i < n; ++i) ref_keyed_register(p, host, netns[i], port[i]);
+}
 // returns the number of events added to a histogram
 uint64_t ref_keyed_resp_batch(void *p, const uint8_t *ev24, uint64_t n, const uint32_t *seg_host, const uint64_t *seg_first, uint32_t nsegs)
 {
