@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc_collect_workloads.sh <outdir-under-gpurun_out> [name ...]     (names: c2_conn c1 c5_zipf; default all)
+# usage: tools/pmc_collect_workloads.sh <outdir-under-gpurun_out> [name ...]     (names: c2_conn c1 c5_zipf c3_levels; default the first three)
 # Per sub-run of bench.py (the other BASELINE configurations, bench.py SUB_CONFIGS): a rocprofv3 kernel trace of the run restricted to its
 # timed steps, and the two HBM counter passes (FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only) merged into
 # <outdir>/pmc_traffic.json `workloads` by tools/pmc_workload.py (copy that file to profiles/pmc_traffic.json to have bench.py report it).
@@ -14,6 +14,7 @@ for name in $NAMES; do
     c2_conn) ARGS="--workload conn"; UNITS=$((1<<24)); UNIT=records ;;
     c1) ARGS="--hosts 1 --svcs 100 --events $((1<<26)) --nbuf 2"; UNITS=$((1<<26)); UNIT=events ;;
     c5_zipf) ARGS="--zipf-milli 1100 --hosts 50 --svcs 2000 --nbuf 2"; UNITS=$((1<<29)); UNIT=events ;;
+    c3_levels) ARGS="--levels 1 --nbuf 2"; UNITS=$((1<<29)); UNIT=events ;;
     *) echo "unknown sub-run $name"; continue ;;
   esac
   K=10
