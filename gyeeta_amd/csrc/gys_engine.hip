@@ -1083,7 +1083,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 	unsigned long long *ghist = (unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_ghist;
 	long long *gmax = (long long *)(c->arena + c->al.off_i64max);
 	if (td) {
-		HIPCHK(hipMemsetAsync(c->merge_count, 0, 8 * 4, c->stream)); // merge / huge / fallback list lengths, run allocation cursor
+		HIPCHK(hipMemsetAsync(c->merge_count, 0, 8 * 4, c->stream)); // merge / huge / fallback list lengths, run allocation cursor ([8] is the constant 1 of the query list)
 		c->resp_dirty = true;
 	}
 	FinP fin{};
@@ -1119,7 +1119,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		fin.append_cap = (uint32_t)c->append_cap;
 		fin.td_pend = c->td_pend;
 		fin.staged = c->staged;
-		HIPCHK(hipMemsetAsync(c->merge_count + FIN_APPEND, 0, 4, c->stream));
+		HIPCHK(hipMemsetAsync(c->merge_count + FIN_APPEND, 0, 4 * 4, c->stream)); // ([12]: the append list's length; [14 .. 15]: the predicted runs' 64-bit reservation counter)
 	}
 	RespHostP hp{};
 	uint32_t hgrid = 0;
@@ -1231,6 +1231,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 			pp.nsvc = nsvc;
 			pp.pcap = c->pcap;
 			pp.pend_cap = c->pend_cap;
+			pp.resv = (unsigned long long *)(c->merge_count + 14); // (merge_count[14 .. 15]: cleared with the list lengths at the start of the batch)
 			pp.run_limit = (uint32_t)std::min<uint64_t>(c->staged_cap - std::min<uint64_t>(n, c->staged_cap), 0xFFFFFFFFull); // the exact runs of the fall-back (<= n words) keep their room
 			++c->pre_seq;
 			hipLaunchKernelGGL(k_mark_hosts, dim3((nsegs + 255) / 256), dim3(256), 0, c->stream, segs_dev, nsegs, c->host_batch, c->batch_stamp);
@@ -2417,7 +2418,10 @@ try {
 			c->pcap = cfg->td_buf_values;
 		} else {
 			const uint64_t fit = ((40ull << 30) / (4 * S)) / 256 * 256;
-			c->pcap = (uint32_t)std::min<uint64_t>(GYS_PCAP_MAX, std::max<uint64_t>(align_up(c->merge_fast, 256), fit));
+			// (at least the fast merge size; with a larger buffer than the default also a quarter of the default's room on top: a service that
+			// brings more values per batch than the room above td_pend_cap takes the predicted-run / spill paths every time it is nearly full)
+			const uint64_t floor_cap = c->pend_cap > GYS_TD_PEND_CAP ? align_up(c->merge_fast, 256) + 256 : align_up(c->merge_fast, 256);
+			c->pcap = (uint32_t)std::min<uint64_t>(GYS_PCAP_MAX, std::max<uint64_t>(floor_cap, fit));
 		}
 		ALLOC(c->td_sum, S * GYS_TD_NB);
 		ALLOC(c->td_cnt, S * GYS_TD_NB);

@@ -649,6 +649,7 @@ struct PreSpillP {
 	uint32_t batch_stamp;        // host_batch[h] == batch_stamp: host h has a segment in this batch
 	uint32_t nsvc, pcap, run_limit; // run_limit: predicted runs end below it (the exact runs of the fall-back need the rest of `staged`)
 	uint32_t pend_cap;
+	unsigned long long *resv;    // words requested so far by this batch's predictions (accepted or not), cleared with the cursor
 };
 
 __global__ __launch_bounds__(256) void k_prespill(PreSpillP p)
@@ -680,20 +681,16 @@ __global__ __launch_bounds__(256) void k_prespill(PreSpillP p)
 			s_w[k] = tot;
 			tot += c;
 		}
-		// the cursor only ever counts ACCEPTED runs (compare-and-swap: a workgroup whose runs would end past run_limit takes nothing --
-		// the exact runs of the fall-back start at the cursor and need the rest of `staged`; a plain add could also carry the 32-bit
-		// cursor around when many keys are predicted at once)
+		// the cursor only ever counts ACCEPTED runs: the exact runs of the fall-back start at it and need the rest of `staged`.  The decision is
+		// taken on a 64-bit RESERVATION counter that every asking workgroup adds to (it never goes back: a refused request only makes later
+		// ones a little more likely to be refused too, and it cannot wrap), the places come from the 32-bit cursor, which accepted requests
+		// alone advance -- accepted sums are bounded by the reservation sums, so the cursor ends at or below run_limit.  (Round 5's first form
+		// was a compare-and-swap loop on the cursor: with thousands of workgroups asking at once -- 5 000 hosts x 1 000 services at 107
+		// values per key and window, 128 values of room -- the retries took 24 ms per batch.)
 		uint32_t base = 0xFFFFFFFFu;
 		if (tot) {
-			uint32_t old = p.counts[FIN_RUN_ALLOC];
-			while ((uint64_t)old + tot <= (uint64_t)p.run_limit) {
-				const uint32_t prev = atomicCAS(&p.counts[FIN_RUN_ALLOC], old, old + tot);
-				if (prev == old) {
-					base = old;
-					break;
-				}
-				old = prev;
-			}
+			const unsigned long long r0 = atomicAdd(p.resv, (unsigned long long)tot);
+			if (r0 + tot <= (unsigned long long)p.run_limit) base = atomicAdd(&p.counts[FIN_RUN_ALLOC], tot);
 		}
 		s_base = base;
 	}
@@ -883,6 +880,9 @@ __host__ __device__ __forceinline__ size_t resp_host_lds_bytes(uint32_t tbl_entr
 // a 128-byte line that the key's next piece, one tile later, completes -- evicted in between, the line is written twice)
 #ifndef GYS_EV_NT
 #define GYS_EV_NT 0 // (r5f: 5.30 -> 5.80 ms with non-temporal event loads: the three 8-byte words of an event come from one line, the second and third read want it cached)
+#endif
+#ifndef GYS_EV_SADDR
+#define GYS_EV_SADDR 0 // (r5m: scalar tile base + one 32-bit offset per event -- the compiler then loads 16 + 8 bytes per event with one address register instead of three 64-bit addresses, 144 fewer static VALU instructions -- 5.28 / 5.29 against 5.33 / 5.30 ms: inside the noise; left off)
 #endif
 #ifndef GYS_EV_X3
 #define GYS_EV_X3 0 // (r5g: 5.27 -> 5.60 ms with two fully coalesced 12-byte loads per event + a DPP swap of halves between neighbouring lanes instead of the three strided 8-byte loads: the loads are not what the event phase waits for, the extra moves and registers cost more than the request efficiency gains)
@@ -1096,6 +1096,14 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 						w0[u] = (uint64_t)d0 | ((uint64_t)d1 << 32);
 						w1[u] = (uint64_t)d2 | ((uint64_t)d3 << 32);
 						w2[u] = (uint64_t)d4 | ((uint64_t)d5 << 32);
+					} else if (GYS_EV_SADDR) {
+						// the tile's base is uniform and an event's byte offset inside the tile fits 32 bits: written so, the three loads share ONE
+						// 32-bit offset register (scalar base + offset + immediate) instead of a 64-bit address each
+						const uint32_t ob = 24u * oo;
+						const char *const tbb = (const char *)tb;
+						w0[u] = *(const uint64_t *)(tbb + ob);
+						w1[u] = *(const uint64_t *)(tbb + ob + 8u);
+						w2[u] = *(const uint64_t *)(tbb + ob + 16u);
 					} else {
 						w0[u] = GYS_EV_LOAD(&tb[3u * oo]);
 						w1[u] = GYS_EV_LOAD(&tb[3u * oo + 1u]);

@@ -232,6 +232,7 @@ int main(int argc, char **argv)
 			pp.nsvc = nsvc;
 			pp.pcap = pcap;
 			pp.pend_cap = GYS_TD_PEND_CAP;
+			pp.resv = (unsigned long long *)&counts[14];
 			// (batch 7: no room for predicted runs -- the cursor stays where it is and the keys take the exact-run fall-back)
 			pp.run_limit = batch == 7 ? 100u : (uint32_t)(staged.size() - n);
 			++pre_seq;
