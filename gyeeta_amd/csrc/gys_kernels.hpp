@@ -2373,6 +2373,62 @@ __global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_dige
 #define GYS_MB_GROUP 1u // the thread's four bins searched GROUP at a time (1, 2 or 4): with 2 / 4 the 8 dependent LDS reads of one threshold search overlap the others' -- measured in round 4 (profiles/r4a_ab_paired_search_and_tests.txt): 4.71 / 4.75 / 4.85 ms for 2 / 1 / 4 at full size, 1.265 / 1.255 / 1.281 at quarter size: no gain, the per-bin pass is not bound by that chain; 1 = the plain form stays the default
 #endif
 		constexpr uint32_t MBG = SCAN ? 1u : GYS_MB_GROUP; // (the scan form sits at 63 VGPRs: left as it was)
+#ifndef GYS_MB_COMPACT
+#define GYS_MB_COMPACT 1 // the per-bin pass walks a compacted list of the NON-EMPTY one-value bins
+#endif
+		// Round 5: of the 1 024 one-value bins a merge touches ~200 - 400 (integer-millisecond response times repeat), spread so that every
+		// wave of every one of the four rounds below has some non-empty bin among its 64 -- each round then runs the 8-step threshold search
+		// for the whole wave.  The non-empty bins are compacted first (four ballots per thread, wave totals through LDS, a 16-bit list in
+		// the unused upper half of the large-value list): ~300 bins are 5 wave-rounds instead of 16.  The kernel is bound by VALU issue
+		// (DESIGN 10): the instructions saved are time saved.  (A merge with more than half of the list's room in large values keeps the plain form.)
+		const bool compact = GYS_MB_COMPACT && MBG == 1u && !GYS_MB_FUSE_OLD && nbig <= BIG_CAP / 2u;
+		if (compact) {
+			uint16_t *const s_ne = (uint16_t *)(s_big + BIG_CAP / 2u); // [<= 1024] bin numbers
+			const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+			uint32_t tw = 0, pos[4];
+			bool ne[4];
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; ++k) {
+				const uint32_t b = tid + 256u * k;
+				ne[k] = !(GYS_MB_SKIP & 1) && ((s_bin[b + 1u] ^ s_bin[b]) & 0xFFFFu) != 0u; // (the low halves are running counts: different = the bin holds values)
+				const unsigned long long bal = __ballot(ne[k]);
+				pos[k] = tw + (uint32_t)__popcll(bal & below);
+				tw += (uint32_t)__popcll(bal);
+			}
+			if (lane == 0u) s_ws[wave] = tw; // (the scan's wave sums were consumed before the barrier above)
+			__syncthreads();
+			uint32_t base = 0, n_ne = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; ++k) {
+				if (k < wave) base += s_ws[k];
+				n_ne += s_ws[k];
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; ++k)
+				if (ne[k]) s_ne[base + pos[k]] = (uint16_t)(tid + 256u * k);
+			__syncthreads();
+			for (uint32_t i = tid; i < n_ne; i += 256u) {
+				const uint32_t b = s_ne[i];
+				const uint32_t bw = s_bin[b];
+				uint32_t rem = (s_bin[b + 1u] & 0xFFFFu) - (bw & 0xFFFFu), mid2 = 2u * ((bw & 0xFFFFu) + s_cpfx[bw >> 16]) + 1u, a = 0;
+#pragma unroll
+				for (uint32_t step = GYS_NBP / 2; step >= 1u; step >>= 1)
+					if (mid2 >= s_T[a + step]) a += step;
+				while (rem) { // (nearly always one round: a cluster spans far more mid-points than a bin's values)
+					const uint32_t Tn = s_T[a + 1u]; // first mid-point of the next cluster (~0 after the last)
+					const uint32_t kk = min(rem, (Tn - mid2 + 1u) >> 1); // values with mid2 + 2 r < Tn
+#if GYS_MB_PACKED
+					atomicAdd(&s_oval[a], ((unsigned long long)kk << 40) | (unsigned long long)(kk * b));
+#else
+					atomicAdd(&s_osum[a], (unsigned long long)(kk * b));
+					atomicAdd(&s_ocnt[a], kk);
+#endif
+					rem -= kk;
+					mid2 += 2u * kk;
+					++a;
+				}
+			}
+		} else
 #pragma unroll
 		for (uint32_t k0 = 0; k0 < GYS_MB_EXACT / 256u; k0 += MBG) {
 			uint32_t bq[MBG], cq[MBG], mq[MBG], aq[MBG], call = 0;
