@@ -413,6 +413,10 @@ struct gys_ctx {
 	// multi-level windows (cfg.enable_levels; kernels: "multi-level windows" in gys_kernels.hpp)
 	gys_hist_rec *lvl_snap = nullptr; // [2][GYS_LEVEL_RING][max_services] cumulative records at the last start of every ring bucket
 	gys_hist_rec *lvl_last = nullptr; // [max_services] the window closed last (level 0)
+	// lazily folded records (t-digest on): hist_win and lvl_last change places at every close instead of a copy; lvl_last[slot] then is the service's
+	// record of window lvl_last_tag[slot] (written by the close's fold pass) and counts only when that is lvl_last_epoch, the window closed last
+	uint32_t *lvl_last_tag = nullptr;
+	uint32_t lvl_last_epoch = 0;
 	int64_t *lvl_first = nullptr;     // [max_services] time (s) of the service's first window close (firstTime_ of its series), 0: none yet
 	gys_hist_rec *qps_hist = nullptr, *act_hist = nullptr; // per-service QPS_HISTOGRAM / ACTIVE_CONN_HISTOGRAM
 	int64_t lvl_t_last = -1;          // close time (s) of the last window, -1: none yet
@@ -935,25 +939,25 @@ int fold_range(gys_ctx *c, uint32_t first, uint32_t n)
 	f.n = n;
 	ProfScope ps(c, "fold");
 	const uint32_t nchunks = (n + 63u) / 64u;
-	hipLaunchKernelGGL(k_fold<false>, dim3(std::min<uint32_t>((nchunks + 3u) / 4u, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, f);
+	hipLaunchKernelGGL(k_fold, dim3(std::min<uint32_t>((nchunks + 3u) / 4u, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, f);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
 }
 
-// window close with the 5-s level: every service's records are brought up to date AND its closing-window record goes to lvl_last in the same pass
+// window close with the 5-s level: every service's records are brought up to date; the same pass leaves the window each record in hist_win
+// belongs to in lvl_last_tag and the services' first close time in lvl_first (level_roll then swaps hist_win and lvl_last)
 int fold_close_levels(gys_ctx *c, int64_t tnow)
 {
 	FoldP f{};
 	f.d = digest_params(c);
 	f.first = 0;
 	f.n = c->nsvc;
-	f.last = c->lvl_last;
+	f.last_tag = c->lvl_last_tag;
 	f.first_sec = c->lvl_first;
 	f.tnow = tnow;
-	f.epoch = c->epoch;
 	ProfScope ps(c, "fold");
 	const uint32_t nchunks = (c->nsvc + 63u) / 64u;
-	hipLaunchKernelGGL(k_fold<true>, dim3(std::min<uint32_t>((nchunks + 3u) / 4u, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, f);
+	hipLaunchKernelGGL(k_fold, dim3(std::min<uint32_t>((nchunks + 3u) / 4u, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, f);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
 }
@@ -1452,32 +1456,44 @@ int level_roll(gys_ctx *c, uint64_t tusec)
 		HIPCHK(hipGetLastError());
 		return GYS_OK;
 	}
-	// every service's closing-window record must be complete; with lazily folded records and the 5-s level the fold pass itself leaves level 0
-	// (and the services' first close time) behind: k_level_roll then only runs when a ring boundary was crossed (every 6th close), for the snapshots
-	// (GYS_FUSED_LAST: level 0 written by the fold pass itself, k_fold<true>, instead of by k_level_roll in a pass of its own.  Measured in round 5
-	// (profiles/r5i_levels_fused_vs_separate.txt): fold 2.74 -> 4.68 ms for the 1.07 ms of k_level_roll it replaces -- the fold walks 4 keys per
-	// wave and round and waits for its stores at every round; one more 256-byte store per key in that loop costs more than a streaming pass.  Off.)
-	static const bool fused_env = getenv("GYS_FUSED_LAST") != nullptr;
-	const bool fused_last = keep_last && c->cfg.enable_tdigest && fused_env;
+	// every service's closing-window record must be complete.  With lazily folded records (t-digest on) and the 5-s level, level 0 costs no pass
+	// of its own: the fold leaves per service which window its record in hist_win belongs to (lvl_last_tag) and the two arrays change places --
+	// the window records ARE the level-0 records, a key's first fold of the next window rewrites its (now stale) record in the other array
+	// without reading it.  (Rounds 2 - 4 copied 256 B per service and close, k_level_roll: 1.1 ms at 10^7 services; writing the copy from the
+	// fold pass was slower still, profiles/r5i_levels_fused_vs_separate.txt.)  k_level_roll runs when a ring boundary was crossed, for the
+	// snapshots, or for the copy when the records are kept eagerly.
+	const bool swap_last = keep_last && c->cfg.enable_tdigest;
 	{
-		const int rcf = fused_last ? fold_close_levels(c, tnow) : fold_range(c, 0, c->nsvc);
+		const int rcf = swap_last ? fold_close_levels(c, tnow) : fold_range(c, 0, c->nsvc);
 		if (rcf) return rcf;
 	}
-	if (fused_last && !(p.mask[0] | p.mask[1])) return GYS_OK;
-	p.win = c->hist_win;
-	p.all = c->hist_all;
-	p.meta = c->cfg.enable_tdigest ? c->td_meta : nullptr;
-	p.epoch = c->epoch;
-	p.nsvc = c->nsvc;
-	p.snap = c->lvl_snap;
-	p.last = keep_last && !fused_last ? c->lvl_last : nullptr;
-	p.stride = c->cfg.max_services;
-	p.first_sec = c->lvl_first;
-	p.tnow = tnow;
-	ProfScope ps(c, "level_roll");
-	hipLaunchKernelGGL(k_level_roll, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
-	HIPCHK(hipGetLastError());
+	if (!swap_last || (p.mask[0] | p.mask[1])) {
+		p.win = c->hist_win;
+		p.all = c->hist_all;
+		p.meta = c->cfg.enable_tdigest ? c->td_meta : nullptr;
+		p.epoch = c->epoch;
+		p.nsvc = c->nsvc;
+		p.snap = c->lvl_snap;
+		p.last = keep_last && !swap_last ? c->lvl_last : nullptr;
+		p.stride = c->cfg.max_services;
+		p.first_sec = c->lvl_first;
+		p.tnow = tnow;
+		ProfScope ps(c, "level_roll");
+		hipLaunchKernelGGL(k_level_roll, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
+		HIPCHK(hipGetLastError());
+	}
+	if (swap_last) {
+		std::swap(c->hist_win, c->lvl_last);
+		c->lvl_last_epoch = c->epoch;
+	}
 	return GYS_OK;
+}
+
+// the array that holds the records of window c->epoch (what the window views read, each record behind its hw_epoch check): hist_win -- except
+// between gys_window_prepare and gys_window_finish when the close has already swapped it with the level-0 array (level_roll)
+inline const gys_hist_rec *window_records(gys_ctx *c)
+{
+	return c->prepared && c->cfg.enable_levels == 1 && c->cfg.enable_tdigest ? c->lvl_last : c->hist_win;
 }
 
 // where a level's records come from at time tq (s): mode 0 = cumulative - *sub (nullptr: nothing to subtract), 1 = empty, 2 = copy of *sub
@@ -1524,6 +1540,8 @@ int level_view(gys_ctx *c, int level, uint64_t tusec, uint32_t first, uint32_t n
 	p.n = n;
 	p.out = d_out;
 	level_source(c, level, tq, &p.mode, &p.sub);
+	p.last_tag = c->cfg.enable_tdigest ? c->lvl_last_tag : nullptr;
+	p.last_epoch = c->lvl_last_epoch;
 	hipLaunchKernelGGL(k_level_view, dim3((uint32_t)(((uint64_t)n * 16 + 255) / 256)), dim3(256), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
@@ -1565,6 +1583,8 @@ int level_period(gys_ctx *c, int64_t start, int64_t end, uint64_t tusec, uint32_
 		const bool held = c->lvl_t_last >= 0 && tq - c->lvl_t_last < LEVEL_SECS[0];
 		p.mode = held && start <= c->lvl_t_last && end > c->lvl_t_last ? 2 : 1;
 		p.last = c->lvl_last;
+		p.last_tag = c->cfg.enable_tdigest ? c->lvl_last_tag : nullptr;
+		p.last_epoch = c->lvl_last_epoch;
 	} else {
 		const int64_t dur = LEVEL_SECS[level], w = dur / GYS_LEVEL_RING;
 		const int64_t cur_start = level_bucket_start(tq, dur, level_bucket_idx(tq, dur));
@@ -2402,6 +2422,7 @@ try {
 	if (cfg->enable_levels) {
 		ALLOC(c->lvl_snap, 2 * GYS_LEVEL_RING * S);
 		ALLOC(c->lvl_last, cfg->enable_levels == 1 ? S : 1);
+		ALLOC(c->lvl_last_tag, cfg->enable_levels == 1 && cfg->enable_tdigest ? S : 1);
 		ALLOC(c->lvl_first, S);
 		ALLOC(c->qps_hist, S);
 		ALLOC(c->act_hist, S);
@@ -2511,6 +2532,8 @@ try {
 	hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->hist_all, (uint64_t)0, S, (int64_t)INT64_MIN);
 	if (cfg->enable_levels) {
 		if (cfg->enable_levels == 1) hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->lvl_last, (uint64_t)0, S, (int64_t)INT64_MIN);
+		if (cfg->enable_levels == 1 && cfg->enable_tdigest) HIPCHK(hipMemsetAsync(c->lvl_last_tag, 0xFF, (size_t)S * 4, c->stream)); // (no window closed yet)
+		c->lvl_last_epoch = 0xFFFFFFFEu;
 		// GY_HISTOGRAM<int, ...>: max_val_seen_ starts at std::numeric_limits<int>::min()
 		hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->qps_hist, (uint64_t)0, S, (int64_t)INT32_MIN);
 		hipLaunchKernelGGL(k_hist_init, dim3(grid_for(S, 256, 2048)), dim3(256), 0, c->stream, c->act_hist, (uint64_t)0, S, (int64_t)INT32_MIN);
@@ -2601,7 +2624,7 @@ void gys_destroy(gys_ctx *c)
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_claim, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->ring_act32, c->ring_act64, c->act_live, c->q_cand_key, c->q_out_keys, c->q_cand_slot, c->q_misc, c->q_host_mask, c->q_slot_list, c->q_set, c->q_out_rows, c->q_acc, c->q_cnt, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
-			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_first, c->qps_hist, c->act_hist, c->cand_pool, c->own_arena ? c->arena : nullptr};
+			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_last_tag, c->lvl_first, c->qps_hist, c->act_hist, c->cand_pool, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -3764,7 +3787,7 @@ try {
 		if (rcf) return rcf;
 	}
 	ProfScope ps(c, "hist_percentiles");
-	hipLaunchKernelGGL(k_hist_percentiles_view, dim3((c->nsvc + 255) / 256), dim3(256), 0, c->stream, c->hist_win, c->hist_all,
+	hipLaunchKernelGGL(k_hist_percentiles_view, dim3((c->nsvc + 255) / 256), dim3(256), 0, c->stream, window_records(c), c->hist_all,
 			   c->cfg.enable_tdigest ? c->td_meta : nullptr, c->epoch, which, c->nsvc, c->dev_pcts, npct, d_out);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
@@ -4204,7 +4227,7 @@ try {
 	}
 	gys_hist_rec *tmp = nullptr; // window / all-time VIEW of the records (hist_view in gys_kernels.hpp)
 	HIPCHK(hipMalloc((void **)&tmp, (size_t)nslots * sizeof(gys_hist_rec)));
-	hipLaunchKernelGGL(k_hist_view, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, c->hist_win, c->hist_all,
+	hipLaunchKernelGGL(k_hist_view, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, window_records(c), c->hist_all,
 			   c->cfg.enable_tdigest ? c->td_meta : nullptr, c->epoch, which, first_slot, nslots, tmp);
 	hipError_t e = hipMemcpyAsync(out, tmp, (size_t)nslots * sizeof(gys_hist_rec), hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -4559,6 +4582,8 @@ try {
 	p.epoch_last = p.epoch_open - 1u;
 	p.nsvc = c->nsvc;
 	for (int lv = 0; lv < GYS_NLEVELS; ++lv) level_source(c, lv, tq, &p.mode[lv], &p.sub[lv]);
+	p.last_tag = c->cfg.enable_tdigest ? c->lvl_last_tag : nullptr;
+	p.last_epoch = c->lvl_last_epoch;
 	p.qps = c->qps_hist;
 	p.act = c->act_hist;
 	p.bitmap = c->bitmap;

@@ -1566,7 +1566,7 @@ struct DigestP {
 //   window record: a record of an older window is dropped first (the reference clears the 5-s state on its timer,
 //   GY_HISTOGRAM::clear :630-636; here a key rolls when the first values of a later window are folded), then += dw; same for the rows.
 __device__ __forceinline__ void fold_records(const DigestP &p, uint32_t slot, uint32_t g, bool roll, unsigned long long da, unsigned long long dw,
-					     uint32_t n_all, uint32_t n_win, int32_t max_all, int32_t max_win, uint32_t bm, uint32_t bm6, uint4 *win_out = nullptr)
+					     uint32_t n_all, uint32_t n_win, int32_t max_all, int32_t max_win, uint32_t bm, uint32_t bm6)
 {
 	uint4 *ap = (uint4 *)&p.hist_all[slot] + g, *wp = (uint4 *)&p.hist_win[slot] + g;
 	if (n_all) {
@@ -1596,7 +1596,6 @@ __device__ __forceinline__ void fold_records(const DigestP &p, uint32_t slot, ui
 			if ((int64_t)hi < (int64_t)max_win) hi = (uint64_t)(int64_t)max_win;
 		}
 		if (roll || g == 15u || dw) *wp = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-		if (win_out) *win_out = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)); // (lane g's pair of the window record as it stands now)
 		uint32_t *bp = &p.bitmap[(size_t)slot * GYS_BM_WORDS + g];
 		const uint32_t old = roll ? 0u : *bp;
 		if (roll || (old | bm) != old) *bp = old | bm;
@@ -1613,17 +1612,15 @@ __device__ __forceinline__ void fold_records(const DigestP &p, uint32_t slot, ui
 struct FoldP {
 	DigestP d;
 	uint32_t first, n;
-	// LEVELS (window close with the 5-s level, gys_config.enable_levels = 1): the same pass leaves the closing window's record of EVERY service
-	// of the range in last[] (level 0: the window closed last; a service without values in the closing window gets the empty record) and
-	// the time of a service's first window close in first_sec[] -- what k_level_roll did in a pass of its own (a second read of every
-	// window record, 272 of ~1 600 bytes per service and close)
-	gys_hist_rec *last;
+	// window close with the 5-s level (gys_config.enable_levels = 1; nullptr otherwise): the pass visits every service of the range anyway, so it
+	// also leaves, per service, the window its record in hist_win belongs to once it is folded (last_tag[]) -- the engine then SWAPS hist_win and
+	// the level-0 array instead of copying 256 bytes per service (k_level_roll's pass of rounds 2 - 4; a key's first fold of the next window
+	// rewrites the record without reading it: `roll` in fold_records) -- and the time of a service's first window close (first_sec[]).
+	uint32_t *last_tag;
 	int64_t *first_sec;
 	int64_t tnow;
-	uint32_t epoch; // the window being closed
 };
 
-template <bool LEVELS>
 __global__ __launch_bounds__(256) void k_fold(FoldP q)
 {
 	const DigestP &p = q.d;
@@ -1638,83 +1635,72 @@ __global__ __launch_bounds__(256) void k_fold(FoldP q)
 		const uint32_t rel = chunk * 64u + lane;
 		uint4 mraw = make_uint4(0, 0, 0, 0);
 		if (rel < q.n) mraw = *(const uint4 *)&p.td_meta[q.first + rel];
-		const unsigned long long todo = LEVELS ? __ballot(rel < q.n) : __ballot(mraw.x > (mraw.y & 0xFFFFu));
-		if (LEVELS && rel < q.n && q.first_sec[q.first + rel] == 0) q.first_sec[q.first + rel] = q.tnow; // BucketedTimeSeries::update on an empty series (one coalesced access per chunk: inside the per-key rounds below the read would be one more dependent round trip per round)
-		if (!todo) continue;
-		for (uint32_t rd = 0; rd < 16u; ++rd) {
-			if (!((todo >> (4u * rd)) & 0xFull)) continue;
-			const uint32_t k = rd * 4u + row;
-			const uint32_t slot = q.first + chunk * 64u + k;
-			const bool live = chunk * 64u + k < q.n; // (LEVELS: every service of the range is visited; a short last chunk has rows past the end)
-			uint4 mt;
-			mt.x = (uint32_t)__shfl((int)mraw.x, (int)k, 64);
-			mt.y = (uint32_t)__shfl((int)mraw.y, (int)k, 64);
-			mt.z = (uint32_t)__shfl((int)mraw.z, (int)k, 64);
-			mt.w = (uint32_t)__shfl((int)mraw.w, (int)k, 64);
-			const uint32_t npend = mt.x, nh = mt.y & 0xFFFFu, nw = mt.y >> 16;
-			const uint32_t nwin0 = max(nh, nw); // first word of the not yet folded part that belongs to window win_epoch
-			const uint32_t m = npend > nh ? npend - nh : 0u;
-			s_a[g] = 0;
-			s_w[g] = 0;
-			s_bm[g] = 0;
-			s_bm[g + 16u] = 0;
-			GYS_WAVE_SYNC();
-			const uint32_t *pend = p.td_pend + (size_t)slot * p.pcap;
-			const uint32_t mmax = max(max((uint32_t)__shfl((int)m, 0, 64), (uint32_t)__shfl((int)m, 16, 64)),
-						  max((uint32_t)__shfl((int)m, 32, 64), (uint32_t)__shfl((int)m, 48, 64)));
-			int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmax = INT32_MIN;
-			for (uint32_t base = 0; base < mmax; base += 16u) {
-				const uint32_t i = nh + base + g;
-				if (base + g < m) {
-					const uint32_t w = pend[i];
-					const int32_t v = (int32_t)(w >> GYS_ROW_BITS);
-					const uint32_t b = resp_bucket((int64_t)v);
-					const unsigned long long one = GYS_PACK_ONE | (unsigned long long)(uint32_t)v;
-					atomicAdd(&s_a[b], one);
-					lmin = min(lmin, v);
-					lmax = max(lmax, v);
-					if (i >= nwin0) {
-						atomicAdd(&s_w[b], one);
-						const uint32_t r = w & GYS_ROW_MASK; // CONN_BITMAP::add_response: respmap_[row].set(bucket) (common/gy_socket_stat.h:403-410); rows 32..63: resp_bitmap_v6_
-						atomicOr(&s_bm[r >> 1], (1u << b) << ((r & 1u) * 16u));
-						wmax = max(wmax, v);
-					}
-				}
-			}
-#pragma unroll
-			for (int d = 8; d >= 1; d >>= 1) {
-				lmin = min(lmin, __shfl_xor(lmin, d, 64));
-				lmax = max(lmax, __shfl_xor(lmax, d, 64));
-				wmax = max(wmax, __shfl_xor(wmax, d, 64));
-			}
-			GYS_WAVE_SYNC();
-			uint32_t hw_now = mt.w; // window the record in hist_win belongs to once this key is done
-			uint4 wrec = make_uint4(0, 0, 0, 0);
-			bool have_wrec = false;
-			if (m) {
+		const unsigned long long todo = __ballot(mraw.x > (mraw.y & 0xFFFFu));
+		if (todo) {
+			for (uint32_t rd = 0; rd < 16u; ++rd) {
+				if (!((todo >> (4u * rd)) & 0xFull)) continue;
+				const uint32_t k = rd * 4u + row;
+				const uint32_t slot = q.first + chunk * 64u + k;
+				uint4 mt;
+				mt.x = (uint32_t)__shfl((int)mraw.x, (int)k, 64);
+				mt.y = (uint32_t)__shfl((int)mraw.y, (int)k, 64);
+				mt.z = (uint32_t)__shfl((int)mraw.z, (int)k, 64);
+				mt.w = (uint32_t)__shfl((int)mraw.w, (int)k, 64);
+				const uint32_t npend = mt.x, nh = mt.y & 0xFFFFu, nw = mt.y >> 16;
+				const uint32_t nwin0 = max(nh, nw); // first word of the not yet folded part that belongs to window win_epoch
+				const uint32_t m = npend > nh ? npend - nh : 0u;
+				s_a[g] = 0;
+				s_w[g] = 0;
+				s_bm[g] = 0;
+				s_bm[g + 16u] = 0;
+				GYS_WAVE_SYNC();
+				const uint32_t *pend = p.td_pend + (size_t)slot * p.pcap;
+				const uint32_t mmax = max(max((uint32_t)__shfl((int)m, 0, 64), (uint32_t)__shfl((int)m, 16, 64)),
+							  max((uint32_t)__shfl((int)m, 32, 64), (uint32_t)__shfl((int)m, 48, 64)));
+				int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmax = INT32_MIN;
 				const uint32_t n_win = npend > nwin0 ? npend - nwin0 : 0u;
 				const bool roll = mt.w != mt.z;
-				fold_records(p, slot, g, roll, s_a[g], s_w[g], m, n_win, lmax, wmax, s_bm[g], s_bm[g + 16u], LEVELS ? &wrec : nullptr);
-				have_wrec = n_win != 0u;
-				if (n_win) hw_now = mt.z;
-				if (g == 0) {
-					*(uint4 *)&p.td_meta[slot] = make_uint4(npend, npend | (nw << 16), mt.z, n_win ? mt.z : mt.w);
-					const int2 mm = p.td_minmax[slot];
-					if (lmin < mm.x || lmax > mm.y) p.td_minmax[slot] = make_int2(min(mm.x, lmin), max(mm.y, lmax));
+				for (uint32_t base = 0; base < mmax; base += 16u) {
+					const uint32_t i = nh + base + g;
+					if (base + g < m) {
+						const uint32_t w = pend[i];
+						const int32_t v = (int32_t)(w >> GYS_ROW_BITS);
+						const uint32_t b = resp_bucket((int64_t)v);
+						const unsigned long long one = GYS_PACK_ONE | (unsigned long long)(uint32_t)v;
+						atomicAdd(&s_a[b], one);
+						lmin = min(lmin, v);
+						lmax = max(lmax, v);
+						if (i >= nwin0) {
+							atomicAdd(&s_w[b], one);
+							const uint32_t r = w & GYS_ROW_MASK; // CONN_BITMAP::add_response: respmap_[row].set(bucket) (common/gy_socket_stat.h:403-410); rows 32..63: resp_bitmap_v6_
+							atomicOr(&s_bm[r >> 1], (1u << b) << ((r & 1u) * 16u));
+							wmax = max(wmax, v);
+						}
+					}
 				}
-			}
-			if (LEVELS && live) {
-				// level 0 = the closing window's record: the window record when it belongs to the closing window (just folded, or folded
-				// earlier in the window by a merge / a query), the empty record otherwise (k_level_roll's `closing`)
-				uint4 *lp = (uint4 *)&q.last[slot] + g;
-				if (hw_now == q.epoch) {
-					if (!have_wrec) wrec = *((const uint4 *)&p.hist_win[slot] + g);
-					*lp = wrec;
-				} else {
-					*lp = g < 15u ? make_uint4(0, 0, 0, 0) : make_uint4(0, 0, 0, 0x80000000u); // {0, INT64_MIN}: total_count_, max_val_seen_
+#pragma unroll
+				for (int d = 8; d >= 1; d >>= 1) {
+					lmin = min(lmin, __shfl_xor(lmin, d, 64));
+					lmax = max(lmax, __shfl_xor(lmax, d, 64));
+					wmax = max(wmax, __shfl_xor(wmax, d, 64));
 				}
+				GYS_WAVE_SYNC();
+				if (m) {
+					fold_records(p, slot, g, roll, s_a[g], s_w[g], m, n_win, lmax, wmax, s_bm[g], s_bm[g + 16u]);
+					if (g == 0) {
+						*(uint4 *)&p.td_meta[slot] = make_uint4(npend, npend | (nw << 16), mt.z, n_win ? mt.z : mt.w);
+						const int2 mm = p.td_minmax[slot];
+						if (lmin < mm.x || lmax > mm.y) p.td_minmax[slot] = make_int2(min(mm.x, lmin), max(mm.y, lmax));
+					}
+				}
+				GYS_WAVE_SYNC();
 			}
-			GYS_WAVE_SYNC();
+		}
+		if (q.last_tag && rel < q.n) {
+			// lane l: the window the record of service chunk * 64 + l belongs to now -- the rounds' `hw_now`, from the lane's own meta word
+			const uint32_t nh = mraw.y & 0xFFFFu, nwin0 = max(nh, mraw.y >> 16);
+			q.last_tag[q.first + rel] = mraw.x > nh && mraw.x > nwin0 ? mraw.z : mraw.w;
+			if (q.first_sec[q.first + rel] == 0) q.first_sec[q.first + rel] = q.tnow; // BucketedTimeSeries::update on an empty series
 		}
 	}
 }
@@ -3699,6 +3685,8 @@ struct LevelViewP {
 	uint32_t first, n;
 	const gys_hist_rec *sub; // mode 0: snapshot to subtract (nullptr: nothing); mode 2: the last-window records
 	int mode;                // 0 cumulative - sub, 1 empty, 2 copy of sub
+	const uint32_t *last_tag; // mode 2 with lazily folded records: sub[slot] is the service's record of window last_tag[slot] -- the closed window's
+	uint32_t last_epoch;      // only when that equals last_epoch (the array is the former hist_win, swapped in at the close; nullptr: always)
 	gys_hist_rec *out;       // [n]; max_val_seen is the all-time maximum for every level (the reference keeps no per-level maximum)
 };
 
@@ -3726,7 +3714,7 @@ __global__ __launch_bounds__(256) void k_level_view(LevelViewP p)
 			r.x -= s.x;
 			if (k < 15u) r.y -= s.y;
 		}
-	} else if (p.mode == 2) {
+	} else if (p.mode == 2 && (!p.last_tag || p.last_tag[slot] == p.last_epoch)) {
 		r = ((const ulonglong2 *)p.sub)[g];
 		if (k == 15u) r.y = cum.y;
 	} else {
@@ -3754,6 +3742,8 @@ struct LevelPeriodP {
 	float scale[GYS_PERIOD_MAXB];
 	uint32_t whole_mask;                           // bit i: ring bucket i lies inside the interval (taken unscaled)
 	const gys_hist_rec *last;                      // mode 2
+	const uint32_t *last_tag;                      // mode 2: see LevelViewP
+	uint32_t last_epoch;
 	const int64_t *first_sec;                      // mode 3
 	int64_t start, end, latest;                    // mode 3: [start, end) and latestTime_
 	gys_hist_rec *out;                             // [n]: stats[b] = the interval's {count, sum}, total_count = their sum, max_val_seen all-time
@@ -3795,9 +3785,11 @@ __global__ __launch_bounds__(256) void k_level_period(LevelPeriodP p)
 				lo = hi;
 			}
 		} else if (p.mode == 2) {
-			const ulonglong2 r = ((const ulonglong2 *)p.last)[g];
-			ac = (long long)r.x;
-			as = (long long)r.y;
+			if (!p.last_tag || p.last_tag[slot] == p.last_epoch) {
+				const ulonglong2 r = ((const ulonglong2 *)p.last)[g];
+				ac = (long long)r.x;
+				as = (long long)r.y;
+			}
 		} else if (p.mode == 3) {
 			const int64_t bs = p.first_sec[slot];
 			int64_t bn = p.latest + 1;
@@ -3877,6 +3869,8 @@ struct ListenerScanP {
 	uint32_t nsvc;
 	int mode[GYS_NLEVELS];               // per level: 0 cumulative - sub, 1 empty, 2 copy of sub (level 0: the last closed window)
 	const gys_hist_rec *sub[GYS_NLEVELS];
+	const uint32_t *last_tag;            // a mode-2 level: see LevelViewP
+	uint32_t last_epoch;
 	const gys_hist_rec *qps, *act;
 	const uint32_t *bitmap;              // [nsvc * GYS_BM_WORDS] u32 = 32 x u16 IPv4 rows, 32 x u16 IPv6 rows
 	const uint64_t *svc_gid;
@@ -3902,6 +3896,7 @@ __global__ __launch_bounds__(256) void k_listener_scan(ListenerScanP p)
 	memset(&o, 0, sizeof(o));
 	o.glob_id = p.svc_gid[slot];
 	const bool open_folded = p.meta && p.meta[slot].hw_epoch == p.epoch_open; // the folded part of the OPEN window is in no level yet
+	const bool last_ok = !p.last_tag || p.last_tag[slot] == p.last_epoch;
 	for (int lv = 0; lv < GYS_NLEVELS; ++lv) {
 		gys_hist_rec r;
 		int64_t ts = 0;
@@ -3910,8 +3905,10 @@ __global__ __launch_bounds__(256) void k_listener_scan(ListenerScanP p)
 			uint64_t cnt = 0;
 			int64_t sum = 0;
 			if (p.mode[lv] == 2) {
-				cnt = p.sub[lv][slot].stats[b].count;
-				sum = p.sub[lv][slot].stats[b].sum;
+				if (last_ok) {
+					cnt = p.sub[lv][slot].stats[b].count;
+					sum = p.sub[lv][slot].stats[b].sum;
+				}
 			} else if (p.mode[lv] == 0) {
 				cnt = p.all[slot].stats[b].count;
 				sum = p.all[slot].stats[b].sum;

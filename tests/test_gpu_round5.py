@@ -408,3 +408,69 @@ def test_larger_digest_buffers_equal_the_oracle_with_the_same_buffer(torch_mod, 
     want = np.array([[L.gyo_tdb_quantile(C.byref(orc.td(s)), q) for q in qs] for s in range(orc.nsvc)])
     assert (got == want).all()
     eng.close()
+
+
+def test_level0_is_the_swapped_window_array(torch_mod, oracle):
+    """enable_levels = 1 with lazily folded records: the close leaves level 0 behind by SWAPPING the window-record array with the level-0 array
+    (per-service window tags written by the close's fold pass, level_roll in gys_engine.hip) instead of copying a record per service.  What has
+    to hold whatever a service did in which window: level 0 = the closed window's record (empty for a service silent in it) right after the
+    close, in the prepared state, and still after the NEXT window's events have been folded into the other array by queries and merges; the
+    window view = the open window's record so far; the all-time view = everything.  Services alternate between silent and busy windows so that
+    both arrays hold stale records of different ages; enough values per call for merges (folds inside the merge kernels) in between."""
+    rng = np.random.default_rng(905)
+    nh, sp = 2, 7
+    nsvc = nh * sp
+    eng = _engine(max_hosts=4, max_services=32, max_batch_events=1 << 16, enable_levels=True)
+    orc_win = oracle.OracleEngine(32, enable_td=False)
+    orc_all = oracle.OracleEngine(32, enable_td=False)
+    info, gids = helpers.register_world(eng, orc_win, range(nh), sp)
+    helpers.register_world(None, orc_all, range(nh), sp)
+    t = 1_700_000_000
+    empty = np.zeros((nsvc, 15, 2), dtype=np.int64)
+    prev = empty
+
+    def feed(w, part):
+        for h in range(nh):
+            active = [s for s in range(sp) if (w + s + h) % 3 != 0 and not (w % 4 == 3 and h == 1)]  # silent services, a silent host every 4th window
+            if not active:
+                continue
+            n = int(rng.integers(200, 900)) * len(active) if (w + part) % 3 else 2600 * len(active)  # (2600 per service: past the buffer, merges)
+            ev = helpers.make_resp_events(rng, h, n, sp, lat_mu=2.5 + 0.2 * (w % 5))
+            s_idx = np.array(active)[rng.integers(0, len(active), n)]
+            ev["netns"] = wire.listener_netns(h, s_idx)
+            ev["sport_be"] = wire.listener_port(s_idx)
+            eng.handle_resp_events(info[h][0], ev)
+            for o in (orc_win, orc_all):
+                o.resp_batch(ev.tobytes(), [info[h][1]], [0])
+
+    def lv0(tq):
+        return eng.export_hist_level(0, tq * 1_000_000, 0, nsvc)[:, :15, :]
+
+    for w in range(14):
+        t += 5
+        feed(w, 0)
+        # mid-window: the queries fold the open window into the (swapped-in) window array; level 0 still is the window closed before
+        assert (lv0(t - 3) == prev).all(), "window %d: level 0 after the next window's first folds" % w
+        helpers.assert_hist_equal(eng.export_hist(0, 0, nsvc), orc_win.hist(), nsvc)
+        helpers.assert_hist_equal(eng.export_hist(1, 0, nsvc), orc_all.hist(), nsvc)
+        feed(w, 1)
+        assert (lv0(t - 1) == prev).all(), "window %d: level 0 before the close" % w
+        win = np.array(orc_win.hist()[:nsvc])[:, :15, :]
+        if w % 3 == 1:
+            capi.check(eng.L.gys_window_prepare(eng.h, t * 1_000_000))
+            # prepared, not finished: the closing window is level 0 already and still is what the window view shows
+            assert (lv0(t) == win).all(), "window %d: level 0 in the prepared state" % w
+            helpers.assert_hist_equal(eng.export_hist(0, 0, nsvc), orc_win.hist(), nsvc)
+            capi.check(eng.L.gys_window_finish(eng.h))
+        else:
+            eng.window_close(t * 1_000_000)
+        assert (lv0(t) == win).all(), "window %d: level 0 after the close" % w
+        assert (lv0(t + 4) == win).all()
+        assert (lv0(t + 5) == empty).all()  # a 5-s ring keeps an add for 5 s
+        orc_win.window_clear(clear_hist=True)
+        orc_all.window_clear(clear_hist=False)
+        helpers.assert_hist_equal(eng.export_hist(0, 0, nsvc), orc_win.hist(), nsvc)  # the new window is empty for every service
+        helpers.assert_hist_equal(eng.export_hist(1, 0, nsvc), orc_all.hist(), nsvc)
+        prev = win
+    assert eng.counters()["td_merges"] > 0
+    eng.close()

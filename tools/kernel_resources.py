@@ -23,6 +23,8 @@ DYN_LDS = {"k_resp_host": "93 KiB dynamic at the bench's 1000-listener hosts (ti
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else None
+    if out and not out.endswith(".txt"):
+        sys.exit("kernel_resources.py: the argument is the OUTPUT file (*.txt); the library is always compiled from the sources")
     with tempfile.TemporaryDirectory() as t:
         obj = os.path.join(t, "dev.o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only",
@@ -59,9 +61,9 @@ def main():
                      lds, waves_reg, wg_lds, waves_wg, note))
     rows.sort(key=lambda r: r[0])
     lines = ["# static kernel resources, gfx950 (tools/kernel_resources.py; hipcc -O3 of gyeeta_amd/csrc/gys_engine.hip)",
-             "%-34s %5s %5s %5s %5s %6s %8s %8s %10s %12s" % ("kernel", "wg", "vgpr", "agpr", "sgpr", "spills", "scratchB", "LDS B", "waves/SIMD", "wg/CU by LDS")]
+             "%-44s %5s %5s %5s %5s %6s %8s %8s %10s %12s" % ("kernel", "wg", "vgpr", "agpr", "sgpr", "spills", "scratchB", "LDS B", "waves/SIMD", "wg/CU by LDS")]
     for n, wg, vg, ag, sg, sp, scr, lds, wr, wl, ww, note in rows:
-        lines.append("%-34s %5d %5d %5d %5d %6d %8d %8d %10d %12s  %s" % (n[:34], wg, vg, ag, sg, sp, scr, lds, wr, "-" if wl is None else str(wl), note))
+        lines.append("%-44s %5d %5d %5d %5d %6d %8d %8d %10d %12s  %s" % (n[:44], wg, vg, ag, sg, sp, scr, lds, wr, "-" if wl is None else str(wl), note))
     text = "\n".join(lines) + "\n"
     if out:
         open(out, "w").write(text)
