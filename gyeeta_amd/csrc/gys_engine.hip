@@ -3226,21 +3226,36 @@ static hipError_t enqueue_finish(gys_ctx *c, hipStream_t st)
 	hipLaunchKernelGGL(k_act_latch, dim3(64), dim3(256), 0, st, (const uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_misc, c->d_epoch, c->act_live,
 			   (const uint32_t *)(c->arena + c->al.off_u32) + c->al.u32_pair,
 			   (const unsigned long long *)(c->arena + c->al.off_i64sum) + c->al.i64_pair, c->ring_act32, c->ring_act64, c->last_act32, c->last_act64);
-	if ((e = hipMemcpyAsync(c->last, c->arena, c->al.total, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(c->arena, 0, c->al.total, st)) != hipSuccess) return e;
-	if ((e = hipMemcpyAsync(c->arena + c->al.off_i64max, &c->i64min, 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(c->hll32, 0, (uint64_t)4 << GYS_HLL_P, st)) != hipSuccess) return e;
 	if (c->nsvc) {
 		// CONN_BITMAP cleared every window (secs_to_reset_ = 5); lazily (per key, on its next touch) when the per-key pass runs
 		if (!c->cfg.enable_tdigest && (e = hipMemsetAsync(c->bitmap, 0, (uint64_t)c->nsvc * GYS_BM_WORDS * 4, st)) != hipSuccess) return e;
 		if (c->svc_hll && (e = hipMemsetAsync(c->svc_hll, 0, (uint64_t)c->nsvc << c->cfg.svc_hll_p, st)) != hipSuccess) return e;
 	}
 	const uint64_t hb = (uint64_t)c->hosts.size() * 16 * 4;
+	if (((uintptr_t)c->arena & 15u) == 0) { // (a caller's reduce_arena is torch / hipMalloc memory: always; the plain sequence below otherwise)
+		WinFinishP p{};
+		p.arena = (uint4 *)c->arena;
+		p.last = (uint4 *)c->last;
+		p.n16 = c->al.total / 16;
+		p.i64max_at = c->al.off_i64max;
+		p.hll32 = (uint4 *)c->hll32;
+		p.hll16 = ((uint64_t)4 << GYS_HLL_P) / 16;
+		p.hs_win = (uint4 *)c->host_summ_win;
+		p.hs_last = (uint4 *)c->host_summ_last;
+		p.hs16 = hb / 16;
+		p.d_epoch = c->d_epoch; // the device copy of the window number follows the host's
+		hipLaunchKernelGGL(k_window_finish, dim3(grid_for(std::max<uint64_t>(p.n16, p.hs16), 256, (uint32_t)c->ncu * 4)), dim3(256), 0, st, p);
+		return hipGetLastError();
+	}
+	if ((e = hipMemcpyAsync(c->last, c->arena, c->al.total, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(c->arena, 0, c->al.total, st)) != hipSuccess) return e;
+	if ((e = hipMemcpyAsync(c->arena + c->al.off_i64max, &c->i64min, 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(c->hll32, 0, (uint64_t)4 << GYS_HLL_P, st)) != hipSuccess) return e;
 	if (hb) {
 		if ((e = hipMemcpyAsync(c->host_summ_last, c->host_summ_win, hb, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
 		if ((e = hipMemsetAsync(c->host_summ_win, 0, hb, st)) != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL(k_epoch_inc, dim3(1), dim3(1), 0, st, c->d_epoch); // the device copy of the window number follows the host's
+	hipLaunchKernelGGL(k_epoch_inc, dim3(1), dim3(1), 0, st, c->d_epoch);
 	return hipGetLastError();
 }
 

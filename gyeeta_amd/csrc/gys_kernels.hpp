@@ -3448,6 +3448,42 @@ struct PrepP {
 // (send_cluster_state skips hosts without a recent state, :16068-16070)
 __global__ void k_epoch_inc(uint32_t *d_epoch) { *d_epoch += 1u; }
 
+// The fixed tail of a window close in ONE launch (round 5; it was a copy, three fills, a host-to-device copy, another copy + fill and a
+// one-thread kernel: nine graph nodes of 10 - 20 us each for ~10 MB of traffic): the window's (reduced) registers are kept for the
+// queries (last = arena), the next window starts from zero (arena, the first-pass HLL filter, the per-host summaries; the i64 MAX
+// section's cell starts at INT64_MIN), the device copy of the window number follows the host's.
+struct WinFinishP {
+	uint4 *arena, *last;
+	uint64_t n16;        // 16-byte pieces of the arena
+	uint64_t i64max_at;  // byte offset of the i64 MAX cell (8-byte aligned)
+	uint4 *hll32;
+	uint64_t hll16;
+	uint4 *hs_win, *hs_last;
+	uint64_t hs16;
+	uint32_t *d_epoch;
+};
+
+__global__ __launch_bounds__(256) void k_window_finish(WinFinishP p)
+{
+	const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+	const uint64_t mx = p.i64max_at >> 4;
+	for (uint64_t i = t0; i < p.n16; i += stride) {
+		p.last[i] = p.arena[i];
+		uint4 z = make_uint4(0, 0, 0, 0);
+		if (i == mx) { // INT64_MIN in the cell's half of the piece
+			if (p.i64max_at & 8u) z.w = 0x80000000u;
+			else z.y = 0x80000000u;
+		}
+		p.arena[i] = z;
+	}
+	for (uint64_t i = t0; i < p.hll16; i += stride) p.hll32[i] = make_uint4(0, 0, 0, 0);
+	for (uint64_t i = t0; i < p.hs16; i += stride) {
+		p.hs_last[i] = p.hs_win[i];
+		p.hs_win[i] = make_uint4(0, 0, 0, 0);
+	}
+	if (t0 == 0) *p.d_epoch += 1u;
+}
+
 __global__ void k_window_prepare(PrepP p)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
