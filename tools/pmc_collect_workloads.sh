@@ -20,7 +20,7 @@ for name in $NAMES; do
   K=10
   rm -rf /tmp/kt_$name /tmp/pf_$name /tmp/pw_$name
   timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/kt_$name -o kt -- python $R/bench.py --sub $name $ARGS --no-quantile-check --steps $K --warmup 3 > $O/${name}_line_profiled.json 2> $O/${name}_kt.err
-  for f in $(find /tmp/kt_$name -name "*.db"); do python $R/tools/rocprof_summary.py $f $O/${name}_kernel_stats.txt --timed $((K+1)) --anchor k_epoch_inc; done  # a step ends with the window close's k_epoch_inc: everything after the (K+1)-th-from-last one = the K timed steps
+  for f in $(find /tmp/kt_$name -name "*.db"); do python $R/tools/rocprof_summary.py $f $O/${name}_kernel_stats.txt --timed $((K+1)) --anchor k_window_finish; done  # a step ends with the window close's k_window_finish: everything after the (K+1)-th-from-last one = the K timed steps
   timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf_$name -o p --output-format csv -- python $R/bench.py --sub $name $ARGS --no-quantile-check --steps 4 --warmup 2 > $O/${name}_pmc_fetch.log 2>&1
   timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw_$name -o p --output-format csv -- python $R/bench.py --sub $name $ARGS --no-quantile-check --steps 4 --warmup 2 > $O/${name}_pmc_write.log 2>&1
   python $R/tools/pmc_workload.py /tmp/pf_$name /tmp/pw_$name $name 4 $O/pmc_traffic.json $UNITS $UNIT > $O/${name}_pmc_traffic_entry.json 2> $O/${name}_pmc_workload.err

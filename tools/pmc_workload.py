@@ -4,8 +4,8 @@ MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots" prescribe), merged into profil
 
   usage: pmc_workload.py <fetch_dir> <write_dir> <name> <keep_last_steps> <json in/out> [units_per_step] [unit]
 
-A step of every bench.py workload ends with the window close, whose last kernel is k_epoch_inc: step i = the dispatches after the
-(i-1)-th and up to the i-th k_epoch_inc.  The timed steps are the last ones of a run whose untimed tails are switched off
+A step of every bench.py workload ends with the window close, whose last kernel is k_window_finish: step i = the dispatches after the
+(i-1)-th and up to the i-th k_window_finish.  The timed steps are the last ones of a run whose untimed tails are switched off
 (--sub / --no-cpu-baseline --no-quantile-check --no-host-fed): the last <keep_last_steps> steps are averaged.
 Units (this environment's rocprofv3): both counters in KiB; on gfx950 FETCH_SIZE tallies a 128-B request as 64 B, so it is doubled
 (calibrated in this repo on the event kernel's access pattern, profiles/r2n_calibrate_fetch.txt; WRITE_SIZE on k_gen_resp, which
@@ -19,7 +19,7 @@ import os
 import re
 import sys
 
-ANCHOR = "k_epoch_inc"
+ANCHOR = "k_window_finish"
 
 
 def compact(kernel_name):
@@ -57,7 +57,7 @@ def scope_of(k):
                     ("k_key_append", "key_append"), ("k_scan_", "scan"), ("k_svc_filter", "svc_filter"), ("k_svc_aggr", "svc_aggr")):
         if k.startswith(pre):
             return sc
-    if k.startswith(("k_conn_fold", "k_cms_", "k_window_prepare", "k_act_latch", "k_epoch_inc")):
+    if k.startswith(("k_conn_fold", "k_cms_", "k_window_prepare", "k_act_latch", "k_window_finish")):
         return "window_close"
     return "other"
 
@@ -75,7 +75,7 @@ def per_step(root, counter, keep):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(lambda: collections.defaultdict(int))
     for d, k, v in rows:
-        step = bisect.bisect_left(ends, d)  # dispatches up to and including the step's own k_epoch_inc
+        step = bisect.bisect_left(ends, d)  # dispatches up to and including the step's own k_window_finish
         if step < len(ends):
             per[k][step] += v
             launches[k][step] += 1
@@ -114,7 +114,7 @@ def main():
     doc.setdefault("workloads", {})[name] = ent
     doc["workloads_note"] = ("per workload: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on the bench.py sub-run of that name "
                              "(tools/pmc_collect_workloads.sh); bytes per kernel and step = average over the last steps_averaged steps, a step ends with "
-                             "k_epoch_inc; KiB -> bytes, FETCH_SIZE x2 (gfx950 correction)")
+                             "k_window_finish; KiB -> bytes, FETCH_SIZE x2 (gfx950 correction)")
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps({name: ent}))
 
