@@ -173,7 +173,7 @@ int main(int argc, char **argv)
 			rows[i].bytes_received = 500;
 			rows[i].active_conns = 4;
 		}
-		rows[2].flags = 2; // is_remote_listen_: counted, not rolled up
+		rows[2].flags = 2; // is_remote_listen_: the reference's remoteconntbl (gy_mconnhdlr.cc:7891) -> the second table pair (which 6 / 7)
 		fprintf(stderr, "[shim] active conns\n");
 		if (!h.handle_partha_active_conns(mid, rows, 3, (const uint8_t *)(rows + 3))) return 23;
 		if (h.handle_partha_active_conns(other, rows, 3, (const uint8_t *)(rows + 3))) return 24; // unknown partha
@@ -182,6 +182,12 @@ int main(int argc, char **argv)
 		if (gys_query_pair_cms(h.ctx(), 0x1002, 0x77, 0, &conns) != GYS_OK || gys_query_pair_cms(h.ctx(), 0x1002, 0x77, 1, &bytes) != GYS_OK) return 25;
 		gys_counters ctr{};
 		if (gys_get_counters(h.ctx(), &ctr) != GYS_OK) return 26;
+		uint64_t rconns = 0, rbytes = 0;
+		if (gys_query_pair_cms(h.ctx(), 0x1002, 0x77, 6, &rconns) != GYS_OK || gys_query_pair_cms(h.ctx(), 0x1002, 0x77, 7, &rbytes) != GYS_OK) return 32;
+		if (rconns != 4 || rbytes != 1500) {
+			fprintf(stderr, "remote-listener rows: conns %llu bytes %llu\n", (unsigned long long)rconns, (unsigned long long)rbytes);
+			return 33;
+		}
 		if (conns != 8 || bytes != 3000 || ctr.actconn_records != 2 || ctr.actconn_remote_listen != 1) {
 			fprintf(stderr, "active conns: conns %llu bytes %llu local %llu remote %llu\n", (unsigned long long)conns, (unsigned long long)bytes,
 				(unsigned long long)ctr.actconn_records, (unsigned long long)ctr.actconn_remote_listen);
@@ -203,6 +209,54 @@ int main(int argc, char **argv)
 			return 30;
 		}
 		if (!h.web_curr_top_listeners(nullptr, GYS_TOP_QPS, "00112233aabbccdd", "", js) || js.find("\"topqps\":[{") == std::string::npos) return 31; // all hosts
+	}
+	// TCP_SOCK_HANDLER::handle_ipv4_resp_event / handle_ipv6_resp_event (gy_socket_stat.cc:1517-1551) through the shim: an any-address IPv4
+	// listener, a listener bound to an IPv6 address (gy_socket_stat.h:708-714: the event's server address has to equal it), one event to an
+	// address nobody listens on
+	{
+		gys_listener_info b6{};
+		b6.glob_id = 0x2000;
+		b6.netns = 4026531840u;
+		b6.port = 9000;
+		b6.is_any_ip = 0;
+		b6.addr_is_v6 = 1;
+		const uint8_t a6[16] = {0x20, 0x01, 0x0d, 0xb8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5};
+		memcpy(b6.addr, a6, 16);
+		snprintf(b6.comm, sizeof(b6.comm), "bound6");
+		if (!h.partha_new_listeners(mid, &b6, 1)) return 34;
+		struct Ev4 { uint32_t saddr, daddr, netns; uint16_t sport_be, dport_be; uint32_t lsndtime, lrcvtime; } e4[3];
+		struct Ev6 { uint8_t saddr[16], daddr[16]; uint32_t netns; uint16_t sport_be, dport_be; uint32_t lsndtime, lrcvtime; } e6[5];
+		static_assert(sizeof(Ev4) == 24 && sizeof(Ev6) == 48, "raw eBPF response events");
+		auto be16 = [](uint16_t v) { return (uint16_t)((v >> 8) | (v << 8)); };
+		for (int i = 0; i < 3; ++i) e4[i] = Ev4{0x0100000au, 0x0200000au + (uint32_t)i, 4026531840u, be16(8004), be16((uint16_t)(40000 + i)), 1010u, 1000u}; // 10 ms each
+		for (int i = 0; i < 5; ++i) {
+			memset(&e6[i], 0, sizeof(Ev6));
+			memcpy(e6[i].saddr, a6, 16);
+			e6[i].daddr[0] = 0xfd;
+			e6[i].daddr[15] = (uint8_t)(i + 1);
+			e6[i].netns = 4026531840u;
+			e6[i].sport_be = be16(9000);
+			e6[i].dport_be = be16((uint16_t)(50000 + i));
+			e6[i].lsndtime = 5020u;
+			e6[i].lrcvtime = 5000u; // 20 ms each
+		}
+		e6[4].saddr[15] = 6; // another server address: no listener takes it
+		gys_counters c0{}, c1{};
+		if (gys_get_counters(h.ctx(), &c0) != GYS_OK) return 35;
+		fprintf(stderr, "[shim] response events\n");
+		if (!h.handle_ipv4_resp_events(mid, e4, 3) || !h.handle_ipv6_resp_events(mid, e6, 5)) return 36;
+		if (h.handle_ipv6_resp_events(other, e6, 5)) return 37; // unknown partha
+		h.send_cluster_state(25000000);
+		if (gys_get_counters(h.ctx(), &c1) != GYS_OK) return 38;
+		gys_time_hist_val tv[1] = {{0, 95.0f, 0}};
+		int64_t n4 = -1, s4 = -1, n6 = -1, s6 = -1;
+		double mean = -1;
+		if (h.get_resp_level_stats(0x1004, 0, 25, tv, 1, n4, s4, mean) != 0 || h.get_resp_level_stats(0x2000, 0, 25, tv, 1, n6, s6, mean) != 0) return 39;
+		if (n4 != 3 || s4 != 30 || n6 != 4 || s6 != 80 || c1.resp_events - c0.resp_events != 8 || c1.resp_dropped_nolistener - c0.resp_dropped_nolistener != 1) {
+			fprintf(stderr, "response events: v4 %lld / %lld v6 %lld / %lld events %llu dropped %llu\n", (long long)n4, (long long)s4, (long long)n6, (long long)s6,
+				(unsigned long long)(c1.resp_events - c0.resp_events), (unsigned long long)(c1.resp_dropped_nolistener - c0.resp_dropped_nolistener));
+			return 40;
+		}
 	}
 	printf("shim ok\n");
 	return 0;

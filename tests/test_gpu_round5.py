@@ -439,6 +439,18 @@ def test_level0_is_the_swapped_window_array(torch_mod, oracle):
             s_idx = np.array(active)[rng.integers(0, len(active), n)]
             ev["netns"] = wire.listener_netns(h, s_idx)
             ev["sport_be"] = wire.listener_port(s_idx)
+            if (w + part + h) % 4 == 3:
+                # the same traffic as IPv6 events (handle_ipv6_resp_event adds to the same resp_hist_, gy_socket_stat.cc:1577-1592)
+                e6 = np.zeros(n, dtype=wire.RESP_EVENT6)
+                e6["saddr"][:, 0], e6["saddr"][:, 1], e6["saddr"][:, 15] = 0x20, 0x01, h + 1
+                e6["daddr"][:, 0] = 0xFD
+                e6["daddr"][:, 12:16] = rng.integers(0, 256, (n, 4))
+                for f in ("netns", "sport_be", "dport_be", "lsndtime", "lrcvtime"):
+                    e6[f] = ev[f]
+                eng.handle_resp_events_v6(info[h][0], e6)
+                for o in (orc_win, orc_all):
+                    o.resp_batch_v6(e6.tobytes(), [info[h][1]], [0])
+                continue
             eng.handle_resp_events(info[h][0], ev)
             for o in (orc_win, orc_all):
                 o.resp_batch(ev.tobytes(), [info[h][1]], [0])
@@ -473,4 +485,25 @@ def test_level0_is_the_swapped_window_array(torch_mod, oracle):
         helpers.assert_hist_equal(eng.export_hist(1, 0, nsvc), orc_all.hist(), nsvc)
         prev = win
     assert eng.counters()["td_merges"] > 0
+    # a service registered after many closes: no level-0 record until a window of its own has closed (its tag names no window yet)
+    gid_new, ns_new, port_new = 0x7777, int(wire.listener_netns(0, 0)), 20000
+    s_new = eng.register_listeners(info[0][0], [gid_new], [ns_new], [port_new])
+    for o in (orc_win, orc_all):
+        assert o.register(info[0][1], gid_new, ns_new, port_new) == s_new
+    assert s_new == nsvc
+    assert (eng.export_hist_level(0, t * 1_000_000, 0, nsvc + 1)[nsvc, :15, :] == 0).all()
+    for rnd in range(2):
+        t += 5
+        ev = helpers.make_resp_events(rng, 0, 700, sp, unknown_frac=0.0)
+        ev["netns"], ev["sport_be"] = ns_new, port_new
+        eng.handle_resp_events(info[0][0], ev)
+        for o in (orc_win, orc_all):
+            o.resp_batch(ev.tobytes(), [info[0][1]], [0])
+        eng.window_close(t * 1_000_000)
+        win = np.array(orc_win.hist()[:nsvc + 1])[:, :15, :]
+        assert win[nsvc, :, 0].sum() > 600
+        assert (eng.export_hist_level(0, t * 1_000_000, 0, nsvc + 1)[:, :15, :] == win).all(), "late service, close %d" % rnd
+        orc_win.window_clear(clear_hist=True)
+        orc_all.window_clear(clear_hist=False)
+    helpers.assert_hist_equal(eng.export_hist(1, 0, nsvc + 1), orc_all.hist(), nsvc + 1)
     eng.close()
