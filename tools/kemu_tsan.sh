@@ -21,3 +21,17 @@ for t in bins resp spill conn cms wire lstate topn rollup svcquery; do
 	TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=0" timeout 2400 /tmp/kemu_${t}_$SAN > /tmp/kemu_${t}_$SAN.log 2>&1
 	echo "== $t"; grep -E "SUMMARY|ERROR: AddressSanitizer|kemu $t ok|FAIL" /tmp/kemu_${t}_$SAN.log | sort | uniq -c
 done
+# the instances the default build of a program does not reach (round 5): merges of 2048 / 4096 values, bound-address listeners, IPv6 events (also in the
+# split form), a larger digest buffer, predicted runs
+variant() { name=$1; src=$2; arg=$3; shift 3
+	g++ -std=c++20 -O1 -g -w -fsanitize=$SAN -Itests/cpp/kemu "$@" tests/cpp/kemu/$src -o /tmp/kemu_v_${name}_$SAN -Loracle -l:liboracle.so -Wl,-rpath,$R/oracle -pthread || exit 1
+	TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=0" timeout 2400 /tmp/kemu_v_${name}_$SAN $arg > /tmp/kemu_v_${name}_$SAN.log 2>&1
+	echo "== $name"; grep -E "SUMMARY|ERROR: AddressSanitizer|kemu .* ok|FAIL" /tmp/kemu_v_${name}_$SAN.log | sort | uniq -c
+}
+variant bins_2048 test_bins.cc 12345 -DKEMU_BINS_VPT=8
+variant bins_4096 test_bins.cc 12345 -DKEMU_BINS_VPT=16
+variant resp_bound_address test_resp.cc 4243 -DKEMU_TPT=16 -DKEMU_MODE=1
+variant resp_ipv6 test_resp.cc 4244 -DKEMU_TPT=16 -DKEMU_MODE=2
+variant resp_ipv6_split test_resp.cc 4245 -DKEMU_TPT=16 -DKEMU_MODE=2 -DKEMU_SPLIT -DKEMU_NB=4
+variant resp_pend_cap_1536 test_resp.cc 4246 -DKEMU_TPT=16 -DKEMU_PEND_CAP=1536 -DKEMU_NB=12
+variant spill_predicted test_spill.cc 778 -DKEMU_PRESPILL

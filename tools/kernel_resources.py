@@ -17,8 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gyeeta_amd", "csrc", "gys_engine.hip")
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 FILT = "c++filt"
-# dynamic LDS of the launches bench.py's default window makes (gys_engine.hip run_resp_batch: 2048-entry table + 1000 counts + tile image)
-DYN_LDS = {"k_resp_host": "93 KiB dynamic at the bench's 1000-listener hosts (tiled form: 16 KiB table + 4 KiB counts + 73 KiB tile image)"}
+# dynamic LDS of the launches bench.py's default window makes (gys_engine.hip run_resp_batch)
+DYN_LDS = {"k_resp_host": "+ dynamic LDS, resp_host_lds_bytes(): 151 KiB for the <16,...> instances at the bench's 1000-listener hosts (32 KiB quarter-full table + 24 B x 1000 keys + 6 B x 16384-event tile image): one 1024-thread workgroup per CU"}
 
 
 def main():
