@@ -14,7 +14,17 @@
  *     PINNED against common/gy_comm_proto.h / .cc compiled into oracle/_ref (gy_sys_hardware.h replaced by a 16-byte GY_MACHINE_ID
  *     stand-in, oracle/build_ref.sh): tests/test_wire.py, tests/test_oracle_vs_ref.py.
  *   - LISTEN_SUMM_STATS<int>::update (server/gy_msocket.h:840-882) and CLUSTER_STATE_ONE::update_from_state
- *     (server/gy_mconnhdlr.cc:16032-16050) live in server/ headers that need folly/liburcu/boost -> structural restatement, unpinned.
+ *     (server/gy_mconnhdlr.cc:16032-16050) live in server/ files that need folly/liburcu/boost: the two classes are small and
+ *     self-contained, oracle/build_ref.sh cuts their text out of the reference in place and compiles it into oracle/_ref ->
+ *     PINNED (tests/test_oracle_vs_ref.py::test_listen_summ_stats_and_cluster_state_one_equal_the_reference_classes).
+ *   - listener lookup of a response event (round 5): GY_IP_ADDR built from raw IPv4 / IPv6 bytes (ip32_be_ shares its storage with
+ *     embedded_ipv4_: 2002::/16, ::ffff:a.b.c.d and 64:ff9b::/32 addresses compare and hash as the IPv4 address they embed),
+ *     GY_IP_ADDR::operator==, NS_IP_PORT and the listener comparator (common/gy_socket_stat.h:708-714), PAIR_IP_PORT::get_hash:
+ *     PINNED against common/gy_inet_inc.h / gy_common_inc.h compiled into oracle/_ref (tests/test_listener_addr.py).  The ORDER in
+ *     which a lookup meets several listeners of one (netns, port) hash chain is liburcu's (cds_lfht, absent from the tree):
+ *     restated (first registered first), parity unpinned.
+ *   - folly::MultiLevelTimeSeries ring arithmetic (gy_oracle_levels.c), the Postgres tdigest external forms, the criteria walk
+ *     (gy_oracle_query.c): sources absent from /root/reference -> restated from the published algorithms, "parity unpinned".
  *   - HLL / CMS / t-digest: builder-defined (no reference implementation exists) -> "parity unpinned" vs reference; the
  *     acceptance test against reference behaviour is rank error vs exact sort + bucket agreement with GY_HISTOGRAM.
  */
