@@ -3,8 +3,10 @@
 #   thread:  LDS / global accesses of a kernel that are ordered neither by a barrier nor by an atomic show up as data races.  Expected
 #            reports, all idempotent by construction: the read-before-atomicMax of the HLL registers in k_resp_host / k_conn_ingest and
 #            the read-before-atomicOr of CONN_BITMAP words in k_huge_count / k_digest_huge (a register / word only grows: a stale read
-#            costs at most a redundant atomic), and same-value stores by several threads (finalize_key: the host's spill stamp;
-#            k_huge_merge: s_over = 1); the read-before-atomicMax of a histogram's max_val_seen (hist_add_atomic); k_wire_round's mark[]
+#            costs at most a redundant atomic; likewise k_resp_host's re-read of the register file for the next tile's floor while other
+#            workgroups raise registers: a stale floor is only lower), and same-value stores by several threads (finalize_one: the host's
+#            spill stamp and the batch's `hot` flag; k_huge_merge: s_over = 1; k_resp_host's parking entry behind a tile image: every place that kept nothing stores the
+#            same {dropped word, key 0} there); the read-before-atomicMax of a histogram's max_val_seen (hist_add_atomic); k_wire_round's mark[]
 #            (a slot marked DURING a doubling round may already pass its mark on in that round: marks only grow and everything that gets
 #            marked is a true record start of the chain, so a round can only run ahead); k_conn_ingest's relaxed read of its LDS table's
 #            fill count beside the atomic adds to it (a stale count only changes how many probes a record tries).  Round 3's one REAL
