@@ -676,6 +676,8 @@ def main():
                     help="multi-level windows (gys_config.enable_levels): 1 = 5 s / 300 s / 5 d / all (every close folds every touched service), "
                          "2 = without the 5-s level (services touched only when a 30-s ring boundary is crossed)")
     ap.add_argument("--workload", choices=["resp", "conn"], default="resp", help="resp: C3/C4/C5 response-event stream (default); conn: C2 TCP_CONN_NOTIFY stream")
+    ap.add_argument("--ipv6", action="store_true", help="the timed windows feed the same traffic as 48-B tcp_ipv6_resp_event_t events (gys_ingest_resp_events_v6_dev: "
+                    "k_resp_host<..., MODE 2>; 2001:db8:: servers, fd00:: clients -- no embedded IPv4 address, the flows hash as 16-byte ends); not part of the default run")
     ap.add_argument("--conn-stream", choices=["messages", "mixed"], default="messages", help="--workload conn: per-partha 2048-record messages (default) or hosts mixed record by record")
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl", help="window exchange at N > 1: RCCL inside the library (default) or torch.distributed")
     ap.add_argument("--rccl-lib", default="torch", help="which RCCL the library binds at N > 1 (GYS_RCCL_LIB): 'torch' = the copy PyTorch bundles "
@@ -852,6 +854,24 @@ def main():
             buf_uses[b] += 1
         eng.sync()
 
+    evb = EVENT_BYTES
+    ingest_dev = eng.handle_resp_events_dev
+    if args.ipv6:
+        # the resident batches once more as IPv6 events (torch copies: set-up, untimed): words {saddr[4], daddr[4], netns, ports, lsndtime, lrcvtime}
+        evb = 48
+        ingest_dev = eng.handle_resp_events_v6_dev
+        for b in range(nbuf):
+            e4 = bufs[b].view(torch.int32).view(-1, 6)
+            e6 = torch.zeros((args.events, 12), dtype=torch.int32, device="cuda")
+            e6[:, 0] = 0xB80D0120 - (1 << 32)  # 20 01 0d b8: 2001:db8::/32
+            e6[:, 3] = e4[:, 0]
+            e6[:, 4] = 0x000000FD                # fd00::/8
+            e6[:, 7] = e4[:, 1]
+            e6[:, 8:12] = e4[:, 2:6]
+            bufs[b] = e6.view(torch.uint8).view(-1)
+            del e4, e6
+        torch.cuda.synchronize()
+
     import ctypes as C
     if args.global_digest_every < 0:
         args.global_digest_every = 4 if args.share_device else 0
@@ -863,7 +883,7 @@ def main():
     def step(i):
         nonlocal gd_calls
         b = i % nbuf
-        eng.handle_resp_events_dev(segs[b], bufs[b].data_ptr(), args.events)
+        ingest_dev(segs[b], bufs[b].data_ptr(), args.events)
         close(tusec=5_000_000 * (i + 1))
         if gd_slab is not None and args.global_digest_every > 0 and i % args.global_digest_every == args.global_digest_every - 1:
             # the fifth register family: per-(host, service) digests stay rank-local, the GLOBAL digest crosses the ranks as fixed-size slabs
@@ -967,7 +987,7 @@ def main():
         # per kept event; a t-digest merge reads the key's clusters (12 B x NB), its buffered words and writes the clusters back
         # (+ the 256-B window / all-time records it folds on the way); the per-service finalize pass reads one 4-B cursor per service.
         step_s = dt / args.steps
-        alg_bytes = EVENT_BYTES * args.events  # per step: every event of the window's batch is read exactly once
+        alg_bytes = evb * args.events  # per step: every event of the window's batch is read exactly once
         kms = {k: v[0] / max(args.steps, 1) for k, v in prof.items()}
         merges_step = (ctr1["td_merges"] - ctr0["td_merges"]) / max(args.steps, 1)
         mvals_step = (ctr1["td_merge_values"] - ctr0["td_merge_values"]) / max(args.steps, 1)
@@ -981,7 +1001,7 @@ def main():
                 ent["algorithmic_bytes"] = kalg[k]
                 ent["achieved_GBps"] = kalg[k] / (ms * 1e-3) / 1e9
                 ent["frac"] = ent["achieved_GBps"] / HBM_PEAK_GBS
-            tr = workload_traffic(args.sub, k, args.events) if args.sub else pmc_traffic(k, args.events, nsvc)
+            tr = workload_traffic(args.sub, k, args.events) if args.sub else (None if args.ipv6 else pmc_traffic(k, args.events, nsvc))  # (the committed passes are of the IPv4 stream)
             if tr is not None:
                 ent["traffic"] = tr
             kernels[k] = ent
@@ -1003,8 +1023,8 @@ def main():
             "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic", "parity_ok": parity_ok,
-            "config": {"workload": "C3/C4: %d hosts x %d services, raw 24-B tcp_ipv4_resp_event_t stream, %s over services, "
-                                   "1 window (ingest + window close) per step" % (args.hosts, args.svcs,
+            "config": {"workload": "C3/C4: %d hosts x %d services, raw %s stream, %s over services, "
+                                   "1 window (ingest + window close) per step" % (args.hosts, args.svcs, "48-B tcp_ipv6_resp_event_t" if args.ipv6 else "24-B tcp_ipv4_resp_event_t",
                                                                                  "uniform" if not args.zipf_milli else "zipf %.2f" % (args.zipf_milli / 1000)),
                        "events_per_rank_per_step": args.events, "service_keys_total": args.hosts * args.svcs,
                        "service_keys_rank0": nsvc, "multi_level_windows": int(args.levels), "td_pend_cap": int(PEND),
@@ -1016,7 +1036,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": alg_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": alg_bytes,
-                         "note": "frac = 24 B x events / WHOLE step (all kernels of the window); per-kernel figures under `kernels`",
+                         "note": "frac = %d B x events / WHOLE step (all kernels of the window); per-kernel figures under `kernels`" % evb,
                          "kernel": dom[0], "kernel_avg_ms": dom[1], "kernel_frac": dom_ent.get("frac"),
                          # SURVEY 8(d)'s own figure for the dominant kernel: 24 B x events / its average launch time (kernel_frac counts the
                          # 4-byte staged word the event kernel also writes per event: 28 B)
@@ -1067,7 +1087,7 @@ def main():
             out["host_fed"]["l2_threads"] = host_fed_l2_threads()  # its own context: after this engine has released the device
         # the other BASELINE configurations (C2 connection records, C1 and C5 shapes) as short sub-runs, each in its own process: appended to
         # the default single-GPU line only (a sub-run never changes `value`; its failure is reported inside `configs`)
-        default_shape = (world == 1 and args.hosts == 10000 and args.svcs == 1000 and args.events == (1 << 29) and not args.zipf_milli and not args.levels)
+        default_shape = (world == 1 and args.hosts == 10000 and args.svcs == 1000 and args.events == (1 << 29) and not args.zipf_milli and not args.levels and not args.ipv6)
         if args.configs != "none" and (default_shape or args.configs != "auto"):
             bufs.clear()  # (this run's resident event batches: the sub-runs bring their own)
             torch.cuda.empty_cache()

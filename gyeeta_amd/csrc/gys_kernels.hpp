@@ -115,6 +115,22 @@ __device__ __forceinline__ void flow_hll_idx_rank(uint32_t daddr, uint16_t dport
 	hll_idx_rank(flow_hash64(daddr, dport, saddr, sport), GYS_HLL_P, idx, rank);
 }
 
+// the same for a flow key in the general word form (IPv6 ends: ten words, four mix rounds per hash half -- every IPv6 event pays them):
+// == hll_idx_rank(hash64<N>(w, nw), GYS_HLL_P)
+template <int N>
+__device__ __forceinline__ void words_hll_idx_rank(const uint32_t (&w)[N], uint32_t nw, uint32_t *idx, uint32_t *rank)
+{
+	const uint32_t hi = jhash2<N>(w, nw, GYS_SEED);
+	const uint32_t rest = hi << GYS_HLL_P;
+	*idx = hi >> (32 - GYS_HLL_P);
+	if (rest) {
+		*rank = (uint32_t)__clz((int)rest) + 1u;
+		return;
+	}
+	const uint32_t lo = jhash2<N>(w, nw, GYS_GOLDEN);
+	*rank = (32u - GYS_HLL_P) + (lo ? (uint32_t)__clz((int)lo) : 32u) + 1u;
+}
+
 // per-service distinct clients: same hash, per-service register file (u8 packed, CAS on the word)
 __device__ __forceinline__ void svc_hll_update(uint8_t *svc_hll, uint32_t svc_hll_p, uint32_t slot, uint64_t h64)
 {
@@ -1257,24 +1273,32 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 					if (!((rare >> u) & 1u)) continue;
 					// (the event this lane holds in place u of the group: see the load above)
 					const uint32_t o = (GYS_EV_X3 && !V6 && !PF) ? ((uint32_t)g + u) * T + (tid & ~63u) + (lane >> 1) + ((lane & 1u) ? 32u : 0u) : ((uint32_t)g + u) * T + tid;
-					uint64_t h64;
+					uint32_t idx, rank;
 					if (V6) {
 						const uint64_t a0 = tb[GYS_EV6_WORDS * o], a1 = tb[GYS_EV6_WORDS * o + 1u], d0 = tb[GYS_EV6_WORDS * o + 2u], d1 = tb[GYS_EV6_WORDS * o + 3u],
 							       x4 = tb[GYS_EV6_WORDS * o + 4u];
 						const uint32_t sa[4] = {(uint32_t)a0, (uint32_t)(a0 >> 32), (uint32_t)a1, (uint32_t)(a1 >> 32)};
 						const uint32_t da[4] = {(uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32)};
-						h64 = flow_hash64_v6(da, bswap16((uint16_t)(x4 >> 48)), sa, bswap16((uint16_t)(x4 >> 32)));
+						uint32_t w[10];
+						const uint32_t nw = pair_words(ip6_embedded_v4(da), da, bswap16((uint16_t)(x4 >> 48)), ip6_embedded_v4(sa), sa, bswap16((uint16_t)(x4 >> 32)), w);
+						if (SVCHLL && p.svc_hll_p) {
+							const uint64_t h64 = hash64<10>(w, nw); // (== flow_hash64_v6; the per-service registers need all 64 bits)
+							hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
+							const uint32_t l = u == 0u ? nlr[0] : u == 1u ? nlr[1] : u == 2u ? nlr[2] : nlr[3];
+							svc_hll_update(p.svc_hll, p.svc_hll_p, s_slot[l], h64);
+						} else {
+							words_hll_idx_rank<10>(w, nw, &idx, &rank); // the second hash half only when the first one's rank bits are all zero
+						}
 					} else {
 						const uint64_t x0 = tb[3u * o], x1 = tb[3u * o + 1u]; // (re-read: keeps the four events' words out of this loop's registers)
 						const uint32_t saddr = (uint32_t)x0, daddr = (uint32_t)(x0 >> 32);
 						const uint16_t sport = bswap16((uint16_t)(x1 >> 32)), dport = bswap16((uint16_t)(x1 >> 48));
-						h64 = flow_hash64(daddr, dport, saddr, sport);
-					}
-					uint32_t idx, rank;
-					hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
-					if (SVCHLL && p.svc_hll_p) {
-						const uint32_t l = u == 0u ? nlr[0] : u == 1u ? nlr[1] : u == 2u ? nlr[2] : nlr[3];
-						svc_hll_update(p.svc_hll, p.svc_hll_p, s_slot[l], h64);
+						const uint64_t h64 = flow_hash64(daddr, dport, saddr, sport);
+						hll_idx_rank(h64, GYS_HLL_P, &idx, &rank);
+						if (SVCHLL && p.svc_hll_p) {
+							const uint32_t l = u == 0u ? nlr[0] : u == 1u ? nlr[1] : u == 2u ? nlr[2] : nlr[3];
+							svc_hll_update(p.svc_hll, p.svc_hll_p, s_slot[l], h64);
+						}
 					}
 					if (rank > hll_floor && p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
 				}
