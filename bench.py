@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+T_START = time.perf_counter()
 EVENT_BYTES = 24          # algorithmic bytes per event (raw tcp_ipv4_resp_event_t)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -45,7 +46,128 @@ def _mem_available_bytes():
     return None
 
 
-def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1):
+LINE_LIMIT = 4096  # the driver keeps an 8-KB tail of stdout: the LAST line must fit whole, with room to spare
+
+
+def _r(x, nd=6):
+    """a float at nd significant digits (the detail file keeps full precision); everything else as it is; NaN / inf -> None (strict JSON)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (nd, x))
+    if isinstance(x, (np.floating,)):
+        return _r(float(x), nd)
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    return x
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out, detail_path=None):
+    """The ONE stdout line the driver parses: the contract's keys + roofline + cpu_baseline + quantile_error + one short entry per sub-run,
+    <= LINE_LIMIT bytes of strict JSON.  Everything else of `out` (per-kernel tables, counter-traffic blocks, host-fed legs, scans, notes)
+    goes to the detail file (--detail-out)."""
+    c = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                     "dtype", "data", "parity_ok")}
+    cfg = out.get("config", {})
+    c["config"] = _pick(cfg, ("workload", "events_per_rank_per_step", "service_keys_total", "multi_level_windows", "td_pend_cap", "td_pend_cap_is_library_default",
+                              "exchange", "records_per_step"))
+    rf = out.get("roofline", {})
+    r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_step", "kernel", "kernel_avg_ms", "kernel_frac", "kernel_frac_24B"))
+    tr = rf.get("traffic")
+    r["traffic"] = ({"bytes": tr.get("bytes"), "source": str(tr.get("source", ""))[:60], "same_kernels_as_this_run": tr.get("same_kernels_as_this_run")}
+                    if isinstance(tr, dict) else None)
+    c["roofline"] = r
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        if "error" in cb and "value" not in cb:
+            c["cpu_baseline"] = {"error": str(cb["error"])[:120]}
+        else:
+            c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "keys", "events", "events_per_key", "allcores_value", "allcores", "reference_hist_value",
+                                           "reference_hist_allcores_value", "gpu_events_per_key_per_window", "leg"))
+            c["cpu_baseline"]["sample"] = str(cb.get("sample_short") or cb.get("sample") or "")[:330]
+            fk = cb.get("matched_ratio")
+            if isinstance(fk, dict):
+                c["cpu_baseline"]["matched_ratio"] = _pick(fk, ("value", "keys", "events_per_key", "allcores_value", "reference_hist_value", "reference_hist_allcores_value"))
+    qe = out.get("quantile_error")
+    if isinstance(qe, dict):
+        c["quantile_error"] = _pick(qe, ("keys_checked", "tolerance", "p50_rank_err_max", "p99_rank_err_max"))
+    xc = out.get("exchange_check")
+    if isinstance(xc, dict):
+        c["exchange_check"] = _pick(xc, ("ok", "ranks_seen", "ranks_consistent", "exchange", "global_digest_consistent", "global_digest_ms"))
+    qs = out.get("quantile_scan")
+    if isinstance(qs, dict):
+        c["quantile_scan"] = _pick(qs, ("services", "kernel_ms", "global_rollup_ms"))
+    subs = out.get("configs")
+    if isinstance(subs, dict):
+        c["configs"] = {}
+        for name, e in subs.items():
+            if not isinstance(e, dict) or "value" not in e:
+                c["configs"][name] = {"error": str((e or {}).get("error", "no line"))[:80]}
+                continue
+            erf = e.get("roofline", {})
+            c["configs"][name] = {"value": _r(e.get("value")), "unit": e.get("unit"), "ms_per_step": _r(e.get("ms_per_step")), "frac": _r(erf.get("frac")),
+                                  "kernel": erf.get("kernel"), "kernel_frac": _r(erf.get("kernel_frac")), "parity_ok": e.get("parity_ok")}
+    for k in ("device_code", "build_commit", "wall_s"):
+        if out.get(k) is not None:
+            c[k] = _r(out[k])
+    if detail_path:
+        c["detail"] = detail_path
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:  # never happens with the fields above; if a later edit grows them, drop the optional parts rather than the contract's
+        for k in ("quantile_scan", "exchange_check", "configs", "build_commit"):
+            c.pop(k, None)
+            line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+            if len(line) <= LINE_LIMIT:
+                break
+    return line
+
+
+def _jsonable(x):
+    if isinstance(x, dict):
+        return {str(k): _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    if isinstance(x, (np.floating, float)):
+        x = float(x)
+        return None if (x != x or x in (float("inf"), float("-inf"))) else x
+    if isinstance(x, np.integer):
+        return int(x)
+    if isinstance(x, np.bool_):
+        return bool(x)
+    return x
+
+
+def emit(out, args):
+    """detail file first (full `out`, strict JSON), then the compact line as the LAST thing on stdout.  A sub-run (--sub) hands its full line to
+    the parent run instead (one line, parsed there, never seen by the driver)."""
+    out = _jsonable(out)
+    if getattr(args, "sub", ""):
+        print(json.dumps(out, allow_nan=False), flush=True)
+        return
+    path = getattr(args, "detail_out", "") or ""
+    wrote = None
+    if path and path != "none":
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(out, f, allow_nan=False)
+                f.write("\n")
+            wrote = os.path.relpath(os.path.abspath(path), os.getcwd())
+        except OSError as ex:
+            print(f"bench.py: detail file {path} not written: {ex}", file=sys.stderr)
+    if getattr(args, "detail_stdout", False):
+        print(json.dumps(out, allow_nan=False), flush=True)
+    sys.stderr.flush()
+    print(compact_line(out, wrote), flush=True)
+
+
+def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1, histonly=True, mt_reps=5):
     """The oracle's sequential restatement of the same hot loop ("port") and the reference's own GY_HISTOGRAM loop (oracle/_ref), timed on the
     host's cores on a bounded sample of the same stream shape (same generator, same bytes): `reps` runs each (the median is reported; every
     repetition ingests the same batch again, as a next window would), one core and all cores.  Returns a dict, or None when the host has
@@ -61,12 +183,13 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1)
         return None
     med = lambda xs: sorted(xs)[len(xs) // 2]
     orc = o.OracleEngine(nsvc, td_cap=td_cap)
-    orc2 = o.OracleEngine(nsvc, enable_td=False)
+    orc2 = o.OracleEngine(nsvc, enable_td=False) if histonly else None
     s = np.arange(svcs)
     for h in range(total_hosts_sample):
         g, ns, pt = wire.glob_id(np.full(svcs, h), s), wire.listener_netns(h, s), wire.listener_port(s)
         orc.register_bulk(h, g, ns, pt)
-        orc2.register_bulk(h, g, ns, pt)
+        if orc2 is not None:
+            orc2.register_bulk(h, g, ns, pt)
     ev = torch.empty(nevents * 24, dtype=torch.uint8, device="cuda")
     segs = eng.gen_resp_events(ev.data_ptr(), nevents, seed, 0, total_hosts_sample, svcs)
     eng.sync()
@@ -75,25 +198,28 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1)
     sh = [sg.host_slot for sg in segs]
     sf = [sg.first_event for sg in segs]
     ncores = os.cpu_count() or 1
-    out = {"keys": nsvc, "events": nevents, "runs": reps, "td_pend_cap": cap, "cores_all": ncores}
+    out = {"keys": nsvc, "events": nevents, "events_per_key": nevents / max(nsvc, 1), "runs": reps, "td_pend_cap": cap, "cores_all": ncores}
     if reps > 1:  # (a first pass pays for the page faults of the per-key state: not timed)
         orc.resp_batch(host, sh, sf)
-        orc2.resp_batch(host, sh, sf, histonly=True)
+        if orc2 is not None:
+            orc2.resp_batch(host, sh, sf, histonly=True)
     full, honly = [], []
     for _ in range(reps):
         t0 = time.perf_counter()
         orc.resp_batch(host, sh, sf)
         t1 = time.perf_counter()
-        orc2.resp_batch(host, sh, sf, histonly=True)
-        t2 = time.perf_counter()
         full.append(nevents / (t1 - t0))
-        honly.append(nevents / (t2 - t1))
-    out["port"], out["histonly"] = med(full), med(honly)
+        if orc2 is not None:
+            orc2.resp_batch(host, sh, sf, histonly=True)
+            honly.append(nevents / (time.perf_counter() - t1))
+    out["port"] = med(full)
+    if honly:
+        out["histonly"] = med(honly)
     del orc2
     try:  # the full port again on every host core (hosts cut into per-thread ranges; identical resulting state, tests/test_oracle_sketches.py)
         if ncores > 1:
             rates = []
-            for _ in range(5):
+            for _ in range(mt_reps):
                 t7 = time.perf_counter()
                 orc.resp_batch(host, sh, sf, nthreads=ncores)
                 rates.append(nevents / (time.perf_counter() - t7))
@@ -128,7 +254,7 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1)
             out["reference_hist"] = med(rates[1:] if reps > 1 else rates)
         if added and ncores > 1 and hasattr(R, "ref_keyed_resp_batch_mt"):  # the same loop on every host core, hosts cut into ranges
             rates = []
-            for _ in range(5):
+            for _ in range(mt_reps):
                 t5 = time.perf_counter()
                 R.ref_keyed_resp_batch_mt(k, buf.ctypes.data, nevents, o.ptr(sh_a, o.u32p), o.ptr(sf_a, o.u64p), len(sh_a), ncores)
                 rates.append(nevents / (time.perf_counter() - t5))
@@ -656,7 +782,7 @@ def run_conn(args, rank, world):
             out["cpu_baseline"] = conn_cpu_baseline(rec, args.conn_stream == "messages", est)
         except Exception as ex:  # never take the line down
             out["cpu_baseline"] = {"error": str(ex)[:300]}
-    print(json.dumps(out), flush=True)
+    emit(out, args)
     eng.close()
     if not parity_ok:
         print("bench.py: connection counters differ from the generator's connection table", file=sys.stderr)
@@ -697,6 +823,10 @@ def main():
     ap.add_argument("--configs", default="auto", help="sub-runs of the other BASELINE configurations appended to the default line under `configs`: "
                     "'auto' = all of them when this is the default single-GPU workload, 'none', or a comma-separated list of c2_conn,c1,c5_zipf")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail-out", default=os.path.join("gpurun_out", "bench_detail.json"), help="the full result (per-kernel tables, counter traffic, host-fed legs, "
+                    "scans, sub-run lines, notes) as one strict-JSON file; 'none' = not written.  stdout's LAST line is the compact line (<= 4 KB)")
+    ap.add_argument("--detail-stdout", action="store_true", help="also print the full result as an EARLIER stdout line")
+    ap.add_argument("--selftest-line", default="", help="no GPU: read a full result from this JSON file and print the compact line made from it (tests/test_bench_line.py)")
     ap.add_argument("--no-quantile-check", action="store_true", help="skip the (untimed) t-digest rank-error check after the run")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the (untimed) host-fed measurement: pinned H2D copy + ingest")
     ap.add_argument("--no-dephase", action="store_true", help="skip the untimed pass that spreads the keys' buffer fill levels")
@@ -710,6 +840,9 @@ def main():
     ap.add_argument("--cpu-events-full", type=int, default=1 << 25)
     args = ap.parse_args()
 
+    if args.selftest_line:
+        print(compact_line(_jsonable(json.load(open(args.selftest_line))), "gpurun_out/bench_detail.json"), flush=True)
+        return
     if args.sub:
         args.no_cpu_baseline = args.no_host_fed = True
         args.configs = "none"
@@ -1028,6 +1161,7 @@ def main():
                                                                                  "uniform" if not args.zipf_milli else "zipf %.2f" % (args.zipf_milli / 1000)),
                        "events_per_rank_per_step": args.events, "service_keys_total": args.hosts * args.svcs,
                        "service_keys_rank0": nsvc, "multi_level_windows": int(args.levels), "td_pend_cap": int(PEND),
+                       "td_pend_cap_is_library_default": bool(int(PEND) == capi.TD_PEND_CAP),
                        "sketches": "exact RESP_TIME_HASH histogram + CONN_BITMAP + HLL p=14 + CMS 4x65536 + t-digest %d clusters + %d-value buffer per key" % (capi.TD_NB, PEND),
                        "parallelism": "host-id-hash shard x%d, RCCL all-reduce of registers per window" % world, "exchange": exchange,
                        "exchange_requested": args.exchange if world > 1 else "none",
@@ -1058,28 +1192,40 @@ def main():
             # 10^6-key sample of the earlier rounds beside it
             legs = []
             big_hosts = min(args.cpu_hosts_full, args.hosts)
-            if big_hosts > args.cpu_hosts:
-                legs.append(("full_keys", cpu_baseline(eng, big_hosts, args.svcs, args.cpu_events_full, 0x1235, td_cap=args.td_pend_cap, reps=5)))
+            tcb = time.perf_counter()
+            if big_hosts > args.cpu_hosts:  # 3 timed repetitions after one untimed pass; no hist-only leg at this size (the reference's own loop is timed instead)
+                legs.append(("full_keys", cpu_baseline(eng, big_hosts, args.svcs, args.cpu_events_full, 0x1235, td_cap=args.td_pend_cap, reps=3, histonly=False, mt_reps=3)))
             legs.append(("sample", cpu_baseline(eng, min(args.cpu_hosts, args.hosts), args.svcs, args.cpu_events, 0x1234, td_cap=args.td_pend_cap, reps=1)))
             legs = [(k, v) for k, v in legs if v is not None]
             if legs:
                 name, m = legs[0]
+                gpu_epk = args.events / max(nsvc, 1)
                 out["cpu_baseline"] = {
-                    "value": m["port"], "unit": "events/s", "cores": 1, "kind": "port",
-                    "sample": ("%d events over %d service keys (%s), td_pend_cap %d; one core: median of %d run(s); all cores (%d threads): median of 5; gcc -O2; "
+                    "value": m["port"], "unit": "events/s", "cores": 1, "kind": "port", "keys": m["keys"], "events": m["events"],
+                    "events_per_key": m["events_per_key"], "gpu_events_per_key_per_window": gpu_epk, "leg": name,
+                    "sample_short": ("value = oracle port (hist+bitmap+HLL+CMS+t-digest), 1 core, %d events x %d keys (%s), td_pend_cap %d (bench setting; library default 896), median of %d; "
+                                     "reference_hist = Gyeeta's GY_HISTOGRAM loop (oracle/_ref)" % (m["events"], m["keys"], "the metric's key count; %.1f events/key per pass vs %.0f on the GPU" %
+                                                                                            (m["events_per_key"], gpu_epk) if name == "full_keys" else "a tenth of the GPU run's keys", m["td_pend_cap"], m["runs"])),
+                    "sample": ("%d events over %d service keys (%s), td_pend_cap %d; one core: median of %d run(s); all cores (%d threads): median of 3-5; gcc -O2; "
                                "value = the full port (hist + bitmap + HLL + CMS + t-digest), histonly = the reference's own per-event work, reference_hist = "
-                               "the reference's GY_HISTOGRAM loop compiled from its sources (oracle/_ref)")
-                              % (m["events"], m["keys"], "the metric's own key count" if name == "full_keys" else "a tenth of the GPU run's keys", m["td_pend_cap"], m["runs"], m["cores_all"]),
-                    "histonly_value": m["histonly"]}
+                               "the reference's GY_HISTOGRAM loop compiled from its sources (oracle/_ref).  `value` is the leg named by `leg`: full_keys = the GPU run's own "
+                               "10^7 keys at FEWER events per key and pass than a GPU window carries (events_per_key vs gpu_events_per_key_per_window: a colder, nearly merge-free "
+                               "shape -- the per-key state lives in DRAM either way); `matched_ratio` = the 10^6-key sample whose events per key match a GPU window's")
+                              % (m["events"], m["keys"], "the metric's own key count" if name == "full_keys" else "a tenth of the GPU run's keys", m["td_pend_cap"], m["runs"], m["cores_all"])}
                 cb = out["cpu_baseline"]
+                if "histonly" in m:
+                    cb["histonly_value"] = m["histonly"]
                 if "port_allcores" in m:  # the same full port on all host threads
                     cb["allcores_value"], cb["allcores"], cb["allcores_form"] = m["port_allcores"], m["cores_all"], m["port_allcores_form"]
                 if "reference_hist" in m:
                     cb["reference_hist_value"], cb["reference_hist_kind"] = m["reference_hist"], "reference"
                 if "reference_hist_allcores" in m:
                     cb["reference_hist_allcores_value"], cb["reference_hist_allcores"] = m["reference_hist_allcores"], m["cores_all"]
-                for k2, m2 in legs[1:]:  # the other sample, whole
-                    cb["sample_%d_keys" % m2["keys"]] = {kk: vv for kk, vv in m2.items() if kk != "port_allcores_form"}
+                for k2, m2 in legs[1:]:  # the other sample, whole (its events per key are those of a GPU window)
+                    cb["matched_ratio"] = {"value": m2["port"], "keys": m2["keys"], "events": m2["events"], "events_per_key": m2["events_per_key"],
+                                           "allcores_value": m2.get("port_allcores"), "reference_hist_value": m2.get("reference_hist"),
+                                           "reference_hist_allcores_value": m2.get("reference_hist_allcores"), "histonly_value": m2.get("histonly")}
+                cb["wall_s"] = time.perf_counter() - tcb
     eng.leave_rccl()
     eng.close()
     if rank == 0:
@@ -1092,7 +1238,8 @@ def main():
             bufs.clear()  # (this run's resident event batches: the sub-runs bring their own)
             torch.cuda.empty_cache()
             out["configs"] = run_sub_configs([] if args.configs in ("auto", "all") else args.configs.split(","))
-        print(json.dumps(out), flush=True)
+        out["wall_s"] = time.perf_counter() - T_START
+        emit(out, args)
     bad = rank == 0 and out.get("parity_ok") is False
     xbad = xcheck is not None and not xcheck["ok"]
     fell_back = world > 1 and args.exchange == "rccl" and exchange != "rccl_in_library"

@@ -33,6 +33,11 @@ def _engine(**kw):
     return SketchEngine(**kw)
 
 
+def capi_default_cap():
+    from gyeeta_amd import capi
+    return capi.TD_PEND_CAP
+
+
 def _register_bulk(eng, nhosts, svcs):
     s = np.arange(svcs)
     mids = []
@@ -45,16 +50,24 @@ def _register_bulk(eng, nhosts, svcs):
 
 
 # ---------------------------------------------------------------------------------------------------------------- C3
-def test_c3_full_size_properties(torch_mod, oracle):
+BENCH_TD_PEND_CAP = 1920  # bench.py's --td-pend-cap default: the headline configuration's gys_config (the library default is 896)
+TD_CAPS = pytest.mark.parametrize("td_cap", [0, BENCH_TD_PEND_CAP], ids=["cap896-library-default", "cap1920-bench-default"])
+
+
+@TD_CAPS
+def test_c3_full_size_properties(torch_mod, oracle, td_cap):
+    """td_cap 1920: the engine is created with exactly the gys_config bench.py's default run uses (10 000 hosts x 1 000 services, t-digest on,
+    td_pend_cap 1920) and the 50-host oracle slice runs with the same buffer size."""
     torch = torch_mod
     nh, sp, n = 10_000, 1_000, 1 << 26
     nsvc = nh * sp
-    eng = _engine(max_hosts=nh, max_services=nsvc, max_batch_events=n)
+    eng = _engine(max_hosts=nh, max_services=nsvc, max_batch_events=n, td_pend_cap=td_cap)
+    assert eng.L.gys_td_pend_cap(eng.h) == (td_cap or capi_default_cap())
     _register_bulk(eng, nh, sp)
     # bit-exact slice inside the full-size engine: the oracle is fed the whole segments of 50 hosts (the first and the last 25 host
     # slots = 50 000 of the 10^7 keys) of every batch the engine ingests, cut out of the very same bytes
     SLICE = list(range(25)) + list(range(nh - 25, nh))
-    orc = oracle.OracleEngine(len(SLICE) * sp)
+    orc = oracle.OracleEngine(len(SLICE) * sp, td_cap=td_cap)
     for j, h in enumerate(SLICE):
         s = np.arange(sp)
         g, ns, pt = wire.glob_id(np.full(sp, h), s), wire.listener_netns(h, s), wire.listener_port(s)
@@ -134,6 +147,8 @@ def test_c3_full_size_properties(torch_mod, oracle):
         vmax = max(vmax, int(h[:, 15, 1].max()))
         assert (h[:, :15, 0].sum(axis=1) == h[:, 15, 0]).all()  # per key: buckets add up to total_count_
         if first in (0, 7_000_000):  # digests of 2 x 10^6 keys: own totals / sums == the exact histogram of the same key
+            if td_cap:  # (a quarter of them with the larger buffers: the host copy of the buffered values is 4 B x 1 920 per key)
+                step, h = 250_000, h[:250_000]
             sums, cnts, mm = eng.export_tdigest(first, step)
             npend, pend = eng.export_tdigest_pending(first, step)
             assert (cnts.sum(axis=1) + npend == h[:, 15, 0]).all()
@@ -152,6 +167,7 @@ def test_c3_full_size_properties(torch_mod, oracle):
                     assert mm[k, 0] * int(cnts[k][nz[0]]) <= int(sums[k][nz[0]]) and int(sums[k][nz[-1]]) <= mm[k, 1] * int(cnts[k][nz[-1]])
             dig_total += int(cnts.sum()) + int(npend.sum())
             dig_sum += int(sums.sum()) + int(psum.sum())
+            step = 1_000_000
     assert total == 4 * n and vmax == max(max_a, max_b)
     assert (tot_cnt == 2 * gh_ab[:, 0]).all() and (tot_sum == 2 * gh_ab[:, 1]).all()
     assert dig_total > 0 and dig_sum > 0
@@ -169,12 +185,13 @@ def test_c3_full_size_properties(torch_mod, oracle):
     # ---- the slice again after its keys have re-clustered inside the 10^7-key engine: 24 batches aimed at the first 25 hosts
     # (~42 values per key and batch: every key crosses the 896-value buffer once, i.e. 25 000 merges of steady-state size), two windows
     nb = 1 << 21  # (~84 values per key and batch: every key passes its buffer size with a wide margin)
-    for r in range(24):
+    rounds = 24 if not td_cap else 24 * -(-td_cap // 896)  # (1 920-value buffers: 72 batches, every key re-clusters two or three times)
+    for r in range(rounds):
         sg = eng.gen_resp_events(bufs[0].data_ptr(), nb, 0xC300 + r, 0, 25, sp)
         eng.handle_resp_events_dev(sg, bufs[0].data_ptr(), nb)
         eng.sync()
         oracle_feed(bufs[0], sg, nb)
-        if r == 11:
+        if r % 12 == 11 and r + 1 < rounds:
             eng.window_close()
             orc.window_clear(clear_hist=False)
     assert eng.counters()["td_merges"] >= 25 * sp
@@ -185,16 +202,17 @@ def test_c3_full_size_properties(torch_mod, oracle):
 
 
 # ---------------------------------------------------------------------------------------------------------------- C1
+@TD_CAPS
 @pytest.mark.parametrize("resp_path", [0, 1, 2, 3], ids=["auto-split", "general", "hostlocal-tiled", "hostlocal-split"])
-def test_c1_single_host_replay_bit_exact(torch_mod, oracle, resp_path):
+def test_c1_single_host_replay_bit_exact(torch_mod, oracle, resp_path, td_cap):
     """ONE host, 100 services, a long replay (2^24 response events in one call, then 2^22 more): every key gets
     ~10^5 values per call (k_digest_huge with buffered values joining the merge), the single segment is far longer than any LDS image:
     the split form of the host-local pipeline (256 / 64 parts of 65536 events; what the time model picks), the general pipeline and the
     fused host-local pipeline with its tiled LDS image when forced.  Everything bit-exact vs the C oracle."""
     torch = torch_mod
     sp = 100
-    eng = _engine(max_hosts=1, max_services=sp, max_batch_events=1 << 24, resp_path=resp_path)
-    orc = oracle.OracleEngine(sp)
+    eng = _engine(max_hosts=1, max_services=sp, max_batch_events=1 << 24, resp_path=resp_path, td_pend_cap=td_cap)
+    orc = oracle.OracleEngine(sp, td_cap=td_cap)
     helpers.register_world(eng, orc, range(1), sp)
     for n, seed in ((1 << 24, 0xC1), (1 << 22, 0xC2), (5000, 0xC3)):
         ev = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
@@ -224,14 +242,15 @@ def test_c1_single_host_replay_bit_exact(torch_mod, oracle, resp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------- C5
-def test_c5_zipf_heavy_hitters_bit_exact(torch_mod, oracle):
+@TD_CAPS
+def test_c5_zipf_heavy_hitters_bit_exact(torch_mod, oracle, td_cap):
     """10^5 services (50 hosts x 2000 listeners: close to the largest LDS sub-tables), Zipf(1.1) over a host's services: the head keys get
     10^5+ values per batch (k_digest_huge), the tail a handful (buffer appends).  Bit-exact vs the C oracle; CMS top-50 == exact top-50."""
     torch = torch_mod
     nh, sp, n = 50, 2000, 1 << 22
     nsvc = nh * sp
-    eng = _engine(max_hosts=nh, max_services=nsvc, max_batch_events=n, resp_path=2)  # 50 long segments: prefer host-local explicitly
-    orc = oracle.OracleEngine(nsvc)
+    eng = _engine(max_hosts=nh, max_services=nsvc, max_batch_events=n, resp_path=2, td_pend_cap=td_cap)  # 50 long segments: prefer host-local explicitly
+    orc = oracle.OracleEngine(nsvc, td_cap=td_cap)
     helpers.register_world(eng, orc, range(nh), sp)
     ev = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
     for rnd in range(3):
@@ -336,4 +355,84 @@ def test_c2_conn_and_listener_state_full_size(torch_mod, oracle):
     for k, v in tot_qps.items():
         cs = eng.clusterstate(k)
         assert cs.total_qps == v and cs.nsvc == sp * sum(1 for h in range(0, nh, 10) if "cluster%d" % (h % 4) == k)
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- C3, IPv6 stream
+def test_c3_full_size_ipv6_slice_bench_config(torch_mod, oracle):
+    """bench.py --ipv6 at its own size and gys_config (10 000 hosts x 1 000 services, td_pend_cap 1 920): the C3 traffic as 48-byte
+    tcp_ipv6_resp_event_t events (2001:db8:: servers, fd00:: clients; bench.py's conversion of the generated IPv4 batch) through
+    gys_ingest_resp_events_v6_dev.  A 50-host oracle slice (handle_ipv6_resp_event, common/gy_socket_stat.cc:1535-1551) is fed the same bytes:
+    records, both CONN_BITMAP families, digests and buffered values bit for bit; counters and totals over all 10^7 keys."""
+    torch = torch_mod
+    nh, sp, n = 10_000, 1_000, 1 << 26
+    nsvc = nh * sp
+    eng = _engine(max_hosts=nh, max_services=nsvc, max_batch_events=n, td_pend_cap=BENCH_TD_PEND_CAP)
+    _register_bulk(eng, nh, sp)
+    SLICE = list(range(25)) + list(range(nh - 25, nh))
+    orc = oracle.OracleEngine(len(SLICE) * sp, td_cap=BENCH_TD_PEND_CAP)
+    for j, h in enumerate(SLICE):
+        s = np.arange(sp)
+        g, ns, pt = wire.glob_id(np.full(sp, h), s), wire.listener_netns(h, s), wire.listener_port(s)
+        for i in range(sp):
+            orc.register(j, int(g[i]), int(ns[i]), int(pt[i]))
+    ev4 = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
+
+    def as_v6(nev):
+        e4 = ev4[:nev * 24].view(torch.int32).view(-1, 6)
+        e6 = torch.zeros((nev, 12), dtype=torch.int32, device="cuda")
+        e6[:, 0] = 0xB80D0120 - (1 << 32)  # 20 01 0d b8
+        e6[:, 3] = e4[:, 0]
+        e6[:, 4] = 0x000000FD                # fd00::/8
+        e6[:, 7] = e4[:, 1]
+        e6[:, 8:12] = e4[:, 2:6]
+        return e6.view(torch.uint8).view(-1)
+
+    def feed(sg, nev, hosts_present):
+        d6 = as_v6(nev)
+        eng.handle_resp_events_v6_dev(sg, d6.data_ptr(), nev)
+        eng.sync()
+        for j, h in enumerate(SLICE):
+            idx = next((k for k, x in enumerate(sg) if x.host_slot == h), None)
+            if idx is None:
+                continue
+            lo = sg[idx].first_event
+            hi = sg[idx + 1].first_event if idx + 1 < len(sg) else nev
+            orc.resp_batch_v6(d6[lo * 48:hi * 48].cpu().numpy().tobytes(), [j], [0])
+        del d6
+
+    def slice_compare():
+        for part, first in ((0, 0), (1, nsvc - 25 * sp)):
+            k0, k1 = part * 25 * sp, (part + 1) * 25 * sp
+            helpers.assert_hist_equal(eng.export_hist(1, first, 25 * sp), orc.hist()[k0:k1], 25 * sp)
+            gb, ob = eng.export_conn_bitmap(first, 25 * sp), orc.bitmap()[k0:k1]
+            assert (gb == ob).all() and not gb[:, :32].any()  # IPv6 events land in resp_bitmap_v6_ only
+            gs, gc, gm = eng.export_tdigest(first, 25 * sp)
+            os_, oc, om = orc.td_arrays()
+            assert (gc == oc[k0:k1]).all() and (gs == os_[k0:k1]).all() and (gm == om[k0:k1]).all()
+            gn, gp = eng.export_tdigest_pending(first, 25 * sp)
+            on, op = orc.td_pending()
+            assert (gn == on[k0:k1]).all() and (gp == op[k0:k1]).all()
+
+    for b in range(2):
+        sg = eng.gen_resp_events(ev4.data_ptr(), n, 0xC6 + b, 0, nh, sp)
+        eng.sync()
+        feed(sg, n, nh)
+    slice_compare()
+    c = eng.counters()
+    assert c["resp_events"] == 2 * n and c["resp_dropped_range"] == 0 and c["resp_dropped_nolistener"] == 0 and c["resp_batches_general"] == 0
+    eng.window_close()
+    gh = eng.export_global_hist()
+    assert gh.total_count == 2 * n and sum(gh.stats[i].count for i in range(15)) == 2 * n
+    assert eng.export_cms(0).sum(axis=1).tolist() == [2 * n] * 4
+    assert abs(eng.distinct_flows() - 2 * n) / (2 * n) < 0.04
+    orc.window_clear(clear_hist=False)
+    # the slice's keys past their 1 920-value buffers (merges inside the 10^7-key engine), IPv6 events only
+    nb = 1 << 21
+    for r in range(30):
+        sg = eng.gen_resp_events(ev4.data_ptr(), nb, 0xC600 + r, 0, 25, sp)
+        eng.sync()
+        feed(sg, nb, 25)
+    assert eng.counters()["td_merges"] >= 25 * sp
+    slice_compare()
     eng.close()
