@@ -182,6 +182,8 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1,
         print(f"bench.py: CPU legs at {nsvc} keys skipped: they need ~{need >> 30} GiB of host memory, {avail >> 30} GiB available", file=sys.stderr)
         return None
     med = lambda xs: sorted(xs)[len(xs) // 2]
+    marks = [("start", time.perf_counter())]
+    mark = lambda name: marks.append((name, time.perf_counter()))
     orc = o.OracleEngine(nsvc, td_cap=td_cap)
     orc2 = o.OracleEngine(nsvc, enable_td=False) if histonly else None
     s = np.arange(svcs)
@@ -197,12 +199,14 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1,
     del ev
     sh = [sg.host_slot for sg in segs]
     sf = [sg.first_event for sg in segs]
+    mark("setup")
     ncores = os.cpu_count() or 1
     out = {"keys": nsvc, "events": nevents, "events_per_key": nevents / max(nsvc, 1), "runs": reps, "td_pend_cap": cap, "cores_all": ncores}
     if reps > 1:  # (a first pass pays for the page faults of the per-key state: not timed)
         orc.resp_batch(host, sh, sf)
         if orc2 is not None:
             orc2.resp_batch(host, sh, sf, histonly=True)
+    mark("first_pass")
     full, honly = [], []
     for _ in range(reps):
         t0 = time.perf_counter()
@@ -216,6 +220,7 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1,
     if honly:
         out["histonly"] = med(honly)
     del orc2
+    mark("port")
     try:  # the full port again on every host core (hosts cut into per-thread ranges; identical resulting state, tests/test_oracle_sketches.py)
         if ncores > 1:
             rates = []
@@ -229,6 +234,7 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1,
     except Exception as ex:  # never let the optional leg take the JSON line down
         print(f"bench.py: all-cores port baseline skipped: {ex}", file=sys.stderr)
     del orc
+    mark("port_allcores")
     # the reference's OWN classes on the same bytes (oracle/_ref: GY_HISTOGRAM<int64_t, RESP_TIME_HASH>::add_data behind an
     # unordered_map with GY_JHASHER standing in for the RCU listener table): kind "reference"
     R = o.ref()
@@ -260,6 +266,8 @@ def cpu_baseline(eng, total_hosts_sample, svcs, nevents, seed, td_cap=0, reps=1,
                 rates.append(nevents / (time.perf_counter() - t5))
             out["reference_hist_allcores"] = med(rates)
         R.ref_keyed_free(k)
+    mark("reference")
+    out["phase_s"] = {marks[i][0]: round(marks[i][1] - marks[i - 1][1], 2) for i in range(1, len(marks))}
     return out
 
 
@@ -270,12 +278,13 @@ def ctypes_u16p():
 
 def quantile_error(eng, torch, ingested, nlocal, svcs, host_ids, host_slots, wire):
     """Second half of BASELINE.json's metric: p50 / p99 of the engine's t-digests against the EXACT quantiles of everything the run fed
-    them.  Untimed, after the run: every distinct batch is regenerated (the generator is deterministic), the segments of two hosts
-    (first and last slot: 2 x svcs service keys) are pulled to the CPU and each key's full value multiset is rebuilt with the number
-    of times its batch was ingested; rank error = distance of the engine's quantile from the [left, right] rank interval of that
-    value in the sorted data (the north-star tolerance is 0.01)."""
+    them.  Untimed, after the run: every distinct batch is regenerated (the generator is deterministic); the segments of two hosts
+    (first and last slot: 2 x svcs service keys) are decoded and sorted by (service, response time) with torch on the device (test
+    plumbing: a 2^26-event segment sorts in milliseconds there, in ~10 s with numpy) and pulled to the CPU; a key's value multiset is
+    the union of its sorted per-batch slices, each with the number of times that batch was ingested; rank error = distance of the
+    engine's quantile from the [left, right] rank interval of that value in the sorted data (the north-star tolerance is 0.01)."""
     tmp = torch.empty(max(n for n, _, _, _ in ingested) * EVENT_BYTES, dtype=torch.uint8, device="cuda")
-    per_key = [[dict() for _ in range(svcs)] for _ in host_slots]
+    per_key = [[[] for _ in range(svcs)] for _ in host_slots]
     for n, seed, code, times in ingested:
         if times == 0:
             continue
@@ -284,17 +293,20 @@ def quantile_error(eng, torch, ingested, nlocal, svcs, host_ids, host_slots, wir
         for hi, slot in enumerate(host_slots):
             lo = sg[slot].first_event
             hi_e = sg[slot + 1].first_event if slot + 1 < nlocal else n
-            a = np.frombuffer(tmp[lo * EVENT_BYTES:hi_e * EVENT_BYTES].cpu().numpy().tobytes(), dtype=wire.RESP_EVENT)
-            lat = (a["lsndtime"] - a["lrcvtime"]).astype(np.int64)
-            svc = a["sport_be"].astype(np.int64) - 1024  # wire.listener_port(s) = 1024 + s for s < 60000 (network-order field name)
-            ok = (lat >= 0) & (lat <= 1000000) & (svc >= 0) & (svc < svcs)
-            lat, svc = lat[ok], svc[ok]
-            order = np.argsort(svc, kind="stable")
-            lat, svc = lat[order], svc[order]
-            cuts = np.searchsorted(svc, np.arange(svcs + 1))
+            if hi_e <= lo:
+                continue
+            w = tmp[lo * EVENT_BYTES:hi_e * EVENT_BYTES].view(torch.int32).view(-1, 6).to(torch.int64)
+            lat = (w[:, 4] - w[:, 5]) & 0xFFFFFFFF                       # lsndtime - lrcvtime, 32-bit wrap (common/gy_socket_stat.cc:1519)
+            pw = w[:, 3] & 0xFFFF                                         # sport, network byte order
+            svc = (((pw & 0xFF) << 8) | (pw >> 8)) - 1024                 # wire.listener_port(s) = 1024 + s for s < 60000
+            ok = (lat <= 1000000) & (svc >= 0) & (svc < svcs)
+            key = torch.sort(svc[ok] * (1 << 21) + lat[ok]).values.cpu().numpy()
+            del w, lat, pw, svc, ok
+            cuts = np.searchsorted(key, np.arange(svcs + 1, dtype=np.int64) << 21)
+            lat_s = (key & ((1 << 21) - 1)).astype(np.int32)
             for s_idx in range(svcs):
                 if cuts[s_idx + 1] > cuts[s_idx]:
-                    per_key[hi][s_idx][len(per_key[hi][s_idx])] = (lat[cuts[s_idx]:cuts[s_idx + 1]], times)
+                    per_key[hi][s_idx].append((lat_s[cuts[s_idx]:cuts[s_idx + 1]], times))  # sorted by value
     res = {"p50": [], "p99": []}
     for hi, h in enumerate(host_ids):
         gids = wire.glob_id(np.full(svcs, h), np.arange(svcs))
@@ -302,12 +314,11 @@ def quantile_error(eng, torch, ingested, nlocal, svcs, host_ids, host_slots, wir
             parts = per_key[hi][s_idx]
             if not parts:
                 continue
-            vals = np.concatenate([np.repeat(v, t) for v, t in parts.values()])
-            x = np.sort(vals)
+            total = sum(len(v) * t for v, t in parts)
             got = eng.quantiles(int(gids[s_idx]), [0.5, 0.99])
             for q, g, name in ((0.5, got[0], "p50"), (0.99, got[1], "p99")):
-                lo = np.searchsorted(x, g, side="left") / len(x)
-                hi_r = np.searchsorted(x, g, side="right") / len(x)
+                lo = sum(int(np.searchsorted(v, g, side="left")) * t for v, t in parts) / total
+                hi_r = sum(int(np.searchsorted(v, g, side="right")) * t for v, t in parts) / total
                 res[name].append(0.0 if lo <= q <= hi_r else min(abs(lo - q), abs(hi_r - q)))
     return {"keys_checked": len(res["p50"]), "tolerance": 0.01,
             "p50_rank_err_max": float(np.max(res["p50"])), "p50_rank_err_mean": float(np.mean(res["p50"])),
@@ -1226,6 +1237,7 @@ def main():
                                            "allcores_value": m2.get("port_allcores"), "reference_hist_value": m2.get("reference_hist"),
                                            "reference_hist_allcores_value": m2.get("reference_hist_allcores"), "histonly_value": m2.get("histonly")}
                 cb["wall_s"] = time.perf_counter() - tcb
+                cb["phase_s"] = {k2: m2.get("phase_s") for k2, m2 in legs}
     eng.leave_rccl()
     eng.close()
     if rank == 0:
