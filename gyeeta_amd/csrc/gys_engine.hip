@@ -1482,7 +1482,7 @@ int level_roll(gys_ctx *c, uint64_t tusec)
 		hipLaunchKernelGGL(k_level_roll, dim3(grid_for((uint64_t)c->nsvc * 16, 256, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, p);
 		HIPCHK(hipGetLastError());
 	}
-	if (swap_last) {
+	if (swap_last && c->lvl_last_epoch != c->epoch) { // (once per window: a gys_window_prepare that is retried after a failure further down must not swap back)
 		std::swap(c->hist_win, c->lvl_last);
 		c->lvl_last_epoch = c->epoch;
 	}
@@ -1493,7 +1493,8 @@ int level_roll(gys_ctx *c, uint64_t tusec)
 // between gys_window_prepare and gys_window_finish when the close has already swapped it with the level-0 array (level_roll)
 inline const gys_hist_rec *window_records(gys_ctx *c)
 {
-	return c->prepared && c->cfg.enable_levels == 1 && c->cfg.enable_tdigest ? c->lvl_last : c->hist_win;
+	// (the swap itself is the test, not `prepared`: it is skipped without services, and it stays in force when the rest of the prepare step failed)
+	return c->cfg.enable_levels == 1 && c->cfg.enable_tdigest && c->lvl_last_epoch == c->epoch ? c->lvl_last : c->hist_win;
 }
 
 // where a level's records come from at time tq (s): mode 0 = cumulative - *sub (nullptr: nothing to subtract), 1 = empty, 2 = copy of *sub

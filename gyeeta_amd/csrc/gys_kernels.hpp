@@ -804,8 +804,31 @@ __global__ __launch_bounds__(256) void k_cms_reduce(const uint32_t *partial, uin
 #ifndef GYS_BUCKET_LUT
 #define GYS_BUCKET_LUT 1
 #endif
+// round 6: the instruction diet of the event phase, each step behind a switch of its own for A/B libraries (tools/ab_libs.sh)
+#ifndef GYS_SHIFT_SWITCH
+#define GYS_SHIFT_SWITCH 0 // (r6b: 5.40 ms with it, 5.32 - 5.33 without -- the scalar branches cost more than the 16 moves they save; left off) a group's results are stored at wd / lr[g .. g + 3] through a scalar branch on the (uniform) group number: 8 moves per group instead of the 24 of the shift by four
+#endif
+#ifndef GYS_PROBE_XOR
+#define GYS_PROBE_XOR 1 // listener probe: entry ^ (port << 16) < 0xFFFF and high word == netns; no tests for empty entries in the two-entry fast path (the table is insert-only: a key behind an empty entry cannot exist)
+#endif
+#ifndef GYS_BK_BYTES
+#define GYS_BK_BYTES 1 // RESP_TIME_HASH bucket table as 1024 bytes (one ds_read_u8 at min(t, 1023)) instead of 256 packed words + shift / mask
+#endif
+#ifndef GYS_DROP_BALLOT
+#define GYS_DROP_BALLOT 0 // (r6: the compiler turns every ballot -- also of a single compare -- into a 0 / 1 select + a second compare: 2 VALU per ballot against 1 for the per-lane add with carry; left off) the two drop counters are kept per WAVE from the compare masks (s_bcnt1 on the scalar unit), not per lane with VALU adds
+#endif
+#ifndef GYS_PARK_INDEX
+#define GYS_PARK_INDEX 1 // the rank atomic of a place that kept nothing goes to s_ts[Lc_park + lane]: one select for the index, no select between two addresses
+#endif
+#ifndef GYS_HASH_FLAT
+#define GYS_HASH_FLAT 1 // the first hash half of the four events in straight-line code (no branch per event around it); an event with a 0.0.0.0 end or with all 18 rank bits zero goes through the rolled general path
+#endif
+#ifndef GYS_PROBE_JOINT
+#define GYS_PROBE_JOINT 0 // (r6b: 5.40 ms with it, 5.32 without; left off) third and later probes of the group's four events in ONE loop (one LDS round trip per step for all four, not one per event and step)
+#endif
 __device__ __forceinline__ void resp_bucket_lut_init(uint32_t *s_bk, uint32_t tid, uint32_t nthreads)
 {
+	// (both table forms hold the same bytes: word i = buckets of 4 i .. 4 i + 3, little endian)
 	for (uint32_t i = tid; i < 256u; i += nthreads)
 		s_bk[i] = resp_bucket((int64_t)(4u * i)) | (resp_bucket((int64_t)(4u * i + 1u)) << 8) | (resp_bucket((int64_t)(4u * i + 2u)) << 16) |
 			  (resp_bucket((int64_t)(4u * i + 3u)) << 24);
@@ -813,7 +836,16 @@ __device__ __forceinline__ void resp_bucket_lut_init(uint32_t *s_bk, uint32_t ti
 __device__ __forceinline__ uint32_t resp_bucket_lut(const uint32_t *s_bk, uint32_t tresp)
 {
 	if (!GYS_BUCKET_LUT) return resp_bucket((int64_t)tresp);
+#if GYS_BK_BYTES
+	// (one ds_read_u8; the opaque statement keeps the compiler from turning it back into a word read + shift + mask)
+	uint32_t bix = tresp & 1023u;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("" : "+v"(bix));
+#endif
+	const uint32_t lo = ((const volatile uint8_t *)s_bk)[bix];
+#else
 	const uint32_t lo = (s_bk[(tresp >> 2) & 255u] >> ((tresp & 3u) * 8u)) & 0xFFu;
+#endif
 	const uint32_t hi = 12u + (tresp > 3000u) + (tresp > 15000u);
 	return tresp < 1024u ? lo : hi;
 }
@@ -898,7 +930,7 @@ __host__ __device__ __forceinline__ size_t resp_host_lds_bytes(uint32_t tbl_entr
 #define GYS_EV_NT 0 // (r5f: 5.30 -> 5.80 ms with non-temporal event loads: the three 8-byte words of an event come from one line, the second and third read want it cached)
 #endif
 #ifndef GYS_EV_SADDR
-#define GYS_EV_SADDR 0 // (r5m: scalar tile base + one 32-bit offset per event -- the compiler then loads 16 + 8 bytes per event with one address register instead of three 64-bit addresses, 144 fewer static VALU instructions -- 5.28 / 5.29 against 5.33 / 5.30 ms: inside the noise; left off)
+#define GYS_EV_SADDR 1 // (round 6: on, with the other steps of the diet; r5m measured it alone: (r5m: scalar tile base + one 32-bit offset per event -- the compiler then loads 16 + 8 bytes per event with one address register instead of three 64-bit addresses, 144 fewer static VALU instructions -- 5.28 / 5.29 against 5.33 / 5.30 ms: inside the noise; left off)
 #endif
 #ifndef GYS_EV_X3
 #define GYS_EV_X3 0 // (r5g: 5.27 -> 5.60 ms with two fully coalesced 12-byte loads per event + a DPP swap of halves between neighbouring lanes instead of the three strided 8-byte loads: the loads are not what the event phase waits for, the extra moves and registers cost more than the request efficiency gains)
@@ -918,6 +950,11 @@ __device__ __forceinline__ uint32_t gys_swap_pair(uint32_t v) // the neighbourin
 #define GYS_EV_LOAD(p) __builtin_nontemporal_load(p)
 #else
 #define GYS_EV_LOAD(p) (*(p))
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GYS_BALLOT(pred) ((unsigned long long)__builtin_amdgcn_ballot_w64(pred)) // (the compare mask itself: __ballot() goes through a 0 / 1 value and a second compare)
+#else
+#define GYS_BALLOT(pred) ((unsigned long long)__ballot(pred))
 #endif
 #define GYS_MEM_FENCE() asm volatile("" ::: "memory") // compiler-only: memory operations are not moved across it (keeps a batch of LDS reads in front of the stores / the next batch)
 
@@ -944,7 +981,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 	// of 17 cells puts the 16 slots of a bucket on 16 different bank pairs.  (Same 2 KB of LDS as the per-wave form: the waves share the cells.)
 	__shared__ unsigned long long s_gh[16 * GYS_GH_STRIDE];
 	__shared__ int32_t s_gmax;
-	__shared__ uint32_t s_bk[GYS_BUCKET_LUT ? 256 : 1];
+	__shared__ uint32_t s_bk[GYS_BUCKET_LUT ? 256 : 1]; // (read as 1024 bytes with GYS_BK_BYTES)
 	__shared__ uint32_t s_hq[SPILL ? 1 : GYS_HQ_CAP]; // the tile's HLL candidates: register index | rank << 16
 	__shared__ uint32_t s_hqn;
 	__shared__ FinWg s_fin;
@@ -1022,7 +1059,9 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 	uint32_t *const dstb = dst - GYS_DST_BIAS; // (only ever indexed with biased indices: see s_dst)
 
 	uint32_t ndrop_range = 0, ndrop_nol = 0, tile_no = 0, dbg_sink = 0;
-	int32_t tmax = INT32_MIN;
+	uint32_t wdrop_range = 0, wdrop_nol = 0; // GYS_DROP_BALLOT: the wave's counts (uniform)
+	const uint32_t tid24 = 24u * tid;
+	int32_t tmax = INT32_MIN, wmax = -1;
 	// PF: the twelve words of the NEXT group of four events per thread are requested while the current group is processed and wait in
 	// n0 / n1 / n2 (the group after a tile's last one is the next tile's first: its loads run under the scan / image / flush phases)
 	constexpr bool PF = TPT == 32 && !SPILL;
@@ -1046,6 +1085,14 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 		// double-buffered and were cleared two phases ago, the floor and the candidate queue were settled behind barriers of the
 		// previous tile; a wave that is done flushing starts on its next events while the others still flush)
 		uint32_t *const s_ts = s_ts2 + (tile_no & 1u) * Lc;
+#if GYS_PARK_INDEX
+#if defined(__HIP_DEVICE_COMPILE__)
+		typedef uint32_t park_ix_t; // (LDS addresses are 32 bits: wrap-around arithmetic on word indices, s_ts[park_ix] is s_park[lane])
+#else
+		typedef ptrdiff_t park_ix_t; // (the CPU emulation of tests/cpp/kemu: two host allocations)
+#endif
+		const park_ix_t park_ix = (park_ix_t)(&s_park[lane] - s_ts);
+#endif
 		if (!SPILL) hll_floor = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_floor[tile_no & 1u]);
 		// ---- resolve, filter, rank: 4 events per thread at a time, each step for all four before the next one (event loads, listener
 		// probes, hashes, HLL register reads, rank atomics), in straight-line predicated code: the LDS / HBM round trips of the four
@@ -1114,8 +1161,11 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 						w2[u] = (uint64_t)d4 | ((uint64_t)d5 << 32);
 					} else if (GYS_EV_SADDR) {
 						// the tile's base is uniform and an event's byte offset inside the tile fits 32 bits: written so, the three loads share ONE
-						// 32-bit offset register (scalar base + offset + immediate) instead of a 64-bit address each
-						const uint32_t ob = 24u * oo;
+						// 32-bit offset register (scalar base + offset + immediate) instead of a 64-bit address each.  Round 6: the offset is
+						// 24 tid (kept) + 24 T (g + u) (scalar) -- no 32-bit multiply (a quarter-rate instruction) per event
+						const uint32_t ob_raw = tid24 + (uint32_t)(g + u) * (24u * T);
+						in[u] = ob_raw < 24u * rem; // (== o < rem)
+						const uint32_t ob = in[u] ? ob_raw : 0u;
 						const char *const tbb = (const char *)tb;
 						w0[u] = *(const uint64_t *)(tbb + ob);
 						w1[u] = *(const uint64_t *)(tbb + ob + 8u);
@@ -1138,16 +1188,28 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			uint32_t tresp[4], local[4];
 			uint64_t ea[4], eb[4];
 			bool ok[4], more[4];
+			unsigned long long m_ok[4];
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				const uint32_t netns = (uint32_t)w1[u];
 				const uint32_t sport = (uint32_t)bswap16((uint16_t)(w1[u] >> 32)); // ntohs :1526-1527
 				tresp[u] = (uint32_t)w2[u] - (uint32_t)(w2[u] >> 32);               // lsndtime - lrcvtime (:1519)
 				const bool range_ok = tresp[u] <= 1000000u;                         // "Ignore responses > 1000 sec or negative" (:1521-1524)
+#if GYS_DROP_BALLOT
+				// (per wave, on the scalar unit: ballots of SINGLE compares are the compare masks themselves -- a ballot of a combined condition
+				// goes through a 0 / 1 value and a second compare; part 0's workgroup is the one whose count is used, see the end)
+				const unsigned long long m_in = GYS_BALLOT(in[u]), m_rng = GYS_BALLOT(range_ok);
+				wdrop_range += (uint32_t)__popcll(m_in & ~m_rng);
+#else
 				if (in[u] && !range_ok && hd.part == 0u) ndrop_range++;              // (counted once per event: by the workgroup of part 0)
+#endif
 				const uint32_t hk = host_tbl_hash(netns, sport);
 				// (a listener of another part of this host: that part's workgroup has the event)
-				ok[u] = in[u] && range_ok && host_tbl_part(hk, hd.pmask) == hd.part;
+				const bool mine = (hk & (hd.pmask << 21)) == (hd.part << 21); // == (host_tbl_part(hk, hd.pmask) == hd.part), one shift less
+#if GYS_DROP_BALLOT
+				m_ok[u] = m_in & m_rng & GYS_BALLOT(mine);
+#endif
+				ok[u] = in[u] && range_ok && mine;
 				const uint32_t h = host_tbl_slot(hk, mask);
 				ea[u] = s_tbl[h];
 				eb[u] = s_tbl[h + 1u];
@@ -1157,14 +1219,49 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 				// entry = netns : 32 | port : 16 | local index : 16 -- compared as two 32-bit words
 				const uint32_t netns = (uint32_t)w1[u], sport = (uint32_t)bswap16((uint16_t)(w1[u] >> 32));
 				const uint32_t alo = (uint32_t)ea[u], ahi = (uint32_t)(ea[u] >> 32), blo = (uint32_t)eb[u], bhi = (uint32_t)(eb[u] >> 32);
+#if GYS_PROBE_XOR
+				// low word of an entry = port << 16 | local: xor-ed with the event's port << 16 it IS the local index when the ports agree
+				// (< 0xFFFF: an empty entry -- all ones -- never matches, whatever the event's key).  The sub-tables are insert-only linear
+				// probing (host_tbl_put): a key found in the second entry implies a used first one, and a miss in both goes to the walk
+				// below, which stops at the first empty entry -- no tests for empty entries here
+				const uint32_t sp16 = sport << 16, xa = alo ^ sp16, xb = blo ^ sp16;
+				const bool hit_a = ahi == netns && xa < 0xFFFFu, hit_b = bhi == netns && xb < 0xFFFFu;
+				uint32_t l = hit_b ? xb : GYS_NOSLOT;
+				l = hit_a ? xa : l;
+				local[u] = l;
+				more[u] = ok[u] && !hit_a && !hit_b;
+#else
 				const bool hit_a = ahi == netns && (alo >> 16) == sport, hit_b = bhi == netns && (blo >> 16) == sport;
 				const bool end_a = (alo & ahi) == 0xFFFFFFFFu, end_b = (blo & bhi) == 0xFFFFFFFFu;
 				uint32_t l = (hit_b && !end_a) ? (blo & 0xFFFFu) : GYS_NOSLOT;
 				l = hit_a ? (alo & 0xFFFFu) : l;
 				local[u] = l;
 				more[u] = ok[u] && !hit_a && !hit_b && !end_a && !end_b;
+#endif
 			}
 			// third and later probes: 3 % of the events at a quarter-full table (one in eight at a half-full one)
+#if GYS_PROBE_JOINT
+			if (more[0] || more[1] || more[2] || more[3]) {
+				uint32_t hh[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+					hh[u] = (host_tbl_slot(host_tbl_hash((uint32_t)w1[u], (uint32_t)bswap16((uint16_t)(w1[u] >> 32))), mask) + 2u) & mask;
+				for (uint32_t probes = 2; probes <= mask; ++probes) {
+					uint64_t e[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) e[u] = s_tbl[hh[u]]; // (all four reads in flight together; a place that is done reads its last entry again)
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const uint64_t key48 = ((uint64_t)(uint32_t)w1[u] << 16) | (uint64_t)bswap16((uint16_t)(w1[u] >> 32));
+						const bool hit = (e[u] >> 16) == key48 && e[u] != GYS_HOST_TBL_EMPTY;
+						if (more[u] && hit) local[u] = (uint32_t)(e[u] & 0xFFFFu);
+						more[u] = more[u] && !hit && e[u] != GYS_HOST_TBL_EMPTY;
+						hh[u] = more[u] ? ((hh[u] + 1u) & mask) : hh[u];
+					}
+					if (!(more[0] || more[1] || more[2] || more[3])) break;
+				}
+			}
+#else
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				if (more[u]) {
@@ -1181,6 +1278,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 					}
 				}
 			}
+#endif
 			if (MODE != 0) {
 				// a key with candidates: the event's server address picks the listener (first match in registration order), or nobody
 #pragma unroll
@@ -1204,7 +1302,11 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				kept[u] = ok[u] && local[u] != GYS_NOSLOT;
+#if GYS_DROP_BALLOT
+				wdrop_nol += (uint32_t)__popcll(m_ok[u] & GYS_BALLOT(local[u] == GYS_NOSLOT)); // no such listener: the reference ignores the event too (:1671-1676 miss path)
+#else
 				if (ok[u] && local[u] == GYS_NOSLOT) ndrop_nol++; // no such listener: the reference ignores the event too (:1671-1676 miss path)
+#endif
 				nlr[u] = kept[u] ? local[u] : 0u;
 			}
 			if (SPILL) {
@@ -1231,8 +1333,15 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			if (SPILL && !(kept[0] || kept[1] || kept[2] || kept[3])) continue; // (second pass: most groups hold no event of a spilled key; wd / lr already read as dropped)
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
+#if GYS_PARK_INDEX
+				// (s_park lies in the same LDS segment: its cell is addressed as an index from s_ts -- one select between two indices, and
+				// the index of a kept place is the local index the staged entry carries anyway)
+				const park_ix_t ci = (kept[u] && !(DBG && (p.dbg & 16u))) ? (park_ix_t)nlr[u] : park_ix;
+				rk12[u] = atomicAdd(&s_ts[ci], 1u);
+#else
 				uint32_t *const cell = (kept[u] && !(DBG && (p.dbg & 16u))) ? &s_ts[nlr[u]] : &s_park[lane];
 				rk12[u] = atomicAdd(cell, 1u);
+#endif
 			}
 			if (!SPILL) {
 #pragma unroll
@@ -1240,7 +1349,9 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 					// all-service histogram of the window (GY_HISTOGRAM::add_data on the aggregate): one packed LDS add per event
 					// (a place that kept nothing adds into the spare cell, which nobody reads: the add itself stays unconditional)
 					if (!(DBG && (p.dbg & 8u))) atomicAdd(&s_gh[(GYS_GH_PER_WAVE ? wave : (lane & 15u)) * GYS_GH_STRIDE + bk[u]], (1ull << 40) | (unsigned long long)tresp[u]);
-					tmax = max(tmax, kept[u] ? (int32_t)tresp[u] : INT32_MIN);
+					// (largest response time through the staged word: value << GYS_ROW_BITS | row is monotone in the value and a place that kept
+					// nothing holds GYS_EV_DROPPED = -1 as a signed number -- one max per event, no select)
+					wmax = max(wmax, (int32_t)nwd[u]);
 				}
 				GYS_OPAQUE_LOADED4(w0);
 			}
@@ -1256,12 +1367,31 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 					// ends hash as 7 / 10 words; the per-service registers need all 64 bits) is rare or a non-default configuration and
 					// goes through ONE rolled copy of the general code below
 					if (DBG && (p.dbg & 4u)) {
+#if GYS_HASH_FLAT
+					} else if (!V6 && !SVCHLL) {
+						// flow_hll_idx_rank's common case without its branches: register index and the first 18 rank bits from the HIGH hash half,
+						// computed for every lane.  A 0.0.0.0 end (hashes as 7 / 10 words) or 18 zero rank bits (one event in 2^18: the low
+						// half decides) send the event through the rolled general code below, which recomputes both halves
+						const uint32_t hi = jhash2_4w(daddr, dport, saddr, sport, GYS_SEED);
+						const uint32_t rest = hi << GYS_HLL_P;
+#if defined(__HIP_DEVICE_COMPILE__)
+						const uint32_t rk = (uint32_t)__builtin_clz(rest) + 1u; // (rest == 0: not used)
+#else
+						const uint32_t rk = rest ? (uint32_t)__clz((int)rest) + 1u : 0u;
+#endif
+						const bool fast = daddr != 0 && saddr != 0 && rest != 0;
+						const bool up = kept[u] && fast && rk > hll_floor; // (a rank at or below the floor cannot raise any register)
+						hidx[u] = up ? (hi >> (32 - GYS_HLL_P)) : 0u;
+						hrank[u] = up ? rk : 0u;
+						rare |= (kept[u] && !fast) ? (1u << u) : 0u;
+#else
 					} else if (!V6 && !SVCHLL && daddr != 0 && saddr != 0) {
 						uint32_t ix, rk;
 						flow_hll_idx_rank(daddr, dport, saddr, sport, &ix, &rk);
 						const bool up = kept[u] && rk > hll_floor; // (a rank at or below the floor cannot raise any register)
 						hidx[u] = up ? ix : 0u;
 						hrank[u] = up ? rk : 0u;
+#endif
 					} else if (kept[u]) {
 						rare |= 1u << u;
 					}
@@ -1332,6 +1462,21 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			}
 #pragma unroll
 			for (int u = 0; u < 4; ++u) nlr[u] |= kept[u] ? (rk12[u] << 12) : 0u;
+#if GYS_SHIFT_SWITCH
+			// the group's results go to places g .. g + 3: g is uniform, so this is one scalar branch into a block of eight moves (the empty
+			// asm statement keeps the blocks from being turned into 8 x TPT / 4 selects)
+#pragma unroll
+			for (int c = 0; c < TPT; c += 4) {
+				if (g == c) {
+					asm volatile("" ::: "memory");
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						wd[c + u] = nwd[u];
+						lr[c + u] = nlr[u];
+					}
+				}
+			}
+#else
 #pragma unroll
 			for (int j = 0; j + 4 < TPT; ++j) {
 				wd[j] = wd[j + 4];
@@ -1342,6 +1487,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 				wd[TPT - 4 + u] = nwd[u];
 				lr[TPT - 4 + u] = nlr[u];
 			}
+#endif
 		}
 		__syncthreads();
 		// ---- the tile's queued HLL candidates: one per thread, the register read is in flight under the scan below
@@ -1473,8 +1619,15 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 	}
 	if (SPILL) return;
 	if (DBG && dbg_sink == 0xDEADBEEFu) p.counters[CTR_RESP_EVENTS] = 1; // (keeps the hashes of the timing-only variant alive)
+	if (wmax >= 0) tmax = wmax >> GYS_ROW_BITS;
 	tmax = wave_max_i32(tmax);
 	if (lane == 0 && tmax != INT32_MIN) atomicMax(&s_gmax, tmax);
+#if GYS_DROP_BALLOT
+	if (lane == 0) {
+		ndrop_range = hd.part == 0u ? wdrop_range : 0u; // (an event out of range is counted once: by the workgroup of part 0)
+		ndrop_nol = wdrop_nol;
+	}
+#endif
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
 	if (ndrop_nol) atomicAdd(&s_drop[1], ndrop_nol);
 	__syncthreads();

@@ -25,6 +25,7 @@ namespace gysre {
 #define GYS_RE_MAX_PATTERN 1024u
 #define GYS_RE_MAX_PROG 16384u
 #define GYS_RE_MAX_REPEAT 1000u
+#define GYS_RE_MAX_ATOMS 262144u // parse steps of one compile, re-parsed copies of repeated operands included
 
 struct CharSet {
 	uint64_t w[4] = {0, 0, 0, 0};
@@ -62,6 +63,8 @@ public:
 		p_ = pat.data();
 		end_ = p_ + pat.size();
 		err_.clear();
+		rep_mult_ = 1;
+		atoms_parsed_ = 0;
 		if (pat.size() > GYS_RE_MAX_PATTERN) return fail(err, "pattern longer than 1024 bytes");
 		Flags f;
 		Frag fr;
@@ -71,7 +74,7 @@ public:
 		}
 		const uint32_t m = emit(Inst{OP_MATCH, 0, 0, 0});
 		patch(fr, m);
-		start_ = fr.start;
+		start_ = fr.empty ? m : fr.start; // (a pattern that matches only the empty string -- "", "a{0}" -- starts at the match instruction: an unreachable operand may sit at 0)
 		if (prog_.size() > GYS_RE_MAX_PROG) return fail(err, "pattern too large");
 		return true;
 	}
@@ -147,6 +150,8 @@ private:
 	uint32_t start_ = 0;
 	const char *p_ = nullptr, *end_ = nullptr;
 	std::string err_;
+	uint64_t rep_mult_ = 1;     // product of the counts of the counted repetitions being expanded around the parser's position
+	uint32_t atoms_parsed_ = 0; // parse_atom calls of this compile (re-parsed copies included)
 
 	static bool fail(std::string *err, const char *msg)
 	{
@@ -319,6 +324,8 @@ private:
 			// quantifiers (several in a row are rejected like RE2's "bad repetition operator")
 			if (p_ < end_ && (*p_ == '*' || *p_ == '+' || *p_ == '?' || *p_ == '{')) {
 				uint32_t lo = 0, hi = 0; // hi = ~0: unbounded
+				const uint64_t mult_outer = rep_mult_;
+				bool counted = false; // an explicit {n}, {n,}, {n,m}
 				if (*p_ == '*') { lo = 0; hi = ~0u; ++p_; }
 				else if (*p_ == '+') { lo = 1; hi = ~0u; ++p_; }
 				else if (*p_ == '?') { lo = 0; hi = 1; ++p_; }
@@ -326,21 +333,20 @@ private:
 					const char *q = p_ + 1;
 					uint32_t v = 0, w = 0;
 					bool have = false, comma = false, have2 = false;
-					while (q < end_ && *q >= '0' && *q <= '9' && v <= GYS_RE_MAX_REPEAT) { v = v * 10 + (uint32_t)(*q - '0'); ++q; have = true; }
+					// (all digits are consumed, the value saturates just above the limit: {10010} is a bad count, not a literal brace)
+					while (q < end_ && *q >= '0' && *q <= '9') { v = v > GYS_RE_MAX_REPEAT ? v : v * 10 + (uint32_t)(*q - '0'); ++q; have = true; }
 					if (q < end_ && *q == ',') {
 						comma = true;
 						++q;
-						while (q < end_ && *q >= '0' && *q <= '9' && w <= GYS_RE_MAX_REPEAT) { w = w * 10 + (uint32_t)(*q - '0'); ++q; have2 = true; }
+						while (q < end_ && *q >= '0' && *q <= '9') { w = w > GYS_RE_MAX_REPEAT ? w : w * 10 + (uint32_t)(*q - '0'); ++q; have2 = true; }
 					}
 					if (!have || q >= end_ || *q != '}') {
-						// not a repetition: a literal '{' (RE2 does the same)
-						CharSet cs;
-						cs.add('{');
+						// not a repetition: the '{' is a literal (RE2 does the same) -- left in place, so that it is parsed as the next atom and
+						// a quantifier behind it applies to it (a{* = a, then zero or more braces)
 						acc = cat(std::move(acc), std::move(atom));
-						acc = cat(std::move(acc), frag_set(cs, f));
-						++p_;
 						continue;
 					}
+					counted = true;
 					lo = v;
 					hi = comma ? (have2 ? w : ~0u) : v;
 					if (lo > GYS_RE_MAX_REPEAT || (hi != ~0u && (hi > GYS_RE_MAX_REPEAT || hi < lo))) return bad("bad repetition count");
@@ -354,6 +360,18 @@ private:
 				}
 				// expand: lo copies, then (hi - lo) optional copies or a star.  Copies are made by re-parsing the operand's source.
 				const char *resume = p_;
+				if (atom.empty && atom.out.empty()) { // a repetition of nothing (an empty group) is nothing: no copies
+					acc = cat(std::move(acc), std::move(atom));
+					if (prog_.size() > GYS_RE_MAX_PROG) return bad("pattern too large");
+					continue;
+				}
+				// RE2 rejects nested counted repetitions whose product exceeds 1000 (kRegexpRepeatSize, RepetitionWalker): the copies of this
+				// operand are parsed under the product of the enclosing counts
+				if (counted) {
+					const uint64_t cnt = std::max<uint32_t>(1u, hi != ~0u ? hi : lo);
+					if (rep_mult_ * cnt > GYS_RE_MAX_REPEAT) return bad("bad repetition count");
+					rep_mult_ *= cnt;
+				}
 				auto reparse = [&](Frag *fr) -> bool {
 					p_ = a0;
 					Flags ff = f_atom;
@@ -396,6 +414,7 @@ private:
 				} else if (ok && !first_used) {
 					// x{0}: the operand's instructions stay unreachable
 				}
+				rep_mult_ = mult_outer;
 				if (!ok) return false;
 				p_ = resume;
 				acc = cat(std::move(acc), std::move(rep));
@@ -573,6 +592,9 @@ private:
 	}
 	bool parse_atom(Flags &f, int depth, Frag *out, bool *flag_only)
 	{
+		// every copy of a counted repetition re-parses its operand: the work is bounded here, whatever the operands emit (an empty group
+		// emits nothing, so the program-size limit alone does not stop ((((){1000}){1000}){1000}){1000})
+		if (++atoms_parsed_ > GYS_RE_MAX_ATOMS) return bad("pattern too large");
 		*flag_only = false;
 		const char c = *p_++;
 		switch (c) {

@@ -17,11 +17,11 @@ bench)
 	out=$2; shift 2; mkdir -p $out; cd $R
 	for lib in gyeeta_amd/lib/libgysketch.so $(ls gyeeta_amd/lib/libgysketch_*.so 2>/dev/null); do
 		tag=$(basename $lib .so)
-		GYS_LIB=$R/$lib timeout 120 python bench.py --no-cpu-baseline --no-host-fed --no-quantile-check "$@" > $out/$tag.json 2> $out/$tag.err
+		GYS_LIB=$R/$lib timeout 120 python bench.py --no-cpu-baseline --no-host-fed --no-quantile-check --detail-out $out/$tag.json "$@" > $out/$tag.line 2> $out/$tag.err
 		python - $out/$tag.json $tag <<'PY'
 import json, sys
 try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    d = json.load(open(sys.argv[1]))  # (the full result: bench.py's stdout line is the compact one)
     print("%-28s %.2f G ev/s %.3f ms" % (sys.argv[2], d["value"] / 1e9, d["ms_per_step"]), {k: round(v["ms"], 3) for k, v in d["roofline"]["kernels"].items() if v["ms"] > 0.05})
 except Exception as e:
     print(sys.argv[2], "no result:", e)
