@@ -178,6 +178,7 @@ SIGNATURES = {
     "gys_scan_percentiles_dev": (C.c_int, [vp, C.c_int, f32p, C.c_uint32, vp]),
     "gys_scan_quantiles_dev": (C.c_int, [vp, f64p, C.c_uint32, vp]),
     "gys_scan_listener_state_dev": (C.c_int, [vp, C.c_uint64, C.c_float, C.c_uint32, vp, vp]),
+    "gys_decide_listener_state_dev": (C.c_int, [vp, vp, vp, vp, vp]),
     "gys_tdigest_rollup_dev": (C.c_int, [vp, C.c_int, vp]),
     "gys_tdigest_merge_slabs_dev": (C.c_int, [vp, vp, C.c_uint32, vp]),
     "gys_tdigest_slab_quantiles": (C.c_int, [vp, vp, f64p, C.c_uint32, f64p]),

@@ -416,6 +416,7 @@ struct gys_ctx {
 	// lazily folded records (t-digest on): hist_win and lvl_last change places at every close instead of a copy; lvl_last[slot] then is the service's
 	// record of window lvl_last_tag[slot] (written by the close's fold pass) and counts only when that is lvl_last_epoch, the window closed last
 	uint32_t *lvl_last_tag = nullptr;
+	uint8_t *svc_bithist = nullptr; // [max_services][2] TCP_LISTENER::issue_bit_hist_ / high_resp_bit_hist_ (gys_decide_listener_state_dev; allocated on first use)
 	uint32_t lvl_last_epoch = 0;
 	int64_t *lvl_first = nullptr;     // [max_services] time (s) of the service's first window close (firstTime_ of its series), 0: none yet
 	gys_hist_rec *qps_hist = nullptr, *act_hist = nullptr; // per-service QPS_HISTOGRAM / ACTIVE_CONN_HISTOGRAM
@@ -2625,7 +2626,7 @@ void gys_destroy(gys_ctx *c)
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_claim, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->ring_act32, c->ring_act64, c->act_live, c->q_cand_key, c->q_out_keys, c->q_cand_slot, c->q_misc, c->q_host_mask, c->q_slot_list, c->q_set, c->q_out_rows, c->q_acc, c->q_cnt, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
-			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_last_tag, c->lvl_first, c->qps_hist, c->act_hist, c->cand_pool, c->own_arena ? c->arena : nullptr};
+			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_last_tag, c->svc_bithist, c->lvl_first, c->qps_hist, c->act_hist, c->cand_pool, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -4384,6 +4385,18 @@ try {
 	static_assert(CTR_NUM <= 31, "counter block (the last word is the sink of k_read_events)");
 	HIPCHK(hipMemcpyAsync(v, c->counters, sizeof(v), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+#ifdef GYS_RESP_TIMING
+	{
+		unsigned long long t[16];
+		HIPCHK(hipMemcpyFromSymbol(t, HIP_SYMBOL(gys::g_resp_timing), sizeof(t)));
+		unsigned long long tot = 0;
+		for (int i = 0; i < 12; ++i) tot += t[i];
+		static const char *nm[12] = {"loads", "probe2", "probe3+", "kept/atomics", "ghist+hash", "hllq/store", "barrier1", "scan1+b", "scan2+b", "image+b", "prologue", "flush"};
+		fprintf(stderr, "GYS_RESP_TIMING waves %llu ticks %llu:", t[15], tot);
+		for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.1f%%", nm[i], tot ? 100.0 * (double)t[i] / (double)tot : 0.0);
+		fprintf(stderr, "\n");
+	}
+#endif
 #ifdef GYS_HUGE_TIMING
 	fprintf(stderr, "GYS_HUGE_TIMING ticks: load %llu words+tail %llu scan %llu assign %llu writeback %llu | entries %llu npend %llu nc %llu\n", (unsigned long long)v[20], (unsigned long long)v[21], (unsigned long long)v[22], (unsigned long long)v[23], (unsigned long long)v[24], (unsigned long long)v[25], (unsigned long long)v[26], (unsigned long long)v[27]);
 #endif
@@ -4610,6 +4623,32 @@ try {
 	p.scan = d_scan;
 	ProfScope ps(c, "listener_scan");
 	hipLaunchKernelGGL(k_listener_scan, dim3((c->nsvc + 255) / 256), dim3(256), 0, c->stream, p);
+	HIPCHK(hipGetLastError());
+	return GYS_OK;
+} GYS_CATCH_ALL
+
+int gys_decide_listener_state_dev(gys_ctx *c, const gys_listener_scan *d_scan, const gys_listener_issue_in *d_issue_in, void *d_notify,
+				  gys_listener_decision *d_out)
+try {
+	GYS_ENTER(c);
+	if (!c || !d_scan) return GYS_ERR_INVAL;
+	if (!c->nsvc) return GYS_OK;
+	if (!c->svc_bithist) { // the listeners' two history bytes: engine state from the first decision on
+		HIPCHK(hipMalloc((void **)&c->svc_bithist, (size_t)c->cfg.max_services * 2));
+		HIPCHK(hipMemsetAsync(c->svc_bithist, 0, (size_t)c->cfg.max_services * 2, c->stream));
+	}
+	ListenerDecideP p{};
+	p.scan = d_scan;
+	p.in = d_issue_in;
+	p.hist = c->svc_bithist;
+	p.notify = (uint8_t *)d_notify;
+	p.out = d_out;
+	p.nsvc = c->nsvc;
+	p.msec1_bucket = 1; // get_bucketid_from_threshold<RESP_TIME_HASH>(1): the bucket whose ceiling is 1 ms
+	for (uint32_t b = 1; b < 14; ++b)
+		if (bucket_max_threshold(hash_def(GYS_RESP_TIME_HASH), b) == 1) p.msec1_bucket = b;
+	ProfScope ps(c, "listener_decide");
+	hipLaunchKernelGGL(k_listener_decide, dim3((c->nsvc + 255) / 256), dim3(256), 0, c->stream, p);
 	HIPCHK(hipGetLastError());
 	return GYS_OK;
 } GYS_CATCH_ALL

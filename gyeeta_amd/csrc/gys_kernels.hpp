@@ -820,6 +820,12 @@ __global__ __launch_bounds__(256) void k_cms_reduce(const uint32_t *partial, uin
 #ifndef GYS_PARK_INDEX
 #define GYS_PARK_INDEX 1 // the rank atomic of a place that kept nothing goes to s_ts[Lc_park + lane]: one select for the index, no select between two addresses
 #endif
+#ifndef GYS_EV_PREFETCH
+#define GYS_EV_PREFETCH 0 // one load instruction per wave and group touches the 48 lines of the wave's NEXT group of events (a dword each, result unused): the demand loads of the next group then come from the L2 instead of HBM
+#endif
+#ifndef GYS_FLOOR_QUARTER
+#define GYS_FLOOR_QUARTER 1 // HLL floor: each tile re-reads a QUARTER of the register file (one 16-byte load per thread, issued before the flush's stores) and the floor is the minimum of the last four partial minima -- registers only grow, so an older minimum is still a lower bound -- instead of four loads per thread behind the stores
+#endif
 #ifndef GYS_HASH_FLAT
 #define GYS_HASH_FLAT 1 // the first hash half of the four events in straight-line code (no branch per event around it); an event with a 0.0.0.0 end or with all 18 rank bits zero goes through the rolled general path
 #endif
@@ -874,6 +880,15 @@ struct HostDesc {
 #define GYS_RESP_WAVES_PER_SIMD(TPT) ((TPT) == 32 ? 2 : 4)
 #define GYS_SPLIT_PART 65536u // events per part when long segments are cut (SHARED)
 
+// EXPERIMENT builds only (-DGYS_RESP_TIMING): shader-clock ticks per phase of k_resp_host, summed over the waves of a launch (every wave adds
+// its own sums at its end; s_memtime waits for the wave's outstanding LDS / scalar-memory operations, so a phase also pays for the returns
+// of what it issued).  Read by gys_get_counters.
+#ifdef GYS_RESP_TIMING
+__device__ unsigned long long g_resp_timing[16];
+#define GYS_TICK(i) do { const unsigned long long t_now__ = (unsigned long long)clock64(); tacc[i] += (uint32_t)(t_now__ - t_prev__); t_prev__ = t_now__; } while (0)
+#else
+#define GYS_TICK(i) do { } while (0)
+#endif
 struct RespHostP {
 	const uint64_t *ev;
 	uint64_t n;
@@ -974,6 +989,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 	__shared__ uint32_t s_wsum[T / 64];
 	__shared__ uint32_t s_drop[2];
 	__shared__ uint32_t s_floor[2]; // HLL floor of the even / odd tiles (refreshed per tile)
+	__shared__ uint32_t s_fqm[4];   // GYS_FLOOR_QUARTER: minimum of each quarter of the register file as last read (quarter q by the tiles with tile_no & 3 == q)
 	// all-service histogram of the window, packed count << 40 | sum per cell.  Round 4: the cells are per (LANE SLOT, bucket), not per (wave,
 	// bucket): the 64 lanes of one add hit at most 15 buckets, i.e. a handful of addresses each taken by many lanes, and LDS atomics on one
 	// address execute one after the other -- measured (profiles/r4b_lds_conflicts_by_access_and_stagger.txt) 36 % of the kernel's bank-conflict
@@ -1051,6 +1067,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 		}
 		__syncthreads();
 		if (tid == 0) s_floor[1] = s_floor[0]; // (tiles 0 and 1 run on the floor taken here; tile t + 2 on the one refreshed behind tile t)
+		if (tid < 4) s_fqm[tid] = s_floor[0];  // (a lower bound for every quarter)
 	}
 	uint32_t hll_floor = 0;
 	const uint32_t K = (L + T - 1) / T;
@@ -1059,7 +1076,12 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 	uint32_t *const dstb = dst - GYS_DST_BIAS; // (only ever indexed with biased indices: see s_dst)
 
 	uint32_t ndrop_range = 0, ndrop_nol = 0, tile_no = 0, dbg_sink = 0;
+#ifdef GYS_RESP_TIMING
+	uint32_t tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long t_prev__ = (unsigned long long)clock64();
+#endif
 	uint32_t wdrop_range = 0, wdrop_nol = 0; // GYS_DROP_BALLOT: the wave's counts (uniform)
+	uint32_t pf_sink = 0;                    // GYS_EV_PREFETCH: destination of the line-touching loads
 	const uint32_t tid24 = 24u * tid;
 	int32_t tmax = INT32_MIN, wmax = -1;
 	// PF: the twelve words of the NEXT group of four events per thread are requested while the current group is processed and wait in
@@ -1080,6 +1102,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 		const uint64_t left0 = e1 - e0;
 		pf_issue(p.ev + 3u * e0, 0u, left0 < (uint64_t)TILE ? (uint32_t)left0 : TILE);
 	}
+	GYS_TICK(10); // prologue: tables, floor
 	for (uint64_t t0 = e0; t0 < e1; t0 += TILE, ++tile_no) {
 		// (no barrier here: the event phase of this tile touches nothing the flush of the previous one reads -- the per-key counters are
 		// double-buffered and were cleared two phases ago, the floor and the candidate queue were settled behind barriers of the
@@ -1184,6 +1207,33 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			GYS_OPAQUE_LOADED4(w0);
 			GYS_OPAQUE_LOADED4(w1);
 			GYS_OPAQUE_LOADED4(w2);
+			GYS_TICK(0); // group top: addresses, the event loads issued and arrived
+#if GYS_EV_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+			if (!PF && !V6 && !SPILL) {
+				// the wave's events of place u of a group are 64 consecutive 24-byte records = twelve 128-byte lines: lanes 0..47 touch one line
+				// each of the NEXT group (this tile's, or the first of the next tile).  Issued once this group's own loads HAVE ARRIVED (r6d: issued
+				// before that wait it was waited for as well -- the compiler's vmcnt(0) cannot tell it apart -- and cost 9 %): it runs under this group's
+				// work and is older than every load that is waited for later; nothing reads pf_sink
+				const uint32_t g2 = (uint32_t)g + 4u;
+				const uint64_t *nb = nullptr;
+				uint32_t nlim = 0, nfirst = 0;
+				if (g2 < (uint32_t)TPT && g2 * T < rem) {
+					nb = tb; nlim = rem; nfirst = g2 * T;
+				} else if (t0 + TILE < e1) {
+					const uint64_t left2 = e1 - t0 - TILE;
+					nb = tb + 3u * TILE; nlim = left2 < (uint64_t)TILE ? (uint32_t)left2 : TILE; nfirst = 0;
+				}
+				if (nb != nullptr && lane < 48u) {
+					const uint32_t pu = lane / 12u, pl = lane - 12u * pu;
+					const uint32_t ev0 = nfirst + pu * T + (tid & ~63u);           // first event of the wave's 64 in place pu
+					const uint32_t byte = 24u * ev0 + 128u * pl;                   // (the tile's base is 8-byte aligned only: "line" = 128-byte piece of the wave's span)
+					if (byte + 4u <= 24u * nlim) {
+						const char *pa = (const char *)nb + byte;
+						asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(pa) : "memory");
+					}
+				}
+			}
+#endif
 			// struct ipv4_tuple_t {u32 saddr, daddr, netns; u16 sport, dport;} + u32 lsndtime, lrcvtime  (24 bytes)
 			uint32_t tresp[4], local[4];
 			uint64_t ea[4], eb[4];
@@ -1239,6 +1289,10 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 				more[u] = ok[u] && !hit_a && !hit_b && !end_a && !end_b;
 #endif
 			}
+#ifdef GYS_RESP_TIMING
+			asm volatile("" : "+v"(local[0]), "+v"(local[1]), "+v"(local[2]), "+v"(local[3]));
+#endif
+			GYS_TICK(1); // hash, probe of two entries, compare
 			// third and later probes: 3 % of the events at a quarter-full table (one in eight at a half-full one)
 #if GYS_PROBE_JOINT
 			if (more[0] || more[1] || more[2] || more[3]) {
@@ -1279,6 +1333,10 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 				}
 			}
 #endif
+#ifdef GYS_RESP_TIMING
+			asm volatile("" : "+v"(local[0]), "+v"(local[1]), "+v"(local[2]), "+v"(local[3]));
+#endif
+			GYS_TICK(2); // third and later probes
 			if (MODE != 0) {
 				// a key with candidates: the event's server address picks the listener (first match in registration order), or nobody
 #pragma unroll
@@ -1343,6 +1401,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 				rk12[u] = atomicAdd(cell, 1u);
 #endif
 			}
+			GYS_TICK(3); // kept / staged word / bucket table read / rank atomics issued (s_memtime waits for their returns)
 			if (!SPILL) {
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
@@ -1433,6 +1492,10 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 					if (rank > hll_floor && p.hll32[idx] < rank) atomicMax(&p.hll32[idx], rank);
 				}
 			}
+#ifdef GYS_RESP_TIMING
+			asm volatile("" : "+v"(hrank[0]), "+v"(hrank[1]), "+v"(hrank[2]), "+v"(hrank[3]));
+#endif
+			GYS_TICK(4); // histogram adds + flow hashes
 			// HLL register traffic is taken OUT of the event loop: an event whose rank exceeds the floor only queues {register, rank} in LDS;
 			// the queue is drained once per tile (below: one batch of register reads, the rare atomicMax behind them).  Measured (r3m): with the
 			// read-first register access inside this loop the waves of a tile waited on L2 / memory-side round trips in most groups -- 14 %
@@ -1489,7 +1552,12 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			}
 #endif
 		}
+#if GYS_EV_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+		asm volatile("" ::"v"(pf_sink)); // (the register stays reserved across the group loop)
+#endif
+		GYS_TICK(5); // HLL queue, results stored, loop control
 		__syncthreads();
+		GYS_TICK(6); // barrier behind the event phase
 		// ---- the tile's queued HLL candidates: one per thread, the register read is in flight under the scan below
 		uint32_t hq_e = 0, hq_cur = 0xFFu;
 		if (!SPILL) {
@@ -1506,9 +1574,15 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			const uint32_t inc = wave_incl_scan_u32(sum); // (DPP: the shuffle loop was six dependent ds_bpermute round trips per tile)
 			if (lane == 63) s_wsum[wave] = inc;
 			__syncthreads();
+			GYS_TICK(7); // HLL candidates read, key sums, wave scan, barrier
 			if (!SPILL && tid == 0) {
 				s_hqn = 0; // (every thread has read the queue length; the next event phase is two barriers away)
-				if (t0 + 2ull * TILE < e1) s_floor[tile_no & 1u] = 0xFFFFFFFFu; // (read by every thread at the top of this tile; refilled behind this tile's flush for tile t + 2)
+				if (t0 + 2ull * TILE < e1) {
+					s_floor[tile_no & 1u] = 0xFFFFFFFFu; // (read by every thread at the top of this tile; refilled behind this tile's flush for tile t + 2)
+#if GYS_FLOOR_QUARTER
+					s_fqm[tile_no & 3u] = 0xFFFFFFFFu;   // (last read behind the previous tile's flush; refilled behind this tile's)
+#endif
+				}
 			}
 			{
 				uint32_t *const s_tn = s_ts2 + ((tile_no + 1u) & 1u) * Lc; // the next tile's counters: last touched before the previous tile's image barrier
@@ -1558,6 +1632,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			}
 		}
 		__syncthreads();
+		GYS_TICK(8); // run starts, destinations, barrier
 		{
 			uint32_t ts[TPT];
 #pragma unroll
@@ -1572,6 +1647,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			}
 		}
 		__syncthreads();
+		GYS_TICK(9); // image, barrier
 		if (!SPILL && hq_cur < (hq_e >> 16)) atomicMax(&p.hll32[hq_e & 0xFFFFu], hq_e >> 16); // (the register read has had two phases to arrive)
 		{
 			uint32_t ntile = 0; // kept events of the tile (every thread computes it from the wave sums)
@@ -1581,6 +1657,15 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			// consecutive image entries -> consecutive lanes -> consecutive addresses inside a key's piece.  8 entries per thread and round:
 			// keys and values of all eight, then the eight destinations, then the stores (two LDS round trips per round, not three per entry)
 			constexpr int FU = 8;
+#if GYS_FLOOR_QUARTER
+			constexpr uint32_t NQ = (1u << GYS_HLL_P) / 16u / T; // 16-byte pieces of a quarter of the register file per thread (1 or 2)
+			uint4 fq[NQ];
+			const bool fq_on = !SPILL && t0 + 2ull * TILE < e1;
+			if (fq_on) {
+#pragma unroll
+				for (uint32_t j = 0; j < NQ; ++j) fq[j] = ((const uint4 *)p.hll32)[(tile_no & 3u) * ((1u << GYS_HLL_P) / 16u) + j * T + tid];
+			}
+#endif
 			for (uint32_t eb0 = 0; eb0 < ntile; eb0 += (uint32_t)FU * T) {
 				uint32_t kk[FU], vv[FU];
 				uint64_t dd[FU];
@@ -1603,8 +1688,26 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			}
 			// the next tile's HLL floor: the register file is re-read (L2 hits: every workgroup reads the same 64 KiB; behind the flush --
 			// held across it, the 16 registers of the four loads spill)
+#if GYS_FLOOR_QUARTER
+			if (fq_on) {
+				// quarter q of the register file was read by this tile; the slot (tile_no & 1) serves tile t + 2: min of this quarter's minimum
+				// and the running minima of the other quarters (s_fq[]: each at most four tiles old -- a lower bound all the same)
+				uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+				for (uint32_t j = 0; j < NQ; ++j) mn = min(min(mn, min(fq[j].x, fq[j].y)), min(fq[j].z, fq[j].w));
+				mn = wave_min_u32(mn);
+				if (lane == 0) {
+					const uint32_t qn = tile_no & 3u;
+					atomicMin(&s_fqm[qn], mn); // (reset behind this tile's scan barrier; read as "another quarter" by the next three tiles)
+					atomicMin(&s_floor[tile_no & 1u], min(min(mn, s_fqm[(qn + 1u) & 3u]), min(s_fqm[(qn + 2u) & 3u], s_fqm[(qn + 3u) & 3u])));
+				}
+			}
+			if (false) {
+				constexpr uint32_t NF = (1u << GYS_HLL_P) / 4u / T;
+#else
 			if (!SPILL && t0 + 2ull * TILE < e1) {
 				constexpr uint32_t NF = (1u << GYS_HLL_P) / 4u / T;
+#endif
 				uint4 fv[NF];
 #pragma unroll
 				for (uint32_t j = 0; j < NF; ++j) fv[j] = ((const uint4 *)p.hll32)[tid + j * T];
@@ -1615,8 +1718,16 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 				if (lane == 0) atomicMin(&s_floor[tile_no & 1u], mn);
 			}
 		}
+		GYS_TICK(11); // flush + floor refresh
 		// (the next tile's event-phase barrier orders this tile's flush before destinations and image are rewritten)
 	}
+#ifdef GYS_RESP_TIMING
+	if (!SPILL && lane == 0) {
+#pragma unroll
+		for (int i = 0; i < 12; ++i) atomicAdd(&g_resp_timing[i], (unsigned long long)tacc[i]);
+		atomicAdd(&g_resp_timing[15], 1ull);
+	}
+#endif
 	if (SPILL) return;
 	if (DBG && dbg_sink == 0xDEADBEEFu) p.counters[CTR_RESP_EVENTS] = 1; // (keeps the hashes of the timing-only variant alive)
 	if (wmax >= 0) tmax = wmax >> GYS_ROW_BITS;
@@ -4198,6 +4309,165 @@ __global__ __launch_bounds__(256) void k_listener_scan(ListenerScanP p)
 		q[7] = (uint32_t)o.p95_ms[0]; // p95_5s_resp_ms_
 		q[8] = (uint32_t)o.p95_ms[1]; // p95_5min_resp_ms_
 		p.notify[(size_t)slot * 88u + 79u] = o.curr_qps == 0 ? 0 /* STATE_IDLE */ : 2 /* STATE_OK */;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------- the listener's state decision
+// TCP_LISTENER::get_curr_state (common/gy_socket_stat.cc:2020-2870): one thread per listener walks the reference's decision tree on the scan
+// record (k_listener_scan) and the caller's inputs.  The tree is kept in the reference's order -- a listener leaves at the first rule that
+// applies, and `why` names that rule by the reference's line -- with its C arithmetic: `ser_errors * 2` is a 32-bit product, a product
+// with 1.1f is a float product when the other factor is an integer and a double product when it is a mean.
+struct ListenerDecideP {
+	const gys_listener_scan *scan;
+	const gys_listener_issue_in *in; // nullptr: defaults
+	uint8_t *hist;                   // [nsvc][2]: issue_bit_hist_, high_resp_bit_hist_
+	uint8_t *notify;                 // [nsvc * 88] or nullptr
+	gys_listener_decision *out;      // or nullptr
+	uint32_t nsvc;
+	uint32_t msec1_bucket;           // get_bucketid_from_threshold<RESP_TIME_HASH>(1) (:2062)
+};
+
+struct LDecision {
+	uint32_t state, issue, why;
+};
+
+__device__ __forceinline__ LDecision ld(uint32_t st, uint32_t is, uint32_t why) { return LDecision{st, is, why}; }
+
+__device__ LDecision listener_curr_state(const gys_listener_scan &sc, const gys_listener_issue_in &in, uint32_t msec1_bucket, uint8_t *high_hist)
+{
+	enum { IDLE = 0, GOOD = 1, OK = 2, BAD = 3, SEVERE = 4 };
+	enum { NONE = 0, TASKS = 1, QPS_HIGH = 2, ACT_HIGH = 3, SER_ERR = 4, DEPENDS = 7, UNKNOWN = 8 };
+	const bool task_issue = in.flags & GYS_LI_TASK_ISSUE, severe = in.flags & GYS_LI_SEVERE, delay = in.flags & GYS_LI_DELAY;
+	const bool cpu_issue = in.flags & GYS_LI_CPU_ISSUE, mem_issue = in.flags & GYS_LI_MEM_ISSUE;
+	const uint32_t errs = in.ser_errors;
+	const uint64_t nq = (uint64_t)sc.tcount[0];                  // nqrys_5s (size_t)
+	const uint64_t resp_msec = (uint64_t)sc.tsum[0];             // total_resp_msec
+	const uint64_t tdelay = in.tasks_delay_msec;
+	const int64_t p95_5 = sc.p95_ms[0], p95_5d = sc.p95_ms[2], qps = sc.curr_qps, q25 = sc.qps_p25, q95 = sc.qps_p95, a25 = sc.act_p25, a95 = sc.act_p95;
+	const int64_t active = sc.nconn_active, nconn = in.nconn;
+	const uint32_t b5 = sc.b5, b300 = sc.b300, b5d = sc.b5day;
+	const bool much_higher = b5 > b5d + 2u && b5 > b300;         // (b5 > b5day + 2) && (b5 > b300)
+	const bool many_errs = (uint64_t)(uint32_t)(errs * 2u) > nq; // ser_errors * 2 > nqrys_5s: the product is 32 bits wide
+	const bool some_errs = (uint64_t)(uint32_t)(errs * 5u) > nq;
+	const uint32_t err_or_none = errs ? SER_ERR : NONE;
+	double m[4];
+	for (int i = 0; i < 4; ++i) m[i] = (double)sc.tsum[i] / (double)(sc.tcount[i] != 0 ? sc.tcount[i] : 1); // mean_val_
+	uint8_t hh = (uint8_t)(*high_hist << 1);                     // :2113
+	*high_hist = hh;
+
+	if (qps == 0 && (!task_issue || !severe || !errs)) return ld(IDLE, NONE, 2126);
+	if (b5 == msec1_bucket || p95_5 < p95_5d) {                  // :2132 the response is fast, or faster than usual
+		if (qps <= q25 && q25 < q95) {                       // ... and there are few queries
+			if (!task_issue) {
+				if (!errs) return ld(IDLE, NONE, 2144);
+				if (many_errs) return ld(SEVERE, SER_ERR, 2153);
+				if (some_errs) return ld(BAD, SER_ERR, 2161);
+				if ((double)errs < (double)nq * 0.1) return ld(OK, SER_ERR, 2169);
+			} else {
+				if (many_errs) return ld(SEVERE, SER_ERR, 2179);
+				if (some_errs) return ld(BAD, SER_ERR, 2187);
+				if (errs) return ld(BAD, TASKS, 2202);
+				if (severe && in.ntasks_issue > 0 && in.ntasks_noissue == 0) return ld(BAD, TASKS, 2213);
+				if (nconn > a25) return ld(OK, TASKS, 2224);
+			}
+		}
+		if (errs && many_errs) return ld(SEVERE, SER_ERR, 2243);
+		if (errs && some_errs) return ld(BAD, SER_ERR, 2257);
+		if (task_issue && severe && in.ntasks_issue > 0 && in.ntasks_noissue == 0) return ld(BAD, TASKS, 2273);
+		if (errs) return ld(OK, SER_ERR, 2305);
+		if (qps <= q95 || b5 + 2u <= b5d) return ld(GOOD, NONE, 2305);
+		return ld(OK, QPS_HIGH, 2305);
+	}
+	if (p95_5 == p95_5d) {                                       // :2308
+		if (errs && many_errs) return ld(SEVERE, SER_ERR, 2322);
+		if (errs && some_errs) return ld(BAD, SER_ERR, 2336);
+		if (m[0] <= m[2] * (double)0.8f) {
+			if (qps <= q25) {
+				if (errs) return ld(BAD, SER_ERR, 2356);
+				if (!task_issue) return ld(IDLE, NONE, 2364);
+				if (in.ntasks_issue > 0 && in.ntasks_noissue == 0) return ld(BAD, TASKS, 2374);
+				if (in.ntasks_issue > 0 && tdelay >= 1000) return ld(BAD, TASKS, 2384);
+			}
+			if (!task_issue && !errs) return ld(GOOD, NONE, 2394);
+			if (errs && task_issue) return ld(BAD, TASKS, 2403);
+			return ld(OK, TASKS, 2417);                  // (:2406-2410 is overwritten by :2412-2413)
+		}
+		if (m[0] <= m[2] * (double)1.2f) return ld(OK, NONE, 2427);
+	}
+	hh |= 1u;                                                    // :2431 the response is higher than usual
+	*high_hist = hh;
+	if (errs && many_errs) return ld(SEVERE, SER_ERR, 2447);
+	if (errs && some_errs) return ld(BAD, SER_ERR, 2461);
+	if (qps > q95 && qps - q95 > 5 && (float)(int32_t)qps > (float)q95 * 1.1f) return ld(much_higher ? SEVERE : BAD, QPS_HIGH, 2492);
+	if (task_issue || (delay && (int)in.ntasks_issue + (int)in.ntasks_noissue > 2 && tdelay * 4u > resp_msec)) return ld(much_higher ? SEVERE : BAD, TASKS, 2525);
+	if (active > a95 && active - a95 > 1) return ld(much_higher && active > 10 ? SEVERE : BAD, ACT_HIGH, 2552);
+	if (p95_5 == p95_5d && sc.p99_ms[0] > sc.p99_ms[2]) return ld(OK, err_or_none, 2571);
+	if (qps <= q25 && nconn <= a25) {                            // :2576
+		if (delay && cpu_issue && mem_issue) return ld(BAD, TASKS, 2593);
+		if (delay && (cpu_issue || mem_issue) && tdelay * 4u > resp_msec) return ld(BAD, TASKS, 2611);
+		return ld(OK, err_or_none, 2630);
+	}
+	{
+		const int64_t span = in.tdiff_start > 0 && in.tdiff_start < 432000 ? in.tdiff_start : 432000; // sec_dist_arr[n5days] (:2064-2071)
+		const int avg5d = (int)(sc.tcount[2] / span);
+		if (avg5d < ((int)qps >> 1) && p95_5 <= (int64_t)sc.p95_ms[3] && m[0] <= m[3] * (double)1.1f) return ld(OK, err_or_none, 2657);
+	}
+	if (qps <= q25 && active <= a25 && b5 <= b5d + 1u) return ld(OK, err_or_none, 2679);
+	if (b5 <= b5d + 1u && b300 == b5d && m[0] > m[1] && m[1] < m[2] * (double)1.1f) return ld(OK, err_or_none, 2702);
+	if (active >= 15 && b5 == b5d + 1u) {                        // :2710 only a few connections sit in the slow buckets
+		uint32_t b = b5;
+		while (b < 15u && sc.nactive_conn_arr[b] <= 3u) ++b;
+		if (b > b5) return ld(OK, err_or_none, 2738);
+	}
+	if (__popc((uint32_t)hh) < 5) return ld(OK, err_or_none, 2768);
+	const uint32_t st = much_higher ? SEVERE : BAD;              // :2774 nothing explains it
+	if (tdelay * 4u > resp_msec && st == BAD) return ld(BAD, TASKS, 2817);
+	if (in.flags & GYS_LI_DEPENDS) return ld(st, DEPENDS, 2866);
+	if (tdelay * 10u > resp_msec) return ld(st, TASKS, 2853);
+	return ld(st, errs ? SER_ERR : UNKNOWN, 2866);
+}
+
+__global__ __launch_bounds__(256) void k_listener_decide(ListenerDecideP p)
+{
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= p.nsvc) return;
+	const gys_listener_scan sc = p.scan[slot];
+	gys_listener_issue_in in{};
+	if (p.in) in = p.in[slot];
+	else in.nconn = sc.nconn_active; // (the scan's notify record reports the active count as nconns_ too)
+	uint8_t ih = p.hist[2u * slot], hh = p.hist[2u * slot + 1u];
+	LDecision d = listener_curr_state(sc, in, p.msec1_bucket, &hh);
+	if (!(in.flags & GYS_LI_YOUNG) || in.ser_errors) { // diffstartusec > 100 s || ser_errors (:4244)
+		ih = (uint8_t)(ih << 1);
+		if (d.state >= 3u) ih |= 1u;
+	} else {                                           // "Listener Just recently started" (:4255-4262)
+		ih = 0;
+		d = LDecision{2u, 0u, 4262u};
+	}
+	p.hist[2u * slot] = ih;
+	p.hist[2u * slot + 1u] = hh;
+	if (p.out) {
+		gys_listener_decision o{};
+		o.state = (uint8_t)d.state;
+		o.issue = (uint8_t)d.issue;
+		o.issue_bit_hist = ih;
+		o.high_resp_bit_hist = hh;
+		o.decided_line = (uint16_t)d.why;
+		p.out[slot] = o;
+	}
+	if (p.notify) { // comm::LISTENER_STATE_NOTIFY (common/gy_comm_proto.h:2183-2254; filled at common/gy_socket_stat.cc:4293-4330)
+		uint8_t *r = p.notify + (size_t)slot * 88u;
+		uint32_t *q = (uint32_t *)r;
+		q[10] = in.ser_errors;                     // ser_errors_ @40
+		q[12] = in.tasks_delay_msec * 1000u;       // tasks_delay_usec_ @48
+		q[13] = in.tasks_cpudelay_msec * 1000u;    // tasks_cpudelay_usec_ @52
+		q[14] = in.tasks_blkiodelay_msec * 1000u;  // tasks_blkiodelay_usec_ @56
+		*(uint16_t *)(r + 76) = in.ntasks_issue;   // ntasks_issue_ @76
+		if (p.in) q[4] = (uint32_t)in.nconn;       // nconns_ @16 = last_chk_nconn_
+		r[79] = (uint8_t)d.state;
+		r[80] = (uint8_t)d.issue;
+		r[81] = ih;
+		r[82] = hh;
 	}
 }
 

@@ -301,6 +301,28 @@ class SketchEngine:
         return (notify, np.frombuffer(notify.cpu().numpy().tobytes(), dtype=wire.LISTENER_STATE_NOTIFY)[:n],
                 np.frombuffer(scan.cpu().numpy().tobytes(), dtype=self.LSCAN_DT)[:n])
 
+    ISSUE_IN_DT = np.dtype([("ser_errors", "<u4"), ("tasks_delay_msec", "<u4"), ("tasks_cpudelay_msec", "<u4"), ("tasks_blkiodelay_msec", "<u4"), ("nconn", "<i4"),
+                            ("ntasks_issue", "<u2"), ("ntasks_noissue", "<u2"), ("flags", "u1"), ("pad", "u1", 3), ("tdiff_start", "<i8")])
+    DECISION_DT = np.dtype([("state", "u1"), ("issue", "u1"), ("issue_bit_hist", "u1"), ("high_resp_bit_hist", "u1"), ("decided_line", "<u2"), ("pad", "<u2")])
+
+    def decide_listener_state(self, scan_np, issue_in=None, notify_dev=None):
+        """TCP_LISTENER::get_curr_state for every listener (gys_decide_listener_state_dev): scan_np = the gys_listener_scan records (numpy, LSCAN_DT),
+        issue_in = numpy ISSUE_IN_DT array or None, notify_dev = the scan's device tensor of 88-byte records (patched in place) or None.
+        Returns the gys_listener_decision records (numpy)."""
+        n = len(scan_np)
+        assert self.ISSUE_IN_DT.itemsize == 40 and self.DECISION_DT.itemsize == 8
+        d_scan = self.torch.from_numpy(np.frombuffer(np.ascontiguousarray(scan_np).tobytes(), dtype=np.uint8).copy()).to(self.device)
+        d_in = None
+        if issue_in is not None:
+            assert issue_in.dtype == self.ISSUE_IN_DT and len(issue_in) == n
+            d_in = self.torch.from_numpy(np.frombuffer(np.ascontiguousarray(issue_in).tobytes(), dtype=np.uint8).copy()).to(self.device)
+        d_out = self.torch.zeros(max(n, 1) * 8, dtype=self.torch.uint8, device=self.device)
+        self.order()
+        capi.check(self.L.gys_decide_listener_state_dev(self.h, C.c_void_p(d_scan.data_ptr()), C.c_void_p(d_in.data_ptr() if d_in is not None else None),
+                                                        C.c_void_p(notify_dev.data_ptr() if notify_dev is not None else None), C.c_void_p(d_out.data_ptr())))
+        self.sync()
+        return np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=self.DECISION_DT)[:n]
+
     SLAB_DT = np.dtype([("sum", "<i8", capi.TD_NB), ("cnt", "<u8", capi.TD_NB), ("vmin", "<i8"), ("vmax", "<i8")])
 
     def tdigest_rollup(self, scope):

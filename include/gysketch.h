@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GYS_ABI_VERSION 6
+#define GYS_ABI_VERSION 7
 
 enum {
 	GYS_OK = 0,
@@ -604,6 +604,36 @@ typedef struct {
 	uint8_t reserved[5];
 } gys_listener_scan;
 int gys_scan_listener_state_dev(gys_ctx *ctx, uint64_t tusec, float qps_multiple, uint32_t diffsec, void *d_notify, gys_listener_scan *d_scan);
+
+/* The listener's state decision: TCP_LISTENER::get_curr_state (common/gy_socket_stat.cc:2020-2870) and its caller's part (:4241-4266) for
+ * ALL listeners at once -- OBJ_STATE_E / LISTENER_ISSUE_SRC from the scan records above and from the inputs the listener's own histograms do
+ * not hold (task status, host CPU / memory issue flags, server errors, connection count, dependent servers), which the reference takes from
+ * RELATED_LISTENERS::LISTENER_TASK_STATUS / is_task_issue (:1914, :2043) and from the host's CPU / memory monitors.  Every branch of the
+ * reference that is a function of those values is evaluated (the issue STRING is not produced).  The two history bytes of a listener
+ * (TCP_LISTENER::issue_bit_hist_, high_resp_bit_hist_: common/gy_socket_stat.h:656-657) are engine state, advanced by every call.
+ *   d_scan      (device) gys_listener_scan x gys_num_services, as gys_scan_listener_state_dev left them;
+ *   d_issue_in  (device, or NULL = no errors, no task / host issue, ten days of history) gys_listener_issue_in x gys_num_services;
+ *   d_notify    (device, or NULL) the 88-byte records of the scan: curr_state_ @79, curr_issue_ @80, issue_bit_hist_ @81, high_resp_bit_hist_ @82
+ *               and, from the inputs, ser_errors_ @40, tasks_delay_usec_ @48, tasks_cpudelay_usec_ @52, tasks_blkiodelay_usec_ @56, ntasks_issue_ @76 are filled in;
+ *   d_out       (device, or NULL) gys_listener_decision x gys_num_services. */
+enum { GYS_LI_TASK_ISSUE = 1, GYS_LI_SEVERE = 2, GYS_LI_DELAY = 4, GYS_LI_CPU_ISSUE = 8, GYS_LI_MEM_ISSUE = 16, GYS_LI_DEPENDS = 32, GYS_LI_YOUNG = 64 };
+typedef struct {
+	uint32_t ser_errors;                                                   /* get_curr_state's ser_errors argument */
+	uint32_t tasks_delay_msec, tasks_cpudelay_msec, tasks_blkiodelay_msec; /* LISTENER_TASK_STATUS::tasks_*_usec_ / 1000 (:2047, :2784-2785) */
+	int32_t nconn;                                                         /* last_chk_nconn_ (:2040) */
+	uint16_t ntasks_issue, ntasks_noissue;                                 /* is_task_issue's counts (:2043-2044) */
+	uint8_t flags;                                                         /* GYS_LI_*: task_issue, is_severe, is_delay, cpu_issue, mem_issue, dependent servers exist (:2823-2829), started less than 100 s ago (:4244) */
+	uint8_t pad[3];
+	int64_t tdiff_start;                                                   /* seconds the listener's response histogram covers (:2033-2034); <= 0: the full 5 days */
+} gys_listener_issue_in;
+typedef struct {
+	uint8_t state, issue;                       /* OBJ_STATE_E (0 Idle, 1 Good, 2 OK, 3 Bad, 4 Severe), LISTENER_ISSUE_SRC (common/gy_json_field_maps.h:242-250, :419-434) */
+	uint8_t issue_bit_hist, high_resp_bit_hist; /* the listener's history bytes after this call */
+	uint16_t decided_line;                      /* the line of common/gy_socket_stat.cc whose `return` (or the function's end, 2866; 4262 = "just started") decided */
+	uint16_t pad;
+} gys_listener_decision;
+int gys_decide_listener_state_dev(gys_ctx *ctx, const gys_listener_scan *d_scan, const gys_listener_issue_in *d_issue_in, void *d_notify,
+				  gys_listener_decision *d_out);
 
 /* -------------------------------------------------------------------------------------------------------------------
  * parity / checkpoint exports (host destination buffers) -- GY_HISTOGRAM::get_serialized analogue (gy_statistics.h:665-673) */

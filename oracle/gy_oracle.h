@@ -311,6 +311,31 @@ uint32_t gyo_bucketid_from_threshold(int kind, int64_t threshold);
 void gyo_listener_scan_one(const gyo_mlhist *resp, const gyo_hist *qps, const gyo_hist *act, const uint16_t respmap[64], uint64_t glob_id,
 			   float multiple, int64_t diffsec, uint8_t notify[88], gyo_listener_scan *out);
 
+/* ---------------------------------------------------------------- the listener's state decision (gy_oracle_lstate.c)
+ * TCP_LISTENER::get_curr_state (common/gy_socket_stat.cc:2020-2870) as a function of the scan record and of the inputs that are not the
+ * listener's own histograms (task / host status, server errors); same layout as gys_listener_issue_in / gys_listener_decision */
+enum { GYO_LI_TASK_ISSUE = 1, GYO_LI_SEVERE = 2, GYO_LI_DELAY = 4, GYO_LI_CPU_ISSUE = 8, GYO_LI_MEM_ISSUE = 16, GYO_LI_DEPENDS = 32, GYO_LI_YOUNG = 64 };
+typedef struct {
+	uint32_t ser_errors;                                                   /* :2020 argument */
+	uint32_t tasks_delay_msec, tasks_cpudelay_msec, tasks_blkiodelay_msec; /* LISTENER_TASK_STATUS::tasks_*_usec_ / 1000 (:2047, :2784-2785) */
+	int32_t nconn;                                                         /* last_chk_nconn_ (:2040) */
+	uint16_t ntasks_issue, ntasks_noissue;                                 /* is_task_issue outputs (:2043-2044) */
+	uint8_t flags;                                                         /* GYO_LI_*: task_issue, is_severe, is_delay, cpu_issue, mem_issue, nserdepends > 0 (:2823-2829), listener younger than 100 s (:4244) */
+	uint8_t pad[3];
+	int64_t tdiff_start;                                                   /* seconds the response histogram covers (:2033-2034); <= 0: the full 5 days */
+} gyo_listener_issue_in;
+typedef struct {
+	uint8_t state, issue;                       /* OBJ_STATE_E, LISTENER_ISSUE_SRC (common/gy_json_field_maps.h:242-250, :419-434) */
+	uint8_t issue_bit_hist, high_resp_bit_hist; /* TCP_LISTENER::issue_bit_hist_ / high_resp_bit_hist_ after the call */
+	uint16_t decided_line;                      /* line of common/gy_socket_stat.cc whose return (or the function's end) decided */
+	uint16_t pad;
+} gyo_listener_decision;
+/* get_curr_state itself: *high_resp_bit_hist is the listener's history byte (in / out); returns the deciding line */
+int gyo_listener_curr_state(const gyo_listener_scan *sc, const gyo_listener_issue_in *in, uint8_t *high_resp_bit_hist, uint8_t *state, uint8_t *issue);
+/* get_curr_state + the caller's part (common/gy_socket_stat.cc:4241-4266: issue_bit_hist_, the "just started" override) */
+void gyo_listener_decide(const gyo_listener_scan *sc, const gyo_listener_issue_in *in, uint8_t *issue_bit_hist, uint8_t *high_resp_bit_hist,
+			 gyo_listener_decision *out);
+
 /* BOUNDED_PRIO_QUEUE<uint64_t, greater> (common/gy_statistics.h:356-383): returns retained values sorted descending */
 size_t gyo_topn_u64(const uint64_t *vals, size_t n, size_t maxn, uint64_t *out);
 

@@ -33,7 +33,7 @@ f32p = C.POINTER(C.c_float)
 HIST_SERIAL_DT = np.dtype([("count", "<u8"), ("sum", "<i8")])  # HIST_SERIAL as a numpy record
 
 
-SOURCES = ["gy_oracle.c", "gy_oracle_engine.c", "gy_oracle_levels.c", "gy_oracle_rollup.c", "gy_oracle_lscan.c", "gy_oracle_query.c"]
+SOURCES = ["gy_oracle.c", "gy_oracle_engine.c", "gy_oracle_levels.c", "gy_oracle_rollup.c", "gy_oracle_lscan.c", "gy_oracle_lstate.c", "gy_oracle_query.c"]
 
 
 def build_oracle(force=False):
@@ -103,6 +103,24 @@ class ListenerScan(C.Structure):
 
 
 assert C.sizeof(ListenerScan) == 168
+
+LI_TASK_ISSUE, LI_SEVERE, LI_DELAY, LI_CPU_ISSUE, LI_MEM_ISSUE, LI_DEPENDS, LI_YOUNG = 1, 2, 4, 8, 16, 32, 64
+
+
+class ListenerIssueIn(C.Structure):
+    """gyo_listener_issue_in == gys_listener_issue_in (include/gysketch.h)"""
+    _fields_ = [("ser_errors", C.c_uint32), ("tasks_delay_msec", C.c_uint32), ("tasks_cpudelay_msec", C.c_uint32), ("tasks_blkiodelay_msec", C.c_uint32),
+                ("nconn", C.c_int32), ("ntasks_issue", C.c_uint16), ("ntasks_noissue", C.c_uint16), ("flags", C.c_uint8), ("pad", C.c_uint8 * 3),
+                ("tdiff_start", C.c_int64)]
+
+
+class ListenerDecision(C.Structure):
+    """gyo_listener_decision == gys_listener_decision"""
+    _fields_ = [("state", C.c_uint8), ("issue", C.c_uint8), ("issue_bit_hist", C.c_uint8), ("high_resp_bit_hist", C.c_uint8),
+                ("decided_line", C.c_uint16), ("pad", C.c_uint16)]
+
+
+assert C.sizeof(ListenerIssueIn) == 40 and C.sizeof(ListenerDecision) == 8
 
 
 class ListenSummStats(C.Structure):
@@ -219,6 +237,8 @@ def lib():
     _sig(L, "gyo_slab_percentile_idx", C.c_size_t, [u64p, C.c_size_t, C.c_double])
     _sig(L, "gyo_mlh_get_stats", None, [C.POINTER(MLHist), C.c_int, f32p, C.c_size_t, i64p, i64p, i64p, C.POINTER(C.c_double)])
     _sig(L, "gyo_bucketid_from_threshold", C.c_uint32, [C.c_int, C.c_int64])
+    _sig(L, "gyo_listener_curr_state", C.c_int, [C.POINTER(ListenerScan), C.POINTER(ListenerIssueIn), u8p, u8p, u8p])
+    _sig(L, "gyo_listener_decide", None, [C.POINTER(ListenerScan), C.POINTER(ListenerIssueIn), u8p, u8p, C.POINTER(ListenerDecision)])
     _sig(L, "gyo_listener_scan_one", None, [C.POINTER(MLHist), C.POINTER(Hist), C.POINTER(Hist), u16p, C.c_uint64, C.c_float, C.c_int64, u8p,
                                             C.POINTER(ListenerScan)])
     _sig(L, "gyo_mlh_level_for_start", C.c_int, [C.POINTER(MLHist), C.c_int, C.c_int64])

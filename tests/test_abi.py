@@ -74,7 +74,7 @@ def test_bad_config_rejected(capi):
     cfg = capi.Config()
     h = C.c_void_p()
     assert L.gys_create(C.byref(cfg), C.byref(h)) == capi.ERR_INVAL  # struct_size 0
-    assert L.gys_abi_version() == 6
+    assert L.gys_abi_version() == 7
 
 
 def test_shard_function_is_reference_machine_id_hash(capi, oracle):

@@ -28,6 +28,8 @@ the hot kernels run on synthetic input:
     listeners, ties, stale and foreign records, all four kinds;
   * the filtered multi-host listener-state query (tests/cpp/kemu/test_svcquery.cc): k_svc_filter, the radix selection, k_svc_gather and
     k_svc_aggr on random records / filters / sorts / maxrecs against the oracle's serial walk (oracle/gy_oracle_query.c);
+  * the listener's state decision k_listener_decide (tests/cpp/kemu/test_ldecide.cc): TCP_LISTENER::get_curr_state's decision tree on random
+    scan records and task / host inputs, the history bytes carried over six rounds, against oracle/gy_oracle_lstate.c;
   * the roll-up digests k_digest_rollup (tests/cpp/kemu/test_rollup.cc): groups of services and groups of slabs folded in order, 64-bit
     weights beyond 2^32, members without clusters / without buffered values / empty.
 This does not replace the -m gpu parity tests (no memory model, no execution masks, no timing): it catches logic errors in kernel
@@ -77,6 +79,8 @@ PROGRAMS = {
     "topn-17": ("test_topn.cc", [], ["17"], "kemu topn ok"),
     "rollup-9": ("test_rollup.cc", [], ["9"], "kemu rollup ok"),
     "rollup-10": ("test_rollup.cc", [], ["10"], "kemu rollup ok"),
+    # the listener's state decision (get_curr_state) on random scan records / inputs over six rounds
+    "ldecide-5": ("test_ldecide.cc", [], ["5"], "kemu ldecide ok"),
     "svcquery-5": ("test_svcquery.cc", [], ["5"], "kemu svcquery ok"),
     "svcquery-6": ("test_svcquery.cc", [], ["6"], "kemu svcquery ok"),
 }
