@@ -293,6 +293,14 @@ public:
 		std::unique_lock<std::shared_mutex> g(mu_);
 		return gys_scan_listener_state_dev(ctx_, (uint64_t)tnow * 1000000ull, qps_multiple, diffsec, d_notify, d_scan) == GYS_OK;
 	}
+	// TCP_LISTENER::get_curr_state for every listener (common/gy_socket_stat.cc:2020-2870, called at :4241) + the caller's history byte and
+	// "just started" rule (:4244-4266): d_scan as listener_stats_update left it, d_issue_in = the task / host inputs per service slot (nullptr:
+	// none), curr_state_ / curr_issue_ / issue_bit_hist_ / high_resp_bit_hist_ patched into d_notify, the decisions into d_out (either may be nullptr)
+	bool listener_curr_states(const gys_listener_scan *d_scan, const gys_listener_issue_in *d_issue_in, void *d_notify, gys_listener_decision *d_out) noexcept
+	{
+		std::unique_lock<std::shared_mutex> g(mu_);
+		return gys_decide_listener_state_dev(ctx_, d_scan, d_issue_in, d_notify, d_out) == GYS_OK;
+	}
 	bool web_curr_clusterstate(const char *shyamaid, const char *timestr, std::string &out) noexcept
 	{
 		return json_call(out, [&](char *b, size_t n, size_t *need) { return gys_json_clusterstate(ctx_, shyamaid, timestr, b, n, need); });

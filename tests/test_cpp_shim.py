@@ -22,7 +22,7 @@ def _build(tmp_path):
 def test_shim_compiles_and_links_with_gxx(tmp_path):
     exe = _build(tmp_path)
     out = subprocess.check_output([exe]).decode()
-    assert "link ok, abi 6" in out
+    assert "link ok, abi 7" in out
 
 
 @pytest.mark.gpu
