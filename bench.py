@@ -76,7 +76,7 @@ def compact_line(out, detail_path=None):
                                      "dtype", "data", "parity_ok")}
     cfg = out.get("config", {})
     c["config"] = _pick(cfg, ("workload", "events_per_rank_per_step", "service_keys_total", "multi_level_windows", "td_pend_cap", "td_pend_cap_is_library_default",
-                              "exchange", "records_per_step"))
+                              "exchange", "exchange_requested", "exchange_fallback", "records_per_step"))
     rf = out.get("roofline", {})
     r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_step", "kernel", "kernel_avg_ms", "kernel_frac", "kernel_frac_24B"))
     tr = rf.get("traffic")

@@ -820,6 +820,22 @@ __global__ __launch_bounds__(256) void k_cms_reduce(const uint32_t *partial, uin
 #ifndef GYS_PARK_INDEX
 #define GYS_PARK_INDEX 1 // the rank atomic of a place that kept nothing goes to s_ts[Lc_park + lane]: one select for the index, no select between two addresses
 #endif
+#ifndef GYS_EV_DMA
+#define GYS_EV_DMA 0 // (r6h / r6i: bit-exact and SLOWER -- 5.85 ms without, 6.22 ms with the requests one group ahead, against 5.24 - 5.39 ms; left off) (16 384-event tiles) a wave's events come in through LDS: six global_load_lds_dwordx4 per group of four event slots -- every 128-byte line of the wave's span requested ONCE, no destination registers -- into the wave's 6 KB of the (idle) tile-image area, then three 8-byte LDS reads per event.  r6g's counters: the vector-memory path stalls on pending lines half the time (TCP_PENDING_STALL_CYCLES 51 %, TD_TC_STALL 52 % of the kernel's cycles) with the strided 16 + 8-byte loads, which ask for every line twice
+#endif
+#ifndef GYS_EV_DMA_AHEAD
+#define GYS_EV_DMA_AHEAD 1 // the requests of group g + 1 are issued as soon as group g's words have been read out of the wave's area (they run under group g's work)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef GYS_EV_DMA_CPOL
+#define GYS_EV_DMA_CPOL 0 // cache policy bits of the requests (2 = nt: the event lines pass through the L2 without displacing the partly written buffer lines of the flush)
+#endif
+#define GYS_DMA16(gptr, ldsptr) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(ldsptr), 16, 0, GYS_EV_DMA_CPOL) // lane l's 16 bytes land at ldsptr + 16 l (ldsptr: wave-uniform)
+#define GYS_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define GYS_DMA16(gptr, ldsptr) memcpy((char *)(ldsptr) + 16u * (threadIdx.x & 63u), (const void *)(gptr), 16)
+#define GYS_DMA_WAIT() ((void)0)
+#endif
 #ifndef GYS_EV_PREFETCH
 #define GYS_EV_PREFETCH 0 // one load instruction per wave and group touches the 48 lines of the wave's NEXT group of events (a dword each, result unused): the demand loads of the next group then come from the L2 instead of HBM
 #endif
@@ -1087,6 +1103,18 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 	// PF: the twelve words of the NEXT group of four events per thread are requested while the current group is processed and wait in
 	// n0 / n1 / n2 (the group after a tile's last one is the next tile's first: its loads run under the scan / image / flush phases)
 	constexpr bool PF = TPT == 32 && !SPILL;
+	// events through LDS (GYS_EV_DMA): the tile image of 6 bytes per event is 6 KB per wave with 16 events per thread -- room for the 4 x 1536 bytes of a
+	// group's four event slots.  Layout of a wave's area: the first KB of slot u at 1024 u, its last 512 bytes at 4096 + 512 u (the tails of two slots
+	// are one full-width request).  The 8-byte piece k of lane l's event (byte 24 l + 8 k of the slot) never straddles the KB boundary.
+	constexpr bool DMA = GYS_EV_DMA && TPT == 16 && !SPILL && MODE != 2;
+	char *const dma_ws = (char *)s_val + wave * 6144u;
+	uint32_t dma_a[3], dma_s[3]; // address of piece k in slot 0 and its stride from slot to slot
+#pragma unroll
+	for (uint32_t k = 0; k < 3u; ++k) {
+		const uint32_t byte = 24u * lane + 8u * k;
+		dma_a[k] = byte < 1024u ? byte : 4096u + (byte - 1024u);
+		dma_s[k] = byte < 1024u ? 1024u : 512u;
+	}
 	uint64_t n0[4], n1[4], n2[4];
 	auto pf_issue = [&](const uint64_t *base, uint32_t first_o, uint32_t lim) {
 #pragma unroll
@@ -1108,6 +1136,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 		// double-buffered and were cleared two phases ago, the floor and the candidate queue were settled behind barriers of the
 		// previous tile; a wave that is done flushing starts on its next events while the others still flush)
 		uint32_t *const s_ts = s_ts2 + (tile_no & 1u) * Lc;
+		if (DMA) __syncthreads(); // (the waves stage their events in the tile-image area: the previous tile's flush must be over)
 #if GYS_PARK_INDEX
 #if defined(__HIP_DEVICE_COMPILE__)
 		typedef uint32_t park_ix_t; // (LDS addresses are 32 bits: wrap-around arithmetic on word indices, s_ts[park_ix] is s_park[lane])
@@ -1182,6 +1211,9 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 						w0[u] = (uint64_t)d0 | ((uint64_t)d1 << 32);
 						w1[u] = (uint64_t)d2 | ((uint64_t)d3 << 32);
 						w2[u] = (uint64_t)d4 | ((uint64_t)d5 << 32);
+					} else if (DMA) {
+						in[u] = (uint32_t)(g + u) * T + tid < rem; // (the words are read from the wave's LDS area below, behind the requests of all four slots)
+						w0[u] = w1[u] = w2[u] = 0;
 					} else if (GYS_EV_SADDR) {
 						// the tile's base is uniform and an event's byte offset inside the tile fits 32 bits: written so, the three loads share ONE
 						// 32-bit offset register (scalar base + offset + immediate) instead of a 64-bit address each.  Round 6: the offset is
@@ -1199,6 +1231,48 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 						w2[u] = GYS_EV_LOAD(&tb[3u * oo + 2u]);
 					}
 				}
+			}
+			if (DMA) {
+				// the requests of a group: six full-width 16-byte-per-lane transfers into the wave's area.  A 16-byte piece may reach 8 bytes past the
+				// tile's last event (into the next tile's or segment's events): it is requested as long as it lies inside the batch; the batch's
+				// very last event (its last piece would pass the buffer's end when n is odd) is re-read below
+				auto dma_issue = [&](uint32_t gg) {
+					const char *const tbb = (const char *)tb;
+					const uint64_t left_b = (p.n - t0) * 24ull;
+					const uint32_t lim = left_b > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)left_b;
+#pragma unroll
+					for (uint32_t u = 0; u < 4u; ++u) { // the first KB of each slot: lane l asks for bytes [16 l, 16 l + 16) of the wave's 1536
+						const uint32_t bo = 24u * ((gg + u) * T + (tid & ~63u)) + 16u * lane;
+						GYS_DMA16(tbb + (bo + 16u <= lim ? bo : 0u), dma_ws + 1024u * u);
+					}
+#pragma unroll
+					for (uint32_t t2 = 0; t2 < 2u; ++t2) { // the last 512 bytes of two slots: lanes 0..31 slot 2 t2, lanes 32..63 slot 2 t2 + 1
+						const uint32_t u = 2u * t2 + (lane >> 5);
+						const uint32_t bo = 24u * ((gg + u) * T + (tid & ~63u)) + 1024u + 16u * (lane & 31u);
+						GYS_DMA16(tbb + (bo + 16u <= lim ? bo : 0u), dma_ws + 4096u + 1024u * t2);
+					}
+				};
+				if (!GYS_EV_DMA_AHEAD || g == 0) dma_issue((uint32_t)g); // (the tile's first group: behind the tile-top barrier)
+				GYS_DMA_WAIT();
+				__builtin_amdgcn_wave_barrier();
+#pragma unroll
+				for (uint32_t u = 0; u < 4u; ++u) {
+					w0[u] = *(const uint64_t *)(dma_ws + dma_a[0] + u * dma_s[0]);
+					w1[u] = *(const uint64_t *)(dma_ws + dma_a[1] + u * dma_s[1]);
+					w2[u] = *(const uint64_t *)(dma_ws + dma_a[2] + u * dma_s[2]);
+					const uint32_t o = (uint32_t)(g + u) * T + tid;
+					if (t0 + o + 1u == p.n) { // (one lane of one workgroup per batch)
+						w0[u] = tb[3u * o];
+						w1[u] = tb[3u * o + 1u];
+						w2[u] = tb[3u * o + 2u];
+					}
+				}
+				GYS_OPAQUE_LOADED4(w0); // (the words are in registers: the area is free again)
+				GYS_OPAQUE_LOADED4(w1);
+				GYS_OPAQUE_LOADED4(w2);
+				__builtin_amdgcn_wave_barrier();
+				// the NEXT group's requests go out now and run under this group's work: software pipelining with one buffer and no registers
+				if (GYS_EV_DMA_AHEAD && g + 4 < TPT && (uint32_t)(g + 4) * T < rem) dma_issue((uint32_t)g + 4u);
 			}
 			// (all twelve words pass through one opaque statement: the four events' loads are issued before the first word is used -- the
 			// scheduler otherwise waits for event 0 and starts on its fields before the loads of events 1..3 are even issued.  Requesting

@@ -48,12 +48,17 @@ def test_bench_two_ranks_on_one_device_whole_flow():
     """`python bench.py --gpus 2 --share-device`: the whole N > 1 flow of the bench on a one-GPU box -- self-launch, host-hash sharding,
     communicator join through the C ABI, gys_window_close_rccl in every window (RCCL entry points served by tests/cpp/fakerccl, both ranks
     on device 0), the cross-rank register check and the side configuration compared with a single-rank engine"""
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="gys_bench_detail_"), "detail.json")
     r = _run("--gpus", "2", "--share-device", "--hosts", "400", "--svcs", "100", "--events", str(1 << 22), "--steps", "4", "--warmup", "1",
-             "--prime-windows", "2", "--no-cpu-baseline", "--no-host-fed", "--strict-exchange", timeout=900)
+             "--prime-windows", "2", "--no-cpu-baseline", "--no-host-fed", "--strict-exchange", "--detail-out", detail, timeout=900)
     assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert len(line) < 4096  # the compact line (what the driver parses); the full result is the detail file
+    d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["exchange"] == "rccl_in_library" and d["config"]["exchange_fallback"] is False
-    x = d["exchange_check"]
+    assert d["exchange_check"]["ranks_seen"] == 2 and d["exchange_check"]["ranks_consistent"] is True and d["exchange_check"]["ok"] is True
+    assert d["parity_ok"] is True and d["value"] > 0
+    x = json.load(open(detail))["exchange_check"]
     assert x["ranks_seen"] == 2 and x["ranks_consistent"] is True and x["ok"] is True
     assert x["side_config"]["ranks_consistent"] is True and x["side_config"]["equals_single_rank_engine"] is True
-    assert d["parity_ok"] is True and d["value"] > 0
