@@ -3974,7 +3974,27 @@ try {
 	int rc = rollup_launch(c, 0, off, members, nullptr, d_hosts);
 	if (rc == GYS_OK && scope != GYS_ROLLUP_HOST) {
 		std::vector<uint32_t> goff, gmem;
-		if (scope == GYS_ROLLUP_GLOBAL) {
+		if (scope == GYS_ROLLUP_GLOBAL && nh > GYS_ROLLUP_FANIN) {
+			// round 6: the hosts' slabs are folded in two levels -- chunks of GYS_ROLLUP_FANIN consecutive host slots in parallel (each in host-slot
+			// order), then the chunks' slabs in order -- instead of one workgroup walking all of them: 10^4 hosts are 79 + 128 sequential member
+			// steps, not 10^4.  (A rank with at most GYS_ROLLUP_FANIN hosts folds them directly, as before.)
+			const uint32_t nchunks = (nh + GYS_ROLLUP_FANIN - 1u) / GYS_ROLLUP_FANIN;
+			std::vector<uint32_t> coff(nchunks + 1), cmem(nh);
+			for (uint32_t k = 0; k <= nchunks; ++k) coff[k] = std::min(nh, k * GYS_ROLLUP_FANIN);
+			for (uint32_t h = 0; h < nh; ++h) cmem[h] = h;
+			gys_tdigest_slab *d_mid = nullptr;
+			HIPCHK(hipMalloc((void **)&d_mid, sizeof(gys_tdigest_slab) * nchunks));
+			rc = rollup_launch(c, 1, coff, cmem, d_hosts, d_mid);
+			if (rc == GYS_OK) {
+				goff = {0u, nchunks};
+				gmem.resize(nchunks);
+				for (uint32_t k = 0; k < nchunks; ++k) gmem[k] = k;
+				rc = rollup_launch(c, 1, goff, gmem, d_mid, d_out);
+			}
+			HIPCHK(hipFree(d_mid));
+			HIPCHK(hipFree(d_hosts));
+			return rc;
+		} else if (scope == GYS_ROLLUP_GLOBAL) {
 			goff = {0u, nh};
 			gmem.resize(nh);
 			for (uint32_t h = 0; h < nh; ++h) gmem[h] = h;

@@ -4532,10 +4532,10 @@ __global__ __launch_bounds__(256) void k_listener_decide(ListenerDecideP p)
 	if (p.notify) { // comm::LISTENER_STATE_NOTIFY (common/gy_comm_proto.h:2183-2254; filled at common/gy_socket_stat.cc:4293-4330)
 		uint8_t *r = p.notify + (size_t)slot * 88u;
 		uint32_t *q = (uint32_t *)r;
-		q[10] = in.ser_errors;                     // ser_errors_ @40
-		q[12] = in.tasks_delay_msec * 1000u;       // tasks_delay_usec_ @48
-		q[13] = in.tasks_cpudelay_msec * 1000u;    // tasks_cpudelay_usec_ @52
-		q[14] = in.tasks_blkiodelay_msec * 1000u;  // tasks_blkiodelay_usec_ @56
+		q[11] = in.ser_errors;                     // ser_errors_ @44
+		q[13] = in.tasks_delay_msec * 1000u;       // tasks_delay_usec_ @52
+		q[14] = in.tasks_cpudelay_msec * 1000u;    // tasks_cpudelay_usec_ @56
+		q[15] = in.tasks_blkiodelay_msec * 1000u;  // tasks_blkiodelay_usec_ @60
 		*(uint16_t *)(r + 76) = in.ntasks_issue;   // ntasks_issue_ @76
 		if (p.in) q[4] = (uint32_t)in.nconn;       // nconns_ @16 = last_chk_nconn_
 		r[79] = (uint8_t)d.state;

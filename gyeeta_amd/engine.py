@@ -302,7 +302,7 @@ class SketchEngine:
                 np.frombuffer(scan.cpu().numpy().tobytes(), dtype=self.LSCAN_DT)[:n])
 
     ISSUE_IN_DT = np.dtype([("ser_errors", "<u4"), ("tasks_delay_msec", "<u4"), ("tasks_cpudelay_msec", "<u4"), ("tasks_blkiodelay_msec", "<u4"), ("nconn", "<i4"),
-                            ("ntasks_issue", "<u2"), ("ntasks_noissue", "<u2"), ("flags", "u1"), ("pad", "u1", 3), ("tdiff_start", "<i8")])
+                            ("ntasks_issue", "<u2"), ("ntasks_noissue", "<u2"), ("flags", "u1"), ("pad", "u1", 7), ("tdiff_start", "<i8")])  # (the C struct's int64 sits at offset 32)
     DECISION_DT = np.dtype([("state", "u1"), ("issue", "u1"), ("issue_bit_hist", "u1"), ("high_resp_bit_hist", "u1"), ("decided_line", "<u2"), ("pad", "<u2")])
 
     def decide_listener_state(self, scan_np, issue_in=None, notify_dev=None):

@@ -373,8 +373,11 @@ typedef struct {
 	int64_t vmin, vmax; /* valid when any cnt != 0 */
 } gys_tdigest_slab;
 enum { GYS_ROLLUP_HOST = 0, GYS_ROLLUP_CLUSTER = 1, GYS_ROLLUP_GLOBAL = 2 };
+#define GYS_ROLLUP_FANIN 128u
 /* d_out (DEVICE): HOST: one slab per host slot [gys_num_hosts]; CLUSTER: one per registered cluster index (fold of its hosts' slabs in
- * host-slot order); GLOBAL: one slab (fold of all host slabs in host-slot order).  No engine state is modified. */
+ * host-slot order); GLOBAL: one slab -- the fold of all host slabs in host-slot order when the rank has at most GYS_ROLLUP_FANIN hosts, else
+ * (round 6) the fold, in order, of the slabs of the chunks of GYS_ROLLUP_FANIN consecutive host slots, each the fold of its hosts' slabs in
+ * host-slot order (the chunks are folded in parallel).  No engine state is modified. */
 int gys_tdigest_rollup_dev(gys_ctx *ctx, int scope, gys_tdigest_slab *d_out);
 /* d_out[0] (DEVICE) = fold of d_in[0..n) in order (the cross-rank merge after an all-gather; also any caller-defined group) */
 int gys_tdigest_merge_slabs_dev(gys_ctx *ctx, const gys_tdigest_slab *d_in, uint32_t n, gys_tdigest_slab *d_out);
@@ -614,7 +617,7 @@ int gys_scan_listener_state_dev(gys_ctx *ctx, uint64_t tusec, float qps_multiple
  *   d_scan      (device) gys_listener_scan x gys_num_services, as gys_scan_listener_state_dev left them;
  *   d_issue_in  (device, or NULL = no errors, no task / host issue, ten days of history) gys_listener_issue_in x gys_num_services;
  *   d_notify    (device, or NULL) the 88-byte records of the scan: curr_state_ @79, curr_issue_ @80, issue_bit_hist_ @81, high_resp_bit_hist_ @82
- *               and, from the inputs, ser_errors_ @40, tasks_delay_usec_ @48, tasks_cpudelay_usec_ @52, tasks_blkiodelay_usec_ @56, ntasks_issue_ @76 are filled in;
+ *               and, from the inputs, ser_errors_ @44, tasks_delay_usec_ @52, tasks_cpudelay_usec_ @56, tasks_blkiodelay_usec_ @60, ntasks_issue_ @76 (nconns_ @16 when inputs are given) are filled in;
  *   d_out       (device, or NULL) gys_listener_decision x gys_num_services. */
 enum { GYS_LI_TASK_ISSUE = 1, GYS_LI_SEVERE = 2, GYS_LI_DELAY = 4, GYS_LI_CPU_ISSUE = 8, GYS_LI_MEM_ISSUE = 16, GYS_LI_DEPENDS = 32, GYS_LI_YOUNG = 64 };
 typedef struct {

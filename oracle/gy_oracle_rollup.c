@@ -13,6 +13,10 @@
  *   merge = the same exact-integer k-bucket merge as a service's own digest (gy_oracle.c td_merge_items): items ordered by mean
  *   (exact rational compare), ties: old clusters first; an item whose weighted mid-point is mid2 / 2 of N goes to cluster
  *   gyo_td_cluster(mid2, 2N).  A group's weight exceeds 32 bits (10^4 hosts x 2^29 events per window), so the counters are 64-bit.
+ *
+ *   Round 6: the GLOBAL roll-up of a rank with more than 128 hosts (GYS_ROLLUP_FANIN) is the fold, in order, of the roll-ups of the chunks
+ *   of 128 consecutive host slots (each the fold of its hosts' roll-ups in slot order): the engine folds the chunks in parallel.  The
+ *   functions below are the fold's step; a test composes them in that order (tests/test_gpu_round6.py).
  */
 #include <limits.h>
 #include <math.h>

@@ -117,6 +117,16 @@ int main(int argc, char **argv)
 			lines.insert(od.decided_line);
 			const gys_listener_decision &g = out[i];
 			const uint8_t *r = &notify[(size_t)i * 88];
+			uint32_t nf[4];
+			uint16_t nti;
+			memcpy(&nf[0], r + 44, 4); // ser_errors_
+			memcpy(&nf[1], r + 52, 4); // tasks_delay_usec_
+			memcpy(&nf[2], r + 56, 4); // tasks_cpudelay_usec_
+			memcpy(&nf[3], r + 60, 4); // tasks_blkiodelay_usec_
+			memcpy(&nti, r + 76, 2);   // ntasks_issue_
+			const bool fields = nf[0] == oi.ser_errors && nf[1] == oi.tasks_delay_msec * 1000u && nf[2] == oi.tasks_cpudelay_msec * 1000u &&
+					    nf[3] == oi.tasks_blkiodelay_msec * 1000u && nti == oi.ntasks_issue;
+			if (!fields && fails++ < 20) printf("FAIL round %d listener %u: input fields of the notify record\n", rnd, i);
 			const bool same = g.state == od.state && g.issue == od.issue && g.issue_bit_hist == od.issue_bit_hist && g.high_resp_bit_hist == od.high_resp_bit_hist &&
 					  g.decided_line == od.decided_line && hist[2 * i] == ohist[2 * i] && hist[2 * i + 1] == ohist[2 * i + 1] && r[79] == od.state &&
 					  r[80] == od.issue && r[81] == od.issue_bit_hist && r[82] == od.high_resp_bit_hist;
