@@ -647,15 +647,29 @@ int host_tbl_upload(gys_ctx *c, HostListeners &hl, uint32_t desc, uint32_t part,
 int host_cands_upload(gys_ctx *c, HostListeners &hl)
 {
 	if (hl.cands.empty()) return GYS_OK;
-	if (!c->cand_pool) {
-		c->cand_cap = 4ull * c->cfg.max_services + 64ull * c->cfg.max_hosts;
-		HIPCHK(hipMalloc((void **)&c->cand_pool, c->cand_cap * sizeof(ListenerCand)));
-	}
 	if (hl.cands.size() > hl.cand_cap) {
 		const uint64_t want = std::max<uint64_t>(16, next_pow2(hl.cands.size()));
-		if (c->cand_used + want > c->cand_cap) {
+		// round 6: the pool grows geometrically from 4 096 records (128 KB) to its bound of 4 x max_services + 64 x max_hosts
+		// records instead of taking all of that -- 1.3 GB at 10^7 services -- on the first bound-address listener.  Regions are offsets
+		// into the pool: they survive the move; kernels take the pool's address at launch.
+		const uint64_t bound = 4ull * c->cfg.max_services + 64ull * c->cfg.max_hosts;
+		if (c->cand_used + want > bound) {
 			set_err("listener candidate pool exhausted");
 			return GYS_ERR_NOMEM;
+		}
+		if (c->cand_used + want > c->cand_cap) {
+			uint64_t ncap = std::max<uint64_t>(c->cand_cap * 2, 4096);
+			while (ncap < c->cand_used + want) ncap *= 2;
+			ncap = std::min(ncap, bound);
+			ListenerCand *np = nullptr;
+			HIPCHK(hipMalloc((void **)&np, ncap * sizeof(ListenerCand)));
+			if (c->cand_pool) {
+				HIPCHK(hipMemcpyAsync(np, c->cand_pool, c->cand_used * sizeof(ListenerCand), hipMemcpyDeviceToDevice, c->stream));
+				HIPCHK(hipStreamSynchronize(c->stream)); // (every launch that reads the old pool is behind us on this stream)
+				HIPCHK(hipFree(c->cand_pool));
+			}
+			c->cand_pool = np;
+			c->cand_cap = ncap;
 		}
 		hl.cand_off = (uint32_t)c->cand_used;
 		hl.cand_cap = (uint32_t)want;
