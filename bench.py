@@ -959,7 +959,9 @@ def main():
             eng.handle_host_state(mids[h], ntasks=100, nlisten=args.svcs)
 
     # two device-resident batches, generated on the GPU before the timed region
-    nbuf = max(2, args.nbuf)  # distinct resident batches the windows cycle through (6 x 6.4 GB by default; 288 GB of HBM)
+    nbuf = max(2, args.nbuf)  # distinct resident batches the windows cycle through (6 x 12.9 GB by default; 288 GB of HBM)
+    if args.ipv6:
+        nbuf = min(nbuf, 3)   # (the 48-byte batches are twice the size and are built next to the 24-byte ones: 3 x 25.8 GB beside the engine's 118 GB)
     buf_uses = [0] * nbuf
     bufs, segs = [], []
     for b in range(nbuf):

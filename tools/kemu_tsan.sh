@@ -18,7 +18,7 @@
 SAN=${1:-thread}
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
 python -c "from oracle import oracle; oracle.lib()" || exit 1
-for t in bins resp spill conn cms wire lstate topn rollup svcquery; do
+for t in bins resp spill conn cms wire lstate topn rollup svcquery ldecide; do
 	g++ -std=c++20 -O1 -g -w -fsanitize=$SAN -DKEMU_NB=4 -Itests/cpp/kemu tests/cpp/kemu/test_$t.cc -o /tmp/kemu_${t}_$SAN -Loracle -l:liboracle.so -Wl,-rpath,$R/oracle -pthread || exit 1
 	TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=0" timeout 2400 /tmp/kemu_${t}_$SAN > /tmp/kemu_${t}_$SAN.log 2>&1
 	echo "== $t"; grep -E "SUMMARY|ERROR: AddressSanitizer|kemu $t ok|FAIL" /tmp/kemu_${t}_$SAN.log | sort | uniq -c
