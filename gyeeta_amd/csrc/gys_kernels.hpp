@@ -814,9 +814,6 @@ __global__ __launch_bounds__(256) void k_cms_reduce(const uint32_t *partial, uin
 #ifndef GYS_BK_BYTES
 #define GYS_BK_BYTES 1 // RESP_TIME_HASH bucket table as 1024 bytes (one ds_read_u8 at min(t, 1023)) instead of 256 packed words + shift / mask
 #endif
-#ifndef GYS_DROP_BALLOT
-#define GYS_DROP_BALLOT 0 // (r6: the compiler turns every ballot -- also of a single compare -- into a 0 / 1 select + a second compare: 2 VALU per ballot against 1 for the per-lane add with carry; left off) the two drop counters are kept per WAVE from the compare masks (s_bcnt1 on the scalar unit), not per lane with VALU adds
-#endif
 #ifndef GYS_PARK_INDEX
 #define GYS_PARK_INDEX 1 // the rank atomic of a place that kept nothing goes to s_ts[Lc_park + lane]: one select for the index, no select between two addresses
 #endif
@@ -982,11 +979,6 @@ __device__ __forceinline__ uint32_t gys_swap_pair(uint32_t v) // the neighbourin
 #else
 #define GYS_EV_LOAD(p) (*(p))
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
-#define GYS_BALLOT(pred) ((unsigned long long)__builtin_amdgcn_ballot_w64(pred)) // (the compare mask itself: __ballot() goes through a 0 / 1 value and a second compare)
-#else
-#define GYS_BALLOT(pred) ((unsigned long long)__ballot(pred))
-#endif
 #define GYS_MEM_FENCE() asm volatile("" ::: "memory") // compiler-only: memory operations are not moved across it (keeps a batch of LDS reads in front of the stores / the next batch)
 
 // MODE 0: IPv4 events, every listener of the batch's hosts alone on its (netns, port) key and bound to the any-address (the instance of the
@@ -1096,8 +1088,9 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 	uint32_t tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long t_prev__ = (unsigned long long)clock64();
 #endif
-	uint32_t wdrop_range = 0, wdrop_nol = 0; // GYS_DROP_BALLOT: the wave's counts (uniform)
-	uint32_t pf_sink = 0;                    // GYS_EV_PREFETCH: destination of the line-touching loads
+#if GYS_EV_PREFETCH
+	uint32_t pf_sink = 0; // destination of the line-touching loads
+#endif
 	const uint32_t tid24 = 24u * tid;
 	int32_t tmax = INT32_MIN, wmax = -1;
 	// PF: the twelve words of the NEXT group of four events per thread are requested while the current group is processed and wait in
@@ -1312,27 +1305,18 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 			uint32_t tresp[4], local[4];
 			uint64_t ea[4], eb[4];
 			bool ok[4], more[4];
-			unsigned long long m_ok[4];
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				const uint32_t netns = (uint32_t)w1[u];
 				const uint32_t sport = (uint32_t)bswap16((uint16_t)(w1[u] >> 32)); // ntohs :1526-1527
 				tresp[u] = (uint32_t)w2[u] - (uint32_t)(w2[u] >> 32);               // lsndtime - lrcvtime (:1519)
 				const bool range_ok = tresp[u] <= 1000000u;                         // "Ignore responses > 1000 sec or negative" (:1521-1524)
-#if GYS_DROP_BALLOT
-				// (per wave, on the scalar unit: ballots of SINGLE compares are the compare masks themselves -- a ballot of a combined condition
-				// goes through a 0 / 1 value and a second compare; part 0's workgroup is the one whose count is used, see the end)
-				const unsigned long long m_in = GYS_BALLOT(in[u]), m_rng = GYS_BALLOT(range_ok);
-				wdrop_range += (uint32_t)__popcll(m_in & ~m_rng);
-#else
-				if (in[u] && !range_ok && hd.part == 0u) ndrop_range++;              // (counted once per event: by the workgroup of part 0)
-#endif
+				// (counted once per event: by the workgroup of part 0.  Round 6 tried the two drop counters per WAVE from the compare masks -- s_bcnt1 on
+				// the scalar unit -- but hipcc turns every ballot, also of a single compare, into a 0 / 1 select + a second compare: 2 VALU against this add with carry)
+				if (in[u] && !range_ok && hd.part == 0u) ndrop_range++;
 				const uint32_t hk = host_tbl_hash(netns, sport);
 				// (a listener of another part of this host: that part's workgroup has the event)
 				const bool mine = (hk & (hd.pmask << 21)) == (hd.part << 21); // == (host_tbl_part(hk, hd.pmask) == hd.part), one shift less
-#if GYS_DROP_BALLOT
-				m_ok[u] = m_in & m_rng & GYS_BALLOT(mine);
-#endif
 				ok[u] = in[u] && range_ok && mine;
 				const uint32_t h = host_tbl_slot(hk, mask);
 				ea[u] = s_tbl[h];
@@ -1434,11 +1418,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				kept[u] = ok[u] && local[u] != GYS_NOSLOT;
-#if GYS_DROP_BALLOT
-				wdrop_nol += (uint32_t)__popcll(m_ok[u] & GYS_BALLOT(local[u] == GYS_NOSLOT)); // no such listener: the reference ignores the event too (:1671-1676 miss path)
-#else
 				if (ok[u] && local[u] == GYS_NOSLOT) ndrop_nol++; // no such listener: the reference ignores the event too (:1671-1676 miss path)
-#endif
 				nlr[u] = kept[u] ? local[u] : 0u;
 			}
 			if (SPILL) {
@@ -1760,8 +1740,6 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 					if (e < ntile && dd[j]) dstb[dd[j] + e] = vv[j];
 				}
 			}
-			// the next tile's HLL floor: the register file is re-read (L2 hits: every workgroup reads the same 64 KiB; behind the flush --
-			// held across it, the 16 registers of the four loads spill)
 #if GYS_FLOOR_QUARTER
 			if (fq_on) {
 				// quarter q of the register file was read by this tile; the slot (tile_no & 1) serves tile t + 2: min of this quarter's minimum
@@ -1776,12 +1754,11 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 					atomicMin(&s_floor[tile_no & 1u], min(min(mn, s_fqm[(qn + 1u) & 3u]), min(s_fqm[(qn + 2u) & 3u], s_fqm[(qn + 3u) & 3u])));
 				}
 			}
-			if (false) {
-				constexpr uint32_t NF = (1u << GYS_HLL_P) / 4u / T;
 #else
+			// the next tile's HLL floor: the whole register file is re-read (L2 hits: every workgroup reads the same 64 KiB; behind the flush --
+			// held across it, the 16 registers of the four loads spill)
 			if (!SPILL && t0 + 2ull * TILE < e1) {
 				constexpr uint32_t NF = (1u << GYS_HLL_P) / 4u / T;
-#endif
 				uint4 fv[NF];
 #pragma unroll
 				for (uint32_t j = 0; j < NF; ++j) fv[j] = ((const uint4 *)p.hll32)[tid + j * T];
@@ -1791,6 +1768,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 				mn = wave_min_u32(mn);
 				if (lane == 0) atomicMin(&s_floor[tile_no & 1u], mn);
 			}
+#endif
 		}
 		GYS_TICK(11); // flush + floor refresh
 		// (the next tile's event-phase barrier orders this tile's flush before destinations and image are rewritten)
@@ -1807,12 +1785,6 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 	if (wmax >= 0) tmax = wmax >> GYS_ROW_BITS;
 	tmax = wave_max_i32(tmax);
 	if (lane == 0 && tmax != INT32_MIN) atomicMax(&s_gmax, tmax);
-#if GYS_DROP_BALLOT
-	if (lane == 0) {
-		ndrop_range = hd.part == 0u ? wdrop_range : 0u; // (an event out of range is counted once: by the workgroup of part 0)
-		ndrop_nol = wdrop_nol;
-	}
-#endif
 	if (ndrop_range) atomicAdd(&s_drop[0], ndrop_range);
 	if (ndrop_nol) atomicAdd(&s_drop[1], ndrop_nol);
 	__syncthreads();
