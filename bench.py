@@ -1114,11 +1114,23 @@ def main():
         scan = {"services": nsvc, "quantiles": [0.25, 0.95, 0.99], "kernel_ms": sp_[0], "wall_ms_incl_copy_to_host": t_scan * 1e3,
                 "services_per_s": nsvc / (sp_[0] * 1e-3) if sp_[0] > 0 else None, "p99_mean_ms": float(qv[:, 2].mean())}
         try:  # the global response-time digest of this rank (what the C4 global query costs per rank before the slabs cross the ranks): every host's services rolled up, then the hosts
+            # (round 6: the roll-up is the union by value bin -- HBM-bound adds, no ordered fold.  The FIRST call after a registration also lays the
+            # hosts' member lists on the device (40 MB at 10^7 services); `global_rollup_ms` is the steady-state call, the first one is stated beside it.)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            _, gslab = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)
+            gdev, gslab = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)
+            scan["global_rollup_first_call_ms"] = (time.perf_counter() - t0) * 1e3
+            eng.profile(True)
+            eng.profile_reset()
+            t0 = time.perf_counter()
+            gdev, gslab = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)
             scan["global_rollup_ms"] = (time.perf_counter() - t0) * 1e3
+            pr = eng.profile_get()
+            eng.profile(False)
+            scan["global_rollup_kernels_ms"] = {k: v[0] for k, v in pr.items() if k.startswith("rollup")}
             scan["global_rollup_weight"] = int(gslab["cnt"].sum())
+            gq = eng.slab_quantiles(gdev, [0.25, 0.5, 0.95, 0.99])
+            scan["global_rollup_quantiles_ms"] = {"p25": gq[0], "p50": gq[1], "p95": gq[2], "p99": gq[3]}
         except Exception as ex:  # noqa: BLE001
             scan["global_rollup_error"] = str(ex)[:200]
     host_fed = None

@@ -416,6 +416,12 @@ struct gys_ctx {
 	// lazily folded records (t-digest on): hist_win and lvl_last change places at every close instead of a copy; lvl_last[slot] then is the service's
 	// record of window lvl_last_tag[slot] (written by the close's fold pass) and counts only when that is lvl_last_epoch, the window closed last
 	uint32_t *lvl_last_tag = nullptr;
+	// roll-up digests (gys_rollup.hpp): the groups' value bins (grows), the hosts' member lists on the device (rebuilt when services were registered)
+	unsigned long long *rb_bins = nullptr;
+	size_t rb_bins_groups = 0;
+	uint32_t *rb_host_members = nullptr;
+	RollupChunk *rb_host_chunks = nullptr;
+	uint32_t rb_host_nsvc = ~0u, rb_host_nh = ~0u, rb_host_nchunks = 0;
 	uint8_t *svc_bithist = nullptr; // [max_services][2] TCP_LISTENER::issue_bit_hist_ / high_resp_bit_hist_ (gys_decide_listener_state_dev; allocated on first use)
 	uint32_t lvl_last_epoch = 0;
 	int64_t *lvl_first = nullptr;     // [max_services] time (s) of the service's first window close (firstTime_ of its series), 0: none yet
@@ -2640,7 +2646,7 @@ void gys_destroy(gys_ctx *c)
 			c->batch_cnt, c->batch_off, c->scan_block_sums, c->ev_kv, c->staged, c->huge_scratch, c->huge_acc, c->huge_tail, c->huge_tb_list, c->huge_bm, c->huge_chunk_off, c->huge_fb_list, c->hll32, c->svc_ctr, c->svc_win, c->svc_state, c->svc_claim, c->svc_hll, c->host_summ_win, c->host_summ_last, c->host_state,
 			c->host_state_epoch, c->host_cluster, c->counters, c->misc, c->htbl, c->hlst, c->hdesc, c->wire_jump[0], c->wire_jump[1], c->wire_cnt,
 			c->wire_rank, c->wire_bsums, c->wire_status, c->wire_mark, c->wire_flags, c->wire_msgs, c->last, c->last_act32, c->last_act64, c->ring_act32, c->ring_act64, c->act_live, c->q_cand_key, c->q_out_keys, c->q_cand_slot, c->q_misc, c->q_host_mask, c->q_slot_list, c->q_set, c->q_out_rows, c->q_acc, c->q_cnt, c->dev_staging, c->dev_offsets, c->csr_off, c->csr_mem, c->svc_act, c->d_epoch, c->topn_slot,
-			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_last_tag, c->svc_bithist, c->lvl_first, c->qps_hist, c->act_hist, c->cand_pool, c->own_arena ? c->arena : nullptr};
+			c->topn_metric, c->dev_pcts, c->zipf_cdf, c->lvl_snap, c->lvl_last, c->lvl_last_tag, c->svc_bithist, c->rb_bins, c->rb_host_members, c->rb_host_chunks, c->lvl_first, c->qps_hist, c->act_hist, c->cand_pool, c->own_arena ? c->arena : nullptr};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -3932,36 +3938,69 @@ static int topn_all_hosts(gys_ctx *c, int kind, std::vector<uint32_t> &slots, st
 }
 
 // ------------------------------------------------------------------------------------------------ roll-up digests
-static int rollup_launch(gys_ctx *c, int kind, const std::vector<uint32_t> &off, const std::vector<uint32_t> &members, const gys_tdigest_slab *d_in,
-			 gys_tdigest_slab *d_out)
+#define GYS_RB_CHUNK_SERVICES 1024u // members a workgroup of k_rollup_accum adds up before it hands its bins to the group's
+#define GYS_RB_CHUNK_SLABS 32u
+
+static void rollup_chunks(const std::vector<uint32_t> &off, uint32_t per, std::vector<RollupChunk> &chunks)
 {
-	const uint32_t ngroups = (uint32_t)off.size() - 1;
+	for (uint32_t g = 0; g + 1 < (uint32_t)off.size(); ++g)
+		for (uint32_t m = off[g]; m < off[g + 1]; m += per) chunks.push_back(RollupChunk{g, m, std::min(off[g + 1], m + per), 0u});
+}
+
+// bins of `ngroups` groups <- the members the chunks name; slabs out.  d_chunks / d_members: DEVICE arrays.
+static int rollup_run(gys_ctx *c, int kind, const RollupChunk *d_chunks, uint32_t nchunks, const uint32_t *d_members, uint32_t ngroups,
+		      const gys_tdigest_slab *d_in, gys_tdigest_slab *d_out)
+{
 	if (!ngroups) return GYS_OK;
-	uint32_t *d_off = nullptr, *d_mem = nullptr;
-	HIPCHK(hipMalloc((void **)&d_off, off.size() * 4));
-	HIPCHK(hipMalloc((void **)&d_mem, std::max<size_t>(members.size(), 1) * 4));
-	HIPCHK(hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
-	if (!members.empty()) HIPCHK(hipMemcpyAsync(d_mem, members.data(), members.size() * 4, hipMemcpyHostToDevice, c->stream));
+	if (c->rb_bins_groups < ngroups) {
+		if (c->rb_bins) {
+			HIPCHK(hipStreamSynchronize(c->stream));
+			HIPCHK(hipFree(c->rb_bins));
+			c->rb_bins = nullptr;
+			c->rb_bins_groups = 0;
+		}
+		HIPCHK(hipMalloc((void **)&c->rb_bins, (size_t)ngroups * GYS_RB_STRIDE * 8));
+		c->rb_bins_groups = ngroups;
+	}
 	RollupP rp{};
 	rp.d = digest_params(c);
-	rp.off = d_off;
-	rp.members = d_mem;
+	rp.chunks = d_chunks;
+	rp.nchunks = nchunks;
+	rp.members = d_members;
 	rp.kind = kind;
 	rp.in = d_in;
+	rp.bins = c->rb_bins;
 	rp.out = d_out;
 	rp.ngroups = ngroups;
 	{
 		ProfScope ps(c, kind == 0 ? "rollup_services" : "rollup_slabs");
-		const dim3 rgrid(std::min<uint32_t>(ngroups, (uint32_t)c->ncu * 4));
-		if (c->pend_cap <= 1024u) hipLaunchKernelGGL(k_digest_rollup<4u>, rgrid, dim3(256), 0, c->stream, rp);
-		else if (c->pend_cap <= 2048u) hipLaunchKernelGGL(k_digest_rollup<8u>, rgrid, dim3(256), 0, c->stream, rp);
-		else hipLaunchKernelGGL(k_digest_rollup<16u>, rgrid, dim3(256), 0, c->stream, rp);
+		const size_t words = (size_t)ngroups * GYS_RB_STRIDE;
+		hipLaunchKernelGGL(k_rollup_init, dim3((uint32_t)std::min<size_t>((words + 255) / 256, (size_t)c->ncu * 16)), dim3(256), 0, c->stream, c->rb_bins, ngroups);
+		if (nchunks) hipLaunchKernelGGL(k_rollup_accum, dim3(std::min<uint32_t>(nchunks, (uint32_t)c->ncu * 16)), dim3(GYS_RB_NT), 0, c->stream, rp);
+		hipLaunchKernelGGL(k_rollup_cluster, dim3(std::min<uint32_t>(ngroups, (uint32_t)c->ncu * 8)), dim3(256), 0, c->stream, rp);
 	}
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipStreamSynchronize(c->stream)); // the member lists are freed below
-	HIPCHK(hipFree(d_off));
-	HIPCHK(hipFree(d_mem));
 	return GYS_OK;
+}
+
+// groups of slabs (kind 1): the lists travel with the call
+static int rollup_slabs(gys_ctx *c, const std::vector<uint32_t> &off, const std::vector<uint32_t> &members, const gys_tdigest_slab *d_in, gys_tdigest_slab *d_out)
+{
+	const uint32_t ngroups = (uint32_t)off.size() - 1;
+	if (!ngroups) return GYS_OK;
+	std::vector<RollupChunk> chunks;
+	rollup_chunks(off, GYS_RB_CHUNK_SLABS, chunks);
+	RollupChunk *d_chunks = nullptr;
+	uint32_t *d_mem = nullptr;
+	HIPCHK(hipMalloc((void **)&d_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(RollupChunk)));
+	HIPCHK(hipMalloc((void **)&d_mem, std::max<size_t>(members.size(), 1) * 4));
+	if (!chunks.empty()) HIPCHK(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(RollupChunk), hipMemcpyHostToDevice, c->stream));
+	if (!members.empty()) HIPCHK(hipMemcpyAsync(d_mem, members.data(), members.size() * 4, hipMemcpyHostToDevice, c->stream));
+	const int rc = rollup_run(c, 1, d_chunks, (uint32_t)chunks.size(), d_mem, ngroups, d_in, d_out);
+	HIPCHK(hipStreamSynchronize(c->stream)); // the lists are freed below
+	HIPCHK(hipFree(d_chunks));
+	HIPCHK(hipFree(d_mem));
+	return rc;
 }
 
 int gys_tdigest_rollup_dev(gys_ctx *c, int scope, gys_tdigest_slab *d_out)
@@ -3974,41 +4013,37 @@ try {
 		if (scope == GYS_ROLLUP_GLOBAL) HIPCHK(hipMemsetAsync(d_out, 0, sizeof(gys_tdigest_slab), c->stream));
 		return GYS_OK;
 	}
-	// host level: members = the host's services in slot order
-	std::vector<uint32_t> off(nh + 1, 0), members;
-	members.reserve(c->nsvc);
-	for (uint32_t h = 0; h < nh; ++h) {
-		std::vector<uint32_t> sl = c->host_lst[h].all_slots;
-		std::sort(sl.begin(), sl.end());
-		members.insert(members.end(), sl.begin(), sl.end());
-		off[h + 1] = (uint32_t)members.size();
+	// host level: members = the host's services.  The lists stay on the device until a service or a host is registered (10^7 services: 40 MB).
+	if (c->rb_host_nsvc != c->nsvc || c->rb_host_nh != nh) {
+		std::vector<uint32_t> off(nh + 1, 0), members;
+		members.reserve(c->nsvc);
+		for (uint32_t h = 0; h < nh; ++h) {
+			const std::vector<uint32_t> &sl = c->host_lst[h].all_slots;
+			members.insert(members.end(), sl.begin(), sl.end());
+			off[h + 1] = (uint32_t)members.size();
+		}
+		std::vector<RollupChunk> chunks;
+		rollup_chunks(off, GYS_RB_CHUNK_SERVICES, chunks);
+		HIPCHK(hipStreamSynchronize(c->stream));
+		if (c->rb_host_members) HIPCHK(hipFree(c->rb_host_members));
+		if (c->rb_host_chunks) HIPCHK(hipFree(c->rb_host_chunks));
+		c->rb_host_members = nullptr;
+		c->rb_host_chunks = nullptr;
+		c->rb_host_nsvc = ~0u;
+		HIPCHK(hipMalloc((void **)&c->rb_host_members, std::max<size_t>(members.size(), 1) * 4));
+		HIPCHK(hipMalloc((void **)&c->rb_host_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(RollupChunk)));
+		if (!members.empty()) HIPCHK(hipMemcpy(c->rb_host_members, members.data(), members.size() * 4, hipMemcpyHostToDevice));
+		if (!chunks.empty()) HIPCHK(hipMemcpy(c->rb_host_chunks, chunks.data(), chunks.size() * sizeof(RollupChunk), hipMemcpyHostToDevice));
+		c->rb_host_nchunks = (uint32_t)chunks.size();
+		c->rb_host_nsvc = c->nsvc;
+		c->rb_host_nh = nh;
 	}
 	gys_tdigest_slab *d_hosts = d_out;
 	if (scope != GYS_ROLLUP_HOST) HIPCHK(hipMalloc((void **)&d_hosts, sizeof(gys_tdigest_slab) * nh));
-	int rc = rollup_launch(c, 0, off, members, nullptr, d_hosts);
+	int rc = rollup_run(c, 0, c->rb_host_chunks, c->rb_host_nchunks, c->rb_host_members, nh, nullptr, d_hosts);
 	if (rc == GYS_OK && scope != GYS_ROLLUP_HOST) {
 		std::vector<uint32_t> goff, gmem;
-		if (scope == GYS_ROLLUP_GLOBAL && nh > GYS_ROLLUP_FANIN) {
-			// round 6: the hosts' slabs are folded in two levels -- chunks of GYS_ROLLUP_FANIN consecutive host slots in parallel (each in host-slot
-			// order), then the chunks' slabs in order -- instead of one workgroup walking all of them: 10^4 hosts are 79 + 128 sequential member
-			// steps, not 10^4.  (A rank with at most GYS_ROLLUP_FANIN hosts folds them directly, as before.)
-			const uint32_t nchunks = (nh + GYS_ROLLUP_FANIN - 1u) / GYS_ROLLUP_FANIN;
-			std::vector<uint32_t> coff(nchunks + 1), cmem(nh);
-			for (uint32_t k = 0; k <= nchunks; ++k) coff[k] = std::min(nh, k * GYS_ROLLUP_FANIN);
-			for (uint32_t h = 0; h < nh; ++h) cmem[h] = h;
-			gys_tdigest_slab *d_mid = nullptr;
-			HIPCHK(hipMalloc((void **)&d_mid, sizeof(gys_tdigest_slab) * nchunks));
-			rc = rollup_launch(c, 1, coff, cmem, d_hosts, d_mid);
-			if (rc == GYS_OK) {
-				goff = {0u, nchunks};
-				gmem.resize(nchunks);
-				for (uint32_t k = 0; k < nchunks; ++k) gmem[k] = k;
-				rc = rollup_launch(c, 1, goff, gmem, d_mid, d_out);
-			}
-			HIPCHK(hipFree(d_mid));
-			HIPCHK(hipFree(d_hosts));
-			return rc;
-		} else if (scope == GYS_ROLLUP_GLOBAL) {
+		if (scope == GYS_ROLLUP_GLOBAL) { // one group: every host slab
 			goff = {0u, nh};
 			gmem.resize(nh);
 			for (uint32_t h = 0; h < nh; ++h) gmem[h] = h;
@@ -4021,9 +4056,12 @@ try {
 				goff[cl + 1] = (uint32_t)gmem.size();
 			}
 		}
-		rc = rollup_launch(c, 1, goff, gmem, d_hosts, d_out);
+		rc = rollup_slabs(c, goff, gmem, d_hosts, d_out);
 	}
-	if (scope != GYS_ROLLUP_HOST) HIPCHK(hipFree(d_hosts));
+	if (scope != GYS_ROLLUP_HOST) {
+		HIPCHK(hipStreamSynchronize(c->stream));
+		HIPCHK(hipFree(d_hosts));
+	}
 	return rc;
 } GYS_CATCH_ALL
 
@@ -4033,7 +4071,7 @@ try {
 	if (!c || !d_in || !d_out || n == 0) return GYS_ERR_INVAL;
 	std::vector<uint32_t> off{0u, n}, mem(n);
 	for (uint32_t i = 0; i < n; ++i) mem[i] = i;
-	return rollup_launch(c, 1, off, mem, d_in, d_out);
+	return rollup_slabs(c, off, mem, d_in, d_out);
 } GYS_CATCH_ALL
 
 int gys_tdigest_slab_quantiles(gys_ctx *c, const gys_tdigest_slab *d_slab, const double *q, uint32_t nq, double *out)

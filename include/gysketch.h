@@ -363,23 +363,24 @@ int gys_scan_quantiles_dev(gys_ctx *ctx, const double *q, uint32_t nq, double *d
  * Roll-up digests: the response-time digest of a GROUP of services -- a host, a cluster, all hosts of this rank ("global") -- and the
  * merge of such digests across ranks.  Replaces the aggregated percentile Postgres computes over a set of listeners' rows,
  * public.tdigest_percentile(col, 100, p) (common/gy_query_common.cc:1818-1855), and feeds the fan-in of
- * SHCONN_HANDLER::aggregate_cluster_state (server/gy_shconnhdlr.cc:4583-4720).  Definition (oracle/gy_oracle_rollup.c): left fold over
- * the members in slot order of d := merge(d, member); a service contributes its clusters, then its buffered values; a roll-up digest
- * contributes its clusters; 64-bit counters.  Fixed-size slab = the unit a multi-rank job all-gathers (ncclAllGather of
- * sizeof(gys_tdigest_slab) bytes per rank) and folds in rank order with gys_tdigest_merge_slabs_dev. */
+ * SHCONN_HANDLER::aggregate_cluster_state (server/gy_shconnhdlr.cc:4583-4720).  Definition (oracle/gy_oracle_rollup.c, gyo_tdbins_*; round 6:
+ * no longer an ordered fold): the UNION BY VALUE BIN -- every member's non-empty clusters go, whole, into the value bin (one per millisecond
+ * below 1024, 64 cells per octave above) of the integer threshold of their mean, a service's buffered values into the bin of the value; the
+ * bins' exact 64-bit {sum, count} are then laid on the rank axis in order and cut into the 200 clusters by the engine's cluster rule, a bin
+ * that spans a cluster boundary sharing its sum in proportion (exact integers).  The result does not depend on the order of the members.  A
+ * roll-up digest as a member contributes its clusters the same way.  Fixed-size slab = the unit a multi-rank job all-gathers (ncclAllGather
+ * of sizeof(gys_tdigest_slab) bytes per rank) and rolls up with gys_tdigest_merge_slabs_dev. */
 typedef struct {
 	int64_t sum[GYS_TD_NB];
 	uint64_t cnt[GYS_TD_NB];
 	int64_t vmin, vmax; /* valid when any cnt != 0 */
 } gys_tdigest_slab;
 enum { GYS_ROLLUP_HOST = 0, GYS_ROLLUP_CLUSTER = 1, GYS_ROLLUP_GLOBAL = 2 };
-#define GYS_ROLLUP_FANIN 128u
-/* d_out (DEVICE): HOST: one slab per host slot [gys_num_hosts]; CLUSTER: one per registered cluster index (fold of its hosts' slabs in
- * host-slot order); GLOBAL: one slab -- the fold of all host slabs in host-slot order when the rank has at most GYS_ROLLUP_FANIN hosts, else
- * (round 6) the fold, in order, of the slabs of the chunks of GYS_ROLLUP_FANIN consecutive host slots, each the fold of its hosts' slabs in
- * host-slot order (the chunks are folded in parallel).  No engine state is modified. */
+/* d_out (DEVICE): HOST: one slab per host slot [gys_num_hosts] -- the roll-up of the host's services; CLUSTER: one per registered cluster
+ * index -- the roll-up of its hosts' slabs; GLOBAL: one slab -- the roll-up of all host slabs of this rank.  No engine state is modified (the
+ * hosts' member lists are kept on the device between calls and rebuilt after a registration). */
 int gys_tdigest_rollup_dev(gys_ctx *ctx, int scope, gys_tdigest_slab *d_out);
-/* d_out[0] (DEVICE) = fold of d_in[0..n) in order (the cross-rank merge after an all-gather; also any caller-defined group) */
+/* d_out[0] (DEVICE) = roll-up of the slabs d_in[0..n) (the cross-rank merge after an all-gather; also any caller-defined group) */
 int gys_tdigest_merge_slabs_dev(gys_ctx *ctx, const gys_tdigest_slab *d_in, uint32_t n, gys_tdigest_slab *d_out);
 /* quantiles q[i] (0..1) of one DEVICE slab into the HOST array out (same interpolation and rounding as gys_query_quantiles) */
 int gys_tdigest_slab_quantiles(gys_ctx *ctx, const gys_tdigest_slab *d_slab, const double *q, uint32_t nq, double *out);
@@ -399,8 +400,8 @@ int gys_rccl_comm_destroy(void *comm);
 /* gys_window_prepare, then the four register families of gys_reduce_sections all-reduced in place (u8 MAX, u32 SUM, i64 SUM, i64 MAX)
  * as ONE ncclGroup on the context stream, then gys_window_finish.  Asynchronous like every other call (gys_sync to wait). */
 int gys_window_close_rccl(gys_ctx *ctx, void *comm, uint64_t tusec);
-/* the global response-time digest across ranks: this rank's GYS_ROLLUP_GLOBAL slab, ncclAllGather of the fixed-size slabs, fold in
- * rank order (gys_tdigest_merge_slabs_dev) into d_out[0] (DEVICE) -- the same slab on every rank */
+/* the global response-time digest across ranks: this rank's GYS_ROLLUP_GLOBAL slab, ncclAllGather of the fixed-size slabs, their
+ * roll-up (gys_tdigest_merge_slabs_dev) into d_out[0] (DEVICE) -- the same slab on every rank */
 int gys_tdigest_global_rccl(gys_ctx *ctx, void *comm, gys_tdigest_slab *d_out);
 
 /* -------------------------------------------------------------------------------------------------------------------

@@ -196,6 +196,19 @@ void gyo_td64_merge_values(gyo_td64 *d, const int32_t *vals, size_t m);
 void gyo_td64_merge_service(gyo_td64 *d, const gyo_td_buffered *b); /* the service's clusters, then its buffered values */
 void gyo_td64_merge_td64(gyo_td64 *d, const gyo_td64 *o);
 double gyo_td64_quantile(const gyo_td64 *d, double q);
+/* the roll-up of a group (round 6): union by value bin -- members are ADDED in any order, gyo_tdbins_finish makes the group's digest */
+#define GYO_TD_BINS 2048
+typedef struct {
+	uint64_t cnt[GYO_TD_BINS];
+	uint64_t sum[GYO_TD_BINS];
+	int64_t vmin, vmax;
+} gyo_td_bins;
+uint32_t gyo_td_value_bin(uint32_t v);
+void gyo_tdbins_init(gyo_td_bins *b);
+void gyo_tdbins_add_values(gyo_td_bins *b, const int32_t *vals, size_t m);
+void gyo_tdbins_add_service(gyo_td_bins *b, const gyo_td_buffered *s); /* its clusters and its buffered values */
+void gyo_tdbins_add_td64(gyo_td_bins *b, const gyo_td64 *o);           /* a roll-up digest's clusters */
+void gyo_tdbins_finish(const gyo_td_bins *b, gyo_td64 *out);
 int gyo_tcp_conn_pair_batch(const uint8_t *batch, int nrec, const uint8_t *pend, uint32_t *pair32, uint64_t *pair64, uint32_t *cpair32, uint64_t *cpair64);
 void gyo_active_conn_sketch_batch(const uint8_t *batch, int nrec, uint32_t *pair32 /*[D*W]*/, uint64_t *pair64 /*[D*W]*/, uint64_t out[2]);
 void gyo_active_conn_sketch_batch2(const uint8_t *batch, int nrec, uint32_t *pair32, uint64_t *pair64, uint32_t *rpair32, uint64_t *rpair64, uint64_t out[2]);

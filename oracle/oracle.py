@@ -83,6 +83,13 @@ class TD64(C.Structure):
     _fields_ = [("sum", C.c_int64 * TD_NB), ("cnt", C.c_uint64 * TD_NB), ("vmin", C.c_int64), ("vmax", C.c_int64)]
 
 
+TD_BINS = 2048
+
+
+class TDBins(C.Structure):
+    _fields_ = [("cnt", C.c_uint64 * TD_BINS), ("sum", C.c_uint64 * TD_BINS), ("vmin", C.c_int64), ("vmax", C.c_int64)]
+
+
 class BTS(C.Structure):
     _fields_ = [("duration", C.c_int64), ("nbuckets", C.c_uint32), ("first_time", C.c_int64), ("latest_time", C.c_int64),
                 ("tot_sum", C.c_int64), ("tot_cnt", C.c_uint64), ("bsum", C.c_int64 * BTS_MAXB), ("bcnt", C.c_uint64 * BTS_MAXB)]
@@ -210,6 +217,12 @@ def lib():
     _sig(L, "gyo_td64_merge_service", None, [C.POINTER(TD64), C.POINTER(TDBuffered)])
     _sig(L, "gyo_td64_merge_td64", None, [C.POINTER(TD64), C.POINTER(TD64)])
     _sig(L, "gyo_td64_quantile", C.c_double, [C.POINTER(TD64), C.c_double])
+    _sig(L, "gyo_td_value_bin", C.c_uint32, [C.c_uint32])
+    _sig(L, "gyo_tdbins_init", None, [C.POINTER(TDBins)])
+    _sig(L, "gyo_tdbins_add_values", None, [C.POINTER(TDBins), i32p, C.c_size_t])
+    _sig(L, "gyo_tdbins_add_service", None, [C.POINTER(TDBins), C.POINTER(TDBuffered)])
+    _sig(L, "gyo_tdbins_add_td64", None, [C.POINTER(TDBins), C.POINTER(TD64)])
+    _sig(L, "gyo_tdbins_finish", None, [C.POINTER(TDBins), C.POINTER(TD64)])
     _sig(L, "gyo_active_conn_sketch_batch", None, [u8p, C.c_int, u32p, u64p, u64p])
     _sig(L, "gyo_active_conn_sketch_batch2", None, [u8p, C.c_int, u32p, u64p, u32p, u64p, u64p])
     _sig(L, "gyo_tcp_conn_pair_batch", C.c_int, [u8p, C.c_int, u8p, u32p, u64p, u32p, u64p])
@@ -541,3 +554,25 @@ class OracleEngine:
 
     def window_clear(self, clear_hist=False):
         self.L.gyo_engine_window_clear(self.h, 1 if clear_hist else 0)
+
+
+def rollup_services(tds):
+    """the roll-up digest (TD64) of a group of services given as TDBuffered objects: gyo_tdbins_* (union by value bin; any order)"""
+    L = lib()
+    b, out = TDBins(), TD64()
+    L.gyo_tdbins_init(C.byref(b))
+    for t in tds:
+        L.gyo_tdbins_add_service(C.byref(b), C.byref(t))
+    L.gyo_tdbins_finish(C.byref(b), C.byref(out))
+    return out
+
+
+def rollup_slabs(slabs):
+    """the roll-up digest (TD64) of a group of roll-up digests (TD64)"""
+    L = lib()
+    b, out = TDBins(), TD64()
+    L.gyo_tdbins_init(C.byref(b))
+    for t in slabs:
+        L.gyo_tdbins_add_td64(C.byref(b), C.byref(t))
+    L.gyo_tdbins_finish(C.byref(b), C.byref(out))
+    return out

@@ -1,9 +1,10 @@
-// TEST INFRASTRUCTURE (CPU): the LOGIC of the roll-up digests k_digest_rollup (gyeeta_amd/csrc/gys_rollup.hpp) under the CPU stand-in of
-// the device model: the digest of a GROUP of services (kind 0: a left fold over the members of d := merge(d, member's clusters), then the
-// member's buffered values) and of a group of roll-up slabs (kind 1: the cross-rank fold), with 64-bit counters -- groups of 0, 1 and many
-// members, members without clusters, without buffered values and without anything, all-equal values, values >= 1024 ms, and a group
-// whose weight passes 2^32 -- equal, cluster by cluster, to the oracle's gyo_td64_merge_service / gyo_td64_merge_td64 folds
-// (oracle/gy_oracle_rollup.c), minimum / maximum included.  Build + run: tests/test_kernel_logic_cpu.py.
+// TEST INFRASTRUCTURE (CPU): the LOGIC of the roll-up digests k_rollup_accum / k_rollup_cluster (gyeeta_amd/csrc/gys_rollup.hpp) under the CPU
+// stand-in of the device model: the digest of a GROUP of services (kind 0: the union by value bin of the members' clusters and buffered values)
+// and of a group of roll-up slabs (kind 1: the cross-rank / cluster / global roll-up), with 64-bit counters -- groups of 0, 1 and many members,
+// members without clusters, without buffered values and without anything, all-equal values, values >= 1024 ms, a group whose weight passes
+// 2^32, groups cut into several chunks (several workgroups add to one group's bins), a buffer stride that is not a multiple of four words
+// (argument 2) -- equal, cluster by cluster, to the oracle's gyo_tdbins_* (oracle/gy_oracle_rollup.c), minimum / maximum included, and
+// independent of the order of the members.  Build + run: tests/test_kernel_logic_cpu.py.
 #define GYS_OPAQUE_VGPR(x) asm volatile("" : "+r"(x))
 #define GYS_OPAQUE_LOADED4(a) asm volatile("" : "+r"(a[0]), "+r"(a[1]), "+r"(a[2]), "+r"(a[3]))
 #define GYS_DYN_LDS(type, name) type *name = (type *)kemu::dyn_lds()
@@ -53,12 +54,12 @@ void compare(const char *what, uint32_t g, const gys_tdigest_slab &got, const gy
 
 int main(int argc, char **argv)
 {
-	if (!kemu::can_run(256u)) {
-		printf("kemu: this process cannot have 256 threads\n");
+	if (!kemu::can_run(GYS_RB_NT)) {
+		printf("kemu: this process cannot have 512 threads\n");
 		return 77;
 	}
 	std::mt19937 rng(argc > 1 ? (unsigned)atoi(argv[1]) : 9u);
-	const uint32_t S = 36, pcap = GYS_TD_PEND_CAP + 64u;
+	const uint32_t S = 36, pcap = GYS_TD_PEND_CAP + 64u + (argc > 2 ? (uint32_t)atoi(argv[2]) : 0u);
 	std::vector<gyo_td_buffered> svc(S);
 	std::vector<int64_t> td_sum((size_t)S * GYS_TD_NB, 0);
 	std::vector<uint32_t> td_cnt((size_t)S * GYS_TD_NB, 0), td_pend((size_t)S * pcap, 0xDEADBEEFu);
@@ -106,7 +107,7 @@ int main(int argc, char **argv)
 		std::vector<uint32_t> all(S);
 		for (uint32_t s = 0; s < S; ++s) all[s] = s;
 		groups.push_back(all);
-		std::vector<uint32_t> rev(all.rbegin(), all.rend()); // (the fold is ordered: the reverse order is another digest)
+		std::vector<uint32_t> rev(all.rbegin(), all.rend()); // (the same digest: the union does not depend on the order)
 		groups.push_back(rev);
 	}
 	std::vector<uint32_t> off(1, 0), members;
@@ -116,53 +117,84 @@ int main(int argc, char **argv)
 	}
 	if (members.empty()) members.push_back(0);
 	const uint32_t NG = (uint32_t)groups.size();
-	std::vector<gys_tdigest_slab> slabs(NG);
-	memset(slabs.data(), 0xAB, sizeof(gys_tdigest_slab) * NG);
-	RollupP q{};
-	q.d.td_sum = td_sum.data();
-	q.d.td_cnt = td_cnt.data();
-	q.d.td_meta = meta.data();
-	q.d.td_minmax = minmax.data();
-	q.d.td_pend = td_pend.data();
-	q.d.pcap = pcap;
-	q.d.pend_cap = GYS_TD_PEND_CAP;
-	q.d.nsvc = S;
-	q.off = off.data();
-	q.members = members.data();
-	q.kind = 0;
-	q.out = slabs.data();
-	q.ngroups = NG;
-	kemu::launch(3, 256, 0, [&] { k_digest_rollup(q); }); // (fewer workgroups than groups: they loop)
+	auto make_chunks = [](const std::vector<uint32_t> &o, uint32_t per) {
+		std::vector<RollupChunk> ch;
+		for (uint32_t g = 0; g + 1 < o.size(); ++g)
+			for (uint32_t m = o[g]; m < o[g + 1]; m += per) ch.push_back(RollupChunk{g, m, std::min(o[g + 1], m + per), 0u});
+		if (ch.empty()) ch.push_back(RollupChunk{0, 0, 0, 0});
+		return ch;
+	};
 	std::vector<gyo_td64> want(NG);
 	uint64_t heavy = 0;
 	for (uint32_t g = 0; g < NG; ++g) {
-		gyo_td64_init(&want[g]);
-		for (uint32_t s : groups[g]) gyo_td64_merge_service(&want[g], &svc[s]);
-		compare("services", g, slabs[g], want[g]);
+		gyo_td_bins *b = new gyo_td_bins;
+		gyo_tdbins_init(b);
+		for (uint32_t s : groups[g]) gyo_tdbins_add_service(b, &svc[s]);
+		gyo_tdbins_finish(b, &want[g]);
+		delete b;
 		heavy = std::max(heavy, gyo_td64_total(&want[g]));
 	}
 	CHECK(heavy > (1ull << 32), "no group passed 2^32 (%llu)", (unsigned long long)heavy);
-	// groups of slabs (the cross-rank fold): the slabs above, in two orders and with an empty one in the middle
-	std::vector<std::vector<uint32_t>> sg = {{3, 4, 7}, {7, 0, 4, 3}, {0}, {}, {8, 7}};
+	CHECK(memcmp(&want[NG - 1], &want[NG - 2], sizeof(gyo_td64)) == 0, "the oracle's roll-up depends on the order of the members");
+	std::vector<gys_tdigest_slab> slabs(NG);
+	for (uint32_t per : {1024u, 5u}) { // one chunk per group; chunks of five members: up to eight workgroups add to one group's bins
+		std::vector<RollupChunk> chunks = make_chunks(off, per);
+		std::vector<unsigned long long> bins((size_t)NG * GYS_RB_STRIDE, 0xABABABABABABABABull);
+		memset(slabs.data(), 0xAB, sizeof(gys_tdigest_slab) * NG);
+		RollupP q{};
+		q.d.td_sum = td_sum.data();
+		q.d.td_cnt = td_cnt.data();
+		q.d.td_meta = meta.data();
+		q.d.td_minmax = minmax.data();
+		q.d.td_pend = td_pend.data();
+		q.d.pcap = pcap;
+		q.d.pend_cap = GYS_TD_PEND_CAP;
+		q.d.nsvc = S;
+		q.chunks = chunks.data();
+		q.nchunks = (uint32_t)chunks.size();
+		q.members = members.data();
+		q.kind = 0;
+		q.bins = bins.data();
+		q.out = slabs.data();
+		q.ngroups = NG;
+		kemu::launch(2, 256, 0, [&] { k_rollup_init(q.bins, NG); });
+		kemu::launch(3, GYS_RB_NT, 0, [&] { k_rollup_accum(q); }); // (fewer workgroups than chunks: they loop)
+		kemu::launch(2, 256, 0, [&] { k_rollup_cluster(q); });
+		for (uint32_t g = 0; g < NG; ++g) compare(per == 5u ? "services in chunks of 5" : "services", g, slabs[g], want[g]);
+	}
+	// groups of slabs (the cross-rank roll-up): the slabs above, in two orders and with an empty one in the middle
+	std::vector<std::vector<uint32_t>> sg = {{3, 4, 7}, {7, 0, 4, 3}, {0}, {}, {8, 7}, {7, 8}};
 	std::vector<uint32_t> soff(1, 0), smem;
 	for (auto &g : sg) {
 		smem.insert(smem.end(), g.begin(), g.end());
 		soff.push_back((uint32_t)smem.size());
 	}
 	std::vector<gys_tdigest_slab> out2(sg.size());
-	RollupP q2 = q;
-	q2.kind = 1;
-	q2.in = slabs.data();
-	q2.off = soff.data();
-	q2.members = smem.data();
-	q2.out = out2.data();
-	q2.ngroups = (uint32_t)sg.size();
-	kemu::launch((uint32_t)sg.size(), 256, 0, [&] { k_digest_rollup(q2); });
-	for (uint32_t g = 0; g < sg.size(); ++g) {
-		gyo_td64 w;
-		gyo_td64_init(&w);
-		for (uint32_t m : sg[g]) gyo_td64_merge_td64(&w, &want[m]);
-		compare("slabs", g, out2[g], w);
+	for (uint32_t per : {32u, 1u}) {
+		std::vector<RollupChunk> chunks = make_chunks(soff, per);
+		std::vector<unsigned long long> bins(sg.size() * GYS_RB_STRIDE, 0xABABABABABABABABull);
+		memset(out2.data(), 0xAB, sizeof(gys_tdigest_slab) * sg.size());
+		RollupP q2{};
+		q2.kind = 1;
+		q2.in = slabs.data();
+		q2.chunks = chunks.data();
+		q2.nchunks = (uint32_t)chunks.size();
+		q2.members = smem.data();
+		q2.bins = bins.data();
+		q2.out = out2.data();
+		q2.ngroups = (uint32_t)sg.size();
+		kemu::launch(1, 256, 0, [&] { k_rollup_init(q2.bins, q2.ngroups); });
+		kemu::launch(4, GYS_RB_NT, 0, [&] { k_rollup_accum(q2); });
+		kemu::launch((uint32_t)sg.size(), 256, 0, [&] { k_rollup_cluster(q2); });
+		for (uint32_t g = 0; g < sg.size(); ++g) {
+			gyo_td_bins *b = new gyo_td_bins;
+			gyo_td64 w;
+			gyo_tdbins_init(b);
+			for (uint32_t m : sg[g]) gyo_tdbins_add_td64(b, &want[m]);
+			gyo_tdbins_finish(b, &w);
+			delete b;
+			compare(per == 1u ? "slabs one by one" : "slabs", g, out2[g], w);
+		}
 	}
 	if (fails) {
 		printf("kemu rollup: %d FAILURES\n", fails);

@@ -274,9 +274,9 @@ def test_scan_quantiles_equals_per_key_queries_and_oracle(torch_mod, oracle):
 
 def test_tdigest_rollup_host_cluster_global_bit_exact(torch_mod, oracle):
     """merged digests of groups of services: per host, per cluster and over all hosts, every slab equal to the
-    oracle's left fold (oracle/gy_oracle_rollup.c) bit for bit -- members with clusters + buffered values, buffer-only members,
+    oracle's roll-up (oracle/gy_oracle_rollup.c: the union by value bin) bit for bit -- members with clusters + buffered values, buffer-only members,
     empty members; then the cross-rank form: slabs of two engines (two ranks' shards, different streams), concatenated as an all-gather would
-    and folded in rank order, equal to the oracle's fold of the two global slabs"""
+    and rolled up, equal to the oracle's roll-up of the two global slabs"""
     import ctypes as C
     torch = torch_mod
     from gyeeta_amd import capi
@@ -305,21 +305,9 @@ def test_tdigest_rollup_host_cluster_global_bit_exact(torch_mod, oracle):
         return eng, orc, nh, sp
 
     def oracle_host_slabs(orc, nh, sp):
-        slabs = []
-        for h in range(nh + 1):
-            d = oracle.TD64()
-            L.gyo_td64_init(C.byref(d))
-            for k in range(sp if h < nh else 3):
-                L.gyo_td64_merge_service(C.byref(d), C.byref(orc.td(h * sp + k)))
-            slabs.append(d)
-        return slabs
+        return [oracle.rollup_services([orc.td(h * sp + k) for k in range(sp if h < nh else 3)]) for h in range(nh + 1)]
 
-    def fold(slabs):
-        d = oracle.TD64()
-        L.gyo_td64_init(C.byref(d))
-        for s_ in slabs:
-            L.gyo_td64_merge_td64(C.byref(d), C.byref(s_))
-        return d
+    fold = oracle.rollup_slabs  # (round 6: the roll-up is the union by value bin, oracle/gy_oracle_rollup.c gyo_tdbins_*)
 
     def same(rec, d):
         ok = (rec["sum"] == np.array(d.sum[:], dtype=np.int64)).all() and (rec["cnt"] == np.array(d.cnt[:], dtype=np.uint64)).all()
@@ -410,14 +398,11 @@ def _rccl_worker(q):
         engs[0].sync()
         got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=engs[0].SLAB_DT)[0]
         _, loc = engs[0].tdigest_rollup(capi.ROLLUP_GLOBAL)
-        d = oracle.TD64()
-        ol = oracle.lib()
-        ol.gyo_td64_init(C.byref(d))
         o1 = oracle.TD64()
         o1.sum[:] = loc[0]["sum"].tolist()
         o1.cnt[:] = loc[0]["cnt"].tolist()
         o1.vmin, o1.vmax = int(loc[0]["vmin"]), int(loc[0]["vmax"])
-        ol.gyo_td64_merge_td64(C.byref(d), C.byref(o1))
+        d = oracle.rollup_slabs([o1])
         assert got["cnt"].sum() == loc[0]["cnt"].sum() > 0
         assert (got["sum"] == np.array(d.sum[:], dtype=np.int64)).all() and (got["cnt"] == np.array(d.cnt[:], dtype=np.uint64)).all()
         capi.check(L.gys_rccl_comm_destroy(comm))
@@ -431,8 +416,8 @@ def _rccl_worker(q):
 
 def test_window_close_rccl_inside_the_library(torch_mod):
     """gys_window_close_rccl / gys_tdigest_global_rccl with a one-rank communicator created through the C ABI (the box has one GPU):
-    the registers after the in-library exchange equal those of a twin engine closed without it, and the all-gathered + folded global
-    digest equals the oracle's fold of the local GYS_ROLLUP_GLOBAL slab"""
+    the registers after the in-library exchange equal those of a twin engine closed without it, and the all-gathered + rolled-up global
+    digest equals the oracle's roll-up of the local GYS_ROLLUP_GLOBAL slab"""
     import queue
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

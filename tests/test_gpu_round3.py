@@ -197,20 +197,18 @@ def test_window_close_rccl_two_ranks(torch_mod, oracle):
         assert res[r][5][0] >= 4 and res[r][5][1] >= 1, "the library's collectives did not go through the stand-in"
         for name, got, exp in zip(names, res[r][2], want):
             assert got == exp, f"rank {r}: {name} differs from the single-rank run"
-    # global digest: identical on both ranks, equal to the oracle's fold of the two local slabs in rank order
+    # global digest: identical on both ranks, equal to the oracle's roll-up of the two local slabs
     assert res[0][3] == res[1][3]
-    L = oracle.lib()
-    d = oracle.TD64()
-    L.gyo_td64_init(C.byref(d))
-    tot = 0
+    tot, locs = 0, []
     for r in range(2):
         loc = np.frombuffer(res[r][4], dtype=single.SLAB_DT)[0]
         o1 = oracle.TD64()
         o1.sum[:] = loc["sum"].tolist()
         o1.cnt[:] = loc["cnt"].tolist()
         o1.vmin, o1.vmax = int(loc["vmin"]), int(loc["vmax"])
-        L.gyo_td64_merge_td64(C.byref(d), C.byref(o1))
+        locs.append(o1)
         tot += int(loc["cnt"].sum())
+    d = oracle.rollup_slabs(locs)
     got = np.frombuffer(res[0][3], dtype=single.SLAB_DT)[0]
     assert int(got["cnt"].sum()) == tot > 0
     assert (got["sum"] == np.array(d.sum[:], dtype=np.int64)).all() and (got["cnt"] == np.array(d.cnt[:], dtype=np.uint64)).all()

@@ -176,57 +176,46 @@ def test_decision_on_the_engines_own_scan_records(torch_mod, oracle):
     eng.close()
 
 
-def test_global_rollup_in_two_levels_above_128_hosts(torch_mod, oracle):
-    """gys_tdigest_rollup_dev(GLOBAL) on a rank with 300 hosts: chunks of GYS_ROLLUP_FANIN = 128 consecutive host slots folded in parallel, the chunks'
-    slabs folded in order -- the engine's slab equals the oracle's fold composed the same way, and differs from nothing else: totals, min / max and
-    the quantiles of the slab agree with the flat fold's within the digest's rank error"""
+def _same_slab(rec, d):
+    return bool((rec["sum"] == np.array(d.sum[:], dtype=np.int64)).all() and (rec["cnt"] == np.array(d.cnt[:], dtype=np.uint64)).all()
+                and int(rec["vmin"]) == d.vmin and int(rec["vmax"]) == d.vmax)
+
+
+def test_rollup_is_the_union_by_value_bin_many_hosts_and_large_hosts(torch_mod, oracle):
+    """gys_tdigest_rollup_dev after the change of definition (round 6: the union by value bin, oracle/gy_oracle_rollup.c gyo_tdbins_*, instead of
+    the ordered fold): (a) a rank with 300 hosts -- the global slab is the roll-up of 300 host slabs, which ten workgroups add up in parallel;
+    (b) two hosts with 2 500 services each -- a host's services are added up by three workgroups; host, cluster and global slabs equal the
+    oracle's bit for bit in both, and the global slab's total is the number of values the services hold"""
     from gyeeta_amd import capi
-    torch = torch_mod
-    L = oracle.lib()
     rng = np.random.default_rng(63)
-    nh, sp = 300, 3
-    eng = _engine(max_hosts=nh, max_services=nh * sp, max_batch_events=1 << 20)
-    orc = oracle.OracleEngine(nh * sp)
-    info, _ = helpers.register_world(eng, orc, range(nh), sp)
-    for rnd in range(2):
+    for nh, sp, rounds, per in ((300, 3, 2, (200, 1500)), (2, 2500, 3, (60000, 90000))):
+        eng = _engine(max_hosts=nh, max_services=nh * sp, max_batch_events=1 << 20, max_clusters=4)
+        orc = oracle.OracleEngine(nh * sp)
+        for cname in ("cluster0", "cluster1", "cluster2"):
+            eng.register_cluster(cname)
+        info, _ = helpers.register_world(eng, orc, range(nh), sp)
+        for rnd in range(rounds):
+            for h in range(nh):
+                ev = helpers.make_resp_events(rng, h, int(rng.integers(*per)), sp, lat_mu=float(rng.uniform(1.0, 6.0)))
+                eng.handle_resp_events(info[h][0], ev)
+                orc.resp_batch(ev.tobytes(), [info[h][1]], [0])
+        eng.sync()
+        hosts = [oracle.rollup_services([orc.td(h * sp + k) for k in range(sp)]) for h in range(nh)]
+        _, rec_h = eng.tdigest_rollup(capi.ROLLUP_HOST)
         for h in range(nh):
-            ev = helpers.make_resp_events(rng, h, int(rng.integers(200, 1500)), sp, lat_mu=float(rng.uniform(1.0, 6.0)))
-            eng.handle_resp_events(info[h][0], ev)
-            orc.resp_batch(ev.tobytes(), [info[h][1]], [0])
-    eng.sync()
-
-    def td64():
-        d = oracle.TD64()
-        L.gyo_td64_init(C.byref(d))
-        return d
-
-    hosts = []
-    for h in range(nh):
-        d = td64()
-        for k in range(sp):
-            L.gyo_td64_merge_service(C.byref(d), C.byref(orc.td(h * sp + k)))
-        hosts.append(d)
-    chunks = []
-    for c0 in range(0, nh, 128):
-        d = td64()
-        for h in range(c0, min(nh, c0 + 128)):
-            L.gyo_td64_merge_td64(C.byref(d), C.byref(hosts[h]))
-        chunks.append(d)
-    want = td64()
-    for d in chunks:
-        L.gyo_td64_merge_td64(C.byref(want), C.byref(d))
-    dev_g, rec_g = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)
-    assert (rec_g[0]["sum"] == np.array(want.sum[:], dtype=np.int64)).all() and (rec_g[0]["cnt"] == np.array(want.cnt[:], dtype=np.uint64)).all()
-    assert int(rec_g[0]["vmin"]) == want.vmin and int(rec_g[0]["vmax"]) == want.vmax
-    flat = td64()
-    for d in hosts:
-        L.gyo_td64_merge_td64(C.byref(flat), C.byref(d))
-    assert L.gyo_td64_total(C.byref(flat)) == int(rec_g[0]["cnt"].sum())
-    for q in (0.25, 0.5, 0.95, 0.99):
-        a, b = L.gyo_td64_quantile(C.byref(want), q), L.gyo_td64_quantile(C.byref(flat), q)
-        assert abs(a - b) <= 0.05 * max(1.0, b), (q, a, b)
-    # the host level is untouched by the change
-    _, rec_h = eng.tdigest_rollup(capi.ROLLUP_HOST)
-    for h in (0, 127, 128, 299):
-        assert (rec_h[h]["cnt"] == np.array(hosts[h].cnt[:], dtype=np.uint64)).all() and (rec_h[h]["sum"] == np.array(hosts[h].sum[:], dtype=np.int64)).all()
-    eng.close()
+            assert _same_slab(rec_h[h], hosts[h]), f"host slab {h} of {nh} differs"
+        _, rec_c = eng.tdigest_rollup(capi.ROLLUP_CLUSTER)
+        for cl in range(3):  # helpers.register_world: cluster%d of (host index % 3)
+            mem = [hosts[h] for h in range(nh) if h % 3 == cl]
+            if mem:
+                assert _same_slab(rec_c[cl], oracle.rollup_slabs(mem)), f"cluster slab {cl} differs"
+        want = oracle.rollup_slabs(hosts)
+        dev_g, rec_g = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)
+        assert _same_slab(rec_g[0], want)
+        assert _same_slab(rec_g[0], oracle.rollup_slabs(hosts[::-1]))  # (the order of the members does not matter)
+        assert int(rec_g[0]["cnt"].sum()) == sum(int(oracle.lib().gyo_tdb_total(C.byref(orc.td(i)))) for i in range(nh * sp)) > 0
+        qs = [0.25, 0.5, 0.95, 0.99]
+        assert eng.slab_quantiles(dev_g, qs) == [oracle.lib().gyo_td64_quantile(C.byref(want), q) for q in qs]
+        _, again = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)  # (the member lists are kept on the device between calls)
+        assert _same_slab(again[0], want)
+        eng.close()

@@ -30,7 +30,7 @@ the hot kernels run on synthetic input:
     k_svc_aggr on random records / filters / sorts / maxrecs against the oracle's serial walk (oracle/gy_oracle_query.c);
   * the listener's state decision k_listener_decide (tests/cpp/kemu/test_ldecide.cc): TCP_LISTENER::get_curr_state's decision tree on random
     scan records and task / host inputs, the history bytes carried over six rounds, against oracle/gy_oracle_lstate.c;
-  * the roll-up digests k_digest_rollup (tests/cpp/kemu/test_rollup.cc): groups of services and groups of slabs folded in order, 64-bit
+  * the roll-up digests k_rollup_accum / k_rollup_cluster (tests/cpp/kemu/test_rollup.cc): groups of services and groups of slabs, the union by value bin, 64-bit
     weights beyond 2^32, members without clusters / without buffered values / empty.
 This does not replace the -m gpu parity tests (no memory model, no execution masks, no timing): it catches logic errors in kernel
 changes before GPU minutes are spent on them.  The programs are built and run side by side once per session (they mostly wait in
@@ -78,7 +78,7 @@ PROGRAMS = {
     "lstate-actconn-random-4": ("test_lstate.cc", [], ["4"], "kemu lstate ok"),
     "topn-17": ("test_topn.cc", [], ["17"], "kemu topn ok"),
     "rollup-9": ("test_rollup.cc", [], ["9"], "kemu rollup ok"),
-    "rollup-10": ("test_rollup.cc", [], ["10"], "kemu rollup ok"),
+    "rollup-10": ("test_rollup.cc", [], ["10", "3"], "kemu rollup ok"),  # (a buffer stride that is not a multiple of four words: the 4-byte loads)
     # the listener's state decision (get_curr_state) on random scan records / inputs over six rounds
     "ldecide-5": ("test_ldecide.cc", [], ["5"], "kemu ldecide ok"),
     "svcquery-5": ("test_svcquery.cc", [], ["5"], "kemu svcquery ok"),

@@ -1,7 +1,8 @@
 """The roll-up oracle (oracle/gy_oracle_rollup.c: 64-bit counters) against the per-service digest oracle it extends (oracle/gy_oracle.c,
 32-bit counters): with weights that fit both, the two must agree cluster for cluster -- merging values, merging a digest's clusters, and
 quantiles -- so that the GPU roll-up's bit-exactness against the 64-bit form is also bit-exactness against the pinned 32-bit definition.
-Plus the properties a roll-up must have: totals add up, min / max cover the members, fold order matters only through the definition."""
+Plus the properties a roll-up must have: totals add up, min / max cover the members.  Round 6: the roll-up itself is the union by value
+bin (gyo_tdbins_*): its finish against a point-by-point restatement, conservation, independence of the members' order, rank error."""
 import ctypes as C
 
 import numpy as np
@@ -91,6 +92,98 @@ def test_td64_rollup_totals_minmax_and_rank_error(oracle):
         lo, hi = np.searchsorted(x, v, side="left") / len(x), np.searchsorted(x, v, side="right") / len(x)
         err = 0.0 if lo <= q <= hi else min(abs(lo - q), abs(hi - q))
         assert err <= 0.01, (q, v, err)
+
+
+# ---------------------------------------------------------------- round 6: the roll-up is the union by value bin (gyo_tdbins_*)
+def _rank_err(x, v, q):
+    lo, hi = np.searchsorted(x, v, side="left") / len(x), np.searchsorted(x, v, side="right") / len(x)
+    return 0.0 if lo <= q <= hi else min(abs(lo - q), abs(hi - q))
+
+
+def test_value_bins_cover_the_domain_in_order(oracle):
+    L = oracle.lib()
+    v = np.arange(0, 1 << 20, dtype=np.uint32)
+    b = np.array([L.gyo_td_value_bin(int(x)) for x in v[:: 7]])
+    assert (np.diff(b) >= 0).all() and b[0] == 0
+    assert [L.gyo_td_value_bin(x) for x in (0, 1, 1023, 1024, 1039, 1040, 2047, 2048)] == [0, 1, 1023, 1024, 1024, 1025, 1087, 1088]
+    assert L.gyo_td_value_bin((1 << 26) - 1) == oracle.TD_BINS - 1 == L.gyo_td_value_bin(0xFFFFFFFF)
+    # a cell is at most 1 / 64 of its lower edge wide
+    for x in (1024, 5000, 99999, 1 << 19):
+        k = L.gyo_td_value_bin(x)
+        same = [y for y in range(x, x + x // 32) if L.gyo_td_value_bin(y) == k]
+        assert len(same) <= x // 64 + 1
+
+
+def test_tdbins_finish_equals_the_point_by_point_restatement(oracle):
+    """gyo_tdbins_finish against the definition spelled out point by point in Python: every unit mid-point of every bin gets its cluster
+    from gyo_td_cluster, a bin's sum is shared by floor(sum r1 / w) - floor(sum r0 / w) over the runs of equal cluster (Python integers)"""
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    for case in range(6):
+        b = oracle.TDBins()
+        L.gyo_tdbins_init(C.byref(b))
+        if case < 4:
+            v = _vals(rng, int(rng.integers(1, 4000)), mu=float(rng.uniform(0.5, 8.0)))
+            L.gyo_tdbins_add_values(C.byref(b), oracle.ptr(v, oracle.i32p), len(v))
+        else:  # few heavy bins with sums that are not multiples of the weight: every cluster boundary cuts a bin
+            for k in rng.integers(0, oracle.TD_BINS, 5):
+                b.cnt[int(k)] = int(rng.integers(500, 3000))
+                b.sum[int(k)] = int(b.cnt[int(k)] * int(k) - rng.integers(0, 400))
+        out = oracle.TD64()
+        L.gyo_tdbins_finish(C.byref(b), C.byref(out))
+        N = sum(b.cnt)
+        want_s, want_c, W = [0] * oracle.TD_NB, [0] * oracle.TD_NB, 0
+        for k in range(oracle.TD_BINS):
+            w, sm = int(b.cnt[k]), int(b.sum[k])
+            if not w:
+                continue
+            cl = [L.gyo_td_cluster(2 * (W + r) + 1, 2 * N) for r in range(w)]
+            r0 = 0
+            for r in range(1, w + 1):
+                if r == w or cl[r] != cl[r0]:
+                    want_s[cl[r0]] += sm * r // w - sm * r0 // w
+                    want_c[cl[r0]] += r - r0
+                    r0 = r
+            W += w
+        assert list(out.cnt) == want_c and list(out.sum) == want_s, case
+        assert sum(out.sum) == sum(b.sum) and sum(out.cnt) == N
+
+
+@pytest.mark.parametrize("name,nsvc,mus,sig", [("mixed", 300, (3, 1), 0.8), ("tight", 300, (1.5, 0.1), 0.3), ("seconds", 200, (7.5, 0.5), 1.0),
+                                               ("one-heavy-value", 300, (0.7, 0.05), 0.2)])
+def test_tdbins_rollup_totals_order_and_rank_error(oracle, name, nsvc, mus, sig):
+    """a group of services rolled up by value bin: weight and sum of the members are conserved exactly, the extremes cover theirs, the
+    order of the members does not matter, and the quantiles rank within 1 % of the pooled exact sort (tolerance of the per-service
+    digests; here: a few 10^-4) -- on one level and on two (services -> 10 host slabs -> one)"""
+    L = oracle.lib()
+    rng = np.random.default_rng(7)
+    svcs, pooled = [], []
+    for s in range(nsvc):
+        b = oracle.TDBuffered()
+        L.gyo_tdb_init(C.byref(b))
+        mu = float(rng.normal(*mus))
+        for _ in range(int(rng.integers(1, 6))):
+            v = np.ascontiguousarray(np.clip(rng.lognormal(mu, sig, int(rng.integers(50, 900))), 0, 1e6).astype(np.int32))
+            pooled.append(v)
+            L.gyo_tdb_add_batch(C.byref(b), oracle.ptr(v, oracle.i32p), len(v))
+        svcs.append(b)
+    x = np.sort(np.concatenate(pooled))
+    one = oracle.rollup_services(svcs)
+    assert L.gyo_td64_total(C.byref(one)) == len(x) and sum(one.sum) == int(x.sum()) and one.vmin == int(x[0]) and one.vmax == int(x[-1])
+    rev = oracle.rollup_services(svcs[::-1])
+    assert list(rev.sum) == list(one.sum) and list(rev.cnt) == list(one.cnt)
+    hosts = [oracle.rollup_services(svcs[h::10]) for h in range(10)]
+    two = oracle.rollup_slabs(hosts)
+    assert L.gyo_td64_total(C.byref(two)) == len(x) and sum(two.sum) == int(x.sum()) and two.vmin == int(x[0]) and two.vmax == int(x[-1])
+    # the clusters' means rise with the bins; the pieces of ONE bin that is cut by cluster boundaries carry integer shares of its sum, so their
+    # means differ by less than one unit per point of the piece among themselves (all of them lie inside the bin)
+    means = np.array([s_ / c_ for s_, c_ in zip(one.sum, one.cnt) if c_])
+    assert (np.diff(means) > -np.maximum(1.0, means[1:] / 64)).all()
+    assert np.abs(np.diff(means)[np.diff(means) < 0]).sum() < 1.0 + means[-1] / 64
+    for q in (0.01, 0.05, 0.25, 0.5, 0.9, 0.95, 0.99, 0.999):
+        for d in (one, two):
+            v = L.gyo_td64_quantile(C.byref(d), q)
+            assert _rank_err(x, v, q) <= 0.01, (name, q, v)
 
 
 def test_active_conn_and_pair_oracles_against_numpy(oracle):
