@@ -20,6 +20,7 @@ namespace gys {
 
 #define GYS_RB_STRIDE (2u * GYS_MB_BINS + 2u) // 64-bit words of a group's bins in HBM: cnt[2048], sum[2048], vmin, vmax
 #define GYS_RB_NT 512u                        // threads of an accumulating workgroup: 8 waves, each walks members of its own
+#define GYS_RB_VC 4096u                       // buffered values below this are COUNTED per exact value in LDS (one 32-bit add each: their sums follow from the counts)
 
 struct RollupChunk {
 	uint32_t group, m0, m1, pad; // members[m0, m1) belong to `group`
@@ -70,7 +71,13 @@ __global__ __launch_bounds__(GYS_RB_NT) void k_rollup_accum(RollupP q)
 {
 	const DigestP &p = q.d;
 	__shared__ unsigned long long s_cnt[GYS_MB_BINS], s_sum[GYS_MB_BINS]; // clusters (any bin) and buffered values >= 1024
-	__shared__ uint32_t s_vc[GYS_MB_EXACT];                              // buffered values below 1024: the count says it all
+	// buffered values below GYS_RB_VC: one counter per exact value -- the count says it all, and minimum / maximum of the values come from the
+	// counters as well: a value is a compare, two address instructions and one LDS add.  Larger values (0.2 % of the bench's stream) take the
+	// general path: cell number, two 64-bit adds, own minimum / maximum.  (Measured on the way, profiles/r6z_*: reading the member's identity
+	// one member ahead and asking for its first 2 KB of values before its clusters 17.9 -> 17.5 ms; this value path instead of bin + two adds +
+	// min / max per value 17.5 -> 16.8 ms; eight counters per value below 256, by lane -- in case lanes that hold the same value serialize
+	// in the LDS -- 17.6 ms: none of the three is what bounds the kernel; at 62 GB per pass it runs at 3.7 TB/s.)
+	__shared__ uint32_t s_vc[GYS_RB_VC];
 	__shared__ long long s_mm[2];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	constexpr uint32_t NW = GYS_RB_NT / 64u;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(GYS_RB_NT) void k_rollup_accum(RollupP q)
 			s_cnt[k] = 0;
 			s_sum[k] = 0;
 		}
-		for (uint32_t k = tid; k < GYS_MB_EXACT; k += GYS_RB_NT) s_vc[k] = 0;
+		for (uint32_t k = tid; k < GYS_RB_VC; k += GYS_RB_NT) s_vc[k] = 0;
 		if (tid == 0) {
 			s_mm[0] = INT32_MAX;
 			s_mm[1] = INT32_MIN;
@@ -89,8 +96,26 @@ __global__ __launch_bounds__(GYS_RB_NT) void k_rollup_accum(RollupP q)
 		const RollupChunk ck = q.chunks[c];
 		long long mmin = INT32_MAX, mmax = INT32_MIN; // lane 0: the extremes of the members that bring clusters
 		int32_t lmin = INT32_MAX, lmax = INT32_MIN;   // the buffered values'
-		for (uint32_t mi = ck.m0 + wave; mi < ck.m1; mi += NW) { // a wave per member: no barrier inside a chunk
-			const uint32_t mem = q.members[mi];
+		// a wave per member, no barrier inside a chunk.  The member's identity and buffer fill are read one member ahead and its first 2 KB of
+		// buffered values are requested before its clusters: one round trip to HBM per member instead of three dependent ones
+		uint32_t mem_n = 0, npend_n = 0;
+		if (ck.m0 + wave < ck.m1) {
+			mem_n = q.members[ck.m0 + wave];
+			if (q.kind == 0) npend_n = min(p.td_meta[mem_n].npend, p.pend_cap); // (between batches a buffer holds at most pend_cap values)
+		}
+		for (uint32_t mi = ck.m0 + wave; mi < ck.m1; mi += NW) {
+			const uint32_t mem = mem_n, npend = npend_n;
+			if (mi + NW < ck.m1) {
+				mem_n = q.members[mi + NW];
+				if (q.kind == 0) npend_n = min(p.td_meta[mem_n].npend, p.pend_cap);
+			}
+			const uint32_t *pend = p.td_pend + (size_t)mem * p.pcap;
+			const bool quads = q.kind == 0 && (p.pcap & 3u) == 0u; // 16 bytes per lane and request
+			uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+			if (quads) {
+				if (4u * lane < npend) v0 = ((const uint4 *)pend)[lane];
+				if (4u * lane + 256u < npend) v1 = ((const uint4 *)pend)[lane + 64u];
+			}
 			// ---- the member's clusters, whole, into the bin of the integer threshold of their mean
 			bool any = false;
 #pragma unroll
@@ -128,33 +153,50 @@ __global__ __launch_bounds__(GYS_RB_NT) void k_rollup_accum(RollupP q)
 			}
 			if (q.kind != 0) continue;
 			// ---- a service's buffered values: unit points
-			const uint32_t npend = min(p.td_meta[mem].npend, p.pend_cap); // (between batches a buffer holds at most pend_cap values)
-			const uint32_t *pend = p.td_pend + (size_t)mem * p.pcap;
 			auto one = [&](uint32_t word) {
-				const uint32_t uv = word >> GYS_ROW_BITS;
-				if (uv < GYS_MB_EXACT) {
-					atomicAdd(&s_vc[uv], 1u);
+				if (word < (GYS_RB_VC << GYS_ROW_BITS)) {
+					atomicAdd((uint32_t *)((char *)s_vc + ((word >> (GYS_ROW_BITS - 2u)) & ~3u)), 1u);
 				} else {
-					const uint32_t b = rb_bin(uv);
+					const uint32_t uv = word >> GYS_ROW_BITS, b = rb_bin(uv);
 					atomicAdd(&s_cnt[b], 1ull);
 					atomicAdd(&s_sum[b], (unsigned long long)uv);
+					lmin = min(lmin, (int32_t)uv);
+					lmax = max(lmax, (int32_t)uv);
 				}
-				lmin = min(lmin, (int32_t)uv);
-				lmax = max(lmax, (int32_t)uv);
 			};
-			if ((p.pcap & 3u) == 0u) { // 16 bytes per lane and request: a wave keeps 2 KB in flight
-				const uint4 *pend4 = (const uint4 *)pend;
-#pragma unroll 2
-				for (uint32_t i = 4u * lane; i < npend; i += 256u) {
-					const uint4 w4 = pend4[i >> 2];
+			auto quad = [&](const uint4 w4, uint32_t i) {
+				if (i + 3u < npend) { // (all but the buffer's last quad)
 					one(w4.x);
+					one(w4.y);
+					one(w4.z);
+					one(w4.w);
+				} else {
+					if (i < npend) one(w4.x);
 					if (i + 1u < npend) one(w4.y);
 					if (i + 2u < npend) one(w4.z);
-					if (i + 3u < npend) one(w4.w);
 				}
+			};
+			if (quads) {
+				quad(v0, 4u * lane);
+				quad(v1, 4u * lane + 256u);
+#pragma unroll 2
+				for (uint32_t i = 4u * lane + 512u; i < npend; i += 256u) quad(((const uint4 *)pend)[i >> 2], i);
 			} else {
 #pragma unroll 4
 				for (uint32_t i = lane; i < npend; i += 64u) one(pend[i]);
+			}
+		}
+		__syncthreads();
+		// the counted values: those of 1024 and more join their cells; the smallest / largest counted value
+		for (uint32_t k = tid; k < GYS_RB_VC; k += GYS_RB_NT) {
+			const uint32_t vc = s_vc[k];
+			if (!vc) continue;
+			lmin = min(lmin, (int32_t)k);
+			lmax = max(lmax, (int32_t)k);
+			if (k >= GYS_MB_EXACT) {
+				const uint32_t b = rb_bin(k);
+				atomicAdd(&s_cnt[b], (unsigned long long)vc);
+				atomicAdd(&s_sum[b], (unsigned long long)vc * k);
 			}
 		}
 		lmin = wave_min_i32(lmin);
