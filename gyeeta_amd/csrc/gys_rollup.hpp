@@ -47,9 +47,10 @@ __global__ __launch_bounds__(256) void k_rollup_init(unsigned long long *bins, u
 	}
 }
 
-// ceil(sum / cnt) for sum < 2^63, cnt != 0, when the quotient is below 2^32 (else: ~0): the double quotient is off by at most one
+// ceil(sum / cnt) for 0 < sum < 2^63, cnt != 0, when the quotient is below 2^32 (else: ~0): the double quotient is off by at most one
 __device__ __forceinline__ uint32_t ceil_div_wide(uint64_t sum, uint64_t cnt)
 {
+	if ((int64_t)sum <= 0) return 0u; // (not an engine digest: a caller's slab; the oracle's rule)
 	const double dq = (double)sum / (double)cnt;
 	if (dq >= 4294967040.0) return 0xFFFFFFFFu;
 	uint64_t f = (uint64_t)dq;

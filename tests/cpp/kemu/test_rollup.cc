@@ -162,8 +162,24 @@ int main(int argc, char **argv)
 		kemu::launch(2, 256, 0, [&] { k_rollup_cluster(q); });
 		for (uint32_t g = 0; g < NG; ++g) compare(per == 5u ? "services in chunks of 5" : "services", g, slabs[g], want[g]);
 	}
-	// groups of slabs (the cross-rank roll-up): the slabs above, in two orders and with an empty one in the middle
-	std::vector<std::vector<uint32_t>> sg = {{3, 4, 7}, {7, 0, 4, 3}, {0}, {}, {8, 7}, {7, 8}};
+	// groups of slabs (the cross-rank roll-up): the slabs above, in two orders and with an empty one in the middle; and a caller's slab that no
+	// engine makes: weights of 2^40, a mean beyond the value domain (last bin), a sum of zero and a negative one (first bin)
+	{
+		gys_tdigest_slab odd{};
+		gyo_td64 oddw;
+		gyo_td64_init(&oddw);
+		const uint64_t oc[5] = {1ull << 40, 3ull, (1ull << 33) + 7ull, 5ull, 9ull};
+		const int64_t os[5] = {(int64_t)((1ull << 40) * 77ull + 12345ull), (int64_t)(3ull << 30), (int64_t)(((1ull << 33) + 7ull) * 1500ull - 3ull), 0, -40};
+		for (int j = 0; j < 5; ++j) {
+			odd.cnt[10 * j + 1] = oddw.cnt[10 * j + 1] = oc[j];
+			odd.sum[10 * j + 1] = oddw.sum[10 * j + 1] = os[j];
+		}
+		odd.vmin = oddw.vmin = -40;
+		odd.vmax = oddw.vmax = 1ll << 30;
+		slabs.push_back(odd);
+		want.push_back(oddw);
+	}
+	std::vector<std::vector<uint32_t>> sg = {{3, 4, 7}, {7, 0, 4, 3}, {0}, {}, {8, 7}, {7, 8}, {NG}, {3, NG, 4}};
 	std::vector<uint32_t> soff(1, 0), smem;
 	for (auto &g : sg) {
 		smem.insert(smem.end(), g.begin(), g.end());
