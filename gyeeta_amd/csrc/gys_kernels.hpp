@@ -985,8 +985,20 @@ __device__ __forceinline__ uint32_t gys_swap_pair(uint32_t v) // the neighbourin
 // measured configurations: nothing below costs it an instruction); 1: IPv4 events, keys with candidates (bound-address listeners) are
 // resolved by the event's server address; 2: IPv6 events (48 bytes; flow hash through the general word packing, candidates as in 1)
 template <int TPT, bool SHARED, bool SPILL, bool SVCHLL, int MODE = 0>
-__global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)) void k_resp_host(RespHostP p) // (4 waves per SIMD: one 1024-thread workgroup or two 512-thread ones per CU; TPT = 32: 2)
+__global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)) void k_resp_host(RespHostP p_arg) // (4 waves per SIMD: one 1024-thread workgroup or two 512-thread ones per CU; TPT = 32: 2)
 {
+#ifndef GYS_RESP_KERNARG
+#define GYS_RESP_KERNARG 1 // the parameters are read from the kernel-argument segment where they are used (scalar loads), re-read per tile, instead of being held in SGPRs -- and spilled into VGPR lanes -- across the whole kernel
+#endif
+#if GYS_RESP_KERNARG && defined(__HIP_DEVICE_COMPILE__)
+	typedef const RespHostP __attribute__((address_space(4))) *KernargP;
+	KernargP p_k = (KernargP)__builtin_amdgcn_kernarg_segment_ptr(); // (the only parameter: offset 0)
+#define GYS_RESP_P_RELOAD() asm volatile("" : "+s"(p_k))
+	const RespHostP &p = *(const RespHostP *)p_k;
+#else
+#define GYS_RESP_P_RELOAD() (void)0
+	const RespHostP &p = p_arg;
+#endif
 	constexpr uint32_t T = GYS_RESP_THREADS(TPT);
 	constexpr uint32_t TILE = (uint32_t)TPT * T;
 	constexpr bool DBG = GYS_RESP_DBG != 0;
@@ -1125,6 +1137,7 @@ __global__ __launch_bounds__(GYS_RESP_THREADS(TPT), GYS_RESP_WAVES_PER_SIMD(TPT)
 	}
 	GYS_TICK(10); // prologue: tables, floor
 	for (uint64_t t0 = e0; t0 < e1; t0 += TILE, ++tile_no) {
+		GYS_RESP_P_RELOAD();
 		// (no barrier here: the event phase of this tile touches nothing the flush of the previous one reads -- the per-key counters are
 		// double-buffered and were cleared two phases ago, the floor and the candidate queue were settled behind barriers of the
 		// previous tile; a wave that is done flushing starts on its next events while the others still flush)
@@ -2417,9 +2430,21 @@ __device__ __forceinline__ double td_quantile_dev(const uint32_t *c_cnt, const u
 #ifndef GYS_MB_WAVES16
 #define GYS_MB_WAVES16 5 // waves per SIMD the 4096-value instance is compiled for (8: 64 VGPRs -- sixteen values per thread then spill to scratch)
 #endif
+#ifndef GYS_MB_KERNARG
+#define GYS_MB_KERNARG 1 // the kernel's parameters are read from the kernel-argument segment where they are used (scalar loads, cached) instead of being held in ~90 SGPRs across the merge loop, which spilled 53 of them into VGPR lanes (170 v_readlane / v_writelane in the 2048-value instance)
+#endif
 template <bool SCAN, uint32_t VPT = 4u>
-__global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_digest_bins(MergeBP q)
+__global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_digest_bins(MergeBP q_arg)
 {
+#if GYS_MB_KERNARG && defined(__HIP_DEVICE_COMPILE__)
+	typedef const MergeBP __attribute__((address_space(4))) *KernargP;
+	KernargP q_k = (KernargP)__builtin_amdgcn_kernarg_segment_ptr(); // (the only parameter: offset 0)
+#define GYS_MB_Q_RELOAD() asm volatile("" : "+s"(q_k))
+	const MergeBP &q = *(const MergeBP *)q_k;
+#else
+#define GYS_MB_Q_RELOAD() (void)0
+	const MergeBP &q = q_arg;
+#endif
 	const DigestP &p = q.d;
 	static_assert(VPT == 4u || VPT == 8u || VPT == 16u, "merges of 1024 / 2048 / 4096 values");
 	__shared__ __align__(16) uint32_t s_bin[GYS_MB_BINS];
@@ -2463,6 +2488,7 @@ __global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_dige
 		// bucket the thread uses is hoisted out of this loop and held in registers across it (> 96 VGPRs instead of < 64)
 		uint32_t tid = threadIdx.x;
 		GYS_OPAQUE_VGPR(tid);
+		GYS_MB_Q_RELOAD();
 		const uint32_t lane = tid & 63u, wave = tid >> 6;
 		MergeEnt ent;
 		if (SCAN) ent = MergeEnt{w, min(p.td_meta[w].npend, p.pend_cap), 0u, 0u}; // between batches a buffer holds at most pend_cap values
