@@ -1076,7 +1076,7 @@ def main():
                   "global_digest_exchanges_timed": gd_calls, "global_digest_every": args.global_digest_every if gd_slab is not None else 0}
         # (gys_tdigest_global_rccl is collective: every rank makes the call below, in the same place)
         if gd_slab is not None:
-            # the fifth register family once more, untimed and timed on its own: this rank's roll-up slab, all-gather, fold in rank order
+            # the fifth register family once more, untimed and timed on its own: this rank's roll-up slab, all-gather, roll-up of the ranks' slabs
             torch.cuda.synchronize()
             tg = time.perf_counter()
             gsum = 0

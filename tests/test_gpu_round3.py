@@ -154,7 +154,7 @@ def test_window_close_rccl_two_ranks(torch_mod, oracle):
     owning its shard of the hosts; the RCCL entry points the library calls are served by tests/cpp/fakerccl ($GYS_RCCL_LIB; RCCL itself
     refuses two ranks on one device), which executes every all-reduce / all-gather with exactly the count, datatype, operator and
     pointers the library passed.  Both ranks end with the registers, Count-Min tables, all-service histogram and cluster rows of a
-    single-rank engine fed all hosts, and with the same global digest = the oracle's fold of the two ranks' slabs in rank order."""
+    single-rank engine fed all hosts, and with the same global digest = the oracle's roll-up of the two ranks' slabs."""
     import ctypes as C
     import os
     import subprocess
