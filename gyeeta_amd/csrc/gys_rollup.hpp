@@ -19,8 +19,18 @@
 namespace gys {
 
 #define GYS_RB_STRIDE (2u * GYS_MB_BINS + 2u) // 64-bit words of a group's bins in HBM: cnt[2048], sum[2048], vmin, vmax
-#define GYS_RB_NT 512u                        // threads of an accumulating workgroup: 8 waves, each walks members of its own
+#ifndef GYS_RB_NT
+#define GYS_RB_NT 1024u                       // threads of an accumulating workgroup: 16 waves, each walks members of its own (two workgroups per CU share its LDS)
+#endif
+#ifndef GYS_RB_AHEAD
+#define GYS_RB_AHEAD 2u                       // 16-byte pieces per lane (1 KB per wave each) of a member's buffered values that are requested before its clusters are looked at
+#endif
+#ifndef GYS_RB_WAVES
+#define GYS_RB_WAVES 8                        // waves per SIMD the accumulate kernel is compiled for (0: the compiler's choice).  The kernel lives on waves in flight: 8 (64 VGPRs, four of them spilled) 13.9 ms, 6 (80 VGPRs) 17.0 ms, 3 - 4.5 28 - 30 ms (profiles/r6ag_*)
+#endif
+#ifndef GYS_RB_VC
 #define GYS_RB_VC 4096u                       // buffered values below this are COUNTED per exact value in LDS (one 32-bit add each: their sums follow from the counts)
+#endif
 
 struct RollupChunk {
 	uint32_t group, m0, m1, pad; // members[m0, m1) belong to `group`
@@ -68,16 +78,21 @@ __device__ __forceinline__ uint32_t ceil_div_wide(uint64_t sum, uint64_t cnt)
 
 __device__ __forceinline__ uint32_t rb_bin(uint32_t v) { return mb_bin(v < (1u << 26) ? v : (1u << 26) - 1u); } // (a staged word carries 26 value bits)
 
+#if GYS_RB_WAVES
+__global__ __launch_bounds__(GYS_RB_NT, GYS_RB_WAVES) void k_rollup_accum(RollupP q)
+#else
 __global__ __launch_bounds__(GYS_RB_NT) void k_rollup_accum(RollupP q)
+#endif
 {
 	const DigestP &p = q.d;
 	__shared__ unsigned long long s_cnt[GYS_MB_BINS], s_sum[GYS_MB_BINS]; // clusters (any bin) and buffered values >= 1024
 	// buffered values below GYS_RB_VC: one counter per exact value -- the count says it all, and minimum / maximum of the values come from the
 	// counters as well: a value is a compare, two address instructions and one LDS add.  Larger values (0.2 % of the bench's stream) take the
-	// general path: cell number, two 64-bit adds, own minimum / maximum.  (Measured on the way, profiles/r6z_*: reading the member's identity
-	// one member ahead and asking for its first 2 KB of values before its clusters 17.9 -> 17.5 ms; this value path instead of bin + two adds +
-	// min / max per value 17.5 -> 16.8 ms; eight counters per value below 256, by lane -- in case lanes that hold the same value serialize
-	// in the LDS -- 17.6 ms: none of the three is what bounds the kernel; at 62 GB per pass it runs at 3.7 TB/s.)
+	// general path: cell number, two 64-bit adds, own minimum / maximum.  (Measured on the way, profiles/r6z_*, r6ag_*: reading the member's
+	// identity one member ahead and asking for its first 2 KB of values before its clusters 17.9 -> 17.5 ms; this value path instead of bin + two
+	// adds + min / max per value 17.5 -> 16.8 ms; eight counters per value below 256, by lane -- in case lanes that hold the same value
+	// serialize in the LDS -- 17.6 ms; 4 or 8 KB requested ahead 20 - 21 ms (registers: fewer waves); 12 - 20 waves per CU instead of 24: 28 - 30 ms;
+	// 32 waves per CU: 13.9 ms -- the kernel is bound by the latency of its loads, i.e. by the number of waves that wait at once.)
 	__shared__ uint32_t s_vc[GYS_RB_VC];
 	__shared__ long long s_mm[2];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -112,10 +127,11 @@ __global__ __launch_bounds__(GYS_RB_NT) void k_rollup_accum(RollupP q)
 			}
 			const uint32_t *pend = p.td_pend + (size_t)mem * p.pcap;
 			const bool quads = q.kind == 0 && (p.pcap & 3u) == 0u; // 16 bytes per lane and request
-			uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-			if (quads) {
-				if (4u * lane < npend) v0 = ((const uint4 *)pend)[lane];
-				if (4u * lane + 256u < npend) v1 = ((const uint4 *)pend)[lane + 64u];
+			uint4 va[GYS_RB_AHEAD];
+#pragma unroll
+			for (uint32_t k = 0; k < GYS_RB_AHEAD; ++k) {
+				va[k] = make_uint4(0, 0, 0, 0);
+				if (quads && 4u * lane + 256u * k < npend) va[k] = ((const uint4 *)pend)[lane + 64u * k];
 			}
 			// ---- the member's clusters, whole, into the bin of the integer threshold of their mean
 			bool any = false;
@@ -178,10 +194,10 @@ __global__ __launch_bounds__(GYS_RB_NT) void k_rollup_accum(RollupP q)
 				}
 			};
 			if (quads) {
-				quad(v0, 4u * lane);
-				quad(v1, 4u * lane + 256u);
+#pragma unroll
+				for (uint32_t k = 0; k < GYS_RB_AHEAD; ++k) quad(va[k], 4u * lane + 256u * k);
 #pragma unroll 2
-				for (uint32_t i = 4u * lane + 512u; i < npend; i += 256u) quad(((const uint4 *)pend)[i >> 2], i);
+				for (uint32_t i = 4u * lane + 256u * GYS_RB_AHEAD; i < npend; i += 256u) quad(((const uint4 *)pend)[i >> 2], i);
 			} else {
 #pragma unroll 4
 				for (uint32_t i = lane; i < npend; i += 64u) one(pend[i]);

@@ -55,7 +55,7 @@ void compare(const char *what, uint32_t g, const gys_tdigest_slab &got, const gy
 int main(int argc, char **argv)
 {
 	if (!kemu::can_run(GYS_RB_NT)) {
-		printf("kemu: this process cannot have 512 threads\n");
+		printf("kemu: this process cannot have 1024 threads\n");
 		return 77;
 	}
 	std::mt19937 rng(argc > 1 ? (unsigned)atoi(argv[1]) : 9u);
