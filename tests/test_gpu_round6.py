@@ -219,3 +219,30 @@ def test_rollup_is_the_union_by_value_bin_many_hosts_and_large_hosts(torch_mod, 
         _, again = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)  # (the member lists are kept on the device between calls)
         assert _same_slab(again[0], want)
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("td_cap,buf_values", [(0, 1027), (1920, 0), (1920, 2307)])
+def test_rollup_at_other_buffer_sizes_and_strides(torch_mod, oracle, td_cap, buf_values):
+    """the roll-up kernels read a service's buffered values 16 bytes per lane when the buffer stride is a multiple of four words and 4 bytes
+    per lane otherwise (gys_config.td_buf_values 1027 / 2307); buffers of 896 and of 1 920 values: host and global slabs == the oracle's"""
+    from gyeeta_amd import capi
+    rng = np.random.default_rng(64 + td_cap + buf_values)
+    nh, sp = 5, 60
+    eng = _engine(max_hosts=nh, max_services=nh * sp, max_batch_events=1 << 20, td_pend_cap=td_cap, td_buf_values=buf_values)
+    orc = oracle.OracleEngine(nh * sp, td_cap=td_cap)
+    info, _ = helpers.register_world(eng, orc, range(nh), sp)
+    for rnd in range(4):
+        for h in range(nh):
+            ev = helpers.make_resp_events(rng, h, int(rng.integers(8000, 30000)), sp, lat_mu=float(rng.uniform(1.0, 7.5)))
+            eng.handle_resp_events(info[h][0], ev)
+            orc.resp_batch(ev.tobytes(), [info[h][1]], [0])
+    eng.sync()
+    hosts = [oracle.rollup_services([orc.td(h * sp + k) for k in range(sp)]) for h in range(nh)]
+    assert max(orc.td(i).npend for i in range(nh * sp)) > 64  # (the buffers hold values: both parts of a member are exercised)
+    _, rec_h = eng.tdigest_rollup(capi.ROLLUP_HOST)
+    for h in range(nh):
+        assert _same_slab(rec_h[h], hosts[h]), f"host slab {h} differs"
+    _, rec_g = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)
+    assert _same_slab(rec_g[0], oracle.rollup_slabs(hosts))
+    eng.close()
