@@ -2477,7 +2477,7 @@ try {
 			return rc;
 		}
 		ALLOC(c->merge_list, std::min<uint64_t>(S, B) + 1);
-		ALLOC(c->merge_list_slow, std::min<uint64_t>(S, B) + 1);
+		ALLOC(c->merge_list_slow, S + 1); // (the all-service scan may list any service)
 		// a key lands in a larger merge size class only when the batch itself brought it more than CLASS0 - PEND_CAP values
 		ALLOC(c->merge_list1, std::min<uint64_t>(S, B / (c->merge_fast - c->pend_cap) + 1) + 1);
 		ALLOC(c->merge_list2, std::min<uint64_t>(S, B / (GYS_MERGE_CLASS1 - c->pend_cap) + 1) + 1);
@@ -3859,7 +3859,7 @@ try {
 	HIPCHK(hipMemcpyAsync(&nslow, c->merge_count + FIN_SLOW, 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipFree(d_q));
-	if (nslow) { // services whose digest weighs 2^31 or more (64-bit weights): one at a time through the general merge
+	if (nslow) { // services whose digest weighs 2^31 or more (64-bit weights) or whose buffer holds more than GYS_MB_BIG_CAP values of a second or longer: one at a time through the general merge
 		std::vector<MergeEnt> slow(nslow);
 		HIPCHK(hipMemcpy(slow.data(), c->merge_list_slow, sizeof(MergeEnt) * nslow, hipMemcpyDeviceToHost));
 		std::vector<double> out(nq);

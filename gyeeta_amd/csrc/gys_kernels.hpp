@@ -2448,7 +2448,11 @@ __global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_dige
 	const DigestP &p = q.d;
 	static_assert(VPT == 4u || VPT == 8u || VPT == 16u, "merges of 1024 / 2048 / 4096 values");
 	__shared__ __align__(16) uint32_t s_bin[GYS_MB_BINS];
-	constexpr uint32_t BIG_CAP = SCAN ? 256u * VPT : GYS_MB_BIG_CAP; // (the all-service scan has no hand-over list: its list holds any merge)
+	// (Until round 6 the scan's list held any merge -- 256 VPT entries, 8 KB for buffers of 1 920 values -- which left 6 workgroups per CU where the
+	// merge has 8; with the merge's list and its hand-over -- gys_scan_quantiles_dev sends the listed services through the general path one by one, as it
+	// does for 64-bit weights -- the scan of 10^7 services takes 61 instead of 78 ms, r6aj.  A service is listed when more than 1 024 of its buffered
+	// values are a second or longer.)
+	constexpr uint32_t BIG_CAP = GYS_MB_BIG_CAP;
 	__shared__ uint32_t s_big[BIG_CAP]; // values >= GYS_MB_EXACT: index << 20 | value
 	__shared__ uint32_t s_thr[GYS_NBP];          // compacted non-empty old clusters: ceil(sum / count), padded with ~0
 	__shared__ uint32_t s_cpfx[GYS_NBP + 1];     // old weight before compacted cluster c

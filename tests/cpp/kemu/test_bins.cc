@@ -189,6 +189,44 @@ int main(int argc, char **argv)
 	q.slow_count = &slow_count;
 
 #if KEMU_BINS_NT == 256 && !defined(KEMU_BINS_TEMPLATE_NT)
+	{ // the all-service scan first (it modifies nothing): quantiles of every key's digest with its buffer merged in (a run is not part of the
+	  // view between batches), equal to the oracle's; keys with 64-bit weights or more large values than the list holds are handed over
+		const double qs[4] = {0.25, 0.5, 0.95, 0.99};
+		std::vector<double> qout((size_t)S * 4, -1.0);
+		std::vector<MergeEnt> sslow(S + 1);
+		uint32_t sslow_count = 0;
+		MergeBP sq = q;
+		sq.qs = qs;
+		sq.nq = 4;
+		sq.qout = qout.data();
+		sq.slow_list = sslow.data();
+		sq.slow_count = &sslow_count;
+		kemu::launch(3, NT, 0, [&] { k_digest_bins<true, KEMU_BINS_VPT>(sq); });
+		uint32_t want = 0;
+		for (uint32_t s = 0; s < S; ++s) {
+			const Key &k = keys[s];
+			const uint32_t m = std::min(k.nbuf, q.d.pend_cap);
+			uint32_t nbig = 0;
+			for (uint32_t i = 0; i < m; ++i) nbig += k.vals[i] >= (int32_t)GYS_MB_EXACT ? 1u : 0u;
+			const bool over = s == 13 || (KEMU_BINS_VPT > 4 && nbig > GYS_MB_BIG_CAP);
+			want += over ? 1u : 0u;
+			bool listed = false;
+			for (uint32_t i = 0; i < sslow_count; ++i) listed = listed || sslow[i].slot == s;
+			CHECK(listed == over, "scan: key %u %s handed over (large values %u)", s, listed ? "was" : "was not", nbig);
+			if (over) continue;
+			gyo_tdigest d = k.d;
+			d.vmin = k.mn0; // (the engine's extremes cover merged and folded values; the not yet folded ones come from the scan itself)
+			d.vmax = k.mx0;
+			if (!gyo_td_total(&d) && !k.nh) {
+				d.vmin = INT32_MAX;
+				d.vmax = INT32_MIN;
+			}
+			gyo_td_merge_values(&d, k.vals.data(), m);
+			for (int i = 0; i < 4; ++i) CHECK(qout[(size_t)s * 4 + i] == gyo_td_quantile(&d, qs[i]), "scan: key %u q %.2f: %.1f, oracle %.1f", s, qs[i], qout[(size_t)s * 4 + i], gyo_td_quantile(&d, qs[i]));
+		}
+		CHECK(sslow_count == want, "scan: %u keys handed over, want %u", sslow_count, want);
+		printf("scan of %u keys; %u handed over\n", S, want);
+	}
 	kemu::launch(3, NT, 0, [&] { k_digest_bins<false, KEMU_BINS_VPT>(q); });
 #else
 	kemu::launch(3, NT, 0, [&] { k_digest_bins<false, KEMU_BINS_NT>(q); });

@@ -246,3 +246,33 @@ def test_rollup_at_other_buffer_sizes_and_strides(torch_mod, oracle, td_cap, buf
     _, rec_g = eng.tdigest_rollup(capi.ROLLUP_GLOBAL)
     assert _same_slab(rec_g[0], oracle.rollup_slabs(hosts))
     eng.close()
+
+
+def test_scan_hands_over_services_with_more_large_values_than_the_list_holds(torch_mod, oracle):
+    """the all-service quantile scan uses the merge kernel's list of 1 024 large values (round 6: 8 instead of 6 workgroups per CU, 78 -> 61 ms at
+    10^7 services); a service whose buffer of 1 920 values holds more than that of a second or longer is listed and answered through the general
+    path: every service's quantiles == the oracle's merged view == the one-service query, whichever path it took"""
+    rng = np.random.default_rng(66)
+    L = oracle.lib()
+    cap, nh, sp = 1920, 3, 6
+    eng = _engine(max_hosts=nh, max_services=nh * sp, max_batch_events=1 << 20, td_pend_cap=cap)
+    orc = oracle.OracleEngine(nh * sp, td_cap=cap)
+    info, gids = helpers.register_world(eng, orc, range(nh), sp)
+    for rnd in range(16):  # (small batches: a buffer is re-clustered early when another batch like the last would pass the merge size)
+        for h in range(nh):  # host 0: milliseconds; host 1: around a second; host 2: seconds
+            ev = helpers.make_resp_events(rng, h, int(rng.integers(100, 112)) * sp, sp, lat_mu=(2.5, 6.9, 8.5)[h], lat_sigma=0.8, bad_frac=0.0, unknown_frac=0.0)
+            eng.handle_resp_events(info[h][0], ev)
+            orc.resp_batch(ev.tobytes(), [info[h][1]], [0])
+    eng.sync()
+    gn, gp = eng.export_tdigest_pending(0, nh * sp)
+    big = np.array([(gp[i, :gn[i]] >= 1024).sum() for i in range(nh * sp)])
+    assert (big > 1024).any() and (big == 0).any() and ((big > 0) & (big <= 1024)).any(), big.tolist()
+    qs = [0.25, 0.5, 0.95, 0.99]
+    got = np.asarray(eng.scan_quantiles(qs)).reshape(nh * sp, len(qs))
+    want = np.array([[L.gyo_tdb_quantile(C.byref(orc.td(i)), q) for q in qs] for i in range(nh * sp)])
+    assert (got == want).all(), (got[(got != want).any(axis=1)][:3], want[(got != want).any(axis=1)][:3])
+    for h in range(nh):
+        for k in (0, sp - 1):
+            g = int(gids[h][k])
+            assert eng.quantiles(g, qs) == got[eng.lookup(g)].tolist()
+    eng.close()
