@@ -23,6 +23,24 @@
 #define GYS_NOSLOT 0xFFFFFFFFu
 #define GYS_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
+// A kernel's parameter block read from the kernel-argument segment where it is used (round 6, r6aa): a struct passed by value is loaded
+// into SGPRs once and held -- and spilled into VGPR lanes -- across the whole kernel.  GYS_KERNARG_REF(T, p, p_arg) makes `p` a reference to
+// the block in the kernel-argument segment (the kernel's ONLY parameter: offset 0); GYS_KERNARG_RELOAD(p) -- in uniform control flow only --
+// forgets what was loaded, so that the uses behind it are scalar loads of their own.
+#ifndef GYS_KERNARG
+#define GYS_KERNARG 1
+#endif
+#if GYS_KERNARG && defined(__HIP_DEVICE_COMPILE__)
+#define GYS_KERNARG_REF(T, name, arg)                                                             \
+	typedef const T __attribute__((address_space(4))) *name##_kernarg_t;                      \
+	name##_kernarg_t name##_k = (name##_kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();     \
+	const T &name = *(const T *)name##_k
+#define GYS_KERNARG_RELOAD(name) asm volatile("" : "+s"(name##_k))
+#else
+#define GYS_KERNARG_REF(T, name, arg) const T &name = arg
+#define GYS_KERNARG_RELOAD(name) (void)0
+#endif
+
 namespace gys {
 
 // ------------------------------------------------------------------------------------------------ jhash (common/jhash.h)

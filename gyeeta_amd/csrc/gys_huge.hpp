@@ -208,8 +208,9 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 // entry with more values >= 16 384 than that is handed to tier B (1024 threads, 16 384 tail values, the whole LDS of a CU) through
 // tb_list, and only what overflows THAT goes to the one-workgroup-per-key fallback (k_digest_huge).
 template <uint32_t NT, uint32_t TAIL, bool FROM_LIST>
-__global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
+__global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p_arg)
 {
+	GYS_KERNARG_REF(Huge2P, p, p_arg);
 	GYS_DYN_LDS(uint32_t, s_img);                 // [GYS_HB_BINS] the entry's exact value counts (run + buffered words), then s_tail
 	uint32_t *s_tail = s_img + GYS_HB_BINS;       // [TAIL] the entry's values >= GYS_HB_BINS, sorted
 	__shared__ int64_t s_csum[GYS_TD_NB];
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(NT) void k_huge_merge(Huge2P p)
 	const uint32_t nuse = FROM_LIST ? *p.tb_count : *p.nent_used;
 	const bool tail_lost = *p.tail_count > p.tail_cap; // the global tail list overflowed: every entry goes to the fallback
 	for (uint32_t ei = blockIdx.x; ei < nuse; ei += gridDim.x) {
+		GYS_KERNARG_RELOAD(p);
 		const uint32_t e = FROM_LIST ? p.tb_list[ei] : ei; // (tier B: the pool entries tier A handed over)
 		const MergeEnt ent = p.list[p.first + e];
 		if (tail_lost && FROM_LIST) continue; // (tier A has sent them to the fallback already)
