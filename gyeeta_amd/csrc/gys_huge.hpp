@@ -24,6 +24,18 @@ namespace gys {
 #endif                          // whatever its size: the C5 window paid 5 x 10^7 of them, 4.8 ms; eight times the values per chunk, an eighth of the adds)
 #define GYS_HB_TAIL_LDS 16384u  // tail values (>= GYS_HB_BINS) one entry may carry on this path (sorted in LDS): tier B of k_huge_merge
 #define GYS_HB_TAIL_A 512u      // ... tier A (two workgroups per CU)
+#ifndef GYS_HB_VEC
+#define GYS_HB_VEC 2u           // k_huge_count: 16-byte pieces a thread requests before it takes their values (0: the one-word loop of rounds 3 - 5).  r6ao - r6ar: C1 k_huge_count 216 -> 116 us, C5 1040 -> 684 us at 2 (4: the same, with scratch; 4 / 8 compiled for 4 waves per SIMD, one workgroup per CU: slower)
+#endif
+#ifndef GYS_HB_STAGED
+#define GYS_HB_STAGED 0          // (r6aq: no difference -- C1 digest_huge 0.306 / 0.307 against 0.302 / 0.306 ms, 14 spilled registers at 8 values; left off) k_huge_count: the LDS reads of a thread's 4 GYS_HB_VEC values are issued together, stage by stage
+#endif
+#ifndef GYS_HB_LUT
+#define GYS_HB_LUT 1             // k_huge_count: a value's RESP_TIME_HASH bucket (for its CONN_BITMAP bit) through the 1-KiB LDS table of k_resp_host (r6ap: C1 digest_huge 0.312 - 0.314 -> 0.303 - 0.306 ms)
+#endif
+#ifndef GYS_HB_WAVES
+#define GYS_HB_WAVES 8            // waves per SIMD k_huge_count is compiled for
+#endif
 #define GYS_HB_ACC 40u          // per entry: u64 [0..15] bucket counts, [16..31] bucket sums, [32] min | max << 32 (as biased u32), [33] tail values of the entry in the global list, [34..] spare
 
 struct Huge2P {
@@ -97,13 +109,15 @@ __global__ __launch_bounds__(256) void k_huge_clear(Huge2P p)
 }
 
 // ---- count: one chunk of one entry's run per workgroup
-__global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
+__global__ __launch_bounds__(1024, GYS_HB_WAVES) void k_huge_count(Huge2P p) // (8 waves per SIMD = 64 VGPRs: two workgroups per CU, as the 64-KiB image allows)
 {
 	GYS_DYN_LDS(uint32_t, s_img); // [GYS_HB_BINS]
 	__shared__ unsigned long long s_hc[16], s_hs[16];
 	__shared__ uint32_t s_bm[GYS_BM_WORDS], s_mm[2];
+	__shared__ uint32_t s_bk[GYS_BUCKET_LUT ? 256 : 1]; // RESP_TIME_HASH bucket of a value below 1024: one byte read instead of 13 compare + add pairs per value
 	const uint32_t nuse = *p.nent_used, tid = threadIdx.x;
 	if (!nuse) return;
+	if (GYS_BUCKET_LUT) resp_bucket_lut_init(s_bk, tid, 1024u); // (read behind the first chunk's barrier)
 	const uint32_t nchunks = p.chunk_off[nuse];
 	for (uint32_t ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
 		uint32_t lo = 0, hi = nuse - 1; // entry of the flat chunk index: largest e with chunk_off[e] <= ck
@@ -129,23 +143,89 @@ __global__ __launch_bounds__(1024) void k_huge_count(Huge2P p)
 		}
 		__syncthreads();
 		uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
-		for (uint32_t i = v0 + tid; i < v1; i += 1024u) {
-			const uint32_t word = run[i], v = word >> GYS_ROW_BITS, row = word & GYS_ROW_MASK;
+		// (every step below commutes -- LDS / device adds, ors, min, max; the tail list is sorted by k_huge_merge -- so the order in which a
+		// chunk's values are taken is free)
+		auto take_tail = [&](const uint32_t v, const uint32_t b) { // bucket 14 (>= 15 001): its deltas directly; the value itself to the tail list
+			atomicAdd(&s_hc[b], 1ull);
+			atomicAdd(&s_hs[b], (unsigned long long)v);
+			const uint32_t at = atomicAdd(p.tail_count, 1u);
+			if (at < p.tail_cap) p.tail[at] = ((unsigned long long)e << 32) | v;
+			atomicAdd(&p.acc[(size_t)e * GYS_HB_ACC + 33u], 1ull); // the entry's own count of tail values: an entry without any skips the list
+		};
+		auto take = [&](const uint32_t word) {
+			const uint32_t v = word >> GYS_ROW_BITS, row = word & GYS_ROW_MASK;
 			lmin = min(lmin, v);
 			lmax = max(lmax, v);
-			const uint32_t b = resp_bucket((int64_t)v);
+			const uint32_t b = GYS_HB_LUT ? resp_bucket_lut(s_bk, v) : resp_bucket((int64_t)v);
 			const uint32_t bit = (1u << b) << ((row & 1u) * 16u); // CONN_BITMAP::add_response (common/gy_socket_stat.h:403-410): every run value is of the open window
 			if ((s_bm[row >> 1] & bit) == 0) atomicOr(&s_bm[row >> 1], bit);
-			if (v < GYS_HB_BINS) {
-				atomicAdd(&s_img[v], 1u);
-			} else { // bucket 14 (>= 15 001): its deltas directly; the value itself to the tail list
-				atomicAdd(&s_hc[b], 1ull);
-				atomicAdd(&s_hs[b], (unsigned long long)v);
-				const uint32_t at = atomicAdd(p.tail_count, 1u);
-				if (at < p.tail_cap) p.tail[at] = ((unsigned long long)e << 32) | v;
-				atomicAdd(&p.acc[(size_t)e * GYS_HB_ACC + 33u], 1ull); // the entry's own count of tail values: an entry without any skips the list
+			if (v < GYS_HB_BINS) atomicAdd(&s_img[v], 1u);
+			else take_tail(v, b);
+		};
+#if GYS_HB_VEC
+		{
+			// Round 6: the plain loop (one 4-byte load per thread and step, the next one issued behind the step's atomics) kept ONE 256-byte
+			// request per wave in flight: 8 KB per CU, 1.2 TB/s (C1: 216 us for 268 MB).  Here a thread asks for GYS_HB_VEC 16-byte pieces
+			// before it takes their values: 8 x as many bytes in flight per wave at GYS_HB_VEC = 2 (C1: 116 us, 2.3 TB/s).
+			const uint32_t *cb = run + v0;
+			const uint32_t n = v1 - v0;
+			const uint32_t head = min(n, (4u - ((uint32_t)((uintptr_t)cb >> 2) & 3u)) & 3u); // words in front of the first 16-byte boundary
+			if (tid < head) take(cb[tid]);
+			const uint4 *cv = (const uint4 *)(cb + head);
+			const uint32_t nvec = (n - head) >> 2;
+			for (uint32_t j0 = 0; j0 < nvec; j0 += GYS_HB_VEC * 1024u) {
+				uint4 w[GYS_HB_VEC];
+#pragma unroll
+				for (uint32_t u = 0; u < GYS_HB_VEC; ++u) {
+					const uint32_t j = j0 + u * 1024u + tid;
+					w[u] = j < nvec ? cv[j] : make_uint4(0, 0, 0, 0);
+				}
+#if GYS_HB_STAGED
+				// the values of the thread's pieces stage by stage (bucket reads of all of them, then the bitmap words, then the adds): the LDS
+				// round trips of one value's chain -- table byte -> bitmap word -> test -- overlap the other values' instead of following them
+				constexpr uint32_t NW = 4u * GYS_HB_VEC;
+				uint32_t ww[NW], bb[NW], cur[NW];
+				bool ok[NW];
+#pragma unroll
+				for (uint32_t u = 0; u < GYS_HB_VEC; ++u) {
+					const bool o = j0 + u * 1024u + tid < nvec;
+					ww[4u * u] = w[u].x; ww[4u * u + 1u] = w[u].y; ww[4u * u + 2u] = w[u].z; ww[4u * u + 3u] = w[u].w;
+					ok[4u * u] = ok[4u * u + 1u] = ok[4u * u + 2u] = ok[4u * u + 3u] = o;
+				}
+#pragma unroll
+				for (uint32_t k = 0; k < NW; ++k) bb[k] = GYS_HB_LUT ? resp_bucket_lut(s_bk, ww[k] >> GYS_ROW_BITS) : resp_bucket((int64_t)(ww[k] >> GYS_ROW_BITS));
+#pragma unroll
+				for (uint32_t k = 0; k < NW; ++k) cur[k] = s_bm[(ww[k] & GYS_ROW_MASK) >> 1];
+				GYS_MEM_FENCE();
+#pragma unroll
+				for (uint32_t k = 0; k < NW; ++k) {
+					if (!ok[k]) continue;
+					const uint32_t v = ww[k] >> GYS_ROW_BITS, row = ww[k] & GYS_ROW_MASK;
+					lmin = min(lmin, v);
+					lmax = max(lmax, v);
+					const uint32_t bit = (1u << bb[k]) << ((row & 1u) * 16u);
+					if ((cur[k] & bit) == 0) atomicOr(&s_bm[row >> 1], bit);
+					if (v < GYS_HB_BINS) atomicAdd(&s_img[v], 1u);
+					else take_tail(v, bb[k]);
+				}
+#else
+#pragma unroll
+				for (uint32_t u = 0; u < GYS_HB_VEC; ++u) {
+					if (j0 + u * 1024u + tid < nvec) {
+						take(w[u].x);
+						take(w[u].y);
+						take(w[u].z);
+						take(w[u].w);
+					}
+				}
+#endif
 			}
+			const uint32_t t0 = head + 4u * nvec;
+			if (t0 + tid < n) take(cb[t0 + tid]); // (at most three words behind the last whole piece)
 		}
+#else
+		for (uint32_t i = v0 + tid; i < v1; i += 1024u) take(run[i]);
+#endif
 		lmin = wave_min_u32(lmin);
 		lmax = wave_max_u32(lmax);
 		if ((tid & 63u) == 0) {
