@@ -1359,35 +1359,50 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		MergeP mp{};
 		mp.d = digest_params(c);
 		const uint32_t cap = (uint32_t)std::min<uint64_t>(nsvc, n);
+		static const bool old_merge = getenv("GYS_OLD_MERGE") != nullptr; // A/B: the general kernel for class 0 as well
+		// Round 6: class 1 (more values than the fast class, up to 4096) through the value-bin kernel's 4096-value instance as well (the same
+		// exact-integer definition: bit-identical), the general kernel only for what either instance hands over (GYS_CLASS1_GENERAL: round 5's routing, A/B)
+		static const bool class1_general = getenv("GYS_CLASS1_GENERAL") != nullptr;
+		const bool class1 = c->merge_fast < GYS_MERGE_CLASS1 && n > c->merge_fast - c->pend_cap;
+		const bool class1_bins = class1 && !class1_general && !(old_merge && c->merge_fast <= GYS_MERGE_CLASS0);
+		MergeBP bp{};
+		bp.d = mp.d;
+		bp.slow_list = c->merge_list_slow;
+		bp.slow_count = c->merge_count + FIN_SLOW;
+		auto slow_pass = [&](bool up_to_class1) { // entries whose total weight needs 64-bit arithmetic, or with more large values than the bin kernel's list holds (normally none)
+			mp.list = c->merge_list_slow;
+			mp.count = c->merge_count + FIN_SLOW;
+			if (!up_to_class1) hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
+			else hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS1, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
+		};
 		{
 			ProfScope ps(c, "digest_merge");
-			static const bool old_merge = getenv("GYS_OLD_MERGE") != nullptr; // A/B: the general kernel for class 0 as well
 			mp.list = c->merge_list;
 			mp.count = c->merge_count + FIN_CLASS0;
 			if (old_merge && c->merge_fast <= GYS_MERGE_CLASS0) {
 				hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 7))), dim3(256), 0, c->stream, mp);
 			} else {
-				MergeBP bp{};
-				bp.d = mp.d;
 				bp.list = c->merge_list;
 				bp.count = c->merge_count + FIN_CLASS0;
-				bp.slow_list = c->merge_list_slow;
-				bp.slow_count = c->merge_count + FIN_SLOW;
 				const dim3 bgrid(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 8)));
 				if (c->merge_fast <= 1024u) hipLaunchKernelGGL((k_digest_bins<false, 4u>), bgrid, dim3(256), 0, c->stream, bp);
 				else if (c->merge_fast <= 2048u) hipLaunchKernelGGL((k_digest_bins<false, 8u>), bgrid, dim3(256), 0, c->stream, bp);
 				else hipLaunchKernelGGL((k_digest_bins<false, 16u>), bgrid, dim3(256), 0, c->stream, bp);
-				mp.list = c->merge_list_slow; // entries whose total weight needs 64-bit arithmetic, or with more large values than the bin kernel's list holds (normally none)
-				mp.count = c->merge_count + FIN_SLOW;
-				if (c->merge_fast <= GYS_MERGE_CLASS0) hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
-				else hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS1, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
+				if (!class1_bins) slow_pass(c->merge_fast > GYS_MERGE_CLASS0); // (else: one pass over the list behind the class-1 launch -- an entry is merged once)
 			}
 		}
-		if (c->merge_fast < GYS_MERGE_CLASS1 && n > c->merge_fast - c->pend_cap) {
+		if (class1) {
 			ProfScope ps(c, "digest_merge_big");
-			mp.list = c->merge_list1;
-			mp.count = c->merge_count + FIN_CLASS1;
-			hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS1, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 3))), dim3(256), 0, c->stream, mp);
+			if (class1_bins) {
+				bp.list = c->merge_list1;
+				bp.count = c->merge_count + FIN_CLASS1;
+				hipLaunchKernelGGL((k_digest_bins<false, 16u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * GYS_MB_WAVES16))), dim3(256), 0, c->stream, bp);
+				slow_pass(true);
+			} else {
+				mp.list = c->merge_list1;
+				mp.count = c->merge_count + FIN_CLASS1;
+				hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS1, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 3))), dim3(256), 0, c->stream, mp);
+			}
 			// (entries above class 1 take the several-workgroup path below; k_digest_merge<GYS_MERGE_LDS_MAX> only serves queries)
 		}
 	}

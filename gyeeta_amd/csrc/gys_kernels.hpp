@@ -735,7 +735,15 @@ __global__ __launch_bounds__(256) void k_run_append(const MergeEnt *list, const 
 		const MergeEnt ent = list[e];
 		const uint32_t *src = staged + (ent.off_end - ent.mrun);
 		uint32_t *dst = td_pend + (size_t)ent.slot * pcap + ent.nbuf;
-		for (uint32_t i = lane; i < ent.mrun; i += 64u) dst[i] = src[i];
+		// (eight loads in flight before the first store: the word-by-word loop waited for each load -- src and dst may alias as far as the compiler knows)
+		for (uint32_t i0 = lane; i0 < ent.mrun; i0 += 64u * 8u) {
+			uint32_t v[8];
+#pragma unroll
+			for (uint32_t u = 0; u < 8u; ++u) v[u] = i0 + 64u * u < ent.mrun ? src[i0 + 64u * u] : 0u;
+#pragma unroll
+			for (uint32_t u = 0; u < 8u; ++u)
+				if (i0 + 64u * u < ent.mrun) dst[i0 + 64u * u] = v[u];
+		}
 	}
 }
 
