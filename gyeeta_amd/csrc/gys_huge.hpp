@@ -27,6 +27,9 @@ namespace gys {
 #ifndef GYS_HB_VEC
 #define GYS_HB_VEC 2u           // k_huge_count: 16-byte pieces a thread requests before it takes their values (0: the one-word loop of rounds 3 - 5).  r6ao - r6ar: C1 k_huge_count 216 -> 116 us, C5 1040 -> 684 us at 2 (4: the same, with scratch; 4 / 8 compiled for 4 waves per SIMD, one workgroup per CU: slower)
 #endif
+#ifndef GYS_HB_PIPE
+#define GYS_HB_PIPE 0            // (r6av: no difference -- C1 digest_huge 0.301 - 0.311 against 0.300 - 0.304 ms; left off) k_huge_count: the next step's pieces are requested before this step's values are taken (register double buffer)
+#endif
 #ifndef GYS_HB_STAGED
 #define GYS_HB_STAGED 0          // (r6aq: no difference -- C1 digest_huge 0.306 / 0.307 against 0.302 / 0.306 ms, 14 spilled registers at 8 values; left off) k_huge_count: the LDS reads of a thread's 4 GYS_HB_VEC values are issued together, stage by stage
 #endif
@@ -173,13 +176,30 @@ __global__ __launch_bounds__(1024, GYS_HB_WAVES) void k_huge_count(Huge2P p) // 
 			if (tid < head) take(cb[tid]);
 			const uint4 *cv = (const uint4 *)(cb + head);
 			const uint32_t nvec = (n - head) >> 2;
+#if GYS_HB_PIPE
+			uint4 nx[GYS_HB_VEC]; // the NEXT step's pieces, requested before this step's values are taken
+#pragma unroll
+			for (uint32_t u = 0; u < GYS_HB_VEC; ++u) nx[u] = u * 1024u + tid < nvec ? cv[u * 1024u + tid] : make_uint4(0, 0, 0, 0);
+#endif
 			for (uint32_t j0 = 0; j0 < nvec; j0 += GYS_HB_VEC * 1024u) {
 				uint4 w[GYS_HB_VEC];
+#if GYS_HB_PIPE
+#pragma unroll
+				for (uint32_t u = 0; u < GYS_HB_VEC; ++u) w[u] = nx[u];
+				if (j0 + GYS_HB_VEC * 1024u < nvec) {
+#pragma unroll
+					for (uint32_t u = 0; u < GYS_HB_VEC; ++u) {
+						const uint32_t j = j0 + (GYS_HB_VEC + u) * 1024u + tid;
+						nx[u] = j < nvec ? cv[j] : make_uint4(0, 0, 0, 0);
+					}
+				}
+#else
 #pragma unroll
 				for (uint32_t u = 0; u < GYS_HB_VEC; ++u) {
 					const uint32_t j = j0 + u * 1024u + tid;
 					w[u] = j < nvec ? cv[j] : make_uint4(0, 0, 0, 0);
 				}
+#endif
 #if GYS_HB_STAGED
 				// the values of the thread's pieces stage by stage (bucket reads of all of them, then the bitmap words, then the adds): the LDS
 				// round trips of one value's chain -- table byte -> bitmap word -> test -- overlap the other values' instead of following them
