@@ -1119,6 +1119,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		fin.pcap = c->pcap;
 		fin.pend_cap = c->pend_cap;
 		fin.merge_fast = c->merge_fast;
+		// Round 6: merges of 4097 .. 16 384 values (size class 2) through the streamed value-bin instance; GYS_CLASS2_HUGE: through the several-workgroup path as in rounds 3 - 5 (A/B)
+		static const bool class2_huge = getenv("GYS_CLASS2_HUGE") != nullptr || getenv("GYS_OLD_HUGE") != nullptr; // (GYS_OLD_HUGE's kernel does not read the fallback list the instance hands over to)
+		fin.class2_max = class2_huge ? 0u : GYS_MERGE_LDS_MAX;
 		fin.epoch = c->epoch;
 		fin.resp_win = c->resp_win;
 		fin.list[FIN_CLASS0] = c->merge_list;
@@ -1365,6 +1368,9 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		static const bool class1_general = getenv("GYS_CLASS1_GENERAL") != nullptr;
 		const bool class1 = c->merge_fast < GYS_MERGE_CLASS1 && n > c->merge_fast - c->pend_cap;
 		const bool class1_bins = class1 && !class1_general && !(old_merge && c->merge_fast <= GYS_MERGE_CLASS0);
+		// size class 2 (4097 .. 16 384 values) through the streamed value-bin instance (finalize_one queues such keys on list 2 unless GYS_CLASS2_HUGE / GYS_OLD_HUGE is set)
+		static const bool class2_huge = getenv("GYS_CLASS2_HUGE") != nullptr || getenv("GYS_OLD_HUGE") != nullptr;
+		const bool class2 = !class2_huge && n > GYS_MERGE_CLASS1 - c->pend_cap;
 		MergeBP bp{};
 		bp.d = mp.d;
 		bp.slow_list = c->merge_list_slow;
@@ -1372,7 +1378,8 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 		auto slow_pass = [&](bool up_to_class1) { // entries whose total weight needs 64-bit arithmetic, or with more large values than the bin kernel's list holds (normally none)
 			mp.list = c->merge_list_slow;
 			mp.count = c->merge_count + FIN_SLOW;
-			if (!up_to_class1) hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
+			if (class2) hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_LDS_MAX, 1024u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(1024), 0, c->stream, mp); // (ONE pass over the list, behind the last value-bin launch: an entry is merged once)
+			else if (!up_to_class1) hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS0, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
 			else hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS1, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu))), dim3(256), 0, c->stream, mp);
 		};
 		{
@@ -1388,7 +1395,7 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 				if (c->merge_fast <= 1024u) hipLaunchKernelGGL((k_digest_bins<false, 4u>), bgrid, dim3(256), 0, c->stream, bp);
 				else if (c->merge_fast <= 2048u) hipLaunchKernelGGL((k_digest_bins<false, 8u>), bgrid, dim3(256), 0, c->stream, bp);
 				else hipLaunchKernelGGL((k_digest_bins<false, 16u>), bgrid, dim3(256), 0, c->stream, bp);
-				if (!class1_bins) slow_pass(c->merge_fast > GYS_MERGE_CLASS0); // (else: one pass over the list behind the class-1 launch -- an entry is merged once)
+				if (!class1_bins && !class2) slow_pass(c->merge_fast > GYS_MERGE_CLASS0); // (else: one pass over the list behind the last value-bin launch -- an entry is merged once)
 			}
 		}
 		if (class1) {
@@ -1397,13 +1404,21 @@ int run_resp_batch(gys_ctx *c, const gys_resp_seg *segs_host, uint32_t nsegs, co
 				bp.list = c->merge_list1;
 				bp.count = c->merge_count + FIN_CLASS1;
 				hipLaunchKernelGGL((k_digest_bins<false, 16u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * GYS_MB_WAVES16))), dim3(256), 0, c->stream, bp);
-				slow_pass(true);
+				if (!class2) slow_pass(true);
 			} else {
 				mp.list = c->merge_list1;
 				mp.count = c->merge_count + FIN_CLASS1;
 				hipLaunchKernelGGL((k_digest_merge<GYS_MERGE_CLASS1, 256u>), dim3(std::max(1u, std::min<uint32_t>(cap, (uint32_t)c->ncu * 3))), dim3(256), 0, c->stream, mp);
 			}
-			// (entries above class 1 take the several-workgroup path below; k_digest_merge<GYS_MERGE_LDS_MAX> only serves queries)
+			// (entries above class 2 take the several-workgroup path below)
+		}
+		if (class2) {
+			ProfScope ps(c, "digest_merge_big");
+			bp.list = c->merge_list2;
+			bp.count = c->merge_count + FIN_CLASS2;
+			const uint32_t cap2 = (uint32_t)std::min<uint64_t>(nsvc, n / (GYS_MERGE_CLASS1 - c->pend_cap) + 1);
+			hipLaunchKernelGGL((k_digest_bins<false, 64u>), dim3(std::max(1u, std::min<uint32_t>(cap2, (uint32_t)c->ncu * 8))), dim3(256), 0, c->stream, bp);
+			slow_pass(true); // (what a value-bin launch handed over -- 64-bit weights, more than 1024 values of a second or longer -- through the general kernel's 16 384-value instance)
 		}
 	}
 	if (n > GYS_MERGE_CLASS1 - c->pend_cap) {

@@ -482,6 +482,7 @@ struct FinP {
 	uint32_t *td_prevm, *hot;
 	uint32_t hot_wr;
 	MergeEnt *append_list;
+	uint32_t class2_max;       // largest (buffered + run) value count of merge size class 2 (the streamed value-bin instance); 0: none -- everything above class 1 takes the several-workgroup path
 	uint32_t append_cap;       // entries of append_list (one per service: a key has at most one entry per batch); past it the thread copies the run itself
 	uint32_t staged_cap;       // words of `staged`: an exact run must end inside it
 	uint32_t *td_pend;
@@ -541,7 +542,7 @@ __device__ __forceinline__ int finalize_one(const FinP &p, bool valid, uint32_t 
 				if (WRITE_CUR || pre) p.td_cur[key] = cur;
 				if (cur > p.pend_cap || cur + m > p.merge_fast) { // (the second: another batch like this one would leave the fast merge class)
 					ent.nbuf = cur;
-					cls = cur <= p.merge_fast ? FIN_CLASS0 : cur <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_HUGE; // (> 4096: the several-workgroup path)
+					cls = cur <= p.merge_fast ? FIN_CLASS0 : cur <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : cur <= p.class2_max ? FIN_CLASS2 : FIN_HUGE; // (above class 2: the several-workgroup path)
 				}
 			} else { // spilled
 				*(uint4 *)&p.td_meta[key] = make_uint4(npend0, nh | (nw << 16), win_epoch, mraw.w);
@@ -570,7 +571,7 @@ __device__ __forceinline__ int finalize_one(const FinP &p, bool valid, uint32_t 
 					p.host_spill[p.svc_host[key]] = p.spill_stamp;
 				}
 				const uint64_t tot = (uint64_t)npend0 + m;
-				cls = tot <= p.merge_fast ? FIN_CLASS0 : tot <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : FIN_HUGE;
+				cls = tot <= p.merge_fast ? FIN_CLASS0 : tot <= GYS_MERGE_CLASS1 ? FIN_CLASS1 : tot <= p.class2_max ? FIN_CLASS2 : FIN_HUGE;
 			}
 		}
 	}
@@ -2454,7 +2455,14 @@ __global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_dige
 	const MergeBP &q = q_arg;
 #endif
 	const DigestP &p = q.d;
-	static_assert(VPT == 4u || VPT == 8u || VPT == 16u, "merges of 1024 / 2048 / 4096 values");
+	static_assert(VPT == 4u || VPT == 8u || VPT == 16u || VPT == 64u, "merges of 1024 / 2048 / 4096 values; 64: up to 16 384, streamed");
+	// VPT = 64 (round 6): the STREAMED instance for merges of up to 16 384 values (size class 2: the middle of a Zipf stream, which took the
+	// several-workgroup path of gys_huge.hpp -- a 64-KiB bin array in HBM and a workgroup-wide dependent chain per key -- until then).  Pass 1
+	// is the only user of the values themselves, so they are taken eight per thread at a time instead of all being held in registers; every
+	// count of the passes behind it has room for 16 384 values (bin words: 16 bits; packed adds: 24-bit counts).  The large-value list holds
+	// the bare value: ties among equal large values rank by list position (equal values are interchangeable).
+	constexpr bool STREAM = VPT > 16u;
+	constexpr uint32_t RV = STREAM ? 8u : VPT; // values a thread holds at a time
 	__shared__ __align__(16) uint32_t s_bin[GYS_MB_BINS];
 	// (Until round 6 the scan's list held any merge -- 256 VPT entries, 8 KB for buffers of 1 920 values -- which left 6 workgroups per CU where the
 	// merge has 8; with the merge's list and its hand-over -- gys_scan_quantiles_dev sends the listed services through the general path one by one, as it
@@ -2520,11 +2528,11 @@ __global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_dige
 			c0 = p.td_cnt[(size_t)slot * GYS_TD_NB + tid];
 			sm0 = p.td_sum[(size_t)slot * GYS_TD_NB + tid];
 		}
-		uint32_t wd[VPT];
+		uint32_t wd[RV];
+		const uint32_t *const pend = p.td_pend + (size_t)slot * p.pcap;
 		{
-			const uint32_t *pend = p.td_pend + (size_t)slot * p.pcap;
 #pragma unroll
-			for (uint32_t k = 0; k < VPT; ++k) {
+			for (uint32_t k = 0; k < RV; ++k) {
 				const uint32_t i = tid + 256u * k;
 				wd[k] = 0;
 				if (i < m) wd[k] = i < ent.nbuf ? pend[i] : p.staged[run0 + (i - ent.nbuf)];
@@ -2533,7 +2541,7 @@ __global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_dige
 		if (GYS_MB_SKIP & 32) { // (the loads stay live: an impossible value writes them out)
 			uint32_t x = c0 ^ (uint32_t)sm0;
 #pragma unroll
-			for (uint32_t k = 0; k < VPT; ++k) x ^= wd[k];
+			for (uint32_t k = 0; k < RV; ++k) x ^= wd[k];
 			if (x == 0xDEADBEEFu) p.td_cur[slot] = 1;
 			continue;
 		}
@@ -2610,16 +2618,27 @@ __global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_dige
 		// ---- values, pass 1: bin count (-> arrival order inside the bin), list of large values, window part of the fold
 		const bool fold_scan = !query && nh == 0u; // the all-time deltas of the one-value bins come from the scan
 		int32_t lmin = INT32_MAX, lmax = INT32_MIN, wmax = INT32_MIN;
+		for (uint32_t cb = 0; cb < (STREAM ? m : 1u); cb += 256u * RV) { // (one round unless STREAM)
+		if (STREAM && cb) { // the next eight values of the thread (the first eight were requested with the clusters)
 #pragma unroll
-		for (uint32_t k = 0; k < VPT; ++k) {
-			const uint32_t i = tid + 256u * k;
-			if (i >= m || (GYS_MB_SKIP & 4)) continue;
+			for (uint32_t k = 0; k < RV; ++k) {
+				const uint32_t i = cb + tid + 256u * k;
+				wd[k] = 0;
+				if (i < m) wd[k] = i < ent.nbuf ? pend[i] : p.staged[run0 + (i - ent.nbuf)];
+			}
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < RV; ++k) {
+			const uint32_t i = cb + tid + 256u * k;
+			// (r6ay: adding a wave's 64 values up per (bucket, record) key first -- ballot, count, DPP sum, one lane's add -- instead of one LDS add per
+			// value and record made the streamed instance SLOWER, 0.48 -> 0.92 ms on C5: the instance is bound by its instructions, not by same-address adds)
+			if (!(i >= m || (GYS_MB_SKIP & 4))) {
 			const uint32_t uv = wd[k] >> GYS_ROW_BITS;
 			atomicAdd(&s_bin[mb_bin(uv)], 1u); // (no rank inside the bin is needed: equal values are interchangeable, pass 2 works per bin)
 			const bool big = uv >= GYS_MB_EXACT;
 			if (big) {
 				const uint32_t at = atomicAdd(&s_nbig, 1u);
-				if (256u * VPT <= BIG_CAP || at < BIG_CAP) s_big[at] = (i << 20) | uv;
+				if (256u * VPT <= BIG_CAP || at < BIG_CAP) s_big[at] = STREAM ? uv : ((i << 20) | uv);
 			}
 			if (SCAN && i >= nh_mm) {
 				lmin = min(lmin, (int32_t)uv);
@@ -2641,7 +2660,9 @@ __global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_dige
 					}
 				}
 			}
+			}
 		}
+		} // (cb)
 		if ((!query && m > nh) || (SCAN && m > nh_mm)) {
 			lmin = wave_min_i32(lmin);
 			lmax = wave_max_i32(lmax);
@@ -2849,7 +2870,7 @@ __global__ __launch_bounds__(256, (VPT == 16u ? GYS_MB_WAVES16 : 8)) void k_dige
 			uint32_t r = s_bin[mb_bin(uv)] & 0xFFFFu;
 			for (uint32_t jj = 0; jj < nbig; ++jj) {
 				const uint32_t e = s_big[jj], u = e & 0xFFFFFu;
-				r += ((u >> sh) == (uv >> sh) && (u < uv || (u == uv && (e >> 20) < i))) ? 1u : 0u;
+				r += ((u >> sh) == (uv >> sh) && (u < uv || (u == uv && (STREAM ? jj < j : (e >> 20) < i)))) ? 1u : 0u;
 			}
 			uint32_t gap = 0;
 #pragma unroll
