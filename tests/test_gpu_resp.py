@@ -181,6 +181,32 @@ def test_resp_huge_key_batches(torch_mod, oracle, resp_path, td_buf):
     eng.close()
 
 
+@PATHS
+@pytest.mark.parametrize("td_cap", [0, 1920], ids=["cap896", "cap1920"])
+def test_resp_merge_size_classes(torch_mod, oracle, resp_path, td_cap):
+    """one key, one batch per merge size class and on each side of the class boundaries (round 6: 2 049 .. 4 096 values go through
+    k_digest_bins<false,16>, 4 097 .. 16 384 through the streamed instance k_digest_bins<false,64>, more through the several-workgroup
+    path): every batch is larger than the buffer, so every call ends in a merge of exactly its own values.  Batches of slow responses
+    (mu 6.5 / 7.5: thousands of values of a second or longer) are what the value-bin instances hand over to the general kernel
+    (k_digest_merge<4096,256> / <16384,1024>)."""
+    rng = np.random.default_rng(61)
+    eng = _engine(max_hosts=2, max_services=8, max_batch_events=1 << 16, resp_path=resp_path, td_pend_cap=td_cap)
+    orc = oracle.OracleEngine(8, td_cap=td_cap)
+    info, gids = helpers.register_world(eng, orc, range(1), 2)
+    mid, slot = info[0]
+    for n, mu in [(2049, 3.0), (4096, 3.0), (4097, 3.0), (9000, 3.0), (3000, 6.5), (12000, 6.5), (16384, 2.0), (16385, 2.0), (7000, 7.5), (5000, 0.5), (40000, 3.0), (4500, 3.0)]:
+        ev = helpers.make_resp_events(rng, 0, n, 1, lat_mu=mu, bad_frac=0.0, unknown_frac=0.0, zero_ip_frac=0.0)
+        eng.handle_resp_events(mid, ev)
+        orc.resp_batch(ev.tobytes(), [slot], [0])
+        eng.sync()
+        _compare_all(eng, orc, oracle)
+    _assert_path(eng, resp_path)
+    g = int(gids[0][0])
+    qs = [0.001, 0.25, 0.5, 0.95, 0.999]
+    assert eng.quantiles(g, qs) == [oracle.lib().gyo_tdb_quantile(C.byref(orc.td(0)), q) for q in qs]
+    eng.close()
+
+
 def test_tdigest_disabled_and_identical_values(torch_mod, oracle):
     rng = np.random.default_rng(9)
     eng = _engine(max_hosts=1, max_services=4, enable_tdigest=False)
