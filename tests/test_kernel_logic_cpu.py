@@ -52,6 +52,9 @@ PROGRAMS = {
     # the instances for larger buffers (gys_config.td_pend_cap): merges of up to 2048 / 4096 values, hand-over of merges with more large values than the list holds
     "bins-2048-values": ("test_bins.cc", ["KEMU_BINS_VPT=8"] + BINS, ["12345"], "kemu bins ok"),
     "bins-4096-values": ("test_bins.cc", ["KEMU_BINS_VPT=16"] + BINS, ["12345"], "kemu bins ok"),
+    # round 6: the STREAMED instance for merges of 4097 .. 16 384 values (size class 2: pass 1 takes the values eight per thread at a time, ties among large values by list position)
+    "bins-16384-values-streamed": ("test_bins.cc", ["KEMU_BINS_VPT=64"] + BINS, ["12345"], "kemu bins ok"),
+    "bins-16384-values-streamed-7": ("test_bins.cc", ["KEMU_BINS_VPT=64"] + BINS, ["7"], "kemu bins ok"),
     "resp-tiles-16384": ("test_resp.cc", ["KEMU_TPT=16"] + BINS, ["4242"], "kemu resp ok"),
     "resp-tiles-6144": ("test_resp.cc", ["KEMU_TPT=12"] + BINS, ["4242"], "kemu resp ok"),
     "resp-512x32-prefetch": ("test_resp.cc", ["KEMU_TPT=32"] + BINS, ["4242"], "kemu resp ok"),

@@ -32,6 +32,7 @@ variant() { name=$1; src=$2; arg=$3; shift 3
 }
 variant bins_2048 test_bins.cc 12345 -DKEMU_BINS_VPT=8
 variant bins_4096 test_bins.cc 12345 -DKEMU_BINS_VPT=16
+variant bins_16384_streamed test_bins.cc 12345 -DKEMU_BINS_VPT=64
 variant resp_bound_address test_resp.cc 4243 -DKEMU_TPT=16 -DKEMU_MODE=1
 variant resp_ipv6 test_resp.cc 4244 -DKEMU_TPT=16 -DKEMU_MODE=2
 variant resp_ipv6_split test_resp.cc 4245 -DKEMU_TPT=16 -DKEMU_MODE=2 -DKEMU_SPLIT -DKEMU_NB=4
